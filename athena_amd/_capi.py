@@ -1,0 +1,125 @@
+"""ctypes binding of libathena_mp.so -- the C ABI declared in include/athena_mp.h.
+
+The library is hand-written HIP for gfx950; there is NO CPU fallback: if the shared object is
+missing or a call fails, an exception is raised (AthenaMPError), never a silent detour.
+
+torch is used only as the owner of device memory and streams: tensors are passed as raw device
+pointers (`tensor.data_ptr()`), the current torch stream as the hipStream_t.
+"""
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libathena_mp.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "athena_mp.h")
+
+
+class AthenaMPError(RuntimeError):
+    """A C-ABI call returned non-zero (the Fortran wrapper would call stop_program)."""
+
+
+_lib = None
+
+_i32, _i64, _vp, _f32 = C.c_int32, C.c_int64, C.c_void_p, C.c_float
+
+# name -> argtypes (restype is int for everything except last_error)
+_PROTOS = {
+    "athena_mp_init": [C.c_int],
+    "athena_mp_finalize": [],
+    "athena_mp_set_stream": [_vp],
+    "athena_mp_synchronize": [],
+    "athena_mp_version": [],
+    "athena_mp_malloc": [C.POINTER(_vp), C.c_uint64],
+    "athena_mp_free": [_vp],
+    "athena_mp_memcpy_h2d": [_vp, _vp, C.c_uint64],
+    "athena_mp_memcpy_d2h": [_vp, _vp, C.c_uint64],
+    "athena_mp_memset_zero": [_vp, C.c_uint64],
+    "athena_mp_graph_create": [_i32, _i32, _i64, _vp, _vp, _i32, _vp, _vp, C.POINTER(_vp)],
+    "athena_mp_graph_destroy": [_vp],
+    "athena_mp_graph_dims": [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i32)],
+    "athena_mp_kipf_propagate_fwd": [_vp, _i32, _vp, _vp],
+    "athena_mp_kipf_propagate_bwd": [_vp, _i32, _vp, _vp, _i32],
+    "athena_mp_gemm_fwd": [_i64, _i32, _i32, _vp, _vp, _vp, _i32, _vp],
+    "athena_mp_gemm_dw": [_i64, _i32, _i32, _vp, _vp, _vp],
+    "athena_mp_gemm_dx": [_i64, _i32, _i32, _vp, _vp, _vp],
+    "athena_mp_activation_fwd": [_i32, _i64, _vp, _vp],
+    "athena_mp_activation_bwd": [_i32, _i64, _vp, _vp, _vp],
+    "athena_mp_axpy": [_i64, _f32, _vp, _vp],
+    "athena_mp_duvenaud_propagate_fwd": [_vp, _i32, _i32, _vp, _vp, _vp],
+    "athena_mp_duvenaud_propagate_bwd_x": [_vp, _i32, _i32, _vp, _vp],
+    "athena_mp_duvenaud_propagate_bwd_e": [_vp, _i32, _i32, _vp, _vp],
+    "athena_mp_duvenaud_update_fwd": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
+    "athena_mp_duvenaud_update_bwd_a": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
+    "athena_mp_duvenaud_update_bwd_w": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
+    "athena_mp_softmax_segsum_fwd": [_i32, _i64, _i32, _vp, _vp, _vp, _vp, _i32],
+    "athena_mp_softmax_segsum_bwd": [_i32, _i64, _i32, _vp, _vp, _vp, _vp],
+    "athena_mp_gno_aggregate_fwd": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
+    "athena_mp_gno_aggregate_bwd_x": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
+    "athena_mp_gno_aggregate_bwd_theta": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
+    "athena_mp_gno_aggregate_bwd_coords": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
+    "athena_mp_kipf_propagate_fwd_host": [_vp, _i32, _vp, _vp],
+    "athena_mp_kipf_propagate_bwd_host": [_vp, _i32, _vp, _vp, _i32],
+    "athena_mp_gemm_fwd_host": [_i64, _i32, _i32, _vp, _vp, _vp, _i32, _vp],
+}
+
+
+def declared_symbols():
+    """Every athena_mp_* function the public header declares."""
+    with open(HEADER_PATH) as fh:
+        text = fh.read()
+    return sorted(set(re.findall(r"\b(athena_mp_[a-z0-9_]+)\s*\(", text)))
+
+
+def load():
+    """Load the shared library (torch first, so both share one HIP runtime)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AthenaMPError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(athena_amd/csrc/build.sh). There is no CPU fallback."
+        )
+    try:
+        import torch  # noqa: F401  (loads torch's libamdhip64 first: same SONAME, one runtime)
+    except Exception:  # pragma: no cover - torch is plumbing only
+        pass
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    lib.athena_mp_last_error.restype = C.c_char_p
+    lib.athena_mp_last_error.argtypes = []
+    for name, argtypes in _PROTOS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = C.c_int
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().athena_mp_last_error()
+        raise AthenaMPError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")
+
+
+def call(name, *args):
+    lib = load()
+    check(getattr(lib, name)(*args), name)
+
+
+_initialised_device = None
+
+
+def init(device=0):
+    global _initialised_device
+    if _initialised_device != device:
+        call("athena_mp_init", int(device))
+        _initialised_device = device
+
+
+def use_torch_stream():
+    """Enqueue subsequent kernels on torch's current stream."""
+    import torch
+
+    s = torch.cuda.current_stream().cuda_stream
+    call("athena_mp_set_stream", C.c_void_p(s))

@@ -1,0 +1,264 @@
+// CSR gather-aggregate kernels: the HBM-bound heart of the path.
+//
+//   y[r, 0:F] = sum_{w in row r} coef[w] * x[idx[w], 0:F]          (idx[w] < 0 contributes 0)
+//
+// One kernel shape serves
+//   kipf_propagate fwd            (idx = col,   coef = (deg_v deg_u)^-1/2)   ..._sub_kipf.f90:29-46
+//   kipf bwd (pull form)          (idx = t_src, coef = none | t_coef)        ..._sub_kipf.f90:100-109
+//   duvenaud_propagate fwd x / e  (idx = col / eid, no coef, strided y)      ..._sub_duvenaud.f90:34-42
+//   duvenaud bwd x / e            (idx = t_src / e_row, strided x)           ..._sub_duvenaud.f90:135-141,164-170
+//
+// Mapping (CDNA4, 64-wide waves): a GROUP of G lanes owns one output row; each lane owns VEC
+// contiguous features, so one group-wide load instruction reads a G*VEC*4-byte run of a vertex row
+// (F=128: G=32, VEC=4 -> a full 512 B row per half-wave as 16 B/lane loads; 2 rows per wave).
+// The group first loads G consecutive (idx, coef) entries of its row with one coalesced load,
+// then walks them IN CSR ORDER, broadcasting each entry with a wave shuffle and keeping UNROLL
+// independent row loads in flight.  Walking in CSR order reproduces the reference's per-feature
+// summation order exactly; with -ffp-contract=off (rounded multiply, rounded add) the result is
+// bit-identical to the strict-fp32 CPU restatement.
+//
+// Scatters of the reference (conflicting `do concurrent` writes) become pulls over the
+// transposed CSR / edge index built at graph_create: no atomics, deterministic order.
+#include "common.h"
+
+namespace {
+
+template <int VEC> struct VecT;
+template <> struct VecT<1> { using type = float; };
+template <> struct VecT<2> { using type = float2; };
+template <> struct VecT<4> { using type = float4; };
+
+template <int VEC> __device__ __forceinline__ void vzero(float (&a)[VEC])
+{
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) a[i] = 0.0f;
+}
+
+template <int VEC>
+__device__ __forceinline__ void vload(float (&dst)[VEC], const float *__restrict__ p)
+{
+    using V = typename VecT<VEC>::type;
+    V t = *reinterpret_cast<const V *>(p);
+    if constexpr (VEC == 1) dst[0] = t;
+    if constexpr (VEC == 2) { dst[0] = t.x; dst[1] = t.y; }
+    if constexpr (VEC == 4) { dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w; }
+}
+
+template <int VEC> __device__ __forceinline__ void vstore(float *__restrict__ p, const float (&src)[VEC])
+{
+    using V = typename VecT<VEC>::type;
+    V t;
+    if constexpr (VEC == 1) t = src[0];
+    if constexpr (VEC == 2) { t.x = src[0]; t.y = src[1]; }
+    if constexpr (VEC == 4) { t.x = src[0]; t.y = src[1]; t.z = src[2]; t.w = src[3]; }
+    *reinterpret_cast<V *>(p) = t;
+}
+
+constexpr int kBlock = 256;
+constexpr int kUnroll = 4;
+
+// G lanes per row, VEC floats per lane, COEF: multiply by coef[w]
+template <int G, int VEC, bool COEF>
+__global__ __launch_bounds__(kBlock) void csr_gather_agg(
+    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ idx, const float *__restrict__ coef,
+    const float *__restrict__ x, int64_t ldx, float *__restrict__ y, int64_t ldy, int32_t n_rows,
+    int32_t F)
+{
+    constexpr int kRowsPerBlock = kBlock / G;
+    const int lane = threadIdx.x & 63;
+    const int gl = threadIdx.x & (G - 1);          // lane inside the group
+    const int row = blockIdx.x * kRowsPerBlock + (threadIdx.x / G);
+    const bool live = row < n_rows;
+
+    int start = 0, len = 0;
+    if (live) {
+        start = rowptr[row];
+        len = rowptr[row + 1] - start;
+    }
+    // longest row among the groups of this wave: keeps every shuffle wave-uniform
+    int maxlen = len;
+#pragma unroll
+    for (int o = G; o < 64; o <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o));
+    (void)lane;
+
+    for (int f0 = 0; f0 < F; f0 += G * VEC) {
+        const int f = f0 + gl * VEC;
+        const bool fin = f < F;
+        float acc[VEC];
+        vzero<VEC>(acc);
+        for (int off = 0; off < maxlen; off += G) {
+            // one coalesced load of up to G entries of the row
+            int my_idx = -1;
+            float my_c = 0.0f;
+            if (off + gl < len) {
+                my_idx = idx[start + off + gl];
+                if constexpr (COEF) my_c = coef[start + off + gl];
+            }
+            const int cnt = min(G, len - off);       // entries of MY row in this chunk (may be <= 0)
+            const int cntmax = min(G, maxlen - off); // wave-uniform
+            for (int j = 0; j < cntmax; j += kUnroll) {
+                int u[kUnroll];
+                float c[kUnroll];
+                float v[kUnroll][VEC];
+#pragma unroll
+                for (int k = 0; k < kUnroll; ++k) {
+                    u[k] = __shfl(my_idx, j + k, G);
+                    if constexpr (COEF) c[k] = __shfl(my_c, j + k, G);
+                }
+#pragma unroll
+                for (int k = 0; k < kUnroll; ++k) {
+                    vzero<VEC>(v[k]);
+                    if (j + k < cnt && u[k] >= 0 && fin) vload<VEC>(v[k], x + (int64_t)u[k] * ldx + f);
+                }
+#pragma unroll
+                for (int k = 0; k < kUnroll; ++k) {
+                    if (j + k < cnt && u[k] >= 0) {
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) {
+                            if constexpr (COEF)
+                                acc[i] = acc[i] + c[k] * v[k][i];
+                            else
+                                acc[i] = acc[i] + v[k][i];
+                        }
+                    }
+                }
+            }
+        }
+        if (live && fin) vstore<VEC>(y + (int64_t)row * ldy + f, acc);
+    }
+}
+
+template <int G, int VEC>
+int launch_gv(bool has_coef, const int32_t *rowptr, const int32_t *idx, const float *coef, const float *x,
+              int64_t ldx, float *y, int64_t ldy, int32_t n_rows, int32_t F)
+{
+    constexpr int rpb = kBlock / G;
+    dim3 grid((n_rows + rpb - 1) / rpb), block(kBlock);
+    if (has_coef)
+        hipLaunchKernelGGL((csr_gather_agg<G, VEC, true>), grid, block, 0, amp::stream(), rowptr, idx, coef, x,
+                           ldx, y, ldy, n_rows, F);
+    else
+        hipLaunchKernelGGL((csr_gather_agg<G, VEC, false>), grid, block, 0, amp::stream(), rowptr, idx, coef,
+                           x, ldx, y, ldy, n_rows, F);
+    AMP_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int VEC>
+int launch_v(int G, bool has_coef, const int32_t *rowptr, const int32_t *idx, const float *coef,
+             const float *x, int64_t ldx, float *y, int64_t ldy, int32_t n_rows, int32_t F)
+{
+    switch (G) {
+    case 1: return launch_gv<1, VEC>(has_coef, rowptr, idx, coef, x, ldx, y, ldy, n_rows, F);
+    case 2: return launch_gv<2, VEC>(has_coef, rowptr, idx, coef, x, ldx, y, ldy, n_rows, F);
+    case 4: return launch_gv<4, VEC>(has_coef, rowptr, idx, coef, x, ldx, y, ldy, n_rows, F);
+    case 8: return launch_gv<8, VEC>(has_coef, rowptr, idx, coef, x, ldx, y, ldy, n_rows, F);
+    case 16: return launch_gv<16, VEC>(has_coef, rowptr, idx, coef, x, ldx, y, ldy, n_rows, F);
+    case 32: return launch_gv<32, VEC>(has_coef, rowptr, idx, coef, x, ldx, y, ldy, n_rows, F);
+    default: return launch_gv<64, VEC>(has_coef, rowptr, idx, coef, x, ldx, y, ldy, n_rows, F);
+    }
+}
+
+} // namespace
+
+namespace amp {
+
+// Generic launcher used by every layer family.  x/y may be column slices of wider tensors
+// (ldx/ldy = leading dimension in floats).
+int gather_agg(const int32_t *rowptr, const int32_t *idx, const float *coef, const float *x, int64_t ldx,
+               float *y, int64_t ldy, int32_t n_rows, int32_t F)
+{
+    if (n_rows == 0 || F == 0) return 0;
+    // widest vector the slices allow (16 B loads need 16 B aligned rows)
+    int vec = 1;
+    auto aligned = [&](int v) {
+        return F % v == 0 && ldx % v == 0 && ldy % v == 0 && ((uintptr_t)x % (4 * v)) == 0 &&
+               ((uintptr_t)y % (4 * v)) == 0;
+    };
+    if (aligned(4)) vec = 4;
+    else if (aligned(2)) vec = 2;
+    int lanes = (F + vec - 1) / vec;
+    int G = 1;
+    while (G < lanes && G < 64) G <<= 1;
+    const bool has_coef = coef != nullptr;
+    switch (vec) {
+    case 4: return launch_v<4>(G, has_coef, rowptr, idx, coef, x, ldx, y, ldy, n_rows, F);
+    case 2: return launch_v<2>(G, has_coef, rowptr, idx, coef, x, ldx, y, ldy, n_rows, F);
+    default: return launch_v<1>(G, has_coef, rowptr, idx, coef, x, ldx, y, ldy, n_rows, F);
+    }
+}
+
+} // namespace amp
+
+using namespace amp;
+
+extern "C" {
+
+int athena_mp_kipf_propagate_fwd(const athena_mp_graph *g, int32_t F, const float *x, float *y)
+{
+    AMP_REQUIRE(g && x && y && F > 0, "kipf_propagate_fwd: bad arguments");
+    return gather_agg(g->rowptr, g->col, g->coef, x, F, y, F, g->n_rows, F);
+}
+
+int athena_mp_kipf_propagate_bwd(const athena_mp_graph *g, int32_t F, const float *grad, float *dx,
+                                 int32_t exact)
+{
+    AMP_REQUIRE(g && grad && dx && F > 0, "kipf_propagate_bwd: bad arguments");
+    return gather_agg(g->t_rowptr, g->t_src, exact ? g->t_coef : nullptr, grad, F, dx, F, g->n_cols, F);
+}
+
+int athena_mp_duvenaud_propagate_fwd(const athena_mp_graph *g, int32_t Fv, int32_t Fe, const float *x,
+                                     const float *e, float *c)
+{
+    AMP_REQUIRE(g && x && c && Fv > 0 && Fe >= 0, "duvenaud_propagate_fwd: bad arguments");
+    AMP_REQUIRE(Fe == 0 || e, "duvenaud_propagate_fwd: null edge features");
+    const int64_t Fc = (int64_t)Fv + Fe;
+    int rc = gather_agg(g->rowptr, g->col, nullptr, x, Fv, c, Fc, g->n_rows, Fv);
+    if (rc == 0 && Fe > 0) rc = gather_agg(g->rowptr, g->eid, nullptr, e, Fe, c + Fv, Fc, g->n_rows, Fe);
+    return rc;
+}
+
+int athena_mp_duvenaud_propagate_bwd_x(const athena_mp_graph *g, int32_t Fv, int32_t Fe, const float *grad,
+                                       float *dx)
+{
+    AMP_REQUIRE(g && grad && dx && Fv > 0 && Fe >= 0, "duvenaud_propagate_bwd_x: bad arguments");
+    return gather_agg(g->t_rowptr, g->t_src, nullptr, grad, (int64_t)Fv + Fe, dx, Fv, g->n_cols, Fv);
+}
+
+int athena_mp_duvenaud_propagate_bwd_e(const athena_mp_graph *g, int32_t Fv, int32_t Fe, const float *grad,
+                                       float *de)
+{
+    AMP_REQUIRE(g && grad && de && Fv > 0 && Fe > 0, "duvenaud_propagate_bwd_e: bad arguments");
+    return gather_agg(g->e_rowptr, g->e_row, nullptr, grad + Fv, (int64_t)Fv + Fe, de, Fe, g->n_edge_cols, Fe);
+}
+
+int athena_mp_kipf_propagate_fwd_host(const athena_mp_graph *g, int32_t F, const float *xh, float *yh)
+{
+    AMP_REQUIRE(g && xh && yh && F > 0, "kipf_propagate_fwd_host: bad arguments");
+    size_t bx = sizeof(float) * (size_t)g->n_cols * F, by = sizeof(float) * (size_t)g->n_rows * F;
+    void *dx = nullptr, *dy = nullptr;
+    if (workspace(&dx, bx, 0) || workspace(&dy, by, 1)) return 1;
+    AMP_HIP(hipMemcpyAsync(dx, xh, bx, hipMemcpyHostToDevice, stream()));
+    int rc = athena_mp_kipf_propagate_fwd(g, F, (const float *)dx, (float *)dy);
+    if (rc) return rc;
+    AMP_HIP(hipMemcpyAsync(yh, dy, by, hipMemcpyDeviceToHost, stream()));
+    AMP_HIP(hipStreamSynchronize(stream()));
+    return 0;
+}
+
+int athena_mp_kipf_propagate_bwd_host(const athena_mp_graph *g, int32_t F, const float *gh, float *dxh,
+                                      int32_t exact)
+{
+    AMP_REQUIRE(g && gh && dxh && F > 0, "kipf_propagate_bwd_host: bad arguments");
+    size_t bg = sizeof(float) * (size_t)g->n_rows * F, bx = sizeof(float) * (size_t)g->n_cols * F;
+    void *dg = nullptr, *dx = nullptr;
+    if (workspace(&dg, bg, 0) || workspace(&dx, bx, 1)) return 1;
+    AMP_HIP(hipMemcpyAsync(dg, gh, bg, hipMemcpyHostToDevice, stream()));
+    int rc = athena_mp_kipf_propagate_bwd(g, F, (const float *)dg, (float *)dx, exact);
+    if (rc) return rc;
+    AMP_HIP(hipMemcpyAsync(dxh, dx, bx, hipMemcpyDeviceToHost, stream()));
+    AMP_HIP(hipStreamSynchronize(stream()));
+    return 0;
+}
+
+} // extern "C"

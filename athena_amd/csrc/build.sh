@@ -1,0 +1,24 @@
+#!/bin/bash
+# Builds athena_amd/libathena_mp.so for gfx950 (MI355X) -- no other target.
+# -ffp-contract=off: a*b+c stays a rounded multiply + rounded add unless the source says fmaf/MFMA,
+# so the aggregation kernels reproduce the reference's strict fp32 sums bit for bit.
+set -e
+cd "$(dirname "$0")"
+OUT=../libathena_mp.so
+SRCS="capi.hip agg.hip gemm.hip elementwise.hip duvenaud.hip gno.hip"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function"
+mkdir -p ../../build/obj
+objs=""
+pids=""
+for s in $SRCS; do
+  [ -f "$s" ] || continue
+  o=../../build/obj/${s%.hip}.o
+  objs="$objs $o"
+  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ ../../include/athena_mp.h -nt "$o" ]; then
+    /opt/rocm/bin/hipcc $FLAGS -c "$s" -o "$o" &
+    pids="$pids $!"
+  fi
+done
+for p in $pids; do wait $p; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o $OUT
+echo "built $(readlink -f $OUT)"

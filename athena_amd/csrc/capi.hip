@@ -1,0 +1,293 @@
+// Runtime + graph handle of libathena_mp.
+//
+// The graph handle replaces the reference's per-call CSR copies
+// (athena_msgpass_layer_sub.f90:144-174, athena_diffstruc_extd_sub_kipf.f90:48-49):
+// the Fortran 1-based CSR is validated and converted ONCE into the device layout the kernels
+// stream (0-based forward CSR, transposed CSR for the pull form of every scatter, per-entry
+// Kipf coefficients, and an edge-column index).
+#include <stdarg.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+
+namespace amp {
+
+static thread_local char g_err[1024] = "";
+static hipStream_t g_stream = nullptr;
+static void *g_ws[4] = {nullptr, nullptr, nullptr, nullptr};
+static size_t g_ws_bytes[4] = {0, 0, 0, 0};
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+hipStream_t stream() { return g_stream; }
+
+int workspace(void **ptr, size_t bytes, int slot)
+{
+    if (bytes > g_ws_bytes[slot]) {
+        if (g_ws[slot]) {
+            AMP_HIP(hipStreamSynchronize(g_stream));
+            AMP_HIP(hipFree(g_ws[slot]));
+            g_ws[slot] = nullptr;
+            g_ws_bytes[slot] = 0;
+        }
+        size_t want = bytes + (bytes >> 2) + 256;
+        AMP_HIP(hipMalloc(&g_ws[slot], want));
+        g_ws_bytes[slot] = want;
+    }
+    *ptr = g_ws[slot];
+    return 0;
+}
+
+} // namespace amp
+
+using namespace amp;
+
+extern "C" {
+
+const char *athena_mp_last_error(void) { return g_err; }
+int athena_mp_version(void) { return 100; }
+
+int athena_mp_init(int device)
+{
+    int n = 0;
+    AMP_HIP(hipGetDeviceCount(&n));
+    AMP_REQUIRE(n > 0, "athena_mp_init: no HIP device visible");
+    AMP_REQUIRE(device >= 0 && device < n, "athena_mp_init: device %d out of range [0,%d)", device, n);
+    AMP_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    AMP_HIP(hipGetDeviceProperties(&prop, device));
+    AMP_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0,
+                "athena_mp_init: built for gfx950 (MI355X) only, device %d is %s", device,
+                prop.gcnArchName);
+    return 0;
+}
+
+int athena_mp_finalize(void)
+{
+    for (int s = 0; s < 4; ++s) {
+        if (g_ws[s]) {
+            AMP_HIP(hipFree(g_ws[s]));
+            g_ws[s] = nullptr;
+            g_ws_bytes[s] = 0;
+        }
+    }
+    return 0;
+}
+
+int athena_mp_set_stream(void *hip_stream)
+{
+    g_stream = (hipStream_t)hip_stream;
+    return 0;
+}
+int athena_mp_synchronize(void)
+{
+    AMP_HIP(hipStreamSynchronize(g_stream));
+    return 0;
+}
+int athena_mp_malloc(void **p, uint64_t bytes)
+{
+    AMP_REQUIRE(p != nullptr, "athena_mp_malloc: null out pointer");
+    AMP_HIP(hipMalloc(p, bytes ? bytes : 4));
+    return 0;
+}
+int athena_mp_free(void *p)
+{
+    if (p) AMP_HIP(hipFree(p));
+    return 0;
+}
+int athena_mp_memcpy_h2d(void *d, const void *h, uint64_t bytes)
+{
+    AMP_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, g_stream));
+    AMP_HIP(hipStreamSynchronize(g_stream));
+    return 0;
+}
+int athena_mp_memcpy_d2h(void *h, const void *d, uint64_t bytes)
+{
+    AMP_HIP(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, g_stream));
+    AMP_HIP(hipStreamSynchronize(g_stream));
+    return 0;
+}
+int athena_mp_memset_zero(void *d, uint64_t bytes)
+{
+    AMP_HIP(hipMemsetAsync(d, 0, bytes, g_stream));
+    return 0;
+}
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// Kipf coefficient per CSR entry.  Reference: coeff = (deg_v * deg_u) ** (-0.5_real32)
+// (athena_diffstruc_extd_sub_kipf.f90:39-42): integer product, converted to real32, then powf.
+// Here the correctly rounded value is produced through fp64 (1/sqrt is IEEE-exact in fp64, and
+// fp64 -> fp32 of a value with 53 significant bits of an irrational-or-exact root rounds to the
+// same fp32 as a correctly rounded powf), so the coefficient equals host libm's powf bit for bit.
+// ---------------------------------------------------------------------------------------------
+__global__ void kipf_coef_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ other,
+                                 const int32_t *__restrict__ deg_self,
+                                 const int32_t *__restrict__ deg_other, float *__restrict__ coef,
+                                 int32_t n)
+{
+    int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    int dv = deg_self[v];
+    for (int w = rowptr[v]; w < rowptr[v + 1]; ++w) {
+        float prod = (float)(dv * deg_other[other[w]]);
+        coef[w] = (float)(1.0 / sqrt((double)prod));
+    }
+}
+
+template <typename T> static int upload(T **dst, const std::vector<T> &src)
+{
+    size_t bytes = sizeof(T) * (src.size() ? src.size() : 1);
+    AMP_HIP(hipMalloc((void **)dst, bytes));
+    if (!src.empty())
+        AMP_HIP(hipMemcpyAsync(*dst, src.data(), sizeof(T) * src.size(), hipMemcpyHostToDevice, stream()));
+    return 0;
+}
+
+extern "C" {
+
+int athena_mp_graph_destroy(athena_mp_graph *g)
+{
+    if (!g) return 0;
+    void *ptrs[] = {g->rowptr, g->col,   g->eid,      g->coef,  g->t_rowptr, g->t_src,  g->t_eid,
+                    g->t_coef, g->e_rowptr, g->e_row, g->e_col, g->deg_row,  g->deg_col};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete g;
+    return 0;
+}
+
+int athena_mp_graph_dims(const athena_mp_graph *g, int32_t *n_rows, int32_t *n_cols, int64_t *nnz,
+                         int32_t *n_edge_cols)
+{
+    AMP_REQUIRE(g != nullptr, "athena_mp_graph_dims: null graph");
+    if (n_rows) *n_rows = g->n_rows;
+    if (n_cols) *n_cols = g->n_cols;
+    if (nnz) *nnz = g->nnz;
+    if (n_edge_cols) *n_edge_cols = g->n_edge_cols;
+    return 0;
+}
+
+int athena_mp_graph_create(int32_t n_rows, int32_t n_cols, int64_t nnz, const int32_t *adj_ia,
+                           const int32_t *adj_ja, int32_t n_edge_cols, const int32_t *row_deg,
+                           const int32_t *col_deg, athena_mp_graph **out)
+{
+    AMP_REQUIRE(out != nullptr, "graph_create: null out pointer");
+    *out = nullptr;
+    AMP_REQUIRE(n_rows >= 0 && n_cols >= 0 && nnz >= 0 && n_edge_cols >= 0, "graph_create: negative size");
+    AMP_REQUIRE(nnz < (int64_t)INT32_MAX, "graph_create: nnz %lld exceeds int32 CSR", (long long)nnz);
+    AMP_REQUIRE(adj_ia != nullptr && (nnz == 0 || adj_ja != nullptr), "graph_create: null CSR arrays");
+    AMP_REQUIRE((row_deg == nullptr) == (col_deg == nullptr),
+                "graph_create: row_deg and col_deg must be given together");
+    AMP_REQUIRE(row_deg != nullptr || n_rows == n_cols,
+                "graph_create: a rectangular block (%d x %d) needs explicit degrees", n_rows, n_cols);
+    AMP_REQUIRE(adj_ia[0] == 1, "graph_create: adj_ia(1) must be 1 (Fortran 1-based), got %d", adj_ia[0]);
+    AMP_REQUIRE((int64_t)adj_ia[n_rows] - 1 == nnz, "graph_create: adj_ia(n+1)-1 = %d != nnz = %lld",
+                adj_ia[n_rows] - 1, (long long)nnz);
+
+    std::vector<int32_t> rowptr(n_rows + 1), col(nnz), eid(nnz), degr(n_rows), degc(n_cols);
+    int32_t max_row = 0;
+    for (int32_t v = 0; v < n_rows; ++v) {
+        AMP_REQUIRE(adj_ia[v + 1] >= adj_ia[v], "graph_create: adj_ia not monotone at row %d", v + 1);
+        rowptr[v] = adj_ia[v] - 1;
+        int32_t len = adj_ia[v + 1] - adj_ia[v];
+        max_row = len > max_row ? len : max_row;
+        degr[v] = row_deg ? row_deg[v] : len;
+    }
+    rowptr[n_rows] = (int32_t)nnz;
+    for (int32_t u = 0; u < n_cols; ++u) degc[u] = col_deg ? col_deg[u] : degr[u];
+
+    // transposed CSR + edge-column index by stable counting sort (entry order w preserved, so each
+    // transposed row lists its sources in ascending v: the reference's accumulation order,
+    // athena_diffstruc_extd_sub_kipf.f90:101-109).
+    std::vector<int32_t> t_rowptr(n_cols + 1, 0), e_rowptr(n_edge_cols + 1, 0);
+    int64_t n_with_edge = 0;
+    for (int64_t w = 0; w < nnz; ++w) {
+        int32_t u = adj_ja[2 * w] - 1, e = adj_ja[2 * w + 1] - 1;
+        AMP_REQUIRE(u >= 0 && u < n_cols, "graph_create: adj_ja(1,%lld) = %d outside [1,%d]",
+                    (long long)w + 1, u + 1, n_cols);
+        AMP_REQUIRE(e >= -1 && e < n_edge_cols, "graph_create: adj_ja(2,%lld) = %d outside [0,%d]",
+                    (long long)w + 1, e + 1, n_edge_cols);
+        col[w] = u;
+        eid[w] = e;
+        t_rowptr[u + 1]++;
+        if (e >= 0) {
+            e_rowptr[e + 1]++;
+            n_with_edge++;
+        }
+    }
+    int32_t max_col = 0;
+    for (int32_t u = 0; u < n_cols; ++u) {
+        max_col = t_rowptr[u + 1] > max_col ? t_rowptr[u + 1] : max_col;
+        t_rowptr[u + 1] += t_rowptr[u];
+    }
+    for (int32_t e = 0; e < n_edge_cols; ++e) e_rowptr[e + 1] += e_rowptr[e];
+    std::vector<int32_t> t_src(nnz), t_eid(nnz), e_row(n_with_edge), e_col(n_with_edge);
+    {
+        std::vector<int32_t> tpos(t_rowptr.begin(), t_rowptr.end() - 1);
+        std::vector<int32_t> epos(e_rowptr.begin(), e_rowptr.end() - 1);
+        for (int32_t v = 0; v < n_rows; ++v)
+            for (int32_t w = rowptr[v]; w < rowptr[v + 1]; ++w) {
+                int32_t p = tpos[col[w]]++;
+                t_src[p] = v;
+                t_eid[p] = eid[w];
+                if (eid[w] >= 0) {
+                    int32_t q = epos[eid[w]]++;
+                    e_row[q] = v;
+                    e_col[q] = col[w];
+                }
+            }
+    }
+
+    athena_mp_graph *g = new athena_mp_graph();
+    g->n_rows = n_rows;
+    g->n_cols = n_cols;
+    g->nnz = nnz;
+    g->n_edge_cols = n_edge_cols;
+    g->max_row_len = max_row;
+    g->max_col_len = max_col;
+    g->n_with_edge = n_with_edge;
+    int rc = 0;
+    rc |= upload(&g->rowptr, rowptr);
+    rc |= upload(&g->col, col);
+    rc |= upload(&g->eid, eid);
+    rc |= upload(&g->t_rowptr, t_rowptr);
+    rc |= upload(&g->t_src, t_src);
+    rc |= upload(&g->t_eid, t_eid);
+    rc |= upload(&g->e_rowptr, e_rowptr);
+    rc |= upload(&g->e_row, e_row);
+    rc |= upload(&g->e_col, e_col);
+    rc |= upload(&g->deg_row, degr);
+    rc |= upload(&g->deg_col, degc);
+    if (rc == 0 && hipMalloc((void **)&g->coef, sizeof(float) * (nnz ? nnz : 1)) != hipSuccess) rc = 1;
+    if (rc == 0 && hipMalloc((void **)&g->t_coef, sizeof(float) * (nnz ? nnz : 1)) != hipSuccess) rc = 1;
+    if (rc != 0) {
+        if (g_err[0] == 0) set_error("graph_create: device allocation failed");
+        athena_mp_graph_destroy(g);
+        return 1;
+    }
+    if (n_rows > 0)
+        hipLaunchKernelGGL(kipf_coef_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, stream(), g->rowptr,
+                           g->col, g->deg_row, g->deg_col, g->coef, n_rows);
+    if (n_cols > 0)
+        hipLaunchKernelGGL(kipf_coef_kernel, dim3((n_cols + 255) / 256), dim3(256), 0, stream(),
+                           g->t_rowptr, g->t_src, g->deg_col, g->deg_row, g->t_coef, n_cols);
+    hipError_t e = hipStreamSynchronize(stream()); // host vectors die at scope exit
+    if (e != hipSuccess) {
+        set_error("graph_create: %s", hipGetErrorString(e));
+        athena_mp_graph_destroy(g);
+        return 1;
+    }
+    *out = g;
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,63 @@
+// Shared internals of libathena_mp (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/athena_mp.h"
+
+namespace amp {
+
+// ---- error plumbing: C side never aborts, it returns a code + message ---------------------
+void set_error(const char *fmt, ...);
+hipStream_t stream();
+
+#define AMP_HIP(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            amp::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,  \
+                           __LINE__);                                                        \
+            return 1;                                                                        \
+        }                                                                                    \
+    } while (0)
+
+#define AMP_REQUIRE(cond, ...)          \
+    do {                                \
+        if (!(cond)) {                  \
+            amp::set_error(__VA_ARGS__); \
+            return 2;                   \
+        }                               \
+    } while (0)
+
+#define AMP_LAUNCH_CHECK() AMP_HIP(hipGetLastError())
+
+// workspace owned by the library (grown on demand, never shrunk; stream-ordered reuse)
+int workspace(void **ptr, size_t bytes, int slot = 0);
+
+} // namespace amp
+
+// ---- graph handle: everything the kernels need, resident in HBM --------------------------------
+struct athena_mp_graph {
+    int32_t n_rows = 0, n_cols = 0, n_edge_cols = 0;
+    int64_t nnz = 0;
+    int32_t max_row_len = 0, max_col_len = 0;
+    // forward CSR, 0-based
+    int32_t *rowptr = nullptr;  // [n_rows+1]
+    int32_t *col = nullptr;     // [nnz]  neighbour u
+    int32_t *eid = nullptr;     // [nnz]  edge-feature column, -1 = none
+    float *coef = nullptr;      // [nnz]  (deg_v*deg_u)^-1/2, the Kipf coefficient of each entry
+    // transposed CSR (pull form of every scatter): row u lists the (v,w) with col[w]==u, v ascending
+    int32_t *t_rowptr = nullptr; // [n_cols+1]
+    int32_t *t_src = nullptr;    // [nnz] source row v
+    int32_t *t_eid = nullptr;    // [nnz]
+    float *t_coef = nullptr;     // [nnz]
+    // edge-column index: column e lists the entries that carry it, in w order
+    int32_t *e_rowptr = nullptr; // [n_edge_cols+1]
+    int32_t *e_row = nullptr;    // [n_with_edge] row v of the entry
+    int32_t *e_col = nullptr;    // [n_with_edge] neighbour u of the entry
+    int32_t *deg_row = nullptr;  // [n_rows]
+    int32_t *deg_col = nullptr;  // [n_cols]
+    int64_t n_with_edge = 0;
+};

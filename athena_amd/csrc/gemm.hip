@@ -1,0 +1,399 @@
+// Dense contraction of the path on fp32 MFMA (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered fma chain).
+//
+// Replaces diffstruc's `matmul(params(t), ptr2)` and its reverse-mode products (call sites
+// athena_kipf_msgpass_layer.f90:951, athena_duvenaud_msgpass_layer.f90:842, athena_graph_nop_layer.f90:761):
+//   fwd : Z[M,N]  = A[M,K] . B[K,N]          A = P, B = Wt (row-major [Fi][Fo]), K=Fi, N=Fo
+//   dx  : dP[M,N] = A[M,K] . B[K,N]          A = dZ, B[k=o][n=i] = Wt[i][o] (stored [N][K]), K=Fo, N=Fi
+//   dw  : dWt[Fi,Fo] = sum_v P[v,:]^T dZ[v,:]
+// M (vertices) is 10^6..10^7, K and N are 32..128: the weight matrix (<= 64 KB) stays resident in LDS
+// for the lifetime of a persistent workgroup, each wave streams its own 32-row slabs of A through a
+// private LDS region (no workgroup barrier in the main loop), and every byte of A and Z moves once.
+//
+// LDS images are [row][K+4] floats: the +4 pad makes the 16 B/lane fragment reads conflict free
+// (MI355X_MICROARCH: ds_read_b128 is serviced in 16-lane groups over 64 banks; row pitch = 33 slots of
+// 16 B puts the 16 rows of a group on 16 distinct slots).  The k index is permuted -- lane half h of
+// MFMA step s consumes k = s + (K/2) h -- so four consecutive steps read one 16-byte run per lane.
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float apply_act(float z, int act)
+{
+    switch (act) {
+    case ATHENA_MP_ACT_RELU: return z > 0.0f ? z : 0.0f;
+    case ATHENA_MP_ACT_SIGMOID: return 1.0f / (1.0f + expf(-z));
+    case ATHENA_MP_ACT_TANH: return tanhf(z);
+    default: return z;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// B-resident persistent GEMM.  b_nk: B is stored [N][K] (dx) instead of [K][N] (fwd).
+// ---------------------------------------------------------------------------------------------
+template <int K, int N>
+__global__ __launch_bounds__(256, 1) void gemm_bres_kernel(const float *__restrict__ A,
+                                                            const float *__restrict__ B, int b_nk,
+                                                            const float *__restrict__ bias, int act,
+                                                            float *__restrict__ Z, int64_t M)
+{
+    constexpr int LD = K + 4;          // floats per LDS row
+    constexpr int NT = N / 32;         // 32-wide column tiles per wave
+    constexpr int A4 = K / 8;          // float4 per lane per 32-row slab (32*K/4/64)
+    constexpr int RQ = K / 4;          // float4 per row
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *Bs = lds;                   // [N][LD]
+    float *As = lds + N * LD + (threadIdx.x >> 6) * 32 * LD; // this wave's [32][LD]
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int r31 = lane & 31;
+    const int h = lane >> 5;
+
+    // ---- stage B once per workgroup --------------------------------------------------------
+    if (b_nk) {
+        for (int t = threadIdx.x; t < N * RQ; t += 256) {
+            int n = t / RQ, q = t - n * RQ;
+            float4 v = *reinterpret_cast<const float4 *>(B + (size_t)n * K + 4 * q);
+            *reinterpret_cast<float4 *>(Bs + n * LD + 4 * q) = v;
+        }
+    } else {
+        for (int t = threadIdx.x; t < K * N; t += 256) {
+            int k = t / N, n = t - k * N;
+            Bs[n * LD + k] = B[t];
+        }
+    }
+    __syncthreads();
+
+    const int64_t n_slabs = (M + 31) / 32;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t slab = (int64_t)blockIdx.x * 4 + wave;
+
+    float4 pre[A4];
+    auto load_slab = [&](int64_t s) {
+        const int64_t r0 = s * 32;
+#pragma unroll
+        for (int it = 0; it < A4; ++it) {
+            int t = it * 64 + lane;
+            int row = t / RQ, q = t - row * RQ;
+            int64_t gr = r0 + row;
+            pre[it] = gr < M ? *reinterpret_cast<const float4 *>(A + gr * K + 4 * q)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    if (slab < n_slabs) load_slab(slab);
+
+    for (; slab < n_slabs; slab += stride) {
+        // registers -> this wave's LDS image
+#pragma unroll
+        for (int it = 0; it < A4; ++it) {
+            int t = it * 64 + lane;
+            int row = t / RQ, q = t - row * RQ;
+            *reinterpret_cast<float4 *>(As + row * LD + 4 * q) = pre[it];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // prefetch the next slab while the MFMAs run
+        if (slab + stride < n_slabs) load_slab(slab + stride);
+
+        f32x16 acc[NT];
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
+
+        const float *arow = As + r31 * LD + (K / 2) * h;
+        const float *brow = Bs + r31 * LD + (K / 2) * h;
+#pragma unroll 2
+        for (int q = 0; q < K / 8; ++q) {
+            float4 a4 = *reinterpret_cast<const float4 *>(arow + 4 * q);
+            float4 b4[NT];
+#pragma unroll
+            for (int c = 0; c < NT; ++c) b4[c] = *reinterpret_cast<const float4 *>(brow + c * 32 * LD + 4 * q);
+#pragma unroll
+            for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4[c].x, acc[c], 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4[c].y, acc[c], 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4[c].z, acc[c], 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4[c].w, acc[c], 0, 0, 0);
+        }
+        // all LDS reads of this slab are done before the next iteration overwrites the image
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*h ------
+        const int64_t r0 = slab * 32;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            const int colg = c * 32 + r31;
+            const float bv = bias ? bias[colg] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int64_t gr = r0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (gr < M) Z[gr * N + colg] = apply_act(acc[c][r] + bv, act);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dW on MFMA: dWt[i,o] = sum_v P[v,i] dZ[v,o].  Both operands are read straight from HBM in fragment
+// order -- the A operand of MFMA row-tile t is element t of the lane's contiguous TI-float load, i.e.
+// tile t, MFMA row m  <->  feature i = ibase + TI*m + t  (a fixed permutation undone at the store) --
+// so no LDS is needed and every load instruction reads contiguous row segments.
+// Each workgroup reduces a contiguous chunk of vertices into a private [FI][FO] slab; a second
+// kernel adds the slabs in fixed order (deterministic; no float atomics).
+// ---------------------------------------------------------------------------------------------
+template <int T> struct FragLoad;
+template <> struct FragLoad<1> {
+    static __device__ __forceinline__ void ld(float (&d)[1], const float *p) { d[0] = *p; }
+};
+template <> struct FragLoad<2> {
+    static __device__ __forceinline__ void ld(float (&d)[2], const float *p)
+    {
+        float2 t = *reinterpret_cast<const float2 *>(p);
+        d[0] = t.x; d[1] = t.y;
+    }
+};
+
+template <int FI, int FO>
+__global__ __launch_bounds__(256, 1) void gemm_dw_kernel(const float *__restrict__ P,
+                                                          const float *__restrict__ dZ,
+                                                          float *__restrict__ slabs, int64_t M,
+                                                          int64_t rows_per_block)
+{
+    // wave (wi, wo) owns features i in [wi*FI/2, +FI/2) x o in [wo*FO/2, +FO/2)
+    constexpr int TI = FI / 64, TJ = FO / 64; // 32x32 tiles per wave along i / o (1 or 2)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 31, h = lane >> 5;
+    const int ibase = (wave >> 1) * (FI / 2), obase = (wave & 1) * (FO / 2);
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int a = 0; a < TI; ++a)
+#pragma unroll
+        for (int b = 0; b < TJ; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    const int64_t v0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t v1 = min(M, v0 + rows_per_block);
+    const float *pa = P + ibase + TI * m;
+    const float *pb = dZ + obase + TJ * m;
+
+    constexpr int U = 8; // MFMA k-steps (2 vertices each) in flight
+    for (int64_t v = v0; v < v1; v += 2 * U) {
+        float a[U][TI], b[U][TJ];
+#pragma unroll
+        for (int s = 0; s < U; ++s) {
+            int64_t vv = v + 2 * s + h;
+            if (vv < v1) {
+                FragLoad<TI>::ld(a[s], pa + vv * FI);
+                FragLoad<TJ>::ld(b[s], pb + vv * FO);
+            } else {
+#pragma unroll
+                for (int t = 0; t < TI; ++t) a[s][t] = 0.0f;
+#pragma unroll
+                for (int t = 0; t < TJ; ++t) b[s][t] = 0.0f;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < U; ++s)
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < TJ; ++tj)
+                    acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][ti], b[s][tj], acc[ti][tj], 0, 0, 0);
+    }
+    float *slab = slabs + (size_t)blockIdx.x * FI * FO;
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
+                int i = ibase + TI * rr + ti;
+                int o = obase + TJ * m + tj;
+                slab[i * FO + o] = acc[ti][tj][r];
+            }
+}
+
+__global__ void slab_reduce_kernel(const float *__restrict__ slabs, int n_slabs, int n, float *__restrict__ out)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    float s = 0.0f;
+    for (int b = 0; b < n_slabs; ++b) s = s + slabs[(size_t)b * n + t];
+    out[t] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Shape-generic VALU kernels (tiny / odd feature counts such as the 6-7-10 of msgpass_chemical).
+// fmaf chain in k order == the MFMA's numerics.
+// ---------------------------------------------------------------------------------------------
+__global__ void gemm_small_kernel(const float *__restrict__ A, const float *__restrict__ B, int b_nk,
+                                  const float *__restrict__ bias, int act, float *__restrict__ Z,
+                                  int64_t M, int K, int N)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M * N) return;
+    int64_t v = t / N;
+    int n = (int)(t - v * N);
+    const float *a = A + v * K;
+    float s = 0.0f;
+    if (b_nk)
+        for (int k = 0; k < K; ++k) s = fmaf(a[k], B[(size_t)n * K + k], s);
+    else
+        for (int k = 0; k < K; ++k) s = fmaf(a[k], B[(size_t)k * N + n], s);
+    if (bias) s += bias[n];
+    Z[t] = apply_act(s, act);
+}
+
+__global__ void gemm_dw_small_kernel(const float *__restrict__ P, const float *__restrict__ dZ,
+                                     float *__restrict__ slabs, int64_t M, int FI, int FO,
+                                     int64_t rows_per_block)
+{
+    const int64_t v0 = (int64_t)blockIdx.x * rows_per_block, v1 = min(M, v0 + rows_per_block);
+    float *slab = slabs + (size_t)blockIdx.x * FI * FO;
+    for (int t = threadIdx.x; t < FI * FO; t += blockDim.x) {
+        int i = t / FO, o = t - i * FO;
+        float s = 0.0f;
+        for (int64_t v = v0; v < v1; ++v) s = fmaf(P[v * FI + i], dZ[v * FO + o], s);
+        slab[t] = s;
+    }
+}
+
+int g_num_cu = 0;
+int num_cu()
+{
+    if (!g_num_cu) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
+            g_num_cu = p.multiProcessorCount;
+        if (g_num_cu <= 0) g_num_cu = 256;
+    }
+    return g_num_cu;
+}
+
+template <int K, int N>
+int launch_bres(const float *A, const float *B, int b_nk, const float *bias, int act, float *Z, int64_t M)
+{
+    constexpr size_t lds = sizeof(float) * (size_t)(N + 4 * 32) * (K + 4);
+    static bool attr_done = false;
+    if (!attr_done) {
+        AMP_HIP(hipFuncSetAttribute((const void *)gemm_bres_kernel<K, N>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    int64_t n_slabs = (M + 31) / 32;
+    int grid = (int)std::min<int64_t>((n_slabs + 3) / 4, num_cu());
+    hipLaunchKernelGGL((gemm_bres_kernel<K, N>), dim3(grid), dim3(256), lds, amp::stream(), A, B, b_nk, bias,
+                       act, Z, M);
+    AMP_LAUNCH_CHECK();
+    return 0;
+}
+
+bool mfma_shape(int K, int N) { return (K == 32 || K == 64 || K == 128) && (N == 32 || N == 64 || N == 128); }
+
+int gemm_dispatch(const float *A, const float *B, int b_nk, const float *bias, int act, float *Z, int64_t M,
+                  int K, int N)
+{
+    if (M == 0) return 0;
+    if (mfma_shape(K, N) && ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0)) {
+#define AMP_CASE(KK, NN) \
+    if (K == KK && N == NN) return launch_bres<KK, NN>(A, B, b_nk, bias, act, Z, M);
+        AMP_CASE(32, 32) AMP_CASE(32, 64) AMP_CASE(32, 128)
+        AMP_CASE(64, 32) AMP_CASE(64, 64) AMP_CASE(64, 128)
+        AMP_CASE(128, 32) AMP_CASE(128, 64) AMP_CASE(128, 128)
+#undef AMP_CASE
+    }
+    int64_t total = M * N;
+    hipLaunchKernelGGL(gemm_small_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, amp::stream(), A,
+                       B, b_nk, bias, act, Z, M, K, N);
+    AMP_LAUNCH_CHECK();
+    return 0;
+}
+
+} // namespace
+
+using namespace amp;
+
+extern "C" {
+
+int athena_mp_gemm_fwd(int64_t N, int32_t Fi, int32_t Fo, const float *P, const float *W, const float *bias,
+                       int32_t act, float *Z)
+{
+    AMP_REQUIRE(N >= 0 && Fi > 0 && Fo > 0 && P && W && Z, "gemm_fwd: bad arguments");
+    return gemm_dispatch(P, W, /*b_nk=*/0, bias, act, Z, N, Fi, Fo);
+}
+
+int athena_mp_gemm_dx(int64_t N, int32_t Fi, int32_t Fo, const float *dZ, const float *W, float *dP)
+{
+    AMP_REQUIRE(N >= 0 && Fi > 0 && Fo > 0 && dZ && W && dP, "gemm_dx: bad arguments");
+    // dP[v,i] = sum_o dZ[v,o] Wt[i,o]:  K = Fo, N = Fi, B stored [N][K]
+    return gemm_dispatch(dZ, W, /*b_nk=*/1, nullptr, ATHENA_MP_ACT_NONE, dP, N, Fo, Fi);
+}
+
+int athena_mp_gemm_dw(int64_t N, int32_t Fi, int32_t Fo, const float *P, const float *dZ, float *dW)
+{
+    AMP_REQUIRE(N >= 0 && Fi > 0 && Fo > 0 && P && dZ && dW, "gemm_dw: bad arguments");
+    const int n = Fi * Fo;
+    if (N == 0) {
+        AMP_HIP(hipMemsetAsync(dW, 0, sizeof(float) * n, stream()));
+        return 0;
+    }
+    int nblk = (int)std::min<int64_t>((N + 255) / 256, 2 * num_cu());
+    int64_t rpb = (N + nblk - 1) / nblk;
+    rpb = (rpb + 1) & ~(int64_t)1; // even: the MFMA form consumes vertex pairs
+    nblk = (int)((N + rpb - 1) / rpb);
+    void *ws = nullptr;
+    if (workspace(&ws, sizeof(float) * (size_t)nblk * n, 2)) return 1;
+    float *slabs = (float *)ws;
+    bool mf = (Fi == 64 || Fi == 128) && (Fo == 64 || Fo == 128) && ((uintptr_t)P % 8 == 0) &&
+              ((uintptr_t)dZ % 8 == 0);
+    if (mf) {
+#define AMP_CASE(A_, B_)                                                                                   \
+    if (Fi == A_ && Fo == B_)                                                                              \
+        hipLaunchKernelGGL((gemm_dw_kernel<A_, B_>), dim3(nblk), dim3(256), 0, stream(), P, dZ, slabs, N, rpb);
+        AMP_CASE(64, 64) AMP_CASE(64, 128) AMP_CASE(128, 64) AMP_CASE(128, 128)
+#undef AMP_CASE
+    } else {
+        hipLaunchKernelGGL(gemm_dw_small_kernel, dim3(nblk), dim3(256), 0, stream(), P, dZ, slabs, N, Fi, Fo, rpb);
+    }
+    AMP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, stream(), slabs, nblk, n, dW);
+    AMP_LAUNCH_CHECK();
+    return 0;
+}
+
+int athena_mp_gemm_fwd_host(int64_t N, int32_t Fi, int32_t Fo, const float *Ph, const float *Wh,
+                            const float *bh, int32_t act, float *Zh)
+{
+    AMP_REQUIRE(N >= 0 && Fi > 0 && Fo > 0 && Ph && Wh && Zh, "gemm_fwd_host: bad arguments");
+    size_t bp = sizeof(float) * (size_t)N * Fi, bz = sizeof(float) * (size_t)N * Fo,
+           bw = sizeof(float) * (size_t)Fi * Fo, bb = sizeof(float) * (size_t)Fo;
+    void *dp = nullptr, *dz = nullptr, *dw = nullptr;
+    if (workspace(&dp, bp, 0) || workspace(&dz, bz, 1) || workspace(&dw, bw + bb, 3)) return 1;
+    AMP_HIP(hipMemcpyAsync(dp, Ph, bp, hipMemcpyHostToDevice, stream()));
+    AMP_HIP(hipMemcpyAsync(dw, Wh, bw, hipMemcpyHostToDevice, stream()));
+    float *db = nullptr;
+    if (bh) {
+        db = (float *)((char *)dw + bw);
+        AMP_HIP(hipMemcpyAsync(db, bh, bb, hipMemcpyHostToDevice, stream()));
+    }
+    int rc = athena_mp_gemm_fwd(N, Fi, Fo, (const float *)dp, (const float *)dw, db, act, (float *)dz);
+    if (rc) return rc;
+    AMP_HIP(hipMemcpyAsync(Zh, dz, bz, hipMemcpyDeviceToHost, stream()));
+    AMP_HIP(hipStreamSynchronize(stream()));
+    return 0;
+}
+
+} // extern "C"

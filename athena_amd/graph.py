@@ -1,0 +1,149 @@
+"""Host-side mirror of graphstruc's `graph_type` as athena's msgpass layers see it, plus the
+device graph handle.
+
+The reference reads only `adj_ia`, `adj_ja`, vertex/edge feature arrays and the counts from
+`graph_type` (call sites athena_kipf_msgpass_layer.f90:943-946,
+athena_msgpass_layer_sub.f90:144-174).  Conventions are kept Fortran-like so tests read like the
+reference's:
+  adj_ia : int32 [num_vertices+1], 1-based row pointers
+  adj_ja : int32 [2, nnz]; adj_ja[0, w] = neighbour (1-based), adj_ja[1, w] = undirected edge id
+           (1-based; 0 for a self-loop entry, as in test/test_diffstruc_extd_kipf.f90:29-31)
+  vertex_features : float32 [num_vertex_features, num_vertices] (Fortran shape) -- stored here
+           transposed as C-contiguous [num_vertices, F], which is the same memory.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+
+
+class graph_type:
+    """Undirected sparse graph in athena's CSR convention."""
+
+    def __init__(self):
+        self.num_vertices = 0
+        self.num_edges = 0
+        self.num_vertex_features = 0
+        self.num_edge_features = 0
+        self.adj_ia = np.ones(1, np.int32)
+        self.adj_ja = np.zeros((2, 0), np.int32, order="F")
+        self.vertex_features = None  # [num_vertices, Fv]
+        self.edge_features = None    # [num_edges, Fe]
+        self.is_sparse = True
+
+    # -- graphstruc API used by the reference's tests (test_kipf_msgpass_layer.f90:71-100) -------
+    def set_num_vertices(self, n, num_features=0):
+        self.num_vertices = int(n)
+        self.num_vertex_features = int(num_features)
+        self.vertex_features = np.zeros((self.num_vertices, self.num_vertex_features), np.float32)
+
+    def set_num_edges(self, n, num_features=0):
+        self.num_edges = int(n)
+        self.num_edge_features = int(num_features)
+        self.edge_features = np.zeros((self.num_edges, self.num_edge_features), np.float32)
+
+    def generate_adjacency(self, index_list):
+        """index_list [2, num_edges], 1-based vertex pairs; edge e = column e (1-based id).
+
+        Each undirected edge contributes two CSR entries sharing the same edge id.  Within a row,
+        entries are ordered by edge id (graphstruc's internal order is not visible from the
+        reference and only affects fp32 summation order)."""
+        idx = np.asarray(index_list, dtype=np.int64)
+        assert idx.ndim == 2 and idx.shape[0] == 2
+        E = idx.shape[1]
+        if self.num_edges == 0:
+            self.num_edges = E
+        src = np.concatenate([idx[0], idx[1]])
+        dst = np.concatenate([idx[1], idx[0]])
+        eid = np.concatenate([np.arange(1, E + 1), np.arange(1, E + 1)])
+        loops = idx[0] == idx[1]
+        if loops.any():  # a self edge is a single CSR entry
+            keep = np.concatenate([np.ones(E, bool), ~loops])
+            src, dst, eid = src[keep], dst[keep], eid[keep]
+        self._from_entries(src, dst, eid)
+
+    def add_self_loops(self):
+        """A~ = A + I: one entry (v, v) with edge id 0 per vertex that has none."""
+        rows = np.repeat(np.arange(1, self.num_vertices + 1), np.diff(self.adj_ia))
+        has = np.zeros(self.num_vertices + 1, bool)
+        has[rows[self.adj_ja[0] == rows]] = True
+        add = np.nonzero(~has[1:])[0] + 1
+        src = np.concatenate([rows, add])
+        dst = np.concatenate([self.adj_ja[0], add])
+        eid = np.concatenate([self.adj_ja[1], np.zeros(add.size, np.int64)])
+        self._from_entries(src, dst, eid, self_loops_first=True)
+
+    def _from_entries(self, src, dst, eid, self_loops_first=False):
+        n = self.num_vertices
+        key = eid.astype(np.int64)
+        if self_loops_first:
+            key = np.where(eid == 0, -1, key)
+        order = np.lexsort((key, src))
+        src, dst, eid = src[order], dst[order], eid[order]
+        counts = np.bincount(src - 1, minlength=n)
+        self.adj_ia = np.concatenate([[1], 1 + np.cumsum(counts)]).astype(np.int32)
+        ja = np.empty((2, src.size), np.int32, order="F")
+        ja[0] = dst
+        ja[1] = eid
+        self.adj_ja = ja
+
+    @property
+    def nnz(self):
+        return int(self.adj_ja.shape[1])
+
+    @classmethod
+    def from_csr(cls, adj_ia, adj_ja, num_edges=None):
+        g = cls()
+        g.adj_ia = np.ascontiguousarray(adj_ia, np.int32)
+        g.adj_ja = np.asfortranarray(adj_ja, np.int32)
+        g.num_vertices = g.adj_ia.size - 1
+        g.num_edges = int(g.adj_ja[1].max()) if (num_edges is None and g.adj_ja.shape[1]) else int(num_edges or 0)
+        return g
+
+
+class DeviceGraph:
+    """Owns an `athena_mp_graph*` (device CSR + transposed CSR + coefficients).
+
+    Built once and reused: the reference re-copies the CSR on every forward
+    (athena_network_sub.f90:2727-2730); the handle is what `set_graph` caches."""
+
+    def __init__(self, adj_ia, adj_ja, n_cols=None, n_edge_cols=None, row_deg=None, col_deg=None, device=0):
+        _capi.init(device)
+        ia = np.ascontiguousarray(adj_ia, np.int32)
+        ja = np.asfortranarray(adj_ja, np.int32)
+        assert ja.ndim == 2 and ja.shape[0] == 2, "adj_ja must be [2, nnz]"
+        self.n_rows = ia.size - 1
+        self.n_cols = self.n_rows if n_cols is None else int(n_cols)
+        self.nnz = int(ja.shape[1])
+        if n_edge_cols is None:
+            n_edge_cols = int(ja[1].max()) if self.nnz else 0
+        self.n_edge_cols = int(n_edge_cols)
+        rd = cd = None
+        if row_deg is not None:
+            rd = np.ascontiguousarray(row_deg, np.int32)
+            cd = np.ascontiguousarray(col_deg, np.int32)
+            assert rd.size == self.n_rows and cd.size == self.n_cols
+        h = C.c_void_p()
+        _capi.call(
+            "athena_mp_graph_create", self.n_rows, self.n_cols, self.nnz,
+            ia.ctypes.data_as(C.c_void_p), ja.ctypes.data_as(C.c_void_p), self.n_edge_cols,
+            rd.ctypes.data_as(C.c_void_p) if rd is not None else None,
+            cd.ctypes.data_as(C.c_void_p) if cd is not None else None, C.byref(h))
+        self.handle = h
+
+    @classmethod
+    def from_graph(cls, g, device=0):
+        return cls(g.adj_ia, g.adj_ja, n_edge_cols=max(g.num_edges, int(g.adj_ja[1].max()) if g.nnz else 0),
+                   device=device)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            _capi.load().athena_mp_graph_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

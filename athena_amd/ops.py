@@ -1,0 +1,226 @@
+"""The autodiff ops of the path on device tensors -- thin wrappers over the C ABI.
+
+Names follow the reference's op library (athena_diffstruc_extd.f90:251-318): kipf_propagate,
+duvenaud_propagate, duvenaud_update, gno_*; `matmul` is diffstruc's.  Each `*_bwd*` function is
+the `get_partial_*_val` callback of the corresponding op.  Tensors are torch CUDA(HIP) float32,
+row-major [N, F] == athena's val(F, N).  Kernels go to torch's current stream.
+"""
+import ctypes as C
+
+import torch
+
+from . import _capi
+from .graph import DeviceGraph
+
+ACT = {"none": 0, "linear": 0, "relu": 1, "sigmoid": 2, "tanh": 3}
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _chk(t, shape=None, dtype=torch.float32):
+    assert t.is_cuda and t.dtype == dtype and t.is_contiguous(), "expect contiguous device tensor"
+    if shape is not None:
+        assert tuple(t.shape) == tuple(shape), f"shape {tuple(t.shape)} != {tuple(shape)}"
+    return t
+
+
+def _go():
+    _capi.use_torch_stream()
+
+
+# ---- Kipf -------------------------------------------------------------------------------------
+def kipf_propagate(g: DeviceGraph, x, out=None):
+    """athena_diffstruc_extd_sub_kipf.f90:7-59"""
+    F = x.shape[1]
+    _chk(x, (g.n_cols, F))
+    y = out if out is not None else torch.empty((g.n_rows, F), device=x.device, dtype=torch.float32)
+    _chk(y, (g.n_rows, F))
+    _go()
+    _capi.call("athena_mp_kipf_propagate_fwd", g.handle, F, _p(x), _p(y))
+    return y
+
+
+def kipf_propagate_bwd(g: DeviceGraph, grad, exact=False, out=None):
+    """get_partial_kipf_propagate_left_val, ..._sub_kipf.f90:85-111 (exact=False: no coefficient)"""
+    F = grad.shape[1]
+    _chk(grad, (g.n_rows, F))
+    dx = out if out is not None else torch.empty((g.n_cols, F), device=grad.device, dtype=torch.float32)
+    _chk(dx, (g.n_cols, F))
+    _go()
+    _capi.call("athena_mp_kipf_propagate_bwd", g.handle, F, _p(grad), _p(dx), int(bool(exact)))
+    return dx
+
+
+# ---- dense contraction (diffstruc matmul) ---------------------------------------------------------
+def matmul(W, P, Fo, bias=None, act="none", out=None):
+    """Z[N,Fo] = act(P[N,Fi] . Wt + bias);  W flat params%val(:,1) = W(Fo,Fi) column-major."""
+    N, Fi = P.shape
+    _chk(P)
+    assert W.numel() == Fo * Fi
+    Z = out if out is not None else torch.empty((N, Fo), device=P.device, dtype=torch.float32)
+    _go()
+    _capi.call("athena_mp_gemm_fwd", N, Fi, Fo, _p(P), _p(_chk(W)), _p(bias), ACT[act], _p(Z))
+    return Z
+
+
+def matmul_dw(P, dZ, out=None):
+    """dW(Fo,Fi) flat = sum_v dZ[v,:] (x) P[v,:]"""
+    N, Fi = P.shape
+    Fo = dZ.shape[1]
+    _chk(P); _chk(dZ, (N, Fo))
+    dW = out if out is not None else torch.empty(Fo * Fi, device=P.device, dtype=torch.float32)
+    _go()
+    _capi.call("athena_mp_gemm_dw", N, Fi, Fo, _p(P), _p(dZ), _p(dW))
+    return dW
+
+
+def matmul_dx(W, dZ, Fi, out=None):
+    """dP[N,Fi] = dZ[N,Fo] . W"""
+    N, Fo = dZ.shape
+    _chk(dZ)
+    assert W.numel() == Fo * Fi
+    dP = out if out is not None else torch.empty((N, Fi), device=dZ.device, dtype=torch.float32)
+    _go()
+    _capi.call("athena_mp_gemm_dx", N, Fi, Fo, _p(dZ), _p(_chk(W)), _p(dP))
+    return dP
+
+
+def activation(kind, z, out=None):
+    y = out if out is not None else torch.empty_like(z)
+    _go()
+    _capi.call("athena_mp_activation_fwd", ACT[kind], z.numel(), _p(_chk(z)), _p(y))
+    return y
+
+
+def activation_bwd(kind, y, g, out=None):
+    dz = out if out is not None else torch.empty_like(y)
+    _go()
+    _capi.call("athena_mp_activation_bwd", ACT[kind], y.numel(), _p(_chk(y)), _p(_chk(g)), _p(dz))
+    return dz
+
+
+def axpy(alpha, x, y):
+    _go()
+    _capi.call("athena_mp_axpy", x.numel(), float(alpha), _p(_chk(x)), _p(_chk(y)))
+    return y
+
+
+# ---- Duvenaud -------------------------------------------------------------------------------------
+def duvenaud_propagate(g: DeviceGraph, x, e, out=None):
+    """athena_diffstruc_extd_sub_duvenaud.f90:7-59"""
+    Fv, Fe = x.shape[1], e.shape[1]
+    _chk(x, (g.n_cols, Fv)); _chk(e)
+    c = out if out is not None else torch.empty((g.n_rows, Fv + Fe), device=x.device, dtype=torch.float32)
+    _go()
+    _capi.call("athena_mp_duvenaud_propagate_fwd", g.handle, Fv, Fe, _p(x), _p(e), _p(c))
+    return c
+
+
+def duvenaud_propagate_bwd_x(g: DeviceGraph, grad, Fv):
+    Fe = grad.shape[1] - Fv
+    _chk(grad, (g.n_rows, Fv + Fe))
+    dx = torch.empty((g.n_cols, Fv), device=grad.device, dtype=torch.float32)
+    _go()
+    _capi.call("athena_mp_duvenaud_propagate_bwd_x", g.handle, Fv, Fe, _p(grad), _p(dx))
+    return dx
+
+
+def duvenaud_propagate_bwd_e(g: DeviceGraph, grad, Fv):
+    Fe = grad.shape[1] - Fv
+    _chk(grad, (g.n_rows, Fv + Fe))
+    de = torch.empty((g.n_edge_cols, Fe), device=grad.device, dtype=torch.float32)
+    _go()
+    _capi.call("athena_mp_duvenaud_propagate_bwd_e", g.handle, Fv, Fe, _p(grad), _p(de))
+    return de
+
+
+def duvenaud_update(g: DeviceGraph, a, weight, min_deg, max_deg, Fo):
+    """athena_diffstruc_extd_sub_duvenaud.f90:176-228"""
+    Fi = a.shape[1]
+    _chk(a, (g.n_rows, Fi))
+    assert weight.numel() == Fo * Fi * (max_deg - min_deg + 1)
+    c = torch.empty((g.n_rows, Fo), device=a.device, dtype=torch.float32)
+    _go()
+    _capi.call("athena_mp_duvenaud_update_fwd", g.handle, Fi, Fo, min_deg, max_deg, _p(a), _p(_chk(weight)), _p(c))
+    return c
+
+
+def duvenaud_update_bwd_a(g: DeviceGraph, grad, weight, min_deg, max_deg, Fi):
+    Fo = grad.shape[1]
+    _chk(grad, (g.n_rows, Fo))
+    da = torch.empty((g.n_rows, Fi), device=grad.device, dtype=torch.float32)
+    _go()
+    _capi.call("athena_mp_duvenaud_update_bwd_a", g.handle, Fi, Fo, min_deg, max_deg, _p(grad), _p(_chk(weight)), _p(da))
+    return da
+
+
+def duvenaud_update_bwd_w(g: DeviceGraph, grad, a, min_deg, max_deg):
+    Fo, Fi = grad.shape[1], a.shape[1]
+    _chk(grad, (g.n_rows, Fo)); _chk(a, (g.n_rows, Fi))
+    dW = torch.empty(Fo * Fi * (max_deg - min_deg + 1), device=grad.device, dtype=torch.float32)
+    _go()
+    _capi.call("athena_mp_duvenaud_update_bwd_w", g.handle, Fi, Fo, min_deg, max_deg, _p(grad), _p(a), _p(dW))
+    return dW
+
+
+def softmax_segsum(logits, seg, out=None):
+    """p = softmax over outputs per vertex; out[s] (+)= sum of p over graph s.  Returns (p, out)."""
+    N, O = logits.shape
+    S = seg.numel() - 1
+    _chk(logits); _chk(seg, dtype=torch.int32)
+    p = torch.empty_like(logits)
+    acc = out is not None
+    if out is None:
+        out = torch.empty((S, O), device=logits.device, dtype=torch.float32)
+    _go()
+    _capi.call("athena_mp_softmax_segsum_fwd", O, N, S, _p(seg), _p(logits), _p(p), _p(out), int(acc))
+    return p, out
+
+
+def softmax_segsum_bwd(p, seg, gout):
+    N, O = p.shape
+    S = seg.numel() - 1
+    _chk(p); _chk(gout, (S, O))
+    dz = torch.empty_like(p)
+    _go()
+    _capi.call("athena_mp_softmax_segsum_bwd", O, N, S, _p(seg), _p(p), _p(gout), _p(dz))
+    return dz
+
+
+# ---- graph neural operator -----------------------------------------------------------------------
+def gno_aggregate(g: DeviceGraph, theta, coords, x, d, H, Fo):
+    """gno_kernel_eval + gno_aggregate (athena_diffstruc_extd_sub_nop.f90:26-115, :330-397) fused"""
+    Fi = x.shape[1]
+    _chk(x, (g.n_cols, Fi)); _chk(coords); _chk(theta)
+    assert theta.numel() == H * d + H + Fo * Fi * H + Fo * Fi
+    m = torch.empty((g.n_rows, Fo), device=x.device, dtype=torch.float32)
+    _go()
+    _capi.call("athena_mp_gno_aggregate_fwd", g.handle, d, H, Fi, Fo, _p(theta), _p(coords), _p(x), _p(m))
+    return m
+
+
+def gno_aggregate_bwd_x(g: DeviceGraph, theta, coords, grad, d, H, Fi):
+    Fo = grad.shape[1]
+    _chk(grad, (g.n_rows, Fo))
+    dx = torch.empty((g.n_cols, Fi), device=grad.device, dtype=torch.float32)
+    _go()
+    _capi.call("athena_mp_gno_aggregate_bwd_x", g.handle, d, H, Fi, Fo, _p(theta), _p(coords), _p(grad), _p(dx))
+    return dx
+
+
+def gno_aggregate_bwd_theta(g: DeviceGraph, theta, coords, x, grad, d, H):
+    Fi, Fo = x.shape[1], grad.shape[1]
+    dth = torch.empty_like(theta)
+    _go()
+    _capi.call("athena_mp_gno_aggregate_bwd_theta", g.handle, d, H, Fi, Fo, _p(theta), _p(coords), _p(x), _p(grad), _p(dth))
+    return dth
+
+
+def gno_aggregate_bwd_coords(g: DeviceGraph, theta, coords, x, grad, d, H):
+    Fi, Fo = x.shape[1], grad.shape[1]
+    dc = torch.empty_like(coords)
+    _go()
+    _capi.call("athena_mp_gno_aggregate_bwd_coords", g.handle, d, H, Fi, Fo, _p(theta), _p(coords), _p(x), _p(grad), _p(dc))
+    return dc

@@ -1,0 +1,167 @@
+/*
+ * athena_mp.h -- C ABI of the MI355X (gfx950) message-passing engine for athena.
+ *
+ * This is the drop-in boundary.  The reference (nedtaylor/athena
+ * v2.1.1) is pure Fortran and has no FFI for this path, so each entry point below
+ * names the reference procedure whose arithmetic it replaces (paths relative to
+ * src/athena/ of the reference).  The Fortran side binds them through
+ * ISO_C_BINDING (athena_amd/fortran/athena_mp_c.f90; INTEGRATION.md shows the
+ * layer-side stub).
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; the message is
+ *     available from athena_mp_last_error() (the Fortran wrapper turns it into
+ *     coreutils' stop_program(msg), cf. athena_kipf_msgpass_layer.f90:271-274).
+ *   - "dev" pointers are device (HBM) pointers; "host" pointers are host memory.
+ *     The *_host variants stage through HBM for callers that only hold
+ *     array_type%val (phase-1 plumbing); they are never timed.
+ *   - feature tensors are athena's val(F, N) column-major == row-major [N][F]
+ *     fp32: one vertex row contiguous.  Dense weights are params(t)%val(:,1):
+ *     W(Fo,Fi) column-major flat == row-major Wt[Fi][Fo].
+ *   - all kernels are enqueued on the stream set with athena_mp_set_stream
+ *     (default: the null stream) and return without synchronising.
+ *   - not thread-safe by design (the reference's layers are stateful and
+ *     single-threaded, SURVEY.md 8b "Threading").
+ */
+#ifndef ATHENA_MP_H
+#define ATHENA_MP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct athena_mp_graph athena_mp_graph; /* opaque: device CSR + transposed CSR + coefficients */
+
+/* activation kinds understood by the fused epilogues and athena_mp_activation_* */
+enum {
+    ATHENA_MP_ACT_NONE = 0,    /* athena_activation_none.f90    */
+    ATHENA_MP_ACT_RELU = 1,    /* athena_activation_relu.f90    */
+    ATHENA_MP_ACT_SIGMOID = 2, /* athena_activation_sigmoid.f90 */
+    ATHENA_MP_ACT_TANH = 3     /* athena_activation_tanh.f90    */
+};
+
+/* ---- runtime ------------------------------------------------------------ */
+int athena_mp_init(int device);            /* hipSetDevice + capability check (gfx950) */
+int athena_mp_finalize(void);
+const char *athena_mp_last_error(void);
+int athena_mp_set_stream(void *hip_stream); /* hipStream_t; NULL = default stream */
+int athena_mp_synchronize(void);
+int athena_mp_version(void);
+
+/* device memory helpers so a Fortran caller can keep tensors resident */
+int athena_mp_malloc(void **dev_ptr, uint64_t bytes);
+int athena_mp_free(void *dev_ptr);
+int athena_mp_memcpy_h2d(void *dev_dst, const void *host_src, uint64_t bytes);
+int athena_mp_memcpy_d2h(void *host_dst, const void *dev_src, uint64_t bytes);
+int athena_mp_memset_zero(void *dev_ptr, uint64_t bytes);
+
+/* ---- graph handle ------------------------------------------------------- *
+ * Replaces the per-call CSR copies of set_graph_msgpass
+ * (athena_msgpass_layer_sub.f90:144-174) and `c%indices = adj_ia; c%adj_ja =
+ * adj_ja` (athena_diffstruc_extd_sub_kipf.f90:48-49): built once, reused.
+ *   adj_ia  [n_rows+1]  1-based row pointers            (host)
+ *   adj_ja  [2, nnz]    column-major; (1,w) neighbour 1-based in [1,n_cols],
+ *                       (2,w) edge-feature column 1-based, 0 = none (host)
+ *   row_deg / col_deg   optional global degrees for a row partition with halo
+ *                       columns (NULL: degree = CSR row length, needs n_rows ==
+ *                       n_cols -- exactly the reference's coefficient,
+ *                       athena_diffstruc_extd_sub_kipf.f90:39-42)
+ */
+int athena_mp_graph_create(int32_t n_rows, int32_t n_cols, int64_t nnz, const int32_t *adj_ia,
+                           const int32_t *adj_ja, int32_t n_edge_cols, const int32_t *row_deg,
+                           const int32_t *col_deg, athena_mp_graph **out);
+int athena_mp_graph_destroy(athena_mp_graph *g);
+int athena_mp_graph_dims(const athena_mp_graph *g, int32_t *n_rows, int32_t *n_cols, int64_t *nnz,
+                         int32_t *n_edge_cols);
+
+/* ---- Kipf --------------------------------------------------------------- */
+/* kipf_propagate, athena_diffstruc_extd_sub_kipf.f90:7-59
+ *   y[v,:] = sum_w ((deg_v*deg_u)^-1/2) x[u,:]        x [n_cols,F], y [n_rows,F] */
+int athena_mp_kipf_propagate_fwd(const athena_mp_graph *g, int32_t F, const float *x_dev, float *y_dev);
+/* get_partial_kipf_propagate_left_val, ..._sub_kipf.f90:85-111
+ *   dx[u,:] = sum_{(v,w): ja(1,w)=u} grad[v,:]   (exact=0: the reference, NO coefficient;
+ *   exact=1: multiplied by the coefficient, the mathematically exact adjoint) */
+int athena_mp_kipf_propagate_bwd(const athena_mp_graph *g, int32_t F, const float *grad_dev,
+                                 float *dx_dev, int32_t exact);
+
+/* ---- dense contraction (diffstruc matmul at athena_kipf_msgpass_layer.f90:951,
+ *      athena_duvenaud_msgpass_layer.f90:842, athena_graph_nop_layer.f90:761) -- fp32 MFMA */
+/* Z[N,Fo] = act( P[N,Fi] . Wt[Fi,Fo] (+ bias[Fo]) );  bias may be NULL */
+int athena_mp_gemm_fwd(int64_t N, int32_t Fi, int32_t Fo, const float *P_dev, const float *W_dev,
+                       const float *bias_dev, int32_t act, float *Z_dev);
+/* dW(Fo,Fi) = dZ^T-contract: dWt[i,o] = sum_v P[v,i] dZ[v,o] */
+int athena_mp_gemm_dw(int64_t N, int32_t Fi, int32_t Fo, const float *P_dev, const float *dZ_dev,
+                      float *dW_dev);
+/* dP[N,Fi] = dZ[N,Fo] . W  (dP[v,i] = sum_o dZ[v,o] Wt[i,o]) */
+int athena_mp_gemm_dx(int64_t N, int32_t Fi, int32_t Fo, const float *dZ_dev, const float *W_dev,
+                      float *dP_dev);
+
+/* ---- element-wise brackets of the path -------------- */
+int athena_mp_activation_fwd(int32_t act, int64_t n, const float *z_dev, float *y_dev);
+int athena_mp_activation_bwd(int32_t act, int64_t n, const float *y_dev, const float *g_dev, float *dz_dev);
+int athena_mp_axpy(int64_t n, float alpha, const float *x_dev, float *y_dev); /* y += alpha x */
+
+/* ---- Duvenaud ------------------------------------------------------------ */
+/* duvenaud_propagate, athena_diffstruc_extd_sub_duvenaud.f90:7-59
+ *   c[v,:] = sum_w [ x[u,:] ; e[ja(2,w),:] ]     c [n_rows, Fv+Fe]; edge id 0 => zero vector */
+int athena_mp_duvenaud_propagate_fwd(const athena_mp_graph *g, int32_t Fv, int32_t Fe,
+                                     const float *x_dev, const float *e_dev, float *c_dev);
+/* get_partial_duvenaud_propagate_left_val :115-141 / _right_val :143-171 */
+int athena_mp_duvenaud_propagate_bwd_x(const athena_mp_graph *g, int32_t Fv, int32_t Fe,
+                                       const float *grad_dev, float *dx_dev);
+int athena_mp_duvenaud_propagate_bwd_e(const athena_mp_graph *g, int32_t Fv, int32_t Fe,
+                                       const float *grad_dev, float *de_dev);
+/* duvenaud_update :176-228;  weight [Fo*Fi*(max_deg-min_deg+1)] packed per degree bucket */
+int athena_mp_duvenaud_update_fwd(const athena_mp_graph *g, int32_t Fi, int32_t Fo, int32_t min_deg,
+                                  int32_t max_deg, const float *a_dev, const float *weight_dev,
+                                  float *c_dev);
+/* get_partial_duvenaud_update_val :284-324 */
+int athena_mp_duvenaud_update_bwd_a(const athena_mp_graph *g, int32_t Fi, int32_t Fo, int32_t min_deg,
+                                    int32_t max_deg, const float *grad_dev, const float *weight_dev,
+                                    float *da_dev);
+/* get_partial_duvenaud_update_weight_val :326-368 */
+int athena_mp_duvenaud_update_bwd_w(const athena_mp_graph *g, int32_t Fi, int32_t Fo, int32_t min_deg,
+                                    int32_t max_deg, const float *grad_dev, const float *a_dev,
+                                    float *dweight_dev);
+/* readout, athena_duvenaud_msgpass_layer.f90:838-855 over a block-diagonal batch:
+ *   p[v,:] = softmax_over_outputs(logits[v,:]); out[s,:] (+)= sum_{v in seg s} p[v,:]
+ *   seg_dev [S+1] 0-based vertex offsets of the graphs */
+int athena_mp_softmax_segsum_fwd(int32_t O, int64_t N, int32_t S, const int32_t *seg_dev,
+                                 const float *logits_dev, float *p_dev, float *out_dev,
+                                 int32_t accumulate);
+/* dlogits[v,:] = p (g_s - <g_s,p>) for v in segment s */
+int athena_mp_softmax_segsum_bwd(int32_t O, int64_t N, int32_t S, const int32_t *seg_dev,
+                                 const float *p_dev, const float *gout_dev, float *dlogits_dev);
+
+/* ---- Graph neural operator ------------------------------------------------
+ * gno_kernel_eval + gno_aggregate, athena_diffstruc_extd_sub_nop.f90:26-115, :330-397,
+ * re-associated so the [Fo*Fi, E] edge-kernel tensor is never materialised:
+ *   m[i,:] = sum_{(j,e) in row i} reshape(V relu(U dx_e + b_u) + b_v,[Fo,Fi]) x[j,:]
+ * theta = [U(H,d) | b_u(H) | V(Fo*Fi,H) | b_v(Fo*Fi)]  (:74-82);  coords [E,d]. */
+int athena_mp_gno_aggregate_fwd(const athena_mp_graph *g, int32_t d, int32_t H, int32_t Fi, int32_t Fo,
+                                const float *theta_dev, const float *coords_dev, const float *x_dev,
+                                float *m_dev);
+/* gradients (:137-216, :235-325, :419-458, :480-526 composed through the same re-association) */
+int athena_mp_gno_aggregate_bwd_x(const athena_mp_graph *g, int32_t d, int32_t H, int32_t Fi, int32_t Fo,
+                                  const float *theta_dev, const float *coords_dev,
+                                  const float *grad_dev, float *dx_dev);
+int athena_mp_gno_aggregate_bwd_theta(const athena_mp_graph *g, int32_t d, int32_t H, int32_t Fi,
+                                      int32_t Fo, const float *theta_dev, const float *coords_dev,
+                                      const float *x_dev, const float *grad_dev, float *dtheta_dev);
+int athena_mp_gno_aggregate_bwd_coords(const athena_mp_graph *g, int32_t d, int32_t H, int32_t Fi,
+                                       int32_t Fo, const float *theta_dev, const float *coords_dev,
+                                       const float *x_dev, const float *grad_dev, float *dcoords_dev);
+
+/* ---- host-pointer staging variants (phase-1 Fortran callbacks) ------------- */
+int athena_mp_kipf_propagate_fwd_host(const athena_mp_graph *g, int32_t F, const float *x_host, float *y_host);
+int athena_mp_kipf_propagate_bwd_host(const athena_mp_graph *g, int32_t F, const float *grad_host,
+                                      float *dx_host, int32_t exact);
+int athena_mp_gemm_fwd_host(int64_t N, int32_t Fi, int32_t Fo, const float *P_host, const float *W_host,
+                            const float *bias_host, int32_t act, float *Z_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ATHENA_MP_H */
