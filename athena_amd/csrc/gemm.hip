@@ -20,6 +20,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4))); // native vector: stays in VGPRs (HIP float4 struct copies became memcpy-to-scratch)
 
 __device__ __forceinline__ float apply_act(float z, int act)
 {
@@ -34,19 +35,45 @@ __device__ __forceinline__ float apply_act(float z, int act)
 // ---------------------------------------------------------------------------------------------
 // B-resident persistent GEMM.  b_nk: B is stored [N][K] (dx) instead of [K][N] (fwd).
 // ---------------------------------------------------------------------------------------------
-template <int K, int N>
+template <int ACT> __device__ __forceinline__ float act_ct(float z)
+{
+    if constexpr (ACT == ATHENA_MP_ACT_RELU) return z > 0.0f ? z : 0.0f;
+    if constexpr (ACT == ATHENA_MP_ACT_SIGMOID) return 1.0f / (1.0f + expf(-z));
+    if constexpr (ACT == ATHENA_MP_ACT_TANH) return tanhf(z);
+    return z;
+}
+
+template <int K>
+__device__ __forceinline__ void load_slab(v4f (&pre)[K / 8], const float *__restrict__ A, int64_t s, int64_t M,
+                                          int lane)
+{
+    constexpr int RQ = K / 4;
+    const int64_t r0 = s * 32;
+#pragma unroll
+    for (int it = 0; it < K / 8; ++it) {
+        int t = it * 64 + lane;
+        int row = t / RQ, q = t - row * RQ;
+        int64_t gr = min(r0 + row, M - 1); // tail rows re-read the last row; never stored
+        pre[it] = *reinterpret_cast<const v4f *>(A + gr * K + 4 * q);
+    }
+}
+
+template <int K, int N, int ACT, bool BIAS>
 __global__ __launch_bounds__(256, 1) void gemm_bres_kernel(const float *__restrict__ A,
                                                             const float *__restrict__ B, int b_nk,
-                                                            const float *__restrict__ bias, int act,
+                                                            const float *__restrict__ bias,
                                                             float *__restrict__ Z, int64_t M)
 {
-    constexpr int LD = K + 4;          // floats per LDS row
-    constexpr int NT = N / 32;         // 32-wide column tiles per wave
-    constexpr int A4 = K / 8;          // float4 per lane per 32-row slab (32*K/4/64)
-    constexpr int RQ = K / 4;          // float4 per row
+    constexpr int LD = K + 4;                 // floats per LDS row of the operand images
+    constexpr int LDW = (K > N ? K : N) + 4;  // pitch of a wave's private region (A image, then C image)
+    constexpr int NT = N / 32;                // 32-wide column tiles per wave
+    constexpr int A4 = K / 8;                 // v4f per lane per 32-row slab of A
+    constexpr int RQ = K / 4;                 // v4f per row of A
+    constexpr int C4 = N / 8;                 // v4f per lane per 32-row slab of C
+    constexpr int CQ = N / 4;                 // v4f per row of C
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *Bs = lds;                   // [N][LD]
-    float *As = lds + N * LD + (threadIdx.x >> 6) * 32 * LD; // this wave's [32][LD]
+    float *Bs = lds;                                              // [N][LD]
+    float *Ws = lds + N * LD + (threadIdx.x >> 6) * 32 * LDW;     // this wave's [32][LDW]
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -57,8 +84,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bres_kernel(const float *__restri
     if (b_nk) {
         for (int t = threadIdx.x; t < N * RQ; t += 256) {
             int n = t / RQ, q = t - n * RQ;
-            float4 v = *reinterpret_cast<const float4 *>(B + (size_t)n * K + 4 * q);
-            *reinterpret_cast<float4 *>(Bs + n * LD + 4 * q) = v;
+            v4f v = *reinterpret_cast<const v4f *>(B + (size_t)n * K + 4 * q);
+            *reinterpret_cast<v4f *>(Bs + n * LD + 4 * q) = v;
         }
     } else {
         for (int t = threadIdx.x; t < K * N; t += 256) {
@@ -72,33 +99,22 @@ __global__ __launch_bounds__(256, 1) void gemm_bres_kernel(const float *__restri
     const int64_t stride = (int64_t)gridDim.x * 4;
     int64_t slab = (int64_t)blockIdx.x * 4 + wave;
 
-    float4 pre[A4];
-    auto load_slab = [&](int64_t s) {
-        const int64_t r0 = s * 32;
-#pragma unroll
-        for (int it = 0; it < A4; ++it) {
-            int t = it * 64 + lane;
-            int row = t / RQ, q = t - row * RQ;
-            int64_t gr = r0 + row;
-            pre[it] = gr < M ? *reinterpret_cast<const float4 *>(A + gr * K + 4 * q)
-                             : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    if (slab < n_slabs) load_slab(slab);
+    v4f pre[A4];
+    if (slab < n_slabs) load_slab<K>(pre, A, slab, M, lane);
 
     for (; slab < n_slabs; slab += stride) {
-        // registers -> this wave's LDS image
+        // registers -> this wave's LDS image of A
 #pragma unroll
         for (int it = 0; it < A4; ++it) {
             int t = it * 64 + lane;
             int row = t / RQ, q = t - row * RQ;
-            *reinterpret_cast<float4 *>(As + row * LD + 4 * q) = pre[it];
+            *reinterpret_cast<v4f *>(Ws + row * LDW + 4 * q) = pre[it];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // prefetch the next slab while the MFMAs run
-        if (slab + stride < n_slabs) load_slab(slab + stride);
+        if (slab + stride < n_slabs) load_slab<K>(pre, A, slab + stride, M, lane);
 
         f32x16 acc[NT];
 #pragma unroll
@@ -106,14 +122,14 @@ __global__ __launch_bounds__(256, 1) void gemm_bres_kernel(const float *__restri
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
 
-        const float *arow = As + r31 * LD + (K / 2) * h;
+        const float *arow = Ws + r31 * LDW + (K / 2) * h;
         const float *brow = Bs + r31 * LD + (K / 2) * h;
 #pragma unroll 2
         for (int q = 0; q < K / 8; ++q) {
-            float4 a4 = *reinterpret_cast<const float4 *>(arow + 4 * q);
-            float4 b4[NT];
+            v4f a4 = *reinterpret_cast<const v4f *>(arow + 4 * q);
+            v4f b4[NT];
 #pragma unroll
-            for (int c = 0; c < NT; ++c) b4[c] = *reinterpret_cast<const float4 *>(brow + c * 32 * LD + 4 * q);
+            for (int c = 0; c < NT; ++c) b4[c] = *reinterpret_cast<const v4f *>(brow + c * 32 * LD + 4 * q);
 #pragma unroll
             for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4[c].x, acc[c], 0, 0, 0);
 #pragma unroll
@@ -123,22 +139,35 @@ __global__ __launch_bounds__(256, 1) void gemm_bres_kernel(const float *__restri
 #pragma unroll
             for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4[c].w, acc[c], 0, 0, 0);
         }
-        // all LDS reads of this slab are done before the next iteration overwrites the image
+        // all LDS reads of the A image are done; the region now receives the C tile
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
-        // ---- epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*h ------
+        // ---- epilogue: C/D map of the 32x32 MFMA is col = lane&31, row = (r&3) + 8*(r>>2) + 4*h.
+        // Transpose through LDS so that HBM sees whole 16 B/lane rows (2 full rows per instruction).
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Ws[((r & 3) + 8 * (r >> 2) + 4 * h) * LDW + c * 32 + r31] = acc[c][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int64_t r0 = slab * 32;
 #pragma unroll
-        for (int c = 0; c < NT; ++c) {
-            const int colg = c * 32 + r31;
-            const float bv = bias ? bias[colg] : 0.0f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int64_t gr = r0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (gr < M) Z[gr * N + colg] = apply_act(acc[c][r] + bv, act);
+        for (int it = 0; it < C4; ++it) {
+            int t = it * 64 + lane;
+            int row = t / CQ, q = t - row * CQ;
+            v4f v = *reinterpret_cast<const v4f *>(Ws + row * LDW + 4 * q);
+            if constexpr (BIAS) {
+                v4f bv = *reinterpret_cast<const v4f *>(bias + 4 * q);
+                v += bv;
             }
+            v.x = act_ct<ACT>(v.x); v.y = act_ct<ACT>(v.y); v.z = act_ct<ACT>(v.z); v.w = act_ct<ACT>(v.w);
+            if (r0 + row < M) *reinterpret_cast<v4f *>(Z + (r0 + row) * N + 4 * q) = v;
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -161,6 +190,37 @@ template <> struct FragLoad<2> {
         d[0] = t.x; d[1] = t.y;
     }
 };
+
+template <bool MASK, int U, int TI, int TJ, int FI, int FO>
+__device__ __forceinline__ void dw_load(float (&a)[U][TI], float (&b)[U][TJ], const float *__restrict__ pa,
+                                        const float *__restrict__ pb, int64_t v, int64_t v1, int h)
+{
+#pragma unroll
+    for (int s = 0; s < U; ++s) {
+        const int64_t vv = v + 2 * s + h;
+        const bool ok = vv < v1;
+        const int64_t vc = ok ? vv : v1 - 1; // unconditional loads; out-of-range steps contribute 0
+        FragLoad<TI>::ld(a[s], pa + vc * FI);
+        FragLoad<TJ>::ld(b[s], pb + vc * FO);
+        if constexpr (MASK) {
+            if (!ok) {
+#pragma unroll
+                for (int t = 0; t < TI; ++t) a[s][t] = 0.0f;
+            }
+        }
+    }
+}
+template <int U, int TI, int TJ>
+__device__ __forceinline__ void dw_mfma(f32x16 (&acc)[TI][TJ], const float (&a)[U][TI], const float (&b)[U][TJ])
+{
+#pragma unroll
+    for (int s = 0; s < U; ++s)
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < TJ; ++tj)
+                acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][ti], b[s][tj], acc[ti][tj], 0, 0, 0);
+}
 
 template <int FI, int FO>
 __global__ __launch_bounds__(256, 1) void gemm_dw_kernel(const float *__restrict__ P,
@@ -187,29 +247,27 @@ __global__ __launch_bounds__(256, 1) void gemm_dw_kernel(const float *__restrict
     const float *pa = P + ibase + TI * m;
     const float *pb = dZ + obase + TJ * m;
 
-    constexpr int U = 8; // MFMA k-steps (2 vertices each) in flight
-    for (int64_t v = v0; v < v1; v += 2 * U) {
-        float a[U][TI], b[U][TJ];
-#pragma unroll
-        for (int s = 0; s < U; ++s) {
-            int64_t vv = v + 2 * s + h;
-            if (vv < v1) {
-                FragLoad<TI>::ld(a[s], pa + vv * FI);
-                FragLoad<TJ>::ld(b[s], pb + vv * FO);
-            } else {
-#pragma unroll
-                for (int t = 0; t < TI; ++t) a[s][t] = 0.0f;
-#pragma unroll
-                for (int t = 0; t < TJ; ++t) b[s][t] = 0.0f;
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < U; ++s)
-#pragma unroll
-            for (int ti = 0; ti < TI; ++ti)
-#pragma unroll
-                for (int tj = 0; tj < TJ; ++tj)
-                    acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][ti], b[s][tj], acc[ti][tj], 0, 0, 0);
+    // Two register buffers of U k-steps each: the loads of batch n+1 are issued (and pinned with a
+    // scheduling barrier) before the MFMAs of batch n, so HBM latency hides under 4*U MFMAs.
+    constexpr int U = 8; // MFMA k-steps (2 vertices each) per batch
+    float a0[U][TI], b0[U][TJ], a1[U][TI], b1[U][TJ];
+    const int64_t n_pairs = (v1 - v0) / (4 * U); // full double-batches: no masking needed inside
+    int64_t v = v0;
+    if (n_pairs > 0) dw_load<false, U, TI, TJ, FI, FO>(a0, b0, pa, pb, v, v1, h);
+    for (int64_t p = 0; p < n_pairs; ++p, v += 4 * U) {
+        dw_load<false, U, TI, TJ, FI, FO>(a1, b1, pa, pb, v + 2 * U, v1, h);
+        __builtin_amdgcn_sched_barrier(0);
+        dw_mfma<U, TI, TJ>(acc, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        // next pair's first batch (addresses clamp at the chunk end; unused if there is no next pair)
+        dw_load<false, U, TI, TJ, FI, FO>(a0, b0, pa, pb, v + 4 * U, v1, h);
+        __builtin_amdgcn_sched_barrier(0);
+        dw_mfma<U, TI, TJ>(acc, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (; v < v1; v += 2 * U) { // tail (< 4U vertices): masked
+        dw_load<true, U, TI, TJ, FI, FO>(a0, b0, pa, pb, v, v1, h);
+        dw_mfma<U, TI, TJ>(acc, a0, b0);
     }
     float *slab = slabs + (size_t)blockIdx.x * FI * FO;
 #pragma unroll
@@ -225,13 +283,20 @@ __global__ __launch_bounds__(256, 1) void gemm_dw_kernel(const float *__restrict
             }
 }
 
-__global__ void slab_reduce_kernel(const float *__restrict__ slabs, int n_slabs, int n, float *__restrict__ out)
+// out[t] = sum_b slabs[b][t], b ascending inside each of 4 interleaved groups, groups added in
+// fixed order: deterministic.  64 outputs per workgroup, 4 slab groups per output.
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ slabs, int n_slabs, int n,
+                                                          float *__restrict__ out)
 {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
+    __shared__ float part[4][64];
+    const int o = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + o;
     float s = 0.0f;
-    for (int b = 0; b < n_slabs; ++b) s = s + slabs[(size_t)b * n + t];
-    out[t] = s;
+    if (t < n)
+        for (int b = grp; b < n_slabs; b += 4) s = s + slabs[(size_t)b * n + t];
+    part[grp][o] = s;
+    __syncthreads();
+    if (grp == 0 && t < n) out[t] = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -283,22 +348,42 @@ int num_cu()
     return g_num_cu;
 }
 
-template <int K, int N>
-int launch_bres(const float *A, const float *B, int b_nk, const float *bias, int act, float *Z, int64_t M)
+template <int K, int N, int ACT, bool BIAS>
+int launch_bres2(const float *A, const float *B, int b_nk, const float *bias, float *Z, int64_t M)
 {
-    constexpr size_t lds = sizeof(float) * (size_t)(N + 4 * 32) * (K + 4);
+    constexpr size_t lds = sizeof(float) * ((size_t)N * (K + 4) + 4 * 32 * ((K > N ? K : N) + 4));
     static bool attr_done = false;
     if (!attr_done) {
-        AMP_HIP(hipFuncSetAttribute((const void *)gemm_bres_kernel<K, N>,
+        AMP_HIP(hipFuncSetAttribute((const void *)gemm_bres_kernel<K, N, ACT, BIAS>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
     int64_t n_slabs = (M + 31) / 32;
     int grid = (int)std::min<int64_t>((n_slabs + 3) / 4, num_cu());
-    hipLaunchKernelGGL((gemm_bres_kernel<K, N>), dim3(grid), dim3(256), lds, amp::stream(), A, B, b_nk, bias,
-                       act, Z, M);
+    hipLaunchKernelGGL((gemm_bres_kernel<K, N, ACT, BIAS>), dim3(grid), dim3(256), lds, amp::stream(), A, B, b_nk,
+                       bias, Z, M);
     AMP_LAUNCH_CHECK();
     return 0;
+}
+
+template <int K, int N>
+int launch_bres(const float *A, const float *B, int b_nk, const float *bias, int act, float *Z, int64_t M)
+{
+    if (!bias && act == ATHENA_MP_ACT_NONE) return launch_bres2<K, N, ATHENA_MP_ACT_NONE, false>(A, B, b_nk, bias, Z, M);
+    static float *zero_bias = nullptr; // bias-free activations reuse the BIAS=true kernels
+    if (!bias) {
+        if (!zero_bias) {
+            AMP_HIP(hipMalloc((void **)&zero_bias, sizeof(float) * 256));
+            AMP_HIP(hipMemset(zero_bias, 0, sizeof(float) * 256));
+        }
+        bias = zero_bias;
+    }
+    switch (act) {
+    case ATHENA_MP_ACT_RELU: return launch_bres2<K, N, ATHENA_MP_ACT_RELU, true>(A, B, b_nk, bias, Z, M);
+    case ATHENA_MP_ACT_SIGMOID: return launch_bres2<K, N, ATHENA_MP_ACT_SIGMOID, true>(A, B, b_nk, bias, Z, M);
+    case ATHENA_MP_ACT_TANH: return launch_bres2<K, N, ATHENA_MP_ACT_TANH, true>(A, B, b_nk, bias, Z, M);
+    default: return launch_bres2<K, N, ATHENA_MP_ACT_NONE, true>(A, B, b_nk, bias, Z, M);
+    }
 }
 
 bool mfma_shape(int K, int N) { return (K == 32 || K == 64 || K == 128) && (N == 32 || N == 64 || N == 128); }
@@ -307,7 +392,8 @@ int gemm_dispatch(const float *A, const float *B, int b_nk, const float *bias, i
                   int K, int N)
 {
     if (M == 0) return 0;
-    if (mfma_shape(K, N) && ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0)) {
+    if (mfma_shape(K, N) && ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)Z % 16 == 0) &&
+        (!bias || (uintptr_t)bias % 16 == 0)) {
 #define AMP_CASE(KK, NN) \
     if (K == KK && N == NN) return launch_bres<KK, NN>(A, B, b_nk, bias, act, Z, M);
         AMP_CASE(32, 32) AMP_CASE(32, 64) AMP_CASE(32, 128)
@@ -369,7 +455,7 @@ int athena_mp_gemm_dw(int64_t N, int32_t Fi, int32_t Fo, const float *P, const f
         hipLaunchKernelGGL(gemm_dw_small_kernel, dim3(nblk), dim3(256), 0, stream(), P, dZ, slabs, N, Fi, Fo, rpb);
     }
     AMP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, stream(), slabs, nblk, n, dW);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, stream(), slabs, nblk, n, dW);
     AMP_LAUNCH_CHECK();
     return 0;
 }

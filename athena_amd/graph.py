@@ -118,6 +118,9 @@ class DeviceGraph:
         self.nnz = int(ja.shape[1])
         if n_edge_cols is None:
             n_edge_cols = int(ja[1].max()) if self.nnz else 0
+        elif n_edge_cols == 0 and self.nnz and ja[1].any():
+            ja = ja.copy(order="F")  # edge ids not needed (Kipf): drop them, skip the edge index
+            ja[1] = 0
         self.n_edge_cols = int(n_edge_cols)
         rd = cd = None
         if row_deg is not None:

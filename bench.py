@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py -- msgpass fwd+bwd edges/sec on BASELINE.json configs[1]:
+Kipf GCN layer, synthetic random graph 1M vertices / 10M CSR entries / 128 features, fp32.
+
+A "step" is one interior Kipf layer forward+backward over the whole graph:
+    P = A^ X ; Z = W P            (kipf_propagate, matmul)
+    dW = dZ P^T ; dP = W^T dZ     (matmul reverse)
+    dX = scatter(dP)              (get_partial_kipf_propagate_left_val -- reference: no coefficient)
+"edges" = CSR entries (nnz).  Inputs are resident in HBM before the timed region.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL): WEAK scaling -- every rank
+owns a 1M-vertex / 10M-entry row block of an N-times larger graph; halo rows of X (forward) and of
+dP (backward) move by all_to_all_single, dW by all_reduce (athena_amd/dist.py).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md "Chip-level parameters")
+
+
+def cpu_baseline(ia, ja, x, w, dz, F, sample_rows):
+    """The oracle (a line-by-line C port of the reference's loops), 1 thread, on the first
+    `sample_rows` rows of the same workload (they gather from / scatter into the full tensors)."""
+    from oracle import oracle
+
+    n = ia.size - 1
+    rows = min(sample_rows, n)
+    sia = ia[: rows + 1].copy()
+    sja = np.asfortranarray(ja[:, : sia[-1] - 1])
+    deg = np.diff(ia).astype(np.int32)
+    ent = int(sia[-1] - 1)
+    oracle.kipf_propagate_rect(x[:1000], sia[:2], sja[:, : sia[1] - 1], deg[:1], deg)  # warm the library
+    t0 = time.perf_counter()
+    p = oracle.kipf_propagate_rect(x, sia, sja, deg[:rows], deg)
+    z = oracle.matmul(w, p, F)
+    dw = oracle.matmul_dw(dz[:rows], p)
+    dp = oracle.matmul_dx(w, dz[:rows], F)
+    dx = oracle.kipf_propagate_bwd(dp, sia, sja, n_out=n)
+    t = time.perf_counter() - t0
+    del z, dw, dx
+    return {"value": ent / t, "unit": "edges/s", "cores": 1, "kind": "port",
+            "sample": f"oracle (C port of the reference loops), first {rows} of {n} rows = {ent} of {ja.shape[1]} entries, "
+                      f"full fwd+bwd step, {t:.1f} s on {os.cpu_count()}-core host, 1 thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--nodes", type=int, default=1_000_000, help="vertices per GPU")
+    ap.add_argument("--pairs", type=int, default=4_500_000, help="undirected pairs per GPU (nnz = 2*pairs + nodes)")
+    ap.add_argument("--feat", type=int, default=128)
+    ap.add_argument("--cut", type=float, default=None, help="N>1: fraction of pairs crossing partitions (default: uniform random = (N-1)/N)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rows", type=int, default=500_000)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py measures the HIP path; no GPU visible"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from athena_amd import DeviceGraph, _capi, ops, synth
+
+    _capi.init(local_rank)
+    F = args.feat
+
+    if world > 1:
+        import torch.distributed as dist
+
+        from athena_amd import dist as adist
+
+        dist.init_process_group("nccl", device_id=dev)
+        shard = adist.make_weak_scaling_shard(rank, world, args.nodes, args.pairs, F, cut=args.cut, device=dev)
+        step, nnz_local, info = adist.build_kipf_step(shard, F, dev)
+        nnz_total = nnz_local * world
+    else:
+        ia, ja = synth.random_graph_csr(args.nodes, args.pairs)
+        x, w, dz = synth.kipf_inputs(args.nodes, F)
+        g = DeviceGraph(ia, ja, n_edge_cols=0, device=local_rank)
+        nnz_local = nnz_total = int(ja.shape[1])
+        xd, wd, dzd = (torch.from_numpy(t).to(dev) for t in (x, w, dz))
+        N = args.nodes
+        P = torch.empty((N, F), device=dev)
+        Z = torch.empty((N, F), device=dev)
+        dW = torch.empty(F * F, device=dev)
+        dP = torch.empty((N, F), device=dev)
+        dX = torch.empty((N, F), device=dev)
+        ev = []
+
+        def step(record=False):
+            if record:
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+            ops.kipf_propagate(g, xd, out=P)
+            if record:
+                e1.record(); ev.append((e0, e1))
+            ops.matmul(wd, P, F, out=Z)
+            ops.matmul_dw(P, dzd, out=dW)
+            ops.matmul_dx(wd, dzd, F, out=dP)
+            ops.kipf_propagate_bwd(g, dP, out=dX)
+        info = {}
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(record=True) if world == 1 else step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+
+    ms_per_step = dt / args.steps * 1e3
+    value = nnz_total * args.steps / dt
+    out = {
+        "metric": "msgpass fwd+bwd edges/sec", "value": value, "unit": "edges/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: Kipf GCN layer fwd+bwd, random graph "
+                               f"{args.nodes} vertices / {nnz_local} CSR entries per GPU, {F} features, fp32",
+                   "vertices_per_gpu": args.nodes, "entries_per_gpu": nnz_local, "features": F,
+                   "parallelism": f"row-partition x{world}" if world > 1 else "single GPU", **info},
+    }
+    if world == 1:
+        # dominant kernel: the CSR gather-aggregate of kipf_propagate (HBM bound)
+        agg_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        alg_bytes = nnz_local * (4 * F + 8) + args.nodes * (4 * F + 8)   # 572 B/entry at F=128
+        achieved = alg_bytes / (agg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("csr_gather_agg_fwd_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out["roofline"] = {"bound": "hbm", "kernel": "csr_gather_agg<32,4,coef> (kipf_propagate fwd)",
+                           "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                           "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": agg_ms}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ia, ja, x, w, dz, F, args.cpu_sample_rows)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

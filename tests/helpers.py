@@ -1,0 +1,65 @@
+"""Shared test utilities: seeded graphs in athena's CSR convention and an INDEPENDENT float64
+dense-matrix formulation of each op (from the layer documentation, not from the oracle's loops)."""
+import json
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden(name):
+    with open(os.path.join(GOLDEN, name)) as fh:
+        return json.load(fh)
+
+
+def csr_from_index_list(n, index_list, self_loops=False):
+    from athena_amd.graph import graph_type
+
+    g = graph_type()
+    g.set_num_vertices(n, 0)
+    g.generate_adjacency(np.asarray(index_list))
+    if self_loops:
+        g.add_self_loops()
+    return g
+
+
+def random_graph(n, n_pairs, seed, self_loops=True, isolated=0):
+    """random multigraph; `isolated` trailing vertices get no entries at all (zero-degree rows)."""
+    from athena_amd import synth
+
+    m = n - isolated
+    ia, ja = synth.random_graph_csr(m, n_pairs, seed=seed, self_loops=self_loops)
+    if isolated:
+        ia = np.concatenate([ia, np.full(isolated, ia[-1], np.int32)])
+    return ia, ja
+
+
+def dense_adjacency(ia, ja, n_cols=None):
+    """A[v,u] = multiplicity of u in row v (float64)"""
+    n = ia.size - 1
+    A = np.zeros((n, n_cols or n), np.float64)
+    for v in range(n):
+        for w in range(ia[v] - 1, ia[v + 1] - 1):
+            A[v, ja[0, w] - 1] += 1.0
+    return A
+
+
+def kipf_dense(ia, ja, x):
+    """D^-1/2 A D^-1/2 X with D = CSR row length (docs/source/layers/msgpass/kipf_msgpass_layer.rst)"""
+    A = dense_adjacency(ia, ja)
+    deg = np.diff(ia).astype(np.float64)
+    with np.errstate(divide="ignore"):
+        dinv = np.where(deg > 0, deg ** -0.5, 0.0)
+    return (dinv[:, None] * A * dinv[None, :]) @ x.astype(np.float64)
+
+
+def rel_err(a, b):
+    b = np.asarray(b, np.float64)
+    return float(np.abs(np.asarray(a, np.float64) - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def assert_close(a, b, rtol=1e-5, what=""):
+    """north-star tolerance: 1e-5 relative fp32 (relative to the tensor's scale)."""
+    e = rel_err(a, b)
+    assert e <= rtol, f"{what}: rel err {e:.3e} > {rtol}"

@@ -1,0 +1,194 @@
+"""CPU: pin the oracle (oracle/athena_oracle.c) before anything trusts it.
+
+1. the reference's own known-answer test (test/test_diffstruc_extd_kipf.f90)
+2. the values the survey recorded from the reference
+3. an independent float64 dense formulation + adjoint identities / finite differences
+"""
+import numpy as np
+import pytest
+
+from helpers import assert_close, csr_from_index_list, dense_adjacency, golden, kipf_dense, random_graph, rel_err
+
+
+def test_reference_kat_identity_graph(oracle):
+    k = golden("reference_kat_kipf_identity.json")
+    ia, ja = np.array(k["adj_ia"], np.int32), np.array(k["adj_ja"], np.int32)
+    x = np.array(k["x"], np.float32)
+    y = oracle.kipf_propagate(x, ia, ja)
+    assert np.abs(y - np.array(k["forward"])).max() <= k["tol_abs"]          # :33-37
+    g = oracle.kipf_propagate_bwd(np.ones_like(x), ia, ja)
+    assert np.abs(g - np.array(k["grad_of_sum"])).max() <= k["tol_abs"]      # :39-45
+    up = np.array(k["upstream"], np.float32)
+    assert np.abs(oracle.kipf_propagate_bwd(up, ia, ja) - np.array(k["reverse_partial"])).max() <= k["tol_abs"]
+    up2 = np.array(k["second_upstream"], np.float32)
+    # partial of reverse_kipf_propagate is kipf_propagate itself (..._sub_kipf.f90:174-176)
+    assert np.abs(oracle.kipf_propagate(up2, ia, ja) - np.array(k["forward_partial"])).max() <= k["tol_abs"]
+
+
+def test_survey_recorded_reference_outputs(oracle):
+    s = golden("survey_recorded_path_graph.json")
+    ia, ja = np.array(s["graph"]["adj_ia"], np.int32), np.array(s["graph"]["adj_ja"], np.int32)
+    x = np.array(s["x"], np.float32)
+    tol = s["tol_rel"]
+    assert rel_err(oracle.kipf_propagate(x, ia, ja), s["kipf_fwd"]) <= tol
+    # backward WITHOUT the coefficient
+    assert rel_err(oracle.kipf_propagate_bwd(np.array(s["kipf_bwd_upstream"], np.float32), ia, ja), s["kipf_bwd"]) <= tol
+    e = np.array(s["edge_features"], np.float32)
+    a = oracle.duvenaud_propagate(x, e, ia, ja)
+    assert rel_err(a, s["duvenaud_propagate"]) <= tol
+    du = s["duvenaud_update"]
+    c = oracle.duvenaud_update(a, np.array(du["weight"], np.float32), ia, du["min_degree"], du["max_degree"], du["num_outputs"])
+    assert rel_err(c, du["out"]) <= tol
+
+
+@pytest.mark.parametrize("name,self_loops", [("kipf_layer_6v8e", False), ("kipf_layer_6v8e", True),
+                                             ("network_5v6e", True), ("onnx_gnn_4v5e", False)])
+def test_kipf_vs_dense_float64_on_reference_topologies(oracle, name, self_loops):
+    t = golden("reference_test_topologies.json")[name]
+    g = csr_from_index_list(t["num_vertices"], t["index_list"], self_loops)
+    rng = np.random.default_rng(7)
+    x = rng.uniform(-1, 1, (t["num_vertices"], 5)).astype(np.float32)
+    assert_close(oracle.kipf_propagate(x, g.adj_ia, g.adj_ja), kipf_dense(g.adj_ia, g.adj_ja, x), 2e-6, name)
+    # reference backward = A^T g (no coefficient)
+    A = dense_adjacency(g.adj_ia, g.adj_ja)
+    assert_close(oracle.kipf_propagate_bwd(x, g.adj_ia, g.adj_ja), A.T @ x.astype(np.float64), 2e-6, name)
+
+
+def test_kipf_random_and_degenerate(oracle):
+    ia, ja = random_graph(300, 900, seed=3, self_loops=True, isolated=5)
+    x = np.random.default_rng(1).uniform(-1, 1, (300, 7)).astype(np.float32)
+    y = oracle.kipf_propagate(x, ia, ja)
+    assert_close(y, kipf_dense(ia, ja, x), 2e-6, "random")
+    assert np.all(y[-5:] == 0.0)  # zero-degree rows give exactly 0 (..._sub_kipf.f90:31)
+    # exact-gradient flag is the true adjoint of the forward: <A x, g> == <x, A^T g>
+    g = np.random.default_rng(2).uniform(-1, 1, y.shape).astype(np.float32)
+    lhs = float((y.astype(np.float64) * g).sum())
+    rhs = float((x.astype(np.float64) * oracle.kipf_propagate_bwd(g, ia, ja, exact=True)).sum())
+    assert abs(lhs - rhs) <= 1e-5 * abs(lhs)
+    # empty graph
+    e_ia = np.ones(1, np.int32)
+    assert oracle.kipf_propagate(np.zeros((0, 4), np.float32), e_ia, np.zeros((2, 0), np.int32)).shape == (0, 4)
+
+
+def test_matmul_family_vs_float64(oracle):
+    rng = np.random.default_rng(5)
+    N, Fi, Fo = 257, 13, 9
+    P = rng.uniform(-1, 1, (N, Fi)).astype(np.float32)
+    W = rng.standard_normal(Fo * Fi).astype(np.float32)
+    dZ = rng.uniform(-1, 1, (N, Fo)).astype(np.float32)
+    Wt = W.reshape(Fi, Fo).astype(np.float64)  # Wt[i,o] = W(o,i)
+    assert_close(oracle.matmul(W, P, Fo), P @ Wt, 1e-6)
+    assert_close(oracle.matmul_dx(W, dZ, Fi), dZ @ Wt.T, 1e-6)
+    assert_close(oracle.matmul_dw(dZ, P).reshape(Fi, Fo), P.astype(np.float64).T @ dZ, 1e-6)
+
+
+def test_duvenaud_ops_vs_float64_and_adjoints(oracle):
+    t = golden("reference_test_topologies.json")["network_5v6e"]
+    g = csr_from_index_list(5, t["index_list"], self_loops=True)   # self-loop entries carry edge id 0
+    ia, ja = g.adj_ia, g.adj_ja
+    x = np.array(t["vertex_features_rows"], np.float32).T.copy()   # [5, 8]
+    e = np.array(t["edge_features_rows"], np.float32).T.copy()     # [6, 2]
+    a = oracle.duvenaud_propagate(x, e, ia, ja)
+    A = dense_adjacency(ia, ja)
+    assert_close(a[:, :8], A @ x.astype(np.float64), 1e-6)
+    # incidence for edge features: B[v,e] = multiplicity of edge e in row v (id 0 -> none)
+    B = np.zeros((5, 6))
+    for v in range(5):
+        for w in range(ia[v] - 1, ia[v + 1] - 1):
+            if ja[1, w] > 0:
+                B[v, ja[1, w] - 1] += 1
+    assert_close(a[:, 8:], B @ e.astype(np.float64), 1e-6)
+    up = np.random.default_rng(0).uniform(-1, 1, a.shape).astype(np.float32)
+    assert_close(oracle.duvenaud_propagate_bwd_x(up, 8, ia, ja), A.T @ up[:, :8].astype(np.float64), 1e-6)
+    assert_close(oracle.duvenaud_propagate_bwd_e(up, 8, 6, ia, ja), B.T @ up[:, 8:].astype(np.float64), 1e-6)
+    # update: bucket index is selector AND divisor
+    Fi, Fo, mn, mx = 10, 4, 2, 3
+    w = np.random.default_rng(1).standard_normal(Fo * Fi * (mx - mn + 1)).astype(np.float32)
+    c = oracle.duvenaud_update(a, w, ia, mn, mx, Fo)
+    deg = np.diff(ia)
+    ref = np.zeros((5, Fo))
+    for v in range(5):
+        d = max(mn, min(deg[v], mx)) - mn + 1
+        Wd = w[(d - 1) * Fo * Fi: d * Fo * Fi].reshape(Fi, Fo).T.astype(np.float64)  # W(o,i)
+        ref[v] = Wd @ (a[v].astype(np.float64) / d)
+    assert_close(c, ref, 1e-6)
+    gup = np.random.default_rng(2).uniform(-1, 1, c.shape).astype(np.float32)
+    da = oracle.duvenaud_update_bwd_a(gup, w, ia, mn, mx, Fi)
+    dw = oracle.duvenaud_update_bwd_w(gup, a, ia, mn, mx)
+    # adjoint identities of the bilinear map c = U(a, w)
+    assert abs((c.astype(np.float64) * gup).sum() - (a.astype(np.float64) * da).sum()) <= 1e-5 * abs((c * gup).sum())
+    assert abs((c.astype(np.float64) * gup).sum() - (w.astype(np.float64) * dw).sum()) <= 1e-5 * abs((c * gup).sum())
+
+
+def test_softmax_segment_sum(oracle):
+    rng = np.random.default_rng(3)
+    z = rng.standard_normal((11, 10)).astype(np.float32)
+    p = oracle.softmax_cols(z)
+    z64 = z.astype(np.float64)
+    ref = np.exp(z64 - z64.max(1, keepdims=True)); ref /= ref.sum(1, keepdims=True)
+    assert_close(p, ref, 1e-6)
+    assert np.all(p > 0) and np.all(p < 1) and np.allclose(p.sum(1), 1, atol=1e-6)
+    seg = np.array([0, 4, 4, 11], np.int32)  # middle graph is empty
+    out = oracle.segment_sum(p, seg)
+    assert_close(out, np.stack([ref[0:4].sum(0), np.zeros(10), ref[4:].sum(0)]), 1e-6)
+    g = rng.standard_normal(p.shape).astype(np.float32)
+    dz = oracle.softmax_cols_bwd(p, g)
+    eps = 1e-3
+    zp = z.copy(); zp[2, 3] += eps
+    zm = z.copy(); zm[2, 3] -= eps
+    fd = ((oracle.softmax_cols(zp).astype(np.float64) * g).sum() - (oracle.softmax_cols(zm).astype(np.float64) * g).sum()) / (2 * eps)
+    assert abs(fd - dz[2, 3]) < 2e-3 * max(1.0, abs(fd))
+
+
+def _gno_problem(seed=0, N=9, d=3, H=5, Fi=4, Fo=3):
+    rng = np.random.default_rng(seed)
+    pairs = np.array([[i, i + 1] for i in range(1, N)] + [[1, N], [2, 5]]).T   # chain + 2 chords
+    g = csr_from_index_list(N, pairs)
+    E = pairs.shape[1]
+    coords = rng.standard_normal((E, d)).astype(np.float32)
+    x = rng.uniform(-1, 1, (N, Fi)).astype(np.float32)
+    theta = (0.5 * rng.standard_normal(H * d + H + Fo * Fi * H + Fo * Fi)).astype(np.float32)
+    return g, coords, x, theta, (d, H, Fi, Fo, E, N)
+
+
+def test_gno_ops_vs_float64_and_finite_differences(oracle):
+    g, coords, x, theta, (d, H, Fi, Fo, E, N) = _gno_problem()
+    ia, ja = g.adj_ia, g.adj_ja
+    F = Fo * Fi
+    kap = oracle.gno_kernel_eval(coords, theta, H, F)
+    U = theta[:H * d].reshape(d, H).T.astype(np.float64)
+    bu = theta[H * d:H * d + H].astype(np.float64)
+    V = theta[H * d + H:H * d + H + F * H].reshape(H, F).T.astype(np.float64)
+    bv = theta[H * d + H + F * H:].astype(np.float64)
+    hid = np.maximum(coords.astype(np.float64) @ U.T + bu, 0)
+    kref = hid @ V.T + bv
+    assert_close(kap, kref, 2e-6)
+    m = oracle.gno_aggregate(x, kap, ia, ja, Fo)
+    mref = np.zeros((N, Fo))
+    for i in range(N):
+        for w in range(ia[i] - 1, ia[i + 1] - 1):
+            K = kref[ja[1, w] - 1].reshape(Fi, Fo).T
+            mref[i] += K @ x[ja[0, w] - 1].astype(np.float64)
+    assert_close(m, mref, 2e-6)
+    up = np.random.default_rng(9).uniform(-1, 1, m.shape).astype(np.float32)
+    dx = oracle.gno_aggregate_bwd_x(up, kap, ia, ja, Fi)
+    dk = oracle.gno_aggregate_bwd_k(up, x, E, ia, ja)
+    dth = oracle.gno_kernel_bwd_theta(coords, theta, dk, H)
+    dco = oracle.gno_kernel_bwd_coords(coords, theta, dk, H)
+
+    def loss(th, co, xx):
+        k = oracle.gno_kernel_eval(co, th, H, F)
+        return float((oracle.gno_aggregate(xx, k, ia, ja, Fo).astype(np.float64) * up).sum())
+
+    rng = np.random.default_rng(4)
+    eps = 1e-2
+    for arr, grad in ((theta, dth), (coords, dco), (x, dx)):
+        for _ in range(6):
+            idx = tuple(rng.integers(0, s) for s in arr.shape)
+            ap, am = arr.copy(), arr.copy()
+            ap[idx] += eps; am[idx] -= eps
+            args_p = [theta, coords, x]; args_m = [theta, coords, x]
+            pos = 0 if arr is theta else (1 if arr is coords else 2)
+            args_p[pos], args_m[pos] = ap, am
+            fd = (loss(*args_p) - loss(*args_m)) / (2 * eps)
+            assert abs(fd - grad[idx]) <= 2e-2 * max(1.0, abs(fd)), (pos, idx, fd, grad[idx])
