@@ -196,14 +196,18 @@ extern "C" {
 
 int athena_mp_kipf_propagate_fwd(const athena_mp_graph *g, int32_t F, const float *x, float *y)
 {
-    AMP_REQUIRE(g && x && y && F > 0, "kipf_propagate_fwd: bad arguments");
+    AMP_REQUIRE(g && F > 0, "kipf_propagate_fwd: bad arguments");
+    if (g->n_rows == 0) return 0; // empty graph: nothing to do (pointers may be null)
+    AMP_REQUIRE(x && y, "kipf_propagate_fwd: null tensor");
     return gather_agg(g->rowptr, g->col, g->coef, x, F, y, F, g->n_rows, F);
 }
 
 int athena_mp_kipf_propagate_bwd(const athena_mp_graph *g, int32_t F, const float *grad, float *dx,
                                  int32_t exact)
 {
-    AMP_REQUIRE(g && grad && dx && F > 0, "kipf_propagate_bwd: bad arguments");
+    AMP_REQUIRE(g && F > 0, "kipf_propagate_bwd: bad arguments");
+    if (g->n_cols == 0) return 0;
+    AMP_REQUIRE(dx && (grad || g->nnz == 0), "kipf_propagate_bwd: null tensor");
     return gather_agg(g->t_rowptr, g->t_src, exact ? g->t_coef : nullptr, grad, F, dx, F, g->n_cols, F);
 }
 

@@ -16,8 +16,8 @@ namespace amp {
 
 static thread_local char g_err[1024] = "";
 static hipStream_t g_stream = nullptr;
-static void *g_ws[4] = {nullptr, nullptr, nullptr, nullptr};
-static size_t g_ws_bytes[4] = {0, 0, 0, 0};
+static void *g_ws[8] = {};
+static size_t g_ws_bytes[8] = {};
 
 void set_error(const char *fmt, ...)
 {
@@ -71,7 +71,7 @@ int athena_mp_init(int device)
 
 int athena_mp_finalize(void)
 {
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < 8; ++s) {
         if (g_ws[s]) {
             AMP_HIP(hipFree(g_ws[s]));
             g_ws[s] = nullptr;
@@ -124,24 +124,28 @@ int athena_mp_memset_zero(void *d, uint64_t bytes)
 
 // ---------------------------------------------------------------------------------------------
 // Kipf coefficient per CSR entry.  Reference: coeff = (deg_v * deg_u) ** (-0.5_real32)
-// (athena_diffstruc_extd_sub_kipf.f90:39-42): integer product, converted to real32, then powf.
-// Here the correctly rounded value is produced through fp64 (1/sqrt is IEEE-exact in fp64, and
-// fp64 -> fp32 of a value with 53 significant bits of an irrational-or-exact root rounds to the
-// same fp32 as a correctly rounded powf), so the coefficient equals host libm's powf bit for bit.
+// (athena_diffstruc_extd_sub_kipf.f90:39-42): integer product, converted to real32, then libm's
+// powf.  It is evaluated here ON THE HOST with the same powf, once per graph, so every coefficient
+// is bit-identical to what the reference computes on this machine (a device pow, or 1/sqrt through
+// fp64, differs from glibc's powf by 1 ulp for a few products).  The coefficient depends only on the
+// integer product, so a small direct-mapped memo makes the pass memory-bound.
 // ---------------------------------------------------------------------------------------------
-__global__ void kipf_coef_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ other,
-                                 const int32_t *__restrict__ deg_self,
-                                 const int32_t *__restrict__ deg_other, float *__restrict__ coef,
-                                 int32_t n)
-{
-    int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n) return;
-    int dv = deg_self[v];
-    for (int w = rowptr[v]; w < rowptr[v + 1]; ++w) {
-        float prod = (float)(dv * deg_other[other[w]]);
-        coef[w] = (float)(1.0 / sqrt((double)prod));
+#include <math.h>
+struct CoefMemo {
+    static constexpr int kSize = 1 << 16;
+    std::vector<int32_t> key;
+    std::vector<float> val;
+    CoefMemo() : key(kSize, -1), val(kSize, 0.0f) {}
+    inline float get(int32_t prod)
+    {
+        const uint32_t slot = ((uint32_t)prod * 2654435761u) >> 16;
+        if (key[slot] != prod) {
+            key[slot] = prod;
+            val[slot] = powf((float)prod, -0.5f);
+        }
+        return val[slot];
     }
-}
+};
 
 template <typename T> static int upload(T **dst, const std::vector<T> &src)
 {
@@ -242,7 +246,7 @@ int athena_mp_graph_create(int32_t n_rows, int32_t n_cols, int64_t nnz, const in
                 if (eid[w] >= 0) {
                     int32_t q = epos[eid[w]]++;
                     e_row[q] = v;
-                    e_col[q] = col[w];
+                    e_col[q] = w; // entry index
                 }
             }
     }
@@ -267,19 +271,21 @@ int athena_mp_graph_create(int32_t n_rows, int32_t n_cols, int64_t nnz, const in
     rc |= upload(&g->e_col, e_col);
     rc |= upload(&g->deg_row, degr);
     rc |= upload(&g->deg_col, degc);
-    if (rc == 0 && hipMalloc((void **)&g->coef, sizeof(float) * (nnz ? nnz : 1)) != hipSuccess) rc = 1;
-    if (rc == 0 && hipMalloc((void **)&g->t_coef, sizeof(float) * (nnz ? nnz : 1)) != hipSuccess) rc = 1;
+    std::vector<float> coef(nnz), t_coef(nnz);
+    {
+        CoefMemo memo;
+        for (int32_t v = 0; v < n_rows; ++v)
+            for (int32_t w = rowptr[v]; w < rowptr[v + 1]; ++w) coef[w] = memo.get(degr[v] * degc[col[w]]);
+        for (int32_t u = 0; u < n_cols; ++u)
+            for (int32_t w = t_rowptr[u]; w < t_rowptr[u + 1]; ++w) t_coef[w] = memo.get(degr[t_src[w]] * degc[u]);
+    }
+    rc |= upload(&g->coef, coef);
+    rc |= upload(&g->t_coef, t_coef);
     if (rc != 0) {
         if (g_err[0] == 0) set_error("graph_create: device allocation failed");
         athena_mp_graph_destroy(g);
         return 1;
     }
-    if (n_rows > 0)
-        hipLaunchKernelGGL(kipf_coef_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, stream(), g->rowptr,
-                           g->col, g->deg_row, g->deg_col, g->coef, n_rows);
-    if (n_cols > 0)
-        hipLaunchKernelGGL(kipf_coef_kernel, dim3((n_cols + 255) / 256), dim3(256), 0, stream(),
-                           g->t_rowptr, g->t_src, g->deg_col, g->deg_row, g->t_coef, n_cols);
     hipError_t e = hipStreamSynchronize(stream()); // host vectors die at scope exit
     if (e != hipSuccess) {
         set_error("graph_create: %s", hipGetErrorString(e));

@@ -56,8 +56,19 @@ struct athena_mp_graph {
     // edge-column index: column e lists the entries that carry it, in w order
     int32_t *e_rowptr = nullptr; // [n_edge_cols+1]
     int32_t *e_row = nullptr;    // [n_with_edge] row v of the entry
-    int32_t *e_col = nullptr;    // [n_with_edge] neighbour u of the entry
+    int32_t *e_col = nullptr;    // [n_with_edge] CSR entry index w of the entry
     int32_t *deg_row = nullptr;  // [n_rows]
     int32_t *deg_col = nullptr;  // [n_cols]
     int64_t n_with_edge = 0;
 };
+
+namespace amp {
+// shared launchers (defined in agg.hip / gemm.hip)
+int gather_agg(const int32_t *rowptr, const int32_t *idx, const float *coef, const float *x, int64_t ldx,
+               float *y, int64_t ldy, int32_t n_rows, int32_t F);
+// Z[M,N] = act(A[M,K] . B + bias); b_nk: B stored [N][K] instead of [K][N]
+int gemm_dispatch(const float *A, const float *B, int b_nk, const float *bias, int act, float *Z, int64_t M,
+                  int K, int N);
+// dWt[Fi,Fo] (+)= sum_v P[v,:]^T dZ[v,:]
+int gemm_dw_dispatch(int64_t N, int Fi, int Fo, const float *P, const float *dZ, float *dW, bool accumulate);
+} // namespace amp

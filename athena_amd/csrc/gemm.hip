@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256, 1) void gemm_dw_kernel(const float *__restrict
 // out[t] = sum_b slabs[b][t], b ascending inside each of 4 interleaved groups, groups added in
 // fixed order: deterministic.  64 outputs per workgroup, 4 slab groups per output.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ slabs, int n_slabs, int n,
-                                                          float *__restrict__ out)
+                                                          float *__restrict__ out, int accumulate)
 {
     __shared__ float part[4][64];
     const int o = threadIdx.x & 63, grp = threadIdx.x >> 6;
@@ -296,7 +296,10 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restric
         for (int b = grp; b < n_slabs; b += 4) s = s + slabs[(size_t)b * n + t];
     part[grp][o] = s;
     __syncthreads();
-    if (grp == 0 && t < n) out[t] = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
+    if (grp == 0 && t < n) {
+        float r = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
+        out[t] = accumulate ? out[t] + r : r;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -388,6 +391,9 @@ int launch_bres(const float *A, const float *B, int b_nk, const float *bias, int
 
 bool mfma_shape(int K, int N) { return (K == 32 || K == 64 || K == 128) && (N == 32 || N == 64 || N == 128); }
 
+} // namespace
+
+namespace amp {
 int gemm_dispatch(const float *A, const float *B, int b_nk, const float *bias, int act, float *Z, int64_t M,
                   int K, int N)
 {
@@ -407,8 +413,40 @@ int gemm_dispatch(const float *A, const float *B, int b_nk, const float *bias, i
     AMP_LAUNCH_CHECK();
     return 0;
 }
+} // namespace amp
 
-} // namespace
+namespace amp {
+int gemm_dw_dispatch(int64_t N, int Fi, int Fo, const float *P, const float *dZ, float *dW, bool accumulate)
+{
+    const int n = Fi * Fo;
+    if (N == 0) {
+        if (!accumulate) AMP_HIP(hipMemsetAsync(dW, 0, sizeof(float) * n, stream()));
+        return 0;
+    }
+    int nblk = (int)std::min<int64_t>((N + 255) / 256, 2 * num_cu());
+    int64_t rpb = (N + nblk - 1) / nblk;
+    rpb = (rpb + 1) & ~(int64_t)1; // even: the MFMA form consumes vertex pairs
+    nblk = (int)((N + rpb - 1) / rpb);
+    void *ws = nullptr;
+    if (workspace(&ws, sizeof(float) * (size_t)nblk * n, 2)) return 1;
+    float *slabs = (float *)ws;
+    bool mf = (Fi == 64 || Fi == 128) && (Fo == 64 || Fo == 128) && ((uintptr_t)P % 8 == 0) &&
+              ((uintptr_t)dZ % 8 == 0);
+    if (mf) {
+#define AMP_CASE(A_, B_)                                                                                   \
+    if (Fi == A_ && Fo == B_)                                                                              \
+        hipLaunchKernelGGL((gemm_dw_kernel<A_, B_>), dim3(nblk), dim3(256), 0, stream(), P, dZ, slabs, N, rpb);
+        AMP_CASE(64, 64) AMP_CASE(64, 128) AMP_CASE(128, 64) AMP_CASE(128, 128)
+#undef AMP_CASE
+    } else {
+        hipLaunchKernelGGL(gemm_dw_small_kernel, dim3(nblk), dim3(256), 0, stream(), P, dZ, slabs, N, Fi, Fo, rpb);
+    }
+    AMP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, stream(), slabs, nblk, n, dW, accumulate ? 1 : 0);
+    AMP_LAUNCH_CHECK();
+    return 0;
+}
+} // namespace amp
 
 using namespace amp;
 
@@ -431,33 +469,7 @@ int athena_mp_gemm_dx(int64_t N, int32_t Fi, int32_t Fo, const float *dZ, const 
 int athena_mp_gemm_dw(int64_t N, int32_t Fi, int32_t Fo, const float *P, const float *dZ, float *dW)
 {
     AMP_REQUIRE(N >= 0 && Fi > 0 && Fo > 0 && P && dZ && dW, "gemm_dw: bad arguments");
-    const int n = Fi * Fo;
-    if (N == 0) {
-        AMP_HIP(hipMemsetAsync(dW, 0, sizeof(float) * n, stream()));
-        return 0;
-    }
-    int nblk = (int)std::min<int64_t>((N + 255) / 256, 2 * num_cu());
-    int64_t rpb = (N + nblk - 1) / nblk;
-    rpb = (rpb + 1) & ~(int64_t)1; // even: the MFMA form consumes vertex pairs
-    nblk = (int)((N + rpb - 1) / rpb);
-    void *ws = nullptr;
-    if (workspace(&ws, sizeof(float) * (size_t)nblk * n, 2)) return 1;
-    float *slabs = (float *)ws;
-    bool mf = (Fi == 64 || Fi == 128) && (Fo == 64 || Fo == 128) && ((uintptr_t)P % 8 == 0) &&
-              ((uintptr_t)dZ % 8 == 0);
-    if (mf) {
-#define AMP_CASE(A_, B_)                                                                                   \
-    if (Fi == A_ && Fo == B_)                                                                              \
-        hipLaunchKernelGGL((gemm_dw_kernel<A_, B_>), dim3(nblk), dim3(256), 0, stream(), P, dZ, slabs, N, rpb);
-        AMP_CASE(64, 64) AMP_CASE(64, 128) AMP_CASE(128, 64) AMP_CASE(128, 128)
-#undef AMP_CASE
-    } else {
-        hipLaunchKernelGGL(gemm_dw_small_kernel, dim3(nblk), dim3(256), 0, stream(), P, dZ, slabs, N, Fi, Fo, rpb);
-    }
-    AMP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, stream(), slabs, nblk, n, dW);
-    AMP_LAUNCH_CHECK();
-    return 0;
+    return gemm_dw_dispatch(N, Fi, Fo, P, dZ, dW, false);
 }
 
 int athena_mp_gemm_fwd_host(int64_t N, int32_t Fi, int32_t Fo, const float *Ph, const float *Wh,

@@ -239,3 +239,46 @@ def test_errors_surface_as_exceptions_not_aborts(dev):
         DeviceGraph(np.array([0, 1], np.int32), np.array([[1], [0]], np.int32))
     with pytest.raises(_capi.AthenaMPError, match="outside"):
         DeviceGraph(np.array([1, 2], np.int32), np.array([[5], [0]], np.int32))
+
+
+def _gno_case(seed, N, d, H, Fi, Fo, extra_pairs=0, self_loops=False):
+    rng = np.random.default_rng(seed)
+    pairs = [[i, i + 1] for i in range(1, N)] + [[1, N]]
+    for _ in range(extra_pairs):
+        a, b = rng.integers(1, N + 1, 2)
+        if a != b:
+            pairs.append([int(a), int(b)])
+    pairs = np.array(pairs).T
+    g = csr_from_index_list(N, pairs, self_loops=self_loops)   # self loops carry edge id 0 => zero kernel
+    E = pairs.shape[1]
+    coords = rng.standard_normal((E, d)).astype(np.float32)
+    x = rng.uniform(-1, 1, (N, Fi)).astype(np.float32)
+    theta = (0.5 * rng.standard_normal(H * d + H + Fo * Fi * H + Fo * Fi)).astype(np.float32)
+    up = rng.uniform(-1, 1, (N, Fo)).astype(np.float32)
+    return g, E, coords, x, theta, up
+
+
+@pytest.mark.parametrize("N,d,H,Fi,Fo,extra", [(9, 3, 5, 4, 3, 2), (20, 1, 8, 3, 3, 0), (300, 3, 16, 8, 8, 600),
+                                               (400, 2, 32, 32, 32, 1500), (64, 3, 64, 64, 64, 300), (50, 3, 7, 5, 9, 60)])
+def test_gno_reassociated_vs_materialising_oracle(dev, oracle, N, d, H, Fi, Fo, extra):
+    """the HIP path never forms kappa [F_out*F_in, E]; the oracle does (athena_diffstruc_extd_sub_nop.f90)"""
+    from athena_amd import DeviceGraph, ops
+
+    g, E, coords, x, theta, up = _gno_case(N + H, N, d, H, Fi, Fo, extra)
+    ia, ja = g.adj_ia, g.adj_ja
+    dg = DeviceGraph(ia, ja, n_edge_cols=E)
+    F = Fo * Fi
+    kap = oracle.gno_kernel_eval(coords, theta, H, F)
+    m_ref = oracle.gno_aggregate(x, kap, ia, ja, Fo)
+    th, co, xd, gd = T(theta, dev), T(coords, dev), T(x, dev), T(up, dev)
+    m = H_(ops.gno_aggregate(dg, th, co, xd, d, H, Fo))
+    assert_close(m, m_ref, 1e-5, "gno fwd")
+    dx_ref = oracle.gno_aggregate_bwd_x(up, kap, ia, ja, Fi)
+    assert_close(H_(ops.gno_aggregate_bwd_x(dg, th, co, gd, d, H, Fi)), dx_ref, 1e-5, "gno dx")
+    dk = oracle.gno_aggregate_bwd_k(up, x, E, ia, ja)
+    assert_close(H_(ops.gno_aggregate_bwd_theta(dg, th, co, xd, gd, d, H)), oracle.gno_kernel_bwd_theta(coords, theta, dk, H), 2e-5, "gno dtheta")
+    assert_close(H_(ops.gno_aggregate_bwd_coords(dg, th, co, xd, gd, d, H)), oracle.gno_kernel_bwd_coords(coords, theta, dk, H), 2e-5, "gno dcoords")
+
+
+def H_(t):
+    return t.cpu().numpy()
