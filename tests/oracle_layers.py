@@ -1,0 +1,108 @@
+"""Oracle-side restatement of the three layers' update_message / update_readout and of the tape walk
+diffstruc's grad_reverse performs over them -- per sample, looping on the host exactly like the
+reference (athena_kipf_msgpass_layer.f90:940-957, athena_duvenaud_msgpass_layer.f90:792-855,
+athena_graph_nop_layer.f90:740-786).  Test infrastructure only."""
+import numpy as np
+
+from oracle import oracle as o
+
+
+def kipf_forward(graphs, xs, params, nvf, act):
+    outs, tapes = [], []
+    for g, x in zip(graphs, xs):
+        cur, tape = x, []
+        for t in range(1, len(nvf)):
+            p = o.kipf_propagate(cur, g.adj_ia, g.adj_ja)
+            z = o.matmul(params[t - 1], p, nvf[t])
+            y = o.activation(act, z)
+            tape.append((p, y))
+            cur = y
+        outs.append(cur); tapes.append(tape)
+    return outs, tapes
+
+
+def kipf_backward(graphs, tapes, params, nvf, act, ups, exact=False):
+    grads = [np.zeros_like(p) for p in params]
+    dxs = []
+    for g, tape, up in zip(graphs, tapes, ups):
+        gc = up
+        for t in range(len(nvf) - 1, 0, -1):
+            p, y = tape[t - 1]
+            dz = o.activation_bwd(act, y, gc)
+            grads[t - 1] += o.matmul_dw(dz, p)
+            dp = o.matmul_dx(params[t - 1], dz, nvf[t - 1])
+            gc = o.kipf_propagate_bwd(dp, g.adj_ia, g.adj_ja, exact=exact)
+        dxs.append(gc)
+    return dxs, grads
+
+
+def duvenaud_forward(graphs, xs, es, params, nvf, Fe, mn, mx, nout, act):
+    T = len(nvf) - 1
+    out = np.zeros((len(graphs), nout), np.float32)
+    tapes = []
+    for s, (g, x, e) in enumerate(zip(graphs, xs, es)):
+        cur, A, Z = x, [], []
+        for t in range(1, T + 1):
+            a = o.duvenaud_propagate(cur, e, g.adj_ia, g.adj_ja)
+            c = o.duvenaud_update(a, params[t - 1], g.adj_ia, mn, mx, nvf[t])
+            z = o.activation(act, c)
+            A.append(a); Z.append(z); cur = z
+        P = []
+        for t in range(1, T + 1):
+            p = o.softmax_cols(o.matmul(params[T + t - 1], Z[t - 1], nout))
+            out[s] += p.sum(axis=0, dtype=np.float32) if False else o.segment_sum(p, np.array([0, p.shape[0]], np.int32))[0]
+            P.append(p)
+        tapes.append((A, Z, P))
+    return out, tapes
+
+
+def duvenaud_backward(graphs, es, tapes, params, nvf, Fe, mn, mx, nout, act, gout):
+    T = len(nvf) - 1
+    grads = [np.zeros_like(p) for p in params]
+    dxs, des = [], []
+    for s, (g, e, (A, Z, P)) in enumerate(zip(graphs, es, tapes)):
+        n = Z[0].shape[0]
+        gv = np.repeat(gout[s:s + 1], n, axis=0)
+        dz_next = None
+        de = np.zeros_like(e)
+        for t in range(T, 0, -1):
+            dl = o.softmax_cols_bwd(P[t - 1], gv)
+            grads[T + t - 1] += o.matmul_dw(dl, Z[t - 1])
+            dz = o.matmul_dx(params[T + t - 1], dl, nvf[t])
+            if dz_next is not None:
+                dz = dz + dz_next
+            dc = o.activation_bwd(act, Z[t - 1], dz)
+            grads[t - 1] += o.duvenaud_update_bwd_w(dc, A[t - 1], g.adj_ia, mn, mx)
+            da = o.duvenaud_update_bwd_a(dc, params[t - 1], g.adj_ia, mn, mx, A[t - 1].shape[1])
+            de += o.duvenaud_propagate_bwd_e(da, nvf[t - 1], e.shape[0], g.adj_ia, g.adj_ja)
+            dz_next = o.duvenaud_propagate_bwd_x(da, nvf[t - 1], g.adj_ia, g.adj_ja)
+        dxs.append(dz_next); des.append(de)
+    return dxs, des, grads
+
+
+def gno_forward(graphs, xs, cs, params, Fi, Fo, d, H, use_bias, act):
+    outs, tapes = [], []
+    for g, x, c in zip(graphs, xs, cs):
+        kap = o.gno_kernel_eval(c, params[0], H, Fo * Fi)
+        m = o.gno_aggregate(x, kap, g.adj_ia, g.adj_ja, Fo)
+        z = m + o.matmul(params[1], x, Fo)
+        if use_bias:
+            z = o.add_bias_rows(z, params[2])
+        y = o.activation(act, z)
+        outs.append(y); tapes.append((kap, y))
+    return outs, tapes
+
+
+def gno_backward(graphs, xs, cs, tapes, params, Fi, Fo, d, H, use_bias, act, ups):
+    grads = [np.zeros_like(p) for p in params]
+    dxs, dcs = [], []
+    for g, x, c, (kap, y), up in zip(graphs, xs, cs, tapes, ups):
+        dz = o.activation_bwd(act, y, up)
+        if use_bias:
+            grads[2] += dz.sum(axis=0)
+        grads[1] += o.matmul_dw(dz, x)
+        dk = o.gno_aggregate_bwd_k(dz, x, c.shape[0], g.adj_ia, g.adj_ja)
+        grads[0] += o.gno_kernel_bwd_theta(c, params[0], dk, H)
+        dxs.append(o.matmul_dx(params[1], dz, Fi) + o.gno_aggregate_bwd_x(dz, kap, g.adj_ia, g.adj_ja, Fi))
+        dcs.append(o.gno_kernel_bwd_coords(c, params[0], dk, H))
+    return dxs, dcs, grads

@@ -1,0 +1,146 @@
+"""GPU: the three layer types end to end (forward, explicit reverse pass, accessor round trips)
+against the per-sample oracle restatement.  Mirrors the reference's layer tests
+(test/test_kipf_msgpass_layer.f90, test_duvenaud_msgpass_layer.f90, test_gno_layer.f90)."""
+import numpy as np
+import pytest
+
+import oracle_layers as ol
+from helpers import assert_close, csr_from_index_list, golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _graphs(rng, sizes, self_loops):
+    gs = []
+    for n in sizes:
+        pairs = [[i, i + 1] for i in range(1, n)]
+        for _ in range(n // 2):
+            a, b = rng.integers(1, n + 1, 2)
+            if a != b:
+                pairs.append([int(a), int(b)])
+        gs.append(csr_from_index_list(n, np.array(pairs).T, self_loops=self_loops))
+    return gs
+
+
+@pytest.mark.parametrize("act,nvf,T", [("none", [5], 1), ("relu", [8, 16, 4], 2), ("sigmoid", [128], 2), ("tanh", [64, 128, 64], 2)])
+def test_kipf_layer(dev, act, nvf, T):
+    from athena_amd.layers import kipf_msgpass_layer_type
+
+    rng = np.random.default_rng(len(nvf) + T)
+    gs = _graphs(rng, [6, 17, 40, 9], self_loops=True)
+    layer = kipf_msgpass_layer_type(num_vertex_features=nvf, num_time_steps=T, activation=act, seed=1)
+    full = layer.num_vertex_features
+    xs = [rng.uniform(-1, 1, (g.num_vertices, full[0])).astype(np.float32) for g in gs]
+    assert layer.get_num_params() == sum(full[t] * full[t - 1] for t in range(1, T + 1))   # test_kipf_msgpass_layer.f90
+    params = layer.get_params()
+    layer.set_params(params * 1.0)
+    assert np.array_equal(layer.get_params(), params)
+    plist, o_ = [], 0
+    for t in range(1, T + 1):
+        n = full[t] * full[t - 1]
+        plist.append(params[o_:o_ + n]); o_ += n
+    layer.set_graph(gs)
+    out = layer.forward(xs).cpu().numpy()
+    outs, tapes = ol.kipf_forward(gs, xs, plist, full, act)
+    assert out.shape == (sum(g.num_vertices for g in gs), full[-1])
+    assert_close(out, np.concatenate(outs), 1e-5, "kipf layer fwd")
+    if act == "relu":
+        assert (out >= 0).all()
+    ups = [rng.uniform(-1, 1, o.shape).astype(np.float32) for o in outs]
+    assert np.array_equal(layer.get_gradients(), np.zeros_like(params))     # no grad yet -> zeros (:627-631)
+    dx = layer.backward(np.concatenate(ups)).cpu().numpy()
+    dxs, grads = ol.kipf_backward(gs, tapes, plist, full, act, ups)
+    assert_close(dx, np.concatenate(dxs), 1e-5, "kipf layer dx")
+    assert_close(layer.get_gradients(), np.concatenate(grads), 1e-5, "kipf layer dW")
+    layer.set_gradients(0.5)
+    assert np.all(layer.get_gradients() == 0.5)
+    # deterministic forward (test_gno_layer.f90:250-261 style)
+    assert np.array_equal(layer.forward(xs).cpu().numpy(), out)
+
+
+def test_kipf_layer_num_vertex_features_contract(dev):
+    from athena_amd.layers import kipf_msgpass_layer_type
+
+    with pytest.raises(ValueError, match="num_time_steps"):
+        kipf_msgpass_layer_type(num_vertex_features=[3, 4], num_time_steps=3)
+
+
+@pytest.mark.parametrize("Fv,Fe,T,nout", [(6, 1, 4, 10), (8, 2, 2, 3)])
+def test_duvenaud_layer_msgpass_chemical_shape(dev, Fv, Fe, T, nout):
+    """example/msgpass_chemical/src/main.f90:129-138 dims: F_v=6, F_e=1, T=4, degrees 1..10, 10 outputs"""
+    from athena_amd.layers import duvenaud_msgpass_layer_type
+
+    rng = np.random.default_rng(Fv)
+    gs = _graphs(rng, [7, 18, 25, 4, 12], self_loops=False)
+    layer = duvenaud_msgpass_layer_type(num_vertex_features=[Fv], num_edge_features=[Fe], num_time_steps=T,
+                                        max_vertex_degree=10, num_outputs=nout, min_vertex_degree=1, seed=2)
+    nvf = layer.num_vertex_features
+    D = 10
+    assert layer.get_num_params() == T * (Fv + Fe) * Fv * D + T * nout * Fv
+    params = layer.get_params()
+    plist, o_ = [], 0
+    for n in [(Fv + Fe) * Fv * D] * T + [nout * Fv] * T:
+        plist.append(params[o_:o_ + n]); o_ += n
+    xs = [rng.uniform(0, 1, (g.num_vertices, Fv)).astype(np.float32) for g in gs]
+    es = [rng.uniform(0, 1, (g.num_edges, Fe)).astype(np.float32) for g in gs]
+    layer.set_graph(gs)
+    out = layer.forward(xs, es).cpu().numpy()
+    ref, tapes = ol.duvenaud_forward(gs, xs, es, plist, nvf, Fe, 1, 10, nout, "sigmoid")
+    assert out.shape == (len(gs), nout)
+    assert_close(out, ref, 1e-5, "duvenaud fwd")
+    # softmax rows sum to 1 -> each graph's output sums to T * num_vertices
+    assert np.allclose(out.sum(1), [T * g.num_vertices for g in gs], rtol=1e-5)
+    gout = rng.uniform(-1, 1, out.shape).astype(np.float32)
+    dx, de = layer.backward(gout, need_edge_grad=True)
+    dxs, des, grads = ol.duvenaud_backward(gs, es, tapes, plist, nvf, Fe, 1, 10, nout, "sigmoid", gout)
+    assert_close(dx.cpu().numpy(), np.concatenate(dxs), 2e-5, "duvenaud dx")
+    assert_close(de.cpu().numpy(), np.concatenate(des), 2e-5, "duvenaud de")
+    assert_close(layer.get_gradients(), np.concatenate(grads), 2e-5, "duvenaud dparams")
+
+
+@pytest.mark.parametrize("Fi,Fo,d,H,bias,act", [(3, 5, 1, 8, True, "none"), (8, 8, 3, 16, False, "relu"), (32, 32, 3, 32, True, "tanh")])
+def test_gno_layer(dev, Fi, Fo, d, H, bias, act):
+    """example/gno_regression uses a 20-vertex chain; test_gno_layer.f90 checks shapes/determinism"""
+    from athena_amd.layers import graph_nop_layer_type
+
+    rng = np.random.default_rng(Fi + H)
+    gs = _graphs(rng, [20, 11, 33], self_loops=False)
+    layer = graph_nop_layer_type(num_outputs=Fo, coord_dim=d, kernel_hidden=H, num_inputs=Fi, use_bias=bias,
+                                 activation=act, seed=3)
+    F = Fo * Fi
+    sizes = [H * d + H + F * H + F, F] + ([Fo] if bias else [])
+    assert layer.get_num_params() == sum(sizes)
+    params = layer.get_params() + rng.standard_normal(sum(sizes)).astype(np.float32) * 0.1   # non-zero biases
+    layer.set_params(params)
+    plist, o_ = [], 0
+    for n in sizes:
+        plist.append(params[o_:o_ + n]); o_ += n
+    xs = [rng.uniform(-1, 1, (g.num_vertices, Fi)).astype(np.float32) for g in gs]
+    cs = [rng.standard_normal((g.num_edges, d)).astype(np.float32) for g in gs]
+    layer.set_graph(gs)
+    out = layer.forward(xs, cs).cpu().numpy()
+    outs, tapes = ol.gno_forward(gs, xs, cs, plist, Fi, Fo, d, H, bias, act)
+    assert_close(out, np.concatenate(outs), 1e-5, "gno fwd")
+    assert np.isfinite(out).all()
+    ups = [rng.uniform(-1, 1, o.shape).astype(np.float32) for o in outs]
+    dx, dc = layer.backward(np.concatenate(ups), need_coord_grad=True)
+    dxs, dcs, grads = ol.gno_backward(gs, xs, cs, tapes, plist, Fi, Fo, d, H, bias, act, ups)
+    assert_close(dx.cpu().numpy(), np.concatenate(dxs), 2e-5, "gno dx")
+    assert_close(dc.cpu().numpy(), np.concatenate(dcs), 2e-5, "gno dcoords")
+    assert_close(layer.get_gradients(), np.concatenate(grads), 2e-5, "gno dparams")
+    assert np.array_equal(layer.forward(xs, cs).cpu().numpy(), out)
+
+
+def test_reference_network_graph_through_layers(dev):
+    """test/test_msgpass_network.f90:249-276: the 5-vertex graph with its concrete feature values"""
+    from athena_amd.layers import duvenaud_msgpass_layer_type
+
+    t = golden("reference_test_topologies.json")["network_5v6e"]
+    g = csr_from_index_list(5, t["index_list"])
+    x = np.array(t["vertex_features_rows"], np.float32).T.copy()
+    e = np.array(t["edge_features_rows"], np.float32).T.copy()
+    layer = duvenaud_msgpass_layer_type(num_vertex_features=[8], num_edge_features=[2], num_time_steps=2,
+                                        max_vertex_degree=4, num_outputs=3, seed=5)
+    layer.set_graph(g)
+    out = layer.forward([x], [e]).cpu().numpy()
+    assert out.shape == (1, 3) and np.isfinite(out).all() and abs(out.sum() - 2 * 5) < 1e-4
