@@ -19,6 +19,8 @@
 //
 // Scatters of the reference (conflicting `do concurrent` writes) become pulls over the
 // transposed CSR / edge index built at graph_create: no atomics, deterministic order.
+#include <vector>
+
 #include "common.h"
 
 namespace {
@@ -234,6 +236,29 @@ int athena_mp_duvenaud_propagate_bwd_e(const athena_mp_graph *g, int32_t Fv, int
 {
     AMP_REQUIRE(g && grad && de && Fv > 0 && Fe > 0, "duvenaud_propagate_bwd_e: bad arguments");
     return gather_agg(g->e_rowptr, g->e_row, nullptr, grad + Fv, (int64_t)Fv + Fe, de, Fe, g->n_edge_cols, Fe);
+}
+
+int athena_mp_gather_rows(int64_t n, int32_t F, const int32_t *idx, const float *x, float *out)
+{
+    AMP_REQUIRE(n >= 0 && F > 0 && n < (int64_t)INT32_MAX, "gather_rows: bad arguments");
+    if (n == 0) return 0;
+    AMP_REQUIRE(idx && x && out, "gather_rows: null pointer");
+    // identity row pointer [0,1,..,n]: every output row has exactly one entry
+    static int32_t *iota = nullptr;
+    static int64_t iota_n = 0;
+    if (iota_n < n + 1) {
+        if (iota) {
+            AMP_HIP(hipStreamSynchronize(stream()));
+            AMP_HIP(hipFree(iota));
+        }
+        int64_t want = n + 1 + (n >> 2);
+        std::vector<int32_t> h(want);
+        for (int64_t i = 0; i < want; ++i) h[i] = (int32_t)i;
+        AMP_HIP(hipMalloc((void **)&iota, sizeof(int32_t) * want));
+        AMP_HIP(hipMemcpy(iota, h.data(), sizeof(int32_t) * want, hipMemcpyHostToDevice));
+        iota_n = want;
+    }
+    return gather_agg(iota, idx, nullptr, x, F, out, F, (int32_t)n, F);
 }
 
 int athena_mp_kipf_propagate_fwd_host(const athena_mp_graph *g, int32_t F, const float *xh, float *yh)

@@ -1,0 +1,237 @@
+"""Row-partitioned Kipf layer step across the GPUs of one node (one process per GPU, torch.distributed
+over RCCL/xGMI).  The reference has nothing distributed: this is new.
+
+Partition: rank r owns the contiguous vertex block [r*n, (r+1)*n) -- its rows of X, the CSR rows of
+its vertices and the matching output rows.  Per propagate ONE exchange step moves the *distinct*
+remote rows a rank's CSR rows reference (halo rows), as grouped point-to-point send/recv to every
+peer (torch `batch_isend_irecv` = ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd: one transfer
+per xGMI link, not a ring).  Forward exchanges X, backward exchanges dP (pull form: athena's graphs
+are undirected, so the transposed rows of a vertex are its own rows sorted by source id); dW is
+all-reduced.  W is replicated.
+
+The compute calls go through a backend object: `HipBackend` (the product path, libathena_mp.so).
+tests/ inject a CPU backend to exercise the partition / halo logic under gloo.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+# --------------------------------------------------------------------------------------------------
+# deterministic shard generator for the weak-scaling workload (every rank builds only its own rows)
+# --------------------------------------------------------------------------------------------------
+def _block_pairs(a, b, n, count, seed):
+    """`count` undirected pairs with one endpoint in partition a and the other in partition b (a<=b),
+    local ids; identical on both owners (seeded by the block)."""
+    rng = np.random.Generator(np.random.PCG64([seed, a, b]))
+    u = rng.integers(0, n, count, dtype=np.int64)
+    if a == b:
+        v = rng.integers(0, n - 1, count, dtype=np.int64)
+        v = v + (v >= u)
+    else:
+        v = rng.integers(0, n, count, dtype=np.int64)
+    return u, v
+
+
+def shard_entries(rank, world, n, pairs, cut=None, seed=20260424):
+    """CSR entries (row_local, col_global) of rank's rows for a graph of world*n vertices with
+    world*pairs undirected pairs (+ one self-loop per vertex).  cut = fraction of pairs that cross
+    partitions; None = (world-1)/world, i.e. both endpoints uniform over the whole graph."""
+    if world == 1:
+        cut = 0.0
+    elif cut is None:
+        cut = (world - 1) / world
+    n_cross_block = int(round(2.0 * pairs * cut / (world - 1))) if world > 1 else 0
+    n_in = pairs - (n_cross_block * (world - 1)) // 2
+    rows = [np.arange(n, dtype=np.int64)]
+    cols = [np.arange(n, dtype=np.int64) + rank * n]                 # self loop first in each row
+    u, v = _block_pairs(rank, rank, n, n_in, seed)
+    rows += [u, v]
+    cols += [v + rank * n, u + rank * n]
+    for b in range(world):
+        if b == rank:
+            continue
+        lo, hi = min(rank, b), max(rank, b)
+        u, v = _block_pairs(lo, hi, n, n_cross_block, seed)
+        mine, theirs = (u, v) if rank == lo else (v, u)
+        rows.append(mine)
+        cols.append(theirs + b * n)
+    rows = np.concatenate(rows)
+    cols = np.concatenate(cols)
+    order = np.argsort(rows, kind="stable")
+    return rows[order], cols[order], cut
+
+
+class Shard:
+    """One rank's rows with columns renumbered [local | halo] and the halo exchange plan."""
+
+    def __init__(self, rank, world, n, rows, cols_global):
+        self.rank, self.world, self.n = rank, world, n
+        counts = np.bincount(rows, minlength=n)
+        self.adj_ia = np.concatenate([[1], 1 + np.cumsum(counts)]).astype(np.int32)
+        self.cols_global = cols_global
+        self.row_deg = counts.astype(np.int32)
+        lo = rank * n
+        local = (cols_global >= lo) & (cols_global < lo + n)
+        self.halo_ids = np.unique(cols_global[~local])                      # sorted => grouped by owner
+        owner = self.halo_ids // n
+        self.recv_counts = np.bincount(owner, minlength=world).astype(np.int64)
+        col = np.where(local, cols_global - lo, n + np.searchsorted(self.halo_ids, cols_global))
+        self.n_halo = int(self.halo_ids.size)
+        self.nnz = int(cols_global.size)
+        ja = np.zeros((2, self.nnz), np.int32, order="F")
+        ja[0] = col + 1
+        self.adj_ja = ja
+        # backward (pull) graph: same rows, entries ordered by global source id (the order the
+        # reference's scatter accumulates in, athena_diffstruc_extd_sub_kipf.f90:101-109)
+        key = rows * (np.int64(world) * n) + cols_global
+        order = np.argsort(key, kind="stable")
+        jb = np.zeros((2, self.nnz), np.int32, order="F")
+        jb[0] = col[order] + 1
+        self.adj_ja_bwd = jb
+        self.send_idx = None     # filled by build_plan
+        self.send_counts = None
+        self.col_deg = None
+
+
+def _p2p_exchange(send_bufs, recv_bufs, rank, world):
+    ops = []
+    for p in range(world):
+        if p == rank:
+            continue
+        if send_bufs[p] is not None and send_bufs[p].numel() > 0:
+            ops.append(dist.P2POp(dist.isend, send_bufs[p], p))
+        if recv_bufs[p] is not None and recv_bufs[p].numel() > 0:
+            ops.append(dist.P2POp(dist.irecv, recv_bufs[p], p))
+    if ops:
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
+
+
+def build_plan(shard, device):
+    """Tell every owner which of its rows we need; learn which of ours the peers need; fetch the
+    global degrees of our halo columns (the Kipf coefficient needs deg of the remote endpoint)."""
+    rank, world, n = shard.rank, shard.world, shard.n
+    if world == 1:
+        shard.send_counts = np.zeros(1, np.int64)
+        shard.send_idx = torch.zeros(0, dtype=torch.int32, device=device)
+        shard.col_deg = shard.row_deg.copy()
+        return shard
+    rc = torch.from_numpy(shard.recv_counts).to(device)
+    allc = [torch.empty_like(rc) for _ in range(world)]
+    dist.all_gather(allc, rc)
+    allc = torch.stack(allc).cpu().numpy()                 # allc[q][p] = rows q needs from p
+    shard.send_counts = allc[:, rank].copy()
+    shard.send_counts[rank] = 0
+    roff = np.concatenate([[0], np.cumsum(shard.recv_counts)])
+    soff = np.concatenate([[0], np.cumsum(shard.send_counts)])
+    want = torch.from_numpy((shard.halo_ids % n).astype(np.int64)).to(device)     # owner-local ids
+    asked = torch.empty(int(soff[-1]), dtype=torch.int64, device=device)
+    _p2p_exchange([want[roff[p]:roff[p + 1]] if p != rank else None for p in range(world)],
+                  [asked[soff[p]:soff[p + 1]] if p != rank else None for p in range(world)], rank, world)
+    shard.send_idx = asked.to(torch.int32).contiguous()
+    shard._roff, shard._soff = roff, soff
+    # degrees of halo columns
+    deg = torch.from_numpy(shard.row_deg.astype(np.int64)).to(device)
+    sdeg = deg[asked] if asked.numel() else asked
+    hdeg = torch.empty(shard.n_halo, dtype=torch.int64, device=device)
+    _p2p_exchange([sdeg[soff[p]:soff[p + 1]] if p != rank else None for p in range(world)],
+                  [hdeg[roff[p]:roff[p + 1]] if p != rank else None for p in range(world)], rank, world)
+    shard.col_deg = np.concatenate([shard.row_deg, hdeg.cpu().numpy().astype(np.int32)])
+    return shard
+
+
+class HaloExchange:
+    """x_ext = [local rows | halo rows]: fills the halo part from the owners."""
+
+    def __init__(self, shard, F, device, backend):
+        self.s, self.F, self.backend = shard, F, backend
+        self.send_buf = torch.empty((int(shard.send_idx.numel()), F), dtype=torch.float32, device=device)
+
+    def __call__(self, x_ext):
+        s = self.s
+        if s.world == 1:
+            return x_ext
+        n = s.n
+        if self.send_buf.shape[0]:
+            self.backend.gather_rows(x_ext[:n], s.send_idx, out=self.send_buf)   # pack (HIP gather kernel)
+        roff, soff = s._roff, s._soff
+        _p2p_exchange([self.send_buf[soff[p]:soff[p + 1]] if p != s.rank else None for p in range(s.world)],
+                      [x_ext[n + roff[p]:n + roff[p + 1]] if p != s.rank else None for p in range(s.world)],
+                      s.rank, s.world)
+        return x_ext
+
+
+class HipBackend:
+    """the product path: hand-written HIP kernels behind the C ABI"""
+
+    def __init__(self, device):
+        from . import _capi
+        _capi.init(device.index or 0)
+        self.device = device
+
+    def make_graph(self, adj_ia, adj_ja, n_cols, row_deg, col_deg):
+        from .graph import DeviceGraph
+        return DeviceGraph(adj_ia, adj_ja, n_cols=n_cols, n_edge_cols=0, row_deg=row_deg, col_deg=col_deg,
+                           device=self.device.index or 0)
+
+    def __getattr__(self, name):
+        from . import ops
+        return getattr(ops, name)
+
+
+def make_weak_scaling_shard(rank, world, n, pairs, F, cut=None, device=None, seed=20260424):
+    rows, cols, cut = shard_entries(rank, world, n, pairs, cut, seed)
+    sh = Shard(rank, world, n, rows, cols)
+    sh.cut = cut
+    return build_plan(sh, device)
+
+
+class KipfShardStep:
+    """One interior Kipf layer fwd+bwd on a row shard (the bench step):
+         exchange(X); P = A^ X; Z = W P; dW = dZ P^T (all-reduce); dP = W^T dZ; exchange(dP); dX = A^T dP"""
+
+    def __init__(self, shard, F, device, backend=None, seed=1, exact=False):
+        self.s, self.F, self.device = shard, F, device
+        self.b = backend or HipBackend(device)
+        n, nh = shard.n, shard.n_halo
+        self.g_fwd = self.b.make_graph(shard.adj_ia, shard.adj_ja, n + nh, shard.row_deg, shard.col_deg)
+        self.g_bwd = self.b.make_graph(shard.adj_ia, shard.adj_ja_bwd, n + nh, shard.row_deg, shard.col_deg)
+        self.exact = exact
+        rng = np.random.Generator(np.random.PCG64([seed, shard.rank]))
+        self.x_ext = torch.empty((n + nh, F), dtype=torch.float32, device=device)
+        self.x_ext[:n] = torch.from_numpy(rng.uniform(-1, 1, (n, F)).astype(np.float32)).to(device)
+        self.dZ = torch.from_numpy(rng.uniform(-1, 1, (n, F)).astype(np.float32)).to(device)
+        wr = np.random.Generator(np.random.PCG64(seed + 1))              # W identical on every rank
+        self.W = torch.from_numpy((wr.standard_normal(F * F) * np.sqrt(2.0 / F)).astype(np.float32)).to(device)
+        self.P = torch.empty((n, F), dtype=torch.float32, device=device)
+        self.Z = torch.empty((n, F), dtype=torch.float32, device=device)
+        self.dW = torch.empty(F * F, dtype=torch.float32, device=device)
+        self.dP_ext = torch.empty((n + nh, F), dtype=torch.float32, device=device)
+        self.dX = torch.empty((n, F), dtype=torch.float32, device=device)
+        self.xchg = HaloExchange(shard, F, device, self.b)
+
+    def __call__(self):
+        s, b, F, n = self.s, self.b, self.F, self.s.n
+        self.xchg(self.x_ext)
+        b.kipf_propagate(self.g_fwd, self.x_ext, out=self.P)
+        b.matmul(self.W, self.P, F, out=self.Z)
+        b.matmul_dw(self.P, self.dZ, out=self.dW)
+        if s.world > 1:
+            dist.all_reduce(self.dW)
+        b.matmul_dx(self.W, self.dZ, F, out=self.dP_ext[:n])
+        self.xchg(self.dP_ext)
+        if self.exact:
+            b.kipf_propagate(self.g_bwd, self.dP_ext, out=self.dX)
+        else:
+            b.neighbour_sum(self.g_bwd, self.dP_ext, out=self.dX)
+        return self.dX
+
+
+def build_kipf_step(shard, F, device, backend=None):
+    step = KipfShardStep(shard, F, device, backend)
+    halo_bytes = 2 * shard.n_halo * F * 4
+    info = {"graph": "undirected pairs uniform over all N*vertices_per_gpu vertices" if abs(shard.cut - (shard.world - 1) / max(shard.world, 1)) < 1e-9
+            else f"{shard.cut:.3f} of the pairs cross partitions",
+            "halo_rows_per_gpu": shard.n_halo, "halo_bytes_per_gpu_per_step": halo_bytes}
+    return step, shard.nnz, info

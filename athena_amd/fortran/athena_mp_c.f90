@@ -1,0 +1,163 @@
+!! ISO_C_BINDING view of include/athena_mp.h -- the thin shim the north star asks for.
+!! Every interface is `bind(C)`; the ones invoked from diffstruc's `pure` get_partial_*_val
+!! callbacks are declared `pure` (legal for bind(C) interfaces; SURVEY.md 8b).
+!! Host arrays are passed by reference exactly as Fortran holds them: array_type%val(F,N) is
+!! column-major, i.e. the row-major [N][F] the kernels read; adj_ia / adj_ja keep their 1-based
+!! values (athena_mp_graph_create converts once).
+module athena_mp_c
+  use, intrinsic :: iso_c_binding
+  implicit none
+  private
+
+  integer(c_int), parameter, public :: ATHENA_MP_ACT_NONE = 0, ATHENA_MP_ACT_RELU = 1, &
+       ATHENA_MP_ACT_SIGMOID = 2, ATHENA_MP_ACT_TANH = 3
+
+  public :: athena_mp_init, athena_mp_finalize, athena_mp_last_error, athena_mp_synchronize
+  public :: athena_mp_graph_create, athena_mp_graph_destroy
+  public :: athena_mp_kipf_propagate_fwd_host, athena_mp_kipf_propagate_bwd_host
+  public :: athena_mp_gemm_fwd_host
+  public :: athena_mp_malloc, athena_mp_free, athena_mp_memcpy_h2d, athena_mp_memcpy_d2h
+  public :: athena_mp_kipf_propagate_fwd, athena_mp_kipf_propagate_bwd
+  public :: athena_mp_gemm_fwd, athena_mp_gemm_dw, athena_mp_gemm_dx
+  public :: athena_mp_error_message
+
+  interface
+     integer(c_int) function athena_mp_init(device) bind(C, name="athena_mp_init")
+       import :: c_int
+       integer(c_int), value :: device
+     end function
+     integer(c_int) function athena_mp_finalize() bind(C, name="athena_mp_finalize")
+       import :: c_int
+     end function
+     integer(c_int) function athena_mp_synchronize() bind(C, name="athena_mp_synchronize")
+       import :: c_int
+     end function
+     type(c_ptr) function athena_mp_last_error() bind(C, name="athena_mp_last_error")
+       import :: c_ptr
+     end function
+
+     !! athena_msgpass_layer_sub.f90:144-174 (set_graph) -- build once, keep the handle
+     integer(c_int) function athena_mp_graph_create(n_rows, n_cols, nnz, adj_ia, adj_ja, &
+          n_edge_cols, row_deg, col_deg, graph) bind(C, name="athena_mp_graph_create")
+       import :: c_int, c_int32_t, c_int64_t, c_ptr
+       integer(c_int32_t), value :: n_rows, n_cols, n_edge_cols
+       integer(c_int64_t), value :: nnz
+       integer(c_int32_t), intent(in) :: adj_ia(*), adj_ja(2,*)
+       type(c_ptr), value :: row_deg, col_deg        !! c_null_ptr: degrees = CSR row lengths
+       type(c_ptr), intent(out) :: graph
+     end function
+     integer(c_int) function athena_mp_graph_destroy(graph) bind(C, name="athena_mp_graph_destroy")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: graph
+     end function
+
+     !! kipf_propagate, athena_diffstruc_extd_sub_kipf.f90:7-59 (host arrays, staged)
+     pure integer(c_int) function athena_mp_kipf_propagate_fwd_host(graph, F, x, y) &
+          bind(C, name="athena_mp_kipf_propagate_fwd_host")
+       import :: c_int, c_int32_t, c_ptr, c_float
+       type(c_ptr), value :: graph
+       integer(c_int32_t), value :: F
+       real(c_float), intent(in) :: x(*)
+       real(c_float), intent(inout) :: y(*)
+     end function
+     !! get_partial_kipf_propagate_left_val, ..._sub_kipf.f90:85-111
+     pure integer(c_int) function athena_mp_kipf_propagate_bwd_host(graph, F, grad, dx, exact) &
+          bind(C, name="athena_mp_kipf_propagate_bwd_host")
+       import :: c_int, c_int32_t, c_ptr, c_float
+       type(c_ptr), value :: graph
+       integer(c_int32_t), value :: F, exact
+       real(c_float), intent(in) :: grad(*)
+       real(c_float), intent(inout) :: dx(*)
+     end function
+     !! matmul(params(t), ptr2), athena_kipf_msgpass_layer.f90:951
+     pure integer(c_int) function athena_mp_gemm_fwd_host(N, Fi, Fo, P, W, bias, act, Z) &
+          bind(C, name="athena_mp_gemm_fwd_host")
+       import :: c_int, c_int32_t, c_int64_t, c_ptr, c_float
+       integer(c_int64_t), value :: N
+       integer(c_int32_t), value :: Fi, Fo, act
+       real(c_float), intent(in) :: P(*), W(*)
+       type(c_ptr), value :: bias
+       real(c_float), intent(inout) :: Z(*)
+     end function
+
+     !! device-resident variants (phase 2: tensors stay in HBM between consecutive HIP layers)
+     integer(c_int) function athena_mp_malloc(dev_ptr, bytes) bind(C, name="athena_mp_malloc")
+       import :: c_int, c_ptr, c_int64_t
+       type(c_ptr), intent(out) :: dev_ptr
+       integer(c_int64_t), value :: bytes
+     end function
+     integer(c_int) function athena_mp_free(dev_ptr) bind(C, name="athena_mp_free")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: dev_ptr
+     end function
+     integer(c_int) function athena_mp_memcpy_h2d(dst, src, bytes) bind(C, name="athena_mp_memcpy_h2d")
+       import :: c_int, c_ptr, c_int64_t, c_float
+       type(c_ptr), value :: dst
+       real(c_float), intent(in) :: src(*)
+       integer(c_int64_t), value :: bytes
+     end function
+     integer(c_int) function athena_mp_memcpy_d2h(dst, src, bytes) bind(C, name="athena_mp_memcpy_d2h")
+       import :: c_int, c_ptr, c_int64_t, c_float
+       real(c_float), intent(inout) :: dst(*)
+       type(c_ptr), value :: src
+       integer(c_int64_t), value :: bytes
+     end function
+     integer(c_int) function athena_mp_kipf_propagate_fwd(graph, F, x_dev, y_dev) &
+          bind(C, name="athena_mp_kipf_propagate_fwd")
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: graph, x_dev, y_dev
+       integer(c_int32_t), value :: F
+     end function
+     integer(c_int) function athena_mp_kipf_propagate_bwd(graph, F, g_dev, dx_dev, exact) &
+          bind(C, name="athena_mp_kipf_propagate_bwd")
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: graph, g_dev, dx_dev
+       integer(c_int32_t), value :: F, exact
+     end function
+     integer(c_int) function athena_mp_gemm_fwd(N, Fi, Fo, P_dev, W_dev, bias_dev, act, Z_dev) &
+          bind(C, name="athena_mp_gemm_fwd")
+       import :: c_int, c_int32_t, c_int64_t, c_ptr
+       integer(c_int64_t), value :: N
+       integer(c_int32_t), value :: Fi, Fo, act
+       type(c_ptr), value :: P_dev, W_dev, bias_dev, Z_dev
+     end function
+     integer(c_int) function athena_mp_gemm_dw(N, Fi, Fo, P_dev, dZ_dev, dW_dev) &
+          bind(C, name="athena_mp_gemm_dw")
+       import :: c_int, c_int32_t, c_int64_t, c_ptr
+       integer(c_int64_t), value :: N
+       integer(c_int32_t), value :: Fi, Fo
+       type(c_ptr), value :: P_dev, dZ_dev, dW_dev
+     end function
+     integer(c_int) function athena_mp_gemm_dx(N, Fi, Fo, dZ_dev, W_dev, dP_dev) &
+          bind(C, name="athena_mp_gemm_dx")
+       import :: c_int, c_int32_t, c_int64_t, c_ptr
+       integer(c_int64_t), value :: N
+       integer(c_int32_t), value :: Fi, Fo
+       type(c_ptr), value :: dZ_dev, W_dev, dP_dev
+     end function
+  end interface
+
+contains
+
+  function athena_mp_error_message() result(msg)
+    !! last C-side error as a Fortran string (what the layer hands to coreutils' stop_program)
+    character(len=:), allocatable :: msg
+    type(c_ptr) :: p
+    character(kind=c_char), pointer :: s(:)
+    integer :: n
+    p = athena_mp_last_error()
+    if(.not.c_associated(p))then
+       msg = ""
+       return
+    end if
+    call c_f_pointer(p, s, [1024])
+    n = 0
+    do while(n .lt. 1024)
+       if(s(n+1) .eq. c_null_char) exit
+       n = n + 1
+    end do
+    allocate(character(len=n) :: msg)
+    msg = transfer(s(1:n), msg)
+  end function athena_mp_error_message
+
+end module athena_mp_c

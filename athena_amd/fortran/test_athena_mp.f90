@@ -1,0 +1,140 @@
+!! Fortran -> ISO_C_BINDING -> libathena_mp.so -> HIP: exercises the boundary the way an athena
+!! layer would, on the reference's own test data:
+!!   * identity-graph known answer   (test/test_diffstruc_extd_kipf.f90:22-45)
+!!   * 6-vertex / 8-edge graph       (test/test_kipf_msgpass_layer.f90:83-90) against the plain loops of
+!!     kipf_propagate / get_partial_kipf_propagate_left_val restated inline below
+!! Exit status 1 on any failure (the reference's test convention: `stop 1`).
+program test_athena_mp
+  use, intrinsic :: iso_c_binding
+  use athena_mp_c
+  implicit none
+  integer, parameter :: real32 = c_float
+  logical :: success
+  type(c_ptr) :: graph
+  integer(c_int) :: rc
+
+  success = .true.
+  rc = athena_mp_init(0_c_int)
+  call check(rc, "init")
+
+  call identity_kat()
+  call six_vertex_graph()
+
+  rc = athena_mp_finalize()
+  if(success)then
+     write(*,*) "test_athena_mp passed all tests"
+  else
+     write(0,*) "test_athena_mp failed one or more tests"
+     stop 1
+  end if
+
+contains
+
+  subroutine check(rc, what)
+    integer(c_int), intent(in) :: rc
+    character(*), intent(in) :: what
+    if(rc .ne. 0)then
+       write(0,*) "athena_mp "//what//" failed: "//athena_mp_error_message()
+       stop 1
+    end if
+  end subroutine check
+
+  subroutine identity_kat()
+    real(real32) :: x(2,2), y(2,2), g(2,2), dx(2,2)
+    integer(c_int32_t) :: adj_ia(3), adj_ja(2,2)
+    x(:,1) = [1._real32, 2._real32]
+    x(:,2) = [3._real32, 4._real32]
+    adj_ia = [1, 2, 3]
+    adj_ja(:,1) = [1, 0]
+    adj_ja(:,2) = [2, 0]
+    rc = athena_mp_graph_create(2, 2, 2_c_int64_t, adj_ia, adj_ja, 0, c_null_ptr, c_null_ptr, graph)
+    call check(rc, "graph_create")
+    rc = athena_mp_kipf_propagate_fwd_host(graph, 2, x, y)
+    call check(rc, "kipf fwd")
+    if(any(abs(y - x) .gt. 1.e-6_real32))then
+       success = .false.
+       write(0,*) "kipf_propagate returned the wrong forward values"
+    end if
+    g = 1._real32
+    rc = athena_mp_kipf_propagate_bwd_host(graph, 2, g, dx, 0)
+    call check(rc, "kipf bwd")
+    if(any(abs(dx - 1._real32) .gt. 1.e-6_real32))then
+       success = .false.
+       write(0,*) "kipf_propagate returned the wrong gradient"
+    end if
+    rc = athena_mp_graph_destroy(graph)
+  end subroutine identity_kat
+
+  subroutine six_vertex_graph()
+    integer, parameter :: nv = 6, ne = 8, nf = 5
+    integer :: index_list(2,ne), deg(nv), pos(nv), v, w, e, u, i
+    integer(c_int32_t) :: adj_ia(nv+1), adj_ja(2,2*ne)
+    real(real32) :: x(nf,nv), y(nf,nv), yref(nf,nv), g(nf,nv), dx(nf,nv), dxref(nf,nv), coeff
+    real(real32) :: wmat(3*nf), z(3,nv), zref(3,nv)
+    index_list(:,1) = [1, 2]; index_list(:,2) = [1, 3]; index_list(:,3) = [2, 3]; index_list(:,4) = [2, 4]
+    index_list(:,5) = [3, 5]; index_list(:,6) = [4, 5]; index_list(:,7) = [4, 6]; index_list(:,8) = [5, 6]
+    deg = 0
+    do e = 1, ne
+       deg(index_list(1,e)) = deg(index_list(1,e)) + 1
+       deg(index_list(2,e)) = deg(index_list(2,e)) + 1
+    end do
+    adj_ia(1) = 1
+    do v = 1, nv
+       adj_ia(v+1) = adj_ia(v) + deg(v)
+    end do
+    pos = adj_ia(1:nv)
+    do e = 1, ne
+       u = index_list(1,e); v = index_list(2,e)
+       adj_ja(:,pos(u)) = [v, e]; pos(u) = pos(u) + 1
+       adj_ja(:,pos(v)) = [u, e]; pos(v) = pos(v) + 1
+    end do
+    do v = 1, nv
+       do i = 1, nf
+          x(i,v) = 0.1_real32 * real(i, real32) - 0.3_real32 * real(v, real32) + 0.05_real32 * real(i*v, real32)
+          g(i,v) = 1._real32 / real(i + v, real32)
+       end do
+    end do
+    ! reference loops (athena_diffstruc_extd_sub_kipf.f90:29-46 and :100-109)
+    do v = 1, nv
+       yref(:,v) = 0._real32
+       do w = adj_ia(v), adj_ia(v+1)-1
+          coeff = ( ( adj_ia(v+1) - adj_ia(v) ) * &
+               ( adj_ia( adj_ja(1,w) + 1 ) - adj_ia( adj_ja(1,w) ) ) ) ** ( -0.5_real32 )
+          yref(:,v) = yref(:,v) + coeff * x(:, adj_ja(1,w))
+       end do
+    end do
+    dxref = 0._real32
+    do v = 1, nv
+       do w = adj_ia(v), adj_ia(v+1)-1
+          dxref(:,adj_ja(1,w)) = dxref(:,adj_ja(1,w)) + g(:,v)
+       end do
+    end do
+    rc = athena_mp_graph_create(nv, nv, int(2*ne, c_int64_t), adj_ia, adj_ja, ne, c_null_ptr, c_null_ptr, graph)
+    call check(rc, "graph_create 6v")
+    rc = athena_mp_kipf_propagate_fwd_host(graph, nf, x, y)
+    call check(rc, "kipf fwd 6v")
+    if(any(abs(y - yref) .gt. 1.e-5_real32 * maxval(abs(yref))))then
+       success = .false.
+       write(0,*) "6-vertex forward differs from the reference loops", maxval(abs(y - yref))
+    end if
+    rc = athena_mp_kipf_propagate_bwd_host(graph, nf, g, dx, 0)
+    call check(rc, "kipf bwd 6v")
+    if(any(abs(dx - dxref) .gt. 1.e-5_real32 * maxval(abs(dxref))))then
+       success = .false.
+       write(0,*) "6-vertex backward differs from the reference loops", maxval(abs(dx - dxref))
+    end if
+    ! dense step: Z = W(3,nf) . Y, W = params%val(:,1) column-major
+    do i = 1, 3*nf
+       wmat(i) = 0.01_real32 * real(i, real32) - 0.07_real32
+    end do
+    zref = matmul(reshape(wmat, [3, nf]), yref)
+    rc = athena_mp_gemm_fwd_host(int(nv, c_int64_t), nf, 3, y, wmat, c_null_ptr, ATHENA_MP_ACT_NONE, z)
+    call check(rc, "gemm fwd 6v")
+    if(any(abs(z - zref) .gt. 1.e-5_real32 * maxval(abs(zref))))then
+       success = .false.
+       write(0,*) "6-vertex matmul differs", maxval(abs(z - zref))
+    end if
+    rc = athena_mp_graph_destroy(graph)
+  end subroutine six_vertex_graph
+
+end program test_athena_mp

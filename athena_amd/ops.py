@@ -53,6 +53,27 @@ def kipf_propagate_bwd(g: DeviceGraph, grad, exact=False, out=None):
     return dx
 
 
+def neighbour_sum(g: DeviceGraph, x, out=None):
+    """y[v,:] = sum_{w in row v} x[col[w],:] (no coefficient): the pull form of the reference's
+    coefficient-free backward on a symmetric graph shard (= duvenaud_propagate with F_e = 0)"""
+    F = x.shape[1]
+    _chk(x, (g.n_cols, F))
+    y = out if out is not None else torch.empty((g.n_rows, F), device=x.device, dtype=torch.float32)
+    _go()
+    _capi.call("athena_mp_duvenaud_propagate_fwd", g.handle, F, 0, _p(x), None, _p(y))
+    return y
+
+
+def gather_rows(x, idx, out=None):
+    """out[r,:] = x[idx[r],:] -- halo packing"""
+    n, F = idx.numel(), x.shape[1]
+    _chk(x); _chk(idx, dtype=torch.int32)
+    y = out if out is not None else torch.empty((n, F), device=x.device, dtype=torch.float32)
+    _go()
+    _capi.call("athena_mp_gather_rows", n, F, _p(idx), _p(x), _p(y))
+    return y
+
+
 # ---- dense contraction (diffstruc matmul) ---------------------------------------------------------
 def matmul(W, P, Fo, bias=None, act="none", out=None):
     """Z[N,Fo] = act(P[N,Fi] . Wt + bias);  W flat params%val(:,1) = W(Fo,Fi) column-major."""

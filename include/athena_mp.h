@@ -86,6 +86,10 @@ int athena_mp_kipf_propagate_fwd(const athena_mp_graph *g, int32_t F, const floa
 int athena_mp_kipf_propagate_bwd(const athena_mp_graph *g, int32_t F, const float *grad_dev,
                                  float *dx_dev, int32_t exact);
 
+/* out[r,:] = x[idx[r],:]  (r < n; idx 0-based device array).  Packs the halo rows a row partition
+ * sends to its peers; same gather kernel as the aggregation. */
+int athena_mp_gather_rows(int64_t n, int32_t F, const int32_t *idx_dev, const float *x_dev, float *out_dev);
+
 /* ---- dense contraction (diffstruc matmul at athena_kipf_msgpass_layer.f90:951,
  *      athena_duvenaud_msgpass_layer.f90:842, athena_graph_nop_layer.f90:761) -- fp32 MFMA */
 /* Z[N,Fo] = act( P[N,Fi] . Wt[Fi,Fo] (+ bias[Fo]) );  bias may be NULL */

@@ -1,0 +1,133 @@
+"""CPU, world_size 2, gloo: the row-partition / halo-exchange logic of athena_amd/dist.py.
+The HIP kernels cannot run here, so an oracle-backed compute backend is injected (tests may use the
+oracle); what is under test is the sharding: shard generation, column renumbering, halo plan,
+point-to-point exchange, degree exchange, dW all-reduce -- the assembled result must equal the
+single-process oracle on the assembled global graph (bit-exact for the two aggregations)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleGraph:
+    def __init__(self, ia, ja, n_cols, row_deg, col_deg):
+        self.ia, self.ja, self.n_cols, self.row_deg, self.col_deg = ia, np.asfortranarray(ja), n_cols, row_deg, col_deg
+        self.n_rows = ia.size - 1
+
+
+class OracleBackend:
+    """same call surface as athena_amd.dist.HipBackend, computed by the CPU oracle"""
+
+    def __init__(self):
+        from oracle import oracle
+        self.o = oracle
+
+    def make_graph(self, ia, ja, n_cols, row_deg, col_deg):
+        return OracleGraph(ia, ja, n_cols, row_deg, col_deg)
+
+    def kipf_propagate(self, g, x, out):
+        out.copy_(torch.from_numpy(self.o.kipf_propagate_rect(x.numpy(), g.ia, g.ja, g.row_deg, g.col_deg)))
+
+    def neighbour_sum(self, g, x, out):
+        ones_r, ones_c = np.ones(g.n_rows, np.int32), np.ones(g.n_cols, np.int32)   # coefficient 1
+        out.copy_(torch.from_numpy(self.o.kipf_propagate_rect(x.numpy(), g.ia, g.ja, ones_r, ones_c)))
+
+    def matmul(self, W, P, Fo, out):
+        out.copy_(torch.from_numpy(self.o.matmul(W.numpy(), P.numpy(), Fo)))
+
+    def matmul_dw(self, P, dZ, out):
+        out.copy_(torch.from_numpy(self.o.matmul_dw(dZ.numpy(), P.numpy())))
+
+    def matmul_dx(self, W, dZ, Fi, out):
+        out.copy_(torch.from_numpy(self.o.matmul_dx(W.numpy(), dZ.numpy(), Fi)))
+
+    def gather_rows(self, x, idx, out):
+        out.copy_(x[idx.long()])
+
+
+def _worker(rank, world, port, n, pairs, F, cut, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from athena_amd import dist as adist
+
+    dev = torch.device("cpu")
+    shard = adist.make_weak_scaling_shard(rank, world, n, pairs, F, cut=cut, device=dev)
+    step = adist.KipfShardStep(shard, F, dev, backend=OracleBackend())
+    x_local = step.x_ext[:n].clone().numpy()
+    dx = step().clone().numpy()
+    q.put((rank, dict(x=x_local, dz=step.dZ.numpy().copy(), w=step.W.numpy().copy(), P=step.P.numpy().copy(),
+                      Z=step.Z.numpy().copy(), dW=step.dW.numpy().copy(), dX=dx, n_halo=shard.n_halo,
+                      send=int(shard.send_idx.numel()), col_deg=shard.col_deg.copy())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+@pytest.mark.parametrize("cut", [None, 0.1])
+def test_two_rank_kipf_step_matches_global_oracle(oracle, cut):
+    from athena_amd import dist as adist
+
+    world, n, pairs, F = 2, 400, 1500, 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, pairs, F, cut, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # assemble the global graph from the same generator
+    rows, cols = [], []
+    for r in range(world):
+        rr, cc, _ = adist.shard_entries(r, world, n, pairs, cut)
+        rows.append(rr + r * n); cols.append(cc)
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    N = world * n
+    ia = np.concatenate([[1], 1 + np.cumsum(np.bincount(rows, minlength=N))]).astype(np.int32)
+    ja = np.zeros((2, rows.size), np.int32, order="F"); ja[0] = cols + 1
+    # the generated graph is symmetric as a multiset (undirected), which the pull-form backward relies on
+    A = np.zeros((N, N), np.int64); np.add.at(A, (rows, cols), 1)
+    assert np.array_equal(A, A.T)
+    x = np.concatenate([res[r]["x"] for r in range(world)])
+    dz = np.concatenate([res[r]["dz"] for r in range(world)])
+    w = res[0]["w"]
+    assert np.array_equal(w, res[1]["w"])
+    P = oracle.kipf_propagate(x, ia, ja)
+    assert np.array_equal(np.concatenate([res[r]["P"] for r in range(world)]), P)          # bit-exact
+    assert np.array_equal(np.concatenate([res[r]["Z"] for r in range(world)]), oracle.matmul(w, P, F))
+    dP = oracle.matmul_dx(w, dz, F)
+    dX = oracle.kipf_propagate_bwd(dP, ia, ja)                                             # reference: no coefficient
+    assert np.array_equal(np.concatenate([res[r]["dX"] for r in range(world)]), dX)
+    dW = oracle.matmul_dw(dz, P)
+    for r in range(world):
+        assert np.abs(res[r]["dW"] - dW).max() <= 1e-5 * np.abs(dW).max()                  # all-reduced
+        assert res[r]["n_halo"] > 0 and res[r]["send"] > 0
+    deg = np.diff(ia)
+    assert np.array_equal(res[0]["col_deg"][:n], deg[:n])
+
+
+def test_shard_generator_balances_entries():
+    from athena_amd import dist as adist
+
+    for world in (1, 2, 4, 8):
+        for cut in (None, 0.05):
+            r, c, used = adist.shard_entries(world - 1, world, 1000, 4500, cut)
+            assert abs(r.size - 10000) <= 8
+            assert c.min() >= 0 and c.max() < world * 1000
+            local = (c >= (world - 1) * 1000)
+            if world > 1:
+                frac = 1 - (local.sum() - 1000) / (r.size - 1000)
+                assert abs(frac - used) < 0.03

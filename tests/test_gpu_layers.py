@@ -144,3 +144,35 @@ def test_reference_network_graph_through_layers(dev):
     layer.set_graph(g)
     out = layer.forward([x], [e]).cpu().numpy()
     assert out.shape == (1, 3) and np.isfinite(out).all() and abs(out.sum() - 2 * 5) < 1e-4
+
+
+def test_shard_step_on_hip_backend_single_rank(dev, oracle):
+    """the multi-GPU step object (athena_amd/dist.py) driven by the HIP backend, world = 1
+    (N > 1 needs one GPU per rank; the 2-rank logic is covered under gloo in test_dist_gloo.py)"""
+    from athena_amd import dist as adist
+
+    n, pairs, F = 3000, 12000, 64
+    shard = adist.make_weak_scaling_shard(0, 1, n, pairs, F, device=dev)
+    step = adist.KipfShardStep(shard, F, dev)
+    dx = step().cpu().numpy()
+    x, dz, w = step.x_ext[:n].cpu().numpy(), step.dZ.cpu().numpy(), step.W.cpu().numpy()
+    P = oracle.kipf_propagate(x, shard.adj_ia, shard.adj_ja)
+    assert np.array_equal(step.P.cpu().numpy(), P)
+    dP = step.dP_ext[:n].cpu().numpy()
+    assert_close(dP, oracle.matmul_dx(w, dz, F), 1e-5)
+    assert np.array_equal(dx, oracle.kipf_propagate_bwd(dP, shard.adj_ia, shard.adj_ja))
+    assert_close(step.dW.cpu().numpy(), oracle.matmul_dw(dz, P), 1e-5)
+
+
+def test_fortran_iso_c_binding_boundary(dev):
+    """athena_amd/fortran/test_athena_mp.f90: Fortran host -> ISO_C_BINDING -> libathena_mp.so -> HIP,
+    on the reference's identity-graph known answer and its 6-vertex test graph"""
+    import os
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "athena_amd", "fortran", "test_athena_mp")
+    if not os.path.exists(exe):
+        pytest.skip("Fortran test program not built (amdflang missing at build time)")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "passed all tests" in r.stdout
