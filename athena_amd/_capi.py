@@ -11,7 +11,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libathena_mp.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("ATHENA_MP_LIB", "libathena_mp.so"))
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "athena_mp.h")
 
 

@@ -19,9 +19,26 @@
 //
 // Scatters of the reference (conflicting `do concurrent` writes) become pulls over the
 // transposed CSR / edge index built at graph_create: no atomics, deterministic order.
+#include <stdlib.h>
+
+#include <algorithm>
 #include <vector>
 
 #include "common.h"
+
+namespace amp {
+// > 0: aggregation launches use at most this many (persistent, grid-striding) workgroups
+static int g_agg_cap = -1;
+int agg_blocks_cap()
+{
+    if (g_agg_cap < 0) {
+        const char *e = getenv("ATHENA_MP_AGG_BLOCKS");
+        g_agg_cap = e ? atoi(e) : 0;
+    }
+    return g_agg_cap;
+}
+void set_agg_blocks_cap(int n) { g_agg_cap = n; }
+} // namespace amp
 
 namespace {
 
@@ -69,7 +86,11 @@ __global__ __launch_bounds__(kBlock) void csr_gather_agg(
     constexpr int kRowsPerBlock = kBlock / G;
     const int lane = threadIdx.x & 63;
     const int gl = threadIdx.x & (G - 1);          // lane inside the group
-    const int row = blockIdx.x * kRowsPerBlock + (threadIdx.x / G);
+    const int n_row_blocks = (n_rows + kRowsPerBlock - 1) / kRowsPerBlock;
+    // grid-stride over row blocks: gridDim.x == n_row_blocks for a plain launch, or a fixed number of
+    // resident workgroups per CU when the launch leaves room for a co-running MFMA kernel
+    for (int rb = blockIdx.x; rb < n_row_blocks; rb += gridDim.x) {
+    const int row = rb * kRowsPerBlock + (threadIdx.x / G);
     const bool live = row < n_rows;
 
     int start = 0, len = 0;
@@ -128,6 +149,7 @@ __global__ __launch_bounds__(kBlock) void csr_gather_agg(
         }
         if (live && fin) vstore<VEC>(y + (int64_t)row * ldy + f, acc);
     }
+    } // row blocks
 }
 
 template <int G, int VEC>
@@ -135,7 +157,9 @@ int launch_gv(bool has_coef, const int32_t *rowptr, const int32_t *idx, const fl
               int64_t ldx, float *y, int64_t ldy, int32_t n_rows, int32_t F)
 {
     constexpr int rpb = kBlock / G;
-    dim3 grid((n_rows + rpb - 1) / rpb), block(kBlock);
+    int nb = (n_rows + rpb - 1) / rpb;
+    if (amp::agg_blocks_cap() > 0) nb = std::min(nb, amp::agg_blocks_cap());
+    dim3 grid(nb), block(kBlock);
     if (has_coef)
         hipLaunchKernelGGL((csr_gather_agg<G, VEC, true>), grid, block, 0, amp::stream(), rowptr, idx, coef, x,
                            ldx, y, ldy, n_rows, F);

@@ -63,6 +63,8 @@ struct athena_mp_graph {
 };
 
 namespace amp {
+int agg_blocks_cap();
+void set_agg_blocks_cap(int n);
 // shared launchers (defined in agg.hip / gemm.hip)
 int gather_agg(const int32_t *rowptr, const int32_t *idx, const float *coef, const float *x, int64_t ldx,
                float *y, int64_t ldy, int32_t n_rows, int32_t F);

@@ -13,6 +13,8 @@
 // (MI355X_MICROARCH: ds_read_b128 is serviced in 16-lane groups over 64 banks; row pitch = 33 slots of
 // 16 B puts the 16 rows of a group on 16 distinct slots).  The k index is permuted -- lane half h of
 // MFMA step s consumes k = s + (K/2) h -- so four consecutive steps read one 16-byte run per lane.
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "common.h"
@@ -41,6 +43,44 @@ template <int ACT> __device__ __forceinline__ float act_ct(float z)
     if constexpr (ACT == ATHENA_MP_ACT_SIGMOID) return 1.0f / (1.0f + expf(-z));
     if constexpr (ACT == ATHENA_MP_ACT_TANH) return tanhf(z);
     return z;
+}
+
+// Stage B into LDS as [n][K+4].  All global loads of a thread are issued before the first LDS write
+// (a load->write loop serialised ~2 us of latency per iteration: 15 % of the kernel at 1M rows).
+template <int K, int N, int THREADS>
+__device__ __forceinline__ void stage_b(float *__restrict__ Bs, const float *__restrict__ B, int b_nk)
+{
+    constexpr int LD = K + 4;
+    constexpr int NV = K * N / 4;                       // v4f in B
+    constexpr int PER = (NV + THREADS - 1) / THREADS;   // v4f per thread
+    v4f tmp[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        int t = i * THREADS + threadIdx.x;
+        tmp[i] = reinterpret_cast<const v4f *>(B)[t < NV ? t : NV - 1];
+    }
+    if (b_nk) { // B stored [N][K]: straight copy of K-runs
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            int t = i * THREADS + threadIdx.x;
+            if (t < NV) {
+                int n = t / (K / 4), q = t - n * (K / 4);
+                *reinterpret_cast<v4f *>(Bs + n * LD + 4 * q) = tmp[i];
+            }
+        }
+    } else {    // B stored [K][N]: transpose while writing
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            int t = i * THREADS + threadIdx.x;
+            if (t < NV) {
+                int k = t / (N / 4), n4 = t - k * (N / 4);
+                Bs[(4 * n4 + 0) * LD + k] = tmp[i].x;
+                Bs[(4 * n4 + 1) * LD + k] = tmp[i].y;
+                Bs[(4 * n4 + 2) * LD + k] = tmp[i].z;
+                Bs[(4 * n4 + 3) * LD + k] = tmp[i].w;
+            }
+        }
+    }
 }
 
 template <int K>
@@ -81,18 +121,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bres_kernel(const float *__restri
     const int h = lane >> 5;
 
     // ---- stage B once per workgroup --------------------------------------------------------
-    if (b_nk) {
-        for (int t = threadIdx.x; t < N * RQ; t += 256) {
-            int n = t / RQ, q = t - n * RQ;
-            v4f v = *reinterpret_cast<const v4f *>(B + (size_t)n * K + 4 * q);
-            *reinterpret_cast<v4f *>(Bs + n * LD + 4 * q) = v;
-        }
-    } else {
-        for (int t = threadIdx.x; t < K * N; t += 256) {
-            int k = t / N, n = t - k * N;
-            Bs[n * LD + k] = B[t];
-        }
-    }
+    stage_b<K, N, 256>(Bs, B, b_nk);
     __syncthreads();
 
     const int64_t n_slabs = (M + 31) / 32;
@@ -168,6 +197,124 @@ __global__ __launch_bounds__(256, 1) void gemm_bres_kernel(const float *__restri
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 8-wave variant for K, N in {64,128}: two independent waves per SIMD, so one wave's LDS staging /
+// epilogue overlaps the other's MFMAs.  To fit 8 private regions beside the resident B in 160 KB of
+// LDS, A is staged in two K-halves and the C tile leaves in two N-halves through the same
+// [32][max(K,N)/2 + 4] region.
+// ---------------------------------------------------------------------------------------------
+template <int K, int N, int ACT, bool BIAS>
+__global__ __launch_bounds__(512, 2) void gemm_bres8_kernel(const float *__restrict__ A,
+                                                             const float *__restrict__ B, int b_nk,
+                                                             const float *__restrict__ bias,
+                                                             float *__restrict__ Z, int64_t M)
+{
+    constexpr int KH = K / 2, NH = N / 2;
+    constexpr int LD = K + 4;
+    constexpr int LDW = (KH > NH ? KH : NH) + 4;
+    constexpr int NT = N / 32, NTH = NT / 2;
+    constexpr int A4 = K / 8, A4H = A4 / 2;   // v4f per lane per slab / per K-half
+    constexpr int RQH = KH / 4;               // v4f per half row of A
+    constexpr int C4H = NH / 8;               // v4f per lane per N-half of C
+    constexpr int CQH = NH / 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *Bs = lds;
+    float *Ws = lds + N * LD + (threadIdx.x >> 6) * 32 * LDW;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int r31 = lane & 31;
+    const int h = lane >> 5;
+
+    stage_b<K, N, 512>(Bs, B, b_nk);
+    __syncthreads();
+
+    const int64_t n_slabs = (M + 31) / 32;
+    const int64_t stride = (int64_t)gridDim.x * 8;
+    int64_t slab = (int64_t)blockIdx.x * 8 + wave;
+
+    v4f pre[A4];
+    auto gaddr = [&](int64_t s, int it) -> const v4f * {
+        const int hk = it / A4H, j = it - hk * A4H;
+        const int t = j * 64 + lane;
+        const int row = t / RQH, q = t - row * RQH;
+        const int64_t gr = min(s * 32 + row, M - 1);
+        return reinterpret_cast<const v4f *>(A + gr * K + hk * KH + 4 * q);
+    };
+    if (slab < n_slabs) {
+#pragma unroll
+        for (int it = 0; it < A4; ++it) pre[it] = *gaddr(slab, it);
+    }
+
+    for (; slab < n_slabs; slab += stride) {
+        f32x16 acc[NT];
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
+
+#pragma unroll
+        for (int hk = 0; hk < 2; ++hk) {
+#pragma unroll
+            for (int j = 0; j < A4H; ++j) {
+                const int t = j * 64 + lane;
+                const int row = t / RQH, q = t - row * RQH;
+                *reinterpret_cast<v4f *>(Ws + row * LDW + 4 * q) = pre[hk * A4H + j];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (hk == 1 && slab + stride < n_slabs) {
+#pragma unroll
+                for (int it = 0; it < A4; ++it) pre[it] = *gaddr(slab + stride, it);
+            }
+            const float *arow = Ws + r31 * LDW + (KH / 2) * h;
+            const float *brow = Bs + r31 * LD + hk * KH + (KH / 2) * h;
+#pragma unroll 2
+            for (int q = 0; q < KH / 8; ++q) {
+                v4f a4 = *reinterpret_cast<const v4f *>(arow + 4 * q);
+                v4f b4[NT];
+#pragma unroll
+                for (int c = 0; c < NT; ++c) b4[c] = *reinterpret_cast<const v4f *>(brow + c * 32 * LD + 4 * q);
+#pragma unroll
+                for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4[c].x, acc[c], 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4[c].y, acc[c], 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4[c].z, acc[c], 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4[c].w, acc[c], 0, 0, 0);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+
+        const int64_t r0 = slab * 32;
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {
+#pragma unroll
+            for (int c = 0; c < NTH; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    Ws[((r & 3) + 8 * (r >> 2) + 4 * h) * LDW + c * 32 + r31] = acc[nh * NTH + c][r];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int it = 0; it < C4H; ++it) {
+                const int t = it * 64 + lane;
+                const int row = t / CQH, q = t - row * CQH;
+                v4f v = *reinterpret_cast<const v4f *>(Ws + row * LDW + 4 * q);
+                if constexpr (BIAS) v += *reinterpret_cast<const v4f *>(bias + nh * NH + 4 * q);
+                v.x = act_ct<ACT>(v.x); v.y = act_ct<ACT>(v.y); v.z = act_ct<ACT>(v.z); v.w = act_ct<ACT>(v.w);
+                if (r0 + row < M) *reinterpret_cast<v4f *>(Z + (r0 + row) * N + nh * NH + 4 * q) = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
     }
 }
 
@@ -283,6 +430,119 @@ __global__ __launch_bounds__(256, 1) void gemm_dw_kernel(const float *__restrict
             }
 }
 
+// ---------------------------------------------------------------------------------------------
+// dW, one WAVE per full [FI x FO] tile: every vertex row of P and dZ is read exactly once chip-wide
+// with 16 B/lane loads (lane m holds features TI*m .. TI*m+TI-1: element t feeds MFMA row-tile t),
+// TI*TJ MFMAs per vertex pair.  256 accumulator registers at 128x128, one wave per SIMD; the four
+// waves of a workgroup add their tiles through LDS in wave order (deterministic), one slab per
+// workgroup.
+// ---------------------------------------------------------------------------------------------
+template <int T> struct FragLoadV;
+template <> struct FragLoadV<1> {
+    static __device__ __forceinline__ void ld(float (&d)[1], const float *p) { d[0] = *p; }
+};
+template <> struct FragLoadV<2> {
+    static __device__ __forceinline__ void ld(float (&d)[2], const float *p)
+    {
+        float2 t = *reinterpret_cast<const float2 *>(p);
+        d[0] = t.x; d[1] = t.y;
+    }
+};
+template <> struct FragLoadV<4> {
+    static __device__ __forceinline__ void ld(float (&d)[4], const float *p)
+    {
+        v4f t = *reinterpret_cast<const v4f *>(p);
+        d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
+    }
+};
+
+template <bool MASK, int U, int TI, int TJ, int FI, int FO>
+__device__ __forceinline__ void dwf_load(float (&a)[U][TI], float (&b)[U][TJ], const float *__restrict__ pa,
+                                         const float *__restrict__ pb, int64_t v, int64_t v1, int h)
+{
+#pragma unroll
+    for (int s = 0; s < U; ++s) {
+        const int64_t vv = v + 2 * s + h;
+        const bool ok = vv < v1;
+        const int64_t vc = ok ? vv : v1 - 1;
+        FragLoadV<TI>::ld(a[s], pa + vc * FI);
+        FragLoadV<TJ>::ld(b[s], pb + vc * FO);
+        if constexpr (MASK) {
+            if (!ok) {
+#pragma unroll
+                for (int t = 0; t < TI; ++t) a[s][t] = 0.0f;
+            }
+        }
+    }
+}
+
+template <int FI, int FO>
+__global__ __launch_bounds__(256, 1) void gemm_dw_full_kernel(const float *__restrict__ P,
+                                                               const float *__restrict__ dZ,
+                                                               float *__restrict__ slabs, int64_t M,
+                                                               int64_t rows_per_wave)
+{
+    constexpr int TI = FI / 32, TJ = FO / 32;
+    constexpr int U = 4;
+    __shared__ __attribute__((aligned(16))) float red[FI * FO];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 31, h = lane >> 5;
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int a = 0; a < TI; ++a)
+#pragma unroll
+        for (int b = 0; b < TJ; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t v0 = min(M, gw * rows_per_wave);
+    const int64_t v1 = min(M, v0 + rows_per_wave);
+    const float *pa = P + TI * m;
+    const float *pb = dZ + TJ * m;
+
+    if (v1 > v0) {
+        float a0[U][TI], b0[U][TJ], a1[U][TI], b1[U][TJ];
+        const int64_t n_pairs = (v1 - v0) / (4 * U);
+        int64_t v = v0;
+        if (n_pairs > 0) dwf_load<false, U, TI, TJ, FI, FO>(a0, b0, pa, pb, v, v1, h);
+        for (int64_t p = 0; p < n_pairs; ++p, v += 4 * U) {
+            dwf_load<false, U, TI, TJ, FI, FO>(a1, b1, pa, pb, v + 2 * U, v1, h);
+            __builtin_amdgcn_sched_barrier(0);
+            dw_mfma<U, TI, TJ>(acc, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            dwf_load<false, U, TI, TJ, FI, FO>(a0, b0, pa, pb, v + 4 * U, v1, h);
+            __builtin_amdgcn_sched_barrier(0);
+            dw_mfma<U, TI, TJ>(acc, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        for (; v < v1; v += 2 * U) {
+            dwf_load<true, U, TI, TJ, FI, FO>(a0, b0, pa, pb, v, v1, h);
+            dw_mfma<U, TI, TJ>(acc, a0, b0);
+        }
+    }
+    // wave-ordered reduction of the four tiles; element (ti, r) of lane (m,h) is dWt[i][TJ*m .. +TJ-1]
+    // with i = TI*((r&3) + 8*(r>>2) + 4*h) + ti  -> one TJ-wide vector store per (ti, r)
+    for (int p = 0; p < 4; ++p) {
+        if (wave == p) {
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = TI * ((r & 3) + 8 * (r >> 2) + 4 * h) + ti;
+                    float *dst = red + i * FO + TJ * m;
+#pragma unroll
+                    for (int tj = 0; tj < TJ; ++tj) dst[tj] = (p == 0 ? 0.0f : dst[tj]) + acc[ti][tj][r];
+                }
+        }
+        __syncthreads();
+    }
+    float *slab = slabs + (size_t)blockIdx.x * FI * FO;
+    for (int t = threadIdx.x; t < FI * FO / 4; t += 256)
+        reinterpret_cast<v4f *>(slab)[t] = reinterpret_cast<const v4f *>(red)[t];
+}
+
 // out[t] = sum_b slabs[b][t], b ascending inside each of 4 interleaved groups, groups added in
 // fixed order: deterministic.  64 outputs per workgroup, 4 slab groups per output.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ slabs, int n_slabs, int n,
@@ -352,8 +612,31 @@ int num_cu()
 }
 
 template <int K, int N, int ACT, bool BIAS>
+int launch_bres8(const float *A, const float *B, int b_nk, const float *bias, float *Z, int64_t M)
+{
+    constexpr int LDW = ((K > N ? K : N) / 2) + 4;
+    constexpr size_t lds = sizeof(float) * ((size_t)N * (K + 4) + 8 * 32 * LDW);
+    static bool attr_done = false;
+    if (!attr_done) {
+        AMP_HIP(hipFuncSetAttribute((const void *)gemm_bres8_kernel<K, N, ACT, BIAS>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    int64_t n_slabs = (M + 31) / 32;
+    int grid = (int)std::min<int64_t>((n_slabs + 7) / 8, num_cu());
+    hipLaunchKernelGGL((gemm_bres8_kernel<K, N, ACT, BIAS>), dim3(grid), dim3(512), lds, amp::stream(), A, B, b_nk,
+                       bias, Z, M);
+    AMP_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int K, int N, int ACT, bool BIAS>
 int launch_bres2(const float *A, const float *B, int b_nk, const float *bias, float *Z, int64_t M)
 {
+    if constexpr (K >= 64 && N >= 64) {
+        static const bool four = getenv("ATHENA_MP_GEMM_4WAVE") != nullptr; // A/B switch
+        if (!four) return launch_bres8<K, N, ACT, BIAS>(A, B, b_nk, bias, Z, M);
+    }
     constexpr size_t lds = sizeof(float) * ((size_t)N * (K + 4) + 4 * 32 * ((K > N ? K : N) + 4));
     static bool attr_done = false;
     if (!attr_done) {
@@ -423,16 +706,32 @@ int gemm_dw_dispatch(int64_t N, int Fi, int Fo, const float *P, const float *dZ,
         if (!accumulate) AMP_HIP(hipMemsetAsync(dW, 0, sizeof(float) * n, stream()));
         return 0;
     }
-    int nblk = (int)std::min<int64_t>((N + 255) / 256, 2 * num_cu());
-    int64_t rpb = (N + nblk - 1) / nblk;
-    rpb = (rpb + 1) & ~(int64_t)1; // even: the MFMA form consumes vertex pairs
-    nblk = (int)((N + rpb - 1) / rpb);
+    static const bool use_quad = getenv("ATHENA_MP_DW_QUAD") != nullptr; // older 4-waves-per-tile form (A/B)
+    bool mf = (Fi == 64 || Fi == 128) && (Fo == 64 || Fo == 128) && ((uintptr_t)P % 16 == 0) &&
+              ((uintptr_t)dZ % 16 == 0);
+    int nblk;
+    int64_t rpb = 0, rpw = 0;
+    if (mf && !use_quad) {
+        nblk = (int)std::min<int64_t>((N + 127) / 128, num_cu());
+        rpw = (N + (int64_t)nblk * 4 - 1) / ((int64_t)nblk * 4);
+        rpw = (rpw + 1) & ~(int64_t)1;
+        nblk = (int)((N + rpw * 4 - 1) / (rpw * 4));
+    } else {
+        nblk = (int)std::min<int64_t>((N + 255) / 256, 2 * num_cu());
+        rpb = (N + nblk - 1) / nblk;
+        rpb = (rpb + 1) & ~(int64_t)1; // even: the MFMA form consumes vertex pairs
+        nblk = (int)((N + rpb - 1) / rpb);
+    }
     void *ws = nullptr;
     if (workspace(&ws, sizeof(float) * (size_t)nblk * n, 2)) return 1;
     float *slabs = (float *)ws;
-    bool mf = (Fi == 64 || Fi == 128) && (Fo == 64 || Fo == 128) && ((uintptr_t)P % 8 == 0) &&
-              ((uintptr_t)dZ % 8 == 0);
-    if (mf) {
+    if (mf && !use_quad) {
+#define AMP_CASE(A_, B_)                                                                                    \
+    if (Fi == A_ && Fo == B_)                                                                               \
+        hipLaunchKernelGGL((gemm_dw_full_kernel<A_, B_>), dim3(nblk), dim3(256), 0, stream(), P, dZ, slabs, N, rpw);
+        AMP_CASE(64, 64) AMP_CASE(64, 128) AMP_CASE(128, 64) AMP_CASE(128, 128)
+#undef AMP_CASE
+    } else if (mf) {
 #define AMP_CASE(A_, B_)                                                                                   \
     if (Fi == A_ && Fo == B_)                                                                              \
         hipLaunchKernelGGL((gemm_dw_kernel<A_, B_>), dim3(nblk), dim3(256), 0, stream(), P, dZ, slabs, N, rpb);
