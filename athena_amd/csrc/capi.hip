@@ -165,6 +165,7 @@ int athena_mp_graph_destroy(athena_mp_graph *g)
                     g->t_coef, g->e_rowptr, g->e_row, g->e_col, g->deg_row,  g->deg_col};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (g->bucket_perm) (void)hipFree(g->bucket_perm);
     delete g;
     return 0;
 }
@@ -259,6 +260,7 @@ int athena_mp_graph_create(int32_t n_rows, int32_t n_cols, int64_t nnz, const in
     g->max_row_len = max_row;
     g->max_col_len = max_col;
     g->n_with_edge = n_with_edge;
+    g->h_deg_row = degr;
     int rc = 0;
     rc |= upload(&g->rowptr, rowptr);
     rc |= upload(&g->col, col);

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include <vector>
 
 #include "../../include/athena_mp.h"
 
@@ -60,6 +61,12 @@ struct athena_mp_graph {
     int32_t *deg_row = nullptr;  // [n_rows]
     int32_t *deg_col = nullptr;  // [n_cols]
     int64_t n_with_edge = 0;
+    std::vector<int32_t> h_deg_row; // host copy (bucket planning)
+    // Duvenaud degree buckets, built on first use for a (min_deg, max_deg) pair: vertices sorted by
+    // bucket (stable), so each bucket is one contiguous run of a row-index array
+    mutable int bucket_min = 0, bucket_max = -1;
+    mutable int32_t *bucket_perm = nullptr;      // [n_rows] device
+    mutable std::vector<int64_t> bucket_off;     // [n_buckets+1] host
 };
 
 namespace amp {
@@ -73,4 +80,19 @@ int gemm_dispatch(const float *A, const float *B, int b_nk, const float *bias, i
                   int K, int N);
 // dWt[Fi,Fo] (+)= sum_v P[v,:]^T dZ[v,:]
 int gemm_dw_dispatch(int64_t N, int Fi, int Fo, const float *P, const float *dZ, float *dW, bool accumulate);
+int slab_reduce(const float *slabs, int n_slabs, int n, float *out, bool accumulate);
+
+// shape-generic tiled MFMA contraction (gemm_tiled.hip)
+struct TiledArgs {
+    const float *A = nullptr; int64_t lda = 0; const int32_t *a_idx = nullptr; float a_div = 1.0f;
+    const float *B = nullptr; int64_t ldb = 0; int b_nk = 0;
+    const float *bias = nullptr; int act = 0; float c_div = 1.0f;
+    float *C = nullptr; int64_t ldc = 0; const int32_t *c_idx = nullptr;
+    int64_t M = 0; int N = 0; int K = 0;
+};
+int gemm_tiled(const TiledArgs &p);
+int gemm_atb_tiled(const float *A, int64_t lda, const float *B, int64_t ldb, const int32_t *idx, float div, int64_t M,
+                   int KI, int NO, float *C, bool accumulate);
+// bucket-sorted vertex permutation of a graph for Duvenaud's degree buckets (duvenaud.hip)
+int duvenaud_buckets(const athena_mp_graph *g, int min_deg, int max_deg);
 } // namespace amp

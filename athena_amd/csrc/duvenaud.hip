@@ -137,7 +137,46 @@ __global__ void softmax_segsum_bwd_kernel(int O, int64_t N, int S, const int32_t
 
 } // namespace
 
+namespace amp {
+// stable sort of the vertices by degree bucket (host, once per (min,max)); each bucket becomes one
+// contiguous run of g->bucket_perm so the bucketed update is <= D dense contractions with row indirection
+int duvenaud_buckets(const athena_mp_graph *g, int min_deg, int max_deg)
+{
+    if (g->bucket_perm && g->bucket_min == min_deg && g->bucket_max == max_deg) return 0;
+    const int nb = max_deg - min_deg + 1;
+    const int32_t n = g->n_rows;
+    std::vector<int64_t> off(nb + 1, 0);
+    std::vector<int32_t> bucket(n);
+    for (int32_t v = 0; v < n; ++v) {
+        int d = std::max(min_deg, std::min(g->h_deg_row[v], max_deg)) - min_deg; // 0-based
+        bucket[v] = d;
+        off[d + 1]++;
+    }
+    for (int b = 0; b < nb; ++b) off[b + 1] += off[b];
+    std::vector<int32_t> perm(n);
+    {
+        std::vector<int64_t> pos(off.begin(), off.end() - 1);
+        for (int32_t v = 0; v < n; ++v) perm[pos[bucket[v]]++] = v;
+    }
+    if (g->bucket_perm) {
+        AMP_HIP(hipStreamSynchronize(stream()));
+        AMP_HIP(hipFree(g->bucket_perm));
+        g->bucket_perm = nullptr;
+    }
+    AMP_HIP(hipMalloc((void **)&g->bucket_perm, sizeof(int32_t) * (n ? n : 1)));
+    if (n) AMP_HIP(hipMemcpy(g->bucket_perm, perm.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    g->bucket_off = off;
+    g->bucket_min = min_deg;
+    g->bucket_max = max_deg;
+    return 0;
+}
+} // namespace amp
+
 using namespace amp;
+
+// MFMA route when both feature counts are matrix-sized; tiny layers (6-7-10 of msgpass_chemical) keep
+// the bit-exact VALU kernels above
+static inline bool duv_use_mfma(int Fi, int Fo, int64_t n) { return Fi >= 16 && Fo >= 16 && n >= 1024; }
 
 extern "C" {
 
@@ -147,6 +186,19 @@ int athena_mp_duvenaud_update_fwd(const athena_mp_graph *g, int32_t Fi, int32_t 
     AMP_REQUIRE(g && a && weight && c && Fi > 0 && Fo > 0 && max_deg >= min_deg, "duvenaud_update_fwd: bad arguments");
     int64_t total = (int64_t)g->n_rows * Fo;
     if (total == 0) return 0;
+    if (duv_use_mfma(Fi, Fo, g->n_rows)) {
+        if (duvenaud_buckets(g, min_deg, max_deg)) return 1;
+        for (int b = 0; b <= max_deg - min_deg; ++b) {
+            const int64_t cnt = g->bucket_off[b + 1] - g->bucket_off[b];
+            if (cnt == 0) continue;
+            TiledArgs t;   // c[v,:] = W_d (a[v,:] / d): the divide happens on the A operand, as in the reference
+            t.A = a; t.lda = Fi; t.a_idx = g->bucket_perm + g->bucket_off[b]; t.a_div = (float)(b + 1);
+            t.B = weight + (size_t)b * Fo * Fi; t.ldb = Fo; t.b_nk = 0;   // W_d(o,i) flat o + Fo*i == [K=i][N=o]
+            t.C = c; t.ldc = Fo; t.c_idx = t.a_idx; t.M = cnt; t.N = Fo; t.K = Fi;
+            if (int rc = gemm_tiled(t)) return rc;
+        }
+        return 0;
+    }
     hipLaunchKernelGGL(duv_update_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream(),
                        g->deg_row, min_deg, max_deg, Fi, Fo, (int64_t)g->n_rows, a, weight, c);
     AMP_LAUNCH_CHECK();
@@ -160,6 +212,20 @@ int athena_mp_duvenaud_update_bwd_a(const athena_mp_graph *g, int32_t Fi, int32_
                 "duvenaud_update_bwd_a: bad arguments");
     int64_t total = (int64_t)g->n_rows * Fi;
     if (total == 0) return 0;
+    if (duv_use_mfma(Fi, Fo, g->n_rows)) {
+        if (duvenaud_buckets(g, min_deg, max_deg)) return 1;
+        for (int b = 0; b <= max_deg - min_deg; ++b) {
+            const int64_t cnt = g->bucket_off[b + 1] - g->bucket_off[b];
+            if (cnt == 0) continue;
+            TiledArgs t;   // da[v,i] = (sum_o g[v,o] W_d(o,i)) / d
+            t.A = grad; t.lda = Fo; t.a_idx = g->bucket_perm + g->bucket_off[b];
+            t.B = weight + (size_t)b * Fo * Fi; t.ldb = Fo; t.b_nk = 1;   // [N=i][K=o]
+            t.c_div = (float)(b + 1);
+            t.C = da; t.ldc = Fi; t.c_idx = t.a_idx; t.M = cnt; t.N = Fi; t.K = Fo;
+            if (int rc = gemm_tiled(t)) return rc;
+        }
+        return 0;
+    }
     hipLaunchKernelGGL(duv_update_bwd_a_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream(),
                        g->deg_row, min_deg, max_deg, Fi, Fo, (int64_t)g->n_rows, grad, weight, da);
     AMP_LAUNCH_CHECK();
@@ -176,6 +242,16 @@ int athena_mp_duvenaud_update_bwd_w(const athena_mp_graph *g, int32_t Fi, int32_
     const int64_t N = g->n_rows;
     if (N == 0) {
         AMP_HIP(hipMemsetAsync(dweight, 0, sizeof(float) * n, stream()));
+        return 0;
+    }
+    if (duv_use_mfma(Fi, Fo, N)) {
+        if (duvenaud_buckets(g, min_deg, max_deg)) return 1;
+        for (int b = 0; b < nb; ++b) {   // dW_d(o,i) = sum_{v in bucket} g[v,o] a[v,i] / d  -> [Fi][Fo] row-major
+            const int64_t cnt = g->bucket_off[b + 1] - g->bucket_off[b];
+            if (int rc = gemm_atb_tiled(a, Fi, grad, Fo, g->bucket_perm + g->bucket_off[b], (float)(b + 1), cnt, Fi, Fo,
+                                        dweight + (size_t)b * Fo * Fi, false))
+                return rc;
+        }
         return 0;
     }
     int chunks = (int)std::min<int64_t>((N + 1023) / 1024, 512);

@@ -690,6 +690,12 @@ int gemm_dispatch(const float *A, const float *B, int b_nk, const float *bias, i
         AMP_CASE(128, 32) AMP_CASE(128, 64) AMP_CASE(128, 128)
 #undef AMP_CASE
     }
+    if (K >= 8 && N >= 8 && M >= 128) { // anything MFMA-worthy that is not weight-resident
+        TiledArgs t;
+        t.A = A; t.lda = K; t.B = B; t.ldb = b_nk ? K : N; t.b_nk = b_nk; t.bias = bias; t.act = act;
+        t.C = Z; t.ldc = N; t.M = M; t.N = N; t.K = K;
+        return gemm_tiled(t);
+    }
     int64_t total = M * N;
     hipLaunchKernelGGL(gemm_small_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, amp::stream(), A,
                        B, b_nk, bias, act, Z, M, K, N);
@@ -699,6 +705,14 @@ int gemm_dispatch(const float *A, const float *B, int b_nk, const float *bias, i
 } // namespace amp
 
 namespace amp {
+int slab_reduce(const float *slabs, int n_slabs, int n, float *out, bool accumulate)
+{
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, stream(), slabs, n_slabs, n, out,
+                       accumulate ? 1 : 0);
+    AMP_LAUNCH_CHECK();
+    return 0;
+}
+
 int gemm_dw_dispatch(int64_t N, int Fi, int Fo, const float *P, const float *dZ, float *dW, bool accumulate)
 {
     const int n = Fi * Fo;
@@ -709,6 +723,8 @@ int gemm_dw_dispatch(int64_t N, int Fi, int Fo, const float *P, const float *dZ,
     static const bool use_quad = getenv("ATHENA_MP_DW_QUAD") != nullptr; // older 4-waves-per-tile form (A/B)
     bool mf = (Fi == 64 || Fi == 128) && (Fo == 64 || Fo == 128) && ((uintptr_t)P % 16 == 0) &&
               ((uintptr_t)dZ % 16 == 0);
+    if (!mf && (int64_t)Fi * Fo >= 256 && N >= 256)
+        return gemm_atb_tiled(P, Fi, dZ, Fo, nullptr, 1.0f, N, Fi, Fo, dW, accumulate);
     int nblk;
     int64_t rpb = 0, rpw = 0;
     if (mf && !use_quad) {

@@ -1,0 +1,272 @@
+// Shape-generic fp32 MFMA contractions (any M, N, K; optional row indirection).
+//
+// gemm.hip keeps the weight matrix resident in LDS, which only works for K, N <= 128.  These two
+// kernels tile all three dimensions and serve everything else on the path:
+//   gemm_tiled      C[c_idx[m], :] = act( (A[a_idx[m], :] / a_div) . B / c_div + bias )
+//                   - Kipf dense step at F = 256 (BASELINE configs[4])
+//                   - GNO contraction m = S . Vaug, K = (H+1) F_in = 4160  (gno.hip)
+//                   - Duvenaud readout R z and its dx  (N or K = num_outputs = 10)
+//                   - Duvenaud degree-bucketed update: one launch per bucket over a bucket-sorted
+//                     vertex permutation, A rows divided by the bucket index on load exactly as the
+//                     reference does (athena_diffstruc_extd_sub_duvenaud.f90:209-210)
+//   gemm_atb_tiled  C[i, o] = sum_m A[idx[m], i] B[idx[m], o] / div      (reductions over vertices)
+//                   - GNO dVaug = S^T g, Duvenaud dW_d, readout dR
+// MFMA: v_mfma_f32_32x32x2_f32 (exact fp32).  Zero-fill handles every ragged edge.
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BN = 64, BK = 32, LDT = BK + 4;
+
+__device__ __forceinline__ float act_rt(float z, int act)
+{
+    switch (act) {
+    case ATHENA_MP_ACT_RELU: return z > 0.0f ? z : 0.0f;
+    case ATHENA_MP_ACT_SIGMOID: return 1.0f / (1.0f + expf(-z));
+    case ATHENA_MP_ACT_TANH: return tanhf(z);
+    default: return z;
+    }
+}
+
+// 4 consecutive floats p[0..3] with element-wise bound `nvalid` (vector fast path when allowed)
+__device__ __forceinline__ v4f load4(const float *__restrict__ p, int nvalid, bool vec_ok)
+{
+    v4f r = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (p == nullptr || nvalid <= 0) return r;
+    if (vec_ok && nvalid >= 4) return *reinterpret_cast<const v4f *>(p);
+    r.x = p[0];
+    if (nvalid > 1) r.y = p[1];
+    if (nvalid > 2) r.z = p[2];
+    if (nvalid > 3) r.w = p[3];
+    return r;
+}
+
+__global__ __launch_bounds__(256) void gemm_tiled_kernel(amp::TiledArgs p)
+{
+    __shared__ __attribute__((aligned(16))) float As[BM * LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * LDT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r31 = lane & 31, h = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const bool a_vec = (p.lda % 4 == 0) && ((uintptr_t)p.A % 16 == 0);
+    const bool b_vec = (p.ldb % 4 == 0) && ((uintptr_t)p.B % 16 == 0);
+
+    // this thread's 4 A rows (row = t>>3, k-quad = t&7)
+    const float *ap[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int64_t m = m0 + ((it * 256 + tid) >> 3);
+        ap[it] = nullptr;
+        if (m < p.M) {
+            const int64_t phys = p.a_idx ? (int64_t)p.a_idx[m] : m;
+            ap[it] = p.A + phys * p.lda;
+        }
+    }
+    v4f ra[4], rb[2];
+    auto load_chunk = [&](int k0) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int q = (it * 256 + tid) & 7;
+            v4f v = load4(ap[it] ? ap[it] + k0 + 4 * q : nullptr, p.K - (k0 + 4 * q), a_vec);
+            if (p.a_div != 1.0f) { v.x = v.x / p.a_div; v.y = v.y / p.a_div; v.z = v.z / p.a_div; v.w = v.w / p.a_div; }
+            ra[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int t = it * 256 + tid;
+            if (p.b_nk) { // B stored [N][K]
+                const int n = t >> 3, q = t & 7;
+                const bool ok = n0 + n < p.N;
+                rb[it] = load4(ok ? p.B + (int64_t)(n0 + n) * p.ldb + k0 + 4 * q : nullptr, p.K - (k0 + 4 * q), b_vec);
+            } else {      // B stored [K][N]
+                const int k = t >> 4, q4 = t & 15;
+                const bool ok = k0 + k < p.K;
+                rb[it] = load4(ok ? p.B + (int64_t)(k0 + k) * p.ldb + n0 + 4 * q4 : nullptr, p.N - (n0 + 4 * q4), b_vec);
+            }
+        }
+    };
+    f32x16 acc[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
+
+    load_chunk(0);
+    for (int k0 = 0; k0 < p.K; k0 += BK) {
+        __syncthreads(); // previous chunk's fragment reads are done
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int t = it * 256 + tid;
+            *reinterpret_cast<v4f *>(As + (t >> 3) * LDT + 4 * (t & 7)) = ra[it];
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int t = it * 256 + tid;
+            if (p.b_nk) {
+                *reinterpret_cast<v4f *>(Bs + (t >> 3) * LDT + 4 * (t & 7)) = rb[it];
+            } else {
+                const int k = t >> 4, q4 = t & 15;
+                Bs[(4 * q4 + 0) * LDT + k] = rb[it].x;
+                Bs[(4 * q4 + 1) * LDT + k] = rb[it].y;
+                Bs[(4 * q4 + 2) * LDT + k] = rb[it].z;
+                Bs[(4 * q4 + 3) * LDT + k] = rb[it].w;
+            }
+        }
+        __syncthreads();
+        if (k0 + BK < p.K) load_chunk(k0 + BK); // in flight under the MFMAs
+        const float *arow = As + (32 * wave + r31) * LDT + 16 * h;
+        const float *brow = Bs + r31 * LDT + 16 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const v4f a4 = *reinterpret_cast<const v4f *>(arow + 4 * q);
+            const v4f b0 = *reinterpret_cast<const v4f *>(brow + 4 * q);
+            const v4f b1 = *reinterpret_cast<const v4f *>(brow + 32 * LDT + 4 * q);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b0.x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b1.x, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b0.y, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b1.y, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b0.z, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b1.z, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b0.w, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b1.w, acc[1], 0, 0, 0);
+        }
+    }
+    // epilogue straight from the accumulators (col = lane&31, row = (r&3) + 8*(r>>2) + 4*h)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int col = n0 + 32 * c + r31;
+        if (col >= p.N) continue;
+        const float bv = p.bias ? p.bias[col] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t m = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m < p.M) {
+                const int64_t phys = p.c_idx ? (int64_t)p.c_idx[m] : m;
+                float v = acc[c][r];
+                if (p.c_div != 1.0f) v = v / p.c_div;
+                p.C[phys * p.ldc + col] = act_rt(v + bv, p.act);
+            }
+        }
+    }
+}
+
+// ---- C[i,o] = sum_m A[idx[m], i0+i] B[idx[m], o] / div : slab per (i-tile, split) ----------------
+constexpr int BI = 128, BO = 64, BMK = 32;
+
+__global__ __launch_bounds__(256) void gemm_atb_tiled_kernel(const float *__restrict__ A, int64_t lda,
+                                                             const float *__restrict__ B, int64_t ldb,
+                                                             const int32_t *__restrict__ idx, float div,
+                                                             int64_t M, int KI, int NO, int64_t rows_per_split,
+                                                             float *__restrict__ slabs)
+{
+    __shared__ __attribute__((aligned(16))) float As[BMK * BI];
+    __shared__ __attribute__((aligned(16))) float Bs[BMK * BO];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r31 = lane & 31, h = lane >> 5;
+    const int i0 = blockIdx.x * BI;
+    const int o0 = blockIdx.z * BO;
+    const int64_t ms = (int64_t)blockIdx.y * rows_per_split, me = min(M, ms + rows_per_split);
+    const bool a_vec = (lda % 4 == 0) && ((uintptr_t)A % 16 == 0);
+    const bool b_vec = (ldb % 4 == 0) && ((uintptr_t)B % 16 == 0);
+    f32x16 acc[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
+
+    v4f ra[4], rb[2];
+    auto load_chunk = [&](int64_t mb) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {  // A chunk: 32 rows x 128 floats = 1024 v4f
+            const int t = it * 256 + tid, mm = t >> 5, q = t & 31;
+            const int64_t m = mb + mm;
+            const float *row = nullptr;
+            if (m < me) row = A + (idx ? (int64_t)idx[m] : m) * lda + i0 + 4 * q;
+            ra[it] = load4(row, KI - (i0 + 4 * q), a_vec);
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {  // B chunk: 32 rows x 64 floats = 512 v4f
+            const int t = it * 256 + tid, mm = t >> 4, q = t & 15;
+            const int64_t m = mb + mm;
+            const float *row = nullptr;
+            if (m < me) row = B + (idx ? (int64_t)idx[m] : m) * ldb + o0 + 4 * q;
+            rb[it] = load4(row, NO - (o0 + 4 * q), b_vec);
+        }
+    };
+    if (ms < me) load_chunk(ms);
+    for (int64_t mb = ms; mb < me; mb += BMK) {
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int t = it * 256 + tid;
+            *reinterpret_cast<v4f *>(As + (t >> 5) * BI + 4 * (t & 31)) = ra[it];
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int t = it * 256 + tid;
+            *reinterpret_cast<v4f *>(Bs + (t >> 4) * BO + 4 * (t & 15)) = rb[it];
+        }
+        __syncthreads();
+        if (mb + BMK < me) load_chunk(mb + BMK);
+        // MFMA step s consumes vertices 2s + h: A[i][k] = As[k][i], lanes along i -> conflict-free b32 reads
+#pragma unroll
+        for (int s = 0; s < BMK / 2; ++s) {
+            const int k = 2 * s + h;
+            const float a = As[k * BI + 32 * wave + r31];
+            const float b0 = Bs[k * BO + r31], b1 = Bs[k * BO + 32 + r31];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+        }
+    }
+    float *slab = slabs + (size_t)blockIdx.y * KI * NO;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int o = o0 + 32 * c + r31;
+        if (o >= NO) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = i0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (i < KI) slab[(size_t)i * NO + o] = div != 1.0f ? acc[c][r] / div : acc[c][r];
+        }
+    }
+}
+
+} // namespace
+
+namespace amp {
+
+int gemm_tiled(const TiledArgs &p)
+{
+    if (p.M <= 0 || p.N <= 0) return 0;
+    dim3 grid((unsigned)((p.M + BM - 1) / BM), (unsigned)((p.N + BN - 1) / BN));
+    hipLaunchKernelGGL(gemm_tiled_kernel, grid, dim3(256), 0, stream(), p);
+    AMP_LAUNCH_CHECK();
+    return 0;
+}
+
+int gemm_atb_tiled(const float *A, int64_t lda, const float *B, int64_t ldb, const int32_t *idx, float div, int64_t M,
+                   int KI, int NO, float *C, bool accumulate)
+{
+    const int n = KI * NO;
+    if (M <= 0) {
+        if (!accumulate) AMP_HIP(hipMemsetAsync(C, 0, sizeof(float) * n, stream()));
+        return 0;
+    }
+    const int n_it = (KI + BI - 1) / BI, n_ot = (NO + BO - 1) / BO;
+    int splits = (int)std::max<int64_t>(1, std::min<int64_t>((M + 255) / 256, std::max(1, 1024 / (n_it * n_ot))));
+    int64_t rps = (M + splits - 1) / splits;
+    rps = (rps + 1) & ~(int64_t)1;
+    splits = (int)((M + rps - 1) / rps);
+    void *ws = nullptr;
+    if (workspace(&ws, sizeof(float) * (size_t)splits * n, 6)) return 1;
+    hipLaunchKernelGGL(gemm_atb_tiled_kernel, dim3(n_it, splits, n_ot), dim3(256), 0, stream(), A, lda, B, ldb, idx, div,
+                       M, KI, NO, rps, (float *)ws);
+    AMP_LAUNCH_CHECK();
+    return slab_reduce((const float *)ws, splits, n, C, accumulate);
+}
+
+} // namespace amp

@@ -35,3 +35,76 @@ def kipf_inputs(n, F, seed=1):
     w = (np.random.Generator(np.random.PCG64(seed + 1)).standard_normal(F * F) * np.sqrt(2.0 / F)).astype(np.float32)
     dz = np.random.Generator(np.random.PCG64(seed + 2)).uniform(-1, 1, (n, F)).astype(np.float32)
     return x, w, dz
+
+
+def molecule_batch(n_graphs, seed=3):
+    """C3: QM9-shaped batch as ONE block-diagonal graph.  Vertices per graph ~
+    clip(round(N(18,3)),4,29); bonds = a random spanning tree (parent among the two previous atoms) +
+    Poisson(1.5) ring-closing bonds (5/6-rings) where both atoms have degree < 4; every vertex gets a
+    self-loop (edge id 0).  Returns (adj_ia, adj_ja, vertex_offsets[S+1], num_edges)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    nv = np.clip(np.rint(rng.normal(18, 3, n_graphs)), 4, 29).astype(np.int64)
+    voff = np.concatenate([[0], np.cumsum(nv)])
+    N = int(voff[-1])
+    gid = np.repeat(np.arange(n_graphs), nv)
+    loc = np.arange(N) - voff[gid]
+    # spanning tree
+    child = np.nonzero(loc >= 1)[0]
+    step = np.where(loc[child] >= 2, rng.integers(1, 3, child.size), 1)
+    parent = child - step
+    u = [parent]; v = [child]
+    deg = np.bincount(np.concatenate([parent, child]), minlength=N)
+    # ring closures
+    n_extra = rng.poisson(1.5, n_graphs)
+    g_rep = np.repeat(np.arange(n_graphs), n_extra)
+    span = rng.integers(4, 6, g_rep.size)
+    room = nv[g_rep] - span
+    ok = room > 0
+    g_rep, span, room = g_rep[ok], span[ok], room[ok]
+    a = voff[g_rep] + (rng.random(g_rep.size) * room).astype(np.int64)
+    b = a + span
+    key = a * 8 + span
+    _, first = np.unique(key, return_index=True)
+    a, b = a[np.sort(first)], b[np.sort(first)]
+    keep = (deg[a] < 4) & (deg[b] < 4)
+    a, b = a[keep], b[keep]
+    u.append(a); v.append(b)
+    u = np.concatenate(u); v = np.concatenate(v)
+    E = u.size
+    eid = np.arange(1, E + 1, dtype=np.int64)
+    loops = np.arange(N, dtype=np.int64)
+    src = np.concatenate([loops, u, v])
+    dst = np.concatenate([loops, v, u])
+    ee = np.concatenate([np.zeros(N, np.int64), eid, eid])
+    order = np.argsort(src, kind="stable")
+    src, dst, ee = src[order], dst[order], ee[order]
+    adj_ia = np.concatenate([[1], 1 + np.cumsum(np.bincount(src, minlength=N))]).astype(np.int32)
+    adj_ja = np.empty((2, src.size), np.int32, order="F")
+    adj_ja[0] = dst + 1
+    adj_ja[1] = ee
+    return adj_ia, adj_ja, voff.astype(np.int32), E
+
+
+def radius_graph(n_points, mean_degree=15.0, seed=4, dim=3):
+    """C4: points uniform in the unit cube, undirected radius graph with the radius
+    chosen for the requested mean degree, no self-loops; edge feature = x_i - x_j for the pair as
+    generated, shared by both directions (the reference's convention).
+    Returns (adj_ia, adj_ja, coords[E, dim])."""
+    from scipy.spatial import cKDTree
+
+    rng = np.random.Generator(np.random.PCG64(seed))
+    pts = rng.random((n_points, dim))
+    r = (mean_degree / (n_points * 4.0 / 3.0 * np.pi)) ** (1.0 / 3.0)
+    pairs = cKDTree(pts).query_pairs(r, output_type="ndarray")
+    i, j = pairs[:, 0].astype(np.int64), pairs[:, 1].astype(np.int64)
+    E = i.size
+    coords = (pts[i] - pts[j]).astype(np.float32)
+    eid = np.arange(1, E + 1, dtype=np.int64)
+    src = np.concatenate([i, j]); dst = np.concatenate([j, i]); ee = np.concatenate([eid, eid])
+    order = np.argsort(src, kind="stable")
+    src, dst, ee = src[order], dst[order], ee[order]
+    adj_ia = np.concatenate([[1], 1 + np.cumsum(np.bincount(src, minlength=n_points))]).astype(np.int32)
+    adj_ja = np.empty((2, src.size), np.int32, order="F")
+    adj_ja[0] = dst + 1
+    adj_ja[1] = ee
+    return adj_ia, adj_ja, coords

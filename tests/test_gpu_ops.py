@@ -134,7 +134,9 @@ def test_kipf_rectangular_block_with_explicit_degrees(dev, oracle):
 
 
 @pytest.mark.parametrize("N,Fi,Fo", [(1000, 128, 128), (4097, 64, 128), (333, 128, 64), (31, 32, 32), (5000, 64, 64),
-                                     (700, 6, 10), (513, 7, 6), (100, 256, 256), (257, 96, 40), (2000, 128, 32)])
+                                     (700, 6, 10), (513, 7, 6), (100, 256, 256), (257, 96, 40), (2000, 128, 32),
+                                     (3001, 256, 256), (2000, 72, 64), (5000, 64, 10), (5000, 10, 64), (1500, 4160, 64),
+                                     (900, 130, 258), (129, 9, 33)])
 def test_gemm_family_vs_float64(dev, oracle, N, Fi, Fo):
     """matmul is diffstruc's (unpinned by the reference's tests): exact-math fp32 GEMM, checked
     against float64 at 1e-5 and against the oracle's k-ordered fp32 sum"""
@@ -204,9 +206,14 @@ def test_duvenaud_update_and_grads(dev, oracle, Fi, Fo, mn, mx):
     g = DeviceGraph(ia, ja)
     c = H(ops.duvenaud_update(g, T(a, dev), T(w, dev), mn, mx, Fo))
     co = oracle.duvenaud_update(a, w, ia, mn, mx, Fo)
-    assert np.array_equal(c, co), f"update fwd not bit exact ({rel_err(c, co):.2e})"
     da = H(ops.duvenaud_update_bwd_a(g, T(up, dev), T(w, dev), mn, mx, Fi))
-    assert np.array_equal(da, oracle.duvenaud_update_bwd_a(up, w, ia, mn, mx, Fi))
+    dao = oracle.duvenaud_update_bwd_a(up, w, ia, mn, mx, Fi)
+    if Fi < 16 or Fo < 16:   # small layers: VALU kernels in the reference's operation order, bit-exact
+        assert np.array_equal(c, co), f"update fwd not bit exact ({rel_err(c, co):.2e})"
+        assert np.array_equal(da, dao)
+    else:                    # matrix-sized layers: degree-bucketed MFMA contraction (fma chain)
+        assert_close(c, co, 1e-5, "update fwd")
+        assert_close(da, dao, 1e-5, "update bwd_a")
     dw = H(ops.duvenaud_update_bwd_w(g, T(up, dev), T(a, dev), mn, mx))
     assert_close(dw, oracle.duvenaud_update_bwd_w(up, a, ia, mn, mx), 1e-5, "dW")
 
