@@ -81,3 +81,96 @@ def test_c2_dense_steps_vs_float64_sample(dev, c2):
     dW = ops.matmul_dw(P, dZ).cpu().numpy().reshape(F, F)
     ref = (P.double().T @ dZ.double()).cpu().numpy()      # float64 on device, only as the yardstick
     assert np.abs(dW - ref).max() <= 1e-5 * np.abs(ref).max()
+
+
+# ---- BASELINE configs[2]: Duvenaud, ~130k QM9-shaped graphs (perf dims F_v=64, F_e=8) ----------------
+@pytest.fixture(scope="module")
+def c3(dev):
+    from athena_amd import DeviceGraph, synth
+
+    ia, ja, voff, E = synth.molecule_batch(130_000)
+    return dict(ia=ia, ja=ja, voff=voff, E=E, N=ia.size - 1, g=DeviceGraph(ia, ja, n_edge_cols=E))
+
+
+def test_c3_duvenaud_step_properties(dev, oracle, c3):
+    from athena_amd import ops
+
+    rng = np.random.default_rng(0)
+    N, E, g = c3["N"], c3["E"], c3["g"]
+    Fv, Fe, O, mn, mx = 64, 8, 10, 1, 10
+    x = torch.from_numpy(rng.random((N, Fv), np.float32)).to(dev)
+    e = torch.from_numpy(rng.random((E, Fe), np.float32)).to(dev)
+    W = torch.from_numpy((rng.standard_normal(Fv * (Fv + Fe) * 10) * 0.1).astype(np.float32)).to(dev)
+    a = ops.duvenaud_propagate(g, x, e)
+    # oracle on the first 3000 graphs' rows (block-diagonal: they only reference their own vertices/edges)
+    nv = int(c3["voff"][3000]); ne = int(c3["ja"][1, : c3["ia"][nv] - 1].max())
+    ia_s, ja_s = c3["ia"][: nv + 1], c3["ja"][:, : c3["ia"][nv] - 1]
+    a_ref = oracle.duvenaud_propagate(x[:nv].cpu().numpy(), e[:ne].cpu().numpy(), ia_s, ja_s)
+    assert np.array_equal(a[:nv].cpu().numpy(), a_ref)
+    c = ops.duvenaud_update(g, a, W, mn, mx, Fv)
+    c_ref = oracle.duvenaud_update(a_ref, W.cpu().numpy(), ia_s, mn, mx, Fv)
+    assert np.abs(c[:nv].cpu().numpy() - c_ref).max() <= 1e-5 * np.abs(c_ref).max()
+    # adjoints of the bilinear update: <c, g> = <a, da> = <W, dW>
+    gup = torch.from_numpy(rng.uniform(-1, 1, (N, Fv)).astype(np.float32)).to(dev)
+    da = ops.duvenaud_update_bwd_a(g, gup, W, mn, mx, Fv + Fe)
+    dW = ops.duvenaud_update_bwd_w(g, gup, a, mn, mx)
+    lhs = (c.double() * gup.double()).sum().item()
+    scale = (c.double().abs() * gup.double().abs()).sum().item()
+    assert abs(lhs - (a.double() * da.double()).sum().item()) <= 1e-6 * scale
+    assert abs(lhs - (W.double() * dW.double()).sum().item()) <= 1e-6 * scale
+    # readout: softmax rows sum to one, so each graph's readout sums to its vertex count
+    R = torch.from_numpy((rng.standard_normal(O * Fv) * 0.1).astype(np.float32)).to(dev)
+    seg = torch.from_numpy(c3["voff"]).to(dev)
+    p, out = ops.softmax_segsum(ops.matmul(R, ops.activation("sigmoid", c), O), seg)
+    nvert = torch.from_numpy(np.diff(c3["voff"]).astype(np.float32)).to(dev)
+    assert torch.allclose(out.sum(1), nvert, rtol=1e-5)
+    # scatter adjoints: <propagate(x,e), g> = <x, dx> + <e, de>
+    g2 = torch.from_numpy(rng.uniform(-1, 1, (N, Fv + Fe)).astype(np.float32)).to(dev)
+    dx = ops.duvenaud_propagate_bwd_x(g, g2, Fv); de = ops.duvenaud_propagate_bwd_e(g, g2, Fv)
+    l2 = (a.double() * g2.double()).sum().item()
+    r2 = (x.double() * dx.double()).sum().item() + (e.double() * de.double()).sum().item()
+    assert abs(l2 - r2) <= 1e-6 * (a.double().abs() * g2.double().abs()).sum().item()
+
+
+# ---- BASELINE configs[3]: GNO on a 2M-point radius graph, ~30M CSR entries, F = H = 64 ------------------
+def test_c4_gno_properties_full_size(dev, oracle):
+    from athena_amd import DeviceGraph, ops, synth
+
+    N = 2_000_000
+    ia, ja, coords = synth.radius_graph(N)
+    E = coords.shape[0]
+    assert 25e6 < ja.shape[1] < 35e6
+    Fi = Fo = H = 64; d = 3
+    rng = np.random.default_rng(1)
+    g = DeviceGraph(ia, ja, n_edge_cols=E)
+    x = torch.from_numpy(rng.uniform(-1, 1, (N, Fi)).astype(np.float32)).to(dev)
+    co = torch.from_numpy(coords).to(dev)
+    theta = torch.from_numpy((0.3 * rng.standard_normal(H * d + H + Fo * Fi * H + Fo * Fi)).astype(np.float32)).to(dev)
+    gup = torch.from_numpy(rng.uniform(-1, 1, (N, Fo)).astype(np.float32)).to(dev)
+    m = ops.gno_aggregate(g, theta, co, x, d, H, Fo)
+    # the materialising oracle on 300 sampled rows (kappa only for the edge columns they touch)
+    rows = np.sort(rng.choice(N, 300, replace=False))
+    ent = np.concatenate([np.arange(ia[r] - 1, ia[r + 1] - 1) for r in rows])
+    ecols, inv = np.unique(ja[1, ent], return_inverse=True)
+    sia = np.concatenate([[1], 1 + np.cumsum(ia[rows + 1] - ia[rows])]).astype(np.int32)
+    ncols, cinv = np.unique(ja[0, ent], return_inverse=True)
+    sja = np.zeros((2, ent.size), np.int32, order="F"); sja[0] = cinv + 1; sja[1] = inv + 1
+    kap = oracle.gno_kernel_eval(coords[ecols - 1], theta.cpu().numpy(), H, Fo * Fi)
+    xs = x[torch.from_numpy(ncols - 1).to(dev)].cpu().numpy()
+    # rectangular: rows = sampled, cols = compacted neighbours -> pad the row count to use the square oracle
+    nsq = max(rows.size, ncols.size)
+    sia_sq = np.concatenate([sia, np.full(nsq - rows.size, sia[-1], np.int32)])
+    xs_sq = np.zeros((nsq, Fi), np.float32); xs_sq[: ncols.size] = xs
+    ref = oracle.gno_aggregate(xs_sq, kap, sia_sq, sja, Fo)[: rows.size]
+    got = m[torch.from_numpy(rows).to(dev)].cpu().numpy()
+    assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
+    # linear in x; adjoint <m, g> = <x, dx>; linear in Vaug: <m, g> = <Vaug, dVaug>
+    assert torch.allclose(ops.gno_aggregate(g, theta, co, 2.0 * x, d, H, Fo), 2.0 * m, rtol=1e-5, atol=1e-5 * m.abs().max().item())
+    dx = ops.gno_aggregate_bwd_x(g, theta, co, gup, d, H, Fi)
+    lhs = (m.double() * gup.double()).sum().item()
+    scale = (m.double().abs() * gup.double().abs()).sum().item()
+    assert abs(lhs - (x.double() * dx.double()).sum().item()) <= 1e-5 * scale
+    dth = ops.gno_aggregate_bwd_theta(g, theta, co, x, gup, d, H)
+    offV = H * d + H
+    assert abs(lhs - (theta[offV:].double() * dth[offV:].double()).sum().item()) <= 1e-5 * scale
+    assert torch.isfinite(dth).all()
