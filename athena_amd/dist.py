@@ -94,7 +94,7 @@ class Shard:
         self.col_deg = None
 
 
-def _p2p_exchange(send_bufs, recv_bufs, rank, world):
+def _p2p_start(send_bufs, recv_bufs, rank, world):
     ops = []
     for p in range(world):
         if p == rank:
@@ -103,9 +103,12 @@ def _p2p_exchange(send_bufs, recv_bufs, rank, world):
             ops.append(dist.P2POp(dist.isend, send_bufs[p], p))
         if recv_bufs[p] is not None and recv_bufs[p].numel() > 0:
             ops.append(dist.P2POp(dist.irecv, recv_bufs[p], p))
-    if ops:
-        for r in dist.batch_isend_irecv(ops):
-            r.wait()
+    return dist.batch_isend_irecv(ops) if ops else []
+
+
+def _p2p_exchange(send_bufs, recv_bufs, rank, world):
+    for r in _p2p_start(send_bufs, recv_bufs, rank, world):
+        r.wait()
 
 
 def build_plan(shard, device):
@@ -148,17 +151,27 @@ class HaloExchange:
         self.s, self.F, self.backend = shard, F, backend
         self.send_buf = torch.empty((int(shard.send_idx.numel()), F), dtype=torch.float32, device=device)
 
-    def __call__(self, x_ext):
+    def start(self, x_ext):
+        """pack + post the grouped sends/receives; returns the requests (RCCL runs them on its own
+        stream, so kernels enqueued before finish() overlap the transfer)"""
         s = self.s
         if s.world == 1:
-            return x_ext
+            return []
         n = s.n
         if self.send_buf.shape[0]:
             self.backend.gather_rows(x_ext[:n], s.send_idx, out=self.send_buf)   # pack (HIP gather kernel)
         roff, soff = s._roff, s._soff
-        _p2p_exchange([self.send_buf[soff[p]:soff[p + 1]] if p != s.rank else None for p in range(s.world)],
-                      [x_ext[n + roff[p]:n + roff[p + 1]] if p != s.rank else None for p in range(s.world)],
-                      s.rank, s.world)
+        return _p2p_start([self.send_buf[soff[p]:soff[p + 1]] if p != s.rank else None for p in range(s.world)],
+                          [x_ext[n + roff[p]:n + roff[p + 1]] if p != s.rank else None for p in range(s.world)],
+                          s.rank, s.world)
+
+    @staticmethod
+    def finish(reqs):
+        for r in reqs:
+            r.wait()
+
+    def __call__(self, x_ext):
+        self.finish(self.start(x_ext))
         return x_ext
 
 
@@ -216,11 +229,12 @@ class KipfShardStep:
         self.xchg(self.x_ext)
         b.kipf_propagate(self.g_fwd, self.x_ext, out=self.P)
         b.matmul(self.W, self.P, F, out=self.Z)
-        b.matmul_dw(self.P, self.dZ, out=self.dW)
+        b.matmul_dx(self.W, self.dZ, F, out=self.dP_ext[:n])
+        reqs = self.xchg.start(self.dP_ext)           # halo of dP in flight ...
+        b.matmul_dw(self.P, self.dZ, out=self.dW)     # ... under the dW contraction
         if s.world > 1:
             dist.all_reduce(self.dW)
-        b.matmul_dx(self.W, self.dZ, F, out=self.dP_ext[:n])
-        self.xchg(self.dP_ext)
+        self.xchg.finish(reqs)
         if self.exact:
             b.kipf_propagate(self.g_bwd, self.dP_ext, out=self.dX)
         else:
@@ -231,7 +245,8 @@ class KipfShardStep:
 def build_kipf_step(shard, F, device, backend=None):
     step = KipfShardStep(shard, F, device, backend)
     halo_bytes = 2 * shard.n_halo * F * 4
-    info = {"graph": "undirected pairs uniform over all N*vertices_per_gpu vertices" if abs(shard.cut - (shard.world - 1) / max(shard.world, 1)) < 1e-9
-            else f"{shard.cut:.3f} of the pairs cross partitions",
+    uniform = shard.world > 1 and abs(shard.cut - (shard.world - 1) / shard.world) < 1e-9
+    info = {"graph": "random graph, both endpoints uniform over all N*vertices_per_gpu vertices (no partition structure)" if uniform
+            else f"random graph with planted partitions: {shard.cut:.3f} of the undirected pairs cross partitions",
             "halo_rows_per_gpu": shard.n_halo, "halo_bytes_per_gpu_per_step": halo_bytes}
     return step, shard.nnz, info
