@@ -202,7 +202,8 @@ def make_weak_scaling_shard(rank, world, n, pairs, F, cut=None, device=None, see
 
 class KipfShardStep:
     """One interior Kipf layer fwd+bwd on a row shard (the bench step):
-         exchange(X); P = A^ X; Z = W P; dW = dZ P^T (all-reduce); dP = W^T dZ; exchange(dP); dX = A^T dP"""
+         exchange(X); (P, Z) = fused(A^ X, . W); exchange(dZ) under dW = dZ P^T (all-reduce);
+         dX = (A^T dZ) . W  (fused pull over the shard's rows)"""
 
     def __init__(self, shard, F, device, backend=None, seed=1, exact=False):
         self.s, self.F, self.device = shard, F, device
@@ -214,31 +215,27 @@ class KipfShardStep:
         rng = np.random.Generator(np.random.PCG64([seed, shard.rank]))
         self.x_ext = torch.empty((n + nh, F), dtype=torch.float32, device=device)
         self.x_ext[:n] = torch.from_numpy(rng.uniform(-1, 1, (n, F)).astype(np.float32)).to(device)
-        self.dZ = torch.from_numpy(rng.uniform(-1, 1, (n, F)).astype(np.float32)).to(device)
+        self.dZ_ext = torch.empty((n + nh, F), dtype=torch.float32, device=device)
+        self.dZ_ext[:n] = torch.from_numpy(rng.uniform(-1, 1, (n, F)).astype(np.float32)).to(device)
+        self.dZ = self.dZ_ext[:n]
         wr = np.random.Generator(np.random.PCG64(seed + 1))              # W identical on every rank
         self.W = torch.from_numpy((wr.standard_normal(F * F) * np.sqrt(2.0 / F)).astype(np.float32)).to(device)
         self.P = torch.empty((n, F), dtype=torch.float32, device=device)
         self.Z = torch.empty((n, F), dtype=torch.float32, device=device)
         self.dW = torch.empty(F * F, dtype=torch.float32, device=device)
-        self.dP_ext = torch.empty((n + nh, F), dtype=torch.float32, device=device)
         self.dX = torch.empty((n, F), dtype=torch.float32, device=device)
         self.xchg = HaloExchange(shard, F, device, self.b)
 
     def __call__(self):
         s, b, F, n = self.s, self.b, self.F, self.s.n
         self.xchg(self.x_ext)
-        b.kipf_propagate(self.g_fwd, self.x_ext, out=self.P)
-        b.matmul(self.W, self.P, F, out=self.Z)
-        b.matmul_dx(self.W, self.dZ, F, out=self.dP_ext[:n])
-        reqs = self.xchg.start(self.dP_ext)           # halo of dP in flight ...
+        b.kipf_layer_fwd(self.g_fwd, self.x_ext, self.W, F, P=self.P, Z=self.Z)
+        reqs = self.xchg.start(self.dZ_ext)           # halo of dZ in flight ...
         b.matmul_dw(self.P, self.dZ, out=self.dW)     # ... under the dW contraction
         if s.world > 1:
             dist.all_reduce(self.dW)
         self.xchg.finish(reqs)
-        if self.exact:
-            b.kipf_propagate(self.g_bwd, self.dP_ext, out=self.dX)
-        else:
-            b.neighbour_sum(self.g_bwd, self.dP_ext, out=self.dX)
+        b.pull_gemm(self.g_bwd, self.dZ_ext, self.W, F, exact=self.exact, out=self.dX)
         return self.dX
 
 

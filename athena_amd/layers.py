@@ -178,8 +178,8 @@ class kipf_msgpass_layer_type(msgpass_layer_type):
         self._tape = []
         cur = x
         for t in range(1, self.num_time_steps + 1):
-            p = ops.kipf_propagate(g, cur)
-            nxt = ops.matmul(self.params[t - 1], p, self.num_vertex_features[t], act=self.activation)
+            # aggregation + dense step (+ activation) in one launch where the fused kernel exists
+            p, nxt = ops.kipf_layer_fwd(g, cur, self.params[t - 1], self.num_vertex_features[t], act=self.activation)
             self._tape.append((p, nxt))
             cur = nxt
         self.output = cur
@@ -196,14 +196,11 @@ class kipf_msgpass_layer_type(msgpass_layer_type):
             p, out = self._tape[t - 1]
             dz = ops.activation_bwd(self.activation, out, gcur) if self.activation not in ("none", "linear") else gcur
             dw = ops.matmul_dw(p, dz)
-            self.grads[t - 1] = dw if self.grads[t - 1] is None or not self._accumulate else self.grads[t - 1] + dw
+            self.grads[t - 1] = dw
             if t == 1 and not need_input_grad:   # input layer output has requires_grad = .false.
                 return None
-            dp = ops.matmul_dx(self.params[t - 1], dz, self.num_vertex_features[t - 1])
-            gcur = ops.kipf_propagate_bwd(g, dp, exact=exact)
+            gcur = ops.kipf_layer_bwd_x(g, dz, self.params[t - 1], self.num_vertex_features[t - 1], exact=exact)
         return gcur
-
-    _accumulate = False
 
 
 # ==================================================================================================

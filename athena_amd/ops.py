@@ -108,6 +108,37 @@ def matmul_dx(W, dZ, Fi, out=None):
     return dP
 
 
+def kipf_layer_fwd(g: DeviceGraph, x, W, Fo, bias=None, act="none", P=None, Z=None):
+    """one Kipf time step in one launch: P = kipf_propagate(x), Z = act(P . Wt + bias)"""
+    Fi = x.shape[1]
+    _chk(x, (g.n_cols, Fi))
+    P = P if P is not None else torch.empty((g.n_rows, Fi), device=x.device, dtype=torch.float32)
+    Z = Z if Z is not None else torch.empty((g.n_rows, Fo), device=x.device, dtype=torch.float32)
+    _go()
+    _capi.call("athena_mp_kipf_layer_fwd", g.handle, Fi, Fo, _p(x), _p(_chk(W)), _p(bias), ACT[act], _p(P), _p(Z))
+    return P, Z
+
+
+def kipf_layer_bwd_x(g: DeviceGraph, dZ, W, Fi, exact=False, out=None):
+    """dX = A^T (dZ . W) in one launch (aggregate first, then contract)"""
+    Fo = dZ.shape[1]
+    _chk(dZ, (g.n_rows, Fo))
+    dX = out if out is not None else torch.empty((g.n_cols, Fi), device=dZ.device, dtype=torch.float32)
+    _go()
+    _capi.call("athena_mp_kipf_layer_bwd_x", g.handle, Fi, Fo, _p(dZ), _p(_chk(W)), int(bool(exact)), _p(dX))
+    return dX
+
+
+def pull_gemm(g: DeviceGraph, dZ, W, Fi, exact=False, out=None):
+    """dX[v,:] = (sum over the forward row v of g of dZ[col,:]) . W -- shard backward (dist.py)"""
+    Fo = dZ.shape[1]
+    _chk(dZ, (g.n_cols, Fo))
+    dX = out if out is not None else torch.empty((g.n_rows, Fi), device=dZ.device, dtype=torch.float32)
+    _go()
+    _capi.call("athena_mp_pull_gemm", g.handle, Fi, Fo, _p(dZ), _p(_chk(W)), int(bool(exact)), _p(dX))
+    return dX
+
+
 def activation(kind, z, out=None):
     y = out if out is not None else torch.empty_like(z)
     _go()

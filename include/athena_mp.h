@@ -102,6 +102,22 @@ int athena_mp_gemm_dw(int64_t N, int32_t Fi, int32_t Fo, const float *P_dev, con
 int athena_mp_gemm_dx(int64_t N, int32_t Fi, int32_t Fo, const float *dZ_dev, const float *W_dev,
                       float *dP_dev);
 
+/* ---- fused Kipf layer step (one launch: aggregation + dense contraction, W resident in LDS) ------
+ * update_message_kipf, athena_kipf_msgpass_layer.f90:943-952, one time step:
+ *   P = kipf_propagate(X) (returned: the reverse pass needs it for dW),  Z = act(P . Wt + bias)     */
+int athena_mp_kipf_layer_fwd(const athena_mp_graph *g, int32_t Fi, int32_t Fo, const float *x_dev,
+                             const float *W_dev, const float *bias_dev, int32_t act, float *P_dev,
+                             float *Z_dev);
+/* reverse of the same step wrt its input: dX = A^T (dZ . W) evaluated as (A^T dZ) . W
+ * (dZ = gradient at the pre-activation; exact as in athena_mp_kipf_propagate_bwd) */
+int athena_mp_kipf_layer_bwd_x(const athena_mp_graph *g, int32_t Fi, int32_t Fo, const float *dZ_dev,
+                               const float *W_dev, int32_t exact, float *dX_dev);
+
+/* same contraction over the FORWARD rows of a (rectangular) shard graph: dX[v,:] = (sum_w [coef] dZ[col[w],:]) . W
+ * -- the backward of a row partition whose rows list their sources (athena_amd/dist.py) */
+int athena_mp_pull_gemm(const athena_mp_graph *g, int32_t Fi, int32_t Fo, const float *dZ_dev,
+                        const float *W_dev, int32_t exact, float *dX_dev);
+
 /* ---- element-wise brackets of the path -------------- */
 int athena_mp_activation_fwd(int32_t act, int64_t n, const float *z_dev, float *y_dev);
 int athena_mp_activation_bwd(int32_t act, int64_t n, const float *y_dev, const float *g_dev, float *dz_dev);

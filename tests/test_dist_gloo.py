@@ -39,8 +39,17 @@ class OracleBackend:
         ones_r, ones_c = np.ones(g.n_rows, np.int32), np.ones(g.n_cols, np.int32)   # coefficient 1
         out.copy_(torch.from_numpy(self.o.kipf_propagate_rect(x.numpy(), g.ia, g.ja, ones_r, ones_c)))
 
-    def matmul(self, W, P, Fo, out):
-        out.copy_(torch.from_numpy(self.o.matmul(W.numpy(), P.numpy(), Fo)))
+    def kipf_layer_fwd(self, g, x, W, Fo, P, Z):
+        self.kipf_propagate(g, x, P)
+        Z.copy_(torch.from_numpy(self.o.matmul(W.numpy(), P.numpy(), Fo)))
+
+    def pull_gemm(self, g, dz_ext, W, Fi, exact, out):
+        t = torch.empty((g.n_rows, dz_ext.shape[1]))
+        if exact:
+            self.kipf_propagate(g, dz_ext, t)
+        else:
+            self.neighbour_sum(g, dz_ext, t)
+        out.copy_(torch.from_numpy(self.o.matmul_dx(W.numpy(), t.numpy(), Fi)))
 
     def matmul_dw(self, P, dZ, out):
         out.copy_(torch.from_numpy(self.o.matmul_dw(dZ.numpy(), P.numpy())))
@@ -110,7 +119,8 @@ def test_two_rank_kipf_step_matches_global_oracle(oracle, cut):
     assert np.array_equal(np.concatenate([res[r]["Z"] for r in range(world)]), oracle.matmul(w, P, F))
     dP = oracle.matmul_dx(w, dz, F)
     dX = oracle.kipf_propagate_bwd(dP, ia, ja)                                             # reference: no coefficient
-    assert np.array_equal(np.concatenate([res[r]["dX"] for r in range(world)]), dX)
+    got = np.concatenate([res[r]["dX"] for r in range(world)])                             # (A^T dZ) W: same map,
+    assert np.abs(got - dX).max() <= 1e-5 * np.abs(dX).max()                               # re-associated
     dW = oracle.matmul_dw(dz, P)
     for r in range(world):
         assert np.abs(res[r]["dW"] - dW).max() <= 1e-5 * np.abs(dW).max()                  # all-reduced

@@ -289,3 +289,42 @@ def test_gno_reassociated_vs_materialising_oracle(dev, oracle, N, d, H, Fi, Fo, 
 
 def H_(t):
     return t.cpu().numpy()
+
+
+@pytest.mark.parametrize("act", ["none", "relu"])
+def test_fused_kipf_layer_kernels(dev, oracle, act):
+    """one-launch aggregation + dense step: P bit-exact vs the oracle's kipf_propagate, Z and dX within
+    1e-5 of the oracle's unfused order (incl. a hub row, zero-degree rows, a ragged tail chunk)"""
+    from athena_amd import DeviceGraph, ops
+
+    n, F = 4133, 128
+    ia, ja = random_graph(n, 5 * n, seed=77, self_loops=True, isolated=9)
+    # add a hub: vertex 1 gets 700 extra symmetric neighbours
+    rng = np.random.default_rng(3)
+    extra = rng.integers(2, n - 9, 700)
+    rows = np.repeat(np.arange(1, n + 1), np.diff(ia))
+    src = np.concatenate([rows, np.ones(700, np.int64), extra]); dst = np.concatenate([ja[0], extra, np.ones(700, np.int64)])
+    order = np.argsort(src, kind="stable")
+    ia = np.concatenate([[1], 1 + np.cumsum(np.bincount(src - 1, minlength=n))]).astype(np.int32)
+    ja = np.zeros((2, src.size), np.int32, order="F"); ja[0] = dst[order]
+    x = rng.uniform(-1, 1, (n, F)).astype(np.float32)
+    w = (rng.standard_normal(F * F) * np.sqrt(2.0 / F)).astype(np.float32)
+    b = rng.standard_normal(F).astype(np.float32)
+    dz = rng.uniform(-1, 1, (n, F)).astype(np.float32)
+    g = DeviceGraph(ia, ja, n_edge_cols=0)
+    P, Z = ops.kipf_layer_fwd(g, T(x, dev), T(w, dev), F, bias=T(b, dev), act=act)
+    Po = oracle.kipf_propagate(x, ia, ja)
+    assert np.array_equal(H(P), Po)
+    assert_close(H(Z), oracle.activation(act, oracle.add_bias_rows(oracle.matmul(w, Po, F), b)), 1e-5, "fused Z")
+    for exact in (False, True):
+        dX = H(ops.kipf_layer_bwd_x(g, T(dz, dev), T(w, dev), F, exact=exact))
+        ref = oracle.kipf_propagate_bwd(oracle.matmul_dx(w, dz, F), ia, ja, exact=exact)
+        assert_close(dX, ref, 1e-5, f"fused dX exact={exact}")
+    # other widths take the two-kernel route behind the same entry points
+    x2 = rng.uniform(-1, 1, (n, 64)).astype(np.float32); w2 = rng.standard_normal(64 * 32).astype(np.float32)
+    P2, Z2 = ops.kipf_layer_fwd(g, T(x2, dev), T(w2, dev), 32)
+    assert np.array_equal(H(P2), oracle.kipf_propagate(x2, ia, ja))
+    assert_close(H(Z2), oracle.matmul(w2, H(P2), 32), 1e-5)
+    dz2 = rng.uniform(-1, 1, (n, 32)).astype(np.float32)
+    assert_close(H(ops.kipf_layer_bwd_x(g, T(dz2, dev), T(w2, dev), 64)),
+                 oracle.kipf_propagate_bwd(oracle.matmul_dx(w2, dz2, 64), ia, ja), 1e-5)
