@@ -85,6 +85,103 @@ __global__ __launch_bounds__(256) void gno_outer_kernel(const int32_t *__restric
     }
 }
 
+// ---- MFMA form of the outer-product accumulation (H, F multiples of 32, <= 64; d <= 4) -----------
+// One wave per vertex.  S_i = Hm^T X with the row's entries as the contraction index:
+//   v_mfma_f32_32x32x2_f32: A[k][e] = h_e[k] (computed on the fly by the lane that owns k),
+//                           B[e][q] = y_j[q] (128 B coalesced loads, two entries per step).
+// The bias row S_i[H,:] = sum_j y_j is accumulated on the VALU from the same loads.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int HT, int QT>
+__global__ __launch_bounds__(256) void gno_outer_mfma_kernel(const int32_t *__restrict__ rowptr,
+                                                             const int32_t *__restrict__ idx,
+                                                             const int32_t *__restrict__ eidx,
+                                                             const float *__restrict__ y,
+                                                             const float *__restrict__ coords,
+                                                             const float *__restrict__ theta, int d, int r0,
+                                                             int n_rows_tile, float *__restrict__ S)
+{
+    constexpr int H = 32 * HT, Fy = 32 * QT, R = (H + 1) * Fy;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r31 = lane & 31, h = lane >> 5;
+    const int lr = blockIdx.x * 4 + wave;
+    if (lr >= n_rows_tile) return;
+    const int row = r0 + lr;
+    // this lane's rows of U and b_u (k = 32 t + r31)
+    float Uk[HT][4], bk[HT];
+#pragma unroll
+    for (int t = 0; t < HT; ++t) {
+        bk[t] = theta[(size_t)H * d + 32 * t + r31];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Uk[t][j] = j < d ? theta[(32 * t + r31) + (size_t)H * j] : 0.0f;
+    }
+    f32x16 acc[HT][QT];
+#pragma unroll
+    for (int a = 0; a < HT; ++a)
+#pragma unroll
+        for (int b = 0; b < QT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    float sb[QT];
+#pragma unroll
+    for (int b = 0; b < QT; ++b) sb[b] = 0.0f;
+
+    const int w0 = rowptr[row], w1 = rowptr[row + 1];
+    for (int wb = w0; wb < w1; wb += 64) {
+        const int nb = min(64, w1 - wb);
+        int my_j = -1, my_e = -1;
+        if (lane < nb) { my_j = idx[wb + lane]; my_e = eidx[wb + lane]; }
+        constexpr int U4 = 4;
+        for (int s0 = 0; s0 < (nb + 1) / 2; s0 += U4) {
+            float yv[U4][QT], dx[U4][4];
+            bool ok[U4];
+#pragma unroll
+            for (int u = 0; u < U4; ++u) {
+                const int ent = 2 * (s0 + u) + h;
+                const int j = __shfl(my_j, ent), e = __shfl(my_e, ent);
+                ok[u] = ent < nb && e >= 0;
+#pragma unroll
+                for (int b = 0; b < QT; ++b) yv[u][b] = ok[u] ? y[(size_t)j * Fy + 32 * b + r31] : 0.0f;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) dx[u][jj] = (ok[u] && jj < d) ? coords[(size_t)e * d + jj] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < U4; ++u) {
+                float hv[HT];
+#pragma unroll
+                for (int t = 0; t < HT; ++t) {
+                    float sacc = 0.0f;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) sacc = sacc + Uk[t][jj] * dx[u][jj];   // j-ordered, as :88-90
+                    sacc = sacc + bk[t];
+                    hv[t] = (ok[u] && sacc > 0.0f) ? sacc : 0.0f;
+                }
+#pragma unroll
+                for (int b = 0; b < QT; ++b) sb[b] = sb[b] + yv[u][b];
+#pragma unroll
+                for (int t = 0; t < HT; ++t)
+#pragma unroll
+                    for (int b = 0; b < QT; ++b)
+                        acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(hv[t], yv[u][b], acc[t][b], 0, 0, 0);
+            }
+        }
+    }
+    float *out = S + (size_t)lr * R;
+#pragma unroll
+    for (int t = 0; t < HT; ++t)
+#pragma unroll
+        for (int b = 0; b < QT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+                out[(size_t)k * Fy + 32 * b + r31] = acc[t][b][r];
+            }
+#pragma unroll
+    for (int b = 0; b < QT; ++b) {
+        const float tot = sb[b] + __shfl_xor(sb[b], 32);
+        if (h == 0) out[(size_t)H * Fy + 32 * b + r31] = tot;
+    }
+}
+
 // B2[(k*Fo + o)*Fi + q] = Vaug[F*k + o + Fo*q]
 __global__ void gno_perm_kernel(const float *__restrict__ vaug, int H1, int Fi, int Fo, float *__restrict__ B2)
 {
@@ -174,14 +271,109 @@ __global__ __launch_bounds__(256) void gno_dh_kernel(const int32_t *__restrict__
     for (int t = threadIdx.x; t < np; t += 256) slabs[(size_t)blockIdx.x * np + t] = part[t];
 }
 
-__global__ void gno_slab_reduce_kernel(const float *__restrict__ slabs, int n_slabs, int n, float *__restrict__ out,
-                                       int accumulate)
+// ---- MFMA form of the kernel-MLP backward (H, F_in multiples of 32, <= 64; d <= 3) -----------------
+// One wave per vertex i, entries in tiles of 32:
+//   DH^T[e][k] = sum_q x_{j(e)}[q] G_i[k][q]                 (A = gathered neighbour rows, B = G_i^T)
+//   GH = relu'(U dx_e + b_u) . DH^T                          (mask applied in the C layout)
+//   dU^T[j][k] += sum_e dx_e[j] GH[e][k],  db_u[k] += sum_e GH[e][k]
+//        -> second MFMA that takes the GH accumulator tile directly as its B operand (register r of
+//           lane half h is row e = (r&3) + 8(r>>2) + 4h), A[j][e] = dx_e[j] for j < d and 1 for j = d.
+// dU^T / db_u stay in accumulators across all vertices of the wave: one slab per wave, no atomics.
+typedef float v4f_g __attribute__((ext_vector_type(4)));
+
+template <int HT, int QT>
+__global__ __launch_bounds__(256) void gno_dh_mfma_kernel(const int32_t *__restrict__ rowptr,
+                                                          const int32_t *__restrict__ col,
+                                                          const int32_t *__restrict__ eid,
+                                                          const float *__restrict__ x,
+                                                          const float *__restrict__ coords,
+                                                          const float *__restrict__ theta, int d,
+                                                          const float *__restrict__ G, int r0, int n_rows_tile,
+                                                          float *__restrict__ slabs, float *__restrict__ ghbuf)
 {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    float s = 0.0f;
-    for (int b = 0; b < n_slabs; ++b) s = s + slabs[(size_t)b * n + t];
-    out[t] = accumulate ? out[t] + s : s;
+    constexpr int H = 32 * HT, Fi = 32 * QT, HF = Fi / 2;   // lane half h owns q in [HF*h, HF*h + HF)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r31 = lane & 31, h = lane >> 5;
+    const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+    float Uk[HT][3], bk[HT];
+#pragma unroll
+    for (int t = 0; t < HT; ++t) {
+        bk[t] = theta[(size_t)H * d + 32 * t + r31];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Uk[t][j] = j < d ? theta[(32 * t + r31) + (size_t)H * j] : 0.0f;
+    }
+    f32x16 du[HT];
+#pragma unroll
+    for (int t = 0; t < HT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) du[t][r] = 0.0f;
+
+    for (int lr = gw; lr < n_rows_tile; lr += nw) {
+        const int row = r0 + lr;
+        const int w0 = rowptr[row], w1 = rowptr[row + 1];
+        if (w0 == w1) continue;
+        // B operand: G_i[k = 32t + r31][HF*h + s], s = 0..HF-1
+        float gf[HT][HF];
+#pragma unroll
+        for (int t = 0; t < HT; ++t)
+#pragma unroll
+            for (int m = 0; m < HF / 4; ++m) {
+                const v4f_g v = *reinterpret_cast<const v4f_g *>(G + ((size_t)lr * H + 32 * t + r31) * Fi + HF * h + 4 * m);
+                gf[t][4 * m] = v.x; gf[t][4 * m + 1] = v.y; gf[t][4 * m + 2] = v.z; gf[t][4 * m + 3] = v.w;
+            }
+        for (int wb = w0; wb < w1; wb += 32) {
+            const int nb = min(32, w1 - wb);
+            const int my_j = r31 < nb ? col[wb + r31] : -1;
+            const int my_e = r31 < nb ? eid[wb + r31] : -1;
+            // A operand: x_{j(e = r31)}[HF*h + s]
+            float xf[HF];
+#pragma unroll
+            for (int m = 0; m < HF / 4; ++m) {
+                v4f_g v = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (my_j >= 0 && my_e >= 0) v = *reinterpret_cast<const v4f_g *>(x + (size_t)my_j * Fi + HF * h + 4 * m);
+                xf[4 * m] = v.x; xf[4 * m + 1] = v.y; xf[4 * m + 2] = v.z; xf[4 * m + 3] = v.w;
+            }
+            f32x16 dh[HT];
+#pragma unroll
+            for (int t = 0; t < HT; ++t) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dh[t][r] = 0.0f;
+#pragma unroll
+                for (int s2 = 0; s2 < HF; ++s2) dh[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xf[s2], gf[t][s2], dh[t], 0, 0, 0);
+            }
+            // mask + the A operand of the second product, register by register
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int e_loc = (r & 3) + 8 * (r >> 2) + 4 * h;          // entry of this register's row
+                const int ee = __shfl(my_e, e_loc);                        // lanes 0..31 hold the tile's entries
+                const bool ok = e_loc < nb && ee >= 0;
+                float dx[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    if (ok && j < d) dx[j] = coords[(size_t)ee * d + j];
+                float amat = 0.0f;                                         // A[j = r31][e] : dx_e[j] | 1 | 0
+                if (ok) amat = r31 < d ? (r31 == 0 ? dx[0] : (r31 == 1 ? dx[1] : dx[2])) : (r31 == d ? 1.0f : 0.0f);
+#pragma unroll
+                for (int t = 0; t < HT; ++t) {
+                    float pre = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) pre = pre + Uk[t][j] * dx[j];
+                    pre = pre + bk[t];
+                    const float gh = (ok && pre > 0.0f) ? dh[t][r] : 0.0f;
+                    if (ghbuf && e_loc < nb) ghbuf[(size_t)(wb + e_loc) * H + 32 * t + r31] = gh;
+                    du[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(amat, gh, du[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // slab[j*H + k]: rows j = 0..d of the accumulator (registers 0..3 of lane half 0)
+    float *slab = slabs + (size_t)gw * (H * d + H);
+    if (h == 0) {
+#pragma unroll
+        for (int t = 0; t < HT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (r <= d) slab[(size_t)r * H + 32 * t + r31] = du[t][r];
+    }
 }
 
 // dcoords[e, j] = sum_{entries w carrying e} sum_k U[k + H*j] gh[w, k]
@@ -204,6 +396,17 @@ int launch_outer(const int32_t *rowptr, const int32_t *idx, const int32_t *eidx,
                  const float *coords, const float *theta, int d, int H, int r0, int rows, float *S)
 {
     const int R = (H + 1) * Fy;
+    if (H % 32 == 0 && Fy % 32 == 0 && H <= 64 && Fy <= 64 && d <= 4) {
+        dim3 g4((rows + 3) / 4), b4(256);
+#define AMP_OM(A_, B_)                                                                                   \
+    if (H == 32 * A_ && Fy == 32 * B_)                                                                   \
+        hipLaunchKernelGGL((gno_outer_mfma_kernel<A_, B_>), g4, b4, 0, amp::stream(), rowptr, idx, eidx, y, coords, \
+                           theta, d, r0, rows, S);
+        AMP_OM(1, 1) AMP_OM(1, 2) AMP_OM(2, 1) AMP_OM(2, 2)
+#undef AMP_OM
+        AMP_LAUNCH_CHECK();
+        return 0;
+    }
     const size_t lds = sizeof(float) * kEB * (size_t)(H + 1 + Fy);
     dim3 grid(rows), block(256);
 #define AMP_OUT(E_)                                                                                      \
@@ -272,18 +475,30 @@ int gno_mlp_backward(const athena_mp_graph *g, int d, int H, int Fi, int Fo, con
         int rc = amp::gemm_dispatch(grad + (size_t)r0 * Fo, theta + off_V, 1, nullptr, ATHENA_MP_ACT_NONE,
                                     (float *)gw, rows, Fo, HF);
         if (rc) return rc;
-        int nblk = std::min(rows, 2048);
-        int rpb = (rows + nblk - 1) / nblk;
-        nblk = (rows + rpb - 1) / rpb;
+        int nblk;
         void *sl = nullptr;
-        if (amp::workspace(&sl, sizeof(float) * (size_t)nblk * np, 3)) return 1;
-        hipLaunchKernelGGL(gno_dh_kernel, dim3(nblk), dim3(256), lds, amp::stream(), g->rowptr, g->col, g->eid, x, Fi,
-                           coords, theta, d, H, (const float *)gw, r0, rows, rpb, (float *)sl, ghbuf);
+        const bool mf = H % 32 == 0 && Fi % 32 == 0 && H <= 64 && Fi <= 64 && d <= 3;
+        if (mf) {
+            nblk = std::min((rows + 3) / 4, 512);      // 4 waves per workgroup, one slab per wave
+            if (amp::workspace(&sl, sizeof(float) * (size_t)nblk * 4 * np, 3)) return 1;
+#define AMP_DH(A_, B_)                                                                                     \
+    if (H == 32 * A_ && Fi == 32 * B_)                                                                     \
+        hipLaunchKernelGGL((gno_dh_mfma_kernel<A_, B_>), dim3(nblk), dim3(256), 0, amp::stream(), g->rowptr, g->col, \
+                           g->eid, x, coords, theta, d, (const float *)gw, r0, rows, (float *)sl, ghbuf);
+            AMP_DH(1, 1) AMP_DH(1, 2) AMP_DH(2, 1) AMP_DH(2, 2)
+#undef AMP_DH
+            nblk *= 4;
+        } else {
+            nblk = std::min(rows, 512);
+            int rpb = (rows + nblk - 1) / nblk;
+            nblk = (rows + rpb - 1) / rpb;
+            if (amp::workspace(&sl, sizeof(float) * (size_t)nblk * np, 3)) return 1;
+            hipLaunchKernelGGL(gno_dh_kernel, dim3(nblk), dim3(256), lds, amp::stream(), g->rowptr, g->col, g->eid, x, Fi,
+                               coords, theta, d, H, (const float *)gw, r0, rows, rpb, (float *)sl, ghbuf);
+        }
         AMP_LAUNCH_CHECK();
         if (dtheta) {
-            hipLaunchKernelGGL(gno_slab_reduce_kernel, dim3((np + 255) / 256), dim3(256), 0, amp::stream(),
-                               (const float *)sl, nblk, np, dtheta, first ? 0 : 1);
-            AMP_LAUNCH_CHECK();
+            if (int rc2 = amp::slab_reduce((const float *)sl, nblk, np, dtheta, !first)) return rc2;
         }
         first = false;
     }
