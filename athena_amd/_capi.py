@@ -65,6 +65,22 @@ _PROTOS = {
     "athena_mp_kipf_propagate_fwd_host": [_vp, _i32, _vp, _vp],
     "athena_mp_kipf_propagate_bwd_host": [_vp, _i32, _vp, _vp, _i32],
     "athena_mp_gemm_fwd_host": [_i64, _i32, _i32, _vp, _vp, _vp, _i32, _vp],
+    "athena_mp_gemm_dw_host": [_i64, _i32, _i32, _vp, _vp, _vp],
+    "athena_mp_gemm_dx_host": [_i64, _i32, _i32, _vp, _vp, _vp],
+    "athena_mp_activation_fwd_host": [_i32, _i64, _vp, _vp],
+    "athena_mp_activation_bwd_host": [_i32, _i64, _vp, _vp, _vp],
+    "athena_mp_duvenaud_propagate_fwd_host": [_vp, _i32, _i32, _vp, _vp, _vp],
+    "athena_mp_duvenaud_propagate_bwd_x_host": [_vp, _i32, _i32, _vp, _vp],
+    "athena_mp_duvenaud_propagate_bwd_e_host": [_vp, _i32, _i32, _vp, _vp],
+    "athena_mp_duvenaud_update_fwd_host": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
+    "athena_mp_duvenaud_update_bwd_a_host": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
+    "athena_mp_duvenaud_update_bwd_w_host": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
+    "athena_mp_softmax_segsum_fwd_host": [_i32, _i64, _i32, _vp, _vp, _vp, _vp, _i32],
+    "athena_mp_softmax_segsum_bwd_host": [_i32, _i64, _i32, _vp, _vp, _vp, _vp],
+    "athena_mp_gno_aggregate_fwd_host": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
+    "athena_mp_gno_aggregate_bwd_x_host": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
+    "athena_mp_gno_aggregate_bwd_theta_host": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
+    "athena_mp_gno_aggregate_bwd_coords_host": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
 }
 
 

@@ -16,6 +16,8 @@ module athena_mp_c
   public :: athena_mp_graph_create, athena_mp_graph_destroy
   public :: athena_mp_kipf_propagate_fwd_host, athena_mp_kipf_propagate_bwd_host
   public :: athena_mp_gemm_fwd_host
+  public :: athena_mp_duvenaud_propagate_fwd_host, athena_mp_duvenaud_propagate_bwd_x_host
+  public :: athena_mp_duvenaud_update_fwd_host
   public :: athena_mp_malloc, athena_mp_free, athena_mp_memcpy_h2d, athena_mp_memcpy_d2h
   public :: athena_mp_kipf_propagate_fwd, athena_mp_kipf_propagate_bwd
   public :: athena_mp_gemm_fwd, athena_mp_gemm_dw, athena_mp_gemm_dx
@@ -78,6 +80,34 @@ module athena_mp_c
        real(c_float), intent(in) :: P(*), W(*)
        type(c_ptr), value :: bias
        real(c_float), intent(inout) :: Z(*)
+     end function
+
+     !! duvenaud_propagate, athena_diffstruc_extd_sub_duvenaud.f90:7-59
+     pure integer(c_int) function athena_mp_duvenaud_propagate_fwd_host(graph, Fv, Fe, x, e, c) &
+          bind(C, name="athena_mp_duvenaud_propagate_fwd_host")
+       import :: c_int, c_int32_t, c_ptr, c_float
+       type(c_ptr), value :: graph
+       integer(c_int32_t), value :: Fv, Fe
+       real(c_float), intent(in) :: x(*), e(*)
+       real(c_float), intent(inout) :: c(*)
+     end function
+     !! get_partial_duvenaud_propagate_left_val, :115-141
+     pure integer(c_int) function athena_mp_duvenaud_propagate_bwd_x_host(graph, Fv, Fe, grad, dx) &
+          bind(C, name="athena_mp_duvenaud_propagate_bwd_x_host")
+       import :: c_int, c_int32_t, c_ptr, c_float
+       type(c_ptr), value :: graph
+       integer(c_int32_t), value :: Fv, Fe
+       real(c_float), intent(in) :: grad(*)
+       real(c_float), intent(inout) :: dx(*)
+     end function
+     !! duvenaud_update, :176-228
+     pure integer(c_int) function athena_mp_duvenaud_update_fwd_host(graph, Fi, Fo, min_deg, max_deg, a, w, c) &
+          bind(C, name="athena_mp_duvenaud_update_fwd_host")
+       import :: c_int, c_int32_t, c_ptr, c_float
+       type(c_ptr), value :: graph
+       integer(c_int32_t), value :: Fi, Fo, min_deg, max_deg
+       real(c_float), intent(in) :: a(*), w(*)
+       real(c_float), intent(inout) :: c(*)
      end function
 
      !! device-resident variants (phase 2: tensors stay in HBM between consecutive HIP layers)

@@ -19,6 +19,7 @@ program test_athena_mp
 
   call identity_kat()
   call six_vertex_graph()
+  call duvenaud_five_vertex_graph()
 
   rc = athena_mp_finalize()
   if(success)then
@@ -136,5 +137,84 @@ contains
     end if
     rc = athena_mp_graph_destroy(graph)
   end subroutine six_vertex_graph
+
+  subroutine duvenaud_five_vertex_graph()
+    !! test/test_msgpass_network.f90:249-276: 5 vertices, 6 edges, 8 vertex and 2 edge features;
+    !! duvenaud_propagate / duvenaud_update restated inline (athena_diffstruc_extd_sub_duvenaud.f90:34-42,205-211)
+    integer, parameter :: nv = 5, ne = 6, fv = 8, fe = 2, fo = 3, mind = 1, maxd = 3
+    integer :: index_list(2,ne), deg(nv), pos(nv), v, w, e, u, dd, i
+    integer(c_int32_t) :: adj_ia(nv+1), adj_ja(2,2*ne)
+    real(real32) :: x(fv,nv), ef(fe,ne), c(fv+fe,nv), cref(fv+fe,nv), wgt(fo*(fv+fe)*(maxd-mind+1))
+    real(real32) :: z(fo,nv), zref(fo,nv), g(fv+fe,nv), dx(fv,nv), dxref(fv,nv)
+    real(real32), pointer :: w_ptr(:,:)
+    real(real32), target :: wt(fo*(fv+fe)*(maxd-mind+1))
+    index_list(:,1) = [1, 2]; index_list(:,2) = [1, 3]; index_list(:,3) = [2, 3]
+    index_list(:,4) = [2, 4]; index_list(:,5) = [3, 5]; index_list(:,6) = [4, 5]
+    x(1,:) = [1.0, 2.0, 3.0, 4.0, 5.0]; x(2,:) = [0.1, 0.2, 0.3, 0.4, 0.5]
+    x(3,:) = [1.1, 1.2, 1.3, 1.4, 1.5]; x(4,:) = [0.5, 0.4, 0.3, 0.2, 0.1]
+    x(5,:) = [2.0, 1.8, 1.6, 1.4, 1.2]; x(6,:) = [0.0, 0.1, 0.2, 0.3, 0.4]
+    x(7,:) = [1.0, 0.9, 0.8, 0.7, 0.6]; x(8,:) = [0.2, 0.4, 0.6, 0.8, 1.0]
+    ef(1,:) = [0.1, 0.2, 0.3, 0.4, 0.5, 0.6]; ef(2,:) = [1.1, 1.2, 1.3, 1.4, 1.5, 1.6]
+    deg = 0
+    do e = 1, ne
+       deg(index_list(1,e)) = deg(index_list(1,e)) + 1
+       deg(index_list(2,e)) = deg(index_list(2,e)) + 1
+    end do
+    adj_ia(1) = 1
+    do v = 1, nv
+       adj_ia(v+1) = adj_ia(v) + deg(v)
+    end do
+    pos = adj_ia(1:nv)
+    do e = 1, ne
+       u = index_list(1,e); v = index_list(2,e)
+       adj_ja(:,pos(u)) = [v, e]; pos(u) = pos(u) + 1
+       adj_ja(:,pos(v)) = [u, e]; pos(v) = pos(v) + 1
+    end do
+    do i = 1, size(wgt)
+       wgt(i) = 0.02_real32 * real(mod(7*i, 23), real32) - 0.2_real32
+    end do
+    wt = wgt
+    do v = 1, nv
+       cref(:,v) = 0._real32
+       do w = adj_ia(v), adj_ia(v+1)-1
+          cref(:,v) = cref(:,v) + [ x(:, adj_ja(1,w)), ef(:, adj_ja(2,w)) ]
+       end do
+       dd = max(mind, min(adj_ia(v+1) - adj_ia(v), maxd)) - mind + 1
+       w_ptr(1:fo, 1:fv+fe) => wt(fo*(fv+fe)*(dd-1)+1 : fo*(fv+fe)*dd)
+       zref(:,v) = matmul(w_ptr, cref(:,v) / real(dd, real32))
+    end do
+    do v = 1, nv
+       do i = 1, fv+fe
+          g(i,v) = 0.3_real32 * real(i, real32) - 0.1_real32 * real(v*i, real32)
+       end do
+    end do
+    dxref = 0._real32
+    do v = 1, nv
+       do w = adj_ia(v), adj_ia(v+1)-1
+          dxref(:,adj_ja(1,w)) = dxref(:,adj_ja(1,w)) + g(1:fv, v)
+       end do
+    end do
+    rc = athena_mp_graph_create(nv, nv, int(2*ne, c_int64_t), adj_ia, adj_ja, ne, c_null_ptr, c_null_ptr, graph)
+    call check(rc, "graph_create 5v")
+    rc = athena_mp_duvenaud_propagate_fwd_host(graph, fv, fe, x, ef, c)
+    call check(rc, "duvenaud propagate")
+    if(any(abs(c - cref) .gt. 1.e-6_real32 * maxval(abs(cref))))then
+       success = .false.
+       write(0,*) "duvenaud_propagate differs from the reference loops", maxval(abs(c - cref))
+    end if
+    rc = athena_mp_duvenaud_update_fwd_host(graph, fv+fe, fo, mind, maxd, c, wgt, z)
+    call check(rc, "duvenaud update")
+    if(any(abs(z - zref) .gt. 1.e-5_real32 * maxval(abs(zref))))then
+       success = .false.
+       write(0,*) "duvenaud_update differs from the reference loops", maxval(abs(z - zref))
+    end if
+    rc = athena_mp_duvenaud_propagate_bwd_x_host(graph, fv, fe, g, dx)
+    call check(rc, "duvenaud propagate bwd")
+    if(any(abs(dx - dxref) .gt. 1.e-6_real32 * maxval(abs(dxref))))then
+       success = .false.
+       write(0,*) "duvenaud propagate gradient differs", maxval(abs(dx - dxref))
+    end if
+    rc = athena_mp_graph_destroy(graph)
+  end subroutine duvenaud_five_vertex_graph
 
 end program test_athena_mp

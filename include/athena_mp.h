@@ -181,6 +181,24 @@ int athena_mp_kipf_propagate_bwd_host(const athena_mp_graph *g, int32_t F, const
 int athena_mp_gemm_fwd_host(int64_t N, int32_t Fi, int32_t Fo, const float *P_host, const float *W_host,
                             const float *bias_host, int32_t act, float *Z_host);
 
+/* more host-pointer staging variants (same semantics as the device entry points above; host.hip) */
+int athena_mp_gemm_dw_host(int64_t N, int32_t Fi, int32_t Fo, const float *P, const float *dZ, float *dW);
+int athena_mp_gemm_dx_host(int64_t N, int32_t Fi, int32_t Fo, const float *dZ, const float *W, float *dP);
+int athena_mp_activation_fwd_host(int32_t act, int64_t n, const float *z, float *y);
+int athena_mp_activation_bwd_host(int32_t act, int64_t n, const float *y, const float *g, float *dz);
+int athena_mp_duvenaud_propagate_fwd_host(const athena_mp_graph *g, int32_t Fv, int32_t Fe, const float *x, const float *e, float *c);
+int athena_mp_duvenaud_propagate_bwd_x_host(const athena_mp_graph *g, int32_t Fv, int32_t Fe, const float *grad, float *dx);
+int athena_mp_duvenaud_propagate_bwd_e_host(const athena_mp_graph *g, int32_t Fv, int32_t Fe, const float *grad, float *de);
+int athena_mp_duvenaud_update_fwd_host(const athena_mp_graph *g, int32_t Fi, int32_t Fo, int32_t mn, int32_t mx, const float *a, const float *w, float *c);
+int athena_mp_duvenaud_update_bwd_a_host(const athena_mp_graph *g, int32_t Fi, int32_t Fo, int32_t mn, int32_t mx, const float *grad, const float *w, float *da);
+int athena_mp_duvenaud_update_bwd_w_host(const athena_mp_graph *g, int32_t Fi, int32_t Fo, int32_t mn, int32_t mx, const float *grad, const float *a, float *dw);
+int athena_mp_softmax_segsum_fwd_host(int32_t O, int64_t N, int32_t S, const int32_t *seg, const float *logits, float *p, float *out, int32_t accumulate);
+int athena_mp_softmax_segsum_bwd_host(int32_t O, int64_t N, int32_t S, const int32_t *seg, const float *p, const float *gout, float *dlogits);
+int athena_mp_gno_aggregate_fwd_host(const athena_mp_graph *g, int32_t d, int32_t H, int32_t Fi, int32_t Fo, const float *theta, const float *coords, const float *x, float *m);
+int athena_mp_gno_aggregate_bwd_x_host(const athena_mp_graph *g, int32_t d, int32_t H, int32_t Fi, int32_t Fo, const float *theta, const float *coords, const float *grad, float *dx);
+int athena_mp_gno_aggregate_bwd_theta_host(const athena_mp_graph *g, int32_t d, int32_t H, int32_t Fi, int32_t Fo, const float *theta, const float *coords, const float *x, const float *grad, float *dtheta);
+int athena_mp_gno_aggregate_bwd_coords_host(const athena_mp_graph *g, int32_t d, int32_t H, int32_t Fi, int32_t Fo, const float *theta, const float *coords, const float *x, const float *grad, float *dcoords);
+
 #ifdef __cplusplus
 }
 #endif

@@ -328,3 +328,45 @@ def test_fused_kipf_layer_kernels(dev, oracle, act):
     dz2 = rng.uniform(-1, 1, (n, 32)).astype(np.float32)
     assert_close(H(ops.kipf_layer_bwd_x(g, T(dz2, dev), T(w2, dev), 64)),
                  oracle.kipf_propagate_bwd(oracle.matmul_dx(w2, dz2, 64), ia, ja), 1e-5)
+
+
+def test_host_pointer_variants(dev, oracle):
+    """the *_host entry points a Fortran caller holding array_type%val would use (phase-1 staging)"""
+    import ctypes as C
+
+    from athena_amd import DeviceGraph, _capi
+
+    def P_(a):
+        return a.ctypes.data_as(C.c_void_p)
+
+    t = golden("reference_test_topologies.json")["network_5v6e"]
+    g = csr_from_index_list(5, t["index_list"], self_loops=True)
+    dg = DeviceGraph(g.adj_ia, g.adj_ja, n_edge_cols=6)
+    x = np.ascontiguousarray(np.array(t["vertex_features_rows"], np.float32).T)
+    e = np.ascontiguousarray(np.array(t["edge_features_rows"], np.float32).T)
+    c = np.empty((5, 10), np.float32)
+    _capi.call("athena_mp_duvenaud_propagate_fwd_host", dg.handle, 8, 2, P_(x), P_(e), P_(c))
+    assert np.array_equal(c, oracle.duvenaud_propagate(x, e, g.adj_ia, g.adj_ja))
+    w = np.random.default_rng(0).standard_normal(4 * 10 * 3).astype(np.float32)
+    u = np.empty((5, 4), np.float32)
+    _capi.call("athena_mp_duvenaud_update_fwd_host", dg.handle, 10, 4, 2, 4, P_(c), P_(w), P_(u))
+    assert np.array_equal(u, oracle.duvenaud_update(c, w, g.adj_ia, 2, 4, 4))
+    up = np.random.default_rng(1).standard_normal((5, 4)).astype(np.float32)
+    dw = np.empty_like(w)
+    _capi.call("athena_mp_duvenaud_update_bwd_w_host", dg.handle, 10, 4, 2, 4, P_(up), P_(c), P_(dw))
+    assert_close(dw, oracle.duvenaud_update_bwd_w(up, c, g.adj_ia, 2, 4), 1e-5)
+    seg = np.array([0, 2, 5], np.int32)
+    p = np.empty_like(u); out = np.empty((2, 4), np.float32)
+    _capi.call("athena_mp_softmax_segsum_fwd_host", 4, 5, 2, P_(seg), P_(u), P_(p), P_(out), 0)
+    assert_close(out, oracle.segment_sum(oracle.softmax_cols(u), seg), 1e-5)
+    # GNO through host arrays
+    gg, E, coords, xx, theta, upg = _gno_case(5, 30, 3, 8, 4, 6, 20)
+    d2 = DeviceGraph(gg.adj_ia, gg.adj_ja, n_edge_cols=E)
+    m = np.empty((30, 6), np.float32)
+    _capi.call("athena_mp_gno_aggregate_fwd_host", d2.handle, 3, 8, 4, 6, P_(theta), P_(coords), P_(xx), P_(m))
+    kap = oracle.gno_kernel_eval(coords, theta, 8, 24)
+    assert_close(m, oracle.gno_aggregate(xx, kap, gg.adj_ia, gg.adj_ja, 6), 1e-5)
+    dth = np.empty_like(theta)
+    _capi.call("athena_mp_gno_aggregate_bwd_theta_host", d2.handle, 3, 8, 4, 6, P_(theta), P_(coords), P_(xx), P_(upg), P_(dth))
+    dk = oracle.gno_aggregate_bwd_k(upg, xx, E, gg.adj_ia, gg.adj_ja)
+    assert_close(dth, oracle.gno_kernel_bwd_theta(coords, theta, dk, 8), 2e-5)
