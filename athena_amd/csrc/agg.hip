@@ -84,7 +84,6 @@ __global__ __launch_bounds__(kBlock) void csr_gather_agg(
     int32_t F)
 {
     constexpr int kRowsPerBlock = kBlock / G;
-    const int lane = threadIdx.x & 63;
     const int gl = threadIdx.x & (G - 1);          // lane inside the group
     const int n_row_blocks = (n_rows + kRowsPerBlock - 1) / kRowsPerBlock;
     // grid-stride over row blocks: gridDim.x == n_row_blocks for a plain launch, or a fixed number of
@@ -102,7 +101,6 @@ __global__ __launch_bounds__(kBlock) void csr_gather_agg(
     int maxlen = len;
 #pragma unroll
     for (int o = G; o < 64; o <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o));
-    (void)lane;
 
     for (int f0 = 0; f0 < F; f0 += G * VEC) {
         const int f = f0 + gl * VEC;

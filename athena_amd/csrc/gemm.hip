@@ -318,45 +318,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bres8_kernel(const float *__restr
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// dW on MFMA: dWt[i,o] = sum_v P[v,i] dZ[v,o].  Both operands are read straight from HBM in fragment
-// order -- the A operand of MFMA row-tile t is element t of the lane's contiguous TI-float load, i.e.
-// tile t, MFMA row m  <->  feature i = ibase + TI*m + t  (a fixed permutation undone at the store) --
-// so no LDS is needed and every load instruction reads contiguous row segments.
-// Each workgroup reduces a contiguous chunk of vertices into a private [FI][FO] slab; a second
-// kernel adds the slabs in fixed order (deterministic; no float atomics).
-// ---------------------------------------------------------------------------------------------
-template <int T> struct FragLoad;
-template <> struct FragLoad<1> {
-    static __device__ __forceinline__ void ld(float (&d)[1], const float *p) { d[0] = *p; }
-};
-template <> struct FragLoad<2> {
-    static __device__ __forceinline__ void ld(float (&d)[2], const float *p)
-    {
-        float2 t = *reinterpret_cast<const float2 *>(p);
-        d[0] = t.x; d[1] = t.y;
-    }
-};
-
-template <bool MASK, int U, int TI, int TJ, int FI, int FO>
-__device__ __forceinline__ void dw_load(float (&a)[U][TI], float (&b)[U][TJ], const float *__restrict__ pa,
-                                        const float *__restrict__ pb, int64_t v, int64_t v1, int h)
-{
-#pragma unroll
-    for (int s = 0; s < U; ++s) {
-        const int64_t vv = v + 2 * s + h;
-        const bool ok = vv < v1;
-        const int64_t vc = ok ? vv : v1 - 1; // unconditional loads; out-of-range steps contribute 0
-        FragLoad<TI>::ld(a[s], pa + vc * FI);
-        FragLoad<TJ>::ld(b[s], pb + vc * FO);
-        if constexpr (MASK) {
-            if (!ok) {
-#pragma unroll
-                for (int t = 0; t < TI; ++t) a[s][t] = 0.0f;
-            }
-        }
-    }
-}
 template <int U, int TI, int TJ>
 __device__ __forceinline__ void dw_mfma(f32x16 (&acc)[TI][TJ], const float (&a)[U][TI], const float (&b)[U][TJ])
 {
@@ -367,67 +328,6 @@ __device__ __forceinline__ void dw_mfma(f32x16 (&acc)[TI][TJ], const float (&a)[
 #pragma unroll
             for (int tj = 0; tj < TJ; ++tj)
                 acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][ti], b[s][tj], acc[ti][tj], 0, 0, 0);
-}
-
-template <int FI, int FO>
-__global__ __launch_bounds__(256, 1) void gemm_dw_kernel(const float *__restrict__ P,
-                                                          const float *__restrict__ dZ,
-                                                          float *__restrict__ slabs, int64_t M,
-                                                          int64_t rows_per_block)
-{
-    // wave (wi, wo) owns features i in [wi*FI/2, +FI/2) x o in [wo*FO/2, +FO/2)
-    constexpr int TI = FI / 64, TJ = FO / 64; // 32x32 tiles per wave along i / o (1 or 2)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int m = lane & 31, h = lane >> 5;
-    const int ibase = (wave >> 1) * (FI / 2), obase = (wave & 1) * (FO / 2);
-
-    f32x16 acc[TI][TJ];
-#pragma unroll
-    for (int a = 0; a < TI; ++a)
-#pragma unroll
-        for (int b = 0; b < TJ; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-
-    const int64_t v0 = (int64_t)blockIdx.x * rows_per_block;
-    const int64_t v1 = min(M, v0 + rows_per_block);
-    const float *pa = P + ibase + TI * m;
-    const float *pb = dZ + obase + TJ * m;
-
-    // Two register buffers of U k-steps each: the loads of batch n+1 are issued (and pinned with a
-    // scheduling barrier) before the MFMAs of batch n, so HBM latency hides under 4*U MFMAs.
-    constexpr int U = 8; // MFMA k-steps (2 vertices each) per batch
-    float a0[U][TI], b0[U][TJ], a1[U][TI], b1[U][TJ];
-    const int64_t n_pairs = (v1 - v0) / (4 * U); // full double-batches: no masking needed inside
-    int64_t v = v0;
-    if (n_pairs > 0) dw_load<false, U, TI, TJ, FI, FO>(a0, b0, pa, pb, v, v1, h);
-    for (int64_t p = 0; p < n_pairs; ++p, v += 4 * U) {
-        dw_load<false, U, TI, TJ, FI, FO>(a1, b1, pa, pb, v + 2 * U, v1, h);
-        __builtin_amdgcn_sched_barrier(0);
-        dw_mfma<U, TI, TJ>(acc, a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        // next pair's first batch (addresses clamp at the chunk end; unused if there is no next pair)
-        dw_load<false, U, TI, TJ, FI, FO>(a0, b0, pa, pb, v + 4 * U, v1, h);
-        __builtin_amdgcn_sched_barrier(0);
-        dw_mfma<U, TI, TJ>(acc, a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    for (; v < v1; v += 2 * U) { // tail (< 4U vertices): masked
-        dw_load<true, U, TI, TJ, FI, FO>(a0, b0, pa, pb, v, v1, h);
-        dw_mfma<U, TI, TJ>(acc, a0, b0);
-    }
-    float *slab = slabs + (size_t)blockIdx.x * FI * FO;
-#pragma unroll
-    for (int ti = 0; ti < TI; ++ti)
-#pragma unroll
-        for (int tj = 0; tj < TJ; ++tj)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
-                int i = ibase + TI * rr + ti;
-                int o = obase + TJ * m + tj;
-                slab[i * FO + o] = acc[ti][tj][r];
-            }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -720,14 +620,13 @@ int gemm_dw_dispatch(int64_t N, int Fi, int Fo, const float *P, const float *dZ,
         if (!accumulate) AMP_HIP(hipMemsetAsync(dW, 0, sizeof(float) * n, stream()));
         return 0;
     }
-    static const bool use_quad = getenv("ATHENA_MP_DW_QUAD") != nullptr; // older 4-waves-per-tile form (A/B)
     bool mf = (Fi == 64 || Fi == 128) && (Fo == 64 || Fo == 128) && ((uintptr_t)P % 16 == 0) &&
               ((uintptr_t)dZ % 16 == 0);
     if (!mf && (int64_t)Fi * Fo >= 256 && N >= 256)
         return gemm_atb_tiled(P, Fi, dZ, Fo, nullptr, 1.0f, N, Fi, Fo, dW, accumulate);
     int nblk;
     int64_t rpb = 0, rpw = 0;
-    if (mf && !use_quad) {
+    if (mf) {
         nblk = (int)std::min<int64_t>((N + 127) / 128, num_cu());
         rpw = (N + (int64_t)nblk * 4 - 1) / ((int64_t)nblk * 4);
         rpw = (rpw + 1) & ~(int64_t)1;
@@ -741,16 +640,10 @@ int gemm_dw_dispatch(int64_t N, int Fi, int Fo, const float *P, const float *dZ,
     void *ws = nullptr;
     if (workspace(&ws, sizeof(float) * (size_t)nblk * n, 2)) return 1;
     float *slabs = (float *)ws;
-    if (mf && !use_quad) {
+    if (mf) {
 #define AMP_CASE(A_, B_)                                                                                    \
     if (Fi == A_ && Fo == B_)                                                                               \
         hipLaunchKernelGGL((gemm_dw_full_kernel<A_, B_>), dim3(nblk), dim3(256), 0, stream(), P, dZ, slabs, N, rpw);
-        AMP_CASE(64, 64) AMP_CASE(64, 128) AMP_CASE(128, 64) AMP_CASE(128, 128)
-#undef AMP_CASE
-    } else if (mf) {
-#define AMP_CASE(A_, B_)                                                                                   \
-    if (Fi == A_ && Fo == B_)                                                                              \
-        hipLaunchKernelGGL((gemm_dw_kernel<A_, B_>), dim3(nblk), dim3(256), 0, stream(), P, dZ, slabs, N, rpb);
         AMP_CASE(64, 64) AMP_CASE(64, 128) AMP_CASE(128, 64) AMP_CASE(128, 128)
 #undef AMP_CASE
     } else {

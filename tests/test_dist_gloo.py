@@ -83,11 +83,11 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-@pytest.mark.parametrize("cut", [None, 0.1])
-def test_two_rank_kipf_step_matches_global_oracle(oracle, cut):
+@pytest.mark.parametrize("world,cut", [(2, None), (2, 0.1), (4, 0.05), (3, None)])
+def test_multi_rank_kipf_step_matches_global_oracle(oracle, world, cut):
     from athena_amd import dist as adist
 
-    world, n, pairs, F = 2, 400, 1500, 8
+    n, pairs, F = 400, 1500, 8
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -113,7 +113,7 @@ def test_two_rank_kipf_step_matches_global_oracle(oracle, cut):
     x = np.concatenate([res[r]["x"] for r in range(world)])
     dz = np.concatenate([res[r]["dz"] for r in range(world)])
     w = res[0]["w"]
-    assert np.array_equal(w, res[1]["w"])
+    assert all(np.array_equal(w, res[r]["w"]) for r in range(world))
     P = oracle.kipf_propagate(x, ia, ja)
     assert np.array_equal(np.concatenate([res[r]["P"] for r in range(world)]), P)          # bit-exact
     assert np.array_equal(np.concatenate([res[r]["Z"] for r in range(world)]), oracle.matmul(w, P, F))
