@@ -244,6 +244,6 @@ def build_kipf_step(shard, F, device, backend=None):
     halo_bytes = 2 * shard.n_halo * F * 4
     uniform = shard.world > 1 and abs(shard.cut - (shard.world - 1) / shard.world) < 1e-9
     info = {"graph": "random graph, both endpoints uniform over all N*vertices_per_gpu vertices (no partition structure)" if uniform
-            else f"random graph with planted partitions: {shard.cut:.3f} of the undirected pairs cross partitions",
+            else f"stochastic block model, one block per GPU, fixed inter-block density: {shard.cut:.4f} of the undirected pairs cross partitions at this N",
             "halo_rows_per_gpu": shard.n_halo, "halo_bytes_per_gpu_per_step": halo_bytes}
     return step, shard.nnz, info

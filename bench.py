@@ -12,9 +12,10 @@ A "step" is one interior Kipf layer forward+backward over the whole graph (SURVE
 N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL): WEAK scaling -- every rank
 owns a 1M-vertex / 10M-entry row block of an N-times larger graph; halo rows of X (forward) and of
 dP (backward) move by grouped point-to-point send/recv, dW by all_reduce (athena_amd/dist.py).
-The N > 1 graph is a random graph with planted partitions (5 % of the undirected pairs cross
-partitions -- what a node partitioner leaves; --cut changes it) and the same run also reports the
-structure-free variant (both endpoints uniform over the whole graph: the worst case for any row
+The N > 1 graph is a stochastic block model: one block per GPU, a FIXED inter-block density (each pair
+of blocks shares 2*pairs*cut8/7 undirected pairs, so the cross-partition fraction is cut8*(N-1)/7:
+0.7 % at N=2, 2.1 % at N=4, 5 % at N=8 with the default --cut8 0.05 -- what a node partitioner leaves on
+meshes and molecule batches) and the same run also reports the structure-free variant (both endpoints uniform over the whole graph: the worst case for any row
 partition, communication bound by construction) as "uniform_random_variant".
 """
 import argparse
@@ -65,7 +66,9 @@ def main():
     ap.add_argument("--nodes", type=int, default=1_000_000, help="vertices per GPU")
     ap.add_argument("--pairs", type=int, default=4_500_000, help="undirected pairs per GPU (nnz = 2*pairs + nodes)")
     ap.add_argument("--feat", type=int, default=128)
-    ap.add_argument("--cut", type=float, default=0.05, help="N>1: fraction of undirected pairs crossing partitions (-1: uniform random = (N-1)/N)")
+    ap.add_argument("--cut8", dest="cut", type=float, default=0.05,
+                    help="N>1: fraction of undirected pairs crossing partitions at 8 blocks (fixed inter-block density; "
+                         "the fraction at N blocks is cut8*(N-1)/7).  -1: structure-free uniform random graph")
     ap.add_argument("--no-variant", action="store_true", help="N>1: skip the uniform-random variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=500_000)
@@ -90,7 +93,7 @@ def main():
         from athena_amd import dist as adist
 
         dist.init_process_group("nccl", device_id=dev)
-        cut = None if args.cut < 0 else args.cut
+        cut = None if args.cut < 0 else args.cut * (world - 1) / 7.0
         shard = adist.make_weak_scaling_shard(rank, world, args.nodes, args.pairs, F, cut=cut, device=dev)
         step, nnz_local, info = adist.build_kipf_step(shard, F, dev)
         nnz_total = nnz_local * world
