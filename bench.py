@@ -170,8 +170,9 @@ def main():
         "metric": "msgpass fwd+bwd edges/sec", "value": value, "unit": "edges/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: Kipf GCN layer fwd+bwd, random graph "
-                               f"{args.nodes} vertices / {nnz_local} CSR entries per GPU, {F} features, fp32",
+        "config": {"workload": ("BASELINE configs[1]: " if (args.nodes, args.pairs, F) == (1_000_000, 4_500_000, 128) else "custom size: ")
+                               + f"Kipf GCN layer fwd+bwd, random graph {args.nodes} vertices / {nnz_local} CSR entries per GPU, "
+                                 f"{F} features, fp32",
                    "vertices_per_gpu": args.nodes, "entries_per_gpu": nnz_local, "features": F,
                    "parallelism": f"row-partition x{world}" if world > 1 else "single GPU", **info},
     }
@@ -189,7 +190,9 @@ def main():
                 traffic = json.load(open(tpath)).get("agg_gemm_fwd_bytes_per_launch")
             except Exception:
                 traffic = None
-        out["roofline"] = {"bound": "hbm", "kernel": "agg_gemm_kernel<128,coef> (fused kipf_propagate + matmul fwd)",
+        kname = ("agg_gemm_kernel<128,coef> (fused kipf_propagate + matmul fwd)" if F == 128 else
+                 "kipf_layer_fwd = csr_gather_agg + dense step (two launches at this width)")
+        out["roofline"] = {"bound": "hbm", "kernel": kname,
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": agg_ms}
