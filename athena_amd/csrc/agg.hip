@@ -79,9 +79,9 @@ constexpr int kUnroll = 4;
 // G lanes per row, VEC floats per lane, COEF: multiply by coef[w]
 template <int G, int VEC, bool COEF>
 __global__ __launch_bounds__(kBlock) void csr_gather_agg(
-    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ idx, const float *__restrict__ coef,
-    const float *__restrict__ x, int64_t ldx, float *__restrict__ y, int64_t ldy, int32_t n_rows,
-    int32_t F)
+    const int32_t *__restrict__ rowbeg, const int32_t *__restrict__ rowend, const int32_t *__restrict__ idx,
+    const float *__restrict__ coef, const float *__restrict__ x, int64_t ldx, float *__restrict__ y,
+    int64_t ldy, int32_t n_rows, int32_t F, int32_t long_thr)
 {
     constexpr int kRowsPerBlock = kBlock / G;
     const int gl = threadIdx.x & (G - 1);          // lane inside the group
@@ -90,12 +90,16 @@ __global__ __launch_bounds__(kBlock) void csr_gather_agg(
     // resident workgroups per CU when the launch leaves room for a co-running MFMA kernel
     for (int rb = blockIdx.x; rb < n_row_blocks; rb += gridDim.x) {
     const int row = rb * kRowsPerBlock + (threadIdx.x / G);
-    const bool live = row < n_rows;
+    bool live = row < n_rows;
 
     int start = 0, len = 0;
     if (live) {
-        start = rowptr[row];
-        len = rowptr[row + 1] - start;
+        start = rowbeg[row];
+        len = rowend[row] - start;
+        if (long_thr > 0 && len > long_thr) { // hub row: summed by the segment launch instead
+            len = 0;
+            live = false;
+        }
     }
     // longest row among the groups of this wave: keeps every shuffle wave-uniform
     int maxlen = len;
@@ -151,36 +155,50 @@ __global__ __launch_bounds__(kBlock) void csr_gather_agg(
 }
 
 template <int G, int VEC>
-int launch_gv(bool has_coef, const int32_t *rowptr, const int32_t *idx, const float *coef, const float *x,
-              int64_t ldx, float *y, int64_t ldy, int32_t n_rows, int32_t F)
+int launch_gv(bool has_coef, const int32_t *rowbeg, const int32_t *rowend, const int32_t *idx, const float *coef,
+              const float *x, int64_t ldx, float *y, int64_t ldy, int32_t n_rows, int32_t F, int32_t long_thr)
 {
     constexpr int rpb = kBlock / G;
     int nb = (n_rows + rpb - 1) / rpb;
     if (amp::agg_blocks_cap() > 0) nb = std::min(nb, amp::agg_blocks_cap());
     dim3 grid(nb), block(kBlock);
     if (has_coef)
-        hipLaunchKernelGGL((csr_gather_agg<G, VEC, true>), grid, block, 0, amp::stream(), rowptr, idx, coef, x,
-                           ldx, y, ldy, n_rows, F);
+        hipLaunchKernelGGL((csr_gather_agg<G, VEC, true>), grid, block, 0, amp::stream(), rowbeg, rowend, idx, coef, x,
+                           ldx, y, ldy, n_rows, F, long_thr);
     else
-        hipLaunchKernelGGL((csr_gather_agg<G, VEC, false>), grid, block, 0, amp::stream(), rowptr, idx, coef,
-                           x, ldx, y, ldy, n_rows, F);
+        hipLaunchKernelGGL((csr_gather_agg<G, VEC, false>), grid, block, 0, amp::stream(), rowbeg, rowend, idx, coef,
+                           x, ldx, y, ldy, n_rows, F, long_thr);
     AMP_LAUNCH_CHECK();
     return 0;
 }
 
 template <int VEC>
-int launch_v(int G, bool has_coef, const int32_t *rowptr, const int32_t *idx, const float *coef,
-             const float *x, int64_t ldx, float *y, int64_t ldy, int32_t n_rows, int32_t F)
+int launch_v(int G, bool has_coef, const int32_t *rowbeg, const int32_t *rowend, const int32_t *idx,
+             const float *coef, const float *x, int64_t ldx, float *y, int64_t ldy, int32_t n_rows, int32_t F,
+             int32_t long_thr)
 {
     switch (G) {
-    case 1: return launch_gv<1, VEC>(has_coef, rowptr, idx, coef, x, ldx, y, ldy, n_rows, F);
-    case 2: return launch_gv<2, VEC>(has_coef, rowptr, idx, coef, x, ldx, y, ldy, n_rows, F);
-    case 4: return launch_gv<4, VEC>(has_coef, rowptr, idx, coef, x, ldx, y, ldy, n_rows, F);
-    case 8: return launch_gv<8, VEC>(has_coef, rowptr, idx, coef, x, ldx, y, ldy, n_rows, F);
-    case 16: return launch_gv<16, VEC>(has_coef, rowptr, idx, coef, x, ldx, y, ldy, n_rows, F);
-    case 32: return launch_gv<32, VEC>(has_coef, rowptr, idx, coef, x, ldx, y, ldy, n_rows, F);
-    default: return launch_gv<64, VEC>(has_coef, rowptr, idx, coef, x, ldx, y, ldy, n_rows, F);
+    case 1: return launch_gv<1, VEC>(has_coef, rowbeg, rowend, idx, coef, x, ldx, y, ldy, n_rows, F, long_thr);
+    case 2: return launch_gv<2, VEC>(has_coef, rowbeg, rowend, idx, coef, x, ldx, y, ldy, n_rows, F, long_thr);
+    case 4: return launch_gv<4, VEC>(has_coef, rowbeg, rowend, idx, coef, x, ldx, y, ldy, n_rows, F, long_thr);
+    case 8: return launch_gv<8, VEC>(has_coef, rowbeg, rowend, idx, coef, x, ldx, y, ldy, n_rows, F, long_thr);
+    case 16: return launch_gv<16, VEC>(has_coef, rowbeg, rowend, idx, coef, x, ldx, y, ldy, n_rows, F, long_thr);
+    case 32: return launch_gv<32, VEC>(has_coef, rowbeg, rowend, idx, coef, x, ldx, y, ldy, n_rows, F, long_thr);
+    default: return launch_gv<64, VEC>(has_coef, rowbeg, rowend, idx, coef, x, ldx, y, ldy, n_rows, F, long_thr);
     }
+}
+
+// y[long row, :] = sum of its segment partials, in segment order
+__global__ void long_combine_kernel(const int32_t *__restrict__ row_id, const int32_t *__restrict__ row_task0,
+                                    const float *__restrict__ partial, int64_t ldp, int32_t n_long, int32_t F,
+                                    float *__restrict__ y, int64_t ldy)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)n_long * F) return;
+    const int r = (int)(t / F), f = (int)(t - (int64_t)r * F);
+    float s = 0.0f;
+    for (int k = row_task0[r]; k < row_task0[r + 1]; ++k) s = s + partial[(size_t)k * ldp + f];
+    y[(int64_t)row_id[r] * ldy + f] = s;
 }
 
 } // namespace
@@ -190,7 +208,7 @@ namespace amp {
 // Generic launcher used by every layer family.  x/y may be column slices of wider tensors
 // (ldx/ldy = leading dimension in floats).
 int gather_agg(const int32_t *rowptr, const int32_t *idx, const float *coef, const float *x, int64_t ldx,
-               float *y, int64_t ldy, int32_t n_rows, int32_t F)
+               float *y, int64_t ldy, int32_t n_rows, int32_t F, const LongPlan *lp)
 {
     if (n_rows == 0 || F == 0) return 0;
     // widest vector the slices allow (16 B loads need 16 B aligned rows)
@@ -205,11 +223,33 @@ int gather_agg(const int32_t *rowptr, const int32_t *idx, const float *coef, con
     int G = 1;
     while (G < lanes && G < 64) G <<= 1;
     const bool has_coef = coef != nullptr;
-    switch (vec) {
-    case 4: return launch_v<4>(G, has_coef, rowptr, idx, coef, x, ldx, y, ldy, n_rows, F);
-    case 2: return launch_v<2>(G, has_coef, rowptr, idx, coef, x, ldx, y, ldy, n_rows, F);
-    default: return launch_v<1>(G, has_coef, rowptr, idx, coef, x, ldx, y, ldy, n_rows, F);
+    const bool hubs = lp && lp->n_long > 0;
+    auto run = [&](const int32_t *rb, const int32_t *re, float *out, int64_t ldo, int32_t rows, int32_t thr) {
+        switch (vec) {
+        case 4: return launch_v<4>(G, has_coef, rb, re, idx, coef, x, ldx, out, ldo, rows, F, thr);
+        case 2: return launch_v<2>(G, has_coef, rb, re, idx, coef, x, ldx, out, ldo, rows, F, thr);
+        default: return launch_v<1>(G, has_coef, rb, re, idx, coef, x, ldx, out, ldo, rows, F, thr);
+        }
+    };
+    int rc = run(rowptr, rowptr + 1, y, ldy, n_rows, hubs ? kLongRow : 0);
+    if (rc || !hubs) return rc;
+    // hub rows: one lane group per kLongRow-entry segment into a partial buffer, then an ordered combine
+    void *ws = nullptr;
+    const int64_t Fp = (F + 3) & ~3; // keep partial rows 16 B aligned
+    if (workspace(&ws, sizeof(float) * (size_t)lp->n_tasks * Fp, 7)) return 1;
+    {
+        // the partial buffer's leading dimension must satisfy the same vector alignment as y
+        const int vec_saved = vec;
+        if (Fp % vec != 0) vec = 1;
+        rc = run(lp->task_beg, lp->task_end, (float *)ws, Fp, lp->n_tasks, 0);
+        vec = vec_saved;
+        if (rc) return rc;
     }
+    const int64_t tot = (int64_t)lp->n_long * F;
+    hipLaunchKernelGGL(long_combine_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream(), lp->row_id,
+                       lp->row_task0, (const float *)ws, Fp, lp->n_long, F, y, ldy);
+    AMP_LAUNCH_CHECK();
+    return 0;
 }
 
 } // namespace amp
@@ -223,7 +263,7 @@ int athena_mp_kipf_propagate_fwd(const athena_mp_graph *g, int32_t F, const floa
     AMP_REQUIRE(g && F > 0, "kipf_propagate_fwd: bad arguments");
     if (g->n_rows == 0) return 0; // empty graph: nothing to do (pointers may be null)
     AMP_REQUIRE(x && y, "kipf_propagate_fwd: null tensor");
-    return gather_agg(g->rowptr, g->col, g->coef, x, F, y, F, g->n_rows, F);
+    return gather_agg(g->rowptr, g->col, g->coef, x, F, y, F, g->n_rows, F, &g->lp_fwd);
 }
 
 int athena_mp_kipf_propagate_bwd(const athena_mp_graph *g, int32_t F, const float *grad, float *dx,
@@ -232,7 +272,7 @@ int athena_mp_kipf_propagate_bwd(const athena_mp_graph *g, int32_t F, const floa
     AMP_REQUIRE(g && F > 0, "kipf_propagate_bwd: bad arguments");
     if (g->n_cols == 0) return 0;
     AMP_REQUIRE(dx && (grad || g->nnz == 0), "kipf_propagate_bwd: null tensor");
-    return gather_agg(g->t_rowptr, g->t_src, exact ? g->t_coef : nullptr, grad, F, dx, F, g->n_cols, F);
+    return gather_agg(g->t_rowptr, g->t_src, exact ? g->t_coef : nullptr, grad, F, dx, F, g->n_cols, F, &g->lp_bwd);
 }
 
 int athena_mp_duvenaud_propagate_fwd(const athena_mp_graph *g, int32_t Fv, int32_t Fe, const float *x,
@@ -241,8 +281,8 @@ int athena_mp_duvenaud_propagate_fwd(const athena_mp_graph *g, int32_t Fv, int32
     AMP_REQUIRE(g && x && c && Fv > 0 && Fe >= 0, "duvenaud_propagate_fwd: bad arguments");
     AMP_REQUIRE(Fe == 0 || e, "duvenaud_propagate_fwd: null edge features");
     const int64_t Fc = (int64_t)Fv + Fe;
-    int rc = gather_agg(g->rowptr, g->col, nullptr, x, Fv, c, Fc, g->n_rows, Fv);
-    if (rc == 0 && Fe > 0) rc = gather_agg(g->rowptr, g->eid, nullptr, e, Fe, c + Fv, Fc, g->n_rows, Fe);
+    int rc = gather_agg(g->rowptr, g->col, nullptr, x, Fv, c, Fc, g->n_rows, Fv, &g->lp_fwd);
+    if (rc == 0 && Fe > 0) rc = gather_agg(g->rowptr, g->eid, nullptr, e, Fe, c + Fv, Fc, g->n_rows, Fe, &g->lp_fwd);
     return rc;
 }
 
@@ -250,7 +290,7 @@ int athena_mp_duvenaud_propagate_bwd_x(const athena_mp_graph *g, int32_t Fv, int
                                        float *dx)
 {
     AMP_REQUIRE(g && grad && dx && Fv > 0 && Fe >= 0, "duvenaud_propagate_bwd_x: bad arguments");
-    return gather_agg(g->t_rowptr, g->t_src, nullptr, grad, (int64_t)Fv + Fe, dx, Fv, g->n_cols, Fv);
+    return gather_agg(g->t_rowptr, g->t_src, nullptr, grad, (int64_t)Fv + Fe, dx, Fv, g->n_cols, Fv, &g->lp_bwd);
 }
 
 int athena_mp_duvenaud_propagate_bwd_e(const athena_mp_graph *g, int32_t Fv, int32_t Fe, const float *grad,

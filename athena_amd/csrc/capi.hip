@@ -8,6 +8,7 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "common.h"
@@ -156,6 +157,31 @@ template <typename T> static int upload(T **dst, const std::vector<T> &src)
     return 0;
 }
 
+static int build_long_plan(const std::vector<int32_t> &rowptr, int32_t n_rows, LongPlan *lp)
+{
+    std::vector<int32_t> beg, end, rid, t0;
+    for (int32_t r = 0; r < n_rows; ++r) {
+        const int32_t len = rowptr[r + 1] - rowptr[r];
+        if (len <= kLongRow) continue;
+        rid.push_back(r);
+        t0.push_back((int32_t)beg.size());
+        for (int32_t b = rowptr[r]; b < rowptr[r + 1]; b += kLongRow) {
+            beg.push_back(b);
+            end.push_back(std::min(b + kLongRow, rowptr[r + 1]));
+        }
+    }
+    t0.push_back((int32_t)beg.size());
+    lp->n_tasks = (int32_t)beg.size();
+    lp->n_long = (int32_t)rid.size();
+    if (lp->n_long == 0) return 0;
+    int rc = 0;
+    rc |= upload(&lp->task_beg, beg);
+    rc |= upload(&lp->task_end, end);
+    rc |= upload(&lp->row_id, rid);
+    rc |= upload(&lp->row_task0, t0);
+    return rc;
+}
+
 extern "C" {
 
 int athena_mp_graph_destroy(athena_mp_graph *g)
@@ -166,6 +192,9 @@ int athena_mp_graph_destroy(athena_mp_graph *g)
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (g->bucket_perm) (void)hipFree(g->bucket_perm);
+    for (LongPlan *lp : {&g->lp_fwd, &g->lp_bwd})
+        for (void *p : {(void *)lp->task_beg, (void *)lp->task_end, (void *)lp->row_id, (void *)lp->row_task0})
+            if (p) (void)hipFree(p);
     delete g;
     return 0;
 }
@@ -283,6 +312,8 @@ int athena_mp_graph_create(int32_t n_rows, int32_t n_cols, int64_t nnz, const in
     }
     rc |= upload(&g->coef, coef);
     rc |= upload(&g->t_coef, t_coef);
+    rc |= build_long_plan(rowptr, n_rows, &g->lp_fwd);
+    rc |= build_long_plan(t_rowptr, n_cols, &g->lp_bwd);
     if (rc != 0) {
         if (g_err[0] == 0) set_error("graph_create: device allocation failed");
         athena_mp_graph_destroy(g);

@@ -39,6 +39,17 @@ int workspace(void **ptr, size_t bytes, int slot = 0);
 
 } // namespace amp
 
+// Rows longer than kLongRow entries (hubs of heavy-tailed graphs) are cut into segments of kLongRow
+// entries that independent lane groups sum in parallel; the segment sums are then added in segment
+// order (deterministic).  Shorter rows keep the strictly sequential CSR-order sum.
+constexpr int kLongRow = 512;
+struct LongPlan {
+    int32_t n_tasks = 0, n_long = 0;
+    int32_t *task_beg = nullptr, *task_end = nullptr; // [n_tasks] entry ranges
+    int32_t *row_id = nullptr;                        // [n_long] the long rows
+    int32_t *row_task0 = nullptr;                     // [n_long+1] first task of each long row
+};
+
 // ---- graph handle: everything the kernels need, resident in HBM --------------------------------
 struct athena_mp_graph {
     int32_t n_rows = 0, n_cols = 0, n_edge_cols = 0;
@@ -61,6 +72,7 @@ struct athena_mp_graph {
     int32_t *deg_row = nullptr;  // [n_rows]
     int32_t *deg_col = nullptr;  // [n_cols]
     int64_t n_with_edge = 0;
+    LongPlan lp_fwd, lp_bwd;        // hub rows of the forward / transposed CSR
     std::vector<int32_t> h_deg_row; // host copy (bucket planning)
     // Duvenaud degree buckets, built on first use for a (min_deg, max_deg) pair: vertices sorted by
     // bucket (stable), so each bucket is one contiguous run of a row-index array
@@ -74,7 +86,7 @@ int agg_blocks_cap();
 void set_agg_blocks_cap(int n);
 // shared launchers (defined in agg.hip / gemm.hip)
 int gather_agg(const int32_t *rowptr, const int32_t *idx, const float *coef, const float *x, int64_t ldx,
-               float *y, int64_t ldy, int32_t n_rows, int32_t F);
+               float *y, int64_t ldy, int32_t n_rows, int32_t F, const LongPlan *lp = nullptr);
 // Z[M,N] = act(A[M,K] . B + bias); b_nk: B stored [N][K] instead of [K][N]
 int gemm_dispatch(const float *A, const float *B, int b_nk, const float *bias, int act, float *Z, int64_t M,
                   int K, int N);

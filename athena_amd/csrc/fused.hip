@@ -270,7 +270,9 @@ int athena_mp_kipf_layer_fwd(const athena_mp_graph *g, int32_t Fi, int32_t Fo, c
     AMP_REQUIRE(g && Fi > 0 && Fo > 0, "kipf_layer_fwd: bad arguments");
     if (g->n_rows == 0) return 0;
     AMP_REQUIRE(x && W && P && Z, "kipf_layer_fwd: null tensor");
-    if (Fi == 128 && Fo == 128)
+    // hub rows (> kLongRow entries) would stall a whole workgroup at the chunk barrier: such graphs take
+    // the two-kernel route, whose aggregation splits them into parallel segments
+    if (Fi == 128 && Fo == 128 && g->lp_fwd.n_long == 0)
         return fused_dispatch(g->rowptr, g->col, g->coef, x, Fi, Fo, W, 0, bias, act, P, Z, g->n_rows);
     int rc = athena_mp_kipf_propagate_fwd(g, Fi, x, P);   // other widths: the two kernels back to back
     if (rc) return rc;
@@ -283,7 +285,7 @@ int athena_mp_kipf_layer_bwd_x(const athena_mp_graph *g, int32_t Fi, int32_t Fo,
     AMP_REQUIRE(g && Fi > 0 && Fo > 0, "kipf_layer_bwd_x: bad arguments");
     if (g->n_cols == 0) return 0;
     AMP_REQUIRE(dZ && W && dX, "kipf_layer_bwd_x: null tensor");
-    if (Fi == 128 && Fo == 128) // dX = (A^T dZ) . W : aggregate Fo-wide rows, contract with B stored [N=Fi][K=Fo]
+    if (Fi == 128 && Fo == 128 && g->lp_bwd.n_long == 0) // dX = (A^T dZ) . W : aggregate, then contract with B [N=Fi][K=Fo]
         return fused_dispatch(g->t_rowptr, g->t_src, exact ? g->t_coef : nullptr, dZ, Fo, Fi, W, 1, nullptr,
                               ATHENA_MP_ACT_NONE, nullptr, dX, g->n_cols);
     void *ws = nullptr;
@@ -301,12 +303,12 @@ int athena_mp_pull_gemm(const athena_mp_graph *g, int32_t Fi, int32_t Fo, const 
     AMP_REQUIRE(g && Fi > 0 && Fo > 0, "pull_gemm: bad arguments");
     if (g->n_rows == 0) return 0;
     AMP_REQUIRE(dZ && W && dX, "pull_gemm: null tensor");
-    if (Fi == 128 && Fo == 128)
+    if (Fi == 128 && Fo == 128 && g->lp_fwd.n_long == 0)
         return fused_dispatch(g->rowptr, g->col, exact ? g->coef : nullptr, dZ, Fo, Fi, W, 1, nullptr,
                               ATHENA_MP_ACT_NONE, nullptr, dX, g->n_rows);
     void *ws = nullptr;
     if (workspace(&ws, sizeof(float) * (size_t)g->n_rows * Fo, 5)) return 1;
-    int rc = gather_agg(g->rowptr, g->col, exact ? g->coef : nullptr, dZ, Fo, (float *)ws, Fo, g->n_rows, Fo);
+    int rc = gather_agg(g->rowptr, g->col, exact ? g->coef : nullptr, dZ, Fo, (float *)ws, Fo, g->n_rows, Fo, &g->lp_fwd);
     if (rc) return rc;
     return athena_mp_gemm_dx(g->n_rows, Fi, Fo, (const float *)ws, W, dX);
 }
