@@ -192,3 +192,23 @@ def test_gno_ops_vs_float64_and_finite_differences(oracle):
             args_p[pos], args_m[pos] = ap, am
             fd = (loss(*args_p) - loss(*args_m)) / (2 * eps)
             assert abs(fd - grad[idx]) <= 2e-2 * max(1.0, abs(fd)), (pos, idx, fd, grad[idx])
+
+
+def test_oracle_has_not_drifted(oracle):
+    """tests/golden/oracle_regression.json (self-generated, see make_oracle_regression.py)"""
+    r = golden("oracle_regression.json")
+    pairs = np.array([[1, 2], [1, 3], [2, 3], [2, 4], [3, 5], [4, 5], [4, 6], [5, 6]]).T
+    g = csr_from_index_list(6, pairs, self_loops=True)
+    g2 = csr_from_index_list(6, pairs)
+    I = {k: np.array(v, np.float32) for k, v in r["inputs"].items()}
+    a = oracle.duvenaud_propagate(I["x"], I["e"], g.adj_ia, g.adj_ja)
+    c = oracle.duvenaud_update(a, I["w"], g.adj_ia, 2, 5, 3)
+    kap = oracle.gno_kernel_eval(I["coords"], I["theta"], 3, 8)
+    dk = oracle.gno_aggregate_bwd_k(I["gm"], I["x"], 8, g2.adj_ia, g2.adj_ja)
+    got = {"kipf_fwd": oracle.kipf_propagate(I["x"], g.adj_ia, g.adj_ja), "kipf_bwd": oracle.kipf_propagate_bwd(I["x"], g.adj_ia, g.adj_ja),
+           "duvenaud_propagate": a, "duvenaud_update": c, "duvenaud_update_bwd_w": oracle.duvenaud_update_bwd_w(c, a, g.adj_ia, 2, 5),
+           "gno_aggregate": oracle.gno_aggregate(I["x"], kap, g2.adj_ia, g2.adj_ja, 2),
+           "gno_dtheta": oracle.gno_kernel_bwd_theta(I["coords"], I["theta"], dk, 3),
+           "gno_dcoords": oracle.gno_kernel_bwd_coords(I["coords"], I["theta"], dk, 3)}
+    for k, v in got.items():
+        assert np.allclose(v, np.array(r[k], np.float32), rtol=2e-6, atol=1e-7), k
