@@ -174,3 +174,36 @@ def test_fortran_iso_c_binding_boundary(dev):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "passed all tests" in r.stdout
+
+
+def test_kipf_layers_on_the_euler_mesh(dev, oracle):
+    """the reference's only realistic in-tree graph: example/msgpass_euler's 12 800-vertex mesh
+    (tests/golden/euler_mesh_edges.npz), 5 time steps as in example/msgpass_euler/src/main.f90:75.
+    tanh rather than relu: over 6.5 M activations a few relu masks flip on last-bit differences of the
+    pre-activation, which makes a 5-step gradient comparison discontinuous (seen: 2e-3)."""
+    import os
+
+    from athena_amd.layers import kipf_msgpass_layer_type
+
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "euler_mesh_edges.npz"))
+    n = int(d["num_vertices"])
+    g = csr_from_index_list(n, d["index_list"], self_loops=True)
+    assert g.nnz == 2 * d["index_list"].shape[1] + n
+    rng = np.random.default_rng(0)
+    T_, nvf = 5, [4, 128, 128, 128, 128, 3]
+    layer = kipf_msgpass_layer_type(num_vertex_features=nvf, num_time_steps=T_, activation="tanh", seed=4)
+    x = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+    params = layer.get_params()
+    plist, o_ = [], 0
+    for t in range(1, T_ + 1):
+        k = nvf[t] * nvf[t - 1]
+        plist.append(params[o_:o_ + k]); o_ += k
+    layer.set_graph(g)
+    out = layer.forward([x]).cpu().numpy()
+    outs, tapes = ol.kipf_forward([g], [x], plist, nvf, "tanh")
+    assert_close(out, outs[0], 2e-5, "euler mesh forward (5 steps)")
+    up = rng.uniform(-1, 1, out.shape).astype(np.float32)
+    dx = layer.backward(up).cpu().numpy()
+    dxs, grads = ol.kipf_backward([g], tapes, plist, nvf, "tanh", [up])
+    assert_close(dx, dxs[0], 5e-5, "euler mesh dX")
+    assert_close(layer.get_gradients(), np.concatenate(grads), 5e-5, "euler mesh dW")
