@@ -387,3 +387,42 @@ def test_host_pointer_variants(dev, oracle):
     _capi.call("athena_mp_gno_aggregate_bwd_theta_host", d2.handle, 3, 8, 4, 6, P_(theta), P_(coords), P_(xx), P_(upg), P_(dth))
     dk = oracle.gno_aggregate_bwd_k(upg, xx, E, gg.adj_ia, gg.adj_ja)
     assert_close(dth, oracle.gno_kernel_bwd_theta(coords, theta, dk, 8), 2e-5)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_kipf_fuzz_shapes_and_degree_distributions(dev, oracle, seed):
+    """seeded fuzz: vertex counts 1..3000, feature counts 1..200, mean degrees 0..40, optional hubs
+    (> 512 entries), zero-degree rows, duplicate entries, rectangular column spaces"""
+    from athena_amd import DeviceGraph, ops
+
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(1, 3000))
+    F = int(rng.choice([1, 2, 3, 5, 8, 17, 32, 64, 100, 128, 132, 200]))
+    mean_deg = float(rng.choice([0.0, 0.5, 3.0, 10.0, 40.0]))
+    deg = rng.poisson(mean_deg, n).astype(np.int64)
+    if seed % 3 == 0 and n > 10:
+        deg[rng.integers(0, n, 2)] = rng.integers(513, 1500, 2)       # hubs
+    rect = seed % 4 == 1
+    n_cols = n + int(rng.integers(1, 500)) if rect else n
+    ia = np.concatenate([[1], 1 + np.cumsum(deg)]).astype(np.int32)
+    nnz = int(deg.sum())
+    ja = np.zeros((2, nnz), np.int32, order="F")
+    ja[0] = rng.integers(1, n_cols + 1, nnz)
+    row_deg = np.maximum(deg, 1).astype(np.int32)                       # avoid 0**-0.5 = inf in the comparison
+    col_deg = rng.integers(1, 50, n_cols).astype(np.int32)
+    if not rect:
+        col_deg = row_deg
+    x = rng.uniform(-1, 1, (n_cols, F)).astype(np.float32)
+    gr = rng.uniform(-1, 1, (n, F)).astype(np.float32)
+    g = DeviceGraph(ia, ja, n_cols=n_cols, n_edge_cols=0, row_deg=row_deg, col_deg=col_deg)
+    y = H(ops.kipf_propagate(g, T(x, dev)))
+    yo = oracle.kipf_propagate_rect(x, ia, ja, row_deg, col_deg)
+    short = deg <= 512
+    assert np.array_equal(y[short], yo[short])
+    assert_close(y, yo, 1e-5, "fwd") if nnz else None
+    d = H(ops.kipf_propagate_bwd(g, T(gr, dev)))
+    do = oracle.kipf_propagate_bwd(gr, ia, ja, n_out=n_cols)
+    cdeg = np.bincount(ja[0] - 1, minlength=n_cols)
+    assert np.array_equal(d[cdeg <= 512], do[cdeg <= 512])
+    if nnz:
+        assert_close(d, do, 1e-5, "bwd")
