@@ -51,7 +51,7 @@ __global__ __launch_bounds__(1024) void agg_gemm_kernel(const int32_t *__restric
                                                         const float *__restrict__ B, int b_nk,
                                                         const float *__restrict__ bias,
                                                         float *__restrict__ P, float *__restrict__ Z,
-                                                        int64_t n_rows)
+                                                        int64_t n_rows, unsigned long long *__restrict__ ticket)
 {
     static_assert(N == 128, "task mapping below assumes 128 output columns");
     constexpr int K = 128;
@@ -174,23 +174,28 @@ __global__ __launch_bounds__(1024) void agg_gemm_kernel(const int32_t *__restric
         if (P != nullptr && chunk < n_chunks && row < n_rows) *reinterpret_cast<v4f *>(P + row * K + 4 * gl) = acc;
     };
 
-    // Pipeline (same trip count in every workgroup, one barrier per chunk):
-    //   prologue: gather chunk 0 -> buffer 0; prefetch state of chunk 1; barrier
-    //   iteration i: issue first row loads of chunk i+1 | MFMA chunk i (buffer i&1) | finish chunk i+1 ->
-    //                buffer (i+1)&1 | prefetch state of chunk i+2 | barrier
-    // Buffer i&1 is rewritten in iteration i+1 (chunk i+2), after barrier i: all MFMA reads of chunk i done.
-    const int64_t iters = (n_chunks + gridDim.x - 1) / gridDim.x;
-    const int64_t stride = gridDim.x;
-    load_state(blockIdx.x);
-    issue_first();
-    store_row(blockIdx.x, 0, finish());
-    load_state(blockIdx.x + stride);
+    // Pipeline, one barrier per chunk.  Chunks are handed out by a device-wide ticket counter (zeroed by
+    // the launcher) so a workgroup that starts late -- e.g. because a communication kernel holds its CU --
+    // or that meets heavier rows simply takes fewer chunks; results do not depend on who processes what.
+    //   prologue: tickets k0, k1, k2; gather k0 -> buffer 0; prefetch state of k1; barrier
+    //   iteration: issue first row loads of k1 | MFMA k0 (buffer b) | finish k1 -> buffer b^1 |
+    //              prefetch state of k2 | draw the next ticket | barrier | (k0,k1,k2) <- (k1,k2,new)
+    // Buffer b is rewritten one iteration later, after the barrier: all MFMA reads of it are done.
+    __shared__ int64_t s_ticket[4];
+    auto draw = [&]() -> int64_t { return (int64_t)atomicAdd(ticket, 1ull); };
+    if (tid == 0) { s_ticket[0] = draw(); s_ticket[1] = draw(); s_ticket[2] = draw(); }
     __syncthreads();
-    for (int64_t it = 0; it < iters; ++it) {
-        const int64_t chunk = it * stride + blockIdx.x;
-        const int buf = (int)(it & 1);
-        issue_first();                                      // chunk + stride
-        if (chunk < n_chunks) {
+    int64_t k0 = s_ticket[0], k1 = s_ticket[1], k2 = s_ticket[2];
+    load_state(k0);
+    issue_first();
+    store_row(k0, 0, finish());
+    load_state(k1);
+    __syncthreads();
+    for (int it = 0; k0 < n_chunks; ++it) {
+        const int64_t chunk = k0;
+        const int buf = it & 1;
+        issue_first();                                      // rows of k1
+        {
             const float *arow = Ts + (buf * CH + 16 * rb + l15) * LD + 32 * g4;
             const float *brow = Bs + (16 * ct + l15) * LD + 32 * g4;
             f32x4 c = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -209,9 +214,13 @@ __global__ __launch_bounds__(1024) void agg_gemm_kernel(const int32_t *__restric
             for (int r = 0; r < 4; ++r)
                 if (row0 + r < n_rows) Z[(row0 + r) * N + col] = act_f<ACT>(c[r] + bv);
         }
-        store_row(chunk + stride, buf ^ 1, finish());
-        load_state(chunk + 2 * stride);
+        store_row(k1, buf ^ 1, finish());
+        load_state(k2);
+        if (tid == 0) s_ticket[it & 1] = draw();
         __syncthreads();
+        k0 = k1;
+        k1 = k2;
+        k2 = s_ticket[it & 1];
     }
 }
 
@@ -226,8 +235,14 @@ int launch_fused(const int32_t *rowptr, const int32_t *idx, const float *coef, c
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
+    // chunk ticket counter: one 8-byte word per launch from a small ring, zeroed on the stream
+    static unsigned long long *ring = nullptr;
+    static int slot = 0;
+    if (!ring) AMP_HIP(hipMalloc((void **)&ring, sizeof(unsigned long long) * 64));
+    unsigned long long *ticket = ring + (slot++ & 63);
+    AMP_HIP(hipMemsetAsync(ticket, 0, sizeof(unsigned long long), amp::stream()));
     hipLaunchKernelGGL((agg_gemm_kernel<N, COEF, ACT>), dim3(grid), dim3(1024), lds, amp::stream(), rowptr, idx, coef, x,
-                       B, b_nk, bias, P, Z, n_rows);
+                       B, b_nk, bias, P, Z, n_rows, ticket);
     AMP_LAUNCH_CHECK();
     return 0;
 }

@@ -63,20 +63,36 @@ def shard_entries(rank, world, n, pairs, cut=None, seed=20260424):
 
 
 class Shard:
-    """One rank's rows with columns renumbered [local | halo] and the halo exchange plan."""
+    """One rank's rows with columns renumbered [local | halo] and the halo exchange plan.
+
+    Local vertices are renumbered INTERIOR FIRST (rows that reference no remote vertex), so the rows
+    [0, n_int) can be processed while the halo is still in flight and only [n_int, n) wait for it.
+    `order[k]` = original local id of the vertex now called k (a layout choice of the partition; the
+    original order is recovered with `order`)."""
 
     def __init__(self, rank, world, n, rows, cols_global):
         self.rank, self.world, self.n = rank, world, n
-        counts = np.bincount(rows, minlength=n)
+        lo = rank * n
+        local = (cols_global >= lo) & (cols_global < lo + n)
+        is_bnd = np.zeros(n, bool)
+        is_bnd[rows[~local]] = True
+        self.order = np.argsort(is_bnd, kind="stable")                     # interior rows first
+        new_of_old = np.empty(n, np.int64)
+        new_of_old[self.order] = np.arange(n)
+        self.new_of_old = new_of_old
+        self.n_int = int(n - is_bnd.sum())
+        rows_new = new_of_old[rows]
+        perm = np.argsort(rows_new, kind="stable")                          # entry order inside a row is kept
+        rows_new, cols_global, local = rows_new[perm], cols_global[perm], local[perm]
+        counts = np.bincount(rows_new, minlength=n)
         self.adj_ia = np.concatenate([[1], 1 + np.cumsum(counts)]).astype(np.int32)
         self.cols_global = cols_global
         self.row_deg = counts.astype(np.int32)
-        lo = rank * n
-        local = (cols_global >= lo) & (cols_global < lo + n)
         self.halo_ids = np.unique(cols_global[~local])                      # sorted => grouped by owner
         owner = self.halo_ids // n
         self.recv_counts = np.bincount(owner, minlength=world).astype(np.int64)
-        col = np.where(local, cols_global - lo, n + np.searchsorted(self.halo_ids, cols_global))
+        col = np.where(local, new_of_old[np.where(local, cols_global - lo, 0)],
+                       n + np.searchsorted(self.halo_ids, cols_global))
         self.n_halo = int(self.halo_ids.size)
         self.nnz = int(cols_global.size)
         ja = np.zeros((2, self.nnz), np.int32, order="F")
@@ -84,7 +100,7 @@ class Shard:
         self.adj_ja = ja
         # backward (pull) graph: same rows, entries ordered by global source id (the order the
         # reference's scatter accumulates in, athena_diffstruc_extd_sub_kipf.f90:101-109)
-        key = rows * (np.int64(world) * n) + cols_global
+        key = rows_new * (np.int64(world) * n) + cols_global
         order = np.argsort(key, kind="stable")
         jb = np.zeros((2, self.nnz), np.int32, order="F")
         jb[0] = col[order] + 1
@@ -92,6 +108,12 @@ class Shard:
         self.send_idx = None     # filled by build_plan
         self.send_counts = None
         self.col_deg = None
+
+    def row_block(self, adj_ja, r0, r1):
+        """CSR of rows [r0, r1) as its own (adj_ia, adj_ja) pair"""
+        e0, e1 = int(self.adj_ia[r0]) - 1, int(self.adj_ia[r1]) - 1
+        ia = (self.adj_ia[r0:r1 + 1] - e0).astype(np.int32)
+        return ia, np.asfortranarray(adj_ja[:, e0:e1])
 
 
 def _p2p_start(send_bufs, recv_bufs, rank, world):
@@ -132,6 +154,8 @@ def build_plan(shard, device):
     asked = torch.empty(int(soff[-1]), dtype=torch.int64, device=device)
     _p2p_exchange([want[roff[p]:roff[p + 1]] if p != rank else None for p in range(world)],
                   [asked[soff[p]:soff[p + 1]] if p != rank else None for p in range(world)], rank, world)
+    new_of_old = torch.from_numpy(shard.new_of_old).to(device)
+    asked = new_of_old[asked] if asked.numel() else asked     # peers ask by original local id
     shard.send_idx = asked.to(torch.int32).contiguous()
     shard._roff, shard._soff = roff, soff
     # degrees of halo columns
@@ -209,8 +233,13 @@ class KipfShardStep:
         self.s, self.F, self.device = shard, F, device
         self.b = backend or HipBackend(device)
         n, nh = shard.n, shard.n_halo
-        self.g_fwd = self.b.make_graph(shard.adj_ia, shard.adj_ja, n + nh, shard.row_deg, shard.col_deg)
-        self.g_bwd = self.b.make_graph(shard.adj_ia, shard.adj_ja_bwd, n + nh, shard.row_deg, shard.col_deg)
+        ni = shard.n_int
+        def block(adj_ja, r0, r1):
+            ia, ja = shard.row_block(adj_ja, r0, r1)
+            return self.b.make_graph(ia, ja, n + nh, shard.row_deg[r0:r1], shard.col_deg)
+        # interior rows touch no halo column: they run while the exchange is in flight
+        self.g_fwd_int, self.g_fwd_bnd = block(shard.adj_ja, 0, ni), block(shard.adj_ja, ni, n)
+        self.g_bwd_int, self.g_bwd_bnd = block(shard.adj_ja_bwd, 0, ni), block(shard.adj_ja_bwd, ni, n)
         self.exact = exact
         rng = np.random.Generator(np.random.PCG64([seed, shard.rank]))
         self.x_ext = torch.empty((n + nh, F), dtype=torch.float32, device=device)
@@ -227,15 +256,18 @@ class KipfShardStep:
         self.xchg = HaloExchange(shard, F, device, self.b)
 
     def __call__(self):
-        s, b, F, n = self.s, self.b, self.F, self.s.n
-        self.xchg(self.x_ext)
-        b.kipf_layer_fwd(self.g_fwd, self.x_ext, self.W, F, P=self.P, Z=self.Z)
-        reqs = self.xchg.start(self.dZ_ext)           # halo of dZ in flight ...
-        b.matmul_dw(self.P, self.dZ, out=self.dW)     # ... under the dW contraction
+        s, b, F, n, ni = self.s, self.b, self.F, self.s.n, self.s.n_int
+        reqs = self.xchg.start(self.x_ext)                                        # halo of X in flight ...
+        b.kipf_layer_fwd(self.g_fwd_int, self.x_ext, self.W, F, P=self.P[:ni], Z=self.Z[:ni])   # ... under the interior rows
+        self.xchg.finish(reqs)
+        b.kipf_layer_fwd(self.g_fwd_bnd, self.x_ext, self.W, F, P=self.P[ni:], Z=self.Z[ni:])
+        reqs = self.xchg.start(self.dZ_ext)                                       # halo of dZ in flight ...
+        b.matmul_dw(self.P, self.dZ, out=self.dW)                                 # ... under dW
         if s.world > 1:
             dist.all_reduce(self.dW)
+        b.pull_gemm(self.g_bwd_int, self.dZ_ext, self.W, F, exact=self.exact, out=self.dX[:ni])   # ... and the interior rows
         self.xchg.finish(reqs)
-        b.pull_gemm(self.g_bwd, self.dZ_ext, self.W, F, exact=self.exact, out=self.dX)
+        b.pull_gemm(self.g_bwd_bnd, self.dZ_ext, self.W, F, exact=self.exact, out=self.dX[ni:])
         return self.dX
 
 
@@ -245,5 +277,6 @@ def build_kipf_step(shard, F, device, backend=None):
     uniform = shard.world > 1 and abs(shard.cut - (shard.world - 1) / shard.world) < 1e-9
     info = {"graph": "random graph, both endpoints uniform over all N*vertices_per_gpu vertices (no partition structure)" if uniform
             else f"stochastic block model, one block per GPU, fixed inter-block density: {shard.cut:.4f} of the undirected pairs cross partitions at this N",
-            "halo_rows_per_gpu": shard.n_halo, "halo_bytes_per_gpu_per_step": halo_bytes}
+            "halo_rows_per_gpu": shard.n_halo, "halo_bytes_per_gpu_per_step": halo_bytes,
+            "interior_rows_per_gpu": shard.n_int}
     return step, shard.nnz, info

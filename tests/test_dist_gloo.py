@@ -74,7 +74,8 @@ def _worker(rank, world, port, n, pairs, F, cut, q):
     dx = step().clone().numpy()
     q.put((rank, dict(x=x_local, dz=step.dZ.numpy().copy(), w=step.W.numpy().copy(), P=step.P.numpy().copy(),
                       Z=step.Z.numpy().copy(), dW=step.dW.numpy().copy(), dX=dx, n_halo=shard.n_halo,
-                      send=int(shard.send_idx.numel()), col_deg=shard.col_deg.copy())))
+                      send=int(shard.send_idx.numel()), col_deg=shard.col_deg.copy(), order=shard.order.copy(),
+                      n_int=shard.n_int)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -110,23 +111,31 @@ def test_multi_rank_kipf_step_matches_global_oracle(oracle, world, cut):
     # the generated graph is symmetric as a multiset (undirected), which the pull-form backward relies on
     A = np.zeros((N, N), np.int64); np.add.at(A, (rows, cols), 1)
     assert np.array_equal(A, A.T)
-    x = np.concatenate([res[r]["x"] for r in range(world)])
-    dz = np.concatenate([res[r]["dz"] for r in range(world)])
+    # shards number their vertices interior-first: row k of rank r is original local vertex order[k]
+    def unperm(key):
+        out = []
+        for r in range(world):
+            a = np.empty_like(res[r][key]); a[res[r]["order"]] = res[r][key]; out.append(a)
+        return np.concatenate(out)
+    x, dz = unperm("x"), unperm("dz")
     w = res[0]["w"]
     assert all(np.array_equal(w, res[r]["w"]) for r in range(world))
     P = oracle.kipf_propagate(x, ia, ja)
-    assert np.array_equal(np.concatenate([res[r]["P"] for r in range(world)]), P)          # bit-exact
-    assert np.array_equal(np.concatenate([res[r]["Z"] for r in range(world)]), oracle.matmul(w, P, F))
+    assert np.array_equal(unperm("P"), P)                                                  # bit-exact
+    assert np.array_equal(unperm("Z"), oracle.matmul(w, P, F))
     dP = oracle.matmul_dx(w, dz, F)
     dX = oracle.kipf_propagate_bwd(dP, ia, ja)                                             # reference: no coefficient
-    got = np.concatenate([res[r]["dX"] for r in range(world)])                             # (A^T dZ) W: same map,
+    got = unperm("dX")                                                                     # (A^T dZ) W: same map,
     assert np.abs(got - dX).max() <= 1e-5 * np.abs(dX).max()                               # re-associated
     dW = oracle.matmul_dw(dz, P)
     for r in range(world):
         assert np.abs(res[r]["dW"] - dW).max() <= 1e-5 * np.abs(dW).max()                  # all-reduced
         assert res[r]["n_halo"] > 0 and res[r]["send"] > 0
     deg = np.diff(ia)
-    assert np.array_equal(res[0]["col_deg"][:n], deg[:n])
+    assert np.array_equal(res[0]["col_deg"][:n], deg[:n][res[0]["order"]])
+    assert all(0 <= res[r]["n_int"] < n for r in range(world))
+    if cut is not None:
+        assert all(res[r]["n_int"] > n // 4 for r in range(world))   # planted partitions leave interior rows
 
 
 def test_shard_generator_balances_entries():
