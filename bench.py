@@ -71,7 +71,7 @@ def main():
                          "the fraction at N blocks is cut8*(N-1)/7).  -1: structure-free uniform random graph")
     ap.add_argument("--no-variant", action="store_true", help="N>1: skip the uniform-random variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-rows", type=int, default=500_000)
+    ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000, help="rows of the workload the 1-thread CPU oracle runs (default: all of it, ~7-15 s)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
