@@ -53,15 +53,20 @@ __global__ __launch_bounds__(1024) void agg_gemm_kernel(const int32_t *__restric
                                                         float *__restrict__ P, float *__restrict__ Z,
                                                         int64_t n_rows, unsigned long long *__restrict__ ticket)
 {
-    static_assert(N == 128, "task mapping below assumes 128 output columns");
-    constexpr int K = 128;
+    // square layers, N = K in {64, 128}: a row is K/4 lanes of float4, a wave holds 64/(K/4) rows, a chunk is
+    // 16 waves' worth of rows, and its CH x N output is exactly 16 blocks of 16x16 -- one per wave
+    static_assert(N == 64 || N == 128, "fused kernel: 64- or 128-wide square layers");
+    constexpr int K = N;
     constexpr int LD = K + 4;
-    constexpr int CH = 32;                // rows per chunk: 16 waves x 1 pair
+    constexpr int G = K / 4;              // lanes per row
+    constexpr int RPW = 64 / G;           // rows per wave: 2 (K=128) or 4 (K=64)
+    constexpr int CH = 16 * RPW;          // rows per chunk
+    constexpr int KG = K / 4;             // k range of one MFMA lane group (k = KG*g4 + s)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *Bs = lds;                      // [N][LD]
     float *Ts = lds + N * LD;             // [2 buffers][CH rows][LD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = lane >> 5, gl = lane & 31;
+    const int h = lane / G, gl = lane & (G - 1);
 
     {   // W resident in LDS as [n][K+4]
         constexpr int NV = K * N / 4, PER = (NV + 1023) / 1024;
@@ -89,11 +94,11 @@ __global__ __launch_bounds__(1024) void agg_gemm_kernel(const int32_t *__restric
         }
     }
     const int64_t n_chunks = (n_rows + CH - 1) / CH;
-    // matrix task: rows 16*rb .. +15 of the chunk (rb = wave&1), columns 16*ct .. +15 (ct = wave>>1)
-    const int rb = wave & 1, ct = wave >> 1;
+    // matrix task: rows 16*rb .. +15 of the chunk, columns 16*ct .. +15
+    const int rb = wave % RPW, ct = wave / RPW;
     const int l15 = lane & 15, g4 = lane >> 4;
     const float bv = bias ? bias[16 * ct + l15] : 0.0f;
-    const int lrow = 2 * wave + h;        // this half-wave's row inside a chunk
+    const int lrow = RPW * wave + h;      // this lane group's row inside a chunk
 
     // per-chunk gather state of this half-wave's row
     int start = 0, len = 0, idx0 = -1;
@@ -110,11 +115,12 @@ __global__ __launch_bounds__(1024) void agg_gemm_kernel(const int32_t *__restric
             if constexpr (COEF) c0 = coef[start + gl];
         }
     };
-    v4f v[kFirst];
-    auto issue_first = [&]() {            // row loads of entries 0 .. kFirst-1 (no waits)
+    constexpr int kF = kFirst < G ? kFirst : G;   // entries whose loads fly under the matrix work
+    v4f v[kF];
+    auto issue_first = [&]() {            // row loads of entries 0 .. kF-1 (no waits)
 #pragma unroll
-        for (int k = 0; k < kFirst; ++k) {
-            const int u = __shfl(idx0, k, 32);
+        for (int k = 0; k < kF; ++k) {
+            const int u = __shfl(idx0, k, G);
             v[k] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
             if (k < len && u >= 0) v[k] = *reinterpret_cast<const v4f *>(x + (int64_t)u * K + 4 * gl);
         }
@@ -122,16 +128,18 @@ __global__ __launch_bounds__(1024) void agg_gemm_kernel(const int32_t *__restric
     auto finish = [&]() -> v4f {          // CSR-order accumulation: first block from registers, rest streamed
         v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int k = 0; k < kFirst; ++k) {
-            const int u = __shfl(idx0, k, 32);
-            const float c = COEF ? __shfl(c0, k, 32) : 1.0f;
+        for (int k = 0; k < kF; ++k) {
+            const int u = __shfl(idx0, k, G);
+            const float c = COEF ? __shfl(c0, k, G) : 1.0f;
             if (k < len && u >= 0) {
                 if constexpr (COEF) { acc.x = acc.x + c * v[k].x; acc.y = acc.y + c * v[k].y; acc.z = acc.z + c * v[k].z; acc.w = acc.w + c * v[k].w; }
                 else { acc.x = acc.x + v[k].x; acc.y = acc.y + v[k].y; acc.z = acc.z + v[k].z; acc.w = acc.w + v[k].w; }
             }
         }
-        const int maxlen = max(len, __shfl_xor(len, 32));
-        for (int off = 0; off < maxlen; off += 32) {          // entries kFirst.. of long rows
+        int maxlen = len;
+#pragma unroll
+        for (int o = G; o < 64; o <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o));
+        for (int off = 0; off < maxlen; off += G) {            // entries kFirst.. of long rows
             int my_idx = idx0;
             float my_c = c0;
             if (off > 0) {
@@ -141,15 +149,15 @@ __global__ __launch_bounds__(1024) void agg_gemm_kernel(const int32_t *__restric
                     if constexpr (COEF) my_c = coef[start + off + gl];
                 }
             }
-            const int cntmax = min(32, maxlen - off);
-            for (int j = (off == 0 ? kFirst : 0); j < cntmax; j += kUn) {
+            const int cntmax = min(G, maxlen - off);
+            for (int j = (off == 0 ? kF : 0); j < cntmax; j += kUn) {
                 int u[kUn];
                 float c[kUn];
                 v4f w[kUn];
 #pragma unroll
                 for (int k = 0; k < kUn; ++k) {
-                    u[k] = __shfl(my_idx, j + k, 32);
-                    if constexpr (COEF) c[k] = __shfl(my_c, j + k, 32);
+                    u[k] = __shfl(my_idx, j + k, G);
+                    if constexpr (COEF) c[k] = __shfl(my_c, j + k, G);
                     if (off + j + k >= len) u[k] = -1;
                 }
 #pragma unroll
@@ -196,11 +204,11 @@ __global__ __launch_bounds__(1024) void agg_gemm_kernel(const int32_t *__restric
         const int buf = it & 1;
         issue_first();                                      // rows of k1
         {
-            const float *arow = Ts + (buf * CH + 16 * rb + l15) * LD + 32 * g4;
-            const float *brow = Bs + (16 * ct + l15) * LD + 32 * g4;
+            const float *arow = Ts + (buf * CH + 16 * rb + l15) * LD + KG * g4;
+            const float *brow = Bs + (16 * ct + l15) * LD + KG * g4;
             f32x4 c = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < KG / 4; ++q) {
                 const v4f a4 = *reinterpret_cast<const v4f *>(arow + 4 * q);
                 const v4f b4 = *reinterpret_cast<const v4f *>(brow + 4 * q);
                 c = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, c, 0, 0, 0);
@@ -228,7 +236,8 @@ template <int N, bool COEF, int ACT>
 int launch_fused(const int32_t *rowptr, const int32_t *idx, const float *coef, const float *x, const float *B,
                  int b_nk, const float *bias, float *P, float *Z, int64_t n_rows, int grid)
 {
-    constexpr size_t lds = sizeof(float) * ((size_t)N * 132 + 2 * 32 * 132);
+    constexpr int CHr = 16 * (64 / (N / 4));
+    constexpr size_t lds = sizeof(float) * ((size_t)N * (N + 4) + 2 * CHr * (N + 4));
     static bool attr = false;
     if (!attr) {
         AMP_HIP(hipFuncSetAttribute((const void *)agg_gemm_kernel<N, COEF, ACT>,
@@ -247,23 +256,29 @@ int launch_fused(const int32_t *rowptr, const int32_t *idx, const float *coef, c
     return 0;
 }
 
+bool fused_shape(int K, int N) { return K == N && (K == 64 || K == 128); }
+
 int fused_dispatch(const int32_t *rowptr, const int32_t *idx, const float *coef, const float *x, int K, int N,
                    const float *B, int b_nk, const float *bias, int act, float *P, float *Z, int64_t n_rows)
 {
-    if (K != 128 || N != 128) {
-        amp::set_error("fused Kipf layer kernel: built for 128 -> 128 features, got %d -> %d", K, N);
+    if (!fused_shape(K, N)) {
+        amp::set_error("fused Kipf layer kernel: built for 64 -> 64 and 128 -> 128 features, got %d -> %d", K, N);
         return 2;
     }
     int dev = 0;
     hipDeviceProp_t prop;
     int cus = 256;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    const int grid = (int)std::min<int64_t>((n_rows + 31) / 32, cus);
+    const int ch = 16 * (64 / (N / 4));
+    const int grid = (int)std::min<int64_t>((n_rows + ch - 1) / ch, cus);
     if (grid == 0) return 0;
     const bool c = coef != nullptr;
-#define AMP_F(ACT_)                                                                                         \
-    return c ? launch_fused<128, true, ACT_>(rowptr, idx, coef, x, B, b_nk, bias, P, Z, n_rows, grid)         \
-             : launch_fused<128, false, ACT_>(rowptr, idx, coef, x, B, b_nk, bias, P, Z, n_rows, grid)
+#define AMP_F2(NN_, ACT_)                                                                                    \
+    return c ? launch_fused<NN_, true, ACT_>(rowptr, idx, coef, x, B, b_nk, bias, P, Z, n_rows, grid)          \
+             : launch_fused<NN_, false, ACT_>(rowptr, idx, coef, x, B, b_nk, bias, P, Z, n_rows, grid)
+#define AMP_F(ACT_)                    \
+    if (N == 64) { AMP_F2(64, ACT_); } \
+    AMP_F2(128, ACT_)
     switch (act) {
     case ATHENA_MP_ACT_RELU: AMP_F(ATHENA_MP_ACT_RELU);
     case ATHENA_MP_ACT_SIGMOID: AMP_F(ATHENA_MP_ACT_SIGMOID);
@@ -271,6 +286,7 @@ int fused_dispatch(const int32_t *rowptr, const int32_t *idx, const float *coef,
     default: AMP_F(ATHENA_MP_ACT_NONE);
     }
 #undef AMP_F
+#undef AMP_F2
 }
 
 } // namespace
@@ -287,7 +303,7 @@ int athena_mp_kipf_layer_fwd(const athena_mp_graph *g, int32_t Fi, int32_t Fo, c
     AMP_REQUIRE(x && W && P && Z, "kipf_layer_fwd: null tensor");
     // hub rows (> kLongRow entries) would stall a whole workgroup at the chunk barrier: such graphs take
     // the two-kernel route, whose aggregation splits them into parallel segments
-    if (Fi == 128 && Fo == 128 && g->lp_fwd.n_long == 0)
+    if (fused_shape(Fi, Fo) && g->lp_fwd.n_long == 0)
         return fused_dispatch(g->rowptr, g->col, g->coef, x, Fi, Fo, W, 0, bias, act, P, Z, g->n_rows);
     int rc = athena_mp_kipf_propagate_fwd(g, Fi, x, P);   // other widths: the two kernels back to back
     if (rc) return rc;
@@ -300,7 +316,7 @@ int athena_mp_kipf_layer_bwd_x(const athena_mp_graph *g, int32_t Fi, int32_t Fo,
     AMP_REQUIRE(g && Fi > 0 && Fo > 0, "kipf_layer_bwd_x: bad arguments");
     if (g->n_cols == 0) return 0;
     AMP_REQUIRE(dZ && W && dX, "kipf_layer_bwd_x: null tensor");
-    if (Fi == 128 && Fo == 128 && g->lp_bwd.n_long == 0) // dX = (A^T dZ) . W : aggregate, then contract with B [N=Fi][K=Fo]
+    if (fused_shape(Fi, Fo) && g->lp_bwd.n_long == 0) // dX = (A^T dZ) . W : aggregate, then contract with B [N=Fi][K=Fo]
         return fused_dispatch(g->t_rowptr, g->t_src, exact ? g->t_coef : nullptr, dZ, Fo, Fi, W, 1, nullptr,
                               ATHENA_MP_ACT_NONE, nullptr, dX, g->n_cols);
     void *ws = nullptr;
@@ -318,7 +334,7 @@ int athena_mp_pull_gemm(const athena_mp_graph *g, int32_t Fi, int32_t Fo, const 
     AMP_REQUIRE(g && Fi > 0 && Fo > 0, "pull_gemm: bad arguments");
     if (g->n_rows == 0) return 0;
     AMP_REQUIRE(dZ && W && dX, "pull_gemm: null tensor");
-    if (Fi == 128 && Fo == 128 && g->lp_fwd.n_long == 0)
+    if (fused_shape(Fi, Fo) && g->lp_fwd.n_long == 0)
         return fused_dispatch(g->rowptr, g->col, exact ? g->coef : nullptr, dZ, Fo, Fi, W, 1, nullptr,
                               ATHENA_MP_ACT_NONE, nullptr, dX, g->n_rows);
     void *ws = nullptr;

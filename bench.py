@@ -190,7 +190,7 @@ def main():
                 traffic = json.load(open(tpath)).get("agg_gemm_fwd_bytes_per_launch")
             except Exception:
                 traffic = None
-        kname = ("agg_gemm_kernel<128,coef> (fused kipf_propagate + matmul fwd)" if F == 128 else
+        kname = (f"agg_gemm_kernel<{F},coef> (fused kipf_propagate + matmul fwd)" if F in (64, 128) else
                  "kipf_layer_fwd = csr_gather_agg + dense step (two launches at this width)")
         out["roofline"] = {"bound": "hbm", "kernel": kname,
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -297,13 +297,13 @@ def H_(t):
     return t.cpu().numpy()
 
 
-@pytest.mark.parametrize("act", ["none", "relu"])
-def test_fused_kipf_layer_kernels(dev, oracle, act):
+@pytest.mark.parametrize("act,F", [("none", 128), ("relu", 128), ("none", 64), ("tanh", 64)])
+def test_fused_kipf_layer_kernels(dev, oracle, act, F):
     """one-launch aggregation + dense step: P bit-exact vs the oracle's kipf_propagate, Z and dX within
     1e-5 of the oracle's unfused order (incl. a hub row, zero-degree rows, a ragged tail chunk)"""
     from athena_amd import DeviceGraph, ops
 
-    n, F = 4133, 128
+    n = 4133
     ia, ja = random_graph(n, 5 * n, seed=77, self_loops=True, isolated=9)
     ia0, ja0 = ia.copy(), ja.copy()
     # add a hub: vertex 1 gets 700 extra symmetric neighbours
@@ -336,6 +336,13 @@ def test_fused_kipf_layer_kernels(dev, oracle, act):
         dX = H(ops.kipf_layer_bwd_x(g, T(dz, dev), T(w, dev), F, exact=exact))
         ref = oracle.kipf_propagate_bwd(oracle.matmul_dx(w, dz, F), ia, ja, exact=exact)
         assert_close(dX, ref, 1e-5, f"fused dX exact={exact}")
+    # rows of 17..40 entries exercise the second index block of the 16-lane (F = 64) mapping
+    ia3, ja3 = random_graph(n, 12 * n, seed=78, self_loops=True)
+    g3 = DeviceGraph(ia3, ja3, n_edge_cols=0)
+    P3, Z3 = ops.kipf_layer_fwd(g3, T(x, dev), T(w, dev), F, act=act)
+    Po3 = oracle.kipf_propagate(x, ia3, ja3)
+    assert np.array_equal(H(P3), Po3)
+    assert_close(H(Z3), oracle.activation(act, oracle.matmul(w, Po3, F)), 1e-5, "fused Z (dense rows)")
     # other widths take the two-kernel route behind the same entry points
     x2 = rng.uniform(-1, 1, (n, 64)).astype(np.float32); w2 = rng.standard_normal(64 * 32).astype(np.float32)
     P2, Z2 = ops.kipf_layer_fwd(g, T(x2, dev), T(w2, dev), 32)
