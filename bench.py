@@ -185,7 +185,7 @@ def main():
         achieved = alg_bytes / (agg_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and (args.nodes, args.pairs, F) == (1_000_000, 4_500_000, 128):
             try:
                 traffic = json.load(open(tpath)).get("agg_gemm_fwd_bytes_per_launch")
             except Exception:
