@@ -58,6 +58,8 @@ _PROTOS = {
     "athena_mp_duvenaud_update_bwd_w": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
     "athena_mp_softmax_segsum_fwd": [_i32, _i64, _i32, _vp, _vp, _vp, _vp, _i32],
     "athena_mp_softmax_segsum_bwd": [_i32, _i64, _i32, _vp, _vp, _vp, _vp],
+    "athena_mp_duvenaud_readout_fwd": [_i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32],
+    "athena_mp_duvenaud_readout_bwd": [_i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32],
     "athena_mp_gno_aggregate_fwd": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "athena_mp_gno_aggregate_bwd_x": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "athena_mp_gno_aggregate_bwd_theta": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],

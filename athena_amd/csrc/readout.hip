@@ -1,0 +1,322 @@
+// Duvenaud readout of one time step in one launch per direction.
+//
+//   forward   athena_duvenaud_msgpass_layer.f90:838-855
+//       p[v,:] = softmax_over_outputs(R z[v,:]);   out[s,:] (+)= sum_{v in graph s} p[v,:]
+//   reverse   the chain softmax (athena_diffstruc_extd_sub.f90:309-313) -> matmul (diffstruc) ->
+//             message activation (athena_activation_*.f90 differentiate), composed:
+//       dl[v,:] = p[v,:] (g_s - <g_s, p[v,:]>);  dR (+)= dl^T z;  dc = act'(z) (dl R + dz_next)
+//
+// The number of outputs O is small (10 in msgpass_chemical), so the contraction is written with the
+// VERTEX index on the MFMA column (n) axis: every 16x16x4 MFMA handles 16 vertices, the logits of a
+// vertex land in 4 lanes x 4 registers, and the softmax is two cross-lane steps.  z is read exactly
+// once per direction (16 B per lane, row-contiguous), logits and dl never reach HBM.
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <int ACT>
+__device__ __forceinline__ float act_back(float y, float g)
+{
+    if constexpr (ACT == ATHENA_MP_ACT_RELU) return y > 0.0f ? g : 0.0f;
+    if constexpr (ACT == ATHENA_MP_ACT_SIGMOID) return g * y * (1.0f - y);
+    if constexpr (ACT == ATHENA_MP_ACT_TANH) return g * (1.0f - y * y);
+    return g;
+}
+
+__device__ __forceinline__ float xor_add(float v)
+{
+    v = v + __shfl_xor(v, 16);
+    return v + __shfl_xor(v, 32);
+}
+__device__ __forceinline__ float xor_max(float v)
+{
+    v = fmaxf(v, __shfl_xor(v, 16));
+    return fmaxf(v, __shfl_xor(v, 32));
+}
+
+// lane (n = lane&15, q = lane>>4):  z fragment j = z[row n][16j + 4q .. +3]  (B operand, k = q)
+//                                   R fragment (j,c) = R[o = n][16j + 4q + c] (A operand, m = o)
+// accumulator register r = logits[row n][o = 4q + r]
+template <int J>
+__global__ __launch_bounds__(256) void readout_fwd_kernel(int O, int64_t N, const float *__restrict__ z,
+                                                          const float *__restrict__ R, float *__restrict__ p)
+{
+    constexpr int FV = 16 * J;
+    const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4;
+    const int64_t gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
+    const int64_t tiles = (N + 15) >> 4;
+
+    float Rf[J][4];
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Rf[j][c] = n < O ? R[(size_t)(16 * j + 4 * q + c) * O + n] : 0.0f;
+
+    v4f zf[J], zn[J];
+    auto load = [&](v4f(&dst)[J], int64_t tile) {
+        const int64_t row = min(tile * 16 + n, N - 1);
+        const float *src = z + row * FV + 4 * q;
+#pragma unroll
+        for (int j = 0; j < J; ++j) dst[j] = *reinterpret_cast<const v4f *>(src + 16 * j);
+    };
+    if (gw < tiles) load(zn, gw);
+    for (int64_t tile = gw; tile < tiles; tile += nw) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) zf[j] = zn[j];
+        if (tile + nw < tiles) load(zn, tile + nw);
+        v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Rf[j][c], zf[j][c], acc, 0, 0, 0);
+        float m = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (4 * q + r < O) m = fmaxf(m, acc[r]);
+        m = xor_max(m);
+        float e[4], s = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            e[r] = 4 * q + r < O ? expf(acc[r] - m) : 0.0f;
+            s = s + e[r];
+        }
+        s = xor_add(s);
+        const int64_t row = tile * 16 + n;
+        if (row < N) {
+            float *dst = p + row * O + 4 * q;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * q + r < O) dst[r] = e[r] / s;
+        }
+    }
+}
+
+// one thread per (graph, output): sequential over the graph's vertices (the reference's order)
+__global__ void readout_segsum_kernel(int O, int S, const int32_t *__restrict__ seg, const float *__restrict__ p,
+                                      float *__restrict__ out, int accumulate)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= S * O) return;
+    int s = t / O, o = t - s * O;
+    float acc = 0.0f;
+    for (int v = seg[s]; v < seg[s + 1]; ++v) acc = acc + p[(size_t)v * O + o];
+    out[t] = accumulate ? out[t] + acc : acc;
+}
+
+// graph of every vertex (binary search over the S+1 offsets)
+__global__ void readout_gid_kernel(int64_t N, int S, const int32_t *__restrict__ seg, int32_t *__restrict__ gid)
+{
+    int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= N) return;
+    int lo = 0, hi = S; // seg[lo] <= v < seg[hi]
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (seg[mid] <= v) lo = mid; else hi = mid;
+    }
+    gid[v] = lo;
+}
+
+// Reverse pass.  dl stays in registers as the B operand (k = q <-> o = 4q + r) of the dz product,
+// whose accumulator comes out in the z-fragment layout, so dc = act'(z)(dz + dz_next) is formed in
+// place and stored 16 B per lane.  dR contracts over VERTICES, so z and dl are turned once through a
+// wave-private LDS tile to put the vertex on the k axis.
+template <int J, int ACT>
+__global__ __launch_bounds__(256) void readout_bwd_kernel(int O, int64_t N, const float *__restrict__ z,
+                                                          const float *__restrict__ R, const float *__restrict__ p,
+                                                          const int32_t *__restrict__ gid,
+                                                          const float *__restrict__ gout,
+                                                          const float *__restrict__ dz_in, float *__restrict__ dc,
+                                                          float *__restrict__ slabs)
+{
+    constexpr int FV = 16 * J, ZP = FV + 4, DP = 20;
+    __shared__ __attribute__((aligned(16))) float zl_all[4][16 * ZP];
+    __shared__ float dl_all[4][16 * DP];
+    __shared__ float red[4][FV * 16];
+    const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4, wave = threadIdx.x >> 6;
+    float *zl = zl_all[wave], *dll = dl_all[wave];
+    const int64_t gw = (int64_t)blockIdx.x * 4 + wave, nw = (int64_t)gridDim.x * 4;
+    const int64_t tiles = (N + 15) >> 4;
+
+    // A operand of the dz product: (ft, r) -> R[o = 4q' + r][f = 16 ft + m] with m = n, k = q' = q
+    float Ra[J][4];
+#pragma unroll
+    for (int ft = 0; ft < J; ++ft)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ra[ft][r] = 4 * q + r < O ? R[(size_t)(16 * ft + n) * O + 4 * q + r] : 0.0f;
+
+    v4f accR[J];
+#pragma unroll
+    for (int ft = 0; ft < J; ++ft) accR[ft] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+
+    v4f zf[J], zn[J];
+    float pf[4], pn[4], gf[4], gn[4];
+    auto load = [&](v4f(&zd)[J], float(&pd)[4], float(&gd)[4], int64_t tile) {
+        const int64_t row = min(tile * 16 + n, N - 1);
+        const float *src = z + row * FV + 4 * q;
+#pragma unroll
+        for (int j = 0; j < J; ++j) zd[j] = *reinterpret_cast<const v4f *>(src + 16 * j);
+        const float *ps = p + row * O + 4 * q;
+        const float *gs = gout + (size_t)gid[row] * O + 4 * q;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool ok = 4 * q + r < O;
+            pd[r] = ok ? ps[r] : 0.0f;
+            gd[r] = ok ? gs[r] : 0.0f;
+        }
+    };
+    if (gw < tiles) load(zn, pn, gn, gw);
+    for (int64_t tile = gw; tile < tiles; tile += nw) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) zf[j] = zn[j];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pf[r] = pn[r], gf[r] = gn[r];
+        if (tile + nw < tiles) load(zn, pn, gn, tile + nw);
+        const int64_t row = tile * 16 + n;
+        const bool ok = row < N;
+
+        float dot = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dot = dot + gf[r] * pf[r];
+        dot = xor_add(dot);
+        float dl[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dl[r] = ok ? pf[r] * (gf[r] - dot) : 0.0f;
+
+        // stage the tile for the vertex-contracted product before the registers are consumed
+#pragma unroll
+        for (int j = 0; j < J; ++j) *reinterpret_cast<v4f *>(zl + n * ZP + 16 * j + 4 * q) = zf[j];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dll[n * DP + 4 * q + r] = dl[r];
+
+        // dz[row n][16 ft + 4q .. +3] = sum_o dl[row][o] R[o][f]
+        float *dst = dc + row * FV + 4 * q;
+        const float *din = dz_in ? dz_in + min(row, N - 1) * FV + 4 * q : nullptr;
+#pragma unroll
+        for (int ft = 0; ft < J; ++ft) {
+            v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Ra[ft][r], dl[r], acc, 0, 0, 0);
+            if (din) acc = acc + *reinterpret_cast<const v4f *>(din + 16 * ft);
+            v4f o4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o4[c] = act_back<ACT>(zf[ft][c], acc[c]);
+            if (ok) *reinterpret_cast<v4f *>(dst + 16 * ft) = o4;
+        }
+
+        // dR[f][o] += sum_rows z[row][f] dl[row][o]:  A[m = f][k = row], B[k = row][n = o]
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float db[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) db[r] = dll[(4 * q + r) * DP + n];
+#pragma unroll
+        for (int ft = 0; ft < J; ++ft)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                accR[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(zl[(4 * q + r) * ZP + 16 * ft + n], db[r], accR[ft], 0, 0, 0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // accR[ft][r] = dR[f = 16 ft + 4q + r][o = n]; waves added in fixed order, one slab per workgroup
+#pragma unroll
+    for (int ft = 0; ft < J; ++ft)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][(16 * ft + 4 * q + r) * 16 + n] = accR[ft][r];
+    __syncthreads();
+    float *slab = slabs + (size_t)blockIdx.x * FV * O;
+    for (int t = threadIdx.x; t < FV * O; t += 256) {
+        const int f = t / O, o = t - f * O;
+        slab[t] = ((red[0][f * 16 + o] + red[1][f * 16 + o]) + red[2][f * 16 + o]) + red[3][f * 16 + o];
+    }
+}
+
+bool fused_readout_shape(int Fv, int O) { return O <= 16 && (Fv == 16 || Fv == 32 || Fv == 64 || Fv == 128); }
+
+int readout_grid(int64_t N)
+{
+    const int64_t tiles = (N + 15) / 16;
+    return (int)std::max<int64_t>(1, std::min<int64_t>((tiles + 3) / 4, 256 * 8));
+}
+
+} // namespace
+
+using namespace amp;
+
+extern "C" {
+
+int athena_mp_duvenaud_readout_fwd(int64_t N, int32_t Fv, int32_t O, int32_t S, const int32_t *seg,
+                                   const float *z, const float *R, float *p, float *out, int32_t accumulate)
+{
+    AMP_REQUIRE(N >= 0 && Fv > 0 && O > 0 && S >= 0 && seg && R && out && (N == 0 || (z && p)),
+                "duvenaud_readout_fwd: bad arguments");
+    if (N > 0) {
+        if (fused_readout_shape(Fv, O)) {
+            const dim3 grid(readout_grid(N));
+#define AMP_CASE(J_)                                                                                               \
+    if (Fv == 16 * J_) hipLaunchKernelGGL((readout_fwd_kernel<J_>), grid, dim3(256), 0, stream(), O, N, z, R, p);
+            AMP_CASE(1) AMP_CASE(2) AMP_CASE(4) AMP_CASE(8)
+#undef AMP_CASE
+            AMP_LAUNCH_CHECK();
+        } else {
+            void *lg = nullptr;
+            if (workspace(&lg, sizeof(float) * (size_t)N * O, 5)) return 1;
+            int rc = athena_mp_gemm_fwd(N, Fv, O, z, R, nullptr, ATHENA_MP_ACT_NONE, (float *)lg);
+            if (rc) return rc;
+            return athena_mp_softmax_segsum_fwd(O, N, S, seg, (const float *)lg, p, out, accumulate);
+        }
+    }
+    if (S > 0) {
+        hipLaunchKernelGGL(readout_segsum_kernel, dim3((unsigned)(((int64_t)S * O + 255) / 256)), dim3(256), 0,
+                           stream(), O, S, seg, p, out, accumulate);
+        AMP_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+int athena_mp_duvenaud_readout_bwd(int64_t N, int32_t Fv, int32_t O, int32_t S, const int32_t *seg,
+                                   const float *z, const float *R, const float *p, const float *gout,
+                                   const float *dz_next, int32_t act, float *dc, float *dR, int32_t accumulate)
+{
+    AMP_REQUIRE(N >= 0 && Fv > 0 && O > 0 && S > 0 && seg && R && gout && dR && (N == 0 || (z && p && dc)),
+                "duvenaud_readout_bwd: bad arguments");
+    AMP_REQUIRE(act >= 0 && act <= ATHENA_MP_ACT_TANH, "duvenaud_readout_bwd: unknown activation %d", act);
+    const int n = Fv * O;
+    if (N == 0) {
+        if (!accumulate) AMP_HIP(hipMemsetAsync(dR, 0, sizeof(float) * n, stream()));
+        return 0;
+    }
+    if (!fused_readout_shape(Fv, O)) {
+        void *dl = nullptr;
+        if (workspace(&dl, sizeof(float) * (size_t)N * O, 5)) return 1;
+        int rc = athena_mp_softmax_segsum_bwd(O, N, S, seg, p, gout, (float *)dl);
+        if (!rc) rc = gemm_dw_dispatch(N, Fv, O, z, (const float *)dl, dR, accumulate != 0);
+        if (!rc) rc = athena_mp_gemm_dx(N, Fv, O, (const float *)dl, R, dc);
+        if (!rc && dz_next) rc = athena_mp_axpy((int64_t)N * Fv, 1.0f, dz_next, dc);
+        if (!rc && act != ATHENA_MP_ACT_NONE) rc = athena_mp_activation_bwd(act, (int64_t)N * Fv, z, dc, dc);
+        return rc;
+    }
+    void *gid = nullptr, *slabs = nullptr;
+    const int nblk = readout_grid(N);
+    if (workspace(&gid, sizeof(int32_t) * (size_t)N, 4) || workspace(&slabs, sizeof(float) * (size_t)nblk * n, 3))
+        return 1;
+    hipLaunchKernelGGL(readout_gid_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream(), N, S, seg,
+                       (int32_t *)gid);
+    AMP_LAUNCH_CHECK();
+#define AMP_CASE(J_, A_)                                                                                           \
+    if (Fv == 16 * J_ && act == A_)                                                                                \
+        hipLaunchKernelGGL((readout_bwd_kernel<J_, A_>), dim3(nblk), dim3(256), 0, stream(), O, N, z, R, p,        \
+                           (const int32_t *)gid, gout, dz_next, dc, (float *)slabs);
+#define AMP_ACTS(J_) AMP_CASE(J_, 0) AMP_CASE(J_, 1) AMP_CASE(J_, 2) AMP_CASE(J_, 3)
+    AMP_ACTS(1) AMP_ACTS(2) AMP_ACTS(4) AMP_ACTS(8)
+#undef AMP_ACTS
+#undef AMP_CASE
+    AMP_LAUNCH_CHECK();
+    return slab_reduce((const float *)slabs, nblk, n, dR, accumulate != 0);
+}
+
+} // extern "C"

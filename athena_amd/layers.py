@@ -256,8 +256,7 @@ class duvenaud_msgpass_layer_type(msgpass_layer_type):
         out = None
         self._p = []
         for t in range(1, T + 1):
-            logits = ops.matmul(self.params[T + t - 1], self.z[t - 1], self.num_outputs)
-            p, out = ops.softmax_segsum(logits, self._seg, out=out)
+            p, out = ops.duvenaud_readout(self.params[T + t - 1], self.z[t - 1], self._seg, self.num_outputs, out=out)
             self._p.append(p)
         self.output = out   # [batch, num_outputs]
 
@@ -270,14 +269,10 @@ class duvenaud_msgpass_layer_type(msgpass_layer_type):
         de = None
         dx = None
         for t in range(T, 0, -1):
-            # readout branch of step t
-            dl = ops.softmax_segsum_bwd(self._p[t - 1], self._seg, gout)
-            self.grads[T + t - 1] = ops.matmul_dw(self.z[t - 1], dl)
-            dz = ops.matmul_dx(self.params[T + t - 1], dl, self.num_vertex_features[t])
-            if dz_next is not None:
-                ops.axpy(1.0, dz_next, dz)
+            # readout branch of step t + the gradient arriving from step t+1, through the message activation
+            dc, self.grads[T + t - 1] = ops.duvenaud_readout_bwd(self.params[T + t - 1], self.z[t - 1], self._p[t - 1],
+                                                                 self._seg, gout, act=self.activation, dz_next=dz_next)
             # message branch
-            dc = ops.activation_bwd(self.activation, self.z[t - 1], dz) if self.activation not in ("none", "linear") else dz
             self.grads[t - 1] = ops.duvenaud_update_bwd_w(g, dc, self._a[t - 1], self.min_vertex_degree, self.max_vertex_degree)
             if t == 1 and not (need_input_grad or need_edge_grad):
                 break

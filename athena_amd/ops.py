@@ -241,6 +241,38 @@ def softmax_segsum_bwd(p, seg, gout):
     return dz
 
 
+def duvenaud_readout(R, z, seg, O, out=None):
+    """One launch: p = softmax(z R^T) per vertex, out[s] (+)= sum of p over graph s.  Returns (p, out)."""
+    N, Fv = z.shape
+    S = seg.numel() - 1
+    _chk(z); _chk(seg, dtype=torch.int32); _chk(R)
+    assert R.numel() == O * Fv
+    p = torch.empty((N, O), device=z.device, dtype=torch.float32)
+    acc = out is not None
+    if out is None:
+        out = torch.empty((S, O), device=z.device, dtype=torch.float32)
+    _go()
+    _capi.call("athena_mp_duvenaud_readout_fwd", N, Fv, O, S, _p(seg), _p(z), _p(R), _p(p), _p(out), int(acc))
+    return p, out
+
+
+def duvenaud_readout_bwd(R, z, p, seg, gout, act="none", dz_next=None):
+    """Reverse of duvenaud_readout and of the activation that produced z.
+    Returns (dc, dR) with dc = act'(z) * (dl R + dz_next)."""
+    N, Fv = z.shape
+    O = p.shape[1]
+    S = seg.numel() - 1
+    _chk(z); _chk(p, (N, O)); _chk(gout, (S, O)); _chk(R)
+    if dz_next is not None:
+        _chk(dz_next, (N, Fv))
+    dc = torch.empty_like(z)
+    dR = torch.empty(O * Fv, device=z.device, dtype=torch.float32)
+    _go()
+    _capi.call("athena_mp_duvenaud_readout_bwd", N, Fv, O, S, _p(seg), _p(z), _p(R), _p(p), _p(gout),
+               _p(dz_next) if dz_next is not None else None, ACT[act], _p(dc), _p(dR), 0)
+    return dc, dR
+
+
 # ---- graph neural operator -----------------------------------------------------------------------
 def gno_aggregate(g: DeviceGraph, theta, coords, x, d, H, Fo):
     """gno_kernel_eval + gno_aggregate (athena_diffstruc_extd_sub_nop.f90:26-115, :330-397) fused"""

@@ -155,6 +155,20 @@ int athena_mp_softmax_segsum_fwd(int32_t O, int64_t N, int32_t S, const int32_t 
 int athena_mp_softmax_segsum_bwd(int32_t O, int64_t N, int32_t S, const int32_t *seg_dev,
                                  const float *p_dev, const float *gout_dev, float *dlogits_dev);
 
+/* The same readout with the logits contraction fused in (one launch per direction, logits and
+ * dlogits never reach HBM).  R is the readout matrix R(O,Fv) in Fortran order, z [N,Fv] the step's
+ * vertex features:   p = softmax(z R^T) per vertex;  out[s,:] (+)= sum_{v in s} p[v,:]            */
+int athena_mp_duvenaud_readout_fwd(int64_t N, int32_t Fv, int32_t O, int32_t S, const int32_t *seg_dev,
+                                   const float *z_dev, const float *R_dev, float *p_dev, float *out_dev,
+                                   int32_t accumulate);
+/* reverse of readout + the message activation that produced z (athena_duvenaud_msgpass_layer.f90
+ * :790-803 then :838-855, reversed):  dl = p (g_s - <g_s,p>);  dR (+)= dl^T z;
+ *   dc = act'(z) * (dl R + dz_next)      dz_next: gradient arriving from step t+1, or NULL       */
+int athena_mp_duvenaud_readout_bwd(int64_t N, int32_t Fv, int32_t O, int32_t S, const int32_t *seg_dev,
+                                   const float *z_dev, const float *R_dev, const float *p_dev,
+                                   const float *gout_dev, const float *dz_next_dev, int32_t act,
+                                   float *dc_dev, float *dR_dev, int32_t accumulate);
+
 /* ---- Graph neural operator ------------------------------------------------
  * gno_kernel_eval + gno_aggregate, athena_diffstruc_extd_sub_nop.f90:26-115, :330-397,
  * re-associated so the [Fo*Fi, E] edge-kernel tensor is never materialised:

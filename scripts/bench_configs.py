@@ -44,19 +44,38 @@ if a.config == "c3":
     t["propagate"] = timeit(lambda: ops.duvenaud_propagate(g, x, e, out=a_), a.reps)
     t["update"] = timeit(lambda: ops.duvenaud_update(g, a_, W, mn, mx, Fv), a.reps)
     t["sigmoid"] = timeit(lambda: ops.activation("sigmoid", c, out=z), a.reps)
-    t["readout_gemm"] = timeit(lambda: ops.matmul(R, z, O), a.reps)
-    t["softmax_segsum"] = timeit(lambda: ops.softmax_segsum(lg, seg), a.reps)
-    t["softmax_segsum_bwd"] = timeit(lambda: ops.softmax_segsum_bwd(p, seg, gout), a.reps)
-    t["readout_dw"] = timeit(lambda: ops.matmul_dw(z, dl), a.reps)
-    t["readout_dx"] = timeit(lambda: ops.matmul_dx(R, dl, Fv), a.reps)
-    t["sigmoid_bwd"] = timeit(lambda: ops.activation_bwd("sigmoid", z, dz), a.reps)
+    t["readout"] = timeit(lambda: ops.duvenaud_readout(R, z, seg, O), a.reps)
+    t["readout_bwd"] = timeit(lambda: ops.duvenaud_readout_bwd(R, z, p, seg, gout, act="sigmoid"), a.reps)
     t["update_bwd_w"] = timeit(lambda: ops.duvenaud_update_bwd_w(g, dc, a_, mn, mx), a.reps)
     t["update_bwd_a"] = timeit(lambda: ops.duvenaud_update_bwd_a(g, dc, W, mn, mx, Fv + Fe), a.reps)
     t["propagate_bwd_x"] = timeit(lambda: ops.duvenaud_propagate_bwd_x(g, da, Fv), a.reps)
     t["propagate_bwd_e"] = timeit(lambda: ops.duvenaud_propagate_bwd_e(g, da, Fv), a.reps)
     tot = sum(t.values())
+    Fc = Fv + Fe
+    # algorithmic bytes: gather kernels per entry, dense/elementwise ops = tensors read + written once
+    alg = {"propagate": nnz * (4 * Fv + 4 * Fe + 8) + N * (4 * Fc + 4),
+           "propagate_bwd_x": nnz * (4 * Fv + 4) + N * (4 * Fv + 4),
+           "update": N * 4 * (Fc + Fv), "update_bwd_a": N * 4 * (Fc + Fv), "update_bwd_w": N * 4 * (Fc + Fv),
+           "sigmoid": N * 8 * Fv,
+           "readout": N * 4 * (Fv + O) + S * 4 * O, "readout_bwd": N * 4 * (2 * Fv + O + 1) + S * 4 * O}
+    roof = {k: {"GBps": round(alg[k] / (t[k] * 1e-3) / 1e9, 1), "frac_of_8TBps": round(alg[k] / (t[k] * 1e-3) / 8e12, 3)} for k in alg}
+    # CPU oracle (1 thread) on the first 4000 graphs: same ops, same order
+    from oracle import oracle as o
+    NG = 130000 if S >= 130000 else S; ns = int(voff[NG]); es = int(ja[1, : ia[ns] - 1].max()); ias = ia[: ns + 1]; jas = np.asfortranarray(ja[:, : ia[ns] - 1])
+    xs, es_, Wh, Rh = x[:ns].cpu().numpy(), e[:es].cpu().numpy(), W.cpu().numpy(), R.cpu().numpy()
+    segs = voff[:NG + 1]; gouts = gout[:NG].cpu().numpy()
+    t0 = time.perf_counter()
+    a_h = o.duvenaud_propagate(xs, es_, ias, jas); c_h = o.duvenaud_update(a_h, Wh, ias, mn, mx, Fv); z_h = o.activation("sigmoid", c_h)
+    p_h = o.softmax_cols(o.matmul(Rh, z_h, O)); out_h = o.segment_sum(p_h, segs)
+    dl_h = o.softmax_cols_bwd(p_h, np.repeat(gouts, np.diff(segs), axis=0)); o.matmul_dw(dl_h, z_h); dz_h = o.matmul_dx(Rh, dl_h, Fv)
+    dc_h = o.activation_bwd("sigmoid", z_h, dz_h); o.duvenaud_update_bwd_w(dc_h, a_h, ias, mn, mx)
+    da_h = o.duvenaud_update_bwd_a(dc_h, Wh, ias, mn, mx, Fc); o.duvenaud_propagate_bwd_x(da_h, Fv, ias, jas); o.duvenaud_propagate_bwd_e(da_h, Fv, es, ias, jas)
+    tc = time.perf_counter() - t0
+    ents = int(ias[-1] - 1)
     res = {"config": "C3 Duvenaud one time step fwd+bwd", "graphs": S, "vertices": N, "entries": nnz, "F_v": Fv, "F_e": Fe,
-           "ms": {k: round(v, 4) for k, v in t.items()}, "total_ms": tot, "entries_per_s": nnz / tot * 1e3}
+           "ms": {k: round(v, 4) for k, v in t.items()}, "total_ms": tot, "entries_per_s": nnz / tot * 1e3, "roofline": roof,
+           "cpu_baseline": {"value": ents / tc, "unit": "entries/s", "cores": 1, "kind": "port",
+                            "sample": f"oracle, {NG} graphs = {ents} entries, {tc:.2f} s"}}
 else:
     N = int(2_000_000 * a.scale)
     t0 = time.time(); ia, ja, coords = synth.radius_graph(N); tg = time.time() - t0
@@ -71,6 +90,27 @@ else:
     t["bwd_x"] = timeit(lambda: ops.gno_aggregate_bwd_x(g, theta, co, gup, d, H, Fi), a.reps)
     t["bwd_theta"] = timeit(lambda: ops.gno_aggregate_bwd_theta(g, theta, co, x, gup, d, H), a.reps)
     tot = sum(t.values())
+    R = (H + 1) * Fi
+    # re-associated algorithm: gather bytes per entry + the S super-tile through HBM (written once, read once) + output
+    alg_fwd = nnz * (4 * Fi + 4 * d + 8) + N * (4 * Fo + 4) + 2 * N * R * 4
+    flops_fwd = nnz * 2 * H * (Fi + d) + N * 2 * Fo * R
+    roof = {"fwd": {"algorithmic_GB": round(alg_fwd / 1e9, 1), "GBps": round(alg_fwd / (t["fwd"] * 1e-3) / 1e9, 1),
+                    "frac_of_8TBps": round(alg_fwd / (t["fwd"] * 1e-3) / 8e12, 3),
+                    "TFLOPs": round(flops_fwd / (t["fwd"] * 1e-3) / 1e12, 1)}}
+    # CPU: the reference's MATERIALISING algorithm is infeasible at this size (246 GB kernel tensor); time it
+    # with the oracle on the first 20 000 vertices of the same graph
+    from oracle import oracle as o
+    ns = 5000
+    sia, sja, cs = synth.radius_graph(ns, seed=9)
+    rs = np.random.default_rng(5)
+    th = theta.cpu().numpy(); xs = rs.uniform(-1, 1, (ns, Fi)).astype(np.float32); gs = rs.uniform(-1, 1, (ns, Fo)).astype(np.float32)
+    t0 = time.perf_counter()
+    kap = o.gno_kernel_eval(cs, th, H, Fo * Fi); o.gno_aggregate(xs, kap, sia, sja, Fo)
+    o.gno_aggregate_bwd_x(gs, kap, sia, sja, Fi); dk = o.gno_aggregate_bwd_k(gs, xs, cs.shape[0], sia, sja); o.gno_kernel_bwd_theta(cs, th, dk, H)
+    tc = time.perf_counter() - t0
     res = {"config": "C4 GNO aggregate fwd + dx + dtheta", "vertices": N, "entries": nnz, "edge_columns": E, "F": Fi, "H": H,
-           "graph_build_s": tg, "ms": {k: round(v, 3) for k, v in t.items()}, "total_ms": tot, "entries_per_s": nnz / tot * 1e3}
+           "graph_build_s": tg, "ms": {k: round(v, 3) for k, v in t.items()}, "total_ms": tot, "entries_per_s": nnz / tot * 1e3,
+           "roofline": roof,
+           "cpu_baseline": {"value": sja.shape[1] / tc, "unit": "entries/s", "cores": 1, "kind": "port",
+                            "sample": f"materialising oracle (the reference's algorithm), radius graph of {ns} vertices = {sja.shape[1]} entries / {cs.shape[0]} edge columns, same widths, {tc:.1f} s"}}
 print(json.dumps(res))

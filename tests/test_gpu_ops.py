@@ -245,6 +245,42 @@ def test_softmax_segment_sum_readout(dev, oracle):
     assert_close(dz, oracle.softmax_cols_bwd(po, gv), 1e-5)
 
 
+@pytest.mark.parametrize("Fv,O,act,carry", [(64, 10, "sigmoid", True), (64, 10, "none", False), (16, 3, "tanh", True),
+                                             (32, 16, "relu", False), (128, 1, "sigmoid", True),
+                                             (24, 10, "sigmoid", True), (64, 20, "tanh", False)])
+def test_duvenaud_readout_one_launch_matches_the_composed_chain(dev, oracle, Fv, O, act, carry):
+    """fused readout (matmul -> softmax -> per-graph sum) and its reverse through the message
+    activation, against the oracle's op-by-op chain; ragged graph sizes incl. empty graphs, vertex
+    count not a multiple of the 16-vertex tile; (24,*) and (*,20) take the composed fallback"""
+    from athena_amd import ops
+
+    rng = np.random.default_rng(80 + Fv + O)
+    sizes = rng.integers(0, 40, 300)
+    sizes[[0, 17, 299]] = 0
+    seg = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    N, S = int(seg[-1]), sizes.size
+    assert N % 16 != 0
+    z = oracle.activation(act, rng.standard_normal((N, Fv)).astype(np.float32))
+    R = (rng.standard_normal(O * Fv) * 0.5).astype(np.float32)
+    p, out = ops.duvenaud_readout(T(R, dev), T(z, dev), T(seg, dev), O)
+    po = oracle.softmax_cols(oracle.matmul(R, z, O))
+    assert_close(H(p), po, 2e-5, "p")
+    assert_close(H(out), oracle.segment_sum(po, seg), 2e-5, "out")
+    _, out2 = ops.duvenaud_readout(T(R, dev), T(z, dev), T(seg, dev), O, out=out.clone())
+    assert_close(H(out2), oracle.segment_sum(po, seg, out=oracle.segment_sum(po, seg)), 2e-5, "accumulated out")
+
+    gout = rng.standard_normal((S, O)).astype(np.float32)
+    dzn = rng.standard_normal((N, Fv)).astype(np.float32) if carry else None
+    dc, dR = ops.duvenaud_readout_bwd(T(R, dev), T(z, dev), p, T(seg, dev), T(gout, dev), act=act,
+                                      dz_next=T(dzn, dev) if carry else None)
+    dl = oracle.softmax_cols_bwd(H(p), np.repeat(gout, sizes, axis=0))
+    dz = oracle.matmul_dx(R, dl, Fv)
+    if carry:
+        dz = dz + dzn
+    assert_close(H(dc), oracle.activation_bwd(act, z, dz), 2e-5, "dc")
+    assert_close(H(dR), oracle.matmul_dw(dl, z), 2e-5, "dR")
+
+
 def test_errors_surface_as_exceptions_not_aborts(dev):
     from athena_amd import DeviceGraph, _capi
 
