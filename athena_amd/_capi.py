@@ -54,6 +54,7 @@ _PROTOS = {
     "athena_mp_duvenaud_propagate_bwd_x": [_vp, _i32, _i32, _vp, _vp],
     "athena_mp_duvenaud_propagate_bwd_e": [_vp, _i32, _i32, _vp, _vp],
     "athena_mp_duvenaud_update_fwd": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
+    "athena_mp_duvenaud_update_act_fwd": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp],
     "athena_mp_duvenaud_update_bwd_a": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
     "athena_mp_duvenaud_update_bwd_w": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
     "athena_mp_softmax_segsum_fwd": [_i32, _i64, _i32, _vp, _vp, _vp, _vp, _i32],

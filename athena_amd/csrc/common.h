@@ -79,6 +79,12 @@ struct athena_mp_graph {
     mutable int bucket_min = 0, bucket_max = -1;
     mutable int32_t *bucket_perm = nullptr;      // [n_rows] device
     mutable std::vector<int64_t> bucket_off;     // [n_buckets+1] host
+    // the same runs cut into 16-vertex tiles (one MFMA column block each), bucket-major
+    mutable int32_t n_btiles = 0;
+    mutable int32_t *btile_start = nullptr;      // [n_btiles] device: first index into bucket_perm
+    mutable int32_t *btile_info = nullptr;       // [n_btiles] device: bucket << 8 | vertices in the tile (1..16)
+    mutable int32_t *btile_off_dev = nullptr;    // [n_buckets+1] device: first tile of each bucket
+    mutable std::vector<int32_t> btile_off;      // [n_buckets+1] host
 };
 
 namespace amp {
@@ -107,4 +113,9 @@ int gemm_atb_tiled(const float *A, int64_t lda, const float *B, int64_t ldb, con
                    int KI, int NO, float *C, bool accumulate);
 // bucket-sorted vertex permutation of a graph for Duvenaud's degree buckets (duvenaud.hip)
 int duvenaud_buckets(const athena_mp_graph *g, int min_deg, int max_deg);
+// register-resident-weight MFMA kernels of the bucketed update (duv_mfma.hip); return -1 when the shape
+// is outside what they cover (caller falls back to the tiled route)
+int duv_mfma_fwd(const athena_mp_graph *g, int Fi, int Fo, const float *a, const float *w, int act, float *c);
+int duv_mfma_bwd_a(const athena_mp_graph *g, int Fi, int Fo, const float *grad, const float *w, float *da);
+int duv_mfma_bwd_w(const athena_mp_graph *g, int Fi, int Fo, const float *grad, const float *a, float *dw);
 } // namespace amp

@@ -158,13 +158,35 @@ int duvenaud_buckets(const athena_mp_graph *g, int min_deg, int max_deg)
         std::vector<int64_t> pos(off.begin(), off.end() - 1);
         for (int32_t v = 0; v < n; ++v) perm[pos[bucket[v]]++] = v;
     }
+    std::vector<int32_t> tstart, tinfo, toff(nb + 1, 0);
+    for (int b = 0; b < nb; ++b) {
+        for (int64_t i = off[b]; i < off[b + 1]; i += 16) {
+            tstart.push_back((int32_t)i);
+            tinfo.push_back((b << 8) | (int32_t)std::min<int64_t>(16, off[b + 1] - i));
+        }
+        toff[b + 1] = (int32_t)tstart.size();
+    }
     if (g->bucket_perm) {
         AMP_HIP(hipStreamSynchronize(stream()));
         AMP_HIP(hipFree(g->bucket_perm));
-        g->bucket_perm = nullptr;
+        AMP_HIP(hipFree(g->btile_start));
+        AMP_HIP(hipFree(g->btile_info));
+        AMP_HIP(hipFree(g->btile_off_dev));
+        g->bucket_perm = g->btile_start = g->btile_info = g->btile_off_dev = nullptr;
     }
+    const size_t nt = tstart.size();
     AMP_HIP(hipMalloc((void **)&g->bucket_perm, sizeof(int32_t) * (n ? n : 1)));
+    AMP_HIP(hipMalloc((void **)&g->btile_start, sizeof(int32_t) * (nt ? nt : 1)));
+    AMP_HIP(hipMalloc((void **)&g->btile_info, sizeof(int32_t) * (nt ? nt : 1)));
+    AMP_HIP(hipMalloc((void **)&g->btile_off_dev, sizeof(int32_t) * (nb + 1)));
     if (n) AMP_HIP(hipMemcpy(g->bucket_perm, perm.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    if (nt) {
+        AMP_HIP(hipMemcpy(g->btile_start, tstart.data(), sizeof(int32_t) * nt, hipMemcpyHostToDevice));
+        AMP_HIP(hipMemcpy(g->btile_info, tinfo.data(), sizeof(int32_t) * nt, hipMemcpyHostToDevice));
+    }
+    AMP_HIP(hipMemcpy(g->btile_off_dev, toff.data(), sizeof(int32_t) * (nb + 1), hipMemcpyHostToDevice));
+    g->n_btiles = (int32_t)nt;
+    g->btile_off = toff;
     g->bucket_off = off;
     g->bucket_min = min_deg;
     g->bucket_max = max_deg;
@@ -180,6 +202,21 @@ static inline bool duv_use_mfma(int Fi, int Fo, int64_t n) { return Fi >= 16 && 
 
 extern "C" {
 
+int athena_mp_duvenaud_update_act_fwd(const athena_mp_graph *g, int32_t Fi, int32_t Fo, int32_t min_deg,
+                                      int32_t max_deg, const float *a, const float *weight, int32_t act, float *z)
+{
+    AMP_REQUIRE(g && a && weight && z && Fi > 0 && Fo > 0 && max_deg >= min_deg, "duvenaud_update_act_fwd: bad arguments");
+    AMP_REQUIRE(act >= 0 && act <= ATHENA_MP_ACT_TANH, "duvenaud_update_act_fwd: unknown activation %d", act);
+    if ((int64_t)g->n_rows * Fo == 0) return 0;
+    if (duv_use_mfma(Fi, Fo, g->n_rows)) {
+        if (duvenaud_buckets(g, min_deg, max_deg)) return 1;
+        const int rc = duv_mfma_fwd(g, Fi, Fo, a, weight, act, z);
+        if (rc >= 0) return rc;
+    }
+    if (int rc = athena_mp_duvenaud_update_fwd(g, Fi, Fo, min_deg, max_deg, a, weight, z)) return rc;
+    return act == ATHENA_MP_ACT_NONE ? 0 : athena_mp_activation_fwd(act, (int64_t)g->n_rows * Fo, z, z);
+}
+
 int athena_mp_duvenaud_update_fwd(const athena_mp_graph *g, int32_t Fi, int32_t Fo, int32_t min_deg,
                                   int32_t max_deg, const float *a, const float *weight, float *c)
 {
@@ -188,6 +225,7 @@ int athena_mp_duvenaud_update_fwd(const athena_mp_graph *g, int32_t Fi, int32_t 
     if (total == 0) return 0;
     if (duv_use_mfma(Fi, Fo, g->n_rows)) {
         if (duvenaud_buckets(g, min_deg, max_deg)) return 1;
+        if (const int rc = duv_mfma_fwd(g, Fi, Fo, a, weight, ATHENA_MP_ACT_NONE, c); rc >= 0) return rc;
         for (int b = 0; b <= max_deg - min_deg; ++b) {
             const int64_t cnt = g->bucket_off[b + 1] - g->bucket_off[b];
             if (cnt == 0) continue;
@@ -214,6 +252,7 @@ int athena_mp_duvenaud_update_bwd_a(const athena_mp_graph *g, int32_t Fi, int32_
     if (total == 0) return 0;
     if (duv_use_mfma(Fi, Fo, g->n_rows)) {
         if (duvenaud_buckets(g, min_deg, max_deg)) return 1;
+        if (const int rc = duv_mfma_bwd_a(g, Fi, Fo, grad, weight, da); rc >= 0) return rc;
         for (int b = 0; b <= max_deg - min_deg; ++b) {
             const int64_t cnt = g->bucket_off[b + 1] - g->bucket_off[b];
             if (cnt == 0) continue;
@@ -246,6 +285,7 @@ int athena_mp_duvenaud_update_bwd_w(const athena_mp_graph *g, int32_t Fi, int32_
     }
     if (duv_use_mfma(Fi, Fo, N)) {
         if (duvenaud_buckets(g, min_deg, max_deg)) return 1;
+        if (const int rc = duv_mfma_bwd_w(g, Fi, Fo, grad, a, dweight); rc >= 0) return rc;
         for (int b = 0; b < nb; ++b) {   // dW_d(o,i) = sum_{v in bucket} g[v,o] a[v,i] / d  -> [Fi][Fo] row-major
             const int64_t cnt = g->bucket_off[b + 1] - g->bucket_off[b];
             if (int rc = gemm_atb_tiled(a, Fi, grad, Fo, g->bucket_perm + g->bucket_off[b], (float)(b + 1), cnt, Fi, Fo,

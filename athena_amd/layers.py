@@ -243,9 +243,8 @@ class duvenaud_msgpass_layer_type(msgpass_layer_type):
         cur = x
         for t in range(1, T + 1):
             a = ops.duvenaud_propagate(g, cur, e)
-            c = ops.duvenaud_update(g, a, self.params[t - 1], self.min_vertex_degree, self.max_vertex_degree,
-                                    self.num_vertex_features[t])
-            zt = ops.activation(self.activation, c) if self.activation not in ("none", "linear") else c
+            zt = ops.duvenaud_update_act(g, a, self.params[t - 1], self.min_vertex_degree, self.max_vertex_degree,
+                                         self.num_vertex_features[t], act=self.activation)
             self._a.append(a)
             self.z.append(zt)
             cur = zt

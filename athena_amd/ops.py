@@ -199,6 +199,17 @@ def duvenaud_update(g: DeviceGraph, a, weight, min_deg, max_deg, Fo):
     return c
 
 
+def duvenaud_update_act(g: DeviceGraph, a, weight, min_deg, max_deg, Fo, act="none"):
+    """z = act(duvenaud_update(a)) with the activation in the kernel epilogue"""
+    Fi = a.shape[1]
+    _chk(a, (g.n_rows, Fi))
+    assert weight.numel() == Fo * Fi * (max_deg - min_deg + 1)
+    z = torch.empty((g.n_rows, Fo), device=a.device, dtype=torch.float32)
+    _go()
+    _capi.call("athena_mp_duvenaud_update_act_fwd", g.handle, Fi, Fo, min_deg, max_deg, _p(a), _p(_chk(weight)), ACT[act], _p(z))
+    return z
+
+
 def duvenaud_update_bwd_a(g: DeviceGraph, grad, weight, min_deg, max_deg, Fi):
     Fo = grad.shape[1]
     _chk(grad, (g.n_rows, Fo))

@@ -137,6 +137,11 @@ int athena_mp_duvenaud_propagate_bwd_e(const athena_mp_graph *g, int32_t Fv, int
 int athena_mp_duvenaud_update_fwd(const athena_mp_graph *g, int32_t Fi, int32_t Fo, int32_t min_deg,
                                   int32_t max_deg, const float *a_dev, const float *weight_dev,
                                   float *c_dev);
+/* the same with the message activation applied in the epilogue (athena_duvenaud_msgpass_layer.f90
+ * :790-803: duvenaud_update then activation%apply): z = act(W_d (a/d)); only z is written */
+int athena_mp_duvenaud_update_act_fwd(const athena_mp_graph *g, int32_t Fi, int32_t Fo, int32_t min_deg,
+                                      int32_t max_deg, const float *a_dev, const float *weight_dev,
+                                      int32_t act, float *z_dev);
 /* get_partial_duvenaud_update_val :284-324 */
 int athena_mp_duvenaud_update_bwd_a(const athena_mp_graph *g, int32_t Fi, int32_t Fo, int32_t min_deg,
                                     int32_t max_deg, const float *grad_dev, const float *weight_dev,

@@ -42,8 +42,7 @@ if a.config == "c3":
     da = ops.duvenaud_update_bwd_a(g, dc, W, mn, mx, Fv + Fe)
     t = {}
     t["propagate"] = timeit(lambda: ops.duvenaud_propagate(g, x, e, out=a_), a.reps)
-    t["update"] = timeit(lambda: ops.duvenaud_update(g, a_, W, mn, mx, Fv), a.reps)
-    t["sigmoid"] = timeit(lambda: ops.activation("sigmoid", c, out=z), a.reps)
+    t["update_sigmoid"] = timeit(lambda: ops.duvenaud_update_act(g, a_, W, mn, mx, Fv, act="sigmoid"), a.reps)
     t["readout"] = timeit(lambda: ops.duvenaud_readout(R, z, seg, O), a.reps)
     t["readout_bwd"] = timeit(lambda: ops.duvenaud_readout_bwd(R, z, p, seg, gout, act="sigmoid"), a.reps)
     t["update_bwd_w"] = timeit(lambda: ops.duvenaud_update_bwd_w(g, dc, a_, mn, mx), a.reps)
@@ -55,8 +54,7 @@ if a.config == "c3":
     # algorithmic bytes: gather kernels per entry, dense/elementwise ops = tensors read + written once
     alg = {"propagate": nnz * (4 * Fv + 4 * Fe + 8) + N * (4 * Fc + 4),
            "propagate_bwd_x": nnz * (4 * Fv + 4) + N * (4 * Fv + 4),
-           "update": N * 4 * (Fc + Fv), "update_bwd_a": N * 4 * (Fc + Fv), "update_bwd_w": N * 4 * (Fc + Fv),
-           "sigmoid": N * 8 * Fv,
+           "update_sigmoid": N * 4 * (Fc + Fv), "update_bwd_a": N * 4 * (Fc + Fv), "update_bwd_w": N * 4 * (Fc + Fv),
            "readout": N * 4 * (Fv + O) + S * 4 * O, "readout_bwd": N * 4 * (2 * Fv + O + 1) + S * 4 * O}
     roof = {k: {"GBps": round(alg[k] / (t[k] * 1e-3) / 1e9, 1), "frac_of_8TBps": round(alg[k] / (t[k] * 1e-3) / 8e12, 3)} for k in alg}
     # CPU oracle (1 thread) on the first 4000 graphs: same ops, same order

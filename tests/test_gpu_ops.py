@@ -199,11 +199,17 @@ def test_duvenaud_propagate_and_grads_bit_exact(dev, oracle, Fv, Fe):
     assert np.array_equal(H(ops.duvenaud_propagate_bwd_e(g, T(up, dev), Fv)), oracle.duvenaud_propagate_bwd_e(up, Fv, E, ia, ja))
 
 
-@pytest.mark.parametrize("Fi,Fo,mn,mx", [(7, 6, 1, 10), (10, 4, 2, 3), (72, 64, 1, 10), (9, 5, 1, 1)])
-def test_duvenaud_update_and_grads(dev, oracle, Fi, Fo, mn, mx):
+@pytest.mark.parametrize("Fi,Fo,mn,mx,n", [(7, 6, 1, 10, 1200), (10, 4, 2, 3, 1200), (72, 64, 1, 10, 1200), (9, 5, 1, 1, 1200),
+                                             (72, 64, 1, 10, 70000), (40, 32, 1, 6, 40000), (20, 16, 2, 5, 3000),
+                                             (96, 64, 1, 4, 2000), (68, 48, 1, 3, 2000), (72, 64, 3, 3, 5000),
+                                             (64, 96, 1, 5, 2000), (16, 16, 1, 2, 1024), (132, 64, 1, 4, 1500),
+                                             (70, 64, 1, 4, 1500), (72, 64, 5, 12, 1500)])
+def test_duvenaud_update_and_grads(dev, oracle, Fi, Fo, mn, mx, n):
+    """small layers: exact VALU kernels; matrix-sized layers: register-resident-weight MFMA kernels over
+    16-vertex bucket tiles (several tiles per wave and bucket changes inside a wave at n >= 40000; a
+    single bucket; buckets that stay empty at (5,12)); (132,*) and (70,*) take the tiled fallback"""
     from athena_amd import DeviceGraph, ops
 
-    n = 1200
     ia, ja = random_graph(n, int(1.5 * n), seed=Fi, self_loops=True, isolated=2)
     rng = np.random.default_rng(Fi)
     a = rng.uniform(0, 4, (n, Fi)).astype(np.float32)
@@ -222,6 +228,9 @@ def test_duvenaud_update_and_grads(dev, oracle, Fi, Fo, mn, mx):
         assert_close(da, dao, 1e-5, "update bwd_a")
     dw = H(ops.duvenaud_update_bwd_w(g, T(up, dev), T(a, dev), mn, mx))
     assert_close(dw, oracle.duvenaud_update_bwd_w(up, a, ia, mn, mx), 1e-5, "dW")
+    for act in ("sigmoid", "relu"):      # activation in the epilogue == update followed by the activation op
+        z = H(ops.duvenaud_update_act(g, T(a, dev), T(w, dev), mn, mx, Fo, act=act))
+        assert_close(z, oracle.activation(act, co), 1e-5 if act == "sigmoid" else 2e-5, "update+" + act)
 
 
 def test_softmax_segment_sum_readout(dev, oracle):
