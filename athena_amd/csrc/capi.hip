@@ -194,6 +194,7 @@ int athena_mp_graph_destroy(athena_mp_graph *g)
     if (g->bucket_perm) (void)hipFree(g->bucket_perm);
     if (g->btile_start) (void)hipFree(g->btile_start);
     if (g->btile_info) (void)hipFree(g->btile_info);
+    if (g->btile_rows) (void)hipFree(g->btile_rows);
     if (g->btile_off_dev) (void)hipFree(g->btile_off_dev);
     for (LongPlan *lp : {&g->lp_fwd, &g->lp_bwd})
         for (void *p : {(void *)lp->task_beg, (void *)lp->task_end, (void *)lp->row_id, (void *)lp->row_task0})

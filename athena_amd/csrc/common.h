@@ -82,6 +82,8 @@ struct athena_mp_graph {
     // the same runs cut into 16-vertex tiles (one MFMA column block each), bucket-major
     mutable int32_t n_btiles = 0;
     mutable int32_t *btile_start = nullptr;      // [n_btiles] device: first index into bucket_perm
+    mutable int32_t *btile_rows = nullptr;       // [16*n_btiles] device: vertex of each tile slot; padding slots hold
+                                                 //   ~(first vertex of the tile) (negative: load from it, never store)
     mutable int32_t *btile_info = nullptr;       // [n_btiles] device: bucket << 8 | vertices in the tile (1..16)
     mutable int32_t *btile_off_dev = nullptr;    // [n_buckets+1] device: first tile of each bucket
     mutable std::vector<int32_t> btile_off;      // [n_buckets+1] host
@@ -99,6 +101,9 @@ int gemm_dispatch(const float *A, const float *B, int b_nk, const float *bias, i
 // dWt[Fi,Fo] (+)= sum_v P[v,:]^T dZ[v,:]
 int gemm_dw_dispatch(int64_t N, int Fi, int Fo, const float *P, const float *dZ, float *dW, bool accumulate);
 int slab_reduce(const float *slabs, int n_slabs, int n, float *out, bool accumulate);
+// n_segs independent ranges [first[i], first[i]+count[i]) of the same slab array -> out + i*out_stride (count 0 => zeros)
+int slab_reduce_segs(const float *slabs, int n, int n_segs, const int *first, const int *count, float *out,
+                     int64_t out_stride, bool accumulate);
 
 // shape-generic tiled MFMA contraction (gemm_tiled.hip)
 struct TiledArgs {

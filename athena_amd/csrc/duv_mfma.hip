@@ -38,16 +38,18 @@ __device__ __forceinline__ float act_apply(float t, int act)
 //   div_in  = 1: X is divided by d = b+1 before the product (forward: a/d, the reference's order)
 //   div_in  = 0: the sum is divided by d afterwards (reverse w.r.t. a)
 template <int KJ, int OT>
-__global__ __launch_bounds__(256) void duv_rows_kernel(int n_tiles, const int32_t *__restrict__ tstart,
-                                                       const int32_t *__restrict__ tinfo,
-                                                       const int32_t *__restrict__ perm, const float *__restrict__ X,
+__global__ __launch_bounds__(256) void duv_rows_kernel(int n_tiles, const int32_t *__restrict__ trows,
+                                                       const int32_t *__restrict__ tinfo, const float *__restrict__ X,
                                                        int K, const float *__restrict__ W, int64_t wb, int so, int sk,
                                                        float *__restrict__ Y, int NO, int div_in, int act,
                                                        int tiles_per_wave)
 {
     const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4;
-    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int t0 = gw * tiles_per_wave, t1 = min(n_tiles, t0 + tiles_per_wave);
+    // wave w takes tiles w, w + W, w + 2W, ...: neighbouring waves stream neighbouring vertices at the same
+    // time, every wave sees the same mix of buckets (balanced), and buckets are long runs so the weight
+    // fragments are still reloaded only a handful of times per wave
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+    const int t0 = gw, t1 = n_tiles;
     if (t0 >= t1) return;
 
     float Wf[OT][KJ][4];
@@ -55,25 +57,25 @@ __global__ __launch_bounds__(256) void duv_rows_kernel(int n_tiles, const int32_
     float d = 1.0f, inv = 1.0f;
     bool pow2 = true;
 
+    // software pipeline: vertex ids two tiles ahead, vertex rows one tile ahead (one dependent load per stage)
     v4f xf[KJ], xn[KJ];
-    int row = 0, row_n = 0;
-    bool ok = false, ok_n = false;
-    auto load = [&](v4f(&xd)[KJ], int &r_out, bool &ok_out, int t) {
-        const int st = tstart[t], cnt = tinfo[t] & 255;
-        ok_out = n < cnt;
-        r_out = perm[st + (ok_out ? n : 0)];
-        const float *src = X + (int64_t)r_out * K + 4 * q;
+    auto load = [&](v4f(&xd)[KJ], int r) {
+        const float *src = X + (int64_t)(r < 0 ? ~r : r) * K + 4 * q;
 #pragma unroll
         for (int j = 0; j < KJ; ++j)
             xd[j] = 16 * j + 4 * q < K ? *reinterpret_cast<const v4f *>(src + 16 * j) : v4f{0.0f, 0.0f, 0.0f, 0.0f};
     };
-    load(xn, row_n, ok_n, t0);
-    for (int t = t0; t < t1; ++t) {
+    int r_cur = 0, r_n = trows[(int64_t)t0 * 16 + n], r_nn = t0 + nw < t1 ? trows[(int64_t)(t0 + nw) * 16 + n] : 0;
+    int info_n = tinfo[t0];   // kept raw: shifting it here would put a full vmcnt(0) wait right behind the prefetch
+    load(xn, r_n);
+    for (int t = t0; t < t1; t += nw) {
 #pragma unroll
         for (int j = 0; j < KJ; ++j) xf[j] = xn[j];
-        row = row_n, ok = ok_n;
-        const int b = __builtin_amdgcn_readfirstlane(tinfo[t] >> 8);
-        if (t + 1 < t1) load(xn, row_n, ok_n, t + 1);
+        r_cur = r_n, r_n = r_nn;
+        const int b = __builtin_amdgcn_readfirstlane(info_n >> 8);
+        // padding slots repeat the tile's first vertex: same loads, same arithmetic, same address, same value --
+        // their stores are benign duplicates, so no store sits under a per-lane branch
+        const int row = r_cur < 0 ? ~r_cur : r_cur;
         if (b != cur_b) {
             cur_b = b;
             d = (float)(b + 1);
@@ -89,7 +91,17 @@ __global__ __launch_bounds__(256) void duv_rows_kernel(int n_tiles, const int32_
                         const int o = 16 * ot + n, k = 16 * j + 4 * q + c;
                         Wf[ot][j][c] = (o < NO && k < K) ? wd[(int64_t)o * so + (int64_t)k * sk] : 0.0f;
                     }
+            // drain the fragment loads HERE: left to the compiler, their wait lands at the first MFMA as a
+            // vmcnt(0) on the join of both paths, i.e. behind the prefetch that the MFMAs are meant to hide
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt/lgkmcnt untouched
         }
+        // prefetch AFTER the (rare) weight reload: the reload's join point carries a full vmcnt(0) wait, which
+        // must not sit between the prefetch and the MFMAs that are meant to hide it
+        if (t + nw < t1) {
+            load(xn, r_n);
+            info_n = tinfo[t + nw];
+        }
+        if (t + 2 * nw < t1) r_nn = trows[(int64_t)(t + 2 * nw) * 16 + n];
         if (div_in) {
             if (pow2) {
 #pragma unroll
@@ -102,14 +114,20 @@ __global__ __launch_bounds__(256) void duv_rows_kernel(int n_tiles, const int32_
             }
         }
         float *dst = Y + (int64_t)row * NO + 4 * q;
+        // OT independent accumulation chains, interleaved so consecutive MFMAs never wait on each other
+        v4f accs[OT];
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) accs[ot] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < KJ; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int ot = 0; ot < OT; ++ot)
+                    accs[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wf[ot][j][c], xf[j][c], accs[ot], 0, 0, 0);
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot) {
-            v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-            for (int j = 0; j < KJ; ++j)
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Wf[ot][j][c], xf[j][c], acc, 0, 0, 0);
+            v4f acc = accs[ot];
             if (!div_in) {
                 if (pow2) acc = acc * inv;
                 else {
@@ -121,17 +139,16 @@ __global__ __launch_bounds__(256) void duv_rows_kernel(int n_tiles, const int32_
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc[c] = act_apply(acc[c], act);
             }
-            if (ok && 16 * ot + 4 * q < NO) *reinterpret_cast<v4f *>(dst + 16 * ot) = acc;
+            if (16 * ot + 4 * q < NO) *reinterpret_cast<v4f *>(dst + 16 * ot) = acc;
         }
     }
 }
 
 // slab[blockIdx + b][i*Fo + o] = sum over this workgroup's tiles of bucket b of (a[v,i]/d) g[v,o]
 template <int IT, int OT>
-__global__ __launch_bounds__(256) void duv_dw_kernel(int n_tiles, const int32_t *__restrict__ tstart,
+__global__ __launch_bounds__(256) void duv_dw_kernel(int n_tiles, const int32_t *__restrict__ trows,
                                                      const int32_t *__restrict__ tinfo,
-                                                     const int32_t *__restrict__ toff,
-                                                     const int32_t *__restrict__ perm, const float *__restrict__ A,
+                                                     const int32_t *__restrict__ toff, const float *__restrict__ A,
                                                      int Fi, const float *__restrict__ G, int Fo,
                                                      float *__restrict__ slabs, int tiles_per_wg)
 {
@@ -143,10 +160,9 @@ __global__ __launch_bounds__(256) void duv_dw_kernel(int n_tiles, const int32_t 
     const int T0 = blockIdx.x * tiles_per_wg, T1 = min(n_tiles, T0 + tiles_per_wg);
 
     v4f af[IT], gf[OT], an[IT], gn[OT];
-    auto load = [&](v4f(&ad)[IT], v4f(&gd)[OT], int t) {
-        const int st = tstart[t], cnt = tinfo[t] & 255;
-        const bool ok = n < cnt;
-        const int r = perm[st + (ok ? n : 0)];
+    auto load = [&](v4f(&ad)[IT], v4f(&gd)[OT], int rr) {
+        const bool ok = rr >= 0;
+        const int r = ok ? rr : ~rr;
         const float *pa = A + (int64_t)r * Fi + 4 * q;
         const float *pg = G + (int64_t)r * Fo + 4 * q;
         const v4f zero = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -169,13 +185,17 @@ __global__ __launch_bounds__(256) void duv_dw_kernel(int n_tiles, const int32_t 
 #pragma unroll
             for (int o = 0; o < OT; ++o) acc[i][o] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
 
-        if (seg + wave < send) load(an, gn, seg + wave);
+        int r_n = seg + wave < send ? trows[(int64_t)(seg + wave) * 16 + n] : 0;
+        int r_nn = seg + wave + 4 < send ? trows[(int64_t)(seg + wave + 4) * 16 + n] : 0;
+        if (seg + wave < send) load(an, gn, r_n);
         for (int t = seg + wave; t < send; t += 4) {
 #pragma unroll
             for (int j = 0; j < IT; ++j) af[j] = an[j];
 #pragma unroll
             for (int j = 0; j < OT; ++j) gf[j] = gn[j];
-            if (t + 4 < send) load(an, gn, t + 4);
+            r_n = r_nn;
+            if (t + 4 < send) load(an, gn, r_n);
+            if (t + 8 < send) r_nn = trows[(int64_t)(t + 8) * 16 + n];
             if (pow2) {
 #pragma unroll
                 for (int j = 0; j < IT; ++j) af[j] = af[j] * inv;
@@ -244,13 +264,13 @@ int launch_rows(const athena_mp_graph *g, const float *X, int K, const float *W,
     const int nt = g->n_btiles;
     if (nt == 0) return 0;
     const int max_waves = 256 * 4 * 2;   // two resident waves per SIMD at ~200 VGPRs
-    const int tpw = std::max(1, (nt + max_waves - 1) / max_waves);
-    const int waves = (nt + tpw - 1) / tpw;
+    const int tpw = 0;
+    const int waves = std::min(nt, max_waves);
     const dim3 grid((waves + 3) / 4);
 #define AMP_CASE(KJ_, OT_)                                                                                         \
     if (kj == KJ_ && ot == OT_) {                                                                                  \
-        hipLaunchKernelGGL((duv_rows_kernel<KJ_, OT_>), grid, dim3(256), 0, amp::stream(), nt, g->btile_start,     \
-                           g->btile_info, g->bucket_perm, X, K, W, wb, so, sk, Y, NO, div_in, act, tpw);           \
+        hipLaunchKernelGGL((duv_rows_kernel<KJ_, OT_>), grid, dim3(256), 0, amp::stream(), nt, g->btile_rows,      \
+                           g->btile_info, X, K, W, wb, so, sk, Y, NO, div_in, act, tpw);                           \
     }
 #define AMP_ROW(KJ_) AMP_CASE(KJ_, 1) AMP_CASE(KJ_, 2) AMP_CASE(KJ_, 3) AMP_CASE(KJ_, 4)
     AMP_ROW(1) AMP_ROW(2) AMP_ROW(3) AMP_ROW(4) AMP_ROW(5) AMP_ROW(6)
@@ -293,8 +313,8 @@ int duv_mfma_bwd_w(const athena_mp_graph *g, int Fi, int Fo, const float *grad, 
     if (workspace(&slabs, sizeof(float) * (size_t)(nwg + nb) * n, 2)) return 1;
 #define AMP_CASE(IT_, OT_)                                                                                         \
     if (it == IT_ && ot == OT_) {                                                                                  \
-        hipLaunchKernelGGL((duv_dw_kernel<IT_, OT_>), dim3(nwg), dim3(256), 0, stream(), nt, g->btile_start,       \
-                           g->btile_info, g->btile_off_dev, g->bucket_perm, a, Fi, grad, Fo, (float *)slabs, tpw); \
+        hipLaunchKernelGGL((duv_dw_kernel<IT_, OT_>), dim3(nwg), dim3(256), 0, stream(), nt, g->btile_rows,        \
+                           g->btile_info, g->btile_off_dev, a, Fi, grad, Fo, (float *)slabs, tpw);                 \
     }
 #define AMP_ROW(IT_) AMP_CASE(IT_, 1) AMP_CASE(IT_, 2) AMP_CASE(IT_, 3) AMP_CASE(IT_, 4)
     AMP_ROW(1) AMP_ROW(2) AMP_ROW(3) AMP_ROW(4) AMP_ROW(5) AMP_ROW(6)
@@ -302,17 +322,14 @@ int duv_mfma_bwd_w(const athena_mp_graph *g, int Fi, int Fo, const float *grad, 
 #undef AMP_ROW
 #undef AMP_CASE
     AMP_LAUNCH_CHECK();
+    std::vector<int> first(nb, 0), count(nb, 0);
     for (int b = 0; b < nb; ++b) {
-        float *out = dw + (size_t)b * n;
         const int tb0 = g->btile_off[b], tb1 = g->btile_off[b + 1];
-        if (tb1 == tb0) {
-            AMP_HIP(hipMemsetAsync(out, 0, sizeof(float) * n, stream()));
-            continue;
-        }
-        const int w0 = tb0 / tpw, w1 = (tb1 - 1) / tpw;   // workgroups that saw bucket b: slabs w0+b .. w1+b
-        if (int rc = slab_reduce((const float *)slabs + (size_t)(w0 + b) * n, w1 - w0 + 1, n, out, false)) return rc;
+        if (tb1 == tb0) continue;                          // empty bucket: count 0 -> zeros
+        const int w0 = tb0 / tpw, w1 = (tb1 - 1) / tpw;    // workgroups that saw bucket b: slabs w0+b .. w1+b
+        first[b] = w0 + b, count[b] = w1 - w0 + 1;
     }
-    return 0;
+    return slab_reduce_segs((const float *)slabs, n, nb, first.data(), count.data(), dw, n, false);
 }
 
 } // namespace amp

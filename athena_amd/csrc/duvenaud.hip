@@ -171,10 +171,18 @@ int duvenaud_buckets(const athena_mp_graph *g, int min_deg, int max_deg)
         AMP_HIP(hipFree(g->bucket_perm));
         AMP_HIP(hipFree(g->btile_start));
         AMP_HIP(hipFree(g->btile_info));
+        AMP_HIP(hipFree(g->btile_rows));
         AMP_HIP(hipFree(g->btile_off_dev));
-        g->bucket_perm = g->btile_start = g->btile_info = g->btile_off_dev = nullptr;
+        g->bucket_perm = g->btile_start = g->btile_info = g->btile_rows = g->btile_off_dev = nullptr;
     }
     const size_t nt = tstart.size();
+    std::vector<int32_t> trows(16 * nt);
+    for (size_t t = 0; t < nt; ++t) {
+        const int cnt = tinfo[t] & 255;
+        for (int i = 0; i < 16; ++i) trows[16 * t + i] = i < cnt ? perm[tstart[t] + i] : ~perm[tstart[t]];
+    }
+    AMP_HIP(hipMalloc((void **)&g->btile_rows, sizeof(int32_t) * (nt ? 16 * nt : 1)));
+    if (nt) AMP_HIP(hipMemcpy(g->btile_rows, trows.data(), sizeof(int32_t) * 16 * nt, hipMemcpyHostToDevice));
     AMP_HIP(hipMalloc((void **)&g->bucket_perm, sizeof(int32_t) * (n ? n : 1)));
     AMP_HIP(hipMalloc((void **)&g->btile_start, sizeof(int32_t) * (nt ? nt : 1)));
     AMP_HIP(hipMalloc((void **)&g->btile_info, sizeof(int32_t) * (nt ? nt : 1)));

@@ -443,22 +443,34 @@ __global__ __launch_bounds__(256, 1) void gemm_dw_full_kernel(const float *__res
         reinterpret_cast<v4f *>(slab)[t] = reinterpret_cast<const v4f *>(red)[t];
 }
 
-// out[t] = sum_b slabs[b][t], b ascending inside each of 4 interleaved groups, groups added in
-// fixed order: deterministic.  64 outputs per workgroup, 4 slab groups per output.
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ slabs, int n_slabs, int n,
-                                                          float *__restrict__ out, int accumulate)
+// out[seg][t] = sum_b slabs[first_seg + b][t]: b ascending inside each of 16 interleaved groups, the groups
+// added in fixed order -- deterministic.  64 outputs x 16 slab groups per workgroup; blockIdx.y walks up
+// to 16 independent slab ranges (the degree buckets of the Duvenaud weight gradient) in one launch.
+struct SlabSegs {
+    int first[16], count[16];
+};
+__global__ __launch_bounds__(1024) void slab_reduce_kernel(const float *__restrict__ slabs, SlabSegs segs, int n,
+                                                           float *__restrict__ out, int64_t out_stride,
+                                                           int accumulate)
 {
-    __shared__ float part[4][64];
+    __shared__ float part[16][64];
     const int o = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int t = blockIdx.x * 64 + o;
+    const int first = segs.first[blockIdx.y], count = segs.count[blockIdx.y];
     float s = 0.0f;
-    if (t < n)
-        for (int b = grp; b < n_slabs; b += 4) s = s + slabs[(size_t)b * n + t];
+    if (t < n) {
+        const float *src = slabs + (size_t)first * n + t;
+#pragma unroll 4
+        for (int b = grp; b < count; b += 16) s = s + src[(size_t)b * n];
+    }
     part[grp][o] = s;
     __syncthreads();
     if (grp == 0 && t < n) {
-        float r = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
-        out[t] = accumulate ? out[t] + r : r;
+        float r = part[0][o];
+#pragma unroll
+        for (int g = 1; g < 16; ++g) r = r + part[g][o];
+        float *dst = out + (size_t)blockIdx.y * out_stride + t;
+        *dst = accumulate ? *dst + r : r;
     }
 }
 
@@ -605,12 +617,24 @@ int gemm_dispatch(const float *A, const float *B, int b_nk, const float *bias, i
 } // namespace amp
 
 namespace amp {
+int slab_reduce_segs(const float *slabs, int n, int n_segs, const int *first, const int *count, float *out,
+                     int64_t out_stride, bool accumulate)
+{
+    for (int s0 = 0; s0 < n_segs; s0 += 16) {
+        SlabSegs segs;
+        const int ns = std::min(16, n_segs - s0);
+        for (int i = 0; i < 16; ++i) segs.first[i] = i < ns ? first[s0 + i] : 0, segs.count[i] = i < ns ? count[s0 + i] : 0;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((n + 63) / 64, ns), dim3(1024), 0, stream(), slabs, segs, n,
+                           out + (size_t)s0 * out_stride, out_stride, accumulate ? 1 : 0);
+        AMP_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 int slab_reduce(const float *slabs, int n_slabs, int n, float *out, bool accumulate)
 {
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, stream(), slabs, n_slabs, n, out,
-                       accumulate ? 1 : 0);
-    AMP_LAUNCH_CHECK();
-    return 0;
+    const int first = 0;
+    return slab_reduce_segs(slabs, n, 1, &first, &n_slabs, out, 0, accumulate);
 }
 
 int gemm_dw_dispatch(int64_t N, int Fi, int Fo, const float *P, const float *dZ, float *dW, bool accumulate)
@@ -650,9 +674,7 @@ int gemm_dw_dispatch(int64_t N, int Fi, int Fo, const float *P, const float *dZ,
         hipLaunchKernelGGL(gemm_dw_small_kernel, dim3(nblk), dim3(256), 0, stream(), P, dZ, slabs, N, Fi, Fo, rpb);
     }
     AMP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, stream(), slabs, nblk, n, dW, accumulate ? 1 : 0);
-    AMP_LAUNCH_CHECK();
-    return 0;
+    return slab_reduce(slabs, nblk, n, dW, accumulate);
 }
 } // namespace amp
 

@@ -85,13 +85,11 @@ __global__ __launch_bounds__(256) void readout_fwd_kernel(int O, int64_t N, cons
             s = s + e[r];
         }
         s = xor_add(s);
-        const int64_t row = tile * 16 + n;
-        if (row < N) {
-            float *dst = p + row * O + 4 * q;
+        // rows past the end repeat row N-1 (same loads, same values): duplicate stores instead of a branch
+        float *dst = p + min(tile * 16 + n, N - 1) * O + 4 * q;
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (4 * q + r < O) dst[r] = e[r] / s;
-        }
+        for (int r = 0; r < 4; ++r)
+            if (4 * q + r < O) dst[r] = e[r] / s;
     }
 }
 
@@ -107,17 +105,12 @@ __global__ void readout_segsum_kernel(int O, int S, const int32_t *__restrict__ 
     out[t] = accumulate ? out[t] + acc : acc;
 }
 
-// graph of every vertex (binary search over the S+1 offsets)
-__global__ void readout_gid_kernel(int64_t N, int S, const int32_t *__restrict__ seg, int32_t *__restrict__ gid)
+// graph of every vertex: one thread per graph fills its vertex range
+__global__ void readout_gid_kernel(int S, const int32_t *__restrict__ seg, int32_t *__restrict__ gid)
 {
-    int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= N) return;
-    int lo = 0, hi = S; // seg[lo] <= v < seg[hi]
-    while (hi - lo > 1) {
-        int mid = (lo + hi) >> 1;
-        if (seg[mid] <= v) lo = mid; else hi = mid;
-    }
-    gid[v] = lo;
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    for (int v = seg[s]; v < seg[s + 1]; ++v) gid[v] = s;
 }
 
 // Reverse pass.  dl stays in registers as the B operand (k = q <-> o = 4q + r) of the dz product,
@@ -154,13 +147,14 @@ __global__ __launch_bounds__(256) void readout_bwd_kernel(int O, int64_t N, cons
 
     v4f zf[J], zn[J];
     float pf[4], pn[4], gf[4], gn[4];
-    auto load = [&](v4f(&zd)[J], float(&pd)[4], float(&gd)[4], int64_t tile) {
+    // software pipeline: graph ids two tiles ahead, rows one tile ahead, so no load waits on a load of its own stage
+    auto load = [&](v4f(&zd)[J], float(&pd)[4], float(&gd)[4], int64_t tile, int g) {
         const int64_t row = min(tile * 16 + n, N - 1);
         const float *src = z + row * FV + 4 * q;
 #pragma unroll
         for (int j = 0; j < J; ++j) zd[j] = *reinterpret_cast<const v4f *>(src + 16 * j);
         const float *ps = p + row * O + 4 * q;
-        const float *gs = gout + (size_t)gid[row] * O + 4 * q;
+        const float *gs = gout + (size_t)g * O + 4 * q;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const bool ok = 4 * q + r < O;
@@ -168,13 +162,17 @@ __global__ __launch_bounds__(256) void readout_bwd_kernel(int O, int64_t N, cons
             gd[r] = ok ? gs[r] : 0.0f;
         }
     };
-    if (gw < tiles) load(zn, pn, gn, gw);
+    auto gid_of = [&](int64_t tile) { return tile < tiles ? gid[min(tile * 16 + n, N - 1)] : 0; };
+    int g_n = gid_of(gw), g_nn = gid_of(gw + nw);
+    if (gw < tiles) load(zn, pn, gn, gw, g_n);
     for (int64_t tile = gw; tile < tiles; tile += nw) {
 #pragma unroll
         for (int j = 0; j < J; ++j) zf[j] = zn[j];
 #pragma unroll
         for (int r = 0; r < 4; ++r) pf[r] = pn[r], gf[r] = gn[r];
-        if (tile + nw < tiles) load(zn, pn, gn, tile + nw);
+        g_n = g_nn;
+        if (tile + nw < tiles) load(zn, pn, gn, tile + nw, g_n);
+        g_nn = gid_of(tile + 2 * nw);
         const int64_t row = tile * 16 + n;
         const bool ok = row < N;
 
@@ -184,16 +182,17 @@ __global__ __launch_bounds__(256) void readout_bwd_kernel(int O, int64_t N, cons
         dot = xor_add(dot);
         float dl[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dl[r] = ok ? pf[r] * (gf[r] - dot) : 0.0f;
+        for (int r = 0; r < 4; ++r) dl[r] = pf[r] * (gf[r] - dot);
 
         // stage the tile for the vertex-contracted product before the registers are consumed
 #pragma unroll
         for (int j = 0; j < J; ++j) *reinterpret_cast<v4f *>(zl + n * ZP + 16 * j + 4 * q) = zf[j];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dll[n * DP + 4 * q + r] = dl[r];
+        for (int r = 0; r < 4; ++r) dll[n * DP + 4 * q + r] = ok ? dl[r] : 0.0f;   // repeated rows count once in dR
 
         // dz[row n][16 ft + 4q .. +3] = sum_o dl[row][o] R[o][f]
-        float *dst = dc + row * FV + 4 * q;
+        // rows past the end repeat row N-1 (same loads, same values): duplicate stores instead of a branch
+        float *dst = dc + min(row, N - 1) * FV + 4 * q;
         const float *din = dz_in ? dz_in + min(row, N - 1) * FV + 4 * q : nullptr;
 #pragma unroll
         for (int ft = 0; ft < J; ++ft) {
@@ -204,7 +203,7 @@ __global__ __launch_bounds__(256) void readout_bwd_kernel(int O, int64_t N, cons
             v4f o4;
 #pragma unroll
             for (int c = 0; c < 4; ++c) o4[c] = act_back<ACT>(zf[ft][c], acc[c]);
-            if (ok) *reinterpret_cast<v4f *>(dst + 16 * ft) = o4;
+            *reinterpret_cast<v4f *>(dst + 16 * ft) = o4;
         }
 
         // dR[f][o] += sum_rows z[row][f] dl[row][o]:  A[m = f][k = row], B[k = row][n = o]
@@ -237,10 +236,10 @@ __global__ __launch_bounds__(256) void readout_bwd_kernel(int O, int64_t N, cons
 
 bool fused_readout_shape(int Fv, int O) { return O <= 16 && (Fv == 16 || Fv == 32 || Fv == 64 || Fv == 128); }
 
-int readout_grid(int64_t N)
+int readout_grid(int64_t N, int wg_per_cu)
 {
     const int64_t tiles = (N + 15) / 16;
-    return (int)std::max<int64_t>(1, std::min<int64_t>((tiles + 3) / 4, 256 * 8));
+    return (int)std::max<int64_t>(1, std::min<int64_t>((tiles + 3) / 4, 256 * wg_per_cu));
 }
 
 } // namespace
@@ -256,7 +255,7 @@ int athena_mp_duvenaud_readout_fwd(int64_t N, int32_t Fv, int32_t O, int32_t S, 
                 "duvenaud_readout_fwd: bad arguments");
     if (N > 0) {
         if (fused_readout_shape(Fv, O)) {
-            const dim3 grid(readout_grid(N));
+            const dim3 grid(readout_grid(N, 7));   // 66 VGPRs at Fv = 64: seven waves per SIMD
 #define AMP_CASE(J_)                                                                                               \
     if (Fv == 16 * J_) hipLaunchKernelGGL((readout_fwd_kernel<J_>), grid, dim3(256), 0, stream(), O, N, z, R, p);
             AMP_CASE(1) AMP_CASE(2) AMP_CASE(4) AMP_CASE(8)
@@ -301,10 +300,10 @@ int athena_mp_duvenaud_readout_bwd(int64_t N, int32_t Fv, int32_t O, int32_t S, 
         return rc;
     }
     void *gid = nullptr, *slabs = nullptr;
-    const int nblk = readout_grid(N);
+    const int nblk = readout_grid(N, 4);      // ~110 VGPRs at Fv = 64: four waves per SIMD, one slab each
     if (workspace(&gid, sizeof(int32_t) * (size_t)N, 4) || workspace(&slabs, sizeof(float) * (size_t)nblk * n, 3))
         return 1;
-    hipLaunchKernelGGL(readout_gid_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream(), N, S, seg,
+    hipLaunchKernelGGL(readout_gid_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, stream(), S, seg,
                        (int32_t *)gid);
     AMP_LAUNCH_CHECK();
 #define AMP_CASE(J_, A_)                                                                                           \
