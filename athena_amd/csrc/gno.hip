@@ -16,6 +16,8 @@
 // S / T / G are produced per super-tile of vertices into a bounded HBM workspace.
 #include <algorithm>
 
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -427,7 +429,10 @@ int launch_outer(const int32_t *rowptr, const int32_t *idx, const int32_t *eidx,
 
 int tile_rows_for(int64_t n_rows, int64_t floats_per_row)
 {
-    const int64_t budget = (int64_t)1 << 30; // 1 GiB per workspace slot
+    static const int64_t budget = [] {   // bytes of S / T / G per super-tile
+        const char *e = getenv("ATHENA_MP_GNO_TILE_MB");
+        return (int64_t)(e ? atoi(e) : 1024) << 20;
+    }();
     int64_t t = budget / (4 * std::max<int64_t>(floats_per_row, 1));
     t = std::max<int64_t>(1, std::min<int64_t>(t, n_rows));
     return (int)t;

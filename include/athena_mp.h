@@ -193,6 +193,23 @@ int athena_mp_gno_aggregate_bwd_coords(const athena_mp_graph *g, int32_t d, int3
                                        int32_t Fo, const float *theta_dev, const float *coords_dev,
                                        const float *x_dev, const float *grad_dev, float *dcoords_dev);
 
+/* ---- tail of a train step, device resident -----------------
+ * compute_mse, athena_loss.f90:393-430:  *loss_dev = mean((p-e)^2)/2 ; dpred = (p-e)/n (may be NULL) */
+int athena_mp_mse_loss(int64_t n, const float *pred_dev, const float *expected_dev, float *loss_dev,
+                       float *dpred_dev);
+/* apply_clip, athena_clipper.f90:165-210 on the flat gradient vector (athena_network_sub.f90:2903) */
+int athena_mp_clip(int64_t n, float *grad_dev, int32_t l_min_max, float clip_min, float clip_max,
+                   int32_t l_norm, float clip_norm);
+/* minimise_sgd, athena_optimiser.f90:634-673.  reg_kind 0 none / 1 l1 / 2 l2 / 3 l1l2
+ * (athena_regulariser.f90:85-138); grad is overwritten with -lr*grad as the reference does */
+int athena_mp_sgd_step(int64_t n, float lr, float momentum, int32_t nesterov, int32_t reg_kind, float l1,
+                       float l2, float *param_dev, float *grad_dev, float *velocity_dev);
+/* minimise_adam, athena_optimiser.f90:1027-1091; iter >= 1 is optimiser%iter AFTER the increment of
+ * network%update; decoupled selects the AdamW branch of the l2 regulariser */
+int athena_mp_adam_step(int64_t n, float lr, float beta1, float beta2, float epsilon, int32_t iter,
+                        int32_t reg_kind, float l1, float l2, int32_t decoupled, float *param_dev,
+                        float *grad_dev, float *m_dev, float *v_dev);
+
 /* ---- host-pointer staging variants (phase-1 Fortran callbacks) ------------- */
 int athena_mp_kipf_propagate_fwd_host(const athena_mp_graph *g, int32_t F, const float *x_host, float *y_host);
 int athena_mp_kipf_propagate_bwd_host(const athena_mp_graph *g, int32_t F, const float *grad_host,

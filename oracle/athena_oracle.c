@@ -480,3 +480,108 @@ void oracle_add_bias_rows(int F, int N, const float *b, float *y)
     for (int v = 0; v < N; ++v)
         for (int o = 0; o < F; ++o) y[(size_t)v * F + o] = y[(size_t)v * F + o] + b[o];
 }
+
+/* ========================================================================= *
+ * Parameter update of a train step: the flat-vector path of
+ * network_type%update, athena_network_sub.f90:2816-2929 -- gradients are
+ * clipped (clip_dict%apply, :2903), then optimiser%minimise(params, gradients).
+ * ========================================================================= */
+
+/* apply_clip        athena_clipper.f90:165-210  (no bias argument: bias_ = [0])
+ *   min/max clamp, then scale = min(1, norm / sqrt(sum(g**2) + sum(bias_)**2)) */
+void oracle_clip(size_t n, float *g, int l_min_max, float mn, float mx, int l_norm, float norm)
+{
+    if (l_min_max)
+        for (size_t i = 0; i < n; ++i) g[i] = fmaxf(mn, fminf(mx, g[i]));
+    if (l_norm) {
+        float s = 0.0f;
+        for (size_t i = 0; i < n; ++i) s = s + g[i] * g[i];
+        float scale = fminf(1.0f, norm / sqrtf(s + 0.0f));
+        if (scale < 1.0f)
+            for (size_t i = 0; i < n; ++i) g[i] = g[i] * scale;
+    }
+}
+
+/* regularise_l1 / _l2 / _l1l2   athena_regulariser.f90:85-138
+ *   kind 0 none, 1 l1, 2 l2, 3 l1l2;  sign(1,p) = +1 for p >= +0, -1 otherwise */
+static inline float reg_term(int kind, float l1, float l2, float p, float lr)
+{
+    const float sg = signbit(p) ? -1.0f : 1.0f;
+    switch (kind) {
+    case 1: return lr * l1 * sg;
+    case 2: return lr * 2.0f * l2 * p;
+    case 3: return lr * (l1 * sg + 2.0f * l2 * p);
+    default: return 0.0f;
+    }
+}
+
+/* minimise_sgd      athena_optimiser.f90:634-673 */
+void oracle_sgd_step(size_t n, float lr, float momentum, int nesterov, int reg_kind, float l1, float l2,
+                     float *param, float *grad, float *velocity)
+{
+    for (size_t i = 0; i < n; ++i) {
+        float g = grad[i];
+        if (reg_kind) g = g + reg_term(reg_kind, l1, l2, param[i], lr);
+        g = -lr * g;
+        if (momentum > 1.0e-8f) {
+            velocity[i] = momentum * velocity[i] + g;
+            if (nesterov) param[i] = param[i] + momentum * velocity[i] + g;
+            else param[i] = param[i] + velocity[i];
+        } else {
+            velocity[i] = g;
+            param[i] = param[i] + velocity[i];
+        }
+        grad[i] = g;
+    }
+}
+
+/* beta**iter with an INTEGER exponent (athena_optimiser.f90:1059-1060): compilers lower real**integer to
+ * repeated multiplication (binary powering), not powf */
+float oracle_powi(float x, int n)
+{
+    float r = (n & 1) ? x : 1.0f;
+    for (n >>= 1; n; n >>= 1) {
+        x = x * x;
+        if (n & 1) r = r * x;
+    }
+    return r;
+}
+
+/* minimise_adam     athena_optimiser.f90:1027-1091
+ *   reg_kind as above; decoupled: l2_regulariser_type%decoupled (AdamW branch :1069-1072);
+ *   the classical-L2 branch (:1073-1079) adds l2*param to m_hat on top of the regularised gradient. */
+void oracle_adam_step(size_t n, float lr, float beta1, float beta2, float epsilon, int iter, int reg_kind,
+                      float l1, float l2, int decoupled, float *param, float *grad, float *m, float *v)
+{
+    const float bc1 = 1.0f - oracle_powi(beta1, iter), bc2 = 1.0f - oracle_powi(beta2, iter);
+    for (size_t i = 0; i < n; ++i) {
+        float g = grad[i];
+        if (reg_kind) g = g + reg_term(reg_kind, l1, l2, param[i], lr);
+        grad[i] = g;
+        m[i] = beta1 * m[i] + (1.0f - beta1) * g;
+        v[i] = beta2 * v[i] + (1.0f - beta2) * g * g;
+        const float m_hat = m[i] / bc1, v_hat = v[i] / bc2;
+        if (reg_kind == 2 && decoupled) {
+            param[i] = param[i] - lr * l2 * param[i];
+            param[i] = param[i] - lr * (m_hat / (sqrtf(v_hat) + epsilon));
+        } else if (reg_kind == 2) {
+            param[i] = param[i] - lr * ((m_hat + l2 * param[i]) / (sqrtf(v_hat) + epsilon));
+        } else {
+            param[i] = param[i] - lr * (m_hat / (sqrtf(v_hat) + epsilon));
+        }
+    }
+}
+
+/* compute_mse       athena_loss.f90:393-430:  mean(squared(predicted - expected)) / 2 over one array
+ *   (diffstruc's mean/squared are outside /root/reference: taken as the mean over all elements; unpinned)
+ *   returns the loss; dpred = d loss / d predicted = (p - e) / n */
+float oracle_mse(size_t n, const float *pred, const float *expected, float *dpred)
+{
+    float s = 0.0f;
+    for (size_t i = 0; i < n; ++i) {
+        const float d = pred[i] - expected[i];
+        s = s + d * d;
+        if (dpred) dpred[i] = d / (float)n;
+    }
+    return s / (float)n / 2.0f;
+}

@@ -273,3 +273,47 @@ def add_bias_rows(y, b):
     N, F = y.shape
     lib().oracle_add_bias_rows(C.c_int(F), C.c_int(N), pb, y.ctypes.data_as(C.c_void_p))
     return y
+
+
+# ---- parameter update of a train step -------------------------------------------
+REG = {None: 0, "none": 0, "l1": 1, "l2": 2, "l1l2": 3}
+
+
+def clip(g, clip_min=None, clip_max=None, clip_norm=None):
+    """athena_clipper.f90:165-210 (in place on a copy)"""
+    g = np.array(g, dtype=np.float32, copy=True)
+    mm = clip_min is not None or clip_max is not None
+    lib().oracle_clip(C.c_size_t(g.size), g.ctypes.data_as(C.c_void_p), C.c_int(int(mm)),
+                      C.c_float(clip_min if clip_min is not None else -np.finfo(np.float32).max),
+                      C.c_float(clip_max if clip_max is not None else np.finfo(np.float32).max),
+                      C.c_int(int(clip_norm is not None)), C.c_float(clip_norm or 0.0))
+    return g
+
+
+def sgd_step(param, grad, velocity, lr, momentum=0.0, nesterov=False, reg=None, l1=0.0, l2=0.0):
+    """athena_optimiser.f90:634-673; returns (param, grad, velocity) copies after the step"""
+    p, g, v = (np.array(a, dtype=np.float32, copy=True) for a in (param, grad, velocity))
+    lib().oracle_sgd_step(C.c_size_t(p.size), C.c_float(lr), C.c_float(momentum), C.c_int(int(nesterov)),
+                          C.c_int(REG[reg]), C.c_float(l1), C.c_float(l2), p.ctypes.data_as(C.c_void_p),
+                          g.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p))
+    return p, g, v
+
+
+def adam_step(param, grad, m, v, lr, it, beta1=0.9, beta2=0.999, epsilon=1e-8, reg=None, l1=0.0, l2=0.0,
+              decoupled=False):
+    """athena_optimiser.f90:1027-1091; returns (param, grad, m, v) copies after the step"""
+    p, g, m_, v_ = (np.array(a, dtype=np.float32, copy=True) for a in (param, grad, m, v))
+    lib().oracle_adam_step(C.c_size_t(p.size), C.c_float(lr), C.c_float(beta1), C.c_float(beta2), C.c_float(epsilon),
+                           C.c_int(it), C.c_int(REG[reg]), C.c_float(l1), C.c_float(l2), C.c_int(int(decoupled)),
+                           p.ctypes.data_as(C.c_void_p), g.ctypes.data_as(C.c_void_p),
+                           m_.ctypes.data_as(C.c_void_p), v_.ctypes.data_as(C.c_void_p))
+    return p, g, m_, v_
+
+
+def mse(pred, expected):
+    """athena_loss.f90:393-430; returns (loss, dloss/dpred)"""
+    p, pp = _f(pred); e, pe = _f(expected)
+    d = np.empty_like(p)
+    f = lib().oracle_mse
+    f.restype = C.c_float
+    return float(f(C.c_size_t(p.size), pp, pe, d.ctypes.data_as(C.c_void_p))), d

@@ -212,3 +212,56 @@ def test_oracle_has_not_drifted(oracle):
            "gno_dcoords": oracle.gno_kernel_bwd_coords(I["coords"], I["theta"], dk, 3)}
     for k, v in got.items():
         assert np.allclose(v, np.array(r[k], np.float32), rtol=2e-6, atol=1e-7), k
+
+
+def test_update_step_restatements_against_float64_closed_forms(oracle):
+    """clip / SGD / Adam / MSE (athena_clipper.f90:165-210, athena_optimiser.f90:634-673, :1027-1091,
+    athena_loss.f90:393-430) against the textbook formulas evaluated in float64"""
+    rng = np.random.default_rng(11)
+    n = 2000
+    p = rng.standard_normal(n).astype(np.float32); g = rng.standard_normal(n).astype(np.float32)
+    P, G = p.astype(np.float64), g.astype(np.float64)
+    # Adam, two iterations, no regulariser: p -= lr * m_hat / (sqrt(v_hat) + eps)
+    lr, b1, b2, eps = 0.01, 0.9, 0.999, 1e-8
+    m = np.zeros(n, np.float32); v = np.zeros(n, np.float32)
+    M = np.zeros(n); V = np.zeros(n); Pq = P.copy()
+    pq = p.copy()
+    for it in (1, 2):
+        pq, _, m, v = oracle.adam_step(pq, g, m, v, lr, it)
+        M = b1 * M + (1 - b1) * G; V = b2 * V + (1 - b2) * G * G
+        Pq = Pq - lr * (M / (1 - b1 ** it)) / (np.sqrt(V / (1 - b2 ** it)) + eps)
+        assert np.allclose(pq, Pq, rtol=2e-6, atol=1e-7)
+    # first Adam step is lr * sign(g) whatever the scale of g
+    assert np.allclose(p - oracle.adam_step(p, g * 1e3, np.zeros(n), np.zeros(n), lr, 1)[0], lr * np.sign(g), rtol=1e-4)
+    # AdamW decoupled decay multiplies the parameter by (1 - lr*l2) first (:1069-1072)
+    pw = oracle.adam_step(p, g, np.zeros(n), np.zeros(n), lr, 1, reg="l2", l2=0.1, decoupled=True)[0]
+    g_reg = G + lr * 2 * 0.1 * P                    # regularise_l2 also touched the gradient (:1045-1046)
+    assert np.allclose(pw, P * (1 - lr * 0.1) - lr * np.sign(g_reg), rtol=1e-5, atol=1e-6)
+    # SGD with momentum / Nesterov
+    vel = rng.standard_normal(n).astype(np.float32)
+    ps, gs, vs = oracle.sgd_step(p, g, vel, 0.1, momentum=0.9)
+    assert np.allclose(vs, 0.9 * vel - 0.1 * G, rtol=1e-6, atol=1e-7) and np.allclose(ps, P + vs, rtol=1e-6, atol=1e-7)
+    assert np.allclose(gs, -0.1 * G, rtol=1e-6)
+    pn, _, vn = oracle.sgd_step(p, g, vel, 0.1, momentum=0.9, nesterov=True)
+    assert np.allclose(pn, P + 0.9 * vn - 0.1 * G, rtol=1e-5, atol=1e-6)
+    p0, _, v0 = oracle.sgd_step(p, g, vel, 0.1)     # momentum 0: velocity is just the step
+    assert np.allclose(p0, P - 0.1 * G, rtol=1e-6, atol=1e-7) and np.allclose(v0, -0.1 * G, rtol=1e-6)
+    # L1 uses sign(1, p): +1 at +0, -1 at -0 (Fortran SIGN transfers the sign bit)
+    z = np.array([0.0, -0.0], np.float32)
+    assert np.array_equal(oracle.sgd_step(z, np.zeros(2), np.zeros(2), 1.0, reg="l1", l1=0.5)[1], np.array([-0.5, 0.5], np.float32))
+    # clipping
+    c = oracle.clip(g * 5, -1.0, 2.0)
+    assert c.min() == -1.0 and c.max() == 2.0
+    c = oracle.clip(g, clip_norm=3.0)
+    assert abs(np.sqrt((c.astype(np.float64) ** 2).sum()) - 3.0) < 1e-4
+    assert np.array_equal(oracle.clip(g * 1e-3, clip_norm=3.0), (g * 1e-3).astype(np.float32))
+    # MSE
+    e = rng.standard_normal(n).astype(np.float32)
+    lo, d = oracle.mse(p, e)
+    assert abs(lo - ((P - e) ** 2).mean() / 2) < 1e-5 and np.allclose(d, (P - e) / n, rtol=1e-5, atol=1e-9)
+    # real ** integer by binary powering
+    f = oracle.lib().oracle_powi
+    import ctypes as C
+    f.restype = C.c_float
+    for it in (1, 2, 3, 10, 1000):
+        assert abs(f(C.c_float(0.999), C.c_int(it)) - 0.999 ** it) < 1e-5
