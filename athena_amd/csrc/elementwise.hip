@@ -43,6 +43,96 @@ __global__ void axpy_kernel(int64_t n, float alpha, const float *__restrict__ x,
         y[i] = y[i] + alpha * x[i];
 }
 
+__global__ void swish_fwd_kernel(int64_t n, float beta, const float *__restrict__ x, float *__restrict__ y)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = x[i] * (1.0f / (1.0f + expf(-beta * x[i])));
+}
+__global__ void swish_bwd_kernel(int64_t n, float beta, const float *__restrict__ x, const float *__restrict__ g,
+                                 float *__restrict__ dx)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float e = expf(beta * x[i]);
+        dx[i] = g[i] * e * (beta * x[i] + e + 1.0f) / ((e + 1.0f) * (e + 1.0f));
+    }
+}
+
+// softmax over the features of each vertex, G lanes per vertex (G = 4, 16 or 64 by feature count)
+template <int G>
+__device__ __forceinline__ float group_max(float v)
+{
+#pragma unroll
+    for (int w = G / 2; w > 0; w >>= 1) v = fmaxf(v, __shfl_xor(v, w));
+    return v;
+}
+template <int G>
+__device__ __forceinline__ float group_sum(float v)
+{
+#pragma unroll
+    for (int w = G / 2; w > 0; w >>= 1) v = v + __shfl_xor(v, w);
+    return v;
+}
+template <int G>
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(int64_t N, int F, const float *__restrict__ z,
+                                                          float *__restrict__ y)
+{
+    const int l = threadIdx.x % G;
+    // a vertex is owned by one G-lane group, so the loop exit is uniform across the lanes that shuffle together
+    for (int64_t v = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G; v < N; v += (int64_t)gridDim.x * (256 / G)) {
+        constexpr bool ok = true;
+        const float *zv = z + (ok ? v : 0) * F;
+        float m = -INFINITY;
+        for (int i = l; i < F; i += G) m = fmaxf(m, zv[i]);
+        m = group_max<G>(m);
+        float s = 0.0f;
+        for (int i = l; i < F; i += G) s = s + expf(zv[i] - m);
+        s = group_sum<G>(s);
+        if (ok)
+            for (int i = l; i < F; i += G) y[v * F + i] = expf(zv[i] - m) / s;
+    }
+}
+template <int G>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(int64_t N, int F, const float *__restrict__ y,
+                                                          const float *__restrict__ g, float *__restrict__ dz)
+{
+    const int l = threadIdx.x % G;
+    // a vertex is owned by one G-lane group, so the loop exit is uniform across the lanes that shuffle together
+    for (int64_t v = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G; v < N; v += (int64_t)gridDim.x * (256 / G)) {
+        constexpr bool ok = true;
+        const float *yv = y + (ok ? v : 0) * F, *gv = g + (ok ? v : 0) * F;
+        float dot = 0.0f;
+        for (int i = l; i < F; i += G) dot = dot + yv[i] * gv[i];
+        dot = group_sum<G>(dot);
+        if (ok)
+            for (int i = l; i < F; i += G) dz[v * F + i] = yv[i] * gv[i] - yv[i] * dot;   // the reference's form
+    }
+}
+
+__global__ void concat_fwd_kernel(int64_t N, int Fa, int Fb, const float *__restrict__ a, const float *__restrict__ b,
+                                  float *__restrict__ out)
+{
+    const int F = Fa + Fb;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < N * F; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t v = t / F;
+        const int i = (int)(t - v * F);
+        out[t] = i < Fa ? a[v * Fa + i] : b[v * Fb + (i - Fa)];
+    }
+}
+__global__ void concat_bwd_kernel(int64_t N, int Fa, int Fb, const float *__restrict__ gout, float *__restrict__ da,
+                                  float *__restrict__ db)
+{
+    const int F = Fa + Fb;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < N * F; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t v = t / F;
+        const int i = (int)(t - v * F);
+        if (i < Fa) {
+            if (da) da[v * Fa + i] = gout[t];
+        } else if (db) {
+            db[v * Fb + (i - Fa)] = gout[t];
+        }
+    }
+}
+
 inline dim3 grid_for(int64_t n) { return dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048 * 4)); }
 
 } // namespace
@@ -74,6 +164,73 @@ int athena_mp_axpy(int64_t n, float alpha, const float *x, float *y)
     AMP_REQUIRE(n >= 0 && (n == 0 || (x && y)), "axpy: bad arguments");
     if (n == 0) return 0;
     hipLaunchKernelGGL(axpy_kernel, grid_for(n), dim3(256), 0, stream(), n, alpha, x, y);
+    AMP_LAUNCH_CHECK();
+    return 0;
+}
+
+
+/* swish_array / get_partial_swish_val, athena_diffstruc_extd_sub.f90:424-492 (reverse pass takes the INPUT) */
+int athena_mp_swish_fwd(int64_t n, float beta, const float *x, float *y)
+{
+    AMP_REQUIRE(n >= 0 && (n == 0 || (x && y)), "swish_fwd: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(swish_fwd_kernel, grid_for(n), dim3(256), 0, stream(), n, beta, x, y);
+    AMP_LAUNCH_CHECK();
+    return 0;
+}
+int athena_mp_swish_bwd(int64_t n, float beta, const float *x, const float *g, float *dx)
+{
+    AMP_REQUIRE(n >= 0 && (n == 0 || (x && g && dx)), "swish_bwd: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(swish_bwd_kernel, grid_for(n), dim3(256), 0, stream(), n, beta, x, g, dx);
+    AMP_LAUNCH_CHECK();
+    return 0;
+}
+
+/* softmax activation (apply_softmax -> softmax(val, dim=2), athena_activation_softmax.f90:183-203;
+ * athena_diffstruc_extd_sub.f90:295-379): over the F features of each of the N vertices */
+int athena_mp_softmax_fwd(int64_t N, int32_t F, const float *z, float *y)
+{
+    AMP_REQUIRE(N >= 0 && F > 0 && (N == 0 || (z && y)), "softmax_fwd: bad arguments");
+    if (N == 0) return 0;
+#define AMP_SM(G_)                                                                                             \
+    hipLaunchKernelGGL((softmax_fwd_kernel<G_>), grid_for(N *G_), dim3(256), 0, stream(), N, F, z, y)
+    if (F <= 8) AMP_SM(4);
+    else if (F <= 48) AMP_SM(16);
+    else AMP_SM(64);
+#undef AMP_SM
+    AMP_LAUNCH_CHECK();
+    return 0;
+}
+int athena_mp_softmax_bwd(int64_t N, int32_t F, const float *y, const float *g, float *dz)
+{
+    AMP_REQUIRE(N >= 0 && F > 0 && (N == 0 || (y && g && dz)), "softmax_bwd: bad arguments");
+    if (N == 0) return 0;
+#define AMP_SM(G_)                                                                                             \
+    hipLaunchKernelGGL((softmax_bwd_kernel<G_>), grid_for(N *G_), dim3(256), 0, stream(), N, F, y, g, dz)
+    if (F <= 8) AMP_SM(4);
+    else if (F <= 48) AMP_SM(16);
+    else AMP_SM(64);
+#undef AMP_SM
+    AMP_LAUNCH_CHECK();
+    return 0;
+}
+
+/* 'concatenate' merge of two layer inputs (network%add(..., operator='concatenate')): per-vertex feature
+ * stacking, a first; the reverse pass splits the gradient (either output may be NULL) */
+int athena_mp_concat_fwd(int64_t N, int32_t Fa, int32_t Fb, const float *a, const float *b, float *out)
+{
+    AMP_REQUIRE(N >= 0 && Fa > 0 && Fb > 0 && (N == 0 || (a && b && out)), "concat_fwd: bad arguments");
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(concat_fwd_kernel, grid_for(N * (Fa + Fb)), dim3(256), 0, stream(), N, Fa, Fb, a, b, out);
+    AMP_LAUNCH_CHECK();
+    return 0;
+}
+int athena_mp_concat_bwd(int64_t N, int32_t Fa, int32_t Fb, const float *gout, float *da, float *db)
+{
+    AMP_REQUIRE(N >= 0 && Fa > 0 && Fb > 0 && (N == 0 || gout), "concat_bwd: bad arguments");
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(concat_bwd_kernel, grid_for(N * (Fa + Fb)), dim3(256), 0, stream(), N, Fa, Fb, gout, da, db);
     AMP_LAUNCH_CHECK();
     return 0;
 }

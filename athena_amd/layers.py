@@ -178,9 +178,18 @@ class kipf_msgpass_layer_type(msgpass_layer_type):
         self._tape = []
         cur = x
         for t in range(1, self.num_time_steps + 1):
-            # aggregation + dense step (+ activation) in one launch where the fused kernel exists
-            p, nxt = ops.kipf_layer_fwd(g, cur, self.params[t - 1], self.num_vertex_features[t], act=self.activation)
-            self._tape.append((p, nxt))
+            if self.activation in ops.ACT:
+                # aggregation + dense step (+ activation) in one launch where the fused kernel exists
+                p, nxt = ops.kipf_layer_fwd(g, cur, self.params[t - 1], self.num_vertex_features[t], act=self.activation)
+                z = None
+            else:
+                # 'softmax' / 'swish' (msgpass_euler): the shaped activations run as their own launch, and the
+                # pre-activation is kept for the ones that differentiate at their input
+                p, z = ops.kipf_layer_fwd(g, cur, self.params[t - 1], self.num_vertex_features[t], act="none")
+                nxt = ops.activation(self.activation, z)
+                if self.activation not in ops.NEEDS_INPUT:
+                    z = None
+            self._tape.append((p, nxt, z))
             cur = nxt
         self.output = cur
 
@@ -193,8 +202,8 @@ class kipf_msgpass_layer_type(msgpass_layer_type):
         g = self.graph.device
         gcur = self._t(upstream)
         for t in range(self.num_time_steps, 0, -1):
-            p, out = self._tape[t - 1]
-            dz = ops.activation_bwd(self.activation, out, gcur) if self.activation not in ("none", "linear") else gcur
+            p, out, z = self._tape[t - 1]
+            dz = ops.activation_bwd(self.activation, out, gcur, z=z) if self.activation not in ("none", "linear") else gcur
             dw = ops.matmul_dw(p, dz)
             self.grads[t - 1] = dw
             if t == 1 and not need_input_grad:   # input layer output has requires_grad = .false.

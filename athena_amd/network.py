@@ -1,0 +1,111 @@
+"""Device-resident chaining of message-passing layers.
+
+A thin mirror of the part of network_type that the msgpass examples use: `add(layer, input_list=,
+operator=)` (athena_network_sub.f90:764-900), a forward that feeds every layer the 'concatenate' (||)
+or 'add' (+) merge of its parents' outputs, the matching reverse pass, and `update` (:2816-2929).
+Activations between layers stay in HBM: the only host transfers are the caller's input and whatever
+the caller reads back.  Parents are merged in ascending order of their position in the network
+(the reference packs the adjacency column in index order), 0 being the network input -- so
+`input_list=[0, -1]` of example/msgpass_euler/src/main.f90:192-255 puts the input features first.
+"""
+import torch
+
+from . import ops, optim
+
+
+class network_type:
+    def __init__(self):
+        self.layers = []      # layer k (1-based id) = self.layers[k-1]
+        self.parents = []     # per layer: sorted parent ids, 0 = network input
+        self.operator = []    # per layer: 1 concatenate, 2 add
+        self.optimiser = None
+
+    def add(self, layer, input_list=None, operator="concatenate"):
+        k = len(self.layers) + 1
+        op = {"||": 1, "concat": 1, "concatenate": 1, "append": 1, 1: 1, "+": 2, "add": 2, 2: 2}.get(
+            operator.lower() if isinstance(operator, str) else operator)
+        if op is None:
+            raise ValueError("invalid operator")                            # stop_program("invalid operator") :824-827
+        if input_list is None:
+            parents = [k - 1]
+        else:
+            parents = []
+            for i in input_list:
+                if i <= -k or i >= k:
+                    raise ValueError(f"input vertex index {i} out of range ({-k + 1}:{k - 1})")
+                parents.append(k + i if i < 0 else i)
+        self.layers.append(layer)
+        self.parents.append(sorted(set(parents)))
+        self.operator.append(op)
+        return self
+
+    def compile(self, optimiser):
+        self.optimiser = optimiser
+        return self
+
+    def set_graph(self, graph):
+        for l in self.layers:
+            l.set_graph(graph)
+
+    def get_num_params(self):
+        return sum(l.get_num_params() for l in self.layers)
+
+    # -------------------------------------------------------------------------------------------
+    def forward(self, x):
+        x = self.layers[0]._cat(x)
+        self._out = [x]
+        self._widths = []
+        for k, layer in enumerate(self.layers, start=1):
+            srcs = [self._out[p] for p in self.parents[k - 1]]
+            inp = srcs[0]
+            if self.operator[k - 1] == 1:
+                for s in srcs[1:]:
+                    inp = ops.concat_features(inp, s)
+            elif len(srcs) > 1:
+                inp = inp.clone()
+                for s in srcs[1:]:
+                    ops.axpy(1.0, s, inp)
+            self._widths.append([s.shape[1] for s in srcs])
+            self._out.append(layer.forward(inp))
+        return self._out[-1]
+
+    def backward(self, upstream, need_input_grad=False):
+        grads = [None] * (len(self.layers) + 1)
+        grads[-1] = self.layers[-1]._t(upstream)
+
+        def give(p, g):
+            if grads[p] is None:
+                grads[p] = g
+            else:
+                ops.axpy(1.0, g, grads[p])
+
+        for k in range(len(self.layers), 0, -1):
+            if grads[k] is None:
+                continue
+            parents = self.parents[k - 1]
+            need = [p > 0 or need_input_grad for p in parents]
+            dinp = self.layers[k - 1].backward(grads[k], need_input_grad=any(need))
+            grads[k] = None
+            if dinp is None:
+                continue
+            if self.operator[k - 1] == 2 or len(parents) == 1:
+                for p, n in zip(parents, need):
+                    if n:
+                        give(p, dinp if len(parents) == 1 else dinp.clone())
+                continue
+            # split a chained concatenation back to its parents, last parent first
+            widths = self._widths[k - 1]
+            rest = dinp
+            for j in range(len(parents) - 1, 0, -1):
+                left = sum(widths[:j])
+                rest, piece = ops.concat_features_bwd(rest, left, need_a=True, need_b=need[j])
+                if need[j]:
+                    give(parents[j], piece)
+            if need[0]:
+                give(parents[0], rest)
+        return grads[0]
+
+    def update(self, epoch=None):
+        if self.optimiser is None:
+            raise RuntimeError("No optimiser is defined for the network")   # :1713-1716
+        return optim.update(self.layers, self.optimiser, epoch)

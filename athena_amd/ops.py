@@ -139,18 +139,60 @@ def pull_gemm(g: DeviceGraph, dZ, W, Fi, exact=False, out=None):
     return dX
 
 
-def activation(kind, z, out=None):
+# activations whose reverse pass needs the INPUT (pre-activation) rather than the output
+NEEDS_INPUT = ("swish",)
+
+
+def activation(kind, z, out=None, beta=1.0):
+    """athena_activation_*.f90 apply: element-wise kinds, plus 'softmax' (over the features of each vertex,
+    z must be [N, F]) and 'swish' (x * sigmoid(beta x))"""
     y = out if out is not None else torch.empty_like(z)
     _go()
-    _capi.call("athena_mp_activation_fwd", ACT[kind], z.numel(), _p(_chk(z)), _p(y))
+    if kind == "softmax":
+        assert z.dim() == 2
+        _capi.call("athena_mp_softmax_fwd", z.shape[0], z.shape[1], _p(_chk(z)), _p(y))
+    elif kind == "swish":
+        _capi.call("athena_mp_swish_fwd", z.numel(), float(beta), _p(_chk(z)), _p(y))
+    else:
+        _capi.call("athena_mp_activation_fwd", ACT[kind], z.numel(), _p(_chk(z)), _p(y))
     return y
 
 
-def activation_bwd(kind, y, g, out=None):
+def activation_bwd(kind, y, g, out=None, z=None, beta=1.0):
+    """reverse factor; y = the activation's OUTPUT, z = its input (required by 'swish' only)"""
     dz = out if out is not None else torch.empty_like(y)
     _go()
-    _capi.call("athena_mp_activation_bwd", ACT[kind], y.numel(), _p(_chk(y)), _p(_chk(g)), _p(dz))
+    if kind == "softmax":
+        assert y.dim() == 2
+        _capi.call("athena_mp_softmax_bwd", y.shape[0], y.shape[1], _p(_chk(y)), _p(_chk(g)), _p(dz))
+    elif kind == "swish":
+        if z is None:
+            raise ValueError("swish differentiates at its input: pass z")
+        _capi.call("athena_mp_swish_bwd", z.numel(), float(beta), _p(_chk(z)), _p(_chk(g)), _p(dz))
+    else:
+        _capi.call("athena_mp_activation_bwd", ACT[kind], y.numel(), _p(_chk(y)), _p(_chk(g)), _p(dz))
     return dz
+
+
+def concat_features(a, b):
+    """'concatenate' merge of two layer inputs: out[v] = [a[v], b[v]]"""
+    _chk(a); _chk(b)
+    assert a.shape[0] == b.shape[0]
+    out = torch.empty((a.shape[0], a.shape[1] + b.shape[1]), device=a.device, dtype=torch.float32)
+    _go()
+    _capi.call("athena_mp_concat_fwd", a.shape[0], a.shape[1], b.shape[1], _p(a), _p(b), _p(out))
+    return out
+
+
+def concat_features_bwd(grad, Fa, need_a=True, need_b=True):
+    """split the gradient of concat_features; returns (da, db) (None where not needed)"""
+    _chk(grad)
+    N, F = grad.shape
+    da = torch.empty((N, Fa), device=grad.device, dtype=torch.float32) if need_a else None
+    db = torch.empty((N, F - Fa), device=grad.device, dtype=torch.float32) if need_b else None
+    _go()
+    _capi.call("athena_mp_concat_bwd", N, Fa, F - Fa, _p(grad), _p(da) if need_a else None, _p(db) if need_b else None)
+    return da, db
 
 
 def axpy(alpha, x, y):

@@ -193,6 +193,22 @@ int athena_mp_gno_aggregate_bwd_coords(const athena_mp_graph *g, int32_t d, int3
                                        int32_t Fo, const float *theta_dev, const float *coords_dev,
                                        const float *x_dev, const float *grad_dev, float *dcoords_dev);
 
+/* ---- activations with their own shape and the 'concatenate' merge (8f-2) -----
+ * swish_array / get_partial_swish_val, athena_diffstruc_extd_sub.f90:424-492: y = x/(1+exp(-beta x));
+ * the reverse pass differentiates at the INPUT x */
+int athena_mp_swish_fwd(int64_t n, float beta, const float *x_dev, float *y_dev);
+int athena_mp_swish_bwd(int64_t n, float beta, const float *x_dev, const float *grad_dev, float *dx_dev);
+/* softmax(val, dim=2): over the F features of each vertex (athena_activation_softmax.f90:183-203,
+ * athena_diffstruc_extd_sub.f90:295-379); reverse: dz = y*g - y*sum(y*g) */
+int athena_mp_softmax_fwd(int64_t N, int32_t F, const float *z_dev, float *y_dev);
+int athena_mp_softmax_bwd(int64_t N, int32_t F, const float *y_dev, const float *grad_dev, float *dz_dev);
+/* network%add(layer, input_list=[..], operator='concatenate') (example/msgpass_euler/src/main.f90:192-255):
+ * out[v,:] = [a[v,:], b[v,:]]; the reverse pass splits grad (da_dev or db_dev may be NULL) */
+int athena_mp_concat_fwd(int64_t N, int32_t Fa, int32_t Fb, const float *a_dev, const float *b_dev,
+                         float *out_dev);
+int athena_mp_concat_bwd(int64_t N, int32_t Fa, int32_t Fb, const float *grad_dev, float *da_dev,
+                         float *db_dev);
+
 /* ---- tail of a train step, device resident -----------------
  * compute_mse, athena_loss.f90:393-430:  *loss_dev = mean((p-e)^2)/2 ; dpred = (p-e)/n (may be NULL) */
 int athena_mp_mse_loss(int64_t n, const float *pred_dev, const float *expected_dev, float *loss_dev,

@@ -312,9 +312,11 @@ void oracle_softmax_cols_bwd(int F, int N, const float *y, const float *g, float
 {
     for (int v = 0; v < N; ++v) {
         const float *yv = y + (size_t)v * F, *gv = g + (size_t)v * F;
+        /* get_partial_softmax_val, athena_diffstruc_extd_sub.f90:358-379: output = val*grad;
+         * output(:,s) = output(:,s) - val(:,s)*sum(output(:,s)) */
         float dot = 0.0f;
-        for (int i = 0; i < F; ++i) dot = dot + gv[i] * yv[i];
-        for (int i = 0; i < F; ++i) dz[(size_t)v * F + i] = yv[i] * (gv[i] - dot);
+        for (int i = 0; i < F; ++i) dot = dot + yv[i] * gv[i];
+        for (int i = 0; i < F; ++i) dz[(size_t)v * F + i] = yv[i] * gv[i] - yv[i] * dot;
     }
 }
 
@@ -584,4 +586,31 @@ float oracle_mse(size_t n, const float *pred, const float *expected, float *dpre
         if (dpred) dpred[i] = d / (float)n;
     }
     return s / (float)n / 2.0f;
+}
+
+
+/* swish_array / get_partial_swish_val    athena_diffstruc_extd_sub.f90:424-455, :477-492
+ *   y = x * (1 / (1 + exp(-beta*x)));  dx = g * e * (beta*x + e + 1) / (e + 1)**2, e = exp(beta*x)
+ *   (the reverse pass differentiates at the INPUT x, and overflows to inf/inf = NaN exactly where
+ *   the reference does, beta*x > ~88) */
+void oracle_swish(size_t n, float beta, const float *x, float *y)
+{
+    for (size_t i = 0; i < n; ++i) y[i] = x[i] * (1.0f / (1.0f + expf(-beta * x[i])));
+}
+void oracle_swish_bwd(size_t n, float beta, const float *x, const float *g, float *dx)
+{
+    for (size_t i = 0; i < n; ++i) {
+        const float e = expf(beta * x[i]);
+        dx[i] = g[i] * e * (beta * x[i] + e + 1.0f) / ((e + 1.0f) * (e + 1.0f));
+    }
+}
+
+/* 'concatenate' merge of two inputs of a layer (network%add(..., operator='concatenate'),
+ * example/msgpass_euler/src/main.f90:192-255): features stacked per vertex, a first */
+void oracle_concat(int N, int Fa, int Fb, const float *a, const float *b, float *out)
+{
+    for (int v = 0; v < N; ++v) {
+        memcpy(out + (size_t)v * (Fa + Fb), a + (size_t)v * Fa, sizeof(float) * Fa);
+        memcpy(out + (size_t)v * (Fa + Fb) + Fa, b + (size_t)v * Fb, sizeof(float) * Fb);
+    }
 }

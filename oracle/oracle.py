@@ -317,3 +317,26 @@ def mse(pred, expected):
     f = lib().oracle_mse
     f.restype = C.c_float
     return float(f(C.c_size_t(p.size), pp, pe, d.ctypes.data_as(C.c_void_p))), d
+
+
+def swish(x, beta=1.0):
+    """athena_diffstruc_extd_sub.f90:424-455"""
+    x, px = _f(x)
+    y = np.empty_like(x)
+    lib().oracle_swish(C.c_size_t(x.size), C.c_float(beta), px, y.ctypes.data_as(C.c_void_p))
+    return y
+
+
+def swish_bwd(x, g, beta=1.0):
+    """athena_diffstruc_extd_sub.f90:477-492 (differentiates at the input x)"""
+    x, px = _f(x); g, pg = _f(g)
+    d = np.empty_like(x)
+    lib().oracle_swish_bwd(C.c_size_t(x.size), C.c_float(beta), px, pg, d.ctypes.data_as(C.c_void_p))
+    return d
+
+
+def concat(a, b):
+    a, pa = _f(a); b, pb = _f(b)
+    out = np.empty((a.shape[0], a.shape[1] + b.shape[1]), np.float32)
+    lib().oracle_concat(C.c_int(a.shape[0]), C.c_int(a.shape[1]), C.c_int(b.shape[1]), pa, pb, out.ctypes.data_as(C.c_void_p))
+    return out

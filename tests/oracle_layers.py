@@ -7,6 +7,23 @@ import numpy as np
 from oracle import oracle as o
 
 
+def act_fwd(act, z):
+    """athena_activation_*.f90 apply, incl. the shaped ones the euler example uses"""
+    if act == "softmax":
+        return o.softmax_cols(z)
+    if act == "swish":
+        return o.swish(z)
+    return o.activation(act, z)
+
+
+def act_bwd(act, y, g, z):
+    if act == "softmax":
+        return o.softmax_cols_bwd(y, g)
+    if act == "swish":
+        return o.swish_bwd(z, g)       # differentiates at the input
+    return o.activation_bwd(act, y, g)
+
+
 def kipf_forward(graphs, xs, params, nvf, act):
     outs, tapes = [], []
     for g, x in zip(graphs, xs):
@@ -14,8 +31,8 @@ def kipf_forward(graphs, xs, params, nvf, act):
         for t in range(1, len(nvf)):
             p = o.kipf_propagate(cur, g.adj_ia, g.adj_ja)
             z = o.matmul(params[t - 1], p, nvf[t])
-            y = o.activation(act, z)
-            tape.append((p, y))
+            y = act_fwd(act, z)
+            tape.append((p, y, z))
             cur = y
         outs.append(cur); tapes.append(tape)
     return outs, tapes
@@ -27,8 +44,8 @@ def kipf_backward(graphs, tapes, params, nvf, act, ups, exact=False):
     for g, tape, up in zip(graphs, tapes, ups):
         gc = up
         for t in range(len(nvf) - 1, 0, -1):
-            p, y = tape[t - 1]
-            dz = o.activation_bwd(act, y, gc)
+            p, y, z = tape[t - 1]
+            dz = act_bwd(act, y, gc, z)
             grads[t - 1] += o.matmul_dw(dz, p)
             dp = o.matmul_dx(params[t - 1], dz, nvf[t - 1])
             gc = o.kipf_propagate_bwd(dp, g.adj_ia, g.adj_ja, exact=exact)

@@ -1,0 +1,135 @@
+"""GPU: shaped activations (softmax over features, swish), the 'concatenate' merge, and the chained
+network of example/msgpass_euler (seven Kipf layers, each fed [input features || previous output])
+kept resident in HBM -- forward, reverse pass and Adam updates against the oracle composed on the host."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_layers as ol
+from helpers import assert_close, csr_from_index_list
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def H(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("N,F", [(1000, 3), (777, 7), (513, 14), (300, 32), (129, 64), (65, 200), (1, 5)])
+def test_softmax_activation_over_features(dev, oracle, N, F):
+    from athena_amd import ops
+
+    rng = np.random.default_rng(N + F)
+    z = (rng.standard_normal((N, F)) * 3).astype(np.float32)
+    g = rng.standard_normal((N, F)).astype(np.float32)
+    y = ops.activation("softmax", T(z, dev))
+    yo = oracle.softmax_cols(z)
+    assert_close(H(y), yo, 2e-6, "softmax")
+    assert np.allclose(H(y).sum(1), 1.0, atol=1e-5)
+    assert_close(H(ops.activation_bwd("softmax", y, T(g, dev))), oracle.softmax_cols_bwd(H(y), g), 2e-6, "softmax bwd")
+
+
+@pytest.mark.parametrize("beta", [1.0, 0.5, 2.0])
+def test_swish_activation(dev, oracle, beta):
+    from athena_amd import ops
+
+    rng = np.random.default_rng(1)
+    x = (rng.standard_normal(100003) * 4).astype(np.float32)
+    g = rng.standard_normal(100003).astype(np.float32)
+    assert_close(H(ops.activation("swish", T(x, dev), beta=beta)), oracle.swish(x, beta), 1e-6, "swish")
+    d = ops.activation_bwd("swish", None if False else T(x, dev), T(g, dev), z=T(x, dev), beta=beta)
+    assert_close(H(d), oracle.swish_bwd(x, g, beta), 1e-6, "swish bwd")
+    with pytest.raises(ValueError, match="input"):
+        ops.activation_bwd("swish", T(x, dev), T(g, dev))
+
+
+def test_concatenate_merge_and_its_split(dev, oracle):
+    from athena_amd import ops
+
+    rng = np.random.default_rng(2)
+    a = rng.standard_normal((1001, 3)).astype(np.float32); b = rng.standard_normal((1001, 14)).astype(np.float32)
+    out = ops.concat_features(T(a, dev), T(b, dev))
+    assert np.array_equal(H(out), oracle.concat(a, b))
+    da, db = ops.concat_features_bwd(out, 3)
+    assert np.array_equal(H(da), a) and np.array_equal(H(db), b)
+    da, db = ops.concat_features_bwd(out, 3, need_a=False)
+    assert da is None and np.array_equal(H(db), b)
+
+
+EULER = [([3, 6], "softmax"), ([9, 14], "softmax"), ([17, 32], "softmax"), ([35, 64], "softmax"),
+         ([67, 32], "softmax"), ([35, 14], "softmax"), ([17, 7], "swish")]     # main.f90:183-255
+
+
+def _oracle_net_forward(g, x, params):
+    outs, tapes, cur = [x], [], None
+    for k, ((fi, fo), act) in enumerate(EULER):
+        inp = x if k == 0 else oracle_concat(x, outs[-1])
+        o_, tape = ol.kipf_forward([g], [inp], [params[k]], [fi, fo], act)
+        outs.append(o_[0]); tapes.append(tape)
+    return outs, tapes
+
+
+def oracle_concat(a, b):
+    from oracle import oracle as o
+    return o.concat(a, b)
+
+
+def _oracle_net_backward(g, params, tapes, up):
+    grads = [None] * len(EULER)
+    gc = up
+    for k in range(len(EULER) - 1, -1, -1):
+        (fi, fo), act = EULER[k]
+        dxs, gr = ol.kipf_backward([g], tapes[k], [params[k]], [fi, fo], act, [gc])
+        grads[k] = gr[0]
+        if k > 0:
+            gc = np.ascontiguousarray(dxs[0][:, 3:])       # the input's share has requires_grad = .false.
+    return grads
+
+
+def test_msgpass_euler_network_resident_chain(dev, oracle):
+    from athena_amd import optim
+    from athena_amd.layers import kipf_msgpass_layer_type
+    from athena_amd.network import network_type
+
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "euler_mesh_edges.npz"))
+    n = int(d["num_vertices"])
+    g = csr_from_index_list(n, d["index_list"], self_loops=True)
+    rng = np.random.default_rng(9)
+    x = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    y = rng.uniform(-1, 1, (n, 7)).astype(np.float32)
+    net = network_type()
+    for k, (nvf, act) in enumerate(EULER):
+        layer = kipf_msgpass_layer_type(num_vertex_features=nvf, num_time_steps=1, activation=act, seed=10 + k)
+        net.add(layer) if k == 0 else net.add(layer, input_list=[0, -1], operator="concatenate")
+    with pytest.raises(ValueError, match="out of range"):
+        net.add(kipf_msgpass_layer_type(num_vertex_features=[7, 7], num_time_steps=1), input_list=[-9])
+    assert net.parents[1] == [0, 1] and net.parents[6] == [0, 6]
+    net.set_graph(g)
+    net.compile(optim.adam_optimiser_type(learning_rate=0.005, clip_dict=optim.clip_type(clip_norm=1.0)))
+    assert net.get_num_params() == sum(a * b for (a, b), _ in EULER)
+    params = [l.get_params().copy() for l in net.layers]
+    m = np.zeros(net.get_num_params(), np.float32); v = np.zeros_like(m)
+    for it in (1, 2):
+        out = net.forward([x])
+        outs, tapes = _oracle_net_forward(g, x, params)
+        assert_close(H(out), outs[-1], 2e-5, f"euler network forward, pass {it}")
+        loss, dl = optim.mse_loss_type().compute(out, T(y, dev))
+        lo, do = oracle.mse(outs[-1], y)
+        assert abs(float(loss.item()) - lo) <= 2e-5 * abs(lo)
+        net.backward(dl)
+        grads = _oracle_net_backward(g, params, tapes, do)
+        for k, l in enumerate(net.layers):
+            assert_close(l.get_gradients(), grads[k], 1e-4, f"dW of layer {k + 1}, pass {it}")
+        net.update()
+        flat = oracle.clip(np.concatenate(grads), clip_norm=1.0)
+        pf, _, m, v = oracle.adam_step(np.concatenate(params), flat, m, v, 0.005, it)
+        o_ = 0
+        for k in range(len(params)):
+            params[k] = pf[o_:o_ + params[k].size]; o_ += params[k].size
+            assert_close(net.layers[k].get_params(), params[k], 1e-4, f"parameters of layer {k + 1} after update {it}")
