@@ -1,0 +1,99 @@
+"""Graph interchange in the reference's `all_graphs.txt` text format and block-diagonal batching.
+
+The format is what example/msgpass_chemical/src/main.f90:353-396 (`export_all_graphs`) writes and
+example/msgpass_chemical/pytorch_network.py:372- reads:
+
+    <num_graphs>
+    per graph:
+      <num_vertices> <num_edges> <num_csr_entries> <num_vertex_features> <num_edge_features>
+      num_vertices rows of vertex features   (ES16.8E2, one row per vertex)
+      num_edges    rows of edge features
+      adj_ia       (num_vertices + 1 integers, 1-based, one line)
+      num_csr_entries rows "adj_ja(1,j) adj_ja(2,j)"
+      <label>      (ES16.8E2)
+
+`batch_graphs` is the ingest step in front of the Duvenaud path: the graphs of a mini-batch become one
+block-diagonal CSR (vertex and edge ids offset per graph) plus the per-graph vertex offsets the readout
+needs -- one device graph handle and one launch per op instead of a host loop over ~130 k tiny graphs
+(SURVEY.md 8a row a10).
+"""
+import numpy as np
+
+from .graph import graph_type
+
+
+def _es(v):
+    """Fortran ES16.8E2: 16 wide, 8 decimals, 2-digit exponent, upper-case E"""
+    s = f"{float(v):.8E}"
+    mant, ex = s.split("E")
+    return f"{mant}E{int(ex):+03d}".rjust(16)
+
+
+def write_all_graphs(path, graphs, labels):
+    with open(path, "w") as f:
+        f.write(f"{len(graphs)}\n")
+        for g, y in zip(graphs, labels):
+            f.write(f"{g.num_vertices} {g.num_edges} {g.nnz} {g.num_vertex_features} {g.num_edge_features}\n")
+            for row in np.asarray(g.vertex_features, np.float32).reshape(g.num_vertices, -1):
+                f.write(" ".join(_es(v) for v in row) + " \n")
+            for row in np.asarray(g.edge_features, np.float32).reshape(g.num_edges, -1):
+                f.write(" ".join(_es(v) for v in row) + " \n")
+            f.write(" ".join(str(int(v)) for v in g.adj_ia) + " \n")
+            for j in range(g.nnz):
+                f.write(f"{int(g.adj_ja[0, j])} {int(g.adj_ja[1, j])}\n")
+            f.write(_es(y) + "\n")
+
+
+def read_all_graphs(path):
+    """returns (list of graph_type with features attached, float32 labels)"""
+    with open(path) as f:
+        tok = f.read().split()
+    pos = 0
+
+    def take(n, dtype):
+        nonlocal pos
+        out = np.array(tok[pos:pos + n], dtype=dtype)
+        if out.size != n:
+            raise ValueError("all_graphs file ended early")
+        pos += n
+        return out
+
+    n_graphs = int(take(1, np.int64)[0])
+    graphs, labels = [], np.empty(n_graphs, np.float32)
+    for s in range(n_graphs):
+        nv, ne, nnz, fv, fe = (int(v) for v in take(5, np.int64))
+        g = graph_type()
+        g.set_num_vertices(nv, fv)
+        g.set_num_edges(ne, fe)
+        g.vertex_features = take(nv * fv, np.float64).astype(np.float32).reshape(nv, fv)
+        g.edge_features = take(ne * fe, np.float64).astype(np.float32).reshape(ne, fe)
+        g.adj_ia = take(nv + 1, np.int64).astype(np.int32)
+        g.adj_ja = np.asfortranarray(take(2 * nnz, np.int64).astype(np.int32).reshape(nnz, 2).T)
+        if g.adj_ia[0] != 1 or g.adj_ia[-1] != nnz + 1:
+            raise ValueError(f"graph {s + 1}: adj_ia does not span the {nnz} CSR entries")
+        labels[s] = np.float32(take(1, np.float64)[0])
+        graphs.append(g)
+    if pos != len(tok):
+        raise ValueError("trailing data in all_graphs file")
+    return graphs, labels
+
+
+def batch_graphs(graphs):
+    """block-diagonal batch: returns (adj_ia, adj_ja, vertex_offsets[S+1] (0-based), vertex_features, edge_features)"""
+    S = len(graphs)
+    voff = np.zeros(S + 1, np.int64); eoff = np.zeros(S + 1, np.int64); woff = np.zeros(S + 1, np.int64)
+    for s, g in enumerate(graphs):
+        voff[s + 1] = voff[s] + g.num_vertices
+        eoff[s + 1] = eoff[s] + g.num_edges
+        woff[s + 1] = woff[s] + g.nnz
+    ia = np.empty(voff[-1] + 1, np.int32)
+    ja = np.empty((2, woff[-1]), np.int32, order="F")
+    ia[0] = 1
+    for s, g in enumerate(graphs):
+        ia[voff[s] + 1: voff[s + 1] + 1] = g.adj_ia[1:] + woff[s]
+        w = slice(woff[s], woff[s + 1])
+        ja[0, w] = g.adj_ja[0] + voff[s]
+        ja[1, w] = np.where(g.adj_ja[1] > 0, g.adj_ja[1] + eoff[s], 0)     # id 0 (self loop) stays 0
+    x = np.concatenate([np.asarray(g.vertex_features, np.float32).reshape(g.num_vertices, -1) for g in graphs]) if S else None
+    e = np.concatenate([np.asarray(g.edge_features, np.float32).reshape(g.num_edges, -1) for g in graphs]) if S else None
+    return ia, ja, voff.astype(np.int32), x, e

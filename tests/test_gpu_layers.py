@@ -207,3 +207,35 @@ def test_kipf_layers_on_the_euler_mesh(dev, oracle):
     dxs, grads = ol.kipf_backward([g], tapes, plist, nvf, "tanh", [up])
     assert_close(dx, dxs[0], 5e-5, "euler mesh dX")
     assert_close(layer.get_gradients(), np.concatenate(grads), 5e-5, "euler mesh dW")
+
+
+def test_duvenaud_layer_on_the_all_graphs_fixture(dev, oracle):
+    """ingest path of msgpass_chemical: all_graphs.txt -> block-diagonal batch -> one Duvenaud layer pass,
+    at the example's own dims (F_v=6, F_e=1, T=4, degrees 1..10, 10 outputs), against the per-graph oracle"""
+    import os
+
+    from athena_amd import io
+    from athena_amd.layers import duvenaud_msgpass_layer_type
+
+    graphs, labels = io.read_all_graphs(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "all_graphs_small.txt"))
+    layer = duvenaud_msgpass_layer_type(num_vertex_features=[6], num_edge_features=[1], num_time_steps=4,
+                                        max_vertex_degree=10, num_outputs=10, min_vertex_degree=1, seed=5)
+    layer.set_graph(graphs)
+    ia, ja, voff, x, e = io.batch_graphs(graphs)
+    assert np.array_equal(ia, layer.graph.adj_ia) and np.array_equal(ja, layer.graph.adj_ja)
+    assert np.array_equal(voff, layer.graph.vertex_offsets)
+    out = layer.forward(x, e).cpu().numpy()
+    nvf = layer.num_vertex_features
+    params = layer.get_params()
+    D, T_ = 10, 4
+    plist, o_ = [], 0
+    for t in range(1, T_ + 1):
+        k = nvf[t] * (nvf[t - 1] + 1) * D
+        plist.append(params[o_:o_ + k]); o_ += k
+    for t in range(1, T_ + 1):
+        k = 10 * nvf[t]
+        plist.append(params[o_:o_ + k]); o_ += k
+    outs, tapes = ol.duvenaud_forward(graphs, [g.vertex_features for g in graphs], [g.edge_features for g in graphs],
+                                      plist, nvf, 1, 1, 10, 10, "sigmoid")
+    assert out.shape == (4, 10)
+    assert_close(out, outs, 1e-5, "duvenaud layer on the interchange fixture")

@@ -3,6 +3,7 @@ import ctypes as C
 import os
 
 import numpy as np
+import pytest
 
 from helpers import csr_from_index_list, golden
 
@@ -54,3 +55,42 @@ def test_synth_generator_is_seeded_and_well_formed():
     assert np.all(ja[0, ia[:-1] - 1] == np.arange(1, 1001))       # self loop first in each row
     assert np.all((ja[1] == 0) == (ja[0] == rows))
     assert ja[0].min() >= 1 and ja[0].max() <= 1000
+
+
+def test_all_graphs_text_format_round_trip(tmp_path):
+    """the reference's graph interchange file (example/msgpass_chemical/src/main.f90:353-396): the committed
+    fixture parses to the graphs its generator built, and write -> read is bit-identical (ES16.8E2 keeps
+    9 significant digits, enough for float32)"""
+    from athena_amd import io
+    from athena_amd.graph import graph_type
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "all_graphs_small.txt")
+    graphs, labels = io.read_all_graphs(path)
+    assert [g.num_vertices for g in graphs] == [3, 5, 4, 6] and [g.num_edges for g in graphs] == [2, 5, 3, 6]
+    assert all(g.num_vertex_features == 6 and g.num_edge_features == 1 for g in graphs)
+    g0 = graphs[0]                       # path 1-2-3 with self loops: loops first (edge id 0), then by edge id
+    assert g0.adj_ia.tolist() == [1, 3, 6, 8]
+    assert g0.adj_ja.T.tolist() == [[1, 0], [2, 1], [2, 0], [1, 1], [3, 2], [3, 0], [2, 2]]
+    ref = graph_type(); ref.set_num_vertices(5, 6)
+    ref.generate_adjacency(np.array([[1, 2], [2, 3], [3, 4], [4, 5], [5, 1]]).T); ref.add_self_loops()
+    assert np.array_equal(graphs[1].adj_ia, ref.adj_ia) and np.array_equal(graphs[1].adj_ja, ref.adj_ja)
+    out = tmp_path / "again.txt"
+    io.write_all_graphs(out, graphs, labels)
+    assert open(out).read() == open(path).read()
+    g2, l2 = io.read_all_graphs(out)
+    assert np.array_equal(l2, labels)
+    for a, b in zip(graphs, g2):
+        assert np.array_equal(a.vertex_features, b.vertex_features) and np.array_equal(a.edge_features, b.edge_features)
+        assert np.array_equal(a.adj_ja, b.adj_ja)
+    # block-diagonal batch: offsets, shifted ids, self-loop id 0 untouched
+    ia, ja, voff, x, e = io.batch_graphs(graphs)
+    assert voff.tolist() == [0, 3, 8, 12, 18] and ia.size == 19 and ja.shape[1] == sum(g.nnz for g in graphs)
+    assert x.shape == (18, 6) and e.shape == (16, 1)
+    w0 = graphs[0].nnz
+    assert np.array_equal(ja[0, w0:w0 + graphs[1].nnz], graphs[1].adj_ja[0] + 3)
+    assert np.array_equal(ja[1, w0:w0 + graphs[1].nnz], np.where(graphs[1].adj_ja[1] > 0, graphs[1].adj_ja[1] + 2, 0))
+    # a truncated file is an error, not a silent short read
+    bad = tmp_path / "bad.txt"
+    bad.write_text(" ".join(open(path).read().split()[:40]))
+    with pytest.raises(ValueError, match="ended early|span"):
+        io.read_all_graphs(bad)
