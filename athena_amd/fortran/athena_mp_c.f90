@@ -21,6 +21,10 @@ module athena_mp_c
   public :: athena_mp_malloc, athena_mp_free, athena_mp_memcpy_h2d, athena_mp_memcpy_d2h
   public :: athena_mp_kipf_propagate_fwd, athena_mp_kipf_propagate_bwd
   public :: athena_mp_gemm_fwd, athena_mp_gemm_dw, athena_mp_gemm_dx
+  public :: athena_mp_adam_step, athena_mp_sgd_step, athena_mp_clip, athena_mp_mse_loss
+  public :: athena_mp_swish_fwd, athena_mp_swish_bwd, athena_mp_softmax_fwd, athena_mp_softmax_bwd
+  public :: athena_mp_concat_fwd, athena_mp_concat_bwd
+  public :: athena_mp_duvenaud_readout_fwd, athena_mp_duvenaud_readout_bwd, athena_mp_duvenaud_update_act_fwd
   public :: athena_mp_error_message
 
   interface
@@ -164,6 +168,106 @@ module athena_mp_c
        integer(c_int64_t), value :: N
        integer(c_int32_t), value :: Fi, Fo
        type(c_ptr), value :: dZ_dev, W_dev, dP_dev
+     end function
+
+     !! ---- device-resident tail of a train step (network%update, athena_network_sub.f90:2816-2929) ----
+     !! minimise_adam, athena_optimiser.f90:1027-1091 (iter = optimiser%iter after the increment)
+     integer(c_int) function athena_mp_adam_step(n, lr, beta1, beta2, epsilon, iter, reg_kind, l1, l2, &
+          decoupled, param_dev, grad_dev, m_dev, v_dev) bind(C, name="athena_mp_adam_step")
+       import :: c_int, c_int32_t, c_int64_t, c_float, c_ptr
+       integer(c_int64_t), value :: n
+       real(c_float), value :: lr, beta1, beta2, epsilon, l1, l2
+       integer(c_int32_t), value :: iter, reg_kind, decoupled
+       type(c_ptr), value :: param_dev, grad_dev, m_dev, v_dev
+     end function
+     !! minimise_sgd, athena_optimiser.f90:634-673
+     integer(c_int) function athena_mp_sgd_step(n, lr, momentum, nesterov, reg_kind, l1, l2, &
+          param_dev, grad_dev, velocity_dev) bind(C, name="athena_mp_sgd_step")
+       import :: c_int, c_int32_t, c_int64_t, c_float, c_ptr
+       integer(c_int64_t), value :: n
+       real(c_float), value :: lr, momentum, l1, l2
+       integer(c_int32_t), value :: nesterov, reg_kind
+       type(c_ptr), value :: param_dev, grad_dev, velocity_dev
+     end function
+     !! apply_clip, athena_clipper.f90:165-210
+     integer(c_int) function athena_mp_clip(n, grad_dev, l_min_max, clip_min, clip_max, l_norm, clip_norm) &
+          bind(C, name="athena_mp_clip")
+       import :: c_int, c_int32_t, c_int64_t, c_float, c_ptr
+       integer(c_int64_t), value :: n
+       type(c_ptr), value :: grad_dev
+       integer(c_int32_t), value :: l_min_max, l_norm
+       real(c_float), value :: clip_min, clip_max, clip_norm
+     end function
+     !! compute_mse, athena_loss.f90:393-430
+     integer(c_int) function athena_mp_mse_loss(n, pred_dev, expected_dev, loss_dev, dpred_dev) &
+          bind(C, name="athena_mp_mse_loss")
+       import :: c_int, c_int64_t, c_ptr
+       integer(c_int64_t), value :: n
+       type(c_ptr), value :: pred_dev, expected_dev, loss_dev, dpred_dev
+     end function
+
+     !! ---- shaped activations and the concatenate merge ----
+     integer(c_int) function athena_mp_swish_fwd(n, beta, x_dev, y_dev) bind(C, name="athena_mp_swish_fwd")
+       import :: c_int, c_int64_t, c_float, c_ptr
+       integer(c_int64_t), value :: n
+       real(c_float), value :: beta
+       type(c_ptr), value :: x_dev, y_dev
+     end function
+     integer(c_int) function athena_mp_swish_bwd(n, beta, x_dev, grad_dev, dx_dev) &
+          bind(C, name="athena_mp_swish_bwd")
+       import :: c_int, c_int64_t, c_float, c_ptr
+       integer(c_int64_t), value :: n
+       real(c_float), value :: beta
+       type(c_ptr), value :: x_dev, grad_dev, dx_dev
+     end function
+     integer(c_int) function athena_mp_softmax_fwd(N, F, z_dev, y_dev) bind(C, name="athena_mp_softmax_fwd")
+       import :: c_int, c_int32_t, c_int64_t, c_ptr
+       integer(c_int64_t), value :: N
+       integer(c_int32_t), value :: F
+       type(c_ptr), value :: z_dev, y_dev
+     end function
+     integer(c_int) function athena_mp_softmax_bwd(N, F, y_dev, grad_dev, dz_dev) &
+          bind(C, name="athena_mp_softmax_bwd")
+       import :: c_int, c_int32_t, c_int64_t, c_ptr
+       integer(c_int64_t), value :: N
+       integer(c_int32_t), value :: F
+       type(c_ptr), value :: y_dev, grad_dev, dz_dev
+     end function
+     integer(c_int) function athena_mp_concat_fwd(N, Fa, Fb, a_dev, b_dev, out_dev) &
+          bind(C, name="athena_mp_concat_fwd")
+       import :: c_int, c_int32_t, c_int64_t, c_ptr
+       integer(c_int64_t), value :: N
+       integer(c_int32_t), value :: Fa, Fb
+       type(c_ptr), value :: a_dev, b_dev, out_dev
+     end function
+     integer(c_int) function athena_mp_concat_bwd(N, Fa, Fb, grad_dev, da_dev, db_dev) &
+          bind(C, name="athena_mp_concat_bwd")
+       import :: c_int, c_int32_t, c_int64_t, c_ptr
+       integer(c_int64_t), value :: N
+       integer(c_int32_t), value :: Fa, Fb
+       type(c_ptr), value :: grad_dev, da_dev, db_dev
+     end function
+
+     !! ---- Duvenaud composite entry points (one launch each) ----
+     integer(c_int) function athena_mp_duvenaud_update_act_fwd(graph, Fi, Fo, min_deg, max_deg, a_dev, &
+          weight_dev, act, z_dev) bind(C, name="athena_mp_duvenaud_update_act_fwd")
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: graph, a_dev, weight_dev, z_dev
+       integer(c_int32_t), value :: Fi, Fo, min_deg, max_deg, act
+     end function
+     integer(c_int) function athena_mp_duvenaud_readout_fwd(N, Fv, O, S, seg_dev, z_dev, R_dev, p_dev, &
+          out_dev, accumulate) bind(C, name="athena_mp_duvenaud_readout_fwd")
+       import :: c_int, c_int32_t, c_int64_t, c_ptr
+       integer(c_int64_t), value :: N
+       integer(c_int32_t), value :: Fv, O, S, accumulate
+       type(c_ptr), value :: seg_dev, z_dev, R_dev, p_dev, out_dev
+     end function
+     integer(c_int) function athena_mp_duvenaud_readout_bwd(N, Fv, O, S, seg_dev, z_dev, R_dev, p_dev, &
+          gout_dev, dz_next_dev, act, dc_dev, dR_dev, accumulate) bind(C, name="athena_mp_duvenaud_readout_bwd")
+       import :: c_int, c_int32_t, c_int64_t, c_ptr
+       integer(c_int64_t), value :: N
+       integer(c_int32_t), value :: Fv, O, S, act, accumulate
+       type(c_ptr), value :: seg_dev, z_dev, R_dev, p_dev, gout_dev, dz_next_dev, dc_dev, dR_dev
      end function
   end interface
 

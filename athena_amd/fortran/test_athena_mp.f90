@@ -20,6 +20,7 @@ program test_athena_mp
   call identity_kat()
   call six_vertex_graph()
   call duvenaud_five_vertex_graph()
+  call adam_update_resident()
 
   rc = athena_mp_finalize()
   if(success)then
@@ -30,6 +31,52 @@ program test_athena_mp
   end if
 
 contains
+
+  subroutine adam_update_resident()
+    !! three Adam updates on device-resident flat vectors against minimise_adam
+    !! (athena_optimiser.f90:1027-1091, no regulariser) restated inline -- including Fortran's own
+    !! real**integer for the bias corrections, which the C side reproduces by binary powering
+    integer, parameter :: n = 1000
+    real(real32) :: param(n), grad(n), m(n), v(n), p_dev_copy(n), m_dev_copy(n)
+    real(real32) :: lr, beta1, beta2, eps, bc1, bc2
+    type(c_ptr) :: d_param, d_grad, d_m, d_v
+    integer :: iter, i
+    lr = 0.01_real32; beta1 = 0.9_real32; beta2 = 0.999_real32; eps = 1.E-8_real32
+    do i = 1, n
+       param(i) = sin(real(i, real32))
+    end do
+    m = 0._real32; v = 0._real32
+    call check(athena_mp_malloc(d_param, int(4*n, c_int64_t)), "malloc")
+    call check(athena_mp_malloc(d_grad, int(4*n, c_int64_t)), "malloc")
+    call check(athena_mp_malloc(d_m, int(4*n, c_int64_t)), "malloc")
+    call check(athena_mp_malloc(d_v, int(4*n, c_int64_t)), "malloc")
+    call check(athena_mp_memcpy_h2d(d_param, param, int(4*n, c_int64_t)), "h2d")
+    call check(athena_mp_memcpy_h2d(d_m, m, int(4*n, c_int64_t)), "h2d")
+    call check(athena_mp_memcpy_h2d(d_v, v, int(4*n, c_int64_t)), "h2d")
+    do iter = 1, 3
+       do i = 1, n
+          grad(i) = cos(real(i * iter, real32)) * 0.5_real32
+       end do
+       call check(athena_mp_memcpy_h2d(d_grad, grad, int(4*n, c_int64_t)), "h2d")
+       call check(athena_mp_adam_step(int(n, c_int64_t), lr, beta1, beta2, eps, int(iter, c_int32_t), &
+            0_c_int32_t, 0._c_float, 0._c_float, 0_c_int32_t, d_param, d_grad, d_m, d_v), "adam_step")
+       ! the reference's statements
+       m = beta1 * m + (1._real32 - beta1) * grad
+       v = beta2 * v + (1._real32 - beta2) * grad * grad
+       bc1 = 1._real32 - beta1**iter
+       bc2 = 1._real32 - beta2**iter
+       param = param - lr * ( (m / bc1) / (sqrt(v / bc2) + eps) )
+    end do
+    call check(athena_mp_memcpy_d2h(p_dev_copy, d_param, int(4*n, c_int64_t)), "d2h")
+    call check(athena_mp_memcpy_d2h(m_dev_copy, d_m, int(4*n, c_int64_t)), "d2h")
+    if(maxval(abs(p_dev_copy - param)) .gt. 2.E-6_real32 .or. &
+         maxval(abs(m_dev_copy - m)) .gt. 1.E-7_real32)then
+       write(0,*) "adam_update_resident: mismatch", maxval(abs(p_dev_copy - param)), maxval(abs(m_dev_copy - m))
+       success = .false.
+    end if
+    call check(athena_mp_free(d_param), "free"); call check(athena_mp_free(d_grad), "free")
+    call check(athena_mp_free(d_m), "free"); call check(athena_mp_free(d_v), "free")
+  end subroutine adam_update_resident
 
   subroutine check(rc, what)
     integer(c_int), intent(in) :: rc
