@@ -1,11 +1,13 @@
 #!/bin/bash
-# Diagnostic (timing-only) builds of libathena_mp with -DDUV_VARIANT=n; output build/libathena_mp_v<n>.so.
-# Use: ATHENA_MP_LIB=build/libathena_mp_v1.so python scripts/bench_configs.py --config c3 --no-cpu
+# Diagnostic (timing-only / A-B) builds of libathena_mp: one source recompiled with an extra define.
+#   scripts/build_variants.sh <source.hip> <tag> <-DNAME=value ...>   ->  variants/libathena_mp_<tag>.so
+# Use: ATHENA_MP_LIB=$PWD/variants/libathena_mp_<tag>.so python bench.py ...
 set -e
+src=$1; tag=$2; shift 2
 cd "$(dirname "$0")/../athena_amd/csrc"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off"
-for v in "$@"; do
-  /opt/rocm/bin/hipcc $FLAGS -DDUV_VARIANT=$v -c duv_mfma.hip -o ../../build/obj/duv_mfma_v$v.o
-  objs=$(ls ../../build/obj/*.o | grep -v "duv_mfma" | tr '\n' ' ')
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs ../../build/obj/duv_mfma_v$v.o -o ../../build/libathena_mp_v$v.so
-done
+mkdir -p ../../variants
+/opt/rocm/bin/hipcc $FLAGS "$@" -c $src -o ../../build/obj/${src%.hip}_$tag.o
+objs=$(ls ../../build/obj/*.o | grep -v "/${src%.hip}\(_[A-Za-z0-9]*\)\?\.o" | tr '\n' ' ')
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs ../../build/obj/${src%.hip}_$tag.o -o ../../variants/libathena_mp_$tag.so
+echo "built variants/libathena_mp_$tag.so"
