@@ -263,11 +263,15 @@ class KipfShardStep:
         b.kipf_layer_fwd(self.g_fwd_bnd, self.x_ext, self.W, F, P=self.P[ni:], Z=self.Z[ni:])
         reqs = self.xchg.start(self.dZ_ext)                                       # halo of dZ in flight ...
         b.matmul_dw(self.P, self.dZ, out=self.dW)                                 # ... under dW
-        if s.world > 1:
-            dist.all_reduce(self.dW)
+        # asynchronous: a blocking all_reduce would make the compute stream wait for the collective, and the
+        # collective queues behind the halo transfer on the communicator's stream -- the interior rows below
+        # would then start only after the exchange they are meant to hide
+        red = dist.all_reduce(self.dW, async_op=True) if s.world > 1 else None
         b.pull_gemm(self.g_bwd_int, self.dZ_ext, self.W, F, exact=self.exact, out=self.dX[:ni])   # ... and the interior rows
         self.xchg.finish(reqs)
         b.pull_gemm(self.g_bwd_bnd, self.dZ_ext, self.W, F, exact=self.exact, out=self.dX[ni:])
+        if red is not None:
+            red.wait()
         return self.dX
 
 
