@@ -376,6 +376,8 @@ void oracle_gno_aggregate(int Fi, int Fo, int N, const float *x, const float *ka
     for (int i = 0; i < N; ++i)
         for (int jj = adj_ia[i] - 1; jj < adj_ia[i + 1] - 1; ++jj) {
             int j = JA(0, jj) - 1, e = JA(1, jj) - 1;
+            if (e < 0) continue; /* edge id 0 (self-loop entry): the reference would index kernel column 0, out of
+                                  * bounds; defined here, as for duvenaud_propagate, as a zero kernel */
             const float *K = kappa + (size_t)e * Fo * Fi;
             const float *xj = x + (size_t)j * Fi;
             for (int o = 0; o < Fo; ++o) {
@@ -393,6 +395,8 @@ void oracle_gno_aggregate_bwd_x(int Fi, int Fo, int N, const float *g, const flo
     for (int i = 0; i < N; ++i)
         for (int jj = adj_ia[i] - 1; jj < adj_ia[i + 1] - 1; ++jj) {
             int j = JA(0, jj) - 1, e = JA(1, jj) - 1;
+            if (e < 0) continue; /* edge id 0 (self-loop entry): the reference would index kernel column 0, out of
+                                  * bounds; defined here, as for duvenaud_propagate, as a zero kernel */
             const float *K = kappa + (size_t)e * Fo * Fi;
             for (int q = 0; q < Fi; ++q) {
                 float s = 0.0f;
@@ -409,6 +413,8 @@ void oracle_gno_aggregate_bwd_k(int Fi, int Fo, int N, int E, const float *g, co
     for (int i = 0; i < N; ++i)
         for (int jj = adj_ia[i] - 1; jj < adj_ia[i + 1] - 1; ++jj) {
             int j = JA(0, jj) - 1, e = JA(1, jj) - 1;
+            if (e < 0) continue; /* edge id 0 (self-loop entry): the reference would index kernel column 0, out of
+                                  * bounds; defined here, as for duvenaud_propagate, as a zero kernel */
             float *dk = dkappa + (size_t)e * Fo * Fi;
             for (int q = 0; q < Fi; ++q)
                 for (int o = 0; o < Fo; ++o)

@@ -1,0 +1,119 @@
+"""GPU: seeded fuzz of the Duvenaud and GNO op chains against the oracle -- random molecule-like batches
+(ragged graph sizes, empty graphs, isolated vertices, self loops with edge id 0), random feature counts
+on both sides of every kernel-selection threshold (VALU kernels / register-resident MFMA / tiled
+fallback), random degree clamps."""
+import numpy as np
+import pytest
+
+from helpers import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def H(t):
+    return t.detach().cpu().numpy()
+
+
+def _batch(rng, n_graphs, max_size, self_loops, isolated_frac):
+    """block-diagonal batch of random connected-ish graphs; returns adj_ia, adj_ja, seg, n_edges"""
+    rows, cols, eids, seg = [], [], [], [0]
+    v0 = e0 = 0
+    for _ in range(n_graphs):
+        nv = int(rng.integers(0, max_size + 1))
+        pairs = [(i, i + 1) for i in range(nv - 1) if rng.random() > isolated_frac]
+        pairs += [tuple(rng.integers(0, nv, 2)) for _ in range(int(rng.integers(0, nv + 1)))] if nv > 1 else []
+        pairs = [(int(a), int(b)) for a, b in pairs if a != b]
+        for k, (a, b) in enumerate(pairs):
+            rows += [v0 + a, v0 + b]; cols += [v0 + b, v0 + a]; eids += [e0 + k + 1] * 2
+        if self_loops:
+            rows += list(range(v0, v0 + nv)); cols += list(range(v0, v0 + nv)); eids += [0] * nv
+        v0 += nv; e0 += len(pairs)
+        seg.append(v0)
+    rows, cols, eids = np.array(rows, np.int64), np.array(cols, np.int64), np.array(eids, np.int64)
+    order = np.lexsort((eids, rows))
+    rows, cols, eids = rows[order], cols[order], eids[order]
+    ia = np.concatenate([[1], 1 + np.cumsum(np.bincount(rows, minlength=v0))]).astype(np.int32)
+    ja = np.zeros((2, rows.size), np.int32, order="F")
+    ja[0] = cols + 1; ja[1] = eids
+    return ia, ja, np.array(seg, np.int32), e0
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_duvenaud_chain_fuzz(dev, oracle, seed):
+    from athena_amd import DeviceGraph, ops
+
+    rng = np.random.default_rng(5000 + seed)
+    big = seed % 4 == 0                                   # enough vertices for the MFMA route (n >= 1024)
+    ia, ja, seg, E = _batch(rng, int(rng.integers(120, 200)) if big else int(rng.integers(1, 30)),
+                            24 if big else 12, self_loops=bool(seed % 2), isolated_frac=0.15)
+    N = ia.size - 1
+    if N == 0 or E == 0:
+        pytest.skip("degenerate draw")
+    Fv = int(rng.choice([3, 6, 8, 16, 20, 32, 64]))
+    Fe = int(rng.choice([1, 2, 4, 8]))
+    Fo = int(rng.choice([4, 7, 16, 32, 64]))
+    O = int(rng.choice([1, 3, 10, 16, 20]))
+    mn = int(rng.integers(1, 3)); mx = mn + int(rng.integers(0, 6))
+    act = str(rng.choice(["sigmoid", "tanh", "relu", "none"]))
+    g = DeviceGraph(ia, ja, n_edge_cols=E)
+    x = rng.uniform(0, 1, (N, Fv)).astype(np.float32)
+    e = rng.uniform(0, 1, (E, Fe)).astype(np.float32)
+    w = (rng.standard_normal(Fo * (Fv + Fe) * (mx - mn + 1)) * 0.3).astype(np.float32)
+    R = (rng.standard_normal(O * Fo) * 0.5).astype(np.float32)
+    gout = rng.standard_normal((seg.size - 1, O)).astype(np.float32)
+
+    a = ops.duvenaud_propagate(g, T(x, dev), T(e, dev))
+    ao = oracle.duvenaud_propagate(x, e, ia, ja)
+    assert np.array_equal(H(a), ao)
+    z = ops.duvenaud_update_act(g, a, T(w, dev), mn, mx, Fo, act=act)
+    zo = oracle.activation(act, oracle.duvenaud_update(ao, w, ia, mn, mx, Fo))
+    assert_close(H(z), zo, 2e-5, "update+act")
+    p, out = ops.duvenaud_readout(T(R, dev), T(zo, dev), T(seg, dev), O)
+    po = oracle.softmax_cols(oracle.matmul(R, zo, O))
+    assert_close(H(p), po, 2e-5, "readout p")
+    assert_close(H(out), oracle.segment_sum(po, seg), 2e-5, "readout out")
+    dc, dR = ops.duvenaud_readout_bwd(T(R, dev), T(zo, dev), T(po, dev), T(seg, dev), T(gout, dev), act=act)
+    dl = oracle.softmax_cols_bwd(po, np.repeat(gout, np.diff(seg), axis=0))
+    dco = oracle.activation_bwd(act, zo, oracle.matmul_dx(R, dl, Fo))
+    assert_close(H(dc), dco, 2e-5, "readout reverse dc")
+    assert_close(H(dR), oracle.matmul_dw(dl, zo), 2e-5, "readout reverse dR")
+    dw = ops.duvenaud_update_bwd_w(g, T(dco, dev), T(ao, dev), mn, mx)
+    assert_close(H(dw), oracle.duvenaud_update_bwd_w(dco, ao, ia, mn, mx), 2e-5, "dW")
+    da = ops.duvenaud_update_bwd_a(g, T(dco, dev), T(w, dev), mn, mx, Fv + Fe)
+    dao = oracle.duvenaud_update_bwd_a(dco, w, ia, mn, mx, Fv + Fe)
+    assert_close(H(da), dao, 2e-5, "da")
+    assert np.array_equal(H(ops.duvenaud_propagate_bwd_x(g, T(dao, dev), Fv)), oracle.duvenaud_propagate_bwd_x(dao, Fv, ia, ja))
+    assert np.array_equal(H(ops.duvenaud_propagate_bwd_e(g, T(dao, dev), Fv)), oracle.duvenaud_propagate_bwd_e(dao, Fv, E, ia, ja))
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_gno_fuzz(dev, oracle, seed):
+    from athena_amd import DeviceGraph, ops
+
+    rng = np.random.default_rng(7000 + seed)
+    ia, ja, _, E = _batch(rng, 1, int(rng.integers(5, 400)), self_loops=bool(seed % 3 == 0), isolated_frac=0.1)
+    N = ia.size - 1
+    if N < 2 or E == 0:
+        pytest.skip("degenerate draw")
+    d = int(rng.integers(1, 4)); Hh = int(rng.choice([3, 8, 16, 32, 64]))
+    Fi = int(rng.choice([2, 5, 16, 32, 64])); Fo = int(rng.choice([3, 8, 32, 64]))
+    g = DeviceGraph(ia, ja, n_edge_cols=E)
+    coords = rng.standard_normal((E, d)).astype(np.float32)
+    x = rng.uniform(-1, 1, (N, Fi)).astype(np.float32)
+    theta = (0.4 * rng.standard_normal(Hh * d + Hh + Fo * Fi * Hh + Fo * Fi)).astype(np.float32)
+    up = rng.uniform(-1, 1, (N, Fo)).astype(np.float32)
+    kap = oracle.gno_kernel_eval(coords, theta, Hh, Fo * Fi)
+    m = ops.gno_aggregate(g, T(theta, dev), T(coords, dev), T(x, dev), d, Hh, Fo)
+    assert_close(H(m), oracle.gno_aggregate(x, kap, ia, ja, Fo), 2e-5, "gno fwd")
+    dx = ops.gno_aggregate_bwd_x(g, T(theta, dev), T(coords, dev), T(up, dev), d, Hh, Fi)
+    assert_close(H(dx), oracle.gno_aggregate_bwd_x(up, kap, ia, ja, Fi), 2e-5, "gno dx")
+    dk = oracle.gno_aggregate_bwd_k(up, x, E, ia, ja)
+    dth = ops.gno_aggregate_bwd_theta(g, T(theta, dev), T(coords, dev), T(x, dev), T(up, dev), d, Hh)
+    assert_close(H(dth), oracle.gno_kernel_bwd_theta(coords, theta, dk, Hh), 5e-5, "gno dtheta")
+    dco = ops.gno_aggregate_bwd_coords(g, T(theta, dev), T(coords, dev), T(x, dev), T(up, dev), d, Hh)
+    assert_close(H(dco), oracle.gno_kernel_bwd_coords(coords, theta, dk, Hh), 5e-5, "gno dcoords")
