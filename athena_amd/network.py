@@ -105,6 +105,44 @@ class network_type:
                 give(parents[0], rest)
         return grads[0]
 
+    # -------------------------------------------------------------------------------------------
+    def capture_step(self, x, target, loss):
+        """Record forward -> loss -> reverse pass of this network once into a HIP graph and return
+        (replay, x_buf, target_buf, loss_buf).  Small graphs (the msgpass_euler mesh, molecule mini-batches)
+        are launch bound: a step is ~100 short kernels, and replaying the captured graph removes the per-launch
+        and per-op host cost.  New samples are fed by copying into x_buf / target_buf; gradients land in the
+        layers' `.grads` buffers as usual, so `update()` (whose Adam bias correction changes every step) is
+        called eagerly after replay().  The graph handles must be set before capturing."""
+        dev = self.layers[0].device
+        x_buf = self.layers[0]._cat(x).clone()
+        t_buf = self.layers[0]._t(target).clone()
+
+        def run():
+            out = self.forward(x_buf)
+            l, d = loss.compute(out, t_buf)
+            self.backward(d)
+            return l
+
+        run()                                   # eager warm-up: grows the library's workspaces outside the capture
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                loss_buf = run()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        grads = [[g for g in l.grads] for l in self.layers]     # the captured step always writes these buffers
+
+        def replay():
+            graph.replay()
+            for l, gs in zip(self.layers, grads):
+                l.grads = list(gs)
+            return loss_buf
+
+        self._captured = graph
+        return replay, x_buf, t_buf, loss_buf
+
     def update(self, epoch=None):
         if self.optimiser is None:
             raise RuntimeError("No optimiser is defined for the network")   # :1713-1716

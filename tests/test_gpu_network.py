@@ -133,3 +133,39 @@ def test_msgpass_euler_network_resident_chain(dev, oracle):
         for k in range(len(params)):
             params[k] = pf[o_:o_ + params[k].size]; o_ += params[k].size
             assert_close(net.layers[k].get_params(), params[k], 1e-4, f"parameters of layer {k + 1} after update {it}")
+
+
+def test_captured_step_replays_the_eager_step(dev, oracle):
+    """forward -> mse -> reverse pass recorded once into a HIP graph: replay writes the same loss and the same
+    gradients as the eager step, for new inputs copied into the captured buffers"""
+    import torch
+    from athena_amd import optim
+    from athena_amd.layers import kipf_msgpass_layer_type
+    from athena_amd.network import network_type
+
+    rng = np.random.default_rng(12)
+    n = 500
+    pairs = np.array([[i, i + 1] for i in range(1, n)] + [[int(a), int(b)] for a, b in rng.integers(1, n + 1, (700, 2)) if a != b]).T
+    g = csr_from_index_list(n, pairs, self_loops=True)
+    net = network_type()
+    net.add(kipf_msgpass_layer_type(num_vertex_features=[3, 16], num_time_steps=1, activation="softmax", seed=1))
+    net.add(kipf_msgpass_layer_type(num_vertex_features=[19, 64], num_time_steps=1, activation="tanh", seed=2), input_list=[0, -1])
+    net.add(kipf_msgpass_layer_type(num_vertex_features=[64, 64], num_time_steps=1, activation="relu", seed=3))
+    net.add(kipf_msgpass_layer_type(num_vertex_features=[67, 5], num_time_steps=1, activation="swish", seed=4), input_list=[0, -1])
+    net.set_graph(g)
+    loss = optim.mse_loss_type()
+    x0 = rng.uniform(-1, 1, (n, 3)).astype(np.float32); y0 = rng.uniform(-1, 1, (n, 5)).astype(np.float32)
+    replay, xb, tb, lb = net.capture_step(x0, y0, loss)
+    for trial in range(2):
+        x = rng.uniform(-1, 1, (n, 3)).astype(np.float32); y = rng.uniform(-1, 1, (n, 5)).astype(np.float32)
+        out = net.forward([x]); l, d = loss.compute(out, T(y, dev)); net.backward(d)
+        eager = [l_.get_gradients().copy() for l_ in net.layers]
+        le = float(l.item())
+        for l_ in net.layers:
+            l_.grads = [None] * len(l_.params)
+        xb.copy_(T(x, dev)); tb.copy_(T(y, dev))
+        replay()
+        torch.cuda.synchronize()
+        assert float(lb.item()) == le
+        for k, l_ in enumerate(net.layers):
+            assert np.array_equal(l_.get_gradients(), eager[k]), f"layer {k + 1} gradients differ under replay"
