@@ -46,20 +46,24 @@ __device__ __forceinline__ v4f load4(const float *__restrict__ p, int nvalid, bo
     return r;
 }
 
+// WM = rows of C per wave (32 or 64); the workgroup tile is (4 WM) x 64.  WM = 64 halves the LDS reads,
+// barriers and B re-reads per MFMA and is used when M gives enough workgroups to fill the chip.
+template <int WM>
 __global__ __launch_bounds__(256) void gemm_tiled_kernel(amp::TiledArgs p)
 {
-    __shared__ __attribute__((aligned(16))) float As[BM * LDT];
+    constexpr int BMT = 4 * WM, NA = BMT * 8 / 256, RB = WM / 32;
+    __shared__ __attribute__((aligned(16))) float As[BMT * LDT];
     __shared__ __attribute__((aligned(16))) float Bs[BN * LDT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r31 = lane & 31, h = lane >> 5;
-    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int64_t m0 = (int64_t)blockIdx.x * BMT;
     const int n0 = blockIdx.y * BN;
     const bool a_vec = (p.lda % 4 == 0) && ((uintptr_t)p.A % 16 == 0);
     const bool b_vec = (p.ldb % 4 == 0) && ((uintptr_t)p.B % 16 == 0);
 
-    // this thread's 4 A rows (row = t>>3, k-quad = t&7)
-    const float *ap[4];
+    // this thread's NA A rows (row = t>>3, k-quad = t&7)
+    const float *ap[NA];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < NA; ++it) {
         const int64_t m = m0 + ((it * 256 + tid) >> 3);
         ap[it] = nullptr;
         if (m < p.M) {
@@ -67,10 +71,10 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(amp::TiledArgs p)
             ap[it] = p.A + phys * p.lda;
         }
     }
-    v4f ra[4], rb[2];
+    v4f ra[NA], rb[2];
     auto load_chunk = [&](int k0) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
+        for (int it = 0; it < NA; ++it) {
             const int q = (it * 256 + tid) & 7;
             v4f v = load4(ap[it] ? ap[it] + k0 + 4 * q : nullptr, p.K - (k0 + 4 * q), a_vec);
             if (p.a_div != 1.0f) { v.x = v.x / p.a_div; v.y = v.y / p.a_div; v.z = v.z / p.a_div; v.w = v.w / p.a_div; }
@@ -90,17 +94,19 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(amp::TiledArgs p)
             }
         }
     };
-    f32x16 acc[2];
+    f32x16 acc[RB][2];
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int a = 0; a < RB; ++a)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.0f;
 
     load_chunk(0);
     for (int k0 = 0; k0 < p.K; k0 += BK) {
         __syncthreads(); // previous chunk's fragment reads are done
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
+        for (int it = 0; it < NA; ++it) {
             const int t = it * 256 + tid;
             *reinterpret_cast<v4f *>(As + (t >> 3) * LDT + 4 * (t & 7)) = ra[it];
         }
@@ -119,40 +125,43 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(amp::TiledArgs p)
         }
         __syncthreads();
         if (k0 + BK < p.K) load_chunk(k0 + BK); // in flight under the MFMAs
-        const float *arow = As + (32 * wave + r31) * LDT + 16 * h;
+        const float *arow = As + (WM * wave + r31) * LDT + 16 * h;
         const float *brow = Bs + r31 * LDT + 16 * h;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const v4f a4 = *reinterpret_cast<const v4f *>(arow + 4 * q);
+            v4f a4[RB];
+#pragma unroll
+            for (int a = 0; a < RB; ++a) a4[a] = *reinterpret_cast<const v4f *>(arow + 32 * a * LDT + 4 * q);
             const v4f b0 = *reinterpret_cast<const v4f *>(brow + 4 * q);
             const v4f b1 = *reinterpret_cast<const v4f *>(brow + 32 * LDT + 4 * q);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b0.x, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b1.x, acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b0.y, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b1.y, acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b0.z, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b1.z, acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b0.w, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b1.w, acc[1], 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int a = 0; a < RB; ++a) {
+                    acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[a][e], b0[e], acc[a][0], 0, 0, 0);
+                    acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[a][e], b1[e], acc[a][1], 0, 0, 0);
+                }
         }
     }
     // epilogue straight from the accumulators (col = lane&31, row = (r&3) + 8*(r>>2) + 4*h)
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const int col = n0 + 32 * c + r31;
-        if (col >= p.N) continue;
-        const float bv = p.bias ? p.bias[col] : 0.0f;
+    for (int a = 0; a < RB; ++a)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t m = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (m < p.M) {
-                const int64_t phys = p.c_idx ? (int64_t)p.c_idx[m] : m;
-                float v = acc[c][r];
-                if (p.c_div != 1.0f) v = v / p.c_div;
-                p.C[phys * p.ldc + col] = act_rt(v + bv, p.act);
+        for (int c = 0; c < 2; ++c) {
+            const int col = n0 + 32 * c + r31;
+            if (col >= p.N) continue;
+            const float bv = p.bias ? p.bias[col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = m0 + WM * wave + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < p.M) {
+                    const int64_t phys = p.c_idx ? (int64_t)p.c_idx[m] : m;
+                    float v = acc[a][c][r];
+                    if (p.c_div != 1.0f) v = v / p.c_div;
+                    p.C[phys * p.ldc + col] = act_rt(v + bv, p.act);
+                }
             }
         }
-    }
 }
 
 // ---- C[i,o] = sum_m A[idx[m], i0+i] B[idx[m], o] / div : slab per (i-tile, split) ----------------
@@ -242,8 +251,13 @@ namespace amp {
 int gemm_tiled(const TiledArgs &p)
 {
     if (p.M <= 0 || p.N <= 0) return 0;
-    dim3 grid((unsigned)((p.M + BM - 1) / BM), (unsigned)((p.N + BN - 1) / BN));
-    hipLaunchKernelGGL(gemm_tiled_kernel, grid, dim3(256), 0, stream(), p);
+    const unsigned ny = (unsigned)((p.N + BN - 1) / BN);
+    // 256-row workgroup tiles once they still give >= 1.5 workgroups per CU; 128-row tiles otherwise
+    if ((p.M + 255) / 256 * ny >= 384) {
+        hipLaunchKernelGGL((gemm_tiled_kernel<64>), dim3((unsigned)((p.M + 255) / 256), ny), dim3(256), 0, stream(), p);
+    } else {
+        hipLaunchKernelGGL((gemm_tiled_kernel<32>), dim3((unsigned)((p.M + 127) / 128), ny), dim3(256), 0, stream(), p);
+    }
     AMP_LAUNCH_CHECK();
     return 0;
 }

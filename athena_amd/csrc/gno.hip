@@ -431,7 +431,7 @@ int tile_rows_for(int64_t n_rows, int64_t floats_per_row)
 {
     static const int64_t budget = [] {   // bytes of S / T / G per super-tile
         const char *e = getenv("ATHENA_MP_GNO_TILE_MB");
-        return (int64_t)(e ? atoi(e) : 1024) << 20;
+        return (int64_t)(e ? atoi(e) : 2048) << 20;
     }();
     int64_t t = budget / (4 * std::max<int64_t>(floats_per_row, 1));
     t = std::max<int64_t>(1, std::min<int64_t>(t, n_rows));
