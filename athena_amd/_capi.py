@@ -88,6 +88,13 @@ _PROTOS = {
     "athena_mp_duvenaud_update_fwd_host": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
     "athena_mp_duvenaud_update_bwd_a_host": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
     "athena_mp_duvenaud_update_bwd_w_host": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
+    "athena_mp_duvenaud_update_act_fwd_host": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp],
+    "athena_mp_duvenaud_readout_fwd_host": [_i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32],
+    "athena_mp_duvenaud_readout_bwd_host": [_i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32],
+    "athena_mp_softmax_fwd_host": [_i64, _i32, _vp, _vp],
+    "athena_mp_softmax_bwd_host": [_i64, _i32, _vp, _vp, _vp],
+    "athena_mp_swish_fwd_host": [_i64, _f32, _vp, _vp],
+    "athena_mp_swish_bwd_host": [_i64, _f32, _vp, _vp, _vp],
     "athena_mp_softmax_segsum_fwd_host": [_i32, _i64, _i32, _vp, _vp, _vp, _vp, _i32],
     "athena_mp_softmax_segsum_bwd_host": [_i32, _i64, _i32, _vp, _vp, _vp, _vp],
     "athena_mp_gno_aggregate_fwd_host": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],

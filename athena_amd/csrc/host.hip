@@ -212,4 +212,69 @@ int athena_mp_gno_aggregate_bwd_coords_host(const athena_mp_graph *g, int32_t d,
                   });
 }
 
+
+// ---- composites and shaped activations ---------------------------------------------------------------
+int athena_mp_duvenaud_update_act_fwd_host(const athena_mp_graph *g, int32_t Fi, int32_t Fo, int32_t mn, int32_t mx,
+                                           const float *a, const float *w, int32_t act, float *z)
+{
+    AMP_REQUIRE(g && a && w && z && Fi > 0 && Fo > 0 && mx >= mn, "duvenaud_update_act_fwd_host: bad arguments");
+    const int64_t N = g->n_rows;
+    return staged({{a, nullptr, fb(N, Fi)}, {w, nullptr, fb((int64_t)Fi * Fo, mx - mn + 1)}, {nullptr, z, fb(N, Fo)}},
+                  [&](std::vector<void *> &d) {
+                      return athena_mp_duvenaud_update_act_fwd(g, Fi, Fo, mn, mx, (float *)d[0], (float *)d[1], act, (float *)d[2]);
+                  });
+}
+int athena_mp_duvenaud_readout_fwd_host(int64_t N, int32_t Fv, int32_t O, int32_t S, const int32_t *seg, const float *z,
+                                        const float *R, float *p, float *out, int32_t accumulate)
+{
+    AMP_REQUIRE(N >= 0 && Fv > 0 && O > 0 && S >= 0 && seg && z && R && p && out, "duvenaud_readout_fwd_host: bad arguments");
+    return staged({{seg, nullptr, sizeof(int32_t) * (size_t)(S + 1)}, {z, nullptr, fb(N, Fv)}, {R, nullptr, fb(O, Fv)},
+                   {nullptr, p, fb(N, O)}, {accumulate ? out : nullptr, out, fb(S, O)}},
+                  [&](std::vector<void *> &d) {
+                      return athena_mp_duvenaud_readout_fwd(N, Fv, O, S, (int32_t *)d[0], (float *)d[1], (float *)d[2],
+                                                            (float *)d[3], (float *)d[4], accumulate);
+                  });
+}
+int athena_mp_duvenaud_readout_bwd_host(int64_t N, int32_t Fv, int32_t O, int32_t S, const int32_t *seg, const float *z,
+                                        const float *R, const float *p, const float *gout, const float *dz_next,
+                                        int32_t act, float *dc, float *dR, int32_t accumulate)
+{
+    AMP_REQUIRE(N >= 0 && Fv > 0 && O > 0 && S > 0 && seg && z && R && p && gout && dc && dR,
+                "duvenaud_readout_bwd_host: bad arguments");
+    return staged({{seg, nullptr, sizeof(int32_t) * (size_t)(S + 1)}, {z, nullptr, fb(N, Fv)}, {R, nullptr, fb(O, Fv)},
+                   {p, nullptr, fb(N, O)}, {gout, nullptr, fb(S, O)}, {dz_next, nullptr, dz_next ? fb(N, Fv) : 0},
+                   {nullptr, dc, fb(N, Fv)}, {accumulate ? dR : nullptr, dR, fb(O, Fv)}},
+                  [&](std::vector<void *> &d) {
+                      return athena_mp_duvenaud_readout_bwd(N, Fv, O, S, (int32_t *)d[0], (float *)d[1], (float *)d[2],
+                                                            (float *)d[3], (float *)d[4], dz_next ? (float *)d[5] : nullptr,
+                                                            act, (float *)d[6], (float *)d[7], accumulate);
+                  });
+}
+int athena_mp_softmax_fwd_host(int64_t N, int32_t F, const float *z, float *y)
+{
+    AMP_REQUIRE(N >= 0 && F > 0 && (N == 0 || (z && y)), "softmax_fwd_host: bad arguments");
+    return staged({{z, nullptr, fb(N, F)}, {nullptr, y, fb(N, F)}},
+                  [&](std::vector<void *> &d) { return athena_mp_softmax_fwd(N, F, (float *)d[0], (float *)d[1]); });
+}
+int athena_mp_softmax_bwd_host(int64_t N, int32_t F, const float *y, const float *g, float *dz)
+{
+    AMP_REQUIRE(N >= 0 && F > 0 && (N == 0 || (y && g && dz)), "softmax_bwd_host: bad arguments");
+    return staged({{y, nullptr, fb(N, F)}, {g, nullptr, fb(N, F)}, {nullptr, dz, fb(N, F)}}, [&](std::vector<void *> &d) {
+        return athena_mp_softmax_bwd(N, F, (float *)d[0], (float *)d[1], (float *)d[2]);
+    });
+}
+int athena_mp_swish_fwd_host(int64_t n, float beta, const float *x, float *y)
+{
+    AMP_REQUIRE(n >= 0 && (n == 0 || (x && y)), "swish_fwd_host: bad arguments");
+    return staged({{x, nullptr, fb(n, 1)}, {nullptr, y, fb(n, 1)}},
+                  [&](std::vector<void *> &d) { return athena_mp_swish_fwd(n, beta, (float *)d[0], (float *)d[1]); });
+}
+int athena_mp_swish_bwd_host(int64_t n, float beta, const float *x, const float *g, float *dx)
+{
+    AMP_REQUIRE(n >= 0 && (n == 0 || (x && g && dx)), "swish_bwd_host: bad arguments");
+    return staged({{x, nullptr, fb(n, 1)}, {g, nullptr, fb(n, 1)}, {nullptr, dx, fb(n, 1)}}, [&](std::vector<void *> &d) {
+        return athena_mp_swish_bwd(n, beta, (float *)d[0], (float *)d[1], (float *)d[2]);
+    });
+}
+
 } // extern "C"

@@ -251,6 +251,15 @@ int athena_mp_gno_aggregate_bwd_x_host(const athena_mp_graph *g, int32_t d, int3
 int athena_mp_gno_aggregate_bwd_theta_host(const athena_mp_graph *g, int32_t d, int32_t H, int32_t Fi, int32_t Fo, const float *theta, const float *coords, const float *x, const float *grad, float *dtheta);
 int athena_mp_gno_aggregate_bwd_coords_host(const athena_mp_graph *g, int32_t d, int32_t H, int32_t Fi, int32_t Fo, const float *theta, const float *coords, const float *x, const float *grad, float *dcoords);
 
+/* host-pointer variants of the composites and shaped activations */
+int athena_mp_duvenaud_update_act_fwd_host(const athena_mp_graph *g, int32_t Fi, int32_t Fo, int32_t mn, int32_t mx, const float *a, const float *w, int32_t act, float *z);
+int athena_mp_duvenaud_readout_fwd_host(int64_t N, int32_t Fv, int32_t O, int32_t S, const int32_t *seg, const float *z, const float *R, float *p, float *out, int32_t accumulate);
+int athena_mp_duvenaud_readout_bwd_host(int64_t N, int32_t Fv, int32_t O, int32_t S, const int32_t *seg, const float *z, const float *R, const float *p, const float *gout, const float *dz_next, int32_t act, float *dc, float *dR, int32_t accumulate);
+int athena_mp_softmax_fwd_host(int64_t N, int32_t F, const float *z, float *y);
+int athena_mp_softmax_bwd_host(int64_t N, int32_t F, const float *y, const float *g, float *dz);
+int athena_mp_swish_fwd_host(int64_t n, float beta, const float *x, float *y);
+int athena_mp_swish_bwd_host(int64_t n, float beta, const float *x, const float *g, float *dx);
+
 #ifdef __cplusplus
 }
 #endif

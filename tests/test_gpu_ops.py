@@ -428,6 +428,27 @@ def test_host_pointer_variants(dev, oracle):
     p = np.empty_like(u); out = np.empty((2, 4), np.float32)
     _capi.call("athena_mp_softmax_segsum_fwd_host", 4, 5, 2, P_(seg), P_(u), P_(p), P_(out), 0)
     assert_close(out, oracle.segment_sum(oracle.softmax_cols(u), seg), 1e-5)
+    # Duvenaud composites and shaped activations through host arrays
+    z = np.empty((5, 4), np.float32)
+    _capi.call("athena_mp_duvenaud_update_act_fwd_host", dg.handle, 10, 4, 2, 4, P_(c), P_(w), 2, P_(z))
+    assert_close(z, oracle.activation("sigmoid", oracle.duvenaud_update(c, w, g.adj_ia, 2, 4, 4)), 1e-6)
+    R = np.random.default_rng(2).standard_normal(3 * 4).astype(np.float32)
+    pr = np.empty((5, 3), np.float32); ro = np.empty((2, 3), np.float32)
+    _capi.call("athena_mp_duvenaud_readout_fwd_host", 5, 4, 3, 2, P_(seg), P_(z), P_(R), P_(pr), P_(ro), 0)
+    po = oracle.softmax_cols(oracle.matmul(R, z, 3))
+    assert_close(pr, po, 1e-6); assert_close(ro, oracle.segment_sum(po, seg), 1e-6)
+    go = np.random.default_rng(3).standard_normal((2, 3)).astype(np.float32)
+    dcc = np.empty((5, 4), np.float32); dRR = np.empty(12, np.float32)
+    _capi.call("athena_mp_duvenaud_readout_bwd_host", 5, 4, 3, 2, P_(seg), P_(z), P_(R), P_(po), P_(go), None, 2, P_(dcc), P_(dRR), 0)
+    dl = oracle.softmax_cols_bwd(po, np.repeat(go, [2, 3], axis=0))
+    assert_close(dcc, oracle.activation_bwd("sigmoid", z, oracle.matmul_dx(R, dl, 4)), 1e-5)
+    assert_close(dRR, oracle.matmul_dw(dl, z), 1e-5)
+    sm = np.empty_like(u)
+    _capi.call("athena_mp_softmax_fwd_host", 5, 4, P_(u), P_(sm))
+    assert_close(sm, oracle.softmax_cols(u), 1e-6)
+    sw = np.empty_like(u)
+    _capi.call("athena_mp_swish_fwd_host", u.size, 1.0, P_(u), P_(sw))
+    assert_close(sw, oracle.swish(u), 1e-6)
     # GNO through host arrays
     gg, E, coords, xx, theta, upg = _gno_case(5, 30, 3, 8, 4, 6, 20)
     d2 = DeviceGraph(gg.adj_ia, gg.adj_ja, n_edge_cols=E)
