@@ -174,3 +174,50 @@ def test_c4_gno_properties_full_size(dev, oracle):
     offV = H * d + H
     assert abs(lhs - (theta[offV:].double() * dth[offV:].double()).sum().item()) <= 1e-5 * scale
     assert torch.isfinite(dth).all()
+
+
+def test_tensors_beyond_2_31_elements_use_64_bit_offsets(dev, oracle):
+    """a BASELINE configs[4]-shaped tensor on ONE GPU: 9 M vertices x 256 features = 2.3e9 elements per
+    tensor (> 2^31), so every row offset in the aggregation, the tiled GEMMs and the dW reduction has to be
+    64-bit.  Sparse on purpose (2 pairs per vertex): the point is addressing, checked on sampled rows that
+    include the last ones (the highest offsets) against the oracle on the compacted sub-problem."""
+    from athena_amd import DeviceGraph, ops, synth
+
+    N, F = 9_000_000, 256
+    assert N * F > 2 ** 31
+    ia, ja = synth.random_graph_csr(N, 2 * N)
+    g = DeviceGraph(ia, ja, n_edge_cols=0)
+    gen = torch.Generator(device=dev).manual_seed(5)
+    x = torch.rand((N, F), device=dev, generator=gen) * 2 - 1
+    rows = np.unique(np.concatenate([np.random.default_rng(1).choice(N, 3000, replace=False), np.arange(N - 40, N), np.arange(40)]))
+    sia, sja = _sub_csr(ia, ja, rows)
+    cols = np.unique(sja[0]) - 1                                   # compact the neighbour set
+    remap = np.searchsorted(cols, sja[0] - 1) + 1
+    sja_c = np.asfortranarray(np.stack([remap, np.zeros_like(remap)]).astype(np.int32))
+    deg = np.diff(ia).astype(np.int32)
+    xs = x[torch.from_numpy(cols).to(dev)].cpu().numpy()
+    rsel = torch.from_numpy(rows).to(dev)
+    # aggregation forward, bit exact
+    y = ops.kipf_propagate(g, x)
+    assert np.array_equal(y[rsel].cpu().numpy(), oracle.kipf_propagate_rect(xs, sia, sja_c, deg[rows], deg[cols]))
+    # dense step through the tiled MFMA kernel and its dx, on the same sampled rows
+    w = torch.from_numpy((np.random.default_rng(2).standard_normal(F * F) * 0.06).astype(np.float32)).to(dev)
+    z = ops.matmul(w, y, F)
+    ys = y[rsel].cpu().numpy()
+    ref = oracle.matmul(w.cpu().numpy(), ys, F)
+    assert np.abs(z[rsel].cpu().numpy() - ref).max() <= 1e-5 * np.abs(ref).max()
+    dp = ops.matmul_dx(w, y, F)
+    ref = oracle.matmul_dx(w.cpu().numpy(), ys, F)
+    assert np.abs(dp[rsel].cpu().numpy() - ref).max() <= 1e-5 * np.abs(ref).max()
+    del z, dp
+    # dW over all 9 M rows vs float64 on the device
+    dz = torch.rand((N, 64), device=dev, generator=gen) - 0.5
+    dw = ops.matmul_dw(y[:, :64].contiguous(), dz)                  # 64 x 64 reduction over 9 M rows
+    ref = (y[:, :64].double().T @ dz.double()).reshape(-1)
+    assert (dw.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    # backward aggregation: coefficient-free scatter conserves mass per feature column
+    del dz, dw
+    dx = ops.kipf_propagate_bwd(g, x)
+    degd = torch.from_numpy(np.diff(ia).astype(np.float64)).to(dev)
+    a = dx[:, :8].double().sum(0); b = (x[:, :8].double() * degd[:, None]).sum(0)
+    assert torch.allclose(a, b, rtol=1e-6, atol=1e-6 * b.abs().max().item())
