@@ -214,6 +214,38 @@ int athena_mp_graph_dims(const athena_mp_graph *g, int32_t *n_rows, int32_t *n_c
     return 0;
 }
 
+int athena_mp_graph_export(const athena_mp_graph *g, int32_t which, void *host_dst, int64_t capacity,
+                           int64_t *count)
+{
+    AMP_REQUIRE(g && count, "graph_export: null argument");
+    const void *src = nullptr;
+    int64_t n = 0;
+    switch (which) {
+    case 0: src = g->rowptr; n = (int64_t)g->n_rows + 1; break;
+    case 1: src = g->col; n = g->nnz; break;
+    case 2: src = g->eid; n = g->nnz; break;
+    case 3: src = g->coef; n = g->nnz; break;
+    case 4: src = g->t_rowptr; n = (int64_t)g->n_cols + 1; break;
+    case 5: src = g->t_src; n = g->nnz; break;
+    case 6: src = g->t_eid; n = g->nnz; break;
+    case 7: src = g->t_coef; n = g->nnz; break;
+    case 8: src = g->e_rowptr; n = (int64_t)g->n_edge_cols + 1; break;
+    case 9: src = g->e_row; n = g->n_with_edge; break;
+    case 10: src = g->e_col; n = g->n_with_edge; break;
+    case 11: src = g->deg_row; n = g->n_rows; break;
+    case 12: src = g->deg_col; n = g->n_cols; break;
+    default: AMP_REQUIRE(false, "graph_export: unknown array id %d", which);
+    }
+    *count = n;
+    if (host_dst == nullptr) return 0;   // size query
+    AMP_REQUIRE(capacity >= n, "graph_export: buffer holds %lld elements, array has %lld", (long long)capacity, (long long)n);
+    if (n > 0) {
+        AMP_HIP(hipMemcpyAsync(host_dst, src, 4 * (size_t)n, hipMemcpyDeviceToHost, g_stream));
+        AMP_HIP(hipStreamSynchronize(g_stream));
+    }
+    return 0;
+}
+
 int athena_mp_graph_create(int32_t n_rows, int32_t n_cols, int64_t nnz, const int32_t *adj_ia,
                            const int32_t *adj_ja, int32_t n_edge_cols, const int32_t *row_deg,
                            const int32_t *col_deg, athena_mp_graph **out)
@@ -242,6 +274,45 @@ int athena_mp_graph_create(int32_t n_rows, int32_t n_cols, int64_t nnz, const in
     }
     rowptr[n_rows] = (int32_t)nnz;
     for (int32_t u = 0; u < n_cols; ++u) degc[u] = col_deg ? col_deg[u] : degr[u];
+
+    // Large graphs are built on the device (graph_build.hip): one upload of the caller's arrays, radix sorts
+    // in HBM.  Small ones (mini-batches: ~0.1 ms on the host) and graphs with too many distinct degrees for
+    // the coefficient table take the host builder below.  ATHENA_MP_GRAPH_BUILD=host|device pins the choice
+    // (tests build both and compare every array).
+    {
+        const char *mode = getenv("ATHENA_MP_GRAPH_BUILD");
+        const bool want_device = mode ? (strcmp(mode, "device") == 0) : (nnz >= ((int64_t)1 << 18));
+        if (want_device && !(mode && strcmp(mode, "host") == 0)) {
+            athena_mp_graph *g = new athena_mp_graph();
+            g->n_rows = n_rows;
+            g->n_cols = n_cols;
+            g->nnz = nnz;
+            g->n_edge_cols = n_edge_cols;
+            g->max_row_len = max_row;
+            std::vector<int32_t> t_rowptr_h;
+            int rc = amp::graph_build_device(g, adj_ja, rowptr, degr, degc, &t_rowptr_h);
+            if (rc == 0) {
+                int32_t max_col = 0;
+                for (int32_t u = 0; u < n_cols; ++u) max_col = std::max(max_col, t_rowptr_h[u + 1] - t_rowptr_h[u]);
+                g->max_col_len = max_col;
+                g->h_deg_row = degr;
+                rc = build_long_plan(rowptr, n_rows, &g->lp_fwd) | build_long_plan(t_rowptr_h, n_cols, &g->lp_bwd);
+                if (rc == 0 && hipStreamSynchronize(stream()) == hipSuccess) {
+                    *out = g;
+                    return 0;
+                }
+                if (g_err[0] == 0) set_error("graph_create: device allocation failed");
+                athena_mp_graph_destroy(g);
+                return 1;
+            }
+            athena_mp_graph_destroy(g);
+            if (rc > 0) {
+                if (g_err[0] == 0) set_error("graph_create: device build failed");
+                return rc;
+            }
+            // rc < 0: not applicable -> host builder
+        }
+    }
 
     // transposed CSR + edge-column index by stable counting sort (entry order w preserved, so each
     // transposed row lists its sources in ascending v: the reference's accumulation order,

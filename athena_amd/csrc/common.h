@@ -90,6 +90,10 @@ struct athena_mp_graph {
 };
 
 namespace amp {
+// device-side construction of the handle arrays (graph_build.hip); -1 = use the host builder
+int graph_build_device(athena_mp_graph *g, const int32_t *adj_ja, const std::vector<int32_t> &rowptr,
+                       const std::vector<int32_t> &degr, const std::vector<int32_t> &degc,
+                       std::vector<int32_t> *t_rowptr_host);
 int agg_blocks_cap();
 void set_agg_blocks_cap(int n);
 // shared launchers (defined in agg.hip / gemm.hip)

@@ -1,0 +1,283 @@
+// Device-side construction of the graph handle: everything athena_mp_graph_create derives
+// from the caller's CSR -- 0-based CSR, per-entry Kipf coefficient, transposed CSR, edge-column index --
+// built in HBM from one upload of adj_ia / adj_ja, for callers whose graphs change between forward passes
+// (set_graph runs before every forward, athena_network_sub.f90:2727-2730; radius graphs of moving points).
+//
+// It produces exactly the arrays of the host builder in capi.hip (tests compare them element for element):
+//   * transposed rows list their sources in ascending row order = a STABLE sort of the entries by column
+//     (hipcub radix sort of (column, entry index) pairs), the reference's scatter order
+//     (athena_diffstruc_extd_sub_kipf.f90:101-109);
+//   * the edge-column index is the stable sort of the entries that carry an edge id by that id;
+//   * the coefficient (deg_v*deg_u)**(-0.5) stays a HOST libm powf -- a device pow is 1 ulp off glibc for
+//     ~0.06 % of the integer products -- but is evaluated once per pair of DISTINCT degrees into a small
+//     table that the device indexes through degree ranks.
+#include <math.h>
+
+#include <algorithm>
+#include <hipcub/hipcub.hpp>
+
+#include "common.h"
+
+namespace {
+
+struct BadEntry {
+    unsigned long long first_bad;   // smallest offending entry index, ~0 if none
+};
+
+__global__ void split_kernel(int64_t nnz, const int32_t *__restrict__ ja, int32_t n_cols, int32_t n_edge_cols,
+                             int32_t *__restrict__ col, int32_t *__restrict__ eid, int32_t *__restrict__ ekey,
+                             int32_t *__restrict__ iota, BadEntry *__restrict__ bad)
+{
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nnz) return;
+    const int32_t u = ja[2 * w] - 1, e = ja[2 * w + 1] - 1;
+    if (u < 0 || u >= n_cols || e < -1 || e >= n_edge_cols) atomicMin(&bad->first_bad, (unsigned long long)w);
+    col[w] = u;
+    eid[w] = e;
+    if (ekey) ekey[w] = e + 1;   // 0 = carries no edge id: sorts in front
+    iota[w] = (int32_t)w;
+}
+
+// row of every entry: binary search of the entry index in rowptr (upper bound - 1)
+__global__ void row_of_kernel(int64_t nnz, int32_t n_rows, const int32_t *__restrict__ rowptr,
+                              int32_t *__restrict__ row_of)
+{
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nnz) return;
+    int lo = 0, hi = n_rows;   // rowptr[lo] <= w < rowptr[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (rowptr[mid] <= (int32_t)w) lo = mid; else hi = mid;
+    }
+    row_of[w] = lo;
+}
+
+__global__ void coef_kernel(int64_t nnz, const int32_t *__restrict__ row_of, const int32_t *__restrict__ col,
+                            const int32_t *__restrict__ deg_row, const int32_t *__restrict__ deg_col,
+                            const int32_t *__restrict__ rank_r, const int32_t *__restrict__ rank_c, int Kc,
+                            const float *__restrict__ table, float *__restrict__ coef)
+{
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nnz) return;
+    coef[w] = table[(size_t)rank_r[deg_row[row_of[w]]] * Kc + rank_c[deg_col[col[w]]]];
+}
+
+// transposed arrays from the stable (column, entry) sort
+__global__ void gather_t_kernel(int64_t nnz, const int32_t *__restrict__ perm, const int32_t *__restrict__ row_of,
+                                const int32_t *__restrict__ eid, const float *__restrict__ coef,
+                                int32_t *__restrict__ t_src, int32_t *__restrict__ t_eid, float *__restrict__ t_coef)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nnz) return;
+    const int32_t w = perm[p];
+    t_src[p] = row_of[w];
+    t_eid[p] = eid[w];
+    t_coef[p] = coef[w];
+}
+
+// ptr[k] = first position whose sorted key is >= k + key0  (k = 0 .. n), minus `shift`
+__global__ void lower_bound_kernel(int32_t n, const int32_t *__restrict__ sorted, int64_t nnz, int32_t key0,
+                                   int32_t shift, int32_t *__restrict__ ptr)
+{
+    const int32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > n) return;
+    const int32_t key = k + key0;
+    int64_t lo = 0, hi = nnz;   // first index with sorted[idx] >= key
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (sorted[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    ptr[k] = (int32_t)lo - shift;
+}
+
+__global__ void gather_e_kernel(int64_t n_with, int64_t n_none, const int32_t *__restrict__ perm,
+                                const int32_t *__restrict__ row_of, int32_t *__restrict__ e_row,
+                                int32_t *__restrict__ e_col)
+{
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_with) return;
+    const int32_t w = perm[n_none + q];
+    e_col[q] = w;
+    e_row[q] = row_of[w];
+}
+
+inline unsigned blocks(int64_t n) { return (unsigned)((n + 255) / 256); }
+inline int bits_for(int64_t max_value)
+{
+    int b = 1;
+    while (b < 31 && ((int64_t)1 << b) <= max_value) ++b;
+    return b;
+}
+
+template <typename T> int dev_alloc(T **p, size_t count)
+{
+    AMP_HIP(hipMalloc((void **)p, sizeof(T) * (count ? count : 1)));
+    return 0;
+}
+
+struct Scratch {   // freed on every exit path
+    std::vector<void *> ptrs;
+    template <typename T> int get(T **p, size_t count)
+    {
+        if (dev_alloc(p, count)) return 1;
+        ptrs.push_back(*p);
+        return 0;
+    }
+    ~Scratch()
+    {
+        for (void *p : ptrs) (void)hipFree(p);
+    }
+};
+
+} // namespace
+
+namespace amp {
+
+// returns 0 ok, -1 "use the host builder" (too many distinct degrees for the coefficient table), > 0 error.
+// On success every device array of g except the long-row plans is filled; t_rowptr_host receives the
+// transposed row pointers (the caller plans hub rows from them).
+int graph_build_device(athena_mp_graph *g, const int32_t *adj_ja, const std::vector<int32_t> &rowptr,
+                       const std::vector<int32_t> &degr, const std::vector<int32_t> &degc,
+                       std::vector<int32_t> *t_rowptr_host)
+{
+    const int32_t n_rows = g->n_rows, n_cols = g->n_cols, n_edge_cols = g->n_edge_cols;
+    const int64_t nnz = g->nnz;
+    hipStream_t st = stream();
+
+    // ---- coefficient table over distinct degrees (host powf, bit-identical to the reference's) ----------
+    auto distinct = [](const std::vector<int32_t> &d, std::vector<int32_t> *uniq, std::vector<int32_t> *rank) {
+        int32_t mx = 0;
+        for (int32_t v : d) mx = std::max(mx, v);
+        std::vector<char> seen((size_t)mx + 1, 0);
+        for (int32_t v : d) seen[v < 0 ? 0 : v] = 1;
+        rank->assign((size_t)mx + 1, 0);
+        for (int32_t v = 0; v <= mx; ++v)
+            if (seen[v]) {
+                (*rank)[v] = (int32_t)uniq->size();
+                uniq->push_back(v);
+            }
+    };
+    for (int32_t v : degr)
+        if (v < 0) return -1;
+    for (int32_t v : degc)
+        if (v < 0) return -1;
+    std::vector<int32_t> uniq_r, uniq_c, rank_r, rank_c;
+    distinct(degr, &uniq_r, &rank_r);
+    distinct(degc, &uniq_c, &rank_c);
+    const size_t Kr = uniq_r.size(), Kc = uniq_c.size();
+    if (Kr * Kc > ((size_t)1 << 22)) return -1;
+    std::vector<float> table(Kr * Kc ? Kr * Kc : 1);
+    for (size_t a = 0; a < Kr; ++a)
+        for (size_t b = 0; b < Kc; ++b) table[a * Kc + b] = powf((float)(uniq_r[a] * uniq_c[b]), -0.5f);
+
+    Scratch tmp;
+    int32_t *d_ja = nullptr, *d_row_of = nullptr, *d_iota = nullptr, *d_perm = nullptr, *d_keys_sorted = nullptr,
+            *d_ekey = nullptr, *d_rank_r = nullptr, *d_rank_c = nullptr;
+    float *d_table = nullptr;
+    BadEntry *d_bad = nullptr;
+    if (tmp.get(&d_ja, 2 * (size_t)nnz) || tmp.get(&d_row_of, nnz) || tmp.get(&d_iota, nnz) || tmp.get(&d_perm, nnz) ||
+        tmp.get(&d_keys_sorted, nnz) || tmp.get(&d_rank_r, rank_r.size()) || tmp.get(&d_rank_c, rank_c.size()) ||
+        tmp.get(&d_table, table.size()) || tmp.get(&d_bad, 1))
+        return 1;
+    if (n_edge_cols > 0 && tmp.get(&d_ekey, nnz)) return 1;
+
+    if (dev_alloc(&g->rowptr, rowptr.size()) || dev_alloc(&g->col, nnz) || dev_alloc(&g->eid, nnz) ||
+        dev_alloc(&g->coef, nnz) || dev_alloc(&g->t_rowptr, (size_t)n_cols + 1) || dev_alloc(&g->t_src, nnz) ||
+        dev_alloc(&g->t_eid, nnz) || dev_alloc(&g->t_coef, nnz) || dev_alloc(&g->e_rowptr, (size_t)n_edge_cols + 1) ||
+        dev_alloc(&g->deg_row, degr.size()) || dev_alloc(&g->deg_col, degc.size()))
+        return 1;
+
+    const BadEntry none = {~0ull};
+    AMP_HIP(hipMemcpyAsync(d_bad, &none, sizeof(none), hipMemcpyHostToDevice, st));
+    AMP_HIP(hipMemcpyAsync(d_ja, adj_ja, sizeof(int32_t) * 2 * (size_t)nnz, hipMemcpyHostToDevice, st));
+    AMP_HIP(hipMemcpyAsync(g->rowptr, rowptr.data(), sizeof(int32_t) * rowptr.size(), hipMemcpyHostToDevice, st));
+    if (!degr.empty()) AMP_HIP(hipMemcpyAsync(g->deg_row, degr.data(), sizeof(int32_t) * degr.size(), hipMemcpyHostToDevice, st));
+    if (!degc.empty()) AMP_HIP(hipMemcpyAsync(g->deg_col, degc.data(), sizeof(int32_t) * degc.size(), hipMemcpyHostToDevice, st));
+    AMP_HIP(hipMemcpyAsync(d_rank_r, rank_r.data(), sizeof(int32_t) * rank_r.size(), hipMemcpyHostToDevice, st));
+    AMP_HIP(hipMemcpyAsync(d_rank_c, rank_c.data(), sizeof(int32_t) * rank_c.size(), hipMemcpyHostToDevice, st));
+    AMP_HIP(hipMemcpyAsync(d_table, table.data(), sizeof(float) * table.size(), hipMemcpyHostToDevice, st));
+
+    if (nnz > 0) {
+        hipLaunchKernelGGL(split_kernel, dim3(blocks(nnz)), dim3(256), 0, st, nnz, (const int32_t *)d_ja, n_cols,
+                           n_edge_cols, g->col, g->eid, d_ekey, d_iota, d_bad);
+        hipLaunchKernelGGL(row_of_kernel, dim3(blocks(nnz)), dim3(256), 0, st, nnz, n_rows, (const int32_t *)g->rowptr,
+                           d_row_of);
+        AMP_LAUNCH_CHECK();
+        BadEntry bad;
+        AMP_HIP(hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, st));
+        AMP_HIP(hipStreamSynchronize(st));
+        if (bad.first_bad != ~0ull) {   // same messages as the host builder
+            const int64_t w = (int64_t)bad.first_bad;
+            const int32_t u = adj_ja[2 * w] - 1, e = adj_ja[2 * w + 1] - 1;
+            if (u < 0 || u >= n_cols)
+                set_error("graph_create: adj_ja(1,%lld) = %d outside [1,%d]", (long long)w + 1, u + 1, n_cols);
+            else
+                set_error("graph_create: adj_ja(2,%lld) = %d outside [0,%d]", (long long)w + 1, e + 1, n_edge_cols);
+            return 2;
+        }
+        hipLaunchKernelGGL(coef_kernel, dim3(blocks(nnz)), dim3(256), 0, st, nnz, (const int32_t *)d_row_of,
+                           (const int32_t *)g->col, (const int32_t *)g->deg_row, (const int32_t *)g->deg_col,
+                           (const int32_t *)d_rank_r, (const int32_t *)d_rank_c, (int)Kc, (const float *)d_table, g->coef);
+        AMP_LAUNCH_CHECK();
+    }
+
+    // ---- transposed CSR: stable radix sort of (column, entry index) -------------------------------------
+    size_t temp_bytes = 0;
+    void *d_temp = nullptr;
+    const int col_bits = bits_for(std::max<int64_t>(n_cols - 1, 1));
+    if (nnz > 0) {
+        AMP_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, (const int32_t *)g->col, d_keys_sorted,
+                                                   (const int32_t *)d_iota, d_perm, (int)nnz, 0, col_bits, st));
+        size_t e_bytes = 0;
+        if (n_edge_cols > 0)
+            AMP_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, e_bytes, (const int32_t *)d_ekey, d_keys_sorted,
+                                                       (const int32_t *)d_iota, d_perm, (int)nnz, 0,
+                                                       bits_for(n_edge_cols), st));
+        temp_bytes = std::max(temp_bytes, e_bytes);
+        if (tmp.get((char **)&d_temp, temp_bytes)) return 1;
+        AMP_HIP(hipcub::DeviceRadixSort::SortPairs(d_temp, temp_bytes, (const int32_t *)g->col, d_keys_sorted,
+                                                   (const int32_t *)d_iota, d_perm, (int)nnz, 0, col_bits, st));
+        hipLaunchKernelGGL(gather_t_kernel, dim3(blocks(nnz)), dim3(256), 0, st, nnz, (const int32_t *)d_perm,
+                           (const int32_t *)d_row_of, (const int32_t *)g->eid, (const float *)g->coef, g->t_src, g->t_eid,
+                           g->t_coef);
+        AMP_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(lower_bound_kernel, dim3(blocks((int64_t)n_cols + 1)), dim3(256), 0, st, n_cols,
+                       (const int32_t *)d_keys_sorted, nnz, 0, 0, g->t_rowptr);
+    AMP_LAUNCH_CHECK();
+    t_rowptr_host->resize((size_t)n_cols + 1);
+    AMP_HIP(hipMemcpyAsync(t_rowptr_host->data(), g->t_rowptr, sizeof(int32_t) * ((size_t)n_cols + 1),
+                           hipMemcpyDeviceToHost, st));
+
+    // ---- edge-column index: stable sort of the entries by edge id, entries without one in front --------
+    int64_t n_with = 0;
+    if (n_edge_cols > 0 && nnz > 0) {
+        AMP_HIP(hipcub::DeviceRadixSort::SortPairs(d_temp, temp_bytes, (const int32_t *)d_ekey, d_keys_sorted,
+                                                   (const int32_t *)d_iota, d_perm, (int)nnz, 0, bits_for(n_edge_cols), st));
+        // e_rowptr[e] = lower_bound(key >= e + 1) - n_none; computed in two steps: first the raw positions
+        hipLaunchKernelGGL(lower_bound_kernel, dim3(blocks((int64_t)n_edge_cols + 1)), dim3(256), 0, st, n_edge_cols,
+                           (const int32_t *)d_keys_sorted, nnz, 1, 0, g->e_rowptr);
+        AMP_LAUNCH_CHECK();
+        int32_t n_none = 0;
+        AMP_HIP(hipMemcpyAsync(&n_none, g->e_rowptr, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        AMP_HIP(hipStreamSynchronize(st));
+        n_with = nnz - n_none;
+        hipLaunchKernelGGL(lower_bound_kernel, dim3(blocks((int64_t)n_edge_cols + 1)), dim3(256), 0, st, n_edge_cols,
+                           (const int32_t *)d_keys_sorted, nnz, 1, n_none, g->e_rowptr);
+        AMP_LAUNCH_CHECK();
+        if (dev_alloc(&g->e_row, n_with) || dev_alloc(&g->e_col, n_with)) return 1;
+        if (n_with > 0) {
+            hipLaunchKernelGGL(gather_e_kernel, dim3(blocks(n_with)), dim3(256), 0, st, n_with, (int64_t)n_none,
+                               (const int32_t *)d_perm, (const int32_t *)d_row_of, g->e_row, g->e_col);
+            AMP_LAUNCH_CHECK();
+        }
+    } else {
+        AMP_HIP(hipMemsetAsync(g->e_rowptr, 0, sizeof(int32_t) * ((size_t)n_edge_cols + 1), st));
+        if (dev_alloc(&g->e_row, 0) || dev_alloc(&g->e_col, 0)) return 1;
+    }
+    g->n_with_edge = n_with;
+    AMP_HIP(hipStreamSynchronize(st));   // host inputs and scratch die with this scope
+    return 0;
+}
+
+} // namespace amp

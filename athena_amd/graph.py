@@ -135,6 +135,20 @@ class DeviceGraph:
             cd.ctypes.data_as(C.c_void_p) if cd is not None else None, C.byref(h))
         self.handle = h
 
+    _ARRAYS = {"rowptr": (0, np.int32), "col": (1, np.int32), "eid": (2, np.int32), "coef": (3, np.float32),
+               "t_rowptr": (4, np.int32), "t_src": (5, np.int32), "t_eid": (6, np.int32), "t_coef": (7, np.float32),
+               "e_rowptr": (8, np.int32), "e_row": (9, np.int32), "e_entry": (10, np.int32),
+               "deg_row": (11, np.int32), "deg_col": (12, np.int32)}
+
+    def export(self, name):
+        """one array of the device handle as numpy (0-based indices)"""
+        which, dt = self._ARRAYS[name]
+        n = C.c_int64()
+        _capi.call("athena_mp_graph_export", self.handle, which, None, 0, C.byref(n))
+        out = np.empty(n.value, dt)
+        _capi.call("athena_mp_graph_export", self.handle, which, out.ctypes.data_as(C.c_void_p), n.value, C.byref(n))
+        return out
+
     @classmethod
     def from_graph(cls, g, device=0):
         return cls(g.adj_ia, g.adj_ja, n_edge_cols=max(g.num_edges, int(g.adj_ja[1].max()) if g.nnz else 0),

@@ -72,6 +72,12 @@ int athena_mp_memset_zero(void *dev_ptr, uint64_t bytes);
 int athena_mp_graph_create(int32_t n_rows, int32_t n_cols, int64_t nnz, const int32_t *adj_ia,
                            const int32_t *adj_ja, int32_t n_edge_cols, const int32_t *row_deg,
                            const int32_t *col_deg, athena_mp_graph **out);
+/* Copies one array of the handle back to the host (4-byte elements; 0-based indices): which =
+ * 0 rowptr, 1 col, 2 eid, 3 coef, 4 t_rowptr, 5 t_src, 6 t_eid, 7 t_coef (transposed CSR: the pull form of the
+ * reference's scatters), 8 e_rowptr, 9 e_row, 10 e_entry (edge-column index), 11 deg_row, 12 deg_col.
+ * host_dst NULL: size query only.  *count = number of elements. */
+int athena_mp_graph_export(const athena_mp_graph *g, int32_t which, void *host_dst, int64_t capacity,
+                           int64_t *count);
 int athena_mp_graph_destroy(athena_mp_graph *g);
 int athena_mp_graph_dims(const athena_mp_graph *g, int32_t *n_rows, int32_t *n_cols, int64_t *nnz,
                          int32_t *n_edge_cols);

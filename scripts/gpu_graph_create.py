@@ -1,7 +1,21 @@
+"""graph handle creation time: host builder vs device builder (ATHENA_MP_GRAPH_BUILD) at C2 and C4 sizes"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from athena_amd import DeviceGraph, synth
-t=time.time(); ia, ja = synth.random_graph_csr(1000000, 4500000); print("numpy CSR build %.2f s" % (time.time()-t))
-for k in range(2):
-    t=time.time(); g = DeviceGraph(ia, ja); print("graph_create (with edge index) %.2f s" % (time.time()-t)); g.close()
-t=time.time(); g = DeviceGraph(ia, ja, n_edge_cols=0); print("graph_create (no edge ids) %.2f s" % (time.time()-t))
+from athena_amd import DeviceGraph, synth, _capi
+_capi.init(0)
+def t(label, fn, reps=3):
+    fn().close()
+    best = 1e9
+    for _ in range(reps):
+        s = time.perf_counter(); g = fn(); best = min(best, time.perf_counter() - s); g.close()
+    print("%-58s %8.1f ms" % (label, best * 1e3))
+ia, ja = synth.random_graph_csr(1000000, 4500000)
+for mode in ("host", "device"):
+    os.environ["ATHENA_MP_GRAPH_BUILD"] = mode
+    t(f"C2 1M vertices / 10M entries, no edge ids   [{mode}]", lambda: DeviceGraph(ia, ja, n_edge_cols=0))
+    t(f"C2 1M vertices / 10M entries, with edge ids [{mode}]", lambda: DeviceGraph(ia, ja))
+ia, ja, coords = synth.radius_graph(2000000)
+for mode in ("host", "device"):
+    os.environ["ATHENA_MP_GRAPH_BUILD"] = mode
+    t(f"C4 2M points / {ja.shape[1]/1e6:.1f}M entries / {coords.shape[0]/1e6:.1f}M edge columns [{mode}]",
+      lambda: DeviceGraph(ia, ja, n_edge_cols=coords.shape[0]), reps=2)

@@ -1,0 +1,89 @@
+"""GPU: the device-side builder of the graph handle (athena_amd/csrc/graph_build.hip) against the host
+builder (capi.hip) -- every array of the handle compared element for element (integer / index work: bit
+exact; the coefficient too, since both take it from the same host powf), on graphs that exercise edge ids,
+self-loop entries without one, rectangular shards with explicit degrees, hub rows, empty rows and columns."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import csr_from_index_list, random_graph
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ["rowptr", "col", "eid", "coef", "t_rowptr", "t_src", "t_eid", "t_coef", "e_rowptr", "e_row", "e_entry",
+         "deg_row", "deg_col"]
+
+
+def _build(mode, *a, **kw):
+    from athena_amd import DeviceGraph
+
+    old = os.environ.get("ATHENA_MP_GRAPH_BUILD")
+    os.environ["ATHENA_MP_GRAPH_BUILD"] = mode
+    try:
+        return DeviceGraph(*a, **kw)
+    finally:
+        if old is None:
+            del os.environ["ATHENA_MP_GRAPH_BUILD"]
+        else:
+            os.environ["ATHENA_MP_GRAPH_BUILD"] = old
+
+
+def _same(a, b):
+    for n in NAMES:
+        x, y = a.export(n), b.export(n)
+        assert x.shape == y.shape, n
+        assert np.array_equal(x, y), f"{n} differs between the host and the device builder"
+
+
+@pytest.mark.parametrize("n,pairs,loops,iso", [(50, 120, True, 3), (5000, 20000, True, 10), (20000, 30000, False, 500), (1, 0, True, 0)])
+def test_device_builder_matches_host_builder(dev, n, pairs, loops, iso):
+    ia, ja = random_graph(n, pairs, seed=n, self_loops=loops, isolated=iso)
+    E = int(ja[1].max()) if ja.shape[1] else 0
+    _same(_build("host", ia, ja, n_edge_cols=E), _build("device", ia, ja, n_edge_cols=E))
+    _same(_build("host", ia, ja, n_edge_cols=0), _build("device", ia, ja, n_edge_cols=0))      # Kipf: no edge index
+
+
+def test_device_builder_rectangular_shard_hubs_and_duplicates(dev, oracle):
+    from athena_amd import ops
+    import torch
+
+    rng = np.random.default_rng(3)
+    n_rows, n_cols = 3000, 4100
+    deg = rng.poisson(6, n_rows).astype(np.int64)
+    deg[[5, 77]] = [900, 1500]                     # hub rows (> 512 entries): long-row plan
+    deg[[0, 1, 2999]] = 0                          # empty rows
+    ia = np.concatenate([[1], 1 + np.cumsum(deg)]).astype(np.int32)
+    nnz = int(deg.sum())
+    ja = np.zeros((2, nnz), np.int32, order="F")
+    ja[0] = rng.integers(1, n_cols - 50, nnz)      # the last 50 columns are never referenced; duplicates occur
+    ja[1] = rng.integers(0, 40, nnz)               # few edge columns, many entries each, id 0 = none
+    rd = rng.integers(1, 30, n_rows).astype(np.int32); cd = rng.integers(1, 30, n_cols).astype(np.int32)
+    a = _build("host", ia, ja, n_cols=n_cols, n_edge_cols=39, row_deg=rd, col_deg=cd)
+    b = _build("device", ia, ja, n_cols=n_cols, n_edge_cols=39, row_deg=rd, col_deg=cd)
+    _same(a, b)
+    x = torch.from_numpy(rng.uniform(-1, 1, (n_cols, 24)).astype(np.float32)).to(dev)
+    g = torch.from_numpy(rng.uniform(-1, 1, (n_rows, 24)).astype(np.float32)).to(dev)
+    assert torch.equal(ops.kipf_propagate(a, x), ops.kipf_propagate(b, x))
+    assert torch.equal(ops.kipf_propagate_bwd(a, g), ops.kipf_propagate_bwd(b, g))
+
+
+def test_device_builder_reports_bad_entries_like_the_host_builder(dev):
+    from athena_amd import _capi
+
+    ia = np.array([1, 3, 4], np.int32)
+    for bad, msg in ((np.array([[1, 9, 2], [0, 0, 0]], np.int32), r"adj_ja\(1,2\) = 9 outside"),
+                     (np.array([[1, 2, 2], [0, 7, 0]], np.int32), r"adj_ja\(2,2\) = 7 outside")):
+        for mode in ("host", "device"):
+            with pytest.raises(_capi.AthenaMPError, match=msg):
+                _build(mode, ia, np.asfortranarray(bad), n_edge_cols=3)
+
+
+def test_default_choice_builds_large_graphs_on_the_device_with_identical_results(dev, oracle):
+    """C2-shaped graph at 1/4 size (2.5 M entries: above the 2^18-entry switch): default build == host build"""
+    from athena_amd import DeviceGraph, synth
+
+    ia, ja = synth.random_graph_csr(250_000, 1_125_000)
+    a = _build("host", ia, ja, n_edge_cols=0)
+    b = DeviceGraph(ia, ja, n_edge_cols=0)
+    _same(a, b)
