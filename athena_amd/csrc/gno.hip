@@ -184,6 +184,196 @@ __global__ __launch_bounds__(256) void gno_outer_mfma_kernel(const int32_t *__re
     }
 }
 
+// ---- fused aggregate for H = 64, gathered width 64, output width 64 (BASELINE configs[3]) ---------------
+// out[r,:] = S_r . Vaug without S ever reaching HBM.  A 16-wave workgroup owns 16 vertices; the hidden index
+// is processed in two halves so that the 16 x (33 x 64) half of S fits LDS (135 KB):
+//   phase 1  wave w builds S_half of vertex w exactly like gno_outer_mfma_kernel (32x32x2 MFMA over the
+//            row's entries, h_e on the fly, neighbour rows re-gathered per half: 2 x 7.6 GB, L2-hot the second
+//            time, instead of the 2 x 33 GB S round trip) and parks it in LDS; the workgroup is persistent and
+//            fetches the next tile's row pointers and ids under the last contraction;
+//   phase 2  out^T[o, r] += sum_kq Vaug[kq, o] S[r, kq] on 16x16x4 MFMAs with the VERTEX on the column axis:
+//            B = S[r, 4s + g] (one LDS word per lane), A = Vaug[4s + g, 4n .. 4n+3] -- one 16 B load from L2
+//            feeds four MFMAs whose output tiles interleave o = 4m + c, so a lane ends up with 16 CONSECUTIVE
+//            outputs of its vertex; the 4 s-steps of a wave's slice are split over the 16 waves.
+// The per-wave partial sums are added through LDS in wave order (deterministic).
+typedef float v4f_g __attribute__((ext_vector_type(4)));
+constexpr int kGF = 64, kGH = 64, kGRows = 16, kGSP = 33 * kGF + 4;   // LDS row pitch of S_half
+
+__global__ __launch_bounds__(1024) void gno_fused_kernel(const int32_t *__restrict__ rowptr,
+                                                         const int32_t *__restrict__ idx,
+                                                         const int32_t *__restrict__ eidx,
+                                                         const float *__restrict__ y,
+                                                         const float *__restrict__ coords,
+                                                         const float *__restrict__ theta, int d,
+                                                         const float *__restrict__ Vaug, int n_rows,
+                                                         float *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) float Sh[];   // [16][kGSP]; reused for the final reduction
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r31 = lane & 31, h = lane >> 5;
+    const int n = lane & 15, g = lane >> 4;
+    const int n_tiles = (n_rows + kGRows - 1) / kGRows;
+
+    // persistent over tiles; the next tile's row pointers and first 64 (neighbour, edge) ids are fetched while
+    // the current tile is on the matrix cores, so phase 1 starts with one dependent load instead of three
+    int tile = blockIdx.x;
+    int w0 = 0, w1 = 0, my_j = -1, my_e = -1;
+    auto fetch_ids = [&](int tl) {
+        const int row = tl * kGRows + wave;
+        w0 = w1 = 0;
+        my_j = my_e = -1;
+        if (tl < n_tiles && row < n_rows) {
+            w0 = rowptr[row];
+            w1 = rowptr[row + 1];
+            if (lane < w1 - w0) { my_j = idx[w0 + lane]; my_e = eidx[w0 + lane]; }
+        }
+    };
+    fetch_ids(tile);
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const int r0 = tile * kGRows;
+        v4f_g om[4];                                     // phase-2 accumulators: tile c, register r -> o = 16g + 4r + c
+#pragma unroll
+        for (int c = 0; c < 4; ++c) om[c] = v4f_g{0.0f, 0.0f, 0.0f, 0.0f};
+        float *srow = Sh + wave * kGSP;
+        const int cw0 = w0, cw1 = w1, cj = my_j, ce = my_e;   // this tile's row (ids of its first 64 entries)
+        for (int half = 0; half < 2; ++half) {
+            // ---------------- phase 1: S_half of vertex `wave` (hidden units 32*half + r31) ----------------
+            // the neighbour rows are re-read for the second half (they are L2-hot); holding both halves in
+            // registers does not fit the 128 registers a 16-wave workgroup leaves per lane
+            float Uk[4], bk;   // this lane's hidden unit of this half: row of U and b_u (L1-hot reload per half)
+            {
+                const int k = 32 * half + r31;
+                bk = theta[(size_t)kGH * d + k];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Uk[j] = j < d ? theta[k + (size_t)kGH * j] : 0.0f;
+            }
+            f32x16 acc[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[b][r] = 0.0f;
+            float sb[2] = {0.0f, 0.0f};
+            for (int wb = cw0; wb < cw1; wb += 64) {
+                const int nb = min(64, cw1 - wb);
+                int bj = cj, be = ce;
+                if (wb != cw0) {   // rows longer than 64 entries: later blocks are fetched here
+                    bj = be = -1;
+                    if (lane < nb) { bj = idx[wb + lane]; be = eidx[wb + lane]; }
+                }
+                constexpr int U4 = 4;
+                for (int s0 = 0; s0 < (nb + 1) / 2; s0 += U4) {
+                    float yv[U4][2], dx[U4][4];
+                    bool ok[U4];
+#pragma unroll
+                    for (int u = 0; u < U4; ++u) {
+                        const int ent = 2 * (s0 + u) + h;
+                        const int j = __shfl(bj, ent), e = __shfl(be, ent);
+                        ok[u] = ent < nb && e >= 0;
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) yv[u][b] = ok[u] ? y[(size_t)j * kGF + 32 * b + r31] : 0.0f;
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) dx[u][jj] = (ok[u] && jj < d) ? coords[(size_t)e * d + jj] : 0.0f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < U4; ++u) {
+                        float sacc = 0.0f;
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) sacc = sacc + Uk[jj] * dx[u][jj];   // j-ordered, as :88-90
+                        sacc = sacc + bk;
+                        const float hv = (ok[u] && sacc > 0.0f) ? sacc : 0.0f;
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            sb[b] = sb[b] + yv[u][b];
+                            acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(hv, yv[u][b], acc[b], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kl = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    srow[kl * kGF + 32 * b + r31] = acc[b][r];
+                }
+            if (half == 1) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const float tot = sb[b] + __shfl_xor(sb[b], 32);
+                    if (h == 0) srow[32 * kGF + 32 * b + r31] = tot;     // bias row k = H
+                }
+                fetch_ids(tile + gridDim.x);   // next tile's ids fly under the last contraction
+            }
+            __syncthreads();
+            // ---------------- phase 2: contraction of this half ----------------
+            const int n_steps = (half == 0 ? 32 * kGF : 33 * kGF) / 4;    // 512 / 528 k-steps of 4
+            const int per_wave = (n_steps + 15) / 16;
+            const int s_beg = wave * per_wave, s_end = min(n_steps, s_beg + per_wave);
+            const float *vbase = Vaug + (size_t)half * 32 * kGF * kGF;     // rows (kq) of this half
+            const float *sl = Sh + n * kGSP + g;
+            constexpr int UN = 8;
+            for (int s0 = s_beg; s0 < s_end; s0 += UN) {
+                v4f_g a[UN];
+                float b[UN];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const int s = min(s0 + u, s_end - 1);
+                    a[u] = *reinterpret_cast<const v4f_g *>(vbase + (size_t)(4 * s + g) * kGF + 4 * n);
+                    b[u] = sl[4 * s];
+                }
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    if (s0 + u < s_end) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) om[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][c], b[u], om[c], 0, 0, 0);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        // ---------------- cross-wave reduction (fixed order) and store ----------------
+        // lane (n = vertex, g): om[c][r] = out[vertex][16g + 4r + c]
+        float *red = Sh;   // [16 waves][16 vertices][64]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const v4f_g v = {om[0][r], om[1][r], om[2][r], om[3][r]};
+            *reinterpret_cast<v4f_g *>(red + ((size_t)wave * kGRows + n) * kGF + 16 * g + 4 * r) = v;
+        }
+        __syncthreads();
+        {
+            const int t = threadIdx.x;                 // 1024 threads = 16 vertices x 64 outputs
+            float sum = red[t];
+#pragma unroll
+            for (int w = 1; w < 16; ++w) sum = sum + red[(size_t)w * kGRows * kGF + t];
+            const int v = t >> 6;
+            if (r0 + v < n_rows) out[(size_t)(r0 + v) * kGF + (t & 63)] = sum;
+        }
+        __syncthreads();   // red is S of the next tile
+    }
+}
+
+bool gno_fused_shape(int H, int Fy, int Fout, int d)
+{
+    static const bool off = getenv("ATHENA_MP_GNO_UNFUSED") != nullptr;   // A/B switch for measurements
+    return !off && H == kGH && Fy == kGF && Fout == kGF && d <= 4;
+}
+
+int launch_gno_fused(const int32_t *rowptr, const int32_t *idx, const int32_t *eidx, const float *y,
+                     const float *coords, const float *theta, int d, const float *Vaug, int n_rows, float *out)
+{
+    constexpr size_t lds = sizeof(float) * (size_t)kGRows * kGSP;
+    static bool attr = false;
+    if (!attr) {
+        AMP_HIP(hipFuncSetAttribute((const void *)gno_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    if (n_rows <= 0) return 0;
+    const int n_tiles = (n_rows + kGRows - 1) / kGRows;
+    hipLaunchKernelGGL(gno_fused_kernel, dim3(std::min(n_tiles, 256)), dim3(1024), lds, amp::stream(), rowptr, idx,
+                       eidx, y, coords, theta, d, Vaug, n_rows, out);
+    AMP_LAUNCH_CHECK();
+    return 0;
+}
+
 // B2[(k*Fo + o)*Fi + q] = Vaug[F*k + o + Fo*q]
 __global__ void gno_perm_kernel(const float *__restrict__ vaug, int H1, int Fi, int Fo, float *__restrict__ B2)
 {
@@ -530,6 +720,8 @@ int athena_mp_gno_aggregate_fwd(const athena_mp_graph *g, int32_t d, int32_t H, 
     AMP_REQUIRE(theta && coords && x && m, "gno_aggregate_fwd: null pointer");
     const size_t off_V = (size_t)H * d + H;
     const int R = (H + 1) * Fi;
+    if (gno_fused_shape(H, Fi, Fo, d))
+        return launch_gno_fused(g->rowptr, g->col, g->eid, x, coords, theta, d, theta + off_V, g->n_rows, m);
     const int tile = tile_rows_for(g->n_rows, R);
     for (int r0 = 0; r0 < g->n_rows; r0 += tile) {
         const int rows = std::min(tile, g->n_rows - r0);
@@ -560,6 +752,8 @@ int athena_mp_gno_aggregate_bwd_x(const athena_mp_graph *g, int32_t d, int32_t H
                            Fo, (float *)b2);
         AMP_LAUNCH_CHECK();
     }
+    if (gno_fused_shape(H, Fo, Fi, d))
+        return launch_gno_fused(g->t_rowptr, g->t_src, g->t_eid, grad, coords, theta, d, (const float *)b2, g->n_cols, dx);
     const int tile = tile_rows_for(g->n_cols, R2);
     for (int r0 = 0; r0 < g->n_cols; r0 += tile) {
         const int rows = std::min(tile, g->n_cols - r0);
