@@ -79,6 +79,10 @@ struct athena_mp_graph {
     mutable int bucket_min = 0, bucket_max = -1;
     mutable int32_t *bucket_perm = nullptr;      // [n_rows] device
     mutable std::vector<int64_t> bucket_off;     // [n_buckets+1] host
+    // rows ordered by length (longest first), built on first use by the fused GNO kernel: the 16 rows of a
+    // tile then have (nearly) equal entry counts, so no wave waits at the tile barrier for a longer row
+    mutable int32_t *len_perm_fwd = nullptr;     // [n_rows] device, forward CSR
+    mutable int32_t *len_perm_bwd = nullptr;     // [n_cols] device, transposed CSR
     // the same runs cut into 16-vertex tiles (one MFMA column block each), bucket-major
     mutable int32_t n_btiles = 0;
     mutable int32_t *btile_start = nullptr;      // [n_btiles] device: first index into bucket_perm

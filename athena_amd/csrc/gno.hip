@@ -206,6 +206,7 @@ __global__ __launch_bounds__(1024) void gno_fused_kernel(const int32_t *__restri
                                                          const float *__restrict__ coords,
                                                          const float *__restrict__ theta, int d,
                                                          const float *__restrict__ Vaug, int n_rows,
+                                                         const int32_t *__restrict__ perm,
                                                          float *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) float Sh[];   // [16][kGSP]; reused for the final reduction
@@ -218,10 +219,11 @@ __global__ __launch_bounds__(1024) void gno_fused_kernel(const int32_t *__restri
     int tile = blockIdx.x;
     int w0 = 0, w1 = 0, my_j = -1, my_e = -1;
     auto fetch_ids = [&](int tl) {
-        const int row = tl * kGRows + wave;
+        const int slot = tl * kGRows + wave;
         w0 = w1 = 0;
         my_j = my_e = -1;
-        if (tl < n_tiles && row < n_rows) {
+        if (tl < n_tiles && slot < n_rows) {
+            const int row = perm[slot];          // slots walk the vertices longest row first
             w0 = rowptr[row];
             w1 = rowptr[row + 1];
             if (lane < w1 - w0) { my_j = idx[w0 + lane]; my_e = eidx[w0 + lane]; }
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(1024) void gno_fused_kernel(const int32_t *__restri
 #pragma unroll
             for (int w = 1; w < 16; ++w) sum = sum + red[(size_t)w * kGRows * kGF + t];
             const int v = t >> 6;
-            if (r0 + v < n_rows) out[(size_t)(r0 + v) * kGF + (t & 63)] = sum;
+            if (r0 + v < n_rows) out[(size_t)perm[r0 + v] * kGF + (t & 63)] = sum;
         }
         __syncthreads();   // red is S of the next tile
     }
@@ -357,9 +359,29 @@ bool gno_fused_shape(int H, int Fy, int Fout, int d)
     return !off && H == kGH && Fy == kGF && Fout == kGF && d <= 4;
 }
 
-int launch_gno_fused(const int32_t *rowptr, const int32_t *idx, const int32_t *eidx, const float *y,
-                     const float *coords, const float *theta, int d, const float *Vaug, int n_rows, float *out)
+// vertices ordered by row length, longest first (stable counting sort on the host, once per graph and CSR)
+int length_order(const int32_t *rowptr_dev, int n_rows, int32_t **perm_dev)
 {
+    if (*perm_dev) return 0;
+    std::vector<int32_t> rp((size_t)n_rows + 1);
+    AMP_HIP(hipMemcpyAsync(rp.data(), rowptr_dev, sizeof(int32_t) * rp.size(), hipMemcpyDeviceToHost, amp::stream()));
+    AMP_HIP(hipStreamSynchronize(amp::stream()));
+    int32_t mx = 0;
+    for (int i = 0; i < n_rows; ++i) mx = std::max(mx, rp[i + 1] - rp[i]);
+    std::vector<int32_t> start((size_t)mx + 2, 0), perm((size_t)std::max(n_rows, 1));
+    for (int i = 0; i < n_rows; ++i) start[(size_t)(mx - (rp[i + 1] - rp[i])) + 1]++;
+    for (int l = 0; l <= mx; ++l) start[(size_t)l + 1] += start[l];
+    for (int i = 0; i < n_rows; ++i) perm[start[(size_t)(mx - (rp[i + 1] - rp[i]))]++] = i;
+    AMP_HIP(hipMalloc((void **)perm_dev, sizeof(int32_t) * perm.size()));
+    AMP_HIP(hipMemcpy(*perm_dev, perm.data(), sizeof(int32_t) * perm.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int launch_gno_fused(const int32_t *rowptr, const int32_t *idx, const int32_t *eidx, const float *y,
+                     const float *coords, const float *theta, int d, const float *Vaug, int n_rows,
+                     int32_t **perm_cache, float *out)
+{
+    if (n_rows > 0 && length_order(rowptr, n_rows, perm_cache)) return 1;
     constexpr size_t lds = sizeof(float) * (size_t)kGRows * kGSP;
     static bool attr = false;
     if (!attr) {
@@ -369,7 +391,7 @@ int launch_gno_fused(const int32_t *rowptr, const int32_t *idx, const int32_t *e
     if (n_rows <= 0) return 0;
     const int n_tiles = (n_rows + kGRows - 1) / kGRows;
     hipLaunchKernelGGL(gno_fused_kernel, dim3(std::min(n_tiles, 256)), dim3(1024), lds, amp::stream(), rowptr, idx,
-                       eidx, y, coords, theta, d, Vaug, n_rows, out);
+                       eidx, y, coords, theta, d, Vaug, n_rows, (const int32_t *)*perm_cache, out);
     AMP_LAUNCH_CHECK();
     return 0;
 }
@@ -721,7 +743,7 @@ int athena_mp_gno_aggregate_fwd(const athena_mp_graph *g, int32_t d, int32_t H, 
     const size_t off_V = (size_t)H * d + H;
     const int R = (H + 1) * Fi;
     if (gno_fused_shape(H, Fi, Fo, d))
-        return launch_gno_fused(g->rowptr, g->col, g->eid, x, coords, theta, d, theta + off_V, g->n_rows, m);
+        return launch_gno_fused(g->rowptr, g->col, g->eid, x, coords, theta, d, theta + off_V, g->n_rows, &g->len_perm_fwd, m);
     const int tile = tile_rows_for(g->n_rows, R);
     for (int r0 = 0; r0 < g->n_rows; r0 += tile) {
         const int rows = std::min(tile, g->n_rows - r0);
@@ -753,7 +775,7 @@ int athena_mp_gno_aggregate_bwd_x(const athena_mp_graph *g, int32_t d, int32_t H
         AMP_LAUNCH_CHECK();
     }
     if (gno_fused_shape(H, Fo, Fi, d))
-        return launch_gno_fused(g->t_rowptr, g->t_src, g->t_eid, grad, coords, theta, d, (const float *)b2, g->n_cols, dx);
+        return launch_gno_fused(g->t_rowptr, g->t_src, g->t_eid, grad, coords, theta, d, (const float *)b2, g->n_cols, &g->len_perm_bwd, dx);
     const int tile = tile_rows_for(g->n_cols, R2);
     for (int r0 = 0; r0 < g->n_cols; r0 += tile) {
         const int rows = std::min(tile, g->n_cols - r0);
