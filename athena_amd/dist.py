@@ -116,16 +116,43 @@ class Shard:
         return ia, np.asfortranarray(adj_ja[:, e0:e1])
 
 
+def _host_staged(t):
+    """gloo moves host memory only.  It is the transport of the CPU tests and of the single-GPU dry run of the
+    N > 1 bench path (all ranks on one device, ATHENA_MP_BENCH_BACKEND=gloo); device tensors are then staged
+    through the host.  With RCCL ("nccl") nothing is staged."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+class _StagedRecv:
+    def __init__(self, req, host, dst):
+        self.req, self.host, self.dst = req, host, dst
+
+    def wait(self):
+        self.req.wait()
+        if self.host is not None:
+            self.dst.copy_(self.host)
+
+
 def _p2p_start(send_bufs, recv_bufs, rank, world):
-    ops = []
+    ops, pending = [], []
     for p in range(world):
         if p == rank:
             continue
         if send_bufs[p] is not None and send_bufs[p].numel() > 0:
-            ops.append(dist.P2POp(dist.isend, send_bufs[p], p))
+            sb = send_bufs[p].cpu() if _host_staged(send_bufs[p]) else send_bufs[p]
+            ops.append(dist.P2POp(dist.isend, sb, p))
+            pending.append((None, None))
         if recv_bufs[p] is not None and recv_bufs[p].numel() > 0:
-            ops.append(dist.P2POp(dist.irecv, recv_bufs[p], p))
-    return dist.batch_isend_irecv(ops) if ops else []
+            if _host_staged(recv_bufs[p]):
+                hb = torch.empty(recv_bufs[p].shape, dtype=recv_bufs[p].dtype)
+                ops.append(dist.P2POp(dist.irecv, hb, p))
+                pending.append((hb, recv_bufs[p]))
+            else:
+                ops.append(dist.P2POp(dist.irecv, recv_bufs[p], p))
+                pending.append((None, None))
+    if not ops:
+        return []
+    return [_StagedRecv(r, h, d) for r, (h, d) in zip(dist.batch_isend_irecv(ops), pending)]
 
 
 def _p2p_exchange(send_bufs, recv_bufs, rank, world):
@@ -142,7 +169,9 @@ def build_plan(shard, device):
         shard.send_idx = torch.zeros(0, dtype=torch.int32, device=device)
         shard.col_deg = shard.row_deg.copy()
         return shard
-    rc = torch.from_numpy(shard.recv_counts).to(device)
+    rc = torch.from_numpy(shard.recv_counts)
+    if dist.get_backend() != "gloo":
+        rc = rc.to(device)
     allc = [torch.empty_like(rc) for _ in range(world)]
     dist.all_gather(allc, rc)
     allc = torch.stack(allc).cpu().numpy()                 # allc[q][p] = rows q needs from p
@@ -255,10 +284,18 @@ class KipfShardStep:
         self.dX = torch.empty((n, F), dtype=torch.float32, device=device)
         self.xchg = HaloExchange(shard, F, device, self.b)
 
-    def __call__(self):
+    def __call__(self, events=None):
+        """events: optional list; a (start, end) pair of torch.cuda events around the interior forward launch is
+        appended (bench.py's roofline at N > 1)"""
         s, b, F, n, ni = self.s, self.b, self.F, self.s.n, self.s.n_int
         reqs = self.xchg.start(self.x_ext)                                        # halo of X in flight ...
+        if events is not None:
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         b.kipf_layer_fwd(self.g_fwd_int, self.x_ext, self.W, F, P=self.P[:ni], Z=self.Z[:ni])   # ... under the interior rows
+        if events is not None:
+            e1.record()
+            events.append((e0, e1))
         self.xchg.finish(reqs)
         b.kipf_layer_fwd(self.g_fwd_bnd, self.x_ext, self.W, F, P=self.P[ni:], Z=self.Z[ni:])
         reqs = self.xchg.start(self.dZ_ext)                                       # halo of dZ in flight ...
@@ -266,7 +303,14 @@ class KipfShardStep:
         # asynchronous: a blocking all_reduce would make the compute stream wait for the collective, and the
         # collective queues behind the halo transfer on the communicator's stream -- the interior rows below
         # would then start only after the exchange they are meant to hide
-        red = dist.all_reduce(self.dW, async_op=True) if s.world > 1 else None
+        red = None
+        if s.world > 1:
+            if _host_staged(self.dW):
+                h = self.dW.cpu()
+                dist.all_reduce(h)
+                self.dW.copy_(h)
+            else:
+                red = dist.all_reduce(self.dW, async_op=True)
         b.pull_gemm(self.g_bwd_int, self.dZ_ext, self.W, F, exact=self.exact, out=self.dX[:ni])   # ... and the interior rows
         self.xchg.finish(reqs)
         b.pull_gemm(self.g_bwd_bnd, self.dZ_ext, self.W, F, exact=self.exact, out=self.dX[ni:])
@@ -282,5 +326,5 @@ def build_kipf_step(shard, F, device, backend=None):
     info = {"graph": "random graph, both endpoints uniform over all N*vertices_per_gpu vertices (no partition structure)" if uniform
             else f"stochastic block model, one block per GPU, fixed inter-block density: {shard.cut:.4f} of the undirected pairs cross partitions at this N",
             "halo_rows_per_gpu": shard.n_halo, "halo_bytes_per_gpu_per_step": halo_bytes,
-            "interior_rows_per_gpu": shard.n_int}
+            "interior_rows_per_gpu": shard.n_int, "interior_entries_per_gpu": int(shard.adj_ia[shard.n_int]) - 1}
     return step, shard.nnz, info

@@ -81,6 +81,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py measures the HIP path; no GPU visible"
+    # dev aid: ATHENA_MP_BENCH_ONE_DEVICE=1 ATHENA_MP_BENCH_BACKEND=gloo runs the N > 1 code path with all ranks on
+    # device 0 and host-staged transport (a dry run of the partition / halo / overlap logic on a 1-GPU box; the
+    # numbers it prints mean nothing).  The driver's runs use one GPU per rank over RCCL.
+    if os.environ.get("ATHENA_MP_BENCH_ONE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -94,12 +99,20 @@ def main():
 
         from athena_amd import dist as adist
 
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("ATHENA_MP_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
         cut = None if args.cut < 0 else args.cut * (world - 1) / 7.0
         shard = adist.make_weak_scaling_shard(rank, world, args.nodes, args.pairs, F, cut=cut, device=dev)
-        step, nnz_local, info = adist.build_kipf_step(shard, F, dev)
+        shard_step, nnz_local, info = adist.build_kipf_step(shard, F, dev)
         nnz_total = nnz_local * world
         x = w = dz = ia = ja = None
+        ev = []
+
+        def step(record=False):
+            shard_step(events=ev if record else None)
     else:
         ia, ja = synth.random_graph_csr(args.nodes, args.pairs)
         x, w, dz = synth.kipf_inputs(args.nodes, F)
@@ -135,12 +148,12 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(record=True) if world == 1 else step()
+        step(record=True)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
 
@@ -152,7 +165,7 @@ def main():
         # the structure-free graph (both endpoints uniform over all N*1M vertices): no row partition can
         # avoid moving ~(N-1)/N of the neighbour rows, so this variant is xGMI bound by construction
         try:
-            del step, shard
+            del step, shard_step, shard
             torch.cuda.empty_cache()
             vsteps = max(3, args.steps // 5)
             shard2 = adist.make_weak_scaling_shard(rank, world, args.nodes, args.pairs, F, cut=None, device=dev)
@@ -165,7 +178,7 @@ def main():
                 step2()
             barrier()
             dt2 = time.perf_counter() - t1
-            tt = torch.tensor([dt2], device=dev, dtype=torch.float64)
+            tt = torch.tensor([dt2], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             variant = {"value": nnz2 * world * vsteps / tt.item(), "unit": "edges/s", "steps": vsteps,
                        "ms_per_step": tt.item() / vsteps * 1e3, **info2}
@@ -181,28 +194,32 @@ def main():
                    "vertices_per_gpu": args.nodes, "entries_per_gpu": nnz_local, "features": F,
                    "parallelism": f"row-partition x{world}" if world > 1 else "single GPU", **info},
     }
-    if world == 1:
-        # dominant kernel: the fused forward launch (CSR gather-aggregate + dense step; HBM bound).
-        # algorithmic bytes = the aggregation's (nnz*(4F+8) + N*(4F+8), P written once)
-        # + the Z rows written; P is not re-read and W (64 KB) stays in LDS.
-        agg_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-        alg_bytes = nnz_local * (4 * F + 8) + args.nodes * (4 * F + 8) + args.nodes * 4 * F
-        achieved = alg_bytes / (agg_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath) and (args.nodes, args.pairs, F) == (1_000_000, 4_500_000, 128):
-            try:
-                traffic = json.load(open(tpath)).get("agg_gemm_fwd_bytes_per_launch")
-            except Exception:
-                traffic = None
-        kname = (f"agg_gemm_kernel<{F},coef> (fused kipf_propagate + matmul fwd)" if F in (64, 128) else
-                 "kipf_layer_fwd = csr_gather_agg + dense step (two launches at this width)")
-        out["roofline"] = {"bound": "hbm", "kernel": kname,
-                           "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                           "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": agg_ms}
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(ia, ja, x, w, dz, F, args.cpu_sample_rows)
+    # dominant kernel: the fused forward launch (CSR gather-aggregate + dense step; HBM bound), timed with HIP events
+    # on its launch stream inside the timed loop.  algorithmic bytes = the aggregation's (SURVEY.md 8d:
+    # nnz*(4F+8) + N*(4F+8), P written once) + the Z rows written; P is not re-read and W (64 KB) stays in LDS.
+    # At N > 1 it is rank 0's launch over the INTERIOR rows of its shard, which runs while the halo is in flight.
+    agg_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    k_rows = args.nodes if world == 1 else info["interior_rows_per_gpu"]
+    k_nnz = nnz_local if world == 1 else info["interior_entries_per_gpu"]
+    alg_bytes = k_nnz * (4 * F + 8) + k_rows * (4 * F + 8) + k_rows * 4 * F
+    achieved = alg_bytes / (agg_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if world == 1 and os.path.exists(tpath) and (args.nodes, args.pairs, F) == (1_000_000, 4_500_000, 128):
+        try:
+            traffic = json.load(open(tpath)).get("agg_gemm_fwd_bytes_per_launch")
+        except Exception:
+            traffic = None
+    kname = (f"agg_gemm_kernel<{F},coef> (fused kipf_propagate + matmul fwd)" if F in (64, 128) else
+             "kipf_layer_fwd = csr_gather_agg + dense step (two launches at this width)")
+    if world > 1:
+        kname += ", interior rows of rank 0's shard (halo exchange in flight)"
+    out["roofline"] = {"bound": "hbm", "kernel": kname,
+                       "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                       "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": agg_ms}
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(ia, ja, x, w, dz, F, args.cpu_sample_rows)
     if variant is not None:
         out["uniform_random_variant"] = variant
     if rank == 0:
