@@ -342,6 +342,44 @@ def H_(t):
     return t.cpu().numpy()
 
 
+@pytest.mark.parametrize("d,loops", [(3, False), (2, True), (4, False)])
+def test_gno_fused_kernel_hub_rows_tail_tiles_and_self_loops(dev, oracle, d, loops):
+    """the one-launch GNO aggregate (H = 64, widths 64): vertices with more than 64 entries (ids beyond the
+    prefetched block), a vertex count that is not a multiple of the 16-vertex tile, isolated vertices, and
+    self-loop entries without an edge id (zero kernel); forward and dx against the materialising oracle"""
+    from athena_amd import DeviceGraph, ops
+
+    rng = np.random.default_rng(40 + d)
+    N = 203
+    pairs = [[i, i + 1] for i in range(1, N - 5)]                 # the last vertices stay isolated
+    pairs += [[7, int(v)] for v in rng.choice(np.arange(9, N - 5), 150, replace=False)]     # hub: 150+ entries
+    pairs += [[60, int(v)] for v in rng.choice(np.arange(62, N - 5), 70, replace=False)]    # 70+ entries
+    pairs += [[int(a), int(b)] for a, b in rng.integers(1, N - 4, (300, 2)) if a != b]
+    pairs = np.array(pairs).T
+    g = csr_from_index_list(N, pairs, self_loops=loops)
+    E = pairs.shape[1]
+    assert np.diff(g.adj_ia).max() > 128 and N % 16 != 0
+    Hh = Fi = Fo = 64
+    coords = rng.standard_normal((E, d)).astype(np.float32)
+    x = rng.uniform(-1, 1, (N, Fi)).astype(np.float32)
+    theta = (0.3 * rng.standard_normal(Hh * d + Hh + Fo * Fi * Hh + Fo * Fi)).astype(np.float32)
+    up = rng.uniform(-1, 1, (N, Fo)).astype(np.float32)
+    dg = DeviceGraph(g.adj_ia, g.adj_ja, n_edge_cols=E)
+    kap = oracle.gno_kernel_eval(coords, theta, Hh, Fo * Fi)
+    th, co = T(theta, dev), T(coords, dev)
+    m = ops.gno_aggregate(dg, th, co, T(x, dev), d, Hh, Fo)
+    assert_close(H_(m), oracle.gno_aggregate(x, kap, g.adj_ia, g.adj_ja, Fo), 1e-5, "fused gno fwd")
+    assert not H_(m)[N - 4:].any()                                # isolated vertices: exact zeros
+    dx = ops.gno_aggregate_bwd_x(dg, th, co, T(up, dev), d, Hh, Fi)
+    assert_close(H_(dx), oracle.gno_aggregate_bwd_x(up, kap, g.adj_ia, g.adj_ja, Fi), 1e-5, "fused gno dx")
+    assert torch_equal_twice(lambda: ops.gno_aggregate(dg, th, co, T(x, dev), d, Hh, Fo))   # deterministic
+
+
+def torch_equal_twice(fn):
+    import torch
+    return torch.equal(fn(), fn())
+
+
 @pytest.mark.parametrize("act,F", [("none", 128), ("relu", 128), ("none", 64), ("tanh", 64)])
 def test_fused_kipf_layer_kernels(dev, oracle, act, F):
     """one-launch aggregation + dense step: P bit-exact vs the oracle's kipf_propagate, Z and dX within
