@@ -97,3 +97,111 @@ def batch_graphs(graphs):
     x = np.concatenate([np.asarray(g.vertex_features, np.float32).reshape(g.num_vertices, -1) for g in graphs]) if S else None
     e = np.concatenate([np.asarray(g.edge_features, np.float32).reshape(g.num_edges, -1) for g in graphs]) if S else None
     return ia, ja, voff.astype(np.int32), x, e
+
+
+# ---- layer cards of athena's network file ("print" / "read" of the three message-passing layers) ------------
+# print_base (athena_base_layer_sub_io.f90:14-65) writes   <NAME> / body / END <NAME>;  the bodies are
+# print_to_unit_kipf (athena_kipf_msgpass_layer.f90:398-436), print_to_unit_duvenaud
+# (athena_duvenaud_msgpass_layer.f90:~640-700) and print_to_unit_gno (athena_graph_nop_layer.f90); activations
+# print an ACTIVATION block of "name = value" attributes (athena_misc_types_sub.f90:43-75).  Weights go out as
+# '(5(E16.8E2))' records, one WRITE per parameter tensor, and are read back list-directed.
+
+def _e16(v):
+    """Fortran E16.8E2: 0.dddddddd mantissa, two-digit exponent, right-justified in 16 columns"""
+    v = float(v)
+    if v == 0.0 or v != v or v in (float("inf"), float("-inf")):
+        body = "0.00000000E+00" if v == 0.0 else ("NaN" if v != v else ("Infinity" if v > 0 else "-Infinity"))
+        return body.rjust(16)
+    mant, ex = f"{abs(v):.7E}".split("E")            # d.ddddddd E ee  ->  0.dddddddd E (ee+1)
+    digits = mant.replace(".", "")
+    return (("-" if v < 0 else "") + "0." + digits + f"E{int(ex) + 1:+03d}").rjust(16)
+
+
+def _weights_block(tensors):
+    lines = ["WEIGHTS"]
+    for t in tensors:                                   # one WRITE statement per tensor: records of five values
+        flat = np.asarray(t, np.float32).reshape(-1)
+        for i in range(0, flat.size, 5):
+            lines.append("".join(_e16(v) for v in flat[i:i + 5]))
+    lines.append("END WEIGHTS")
+    return lines
+
+
+def _activation_block(name, scale=1.0, identifier=None, extra=()):
+    out = ["   ACTIVATION" + (f": {identifier}" if identifier else "")]
+    out.append(f"      name = {name}")
+    out.append(f"      scale = {scale:.6f}")
+    for k, v in extra:
+        out.append(f"      {k} = {v}")
+    out.append("   END ACTIVATION")
+    return out
+
+
+def layer_card(layer):
+    """the text card of a layer mirror (kipf / duvenaud / graph_nop), as print_base would write it"""
+    name = layer.name.upper()
+    lines = [name]
+    params = [p.detach().cpu().numpy() for p in layer.params]
+    if layer.name == "kipf":
+        lines.append(f"   NUM_TIME_STEPS = {layer.num_time_steps}")
+        lines.append("   NUM_VERTEX_FEATURES =" + "".join(f" {v}" for v in layer.num_vertex_features))
+        if layer.activation != "none":
+            lines += _activation_block(layer.activation)
+    elif layer.name == "duvenaud":
+        lines.append(f"   NUM_TIME_STEPS = {layer.num_time_steps}")
+        lines.append("   NUM_VERTEX_FEATURES =" + "".join(f" {v}" for v in layer.num_vertex_features))
+        lines.append("   NUM_EDGE_FEATURES =" + "".join(f" {v}" for v in layer.num_edge_features))
+        if layer.activation != "none":
+            lines += _activation_block(layer.activation, identifier="MESSAGE")
+        lines += _activation_block("softmax", identifier="READOUT")
+    elif layer.name == "graph_nop":
+        lines.append(f"   NUM_INPUTS = {layer.num_vertex_features[0]}")
+        lines.append(f"   NUM_OUTPUTS = {layer.num_outputs}")
+        lines.append(f"   COORD_DIM = {layer.coord_dim}")
+        lines.append(f"   KERNEL_HIDDEN = {layer.kernel_hidden}")
+        lines.append(f"   USE_BIAS = {'T' if layer.use_bias else 'F'}")
+        if layer.activation != "none":
+            lines += _activation_block(layer.activation)
+    else:
+        raise ValueError(f"no card format for layer '{layer.name}'")
+    lines += _weights_block(params)
+    lines.append("END " + name)
+    return "\n".join(lines) + "\n"
+
+
+def parse_layer_card(text):
+    """Reads one KIPF or GRAPH_NOP card (read_kipf :440-600, read_gno; the reference's read_duvenaud is an empty
+    stub, :703-714, so there is nothing to mirror for it).  Returns (name, hyperparameters, flat weight vector)."""
+    lines = [l.rstrip() for l in text.splitlines() if l.strip()]
+    name = lines[0].strip().lower()
+    if name not in ("kipf", "graph_nop"):
+        raise ValueError(f"unsupported layer card '{lines[0].strip()}'")
+    if lines[-1].strip() != "END " + name.upper():
+        raise ValueError(f"END {name.upper()} not where expected")                  # the reference's message
+    hp, weights, i = {}, None, 1
+    while i < len(lines) - 1:
+        l = lines[i].strip()
+        if l.startswith("ACTIVATION"):
+            j = i + 1
+            while lines[j].strip() != "END ACTIVATION":
+                k, v = (s.strip() for s in lines[j].split("=", 1))
+                hp["activation_" + k] = v
+                j += 1
+            i = j + 1
+        elif l == "WEIGHTS":
+            j = i + 1
+            vals = []
+            while lines[j].strip() != "END WEIGHTS":
+                vals += [float(f) for f in lines[j].split()]   # every E16.8E2 field starts with a blank: list-directed read
+                j += 1
+                if j >= len(lines):
+                    raise ValueError("END WEIGHTS not where expected")
+            weights = np.array(vals, np.float32)
+            i = j + 1
+        elif "=" in l:
+            k, v = (s.strip() for s in l.split("=", 1))
+            hp[k] = v
+            i += 1
+        else:
+            raise ValueError(f"Unrecognised line in input file: {l}")            # read_kipf :~545
+    return name, hp, weights

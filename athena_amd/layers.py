@@ -96,6 +96,16 @@ class msgpass_layer_type:
             self._seg = torch.from_numpy(self.graph.vertex_offsets).to(self.device)
         return self
 
+    # -- text card of the network file (print_base / read) -------------------------------------------
+    def print(self, file=None):
+        """the layer's card as athena writes it (athena_base_layer_sub_io.f90:14-65); appended to `file` if given"""
+        from . import io
+        card = io.layer_card(self)
+        if file is not None:
+            with open(file, "a") as f:
+                f.write(card)
+        return card
+
     # -- learnable accessors (athena_base_layer_sub.f90:545-691) ----------------------------------
     def get_num_params(self):
         return int(sum(p.numel() for p in self.params))
@@ -367,3 +377,27 @@ class graph_nop_layer_type(msgpass_layer_type):
         if need_coord_grad:
             dc = ops.gno_aggregate_bwd_coords(g, self.params[0], self._coords, self._x, dz, d, H)
         return (dx, dc) if need_coord_grad else dx
+
+
+def read_layer(text, device="cuda:0"):
+    """layer from its text card (read_kipf_msgpass_layer / read_graph_nop_layer); weights are set as read"""
+    from . import io
+    name, hp, weights = io.parse_layer_card(text)
+    act = hp.get("activation_name", "none")
+    if name == "kipf":
+        nvf = [int(v) for v in hp["NUM_VERTEX_FEATURES"].split()]
+        T = int(hp.get("NUM_TIME_STEPS", len(nvf) - 1))
+        if T != len(nvf) - 1:
+            raise ValueError(f"NUM_TIME_STEPS = {T} does not match length of NUM_VERTEX_FEATURES = {len(nvf) - 1}")
+        layer = kipf_msgpass_layer_type(num_vertex_features=nvf, num_time_steps=T, activation=act, device=device)
+    else:
+        layer = graph_nop_layer_type(num_outputs=int(hp["NUM_OUTPUTS"]), coord_dim=int(hp["COORD_DIM"]),
+                                     kernel_hidden=int(hp["KERNEL_HIDDEN"]), num_inputs=int(hp["NUM_INPUTS"]),
+                                     use_bias=hp.get("USE_BIAS", "T").strip().upper().startswith("T"), activation=act,
+                                     device=device)
+    if weights is None:
+        import warnings
+        warnings.warn(f"WEIGHTS card in {name.upper()} not found")
+    else:
+        layer.set_params(weights)
+    return layer

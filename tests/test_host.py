@@ -94,3 +94,20 @@ def test_all_graphs_text_format_round_trip(tmp_path):
     bad.write_text(" ".join(open(path).read().split()[:40]))
     with pytest.raises(ValueError, match="ended early|span"):
         io.read_all_graphs(bad)
+
+
+def test_fortran_e16_8e2_field_formatting():
+    """'(5(E16.8E2))' as the reference writes weights (athena_kipf_msgpass_layer.f90:430-433): 0.d mantissa of
+    eight digits, two-digit exponent, 16 columns -- of the STORED float32 value"""
+    from athena_amd.io import _e16, parse_layer_card
+
+    assert _e16(1.0) == "  0.10000000E+01" and _e16(-1.0) == " -0.10000000E+01" and _e16(0.0) == "  0.00000000E+00"
+    assert _e16(np.float32(0.3)) == "  0.30000001E+00"           # float32(0.3) = 0.300000011920929
+    assert _e16(-9.87654321e-5) == " -0.98765432E-04" and _e16(0.999999999) == "  0.10000000E+01"
+    assert all(len(_e16(v)) == 16 for v in (3.4e38, -1.17e-38, 123456.789))
+    text = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kipf_layer_card.txt")).read()
+    name, hp, w = parse_layer_card(text)
+    assert name == "kipf" and hp["NUM_VERTEX_FEATURES"] == "2 3 1" and hp["activation_name"] == "relu"
+    assert w.tolist() == [0.5, -0.25, 0.125, -0.75, 1.5, 2.0, 1.5, -0.03125, 0.125]
+    with pytest.raises(ValueError, match="Unrecognised line"):
+        parse_layer_card(text.replace("   NUM_TIME_STEPS = 2", "   what is this"))
