@@ -328,3 +328,47 @@ def build_kipf_step(shard, F, device, backend=None):
             "halo_rows_per_gpu": shard.n_halo, "halo_bytes_per_gpu_per_step": halo_bytes,
             "interior_rows_per_gpu": shard.n_int, "interior_entries_per_gpu": int(shard.adj_ia[shard.n_int]) - 1}
     return step, shard.nnz, info
+
+
+# --------------------------------------------------------------------------------------------------
+# data parallelism over independent graphs (Duvenaud / GNO mini-batches)
+# --------------------------------------------------------------------------------------------------
+def shard_graphs(graphs, rank, world):
+    """the graphs of a batch are the sharding unit: rank r takes graphs r, r + world, ... (no halo, no
+    collective on the data path); returns (its graphs, their positions in the batch)"""
+    pos = list(range(rank, len(graphs), world))
+    return [graphs[i] for i in pos], pos
+
+
+def allreduce_layer_gradients(layers):
+    """sum the parameter gradients of `layers` over all ranks in ONE bucketed all-reduce (the only collective a
+    batch of independent graphs needs: dW / dR of the Duvenaud layer, dtheta / dW / db of the GNO layer), then
+    hand each layer its slice back.  Gradients a rank did not produce count as zero."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    slots = [(l, i) for l in layers for i in range(len(l.params))]
+    if not slots:
+        return
+    flat = torch.cat([(l.grads[i] if l.grads[i] is not None else torch.zeros_like(l.params[i])).reshape(-1)
+                      for l, i in slots])
+    if _host_staged(flat):
+        h = flat.cpu()
+        dist.all_reduce(h)
+        flat.copy_(h)
+    else:
+        dist.all_reduce(flat)
+    off = 0
+    for l, i in slots:
+        n = l.params[i].numel()
+        l.grads[i] = flat[off:off + n].view_as(l.params[i]).clone()
+        off += n
+
+
+def gather_graph_outputs(local_out, positions, n_graphs):
+    """assemble the per-graph readout [batch, num_outputs] from the ranks' shards (rank r holds the rows
+    `positions`); every rank receives the full tensor"""
+    world = dist.get_world_size()
+    full = torch.zeros((n_graphs, local_out.shape[1]), dtype=local_out.dtype)
+    full[torch.as_tensor(positions, dtype=torch.long)] = local_out.detach().cpu()
+    dist.all_reduce(full)          # disjoint rows: the sum is the gather
+    return full.to(local_out.device) if world >= 1 else full
