@@ -72,6 +72,7 @@ int athena_mp_init(int device)
 
 int athena_mp_finalize(void)
 {
+    amp::host_pool_release();
     for (int s = 0; s < 8; ++s) {
         if (g_ws[s]) {
             AMP_HIP(hipFree(g_ws[s]));

@@ -98,6 +98,7 @@ namespace amp {
 int graph_build_device(athena_mp_graph *g, const int32_t *adj_ja, const std::vector<int32_t> &rowptr,
                        const std::vector<int32_t> &degr, const std::vector<int32_t> &degc,
                        std::vector<int32_t> *t_rowptr_host);
+void host_pool_release();   // staging buffers of the *_host entry points (host.hip)
 int agg_blocks_cap();
 void set_agg_blocks_cap(int n);
 // shared launchers (defined in agg.hip / gemm.hip)

@@ -16,14 +16,42 @@ struct Stage {
     void *dev = nullptr;
 };
 
-// allocates a device buffer per argument, uploads inputs, runs body(dev pointers), downloads outputs
+// Staging buffers are pooled per argument position (grown on demand, kept until athena_mp_finalize): a
+// hipMalloc / hipFree pair per argument costs more than the whole kernel for mini-batch sized inputs.
+constexpr int kMaxStaged = 12;
+void *g_pool[kMaxStaged] = {};
+size_t g_pool_bytes[kMaxStaged] = {};
+
+int pool_get(int slot, size_t bytes, void **out)
+{
+    if (bytes == 0) bytes = 4;
+    if (g_pool_bytes[slot] < bytes) {
+        if (g_pool[slot]) {
+            AMP_HIP(hipStreamSynchronize(stream()));
+            AMP_HIP(hipFree(g_pool[slot]));
+            g_pool[slot] = nullptr;
+            g_pool_bytes[slot] = 0;
+        }
+        const size_t want = bytes + bytes / 4;   // headroom so a slowly growing batch does not reallocate every call
+        AMP_HIP(hipMalloc(&g_pool[slot], want));
+        g_pool_bytes[slot] = want;
+    }
+    *out = g_pool[slot];
+    return 0;
+}
+
+// takes a pooled device buffer per argument, uploads inputs, runs body(dev pointers), downloads outputs
 template <typename Body> int staged(std::initializer_list<Stage> args, Body &&body)
 {
     std::vector<Stage> a(args);
-    int rc = 0;
+    if ((int)a.size() > kMaxStaged) {
+        set_error("host staging: too many arguments");
+        return 1;
+    }
+    int rc = 0, slot = 0;
     for (auto &s : a) {
-        if (hipMalloc(&s.dev, s.bytes ? s.bytes : 4) != hipSuccess) {
-            set_error("host staging: device allocation of %zu bytes failed", s.bytes);
+        if (pool_get(slot++, s.bytes, &s.dev)) {
+            if (rc == 0) set_error("host staging: device allocation of %zu bytes failed", s.bytes);
             rc = 1;
             break;
         }
@@ -51,14 +79,23 @@ template <typename Body> int staged(std::initializer_list<Stage> args, Body &&bo
     } else {
         (void)hipStreamSynchronize(stream());
     }
-    for (auto &s : a)
-        if (s.dev) (void)hipFree(s.dev);
     return rc;
 }
 
 inline size_t fb(int64_t rows, int64_t cols) { return sizeof(float) * (size_t)rows * (size_t)cols; }
 
 } // namespace
+
+namespace amp {
+void host_pool_release()
+{
+    for (int i = 0; i < kMaxStaged; ++i) {
+        if (g_pool[i]) (void)hipFree(g_pool[i]);
+        g_pool[i] = nullptr;
+        g_pool_bytes[i] = 0;
+    }
+}
+} // namespace amp
 
 extern "C" {
 
