@@ -25,6 +25,7 @@ module athena_mp_c
   public :: athena_mp_swish_fwd, athena_mp_swish_bwd, athena_mp_softmax_fwd, athena_mp_softmax_bwd
   public :: athena_mp_concat_fwd, athena_mp_concat_bwd
   public :: athena_mp_duvenaud_readout_fwd, athena_mp_duvenaud_readout_bwd, athena_mp_duvenaud_update_act_fwd
+  public :: athena_mp_kipf_layer_fwd, athena_mp_kipf_layer_bwd_x, athena_mp_activation_bwd
   public :: athena_mp_error_message
 
   interface
@@ -168,6 +169,27 @@ module athena_mp_c
        integer(c_int64_t), value :: N
        integer(c_int32_t), value :: Fi, Fo
        type(c_ptr), value :: dZ_dev, W_dev, dP_dev
+     end function
+
+     !! ---- one-launch Kipf layer step on device-resident arrays (update_message_kipf :943-952 and its reverse) ----
+     integer(c_int) function athena_mp_kipf_layer_fwd(graph, Fi, Fo, x_dev, W_dev, bias_dev, act, P_dev, Z_dev) &
+          bind(C, name="athena_mp_kipf_layer_fwd")
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: graph, x_dev, W_dev, bias_dev, P_dev, Z_dev
+       integer(c_int32_t), value :: Fi, Fo, act
+     end function
+     integer(c_int) function athena_mp_kipf_layer_bwd_x(graph, Fi, Fo, dZ_dev, W_dev, exact, dX_dev) &
+          bind(C, name="athena_mp_kipf_layer_bwd_x")
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: graph, dZ_dev, W_dev, dX_dev
+       integer(c_int32_t), value :: Fi, Fo, exact
+     end function
+     integer(c_int) function athena_mp_activation_bwd(act, n, y_dev, g_dev, dz_dev) &
+          bind(C, name="athena_mp_activation_bwd")
+       import :: c_int, c_int32_t, c_int64_t, c_ptr
+       integer(c_int32_t), value :: act
+       integer(c_int64_t), value :: n
+       type(c_ptr), value :: y_dev, g_dev, dz_dev
      end function
 
      !! ---- device-resident tail of a train step (network%update, athena_network_sub.f90:2816-2929) ----

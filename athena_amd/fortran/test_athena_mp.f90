@@ -21,6 +21,7 @@ program test_athena_mp
   call six_vertex_graph()
   call duvenaud_five_vertex_graph()
   call adam_update_resident()
+  call train_loop_resident()
 
   rc = athena_mp_finalize()
   if(success)then
@@ -77,6 +78,100 @@ contains
     call check(athena_mp_free(d_param), "free"); call check(athena_mp_free(d_grad), "free")
     call check(athena_mp_free(d_m), "free"); call check(athena_mp_free(d_v), "free")
   end subroutine adam_update_resident
+
+  subroutine train_loop_resident()
+    !! phase 2 of INTEGRATION.md from Fortran: everything stays in HBM across iterations --
+    !!   Z = tanh(W . kipf_propagate(X));  loss = mse(Z, Y);  dW = dZ . P^T;  Adam update of W
+    !! on the 6-vertex / 8-edge test graph, 25 iterations, against the same loop written out on the host with the
+    !! reference's statements (kipf_propagate :29-46, minimise_adam :1047-1087, compute_mse :414-415).
+    integer, parameter :: nv = 6, ne = 8, fi = 5, fo = 3, niter = 25
+    integer :: index_list(2,ne), deg(nv), pos(nv), v, w, e, u, i, o, iter
+    integer(c_int32_t) :: adj_ia(nv+1), adj_ja(2,2*ne)
+    real(real32) :: x(fi,nv), y(fo,nv), wm(fo*fi), wref(fo*fi), p(fi,nv), z(fo,nv), dz(fo,nv), dw(fo*fi)
+    real(real32) :: m(fo*fi), vv(fo*fi), coeff, loss_ref, loss_dev(1), loss_first, lr, b1, b2, eps, bc1, bc2
+    type(c_ptr) :: d_x, d_y, d_w, d_p, d_z, d_dl, d_dz, d_dw, d_m, d_v, d_loss, g2
+    lr = 0.05_real32; b1 = 0.9_real32; b2 = 0.999_real32; eps = 1.E-8_real32
+    index_list(:,1) = [1, 2]; index_list(:,2) = [1, 3]; index_list(:,3) = [2, 3]; index_list(:,4) = [2, 4]
+    index_list(:,5) = [3, 5]; index_list(:,6) = [4, 5]; index_list(:,7) = [4, 6]; index_list(:,8) = [5, 6]
+    deg = 0
+    do e = 1, ne
+       deg(index_list(1,e)) = deg(index_list(1,e)) + 1
+       deg(index_list(2,e)) = deg(index_list(2,e)) + 1
+    end do
+    adj_ia(1) = 1
+    do v = 1, nv
+       adj_ia(v+1) = adj_ia(v) + deg(v)
+    end do
+    pos = adj_ia(1:nv)
+    do e = 1, ne
+       u = index_list(1,e); v = index_list(2,e)
+       adj_ja(:,pos(u)) = [v, e]; pos(u) = pos(u) + 1
+       adj_ja(:,pos(v)) = [u, e]; pos(v) = pos(v) + 1
+    end do
+    do v = 1, nv
+       do i = 1, fi
+          x(i,v) = sin(real(i + 2*v, real32))
+       end do
+       do o = 1, fo
+          y(o,v) = 0.5_real32 * cos(real(o * v, real32))
+       end do
+    end do
+    do i = 1, fo*fi
+       wm(i) = 0.3_real32 * sin(real(3*i, real32))
+    end do
+    wref = wm
+    call check(athena_mp_graph_create(nv, nv, int(2*ne, c_int64_t), adj_ia, adj_ja, ne, c_null_ptr, c_null_ptr, g2), "graph")
+    call check(athena_mp_malloc(d_x, int(4*fi*nv, c_int64_t)), "malloc"); call check(athena_mp_malloc(d_y, int(4*fo*nv, c_int64_t)), "malloc")
+    call check(athena_mp_malloc(d_w, int(4*fo*fi, c_int64_t)), "malloc"); call check(athena_mp_malloc(d_p, int(4*fi*nv, c_int64_t)), "malloc")
+    call check(athena_mp_malloc(d_z, int(4*fo*nv, c_int64_t)), "malloc"); call check(athena_mp_malloc(d_dl, int(4*fo*nv, c_int64_t)), "malloc")
+    call check(athena_mp_malloc(d_dz, int(4*fo*nv, c_int64_t)), "malloc"); call check(athena_mp_malloc(d_dw, int(4*fo*fi, c_int64_t)), "malloc")
+    call check(athena_mp_malloc(d_m, int(4*fo*fi, c_int64_t)), "malloc"); call check(athena_mp_malloc(d_v, int(4*fo*fi, c_int64_t)), "malloc")
+    call check(athena_mp_malloc(d_loss, 4_c_int64_t), "malloc")
+    m = 0._real32; vv = 0._real32
+    call check(athena_mp_memcpy_h2d(d_x, x, int(4*fi*nv, c_int64_t)), "h2d"); call check(athena_mp_memcpy_h2d(d_y, y, int(4*fo*nv, c_int64_t)), "h2d")
+    call check(athena_mp_memcpy_h2d(d_w, wm, int(4*fo*fi, c_int64_t)), "h2d")
+    call check(athena_mp_memcpy_h2d(d_m, m, int(4*fo*fi, c_int64_t)), "h2d"); call check(athena_mp_memcpy_h2d(d_v, vv, int(4*fo*fi, c_int64_t)), "h2d")
+    do iter = 1, niter
+       ! ---- device: five launches, nothing copied ----
+       call check(athena_mp_kipf_layer_fwd(g2, fi, fo, d_x, d_w, c_null_ptr, ATHENA_MP_ACT_TANH, d_p, d_z), "layer_fwd")
+       call check(athena_mp_mse_loss(int(fo*nv, c_int64_t), d_z, d_y, d_loss, d_dl), "mse")
+       call check(athena_mp_activation_bwd(ATHENA_MP_ACT_TANH, int(fo*nv, c_int64_t), d_z, d_dl, d_dz), "act_bwd")
+       call check(athena_mp_gemm_dw(int(nv, c_int64_t), fi, fo, d_p, d_dz, d_dw), "gemm_dw")
+       call check(athena_mp_adam_step(int(fo*fi, c_int64_t), lr, b1, b2, eps, int(iter, c_int32_t), 0_c_int32_t, &
+            0._c_float, 0._c_float, 0_c_int32_t, d_w, d_dw, d_m, d_v), "adam")
+       ! ---- host: the reference's statements ----
+       do v = 1, nv
+          p(:,v) = 0._real32
+          do w = adj_ia(v), adj_ia(v+1)-1
+             coeff = ( ( adj_ia(v+1) - adj_ia(v) ) * &
+                  ( adj_ia( adj_ja(1,w) + 1 ) - adj_ia( adj_ja(1,w) ) ) ) ** ( -0.5_real32 )
+             p(:,v) = p(:,v) + coeff * x(:, adj_ja(1,w))
+          end do
+       end do
+       z = tanh(matmul(reshape(wref, [fo, fi]), p))
+       loss_ref = sum((z - y)**2) / real(fo*nv, real32) / 2._real32
+       dz = (z - y) / real(fo*nv, real32) * (1._real32 - z*z)
+       dw = reshape(matmul(dz, transpose(p)), [fo*fi])
+       if(iter .eq. 1) loss_first = loss_ref
+       m = b1 * m + (1._real32 - b1) * dw
+       vv = b2 * vv + (1._real32 - b2) * dw * dw
+       bc1 = 1._real32 - b1**iter
+       bc2 = 1._real32 - b2**iter
+       wref = wref - lr * ( (m / bc1) / (sqrt(vv / bc2) + eps) )
+    end do
+    call check(athena_mp_memcpy_d2h(wm, d_w, int(4*fo*fi, c_int64_t)), "d2h")
+    call check(athena_mp_memcpy_d2h(loss_dev, d_loss, 4_c_int64_t), "d2h")
+    if(maxval(abs(wm - wref)) .gt. 2.E-4_real32 * maxval(abs(wref)) .or. &
+         abs(loss_dev(1) - loss_ref) .gt. 1.E-4_real32 * loss_ref .or. loss_ref .ge. loss_first)then
+       write(0,*) "train_loop_resident: mismatch", maxval(abs(wm - wref)), loss_dev(1), loss_ref, loss_first
+       success = .false.
+    end if
+    call check(athena_mp_graph_destroy(g2), "destroy")
+    call check(athena_mp_free(d_x), "free"); call check(athena_mp_free(d_y), "free"); call check(athena_mp_free(d_w), "free")
+    call check(athena_mp_free(d_p), "free"); call check(athena_mp_free(d_z), "free"); call check(athena_mp_free(d_dl), "free")
+    call check(athena_mp_free(d_dz), "free"); call check(athena_mp_free(d_dw), "free"); call check(athena_mp_free(d_m), "free")
+    call check(athena_mp_free(d_v), "free"); call check(athena_mp_free(d_loss), "free")
+  end subroutine train_loop_resident
 
   subroutine check(rc, what)
     integer(c_int), intent(in) :: rc
