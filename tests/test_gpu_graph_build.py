@@ -87,3 +87,33 @@ def test_default_choice_builds_large_graphs_on_the_device_with_identical_results
     a = _build("host", ia, ja, n_edge_cols=0)
     b = DeviceGraph(ia, ja, n_edge_cols=0)
     _same(a, b)
+
+
+def test_graph_handles_do_not_leak_device_memory(dev):
+    """create / use / destroy many handles with both builders (incl. the lazily built bucket tiles and
+    length-sorted row orders): free device memory returns to where it started"""
+    import torch
+    from athena_amd import ops
+
+    ia, ja = random_graph(30000, 120000, seed=9, self_loops=True, isolated=5)
+    E = int(ja[1].max())
+    x = torch.rand((30000, 64), device=dev)
+    e = torch.rand((E, 8), device=dev)
+    w = torch.rand(64 * 72 * 4, device=dev)
+
+    def cycle(mode):
+        g = _build(mode, ia, ja, n_edge_cols=E)
+        ops.kipf_propagate(g, x)
+        a = ops.duvenaud_propagate(g, x, e)
+        ops.duvenaud_update_act(g, a, w, 1, 4, 64, act="sigmoid")      # builds the bucket tiles
+        g.close()
+
+    for mode in ("host", "device"):
+        cycle(mode)                                                    # warm: workspaces, pools
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(40):
+        cycle("host"); cycle("device")
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 8 << 20, f"{(free0 - free1) >> 20} MiB of device memory lost over 80 graph handles"
