@@ -53,9 +53,22 @@ def cpu_baseline(ia, ja, x, w, dz, F, sample_rows):
     dx = oracle.kipf_propagate_bwd(dp, sia, sja, n_out=n)
     t = time.perf_counter() - t0
     del z, dw, dx
-    return {"value": ent / t, "unit": "edges/s", "cores": 1, "kind": "port",
-            "sample": f"oracle (C port of the reference loops), first {rows} of {n} rows = {ent} of {ja.shape[1]} entries, "
-                      f"full fwd+bwd step, {t:.1f} s on {os.cpu_count()}-core host, 1 thread"}
+    out = {"value": ent / t, "unit": "edges/s", "cores": 1, "kind": "port",
+           "sample": f"oracle (C port of the reference loops), first {rows} of {n} rows = {ent} of {ja.shape[1]} entries, "
+                     f"full fwd+bwd step, {t:.1f} s on {os.cpu_count()}-core host, 1 thread"}
+    # context only: the same step threaded over rows on ALL host cores.  The reference itself has no
+    # threading, so the single-thread figure above is the baseline; this one shows what the whole socket pair reaches.
+    try:
+        best = None
+        for _ in range(3):
+            *_, dt, threads = oracle.omp_kipf_step(x, w, dz, ia, ja)
+            best = dt if best is None else min(best, dt)
+        out["all_cores_context"] = {"value": ja.shape[1] / best, "unit": "edges/s", "cores": threads,
+                                    "kind": "port, OpenMP over rows, pull-form backward (not the reference's algorithm)",
+                                    "sample": f"whole workload, best of 3, {best * 1e3:.0f} ms"}
+    except Exception as exc:   # no OpenMP runtime on the host: the contract fields above are complete without it
+        out["all_cores_context"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+    return out
 
 
 def main():

@@ -340,3 +340,45 @@ def concat(a, b):
     out = np.empty((a.shape[0], a.shape[1] + b.shape[1]), np.float32)
     lib().oracle_concat(C.c_int(a.shape[0]), C.c_int(a.shape[1]), C.c_int(b.shape[1]), pa, pb, out.ctypes.data_as(C.c_void_p))
     return out
+
+
+# ---- all-cores context number (athena_oracle_omp.c; measurement aid of bench.py's cpu_baseline leg) ---------
+_LIB_OMP = None
+
+
+def lib_omp():
+    global _LIB_OMP
+    if _LIB_OMP is None:
+        so = os.path.join(_HERE, "liboracle_omp.so")
+        src = os.path.join(_HERE, "athena_oracle_omp.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle_omp.so"], stdout=subprocess.DEVNULL)
+        _LIB_OMP = C.CDLL(so)
+    return _LIB_OMP
+
+
+def omp_kipf_step(x, W, dz, adj_ia, adj_ja):
+    """one Kipf layer fwd+bwd step threaded over rows (pull-form backward); returns
+    (P, Z, dW, dX, seconds of the timed call, threads).  The transposed CSR and the coefficients are prepared
+    outside the timed call."""
+    import time
+    x, px = _f(x); W, pW = _f(W); dz, pdz = _f(dz)
+    ia = np.ascontiguousarray(adj_ia, np.int32)
+    N, F = x.shape
+    rowptr = (ia - 1).astype(np.int32)
+    col = np.ascontiguousarray(np.asarray(adj_ja)[0] - 1, dtype=np.int32)
+    deg = np.diff(ia).astype(np.int64)
+    rows = np.repeat(np.arange(N, dtype=np.int64), deg)
+    coef = np.power((deg[rows] * deg[col]).astype(np.float32), np.float32(-0.5)).astype(np.float32)
+    order = np.argsort(col, kind="stable")                     # sources ascending inside each transposed row
+    t_src = rows[order].astype(np.int32)
+    t_rowptr = np.concatenate([[0], np.cumsum(np.bincount(col, minlength=N))]).astype(np.int32)
+    P = np.empty((N, F), np.float32); Z = np.empty((N, F), np.float32); dP = np.empty((N, F), np.float32)
+    dX = np.empty((N, F), np.float32); dW = np.empty(F * F, np.float32)
+    L = lib_omp()
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    t0 = time.perf_counter()
+    L.oracle_omp_kipf_step(C.c_int(N), C.c_int(F), vp(rowptr), vp(col), vp(coef), vp(t_rowptr), vp(t_src), px, pW, pdz,
+                           vp(P), vp(Z), vp(dW), vp(dP), vp(dX))
+    dt = time.perf_counter() - t0
+    return P, Z, dW, dX, dt, int(L.oracle_omp_threads())

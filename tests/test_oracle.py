@@ -265,3 +265,20 @@ def test_update_step_restatements_against_float64_closed_forms(oracle):
     f.restype = C.c_float
     for it in (1, 2, 3, 10, 1000):
         assert abs(f(C.c_float(0.999), C.c_int(it)) - 0.999 ** it) < 1e-5
+
+
+def test_threaded_context_baseline_equals_the_single_thread_oracle(oracle):
+    """athena_oracle_omp.c (bench.py's all-cores context number): same step, rows shared out over threads"""
+    rng = np.random.default_rng(21)
+    n, F = 700, 16
+    ia, ja = random_graph(n, 2500, seed=21, self_loops=True, isolated=4)
+    x = rng.uniform(-1, 1, (n, F)).astype(np.float32)
+    w = rng.standard_normal(F * F).astype(np.float32) * 0.3
+    dz = rng.uniform(-1, 1, (n, F)).astype(np.float32)
+    P, Z, dW, dX, dt, threads = oracle.omp_kipf_step(x, w, dz, ia, ja)
+    Pr = oracle.kipf_propagate(x, ia, ja)
+    assert np.allclose(P, Pr, rtol=1e-6, atol=1e-7)          # numpy's float32 power vs libm powf: <= 1 ulp on coefficients
+    assert np.allclose(Z, oracle.matmul(w, Pr, F), rtol=1e-5, atol=1e-6)
+    assert np.allclose(dW, oracle.matmul_dw(dz, Pr), rtol=1e-4, atol=1e-5)
+    assert np.allclose(dX, oracle.kipf_propagate_bwd(oracle.matmul_dx(w, dz, F), ia, ja), rtol=1e-5, atol=1e-6)
+    assert threads >= 1 and dt > 0
