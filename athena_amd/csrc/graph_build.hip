@@ -281,3 +281,150 @@ int graph_build_device(athena_mp_graph *g, const int32_t *adj_ja, const std::vec
 }
 
 } // namespace amp
+
+// ---------------------------------------------------------------------------------------------------------------
+// Edge list -> athena's CSR on the device: what graphstruc's generate_adjacency (+ add_self_loops)
+// hands to the layers, for callers that hold pairs (radius graphs, mesh connectivity).  Conventions of the host
+// mirror athena_amd/graph.py (which the tests compare against, element for element):
+//   * edge e (1-based column of index_list) contributes (u -> v, id e) and (v -> u, id e); a self edge u == v one entry;
+//   * add_self_loops adds (v, v, id 0) for every vertex without a self entry;
+//   * inside a row the entries are ordered by edge id, self-loop entries without an id first.
+// One radix sort of 64-bit keys  src * (E + 2) + (id + 1 for edges | 0 for an added loop)  does all of it.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ void edge_entries_kernel(int64_t E, const int32_t *__restrict__ pairs /* [2,E] column-major, 1-based */,
+                                    int32_t n, unsigned long long stride, unsigned long long *__restrict__ keys,
+                                    int32_t *__restrict__ dst, int32_t *__restrict__ has_loop,
+                                    unsigned long long *__restrict__ bad)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int32_t u = pairs[2 * e] - 1, v = pairs[2 * e + 1] - 1;
+    if (u < 0 || u >= n || v < 0 || v >= n) {
+        atomicMin(bad, (unsigned long long)e);
+        keys[2 * e] = keys[2 * e + 1] = ~0ull;
+        return;
+    }
+    keys[2 * e] = (unsigned long long)u * stride + (unsigned long long)(e + 2);
+    dst[2 * e] = v;
+    if (u == v) {
+        keys[2 * e + 1] = ~0ull;          // a self edge is one entry
+        has_loop[u] = 1;
+    } else {
+        keys[2 * e + 1] = (unsigned long long)v * stride + (unsigned long long)(e + 2);
+        dst[2 * e + 1] = u;
+    }
+}
+
+__global__ void loop_entries_kernel(int32_t n, int add, unsigned long long stride, const int32_t *__restrict__ has_loop,
+                                    unsigned long long *__restrict__ keys, int32_t *__restrict__ dst)
+{
+    const int32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const bool need = add && !has_loop[v];
+    keys[v] = need ? (unsigned long long)v * stride + 1ull : ~0ull;   // key 1: before every edge id (>= 2)
+    dst[v] = v;
+}
+
+// adj_ia (1-based) from the sorted keys; adj_ja[2, nnz] (1-based neighbour, edge id with 0 = none)
+__global__ void csr_rows_kernel(int32_t n, const unsigned long long *__restrict__ sorted, int64_t total,
+                                unsigned long long stride, int32_t *__restrict__ adj_ia)
+{
+    const int32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v > n) return;
+    const unsigned long long key = (unsigned long long)v * stride;
+    int64_t lo = 0, hi = total;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (sorted[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    adj_ia[v] = (int32_t)lo + 1;
+}
+
+__global__ void csr_entries_kernel(int64_t nnz, const unsigned long long *__restrict__ sorted,
+                                   const int32_t *__restrict__ dst_sorted, unsigned long long stride,
+                                   int32_t *__restrict__ adj_ja)
+{
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nnz) return;
+    const unsigned long long low = sorted[w] % stride;      // 1 = added self loop (id 0), e + 2 for edge e (id e + 1)
+    adj_ja[2 * w] = dst_sorted[w] + 1;
+    adj_ja[2 * w + 1] = low <= 1 ? 0 : (int32_t)(low - 1);
+}
+
+} // namespace
+
+extern "C" int athena_mp_csr_from_edges(int32_t n_vertices, int64_t n_pairs, const int32_t *index_list,
+                                        int32_t add_self_loops, int32_t *adj_ia_out, int32_t *adj_ja_out,
+                                        int64_t capacity, int64_t *nnz_out)
+{
+    using namespace amp;
+    AMP_REQUIRE(n_vertices >= 0 && n_pairs >= 0 && nnz_out && adj_ia_out && (n_pairs == 0 || index_list),
+                "csr_from_edges: bad arguments");
+    AMP_REQUIRE(2 * n_pairs + n_vertices < (int64_t)INT32_MAX, "csr_from_edges: more than 2^31 CSR entries");
+    hipStream_t st = stream();
+    const int64_t total = 2 * n_pairs + n_vertices;
+    const unsigned long long stride = (unsigned long long)n_pairs + 2;
+    Scratch tmp;
+    int32_t *d_pairs = nullptr, *d_dst = nullptr, *d_dst_s = nullptr, *d_loop = nullptr, *d_ia = nullptr, *d_ja = nullptr;
+    unsigned long long *d_keys = nullptr, *d_keys_s = nullptr, *d_bad = nullptr;
+    if (tmp.get(&d_pairs, 2 * (size_t)n_pairs) || tmp.get(&d_dst, total) || tmp.get(&d_dst_s, total) ||
+        tmp.get(&d_loop, n_vertices) || tmp.get(&d_ia, (size_t)n_vertices + 1) || tmp.get(&d_keys, total) ||
+        tmp.get(&d_keys_s, total) || tmp.get(&d_bad, 1))
+        return 1;
+    const unsigned long long none = ~0ull;
+    AMP_HIP(hipMemcpyAsync(d_bad, &none, sizeof(none), hipMemcpyHostToDevice, st));
+    AMP_HIP(hipMemsetAsync(d_loop, 0, sizeof(int32_t) * (size_t)std::max(n_vertices, 1), st));
+    if (n_pairs > 0) {
+        AMP_HIP(hipMemcpyAsync(d_pairs, index_list, sizeof(int32_t) * 2 * (size_t)n_pairs, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(edge_entries_kernel, dim3(blocks(n_pairs)), dim3(256), 0, st, n_pairs, (const int32_t *)d_pairs,
+                           n_vertices, stride, d_keys, d_dst, d_loop, d_bad);
+        AMP_LAUNCH_CHECK();
+    }
+    if (n_vertices > 0) {
+        hipLaunchKernelGGL(loop_entries_kernel, dim3(blocks(n_vertices)), dim3(256), 0, st, n_vertices, add_self_loops,
+                           stride, (const int32_t *)d_loop, d_keys + 2 * n_pairs, d_dst + 2 * n_pairs);
+        AMP_LAUNCH_CHECK();
+    }
+    unsigned long long bad = none;
+    AMP_HIP(hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, st));
+    AMP_HIP(hipStreamSynchronize(st));
+    if (bad != none) {
+        set_error("csr_from_edges: index_list(:,%llu) = (%d, %d) outside [1,%d]", bad + 1, index_list[2 * bad],
+                  index_list[2 * bad + 1], n_vertices);
+        return 2;
+    }
+    int64_t nnz = 0;
+    if (total > 0) {
+        size_t temp_bytes = 0;
+        void *d_temp = nullptr;
+        AMP_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, (const unsigned long long *)d_keys, d_keys_s,
+                                                   (const int32_t *)d_dst, d_dst_s, (int)total, 0, 64, st));
+        if (tmp.get((char **)&d_temp, temp_bytes)) return 1;
+        AMP_HIP(hipcub::DeviceRadixSort::SortPairs(d_temp, temp_bytes, (const unsigned long long *)d_keys, d_keys_s,
+                                                   (const int32_t *)d_dst, d_dst_s, (int)total, 0, 64, st));
+        hipLaunchKernelGGL(csr_rows_kernel, dim3(blocks((int64_t)n_vertices + 1)), dim3(256), 0, st, n_vertices,
+                           (const unsigned long long *)d_keys_s, total, stride, d_ia);
+        AMP_LAUNCH_CHECK();
+    } else {
+        const int32_t one = 1;
+        AMP_HIP(hipMemcpyAsync(d_ia, &one, sizeof(one), hipMemcpyHostToDevice, st));
+    }
+    AMP_HIP(hipMemcpyAsync(adj_ia_out, d_ia, sizeof(int32_t) * ((size_t)n_vertices + 1), hipMemcpyDeviceToHost, st));
+    AMP_HIP(hipStreamSynchronize(st));
+    nnz = (int64_t)adj_ia_out[n_vertices] - 1;     // invalid slots carry the all-ones key and sort behind every row
+    *nnz_out = nnz;
+    if (adj_ja_out == nullptr) return 0;             // size query
+    AMP_REQUIRE(capacity >= nnz, "csr_from_edges: adj_ja buffer holds %lld entries, the graph has %lld", (long long)capacity,
+                (long long)nnz);
+    if (nnz > 0) {
+        if (tmp.get(&d_ja, 2 * (size_t)nnz)) return 1;
+        hipLaunchKernelGGL(csr_entries_kernel, dim3(blocks(nnz)), dim3(256), 0, st, nnz, (const unsigned long long *)d_keys_s,
+                           (const int32_t *)d_dst_s, stride, d_ja);
+        AMP_LAUNCH_CHECK();
+        AMP_HIP(hipMemcpyAsync(adj_ja_out, d_ja, sizeof(int32_t) * 2 * (size_t)nnz, hipMemcpyDeviceToHost, st));
+        AMP_HIP(hipStreamSynchronize(st));
+    }
+    return 0;
+}

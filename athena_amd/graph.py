@@ -63,6 +63,24 @@ class graph_type:
             src, dst, eid = src[keep], dst[keep], eid[keep]
         self._from_entries(src, dst, eid)
 
+    def generate_adjacency_device(self, index_list, add_self_loops=False):
+        """generate_adjacency (+ add_self_loops) on the GPU: same arrays as the host methods, built by one radix sort
+        (athena_mp_csr_from_edges); for edge lists of millions of pairs"""
+        idx = np.asfortranarray(np.asarray(index_list, dtype=np.int32))
+        assert idx.ndim == 2 and idx.shape[0] == 2
+        E = idx.shape[1]
+        if self.num_edges == 0:
+            self.num_edges = E
+        _capi.init(0)
+        ia = np.empty(self.num_vertices + 1, np.int32)
+        nnz = C.c_int64()
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        _capi.call("athena_mp_csr_from_edges", self.num_vertices, E, vp(idx), int(add_self_loops), vp(ia), None, 0, C.byref(nnz))
+        ja = np.empty((2, nnz.value), np.int32, order="F")
+        _capi.call("athena_mp_csr_from_edges", self.num_vertices, E, vp(idx), int(add_self_loops), vp(ia), vp(ja), nnz.value,
+                   C.byref(nnz))
+        self.adj_ia, self.adj_ja = ia, ja
+
     def add_self_loops(self):
         """A~ = A + I: one entry (v, v) with edge id 0 per vertex that has none."""
         rows = np.repeat(np.arange(1, self.num_vertices + 1), np.diff(self.adj_ia))

@@ -72,6 +72,14 @@ int athena_mp_memset_zero(void *dev_ptr, uint64_t bytes);
 int athena_mp_graph_create(int32_t n_rows, int32_t n_cols, int64_t nnz, const int32_t *adj_ia,
                            const int32_t *adj_ja, int32_t n_edge_cols, const int32_t *row_deg,
                            const int32_t *col_deg, athena_mp_graph **out);
+/* Edge list -> athena's CSR on the device (what graphstruc's generate_adjacency [+ add_self_loops] produces, in the
+ * conventions of SURVEY.md Appendix C): index_list [2, n_pairs] column-major, 1-based vertex pairs, edge id = column.
+ * Each pair gives (u -> v, id) and (v -> u, id); a self pair one entry; add_self_loops adds (v, v, id 0) where missing;
+ * inside a row entries are ordered by edge id, id-less self loops first.  adj_ia_out [n_vertices+1] (1-based),
+ * adj_ja_out [2, nnz] column-major; pass adj_ja_out = NULL to query *nnz_out first. */
+int athena_mp_csr_from_edges(int32_t n_vertices, int64_t n_pairs, const int32_t *index_list_host,
+                             int32_t add_self_loops, int32_t *adj_ia_out_host, int32_t *adj_ja_out_host,
+                             int64_t capacity, int64_t *nnz_out);
 /* Copies one array of the handle back to the host (4-byte elements; 0-based indices): which =
  * 0 rowptr, 1 col, 2 eid, 3 coef, 4 t_rowptr, 5 t_src, 6 t_eid, 7 t_coef (transposed CSR: the pull form of the
  * reference's scatters), 8 e_rowptr, 9 e_row, 10 e_entry (edge-column index), 11 deg_row, 12 deg_col.

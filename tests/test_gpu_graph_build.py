@@ -117,3 +117,32 @@ def test_graph_handles_do_not_leak_device_memory(dev):
     torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < 8 << 20, f"{(free0 - free1) >> 20} MiB of device memory lost over 80 graph handles"
+
+
+@pytest.mark.parametrize("n,E,loops", [(1, 0, True), (7, 5, False), (300, 900, True), (5000, 40000, True), (5000, 40000, False),
+                                       (100000, 450000, True)])
+def test_edge_list_to_csr_on_the_device_equals_the_host_mirror(dev, n, E, loops):
+    """generate_adjacency (+ add_self_loops) built by one device radix sort == athena_amd.graph.graph_type's host
+    methods, element for element: self pairs (one entry), duplicate pairs, isolated vertices, vertices that
+    already carry a self edge (no second loop), id-less loops first inside a row"""
+    from athena_amd import _capi
+    from athena_amd.graph import graph_type
+
+    rng = np.random.default_rng(n + E)
+    idx = rng.integers(1, n + 1, (2, E)).astype(np.int64)
+    if E >= 5:
+        idx[:, 0] = [3, 3] if n >= 3 else [1, 1]          # a self pair
+        idx[:, 1] = idx[:, 2]                              # a duplicate pair
+    h = graph_type(); h.set_num_vertices(n, 1); h.generate_adjacency(idx)
+    d = graph_type(); d.set_num_vertices(n, 1); d.generate_adjacency_device(idx, add_self_loops=False)
+    assert np.array_equal(h.adj_ia, d.adj_ia) and np.array_equal(h.adj_ja, d.adj_ja)
+    if loops:
+        h.add_self_loops()
+        d2 = graph_type(); d2.set_num_vertices(n, 1); d2.generate_adjacency_device(idx, add_self_loops=True)
+        assert np.array_equal(h.adj_ia, d2.adj_ia) and np.array_equal(h.adj_ja, d2.adj_ja)
+        assert d2.nnz == h.nnz
+    bad = idx.copy()
+    if E:
+        bad[1, E // 2] = n + 5
+        with pytest.raises(_capi.AthenaMPError, match=r"index_list\(:,%d\)" % (E // 2 + 1)):
+            graph_type_dev = graph_type(); graph_type_dev.set_num_vertices(n, 1); graph_type_dev.generate_adjacency_device(bad)
