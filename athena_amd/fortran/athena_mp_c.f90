@@ -26,6 +26,7 @@ module athena_mp_c
   public :: athena_mp_concat_fwd, athena_mp_concat_bwd
   public :: athena_mp_duvenaud_readout_fwd, athena_mp_duvenaud_readout_bwd, athena_mp_duvenaud_update_act_fwd
   public :: athena_mp_kipf_layer_fwd, athena_mp_kipf_layer_bwd_x, athena_mp_activation_bwd
+  public :: athena_mp_csr_from_edges, athena_mp_graph_export
   public :: athena_mp_error_message
 
   interface
@@ -169,6 +170,27 @@ module athena_mp_c
        integer(c_int64_t), value :: N
        integer(c_int32_t), value :: Fi, Fo
        type(c_ptr), value :: dZ_dev, W_dev, dP_dev
+     end function
+
+     !! edge list -> CSR on the device (graphstruc's generate_adjacency [+ add_self_loops]); adj_ja = c_null_ptr queries nnz
+     integer(c_int) function athena_mp_csr_from_edges(n_vertices, n_pairs, index_list, add_self_loops, adj_ia, &
+          adj_ja, capacity, nnz) bind(C, name="athena_mp_csr_from_edges")
+       import :: c_int, c_int32_t, c_int64_t, c_ptr
+       integer(c_int32_t), value :: n_vertices, add_self_loops
+       integer(c_int64_t), value :: n_pairs, capacity
+       integer(c_int32_t), intent(in) :: index_list(2,*)
+       integer(c_int32_t), intent(inout) :: adj_ia(*)
+       type(c_ptr), value :: adj_ja                     !! c_loc of an integer(c_int32_t) adj_ja(2,capacity) target
+       integer(c_int64_t), intent(out) :: nnz
+     end function
+     !! one array of the handle back on the host (which: see include/athena_mp.h); host_dst = c_null_ptr queries count
+     integer(c_int) function athena_mp_graph_export(graph, which, host_dst, capacity, count) &
+          bind(C, name="athena_mp_graph_export")
+       import :: c_int, c_int32_t, c_int64_t, c_ptr
+       type(c_ptr), value :: graph, host_dst
+       integer(c_int32_t), value :: which
+       integer(c_int64_t), value :: capacity
+       integer(c_int64_t), intent(out) :: count
      end function
 
      !! ---- one-launch Kipf layer step on device-resident arrays (update_message_kipf :943-952 and its reverse) ----

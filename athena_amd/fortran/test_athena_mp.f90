@@ -22,6 +22,7 @@ program test_athena_mp
   call duvenaud_five_vertex_graph()
   call adam_update_resident()
   call train_loop_resident()
+  call csr_from_edges_on_device()
 
   rc = athena_mp_finalize()
   if(success)then
@@ -172,6 +173,39 @@ contains
     call check(athena_mp_free(d_dz), "free"); call check(athena_mp_free(d_dw), "free"); call check(athena_mp_free(d_m), "free")
     call check(athena_mp_free(d_v), "free"); call check(athena_mp_free(d_loss), "free")
   end subroutine train_loop_resident
+
+  subroutine csr_from_edges_on_device()
+    !! the 6-vertex / 8-edge list of test_kipf_msgpass_layer.f90:83-90 -> CSR with self loops, built on the GPU
+    integer, parameter :: nv = 6, ne = 8
+    integer(c_int32_t) :: index_list(2,ne), adj_ia(nv+1)
+    integer(c_int32_t), target :: adj_ja(2, 2*ne + nv)
+    integer(c_int64_t) :: nnz
+    integer :: v, w, nself
+    index_list(:,1) = [1, 2]; index_list(:,2) = [1, 3]; index_list(:,3) = [2, 3]; index_list(:,4) = [2, 4]
+    index_list(:,5) = [3, 5]; index_list(:,6) = [4, 5]; index_list(:,7) = [4, 6]; index_list(:,8) = [5, 6]
+    call check(athena_mp_csr_from_edges(nv, int(ne, c_int64_t), index_list, 1_c_int32_t, adj_ia, c_null_ptr, &
+         0_c_int64_t, nnz), "csr_from_edges (size query)")
+    if(nnz .ne. 2*ne + nv)then
+       write(0,*) "csr_from_edges: nnz", nnz; success = .false.; return
+    end if
+    call check(athena_mp_csr_from_edges(nv, int(ne, c_int64_t), index_list, 1_c_int32_t, adj_ia, c_loc(adj_ja), &
+         int(size(adj_ja,2), c_int64_t), nnz), "csr_from_edges")
+    nself = 0
+    do v = 1, nv
+       if(adj_ja(1, adj_ia(v)) .ne. v .or. adj_ja(2, adj_ia(v)) .ne. 0) success = .false.   ! the id-less self loop comes first
+       do w = adj_ia(v), adj_ia(v+1) - 1
+          if(adj_ja(1,w) .eq. v) nself = nself + 1
+          if(w .gt. adj_ia(v) + 1)then
+             if(adj_ja(2,w) .le. adj_ja(2,w-1)) success = .false.                          ! then ascending edge ids
+          end if
+       end do
+    end do
+    if(adj_ia(1) .ne. 1 .or. adj_ia(nv+1) .ne. nnz + 1 .or. nself .ne. nv .or. adj_ia(3) - adj_ia(2) .ne. 4)then
+       write(0,*) "csr_from_edges: structure differs", adj_ia, nself
+       success = .false.
+    end if
+    if(.not. success) write(0,*) "csr_from_edges_on_device failed"
+  end subroutine csr_from_edges_on_device
 
   subroutine check(rc, what)
     integer(c_int), intent(in) :: rc
