@@ -55,8 +55,11 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(amp::TiledArgs p)
     __shared__ __attribute__((aligned(16))) float As[BMT * LDT];
     __shared__ __attribute__((aligned(16))) float Bs[BN * LDT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r31 = lane & 31, h = lane >> 5;
-    const int64_t m0 = (int64_t)blockIdx.x * BMT;
-    const int n0 = blockIdx.y * BN;
+    // column block fastest: the workgroups that run together write neighbouring pieces of the SAME C rows (whole
+    // DRAM pages instead of one 256 B piece per 4*N-byte row pitch) and share their A tile through L2
+    const int ncb = (p.N + BN - 1) / BN;
+    const int64_t m0 = (int64_t)(blockIdx.x / ncb) * BMT;
+    const int n0 = (int)(blockIdx.x % ncb) * BN;
     const bool a_vec = (p.lda % 4 == 0) && ((uintptr_t)p.A % 16 == 0);
     const bool b_vec = (p.ldb % 4 == 0) && ((uintptr_t)p.B % 16 == 0);
 
@@ -164,6 +167,84 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(amp::TiledArgs p)
         }
 }
 
+// ---- short contraction, very wide output:  C[M, N] = A[M, 64] . B^T,  B stored [N][64],  N >> 64 ------------------
+// (GNO: G = g . Vmat^T with N = H*F_in = 4096.)  The generic kernel above spends most of such a launch outside the
+// matrix pipe -- two k-iterations per 256 x 64 tile, 32 k workgroups whose first load nothing hides.  Here a workgroup
+// keeps its 128 rows of A in LDS and walks all column blocks: B blocks (16 KB, L2) are fetched one block ahead into
+// registers, one barrier per block, and the workgroup writes whole C rows piece by piece (DRAM pages stay open).
+constexpr int AR_K = 64, AR_LD = AR_K + 4, AR_BM = 128;
+
+__global__ __launch_bounds__(256) void gemm_arow_kernel(const float *__restrict__ A, const float *__restrict__ B,
+                                                        float *__restrict__ C, int64_t M, int N)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *As = sm;                       // [128][68]
+    float *Bs = sm + AR_BM * AR_LD;       // [2][64][68]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r31 = lane & 31, h = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.x * AR_BM;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {      // A tile: 128 rows x 16 float4
+        const int t = it * 256 + tid, row = t >> 4, q = t & 15;
+        v4f v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (m0 + row < M) v = *reinterpret_cast<const v4f *>(A + (m0 + row) * AR_K + 4 * q);
+        *reinterpret_cast<v4f *>(As + row * AR_LD + 4 * q) = v;
+    }
+    v4f rb[4];
+    auto load_b = [&](int nb) {           // B block: 64 rows (n) x 16 float4
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int t = it * 256 + tid, n = t >> 4, q = t & 15;
+            rb[it] = *reinterpret_cast<const v4f *>(B + ((size_t)nb * 64 + n) * AR_K + 4 * q);
+        }
+    };
+    auto store_b = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int t = it * 256 + tid;
+            *reinterpret_cast<v4f *>(Bs + (buf * 64 + (t >> 4)) * AR_LD + 4 * (t & 15)) = rb[it];
+        }
+    };
+    const int n_blocks = N / 64;
+    load_b(0);
+    store_b(0);
+    __syncthreads();
+    for (int nb = 0; nb < n_blocks; ++nb) {
+        const int buf = nb & 1;
+        if (nb + 1 < n_blocks) load_b(nb + 1);     // in flight under this block's MFMAs
+        f32x16 acc[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
+        const float *arow = As + (32 * wave + r31) * AR_LD + 16 * h;
+        const float *brow = Bs + (buf * 64 + r31) * AR_LD + 16 * h;
+#pragma unroll
+        for (int kc = 0; kc < AR_K; kc += 32)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const v4f a4 = *reinterpret_cast<const v4f *>(arow + kc + 4 * q);
+                const v4f b0 = *reinterpret_cast<const v4f *>(brow + kc + 4 * q);
+                const v4f b1 = *reinterpret_cast<const v4f *>(brow + 32 * AR_LD + kc + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b0[e], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b1[e], acc[1], 0, 0, 0);
+                }
+            }
+        if (nb + 1 < n_blocks) store_b(buf ^ 1);   // the other buffer was last read one barrier ago
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int col = nb * 64 + 32 * c + r31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < M) C[m * N + col] = acc[c][r];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ---- C[i,o] = sum_m A[idx[m], i0+i] B[idx[m], o] / div : slab per (i-tile, split) ----------------
 constexpr int BI = 128, BO = 64, BMK = 32;
 
@@ -251,12 +332,26 @@ namespace amp {
 int gemm_tiled(const TiledArgs &p)
 {
     if (p.M <= 0 || p.N <= 0) return 0;
-    const unsigned ny = (unsigned)((p.N + BN - 1) / BN);
+    if (p.K == AR_K && p.b_nk && p.N % 64 == 0 && p.N >= 512 && p.M >= 1024 && !p.a_idx && !p.c_idx && !p.bias &&
+        p.act == ATHENA_MP_ACT_NONE && p.a_div == 1.0f && p.c_div == 1.0f && p.lda == AR_K && p.ldb == AR_K &&
+        p.ldc == p.N && (uintptr_t)p.A % 16 == 0 && (uintptr_t)p.B % 16 == 0) {
+        constexpr size_t lds = sizeof(float) * (size_t)(AR_BM + 128) * AR_LD;
+        static bool attr = false;
+        if (!attr) {
+            AMP_HIP(hipFuncSetAttribute((const void *)gemm_arow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr = true;
+        }
+        hipLaunchKernelGGL(gemm_arow_kernel, dim3((unsigned)((p.M + AR_BM - 1) / AR_BM)), dim3(256), lds, stream(), p.A, p.B,
+                           p.C, p.M, p.N);
+        AMP_LAUNCH_CHECK();
+        return 0;
+    }
+    const int64_t ny = (p.N + BN - 1) / BN;
     // 256-row workgroup tiles once they still give >= 1.5 workgroups per CU; 128-row tiles otherwise
     if ((p.M + 255) / 256 * ny >= 384) {
-        hipLaunchKernelGGL((gemm_tiled_kernel<64>), dim3((unsigned)((p.M + 255) / 256), ny), dim3(256), 0, stream(), p);
+        hipLaunchKernelGGL((gemm_tiled_kernel<64>), dim3((unsigned)((p.M + 255) / 256 * ny)), dim3(256), 0, stream(), p);
     } else {
-        hipLaunchKernelGGL((gemm_tiled_kernel<32>), dim3((unsigned)((p.M + 127) / 128), ny), dim3(256), 0, stream(), p);
+        hipLaunchKernelGGL((gemm_tiled_kernel<32>), dim3((unsigned)((p.M + 127) / 128 * ny)), dim3(256), 0, stream(), p);
     }
     AMP_LAUNCH_CHECK();
     return 0;

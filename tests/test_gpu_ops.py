@@ -342,6 +342,21 @@ def H_(t):
     return t.cpu().numpy()
 
 
+@pytest.mark.parametrize("M,N", [(5000, 1024), (1024, 512), (4099, 4096)])
+def test_short_contraction_wide_output_gemm(dev, oracle, M, N):
+    """C[M, N] = A[M, 64] . B^T with B stored [N][64] (the GNO 'G = g . Vmat^T' shape): the A-resident kernel
+    that walks the column blocks, incl. a ragged last row block; against the oracle's matmul_dx"""
+    from athena_amd import ops
+
+    rng = np.random.default_rng(M)
+    dz = rng.uniform(-1, 1, (M, 64)).astype(np.float32)
+    w = (rng.standard_normal(64 * N) * 0.2).astype(np.float32)            # W(Fo = 64, Fi = N) column-major
+    got = H_(ops.matmul_dx(T(w, dev), T(dz, dev), N))
+    ref = oracle.matmul_dx(w, dz, N)
+    assert got.shape == (M, N)
+    assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
+
+
 @pytest.mark.parametrize("d,loops", [(3, False), (2, True), (4, False)])
 def test_gno_fused_kernel_hub_rows_tail_tiles_and_self_loops(dev, oracle, d, loops):
     """the one-launch GNO aggregate (H = 64, widths 64): vertices with more than 64 entries (ids beyond the
