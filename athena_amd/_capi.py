@@ -71,6 +71,8 @@ _PROTOS = {
     "athena_mp_clip": [_i64, _vp, _i32, _f32, _f32, _i32, _f32],
     "athena_mp_sgd_step": [_i64, _f32, _f32, _i32, _i32, _f32, _f32, _vp, _vp, _vp],
     "athena_mp_adam_step": [_i64, _f32, _f32, _f32, _f32, _i32, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _vp],
+    "athena_mp_segment_sum": [_i32, _i64, _i32, _vp, _vp, _vp, _i32],
+    "athena_mp_segment_sum_bwd": [_i32, _i64, _i32, _vp, _vp, _vp],
     "athena_mp_duvenaud_readout_fwd": [_i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32],
     "athena_mp_duvenaud_readout_bwd": [_i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32],
     "athena_mp_gno_aggregate_fwd": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],

@@ -113,6 +113,16 @@ __global__ void readout_gid_kernel(int S, const int32_t *__restrict__ seg, int32
     for (int v = seg[s]; v < seg[s + 1]; ++v) gid[v] = s;
 }
 
+// dp[v, :] = gout[graph of v, :]
+__global__ void readout_bcast_kernel(int O, int64_t N, const int32_t *__restrict__ gid, const float *__restrict__ gout,
+                                     float *__restrict__ dp)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N * O) return;
+    const int64_t v = t / O;
+    dp[t] = gout[(size_t)gid[v] * O + (t - v * O)];
+}
+
 // Reverse pass.  dl stays in registers as the B operand (k = q <-> o = 4q + r) of the dz product,
 // whose accumulator comes out in the z-fragment layout, so dc = act'(z)(dz + dz_next) is formed in
 // place and stored 16 B per lane.  dR contracts over VERTICES, so z and dl are turned once through a
@@ -316,6 +326,35 @@ int athena_mp_duvenaud_readout_bwd(int64_t N, int32_t Fv, int32_t O, int32_t S, 
 #undef AMP_CASE
     AMP_LAUNCH_CHECK();
     return slab_reduce((const float *)slabs, nblk, n, dR, accumulate != 0);
+}
+
+
+/* per-graph sum of already-activated per-vertex values, and its reverse (a broadcast): the readout of
+ * athena_duvenaud_msgpass_layer.f90:838-855 for a readout activation other than softmax */
+int athena_mp_segment_sum(int32_t O, int64_t N, int32_t S, const int32_t *seg, const float *p, float *out,
+                          int32_t accumulate)
+{
+    AMP_REQUIRE(O > 0 && N >= 0 && S >= 0 && seg && out && (N == 0 || p), "segment_sum: bad arguments");
+    if (S > 0) {
+        hipLaunchKernelGGL(readout_segsum_kernel, dim3((unsigned)(((int64_t)S * O + 255) / 256)), dim3(256), 0,
+                           stream(), O, S, seg, p, out, accumulate);
+        AMP_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+int athena_mp_segment_sum_bwd(int32_t O, int64_t N, int32_t S, const int32_t *seg, const float *gout, float *dp)
+{
+    AMP_REQUIRE(O > 0 && N >= 0 && S > 0 && seg && gout && (N == 0 || dp), "segment_sum_bwd: bad arguments");
+    if (N == 0) return 0;
+    void *gid = nullptr;
+    if (workspace(&gid, sizeof(int32_t) * (size_t)N, 4)) return 1;
+    hipLaunchKernelGGL(readout_gid_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, stream(), S, seg,
+                       (int32_t *)gid);
+    hipLaunchKernelGGL(readout_bcast_kernel, dim3((unsigned)((N * O + 255) / 256)), dim3(256), 0, stream(), O, N,
+                       (const int32_t *)gid, gout, dp);
+    AMP_LAUNCH_CHECK();
+    return 0;
 }
 
 } // extern "C"

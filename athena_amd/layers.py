@@ -238,8 +238,8 @@ class duvenaud_msgpass_layer_type(msgpass_layer_type):
         self.num_outputs = int(num_outputs)
         self.activation = message_activation or "sigmoid"       # :123
         self.activation_readout = readout_activation or "softmax"  # :124
-        if self.activation_readout != "softmax":
-            raise ValueError("duvenaud readout on the HIP path: only the reference default 'softmax' is built")
+        if self.activation_readout not in ops.ACT and self.activation_readout not in ("softmax", "swish"):
+            raise ValueError(f"duvenaud readout activation '{self.activation_readout}' is not built on the HIP path")
         self.use_graph_output = False
         D = self.max_vertex_degree - self.min_vertex_degree + 1
         Fe = self.num_edge_features[0]
@@ -274,7 +274,14 @@ class duvenaud_msgpass_layer_type(msgpass_layer_type):
         out = None
         self._p = []
         for t in range(1, T + 1):
-            p, out = ops.duvenaud_readout(self.params[T + t - 1], self.z[t - 1], self._seg, self.num_outputs, out=out)
+            if self.activation_readout == "softmax":      # the default: one launch incl. the logits contraction
+                p, out = ops.duvenaud_readout(self.params[T + t - 1], self.z[t - 1], self._seg, self.num_outputs, out=out)
+            else:                                         # any other readout activation: op by op
+                logits = ops.matmul(self.params[T + t - 1], self.z[t - 1], self.num_outputs)
+                p = ops.activation(self.activation_readout, logits) if self.activation_readout not in ("none", "linear") else logits
+                out = ops.segment_sum(p, self._seg, out=out)
+                if self.activation_readout in ops.NEEDS_INPUT:
+                    p = (p, logits)
             self._p.append(p)
         self.output = out   # [batch, num_outputs]
 
@@ -288,8 +295,20 @@ class duvenaud_msgpass_layer_type(msgpass_layer_type):
         dx = None
         for t in range(T, 0, -1):
             # readout branch of step t + the gradient arriving from step t+1, through the message activation
-            dc, self.grads[T + t - 1] = ops.duvenaud_readout_bwd(self.params[T + t - 1], self.z[t - 1], self._p[t - 1],
-                                                                 self._seg, gout, act=self.activation, dz_next=dz_next)
+            if self.activation_readout == "softmax":
+                dc, self.grads[T + t - 1] = ops.duvenaud_readout_bwd(self.params[T + t - 1], self.z[t - 1], self._p[t - 1],
+                                                                     self._seg, gout, act=self.activation, dz_next=dz_next)
+            else:
+                p = self._p[t - 1]
+                p, logits = p if isinstance(p, tuple) else (p, None)
+                dl = ops.segment_sum_bwd(gout, self._seg, p.shape[0])
+                if self.activation_readout not in ("none", "linear"):
+                    dl = ops.activation_bwd(self.activation_readout, p, dl, z=logits)
+                self.grads[T + t - 1] = ops.matmul_dw(self.z[t - 1], dl)
+                dz = ops.matmul_dx(self.params[T + t - 1], dl, self.num_vertex_features[t])
+                if dz_next is not None:
+                    ops.axpy(1.0, dz_next, dz)
+                dc = ops.activation_bwd(self.activation, self.z[t - 1], dz) if self.activation not in ("none", "linear") else dz
             # message branch
             self.grads[t - 1] = ops.duvenaud_update_bwd_w(g, dc, self._a[t - 1], self.min_vertex_degree, self.max_vertex_degree)
             if t == 1 and not (need_input_grad or need_edge_grad):

@@ -294,6 +294,28 @@ def softmax_segsum_bwd(p, seg, gout):
     return dz
 
 
+def segment_sum(p, seg, out=None):
+    """out[s] (+)= sum of p over the vertices of graph s"""
+    N, O = p.shape
+    S = seg.numel() - 1
+    _chk(p); _chk(seg, dtype=torch.int32)
+    acc = out is not None
+    if out is None:
+        out = torch.empty((S, O), device=p.device, dtype=torch.float32)
+    _go()
+    _capi.call("athena_mp_segment_sum", O, N, S, _p(seg), _p(p), _p(out), int(acc))
+    return out
+
+
+def segment_sum_bwd(gout, seg, N):
+    S, O = gout.shape
+    _chk(gout); _chk(seg, dtype=torch.int32)
+    dp = torch.empty((N, O), device=gout.device, dtype=torch.float32)
+    _go()
+    _capi.call("athena_mp_segment_sum_bwd", O, N, S, _p(seg), _p(gout), _p(dp))
+    return dp
+
+
 def duvenaud_readout(R, z, seg, O, out=None):
     """One launch: p = softmax(z R^T) per vertex, out[s] (+)= sum of p over graph s.  Returns (p, out)."""
     N, Fv = z.shape

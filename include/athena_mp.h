@@ -174,6 +174,12 @@ int athena_mp_softmax_segsum_fwd(int32_t O, int64_t N, int32_t S, const int32_t 
 int athena_mp_softmax_segsum_bwd(int32_t O, int64_t N, int32_t S, const int32_t *seg_dev,
                                  const float *p_dev, const float *gout_dev, float *dlogits_dev);
 
+/* readout with a readout activation other than softmax: activate with athena_mp_activation_* / _swish_*, then
+ * out[s,:] (+)= sum_{v in seg s} p[v,:];  reverse: dp[v,:] = gout[graph of v,:] */
+int athena_mp_segment_sum(int32_t O, int64_t N, int32_t S, const int32_t *seg_dev, const float *p_dev,
+                          float *out_dev, int32_t accumulate);
+int athena_mp_segment_sum_bwd(int32_t O, int64_t N, int32_t S, const int32_t *seg_dev, const float *gout_dev,
+                              float *dp_dev);
 /* The same readout with the logits contraction fused in (one launch per direction, logits and
  * dlogits never reach HBM).  R is the readout matrix R(O,Fv) in Fortran order, z [N,Fv] the step's
  * vertex features:   p = softmax(z R^T) per vertex;  out[s,:] (+)= sum_{v in s} p[v,:]            */

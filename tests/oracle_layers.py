@@ -53,7 +53,7 @@ def kipf_backward(graphs, tapes, params, nvf, act, ups, exact=False):
     return dxs, grads
 
 
-def duvenaud_forward(graphs, xs, es, params, nvf, Fe, mn, mx, nout, act):
+def duvenaud_forward(graphs, xs, es, params, nvf, Fe, mn, mx, nout, act, act_readout="softmax"):
     T = len(nvf) - 1
     out = np.zeros((len(graphs), nout), np.float32)
     tapes = []
@@ -66,14 +66,15 @@ def duvenaud_forward(graphs, xs, es, params, nvf, Fe, mn, mx, nout, act):
             A.append(a); Z.append(z); cur = z
         P = []
         for t in range(1, T + 1):
-            p = o.softmax_cols(o.matmul(params[T + t - 1], Z[t - 1], nout))
-            out[s] += p.sum(axis=0, dtype=np.float32) if False else o.segment_sum(p, np.array([0, p.shape[0]], np.int32))[0]
-            P.append(p)
+            lg = o.matmul(params[T + t - 1], Z[t - 1], nout)
+            p = act_fwd(act_readout, lg)
+            out[s] += o.segment_sum(p, np.array([0, p.shape[0]], np.int32))[0]
+            P.append((p, lg))
         tapes.append((A, Z, P))
     return out, tapes
 
 
-def duvenaud_backward(graphs, es, tapes, params, nvf, Fe, mn, mx, nout, act, gout):
+def duvenaud_backward(graphs, es, tapes, params, nvf, Fe, mn, mx, nout, act, gout, act_readout="softmax"):
     T = len(nvf) - 1
     grads = [np.zeros_like(p) for p in params]
     dxs, des = [], []
@@ -83,7 +84,7 @@ def duvenaud_backward(graphs, es, tapes, params, nvf, Fe, mn, mx, nout, act, gou
         dz_next = None
         de = np.zeros_like(e)
         for t in range(T, 0, -1):
-            dl = o.softmax_cols_bwd(P[t - 1], gv)
+            dl = act_bwd(act_readout, P[t - 1][0], gv, P[t - 1][1])
             grads[T + t - 1] += o.matmul_dw(dl, Z[t - 1])
             dz = o.matmul_dx(params[T + t - 1], dl, nvf[t])
             if dz_next is not None:

@@ -270,3 +270,38 @@ def test_layer_text_cards_round_trip(dev, oracle):
     assert g2.print() == gno.print() and g2.get_num_params() == gno.get_num_params()
     with pytest.raises(ValueError, match="END KIPF not where expected"):
         read_layer(text.replace("END KIPF", "END"))
+
+
+@pytest.mark.parametrize("act_readout", ["none", "sigmoid", "swish"])
+def test_duvenaud_layer_with_another_readout_activation(dev, act_readout):
+    """activation_readout other than the default softmax (athena_duvenaud_msgpass_layer.f90:124 is only the default):
+    the op-by-op readout path (matmul -> activation -> per-graph sum) and its reverse, against the oracle"""
+    from athena_amd.layers import duvenaud_msgpass_layer_type
+
+    rng = np.random.default_rng(31)
+    gs = _graphs(rng, [9, 14, 5, 20], self_loops=False)
+    Fv, Fe, T, nout = 8, 2, 2, 4
+    layer = duvenaud_msgpass_layer_type(num_vertex_features=[Fv], num_edge_features=[Fe], num_time_steps=T,
+                                        max_vertex_degree=6, num_outputs=nout, min_vertex_degree=1,
+                                        readout_activation=act_readout, seed=8)
+    nvf = layer.num_vertex_features
+    xs = [rng.uniform(0, 1, (g.num_vertices, Fv)).astype(np.float32) for g in gs]
+    es = [rng.uniform(0, 1, (g.num_edges, Fe)).astype(np.float32) for g in gs]
+    params = layer.get_params()
+    D = 6
+    plist, o_ = [], 0
+    for t in range(1, T + 1):
+        k = nvf[t] * (nvf[t - 1] + Fe) * D
+        plist.append(params[o_:o_ + k]); o_ += k
+    for t in range(1, T + 1):
+        k = nout * nvf[t]
+        plist.append(params[o_:o_ + k]); o_ += k
+    layer.set_graph(gs)
+    out = layer.forward(xs, es).cpu().numpy()
+    outs, tapes = ol.duvenaud_forward(gs, xs, es, plist, nvf, Fe, 1, 6, nout, "sigmoid", act_readout=act_readout)
+    assert_close(out, outs, 1e-5, f"readout activation {act_readout}: forward")
+    up = rng.uniform(-1, 1, out.shape).astype(np.float32)
+    dx = layer.backward(up).cpu().numpy()
+    dxs, des, grads = ol.duvenaud_backward(gs, es, tapes, plist, nvf, Fe, 1, 6, nout, "sigmoid", up, act_readout=act_readout)
+    assert_close(dx, np.concatenate(dxs), 2e-5, f"readout activation {act_readout}: dx")
+    assert_close(layer.get_gradients(), np.concatenate(grads), 2e-5, f"readout activation {act_readout}: gradients")
