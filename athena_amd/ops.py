@@ -139,6 +139,12 @@ def pull_gemm(g: DeviceGraph, dZ, W, Fi, exact=False, out=None):
     return dX
 
 
+def _act_code(kind):
+    if kind not in ACT:
+        raise ValueError(f"activation '{kind}' is not built on the HIP path (built: {sorted(ACT)} + softmax, swish)")
+    return ACT[kind]
+
+
 # activations whose reverse pass needs the INPUT (pre-activation) rather than the output
 NEEDS_INPUT = ("swish",)
 
@@ -154,7 +160,7 @@ def activation(kind, z, out=None, beta=1.0):
     elif kind == "swish":
         _capi.call("athena_mp_swish_fwd", z.numel(), float(beta), _p(_chk(z)), _p(y))
     else:
-        _capi.call("athena_mp_activation_fwd", ACT[kind], z.numel(), _p(_chk(z)), _p(y))
+        _capi.call("athena_mp_activation_fwd", _act_code(kind), z.numel(), _p(_chk(z)), _p(y))
     return y
 
 
@@ -170,7 +176,7 @@ def activation_bwd(kind, y, g, out=None, z=None, beta=1.0):
             raise ValueError("swish differentiates at its input: pass z")
         _capi.call("athena_mp_swish_bwd", z.numel(), float(beta), _p(_chk(z)), _p(_chk(g)), _p(dz))
     else:
-        _capi.call("athena_mp_activation_bwd", ACT[kind], y.numel(), _p(_chk(y)), _p(_chk(g)), _p(dz))
+        _capi.call("athena_mp_activation_bwd", _act_code(kind), y.numel(), _p(_chk(y)), _p(_chk(g)), _p(dz))
     return dz
 
 
