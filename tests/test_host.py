@@ -111,3 +111,27 @@ def test_fortran_e16_8e2_field_formatting():
     assert w.tolist() == [0.5, -0.25, 0.125, -0.75, 1.5, 2.0, 1.5, -0.03125, 0.125]
     with pytest.raises(ValueError, match="Unrecognised line"):
         parse_layer_card(text.replace("   NUM_TIME_STEPS = 2", "   what is this"))
+
+
+def test_e16_field_is_the_eight_digit_rounding_of_the_value_property():
+    """hypothesis: for any finite float32, the E16.8E2 field is 16 columns, parses back to within half a unit of
+    the eighth significant digit, re-prints identically (idempotent), and the mantissa is normalised 0.1 <= m < 1"""
+    from hypothesis import given, settings, strategies as st
+
+    from athena_amd.io import _e16
+
+    @settings(max_examples=400, deadline=None)
+    @given(st.floats(width=32, allow_nan=False, allow_infinity=False))
+    def check(v):
+        f = _e16(np.float32(v))
+        assert len(f) == 16
+        back = float(f)
+        if v == 0.0:
+            assert back == 0.0
+            return
+        assert abs(back - v) <= 0.5000001e-8 * 10.0 ** (np.floor(np.log10(abs(v))) + 1)
+        assert _e16(back) == f
+        m = f.strip().lstrip("-")
+        assert m.startswith("0.") and m[2] != "0"
+
+    check()
