@@ -57,6 +57,63 @@ __global__ void swish_bwd_kernel(int64_t n, float beta, const float *__restrict_
     }
 }
 
+// parameterised activations (athena_activation_{linear,relu,sigmoid,tanh,leaky_relu,selu,gaussian,piecewise}.f90
+// `apply` with their scale / threshold / alpha / lambda / sigma / mu / gradient / limit attributes).  The reverse
+// factor is evaluated at the INPUT x, as the autodiff nodes of these ops do.
+__device__ __forceinline__ float actp_f(int kind, float x, float p0, float p1)
+{
+    switch (kind) {
+    case ATHENA_MP_ACTP_RELU: return fmaxf(x, p0);                       // max(val, threshold)
+    case ATHENA_MP_ACTP_SIGMOID: return 1.0f / (1.0f + expf(-x));
+    case ATHENA_MP_ACTP_TANH: return tanhf(x);
+    case ATHENA_MP_ACTP_LEAKY_RELU: return fmaxf(x * p0, x);             // max(val*alpha, val)
+    case ATHENA_MP_ACTP_SELU: return x > 0.0f ? x * p1 : (expf(x) - 1.0f) * p0 * p1;
+    case ATHENA_MP_ACTP_GAUSSIAN: {
+        const float t = (x - p1) / p0;
+        return 1.0f / (sqrtf(6.283185307179586f) * p0) * expf(-0.5f * t * t);
+    }
+    case ATHENA_MP_ACTP_PIECEWISE:                                       // piecewise_array :216-254
+        return x >= p1 ? p0 * (x - p1) + p1 : (x <= -p1 ? p0 * (x + p1) - p1 : x);
+    default: return x;
+    }
+}
+__device__ __forceinline__ float actp_b(int kind, float x, float g, float p0, float p1)
+{
+    switch (kind) {
+    case ATHENA_MP_ACTP_RELU: return x > p0 ? g : 0.0f;
+    case ATHENA_MP_ACTP_SIGMOID: {
+        const float y = 1.0f / (1.0f + expf(-x));
+        return g * y * (1.0f - y);
+    }
+    case ATHENA_MP_ACTP_TANH: {
+        const float y = tanhf(x);
+        return g * (1.0f - y * y);
+    }
+    case ATHENA_MP_ACTP_LEAKY_RELU: return x * p0 > x ? g * p0 : g;
+    case ATHENA_MP_ACTP_SELU: return x > 0.0f ? g * p1 : g * (expf(x) * p0 * p1);
+    case ATHENA_MP_ACTP_GAUSSIAN: {
+        const float t = (x - p1) / p0;
+        const float f = 1.0f / (sqrtf(6.283185307179586f) * p0) * expf(-0.5f * t * t);
+        return g * (-(x - p1) / (p0 * p0) * f);
+    }
+    case ATHENA_MP_ACTP_PIECEWISE:                                       // get_partial_piecewise_val :275-290, as written
+        return (x <= p1 || x >= -p1) ? g : g * p0;
+    default: return g;
+    }
+}
+__global__ void actp_fwd_kernel(int kind, int64_t n, float scale, float p0, float p1, const float *__restrict__ x,
+                                float *__restrict__ y)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = actp_f(kind, x[i], p0, p1) * scale;
+}
+__global__ void actp_bwd_kernel(int kind, int64_t n, float scale, float p0, float p1, const float *__restrict__ x,
+                                const float *__restrict__ g, float *__restrict__ dx)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dx[i] = actp_b(kind, x[i], g[i] * scale, p0, p1);
+}
+
 // softmax over the features of each vertex, G lanes per vertex (G = 4, 16 or 64 by feature count)
 template <int G>
 __device__ __forceinline__ float group_max(float v)
@@ -183,6 +240,27 @@ int athena_mp_swish_bwd(int64_t n, float beta, const float *x, const float *g, f
     AMP_REQUIRE(n >= 0 && (n == 0 || (x && g && dx)), "swish_bwd: bad arguments");
     if (n == 0) return 0;
     hipLaunchKernelGGL(swish_bwd_kernel, grid_for(n), dim3(256), 0, stream(), n, beta, x, g, dx);
+    AMP_LAUNCH_CHECK();
+    return 0;
+}
+
+/* parameterised activations, athena_activation_*.f90 `apply` (scale applied to the output) */
+int athena_mp_activation_param_fwd(int32_t kind, int64_t n, float scale, float p0, float p1, const float *x, float *y)
+{
+    AMP_REQUIRE(n >= 0 && (n == 0 || (x && y)), "activation_param_fwd: bad arguments");
+    AMP_REQUIRE(kind >= 0 && kind <= ATHENA_MP_ACTP_PIECEWISE, "activation_param_fwd: unknown activation %d", kind);
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(actp_fwd_kernel, grid_for(n), dim3(256), 0, stream(), kind, n, scale, p0, p1, x, y);
+    AMP_LAUNCH_CHECK();
+    return 0;
+}
+int athena_mp_activation_param_bwd(int32_t kind, int64_t n, float scale, float p0, float p1, const float *x,
+                                   const float *g, float *dx)
+{
+    AMP_REQUIRE(n >= 0 && (n == 0 || (x && g && dx)), "activation_param_bwd: bad arguments");
+    AMP_REQUIRE(kind >= 0 && kind <= ATHENA_MP_ACTP_PIECEWISE, "activation_param_bwd: unknown activation %d", kind);
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(actp_bwd_kernel, grid_for(n), dim3(256), 0, stream(), kind, n, scale, p0, p1, x, g, dx);
     AMP_LAUNCH_CHECK();
     return 0;
 }

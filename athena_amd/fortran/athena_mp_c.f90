@@ -24,6 +24,7 @@ module athena_mp_c
   public :: athena_mp_adam_step, athena_mp_sgd_step, athena_mp_clip, athena_mp_mse_loss
   public :: athena_mp_swish_fwd, athena_mp_swish_bwd, athena_mp_softmax_fwd, athena_mp_softmax_bwd
   public :: athena_mp_concat_fwd, athena_mp_concat_bwd
+  public :: athena_mp_activation_param_fwd, athena_mp_activation_param_bwd
   public :: athena_mp_duvenaud_readout_fwd, athena_mp_duvenaud_readout_bwd, athena_mp_duvenaud_update_act_fwd
   public :: athena_mp_kipf_layer_fwd, athena_mp_kipf_layer_bwd_x, athena_mp_activation_bwd
   public :: athena_mp_csr_from_edges, athena_mp_graph_export
@@ -248,6 +249,25 @@ module athena_mp_c
        import :: c_int, c_int64_t, c_ptr
        integer(c_int64_t), value :: n
        type(c_ptr), value :: pred_dev, expected_dev, loss_dev, dpred_dev
+     end function
+
+     !! ---- activations with attributes (kind: 0 linear, 1 relu(threshold), 2 sigmoid, 3 tanh,
+     !!      4 leaky_relu(alpha), 5 selu(alpha, lambda), 6 gaussian(sigma, mu), 7 piecewise(gradient, limit)) ----
+     integer(c_int) function athena_mp_activation_param_fwd(kind, n, scale, p0, p1, x_dev, y_dev) &
+          bind(C, name="athena_mp_activation_param_fwd")
+       import :: c_int, c_int32_t, c_int64_t, c_float, c_ptr
+       integer(c_int32_t), value :: kind
+       integer(c_int64_t), value :: n
+       real(c_float), value :: scale, p0, p1
+       type(c_ptr), value :: x_dev, y_dev
+     end function
+     integer(c_int) function athena_mp_activation_param_bwd(kind, n, scale, p0, p1, x_dev, grad_dev, dx_dev) &
+          bind(C, name="athena_mp_activation_param_bwd")
+       import :: c_int, c_int32_t, c_int64_t, c_float, c_ptr
+       integer(c_int32_t), value :: kind
+       integer(c_int64_t), value :: n
+       real(c_float), value :: scale, p0, p1
+       type(c_ptr), value :: x_dev, grad_dev, dx_dev
      end function
 
      !! ---- shaped activations and the concatenate merge ----

@@ -127,14 +127,29 @@ def _weights_block(tensors):
     return lines
 
 
-def _activation_block(name, scale=1.0, identifier=None, extra=()):
+def _activation_block(actv, identifier=None):
+    """print_to_unit_actv (athena_misc_types_sub.f90:43-75) over export_attributes_* : name, scale, then the
+    activation's own attributes, floats as adjustl('(F10.6)')"""
+    from . import ops
+    a = actv if isinstance(actv, ops.actv_type) else ops.actv_type(actv)
     out = ["   ACTIVATION" + (f": {identifier}" if identifier else "")]
-    out.append(f"      name = {name}")
-    out.append(f"      scale = {scale:.6f}")
-    for k, v in extra:
-        out.append(f"      {k} = {v}")
+    out.append(f"      name = {a.name}")
+    out.append(f"      scale = {a.scale:.6f}")
+    if a.name == "swish":
+        out.append(f"      beta = {a.beta:.6f}")
+    for k, spec in enumerate(ops.ACTP.get(a.name, (0, None, None))[1:]):
+        if spec is not None:
+            out.append(f"      {spec[0].rstrip('_')} = {a.p[k]:.6f}")
     out.append("   END ACTIVATION")
     return out
+
+
+def activation_from_card(hp, prefix="activation_"):
+    """the ACTIVATION block of a parsed card -> a name or an ops.actv_type (read_activation + apply_attributes_*)"""
+    from . import ops
+    name = hp.get(prefix + "name", "none")
+    attrs = {k[len(prefix):]: float(v) for k, v in hp.items() if k.startswith(prefix) and k != prefix + "name"}
+    return ops.resolve_activation(ops.actv_type(name, **attrs))
 
 
 def layer_card(layer):
@@ -153,7 +168,7 @@ def layer_card(layer):
         lines.append("   NUM_EDGE_FEATURES =" + "".join(f" {v}" for v in layer.num_edge_features))
         if layer.activation != "none":
             lines += _activation_block(layer.activation, identifier="MESSAGE")
-        lines += _activation_block("softmax", identifier="READOUT")
+        lines += _activation_block(layer.activation_readout, identifier="READOUT")
     elif layer.name == "graph_nop":
         lines.append(f"   NUM_INPUTS = {layer.num_vertex_features[0]}")
         lines.append(f"   NUM_OUTPUTS = {layer.num_outputs}")

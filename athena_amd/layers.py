@@ -23,6 +23,15 @@ from . import ops
 from .graph import DeviceGraph, graph_type
 
 
+def _fusable(activation):
+    """can the activation ride in a GEMM epilogue (plain none / relu / sigmoid / tanh)?"""
+    return isinstance(activation, str) and activation in ops.ACT
+
+
+def _identity(activation):
+    return isinstance(activation, str) and activation in ("none", "linear")
+
+
 def _expand(nf, T, what):
     nf = list(np.atleast_1d(nf))
     if len(nf) == 1:
@@ -36,7 +45,7 @@ def _expand(nf, T, what):
 def _init_weights(rng, n, fan_in, fan_out, activation):
     """default initialiser: he_normal for relu-family else glorot_uniform
     (docs/source/layers/msgpass/kipf_msgpass_layer.rst:61-65)"""
-    if activation in ("relu", "leaky_relu", "swish", "selu"):
+    if getattr(activation, "name", activation) in ("relu", "leaky_relu", "swish", "selu"):
         return (rng.standard_normal(n) * np.sqrt(2.0 / fan_in)).astype(np.float32)
     lim = np.sqrt(6.0 / (fan_in + fan_out))
     return rng.uniform(-lim, lim, n).astype(np.float32)
@@ -171,7 +180,7 @@ class kipf_msgpass_layer_type(msgpass_layer_type):
         self.num_time_steps = int(num_time_steps)
         self.num_vertex_features = _expand(num_vertex_features, self.num_time_steps, "num_vertex_features")
         self.num_edge_features = [0] * (self.num_time_steps + 1)
-        self.activation = activation or "none"
+        self.activation = ops.resolve_activation(activation or "none")   # a name or an ops.actv_type
         self.use_graph_output = True
         # init_kipf :345-380 -- params(t): W(F_t, F_{t-1}) flat column-major
         for t in range(1, self.num_time_steps + 1):
@@ -188,16 +197,16 @@ class kipf_msgpass_layer_type(msgpass_layer_type):
         self._tape = []
         cur = x
         for t in range(1, self.num_time_steps + 1):
-            if self.activation in ops.ACT:
+            if _fusable(self.activation):
                 # aggregation + dense step (+ activation) in one launch where the fused kernel exists
                 p, nxt = ops.kipf_layer_fwd(g, cur, self.params[t - 1], self.num_vertex_features[t], act=self.activation)
                 z = None
             else:
-                # 'softmax' / 'swish' (msgpass_euler): the shaped activations run as their own launch, and the
-                # pre-activation is kept for the ones that differentiate at their input
+                # 'softmax' / 'swish' (msgpass_euler) and the activations with attributes run as their own launch;
+                # the pre-activation is kept for the ones that differentiate at their input
                 p, z = ops.kipf_layer_fwd(g, cur, self.params[t - 1], self.num_vertex_features[t], act="none")
                 nxt = ops.activation(self.activation, z)
-                if self.activation not in ops.NEEDS_INPUT:
+                if not ops.needs_input(self.activation):
                     z = None
             self._tape.append((p, nxt, z))
             cur = nxt
@@ -213,7 +222,7 @@ class kipf_msgpass_layer_type(msgpass_layer_type):
         gcur = self._t(upstream)
         for t in range(self.num_time_steps, 0, -1):
             p, out, z = self._tape[t - 1]
-            dz = ops.activation_bwd(self.activation, out, gcur, z=z) if self.activation not in ("none", "linear") else gcur
+            dz = ops.activation_bwd(self.activation, out, gcur, z=z) if not _identity(self.activation) else gcur
             dw = ops.matmul_dw(p, dz)
             self.grads[t - 1] = dw
             if t == 1 and not need_input_grad:   # input layer output has requires_grad = .false.
@@ -236,10 +245,8 @@ class duvenaud_msgpass_layer_type(msgpass_layer_type):
         self.num_edge_features = _expand(num_edge_features, T, "num_edge_features")
         self.min_vertex_degree, self.max_vertex_degree = int(min_vertex_degree), int(max_vertex_degree)
         self.num_outputs = int(num_outputs)
-        self.activation = message_activation or "sigmoid"       # :123
-        self.activation_readout = readout_activation or "softmax"  # :124
-        if self.activation_readout not in ops.ACT and self.activation_readout not in ("softmax", "swish"):
-            raise ValueError(f"duvenaud readout activation '{self.activation_readout}' is not built on the HIP path")
+        self.activation = ops.resolve_activation(message_activation or "sigmoid")       # :123
+        self.activation_readout = ops.resolve_activation(readout_activation or "softmax")  # :124
         self.use_graph_output = False
         D = self.max_vertex_degree - self.min_vertex_degree + 1
         Fe = self.num_edge_features[0]
@@ -258,14 +265,23 @@ class duvenaud_msgpass_layer_type(msgpass_layer_type):
         T = self.num_time_steps
         assert e is not None and e.shape[0] == g.n_edge_cols, "edge feature shape mismatch"
         self._e = e
-        self._a, self.z = [], []
+        self._a, self.z, self._c = [], [], []
         cur = x
         for t in range(1, T + 1):
             a = ops.duvenaud_propagate(g, cur, e)
-            zt = ops.duvenaud_update_act(g, a, self.params[t - 1], self.min_vertex_degree, self.max_vertex_degree,
-                                         self.num_vertex_features[t], act=self.activation)
+            if _fusable(self.activation):     # the bucket contraction with the activation in its epilogue
+                zt = ops.duvenaud_update_act(g, a, self.params[t - 1], self.min_vertex_degree, self.max_vertex_degree,
+                                             self.num_vertex_features[t], act=self.activation)
+                c = None
+            else:                             # shaped / attributed activations: their own launch
+                c = ops.duvenaud_update_act(g, a, self.params[t - 1], self.min_vertex_degree, self.max_vertex_degree,
+                                            self.num_vertex_features[t], act="none")
+                zt = ops.activation(self.activation, c)
+                if not ops.needs_input(self.activation):
+                    c = None
             self._a.append(a)
             self.z.append(zt)
+            self._c.append(c)
             cur = zt
 
     def update_readout(self):
@@ -278,9 +294,9 @@ class duvenaud_msgpass_layer_type(msgpass_layer_type):
                 p, out = ops.duvenaud_readout(self.params[T + t - 1], self.z[t - 1], self._seg, self.num_outputs, out=out)
             else:                                         # any other readout activation: op by op
                 logits = ops.matmul(self.params[T + t - 1], self.z[t - 1], self.num_outputs)
-                p = ops.activation(self.activation_readout, logits) if self.activation_readout not in ("none", "linear") else logits
+                p = ops.activation(self.activation_readout, logits) if not _identity(self.activation_readout) else logits
                 out = ops.segment_sum(p, self._seg, out=out)
-                if self.activation_readout in ops.NEEDS_INPUT:
+                if ops.needs_input(self.activation_readout):
                     p = (p, logits)
             self._p.append(p)
         self.output = out   # [batch, num_outputs]
@@ -295,20 +311,24 @@ class duvenaud_msgpass_layer_type(msgpass_layer_type):
         dx = None
         for t in range(T, 0, -1):
             # readout branch of step t + the gradient arriving from step t+1, through the message activation
+            fused_act = _fusable(self.activation)
             if self.activation_readout == "softmax":
                 dc, self.grads[T + t - 1] = ops.duvenaud_readout_bwd(self.params[T + t - 1], self.z[t - 1], self._p[t - 1],
-                                                                     self._seg, gout, act=self.activation, dz_next=dz_next)
+                                                                     self._seg, gout, dz_next=dz_next,
+                                                                     act=self.activation if fused_act else "none")
+                if not fused_act:
+                    dc = ops.activation_bwd(self.activation, self.z[t - 1], dc, z=self._c[t - 1])
             else:
                 p = self._p[t - 1]
                 p, logits = p if isinstance(p, tuple) else (p, None)
                 dl = ops.segment_sum_bwd(gout, self._seg, p.shape[0])
-                if self.activation_readout not in ("none", "linear"):
+                if not _identity(self.activation_readout):
                     dl = ops.activation_bwd(self.activation_readout, p, dl, z=logits)
                 self.grads[T + t - 1] = ops.matmul_dw(self.z[t - 1], dl)
                 dz = ops.matmul_dx(self.params[T + t - 1], dl, self.num_vertex_features[t])
                 if dz_next is not None:
                     ops.axpy(1.0, dz_next, dz)
-                dc = ops.activation_bwd(self.activation, self.z[t - 1], dz) if self.activation not in ("none", "linear") else dz
+                dc = ops.activation_bwd(self.activation, self.z[t - 1], dz, z=self._c[t - 1]) if not _identity(self.activation) else dz
             # message branch
             self.grads[t - 1] = ops.duvenaud_update_bwd_w(g, dc, self._a[t - 1], self.min_vertex_degree, self.max_vertex_degree)
             if t == 1 and not (need_input_grad or need_edge_grad):
@@ -339,7 +359,7 @@ class graph_nop_layer_type(msgpass_layer_type):
         self.coord_dim = int(coord_dim)
         self.kernel_hidden = int(kernel_hidden) if kernel_hidden else 16
         self.use_bias = bool(use_bias)
-        self.activation = activation or "none"
+        self.activation = ops.resolve_activation(activation or "none")
         self.use_graph_output = True
         self.num_time_steps = 1
         if num_inputs is not None:
@@ -371,7 +391,8 @@ class graph_nop_layer_type(msgpass_layer_type):
         m = ops.gno_aggregate(g, self.params[0], coords, x, self.coord_dim, self.kernel_hidden, Fo)   # steps 1+2
         z = ops.matmul(self.params[1], x, Fo, bias=self.params[2] if self.use_bias else None)          # steps 3+5
         ops.axpy(1.0, m, z)                                                                            # step 4
-        out = ops.activation(self.activation, z) if self.activation not in ("none", "linear") else z    # step 6
+        out = ops.activation(self.activation, z) if not _identity(self.activation) else z               # step 6
+        self._z = z if ops.needs_input(self.activation) else None
         self.output = out
         self.output_edge = coords   # output(2,s): edge geometry forwarded without gradient (:781-785)
 
@@ -383,7 +404,7 @@ class graph_nop_layer_type(msgpass_layer_type):
         Fi, Fo = self.num_vertex_features
         d, H = self.coord_dim, self.kernel_hidden
         gup = self._t(upstream)
-        dz = ops.activation_bwd(self.activation, self.output, gup) if self.activation not in ("none", "linear") else gup
+        dz = ops.activation_bwd(self.activation, self.output, gup, z=self._z) if not _identity(self.activation) else gup
         if self.use_bias:
             ones = torch.ones((dz.shape[0], 1), device=self.device)
             self.grads[2] = ops.matmul_dw(ones, dz)          # db[o] = sum_v dz[v,o]
@@ -402,7 +423,7 @@ def read_layer(text, device="cuda:0"):
     """layer from its text card (read_kipf_msgpass_layer / read_graph_nop_layer); weights are set as read"""
     from . import io
     name, hp, weights = io.parse_layer_card(text)
-    act = hp.get("activation_name", "none")
+    act = io.activation_from_card(hp)
     if name == "kipf":
         nvf = [int(v) for v in hp["NUM_VERTEX_FEATURES"].split()]
         T = int(hp.get("NUM_TIME_STEPS", len(nvf) - 1))

@@ -7,6 +7,8 @@ row-major [N, F] == athena's val(F, N).  Kernels go to torch's current stream.
 """
 import ctypes as C
 
+import numpy as np
+
 import torch
 
 from . import _capi
@@ -146,7 +148,63 @@ def _act_code(kind):
 
 
 # activations whose reverse pass needs the INPUT (pre-activation) rather than the output
-NEEDS_INPUT = ("swish",)
+NEEDS_INPUT = ("swish", "leaky_relu", "selu", "gaussian", "piecewise")
+
+# activations with attributes: name -> (C-ABI kind, (first attribute, default), (second attribute, default));
+# defaults are the reference's reset_* values (athena_activation_leaky_relu.f90:83-85, _selu.f90:95-99,
+# _gaussian.f90:92-96, _piecewise.f90:80-84, _relu.f90:79-80)
+ACTP = {"linear": (0, None, None), "none": (0, None, None), "relu": (1, ("threshold", 0.0), None),
+        "sigmoid": (2, None, None), "tanh": (3, None, None), "leaky_relu": (4, ("alpha", 0.01), None),
+        "selu": (5, ("alpha", 1.67326), ("lambda_", 1.0507)), "gaussian": (6, ("sigma", 1.5), ("mu", 0.0)),
+        "piecewise": (7, ("gradient", 0.1), ("limit", 1.0))}
+
+
+class actv_type:
+    """base_actv_type with its attributes (athena_misc_types / athena_activation_*.f90 `initialise`): a layer's
+    `activation` argument may be a name or one of these.  `scale` multiplies the output only when it differs from
+    1 by more than 1e-6, as `apply_scaling` does."""
+
+    def __init__(self, name, scale=1.0, **attrs):
+        if name not in ACTP and name not in ("swish", "softmax"):
+            raise ValueError(f"unknown activation '{name}'")
+        self.name = name
+        self.scale = float(scale)
+        self.apply_scaling = abs(np.float32(self.scale) - np.float32(1)) > np.float32(1e-6)
+        self.beta = float(attrs.pop("beta", 1.0))                      # swish
+        self.p = [0.0, 0.0]
+        if name in ACTP:
+            for k, spec in enumerate(ACTP[name][1:]):
+                if spec is not None:
+                    self.p[k] = float(attrs.pop(spec[0], attrs.pop(spec[0].rstrip("_"), spec[1])))
+        if attrs:
+            raise ValueError(f"activation '{name}' has no attribute(s) {sorted(attrs)}")
+
+    def simple(self):
+        """the plain name when the attributes are the defaults of an activation the fused epilogues know"""
+        plain = not self.apply_scaling and self.p == [0.0, 0.0] and self.beta == 1.0
+        return self.name if plain and (self.name in ACT or self.name in ("softmax", "swish")) else None
+
+    def __repr__(self):
+        return f"actv_type({self.name!r}, scale={self.scale}, p={self.p})"
+
+
+def resolve_activation(a):
+    """a name stays a name; an actv_type collapses to its name when it carries no non-default attribute"""
+    if isinstance(a, actv_type):
+        return a.simple() or a
+    return a
+
+
+def needs_input(kind):
+    """does the reverse pass of this activation take the pre-activation? (else it takes the output)"""
+    return isinstance(kind, actv_type) or kind in NEEDS_INPUT
+
+
+def _actp_args(kind):
+    a = kind if isinstance(kind, actv_type) else actv_type(kind)
+    if a.name not in ACTP:
+        raise ValueError(f"activation '{a.name}' takes no scale / attributes on the HIP path")
+    return ACTP[a.name][0], (a.scale if a.apply_scaling else 1.0), a.p[0], a.p[1]
 
 
 def activation(kind, z, out=None, beta=1.0):
@@ -154,7 +212,13 @@ def activation(kind, z, out=None, beta=1.0):
     z must be [N, F]) and 'swish' (x * sigmoid(beta x))"""
     y = out if out is not None else torch.empty_like(z)
     _go()
-    if kind == "softmax":
+    kind = resolve_activation(kind)
+    if isinstance(kind, actv_type) and kind.name == "swish" and not kind.apply_scaling:
+        kind, beta = "swish", kind.beta
+    if isinstance(kind, actv_type) or kind in ("leaky_relu", "selu", "gaussian", "piecewise"):
+        code, scale, p0, p1 = _actp_args(kind)
+        _capi.call("athena_mp_activation_param_fwd", code, z.numel(), scale, p0, p1, _p(_chk(z)), _p(y))
+    elif kind == "softmax":
         assert z.dim() == 2
         _capi.call("athena_mp_softmax_fwd", z.shape[0], z.shape[1], _p(_chk(z)), _p(y))
     elif kind == "swish":
@@ -168,7 +232,15 @@ def activation_bwd(kind, y, g, out=None, z=None, beta=1.0):
     """reverse factor; y = the activation's OUTPUT, z = its input (required by 'swish' only)"""
     dz = out if out is not None else torch.empty_like(y)
     _go()
-    if kind == "softmax":
+    kind = resolve_activation(kind)
+    if isinstance(kind, actv_type) and kind.name == "swish" and not kind.apply_scaling:
+        kind, beta = "swish", kind.beta
+    if isinstance(kind, actv_type) or kind in ("leaky_relu", "selu", "gaussian", "piecewise"):
+        if z is None:
+            raise ValueError("activations with attributes differentiate at their input: pass z")
+        code, scale, p0, p1 = _actp_args(kind)
+        _capi.call("athena_mp_activation_param_bwd", code, z.numel(), scale, p0, p1, _p(_chk(z)), _p(_chk(g)), _p(dz))
+    elif kind == "softmax":
         assert y.dim() == 2
         _capi.call("athena_mp_softmax_bwd", y.shape[0], y.shape[1], _p(_chk(y)), _p(_chk(g)), _p(dz))
     elif kind == "swish":

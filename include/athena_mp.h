@@ -218,6 +218,34 @@ int athena_mp_gno_aggregate_bwd_coords(const athena_mp_graph *g, int32_t d, int3
  * the reverse pass differentiates at the INPUT x */
 int athena_mp_swish_fwd(int64_t n, float beta, const float *x_dev, float *y_dev);
 int athena_mp_swish_bwd(int64_t n, float beta, const float *x_dev, const float *grad_dev, float *dx_dev);
+/* the activations that carry attributes (athena_activation_{linear,relu,sigmoid,tanh,leaky_relu,selu,gaussian,
+ * piecewise}.f90 `apply`): y = f(x; p0, p1) * scale; the reverse pass differentiates at the INPUT x.
+ *   kind        p0          p1       f
+ *   LINEAR      -           -        x                                            (linear.f90:194)
+ *   RELU        threshold   -        max(x, threshold)                            (relu.f90:201)
+ *   SIGMOID     -           -        1/(1+exp(-x))
+ *   TANH        -           -        tanh(x)
+ *   LEAKY_RELU  alpha       -        max(x*alpha, x)                              (leaky_relu.f90:204)
+ *   SELU        alpha       lambda   x>0 ? lambda x : alpha lambda (exp(x)-1)     (selu.f90:227-229)
+ *   GAUSSIAN    sigma       mu       exp(-((x-mu)/sigma)^2/2) / (sqrt(2 pi) sigma) (gaussian.f90:8,221)
+ *   PIECEWISE   gradient    limit    piecewise_array, athena_diffstruc_extd_sub.f90:216-254; its reverse factor
+ *                                    follows get_partial_piecewise_val :275-290 AS WRITTEN (the test
+ *                                    `x <= limit .or. x >= -limit` holds everywhere for limit >= 0, so the
+ *                                    gradient passes through unchanged -- DESIGN.md 3.7) */
+typedef enum {
+    ATHENA_MP_ACTP_LINEAR = 0,
+    ATHENA_MP_ACTP_RELU = 1,
+    ATHENA_MP_ACTP_SIGMOID = 2,
+    ATHENA_MP_ACTP_TANH = 3,
+    ATHENA_MP_ACTP_LEAKY_RELU = 4,
+    ATHENA_MP_ACTP_SELU = 5,
+    ATHENA_MP_ACTP_GAUSSIAN = 6,
+    ATHENA_MP_ACTP_PIECEWISE = 7
+} athena_mp_activation_param;
+int athena_mp_activation_param_fwd(int32_t kind, int64_t n, float scale, float p0, float p1, const float *x_dev,
+                                   float *y_dev);
+int athena_mp_activation_param_bwd(int32_t kind, int64_t n, float scale, float p0, float p1, const float *x_dev,
+                                   const float *grad_dev, float *dx_dev);
 /* softmax(val, dim=2): over the F features of each vertex (athena_activation_softmax.f90:183-203,
  * athena_diffstruc_extd_sub.f90:295-379); reverse: dz = y*g - y*sum(y*g) */
 int athena_mp_softmax_fwd(int64_t N, int32_t F, const float *z_dev, float *y_dev);

@@ -611,6 +611,57 @@ void oracle_swish_bwd(size_t n, float beta, const float *x, const float *g, floa
     }
 }
 
+/* activations with attributes: athena_activation_{linear,relu,sigmoid,tanh,leaky_relu,selu,gaussian,piecewise}.f90
+ * `apply` -- y = f(x) * scale.  kind: 0 linear (:194), 1 relu max(val, threshold) (:201), 2 sigmoid, 3 tanh,
+ * 4 leaky_relu max(val*alpha, val) (:204), 5 selu merge(val*lambda, (exp(val)-1)*alpha*lambda, val>0) (:227-229),
+ * 6 gaussian (formula in the module header, athena_activation_gaussian.f90:8-11; the function itself lives in
+ * diffstruc, absent here), 7 piecewise (piecewise_array, athena_diffstruc_extd_sub.f90:216-254).
+ * Reverse factors, evaluated at the input: the elementary ones are diffstruc's (absent; the mathematical
+ * derivative is restated, ties of max() unpinned); piecewise follows get_partial_piecewise_val :275-290 literally,
+ * including its always-true test for limit >= 0. */
+static float oracle_actp_f(int kind, float x, float p0, float p1)
+{
+    switch (kind) {
+    case 1: return x > p0 ? x : p0;
+    case 2: return 1.0f / (1.0f + expf(-x));
+    case 3: return tanhf(x);
+    case 4: return x * p0 > x ? x * p0 : x;
+    case 5: return x > 0.0f ? x * p1 : (expf(x) - 1.0f) * p0 * p1;
+    case 6: {
+        const float t = (x - p1) / p0;
+        return 1.0f / (sqrtf(6.283185307179586f) * p0) * expf(-0.5f * t * t);
+    }
+    case 7:
+        if (x >= p1) return p0 * (x - p1) + p1;
+        if (x <= -p1) return p0 * (x + p1) - p1;
+        return x;
+    default: return x;
+    }
+}
+void oracle_activation_param(int kind, size_t n, float scale, float p0, float p1, const float *x, float *y)
+{
+    for (size_t i = 0; i < n; ++i) y[i] = oracle_actp_f(kind, x[i], p0, p1) * scale;
+}
+void oracle_activation_param_bwd(int kind, size_t n, float scale, float p0, float p1, const float *x, const float *g,
+                                 float *dx)
+{
+    for (size_t i = 0; i < n; ++i) {
+        const float u = g[i] * scale, v = x[i];
+        float d;
+        switch (kind) {
+        case 1: d = v > p0 ? u : 0.0f; break;
+        case 2: { const float y = 1.0f / (1.0f + expf(-v)); d = u * y * (1.0f - y); break; }
+        case 3: { const float y = tanhf(v); d = u * (1.0f - y * y); break; }
+        case 4: d = v * p0 > v ? u * p0 : u; break;
+        case 5: d = v > 0.0f ? u * p1 : u * (expf(v) * p0 * p1); break;
+        case 6: d = u * (-(v - p1) / (p0 * p0) * oracle_actp_f(6, v, p0, p1)); break;
+        case 7: d = (v <= p1 || v >= -p1) ? u : u * p0; break;
+        default: d = u;
+        }
+        dx[i] = d;
+    }
+}
+
 /* 'concatenate' merge of two inputs of a layer (network%add(..., operator='concatenate'),
  * example/msgpass_euler/src/main.f90:192-255): features stacked per vertex, a first */
 void oracle_concat(int N, int Fa, int Fb, const float *a, const float *b, float *out)

@@ -335,6 +335,26 @@ def swish_bwd(x, g, beta=1.0):
     return d
 
 
+ACTP = {"linear": 0, "relu": 1, "sigmoid": 2, "tanh": 3, "leaky_relu": 4, "selu": 5, "gaussian": 6, "piecewise": 7}
+
+
+def activation_param(kind, x, scale=1.0, p0=0.0, p1=0.0):
+    """athena_activation_*.f90 apply with attributes (see athena_oracle.c)"""
+    x, px = _f(x)
+    y = np.empty_like(x)
+    lib().oracle_activation_param(ACTP[kind], C.c_size_t(x.size), C.c_float(scale), C.c_float(p0), C.c_float(p1), px,
+                                  y.ctypes.data_as(C.c_void_p))
+    return y
+
+
+def activation_param_bwd(kind, x, g, scale=1.0, p0=0.0, p1=0.0):
+    x, px = _f(x); g, pg = _f(g)
+    d = np.empty_like(x)
+    lib().oracle_activation_param_bwd(ACTP[kind], C.c_size_t(x.size), C.c_float(scale), C.c_float(p0), C.c_float(p1),
+                                      px, pg, d.ctypes.data_as(C.c_void_p))
+    return d
+
+
 def concat(a, b):
     a, pa = _f(a); b, pb = _f(b)
     out = np.empty((a.shape[0], a.shape[1] + b.shape[1]), np.float32)

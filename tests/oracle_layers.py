@@ -7,8 +7,25 @@ import numpy as np
 from oracle import oracle as o
 
 
+_ATTRIBUTED = ("leaky_relu", "selu", "gaussian", "piecewise")
+
+
+def _spec(act):
+    """(name, scale, p0, p1) of an activation given by name (reference defaults) or as an object with
+    .name / .scale / .apply_scaling / .p (athena_amd.ops.actv_type)"""
+    if hasattr(act, "name"):
+        return act.name, (act.scale if act.apply_scaling else 1.0), act.p[0], act.p[1]
+    d = {"leaky_relu": (0.01, 0.0), "selu": (1.67326, 1.0507), "gaussian": (1.5, 0.0), "piecewise": (0.1, 1.0)}
+    return (act, 1.0) + d[act]
+
+
 def act_fwd(act, z):
-    """athena_activation_*.f90 apply, incl. the shaped ones the euler example uses"""
+    """athena_activation_*.f90 apply, incl. the shaped ones the euler example uses and the attributed ones"""
+    if hasattr(act, "name") or act in _ATTRIBUTED:
+        if getattr(act, "name", act) == "swish":
+            return o.swish(z, act.beta)
+        n, sc, p0, p1 = _spec(act)
+        return o.activation_param(n, z, sc, p0, p1)
     if act == "softmax":
         return o.softmax_cols(z)
     if act == "swish":
@@ -17,6 +34,11 @@ def act_fwd(act, z):
 
 
 def act_bwd(act, y, g, z):
+    if hasattr(act, "name") or act in _ATTRIBUTED:
+        if getattr(act, "name", act) == "swish":
+            return o.swish_bwd(z, g, act.beta)
+        n, sc, p0, p1 = _spec(act)
+        return o.activation_param_bwd(n, z, g, sc, p0, p1)
     if act == "softmax":
         return o.softmax_cols_bwd(y, g)
     if act == "swish":
@@ -62,11 +84,11 @@ def duvenaud_forward(graphs, xs, es, params, nvf, Fe, mn, mx, nout, act, act_rea
         for t in range(1, T + 1):
             a = o.duvenaud_propagate(cur, e, g.adj_ia, g.adj_ja)
             c = o.duvenaud_update(a, params[t - 1], g.adj_ia, mn, mx, nvf[t])
-            z = o.activation(act, c)
-            A.append(a); Z.append(z); cur = z
+            z = act_fwd(act, c)
+            A.append(a); Z.append((z, c)); cur = z
         P = []
         for t in range(1, T + 1):
-            lg = o.matmul(params[T + t - 1], Z[t - 1], nout)
+            lg = o.matmul(params[T + t - 1], Z[t - 1][0], nout)
             p = act_fwd(act_readout, lg)
             out[s] += o.segment_sum(p, np.array([0, p.shape[0]], np.int32))[0]
             P.append((p, lg))
@@ -79,17 +101,17 @@ def duvenaud_backward(graphs, es, tapes, params, nvf, Fe, mn, mx, nout, act, gou
     grads = [np.zeros_like(p) for p in params]
     dxs, des = [], []
     for s, (g, e, (A, Z, P)) in enumerate(zip(graphs, es, tapes)):
-        n = Z[0].shape[0]
+        n = Z[0][0].shape[0]
         gv = np.repeat(gout[s:s + 1], n, axis=0)
         dz_next = None
         de = np.zeros_like(e)
         for t in range(T, 0, -1):
             dl = act_bwd(act_readout, P[t - 1][0], gv, P[t - 1][1])
-            grads[T + t - 1] += o.matmul_dw(dl, Z[t - 1])
+            grads[T + t - 1] += o.matmul_dw(dl, Z[t - 1][0])
             dz = o.matmul_dx(params[T + t - 1], dl, nvf[t])
             if dz_next is not None:
                 dz = dz + dz_next
-            dc = o.activation_bwd(act, Z[t - 1], dz)
+            dc = act_bwd(act, Z[t - 1][0], dz, Z[t - 1][1])
             grads[t - 1] += o.duvenaud_update_bwd_w(dc, A[t - 1], g.adj_ia, mn, mx)
             da = o.duvenaud_update_bwd_a(dc, params[t - 1], g.adj_ia, mn, mx, A[t - 1].shape[1])
             de += o.duvenaud_propagate_bwd_e(da, nvf[t - 1], e.shape[0], g.adj_ia, g.adj_ja)
@@ -106,16 +128,16 @@ def gno_forward(graphs, xs, cs, params, Fi, Fo, d, H, use_bias, act):
         z = m + o.matmul(params[1], x, Fo)
         if use_bias:
             z = o.add_bias_rows(z, params[2])
-        y = o.activation(act, z)
-        outs.append(y); tapes.append((kap, y))
+        y = act_fwd(act, z)
+        outs.append(y); tapes.append((kap, y, z))
     return outs, tapes
 
 
 def gno_backward(graphs, xs, cs, tapes, params, Fi, Fo, d, H, use_bias, act, ups):
     grads = [np.zeros_like(p) for p in params]
     dxs, dcs = [], []
-    for g, x, c, (kap, y), up in zip(graphs, xs, cs, tapes, ups):
-        dz = o.activation_bwd(act, y, up)
+    for g, x, c, (kap, y, z), up in zip(graphs, xs, cs, tapes, ups):
+        dz = act_bwd(act, y, up, z)
         if use_bias:
             grads[2] += dz.sum(axis=0)
         grads[1] += o.matmul_dw(dz, x)

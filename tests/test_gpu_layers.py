@@ -305,3 +305,102 @@ def test_duvenaud_layer_with_another_readout_activation(dev, act_readout):
     dxs, des, grads = ol.duvenaud_backward(gs, es, tapes, plist, nvf, Fe, 1, 6, nout, "sigmoid", up, act_readout=act_readout)
     assert_close(dx, np.concatenate(dxs), 2e-5, f"readout activation {act_readout}: dx")
     assert_close(layer.get_gradients(), np.concatenate(grads), 2e-5, f"readout activation {act_readout}: gradients")
+
+
+@pytest.mark.parametrize("layer_kind", ["kipf", "duvenaud", "graph_nop"])
+@pytest.mark.parametrize("name,attrs", [("leaky_relu", {"alpha": 0.1}), ("selu", {}), ("gaussian", {"sigma": 1.0}),
+                                        ("piecewise", {"gradient": 0.3, "limit": 0.4}), ("relu", {"threshold": 0.1, "scale": 1.5})])
+def test_layers_with_attributed_activations(dev, layer_kind, name, attrs):
+    """a layer's activation given as an activation object with attributes (the reference's `activation` argument
+    is class(*): a name or a base_actv_type, athena_kipf_msgpass_layer.f90:232-262): forward and every gradient
+    against the per-sample oracle restatement"""
+    from athena_amd import ops
+    from athena_amd.layers import duvenaud_msgpass_layer_type, graph_nop_layer_type, kipf_msgpass_layer_type
+
+    rng = np.random.default_rng(sum(map(ord, name)))
+    act = ops.actv_type(name, **attrs)
+    if layer_kind == "kipf":
+        gs = _graphs(rng, [7, 19, 30], self_loops=True)
+        nvf, T_ = [6, 9, 5], 2
+        layer = kipf_msgpass_layer_type(num_vertex_features=nvf, num_time_steps=T_, activation=act, seed=2)
+        params = layer.get_params()
+        plist, o_ = [], 0
+        for t in range(1, T_ + 1):
+            plist.append(params[o_:o_ + nvf[t] * nvf[t - 1]]); o_ += nvf[t] * nvf[t - 1]
+        xs = [rng.uniform(-1, 1, (g.num_vertices, nvf[0])).astype(np.float32) for g in gs]
+        layer.set_graph(gs)
+        out = layer.forward(xs).cpu().numpy()
+        outs, tapes = ol.kipf_forward(gs, xs, plist, nvf, act)
+        assert_close(out, np.concatenate(outs), 1e-5, "fwd")
+        ups = [rng.uniform(-1, 1, o.shape).astype(np.float32) for o in outs]
+        dx = layer.backward(np.concatenate(ups)).cpu().numpy()
+        dxs, grads = ol.kipf_backward(gs, tapes, plist, nvf, act, ups)
+        assert_close(dx, np.concatenate(dxs), 2e-5, "dx")
+        assert_close(layer.get_gradients(), np.concatenate(grads), 2e-5, "dW")
+        # the card carries the attributes and reads back to the same layer
+        from athena_amd.layers import read_layer
+        card = layer.print()
+        assert f"name = {name}" in card
+        assert read_layer(card).print() == card
+    elif layer_kind == "duvenaud":
+        gs = _graphs(rng, [9, 14, 21], self_loops=False)
+        Fv, Fe, T_, nout, D = 8, 2, 2, 3, 6
+        layer = duvenaud_msgpass_layer_type(num_vertex_features=[Fv], num_edge_features=[Fe], num_time_steps=T_,
+                                            max_vertex_degree=D, num_outputs=nout, min_vertex_degree=1,
+                                            message_activation=act, readout_activation=act, seed=5)
+        nvf = layer.num_vertex_features
+        params = layer.get_params()
+        plist, o_ = [], 0
+        for t in range(1, T_ + 1):
+            k = nvf[t] * (nvf[t - 1] + Fe) * D
+            plist.append(params[o_:o_ + k]); o_ += k
+        for t in range(1, T_ + 1):
+            plist.append(params[o_:o_ + nout * nvf[t]]); o_ += nout * nvf[t]
+        xs = [rng.uniform(0, 1, (g.num_vertices, Fv)).astype(np.float32) for g in gs]
+        es = [rng.uniform(0, 1, (g.num_edges, Fe)).astype(np.float32) for g in gs]
+        layer.set_graph(gs)
+        out = layer.forward(xs, es).cpu().numpy()
+        outs, tapes = ol.duvenaud_forward(gs, xs, es, plist, nvf, Fe, 1, D, nout, act, act_readout=act)
+        assert_close(out, outs, 1e-5, "fwd")
+        up = rng.uniform(-1, 1, out.shape).astype(np.float32)
+        dx = layer.backward(up).cpu().numpy()
+        dxs, des, grads = ol.duvenaud_backward(gs, es, tapes, plist, nvf, Fe, 1, D, nout, act, up, act_readout=act)
+        assert_close(dx, np.concatenate(dxs), 2e-5, "dx")
+        assert_close(layer.get_gradients(), np.concatenate(grads), 2e-5, "gradients")
+        # default softmax readout with an attributed message activation: the fused readout reverse + separate factor
+        layer2 = duvenaud_msgpass_layer_type(num_vertex_features=[Fv], num_edge_features=[Fe], num_time_steps=T_,
+                                             max_vertex_degree=D, num_outputs=nout, min_vertex_degree=1,
+                                             message_activation=act, seed=5)
+        layer2.set_params(params)
+        layer2.set_graph(gs)
+        out2 = layer2.forward(xs, es).cpu().numpy()
+        outs2, tapes2 = ol.duvenaud_forward(gs, xs, es, plist, nvf, Fe, 1, D, nout, act)
+        assert_close(out2, outs2, 1e-5, "fwd (softmax readout)")
+        dx2 = layer2.backward(up).cpu().numpy()
+        dxs2, _, grads2 = ol.duvenaud_backward(gs, es, tapes2, plist, nvf, Fe, 1, D, nout, act, up)
+        assert_close(dx2, np.concatenate(dxs2), 2e-5, "dx (softmax readout)")
+        assert_close(layer2.get_gradients(), np.concatenate(grads2), 2e-5, "gradients (softmax readout)")
+    else:
+        gs = _graphs(rng, [20, 11], self_loops=False)
+        Fi, Fo, d, H_ = 4, 6, 2, 8
+        layer = graph_nop_layer_type(num_outputs=Fo, coord_dim=d, kernel_hidden=H_, num_inputs=Fi, use_bias=True,
+                                     activation=act, seed=3)
+        F = Fo * Fi
+        sizes = [H_ * d + H_ + F * H_ + F, F, Fo]
+        params = layer.get_params() + rng.standard_normal(sum(sizes)).astype(np.float32) * 0.1
+        layer.set_params(params)
+        plist, o_ = [], 0
+        for n in sizes:
+            plist.append(params[o_:o_ + n]); o_ += n
+        xs = [rng.uniform(-1, 1, (g.num_vertices, Fi)).astype(np.float32) for g in gs]
+        cs = [rng.standard_normal((g.num_edges, d)).astype(np.float32) for g in gs]
+        layer.set_graph(gs)
+        out = layer.forward(xs, cs).cpu().numpy()
+        outs, tapes = ol.gno_forward(gs, xs, cs, plist, Fi, Fo, d, H_, True, act)
+        assert_close(out, np.concatenate(outs), 1e-5, "fwd")
+        ups = [rng.uniform(-1, 1, o.shape).astype(np.float32) for o in outs]
+        dx, dc = layer.backward(np.concatenate(ups), need_coord_grad=True)
+        dxs, dcs, grads = ol.gno_backward(gs, xs, cs, tapes, plist, Fi, Fo, d, H_, True, act, ups)
+        assert_close(dx.cpu().numpy(), np.concatenate(dxs), 2e-5, "dx")
+        assert_close(dc.cpu().numpy(), np.concatenate(dcs), 2e-5, "dcoords")
+        assert_close(layer.get_gradients(), np.concatenate(grads), 2e-5, "dparams")

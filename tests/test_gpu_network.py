@@ -49,6 +49,37 @@ def test_swish_activation(dev, oracle, beta):
         ops.activation_bwd("swish", T(x, dev), T(g, dev))
 
 
+ATTRIBUTED = [("leaky_relu", {}), ("leaky_relu", {"alpha": 0.2, "scale": 1.5}), ("selu", {}),
+              ("selu", {"alpha": 1.2, "lambda": 0.9}), ("gaussian", {}), ("gaussian", {"sigma": 0.7, "mu": 0.3, "scale": 2.0}),
+              ("piecewise", {}), ("piecewise", {"gradient": 0.25, "limit": 0.5}), ("relu", {"threshold": 0.25}),
+              ("relu", {"scale": 3.0}), ("linear", {"scale": 0.5}), ("sigmoid", {"scale": 2.0}), ("tanh", {"scale": 1.0000005})]
+
+
+@pytest.mark.parametrize("name,attrs", ATTRIBUTED)
+def test_activations_with_attributes(dev, oracle, name, attrs):
+    """athena_activation_*.f90 with scale / threshold / alpha / lambda / sigma / mu / gradient / limit, given by
+    name (reference defaults) and as ops.actv_type; value and reverse factor against the oracle.
+    Tolerance 2e-6 relative to the largest value: the device's expf / tanhf differ from libm's by a few ulp."""
+    from athena_amd import ops
+
+    rng = np.random.default_rng(7)
+    x = (rng.standard_normal(70001) * 2).astype(np.float32)
+    g = rng.standard_normal(70001).astype(np.float32)
+    a = ops.actv_type(name, **attrs)
+    kind = ops.resolve_activation(a)
+    scale = a.scale if a.apply_scaling else 1.0
+    y = ops.activation(kind, T(x, dev))
+    assert_close(H(y), oracle.activation_param(name, x, scale, a.p[0], a.p[1]), 2e-6, f"{name} {attrs}")
+    d = ops.activation_bwd(kind, y, T(g, dev), z=T(x, dev))
+    assert_close(H(d), oracle.activation_param_bwd(name, x, g, scale, a.p[0], a.p[1]), 2e-6, f"{name} {attrs} bwd")
+    if not attrs:      # by name: the reference's reset_* defaults
+        assert np.array_equal(H(ops.activation(name, T(x, dev))), H(y))
+    if name == "tanh":  # |scale - 1| <= 1e-6 does not scale (apply_scaling, athena_activation_tanh.f90 initialise)
+        assert kind == "tanh"
+    with pytest.raises(ValueError):
+        ops.actv_type(name, no_such_attribute=1.0)
+
+
 def test_concatenate_merge_and_its_split(dev, oracle):
     from athena_amd import ops
 

@@ -135,3 +135,37 @@ def test_e16_field_is_the_eight_digit_rounding_of_the_value_property():
         assert m.startswith("0.") and m[2] != "0"
 
     check()
+
+
+def test_activation_objects_and_their_card_blocks():
+    """ops.actv_type mirrors base_actv_type: reset_* defaults, `apply_scaling` only beyond 1e-6 of one, unknown
+    attributes rejected; the ACTIVATION block lists name, scale, then the activation's own attributes as
+    adjustl(F10.6) in export_attributes_* order (athena_activation_{relu,leaky_relu,selu,gaussian,piecewise,swish}.f90)
+    and reads back to an equal object"""
+    from athena_amd import ops
+    from athena_amd.io import _activation_block, activation_from_card
+
+    assert ops.resolve_activation(ops.actv_type("relu")) == "relu"
+    assert ops.resolve_activation(ops.actv_type("tanh", scale=1.0000005)) == "tanh"
+    a = ops.resolve_activation(ops.actv_type("relu", threshold=0.1))
+    assert isinstance(a, ops.actv_type) and a.p == [0.1, 0.0] and ops.needs_input(a) and not ops.needs_input("relu")
+    assert ops.actv_type("selu").p == [1.67326, 1.0507] and ops.actv_type("selu", **{"lambda": 2.0}).p[1] == 2.0
+    assert ops.actv_type("gaussian").p == [1.5, 0.0] and ops.actv_type("piecewise").p == [0.1, 1.0]
+    assert ops.actv_type("leaky_relu").p[0] == 0.01
+    with pytest.raises(ValueError, match="no attribute"):
+        ops.actv_type("sigmoid", alpha=1.0)
+    with pytest.raises(ValueError, match="unknown activation"):
+        ops.actv_type("gelu")
+    assert _activation_block("relu") == ["   ACTIVATION", "      name = relu", "      scale = 1.000000",
+                                         "      threshold = 0.000000", "   END ACTIVATION"]
+    blk = _activation_block(ops.actv_type("selu", scale=2.0), identifier="MESSAGE")
+    assert blk == ["   ACTIVATION: MESSAGE", "      name = selu", "      scale = 2.000000", "      alpha = 1.673260",
+                   "      lambda = 1.050700", "   END ACTIVATION"]
+    assert _activation_block(ops.actv_type("swish", beta=0.5))[3] == "      beta = 0.500000"
+    for a in (ops.actv_type("gaussian", sigma=0.7, mu=0.25), ops.actv_type("piecewise", gradient=0.3), ops.actv_type("swish", beta=2.0)):
+        hp = {}
+        for line in _activation_block(a)[1:-1]:
+            k, v = (s.strip() for s in line.split("=", 1))
+            hp["activation_" + k] = v
+        b = activation_from_card(hp)
+        assert (b.name, b.scale, b.p, b.beta) == (a.name, a.scale, a.p, a.beta)

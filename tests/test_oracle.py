@@ -282,3 +282,41 @@ def test_threaded_context_baseline_equals_the_single_thread_oracle(oracle):
     assert np.allclose(dW, oracle.matmul_dw(dz, Pr), rtol=1e-4, atol=1e-5)
     assert np.allclose(dX, oracle.kipf_propagate_bwd(oracle.matmul_dx(w, dz, F), ia, ja), rtol=1e-5, atol=1e-6)
     assert threads >= 1 and dt > 0
+
+
+def test_attributed_activations_against_the_reference_test_formulas(oracle):
+    """test/test_activations.f90:395-480 (compare_output / compare_derivative) states the expected values of the
+    activations at their default attributes; the float64 forms below restate those lines."""
+    x = np.linspace(-3, 3, 61).astype(np.float32)
+    x64 = x.astype(np.float64)
+    g = np.ones_like(x)
+    # gaussian, sigma 1.5, mu 0 (:403-405, :457-460)
+    f = 1.0 / (np.sqrt(8.0 * np.arctan(1.0)) * 1.5) * np.exp(-0.5 * (x64 / 1.5) ** 2)
+    assert np.abs(oracle.activation_param("gaussian", x, 1.0, 1.5, 0.0) - f).max() <= 1e-6
+    assert np.abs(oracle.activation_param_bwd("gaussian", x, g, 1.0, 1.5, 0.0) - (-x64 / 1.5 ** 2 * f)).max() <= 1e-6
+    # leaky_relu / relu / piecewise at a positive input inside the limit return the input (:406-411)
+    pos = np.array([0.5], np.float32)
+    for kind, p0, p1 in (("leaky_relu", 0.01, 0.0), ("relu", 0.0, 0.0), ("piecewise", 0.1, 1.0), ("linear", 0.0, 0.0)):
+        assert oracle.activation_param(kind, pos, 1.0, p0, p1)[0] == pos[0]
+    # piecewise derivative is 1 where |x| >= 1 (:465-468); as written in get_partial_piecewise_val it is 1 everywhere
+    assert np.array_equal(oracle.activation_param_bwd("piecewise", x, g, 1.0, 0.1, 1.0), g)
+    # piecewise forward: slope `gradient` outside +-limit, continuous at the limit (piecewise_array :216-254)
+    pw = oracle.activation_param("piecewise", x, 1.0, 0.1, 1.0)
+    ref = np.where(x64 >= 1, 0.1 * (x64 - 1) + 1, np.where(x64 <= -1, 0.1 * (x64 + 1) - 1, x64))
+    assert np.abs(pw - ref).max() <= 1e-6
+    # selu / leaky_relu closed forms and their derivatives by central differences in float64
+    al, lam = 1.67326, 1.0507
+    selu = np.where(x64 > 0, lam * x64, al * lam * (np.exp(x64) - 1))
+    assert np.abs(oracle.activation_param("selu", x, 1.0, al, lam) - selu).max() <= 2e-6
+    dselu = np.where(x64 > 0, lam, al * lam * np.exp(x64))
+    assert np.abs(oracle.activation_param_bwd("selu", x, g, 1.0, al, lam) - dselu).max() <= 2e-6
+    lr = oracle.activation_param("leaky_relu", x, 1.0, 0.01, 0.0)
+    assert np.abs(lr - np.where(x64 > 0, x64, 0.01 * x64)).max() <= 1e-7
+    nz = np.abs(x) > 1e-6     # the tie of max() at 0 is diffstruc's choice (absent): not pinned
+    assert np.allclose(oracle.activation_param_bwd("leaky_relu", x, g, 1.0, 0.01, 0.0)[nz], np.where(x > 0, 1.0, 0.01)[nz])
+    # scale multiplies output and gradient; relu threshold clamps from below (athena_activation_relu.f90:201)
+    assert np.allclose(oracle.activation_param("relu", x, 2.0, 0.5, 0.0), 2.0 * np.maximum(x, 0.5))
+    assert np.allclose(oracle.activation_param_bwd("relu", x, g, 2.0, 0.5, 0.0), np.where(x > 0.5, 2.0, 0.0))
+    for kind in ("sigmoid", "tanh"):
+        assert np.abs(oracle.activation_param(kind, x, 1.0) - oracle.activation(kind, x)).max() == 0
+        assert np.abs(oracle.activation_param_bwd(kind, x, g, 1.0) - oracle.activation_bwd(kind, oracle.activation(kind, x), g)).max() <= 1e-7
