@@ -42,6 +42,7 @@ _PROTOS = {
     "athena_mp_graph_dims": [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i32)],
     "athena_mp_kipf_propagate_fwd": [_vp, _i32, _vp, _vp],
     "athena_mp_kipf_propagate_bwd": [_vp, _i32, _vp, _vp, _i32],
+    "athena_mp_kipf_propagate_bwd_dual": [_vp, _i32, _vp, _vp, _vp],
     "athena_mp_gather_rows": [_i64, _i32, _vp, _vp, _vp],
     "athena_mp_gemm_fwd": [_i64, _i32, _i32, _vp, _vp, _vp, _i32, _vp],
     "athena_mp_gemm_dw": [_i64, _i32, _i32, _vp, _vp, _vp],
@@ -101,6 +102,8 @@ _PROTOS = {
     "athena_mp_softmax_bwd_host": [_i64, _i32, _vp, _vp, _vp],
     "athena_mp_swish_fwd_host": [_i64, _f32, _vp, _vp],
     "athena_mp_swish_bwd_host": [_i64, _f32, _vp, _vp, _vp],
+    "athena_mp_activation_param_fwd_host": [_i32, _i64, _f32, _f32, _f32, _vp, _vp],
+    "athena_mp_activation_param_bwd_host": [_i32, _i64, _f32, _f32, _f32, _vp, _vp, _vp],
     "athena_mp_softmax_segsum_fwd_host": [_i32, _i64, _i32, _vp, _vp, _vp, _vp, _i32],
     "athena_mp_softmax_segsum_bwd_host": [_i32, _i64, _i32, _vp, _vp, _vp, _vp],
     "athena_mp_gno_aggregate_fwd_host": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],

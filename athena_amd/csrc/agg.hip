@@ -76,12 +76,13 @@ template <int VEC> __device__ __forceinline__ void vstore(float *__restrict__ p,
 constexpr int kBlock = 256;
 constexpr int kUnroll = 4;
 
-// G lanes per row, VEC floats per lane, COEF: multiply by coef[w]
-template <int G, int VEC, bool COEF>
+// G lanes per row, VEC floats per lane, COEF: multiply by coef[w]; DUAL (with COEF): the rows are gathered once
+// and summed twice -- y = plain sum, y2 = coefficient-weighted sum (same leading dimension)
+template <int G, int VEC, bool COEF, bool DUAL = false>
 __global__ __launch_bounds__(kBlock) void csr_gather_agg(
     const int32_t *__restrict__ rowbeg, const int32_t *__restrict__ rowend, const int32_t *__restrict__ idx,
     const float *__restrict__ coef, const float *__restrict__ x, int64_t ldx, float *__restrict__ y,
-    int64_t ldy, int32_t n_rows, int32_t F, int32_t long_thr)
+    int64_t ldy, int32_t n_rows, int32_t F, int32_t long_thr, float *__restrict__ y2)
 {
     constexpr int kRowsPerBlock = kBlock / G;
     const int gl = threadIdx.x & (G - 1);          // lane inside the group
@@ -109,8 +110,9 @@ __global__ __launch_bounds__(kBlock) void csr_gather_agg(
     for (int f0 = 0; f0 < F; f0 += G * VEC) {
         const int f = f0 + gl * VEC;
         const bool fin = f < F;
-        float acc[VEC];
+        float acc[VEC], acc2[VEC];
         vzero<VEC>(acc);
+        vzero<VEC>(acc2);
         for (int off = 0; off < maxlen; off += G) {
             // one coalesced load of up to G entries of the row
             int my_idx = -1;
@@ -140,7 +142,10 @@ __global__ __launch_bounds__(kBlock) void csr_gather_agg(
                     if (j + k < cnt && u[k] >= 0) {
 #pragma unroll
                         for (int i = 0; i < VEC; ++i) {
-                            if constexpr (COEF)
+                            if constexpr (DUAL) {
+                                acc[i] = acc[i] + v[k][i];
+                                acc2[i] = acc2[i] + c[k] * v[k][i];
+                            } else if constexpr (COEF)
                                 acc[i] = acc[i] + c[k] * v[k][i];
                             else
                                 acc[i] = acc[i] + v[k][i];
@@ -149,9 +154,39 @@ __global__ __launch_bounds__(kBlock) void csr_gather_agg(
                 }
             }
         }
-        if (live && fin) vstore<VEC>(y + (int64_t)row * ldy + f, acc);
+        if (live && fin) {
+            vstore<VEC>(y + (int64_t)row * ldy + f, acc);
+            if constexpr (DUAL) vstore<VEC>(y2 + (int64_t)row * ldy + f, acc2);
+        }
     }
     } // row blocks
+}
+
+template <int G, int VEC>
+int launch_dual_gv(const int32_t *rowbeg, const int32_t *rowend, const int32_t *idx, const float *coef, const float *x,
+                   int64_t ldx, float *y, float *y2, int64_t ldy, int32_t n_rows, int32_t F)
+{
+    constexpr int rpb = kBlock / G;
+    int nb = (n_rows + rpb - 1) / rpb;
+    if (amp::agg_blocks_cap() > 0) nb = std::min(nb, amp::agg_blocks_cap());
+    hipLaunchKernelGGL((csr_gather_agg<G, VEC, true, true>), dim3(nb), dim3(kBlock), 0, amp::stream(), rowbeg, rowend,
+                       idx, coef, x, ldx, y, ldy, n_rows, F, 0, y2);
+    AMP_LAUNCH_CHECK();
+    return 0;
+}
+template <int VEC>
+int launch_dual_v(int G, const int32_t *rowbeg, const int32_t *rowend, const int32_t *idx, const float *coef,
+                  const float *x, int64_t ldx, float *y, float *y2, int64_t ldy, int32_t n_rows, int32_t F)
+{
+    switch (G) {
+    case 1: return launch_dual_gv<1, VEC>(rowbeg, rowend, idx, coef, x, ldx, y, y2, ldy, n_rows, F);
+    case 2: return launch_dual_gv<2, VEC>(rowbeg, rowend, idx, coef, x, ldx, y, y2, ldy, n_rows, F);
+    case 4: return launch_dual_gv<4, VEC>(rowbeg, rowend, idx, coef, x, ldx, y, y2, ldy, n_rows, F);
+    case 8: return launch_dual_gv<8, VEC>(rowbeg, rowend, idx, coef, x, ldx, y, y2, ldy, n_rows, F);
+    case 16: return launch_dual_gv<16, VEC>(rowbeg, rowend, idx, coef, x, ldx, y, y2, ldy, n_rows, F);
+    case 32: return launch_dual_gv<32, VEC>(rowbeg, rowend, idx, coef, x, ldx, y, y2, ldy, n_rows, F);
+    default: return launch_dual_gv<64, VEC>(rowbeg, rowend, idx, coef, x, ldx, y, y2, ldy, n_rows, F);
+    }
 }
 
 template <int G, int VEC>
@@ -164,10 +199,10 @@ int launch_gv(bool has_coef, const int32_t *rowbeg, const int32_t *rowend, const
     dim3 grid(nb), block(kBlock);
     if (has_coef)
         hipLaunchKernelGGL((csr_gather_agg<G, VEC, true>), grid, block, 0, amp::stream(), rowbeg, rowend, idx, coef, x,
-                           ldx, y, ldy, n_rows, F, long_thr);
+                           ldx, y, ldy, n_rows, F, long_thr, (float *)nullptr);
     else
         hipLaunchKernelGGL((csr_gather_agg<G, VEC, false>), grid, block, 0, amp::stream(), rowbeg, rowend, idx, coef,
-                           x, ldx, y, ldy, n_rows, F, long_thr);
+                           x, ldx, y, ldy, n_rows, F, long_thr, (float *)nullptr);
     AMP_LAUNCH_CHECK();
     return 0;
 }
@@ -252,6 +287,31 @@ int gather_agg(const int32_t *rowptr, const int32_t *idx, const float *coef, con
     return 0;
 }
 
+// One gather, two sums: y = sum of the rows, y2 = coefficient-weighted sum (dense rows, ld = F).  Graphs with hub
+// rows (segment plan) take two single passes instead -- the segment path is not duplicated for this.
+int gather_agg_dual(const int32_t *rowptr, const int32_t *idx, const float *coef, const float *x, float *y, float *y2,
+                    int32_t n_rows, int32_t F, const LongPlan *lp)
+{
+    if (n_rows == 0 || F == 0) return 0;
+    if (lp && lp->n_long > 0) {
+        if (int rc = gather_agg(rowptr, idx, nullptr, x, F, y, F, n_rows, F, lp)) return rc;
+        return gather_agg(rowptr, idx, coef, x, F, y2, F, n_rows, F, lp);
+    }
+    auto aligned = [&](int v) {
+        return F % v == 0 && ((uintptr_t)x % (4 * v)) == 0 && ((uintptr_t)y % (4 * v)) == 0 &&
+               ((uintptr_t)y2 % (4 * v)) == 0;
+    };
+    const int vec = aligned(4) ? 4 : (aligned(2) ? 2 : 1);
+    const int lanes = (F + vec - 1) / vec;
+    int G = 1;
+    while (G < lanes && G < 64) G <<= 1;
+    switch (vec) {
+    case 4: return launch_dual_v<4>(G, rowptr, rowptr + 1, idx, coef, x, F, y, y2, F, n_rows, F);
+    case 2: return launch_dual_v<2>(G, rowptr, rowptr + 1, idx, coef, x, F, y, y2, F, n_rows, F);
+    default: return launch_dual_v<1>(G, rowptr, rowptr + 1, idx, coef, x, F, y, y2, F, n_rows, F);
+    }
+}
+
 } // namespace amp
 
 using namespace amp;
@@ -273,6 +333,17 @@ int athena_mp_kipf_propagate_bwd(const athena_mp_graph *g, int32_t F, const floa
     if (g->n_cols == 0) return 0;
     AMP_REQUIRE(dx && (grad || g->nnz == 0), "kipf_propagate_bwd: null tensor");
     return gather_agg(g->t_rowptr, g->t_src, exact ? g->t_coef : nullptr, grad, F, dx, F, g->n_cols, F, &g->lp_bwd);
+}
+
+/* both reverse forms of kipf_propagate from one gather of the upstream rows: dx_plain = the reference's
+ * coefficient-free scatter (get_partial_kipf_propagate_left_val :85-111), dx_coef = the adjoint of the forward */
+int athena_mp_kipf_propagate_bwd_dual(const athena_mp_graph *g, int32_t F, const float *grad, float *dx_plain,
+                                      float *dx_coef)
+{
+    AMP_REQUIRE(g && F > 0, "kipf_propagate_bwd_dual: bad arguments");
+    if (g->n_cols == 0) return 0;
+    AMP_REQUIRE(dx_plain && dx_coef && (grad || g->nnz == 0), "kipf_propagate_bwd_dual: null tensor");
+    return gather_agg_dual(g->t_rowptr, g->t_src, g->t_coef, grad, dx_plain, dx_coef, g->n_cols, F, &g->lp_bwd);
 }
 
 int athena_mp_duvenaud_propagate_fwd(const athena_mp_graph *g, int32_t Fv, int32_t Fe, const float *x,

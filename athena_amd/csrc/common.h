@@ -104,6 +104,8 @@ void set_agg_blocks_cap(int n);
 // shared launchers (defined in agg.hip / gemm.hip)
 int gather_agg(const int32_t *rowptr, const int32_t *idx, const float *coef, const float *x, int64_t ldx,
                float *y, int64_t ldy, int32_t n_rows, int32_t F, const LongPlan *lp = nullptr);
+int gather_agg_dual(const int32_t *rowptr, const int32_t *idx, const float *coef, const float *x, float *y, float *y2,
+                    int32_t n_rows, int32_t F, const LongPlan *lp);
 // Z[M,N] = act(A[M,K] . B + bias); b_nk: B stored [N][K] instead of [K][N]
 int gemm_dispatch(const float *A, const float *B, int b_nk, const float *bias, int act, float *Z, int64_t M,
                   int K, int N);

@@ -314,4 +314,20 @@ int athena_mp_swish_bwd_host(int64_t n, float beta, const float *x, const float 
     });
 }
 
+int athena_mp_activation_param_fwd_host(int32_t kind, int64_t n, float scale, float p0, float p1, const float *x, float *y)
+{
+    AMP_REQUIRE(n >= 0 && (n == 0 || (x && y)), "activation_param_fwd_host: bad arguments");
+    return staged({{x, nullptr, fb(n, 1)}, {nullptr, y, fb(n, 1)}}, [&](std::vector<void *> &d) {
+        return athena_mp_activation_param_fwd(kind, n, scale, p0, p1, (float *)d[0], (float *)d[1]);
+    });
+}
+int athena_mp_activation_param_bwd_host(int32_t kind, int64_t n, float scale, float p0, float p1, const float *x,
+                                        const float *g, float *dx)
+{
+    AMP_REQUIRE(n >= 0 && (n == 0 || (x && g && dx)), "activation_param_bwd_host: bad arguments");
+    return staged({{x, nullptr, fb(n, 1)}, {g, nullptr, fb(n, 1)}, {nullptr, dx, fb(n, 1)}}, [&](std::vector<void *> &d) {
+        return athena_mp_activation_param_bwd(kind, n, scale, p0, p1, (float *)d[0], (float *)d[1], (float *)d[2]);
+    });
+}
+
 } // extern "C"

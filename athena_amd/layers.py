@@ -175,8 +175,14 @@ class kipf_msgpass_layer_type(msgpass_layer_type):
     name = "kipf"
 
     def __init__(self, num_vertex_features, num_time_steps, activation="none", kernel_initialiser=None,
-                 verbose=0, device="cuda:0", seed=0):
+                 verbose=0, device="cuda:0", seed=0, order="auto"):
+        """order: which of the two associations of W.(A X) a time step evaluates --
+        "aggregate_first" (the reference's: P = A X, then the dense step), "transform_first" (Y = X W^T, then
+        A Y: the aggregation runs on F_out-wide rows) or "auto" (transform first when 4 F_out <= 3 F_in).
+        Same result up to fp32 summation order."""
         super().__init__(device, seed)
+        assert order in ("auto", "aggregate_first", "transform_first")
+        self.order = order
         self.num_time_steps = int(num_time_steps)
         self.num_vertex_features = _expand(num_vertex_features, self.num_time_steps, "num_vertex_features")
         self.num_edge_features = [0] * (self.num_time_steps + 1)
@@ -197,6 +203,14 @@ class kipf_msgpass_layer_type(msgpass_layer_type):
         self._tape = []
         cur = x
         for t in range(1, self.num_time_steps + 1):
+            if self._transform_first(t):
+                # dense step first: the gather then moves F_t-wide rows instead of F_{t-1}-wide ones
+                y = ops.matmul(self.params[t - 1], cur, self.num_vertex_features[t])
+                z = ops.kipf_propagate(g, y)
+                nxt = ops.activation(self.activation, z) if not _identity(self.activation) else z
+                self._tape.append((cur, nxt, z if ops.needs_input(self.activation) else None))
+                cur = nxt
+                continue
             if _fusable(self.activation):
                 # aggregation + dense step (+ activation) in one launch where the fused kernel exists
                 p, nxt = ops.kipf_layer_fwd(g, cur, self.params[t - 1], self.num_vertex_features[t], act=self.activation)
@@ -212,6 +226,13 @@ class kipf_msgpass_layer_type(msgpass_layer_type):
             cur = nxt
         self.output = cur
 
+    def _transform_first(self, t):
+        fi, fo = self.num_vertex_features[t - 1], self.num_vertex_features[t]
+        g = self.graph.device
+        if g.n_rows != g.n_cols:      # a row shard gathers halo rows: the layer step of athena_amd.dist decides there
+            return False
+        return self.order == "transform_first" or (self.order == "auto" and 4 * fo <= 3 * fi)
+
     def update_readout(self):
         pass  # node-level output (update_readout_kipf :964-971)
 
@@ -223,6 +244,19 @@ class kipf_msgpass_layer_type(msgpass_layer_type):
         for t in range(self.num_time_steps, 0, -1):
             p, out, z = self._tape[t - 1]
             dz = ops.activation_bwd(self.activation, out, gcur, z=z) if not _identity(self.activation) else gcur
+            if self._transform_first(t):
+                # Z = A (X W^T):  dW = (A^T dZ)^T X with the coefficient, dX = (scatter of dZ) W in the reference's
+                # coefficient-free form -- both sums from one gather of the dZ rows (p holds the step's input X)
+                if t == 1 and not need_input_grad:
+                    self.grads[t - 1] = ops.matmul_dw(p, ops.kipf_propagate_bwd(g, dz, exact=True))
+                    return None
+                if exact:
+                    q_plain = q_coef = ops.kipf_propagate_bwd(g, dz, exact=True)
+                else:
+                    q_plain, q_coef = ops.kipf_propagate_bwd_dual(g, dz)
+                self.grads[t - 1] = ops.matmul_dw(p, q_coef)
+                gcur = ops.matmul_dx(self.params[t - 1], q_plain, self.num_vertex_features[t - 1])
+                continue
             dw = ops.matmul_dw(p, dz)
             self.grads[t - 1] = dw
             if t == 1 and not need_input_grad:   # input layer output has requires_grad = .false.

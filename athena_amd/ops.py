@@ -55,6 +55,18 @@ def kipf_propagate_bwd(g: DeviceGraph, grad, exact=False, out=None):
     return dx
 
 
+def kipf_propagate_bwd_dual(g: DeviceGraph, grad):
+    """both reverse forms of kipf_propagate from one gather of the upstream rows: (coefficient-free scatter of the
+    reference, adjoint of the forward)"""
+    F = grad.shape[1]
+    _chk(grad, (g.n_rows, F))
+    plain = torch.empty((g.n_cols, F), device=grad.device, dtype=torch.float32)
+    coef = torch.empty((g.n_cols, F), device=grad.device, dtype=torch.float32)
+    _go()
+    _capi.call("athena_mp_kipf_propagate_bwd_dual", g.handle, F, _p(grad), _p(plain), _p(coef))
+    return plain, coef
+
+
 def neighbour_sum(g: DeviceGraph, x, out=None):
     """y[v,:] = sum_{w in row v} x[col[w],:] (no coefficient): the pull form of the reference's
     coefficient-free backward on a symmetric graph shard (= duvenaud_propagate with F_e = 0)"""

@@ -99,6 +99,11 @@ int athena_mp_kipf_propagate_fwd(const athena_mp_graph *g, int32_t F, const floa
  *   exact=1: multiplied by the coefficient, the mathematically exact adjoint) */
 int athena_mp_kipf_propagate_bwd(const athena_mp_graph *g, int32_t F, const float *grad_dev,
                                  float *dx_dev, int32_t exact);
+/* both reverse forms from ONE gather of the upstream rows: dx_plain = the reference's coefficient-free scatter
+ * (exact = 0 above), dx_coef = the adjoint of the forward (exact = 1).  What a layer step needs when it applies
+ * the dense step BEFORE the aggregation (F_out < F_in): dX = dx_plain . W,  dW = dx_coef^T . X */
+int athena_mp_kipf_propagate_bwd_dual(const athena_mp_graph *g, int32_t F, const float *grad_dev,
+                                      float *dx_plain_dev, float *dx_coef_dev);
 
 /* out[r,:] = x[idx[r],:]  (r < n; idx 0-based device array).  Packs the halo rows a row partition
  * sends to its peers; same gather kernel as the aggregation. */
@@ -307,6 +312,10 @@ int athena_mp_softmax_fwd_host(int64_t N, int32_t F, const float *z, float *y);
 int athena_mp_softmax_bwd_host(int64_t N, int32_t F, const float *y, const float *g, float *dz);
 int athena_mp_swish_fwd_host(int64_t n, float beta, const float *x, float *y);
 int athena_mp_swish_bwd_host(int64_t n, float beta, const float *x, const float *g, float *dx);
+int athena_mp_activation_param_fwd_host(int32_t kind, int64_t n, float scale, float p0, float p1, const float *x,
+                                        float *y);
+int athena_mp_activation_param_bwd_host(int32_t kind, int64_t n, float scale, float p0, float p1, const float *x,
+                                        const float *g, float *dx);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,45 @@
+"""Kipf step on the C2 graph with a shrinking dense step: aggregate-first (the reference's association) against
+transform-first (dense step before the aggregation; reverse pass = one dual gather + two GEMMs)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from athena_amd import DeviceGraph, ops, synth
+dev = torch.device("cuda:0")
+n, pairs = 1000000, 4500000
+ia, ja = synth.random_graph_csr(n, pairs)
+g = DeviceGraph(ia, ja, n_edge_cols=0)
+nnz = ja.shape[1]
+
+
+def timeit(fn, reps=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+for Fi, Fo in ((128, 128), (128, 96), (128, 64), (128, 32), (256, 64), (64, 16)):
+    x = torch.rand((n, Fi), device=dev) - 0.5
+    w = (torch.rand(Fo * Fi, device=dev) - 0.5) * 0.2
+    dz = torch.rand((n, Fo), device=dev) - 0.5
+
+    def agg_first():
+        p, z = ops.kipf_layer_fwd(g, x, w, Fo)
+        dw = ops.matmul_dw(p, dz)
+        return ops.kipf_layer_bwd_x(g, dz, w, Fi)
+
+    def tr_first():
+        y = ops.matmul(w, x, Fo)
+        z = ops.kipf_propagate(g, y)
+        qp, qc = ops.kipf_propagate_bwd_dual(g, dz)
+        dw = ops.matmul_dw(x, qc)
+        return ops.matmul_dx(w, qp, Fi)
+
+    ta, tt = timeit(agg_first), timeit(tr_first)
+    print(f"F {Fi:4d} -> {Fo:4d}: aggregate-first {ta:7.3f} ms ({nnz / ta / 1e6:6.2f} G edges/s)   "
+          f"transform-first {tt:7.3f} ms ({nnz / tt / 1e6:6.2f} G edges/s)   ratio {ta / tt:5.2f}", flush=True)

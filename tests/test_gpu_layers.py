@@ -404,3 +404,39 @@ def test_layers_with_attributed_activations(dev, layer_kind, name, attrs):
         assert_close(dx.cpu().numpy(), np.concatenate(dxs), 2e-5, "dx")
         assert_close(dc.cpu().numpy(), np.concatenate(dcs), 2e-5, "dcoords")
         assert_close(layer.get_gradients(), np.concatenate(grads), 2e-5, "dparams")
+
+
+@pytest.mark.parametrize("act", ["none", "relu", "swish"])
+@pytest.mark.parametrize("exact", [False, True])
+def test_kipf_layer_dense_step_before_the_aggregation(dev, act, exact):
+    """order="transform_first": Z = A (X W^T) instead of the reference's W (A X) -- same forward, same dW, same dX
+    (incl. the reference's coefficient-free reverse scatter, exact=False) up to fp32 summation order, 1e-5; "auto"
+    picks it for the shrinking step only"""
+    from athena_amd.layers import kipf_msgpass_layer_type
+
+    rng = np.random.default_rng(77)
+    gs = _graphs(rng, [30, 55, 12, 41], self_loops=True)
+    nvf, T_ = [48, 12, 20, 5], 3
+    xs = [rng.uniform(-1, 1, (g.num_vertices, nvf[0])).astype(np.float32) for g in gs]
+    ref = None
+    for order in ("aggregate_first", "transform_first", "auto"):
+        layer = kipf_msgpass_layer_type(num_vertex_features=nvf, num_time_steps=T_, activation=act, seed=4, order=order)
+        params = layer.get_params()
+        plist, o_ = [], 0
+        for t in range(1, T_ + 1):
+            plist.append(params[o_:o_ + nvf[t] * nvf[t - 1]]); o_ += nvf[t] * nvf[t - 1]
+        layer.set_graph(gs)
+        out = layer.forward(xs).cpu().numpy()
+        if order == "auto":
+            assert [layer._transform_first(t) for t in (1, 2, 3)] == [True, False, True]
+        outs, tapes = ol.kipf_forward(gs, xs, plist, nvf, act)
+        assert_close(out, np.concatenate(outs), 1e-5, f"{order}: fwd")
+        ups = [np.random.default_rng(5).uniform(-1, 1, o.shape).astype(np.float32) for o in outs]
+        dx = layer.backward(np.concatenate(ups), exact=exact).cpu().numpy()
+        dxs, grads = ol.kipf_backward(gs, tapes, plist, nvf, act, ups, exact=exact)
+        assert_close(dx, np.concatenate(dxs), 2e-5, f"{order}: dx")
+        assert_close(layer.get_gradients(), np.concatenate(grads), 2e-5, f"{order}: dW")
+        # first layer of a network: no input gradient requested, dW still complete
+        layer.forward(xs)
+        assert layer.backward(np.concatenate(ups), need_input_grad=False, exact=exact) is None
+        assert_close(layer.get_gradients(), np.concatenate(grads), 2e-5, f"{order}: dW without dx")

@@ -118,6 +118,37 @@ def test_kipf_empty_and_single(dev, oracle):
     assert torch.all(y == 0)
 
 
+@pytest.mark.parametrize("F", [1, 3, 6, 16, 32, 64, 130])
+def test_kipf_reverse_both_forms_from_one_gather(dev, oracle, F):
+    """athena_mp_kipf_propagate_bwd_dual: the coefficient-free scatter of the reference and the adjoint of the
+    forward from ONE pass over the upstream rows -- each BIT-equal to its own launch and to the oracle; a graph
+    with hub columns (segment plan) takes the two-pass route behind the same entry point"""
+    from athena_amd import DeviceGraph, ops
+
+    for hubs in (False, True):
+        rng = np.random.default_rng(F + hubs)
+        n = 900
+        deg = rng.integers(1, 12, n)     # no empty rows: a zero-degree column would make the coefficient infinite
+        if hubs:
+            deg[[5, 400]] = [1500, 700]
+        ia = np.concatenate([[1], 1 + np.cumsum(deg)]).astype(np.int32)
+        ja = np.zeros((2, int(deg.sum())), np.int32, order="F")
+        ja[0] = rng.integers(1, n + 1, ja.shape[1])
+        if hubs:
+            ja[0, :1200] = 17       # column 17 becomes a hub of the transposed structure
+        g = DeviceGraph(ia, ja, n_edge_cols=0)
+        up = rng.uniform(-1, 1, (n, F)).astype(np.float32)
+        plain, coef = ops.kipf_propagate_bwd_dual(g, T(up, dev))
+        p1, c1 = ops.kipf_propagate_bwd(g, T(up, dev)), ops.kipf_propagate_bwd(g, T(up, dev), exact=True)
+        assert torch.equal(plain, p1) and torch.equal(coef, c1)
+        po, co = oracle.kipf_propagate_bwd(up, ia, ja), oracle.kipf_propagate_bwd(up, ia, ja, exact=True)
+        if hubs:      # segmented hub sums: a 1200-term fp32 sum in another order than the sequential oracle's --
+            # 3e-5 of the largest value (the hub itself) is that sum's own rounding noise
+            assert_close(H(plain), po, 3e-5, "plain"); assert_close(H(coef), co, 3e-5, "coef")
+        else:
+            assert np.array_equal(H(plain), po) and np.array_equal(H(coef), co)
+
+
 def test_kipf_rectangular_block_with_explicit_degrees(dev, oracle):
     """row partition with halo columns: degrees supplied (the multi-GPU shard shape)"""
     from athena_amd import DeviceGraph, ops
@@ -502,6 +533,11 @@ def test_host_pointer_variants(dev, oracle):
     sw = np.empty_like(u)
     _capi.call("athena_mp_swish_fwd_host", u.size, 1.0, P_(u), P_(sw))
     assert_close(sw, oracle.swish(u), 1e-6)
+    ga, dga = np.empty_like(u), np.empty_like(u)
+    _capi.call("athena_mp_activation_param_fwd_host", 6, u.size, 2.0, 0.7, 0.1, P_(u), P_(ga))     # gaussian
+    assert_close(ga, oracle.activation_param("gaussian", u, 2.0, 0.7, 0.1), 2e-6)
+    _capi.call("athena_mp_activation_param_bwd_host", 5, u.size, 1.0, 1.67326, 1.0507, P_(u), P_(sm), P_(dga))   # selu
+    assert_close(dga, oracle.activation_param_bwd("selu", u, sm, 1.0, 1.67326, 1.0507), 2e-6)
     # GNO through host arrays
     gg, E, coords, xx, theta, upg = _gno_case(5, 30, 3, 8, 4, 6, 20)
     d2 = DeviceGraph(gg.adj_ia, gg.adj_ja, n_edge_cols=E)
