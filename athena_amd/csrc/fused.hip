@@ -320,6 +320,12 @@ int athena_mp_kipf_layer_bwd_x(const athena_mp_graph *g, int32_t Fi, int32_t Fo,
         return fused_dispatch(g->t_rowptr, g->t_src, exact ? g->t_coef : nullptr, dZ, Fo, Fi, W, 1, nullptr,
                               ATHENA_MP_ACT_NONE, nullptr, dX, g->n_cols);
     void *ws = nullptr;
+    if (Fo < Fi) { // (A^T dZ) . W : the scatter moves the narrower rows
+        if (workspace(&ws, sizeof(float) * (size_t)g->n_cols * Fo, 5)) return 1;
+        int rc = athena_mp_kipf_propagate_bwd(g, Fo, dZ, (float *)ws, exact);
+        if (rc) return rc;
+        return athena_mp_gemm_dx(g->n_cols, Fi, Fo, (const float *)ws, W, dX);
+    }
     if (workspace(&ws, sizeof(float) * (size_t)g->n_rows * Fi, 5)) return 1;
     int rc = athena_mp_gemm_dx(g->n_rows, Fi, Fo, dZ, W, (float *)ws);
     if (rc) return rc;
@@ -338,6 +344,13 @@ int athena_mp_pull_gemm(const athena_mp_graph *g, int32_t Fi, int32_t Fo, const 
         return fused_dispatch(g->rowptr, g->col, exact ? g->coef : nullptr, dZ, Fo, Fi, W, 1, nullptr,
                               ATHENA_MP_ACT_NONE, nullptr, dX, g->n_rows);
     void *ws = nullptr;
+    if (Fi < Fo) { // A (dZ . W) : contract every source row first, gather the narrower result
+        if (workspace(&ws, sizeof(float) * (size_t)g->n_cols * Fi, 5)) return 1;
+        int rc = athena_mp_gemm_dx(g->n_cols, Fi, Fo, dZ, W, (float *)ws);
+        if (rc) return rc;
+        return gather_agg(g->rowptr, g->col, exact ? g->coef : nullptr, (const float *)ws, Fi, dX, Fi, g->n_rows, Fi,
+                          &g->lp_fwd);
+    }
     if (workspace(&ws, sizeof(float) * (size_t)g->n_rows * Fo, 5)) return 1;
     int rc = gather_agg(g->rowptr, g->col, exact ? g->coef : nullptr, dZ, Fo, (float *)ws, Fo, g->n_rows, Fo, &g->lp_fwd);
     if (rc) return rc;

@@ -483,6 +483,36 @@ def test_fused_kipf_layer_kernels(dev, oracle, act, F):
                  oracle.kipf_propagate_bwd(oracle.matmul_dx(w2, dz2, 64), ia, ja), 1e-5)
 
 
+@pytest.mark.parametrize("Fi,Fo", [(48, 20), (20, 48), (64, 32), (32, 64), (7, 130)])
+def test_reverse_step_picks_the_narrower_side_for_the_scatter(dev, oracle, Fi, Fo):
+    """kipf_layer_bwd_x / pull_gemm evaluate A^T(dZ W) or (A^T dZ) W -- whichever moves the narrower rows through
+    the scatter; both associations agree with the oracle's (the reference's order) to 1e-5, on a rectangular
+    row block (the shard shape) with supplied degrees"""
+    from athena_amd import DeviceGraph, ops
+
+    rng = np.random.default_rng(Fi * 3 + Fo)
+    n_rows, n_cols = 400, 700
+    deg = rng.integers(0, 15, n_rows)
+    ia = np.concatenate([[1], 1 + np.cumsum(deg)]).astype(np.int32)
+    ja = np.zeros((2, int(deg.sum())), np.int32, order="F")
+    ja[0] = rng.integers(1, n_cols + 1, ja.shape[1])
+    row_deg = (deg + 1).astype(np.int32)
+    col_deg = rng.integers(1, 30, n_cols).astype(np.int32)
+    g = DeviceGraph(ia, ja, n_cols=n_cols, n_edge_cols=0, row_deg=row_deg, col_deg=col_deg)
+    w = (rng.standard_normal(Fo * Fi) * 0.2).astype(np.float32)
+    dz = rng.uniform(-1, 1, (n_rows, Fo)).astype(np.float32)
+    dx = H(ops.kipf_layer_bwd_x(g, T(dz, dev), T(w, dev), Fi))
+    assert_close(dx, oracle.kipf_propagate_bwd(oracle.matmul_dx(w, dz, Fi), ia, ja, n_out=n_cols), 1e-5, "bwd_x")
+    # pull form: rows of g list the SOURCES; dX[v] = (sum_w dZ[col w]) W
+    dzs = rng.uniform(-1, 1, (n_cols, Fo)).astype(np.float32)
+    pulled = H(ops.pull_gemm(g, T(dzs, dev), T(w, dev), Fi))
+    dense = np.zeros((n_rows, n_cols))
+    for v in range(n_rows):
+        for k in range(ia[v] - 1, ia[v + 1] - 1):
+            dense[v, ja[0, k] - 1] += 1.0
+    assert_close(pulled, dense @ dzs.astype(np.float64) @ w.reshape(Fi, Fo).astype(np.float64).T, 1e-5, "pull_gemm")
+
+
 def test_host_pointer_variants(dev, oracle):
     """the *_host entry points a Fortran caller holding array_type%val would use (phase-1 staging)"""
     import ctypes as C
