@@ -169,6 +169,12 @@ def layer_card(layer):
         if layer.activation != "none":
             lines += _activation_block(layer.activation, identifier="MESSAGE")
         lines += _activation_block(layer.activation_readout, identifier="READOUT")
+    elif layer.name == "full":             # print_to_unit_full, athena_full_layer.f90:434-468
+        lines.append(f"   NUM_INPUTS = {layer.num_inputs}")
+        lines.append(f"   NUM_OUTPUTS = {layer.num_outputs}")
+        lines.append(f"   USE_BIAS = {'T' if layer.use_bias else 'F'}")
+        if layer.activation != "none":
+            lines += _activation_block(layer.activation)
     elif layer.name == "graph_nop":
         lines.append(f"   NUM_INPUTS = {layer.num_vertex_features[0]}")
         lines.append(f"   NUM_OUTPUTS = {layer.num_outputs}")
@@ -189,7 +195,7 @@ def parse_layer_card(text):
     stub, :703-714, so there is nothing to mirror for it).  Returns (name, hyperparameters, flat weight vector)."""
     lines = [l.rstrip() for l in text.splitlines() if l.strip()]
     name = lines[0].strip().lower()
-    if name not in ("kipf", "graph_nop"):
+    if name not in ("kipf", "graph_nop", "full"):
         raise ValueError(f"unsupported layer card '{lines[0].strip()}'")
     if lines[-1].strip() != "END " + name.upper():
         raise ValueError(f"END {name.upper()} not where expected")                  # the reference's message

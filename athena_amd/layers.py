@@ -42,13 +42,24 @@ def _expand(nf, T, what):
     raise ValueError(f"Error: {what} must be a scalar or a vector of length num_time_steps + 1")
 
 
-def _init_weights(rng, n, fan_in, fan_out, activation):
+def _init_weights(rng, n, fan_in, fan_out, activation, initialiser=None):
     """default initialiser: he_normal for relu-family else glorot_uniform
-    (docs/source/layers/msgpass/kipf_msgpass_layer.rst:61-65)"""
-    if getattr(activation, "name", activation) in ("relu", "leaky_relu", "swish", "selu"):
-        return (rng.standard_normal(n) * np.sqrt(2.0 / fan_in)).astype(np.float32)
-    lim = np.sqrt(6.0 / (fan_in + fan_out))
-    return rng.uniform(-lim, lim, n).astype(np.float32)
+    (docs/source/layers/msgpass/kipf_msgpass_layer.rst:61-65); by name: athena_initialiser_{glorot,he,lecun,
+    zeros,ones}.f90 (limits / sigmas as at _glorot.f90:120,178, _he.f90:167,229, _lecun.f90:117,172).  The
+    random stream is numpy's, not the reference's -- distributions match, draws do not."""
+    name = initialiser
+    if name is None:
+        name = "he_normal" if getattr(activation, "name", activation) in ("relu", "leaky_relu", "swish", "selu") else "glorot_uniform"
+    uniform = {"glorot_uniform": 6.0 / (fan_in + fan_out), "he_uniform": 6.0 / fan_in, "lecun_uniform": 3.0 / fan_in}
+    normal = {"glorot_normal": 2.0 / (fan_in + fan_out), "he_normal": 2.0 / fan_in, "lecun_normal": 1.0 / fan_in}
+    if name in uniform:
+        lim = np.sqrt(uniform[name])
+        return rng.uniform(-lim, lim, n).astype(np.float32)
+    if name in normal:
+        return (rng.standard_normal(n) * np.sqrt(normal[name])).astype(np.float32)
+    if name in ("zeros", "ones"):
+        return np.full(n, 0.0 if name == "zeros" else 1.0, np.float32)
+    raise ValueError(f"unknown initialiser '{name}'")
 
 
 class _batched_graph:
@@ -191,7 +202,7 @@ class kipf_msgpass_layer_type(msgpass_layer_type):
         # init_kipf :345-380 -- params(t): W(F_t, F_{t-1}) flat column-major
         for t in range(1, self.num_time_steps + 1):
             fi, fo = self.num_vertex_features[t - 1], self.num_vertex_features[t]
-            self.params.append(self._t(_init_weights(self._rng, fo * fi, fi, fo, self.activation)))
+            self.params.append(self._t(_init_weights(self._rng, fo * fi, fi, fo, self.activation, kernel_initialiser)))
         self.grads = [None] * len(self.params)
         if verbose:
             print(f"KIPF activation function: {self.activation}")
@@ -287,10 +298,11 @@ class duvenaud_msgpass_layer_type(msgpass_layer_type):
         # init_duvenaud :547-589 -- T message tensors W(F_t, F_{t-1}+Fe, D), then T readout R(num_outputs, F_t)
         for t in range(1, T + 1):
             fi, fo = self.num_vertex_features[t - 1] + Fe, self.num_vertex_features[t]
-            self.params.append(self._t(_init_weights(self._rng, fo * fi * D, fi, fo, self.activation)))
+            self.params.append(self._t(_init_weights(self._rng, fo * fi * D, fi, fo, self.activation, kernel_initialiser)))
         for t in range(1, T + 1):
             fv = self.num_vertex_features[t]
-            self.params.append(self._t(_init_weights(self._rng, self.num_outputs * fv, sum(self.num_vertex_features), self.num_outputs, self.activation)))
+            self.params.append(self._t(_init_weights(self._rng, self.num_outputs * fv, sum(self.num_vertex_features), self.num_outputs,
+                                                     self.activation, kernel_initialiser)))
         self.grads = [None] * len(self.params)
 
     def update_message(self, x, e):
@@ -453,12 +465,81 @@ class graph_nop_layer_type(msgpass_layer_type):
         return (dx, dc) if need_coord_grad else dx
 
 
+# ==================================================================================================
+class full_layer_type(msgpass_layer_type):
+    """athena_full_layer.f90 -- the dense head the msgpass examples put after a graph-level readout
+    (example/msgpass_chemical/src/main.f90:139-157): output = act(W . input + b) on [batch, num_inputs] rows
+    (forward_full :835-875: matmul(params(1), input) + params(2), then the activation).  params(1) = W(num_outputs,
+    num_inputs) flat column-major, params(2) = b (init_full :369-413).  One GEMM launch with the bias (and a plain
+    activation) in its epilogue; activations with attributes run as their own launch on the kept pre-activation."""
+
+    name = "full"
+
+    def __init__(self, num_outputs, num_inputs=None, use_bias=True, activation="none", kernel_initialiser=None,
+                 bias_initialiser=None, verbose=0, device="cuda:0", seed=0):
+        super().__init__(device, seed)
+        self.num_outputs, self.num_inputs = int(num_outputs), None
+        self.use_bias = bool(use_bias)
+        self.activation = ops.resolve_activation(activation or "none")
+        self._kernel_initialiser, self._bias_initialiser = kernel_initialiser, bias_initialiser or "zeros"
+        if num_inputs is not None:
+            self._init(int(num_inputs))
+
+    def _init(self, num_inputs):
+        """init_full: the input width may come from the previous layer when the network is assembled"""
+        self.num_inputs = num_inputs
+        fi, fo = num_inputs, self.num_outputs
+        self.params = [self._t(_init_weights(self._rng, fo * fi, fi, fo, self.activation, self._kernel_initialiser))]
+        if self.use_bias:
+            self.params.append(self._t(_init_weights(self._rng, fo, fi, fo, self.activation, self._bias_initialiser)))
+        self.grads = [None] * len(self.params)
+
+    def get_num_params(self):
+        if self.num_inputs is None:
+            return 0
+        return (self.num_inputs + int(self.use_bias)) * self.num_outputs       # get_num_params_full :122-138
+
+    def set_graph(self, graphs):
+        return self          # no graph input
+
+    def forward(self, x, edge_features=None):
+        x = self._cat(x)
+        if self.num_inputs is None:
+            self._init(int(x.shape[1]))
+        assert x.dim() == 2 and x.shape[1] == self.num_inputs, "full layer: input width mismatch"
+        self._x = x
+        b = self.params[1] if self.use_bias else None
+        if _fusable(self.activation):
+            self._z = None
+            self.output = ops.matmul(self.params[0], x, self.num_outputs, bias=b, act=self.activation)
+        else:
+            z = ops.matmul(self.params[0], x, self.num_outputs, bias=b)
+            self.output = ops.activation(self.activation, z)
+            self._z = z if ops.needs_input(self.activation) else None
+        return self.output
+
+    def backward(self, upstream, need_input_grad=True):
+        gup = self._t(upstream)
+        dz = ops.activation_bwd(self.activation, self.output, gup, z=self._z) if not _identity(self.activation) else gup
+        self.grads[0] = ops.matmul_dw(self._x, dz)
+        if self.use_bias:
+            ones = torch.ones((dz.shape[0], 1), device=self.device)
+            self.grads[1] = ops.matmul_dw(ones, dz)               # db[o] = sum over the batch
+        if not need_input_grad:
+            return None
+        return ops.matmul_dx(self.params[0], dz, self.num_inputs)
+
+
 def read_layer(text, device="cuda:0"):
     """layer from its text card (read_kipf_msgpass_layer / read_graph_nop_layer); weights are set as read"""
     from . import io
     name, hp, weights = io.parse_layer_card(text)
     act = io.activation_from_card(hp)
-    if name == "kipf":
+    if name == "full":
+        layer = full_layer_type(num_outputs=int(hp["NUM_OUTPUTS"]), num_inputs=int(hp["NUM_INPUTS"]),
+                                use_bias=hp.get("USE_BIAS", "T").strip().upper().startswith("T"), activation=act,
+                                device=device)
+    elif name == "kipf":
         nvf = [int(v) for v in hp["NUM_VERTEX_FEATURES"].split()]
         T = int(hp.get("NUM_TIME_STEPS", len(nvf) - 1))
         if T != len(nvf) - 1:

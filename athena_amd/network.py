@@ -51,8 +51,11 @@ class network_type:
         return sum(l.get_num_params() for l in self.layers)
 
     # -------------------------------------------------------------------------------------------
-    def forward(self, x):
+    def forward(self, x, edge_features=None):
+        """edge_features: the input graphs' edge features, handed to every layer that takes them (Duvenaud / GNO;
+        the reference forwards input(2,s) alongside the vertex features, athena_msgpass_layer_sub.f90:184-198)"""
         x = self.layers[0]._cat(x)
+        e = self.layers[0]._cat(edge_features) if edge_features is not None else None
         self._out = [x]
         self._widths = []
         for k, layer in enumerate(self.layers, start=1):
@@ -66,7 +69,7 @@ class network_type:
                 for s in srcs[1:]:
                     ops.axpy(1.0, s, inp)
             self._widths.append([s.shape[1] for s in srcs])
-            self._out.append(layer.forward(inp))
+            self._out.append(layer.forward(inp, e) if layer._needs_edges else layer.forward(inp))
         return self._out[-1]
 
     def backward(self, upstream, need_input_grad=False):
@@ -106,19 +109,22 @@ class network_type:
         return grads[0]
 
     # -------------------------------------------------------------------------------------------
-    def capture_step(self, x, target, loss):
+    def capture_step(self, x, target, loss, edge_features=None):
         """Record forward -> loss -> reverse pass of this network once into a HIP graph and return
         (replay, x_buf, target_buf, loss_buf).  Small graphs (the msgpass_euler mesh, molecule mini-batches)
         are launch bound: a step is ~100 short kernels, and replaying the captured graph removes the per-launch
         and per-op host cost.  New samples are fed by copying into x_buf / target_buf; gradients land in the
         layers' `.grads` buffers as usual, so `update()` (whose Adam bias correction changes every step) is
-        called eagerly after replay().  The graph handles must be set before capturing."""
+        called eagerly after replay().  The graph handles must be set before capturing.  With edge_features
+        (Duvenaud / GNO networks) the captured edge buffer is `self.captured_edge_buf`."""
         dev = self.layers[0].device
         x_buf = self.layers[0]._cat(x).clone()
         t_buf = self.layers[0]._t(target).clone()
+        e_buf = self.layers[0]._cat(edge_features).clone() if edge_features is not None else None
+        self.captured_edge_buf = e_buf
 
         def run():
-            out = self.forward(x_buf)
+            out = self.forward(x_buf, e_buf)
             l, d = loss.compute(out, t_buf)
             self.backward(d)
             return l

@@ -146,3 +146,23 @@ def gno_backward(graphs, xs, cs, tapes, params, Fi, Fo, d, H, use_bias, act, ups
         dxs.append(o.matmul_dx(params[1], dz, Fi) + o.gno_aggregate_bwd_x(dz, kap, g.adj_ia, g.adj_ja, Fi))
         dcs.append(o.gno_kernel_bwd_coords(c, params[0], dk, H))
     return dxs, dcs, grads
+
+
+def full_forward(x, W, b, Fo, act):
+    """forward_full, athena_full_layer.f90:835-875: act(matmul(params(1), input) + params(2)); returns (y, z)"""
+    z = o.matmul(W, x, Fo)
+    if b is not None:
+        z = o.add_bias_rows(z, b)
+    return act_fwd(act, z), z
+
+
+def full_backward(x, W, b, y, z, act, up):
+    """the tape walk through activation -> + bias -> matmul; returns (dx, [dW, db])"""
+    dz = act_bwd(act, y, up, z)
+    grads = [o.matmul_dw(dz, x)]
+    if b is not None:
+        db = np.zeros(dz.shape[1], np.float32)
+        for r in range(dz.shape[0]):
+            db = db + dz[r]                       # batch rows in order, fp32
+        grads.append(db)
+    return o.matmul_dx(W, dz, x.shape[1]), grads
