@@ -429,6 +429,8 @@ class graph_nop_layer_type(msgpass_layer_type):
     def update_message(self, x, coords):
         """athena_graph_nop_layer.f90:690-788"""
         g = self.graph.device
+        if not self.params:                 # num_inputs left to the network: taken from the upstream width
+            self.init([int(x.shape[1]), 0])
         Fi, Fo = self.num_vertex_features
         if coords is None:
             raise RuntimeError("graph_nop layer expects vertex and edge feature inputs")   # :725-728

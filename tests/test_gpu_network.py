@@ -306,3 +306,69 @@ def test_msgpass_chemical_network_resident(dev, oracle):
     assert float(lb.item()) == float(l.item())
     for l_, ge in zip(net.layers, eager):
         assert np.array_equal(l_.get_gradients(), ge)
+
+
+def test_gno_regression_network_resident(dev, oracle):
+    """example/gno_regression/src/main.f90: a 20-vertex chain, edge feature = coordinate difference of the pair,
+    two stacked graph_nop layers (1 -> 8 relu -> 2, kernel_hidden 8; the second takes its input width from the
+    first, the edge geometry is forwarded unchanged), mse, plain gradient descent (base_optimiser_type) --
+    three training steps against the oracle composed on the host"""
+    from athena_amd import optim
+    from athena_amd.layers import graph_nop_layer_type
+    from athena_amd.network import network_type
+
+    nv, F_in, F_h, F_out, Hk, d, lr = 20, 1, 8, 2, 8, 1, 0.01
+    pairs = np.array([[i, i + 1] for i in range(1, nv)]).T
+    g = csr_from_index_list(nv, pairs, self_loops=False)
+    coords = (np.arange(nv, dtype=np.float32) / np.float32(nv - 1) * np.float32(2 * np.pi)).astype(np.float32)
+    x = np.ones((nv, F_in), np.float32)
+    tgt = np.stack([np.sin(coords), np.cos(coords)], axis=1).astype(np.float32)
+    ec = (coords[:-1] - coords[1:]).reshape(nv - 1, d).astype(np.float32)
+    net = network_type()
+    net.add(graph_nop_layer_type(num_inputs=F_in, num_outputs=F_h, coord_dim=d, kernel_hidden=Hk, activation="relu", seed=1))
+    net.add(graph_nop_layer_type(num_outputs=F_out, coord_dim=d, kernel_hidden=Hk, seed=2))
+    net.set_graph(g)
+    net.compile(optim.base_optimiser_type(learning_rate=lr))
+    out = net.forward([x], [ec])
+    assert tuple(out.shape) == (nv, F_out)
+    dims = [(F_in, F_h, "relu"), (F_h, F_out, "none")]
+    assert net.get_num_params() == sum(Hk * d + Hk + fo * fi * Hk + fo * fi + fo * fi + fo for fi, fo, _ in dims)
+
+    def split(flat, fi, fo):
+        F = fo * fi
+        sizes = [Hk * d + Hk + F * Hk + F, F, fo]
+        pl, o_ = [], 0
+        for n in sizes:
+            pl.append(flat[o_:o_ + n]); o_ += n
+        return pl
+
+    # non-zero biases so that every gradient path carries signal
+    rng = np.random.default_rng(3)
+    for l in net.layers:
+        l.set_params(l.get_params() + rng.standard_normal(l.get_num_params()).astype(np.float32) * 0.05)
+    params = [l.get_params().copy() for l in net.layers]
+    for it in (1, 2, 3):
+        out = net.forward([x], [ec])
+        cur, keep = x, []
+        for (fi, fo, act), pf in zip(dims, params):
+            pl = split(pf, fi, fo)
+            o_, tp = ol.gno_forward([g], [cur], [ec], pl, fi, fo, d, Hk, True, act)
+            keep.append((pl, cur, tp)); cur = o_[0]
+        assert_close(H(out), cur, 2e-5, f"gno network forward, step {it}")
+        loss, dl = optim.mse_loss_type().compute(out, T(tgt, dev))
+        lo, do = oracle.mse(cur, tgt)
+        assert abs(float(loss.item()) - lo) <= 2e-5 * abs(lo)
+        net.backward(dl)
+        gc = do
+        grads = [None, None]
+        for k in (1, 0):
+            fi, fo, act = dims[k]
+            pl, xin, tp = keep[k]
+            dxs, _, gk = ol.gno_backward([g], [xin], [ec], tp, pl, fi, fo, d, Hk, True, act, [gc])
+            grads[k] = np.concatenate(gk); gc = dxs[0]
+        for k, l in enumerate(net.layers):
+            assert_close(l.get_gradients(), grads[k], 1e-4, f"gradients of layer {k + 1}, step {it}")
+        net.update()
+        for k in range(2):
+            params[k] = (params[k] - np.float32(lr) * grads[k]).astype(np.float32)      # minimise_base :396-418
+            assert_close(net.layers[k].get_params(), params[k], 1e-5, f"parameters of layer {k + 1} after step {it}")
