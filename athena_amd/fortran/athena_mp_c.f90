@@ -25,6 +25,12 @@ module athena_mp_c
   public :: athena_mp_swish_fwd, athena_mp_swish_bwd, athena_mp_softmax_fwd, athena_mp_softmax_bwd
   public :: athena_mp_concat_fwd, athena_mp_concat_bwd
   public :: athena_mp_activation_param_fwd, athena_mp_activation_param_bwd
+  public :: athena_mp_memset_zero, athena_mp_activation_fwd, athena_mp_axpy, athena_mp_kipf_propagate_bwd_dual
+  public :: athena_mp_duvenaud_propagate_fwd, athena_mp_duvenaud_propagate_bwd_x, athena_mp_duvenaud_propagate_bwd_e
+  public :: athena_mp_duvenaud_update_bwd_a, athena_mp_duvenaud_update_bwd_w
+  public :: athena_mp_segment_sum, athena_mp_segment_sum_bwd
+  public :: athena_mp_gno_aggregate_fwd, athena_mp_gno_aggregate_bwd_x, athena_mp_gno_aggregate_bwd_theta
+  public :: athena_mp_gno_aggregate_bwd_coords
   public :: athena_mp_duvenaud_readout_fwd, athena_mp_duvenaud_readout_bwd, athena_mp_duvenaud_update_act_fwd
   public :: athena_mp_kipf_layer_fwd, athena_mp_kipf_layer_bwd_x, athena_mp_activation_bwd
   public :: athena_mp_csr_from_edges, athena_mp_graph_export
@@ -128,14 +134,14 @@ module athena_mp_c
        type(c_ptr), value :: dev_ptr
      end function
      integer(c_int) function athena_mp_memcpy_h2d(dst, src, bytes) bind(C, name="athena_mp_memcpy_h2d")
-       import :: c_int, c_ptr, c_int64_t, c_float
+       import :: c_int, c_ptr, c_int64_t
        type(c_ptr), value :: dst
-       real(c_float), intent(in) :: src(*)
+       type(*), dimension(*), intent(in) :: src        ! any host array (real32 tensors, int32 index arrays)
        integer(c_int64_t), value :: bytes
      end function
      integer(c_int) function athena_mp_memcpy_d2h(dst, src, bytes) bind(C, name="athena_mp_memcpy_d2h")
-       import :: c_int, c_ptr, c_int64_t, c_float
-       real(c_float), intent(inout) :: dst(*)
+       import :: c_int, c_ptr, c_int64_t
+       type(*), dimension(*), intent(inout) :: dst
        type(c_ptr), value :: src
        integer(c_int64_t), value :: bytes
      end function
@@ -332,6 +338,99 @@ module athena_mp_c
        integer(c_int64_t), value :: N
        integer(c_int32_t), value :: Fv, O, S, act, accumulate
        type(c_ptr), value :: seg_dev, z_dev, R_dev, p_dev, gout_dev, dz_next_dev, dc_dev, dR_dev
+     end function
+
+     !! ---- the remaining device-pointer entry points the layer types of athena_mp_layers use ----
+     integer(c_int) function athena_mp_memset_zero(dev_ptr, bytes) bind(C, name="athena_mp_memset_zero")
+       import :: c_int, c_ptr, c_int64_t
+       type(c_ptr), value :: dev_ptr
+       integer(c_int64_t), value :: bytes
+     end function
+     integer(c_int) function athena_mp_activation_fwd(act, n, z_dev, y_dev) bind(C, name="athena_mp_activation_fwd")
+       import :: c_int, c_int32_t, c_int64_t, c_ptr
+       integer(c_int32_t), value :: act
+       integer(c_int64_t), value :: n
+       type(c_ptr), value :: z_dev, y_dev
+     end function
+     integer(c_int) function athena_mp_axpy(n, alpha, x_dev, y_dev) bind(C, name="athena_mp_axpy")
+       import :: c_int, c_int64_t, c_float, c_ptr
+       integer(c_int64_t), value :: n
+       real(c_float), value :: alpha
+       type(c_ptr), value :: x_dev, y_dev
+     end function
+     integer(c_int) function athena_mp_kipf_propagate_bwd_dual(graph, F, g_dev, dx_plain_dev, dx_coef_dev) &
+          bind(C, name="athena_mp_kipf_propagate_bwd_dual")
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: graph, g_dev, dx_plain_dev, dx_coef_dev
+       integer(c_int32_t), value :: F
+     end function
+     integer(c_int) function athena_mp_duvenaud_propagate_fwd(graph, Fv, Fe, x_dev, e_dev, c_dev) &
+          bind(C, name="athena_mp_duvenaud_propagate_fwd")
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: graph, x_dev, e_dev, c_dev
+       integer(c_int32_t), value :: Fv, Fe
+     end function
+     integer(c_int) function athena_mp_duvenaud_propagate_bwd_x(graph, Fv, Fe, grad_dev, dx_dev) &
+          bind(C, name="athena_mp_duvenaud_propagate_bwd_x")
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: graph, grad_dev, dx_dev
+       integer(c_int32_t), value :: Fv, Fe
+     end function
+     integer(c_int) function athena_mp_duvenaud_propagate_bwd_e(graph, Fv, Fe, grad_dev, de_dev) &
+          bind(C, name="athena_mp_duvenaud_propagate_bwd_e")
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: graph, grad_dev, de_dev
+       integer(c_int32_t), value :: Fv, Fe
+     end function
+     integer(c_int) function athena_mp_duvenaud_update_bwd_a(graph, Fi, Fo, min_deg, max_deg, grad_dev, &
+          weight_dev, da_dev) bind(C, name="athena_mp_duvenaud_update_bwd_a")
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: graph, grad_dev, weight_dev, da_dev
+       integer(c_int32_t), value :: Fi, Fo, min_deg, max_deg
+     end function
+     integer(c_int) function athena_mp_duvenaud_update_bwd_w(graph, Fi, Fo, min_deg, max_deg, grad_dev, &
+          a_dev, dweight_dev) bind(C, name="athena_mp_duvenaud_update_bwd_w")
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: graph, grad_dev, a_dev, dweight_dev
+       integer(c_int32_t), value :: Fi, Fo, min_deg, max_deg
+     end function
+     integer(c_int) function athena_mp_segment_sum(O, N, S, seg_dev, p_dev, out_dev, accumulate) &
+          bind(C, name="athena_mp_segment_sum")
+       import :: c_int, c_int32_t, c_int64_t, c_ptr
+       integer(c_int32_t), value :: O, S, accumulate
+       integer(c_int64_t), value :: N
+       type(c_ptr), value :: seg_dev, p_dev, out_dev
+     end function
+     integer(c_int) function athena_mp_segment_sum_bwd(O, N, S, seg_dev, gout_dev, dp_dev) &
+          bind(C, name="athena_mp_segment_sum_bwd")
+       import :: c_int, c_int32_t, c_int64_t, c_ptr
+       integer(c_int32_t), value :: O, S
+       integer(c_int64_t), value :: N
+       type(c_ptr), value :: seg_dev, gout_dev, dp_dev
+     end function
+     integer(c_int) function athena_mp_gno_aggregate_fwd(graph, d, H, Fi, Fo, theta_dev, coords_dev, x_dev, m_dev) &
+          bind(C, name="athena_mp_gno_aggregate_fwd")
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: graph, theta_dev, coords_dev, x_dev, m_dev
+       integer(c_int32_t), value :: d, H, Fi, Fo
+     end function
+     integer(c_int) function athena_mp_gno_aggregate_bwd_x(graph, d, H, Fi, Fo, theta_dev, coords_dev, grad_dev, &
+          dx_dev) bind(C, name="athena_mp_gno_aggregate_bwd_x")
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: graph, theta_dev, coords_dev, grad_dev, dx_dev
+       integer(c_int32_t), value :: d, H, Fi, Fo
+     end function
+     integer(c_int) function athena_mp_gno_aggregate_bwd_theta(graph, d, H, Fi, Fo, theta_dev, coords_dev, x_dev, &
+          grad_dev, dtheta_dev) bind(C, name="athena_mp_gno_aggregate_bwd_theta")
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: graph, theta_dev, coords_dev, x_dev, grad_dev, dtheta_dev
+       integer(c_int32_t), value :: d, H, Fi, Fo
+     end function
+     integer(c_int) function athena_mp_gno_aggregate_bwd_coords(graph, d, H, Fi, Fo, theta_dev, coords_dev, x_dev, &
+          grad_dev, dcoords_dev) bind(C, name="athena_mp_gno_aggregate_bwd_coords")
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: graph, theta_dev, coords_dev, x_dev, grad_dev, dcoords_dev
+       integer(c_int32_t), value :: d, H, Fi, Fo
      end function
   end interface
 

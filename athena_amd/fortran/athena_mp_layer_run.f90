@@ -1,0 +1,180 @@
+!! Runs one layer of athena_mp_layers on a case file and writes what it computed -- the bridge the
+!! parity tests use to hold the FORTRAN host side against the oracle (tests/test_gpu_fortran_layers.py
+!! writes the case, runs this program on the GPU box and compares).
+!!
+!!   athena_mp_layer_run <case.bin> <result.bin>
+!!
+!! Both files are unformatted streams of int32 / real32 in the order read below.
+program athena_mp_layer_run
+  use, intrinsic :: iso_c_binding
+  use athena_mp_c
+  use athena_mp_layers
+  implicit none
+  character(1024) :: fin, fout
+  integer :: uin, uout, kind, batch, s, nv, ne, nnz, nparams, exact_flag
+  type(mp_graph_type), allocatable :: graphs(:)
+  real(real32), allocatable :: params(:), x(:,:), e(:,:), up(:,:), out(:,:), dx(:,:), de(:,:)
+  integer :: dims(2)
+
+  if(command_argument_count() .ne. 2)then
+     write(0,*) "usage: athena_mp_layer_run <case.bin> <result.bin>"
+     stop 2
+  end if
+  call get_command_argument(1, fin)
+  call get_command_argument(2, fout)
+  open(newunit=uin, file=trim(fin), access="stream", form="unformatted", status="old", action="read")
+  open(newunit=uout, file=trim(fout), access="stream", form="unformatted", status="replace", action="write")
+  if(athena_mp_init(0_c_int) .ne. 0) stop 3
+
+  read(uin) kind, batch
+  allocate(graphs(batch))
+  do s = 1, batch
+     read(uin) nv, ne, nnz
+     graphs(s)%num_vertices = nv
+     graphs(s)%num_edges = ne
+     allocate(graphs(s)%adj_ia(nv + 1), graphs(s)%adj_ja(2, nnz))
+     read(uin) graphs(s)%adj_ia
+     if(nnz .gt. 0) read(uin) graphs(s)%adj_ja
+  end do
+
+  select case(kind)
+  case(1)
+     call run_kipf()
+  case(2)
+     call run_duvenaud()
+  case(3)
+     call run_gno()
+  case default
+     write(0,*) "unknown layer kind", kind
+     stop 4
+  end select
+  close(uin)
+  close(uout)
+  if(athena_mp_finalize() .ne. 0) stop 5
+
+contains
+
+  function read_actv() result(a)
+    type(mp_actv_type) :: a
+    character(16) :: name
+    real(real32) :: v(3)
+    read(uin) name
+    read(uin) v
+    a = mp_actv_type(trim(name))          ! validates the name, sets the reference's defaults
+    a%scale = v(1)
+    a%p0 = v(2)
+    a%p1 = v(3)
+  end function read_actv
+
+  subroutine read_matrix(a)
+    real(real32), allocatable, intent(out) :: a(:,:)
+    read(uin) dims
+    allocate(a(dims(1), dims(2)))
+    if(size(a) .gt. 0) read(uin) a
+  end subroutine read_matrix
+
+  subroutine write_matrix(a)
+    real(real32), intent(in) :: a(:,:)
+    write(uout) int(shape(a), c_int32_t)
+    if(size(a) .gt. 0) write(uout) a
+  end subroutine write_matrix
+
+  subroutine write_vector(a)
+    real(real32), intent(in) :: a(:)
+    write(uout) int(size(a), c_int32_t)
+    if(size(a) .gt. 0) write(uout) a
+  end subroutine write_vector
+
+  subroutine run_kipf()
+    type(kipf_mp_layer_type) :: layer
+    type(mp_actv_type) :: act
+    integer :: t, nf, order_code, need_dx
+    integer, allocatable :: nvf(:)
+    character(16) :: order
+
+    read(uin) t, nf
+    allocate(nvf(nf))
+    read(uin) nvf
+    act = read_actv()
+    read(uin) order_code, exact_flag, need_dx
+    order = "auto"
+    if(order_code .eq. 1) order = "aggregate_first"
+    if(order_code .eq. 2) order = "transform_first"
+    layer = kipf_mp_layer_type(num_vertex_features=nvf, num_time_steps=t, activation=act, order=order)
+    read(uin) nparams
+    allocate(params(nparams))
+    read(uin) params
+    if(layer%get_num_params() .ne. nparams) stop 6
+    call layer%set_params(params)
+    call layer%set_graph(graphs)
+    call read_matrix(x)
+    call read_matrix(up)
+    call write_vector(layer%get_gradients())                 ! zeros before any reverse pass
+    out = layer%forward(x)
+    call write_matrix(out)
+    dx = layer%backward(up, exact=exact_flag .eq. 1, need_input_grad=need_dx .eq. 1)
+    call write_matrix(dx)
+    call write_vector(layer%get_gradients())
+    call write_vector(layer%get_params())
+    out = layer%forward(x)                                   ! a second pass reproduces the first bit for bit
+    call write_matrix(out)
+    call layer%destroy()
+  end subroutine run_kipf
+
+  subroutine run_duvenaud()
+    type(duvenaud_mp_layer_type) :: layer
+    type(mp_actv_type) :: act, act_r
+    integer :: t, fv, fe, mn, mx, nout
+
+    read(uin) t, fv, fe, mn, mx, nout
+    act = read_actv()
+    act_r = read_actv()
+    layer = duvenaud_mp_layer_type(num_vertex_features=[fv], num_edge_features=[fe], num_time_steps=t, &
+         max_vertex_degree=mx, num_outputs=nout, min_vertex_degree=mn, message_activation=act, &
+         readout_activation=act_r)
+    read(uin) nparams
+    allocate(params(nparams))
+    read(uin) params
+    if(layer%get_num_params() .ne. nparams) stop 6
+    call layer%set_params(params)
+    call layer%set_graph(graphs)
+    call read_matrix(x)
+    call read_matrix(e)
+    call read_matrix(up)
+    out = layer%forward(x, e)
+    call write_matrix(out)
+    call layer%backward(up, dx=dx, de=de)
+    call write_matrix(dx)
+    call write_matrix(de)
+    call write_vector(layer%get_gradients())
+    call layer%destroy()
+  end subroutine run_duvenaud
+
+  subroutine run_gno()
+    type(graph_nop_mp_layer_type) :: layer
+    type(mp_actv_type) :: act
+    integer :: fi, fo, d, h, bias
+
+    read(uin) fi, fo, d, h, bias
+    act = read_actv()
+    layer = graph_nop_mp_layer_type(num_outputs=fo, coord_dim=d, num_inputs=fi, kernel_hidden=h, &
+         use_bias=bias .eq. 1, activation=act)
+    read(uin) nparams
+    allocate(params(nparams))
+    read(uin) params
+    if(layer%get_num_params() .ne. nparams) stop 6
+    call layer%set_params(params)
+    call layer%set_graph(graphs)
+    call read_matrix(x)
+    call read_matrix(e)
+    call read_matrix(up)
+    out = layer%forward(x, e)
+    call write_matrix(out)
+    call layer%backward(up, dx=dx, dcoords=de)
+    call write_matrix(dx)
+    call write_matrix(de)
+    call write_vector(layer%get_gradients())
+    call layer%destroy()
+  end subroutine run_gno
+
+end program athena_mp_layer_run

@@ -1,0 +1,188 @@
+"""GPU: the FORTRAN host side (athena_amd/fortran/athena_mp_layers.f90 -- kipf / duvenaud / graph_nop layer types
+with the reference's layer API over the C ABI) against the oracle.  Each test writes a case file, runs
+athena_mp_layer_run (built by __graft_entry__.build(), travels with the snapshot) and compares what the Fortran
+layer computed -- forward, input / edge gradients, parameter gradients, accessors -- with the per-sample oracle
+restatement of the layer (tests/oracle_layers.py).  Tolerance: the north star's 1e-5 relative (2e-5 on gradients
+that chain several GEMMs)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_layers as ol
+from helpers import assert_close, csr_from_index_list
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RUNNER = os.path.join(ROOT, "athena_amd", "fortran", "athena_mp_layer_run")
+
+
+class _actv:
+    """what oracle_layers' activation helpers read (name, scale, apply_scaling, p, beta)"""
+
+    def __init__(self, name, scale=1.0, p0=0.0, p1=0.0):
+        self.name, self.scale, self.p = name, float(scale), [float(p0), float(p1)]
+        self.apply_scaling = abs(np.float32(scale) - np.float32(1)) > np.float32(1e-6)
+        self.beta = float(p0) if name == "swish" else 1.0
+
+
+def _oracle_act(a):
+    plain = not a.apply_scaling and a.p == [0.0, 0.0]
+    if a.name in ("none", "relu", "sigmoid", "tanh", "softmax") and plain:
+        return a.name
+    if a.name == "swish" and not a.apply_scaling and a.p[0] == 1.0:
+        return "swish"
+    return a
+
+
+def _graphs(rng, sizes, self_loops):
+    gs = []
+    for n in sizes:
+        pairs = [[i, i + 1] for i in range(1, n)]
+        for _ in range(n // 2):
+            a, b = rng.integers(1, n + 1, 2)
+            if a != b:
+                pairs.append([int(a), int(b)])
+        gs.append(csr_from_index_list(n, np.array(pairs).T, self_loops=self_loops))
+    return gs
+
+
+def _i(*v):
+    return np.asarray(v, np.int32).tobytes()
+
+
+def _mat(a):
+    """a is [elements, features] row-major == Fortran (features, elements)"""
+    a = np.ascontiguousarray(a, np.float32)
+    return _i(a.shape[1], a.shape[0]) + a.tobytes()
+
+
+def _act_bytes(a):
+    return a.name.ljust(16).encode() + np.asarray([a.scale, a.p[0], a.p[1]], np.float32).tobytes()
+
+
+def _case_header(kind, gs):
+    out = _i(kind, len(gs))
+    for g in gs:
+        out += _i(g.num_vertices, g.num_edges, g.nnz) + np.asarray(g.adj_ia, np.int32).tobytes()
+        out += np.asfortranarray(g.adj_ja, dtype=np.int32).tobytes(order="F")
+    return out
+
+
+class _reader:
+    def __init__(self, path):
+        self.b = open(path, "rb").read()
+        self.o = 0
+
+    def ints(self, n):
+        v = np.frombuffer(self.b, np.int32, n, self.o); self.o += 4 * n
+        return v
+
+    def matrix(self):
+        f, n = self.ints(2)
+        v = np.frombuffer(self.b, np.float32, int(f) * int(n), self.o).reshape(int(n), int(f)); self.o += 4 * int(f) * int(n)
+        return v
+
+    def vector(self):
+        n = int(self.ints(1)[0])
+        v = np.frombuffer(self.b, np.float32, n, self.o); self.o += 4 * n
+        return v
+
+
+def _run(tmp_path, blob):
+    if not os.path.exists(RUNNER):
+        pytest.fail("athena_mp_layer_run is not built: __graft_entry__.build() compiles the Fortran host side")
+    case, res = str(tmp_path / "case.bin"), str(tmp_path / "result.bin")
+    with open(case, "wb") as f:
+        f.write(blob)
+    r = subprocess.run([RUNNER, case, res], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, f"athena_mp_layer_run failed ({r.returncode}): {r.stderr[-2000:]}"
+    return _reader(res)
+
+
+KIPF_CASES = [
+    ([5], 1, _actv("none"), 0, 0),
+    ([8, 16, 4], 2, _actv("relu"), 0, 0),
+    ([64, 128, 64], 2, _actv("tanh"), 1, 0),
+    ([48, 12, 20, 5], 3, _actv("swish", p0=1.0), 0, 0),           # auto: steps 1 and 3 run transform-first
+    ([48, 12, 20, 5], 3, _actv("sigmoid"), 2, 1),                  # transform-first everywhere, exact reverse
+    ([6, 9], 1, _actv("leaky_relu", p0=0.1, scale=1.5), 0, 0),
+    ([7, 7, 7], 2, _actv("softmax"), 1, 0),
+]
+
+
+@pytest.mark.parametrize("nvf,T,act,order,exact", KIPF_CASES)
+def test_fortran_kipf_layer(dev, tmp_path, nvf, T, act, order, exact):
+    rng = np.random.default_rng(len(nvf) * 7 + T + order)
+    gs = _graphs(rng, [6, 17, 40, 9], self_loops=True)
+    full = nvf * (T + 1) if len(nvf) == 1 else nvf
+    plist = [(rng.standard_normal(full[t] * full[t - 1]) * np.sqrt(2.0 / full[t - 1])).astype(np.float32) for t in range(1, T + 1)]
+    xs = [rng.uniform(-1, 1, (g.num_vertices, full[0])).astype(np.float32) for g in gs]
+    oa = _oracle_act(act)
+    outs, tapes = ol.kipf_forward(gs, xs, plist, full, oa)
+    ups = [rng.uniform(-1, 1, o.shape).astype(np.float32) for o in outs]
+    blob = _case_header(1, gs) + _i(T, len(nvf)) + _i(*nvf) + _act_bytes(act) + _i(order, exact, 1)
+    blob += _i(sum(p.size for p in plist)) + np.concatenate(plist).tobytes()
+    blob += _mat(np.concatenate(xs)) + _mat(np.concatenate(ups))
+    r = _run(tmp_path, blob)
+    assert np.all(r.vector() == 0)                                   # get_gradients before a reverse pass: zeros
+    out = r.matrix()
+    assert_close(out, np.concatenate(outs), 1e-5, "fortran kipf forward")
+    dx = r.matrix()
+    dxs, grads = ol.kipf_backward(gs, tapes, plist, full, oa, ups, exact=bool(exact))
+    assert_close(dx, np.concatenate(dxs), 2e-5, "fortran kipf dx")
+    assert_close(r.vector(), np.concatenate(grads), 2e-5, "fortran kipf dW")
+    assert np.array_equal(r.vector(), np.concatenate(plist))         # get_params returns what set_params stored
+    assert np.array_equal(r.matrix(), out)                           # deterministic forward
+
+
+@pytest.mark.parametrize("act,act_r", [(_actv("sigmoid"), _actv("softmax")), (_actv("tanh"), _actv("sigmoid")),
+                                       (_actv("selu", p0=1.67326, p1=1.0507), _actv("softmax")),
+                                       (_actv("relu"), _actv("none")), (_actv("gaussian", p0=1.0), _actv("swish", p0=1.0))])
+def test_fortran_duvenaud_layer(dev, tmp_path, act, act_r):
+    rng = np.random.default_rng(33)
+    gs = _graphs(rng, [9, 14, 5, 20, 11], self_loops=False)
+    Fv, Fe, T, D, nout = 8, 2, 3, 6, 4
+    nvf = [Fv] * (T + 1)
+    plist = [(rng.standard_normal(nvf[t] * (nvf[t - 1] + Fe) * D) * 0.3).astype(np.float32) for t in range(1, T + 1)]
+    plist += [(rng.standard_normal(nout * nvf[t]) * 0.3).astype(np.float32) for t in range(1, T + 1)]
+    xs = [rng.uniform(0, 1, (g.num_vertices, Fv)).astype(np.float32) for g in gs]
+    es = [rng.uniform(0, 1, (g.num_edges, Fe)).astype(np.float32) for g in gs]
+    oa, oar = _oracle_act(act), _oracle_act(act_r)
+    outs, tapes = ol.duvenaud_forward(gs, xs, es, plist, nvf, Fe, 1, D, nout, oa, act_readout=oar)
+    up = rng.uniform(-1, 1, outs.shape).astype(np.float32)
+    blob = _case_header(2, gs) + _i(T, Fv, Fe, 1, D, nout) + _act_bytes(act) + _act_bytes(act_r)
+    blob += _i(sum(p.size for p in plist)) + np.concatenate(plist).tobytes()
+    blob += _mat(np.concatenate(xs)) + _mat(np.concatenate(es)) + _mat(up)
+    r = _run(tmp_path, blob)
+    assert_close(r.matrix(), outs, 1e-5, "fortran duvenaud forward")
+    dxs, des, grads = ol.duvenaud_backward(gs, es, tapes, plist, nvf, Fe, 1, D, nout, oa, up, act_readout=oar)
+    assert_close(r.matrix(), np.concatenate(dxs), 2e-5, "fortran duvenaud dx")
+    assert_close(r.matrix(), np.concatenate(des), 2e-5, "fortran duvenaud de")
+    assert_close(r.vector(), np.concatenate(grads), 2e-5, "fortran duvenaud gradients")
+
+
+@pytest.mark.parametrize("Fi,Fo,d,H,bias,act", [(3, 5, 1, 8, 1, _actv("none")), (8, 8, 3, 16, 0, _actv("relu")),
+                                               (32, 32, 3, 32, 1, _actv("tanh")), (4, 6, 2, 8, 1, _actv("piecewise", p0=0.3, p1=0.4))])
+def test_fortran_graph_nop_layer(dev, tmp_path, Fi, Fo, d, H, bias, act):
+    rng = np.random.default_rng(Fi + H)
+    gs = _graphs(rng, [20, 11, 33], self_loops=False)
+    F = Fo * Fi
+    sizes = [H * d + H + F * H + F, F] + ([Fo] if bias else [])
+    plist = [(rng.standard_normal(n) * 0.2).astype(np.float32) for n in sizes]
+    xs = [rng.uniform(-1, 1, (g.num_vertices, Fi)).astype(np.float32) for g in gs]
+    cs = [rng.standard_normal((g.num_edges, d)).astype(np.float32) for g in gs]
+    oa = _oracle_act(act)
+    outs, tapes = ol.gno_forward(gs, xs, cs, plist, Fi, Fo, d, H, bool(bias), oa)
+    ups = [rng.uniform(-1, 1, o.shape).astype(np.float32) for o in outs]
+    blob = _case_header(3, gs) + _i(Fi, Fo, d, H, bias) + _act_bytes(act)
+    blob += _i(sum(sizes)) + np.concatenate(plist).tobytes()
+    blob += _mat(np.concatenate(xs)) + _mat(np.concatenate(cs)) + _mat(np.concatenate(ups))
+    r = _run(tmp_path, blob)
+    assert_close(r.matrix(), np.concatenate(outs), 1e-5, "fortran graph_nop forward")
+    dxs, dcs, grads = ol.gno_backward(gs, xs, cs, tapes, plist, Fi, Fo, d, H, bool(bias), oa, ups)
+    assert_close(r.matrix(), np.concatenate(dxs), 2e-5, "fortran graph_nop dx")
+    assert_close(r.matrix(), np.concatenate(dcs), 2e-5, "fortran graph_nop dcoords")
+    assert_close(r.vector(), np.concatenate(grads), 2e-5, "fortran graph_nop gradients")

@@ -169,3 +169,16 @@ def test_activation_objects_and_their_card_blocks():
             hp["activation_" + k] = v
         b = activation_from_card(hp)
         assert (b.name, b.scale, b.p, b.beta) == (a.name, a.scale, a.p, a.beta)
+
+
+def test_fortran_host_side_is_built():
+    """__graft_entry__.build() compiles the Fortran host side (interface module, layer types, the boundary test and
+    the case runner); the runner's usage path exits 2 without touching a GPU"""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    runner = os.path.join(root, "athena_amd", "fortran", "athena_mp_layer_run")
+    if not os.path.exists(runner):
+        pytest.skip("Fortran host side not built here (run __graft_entry__.build())")
+    r = subprocess.run([runner], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "usage" in r.stderr
