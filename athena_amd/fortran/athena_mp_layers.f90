@@ -81,10 +81,12 @@ module athena_mp_layers
      type(mp_actv_type) :: activation
      character(16) :: order = "auto"                   ! auto | aggregate_first | transform_first
      type(dbuf), allocatable :: tape_p(:), tape_y(:), tape_z(:)
-     type(dbuf) :: x_in, scratch(3)
+     type(dbuf) :: x_in, up_in, dual, scratch(3)
    contains
      procedure, pass(this) :: forward => kipf_forward
      procedure, pass(this) :: backward => kipf_backward
+     procedure, pass(this) :: forward_dev => kipf_forward_dev
+     procedure, pass(this) :: backward_dev => kipf_backward_dev
      procedure, pass(this) :: destroy => kipf_destroy
      procedure, pass(this), private :: transform_first => kipf_transform_first
   end type kipf_mp_layer_type
@@ -543,29 +545,45 @@ contains
   end function kipf_transform_first
 
   function kipf_forward(this, vertex_features) result(output)
-    !! update_message_kipf :915-959: X_t = act( W_t . kipf_propagate(X_{t-1}) ), all samples of the batch at once
+    !! update_message_kipf :915-959 on host arrays: upload, forward_dev, download
     class(kipf_mp_layer_type), intent(inout) :: this
     real(real32), intent(in) :: vertex_features(:,:)                     ! (F_0, num_vertices of the batch)
     real(real32), allocatable :: output(:,:)
+    type(c_ptr) :: y
+    integer :: n
+
+    n = this%nv
+    if(size(vertex_features, 1) .ne. this%num_vertex_features(0) .or. size(vertex_features, 2) .ne. n) &
+         call stop_program("kipf forward: vertex feature shape mismatch")
+    call need(this%x_in, i8(n) * i8(this%num_vertex_features(0)))
+    call chk(athena_mp_memcpy_h2d(this%x_in%p, vertex_features, 4_c_int64_t * i8(n) * i8(this%num_vertex_features(0))), "h2d")
+    y = this%forward_dev(this%x_in%p)
+    allocate(output(this%num_vertex_features(this%num_time_steps), n))
+    call chk(athena_mp_memcpy_d2h(output, y, 4_c_int64_t * i8(n) * i8(this%num_vertex_features(this%num_time_steps))), "d2h")
+  end function kipf_forward
+
+  function kipf_forward_dev(this, x_dev) result(y_dev)
+    !! X_t = act( W_t . kipf_propagate(X_{t-1}) ) for all samples of the batch at once, on tensors that stay in HBM:
+    !! x_dev = (F_0, vertices) on the device, the result points into the layer's tape (valid until the next forward).
+    !! This is how consecutive HIP layers are chained from Fortran without a host round trip.
+    class(kipf_mp_layer_type), intent(inout) :: this
+    type(c_ptr), intent(in) :: x_dev
+    type(c_ptr) :: y_dev
     type(c_ptr) :: cur
     integer :: t, fi, fo, n
     integer(c_int32_t) :: code
 
     if(.not. c_associated(this%graph)) call stop_program("set_graph must be called before forward")
     n = this%nv
-    if(size(vertex_features, 1) .ne. this%num_vertex_features(0) .or. size(vertex_features, 2) .ne. n) &
-         call stop_program("kipf forward: vertex feature shape mismatch")
-    call need(this%x_in, i8(n) * i8(this%num_vertex_features(0)))
-    call chk(athena_mp_memcpy_h2d(this%x_in%p, vertex_features, 4_c_int64_t * i8(n) * i8(this%num_vertex_features(0))), "h2d")
-    cur = this%x_in%p
+    cur = x_dev
     code = fused_code(this%activation)
     do t = 1, this%num_time_steps
        fi = this%num_vertex_features(t - 1)
        fo = this%num_vertex_features(t)
        call need(this%tape_y(t), i8(n) * i8(fo))
+       call need(this%tape_p(t), i8(n) * i8(fi))
        if(this%transform_first(t))then
           ! Y = X W^T, then the aggregation on F_t-wide rows; the tape keeps the step's input in tape_p
-          call need(this%tape_p(t), i8(n) * i8(fi))
           call need(this%tape_z(t), i8(n) * i8(fo))
           call need(this%scratch(1), i8(n) * i8(fo))
           call copy_dev(this%tape_p(t)%p, cur, i8(n) * i8(fi))
@@ -577,24 +595,20 @@ contains
              call chk(athena_mp_kipf_propagate_fwd(this%graph, int(fo, c_int32_t), this%scratch(1)%p, this%tape_z(t)%p), "propagate")
              call act_apply(this%activation, n, fo, this%tape_z(t)%p, this%tape_y(t)%p)
           end if
+       else if(code .ge. 0)then
+          ! aggregation + dense step + activation in one launch where the fused kernel exists
+          call chk(athena_mp_kipf_layer_fwd(this%graph, int(fi, c_int32_t), int(fo, c_int32_t), cur, this%params(t)%p, &
+               c_null_ptr, code, this%tape_p(t)%p, this%tape_y(t)%p), "kipf_layer_fwd")
        else
-          call need(this%tape_p(t), i8(n) * i8(fi))
-          if(code .ge. 0)then
-             ! aggregation + dense step + activation in one launch where the fused kernel exists
-             call chk(athena_mp_kipf_layer_fwd(this%graph, int(fi, c_int32_t), int(fo, c_int32_t), cur, this%params(t)%p, &
-                  c_null_ptr, code, this%tape_p(t)%p, this%tape_y(t)%p), "kipf_layer_fwd")
-          else
-             call need(this%tape_z(t), i8(n) * i8(fo))
-             call chk(athena_mp_kipf_layer_fwd(this%graph, int(fi, c_int32_t), int(fo, c_int32_t), cur, this%params(t)%p, &
-                  c_null_ptr, ATHENA_MP_ACT_NONE, this%tape_p(t)%p, this%tape_z(t)%p), "kipf_layer_fwd")
-             call act_apply(this%activation, n, fo, this%tape_z(t)%p, this%tape_y(t)%p)
-          end if
+          call need(this%tape_z(t), i8(n) * i8(fo))
+          call chk(athena_mp_kipf_layer_fwd(this%graph, int(fi, c_int32_t), int(fo, c_int32_t), cur, this%params(t)%p, &
+               c_null_ptr, ATHENA_MP_ACT_NONE, this%tape_p(t)%p, this%tape_z(t)%p), "kipf_layer_fwd")
+          call act_apply(this%activation, n, fo, this%tape_z(t)%p, this%tape_y(t)%p)
        end if
        cur = this%tape_y(t)%p
     end do
-    allocate(output(this%num_vertex_features(this%num_time_steps), n))
-    call chk(athena_mp_memcpy_d2h(output, cur, 4_c_int64_t * i8(n) * i8(this%num_vertex_features(this%num_time_steps))), "d2h")
-  end function kipf_forward
+    y_dev = cur
+  end function kipf_forward_dev
 
   subroutine copy_dev(dst, src, n)
     !! device-to-device copy of n floats: dst = 0; dst += 1 * src
@@ -605,14 +619,43 @@ contains
   end subroutine copy_dev
 
   function kipf_backward(this, upstream, exact, need_input_grad) result(dx)
-    !! the tape walk of grad_reverse: activation -> matmul (dW, dP) -> get_partial_kipf_propagate_left_val.
-    !! exact = .false. (default) reproduces the reference's coefficient-free scatter (:85-111).
+    !! reverse pass on host arrays: upload, backward_dev, download
     class(kipf_mp_layer_type), intent(inout) :: this
     real(real32), intent(in) :: upstream(:,:)                            ! (F_T, num_vertices)
     logical, intent(in), optional :: exact, need_input_grad
     real(real32), allocatable :: dx(:,:)
+    type(c_ptr) :: g
+    integer :: n, fo
+    logical :: want_dx
+
+    n = this%nv
+    fo = this%num_vertex_features(this%num_time_steps)
+    if(size(upstream, 1) .ne. fo .or. size(upstream, 2) .ne. n) call stop_program("kipf backward: upstream shape mismatch")
+    want_dx = .true.
+    if(present(need_input_grad)) want_dx = need_input_grad
+    call need(this%up_in, i8(n) * i8(fo))
+    call chk(athena_mp_memcpy_h2d(this%up_in%p, upstream, 4_c_int64_t * i8(n) * i8(fo)), "h2d")
+    g = this%backward_dev(this%up_in%p, exact, need_input_grad)
+    if(want_dx)then
+       allocate(dx(this%num_vertex_features(0), n))
+       call chk(athena_mp_memcpy_d2h(dx, g, 4_c_int64_t * i8(n) * i8(this%num_vertex_features(0))), "d2h")
+    else
+       allocate(dx(0, 0))
+    end if
+  end function kipf_backward
+
+  function kipf_backward_dev(this, upstream_dev, exact, need_input_grad) result(dx_dev)
+    !! the tape walk of grad_reverse: activation -> matmul (dW, dP) -> get_partial_kipf_propagate_left_val.
+    !! exact = .false. (default) reproduces the reference's coefficient-free scatter (:85-111).  upstream_dev =
+    !! (F_T, vertices) on the device (read only); the result points into the layer's scratch (valid until the next
+    !! backward), c_null_ptr when need_input_grad = .false.  Parameter gradients land in the layer (get_gradients).
+    class(kipf_mp_layer_type), intent(inout) :: this
+    type(c_ptr), intent(in) :: upstream_dev
+    logical, intent(in), optional :: exact, need_input_grad
+    type(c_ptr) :: dx_dev
     type(c_ptr) :: gcur, dz, y_prev
     integer :: t, fi, fo, n, ex
+    integer(c_int64_t) :: widest
     logical :: want_dx
 
     n = this%nv
@@ -620,13 +663,12 @@ contains
     if(present(exact)) ex = merge(1, 0, exact)
     want_dx = .true.
     if(present(need_input_grad)) want_dx = need_input_grad
-    fo = this%num_vertex_features(this%num_time_steps)
-    if(size(upstream, 1) .ne. fo .or. size(upstream, 2) .ne. n) call stop_program("kipf backward: upstream shape mismatch")
-    call need(this%scratch(2), i8(n) * i8(maxval(this%num_vertex_features)))
-    call need(this%scratch(3), i8(n) * i8(maxval(this%num_vertex_features)))
-    call need(this%scratch(1), i8(n) * i8(maxval(this%num_vertex_features)))
-    call chk(athena_mp_memcpy_h2d(this%scratch(2)%p, upstream, 4_c_int64_t * i8(n) * i8(fo)), "h2d")
-    gcur = this%scratch(2)%p
+    widest = i8(n) * i8(maxval(this%num_vertex_features))
+    call need(this%scratch(1), widest)
+    call need(this%scratch(2), widest)
+    call need(this%scratch(3), widest)
+    gcur = upstream_dev
+    dx_dev = c_null_ptr
     do t = this%num_time_steps, 1, -1
        fi = this%num_vertex_features(t - 1)
        fo = this%num_vertex_features(t)
@@ -639,50 +681,42 @@ contains
        if(this%transform_first(t))then
           ! dW = (A^T dZ)^T X with the coefficient, dX = (scatter of dZ) W without it: one gather, two sums
           y_prev = this%tape_p(t)%p
-          call need(this%x_in, i8(n) * i8(max(fo, this%num_vertex_features(0))))
           if(ex .eq. 1 .or. (t .eq. 1 .and. .not. want_dx))then
              call chk(athena_mp_kipf_propagate_bwd(this%graph, int(fo, c_int32_t), dz, this%scratch(1)%p, 1_c_int32_t), "propagate_bwd")
              call chk(athena_mp_gemm_dw(i8(n), int(fi, c_int32_t), int(fo, c_int32_t), y_prev, this%scratch(1)%p, this%grads(t)%p), "gemm_dw")
              this%has_grad(t) = .true.
-             if(t .eq. 1 .and. .not. want_dx) exit
-             call chk(athena_mp_gemm_dx(i8(n), int(fi, c_int32_t), int(fo, c_int32_t), this%scratch(1)%p, this%params(t)%p, &
-                  this%scratch(2)%p), "gemm_dx")
+             if(t .eq. 1 .and. .not. want_dx) return
           else
-             call dual_into(this, fo, dz)
-             call chk(athena_mp_gemm_dw(i8(n), int(fi, c_int32_t), int(fo, c_int32_t), y_prev, this%x_in%p, this%grads(t)%p), "gemm_dw")
+             call need(this%dual, i8(n) * i8(fo))
+             call chk(athena_mp_kipf_propagate_bwd_dual(this%graph, int(fo, c_int32_t), dz, this%scratch(1)%p, this%dual%p), &
+                  "propagate_bwd_dual")
+             call chk(athena_mp_gemm_dw(i8(n), int(fi, c_int32_t), int(fo, c_int32_t), y_prev, this%dual%p, this%grads(t)%p), "gemm_dw")
              this%has_grad(t) = .true.
-             call chk(athena_mp_gemm_dx(i8(n), int(fi, c_int32_t), int(fo, c_int32_t), this%scratch(1)%p, this%params(t)%p, &
-                  this%scratch(2)%p), "gemm_dx")
           end if
+          call chk(athena_mp_gemm_dx(i8(n), int(fi, c_int32_t), int(fo, c_int32_t), this%scratch(1)%p, this%params(t)%p, &
+               this%scratch(2)%p), "gemm_dx")
           gcur = this%scratch(2)%p
           cycle
        end if
        call chk(athena_mp_gemm_dw(i8(n), int(fi, c_int32_t), int(fo, c_int32_t), this%tape_p(t)%p, dz, this%grads(t)%p), "gemm_dw")
        this%has_grad(t) = .true.
-       if(t .eq. 1 .and. .not. want_dx) exit            ! the input layer's output has requires_grad = .false.
+       if(t .eq. 1 .and. .not. want_dx) return            ! the input layer's output has requires_grad = .false.
        call chk(athena_mp_kipf_layer_bwd_x(this%graph, int(fi, c_int32_t), int(fo, c_int32_t), dz, this%params(t)%p, &
             int(ex, c_int32_t), this%scratch(1)%p), "kipf_layer_bwd_x")
-       ! rotate: the result becomes the upstream of step t-1
-       call copy_dev(this%scratch(2)%p, this%scratch(1)%p, i8(n) * i8(fi))
+       ! the result becomes the upstream of step t-1: swap the roles of scratch 1 and 2 instead of copying
+       call swap_buf(this%scratch(1), this%scratch(2))
        gcur = this%scratch(2)%p
     end do
-    if(want_dx)then
-       allocate(dx(this%num_vertex_features(0), n))
-       call chk(athena_mp_memcpy_d2h(dx, gcur, 4_c_int64_t * i8(n) * i8(this%num_vertex_features(0))), "d2h")
-    else
-       allocate(dx(0, 0))
-    end if
-  end function kipf_backward
+    dx_dev = gcur
+  end function kipf_backward_dev
 
-  subroutine dual_into(this, f, dz)
-    !! scratch(1) = coefficient-free scatter of dz, x_in = coefficient-weighted one (the forward input copy in x_in
-    !! is not needed once the reverse pass runs: tape_p holds each step's input)
-    class(kipf_mp_layer_type), intent(inout) :: this
-    integer, intent(in) :: f
-    type(c_ptr), intent(in) :: dz
-    call chk(athena_mp_kipf_propagate_bwd_dual(this%graph, int(f, c_int32_t), dz, this%scratch(1)%p, this%x_in%p), &
-         "propagate_bwd_dual")
-  end subroutine dual_into
+  subroutine swap_buf(a, b)
+    type(dbuf), intent(inout) :: a, b
+    type(dbuf) :: t
+    t = a
+    a = b
+    b = t
+  end subroutine swap_buf
 
   subroutine kipf_destroy(this)
     class(kipf_mp_layer_type), intent(inout) :: this
@@ -690,7 +724,7 @@ contains
     do t = 1, this%num_time_steps
        call release(this%tape_p(t)); call release(this%tape_y(t)); call release(this%tape_z(t))
     end do
-    call release(this%x_in)
+    call release(this%x_in); call release(this%up_in); call release(this%dual)
     do t = 1, 3
        call release(this%scratch(t))
     end do
