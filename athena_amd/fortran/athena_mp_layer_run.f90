@@ -44,6 +44,8 @@ program athena_mp_layer_run
      call run_duvenaud()
   case(3)
      call run_gno()
+  case(4)
+     call run_kipf_chain()
   case default
      write(0,*) "unknown layer kind", kind
      stop 4
@@ -176,5 +178,52 @@ contains
     call write_vector(layer%get_gradients())
     call layer%destroy()
   end subroutine run_gno
+
+  subroutine run_kipf_chain()
+    !! two Kipf layers chained on the device: the first layer's tape feeds the second (forward_dev), the second's
+    !! input gradient feeds the first (backward_dev); only the ends of the chain cross the host boundary
+    type(kipf_mp_layer_type) :: l1, l2
+    type(mp_actv_type) :: a1, a2
+    integer :: f0, f1, f2, n, n1, n2
+    real(real32), allocatable :: p1(:), p2(:)
+    type(c_ptr) :: x_dev, up_dev, y1, y2, g1, g0
+
+    read(uin) f0, f1, f2
+    a1 = read_actv()
+    a2 = read_actv()
+    l1 = kipf_mp_layer_type(num_vertex_features=[f0, f1], num_time_steps=1, activation=a1)
+    l2 = kipf_mp_layer_type(num_vertex_features=[f1, f2], num_time_steps=1, activation=a2)
+    read(uin) n1
+    allocate(p1(n1)); read(uin) p1
+    read(uin) n2
+    allocate(p2(n2)); read(uin) p2
+    call l1%set_params(p1)
+    call l2%set_params(p2)
+    call l1%set_graph(graphs)
+    call l2%set_graph(graphs)
+    call read_matrix(x)
+    call read_matrix(up)
+    n = size(x, 2)
+    if(athena_mp_malloc(x_dev, 4_c_int64_t * size(x, kind=c_int64_t)) .ne. 0) stop 7
+    if(athena_mp_malloc(up_dev, 4_c_int64_t * size(up, kind=c_int64_t)) .ne. 0) stop 7
+    if(athena_mp_memcpy_h2d(x_dev, x, 4_c_int64_t * size(x, kind=c_int64_t)) .ne. 0) stop 7
+    if(athena_mp_memcpy_h2d(up_dev, up, 4_c_int64_t * size(up, kind=c_int64_t)) .ne. 0) stop 7
+    y1 = l1%forward_dev(x_dev)
+    y2 = l2%forward_dev(y1)
+    allocate(out(f2, n))
+    if(athena_mp_memcpy_d2h(out, y2, 4_c_int64_t * size(out, kind=c_int64_t)) .ne. 0) stop 7
+    call write_matrix(out)
+    g1 = l2%backward_dev(up_dev)
+    g0 = l1%backward_dev(g1)
+    allocate(dx(f0, n))
+    if(athena_mp_memcpy_d2h(dx, g0, 4_c_int64_t * size(dx, kind=c_int64_t)) .ne. 0) stop 7
+    call write_matrix(dx)
+    call write_vector(l1%get_gradients())
+    call write_vector(l2%get_gradients())
+    if(athena_mp_free(x_dev) .ne. 0) stop 7
+    if(athena_mp_free(up_dev) .ne. 0) stop 7
+    call l1%destroy()
+    call l2%destroy()
+  end subroutine run_kipf_chain
 
 end program athena_mp_layer_run

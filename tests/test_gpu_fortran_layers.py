@@ -186,3 +186,28 @@ def test_fortran_graph_nop_layer(dev, tmp_path, Fi, Fo, d, H, bias, act):
     assert_close(r.matrix(), np.concatenate(dxs), 2e-5, "fortran graph_nop dx")
     assert_close(r.matrix(), np.concatenate(dcs), 2e-5, "fortran graph_nop dcoords")
     assert_close(r.vector(), np.concatenate(grads), 2e-5, "fortran graph_nop gradients")
+
+
+@pytest.mark.parametrize("a1,a2,dims", [(_actv("relu"), _actv("none"), (16, 64, 64)), (_actv("swish", p0=1.0), _actv("tanh"), (64, 24, 7))])
+def test_fortran_kipf_layers_chained_on_the_device(dev, tmp_path, a1, a2, dims):
+    """forward_dev / backward_dev: two Kipf layers stacked from Fortran with the activations between them kept in
+    HBM (the first layer's tape feeds the second, the second's input gradient feeds the first)"""
+    rng = np.random.default_rng(sum(dims))
+    gs = _graphs(rng, [30, 12, 45], self_loops=True)
+    f0, f1, f2 = dims
+    p1 = (rng.standard_normal(f1 * f0) * np.sqrt(2.0 / f0)).astype(np.float32)
+    p2 = (rng.standard_normal(f2 * f1) * np.sqrt(2.0 / f1)).astype(np.float32)
+    xs = [rng.uniform(-1, 1, (g.num_vertices, f0)).astype(np.float32) for g in gs]
+    o1, t1 = ol.kipf_forward(gs, xs, [p1], [f0, f1], _oracle_act(a1))
+    o2, t2 = ol.kipf_forward(gs, o1, [p2], [f1, f2], _oracle_act(a2))
+    ups = [rng.uniform(-1, 1, o.shape).astype(np.float32) for o in o2]
+    g1, gr2 = ol.kipf_backward(gs, t2, [p2], [f1, f2], _oracle_act(a2), ups)
+    g0, gr1 = ol.kipf_backward(gs, t1, [p1], [f0, f1], _oracle_act(a1), g1)
+    blob = _case_header(4, gs) + _i(f0, f1, f2) + _act_bytes(a1) + _act_bytes(a2)
+    blob += _i(p1.size) + p1.tobytes() + _i(p2.size) + p2.tobytes()
+    blob += _mat(np.concatenate(xs)) + _mat(np.concatenate(ups))
+    r = _run(tmp_path, blob)
+    assert_close(r.matrix(), np.concatenate(o2), 1e-5, "chained forward")
+    assert_close(r.matrix(), np.concatenate(g0), 2e-5, "chained dx")
+    assert_close(r.vector(), gr1[0], 2e-5, "dW of the first layer")
+    assert_close(r.vector(), gr2[0], 2e-5, "dW of the second layer")
