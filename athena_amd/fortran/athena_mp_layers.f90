@@ -105,6 +105,8 @@ module athena_mp_layers
    contains
      procedure, pass(this) :: forward => duvenaud_forward
      procedure, pass(this) :: backward => duvenaud_backward
+     procedure, pass(this) :: forward_dev => duvenaud_forward_dev
+     procedure, pass(this) :: backward_dev => duvenaud_backward_dev
      procedure, pass(this) :: destroy => duvenaud_destroy
   end type duvenaud_mp_layer_type
 
@@ -116,10 +118,13 @@ module athena_mp_layers
      integer :: num_inputs = 0, num_outputs = 0, coord_dim = 0, kernel_hidden = 16
      logical :: use_bias = .true.
      type(mp_actv_type) :: activation
-     type(dbuf) :: x_in, c_in, z_pre, y_out, scratch(3)
+     type(dbuf) :: x_in, c_in, up_in, z_pre, y_out, ones, dc_out, scratch(3)
+     type(c_ptr) :: x_tape = c_null_ptr, c_tape = c_null_ptr     ! the forward inputs (caller-owned in forward_dev)
    contains
      procedure, pass(this) :: forward => gno_forward
      procedure, pass(this) :: backward => gno_backward
+     procedure, pass(this) :: forward_dev => gno_forward_dev
+     procedure, pass(this) :: backward_dev => gno_backward_dev
      procedure, pass(this) :: destroy => gno_destroy
   end type graph_nop_mp_layer_type
 
@@ -787,6 +792,30 @@ contains
     real(real32), intent(in) :: vertex_features(:,:)       ! (F_v, vertices of the batch)
     real(real32), intent(in) :: edge_features(:,:)         ! (F_e, edge columns of the batch)
     real(real32), allocatable :: output(:,:)               ! (num_outputs, batch)
+    type(c_ptr) :: out
+    integer :: n, fe
+
+    n = this%nv
+    fe = this%num_edge_features(0)
+    if(size(vertex_features, 1) .ne. this%num_vertex_features(0) .or. size(vertex_features, 2) .ne. n) &
+         call stop_program("duvenaud forward: vertex feature shape mismatch")
+    if(size(edge_features, 1) .ne. fe .or. size(edge_features, 2) .ne. this%ne) &
+         call stop_program("duvenaud forward: edge feature shape mismatch")
+    call need(this%x_in, i8(n) * i8(this%num_vertex_features(0)))
+    call need(this%e_in, i8(max(this%ne, 1)) * i8(fe))
+    call chk(athena_mp_memcpy_h2d(this%x_in%p, vertex_features, 4_c_int64_t * i8(n) * i8(this%num_vertex_features(0))), "h2d")
+    if(this%ne .gt. 0) call chk(athena_mp_memcpy_h2d(this%e_in%p, edge_features, 4_c_int64_t * i8(this%ne) * i8(fe)), "h2d")
+    out = this%forward_dev(this%x_in%p, this%e_in%p)
+    allocate(output(this%num_outputs, this%batch))
+    call chk(athena_mp_memcpy_d2h(output, out, 4_c_int64_t * i8(this%batch) * i8(this%num_outputs)), "d2h")
+  end function duvenaud_forward
+
+  function duvenaud_forward_dev(this, x_dev, e_dev) result(out_dev)
+    !! the same on tensors resident in HBM: x_dev (F_v, vertices), e_dev (F_e, edge columns) -> (num_outputs, batch),
+    !! a pointer into the layer (valid until the next forward)
+    class(duvenaud_mp_layer_type), intent(inout) :: this
+    type(c_ptr), intent(in) :: x_dev, e_dev
+    type(c_ptr) :: out_dev
     type(c_ptr) :: cur
     integer :: t, tt, n, fv, fe, fin, fo, o
     integer(c_int32_t) :: code, acc
@@ -796,23 +825,15 @@ contains
     tt = this%num_time_steps
     fe = this%num_edge_features(0)
     o = this%num_outputs
-    if(size(vertex_features, 1) .ne. this%num_vertex_features(0) .or. size(vertex_features, 2) .ne. n) &
-         call stop_program("duvenaud forward: vertex feature shape mismatch")
-    if(size(edge_features, 1) .ne. fe .or. size(edge_features, 2) .ne. this%ne) &
-         call stop_program("duvenaud forward: edge feature shape mismatch")
-    call need(this%x_in, i8(n) * i8(this%num_vertex_features(0)))
-    call need(this%e_in, i8(max(this%ne, 1)) * i8(fe))
-    call chk(athena_mp_memcpy_h2d(this%x_in%p, vertex_features, 4_c_int64_t * i8(n) * i8(this%num_vertex_features(0))), "h2d")
-    if(this%ne .gt. 0) call chk(athena_mp_memcpy_h2d(this%e_in%p, edge_features, 4_c_int64_t * i8(this%ne) * i8(fe)), "h2d")
     code = fused_code(this%activation)
-    cur = this%x_in%p
+    cur = x_dev
     do t = 1, tt
        fv = this%num_vertex_features(t - 1)
        fin = fv + fe
        fo = this%num_vertex_features(t)
        call need(this%tape_a(t), i8(n) * i8(fin))
        call need(this%tape_z(t), i8(n) * i8(fo))
-       call chk(athena_mp_duvenaud_propagate_fwd(this%graph, int(fv, c_int32_t), int(fe, c_int32_t), cur, this%e_in%p, &
+       call chk(athena_mp_duvenaud_propagate_fwd(this%graph, int(fv, c_int32_t), int(fe, c_int32_t), cur, e_dev, &
             this%tape_a(t)%p), "duvenaud_propagate")
        if(code .ge. 0)then
           call chk(athena_mp_duvenaud_update_act_fwd(this%graph, int(fin, c_int32_t), int(fo, c_int32_t), &
@@ -848,9 +869,8 @@ contains
                this%out_dev%p, acc), "segment_sum")
        end if
     end do
-    allocate(output(o, this%batch))
-    call chk(athena_mp_memcpy_d2h(output, this%out_dev%p, 4_c_int64_t * i8(this%batch) * i8(o)), "d2h")
-  end function duvenaud_forward
+    out_dev = this%out_dev%p
+  end function duvenaud_forward_dev
 
   subroutine duvenaud_backward(this, upstream, dx, de)
     !! reverse pass over the readout branches and the message chain; dx / de are produced when present
@@ -858,6 +878,41 @@ contains
     real(real32), intent(in) :: upstream(:,:)                         ! (num_outputs, batch)
     real(real32), allocatable, intent(out), optional :: dx(:,:)       ! (F_v, vertices)
     real(real32), allocatable, intent(out), optional :: de(:,:)       ! (F_e, edge columns)
+    type(c_ptr) :: dxp, dep
+    integer :: n, o, fe
+
+    n = this%nv
+    o = this%num_outputs
+    fe = this%num_edge_features(0)
+    if(size(upstream, 1) .ne. o .or. size(upstream, 2) .ne. this%batch) &
+         call stop_program("duvenaud backward: upstream shape mismatch")
+    call need(this%gout, i8(this%batch) * i8(o))
+    call chk(athena_mp_memcpy_h2d(this%gout%p, upstream, 4_c_int64_t * i8(this%batch) * i8(o)), "h2d")
+    if(present(dx) .and. present(de))then
+       call this%backward_dev(this%gout%p, dx_dev=dxp, de_dev=dep)
+    else if(present(dx))then
+       call this%backward_dev(this%gout%p, dx_dev=dxp)
+    else if(present(de))then
+       call this%backward_dev(this%gout%p, de_dev=dep)
+    else
+       call this%backward_dev(this%gout%p)
+    end if
+    if(present(dx))then
+       allocate(dx(this%num_vertex_features(0), n))
+       call chk(athena_mp_memcpy_d2h(dx, dxp, 4_c_int64_t * i8(n) * i8(this%num_vertex_features(0))), "d2h")
+    end if
+    if(present(de))then
+       allocate(de(fe, this%ne))
+       if(this%ne .gt. 0) call chk(athena_mp_memcpy_d2h(de, dep, 4_c_int64_t * i8(this%ne) * i8(fe)), "d2h")
+    end if
+  end subroutine duvenaud_backward
+
+  subroutine duvenaud_backward_dev(this, upstream_dev, dx_dev, de_dev)
+    !! upstream_dev (num_outputs, batch) on the device; dx_dev / de_dev, when present, return pointers into the
+    !! layer's scratch (valid until the next backward).  Parameter gradients land in the layer.
+    class(duvenaud_mp_layer_type), intent(inout) :: this
+    type(c_ptr), intent(in) :: upstream_dev
+    type(c_ptr), intent(out), optional :: dx_dev, de_dev
     type(c_ptr) :: gout, dzn, dzn_arg, dc, da, dl, tmp
     integer :: t, tt, n, o, fe, fv, fo, fin, fmax
     logical :: have_next, fused_msg, first_de, softmax_readout
@@ -867,17 +922,13 @@ contains
     tt = this%num_time_steps
     o = this%num_outputs
     fe = this%num_edge_features(0)
-    if(size(upstream, 1) .ne. o .or. size(upstream, 2) .ne. this%batch) &
-         call stop_program("duvenaud backward: upstream shape mismatch")
     fmax = max(maxval(this%num_vertex_features) + fe, o)
     call need(this%scratch(1), i8(max(n, 1)) * i8(fmax))      ! dl / temporary
     call need(this%scratch(2), i8(max(n, 1)) * i8(fmax))      ! dc
     call need(this%scratch(3), i8(max(n, 1)) * i8(fmax))      ! da
     call need(this%scratch(4), i8(max(n, 1)) * i8(fmax))      ! dz arriving from step t+1
     call need(this%scratch(5), i8(max(n, 1)) * i8(fmax))      ! readout logits' gradient after its activation
-    call need(this%gout, i8(this%batch) * i8(o))
-    call chk(athena_mp_memcpy_h2d(this%gout%p, upstream, 4_c_int64_t * i8(this%batch) * i8(o)), "h2d")
-    gout = this%gout%p
+    gout = upstream_dev
     code = fused_code(this%activation)
     fused_msg = code .ge. 0
     code_arg = ATHENA_MP_ACT_NONE
@@ -888,7 +939,7 @@ contains
     dc = this%scratch(2)%p
     da = this%scratch(3)%p
     dzn = this%scratch(4)%p
-    if(present(de) .and. this%ne .gt. 0) call need(this%de_acc, i8(this%ne) * i8(fe))
+    if(present(de_dev) .and. this%ne .gt. 0) call need(this%de_acc, i8(this%ne) * i8(fe))
     do t = tt, 1, -1
        fv = this%num_vertex_features(t - 1)
        fo = this%num_vertex_features(t)
@@ -924,11 +975,11 @@ contains
             int(this%min_vertex_degree, c_int32_t), int(this%max_vertex_degree, c_int32_t), dc, this%tape_a(t)%p, &
             this%grads(t)%p), "duvenaud_update reverse (weights)")
        this%has_grad(t) = .true.
-       if(t .eq. 1 .and. .not. (present(dx) .or. present(de))) exit
+       if(t .eq. 1 .and. .not. (present(dx_dev) .or. present(de_dev))) exit
        call chk(athena_mp_duvenaud_update_bwd_a(this%graph, int(fin, c_int32_t), int(fo, c_int32_t), &
             int(this%min_vertex_degree, c_int32_t), int(this%max_vertex_degree, c_int32_t), dc, this%params(t)%p, da), &
             "duvenaud_update reverse (input)")
-       if(present(de) .and. this%ne .gt. 0)then
+       if(present(de_dev) .and. this%ne .gt. 0)then
           if(first_de)then
              call chk(athena_mp_duvenaud_propagate_bwd_e(this%graph, int(fv, c_int32_t), int(fe, c_int32_t), da, &
                   this%de_acc%p), "duvenaud_propagate reverse (edges)")
@@ -939,21 +990,15 @@ contains
              call chk(athena_mp_axpy(i8(this%ne) * i8(fe), 1._real32, this%scratch(1)%p, this%de_acc%p), "axpy")
           end if
        end if
-       if(t .gt. 1 .or. present(dx))then
+       if(t .gt. 1 .or. present(dx_dev))then
           call chk(athena_mp_duvenaud_propagate_bwd_x(this%graph, int(fv, c_int32_t), int(fe, c_int32_t), da, dzn), &
                "duvenaud_propagate reverse (vertices)")
           have_next = .true.
        end if
     end do
-    if(present(dx))then
-       allocate(dx(this%num_vertex_features(0), n))
-       call chk(athena_mp_memcpy_d2h(dx, dzn, 4_c_int64_t * i8(n) * i8(this%num_vertex_features(0))), "d2h")
-    end if
-    if(present(de))then
-       allocate(de(fe, this%ne))
-       if(this%ne .gt. 0) call chk(athena_mp_memcpy_d2h(de, this%de_acc%p, 4_c_int64_t * i8(this%ne) * i8(fe)), "d2h")
-    end if
-  end subroutine duvenaud_backward
+    if(present(dx_dev)) dx_dev = dzn
+    if(present(de_dev)) de_dev = this%de_acc%p
+  end subroutine duvenaud_backward_dev
 
   subroutine duvenaud_destroy(this)
     class(duvenaud_mp_layer_type), intent(inout) :: this
@@ -1011,15 +1056,14 @@ contains
   end function gno_setup
 
   function gno_forward(this, vertex_features, edge_features) result(output)
-    !! update_message_gno :690-788: out = act( gno_aggregate(kappa(coords), x) + W x + b )
+    !! update_message_gno :690-788 on host arrays: upload, forward_dev, download
     class(graph_nop_mp_layer_type), intent(inout) :: this
     real(real32), intent(in) :: vertex_features(:,:)       ! (num_inputs, vertices)
     real(real32), intent(in) :: edge_features(:,:)         ! (coord_dim, edge columns): the pair's coordinate difference
     real(real32), allocatable :: output(:,:)
-    type(c_ptr) :: bias
+    type(c_ptr) :: y
     integer :: n, fi, fo
 
-    if(.not. c_associated(this%graph)) call stop_program("set_graph must be called before forward")
     n = this%nv
     fi = this%num_inputs
     fo = this%num_outputs
@@ -1029,33 +1073,89 @@ contains
          call stop_program("graph_nop layer expects vertex and edge feature inputs")       ! :725-728
     call need(this%x_in, i8(n) * i8(fi))
     call need(this%c_in, i8(max(this%ne, 1)) * i8(this%coord_dim))
+    call chk(athena_mp_memcpy_h2d(this%x_in%p, vertex_features, 4_c_int64_t * i8(n) * i8(fi)), "h2d")
+    if(this%ne .gt. 0) call chk(athena_mp_memcpy_h2d(this%c_in%p, edge_features, 4_c_int64_t * i8(this%ne) * i8(this%coord_dim)), "h2d")
+    y = this%forward_dev(this%x_in%p, this%c_in%p)
+    allocate(output(fo, n))
+    call chk(athena_mp_memcpy_d2h(output, y, 4_c_int64_t * i8(n) * i8(fo)), "d2h")
+  end function gno_forward
+
+  function gno_forward_dev(this, x_dev, coords_dev) result(y_dev)
+    !! out = act( gno_aggregate(kappa(coords), x) + W x + b ) on tensors resident in HBM.  x_dev and coords_dev are
+    !! part of the tape: they must stay valid until backward_dev has run.  The edge geometry is forwarded unchanged
+    !! to a following graph_nop layer (output(2,s), :781-785) -- pass the same coords_dev on.
+    class(graph_nop_mp_layer_type), intent(inout) :: this
+    type(c_ptr), intent(in) :: x_dev, coords_dev
+    type(c_ptr) :: y_dev
+    type(c_ptr) :: bias
+    integer :: n, fi, fo
+
+    if(.not. c_associated(this%graph)) call stop_program("set_graph must be called before forward")
+    n = this%nv
+    fi = this%num_inputs
+    fo = this%num_outputs
+    this%x_tape = x_dev
+    this%c_tape = coords_dev
     call need(this%z_pre, i8(n) * i8(fo))
     call need(this%y_out, i8(n) * i8(fo))
     call need(this%scratch(1), i8(n) * i8(max(fi, fo)))
-    call chk(athena_mp_memcpy_h2d(this%x_in%p, vertex_features, 4_c_int64_t * i8(n) * i8(fi)), "h2d")
-    if(this%ne .gt. 0) call chk(athena_mp_memcpy_h2d(this%c_in%p, edge_features, 4_c_int64_t * i8(this%ne) * i8(this%coord_dim)), "h2d")
     call chk(athena_mp_gno_aggregate_fwd(this%graph, int(this%coord_dim, c_int32_t), int(this%kernel_hidden, c_int32_t), &
-         int(fi, c_int32_t), int(fo, c_int32_t), this%params(1)%p, this%c_in%p, this%x_in%p, this%scratch(1)%p), "gno_aggregate")
+         int(fi, c_int32_t), int(fo, c_int32_t), this%params(1)%p, coords_dev, x_dev, this%scratch(1)%p), "gno_aggregate")
     bias = c_null_ptr
     if(this%use_bias) bias = this%params(3)%p
-    call chk(athena_mp_gemm_fwd(i8(n), int(fi, c_int32_t), int(fo, c_int32_t), this%x_in%p, this%params(2)%p, bias, &
+    call chk(athena_mp_gemm_fwd(i8(n), int(fi, c_int32_t), int(fo, c_int32_t), x_dev, this%params(2)%p, bias, &
          ATHENA_MP_ACT_NONE, this%z_pre%p), "gemm_fwd")
     call chk(athena_mp_axpy(i8(n) * i8(fo), 1._real32, this%scratch(1)%p, this%z_pre%p), "axpy")
     if(is_identity(this%activation))then
-       call copy_dev(this%y_out%p, this%z_pre%p, i8(n) * i8(fo))
+       y_dev = this%z_pre%p
     else
        call act_apply(this%activation, n, fo, this%z_pre%p, this%y_out%p)
+       y_dev = this%y_out%p
     end if
-    allocate(output(fo, n))
-    call chk(athena_mp_memcpy_d2h(output, this%y_out%p, 4_c_int64_t * i8(n) * i8(fo)), "d2h")
-  end function gno_forward
+  end function gno_forward_dev
 
   subroutine gno_backward(this, upstream, dx, dcoords)
+    !! reverse pass on host arrays
     class(graph_nop_mp_layer_type), intent(inout) :: this
     real(real32), intent(in) :: upstream(:,:)                              ! (num_outputs, vertices)
     real(real32), allocatable, intent(out), optional :: dx(:,:)            ! (num_inputs, vertices)
     real(real32), allocatable, intent(out), optional :: dcoords(:,:)       ! (coord_dim, edge columns)
-    type(c_ptr) :: dz
+    type(c_ptr) :: dxp, dcp
+    integer :: n, fi, fo, d
+
+    n = this%nv
+    fi = this%num_inputs
+    fo = this%num_outputs
+    d = this%coord_dim
+    if(size(upstream, 1) .ne. fo .or. size(upstream, 2) .ne. n) call stop_program("graph_nop backward: upstream shape mismatch")
+    call need(this%up_in, i8(n) * i8(fo))
+    call chk(athena_mp_memcpy_h2d(this%up_in%p, upstream, 4_c_int64_t * i8(n) * i8(fo)), "h2d")
+    if(present(dx) .and. present(dcoords))then
+       call this%backward_dev(this%up_in%p, dx_dev=dxp, dcoords_dev=dcp)
+    else if(present(dx))then
+       call this%backward_dev(this%up_in%p, dx_dev=dxp)
+    else if(present(dcoords))then
+       call this%backward_dev(this%up_in%p, dcoords_dev=dcp)
+    else
+       call this%backward_dev(this%up_in%p)
+    end if
+    if(present(dx))then
+       allocate(dx(fi, n))
+       call chk(athena_mp_memcpy_d2h(dx, dxp, 4_c_int64_t * i8(n) * i8(fi)), "d2h")
+    end if
+    if(present(dcoords))then
+       allocate(dcoords(d, this%ne))
+       if(this%ne .gt. 0) call chk(athena_mp_memcpy_d2h(dcoords, dcp, 4_c_int64_t * i8(this%ne) * i8(d)), "d2h")
+    end if
+  end subroutine gno_backward
+
+  subroutine gno_backward_dev(this, upstream_dev, dx_dev, dcoords_dev)
+    !! upstream_dev (num_outputs, vertices) on the device (read only); dx_dev / dcoords_dev, when present, return
+    !! pointers into the layer's scratch (valid until the next backward)
+    class(graph_nop_mp_layer_type), intent(inout) :: this
+    type(c_ptr), intent(in) :: upstream_dev
+    type(c_ptr), intent(out), optional :: dx_dev, dcoords_dev
+    type(c_ptr) :: dz, y
     real(real32), allocatable :: ones(:)
     integer :: n, fi, fo, d, h
 
@@ -1064,57 +1164,54 @@ contains
     fo = this%num_outputs
     d = this%coord_dim
     h = this%kernel_hidden
-    if(size(upstream, 1) .ne. fo .or. size(upstream, 2) .ne. n) call stop_program("graph_nop backward: upstream shape mismatch")
     call need(this%scratch(1), i8(n) * i8(max(fi, fo)))
     call need(this%scratch(2), i8(n) * i8(max(fi, fo)))
-    call need(this%scratch(3), i8(max(n, this%ne * d, 1)) * i8(max(fi, fo)))
-    call chk(athena_mp_memcpy_h2d(this%scratch(1)%p, upstream, 4_c_int64_t * i8(n) * i8(fo)), "h2d")
+    call need(this%scratch(3), i8(n) * i8(max(fi, fo)))
     if(is_identity(this%activation))then
-       dz = this%scratch(1)%p
+       dz = upstream_dev
     else
        dz = this%scratch(2)%p
-       call act_reverse(this%activation, n, fo, this%y_out%p, this%z_pre%p, this%scratch(1)%p, dz)
+       y = this%y_out%p
+       call act_reverse(this%activation, n, fo, y, this%z_pre%p, upstream_dev, dz)
     end if
     if(this%use_bias)then
        ! db(o) = sum_v dz(o, v): the contraction of a column of ones with dz
-       allocate(ones(n))
-       ones = 1._real32
-       call chk(athena_mp_memcpy_h2d(this%scratch(3)%p, ones, 4_c_int64_t * i8(n)), "h2d")
-       call chk(athena_mp_gemm_dw(i8(n), 1_c_int32_t, int(fo, c_int32_t), this%scratch(3)%p, dz, this%grads(3)%p), "gemm_dw")
+       if(this%ones%cap .lt. i8(n))then
+          call need(this%ones, i8(n))
+          allocate(ones(n))
+          ones = 1._real32
+          call chk(athena_mp_memcpy_h2d(this%ones%p, ones, 4_c_int64_t * i8(n)), "h2d")
+       end if
+       call chk(athena_mp_gemm_dw(i8(n), 1_c_int32_t, int(fo, c_int32_t), this%ones%p, dz, this%grads(3)%p), "gemm_dw")
        this%has_grad(3) = .true.
     end if
-    call chk(athena_mp_gemm_dw(i8(n), int(fi, c_int32_t), int(fo, c_int32_t), this%x_in%p, dz, this%grads(2)%p), "gemm_dw")
+    call chk(athena_mp_gemm_dw(i8(n), int(fi, c_int32_t), int(fo, c_int32_t), this%x_tape, dz, this%grads(2)%p), "gemm_dw")
     call chk(athena_mp_gno_aggregate_bwd_theta(this%graph, int(d, c_int32_t), int(h, c_int32_t), int(fi, c_int32_t), &
-         int(fo, c_int32_t), this%params(1)%p, this%c_in%p, this%x_in%p, dz, this%grads(1)%p), "gno reverse (theta)")
+         int(fo, c_int32_t), this%params(1)%p, this%c_tape, this%x_tape, dz, this%grads(1)%p), "gno reverse (theta)")
     this%has_grad(1:2) = .true.
-    if(present(dx))then
+    if(present(dx_dev))then
        call chk(athena_mp_gemm_dx(i8(n), int(fi, c_int32_t), int(fo, c_int32_t), dz, this%params(2)%p, this%scratch(3)%p), "gemm_dx")
-       if(is_identity(this%activation))then
-          call chk(athena_mp_gno_aggregate_bwd_x(this%graph, int(d, c_int32_t), int(h, c_int32_t), int(fi, c_int32_t), &
-               int(fo, c_int32_t), this%params(1)%p, this%c_in%p, dz, this%scratch(2)%p), "gno reverse (features)")
-          call chk(athena_mp_axpy(i8(n) * i8(fi), 1._real32, this%scratch(2)%p, this%scratch(3)%p), "axpy")
-       else
-          call chk(athena_mp_gno_aggregate_bwd_x(this%graph, int(d, c_int32_t), int(h, c_int32_t), int(fi, c_int32_t), &
-               int(fo, c_int32_t), this%params(1)%p, this%c_in%p, dz, this%scratch(1)%p), "gno reverse (features)")
-          call chk(athena_mp_axpy(i8(n) * i8(fi), 1._real32, this%scratch(1)%p, this%scratch(3)%p), "axpy")
-       end if
-       allocate(dx(fi, n))
-       call chk(athena_mp_memcpy_d2h(dx, this%scratch(3)%p, 4_c_int64_t * i8(n) * i8(fi)), "d2h")
+       call chk(athena_mp_gno_aggregate_bwd_x(this%graph, int(d, c_int32_t), int(h, c_int32_t), int(fi, c_int32_t), &
+            int(fo, c_int32_t), this%params(1)%p, this%c_tape, dz, this%scratch(1)%p), "gno reverse (features)")
+       call chk(athena_mp_axpy(i8(n) * i8(fi), 1._real32, this%scratch(1)%p, this%scratch(3)%p), "axpy")
+       dx_dev = this%scratch(3)%p
     end if
-    if(present(dcoords))then
-       allocate(dcoords(d, this%ne))
+    if(present(dcoords_dev))then
+       dcoords_dev = c_null_ptr
        if(this%ne .gt. 0)then
+          call need(this%dc_out, i8(this%ne) * i8(d))
           call chk(athena_mp_gno_aggregate_bwd_coords(this%graph, int(d, c_int32_t), int(h, c_int32_t), int(fi, c_int32_t), &
-               int(fo, c_int32_t), this%params(1)%p, this%c_in%p, this%x_in%p, dz, this%scratch(3)%p), "gno reverse (coords)")
-          call chk(athena_mp_memcpy_d2h(dcoords, this%scratch(3)%p, 4_c_int64_t * i8(this%ne) * i8(d)), "d2h")
+               int(fo, c_int32_t), this%params(1)%p, this%c_tape, this%x_tape, dz, this%dc_out%p), "gno reverse (coords)")
+          dcoords_dev = this%dc_out%p
        end if
     end if
-  end subroutine gno_backward
+  end subroutine gno_backward_dev
 
   subroutine gno_destroy(this)
     class(graph_nop_mp_layer_type), intent(inout) :: this
     integer :: t
     call release(this%x_in); call release(this%c_in); call release(this%z_pre); call release(this%y_out)
+    call release(this%up_in); call release(this%ones); call release(this%dc_out)
     do t = 1, 3
        call release(this%scratch(t))
     end do
