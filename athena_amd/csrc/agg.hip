@@ -335,6 +335,16 @@ int athena_mp_kipf_propagate_bwd(const athena_mp_graph *g, int32_t F, const floa
     return gather_agg(g->t_rowptr, g->t_src, exact ? g->t_coef : nullptr, grad, F, dx, F, g->n_cols, F, &g->lp_bwd);
 }
 
+/* the pull form of the same pair on a row shard (athena_amd/dist.py): over the FORWARD rows of g,
+ * y_plain[v] = sum_w x[col w], y_coef[v] = sum_w coef_w x[col w] -- one gather of the (local + halo) rows */
+int athena_mp_kipf_propagate_fwd_dual(const athena_mp_graph *g, int32_t F, const float *x, float *y_plain, float *y_coef)
+{
+    AMP_REQUIRE(g && F > 0, "kipf_propagate_fwd_dual: bad arguments");
+    if (g->n_rows == 0) return 0;
+    AMP_REQUIRE(y_plain && y_coef && (x || g->nnz == 0), "kipf_propagate_fwd_dual: null tensor");
+    return gather_agg_dual(g->rowptr, g->col, g->coef, x, y_plain, y_coef, g->n_rows, F, &g->lp_fwd);
+}
+
 /* both reverse forms of kipf_propagate from one gather of the upstream rows: dx_plain = the reference's
  * coefficient-free scatter (get_partial_kipf_propagate_left_val :85-111), dx_coef = the adjoint of the forward */
 int athena_mp_kipf_propagate_bwd_dual(const athena_mp_graph *g, int32_t F, const float *grad, float *dx_plain,

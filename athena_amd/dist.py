@@ -254,12 +254,20 @@ def make_weak_scaling_shard(rank, world, n, pairs, F, cut=None, device=None, see
 
 
 class KipfShardStep:
-    """One interior Kipf layer fwd+bwd on a row shard (the bench step):
-         exchange(X); (P, Z) = fused(A^ X, . W); exchange(dZ) under dW = dZ P^T (all-reduce);
-         dX = (A^T dZ) . W  (fused pull over the shard's rows)"""
+    """One interior Kipf layer fwd+bwd on a row shard (the bench step), F -> Fo features:
+         aggregate first (the reference's association):
+             exchange(X); (P, Z) = fused(A^ X, . W); exchange(dZ) under dW = dZ P^T (all-reduce);
+             dX = (A^T dZ) . W  (fused pull over the shard's rows)
+         transform first (4 Fo <= 3 F): the dense step runs on the local rows BEFORE the exchange, so
+         the forward halo carries Fo-wide rows instead of F-wide ones:
+             Y = X W^T; exchange(Y); Z = A^ Y; exchange(dZ); (Qp, Qc) = one dual pull of dZ;
+             dW = Qc^T X (all-reduce); dX = Qp W"""
 
-    def __init__(self, shard, F, device, backend=None, seed=1, exact=False):
+    def __init__(self, shard, F, device, backend=None, seed=1, exact=False, Fo=None, order="auto"):
         self.s, self.F, self.device = shard, F, device
+        self.Fo = Fo = F if Fo is None else int(Fo)
+        assert order in ("auto", "aggregate_first", "transform_first")
+        self.transform_first = order == "transform_first" or (order == "auto" and 4 * Fo <= 3 * F)
         self.b = backend or HipBackend(device)
         n, nh = shard.n, shard.n_halo
         ni = shard.n_int
@@ -271,57 +279,100 @@ class KipfShardStep:
         self.g_bwd_int, self.g_bwd_bnd = block(shard.adj_ja_bwd, 0, ni), block(shard.adj_ja_bwd, ni, n)
         self.exact = exact
         rng = np.random.Generator(np.random.PCG64([seed, shard.rank]))
-        self.x_ext = torch.empty((n + nh, F), dtype=torch.float32, device=device)
+        xw = Fo if self.transform_first else F            # width of the rows the forward exchange moves
+        self.x_ext = torch.empty((n + nh, F) if not self.transform_first else (n, F), dtype=torch.float32, device=device)
         self.x_ext[:n] = torch.from_numpy(rng.uniform(-1, 1, (n, F)).astype(np.float32)).to(device)
-        self.dZ_ext = torch.empty((n + nh, F), dtype=torch.float32, device=device)
-        self.dZ_ext[:n] = torch.from_numpy(rng.uniform(-1, 1, (n, F)).astype(np.float32)).to(device)
+        self.dZ_ext = torch.empty((n + nh, Fo), dtype=torch.float32, device=device)
+        self.dZ_ext[:n] = torch.from_numpy(rng.uniform(-1, 1, (n, Fo)).astype(np.float32)).to(device)
         self.dZ = self.dZ_ext[:n]
         wr = np.random.Generator(np.random.PCG64(seed + 1))              # W identical on every rank
-        self.W = torch.from_numpy((wr.standard_normal(F * F) * np.sqrt(2.0 / F)).astype(np.float32)).to(device)
-        self.P = torch.empty((n, F), dtype=torch.float32, device=device)
-        self.Z = torch.empty((n, F), dtype=torch.float32, device=device)
-        self.dW = torch.empty(F * F, dtype=torch.float32, device=device)
+        self.W = torch.from_numpy((wr.standard_normal(Fo * F) * np.sqrt(2.0 / F)).astype(np.float32)).to(device)
+        self.Z = torch.empty((n, Fo), dtype=torch.float32, device=device)
+        self.dW = torch.empty(Fo * F, dtype=torch.float32, device=device)
         self.dX = torch.empty((n, F), dtype=torch.float32, device=device)
-        self.xchg = HaloExchange(shard, F, device, self.b)
+        if self.transform_first:
+            self.y_ext = torch.empty((n + nh, Fo), dtype=torch.float32, device=device)
+            self.Qp = torch.empty((n, Fo), dtype=torch.float32, device=device)
+            self.Qc = self.Qp if exact else torch.empty((n, Fo), dtype=torch.float32, device=device)
+            self.P = None
+        else:
+            self.P = torch.empty((n, F), dtype=torch.float32, device=device)
+        self.xchg = HaloExchange(shard, xw, device, self.b)               # forward rows
+        self.xchg_o = self.xchg if xw == Fo else HaloExchange(shard, Fo, device, self.b)   # dZ rows
+
+    def _allreduce_dw(self):
+        # asynchronous: a blocking all_reduce would make the compute stream wait for the collective, and the
+        # collective queues behind the halo transfer on the communicator's stream -- the interior rows
+        # would then start only after the exchange they are meant to hide
+        if self.s.world == 1:
+            return None
+        if _host_staged(self.dW):
+            h = self.dW.cpu()
+            dist.all_reduce(h)
+            self.dW.copy_(h)
+            return None
+        return dist.all_reduce(self.dW, async_op=True)
 
     def __call__(self, events=None):
         """events: optional list; a (start, end) pair of torch.cuda events around the interior forward launch is
         appended (bench.py's roofline at N > 1)"""
-        s, b, F, n, ni = self.s, self.b, self.F, self.s.n, self.s.n_int
+        if self.transform_first:
+            return self._step_transform_first(events)
+        s, b, F, Fo, n, ni = self.s, self.b, self.F, self.Fo, self.s.n, self.s.n_int
         reqs = self.xchg.start(self.x_ext)                                        # halo of X in flight ...
         if events is not None:
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
-        b.kipf_layer_fwd(self.g_fwd_int, self.x_ext, self.W, F, P=self.P[:ni], Z=self.Z[:ni])   # ... under the interior rows
+        b.kipf_layer_fwd(self.g_fwd_int, self.x_ext, self.W, Fo, P=self.P[:ni], Z=self.Z[:ni])   # ... under the interior rows
         if events is not None:
             e1.record()
             events.append((e0, e1))
         self.xchg.finish(reqs)
-        b.kipf_layer_fwd(self.g_fwd_bnd, self.x_ext, self.W, F, P=self.P[ni:], Z=self.Z[ni:])
-        reqs = self.xchg.start(self.dZ_ext)                                       # halo of dZ in flight ...
+        b.kipf_layer_fwd(self.g_fwd_bnd, self.x_ext, self.W, Fo, P=self.P[ni:], Z=self.Z[ni:])
+        reqs = self.xchg_o.start(self.dZ_ext)                                     # halo of dZ in flight ...
         b.matmul_dw(self.P, self.dZ, out=self.dW)                                 # ... under dW
-        # asynchronous: a blocking all_reduce would make the compute stream wait for the collective, and the
-        # collective queues behind the halo transfer on the communicator's stream -- the interior rows below
-        # would then start only after the exchange they are meant to hide
-        red = None
-        if s.world > 1:
-            if _host_staged(self.dW):
-                h = self.dW.cpu()
-                dist.all_reduce(h)
-                self.dW.copy_(h)
-            else:
-                red = dist.all_reduce(self.dW, async_op=True)
+        red = self._allreduce_dw()
         b.pull_gemm(self.g_bwd_int, self.dZ_ext, self.W, F, exact=self.exact, out=self.dX[:ni])   # ... and the interior rows
-        self.xchg.finish(reqs)
+        self.xchg_o.finish(reqs)
         b.pull_gemm(self.g_bwd_bnd, self.dZ_ext, self.W, F, exact=self.exact, out=self.dX[ni:])
         if red is not None:
             red.wait()
         return self.dX
 
+    def _step_transform_first(self, events=None):
+        s, b, F, Fo, n, ni = self.s, self.b, self.F, self.Fo, self.s.n, self.s.n_int
+        b.matmul(self.W, self.x_ext[:n], Fo, out=self.y_ext[:n])                  # dense step on the local rows
+        reqs = self.xchg.start(self.y_ext)                                        # halo of Y (Fo wide) in flight ...
+        if events is not None:
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+        b.kipf_propagate(self.g_fwd_int, self.y_ext, out=self.Z[:ni])             # ... under the interior rows
+        if events is not None:
+            e1.record()
+            events.append((e0, e1))
+        self.xchg.finish(reqs)
+        b.kipf_propagate(self.g_fwd_bnd, self.y_ext, out=self.Z[ni:])
+        reqs = self.xchg_o.start(self.dZ_ext)                                     # halo of dZ in flight ...
+        self._pull(self.g_bwd_int, 0, ni)                                         # ... under the interior rows
+        self.xchg_o.finish(reqs)
+        self._pull(self.g_bwd_bnd, ni, n)
+        b.matmul_dw(self.x_ext[:n], self.Qc, out=self.dW)                         # dW = (A^^T dZ)^T X
+        red = self._allreduce_dw()
+        b.matmul_dx(self.W, self.Qp, F, out=self.dX)                              # dX = (A^T dZ) W, the reference's scatter
+        if red is not None:
+            red.wait()
+        return self.dX
 
-def build_kipf_step(shard, F, device, backend=None):
-    step = KipfShardStep(shard, F, device, backend)
-    halo_bytes = 2 * shard.n_halo * F * 4
+    def _pull(self, g, r0, r1):
+        if self.exact:
+            self.b.kipf_propagate(g, self.dZ_ext, out=self.Qp[r0:r1])
+        else:
+            self.b.pull_dual(g, self.dZ_ext, plain=self.Qp[r0:r1], coef=self.Qc[r0:r1])
+
+
+def build_kipf_step(shard, F, device, backend=None, Fo=None, order="auto"):
+    step = KipfShardStep(shard, F, device, backend, Fo=Fo, order=order)
+    halo_bytes = shard.n_halo * 4 * ((step.Fo if step.transform_first else F) + step.Fo)
     uniform = shard.world > 1 and abs(shard.cut - (shard.world - 1) / shard.world) < 1e-9
     info = {"graph": "random graph, both endpoints uniform over all N*vertices_per_gpu vertices (no partition structure)" if uniform
             else f"stochastic block model, one block per GPU, fixed inter-block density: {shard.cut:.4f} of the undirected pairs cross partitions at this N",

@@ -67,6 +67,19 @@ def kipf_propagate_bwd_dual(g: DeviceGraph, grad):
     return plain, coef
 
 
+def pull_dual(g: DeviceGraph, x, plain=None, coef=None):
+    """over the forward rows of g: (sum of the listed rows, coefficient-weighted sum) from one gather -- the pull
+    form of kipf_propagate_bwd_dual on a symmetric row shard (dist.py)"""
+    F = x.shape[1]
+    _chk(x, (g.n_cols, F))
+    plain = plain if plain is not None else torch.empty((g.n_rows, F), device=x.device, dtype=torch.float32)
+    coef = coef if coef is not None else torch.empty((g.n_rows, F), device=x.device, dtype=torch.float32)
+    _go()
+    _capi.call("athena_mp_kipf_propagate_fwd_dual", g.handle, F, _p(x), _p(_chk(plain, (g.n_rows, F))),
+               _p(_chk(coef, (g.n_rows, F))))
+    return plain, coef
+
+
 def neighbour_sum(g: DeviceGraph, x, out=None):
     """y[v,:] = sum_{w in row v} x[col[w],:] (no coefficient): the pull form of the reference's
     coefficient-free backward on a symmetric graph shard (= duvenaud_propagate with F_e = 0)"""

@@ -104,6 +104,10 @@ int athena_mp_kipf_propagate_bwd(const athena_mp_graph *g, int32_t F, const floa
  * the dense step BEFORE the aggregation (F_out < F_in): dX = dx_plain . W,  dW = dx_coef^T . X */
 int athena_mp_kipf_propagate_bwd_dual(const athena_mp_graph *g, int32_t F, const float *grad_dev,
                                       float *dx_plain_dev, float *dx_coef_dev);
+/* the same pair in pull form over the FORWARD rows (a row shard of an undirected graph, whose transposed rows are
+ * its own rows): y_plain[v] = sum_w x[col w], y_coef[v] = sum_w coef_w x[col w]; x has n_cols rows (local + halo) */
+int athena_mp_kipf_propagate_fwd_dual(const athena_mp_graph *g, int32_t F, const float *x_dev,
+                                      float *y_plain_dev, float *y_coef_dev);
 
 /* out[r,:] = x[idx[r],:]  (r < n; idx 0-based device array).  Packs the halo rows a row partition
  * sends to its peers; same gather kernel as the aggregation. */

@@ -54,6 +54,13 @@ class OracleBackend:
     def matmul_dw(self, P, dZ, out):
         out.copy_(torch.from_numpy(self.o.matmul_dw(dZ.numpy(), P.numpy())))
 
+    def matmul(self, W, P, Fo, out):
+        out.copy_(torch.from_numpy(self.o.matmul(W.numpy(), P.numpy(), Fo)))
+
+    def pull_dual(self, g, x, plain, coef):
+        self.neighbour_sum(g, x, plain)
+        self.kipf_propagate(g, x, coef)
+
     def matmul_dx(self, W, dZ, Fi, out):
         out.copy_(torch.from_numpy(self.o.matmul_dx(W.numpy(), dZ.numpy(), Fi)))
 
@@ -61,7 +68,7 @@ class OracleBackend:
         out.copy_(x[idx.long()])
 
 
-def _worker(rank, world, port, n, pairs, F, cut, q):
+def _worker(rank, world, port, n, pairs, F, cut, q, Fo=None, order="auto"):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -69,10 +76,11 @@ def _worker(rank, world, port, n, pairs, F, cut, q):
 
     dev = torch.device("cpu")
     shard = adist.make_weak_scaling_shard(rank, world, n, pairs, F, cut=cut, device=dev)
-    step = adist.KipfShardStep(shard, F, dev, backend=OracleBackend())
+    step = adist.KipfShardStep(shard, F, dev, backend=OracleBackend(), Fo=Fo, order=order)
     x_local = step.x_ext[:n].clone().numpy()
     dx = step().clone().numpy()
-    q.put((rank, dict(x=x_local, dz=step.dZ.numpy().copy(), w=step.W.numpy().copy(), P=step.P.numpy().copy(),
+    q.put((rank, dict(x=x_local, dz=step.dZ.numpy().copy(), w=step.W.numpy().copy(),
+                      P=step.P.numpy().copy() if step.P is not None else None, transform_first=step.transform_first,
                       Z=step.Z.numpy().copy(), dW=step.dW.numpy().copy(), dX=dx, n_halo=shard.n_halo,
                       send=int(shard.send_idx.numel()), col_deg=shard.col_deg.copy(), order=shard.order.copy(),
                       n_int=shard.n_int)))
@@ -84,15 +92,19 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-@pytest.mark.parametrize("world,cut", [(2, None), (2, 0.1), (4, 0.05), (3, None)])
-def test_multi_rank_kipf_step_matches_global_oracle(oracle, world, cut):
+@pytest.mark.parametrize("world,cut,Fo,order", [(2, None, None, "auto"), (2, 0.1, None, "auto"), (4, 0.05, None, "auto"),
+                                                (3, None, None, "auto"),
+                                                (2, 0.1, 3, "auto"),               # 8 -> 3: dense step before the exchange
+                                                (3, None, 7, "auto"),              # 8 -> 7: rectangular, aggregate first
+                                                (2, None, 8, "transform_first")])
+def test_multi_rank_kipf_step_matches_global_oracle(oracle, world, cut, Fo, order):
     from athena_amd import dist as adist
 
     n, pairs, F = 400, 1500, 8
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, pairs, F, cut, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, pairs, F, cut, q, Fo, order)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=120) for _ in range(world))
@@ -120,9 +132,15 @@ def test_multi_rank_kipf_step_matches_global_oracle(oracle, world, cut):
     x, dz = unperm("x"), unperm("dz")
     w = res[0]["w"]
     assert all(np.array_equal(w, res[r]["w"]) for r in range(world))
+    Fo = F if Fo is None else Fo
     P = oracle.kipf_propagate(x, ia, ja)
-    assert np.array_equal(unperm("P"), P)                                                  # bit-exact
-    assert np.array_equal(unperm("Z"), oracle.matmul(w, P, F))
+    Zo = oracle.matmul(w, P, Fo)
+    if res[0]["transform_first"]:
+        assert (Fo, order) in ((3, "auto"), (8, "transform_first"))
+        assert np.abs(unperm("Z") - Zo).max() <= 1e-5 * np.abs(Zo).max()                   # A (X W^T): re-associated
+    else:
+        assert np.array_equal(unperm("P"), P)                                              # bit-exact
+        assert np.array_equal(unperm("Z"), Zo)
     dP = oracle.matmul_dx(w, dz, F)
     dX = oracle.kipf_propagate_bwd(dP, ia, ja)                                             # reference: no coefficient
     got = unperm("dX")                                                                     # (A^T dZ) W: same map,

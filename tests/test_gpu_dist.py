@@ -17,7 +17,7 @@ from test_dist_gloo import ROOT, _free_port
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, n, pairs, F, cut, q):
+def _worker(rank, world, port, n, pairs, F, cut, q, Fo=None):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -26,31 +26,35 @@ def _worker(rank, world, port, n, pairs, F, cut, q):
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     shard = adist.make_weak_scaling_shard(rank, world, n, pairs, F, cut=cut, device=dev)
-    step = adist.KipfShardStep(shard, F, dev)                       # HipBackend
+    step = adist.KipfShardStep(shard, F, dev, Fo=Fo)                # HipBackend
     x_local = step.x_ext[:n].clone().cpu().numpy()
     ev = []
     dx = step(events=ev).clone().cpu().numpy()
     torch.cuda.synchronize()
     q.put((rank, dict(x=x_local, dz=step.dZ.cpu().numpy().copy(), w=step.W.cpu().numpy().copy(),
-                      P=step.P.cpu().numpy().copy(), Z=step.Z.cpu().numpy().copy(), dW=step.dW.cpu().numpy().copy(),
+                      P=step.P.cpu().numpy().copy() if step.P is not None else None, transform_first=step.transform_first,
+                      Z=step.Z.cpu().numpy().copy(), dW=step.dW.cpu().numpy().copy(),
                       dX=dx, order=shard.order.copy(), n_int=shard.n_int, n_halo=shard.n_halo,
                       fwd_ms=ev[0][0].elapsed_time(ev[0][1]))))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,cut,F", [(2, 0.1, 128), (3, None, 64), (2, 0.05, 24)])
-def test_multi_rank_step_with_hip_backend_matches_global_oracle(dev, oracle, world, cut, F):
+@pytest.mark.parametrize("world,cut,F,Fo", [(2, 0.1, 128, None), (3, None, 64, None), (2, 0.05, 24, None),
+                                            (2, 0.1, 128, 32),     # narrowing step: dense step before the exchange
+                                            (3, None, 64, 96)])    # widening step: rectangular, aggregate first
+def test_multi_rank_step_with_hip_backend_matches_global_oracle(dev, oracle, world, cut, F, Fo):
     from athena_amd import dist as adist
 
     n, pairs = 3000, 12000
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, pairs, F, cut, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, pairs, F, cut, q, Fo)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=300) for _ in range(world))
+    Fo = F if Fo is None else Fo
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -71,8 +75,11 @@ def test_multi_rank_step_with_hip_backend_matches_global_oracle(dev, oracle, wor
 
     x, dz, w = unperm("x"), unperm("dz"), res[0]["w"]
     P = oracle.kipf_propagate(x, ia, ja)
-    assert np.array_equal(unperm("P"), P)                                         # aggregation: bit exact across shards
-    Z = oracle.matmul(w, P, F)
+    if res[0]["transform_first"]:
+        assert 4 * Fo <= 3 * F
+    else:
+        assert np.array_equal(unperm("P"), P)                                     # aggregation: bit exact across shards
+    Z = oracle.matmul(w, P, Fo)
     assert np.abs(unperm("Z") - Z).max() <= 1e-5 * np.abs(Z).max()
     dX = oracle.kipf_propagate_bwd(oracle.matmul_dx(w, dz, F), ia, ja)
     assert np.abs(unperm("dX") - dX).max() <= 1e-5 * np.abs(dX).max()
