@@ -639,6 +639,219 @@ int launch_outer(const int32_t *rowptr, const int32_t *idx, const int32_t *eidx,
     return 0;
 }
 
+// ---- fused kernel-MLP backward for H = 64, F_in = F_out = 64 (BASELINE configs[3]) -------------------------
+// dh_e = x_{j(e)} . G_i with G_i[k][q] = sum_o g[i,o] V[o + Fo q + F k] -- G (16 KB per vertex, 32 GB at C4) never
+// reaches HBM.  Same shape as gno_fused_kernel: a persistent 16-wave workgroup owns 16 vertices and walks the hidden
+// index in two halves so that the 16 x (32 x 64) half of G fits LDS (140 KB):
+//   phase A  G_half^T[(kl,q), v] = sum_o Vp[o][k][q] g[v,o] on 16x16x4 MFMAs with the VERTEX on the column axis:
+//            B = g[v, 4s + gq] (16 registers per lane for the whole tile), A = Vp[4s + gq][32 half + kl][4m .. 4m+3]
+//            (Vp = V re-laid [o][k][q] once per call) -- one 16 B load from L2 feeds four MFMAs whose output tiles
+//            interleave q = 4m + c, so a lane ends up with 16 consecutive q of its vertex and parks them in LDS with
+//            16 B stores; wave w produces hidden units kl = 2w, 2w + 1 of the half;
+//   phase B  wave w owns vertex w exactly like gno_dh_mfma_kernel: DH^T[e][kl] = sum_q x_{j(e)}[q] G[kl][q] on
+//            32x32x2 MFMAs (B operand read from LDS as it is needed), relu' mask in the C layout, then the
+//            second MFMA that accumulates dU^T / db_u over all entries of all of the wave's vertices.
+// One slab of (H d + H) partial sums per wave, reduced in fixed order by slab_reduce (no atomics).
+#ifndef GDH_VARIANT
+#define GDH_VARIANT 0   // 1: no phase A, 2: no phase B, 3: phase A without its LDS stores -- timing-only builds, never shipped
+#endif
+constexpr int kDRow = 68;                       // LDS pitch of one (vertex, kl) row of 64 q
+constexpr int kDVtx = 32 * kDRow + 4;           // LDS pitch of one vertex' half
+
+__global__ void gno_vperm_okq_kernel(const float *__restrict__ V, float *__restrict__ Vp)
+{
+    // Vp[(o*64 + k)*64 + q] = V[o + 64 q + 4096 k]
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 64 * 64 * 64) return;
+    const int q = t & 63, k = (t >> 6) & 63, o = t >> 12;
+    Vp[t] = V[o + 64 * q + 4096 * k];
+}
+
+template <bool WRITE_GH>
+__global__ __launch_bounds__(1024) void gno_gdh_kernel(const int32_t *__restrict__ rowptr,
+                                                       const int32_t *__restrict__ col,
+                                                       const int32_t *__restrict__ eid,
+                                                       const float *__restrict__ x,
+                                                       const float *__restrict__ coords,
+                                                       const float *__restrict__ theta, int d,
+                                                       const float *__restrict__ Vp,
+                                                       const float *__restrict__ grad, int n_rows,
+                                                       const int32_t *__restrict__ perm,
+                                                       float *__restrict__ slabs, float *__restrict__ ghbuf)
+{
+    extern __shared__ __attribute__((aligned(16))) float Gs[];   // [16 vertices][32 kl][kDRow] (+4 per vertex)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r31 = lane & 31, h = lane >> 5;
+    const int m = lane & 15, gq = lane >> 4;
+    const int n_tiles = (n_rows + kGRows - 1) / kGRows;
+    // dU^T[j][k] (j < d) and db_u[k] (j = 3) for this lane's hidden unit k = 32 half + r31, summed over the entry
+    // rows this lane half sees; the two lane halves are combined at the end
+    float du[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) du[t][jj] = 0.0f;
+    float *cbuf = Gs + (size_t)kGRows * kDVtx + wave * 128;   // per wave: coordinates of the 32 entries in flight
+
+    // the next tile's row pointers and first 32 (neighbour, edge) ids are fetched while the current tile is on the
+    // matrix cores, so phase B starts with its gathers instead of two dependent index loads
+    int nw0 = 0, nw1 = 0, nj = -1, ne = -1;
+    auto fetch_ids = [&](int tl) {
+        const int slot = tl * kGRows + wave;
+        nw0 = nw1 = 0;
+        nj = ne = -1;
+        if (tl < n_tiles && slot < n_rows) {
+            const int row = perm[slot];
+            nw0 = rowptr[row];
+            nw1 = rowptr[row + 1];
+            if (r31 < nw1 - nw0) { nj = col[nw0 + r31]; ne = eid[nw0 + r31]; }
+        }
+    };
+    fetch_ids(blockIdx.x);
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int r0 = tile * kGRows;
+        const int vrow = (r0 + m) < n_rows ? perm[r0 + m] : -1;   // phase-A vertex of this lane
+        const int w0 = nw0, w1 = nw1, cj = nj, ce = ne;           // phase-B row of this wave
+        for (int half = 0; half < 2; ++half) {
+            // ---------------- phase A: hidden units kl = 2 wave, 2 wave + 1 of this half ----------------
+            // B operand: g[vertex m of the tile][o = 4s + gq], s = 0..15 (re-read per half: L1-hot, and it keeps
+            // 16 registers free during phase B)
+            float gb[16];
+            {
+                const float *gr = grad + (size_t)max(vrow, 0) * 64 + gq;     // clamped address, value selected after
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const float v = gr[4 * s];
+                    gb[s] = vrow >= 0 ? v : 0.0f;
+                }
+            }
+#pragma unroll 1
+            for (int b = 0; b < (GDH_VARIANT == 1 ? 0 : 2); ++b) {
+                const int kl = 2 * wave + b;
+                v4f_g om[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) om[c] = v4f_g{0.0f, 0.0f, 0.0f, 0.0f};
+                const float *vb = Vp + ((size_t)gq * 64 + 32 * half + kl) * 64 + 4 * m;   // + s * (4 * 64 * 64)
+#pragma unroll
+                for (int s0 = 0; s0 < 16; s0 += 4) {
+                    v4f_g a[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const v4f_g *>(vb + (size_t)(s0 + u) * (4 * 64 * 64));
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            om[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][c], gb[s0 + u], om[c], 0, 0, 0);
+                }
+                // lane (vertex m, gq): om[c][r] = G[vertex][kl][q = 16 gq + 4 r + c]
+                float *dst = Gs + (size_t)m * kDVtx + kl * kDRow + 16 * gq;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (GDH_VARIANT != 3 || om[0][r] == 12345.0f)
+                        *reinterpret_cast<v4f_g *>(dst + 4 * r) = v4f_g{om[0][r], om[1][r], om[2][r], om[3][r]};
+            }
+            if (half == 1) fetch_ids(tile + gridDim.x);   // flies under the last phase B and the next phase A
+            __syncthreads();
+            // ---------------- phase B: entries of vertex `wave`, hidden units 32 half + r31 ----------------
+            {
+                float Uk[3], bk;
+                {
+                    const int k = 32 * half + r31;
+                    bk = theta[(size_t)kGH * d + k];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) Uk[j] = j < d ? theta[k + (size_t)kGH * j] : 0.0f;
+                }
+                const float *grow = Gs + (size_t)wave * kDVtx + r31 * kDRow + 32 * h;   // G[k = r31][q = 32 h + s]
+                for (int wb = w0; wb < (GDH_VARIANT == 2 ? w0 : w1); wb += 32) {
+                    const int nb = min(32, w1 - wb);
+                    int my_j = cj, my_e = ce;
+                    if (wb != w0) {   // rows longer than 32 entries: later blocks are fetched here
+                        my_j = r31 < nb ? col[wb + r31] : -1;
+                        my_e = r31 < nb ? eid[wb + r31] : -1;
+                    }
+                    // the entry's coordinate difference goes through LDS: one gather per entry (lane half 0) next
+                    // to the neighbour-row gathers, instead of a dependent load per accumulator row afterwards
+                    if (h == 0) {
+                        v4f_g cv = {0.0f, 0.0f, 0.0f, 0.0f};
+                        if (my_e >= 0) {
+                            cv.x = coords[(size_t)my_e * d];
+                            if (d > 1) cv.y = coords[(size_t)my_e * d + 1];
+                            if (d > 2) cv.z = coords[(size_t)my_e * d + 2];
+                        }
+                        *reinterpret_cast<v4f_g *>(cbuf + 4 * r31) = cv;
+                    }
+                    f32x16 dh;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dh[r] = 0.0f;
+                    {
+                        // all eight 16 B pieces of the neighbour row at once (clamped address, value selected after)
+                        const bool live = my_j >= 0 && my_e >= 0;
+                        const float *xr = x + (size_t)max(my_j, 0) * 64 + 32 * h;
+                        v4f_g xv[8];
+#pragma unroll
+                        for (int mm = 0; mm < 8; ++mm) xv[mm] = *reinterpret_cast<const v4f_g *>(xr + 4 * mm);
+#pragma unroll
+                        for (int mm = 0; mm < 8; ++mm) {
+                            const v4f_g gv = *reinterpret_cast<const v4f_g *>(grow + 4 * mm);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c)
+                                dh = __builtin_amdgcn_mfma_f32_32x32x2f32(live ? xv[mm][c] : 0.0f, gv[c], dh, 0, 0, 0);
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    float *ghp = nullptr;
+                    if constexpr (WRITE_GH) ghp = ghbuf + (size_t)(wb + 4 * h) * kGH + 32 * half + r31;
+                    // relu' mask in the C layout (register r of lane half h is entry (r&3) + 8(r>>2) + 4h), then the
+                    // rank-1 updates of dU^T / db_u on the VALU
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int e_loc = (r & 3) + 8 * (r >> 2) + 4 * h;
+                        const int ee = __shfl(my_e, e_loc);
+                        const bool ok = e_loc < nb && ee >= 0;
+                        const v4f_g cv = *reinterpret_cast<const v4f_g *>(cbuf + 4 * e_loc);
+                        float pre = 0.0f;
+                        pre = pre + Uk[0] * cv.x;
+                        pre = pre + Uk[1] * cv.y;
+                        pre = pre + Uk[2] * cv.z;
+                        pre = pre + bk;
+                        const float gh = (ok && pre > 0.0f) ? dh[r] : 0.0f;
+                        if constexpr (WRITE_GH) {
+                            if (e_loc < nb) ghp[((r & 3) + 8 * (r >> 2)) * kGH] = gh;
+                        }
+                        if (half == 0) {
+                            du[0][0] = du[0][0] + cv.x * gh; du[0][1] = du[0][1] + cv.y * gh;
+                            du[0][2] = du[0][2] + cv.z * gh; du[0][3] = du[0][3] + gh;
+                        } else {
+                            du[1][0] = du[1][0] + cv.x * gh; du[1][1] = du[1][1] + cv.y * gh;
+                            du[1][2] = du[1][2] + cv.z * gh; du[1][3] = du[1][3] + gh;
+                        }
+                        if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four rows of LDS reads in flight, not sixteen
+                    }
+                    __builtin_amdgcn_wave_barrier();   // cbuf is rewritten by the next block of entries
+                }
+            }
+            __syncthreads();   // the next half / tile overwrites Gs
+        }
+    }
+    // slab[j*H + k], j = 0..d-1: dU^T; slab[d*H + k]: db_u -- lane halves combined, lane half 0 writes
+    float *slab = slabs + ((size_t)blockIdx.x * 16 + wave) * (kGH * d + kGH);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const float tot = du[t][jj] + __shfl_xor(du[t][jj], 32);
+            if (h == 0) {
+                if (jj < 3 && jj < d) slab[(size_t)jj * kGH + 32 * t + r31] = tot;
+                if (jj == 3) slab[(size_t)d * kGH + 32 * t + r31] = tot;
+            }
+        }
+}
+
+bool gno_gdh_shape(int H, int Fi, int Fo, int d)
+{
+    static const bool off = getenv("ATHENA_MP_GNO_UNFUSED_DH") != nullptr;   // A/B switch for measurements
+    return !off && H == kGH && Fi == kGF && Fo == kGF && d <= 3;
+}
+
 int tile_rows_for(int64_t n_rows, int64_t floats_per_row)
 {
     static const int64_t budget = [] {   // bytes of S / T / G per super-tile
@@ -675,6 +888,43 @@ int gno_mlp_backward(const athena_mp_graph *g, int d, int H, int Fi, int Fo, con
         void *p = nullptr;
         if (amp::workspace(&p, sizeof(float) * (size_t)std::max<int64_t>(g->nnz, 1) * H, 4)) return 1;
         ghbuf = (float *)p;
+    }
+    if (gno_gdh_shape(H, Fi, Fo, d) && g->n_rows > 0) {
+        // one launch over all vertices: G is produced and consumed inside the workgroup
+        if (length_order(g->rowptr, g->n_rows, &g->len_perm_fwd)) return 1;
+        void *vp = nullptr, *sl = nullptr;
+        if (amp::workspace(&vp, sizeof(float) * 64 * 64 * 64, 1)) return 1;
+        hipLaunchKernelGGL(gno_vperm_okq_kernel, dim3(64 * 64 * 64 / 256), dim3(256), 0, amp::stream(), theta + off_V, (float *)vp);
+        AMP_LAUNCH_CHECK();
+        const int n_tiles = (g->n_rows + kGRows - 1) / kGRows;
+        const int nwg = std::min(n_tiles, 256);
+        if (amp::workspace(&sl, sizeof(float) * (size_t)nwg * 16 * np, 3)) return 1;
+        constexpr size_t glds = sizeof(float) * ((size_t)kGRows * kDVtx + 16 * 128);   // G half + per-wave coordinates
+        static bool gattr = false;
+        if (!gattr) {
+            AMP_HIP(hipFuncSetAttribute((const void *)gno_gdh_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
+            AMP_HIP(hipFuncSetAttribute((const void *)gno_gdh_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
+            gattr = true;
+        }
+        if (ghbuf)
+            hipLaunchKernelGGL(gno_gdh_kernel<true>, dim3(nwg), dim3(1024), glds, amp::stream(), g->rowptr, g->col, g->eid, x,
+                               coords, theta, d, (const float *)vp, grad, g->n_rows, (const int32_t *)g->len_perm_fwd,
+                               (float *)sl, ghbuf);
+        else
+            hipLaunchKernelGGL(gno_gdh_kernel<false>, dim3(nwg), dim3(1024), glds, amp::stream(), g->rowptr, g->col, g->eid, x,
+                               coords, theta, d, (const float *)vp, grad, g->n_rows, (const int32_t *)g->len_perm_fwd,
+                               (float *)sl, ghbuf);
+        AMP_LAUNCH_CHECK();
+        if (dtheta) {
+            if (int rc2 = amp::slab_reduce((const float *)sl, nwg * 16, np, dtheta, false)) return rc2;
+        }
+        if (dcoords && g->n_edge_cols > 0) {
+            int64_t n = (int64_t)g->n_edge_cols * d;
+            hipLaunchKernelGGL(gno_dcoords_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, amp::stream(),
+                               g->e_rowptr, g->e_col, ghbuf, theta, d, H, g->n_edge_cols, dcoords);
+            AMP_LAUNCH_CHECK();
+        }
+        return 0;
     }
     const int tile = tile_rows_for(g->n_rows, HF);
     const size_t lds = sizeof(float) * ((size_t)H * (Fi + 1) + (size_t)kEB * (Fi + H) + np);
