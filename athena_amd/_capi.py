@@ -37,6 +37,7 @@ _PROTOS = {
     "athena_mp_memset_zero": [_vp, C.c_uint64],
     "athena_mp_graph_create": [_i32, _i32, _i64, _vp, _vp, _i32, _vp, _vp, C.POINTER(_vp)],
     "athena_mp_csr_from_edges": [_i32, _i64, _vp, _i32, _vp, _vp, _i64, _vp],
+    "athena_mp_graph_create_from_edges": [_i32, _i64, _vp, _i32, _i32, _vp, _vp, _i64, _vp, C.POINTER(_vp)],
     "athena_mp_graph_export": [_vp, _i32, _vp, _i64, _vp],
     "athena_mp_graph_destroy": [_vp],
     "athena_mp_graph_dims": [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i32)],

@@ -249,15 +249,54 @@ int athena_mp_graph_export(const athena_mp_graph *g, int32_t which, void *host_d
     return 0;
 }
 
+static int graph_create_impl(int32_t n_rows, int32_t n_cols, int64_t nnz, const int32_t *adj_ia,
+                             const int32_t *adj_ja, const int32_t *adj_ja_dev, int32_t n_edge_cols,
+                             const int32_t *row_deg, const int32_t *col_deg, athena_mp_graph **out);
+
 int athena_mp_graph_create(int32_t n_rows, int32_t n_cols, int64_t nnz, const int32_t *adj_ia,
                            const int32_t *adj_ja, int32_t n_edge_cols, const int32_t *row_deg,
                            const int32_t *col_deg, athena_mp_graph **out)
 {
     AMP_REQUIRE(out != nullptr, "graph_create: null out pointer");
     *out = nullptr;
+    AMP_REQUIRE(nnz <= 0 || adj_ja != nullptr, "graph_create: null CSR arrays");
+    return graph_create_impl(n_rows, n_cols, nnz, adj_ia, adj_ja, nullptr, n_edge_cols, row_deg, col_deg, out);
+}
+
+/* edge list -> CSR -> handle without the entries leaving HBM in between (graphstruc's generate_adjacency
+ * [+ add_self_loops] followed by set_graph).  adj_ia_out (n_vertices + 1, host) is always filled; adj_ja_out
+ * (2 x capacity, host) only when non-null -- a caller that keeps the graph_type needs it, the layers do not. */
+int athena_mp_graph_create_from_edges(int32_t n_vertices, int64_t n_pairs, const int32_t *index_list,
+                                      int32_t add_self_loops, int32_t with_edge_ids, int32_t *adj_ia_out,
+                                      int32_t *adj_ja_out, int64_t capacity, int64_t *nnz_out, athena_mp_graph **out)
+{
+    AMP_REQUIRE(out != nullptr && nnz_out != nullptr && adj_ia_out != nullptr, "graph_create_from_edges: null output pointer");
+    *out = nullptr;
+    int32_t *ja_dev = nullptr;
+    int rc = amp::csr_from_edges_core(n_vertices, n_pairs, index_list, add_self_loops, adj_ia_out, adj_ja_out, capacity,
+                                      nnz_out, &ja_dev);
+    if (rc) {
+        if (ja_dev) (void)hipFree(ja_dev);
+        return rc;
+    }
+    const int32_t n_edge_cols = with_edge_ids ? (int32_t)n_pairs : 0;
+    if (!with_edge_ids && *nnz_out > 0) {   // a handle without edge features ignores the ids: zero them in place
+        AMP_HIP(hipMemset2DAsync(ja_dev + 1, 2 * sizeof(int32_t), 0, sizeof(int32_t), (size_t)*nnz_out, stream()));
+    }
+    rc = graph_create_impl(n_vertices, n_vertices, *nnz_out, adj_ia_out, adj_ja_out && with_edge_ids ? adj_ja_out : nullptr,
+                           ja_dev, n_edge_cols, nullptr, nullptr, out);
+    (void)hipFree(ja_dev);
+    return rc;
+}
+
+static int graph_create_impl(int32_t n_rows, int32_t n_cols, int64_t nnz, const int32_t *adj_ia,
+                             const int32_t *adj_ja, const int32_t *adj_ja_dev, int32_t n_edge_cols,
+                             const int32_t *row_deg, const int32_t *col_deg, athena_mp_graph **out)
+{
+    *out = nullptr;
     AMP_REQUIRE(n_rows >= 0 && n_cols >= 0 && nnz >= 0 && n_edge_cols >= 0, "graph_create: negative size");
     AMP_REQUIRE(nnz < (int64_t)INT32_MAX, "graph_create: nnz %lld exceeds int32 CSR", (long long)nnz);
-    AMP_REQUIRE(adj_ia != nullptr && (nnz == 0 || adj_ja != nullptr), "graph_create: null CSR arrays");
+    AMP_REQUIRE(adj_ia != nullptr && (nnz == 0 || adj_ja != nullptr || adj_ja_dev != nullptr), "graph_create: null CSR arrays");
     AMP_REQUIRE((row_deg == nullptr) == (col_deg == nullptr),
                 "graph_create: row_deg and col_deg must be given together");
     AMP_REQUIRE(row_deg != nullptr || n_rows == n_cols,
@@ -293,7 +332,7 @@ int athena_mp_graph_create(int32_t n_rows, int32_t n_cols, int64_t nnz, const in
             g->n_edge_cols = n_edge_cols;
             g->max_row_len = max_row;
             std::vector<int32_t> t_rowptr_h;
-            int rc = amp::graph_build_device(g, adj_ja, rowptr, degr, degc, &t_rowptr_h);
+            int rc = amp::graph_build_device(g, adj_ja, rowptr, degr, degc, &t_rowptr_h, adj_ja_dev);
             if (rc == 0) {
                 int32_t max_col = 0;
                 for (int32_t u = 0; u < n_cols; ++u) max_col = std::max(max_col, t_rowptr_h[u + 1] - t_rowptr_h[u]);
@@ -317,6 +356,13 @@ int athena_mp_graph_create(int32_t n_rows, int32_t n_cols, int64_t nnz, const in
         }
     }
 
+    // host builder: needs the entries on the host
+    std::vector<int32_t> ja_copy;
+    if (adj_ja == nullptr && nnz > 0) {
+        ja_copy.resize(2 * (size_t)nnz);
+        AMP_HIP(hipMemcpy(ja_copy.data(), adj_ja_dev, sizeof(int32_t) * ja_copy.size(), hipMemcpyDeviceToHost));
+        adj_ja = ja_copy.data();
+    }
     // transposed CSR + edge-column index by stable counting sort (entry order w preserved, so each
     // transposed row lists its sources in ascending v: the reference's accumulation order,
     // athena_diffstruc_extd_sub_kipf.f90:101-109).

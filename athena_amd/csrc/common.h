@@ -97,7 +97,10 @@ namespace amp {
 // device-side construction of the handle arrays (graph_build.hip); -1 = use the host builder
 int graph_build_device(athena_mp_graph *g, const int32_t *adj_ja, const std::vector<int32_t> &rowptr,
                        const std::vector<int32_t> &degr, const std::vector<int32_t> &degc,
-                       std::vector<int32_t> *t_rowptr_host);
+                       std::vector<int32_t> *t_rowptr_host, const int32_t *adj_ja_dev = nullptr);
+int csr_from_edges_core(int32_t n_vertices, int64_t n_pairs, const int32_t *index_list, int32_t add_self_loops,
+                        int32_t *adj_ia_out, int32_t *adj_ja_out, int64_t capacity, int64_t *nnz_out,
+                        int32_t **keep_ja_dev);
 void host_pool_release();   // staging buffers of the *_host entry points (host.hip)
 int agg_blocks_cap();
 void set_agg_blocks_cap(int n);

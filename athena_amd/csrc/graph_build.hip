@@ -138,8 +138,10 @@ namespace amp {
 // transposed row pointers (the caller plans hub rows from them).
 int graph_build_device(athena_mp_graph *g, const int32_t *adj_ja, const std::vector<int32_t> &rowptr,
                        const std::vector<int32_t> &degr, const std::vector<int32_t> &degc,
-                       std::vector<int32_t> *t_rowptr_host)
+                       std::vector<int32_t> *t_rowptr_host, const int32_t *adj_ja_dev)
 {
+    // adj_ja_dev != nullptr: the CSR entries are already in HBM (athena_mp_graph_create_from_edges); adj_ja may
+    // then be null
     const int32_t n_rows = g->n_rows, n_cols = g->n_cols, n_edge_cols = g->n_edge_cols;
     const int64_t nnz = g->nnz;
     hipStream_t st = stream();
@@ -175,7 +177,7 @@ int graph_build_device(athena_mp_graph *g, const int32_t *adj_ja, const std::vec
             *d_ekey = nullptr, *d_rank_r = nullptr, *d_rank_c = nullptr;
     float *d_table = nullptr;
     BadEntry *d_bad = nullptr;
-    if (tmp.get(&d_ja, 2 * (size_t)nnz) || tmp.get(&d_row_of, nnz) || tmp.get(&d_iota, nnz) || tmp.get(&d_perm, nnz) ||
+    if ((adj_ja_dev == nullptr && tmp.get(&d_ja, 2 * (size_t)nnz)) || tmp.get(&d_row_of, nnz) || tmp.get(&d_iota, nnz) || tmp.get(&d_perm, nnz) ||
         tmp.get(&d_keys_sorted, nnz) || tmp.get(&d_rank_r, rank_r.size()) || tmp.get(&d_rank_c, rank_c.size()) ||
         tmp.get(&d_table, table.size()) || tmp.get(&d_bad, 1))
         return 1;
@@ -189,7 +191,10 @@ int graph_build_device(athena_mp_graph *g, const int32_t *adj_ja, const std::vec
 
     const BadEntry none = {~0ull};
     AMP_HIP(hipMemcpyAsync(d_bad, &none, sizeof(none), hipMemcpyHostToDevice, st));
-    AMP_HIP(hipMemcpyAsync(d_ja, adj_ja, sizeof(int32_t) * 2 * (size_t)nnz, hipMemcpyHostToDevice, st));
+    if (adj_ja_dev == nullptr)
+        AMP_HIP(hipMemcpyAsync(d_ja, adj_ja, sizeof(int32_t) * 2 * (size_t)nnz, hipMemcpyHostToDevice, st));
+    else
+        d_ja = const_cast<int32_t *>(adj_ja_dev);
     AMP_HIP(hipMemcpyAsync(g->rowptr, rowptr.data(), sizeof(int32_t) * rowptr.size(), hipMemcpyHostToDevice, st));
     if (!degr.empty()) AMP_HIP(hipMemcpyAsync(g->deg_row, degr.data(), sizeof(int32_t) * degr.size(), hipMemcpyHostToDevice, st));
     if (!degc.empty()) AMP_HIP(hipMemcpyAsync(g->deg_col, degc.data(), sizeof(int32_t) * degc.size(), hipMemcpyHostToDevice, st));
@@ -208,7 +213,10 @@ int graph_build_device(athena_mp_graph *g, const int32_t *adj_ja, const std::vec
         AMP_HIP(hipStreamSynchronize(st));
         if (bad.first_bad != ~0ull) {   // same messages as the host builder
             const int64_t w = (int64_t)bad.first_bad;
-            const int32_t u = adj_ja[2 * w] - 1, e = adj_ja[2 * w + 1] - 1;
+            int32_t pair[2] = {0, 0};
+            if (adj_ja) { pair[0] = adj_ja[2 * w]; pair[1] = adj_ja[2 * w + 1]; }
+            else AMP_HIP(hipMemcpy(pair, d_ja + 2 * w, sizeof(pair), hipMemcpyDeviceToHost));
+            const int32_t u = pair[0] - 1, e = pair[1] - 1;
             if (u < 0 || u >= n_cols)
                 set_error("graph_create: adj_ja(1,%lld) = %d outside [1,%d]", (long long)w + 1, u + 1, n_cols);
             else
@@ -355,11 +363,13 @@ __global__ void csr_entries_kernel(int64_t nnz, const unsigned long long *__rest
 
 } // namespace
 
-extern "C" int athena_mp_csr_from_edges(int32_t n_vertices, int64_t n_pairs, const int32_t *index_list,
-                                        int32_t add_self_loops, int32_t *adj_ia_out, int32_t *adj_ja_out,
-                                        int64_t capacity, int64_t *nnz_out)
+namespace amp {
+// the edge list -> CSR pass.  adj_ja_out: host copy of the entries (may be null); keep_ja_dev: when non-null the
+// device copy of the entries is handed to the caller (hipFree it) instead of being released
+int csr_from_edges_core(int32_t n_vertices, int64_t n_pairs, const int32_t *index_list, int32_t add_self_loops,
+                        int32_t *adj_ia_out, int32_t *adj_ja_out, int64_t capacity, int64_t *nnz_out,
+                        int32_t **keep_ja_dev)
 {
-    using namespace amp;
     AMP_REQUIRE(n_vertices >= 0 && n_pairs >= 0 && nnz_out && adj_ia_out && (n_pairs == 0 || index_list),
                 "csr_from_edges: bad arguments");
     AMP_REQUIRE(2 * n_pairs + n_vertices < (int64_t)INT32_MAX, "csr_from_edges: more than 2^31 CSR entries");
@@ -415,16 +425,30 @@ extern "C" int athena_mp_csr_from_edges(int32_t n_vertices, int64_t n_pairs, con
     AMP_HIP(hipStreamSynchronize(st));
     nnz = (int64_t)adj_ia_out[n_vertices] - 1;     // invalid slots carry the all-ones key and sort behind every row
     *nnz_out = nnz;
-    if (adj_ja_out == nullptr) return 0;             // size query
-    AMP_REQUIRE(capacity >= nnz, "csr_from_edges: adj_ja buffer holds %lld entries, the graph has %lld", (long long)capacity,
-                (long long)nnz);
+    if (adj_ja_out == nullptr && keep_ja_dev == nullptr) return 0;             // size query
+    if (adj_ja_out)
+        AMP_REQUIRE(capacity >= nnz, "csr_from_edges: adj_ja buffer holds %lld entries, the graph has %lld",
+                    (long long)capacity, (long long)nnz);
+    if (keep_ja_dev) {
+        if (dev_alloc(&d_ja, 2 * (size_t)nnz)) return 1;
+        *keep_ja_dev = d_ja;
+    } else if (tmp.get(&d_ja, 2 * (size_t)nnz))
+        return 1;
     if (nnz > 0) {
-        if (tmp.get(&d_ja, 2 * (size_t)nnz)) return 1;
         hipLaunchKernelGGL(csr_entries_kernel, dim3(blocks(nnz)), dim3(256), 0, st, nnz, (const unsigned long long *)d_keys_s,
                            (const int32_t *)d_dst_s, stride, d_ja);
         AMP_LAUNCH_CHECK();
-        AMP_HIP(hipMemcpyAsync(adj_ja_out, d_ja, sizeof(int32_t) * 2 * (size_t)nnz, hipMemcpyDeviceToHost, st));
+        if (adj_ja_out) AMP_HIP(hipMemcpyAsync(adj_ja_out, d_ja, sizeof(int32_t) * 2 * (size_t)nnz, hipMemcpyDeviceToHost, st));
         AMP_HIP(hipStreamSynchronize(st));
     }
     return 0;
+}
+} // namespace amp
+
+extern "C" int athena_mp_csr_from_edges(int32_t n_vertices, int64_t n_pairs, const int32_t *index_list,
+                                        int32_t add_self_loops, int32_t *adj_ia_out, int32_t *adj_ja_out,
+                                        int64_t capacity, int64_t *nnz_out)
+{
+    return amp::csr_from_edges_core(n_vertices, n_pairs, index_list, add_self_loops, adj_ia_out, adj_ja_out, capacity,
+                                    nnz_out, nullptr);
 }

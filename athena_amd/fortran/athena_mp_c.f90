@@ -33,7 +33,7 @@ module athena_mp_c
   public :: athena_mp_gno_aggregate_bwd_coords
   public :: athena_mp_duvenaud_readout_fwd, athena_mp_duvenaud_readout_bwd, athena_mp_duvenaud_update_act_fwd
   public :: athena_mp_kipf_layer_fwd, athena_mp_kipf_layer_bwd_x, athena_mp_activation_bwd
-  public :: athena_mp_csr_from_edges, athena_mp_graph_export
+  public :: athena_mp_csr_from_edges, athena_mp_graph_export, athena_mp_graph_create_from_edges
   public :: athena_mp_error_message
 
   interface
@@ -189,6 +189,18 @@ module athena_mp_c
        integer(c_int32_t), intent(inout) :: adj_ia(*)
        type(c_ptr), value :: adj_ja                     !! c_loc of an integer(c_int32_t) adj_ja(2,capacity) target
        integer(c_int64_t), intent(out) :: nnz
+     end function
+     !! edge list -> CSR -> handle with the entries staying in HBM in between; adj_ja_out = c_null_ptr: not wanted
+     integer(c_int) function athena_mp_graph_create_from_edges(n_vertices, n_pairs, index_list, add_self_loops, &
+          with_edge_ids, adj_ia, adj_ja, capacity, nnz, graph) bind(C, name="athena_mp_graph_create_from_edges")
+       import :: c_int, c_int32_t, c_int64_t, c_ptr
+       integer(c_int32_t), value :: n_vertices, add_self_loops, with_edge_ids
+       integer(c_int64_t), value :: n_pairs, capacity
+       integer(c_int32_t), intent(in) :: index_list(2,*)
+       integer(c_int32_t), intent(inout) :: adj_ia(*)
+       type(c_ptr), value :: adj_ja
+       integer(c_int64_t), intent(out) :: nnz
+       type(c_ptr), intent(out) :: graph
      end function
      !! one array of the handle back on the host (which: see include/athena_mp.h); host_dst = c_null_ptr queries count
      integer(c_int) function athena_mp_graph_export(graph, which, host_dst, capacity, count) &

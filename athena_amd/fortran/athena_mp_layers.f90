@@ -67,6 +67,7 @@ module athena_mp_layers
      logical, allocatable :: has_grad(:)
    contains
      procedure, pass(this) :: set_graph => layer_set_graph
+     procedure, pass(this) :: set_graph_from_edges => layer_set_graph_from_edges
      procedure, pass(this) :: get_num_params => layer_get_num_params
      procedure, pass(this) :: get_params => layer_get_params
      procedure, pass(this) :: set_params => layer_set_params
@@ -406,6 +407,35 @@ contains
     call need(this%seg, i8(this%batch + 1))
     call chk(athena_mp_memcpy_h2d(this%seg%p, this%vertex_offset, 4_c_int64_t * i8(this%batch + 1)), "h2d")
   end subroutine layer_set_graph
+
+  subroutine layer_set_graph_from_edges(this, num_vertices, index_list, add_self_loops)
+    !! one graph given as its edge list (what generate_adjacency takes): CSR and device handle are built on the GPU in
+    !! one call, the entries never visit the host (athena_mp_graph_create_from_edges); edge id = column of index_list
+    class(mp_layer_type), intent(inout) :: this
+    integer, intent(in) :: num_vertices
+    integer(c_int32_t), intent(in) :: index_list(:,:)                  ! (2, num_edges)
+    logical, intent(in), optional :: add_self_loops
+    integer(c_int32_t), allocatable :: ia(:)
+    integer(c_int64_t) :: nnz
+    integer(c_int32_t) :: loops
+
+    if(size(index_list, 1) .ne. 2) call stop_program("set_graph_from_edges: index_list must be (2, num_edges)")
+    loops = 0
+    if(present(add_self_loops)) loops = merge(1_c_int32_t, 0_c_int32_t, add_self_loops)
+    if(c_associated(this%graph)) call chk(athena_mp_graph_destroy(this%graph), "graph_destroy")
+    this%graph = c_null_ptr
+    this%batch = 1
+    this%nv = num_vertices
+    this%ne = size(index_list, 2)
+    if(allocated(this%vertex_offset)) deallocate(this%vertex_offset)
+    allocate(this%vertex_offset(2), ia(num_vertices + 1))
+    this%vertex_offset = [0, num_vertices]
+    call chk(athena_mp_graph_create_from_edges(int(num_vertices, c_int32_t), int(size(index_list, 2), c_int64_t), index_list, &
+         loops, merge(1_c_int32_t, 0_c_int32_t, this%keep_edges), ia, c_null_ptr, 0_c_int64_t, nnz, this%graph), &
+         "graph_create_from_edges")
+    call need(this%seg, 2_c_int64_t)
+    call chk(athena_mp_memcpy_h2d(this%seg%p, this%vertex_offset, 8_c_int64_t), "h2d")
+  end subroutine layer_set_graph_from_edges
 
   subroutine layer_alloc_params(this, sizes)
     class(mp_layer_type), intent(inout) :: this

@@ -1,7 +1,7 @@
 !! The headline step driven from FORTRAN: one interior Kipf layer forward + backward on a random graph,
 !! through kipf_mp_layer_type's device-pointer methods (tensors resident in HBM, as between consecutive HIP
 !! layers of a network).  Graph: `pairs` undirected pairs drawn uniformly (u /= v) + self loops, CSR built on the
-!! GPU by athena_mp_csr_from_edges -- the shape of BASELINE configs[1], though not bench.py's exact graph
+!! GPU by athena_mp_graph_create_from_edges -- the shape of BASELINE configs[1], though not bench.py's exact graph
 !! (this program uses Fortran's random_number).  bench.py remains the measurement of record.
 !!
 !!   bench_kipf_layer [vertices] [pairs] [features] [steps]
@@ -13,10 +13,8 @@ program bench_kipf_layer
   integer :: n, f, steps, i, k
   integer(c_int64_t) :: pairs, nnz, c0, c1, rate
   character(32) :: arg
-  type(mp_graph_type) :: graph(1)
   type(kipf_mp_layer_type) :: layer
   integer(c_int32_t), allocatable :: index_list(:,:)
-  integer(c_int32_t), allocatable, target :: ja(:,:)
   real(real32), allocatable :: x(:,:), u(:)
   type(c_ptr) :: x_dev, dz_dev, y_dev, dx_dev
   real(real32) :: r(2)
@@ -46,19 +44,13 @@ program bench_kipf_layer
         if(index_list(1, i) .ne. index_list(2, i)) exit
      end do
   end do
-  graph(1)%num_vertices = n
-  graph(1)%num_edges = int(pairs)
-  allocate(graph(1)%adj_ia(n + 1))
-  call must(athena_mp_csr_from_edges(int(n, c_int32_t), pairs, index_list, 1_c_int32_t, graph(1)%adj_ia, c_null_ptr, &
-       0_c_int64_t, nnz), "csr_from_edges (size)")
-  allocate(ja(2, nnz))
-  call must(athena_mp_csr_from_edges(int(n, c_int32_t), pairs, index_list, 1_c_int32_t, graph(1)%adj_ia, c_loc(ja), &
-       nnz, nnz), "csr_from_edges")
-  call move_alloc(ja, graph(1)%adj_ja)
-  deallocate(index_list)
-
   layer = kipf_mp_layer_type(num_vertex_features=[f], num_time_steps=1, activation="none")
-  call layer%set_graph(graph)
+  call system_clock(c0, rate)
+  call layer%set_graph_from_edges(n, index_list, add_self_loops=.true.)     ! CSR + handle on the GPU, one call
+  call system_clock(c1)
+  nnz = 2_c_int64_t * pairs + n
+  write(*,'(A,F8.2,A)') "# graph handle from the edge list: ", real(c1 - c0, c_double) / real(rate, c_double) * 1.d3, " ms"
+  deallocate(index_list)
 
   allocate(x(f, n))
   call random_number(x)

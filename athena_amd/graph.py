@@ -168,6 +168,34 @@ class DeviceGraph:
         return out
 
     @classmethod
+    def from_edges(cls, num_vertices, index_list, add_self_loops=False, with_edge_ids=True, want_adjacency=False, device=0):
+        """edge list -> device handle in one call (athena_mp_graph_create_from_edges): generate_adjacency
+        [+ add_self_loops] and set_graph with the CSR entries staying in HBM in between.  Returns the handle, or
+        (handle, adj_ia, adj_ja) with want_adjacency (adj_ia is produced either way)."""
+        _capi.init(device)
+        idx = np.asfortranarray(np.asarray(index_list, dtype=np.int32))
+        assert idx.ndim == 2 and idx.shape[0] == 2
+        n, E = int(num_vertices), idx.shape[1]
+        self = cls.__new__(cls)
+        ia = np.empty(n + 1, np.int32)
+        nnz = C.c_int64()
+        h = C.c_void_p()
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        ja = None
+        if want_adjacency:
+            cap = 2 * E + n
+            ja = np.empty((2, cap), np.int32, order="F")
+        _capi.call("athena_mp_graph_create_from_edges", n, E, vp(idx), int(bool(add_self_loops)), int(bool(with_edge_ids)),
+                   vp(ia), vp(ja) if ja is not None else None, ja.shape[1] if ja is not None else 0, C.byref(nnz), C.byref(h))
+        self.handle = h
+        self.n_rows = self.n_cols = n
+        self.nnz = int(nnz.value)
+        self.n_edge_cols = E if with_edge_ids else 0
+        if want_adjacency:
+            return self, ia, np.asfortranarray(ja[:, :self.nnz])
+        return self
+
+    @classmethod
     def from_graph(cls, g, device=0):
         return cls(g.adj_ia, g.adj_ja, n_edge_cols=max(g.num_edges, int(g.adj_ja[1].max()) if g.nnz else 0),
                    device=device)

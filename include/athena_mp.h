@@ -84,6 +84,14 @@ int athena_mp_csr_from_edges(int32_t n_vertices, int64_t n_pairs, const int32_t 
  * 0 rowptr, 1 col, 2 eid, 3 coef, 4 t_rowptr, 5 t_src, 6 t_eid, 7 t_coef (transposed CSR: the pull form of the
  * reference's scatters), 8 e_rowptr, 9 e_row, 10 e_entry (edge-column index), 11 deg_row, 12 deg_col.
  * host_dst NULL: size query only.  *count = number of elements. */
+/* edge list -> CSR -> handle with the entries staying in HBM in between (generate_adjacency [+ add_self_loops]
+ * followed by set_graph in one call).  adj_ia_out (n_vertices + 1, host) is always filled; adj_ja_out
+ * (2 x capacity, host, column-major) only when non-null.  with_edge_ids = 0 builds a handle without edge-feature
+ * columns (Kipf); 1 keeps the pair index as the edge id of both directed entries (Duvenaud / GNO). */
+int athena_mp_graph_create_from_edges(int32_t n_vertices, int64_t n_pairs, const int32_t *index_list_host,
+                                      int32_t add_self_loops, int32_t with_edge_ids, int32_t *adj_ia_out,
+                                      int32_t *adj_ja_out, int64_t capacity, int64_t *nnz_out,
+                                      athena_mp_graph **out);
 int athena_mp_graph_export(const athena_mp_graph *g, int32_t which, void *host_dst, int64_t capacity,
                            int64_t *count);
 int athena_mp_graph_destroy(athena_mp_graph *g);

@@ -146,3 +146,39 @@ def test_edge_list_to_csr_on_the_device_equals_the_host_mirror(dev, n, E, loops)
         bad[1, E // 2] = n + 5
         with pytest.raises(_capi.AthenaMPError, match=r"index_list\(:,%d\)" % (E // 2 + 1)):
             graph_type_dev = graph_type(); graph_type_dev.set_num_vertices(n, 1); graph_type_dev.generate_adjacency_device(bad)
+
+
+@pytest.mark.parametrize("n,pairs,loops,edge_ids,mode", [(60, 150, True, True, "host"), (60, 150, True, False, "device"),
+                                                         (40000, 150000, True, True, "device"), (40000, 150000, False, False, None),
+                                                         (300000, 200000, True, True, None), (5, 0, True, True, None)])
+def test_handle_from_an_edge_list_in_one_call(dev, n, pairs, loops, edge_ids, mode):
+    """athena_mp_graph_create_from_edges = generate_adjacency [+ add_self_loops] + set_graph with the CSR entries kept
+    in HBM in between: every array of the handle equals the two-call route's (csr_from_edges -> graph_create), and the
+    adjacency it can hand back equals generate_adjacency_device's, element for element"""
+    from athena_amd import DeviceGraph
+    from athena_amd.graph import graph_type
+
+    rng = np.random.default_rng(n + pairs)
+    idx = rng.integers(1, n + 1, (2, pairs)).astype(np.int32) if pairs else np.zeros((2, 0), np.int32)
+    if pairs:
+        idx[1, idx[0] == idx[1]] = idx[1, idx[0] == idx[1]] % n + 1          # a few self pairs stay when n is tiny
+    old = os.environ.get("ATHENA_MP_GRAPH_BUILD")
+    if mode:
+        os.environ["ATHENA_MP_GRAPH_BUILD"] = mode
+    try:
+        g = graph_type()
+        g.num_vertices = n
+        g.generate_adjacency_device(idx, add_self_loops=loops)
+        two = DeviceGraph(g.adj_ia, g.adj_ja, n_edge_cols=pairs if edge_ids else 0)
+        one, ia, ja = DeviceGraph.from_edges(n, idx, add_self_loops=loops, with_edge_ids=edge_ids, want_adjacency=True)
+        lean = DeviceGraph.from_edges(n, idx, add_self_loops=loops, with_edge_ids=edge_ids)
+    finally:
+        if mode:
+            if old is None:
+                del os.environ["ATHENA_MP_GRAPH_BUILD"]
+            else:
+                os.environ["ATHENA_MP_GRAPH_BUILD"] = old
+    assert np.array_equal(ia, g.adj_ia) and np.array_equal(ja, g.adj_ja)
+    assert (one.n_rows, one.nnz, one.n_edge_cols) == (two.n_rows, two.nnz, two.n_edge_cols)
+    _same(one, two)
+    _same(lean, two)
