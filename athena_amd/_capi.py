@@ -43,6 +43,7 @@ _PROTOS = {
     "athena_mp_graph_dims": [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i32)],
     "athena_mp_kipf_propagate_fwd": [_vp, _i32, _vp, _vp],
     "athena_mp_kipf_propagate_bwd": [_vp, _i32, _vp, _vp, _i32],
+    "athena_mp_kipf_propagate_act_fwd": [_vp, _i32, _vp, _i32, _vp],
     "athena_mp_kipf_propagate_bwd_dual": [_vp, _i32, _vp, _vp, _vp],
     "athena_mp_kipf_propagate_fwd_dual": [_vp, _i32, _vp, _vp, _vp],
     "athena_mp_gather_rows": [_i64, _i32, _vp, _vp, _vp],

@@ -76,13 +76,23 @@ template <int VEC> __device__ __forceinline__ void vstore(float *__restrict__ p,
 constexpr int kBlock = 256;
 constexpr int kUnroll = 4;
 
+__device__ __forceinline__ float agg_act(float t, int act)
+{
+    switch (act) {
+    case ATHENA_MP_ACT_RELU: return t > 0.0f ? t : 0.0f;
+    case ATHENA_MP_ACT_SIGMOID: return 1.0f / (1.0f + expf(-t));
+    case ATHENA_MP_ACT_TANH: return tanhf(t);
+    default: return t;
+    }
+}
+
 // G lanes per row, VEC floats per lane, COEF: multiply by coef[w]; DUAL (with COEF): the rows are gathered once
 // and summed twice -- y = plain sum, y2 = coefficient-weighted sum (same leading dimension)
 template <int G, int VEC, bool COEF, bool DUAL = false>
 __global__ __launch_bounds__(kBlock) void csr_gather_agg(
     const int32_t *__restrict__ rowbeg, const int32_t *__restrict__ rowend, const int32_t *__restrict__ idx,
     const float *__restrict__ coef, const float *__restrict__ x, int64_t ldx, float *__restrict__ y,
-    int64_t ldy, int32_t n_rows, int32_t F, int32_t long_thr, float *__restrict__ y2)
+    int64_t ldy, int32_t n_rows, int32_t F, int32_t long_thr, float *__restrict__ y2, int32_t act)
 {
     constexpr int kRowsPerBlock = kBlock / G;
     const int gl = threadIdx.x & (G - 1);          // lane inside the group
@@ -155,6 +165,10 @@ __global__ __launch_bounds__(kBlock) void csr_gather_agg(
             }
         }
         if (live && fin) {
+            if (act != 0) {   // activation of the aggregated row (the dense step ran BEFORE the aggregation)
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc[i] = agg_act(acc[i], act);
+            }
             vstore<VEC>(y + (int64_t)row * ldy + f, acc);
             if constexpr (DUAL) vstore<VEC>(y2 + (int64_t)row * ldy + f, acc2);
         }
@@ -170,7 +184,7 @@ int launch_dual_gv(const int32_t *rowbeg, const int32_t *rowend, const int32_t *
     int nb = (n_rows + rpb - 1) / rpb;
     if (amp::agg_blocks_cap() > 0) nb = std::min(nb, amp::agg_blocks_cap());
     hipLaunchKernelGGL((csr_gather_agg<G, VEC, true, true>), dim3(nb), dim3(kBlock), 0, amp::stream(), rowbeg, rowend,
-                       idx, coef, x, ldx, y, ldy, n_rows, F, 0, y2);
+                       idx, coef, x, ldx, y, ldy, n_rows, F, 0, y2, 0);
     AMP_LAUNCH_CHECK();
     return 0;
 }
@@ -191,7 +205,7 @@ int launch_dual_v(int G, const int32_t *rowbeg, const int32_t *rowend, const int
 
 template <int G, int VEC>
 int launch_gv(bool has_coef, const int32_t *rowbeg, const int32_t *rowend, const int32_t *idx, const float *coef,
-              const float *x, int64_t ldx, float *y, int64_t ldy, int32_t n_rows, int32_t F, int32_t long_thr)
+              const float *x, int64_t ldx, float *y, int64_t ldy, int32_t n_rows, int32_t F, int32_t long_thr, int act)
 {
     constexpr int rpb = kBlock / G;
     int nb = (n_rows + rpb - 1) / rpb;
@@ -199,10 +213,10 @@ int launch_gv(bool has_coef, const int32_t *rowbeg, const int32_t *rowend, const
     dim3 grid(nb), block(kBlock);
     if (has_coef)
         hipLaunchKernelGGL((csr_gather_agg<G, VEC, true>), grid, block, 0, amp::stream(), rowbeg, rowend, idx, coef, x,
-                           ldx, y, ldy, n_rows, F, long_thr, (float *)nullptr);
+                           ldx, y, ldy, n_rows, F, long_thr, (float *)nullptr, act);
     else
         hipLaunchKernelGGL((csr_gather_agg<G, VEC, false>), grid, block, 0, amp::stream(), rowbeg, rowend, idx, coef,
-                           x, ldx, y, ldy, n_rows, F, long_thr, (float *)nullptr);
+                           x, ldx, y, ldy, n_rows, F, long_thr, (float *)nullptr, act);
     AMP_LAUNCH_CHECK();
     return 0;
 }
@@ -210,30 +224,30 @@ int launch_gv(bool has_coef, const int32_t *rowbeg, const int32_t *rowend, const
 template <int VEC>
 int launch_v(int G, bool has_coef, const int32_t *rowbeg, const int32_t *rowend, const int32_t *idx,
              const float *coef, const float *x, int64_t ldx, float *y, int64_t ldy, int32_t n_rows, int32_t F,
-             int32_t long_thr)
+             int32_t long_thr, int act)
 {
     switch (G) {
-    case 1: return launch_gv<1, VEC>(has_coef, rowbeg, rowend, idx, coef, x, ldx, y, ldy, n_rows, F, long_thr);
-    case 2: return launch_gv<2, VEC>(has_coef, rowbeg, rowend, idx, coef, x, ldx, y, ldy, n_rows, F, long_thr);
-    case 4: return launch_gv<4, VEC>(has_coef, rowbeg, rowend, idx, coef, x, ldx, y, ldy, n_rows, F, long_thr);
-    case 8: return launch_gv<8, VEC>(has_coef, rowbeg, rowend, idx, coef, x, ldx, y, ldy, n_rows, F, long_thr);
-    case 16: return launch_gv<16, VEC>(has_coef, rowbeg, rowend, idx, coef, x, ldx, y, ldy, n_rows, F, long_thr);
-    case 32: return launch_gv<32, VEC>(has_coef, rowbeg, rowend, idx, coef, x, ldx, y, ldy, n_rows, F, long_thr);
-    default: return launch_gv<64, VEC>(has_coef, rowbeg, rowend, idx, coef, x, ldx, y, ldy, n_rows, F, long_thr);
+    case 1: return launch_gv<1, VEC>(has_coef, rowbeg, rowend, idx, coef, x, ldx, y, ldy, n_rows, F, long_thr, act);
+    case 2: return launch_gv<2, VEC>(has_coef, rowbeg, rowend, idx, coef, x, ldx, y, ldy, n_rows, F, long_thr, act);
+    case 4: return launch_gv<4, VEC>(has_coef, rowbeg, rowend, idx, coef, x, ldx, y, ldy, n_rows, F, long_thr, act);
+    case 8: return launch_gv<8, VEC>(has_coef, rowbeg, rowend, idx, coef, x, ldx, y, ldy, n_rows, F, long_thr, act);
+    case 16: return launch_gv<16, VEC>(has_coef, rowbeg, rowend, idx, coef, x, ldx, y, ldy, n_rows, F, long_thr, act);
+    case 32: return launch_gv<32, VEC>(has_coef, rowbeg, rowend, idx, coef, x, ldx, y, ldy, n_rows, F, long_thr, act);
+    default: return launch_gv<64, VEC>(has_coef, rowbeg, rowend, idx, coef, x, ldx, y, ldy, n_rows, F, long_thr, act);
     }
 }
 
 // y[long row, :] = sum of its segment partials, in segment order
 __global__ void long_combine_kernel(const int32_t *__restrict__ row_id, const int32_t *__restrict__ row_task0,
                                     const float *__restrict__ partial, int64_t ldp, int32_t n_long, int32_t F,
-                                    float *__restrict__ y, int64_t ldy)
+                                    float *__restrict__ y, int64_t ldy, int32_t act)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (int64_t)n_long * F) return;
     const int r = (int)(t / F), f = (int)(t - (int64_t)r * F);
     float s = 0.0f;
     for (int k = row_task0[r]; k < row_task0[r + 1]; ++k) s = s + partial[(size_t)k * ldp + f];
-    y[(int64_t)row_id[r] * ldy + f] = s;
+    y[(int64_t)row_id[r] * ldy + f] = agg_act(s, act);
 }
 
 } // namespace
@@ -243,7 +257,7 @@ namespace amp {
 // Generic launcher used by every layer family.  x/y may be column slices of wider tensors
 // (ldx/ldy = leading dimension in floats).
 int gather_agg(const int32_t *rowptr, const int32_t *idx, const float *coef, const float *x, int64_t ldx,
-               float *y, int64_t ldy, int32_t n_rows, int32_t F, const LongPlan *lp)
+               float *y, int64_t ldy, int32_t n_rows, int32_t F, const LongPlan *lp, int act)
 {
     if (n_rows == 0 || F == 0) return 0;
     // widest vector the slices allow (16 B loads need 16 B aligned rows)
@@ -259,14 +273,14 @@ int gather_agg(const int32_t *rowptr, const int32_t *idx, const float *coef, con
     while (G < lanes && G < 64) G <<= 1;
     const bool has_coef = coef != nullptr;
     const bool hubs = lp && lp->n_long > 0;
-    auto run = [&](const int32_t *rb, const int32_t *re, float *out, int64_t ldo, int32_t rows, int32_t thr) {
+    auto run = [&](const int32_t *rb, const int32_t *re, float *out, int64_t ldo, int32_t rows, int32_t thr, int a) {
         switch (vec) {
-        case 4: return launch_v<4>(G, has_coef, rb, re, idx, coef, x, ldx, out, ldo, rows, F, thr);
-        case 2: return launch_v<2>(G, has_coef, rb, re, idx, coef, x, ldx, out, ldo, rows, F, thr);
-        default: return launch_v<1>(G, has_coef, rb, re, idx, coef, x, ldx, out, ldo, rows, F, thr);
+        case 4: return launch_v<4>(G, has_coef, rb, re, idx, coef, x, ldx, out, ldo, rows, F, thr, a);
+        case 2: return launch_v<2>(G, has_coef, rb, re, idx, coef, x, ldx, out, ldo, rows, F, thr, a);
+        default: return launch_v<1>(G, has_coef, rb, re, idx, coef, x, ldx, out, ldo, rows, F, thr, a);
         }
     };
-    int rc = run(rowptr, rowptr + 1, y, ldy, n_rows, hubs ? kLongRow : 0);
+    int rc = run(rowptr, rowptr + 1, y, ldy, n_rows, hubs ? kLongRow : 0, act);
     if (rc || !hubs) return rc;
     // hub rows: one lane group per kLongRow-entry segment into a partial buffer, then an ordered combine
     void *ws = nullptr;
@@ -276,13 +290,13 @@ int gather_agg(const int32_t *rowptr, const int32_t *idx, const float *coef, con
         // the partial buffer's leading dimension must satisfy the same vector alignment as y
         const int vec_saved = vec;
         if (Fp % vec != 0) vec = 1;
-        rc = run(lp->task_beg, lp->task_end, (float *)ws, Fp, lp->n_tasks, 0);
+        rc = run(lp->task_beg, lp->task_end, (float *)ws, Fp, lp->n_tasks, 0, 0);   // partial sums: no activation yet
         vec = vec_saved;
         if (rc) return rc;
     }
     const int64_t tot = (int64_t)lp->n_long * F;
     hipLaunchKernelGGL(long_combine_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream(), lp->row_id,
-                       lp->row_task0, (const float *)ws, Fp, lp->n_long, F, y, ldy);
+                       lp->row_task0, (const float *)ws, Fp, lp->n_long, F, y, ldy, act);
     AMP_LAUNCH_CHECK();
     return 0;
 }
@@ -324,6 +338,17 @@ int athena_mp_kipf_propagate_fwd(const athena_mp_graph *g, int32_t F, const floa
     if (g->n_rows == 0) return 0; // empty graph: nothing to do (pointers may be null)
     AMP_REQUIRE(x && y, "kipf_propagate_fwd: null tensor");
     return gather_agg(g->rowptr, g->col, g->coef, x, F, y, F, g->n_rows, F, &g->lp_fwd);
+}
+
+/* y = act( kipf_propagate(x) ): the activation of a time step whose dense step ran BEFORE the aggregation
+ * (Z = A^ (X W^T)) applied in the aggregation's store instead of a pass of its own */
+int athena_mp_kipf_propagate_act_fwd(const athena_mp_graph *g, int32_t F, const float *x, int32_t act, float *y)
+{
+    AMP_REQUIRE(g && F > 0, "kipf_propagate_act_fwd: bad arguments");
+    AMP_REQUIRE(act >= 0 && act <= ATHENA_MP_ACT_TANH, "kipf_propagate_act_fwd: unknown activation %d", act);
+    if (g->n_rows == 0) return 0;
+    AMP_REQUIRE(x && y, "kipf_propagate_act_fwd: null tensor");
+    return gather_agg(g->rowptr, g->col, g->coef, x, F, y, F, g->n_rows, F, &g->lp_fwd, act);
 }
 
 int athena_mp_kipf_propagate_bwd(const athena_mp_graph *g, int32_t F, const float *grad, float *dx,

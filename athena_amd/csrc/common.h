@@ -106,7 +106,7 @@ int agg_blocks_cap();
 void set_agg_blocks_cap(int n);
 // shared launchers (defined in agg.hip / gemm.hip)
 int gather_agg(const int32_t *rowptr, const int32_t *idx, const float *coef, const float *x, int64_t ldx,
-               float *y, int64_t ldy, int32_t n_rows, int32_t F, const LongPlan *lp = nullptr);
+               float *y, int64_t ldy, int32_t n_rows, int32_t F, const LongPlan *lp = nullptr, int act = 0);
 int gather_agg_dual(const int32_t *rowptr, const int32_t *idx, const float *coef, const float *x, float *y, float *y2,
                     int32_t n_rows, int32_t F, const LongPlan *lp);
 // Z[M,N] = act(A[M,K] . B + bias); b_nk: B stored [N][K] instead of [K][N]

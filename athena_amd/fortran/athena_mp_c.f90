@@ -26,6 +26,7 @@ module athena_mp_c
   public :: athena_mp_concat_fwd, athena_mp_concat_bwd
   public :: athena_mp_activation_param_fwd, athena_mp_activation_param_bwd
   public :: athena_mp_memset_zero, athena_mp_activation_fwd, athena_mp_axpy, athena_mp_kipf_propagate_bwd_dual
+  public :: athena_mp_kipf_propagate_act_fwd
   public :: athena_mp_duvenaud_propagate_fwd, athena_mp_duvenaud_propagate_bwd_x, athena_mp_duvenaud_propagate_bwd_e
   public :: athena_mp_duvenaud_update_bwd_a, athena_mp_duvenaud_update_bwd_w
   public :: athena_mp_segment_sum, athena_mp_segment_sum_bwd
@@ -369,6 +370,12 @@ module athena_mp_c
        integer(c_int64_t), value :: n
        real(c_float), value :: alpha
        type(c_ptr), value :: x_dev, y_dev
+     end function
+     integer(c_int) function athena_mp_kipf_propagate_act_fwd(graph, F, x_dev, act, y_dev) &
+          bind(C, name="athena_mp_kipf_propagate_act_fwd")
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: graph, x_dev, y_dev
+       integer(c_int32_t), value :: F, act
      end function
      integer(c_int) function athena_mp_kipf_propagate_bwd_dual(graph, F, g_dev, dx_plain_dev, dx_coef_dev) &
           bind(C, name="athena_mp_kipf_propagate_bwd_dual")

@@ -624,8 +624,10 @@ contains
           call copy_dev(this%tape_p(t)%p, cur, i8(n) * i8(fi))
           call chk(athena_mp_gemm_fwd(i8(n), int(fi, c_int32_t), int(fo, c_int32_t), cur, this%params(t)%p, c_null_ptr, &
                ATHENA_MP_ACT_NONE, this%scratch(1)%p), "gemm_fwd")
-          if(is_identity(this%activation))then
-             call chk(athena_mp_kipf_propagate_fwd(this%graph, int(fo, c_int32_t), this%scratch(1)%p, this%tape_y(t)%p), "propagate")
+          if(code .ge. 0)then
+             ! plain activation: applied in the aggregation's store
+             call chk(athena_mp_kipf_propagate_act_fwd(this%graph, int(fo, c_int32_t), this%scratch(1)%p, code, &
+                  this%tape_y(t)%p), "propagate")
           else
              call chk(athena_mp_kipf_propagate_fwd(this%graph, int(fo, c_int32_t), this%scratch(1)%p, this%tape_z(t)%p), "propagate")
              call act_apply(this%activation, n, fo, this%tape_z(t)%p, this%tape_y(t)%p)

@@ -217,8 +217,12 @@ class kipf_msgpass_layer_type(msgpass_layer_type):
             if self._transform_first(t):
                 # dense step first: the gather then moves F_t-wide rows instead of F_{t-1}-wide ones
                 y = ops.matmul(self.params[t - 1], cur, self.num_vertex_features[t])
-                z = ops.kipf_propagate(g, y)
-                nxt = ops.activation(self.activation, z) if not _identity(self.activation) else z
+                if _fusable(self.activation):     # plain activation: in the aggregation's store
+                    z = None
+                    nxt = ops.kipf_propagate_act(g, y, act=self.activation)
+                else:
+                    z = ops.kipf_propagate(g, y)
+                    nxt = ops.activation(self.activation, z)
                 self._tape.append((cur, nxt, z if ops.needs_input(self.activation) else None))
                 cur = nxt
                 continue

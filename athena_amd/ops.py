@@ -44,6 +44,16 @@ def kipf_propagate(g: DeviceGraph, x, out=None):
     return y
 
 
+def kipf_propagate_act(g: DeviceGraph, x, act="none", out=None):
+    """act(kipf_propagate(x)) in one launch (act in ops.ACT) -- the step of a layer that runs its dense step first"""
+    F = x.shape[1]
+    _chk(x, (g.n_cols, F))
+    y = out if out is not None else torch.empty((g.n_rows, F), device=x.device, dtype=torch.float32)
+    _go()
+    _capi.call("athena_mp_kipf_propagate_act_fwd", g.handle, F, _p(x), ACT[act], _p(_chk(y, (g.n_rows, F))))
+    return y
+
+
 def kipf_propagate_bwd(g: DeviceGraph, grad, exact=False, out=None):
     """get_partial_kipf_propagate_left_val, ..._sub_kipf.f90:85-111 (exact=False: no coefficient)"""
     F = grad.shape[1]

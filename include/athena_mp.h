@@ -102,6 +102,9 @@ int athena_mp_graph_dims(const athena_mp_graph *g, int32_t *n_rows, int32_t *n_c
 /* kipf_propagate, athena_diffstruc_extd_sub_kipf.f90:7-59
  *   y[v,:] = sum_w ((deg_v*deg_u)^-1/2) x[u,:]        x [n_cols,F], y [n_rows,F] */
 int athena_mp_kipf_propagate_fwd(const athena_mp_graph *g, int32_t F, const float *x_dev, float *y_dev);
+/* y = act(kipf_propagate(x)), act in {none, relu, sigmoid, tanh}: the activation of a time step whose dense step ran
+ * before the aggregation, applied in the aggregation's store */
+int athena_mp_kipf_propagate_act_fwd(const athena_mp_graph *g, int32_t F, const float *x_dev, int32_t act, float *y_dev);
 /* get_partial_kipf_propagate_left_val, ..._sub_kipf.f90:85-111
  *   dx[u,:] = sum_{(v,w): ja(1,w)=u} grad[v,:]   (exact=0: the reference, NO coefficient;
  *   exact=1: multiplied by the coefficient, the mathematically exact adjoint) */

@@ -149,6 +149,29 @@ def test_kipf_reverse_both_forms_from_one_gather(dev, oracle, F):
             assert np.array_equal(H(plain), po) and np.array_equal(H(coef), co)
 
 
+@pytest.mark.parametrize("act", ["none", "relu", "sigmoid", "tanh"])
+@pytest.mark.parametrize("F", [5, 32, 64])
+def test_kipf_propagate_with_the_activation_in_its_store(dev, oracle, act, F):
+    """athena_mp_kipf_propagate_act_fwd = activation(kipf_propagate(x)) in one launch, hub rows (segment plan +
+    ordered combine) included: equal to the two launches bit for bit"""
+    from athena_amd import DeviceGraph, ops
+
+    rng = np.random.default_rng(F)
+    n = 1200
+    deg = rng.integers(0, 9, n)
+    deg[[3, 700]] = [900, 1300]
+    ia = np.concatenate([[1], 1 + np.cumsum(deg)]).astype(np.int32)
+    ja = np.zeros((2, int(deg.sum())), np.int32, order="F")
+    ja[0] = rng.integers(1, n + 1, ja.shape[1])
+    g = DeviceGraph(ia, ja, n_edge_cols=0, row_deg=(deg + 1).astype(np.int32), col_deg=rng.integers(1, 9, n).astype(np.int32))
+    x = T(rng.uniform(-1, 1, (n, F)).astype(np.float32), dev)
+    one = ops.kipf_propagate_act(g, x, act=act)
+    two = ops.kipf_propagate(g, x)
+    if act != "none":
+        two = ops.activation(act, two)
+    assert torch.equal(one, two)
+
+
 def test_kipf_rectangular_block_with_explicit_degrees(dev, oracle):
     """row partition with halo columns: degrees supplied (the multi-GPU shard shape)"""
     from athena_amd import DeviceGraph, ops
