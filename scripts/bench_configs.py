@@ -1,5 +1,7 @@
 """Secondary measurements (not the bench.py contract): BASELINE configs[2] (Duvenaud, QM9-shaped batch)
-and configs[3] (GNO on a 3-D radius graph).  Prints per-op HIP-event times and fwd+bwd entries/s."""
+and configs[3] (GNO on a 3-D radius graph).  Prints per-op HIP-event times and fwd+bwd entries/s.
+The CPU leg (`cpu_baseline`, skipped with --no-cpu) times the oracle beside the GPU exactly as bench.py's
+cpu_baseline leg does for configs[1]: the oracle is the thing COMPARED WITH here, never part of the measured path."""
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
