@@ -211,3 +211,43 @@ def test_fortran_kipf_layers_chained_on_the_device(dev, tmp_path, a1, a2, dims):
     assert_close(r.matrix(), np.concatenate(g0), 2e-5, "chained dx")
     assert_close(r.vector(), gr1[0], 2e-5, "dW of the first layer")
     assert_close(r.vector(), gr2[0], 2e-5, "dW of the second layer")
+
+
+def test_fortran_layers_with_an_edgeless_graph_in_the_batch(dev, tmp_path):
+    """a batch whose middle graph has vertices but no edges (and one single-vertex graph): empty CSR rows, zero
+    edge-feature columns of its own -- Duvenaud through the Fortran layer and through the Python mirror, both against
+    the oracle"""
+    from athena_amd.layers import duvenaud_msgpass_layer_type
+
+    rng = np.random.default_rng(91)
+    gs = _graphs(rng, [7, 12], self_loops=False)
+    lonely = csr_from_index_list(3, np.zeros((2, 0), np.int64), self_loops=False)
+    single = csr_from_index_list(1, np.zeros((2, 0), np.int64), self_loops=False)
+    gs = [gs[0], lonely, gs[1], single]
+    Fv, Fe, T, D, nout = 5, 2, 2, 4, 3
+    nvf = [Fv] * (T + 1)
+    plist = [(rng.standard_normal(nvf[t] * (nvf[t - 1] + Fe) * D) * 0.3).astype(np.float32) for t in range(1, T + 1)]
+    plist += [(rng.standard_normal(nout * nvf[t]) * 0.3).astype(np.float32) for t in range(1, T + 1)]
+    xs = [rng.uniform(0, 1, (g.num_vertices, Fv)).astype(np.float32) for g in gs]
+    es = [rng.uniform(0, 1, (g.num_edges, Fe)).astype(np.float32) for g in gs]
+    act, act_r = _actv("sigmoid"), _actv("softmax")
+    outs, tapes = ol.duvenaud_forward(gs, xs, es, plist, nvf, Fe, 1, D, nout, "sigmoid")
+    up = rng.uniform(-1, 1, outs.shape).astype(np.float32)
+    dxs, des, grads = ol.duvenaud_backward(gs, es, tapes, plist, nvf, Fe, 1, D, nout, "sigmoid", up)
+    blob = _case_header(2, gs) + _i(T, Fv, Fe, 1, D, nout) + _act_bytes(act) + _act_bytes(act_r)
+    blob += _i(sum(p.size for p in plist)) + np.concatenate(plist).tobytes()
+    blob += _mat(np.concatenate(xs)) + _mat(np.concatenate(es)) + _mat(up)
+    r = _run(tmp_path, blob)
+    assert_close(r.matrix(), outs, 1e-5, "fortran forward")
+    assert_close(r.matrix(), np.concatenate(dxs), 2e-5, "fortran dx")
+    assert_close(r.matrix(), np.concatenate(des), 2e-5, "fortran de")
+    assert_close(r.vector(), np.concatenate(grads), 2e-5, "fortran gradients")
+    layer = duvenaud_msgpass_layer_type(num_vertex_features=[Fv], num_edge_features=[Fe], num_time_steps=T,
+                                        max_vertex_degree=D, num_outputs=nout, min_vertex_degree=1, seed=1)
+    layer.set_params(np.concatenate(plist))
+    layer.set_graph(gs)
+    assert_close(layer.forward(xs, es).cpu().numpy(), outs, 1e-5, "python forward")
+    dx, de = layer.backward(up, need_edge_grad=True)
+    assert_close(dx.cpu().numpy(), np.concatenate(dxs), 2e-5, "python dx")
+    assert_close(de.cpu().numpy(), np.concatenate(des), 2e-5, "python de")
+    assert_close(layer.get_gradients(), np.concatenate(grads), 2e-5, "python gradients")
