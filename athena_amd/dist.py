@@ -266,7 +266,8 @@ class KipfShardStep:
     def __init__(self, shard, F, device, backend=None, seed=1, exact=False, Fo=None, order="auto"):
         self.s, self.F, self.device = shard, F, device
         self.Fo = Fo = F if Fo is None else int(Fo)
-        assert order in ("auto", "aggregate_first", "transform_first")
+        if not (order in ("auto", "aggregate_first", "transform_first")):
+            raise ValueError('expected: order in ("auto", "aggregate_first", "transform_first")')
         self.transform_first = order == "transform_first" or (order == "auto" and 4 * Fo <= 3 * F)
         self.b = backend or HipBackend(device)
         n, nh = shard.n, shard.n_halo

@@ -50,7 +50,8 @@ class graph_type:
         entries are ordered by edge id (graphstruc's internal order is not visible from the
         reference and only affects fp32 summation order)."""
         idx = np.asarray(index_list, dtype=np.int64)
-        assert idx.ndim == 2 and idx.shape[0] == 2
+        if not (idx.ndim == 2 and idx.shape[0] == 2):
+            raise ValueError('expected: idx.ndim == 2 and idx.shape[0] == 2')
         E = idx.shape[1]
         if self.num_edges == 0:
             self.num_edges = E
@@ -67,7 +68,8 @@ class graph_type:
         """generate_adjacency (+ add_self_loops) on the GPU: same arrays as the host methods, built by one radix sort
         (athena_mp_csr_from_edges); for edge lists of millions of pairs"""
         idx = np.asfortranarray(np.asarray(index_list, dtype=np.int32))
-        assert idx.ndim == 2 and idx.shape[0] == 2
+        if not (idx.ndim == 2 and idx.shape[0] == 2):
+            raise ValueError('expected: idx.ndim == 2 and idx.shape[0] == 2')
         E = idx.shape[1]
         if self.num_edges == 0:
             self.num_edges = E
@@ -130,7 +132,8 @@ class DeviceGraph:
         _capi.init(device)
         ia = np.ascontiguousarray(adj_ia, np.int32)
         ja = np.asfortranarray(adj_ja, np.int32)
-        assert ja.ndim == 2 and ja.shape[0] == 2, "adj_ja must be [2, nnz]"
+        if not (ja.ndim == 2 and ja.shape[0] == 2):
+            raise ValueError("adj_ja must be [2, nnz]")
         self.n_rows = ia.size - 1
         self.n_cols = self.n_rows if n_cols is None else int(n_cols)
         self.nnz = int(ja.shape[1])
@@ -144,7 +147,8 @@ class DeviceGraph:
         if row_deg is not None:
             rd = np.ascontiguousarray(row_deg, np.int32)
             cd = np.ascontiguousarray(col_deg, np.int32)
-            assert rd.size == self.n_rows and cd.size == self.n_cols
+            if not (rd.size == self.n_rows and cd.size == self.n_cols):
+                raise ValueError('expected: rd.size == self.n_rows and cd.size == self.n_cols')
         h = C.c_void_p()
         _capi.call(
             "athena_mp_graph_create", self.n_rows, self.n_cols, self.nnz,
@@ -174,7 +178,8 @@ class DeviceGraph:
         (handle, adj_ia, adj_ja) with want_adjacency (adj_ia is produced either way)."""
         _capi.init(device)
         idx = np.asfortranarray(np.asarray(index_list, dtype=np.int32))
-        assert idx.ndim == 2 and idx.shape[0] == 2
+        if not (idx.ndim == 2 and idx.shape[0] == 2):
+            raise ValueError('expected: idx.ndim == 2 and idx.shape[0] == 2')
         n, E = int(num_vertices), idx.shape[1]
         self = cls.__new__(cls)
         ia = np.empty(n + 1, np.int32)

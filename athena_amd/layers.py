@@ -192,7 +192,8 @@ class kipf_msgpass_layer_type(msgpass_layer_type):
         A Y: the aggregation runs on F_out-wide rows) or "auto" (transform first when 4 F_out <= 3 F_in).
         Same result up to fp32 summation order."""
         super().__init__(device, seed)
-        assert order in ("auto", "aggregate_first", "transform_first")
+        if not (order in ("auto", "aggregate_first", "transform_first")):
+            raise ValueError('expected: order in ("auto", "aggregate_first", "transform_first")')
         self.order = order
         self.num_time_steps = int(num_time_steps)
         self.num_vertex_features = _expand(num_vertex_features, self.num_time_steps, "num_vertex_features")
@@ -210,7 +211,8 @@ class kipf_msgpass_layer_type(msgpass_layer_type):
     def update_message(self, x, e=None):
         """athena_kipf_msgpass_layer.f90:915-959: X_t = act(W_t . kipf_propagate(X_{t-1}))"""
         g = self.graph.device
-        assert x.shape == (g.n_cols, self.num_vertex_features[0]), "vertex feature shape mismatch"
+        if not (x.shape == (g.n_cols, self.num_vertex_features[0])):
+            raise ValueError("vertex feature shape mismatch")
         self._tape = []
         cur = x
         for t in range(1, self.num_time_steps + 1):
@@ -313,7 +315,8 @@ class duvenaud_msgpass_layer_type(msgpass_layer_type):
         """athena_duvenaud_msgpass_layer.f90:755-817"""
         g = self.graph.device
         T = self.num_time_steps
-        assert e is not None and e.shape[0] == g.n_edge_cols, "edge feature shape mismatch"
+        if not (e is not None and e.shape[0] == g.n_edge_cols):
+            raise ValueError("edge feature shape mismatch")
         self._e = e
         self._a, self.z, self._c = [], [], []
         cur = x
@@ -355,7 +358,8 @@ class duvenaud_msgpass_layer_type(msgpass_layer_type):
         g = self.graph.device
         T = self.num_time_steps
         gout = self._t(upstream)
-        assert gout.shape == (self.graph.batch, self.num_outputs)
+        if not (gout.shape == (self.graph.batch, self.num_outputs)):
+            raise ValueError('expected: gout.shape == (self.graph.batch, self.num_outputs)')
         dz_next = None
         de = None
         dx = None
@@ -438,7 +442,8 @@ class graph_nop_layer_type(msgpass_layer_type):
         Fi, Fo = self.num_vertex_features
         if coords is None:
             raise RuntimeError("graph_nop layer expects vertex and edge feature inputs")   # :725-728
-        assert x.shape == (g.n_cols, Fi) and coords.shape == (g.n_edge_cols, self.coord_dim)
+        if not (x.shape == (g.n_cols, Fi) and coords.shape == (g.n_edge_cols, self.coord_dim)):
+            raise ValueError('expected: x.shape == (g.n_cols, Fi) and coords.shape == (g.n_edge_cols, self.coord_dim)')
         self._x, self._coords = x, coords
         m = ops.gno_aggregate(g, self.params[0], coords, x, self.coord_dim, self.kernel_hidden, Fo)   # steps 1+2
         z = ops.matmul(self.params[1], x, Fo, bias=self.params[2] if self.use_bias else None)          # steps 3+5
@@ -512,7 +517,8 @@ class full_layer_type(msgpass_layer_type):
         x = self._cat(x)
         if self.num_inputs is None:
             self._init(int(x.shape[1]))
-        assert x.dim() == 2 and x.shape[1] == self.num_inputs, "full layer: input width mismatch"
+        if not (x.dim() == 2 and x.shape[1] == self.num_inputs):
+            raise ValueError("full layer: input width mismatch")
         self._x = x
         b = self.params[1] if self.use_bias else None
         if _fusable(self.activation):

@@ -22,9 +22,11 @@ def _p(t):
 
 
 def _chk(t, shape=None, dtype=torch.float32):
-    assert t.is_cuda and t.dtype == dtype and t.is_contiguous(), "expect contiguous device tensor"
+    if not (t.is_cuda and t.dtype == dtype and t.is_contiguous()):
+        raise ValueError("expect contiguous device tensor")
     if shape is not None:
-        assert tuple(t.shape) == tuple(shape), f"shape {tuple(t.shape)} != {tuple(shape)}"
+        if not (tuple(t.shape) == tuple(shape)):
+            raise ValueError(f"shape {tuple(t.shape)} != {tuple(shape)}")
     return t
 
 
@@ -116,7 +118,8 @@ def matmul(W, P, Fo, bias=None, act="none", out=None):
     """Z[N,Fo] = act(P[N,Fi] . Wt + bias);  W flat params%val(:,1) = W(Fo,Fi) column-major."""
     N, Fi = P.shape
     _chk(P)
-    assert W.numel() == Fo * Fi
+    if not (W.numel() == Fo * Fi):
+        raise ValueError('expected: W.numel() == Fo * Fi')
     Z = out if out is not None else torch.empty((N, Fo), device=P.device, dtype=torch.float32)
     _go()
     _capi.call("athena_mp_gemm_fwd", N, Fi, Fo, _p(P), _p(_chk(W)), _p(bias), ACT[act], _p(Z))
@@ -138,7 +141,8 @@ def matmul_dx(W, dZ, Fi, out=None):
     """dP[N,Fi] = dZ[N,Fo] . W"""
     N, Fo = dZ.shape
     _chk(dZ)
-    assert W.numel() == Fo * Fi
+    if not (W.numel() == Fo * Fi):
+        raise ValueError('expected: W.numel() == Fo * Fi')
     dP = out if out is not None else torch.empty((N, Fi), device=dZ.device, dtype=torch.float32)
     _go()
     _capi.call("athena_mp_gemm_dx", N, Fi, Fo, _p(dZ), _p(_chk(W)), _p(dP))
@@ -254,7 +258,8 @@ def activation(kind, z, out=None, beta=1.0):
         code, scale, p0, p1 = _actp_args(kind)
         _capi.call("athena_mp_activation_param_fwd", code, z.numel(), scale, p0, p1, _p(_chk(z)), _p(y))
     elif kind == "softmax":
-        assert z.dim() == 2
+        if not (z.dim() == 2):
+            raise ValueError('expected: z.dim() == 2')
         _capi.call("athena_mp_softmax_fwd", z.shape[0], z.shape[1], _p(_chk(z)), _p(y))
     elif kind == "swish":
         _capi.call("athena_mp_swish_fwd", z.numel(), float(beta), _p(_chk(z)), _p(y))
@@ -276,7 +281,8 @@ def activation_bwd(kind, y, g, out=None, z=None, beta=1.0):
         code, scale, p0, p1 = _actp_args(kind)
         _capi.call("athena_mp_activation_param_bwd", code, z.numel(), scale, p0, p1, _p(_chk(z)), _p(_chk(g)), _p(dz))
     elif kind == "softmax":
-        assert y.dim() == 2
+        if not (y.dim() == 2):
+            raise ValueError('expected: y.dim() == 2')
         _capi.call("athena_mp_softmax_bwd", y.shape[0], y.shape[1], _p(_chk(y)), _p(_chk(g)), _p(dz))
     elif kind == "swish":
         if z is None:
@@ -290,7 +296,8 @@ def activation_bwd(kind, y, g, out=None, z=None, beta=1.0):
 def concat_features(a, b):
     """'concatenate' merge of two layer inputs: out[v] = [a[v], b[v]]"""
     _chk(a); _chk(b)
-    assert a.shape[0] == b.shape[0]
+    if not (a.shape[0] == b.shape[0]):
+        raise ValueError('expected: a.shape[0] == b.shape[0]')
     out = torch.empty((a.shape[0], a.shape[1] + b.shape[1]), device=a.device, dtype=torch.float32)
     _go()
     _capi.call("athena_mp_concat_fwd", a.shape[0], a.shape[1], b.shape[1], _p(a), _p(b), _p(out))
@@ -347,7 +354,8 @@ def duvenaud_update(g: DeviceGraph, a, weight, min_deg, max_deg, Fo):
     """athena_diffstruc_extd_sub_duvenaud.f90:176-228"""
     Fi = a.shape[1]
     _chk(a, (g.n_rows, Fi))
-    assert weight.numel() == Fo * Fi * (max_deg - min_deg + 1)
+    if not (weight.numel() == Fo * Fi * (max_deg - min_deg + 1)):
+        raise ValueError('expected: weight.numel() == Fo * Fi * (max_deg - min_deg + 1)')
     c = torch.empty((g.n_rows, Fo), device=a.device, dtype=torch.float32)
     _go()
     _capi.call("athena_mp_duvenaud_update_fwd", g.handle, Fi, Fo, min_deg, max_deg, _p(a), _p(_chk(weight)), _p(c))
@@ -358,7 +366,8 @@ def duvenaud_update_act(g: DeviceGraph, a, weight, min_deg, max_deg, Fo, act="no
     """z = act(duvenaud_update(a)) with the activation in the kernel epilogue"""
     Fi = a.shape[1]
     _chk(a, (g.n_rows, Fi))
-    assert weight.numel() == Fo * Fi * (max_deg - min_deg + 1)
+    if not (weight.numel() == Fo * Fi * (max_deg - min_deg + 1)):
+        raise ValueError('expected: weight.numel() == Fo * Fi * (max_deg - min_deg + 1)')
     z = torch.empty((g.n_rows, Fo), device=a.device, dtype=torch.float32)
     _go()
     _capi.call("athena_mp_duvenaud_update_act_fwd", g.handle, Fi, Fo, min_deg, max_deg, _p(a), _p(_chk(weight)), ACT[act], _p(z))
@@ -434,7 +443,8 @@ def duvenaud_readout(R, z, seg, O, out=None):
     N, Fv = z.shape
     S = seg.numel() - 1
     _chk(z); _chk(seg, dtype=torch.int32); _chk(R)
-    assert R.numel() == O * Fv
+    if not (R.numel() == O * Fv):
+        raise ValueError('expected: R.numel() == O * Fv')
     p = torch.empty((N, O), device=z.device, dtype=torch.float32)
     acc = out is not None
     if out is None:
@@ -466,7 +476,8 @@ def gno_aggregate(g: DeviceGraph, theta, coords, x, d, H, Fo):
     """gno_kernel_eval + gno_aggregate (athena_diffstruc_extd_sub_nop.f90:26-115, :330-397) fused"""
     Fi = x.shape[1]
     _chk(x, (g.n_cols, Fi)); _chk(coords); _chk(theta)
-    assert theta.numel() == H * d + H + Fo * Fi * H + Fo * Fi
+    if not (theta.numel() == H * d + H + Fo * Fi * H + Fo * Fi):
+        raise ValueError('expected: theta.numel() == H * d + H + Fo * Fi * H + Fo * Fi')
     m = torch.empty((g.n_rows, Fo), device=x.device, dtype=torch.float32)
     _go()
     _capi.call("athena_mp_gno_aggregate_fwd", g.handle, d, H, Fi, Fo, _p(theta), _p(coords), _p(x), _p(m))
