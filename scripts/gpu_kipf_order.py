@@ -23,7 +23,7 @@ def timeit(fn, reps=20):
     return a.elapsed_time(b) / reps
 
 
-for Fi, Fo in ((128, 128), (128, 96), (128, 64), (128, 32), (256, 64), (64, 16)):
+for Fi, Fo in ((128, 128), (128, 96), (128, 64), (128, 32), (256, 64), (64, 16), (64, 64), (64, 128), (32, 128)):
     x = torch.rand((n, Fi), device=dev) - 0.5
     w = (torch.rand(Fo * Fi, device=dev) - 0.5) * 0.2
     dz = torch.rand((n, Fo), device=dev) - 0.5
