@@ -64,6 +64,7 @@ module athena_mp_layers
      integer :: num_tensors = 0
      integer, allocatable :: psize(:)                  ! size of params(i)%val(:,1)
      type(dbuf), allocatable :: params(:), grads(:)
+     type(dbuf), allocatable :: adam_m(:), adam_v(:)   ! created by minimise_adam
      logical, allocatable :: has_grad(:)
    contains
      procedure, pass(this) :: set_graph => layer_set_graph
@@ -74,6 +75,8 @@ module athena_mp_layers
      procedure, pass(this) :: get_gradients => layer_get_gradients
      procedure, pass(this) :: alloc_params => layer_alloc_params
      procedure, pass(this) :: release_base => layer_release_base
+     procedure, pass(this) :: minimise_base => layer_minimise_base
+     procedure, pass(this) :: minimise_adam => layer_minimise_adam
   end type mp_layer_type
 
   type, extends(mp_layer_type) :: kipf_mp_layer_type
@@ -501,6 +504,51 @@ contains
     end do
   end function layer_get_gradients
 
+  subroutine layer_minimise_base(this, learning_rate)
+    !! base_optimiser_type%minimise (athena_optimiser.f90:396-418) on the resident tensors: param = param - lr * gradient,
+    !! then the gradients count as reset (network%update, athena_network_sub.f90:2816-2929)
+    class(mp_layer_type), intent(inout) :: this
+    real(real32), intent(in) :: learning_rate
+    integer :: i
+    do i = 1, this%num_tensors
+       if(.not. this%has_grad(i)) call stop_program("Gradient not allocated for parameters")       ! :2857-2861
+       call chk(athena_mp_axpy(i8(this%psize(i)), -learning_rate, this%grads(i)%p, this%params(i)%p), "axpy")
+       this%has_grad(i) = .false.
+    end do
+  end subroutine layer_minimise_base
+
+  subroutine layer_minimise_adam(this, learning_rate, iter, beta1, beta2, epsilon)
+    !! adam_optimiser_type%minimise (athena_optimiser.f90:1027-1091, no regulariser) per parameter tensor; the moment
+    !! vectors live beside the parameters and are created (zero) on first use; iter = optimiser%iter after its increment
+    class(mp_layer_type), intent(inout) :: this
+    real(real32), intent(in) :: learning_rate
+    integer, intent(in) :: iter
+    real(real32), intent(in), optional :: beta1, beta2, epsilon
+    real(real32) :: b1, b2, eps
+    integer :: i
+
+    b1 = 0.9_real32; b2 = 0.999_real32; eps = 1.e-8_real32
+    if(present(beta1)) b1 = beta1
+    if(present(beta2)) b2 = beta2
+    if(present(epsilon)) eps = epsilon
+    if(.not. allocated(this%adam_m))then
+       allocate(this%adam_m(this%num_tensors), this%adam_v(this%num_tensors))
+       do i = 1, this%num_tensors
+          call need(this%adam_m(i), i8(this%psize(i)))
+          call need(this%adam_v(i), i8(this%psize(i)))
+          call chk(athena_mp_memset_zero(this%adam_m(i)%p, 4_c_int64_t * i8(this%psize(i))), "memset")
+          call chk(athena_mp_memset_zero(this%adam_v(i)%p, 4_c_int64_t * i8(this%psize(i))), "memset")
+       end do
+    end if
+    do i = 1, this%num_tensors
+       if(.not. this%has_grad(i)) call stop_program("Gradient not allocated for parameters")
+       call chk(athena_mp_adam_step(i8(this%psize(i)), learning_rate, b1, b2, eps, int(iter, c_int32_t), 0_c_int32_t, &
+            0._real32, 0._real32, 0_c_int32_t, this%params(i)%p, this%grads(i)%p, this%adam_m(i)%p, this%adam_v(i)%p), &
+            "adam_step")
+       this%has_grad(i) = .false.
+    end do
+  end subroutine layer_minimise_adam
+
   subroutine layer_release_base(this)
     class(mp_layer_type), intent(inout) :: this
     integer :: i
@@ -510,6 +558,10 @@ contains
     do i = 1, this%num_tensors
        call release(this%params(i))
        call release(this%grads(i))
+       if(allocated(this%adam_m))then
+          call release(this%adam_m(i))
+          call release(this%adam_v(i))
+       end if
     end do
   end subroutine layer_release_base
 

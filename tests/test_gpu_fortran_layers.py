@@ -251,3 +251,17 @@ def test_fortran_layers_with_an_edgeless_graph_in_the_batch(dev, tmp_path):
     assert_close(dx.cpu().numpy(), np.concatenate(dxs), 2e-5, "python dx")
     assert_close(de.cpu().numpy(), np.concatenate(des), 2e-5, "python de")
     assert_close(layer.get_gradients(), np.concatenate(grads), 2e-5, "python gradients")
+
+
+def test_fortran_gno_regression_example(dev):
+    """athena_amd/fortran/example_gno_regression.f90: the reference's example/gno_regression driven from Fortran with
+    the layers chained on the device, athena_mp_mse_loss and minimise_base -- 200 epochs, the loss falls from O(1) to
+    the plateau the tiny model reaches (exit status 0 = below a tenth of the first value)"""
+    exe = os.path.join(ROOT, "athena_amd", "fortran", "example_gno_regression")
+    if not os.path.exists(exe):
+        pytest.fail("example_gno_regression is not built: __graft_entry__.build() compiles the Fortran host side")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "Number of parameters: 282" in " ".join(r.stdout.split())
+    final = float(r.stdout.split("Final loss:")[1].split()[0])
+    assert 0.0 < final < 0.5
