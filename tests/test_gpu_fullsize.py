@@ -83,6 +83,32 @@ def test_c2_dense_steps_vs_float64_sample(dev, c2):
     assert np.abs(dW - ref).max() <= 1e-5 * np.abs(ref).max()
 
 
+def test_c2_narrowing_step_both_associations_agree_at_full_size(dev, c2):
+    """a 128 -> 64 step on the full C2 graph: Z = W (A^ X) against Z = A^ (X W^T) and the reverse passes built on
+    each (dual gather: one pass, plain + coefficient sums) -- 1e-5 relative, plus the dual kernel's two outputs
+    bit-equal to their own launches at this size"""
+    from athena_amd import ops
+
+    g, N, Fi, Fo = c2["g"], c2["N"], c2["F"], 64
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy(c2["x"]).to(dev)
+    w = torch.from_numpy((rng.standard_normal(Fo * Fi) * np.sqrt(2.0 / Fi)).astype(np.float32)).to(dev)
+    dz = torch.from_numpy(rng.uniform(-1, 1, (N, Fo)).astype(np.float32)).to(dev)
+    p, z_a = ops.kipf_layer_fwd(g, x, w, Fo)
+    z_t = ops.kipf_propagate(g, ops.matmul(w, x, Fo))
+    assert (z_a - z_t).abs().max().item() <= 1e-5 * z_a.abs().max().item()
+    dw_a = ops.matmul_dw(p, dz)
+    dx_a = ops.kipf_layer_bwd_x(g, dz, w, Fi)
+    qp, qc = ops.kipf_propagate_bwd_dual(g, dz)
+    assert torch.equal(qp, ops.kipf_propagate_bwd(g, dz)) and torch.equal(qc, ops.kipf_propagate_bwd(g, dz, exact=True))
+    dw_t = ops.matmul_dw(x, qc)
+    dx_t = ops.matmul_dx(w, qp, Fi)
+    assert (dw_a - dw_t).abs().max().item() <= 1e-5 * dw_a.abs().max().item()
+    assert (dx_a - dx_t).abs().max().item() <= 1e-5 * dx_a.abs().max().item()
+    # the activation in the aggregation's store equals the separate pass
+    assert torch.equal(ops.kipf_propagate_act(g, z_t, act="relu"), ops.activation("relu", ops.kipf_propagate(g, z_t)))
+
+
 # ---- BASELINE configs[2]: Duvenaud, ~130k QM9-shaped graphs (perf dims F_v=64, F_e=8) ----------------
 @pytest.fixture(scope="module")
 def c3(dev):
