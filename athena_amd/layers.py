@@ -162,6 +162,28 @@ class msgpass_layer_type:
             self.grads[i] = torch.from_numpy(gradients[o:o + p.numel()].copy()).to(self.device)
             o += p.numel()
 
+    # -- merging replicas (reduce_learnable / add_learnable, athena_base_layer_sub.f90:468-540) -------------
+    def reduce(self, other):
+        """this = this + other: parameters summed, gradients summed where both layers hold one -- what the reference
+        uses to merge per-thread replicas of a layer; on the device, one axpy per tensor"""
+        if len(self.params) != len(other.params):
+            raise ValueError("reduce_learnable: incompatible parameter sizes")
+        for i in range(len(self.params)):
+            if self.params[i].numel() != other.params[i].numel():
+                raise ValueError("reduce_learnable: incompatible parameter sizes")
+            ops.axpy(1.0, other.params[i].to(self.device), self.params[i])
+            if self.grads[i] is not None and other.grads[i] is not None:
+                ops.axpy(1.0, other.grads[i].to(self.device), self.grads[i])
+        return self
+
+    def __add__(self, other):
+        """add_learnable: a copy of this layer (same hyperparameters, graph handle shared) reduced with other"""
+        import copy
+        out = copy.copy(self)
+        out.params = [p.clone() for p in self.params]
+        out.grads = [None if g is None else g.clone() for g in self.grads]
+        return out.reduce(other)
+
     def _t(self, a):
         if isinstance(a, torch.Tensor):
             return a.to(self.device, torch.float32).contiguous()

@@ -440,3 +440,42 @@ def test_kipf_layer_dense_step_before_the_aggregation(dev, act, exact):
         layer.forward(xs)
         assert layer.backward(np.concatenate(ups), need_input_grad=False, exact=exact) is None
         assert_close(layer.get_gradients(), np.concatenate(grads), 2e-5, f"{order}: dW without dx")
+
+
+def test_layer_addition_and_reduction(dev):
+    """test_gno_layer.f90:318-372 / test_full_layer.f90:63-81: `l2 + l3` and `l2%reduce(l3)` keep type, shape and
+    activation; parameters are summed, gradients are summed where both layers hold one (reduce_learnable /
+    add_learnable, athena_base_layer_sub.f90:468-540)"""
+    from athena_amd.layers import full_layer_type, graph_nop_layer_type, kipf_msgpass_layer_type
+
+    rng = np.random.default_rng(8)
+    gs = _graphs(rng, [12, 9], self_loops=False)
+    F_in, F_out, d, H_ = 4, 3, 2, 5
+    l2 = graph_nop_layer_type(num_inputs=F_in, num_outputs=F_out, coord_dim=d, kernel_hidden=H_, activation="sigmoid", seed=1)
+    l3 = graph_nop_layer_type(num_inputs=F_in, num_outputs=F_out, coord_dim=d, kernel_hidden=H_, activation="sigmoid", seed=2)
+    xs = [rng.uniform(-1, 1, (g.num_vertices, F_in)).astype(np.float32) for g in gs]
+    cs = [rng.standard_normal((g.num_edges, d)).astype(np.float32) for g in gs]
+    for l, sgn in ((l2, 1.0), (l3, -0.5)):
+        l.set_graph(gs)
+        out = l.forward(xs, cs)
+        l.backward(sgn * np.ones(tuple(out.shape), np.float32))
+    p2, p3, g2, g3 = l2.get_params(), l3.get_params(), l2.get_gradients(), l3.get_gradients()
+    res = l2 + l3
+    assert type(res) is graph_nop_layer_type and res.num_vertex_features[0] == F_in and res.num_outputs == F_out
+    assert res.activation == "sigmoid"
+    assert np.array_equal(res.get_params(), p2 + p3) and np.array_equal(res.get_gradients(), g2 + g3)
+    assert np.array_equal(l2.get_params(), p2)                       # the operands are untouched
+    l2.reduce(l3)
+    assert type(l2) is graph_nop_layer_type and l2.num_vertex_features[0] == F_in
+    assert np.array_equal(l2.get_params(), p2 + p3) and np.array_equal(l2.get_gradients(), g2 + g3)
+    # a layer without gradients yet: parameters add, gradients stay as they are
+    k1 = kipf_msgpass_layer_type(num_vertex_features=[4, 3], num_time_steps=1, seed=1)
+    k2 = kipf_msgpass_layer_type(num_vertex_features=[4, 3], num_time_steps=1, seed=2)
+    s_ = k1.get_params() + k2.get_params()
+    k1.reduce(k2)
+    assert np.array_equal(k1.get_params(), s_) and not k1.get_gradients().any()
+    with pytest.raises(ValueError, match="incompatible parameter sizes"):
+        k1.reduce(kipf_msgpass_layer_type(num_vertex_features=[4, 5], num_time_steps=1))
+    f1 = full_layer_type(num_inputs=1, num_outputs=10, activation="sigmoid", seed=1)
+    f2 = full_layer_type(num_inputs=1, num_outputs=10, activation="sigmoid", seed=2)
+    assert (f1 + f2).num_inputs == 1 and (f1 + f2).activation == "sigmoid"
