@@ -195,7 +195,7 @@ def parse_layer_card(text):
     stub, :703-714, so there is nothing to mirror for it).  Returns (name, hyperparameters, flat weight vector)."""
     lines = [l.rstrip() for l in text.splitlines() if l.strip()]
     name = lines[0].strip().lower()
-    if name not in ("kipf", "graph_nop", "full"):
+    if name not in ("kipf", "graph_nop", "full", "duvenaud"):
         raise ValueError(f"unsupported layer card '{lines[0].strip()}'")
     if lines[-1].strip() != "END " + name.upper():
         raise ValueError(f"END {name.upper()} not where expected")                  # the reference's message

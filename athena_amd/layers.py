@@ -47,6 +47,8 @@ def _init_weights(rng, n, fan_in, fan_out, activation, initialiser=None):
     (docs/source/layers/msgpass/kipf_msgpass_layer.rst:61-65); by name: athena_initialiser_{glorot,he,lecun,
     zeros,ones}.f90 (limits / sigmas as at _glorot.f90:120,178, _he.f90:167,229, _lecun.f90:117,172).  The
     random stream is numpy's, not the reference's -- distributions match, draws do not."""
+    if n == 0:                      # zero-width tensors (the placeholder layers the reference's readers build)
+        return np.zeros(0, np.float32)
     name = initialiser
     if name is None:
         name = "he_normal" if getattr(activation, "name", activation) in ("relu", "leaky_relu", "swish", "selu") else "glorot_uniform"
@@ -569,6 +571,14 @@ def read_layer(text, device="cuda:0"):
     from . import io
     name, hp, weights = io.parse_layer_card(text)
     act = io.activation_from_card(hp)
+    if name == "duvenaud":
+        # read_duvenaud_msgpass_layer (athena_duvenaud_msgpass_layer.f90:719-745) builds this placeholder and calls
+        # read_duvenaud, which is an empty stub (:703-714): the card's contents are NOT loaded.  Mirrored as is --
+        # the card carries neither the degree range nor num_outputs, so it could not rebuild the layer anyway.
+        import warnings
+        warnings.warn("DUVENAUD card: the reference's read_duvenaud is an empty stub; returning its placeholder layer")
+        return duvenaud_msgpass_layer_type(num_vertex_features=[0], num_edge_features=[0], num_time_steps=1,
+                                           max_vertex_degree=1, num_outputs=1, device=device)
     if name == "full":
         layer = full_layer_type(num_outputs=int(hp["NUM_OUTPUTS"]), num_inputs=int(hp["NUM_INPUTS"]),
                                 use_bias=hp.get("USE_BIAS", "T").strip().upper().startswith("T"), activation=act,

@@ -479,3 +479,18 @@ def test_layer_addition_and_reduction(dev):
     f1 = full_layer_type(num_inputs=1, num_outputs=10, activation="sigmoid", seed=1)
     f2 = full_layer_type(num_inputs=1, num_outputs=10, activation="sigmoid", seed=2)
     assert (f1 + f2).num_inputs == 1 and (f1 + f2).activation == "sigmoid"
+
+
+def test_reading_a_duvenaud_card_returns_the_reference_placeholder(dev):
+    """test_duvenaud_msgpass_layer.f90:152-180 writes a DUVENAUD card and reads it back through
+    read_duvenaud_msgpass_layer, whose `read` is an empty stub: the result is the placeholder layer (name 'duvenaud',
+    one time step, zero features) -- mirrored, with a warning that nothing was loaded"""
+    from athena_amd.layers import duvenaud_msgpass_layer_type, read_layer
+
+    layer = duvenaud_msgpass_layer_type(num_vertex_features=[3], num_edge_features=[2], num_time_steps=2,
+                                        max_vertex_degree=4, num_outputs=5, seed=1)
+    card = layer.print()
+    assert card.startswith("DUVENAUD\n   NUM_TIME_STEPS = 2\n   NUM_VERTEX_FEATURES = 3 3 3\n   NUM_EDGE_FEATURES = 2 2 2")
+    with pytest.warns(UserWarning, match="empty stub"):
+        back = read_layer(card)
+    assert back.name == "duvenaud" and back.num_time_steps == 1 and back.get_num_params() == 0
