@@ -50,6 +50,37 @@ class network_type:
     def get_num_params(self):
         return sum(l.get_num_params() for l in self.layers)
 
+    @property
+    def num_layers(self):
+        """the reference counts the input layer it inserts in front of the first added layer
+        (test_msgpass_network.f90:55: one msgpass layer -> num_layers = 2)"""
+        return len(self.layers) + 1 if self.layers else 0
+
+    def get_params(self):
+        """flat parameter vector, layers in order (network%get_params)"""
+        import numpy as np
+        parts = [l.get_params() for l in self.layers if l.get_num_params()]
+        return np.concatenate(parts).astype(np.float32) if parts else np.zeros(0, np.float32)
+
+    def set_params(self, params):
+        import numpy as np
+        params = np.asarray(params, np.float32)
+        if params.size != self.get_num_params():
+            raise ValueError("set_params: wrong number of parameters")
+        o = 0
+        for l in self.layers:
+            n = l.get_num_params()
+            if n:
+                l.set_params(params[o:o + n])
+                o += n
+
+    def reset(self):
+        """network%reset: back to an empty network (test_msgpass_network.f90:207-211)"""
+        self.layers, self.parents, self.operator = [], [], []
+        self.optimiser = None
+        self._out = None
+        self._captured = None
+
     # -------------------------------------------------------------------------------------------
     def forward(self, x, edge_features=None):
         """edge_features: the input graphs' edge features, handed to every layer that takes them (Duvenaud / GNO;

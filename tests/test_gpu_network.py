@@ -372,3 +372,31 @@ def test_gno_regression_network_resident(dev, oracle):
         for k in range(2):
             params[k] = (params[k] - np.float32(lr) * grads[k]).astype(np.float32)      # minimise_base :396-418
             assert_close(net.layers[k].get_params(), params[k], 1e-5, f"parameters of layer {k + 1} after step {it}")
+
+
+def test_network_accessors_of_the_reference_msgpass_network_test(dev):
+    """test_msgpass_network.f90: num_layers counts the inserted input layer (:55, :117), get_num_params / get_params
+    over the whole network (:162-188), reset empties it (:207-211)"""
+    from athena_amd import optim
+    from athena_amd.layers import duvenaud_msgpass_layer_type, full_layer_type, kipf_msgpass_layer_type
+    from athena_amd.network import network_type
+
+    net = network_type()
+    assert net.num_layers == 0 and net.get_num_params() == 0 and net.get_params().size == 0
+    net.add(kipf_msgpass_layer_type(num_vertex_features=[3, 4], num_time_steps=1, activation="relu", seed=1))
+    net.compile(optim.sgd_optimiser_type(learning_rate=0.01))
+    assert net.num_layers == 2 and net.get_num_params() == 12
+    p = net.get_params()
+    assert p.size == 12 and np.array_equal(p, net.layers[0].get_params())
+    net.set_params(p * 2)
+    assert np.array_equal(net.get_params(), p * 2)
+    with pytest.raises(ValueError, match="wrong number of parameters"):
+        net.set_params(p[:5])
+    net.reset()
+    assert net.num_layers == 0 and net.optimiser is None
+    d = network_type()
+    d.add(duvenaud_msgpass_layer_type(num_vertex_features=[4], num_edge_features=[2], num_time_steps=2,
+                                      max_vertex_degree=3, num_outputs=5, seed=2))
+    d.add(full_layer_type(num_inputs=5, num_outputs=1, seed=3))
+    assert d.num_layers == 3
+    assert d.get_num_params() == 2 * 4 * 6 * 3 + 2 * 5 * 4 + 6 and d.get_params().size == d.get_num_params()
