@@ -351,6 +351,23 @@ def test_errors_surface_as_exceptions_not_aborts(dev):
         DeviceGraph(np.array([0, 1], np.int32), np.array([[1], [0]], np.int32))
     with pytest.raises(_capi.AthenaMPError, match="outside"):
         DeviceGraph(np.array([1, 2], np.int32), np.array([[5], [0]], np.int32))
+    # the entry points added later keep the convention: status + message, never an abort
+    import ctypes as C
+    from athena_amd import ops
+    with pytest.raises(_capi.AthenaMPError, match=r"index_list\(:,2\) = \(3, 9\) outside \[1,4\]"):
+        DeviceGraph.from_edges(4, np.array([[1, 3], [2, 9]], np.int32))
+    g = DeviceGraph.from_edges(4, np.array([[1, 3], [2, 4]], np.int32), add_self_loops=True)
+    x = torch.zeros((4, 8), device=dev)
+    with pytest.raises(_capi.AthenaMPError, match="unknown activation 9"):
+        _capi.call("athena_mp_kipf_propagate_act_fwd", g.handle, 8, C.c_void_p(x.data_ptr()), 9, C.c_void_p(x.data_ptr()))
+    with pytest.raises(_capi.AthenaMPError, match="unknown activation 42"):
+        _capi.call("athena_mp_activation_param_fwd", 42, 32, 1.0, 0.0, 0.0, C.c_void_p(x.data_ptr()), C.c_void_p(x.data_ptr()))
+    with pytest.raises(_capi.AthenaMPError, match="null tensor"):
+        _capi.call("athena_mp_kipf_propagate_bwd_dual", g.handle, 8, C.c_void_p(x.data_ptr()), None, None)
+    with pytest.raises(ValueError, match="shape"):
+        ops.kipf_propagate_bwd_dual(g, torch.zeros((5, 8), device=dev))
+    with pytest.raises(ValueError, match="unknown activation"):
+        ops.actv_type("mish")
 
 
 def _gno_case(seed, N, d, H, Fi, Fo, extra_pairs=0, self_loops=False):
