@@ -117,3 +117,47 @@ def test_gno_fuzz(dev, oracle, seed):
     assert_close(H(dth), oracle.gno_kernel_bwd_theta(coords, theta, dk, Hh), 5e-5, "gno dtheta")
     dco = ops.gno_aggregate_bwd_coords(g, T(theta, dev), T(coords, dev), T(x, dev), T(up, dev), d, Hh)
     assert_close(H(dco), oracle.gno_kernel_bwd_coords(coords, theta, dk, Hh), 5e-5, "gno dcoords")
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_kipf_layer_order_fuzz(dev, seed):
+    """seeded fuzz of the Kipf layer mirror: random step counts, feature widths on both sides of the narrowing
+    threshold, fused and separate activations, hub vertices -- the layer in each order (aggregate_first,
+    transform_first, auto) against the per-sample oracle (forward 1e-5; gradients 3e-5: up to three chained steps)"""
+    import oracle_layers as ol
+    from helpers import csr_from_index_list
+    from athena_amd import ops
+    from athena_amd.layers import kipf_msgpass_layer_type
+
+    rng = np.random.default_rng(1000 + seed)
+    T_ = int(rng.integers(1, 4))
+    nvf = [int(rng.choice([1, 3, 8, 17, 32, 64, 96, 128])) for _ in range(T_ + 1)]
+    act = [("none"), ("relu"), ("tanh"), ("swish"), ops.actv_type("leaky_relu", alpha=0.2), ("softmax")][seed % 6]
+    gs = []
+    for n in rng.integers(2, 60, int(rng.integers(1, 5))):
+        n = int(n)
+        pairs = [[i, i + 1] for i in range(1, n)]
+        pairs += [[int(a), int(b)] for a, b in rng.integers(1, n + 1, (int(rng.integers(0, 3 * n)), 2)) if a != b]
+        gs.append(csr_from_index_list(n, np.array(pairs).T, self_loops=True))
+    if seed % 3 == 0:      # one graph with a hub vertex (> 512 entries: segment plan)
+        n = 700
+        pairs = [[1, k] for k in range(2, n + 1)] + [[i, i + 1] for i in range(2, n)]
+        gs.append(csr_from_index_list(n, np.array(pairs).T, self_loops=True))
+    xs = [rng.uniform(-1, 1, (g.num_vertices, nvf[0])).astype(np.float32) for g in gs]
+    ref_layer = kipf_msgpass_layer_type(num_vertex_features=nvf, num_time_steps=T_, activation=act, seed=seed)
+    params = ref_layer.get_params()
+    plist, o_ = [], 0
+    for t in range(1, T_ + 1):
+        plist.append(params[o_:o_ + nvf[t] * nvf[t - 1]]); o_ += nvf[t] * nvf[t - 1]
+    outs, tapes = ol.kipf_forward(gs, xs, plist, nvf, act)
+    ups = [rng.uniform(-1, 1, o.shape).astype(np.float32) for o in outs]
+    exact = bool(seed & 1)
+    dxs, grads = ol.kipf_backward(gs, tapes, plist, nvf, act, ups, exact=exact)
+    for order in ("aggregate_first", "transform_first", "auto"):
+        layer = kipf_msgpass_layer_type(num_vertex_features=nvf, num_time_steps=T_, activation=act, seed=seed, order=order)
+        layer.set_params(params)
+        layer.set_graph(gs)
+        assert_close(H(layer.forward(xs)), np.concatenate(outs), 1e-5, f"seed {seed} {order} {nvf} fwd")
+        dx = layer.backward(np.concatenate(ups), exact=exact)
+        assert_close(H(dx), np.concatenate(dxs), 3e-5, f"seed {seed} {order} {nvf} dx")
+        assert_close(layer.get_gradients(), np.concatenate(grads), 3e-5, f"seed {seed} {order} {nvf} dW")
