@@ -42,7 +42,8 @@ def _worker(rank, world, port, n, pairs, F, cut, q, Fo=None):
 
 @pytest.mark.parametrize("world,cut,F,Fo", [(2, 0.1, 128, None), (3, None, 64, None), (2, 0.05, 24, None),
                                             (2, 0.1, 128, 32),     # narrowing step: dense step before the exchange
-                                            (3, None, 64, 96)])    # widening step: rectangular, aggregate first
+                                            (3, None, 64, 96),     # widening step: rectangular, aggregate first
+                                            (2, 0.1, 256, None)])  # BASELINE configs[4] width (two-kernel route per shard)
 def test_multi_rank_step_with_hip_backend_matches_global_oracle(dev, oracle, world, cut, F, Fo):
     from athena_amd import dist as adist
 
