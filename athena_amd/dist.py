@@ -253,6 +253,22 @@ def make_weak_scaling_shard(rank, world, n, pairs, F, cut=None, device=None, see
     return build_plan(sh, device)
 
 
+def make_global_shard(rank, world, n_total, pairs, device=None, seed=20260424, locality=None):
+    """STRONG scaling: rank's contiguous row block of ONE fixed graph -- synth.random_graph_csr(n_total, pairs, seed),
+    the generator of BASELINE configs[1] / configs[4] -- built from the shared pair stream without
+    materialising the other ranks' rows.  n_total must divide by world."""
+    from . import synth
+    if n_total % world:
+        raise ValueError(f"{n_total} vertices do not split into {world} equal row blocks")
+    n = n_total // world
+    ia, cols = synth.random_graph_csr_rows(n_total, pairs, rank * n, (rank + 1) * n, seed=seed, locality=locality)
+    rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(ia))
+    sh = Shard(rank, world, n, rows, cols)
+    sh.cut = None
+    sh.n_total = n_total
+    return build_plan(sh, device)
+
+
 class KipfShardStep:
     """One interior Kipf layer fwd+bwd on a row shard (the bench step), F -> Fo features:
          aggregate first (the reference's association):
@@ -263,7 +279,9 @@ class KipfShardStep:
              Y = X W^T; exchange(Y); Z = A^ Y; exchange(dZ); (Qp, Qc) = one dual pull of dZ;
              dW = Qc^T X (all-reduce); dX = Qp W"""
 
-    def __init__(self, shard, F, device, backend=None, seed=1, exact=False, Fo=None, order="auto"):
+    def __init__(self, shard, F, device, backend=None, seed=1, exact=False, Fo=None, order="auto", inputs=None):
+        """inputs: optional (x [n, F], dz [n, Fo], w [Fo*F]) host arrays for the rank's rows in their ORIGINAL local
+        order (the shard renumbers them interior-first); default: seeded random per rank"""
         self.s, self.F, self.device = shard, F, device
         self.Fo = Fo = F if Fo is None else int(Fo)
         if not (order in ("auto", "aggregate_first", "transform_first")):
@@ -282,12 +300,21 @@ class KipfShardStep:
         rng = np.random.Generator(np.random.PCG64([seed, shard.rank]))
         xw = Fo if self.transform_first else F            # width of the rows the forward exchange moves
         self.x_ext = torch.empty((n + nh, F) if not self.transform_first else (n, F), dtype=torch.float32, device=device)
-        self.x_ext[:n] = torch.from_numpy(rng.uniform(-1, 1, (n, F)).astype(np.float32)).to(device)
+        if inputs is not None:
+            x_h, dz_h, w_h = inputs
+            if not (x_h.shape == (n, F) and dz_h.shape == (n, Fo) and w_h.size == Fo * F):
+                raise ValueError("inputs: expected x [n, F], dz [n, Fo], w [Fo*F] for this rank's rows")
+            x_h, dz_h = x_h[shard.order], dz_h[shard.order]
+        else:
+            x_h = rng.uniform(-1, 1, (n, F)).astype(np.float32)
+            dz_h = rng.uniform(-1, 1, (n, Fo)).astype(np.float32)
+            wr = np.random.Generator(np.random.PCG64(seed + 1))          # W identical on every rank
+            w_h = (wr.standard_normal(Fo * F) * np.sqrt(2.0 / F)).astype(np.float32)
+        self.x_ext[:n] = torch.from_numpy(np.ascontiguousarray(x_h, np.float32)).to(device)
         self.dZ_ext = torch.empty((n + nh, Fo), dtype=torch.float32, device=device)
-        self.dZ_ext[:n] = torch.from_numpy(rng.uniform(-1, 1, (n, Fo)).astype(np.float32)).to(device)
+        self.dZ_ext[:n] = torch.from_numpy(np.ascontiguousarray(dz_h, np.float32)).to(device)
         self.dZ = self.dZ_ext[:n]
-        wr = np.random.Generator(np.random.PCG64(seed + 1))              # W identical on every rank
-        self.W = torch.from_numpy((wr.standard_normal(Fo * F) * np.sqrt(2.0 / F)).astype(np.float32)).to(device)
+        self.W = torch.from_numpy(np.ascontiguousarray(w_h, np.float32).reshape(-1)).to(device)
         self.Z = torch.empty((n, Fo), dtype=torch.float32, device=device)
         self.dW = torch.empty(Fo * F, dtype=torch.float32, device=device)
         self.dX = torch.empty((n, F), dtype=torch.float32, device=device)
@@ -314,9 +341,9 @@ class KipfShardStep:
             return None
         return dist.all_reduce(self.dW, async_op=True)
 
-    def __call__(self, events=None):
-        """events: optional list; a (start, end) pair of torch.cuda events around the interior forward launch is
-        appended (bench.py's roofline at N > 1)"""
+    def __call__(self, events=None, events_bnd=None):
+        """events / events_bnd: optional lists; a (start, end) pair of torch.cuda events around the interior / the
+        boundary forward launch is appended (bench.py's roofline at N > 1)"""
         if self.transform_first:
             return self._step_transform_first(events)
         s, b, F, Fo, n, ni = self.s, self.b, self.F, self.Fo, self.s.n, self.s.n_int
@@ -329,7 +356,13 @@ class KipfShardStep:
             e1.record()
             events.append((e0, e1))
         self.xchg.finish(reqs)
+        if events_bnd is not None:
+            e2 = torch.cuda.Event(enable_timing=True); e3 = torch.cuda.Event(enable_timing=True)
+            e2.record()
         b.kipf_layer_fwd(self.g_fwd_bnd, self.x_ext, self.W, Fo, P=self.P[ni:], Z=self.Z[ni:])
+        if events_bnd is not None:
+            e3.record()
+            events_bnd.append((e2, e3))
         reqs = self.xchg_o.start(self.dZ_ext)                                     # halo of dZ in flight ...
         b.matmul_dw(self.P, self.dZ, out=self.dW)                                 # ... under dW
         red = self._allreduce_dw()
@@ -371,15 +404,65 @@ class KipfShardStep:
             self.b.pull_dual(g, self.dZ_ext, plain=self.Qp[r0:r1], coef=self.Qc[r0:r1])
 
 
-def build_kipf_step(shard, F, device, backend=None, Fo=None, order="auto"):
-    step = KipfShardStep(shard, F, device, backend, Fo=Fo, order=order)
+def build_kipf_step(shard, F, device, backend=None, Fo=None, order="auto", inputs=None):
+    step = KipfShardStep(shard, F, device, backend, Fo=Fo, order=order, inputs=inputs)
     halo_bytes = shard.n_halo * 4 * ((step.Fo if step.transform_first else F) + step.Fo)
-    uniform = shard.world > 1 and abs(shard.cut - (shard.world - 1) / shard.world) < 1e-9
-    info = {"graph": "random graph, both endpoints uniform over all N*vertices_per_gpu vertices (no partition structure)" if uniform
-            else f"stochastic block model, one block per GPU, fixed inter-block density: {shard.cut:.4f} of the undirected pairs cross partitions at this N",
+    if getattr(shard, "n_total", None) is not None:
+        graph = f"contiguous row block of ONE fixed graph of {shard.n_total} vertices (the single-GPU workload, strong scaling)"
+    elif shard.world > 1 and abs(shard.cut - (shard.world - 1) / shard.world) < 1e-9:
+        graph = "random graph, both endpoints uniform over all N*vertices_per_gpu vertices (no partition structure)"
+    else:
+        graph = (f"stochastic block model, one block per GPU, fixed inter-block density: {shard.cut:.4f} of the undirected "
+                 "pairs cross partitions at this N")
+    info = {"graph": graph,
             "halo_rows_per_gpu": shard.n_halo, "halo_bytes_per_gpu_per_step": halo_bytes,
             "interior_rows_per_gpu": shard.n_int, "interior_entries_per_gpu": int(shard.adj_ia[shard.n_int]) - 1}
     return step, shard.nnz, info
+
+
+def measure_breakdown(step, iters=5):
+    """Each part of the sharded step timed ALONE (device events, after the timed loop of bench.py): the two halo
+    exchanges (pack + grouped send/recv + wait), the interior launches and the boundary launches of both passes, the
+    dW contraction.  In the step itself the exchanges run under the interior launches; the parts are timed apart so a
+    scaling curve can be read (what is communication, what is compute).  Aggregate-first steps only."""
+    if step.transform_first:
+        return {}
+    s, b, F, Fo, n, ni = step.s, step.b, step.F, step.Fo, step.s.n, step.s.n_int
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        if s.world > 1:
+            dist.barrier()
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    def halo():
+        step.xchg.finish(step.xchg.start(step.x_ext))
+        step.xchg_o.finish(step.xchg_o.start(step.dZ_ext))
+
+    def interior():
+        b.kipf_layer_fwd(step.g_fwd_int, step.x_ext, step.W, Fo, P=step.P[:ni], Z=step.Z[:ni])
+        b.pull_gemm(step.g_bwd_int, step.dZ_ext, step.W, F, exact=step.exact, out=step.dX[:ni])
+
+    def boundary():
+        b.kipf_layer_fwd(step.g_fwd_bnd, step.x_ext, step.W, Fo, P=step.P[ni:], Z=step.Z[ni:])
+        b.pull_gemm(step.g_bwd_bnd, step.dZ_ext, step.W, F, exact=step.exact, out=step.dX[ni:])
+
+    def dw():
+        b.matmul_dw(step.P, step.dZ, out=step.dW)
+
+    out = {"halo_ms": timed(halo) if s.world > 1 else 0.0, "interior_ms": timed(interior), "boundary_ms": timed(boundary),
+           "dw_ms": timed(dw)}
+    recv_bytes = s.n_halo * 4 * (F + Fo)
+    out["halo_recv_bytes_per_gpu_per_step"] = recv_bytes
+    out["xgmi_recv_GBps_per_gpu"] = (recv_bytes / (out["halo_ms"] * 1e-3) / 1e9) if out["halo_ms"] > 0 else None
+    return out
 
 
 # --------------------------------------------------------------------------------------------------
@@ -419,8 +502,13 @@ def allreduce_layer_gradients(layers):
 def gather_graph_outputs(local_out, positions, n_graphs):
     """assemble the per-graph readout [batch, num_outputs] from the ranks' shards (rank r holds the rows
     `positions`); every rank receives the full tensor"""
-    world = dist.get_world_size()
-    full = torch.zeros((n_graphs, local_out.shape[1]), dtype=local_out.dtype)
-    full[torch.as_tensor(positions, dtype=torch.long)] = local_out.detach().cpu()
-    dist.all_reduce(full)          # disjoint rows: the sum is the gather
-    return full.to(local_out.device) if world >= 1 else full
+    pos = torch.as_tensor(positions, dtype=torch.long)
+    if _host_staged(local_out) or not local_out.is_cuda:       # gloo: host memory only
+        full = torch.zeros((n_graphs, local_out.shape[1]), dtype=local_out.dtype)
+        full[pos] = local_out.detach().cpu()
+        dist.all_reduce(full)      # disjoint rows: the sum is the gather
+        return full.to(local_out.device)
+    full = torch.zeros((n_graphs, local_out.shape[1]), dtype=local_out.dtype, device=local_out.device)
+    full[pos.to(local_out.device)] = local_out.detach()
+    dist.all_reduce(full)          # RCCL: nothing leaves the device
+    return full

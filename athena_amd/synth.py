@@ -29,10 +29,15 @@ def random_graph_csr(n, n_pairs, seed=20260424, self_loops=True):
     return adj_ia, adj_ja
 
 
+def kipf_weight(F, seed=2):
+    """W ~ N(0, 2/F), flat W(F, F) column-major; fp32"""
+    return (np.random.Generator(np.random.PCG64(seed)).standard_normal(F * F) * np.sqrt(2.0 / F)).astype(np.float32)
+
+
 def kipf_inputs(n, F, seed=1):
     """X ~ U(-1,1) (seed), W ~ N(0, 2/F) (seed+1), dZ ~ U(-1,1) (seed+2); fp32."""
     x = np.random.Generator(np.random.PCG64(seed)).uniform(-1, 1, (n, F)).astype(np.float32)
-    w = (np.random.Generator(np.random.PCG64(seed + 1)).standard_normal(F * F) * np.sqrt(2.0 / F)).astype(np.float32)
+    w = kipf_weight(F, seed + 1)
     dz = np.random.Generator(np.random.PCG64(seed + 2)).uniform(-1, 1, (n, F)).astype(np.float32)
     return x, w, dz
 
@@ -108,3 +113,52 @@ def radius_graph(n_points, mean_degree=15.0, seed=4, dim=3):
     adj_ja[0] = dst + 1
     adj_ja[1] = ee
     return adj_ia, adj_ja, coords
+
+
+def random_graph_csr_rows(n, n_pairs, r0, r1, seed=20260424, locality=None):
+    """Rows [r0, r1) of the graph random_graph_csr(n, n_pairs, seed) builds, without building the rest: the same
+    pair stream, the same entry order inside a row (self-loop, then the pairs that list the vertex first, then those
+    that list it second, each in generation order).  Returns (adj_ia [r1-r0+1] 1-based, cols [nnz] 0-based GLOBAL
+    vertex ids).  locality=(w, p): the C5 locality variant of SURVEY.md 8d -- with probability p the second endpoint
+    is drawn with 0 < |u - v| <= w (reflected at the ends of the vertex range), otherwise uniform."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    u = rng.integers(0, n, n_pairs, dtype=np.int64)
+    v = rng.integers(0, n - 1, n_pairs, dtype=np.int64)
+    v = v + (v >= u)
+    if locality is not None:
+        w, p = locality
+        near = rng.random(n_pairs) < p
+        off = rng.integers(1, w + 1, n_pairs, dtype=np.int64) * np.where(rng.random(n_pairs) < 0.5, -1, 1)
+        vn = u + off
+        bad = (vn < 0) | (vn >= n)
+        vn = np.where(bad, u - off, vn)
+        v = np.where(near, vn, v)
+    mu = (u >= r0) & (u < r1)
+    mv = (v >= r0) & (v < r1)
+    loops = np.arange(r0, r1, dtype=np.int64)
+    src = np.concatenate([loops, u[mu], v[mv]])
+    dst = np.concatenate([loops, v[mu], u[mv]])
+    order = np.argsort(src, kind="stable")
+    src, dst = src[order], dst[order]
+    counts = np.bincount(src - r0, minlength=r1 - r0)
+    adj_ia = np.concatenate([[1], 1 + np.cumsum(counts)]).astype(np.int64)
+    return adj_ia, dst
+
+
+def feature_rows(seed, ids, F, lo=-1.0, hi=1.0):
+    """rows `ids` of the [n, F] matrix Generator(PCG64(seed)).uniform(lo, hi, (n, F)).astype(float32) (what kipf_inputs
+    draws for X and dZ) without drawing the rows before them (PCG64.advance: one 64-bit draw per value)"""
+    ids = np.asarray(ids, np.int64)
+    out = np.empty((ids.size, F), np.float32)
+    for k, i in enumerate(ids):
+        bg = np.random.PCG64(seed)
+        bg.advance(int(i) * F)
+        out[k] = np.random.Generator(bg).uniform(lo, hi, F).astype(np.float32)
+    return out
+
+
+def feature_block(seed, r0, r1, F, lo=-1.0, hi=1.0):
+    """rows [r0, r1) of the same matrix as one block"""
+    bg = np.random.PCG64(seed)
+    bg.advance(int(r0) * F)
+    return np.random.Generator(bg).uniform(lo, hi, (r1 - r0, F)).astype(np.float32)

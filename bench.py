@@ -9,33 +9,95 @@ A "step" is one interior Kipf layer forward+backward over the whole graph (SURVE
                                    no coefficient), evaluated as (A^T dZ) W in one fused launch
 "edges" = CSR entries (nnz).  Inputs are resident in HBM before the timed region.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL): WEAK scaling -- every rank
-owns a 1M-vertex / 10M-entry row block of an N-times larger graph; halo rows of X (forward) and of
-dP (backward) move by grouped point-to-point send/recv, dW by all_reduce (athena_amd/dist.py).
-The N > 1 graph is a stochastic block model: one block per GPU, a FIXED inter-block density (each pair
-of blocks shares 2*pairs*cut8/7 undirected pairs, so the cross-partition fraction is cut8*(N-1)/7:
-0.7 % at N=2, 2.1 % at N=4, 5 % at N=8 with the default --cut8 0.05 -- what a node partitioner leaves on
-meshes and molecule batches) and the same run also reports the structure-free variant (both endpoints uniform over the whole graph: the worst case for any row
-partition, communication bound by construction) as "uniform_random_variant".
+`python3 bench.py --gpus N` launches itself: with WORLD_SIZE unset and N > 1 the parent starts
+`python -m torch.distributed.run --nproc-per-node N ... bench.py` as a CHILD before anything touches the
+GPU and exits with its code (a driver that starts the ranks itself sets WORLD_SIZE and skips this).
+
+Workloads (--config):
+  c2 (default)   N = 1: BASELINE configs[1].  N > 1: STRONG scaling of the SAME graph (SURVEY.md 8d generator:
+                 uniform pairs, PCG64 seed 20260424) under a contiguous row partition -- the metric's
+                 "1M-node/10M-edge, 1/2/4/8 GPU".  A uniformly random graph has no partition structure: every rank
+                 needs most remote rows, so this line is xGMI bound by construction; the line says how much
+                 (halo_ms / interior_ms / boundary_ms / bytes / achieved GB/s per GPU).
+  c2-weak-sbm    WEAK scaling, 1M vertices / 10M entries per GPU, stochastic block model with a fixed inter-block
+                 density (--cut8; what a node partitioner leaves on meshes and molecule batches).
+  c5, c5-local   BASELINE configs[4]: 10M vertices / 150M entries / 256 features split over the ranks (8-way in the
+                 config; any N that divides 10M runs); c5-local = the locality variant of SURVEY.md 8d
+                 (|u-v| <= 50 000 with probability 0.95).
+Every line carries "parity": the device results of the LAST timed step against the CPU oracle (N = 1: the whole
+workload; N > 1: sampled rows of every rank + the transported halo rows against the generator); the process exits
+non-zero when parity is above 1e-5 (or P is not bit-exact).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md "Chip-level parameters")
+TOL = 1e-5             # north_star: 1e-5 relative fp32
+
+CONFIGS = {
+    "c2": dict(nodes=1_000_000, pairs=4_500_000, feat=128, locality=None),
+    "c2-weak-sbm": dict(nodes=1_000_000, pairs=4_500_000, feat=128, locality=None),
+    "c5": dict(nodes=10_000_000, pairs=70_000_000, feat=256, locality=None),
+    "c5-local": dict(nodes=10_000_000, pairs=70_000_000, feat=256, locality=(50_000, 0.95)),
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
+    ap.add_argument("--nodes", type=int, default=None, help="vertices (c2-weak-sbm: per GPU; otherwise of the whole graph)")
+    ap.add_argument("--pairs", type=int, default=None, help="undirected pairs (nnz = 2*pairs + nodes)")
+    ap.add_argument("--feat", type=int, default=None)
+    ap.add_argument("--cut8", dest="cut", type=float, default=0.05,
+                    help="c2-weak-sbm: fraction of undirected pairs crossing partitions at 8 blocks (fixed inter-block "
+                         "density; the fraction at N blocks is cut8*(N-1)/7).  -1: structure-free uniform random graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle (no cpu_baseline, N=1 parity null)")
+    ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000,
+                    help="rows of the workload the 1-thread CPU oracle runs (default: all of C2, ~7-15 s)")
+    args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    args.custom = any(v is not None for v in (args.nodes, args.pairs, args.feat))
+    args.nodes = cfg["nodes"] if args.nodes is None else args.nodes
+    args.pairs = cfg["pairs"] if args.pairs is None else args.pairs
+    args.feat = cfg["feat"] if args.feat is None else args.feat
+    args.locality = cfg["locality"]
+    return args
+
+
+def self_launch(args):
+    """N > 1 from a bare shell: start the ranks as a child process (never exec: nothing here has touched the GPU, and
+    the children are fresh processes)."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+def rel(a, b):
+    import numpy as np
+    b = np.asarray(b, np.float64)
+    return float(np.abs(np.asarray(a, np.float64) - b).max() / max(np.abs(b).max(), 1e-30))
 
 
 def cpu_baseline(ia, ja, x, w, dz, F, sample_rows):
     """The oracle (a line-by-line C port of the reference's loops), 1 thread, on the first
-    `sample_rows` rows of the same workload (they gather from / scatter into the full tensors)."""
+    `sample_rows` rows of the same workload (they gather from / scatter into the full tensors).
+    Returns (the cpu_baseline object, the oracle's results for the parity block)."""
+    import numpy as np
     from oracle import oracle
 
     n = ia.size - 1
@@ -52,7 +114,6 @@ def cpu_baseline(ia, ja, x, w, dz, F, sample_rows):
     dp = oracle.matmul_dx(w, dz[:rows], F)
     dx = oracle.kipf_propagate_bwd(dp, sia, sja, n_out=n)
     t = time.perf_counter() - t0
-    del z, dw, dx
     out = {"value": ent / t, "unit": "edges/s", "cores": 1, "kind": "port",
            "sample": f"oracle (C port of the reference loops), first {rows} of {n} rows = {ent} of {ja.shape[1]} entries, "
                      f"full fwd+bwd step, {t:.1f} s on {os.cpu_count()}-core host, 1 thread"}
@@ -68,37 +129,112 @@ def cpu_baseline(ia, ja, x, w, dz, F, sample_rows):
                                     "sample": f"whole workload, best of 3, {best * 1e3:.0f} ms"}
     except Exception as exc:   # no OpenMP runtime on the host: the contract fields above are complete without it
         out["all_cores_context"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+    return out, dict(rows=rows, full=(rows == n), p=p, z=z, dw=dw, dx=dx)
+
+
+def parity_single(ref, P, Z, dW, dX):
+    """device results of the last timed step against the oracle's (whole workload when the oracle ran all rows)"""
+    import numpy as np
+    r = ref["rows"]
+    out = {"against": "oracle (C port of the reference loops), " + ("all rows" if ref["full"] else f"first {r} rows (dW, dX need all rows: null)"),
+           "P_bit_exact": bool(np.array_equal(P[:r].cpu().numpy(), ref["p"])),
+           "Z_rel": rel(Z[:r].cpu().numpy(), ref["z"]),
+           "dW_rel": rel(dW.cpu().numpy(), ref["dw"]) if ref["full"] else None,
+           "dX_rel": rel(dX.cpu().numpy(), ref["dx"]) if ref["full"] else None, "tol": TOL}
+    out["ok"] = bool(out["P_bit_exact"] and all(v is None or v <= TOL for v in (out["Z_rel"], out["dW_rel"], out["dX_rel"])))
+    return out
+
+
+def parity_sharded(step, shard, seeds, dev, n_sample=4000):
+    """N > 1: (1) the halo rows the exchanges delivered against the generator (transport, bit-exact); (2) sampled rows
+    of this rank: P bit-exact / Z / dX <= 1e-5 against the oracle on the compacted sub-problem; (3) the all-reduced dW
+    against a float64 contraction on the device (a yardstick, not the oracle: the oracle would need every rank's P)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from athena_amd import synth
+    from oracle import oracle
+
+    s, F, Fo, n = shard, step.F, step.Fo, shard.n
+    rng = np.random.default_rng(100 + s.rank)
+    res = {}
+    torch.cuda.synchronize()
+    # (1) transported rows
+    ok_halo = True
+    if s.n_halo and seeds is not None:
+        k = np.sort(rng.choice(s.n_halo, min(500, s.n_halo), replace=False))
+        kd = torch.from_numpy(n + k).to(dev)
+        ok_halo = bool(np.array_equal(step.x_ext[kd].cpu().numpy(), synth.feature_rows(seeds[0], s.halo_ids[k], F)) and
+                       np.array_equal(step.dZ_ext[kd].cpu().numpy(), synth.feature_rows(seeds[1], s.halo_ids[k], Fo)))
+    res["halo_rows_bit_exact"] = ok_halo
+    # (2) sampled rows
+    rows = np.sort(rng.choice(n, min(n_sample, n), replace=False))
+    W = step.W.cpu().numpy()
+
+    def sub(adj_ja):
+        ent = np.concatenate([np.arange(s.adj_ia[r] - 1, s.adj_ia[r + 1] - 1) for r in rows])
+        cols, inv = np.unique(adj_ja[0, ent].astype(np.int64) - 1, return_inverse=True)
+        sia = np.concatenate([[1], 1 + np.cumsum(s.adj_ia[rows + 1] - s.adj_ia[rows])]).astype(np.int32)
+        sja = np.zeros((2, ent.size), np.int32, order="F"); sja[0] = inv + 1
+        return cols, sia, sja
+
+    rsel = torch.from_numpy(rows).to(dev)
+    cols, sia, sja = sub(s.adj_ja)
+    xc = step.x_ext[torch.from_numpy(cols).to(dev)].cpu().numpy()
+    p_ref = oracle.kipf_propagate_rect(xc, sia, sja, s.row_deg[rows], s.col_deg[cols])
+    res["P_bit_exact"] = bool(np.array_equal(step.P[rsel].cpu().numpy(), p_ref))
+    res["Z_rel"] = rel(step.Z[rsel].cpu().numpy(), oracle.matmul(W, p_ref, Fo))
+    cols, sia, sja = sub(s.adj_ja_bwd)
+    dzc = step.dZ_ext[torch.from_numpy(cols).to(dev)].cpu().numpy()
+    dp = oracle.matmul_dx(W, dzc, F)                                            # reference order: W^T dZ, then the scatter
+    ones = np.ones(max(rows.size, cols.size), np.int32)
+    dx_ref = oracle.kipf_propagate_rect(dp, sia, sja, ones[:rows.size], ones[:cols.size])   # coefficient 1: plain sums
+    res["dX_rel"] = rel(step.dX[rsel].cpu().numpy(), dx_ref)
+    # (3) dW
+    d64 = (step.P.double().T @ step.dZ.double()).reshape(-1)                     # dW(Fo,Fi) column-major == [Fi][Fo] row-major = P^T dZ
+    if dist.get_backend() == "nccl":
+        dist.all_reduce(d64)
+    else:
+        h = d64.cpu(); dist.all_reduce(h); d64 = h.to(dev)
+    res["dW_rel_vs_float64"] = float((step.dW.double() - d64).abs().max().item() / max(d64.abs().max().item(), 1e-30))
+    flags = torch.tensor([float(not (res["halo_rows_bit_exact"] and res["P_bit_exact"])), res["Z_rel"], res["dX_rel"],
+                          res["dW_rel_vs_float64"]], dtype=torch.float64)
+    if dist.get_backend() == "nccl":
+        flags = flags.to(dev)
+    dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+    flags = flags.cpu().tolist()
+    out = {"against": f"oracle on {rows.size} sampled rows of every rank (max over ranks); halo rows against the generator; "
+                      "dW against float64 on the device",
+           "halo_rows_bit_exact": flags[0] == 0.0 and res["halo_rows_bit_exact"], "P_bit_exact": flags[0] == 0.0,
+           "Z_rel": flags[1], "dX_rel": flags[2], "dW_rel_vs_float64": flags[3], "tol": TOL}
+    out["ok"] = bool(flags[0] == 0.0 and max(flags[1:]) <= TOL)
     return out
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--nodes", type=int, default=1_000_000, help="vertices per GPU")
-    ap.add_argument("--pairs", type=int, default=4_500_000, help="undirected pairs per GPU (nnz = 2*pairs + nodes)")
-    ap.add_argument("--feat", type=int, default=128)
-    ap.add_argument("--cut8", dest="cut", type=float, default=0.05,
-                    help="N>1: fraction of undirected pairs crossing partitions at 8 blocks (fixed inter-block density; "
-                         "the fraction at N blocks is cut8*(N-1)/7).  -1: structure-free uniform random graph")
-    ap.add_argument("--variant", action="store_true",
-                    help="N>1: also time the structure-free uniform-random graph (xGMI bound by construction) and "
-                         "report it as uniform_random_variant; off by default so the contract line never waits on it")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000, help="rows of the workload the 1-thread CPU oracle runs (default: all of it, ~7-15 s)")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+
+    import numpy as np
+    import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.is_available(), "bench.py measures the HIP path; no GPU visible"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     # dev aid: ATHENA_MP_BENCH_ONE_DEVICE=1 ATHENA_MP_BENCH_BACKEND=gloo runs the N > 1 code path with all ranks on
     # device 0 and host-staged transport (a dry run of the partition / halo / overlap logic on a 1-GPU box; the
     # numbers it prints mean nothing).  The driver's runs use one GPU per rank over RCCL.
-    if os.environ.get("ATHENA_MP_BENCH_ONE_DEVICE"):
+    one_device = bool(os.environ.get("ATHENA_MP_BENCH_ONE_DEVICE"))
+    if one_device:
         local_rank = 0
+    elif torch.cuda.device_count() < world:
+        sys.exit(f"bench.py: {world} ranks but {torch.cuda.device_count()} GPU(s) visible "
+                 "(dry run on one device: ATHENA_MP_BENCH_ONE_DEVICE=1 ATHENA_MP_BENCH_BACKEND=gloo)")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py measures the HIP path; no GPU visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -106,6 +242,9 @@ def main():
 
     _capi.init(local_rank)
     F = args.feat
+    weak = args.config == "c2-weak-sbm"
+    ev, ev_bnd = [], []
+    breakdown, seeds = None, None
 
     if world > 1:
         import torch.distributed as dist
@@ -117,17 +256,26 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-        cut = None if args.cut < 0 else args.cut * (world - 1) / 7.0
-        shard = adist.make_weak_scaling_shard(rank, world, args.nodes, args.pairs, F, cut=cut, device=dev)
-        shard_step, nnz_local, info = adist.build_kipf_step(shard, F, dev)
-        nnz_total = nnz_local * world
+        if weak:
+            cut = None if args.cut < 0 else args.cut * (world - 1) / 7.0
+            shard = adist.make_weak_scaling_shard(rank, world, args.nodes, args.pairs, F, cut=cut, device=dev)
+            inputs = None
+        else:
+            shard = adist.make_global_shard(rank, world, args.nodes, args.pairs, device=dev, locality=args.locality)
+            n = shard.n
+            seeds = (1, 3)                                    # synth.kipf_inputs: X seed 1, W seed 2, dZ seed 3
+            inputs = (synth.feature_block(1, rank * n, (rank + 1) * n, F), synth.feature_block(3, rank * n, (rank + 1) * n, F),
+                      synth.kipf_weight(F))
+        shard_step, nnz_local, info = adist.build_kipf_step(shard, F, dev, inputs=inputs)
+        tt = torch.tensor([nnz_local], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(tt)
+        nnz_total = int(tt.item())
         x = w = dz = ia = ja = None
-        ev = []
 
         def step(record=False):
-            shard_step(events=ev if record else None)
+            shard_step(events=ev if record else None, events_bnd=ev_bnd if record else None)
     else:
-        ia, ja = synth.random_graph_csr(args.nodes, args.pairs)
+        ia, ja = synth.random_graph_csr(args.nodes, args.pairs) if args.locality is None else _global_csr(synth, args)
         x, w, dz = synth.kipf_inputs(args.nodes, F)
         g = DeviceGraph(ia, ja, n_edge_cols=0, device=local_rank)
         nnz_local = nnz_total = int(ja.shape[1])
@@ -137,7 +285,6 @@ def main():
         Z = torch.empty((N, F), device=dev)
         dW = torch.empty(F * F, device=dev)
         dX = torch.empty((N, F), device=dev)
-        ev = []
 
         def step(record=False):
             if record:
@@ -173,73 +320,89 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = nnz_total * args.steps / dt
 
-    variant = None
-    if world > 1 and args.variant and args.cut >= 0:
-        # the structure-free graph (both endpoints uniform over all N*1M vertices): no row partition can
-        # avoid moving ~(N-1)/N of the neighbour rows, so this variant is xGMI bound by construction
-        try:
-            del step, shard_step, shard
-            torch.cuda.empty_cache()
-            vsteps = max(3, args.steps // 5)
-            shard2 = adist.make_weak_scaling_shard(rank, world, args.nodes, args.pairs, F, cut=None, device=dev)
-            step2, nnz2, info2 = adist.build_kipf_step(shard2, F, dev)
-            for _ in range(2):
-                step2()
-            barrier()
-            t1 = time.perf_counter()
-            for _ in range(vsteps):
-                step2()
-            barrier()
-            dt2 = time.perf_counter() - t1
-            tt = torch.tensor([dt2], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            variant = {"value": nnz2 * world * vsteps / tt.item(), "unit": "edges/s", "steps": vsteps,
-                       "ms_per_step": tt.item() / vsteps * 1e3, **info2}
-        except Exception as exc:   # the variant is extra information: never lose the main line to it
-            variant = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+    if args.custom:
+        wl = "custom size: "
+    else:
+        wl = {"c2": "BASELINE configs[1]: ", "c2-weak-sbm": "BASELINE configs[1] per GPU (weak scaling, block model): ",
+              "c5": "BASELINE configs[4]: ", "c5-local": "BASELINE configs[4], locality variant (SURVEY.md 8d): "}[args.config]
+    n_total = args.nodes * world if weak else args.nodes
+    wl += (f"Kipf GCN layer fwd+bwd, random graph {n_total} vertices / {nnz_total} CSR entries, {F} features, fp32"
+           + (f", row-partitioned over {world} GPUs" if world > 1 else ""))
     out = {
         "metric": "msgpass fwd+bwd edges/sec", "value": value, "unit": "edges/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": ("BASELINE configs[1]: " if (args.nodes, args.pairs, F) == (1_000_000, 4_500_000, 128) else "custom size: ")
-                               + f"Kipf GCN layer fwd+bwd, random graph {args.nodes} vertices / {nnz_local} CSR entries per GPU, "
-                                 f"{F} features, fp32",
-                   "vertices_per_gpu": args.nodes, "entries_per_gpu": nnz_local, "features": F,
+        "scaling": "weak" if (weak or world == 1) else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": wl, "vertices": n_total, "entries": nnz_total, "entries_per_gpu": nnz_local, "features": F,
                    "parallelism": f"row-partition x{world}" if world > 1 else "single GPU", **info},
     }
     # dominant kernel: the fused forward launch (CSR gather-aggregate + dense step; HBM bound), timed with HIP events
     # on its launch stream inside the timed loop.  algorithmic bytes = the aggregation's (SURVEY.md 8d:
     # nnz*(4F+8) + N*(4F+8), P written once) + the Z rows written; P is not re-read and W (64 KB) stays in LDS.
-    # At N > 1 it is rank 0's launch over the INTERIOR rows of its shard, which runs while the halo is in flight.
-    agg_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    k_rows = args.nodes if world == 1 else info["interior_rows_per_gpu"]
-    k_nnz = nnz_local if world == 1 else info["interior_entries_per_gpu"]
+    # At N > 1 it is rank 0's larger forward launch: the interior rows of its shard (run while the halo is in flight)
+    # or the boundary rows (run after it), whichever holds more entries.
+    if world == 1:
+        agg_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        k_rows, k_nnz, part = args.nodes, nnz_local, ""
+    else:
+        int_nnz = info["interior_entries_per_gpu"]
+        use_int = int_nnz >= nnz_local - int_nnz and len(ev) > 0
+        pairs = ev if use_int else ev_bnd
+        agg_ms = float(np.mean([a.elapsed_time(b) for a, b in pairs])) if pairs else float("nan")
+        k_rows = info["interior_rows_per_gpu"] if use_int else shard.n - info["interior_rows_per_gpu"]
+        k_nnz = int_nnz if use_int else nnz_local - int_nnz
+        part = (", interior rows of rank 0's shard (halo exchange in flight)" if use_int
+                else ", boundary rows of rank 0's shard (after the halo exchange)")
     alg_bytes = k_nnz * (4 * F + 8) + k_rows * (4 * F + 8) + k_rows * 4 * F
     achieved = alg_bytes / (agg_ms * 1e-3) / 1e9
-    traffic = None
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if world == 1 and os.path.exists(tpath) and (args.nodes, args.pairs, F) == (1_000_000, 4_500_000, 128):
+    if world == 1 and os.path.exists(tpath) and not args.custom and args.config == "c2":
         try:
-            traffic = json.load(open(tpath)).get("agg_gemm_fwd_bytes_per_launch")
+            tj = json.load(open(tpath))
+            traffic = tj.get("agg_gemm_fwd_bytes_per_launch")
+            traffic_source = ("profiles/traffic_latest.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an EARLIER run of "
+                              "this command (2*FETCH_SIZE + WRITE_SIZE, gfx950 correction); not measured by this run -- "
+                              + str(tj.get("source", "")))
         except Exception:
             traffic = None
-    kname = (f"agg_gemm_kernel<{F},coef> (fused kipf_propagate + matmul fwd)" if F in (64, 128) else
-             "kipf_layer_fwd = csr_gather_agg + dense step (two launches at this width)")
-    if world > 1:
-        kname += ", interior rows of rank 0's shard (halo exchange in flight)"
+    fused = F in (64, 128, 256)
+    kname = (f"agg_gemm_kernel<{F},coef> (fused kipf_propagate + matmul fwd)" if fused else
+             "kipf_layer_fwd = csr_gather_agg + dense step (two launches at this width)") + part
     out["roofline"] = {"bound": "hbm", "kernel": kname,
                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                       "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                        "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": agg_ms}
-    if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(ia, ja, x, w, dz, F, args.cpu_sample_rows)
-    if variant is not None:
-        out["uniform_random_variant"] = variant
+    ok = True
+    if world == 1:
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"], ref = cpu_baseline(ia, ja, x, w, dz, F, args.cpu_sample_rows)
+            out["parity"] = parity_single(ref, P, Z, dW, dX)
+            ok = out["parity"]["ok"]
+        else:
+            out["parity"] = None
+    else:
+        out["parity"] = parity_sharded(shard_step, shard, seeds, dev) if not shard_step.transform_first else None
+        ok = out["parity"] is None or out["parity"]["ok"]
+        out["breakdown"] = adist.measure_breakdown(shard_step)
+        out["breakdown"]["note"] = ("each part timed alone after the timed loop, rank 0 (events); in the step the exchanges "
+                                    "run under the interior launches")
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
+        dist.barrier()
         dist.destroy_process_group()
+    if not ok:
+        sys.exit("bench.py: parity against the oracle FAILED (see the 'parity' object of the line above)")
+
+
+def _global_csr(synth, args):
+    """whole-graph CSR of the locality variant on one GPU (Fortran-convention arrays)"""
+    import numpy as np
+    ia, cols = synth.random_graph_csr_rows(args.nodes, args.pairs, 0, args.nodes, locality=args.locality)
+    ja = np.zeros((2, cols.size), np.int32, order="F")
+    ja[0] = cols + 1
+    return ia.astype(np.int32), ja
 
 
 if __name__ == "__main__":
