@@ -44,6 +44,9 @@ _PROTOS = {
     "athena_mp_kipf_propagate_fwd": [_vp, _i32, _vp, _vp],
     "athena_mp_kipf_propagate_bwd": [_vp, _i32, _vp, _vp, _i32],
     "athena_mp_kipf_propagate_act_fwd": [_vp, _i32, _vp, _i32, _vp],
+    "athena_mp_reverse_kipf_propagate_fwd": [_vp, _i32, _vp, _vp],
+    "athena_mp_reverse_kipf_propagate_partial": [_vp, _i32, _vp, _vp],
+    "athena_mp_reverse_kipf_propagate_partial_val": [_vp, _i32, _vp, _vp],
     "athena_mp_kipf_propagate_bwd_dual": [_vp, _i32, _vp, _vp, _vp],
     "athena_mp_kipf_propagate_fwd_dual": [_vp, _i32, _vp, _vp, _vp],
     "athena_mp_gather_rows": [_i64, _i32, _vp, _vp, _vp],

@@ -360,6 +360,20 @@ int athena_mp_kipf_propagate_bwd(const athena_mp_graph *g, int32_t F, const floa
     return gather_agg(g->t_rowptr, g->t_src, exact ? g->t_coef : nullptr, grad, F, dx, F, g->n_cols, F, &g->lp_bwd);
 }
 
+/* reverse_kipf_propagate and its two partial forms (athena_diffstruc_extd_sub_kipf.f90:116-205) */
+int athena_mp_reverse_kipf_propagate_fwd(const athena_mp_graph *g, int32_t F, const float *a, float *c)
+{
+    return athena_mp_kipf_propagate_bwd(g, F, a, c, 0);
+}
+int athena_mp_reverse_kipf_propagate_partial(const athena_mp_graph *g, int32_t F, const float *upstream, float *out)
+{
+    return athena_mp_kipf_propagate_fwd(g, F, upstream, out);
+}
+int athena_mp_reverse_kipf_propagate_partial_val(const athena_mp_graph *g, int32_t F, const float *upstream, float *out)
+{
+    return athena_mp_kipf_propagate_bwd(g, F, upstream, out, 0);
+}
+
 /* the pull form of the same pair on a row shard (athena_amd/dist.py): over the FORWARD rows of g,
  * y_plain[v] = sum_w x[col w], y_coef[v] = sum_w coef_w x[col w] -- one gather of the (local + halo) rows */
 int athena_mp_kipf_propagate_fwd_dual(const athena_mp_graph *g, int32_t F, const float *x, float *y_plain, float *y_coef)
@@ -412,19 +426,17 @@ int athena_mp_gather_rows(int64_t n, int32_t F, const int32_t *idx, const float 
     if (n == 0) return 0;
     AMP_REQUIRE(idx && x && out, "gather_rows: null pointer");
     // identity row pointer [0,1,..,n]: every output row has exactly one entry
-    static int32_t *iota = nullptr;
-    static int64_t iota_n = 0;
-    if (iota_n < n + 1) {
-        if (iota) {
-            AMP_HIP(hipStreamSynchronize(stream()));
-            AMP_HIP(hipFree(iota));
-        }
-        int64_t want = n + 1 + (n >> 2);
+    static int64_t iota_n[amp::kMaxDevices] = {};      // elements of the per-device buffer "agg.iota"
+    int32_t *iota = nullptr;
+    int64_t &have = iota_n[amp::device()];
+    const int64_t want = have < n + 1 ? n + 1 + (n >> 2) : have;
+    bool fresh = false;
+    if (amp::named_buffer("agg.iota", sizeof(int32_t) * (size_t)want, false, (void **)&iota, &fresh)) return 1;
+    if (fresh) {
         std::vector<int32_t> h(want);
         for (int64_t i = 0; i < want; ++i) h[i] = (int32_t)i;
-        AMP_HIP(hipMalloc((void **)&iota, sizeof(int32_t) * want));
         AMP_HIP(hipMemcpy(iota, h.data(), sizeof(int32_t) * want, hipMemcpyHostToDevice));
-        iota_n = want;
+        have = want;
     }
     return gather_agg(iota, idx, nullptr, x, F, out, F, (int32_t)n, F);
 }

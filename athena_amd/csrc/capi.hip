@@ -9,6 +9,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
+#include <string>
 #include <vector>
 
 #include "common.h"
@@ -17,8 +19,20 @@ namespace amp {
 
 static thread_local char g_err[1024] = "";
 static hipStream_t g_stream = nullptr;
-static void *g_ws[8] = {};
-static size_t g_ws_bytes[8] = {};
+struct NamedBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+struct DevCtx {
+    void *ws[8] = {};
+    size_t ws_bytes[8] = {};
+    std::map<std::string, NamedBuf> named;
+    int cus = 0;
+};
+static DevCtx g_ctx[kMaxDevices];
+static int g_device = 0;
+#define g_ws g_ctx[g_device].ws
+#define g_ws_bytes g_ctx[g_device].ws_bytes
 
 void set_error(const char *fmt, ...)
 {
@@ -28,6 +42,36 @@ void set_error(const char *fmt, ...)
     va_end(ap);
 }
 hipStream_t stream() { return g_stream; }
+int device() { return g_device; }
+int num_cus()
+{
+    DevCtx &c = g_ctx[g_device];
+    if (c.cus <= 0) {
+        hipDeviceProp_t p;
+        c.cus = (hipGetDeviceProperties(&p, g_device) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+    }
+    return c.cus;
+}
+
+int named_buffer(const char *name, size_t bytes, bool zero_fill, void **ptr, bool *fresh)
+{
+    NamedBuf &b = g_ctx[g_device].named[name];
+    if (fresh) *fresh = false;
+    if (b.bytes < bytes || b.p == nullptr) {
+        if (b.p) {
+            AMP_HIP(hipStreamSynchronize(g_stream));
+            AMP_HIP(hipFree(b.p));
+            b.p = nullptr;
+            b.bytes = 0;
+        }
+        AMP_HIP(hipMalloc(&b.p, bytes ? bytes : 4));
+        b.bytes = bytes;
+        if (zero_fill) AMP_HIP(hipMemset(b.p, 0, bytes ? bytes : 4));
+        if (fresh) *fresh = true;
+    }
+    *ptr = b.p;
+    return 0;
+}
 
 int workspace(void **ptr, size_t bytes, int slot)
 {
@@ -67,18 +111,28 @@ int athena_mp_init(int device)
     AMP_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0,
                 "athena_mp_init: built for gfx950 (MI355X) only, device %d is %s", device,
                 prop.gcnArchName);
+    AMP_REQUIRE(device < kMaxDevices, "athena_mp_init: device %d beyond the %d this library tracks", device, kMaxDevices);
+    if (device != g_device) g_stream = nullptr;   // the stream of the previous device does not carry over
+    g_device = device;
+    g_ctx[device].cus = prop.multiProcessorCount;
     return 0;
 }
 
 int athena_mp_finalize(void)
 {
     amp::host_pool_release();
-    for (int s = 0; s < 8; ++s) {
-        if (g_ws[s]) {
-            AMP_HIP(hipFree(g_ws[s]));
-            g_ws[s] = nullptr;
-            g_ws_bytes[s] = 0;
+    for (int d = 0; d < kMaxDevices; ++d) {       // every device this process initialised
+        DevCtx &c = g_ctx[d];
+        for (int s = 0; s < 8; ++s) {
+            if (c.ws[s]) {
+                AMP_HIP(hipFree(c.ws[s]));
+                c.ws[s] = nullptr;
+                c.ws_bytes[s] = 0;
+            }
         }
+        for (auto &kv : c.named)
+            if (kv.second.p) AMP_HIP(hipFree(kv.second.p));
+        c.named.clear();
     }
     return 0;
 }
@@ -180,6 +234,7 @@ static int build_long_plan(const std::vector<int32_t> &rowptr, int32_t n_rows, L
     rc |= upload(&lp->task_end, end);
     rc |= upload(&lp->row_id, rid);
     rc |= upload(&lp->row_task0, t0);
+    if (rc == 0) AMP_HIP(hipStreamSynchronize(stream()));   // beg / end / rid / t0 die at return: the copies must be done
     return rc;
 }
 
@@ -294,6 +349,7 @@ static int graph_create_impl(int32_t n_rows, int32_t n_cols, int64_t nnz, const 
                              const int32_t *row_deg, const int32_t *col_deg, athena_mp_graph **out)
 {
     *out = nullptr;
+    g_err[0] = 0;   // the "allocation failed" fallbacks below only fill in when no callee left a message in THIS call
     AMP_REQUIRE(n_rows >= 0 && n_cols >= 0 && nnz >= 0 && n_edge_cols >= 0, "graph_create: negative size");
     AMP_REQUIRE(nnz < (int64_t)INT32_MAX, "graph_create: nnz %lld exceeds int32 CSR", (long long)nnz);
     AMP_REQUIRE(adj_ia != nullptr && (nnz == 0 || adj_ja != nullptr || adj_ja_dev != nullptr), "graph_create: null CSR arrays");

@@ -34,8 +34,23 @@ hipStream_t stream();
 
 #define AMP_LAUNCH_CHECK() AMP_HIP(hipGetLastError())
 
-// workspace owned by the library (grown on demand, never shrunk; stream-ordered reuse)
+// workspace owned by the library (grown on demand, never shrunk; stream-ordered reuse); per device
 int workspace(void **ptr, size_t bytes, int slot = 0);
+
+// Everything the library keeps on a device belongs to the device athena_mp_init selected: the workspaces above, the
+// named buffers below (ticket ring, identity row pointer, zero bias ...) and the "attribute set" flags of kernels with
+// more than 64 KB of LDS.  athena_mp_finalize releases the buffers of every device; a second athena_mp_init for
+// another device gets buffers of its own.
+constexpr int kMaxDevices = 32;
+int device();        // the device athena_mp_init selected (0 before the first call)
+int num_cus();       // its compute units (256 on MI355X)
+// a device buffer of at least `bytes` under `name` on the current device.  *fresh is set when it was (re)allocated --
+// its contents are then undefined (or zero with zero_fill) and the caller initialises them.
+int named_buffer(const char *name, size_t bytes, bool zero_fill, void **ptr, bool *fresh = nullptr);
+struct PerDeviceFlag {
+    bool done[kMaxDevices] = {};
+    bool &get() { return done[device()]; }
+};
 
 } // namespace amp
 

@@ -238,16 +238,16 @@ int launch_fused(const int32_t *rowptr, const int32_t *idx, const float *coef, c
 {
     constexpr int CHr = 16 * (64 / (N / 4));
     constexpr size_t lds = sizeof(float) * ((size_t)N * (N + 4) + 2 * CHr * (N + 4));
-    static bool attr = false;
-    if (!attr) {
+    static amp::PerDeviceFlag attr;
+    if (!attr.get()) {
         AMP_HIP(hipFuncSetAttribute((const void *)agg_gemm_kernel<N, COEF, ACT>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
+        attr.get() = true;
     }
-    // chunk ticket counter: one 8-byte word per launch from a small ring, zeroed on the stream
-    static unsigned long long *ring = nullptr;
+    // chunk ticket counter: one 8-byte word per launch from a small per-device ring, zeroed on the stream
     static int slot = 0;
-    if (!ring) AMP_HIP(hipMalloc((void **)&ring, sizeof(unsigned long long) * 64));
+    unsigned long long *ring = nullptr;
+    if (amp::named_buffer("fused.ticket_ring", sizeof(unsigned long long) * 64, true, (void **)&ring)) return 1;
     unsigned long long *ticket = ring + (slot++ & 63);
     AMP_HIP(hipMemsetAsync(ticket, 0, sizeof(unsigned long long), amp::stream()));
     hipLaunchKernelGGL((agg_gemm_kernel<N, COEF, ACT>), dim3(grid), dim3(1024), lds, amp::stream(), rowptr, idx, coef, x,
@@ -265,10 +265,7 @@ int fused_dispatch(const int32_t *rowptr, const int32_t *idx, const float *coef,
         amp::set_error("fused Kipf layer kernel: built for 64 -> 64 and 128 -> 128 features, got %d -> %d", K, N);
         return 2;
     }
-    int dev = 0;
-    hipDeviceProp_t prop;
-    int cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    const int cus = amp::num_cus();
     const int ch = 16 * (64 / (N / 4));
     const int grid = (int)std::min<int64_t>((n_rows + ch - 1) / ch, cus);
     if (grid == 0) return 0;

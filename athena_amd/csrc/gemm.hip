@@ -510,29 +510,18 @@ __global__ void gemm_dw_small_kernel(const float *__restrict__ P, const float *_
     }
 }
 
-int g_num_cu = 0;
-int num_cu()
-{
-    if (!g_num_cu) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
-            g_num_cu = p.multiProcessorCount;
-        if (g_num_cu <= 0) g_num_cu = 256;
-    }
-    return g_num_cu;
-}
+int num_cu() { return amp::num_cus(); }
 
 template <int K, int N, int ACT, bool BIAS>
 int launch_bres8(const float *A, const float *B, int b_nk, const float *bias, float *Z, int64_t M)
 {
     constexpr int LDW = ((K > N ? K : N) / 2) + 4;
     constexpr size_t lds = sizeof(float) * ((size_t)N * (K + 4) + 8 * 32 * LDW);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static amp::PerDeviceFlag attr_done;
+    if (!attr_done.get()) {
         AMP_HIP(hipFuncSetAttribute((const void *)gemm_bres8_kernel<K, N, ACT, BIAS>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+        attr_done.get() = true;
     }
     int64_t n_slabs = (M + 31) / 32;
     int grid = (int)std::min<int64_t>((n_slabs + 7) / 8, num_cu());
@@ -550,11 +539,11 @@ int launch_bres2(const float *A, const float *B, int b_nk, const float *bias, fl
         if (!four) return launch_bres8<K, N, ACT, BIAS>(A, B, b_nk, bias, Z, M);
     }
     constexpr size_t lds = sizeof(float) * ((size_t)N * (K + 4) + 4 * 32 * ((K > N ? K : N) + 4));
-    static bool attr_done = false;
-    if (!attr_done) {
+    static amp::PerDeviceFlag attr_done;
+    if (!attr_done.get()) {
         AMP_HIP(hipFuncSetAttribute((const void *)gemm_bres_kernel<K, N, ACT, BIAS>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+        attr_done.get() = true;
     }
     int64_t n_slabs = (M + 31) / 32;
     int grid = (int)std::min<int64_t>((n_slabs + 3) / 4, num_cu());
@@ -568,12 +557,9 @@ template <int K, int N>
 int launch_bres(const float *A, const float *B, int b_nk, const float *bias, int act, float *Z, int64_t M)
 {
     if (!bias && act == ATHENA_MP_ACT_NONE) return launch_bres2<K, N, ATHENA_MP_ACT_NONE, false>(A, B, b_nk, bias, Z, M);
-    static float *zero_bias = nullptr; // bias-free activations reuse the BIAS=true kernels
-    if (!bias) {
-        if (!zero_bias) {
-            AMP_HIP(hipMalloc((void **)&zero_bias, sizeof(float) * 256));
-            AMP_HIP(hipMemset(zero_bias, 0, sizeof(float) * 256));
-        }
+    if (!bias) {   // bias-free activations reuse the BIAS=true kernels
+        float *zero_bias = nullptr;
+        if (amp::named_buffer("gemm.zero_bias", sizeof(float) * 256, true, (void **)&zero_bias)) return 1;
         bias = zero_bias;
     }
     switch (act) {

@@ -336,10 +336,10 @@ int gemm_tiled(const TiledArgs &p)
         p.act == ATHENA_MP_ACT_NONE && p.a_div == 1.0f && p.c_div == 1.0f && p.lda == AR_K && p.ldb == AR_K &&
         p.ldc == p.N && (uintptr_t)p.A % 16 == 0 && (uintptr_t)p.B % 16 == 0) {
         constexpr size_t lds = sizeof(float) * (size_t)(AR_BM + 128) * AR_LD;
-        static bool attr = false;
-        if (!attr) {
+        static amp::PerDeviceFlag attr;
+        if (!attr.get()) {
             AMP_HIP(hipFuncSetAttribute((const void *)gemm_arow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr = true;
+            attr.get() = true;
         }
         hipLaunchKernelGGL(gemm_arow_kernel, dim3((unsigned)((p.M + AR_BM - 1) / AR_BM)), dim3(256), lds, stream(), p.A, p.B,
                            p.C, p.M, p.N);

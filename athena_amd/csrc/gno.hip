@@ -383,10 +383,10 @@ int launch_gno_fused(const int32_t *rowptr, const int32_t *idx, const int32_t *e
 {
     if (n_rows > 0 && length_order(rowptr, n_rows, perm_cache)) return 1;
     constexpr size_t lds = sizeof(float) * (size_t)kGRows * kGSP;
-    static bool attr = false;
-    if (!attr) {
+    static amp::PerDeviceFlag attr;
+    if (!attr.get()) {
         AMP_HIP(hipFuncSetAttribute((const void *)gno_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
+        attr.get() = true;
     }
     if (n_rows <= 0) return 0;
     const int n_tiles = (n_rows + kGRows - 1) / kGRows;
@@ -900,11 +900,11 @@ int gno_mlp_backward(const athena_mp_graph *g, int d, int H, int Fi, int Fo, con
         const int nwg = std::min(n_tiles, 256);
         if (amp::workspace(&sl, sizeof(float) * (size_t)nwg * 16 * np, 3)) return 1;
         constexpr size_t glds = sizeof(float) * ((size_t)kGRows * kDVtx + 16 * 128);   // G half + per-wave coordinates
-        static bool gattr = false;
-        if (!gattr) {
+        static amp::PerDeviceFlag gattr;
+        if (!gattr.get()) {
             AMP_HIP(hipFuncSetAttribute((const void *)gno_gdh_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
             AMP_HIP(hipFuncSetAttribute((const void *)gno_gdh_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
-            gattr = true;
+            gattr.get() = true;
         }
         if (ghbuf)
             hipLaunchKernelGGL(gno_gdh_kernel<true>, dim3(nwg), dim3(1024), glds, amp::stream(), g->rowptr, g->col, g->eid, x,
@@ -928,10 +928,10 @@ int gno_mlp_backward(const athena_mp_graph *g, int d, int H, int Fi, int Fo, con
     }
     const int tile = tile_rows_for(g->n_rows, HF);
     const size_t lds = sizeof(float) * ((size_t)H * (Fi + 1) + (size_t)kEB * (Fi + H) + np);
-    static bool attr = false;
-    if (!attr) {
+    static amp::PerDeviceFlag attr;
+    if (!attr.get()) {
         AMP_HIP(hipFuncSetAttribute((const void *)gno_dh_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
+        attr.get() = true;
     }
     bool first = true;
     for (int r0 = 0; r0 < g->n_rows; r0 += tile) {

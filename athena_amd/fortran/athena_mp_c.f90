@@ -27,6 +27,8 @@ module athena_mp_c
   public :: athena_mp_activation_param_fwd, athena_mp_activation_param_bwd
   public :: athena_mp_memset_zero, athena_mp_activation_fwd, athena_mp_axpy, athena_mp_kipf_propagate_bwd_dual
   public :: athena_mp_kipf_propagate_act_fwd
+  public :: athena_mp_reverse_kipf_propagate_fwd, athena_mp_reverse_kipf_propagate_partial
+  public :: athena_mp_reverse_kipf_propagate_partial_val
   public :: athena_mp_duvenaud_propagate_fwd, athena_mp_duvenaud_propagate_bwd_x, athena_mp_duvenaud_propagate_bwd_e
   public :: athena_mp_duvenaud_update_bwd_a, athena_mp_duvenaud_update_bwd_w
   public :: athena_mp_segment_sum, athena_mp_segment_sum_bwd
@@ -157,6 +159,25 @@ module athena_mp_c
        import :: c_int, c_int32_t, c_ptr
        type(c_ptr), value :: graph, g_dev, dx_dev
        integer(c_int32_t), value :: F, exact
+     end function
+     !! reverse_kipf_propagate and its partials, athena_diffstruc_extd_sub_kipf.f90:116-205
+     integer(c_int) function athena_mp_reverse_kipf_propagate_fwd(graph, F, a_dev, c_dev) &
+          bind(C, name="athena_mp_reverse_kipf_propagate_fwd")
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: graph, a_dev, c_dev
+       integer(c_int32_t), value :: F
+     end function
+     integer(c_int) function athena_mp_reverse_kipf_propagate_partial(graph, F, up_dev, out_dev) &
+          bind(C, name="athena_mp_reverse_kipf_propagate_partial")
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: graph, up_dev, out_dev
+       integer(c_int32_t), value :: F
+     end function
+     integer(c_int) function athena_mp_reverse_kipf_propagate_partial_val(graph, F, up_dev, out_dev) &
+          bind(C, name="athena_mp_reverse_kipf_propagate_partial_val")
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: graph, up_dev, out_dev
+       integer(c_int32_t), value :: F
      end function
      integer(c_int) function athena_mp_gemm_fwd(N, Fi, Fo, P_dev, W_dev, bias_dev, act, Z_dev) &
           bind(C, name="athena_mp_gemm_fwd")

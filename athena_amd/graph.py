@@ -22,6 +22,7 @@ class graph_type:
     """Undirected sparse graph in athena's CSR convention."""
 
     def __init__(self):
+        self._version = 0
         self.num_vertices = 0
         self.num_edges = 0
         self.num_vertex_features = 0
@@ -31,6 +32,42 @@ class graph_type:
         self.vertex_features = None  # [num_vertices, Fv]
         self.edge_features = None    # [num_edges, Fe]
         self.is_sparse = True
+
+    # adjacency arrays: assigning either one (generate_adjacency, add_self_loops, from_csr, user code) bumps a version
+    # counter that the layers' device-handle cache keys on
+    @property
+    def adj_ia(self):
+        return self._adj_ia
+
+    @adj_ia.setter
+    def adj_ia(self, a):
+        self._adj_ia = a
+        self._version += 1
+
+    @property
+    def adj_ja(self):
+        return self._adj_ja
+
+    @adj_ja.setter
+    def adj_ja(self, a):
+        self._adj_ja = a
+        self._version += 1
+
+    def topology_key(self):
+        """what a cached device handle of this graph is valid for: the object, its version (bumped by every assignment
+        of adj_ia / adj_ja), the sizes and a checksum of the arrays' CONTENT -- all of it below 2^18 entries, a strided
+        sample plus head and tail above (in-place edits of a mini-batch graph are always seen; hashing 80 MB per
+        forward on a 10 M-entry graph would cost more than the layer step)."""
+        import xxhash
+        ia, ja = np.ascontiguousarray(self._adj_ia), self._adj_ja
+        h = xxhash.xxh3_64()
+        if ja.shape[1] < (1 << 18):
+            h.update(ia.tobytes()); h.update(np.asfortranarray(ja).tobytes(order="F"))
+        else:
+            st_i, st_j = max(1, ia.size // 4096), max(1, ja.shape[1] // 4096)
+            for part in (ia[:1024], ia[-1024:], ia[::st_i], ja[:, :1024], ja[:, -1024:], ja[:, ::st_j]):
+                h.update(np.ascontiguousarray(part).tobytes())
+        return (id(self), self._version, int(self.num_vertices), int(ja.shape[1]), h.intdigest())
 
     # -- graphstruc API used by the reference's tests (test_kipf_msgpass_layer.f90:71-100) -------
     def set_num_vertices(self, n, num_features=0):

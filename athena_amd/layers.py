@@ -111,10 +111,13 @@ class msgpass_layer_type:
         """athena_msgpass_layer_sub.f90:144-174; here the device handle is built once and cached"""
         if isinstance(graphs, graph_type):
             graphs = [graphs]
-        key = tuple(id(g) for g in graphs)
+        # the cache is keyed on CONTENT (object, version, sizes, checksum of adj_ia / adj_ja), and the layer holds the
+        # graph objects so that an id cannot be recycled for a new graph while the key is alive
+        key = tuple(g.topology_key() for g in graphs)
         if getattr(self, "_graph_key", None) != key:
             self.graph = _batched_graph(graphs, self.device.index or 0, self._needs_edges)
             self._graph_key = key
+            self._graph_refs = list(graphs)
             self._seg = torch.from_numpy(self.graph.vertex_offsets).to(self.device)
         return self
 

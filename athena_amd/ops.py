@@ -67,6 +67,34 @@ def kipf_propagate_bwd(g: DeviceGraph, grad, exact=False, out=None):
     return dx
 
 
+def reverse_kipf_propagate(g: DeviceGraph, a, out=None):
+    """reverse_kipf_propagate, athena_diffstruc_extd_sub_kipf.f90:116-158: c[u] = sum of a[v] over the entries (v -> u),
+    no coefficient (the node of the higher-order path; its value is the scatter of get_partial_kipf_propagate_left_val)"""
+    F = a.shape[1]
+    _chk(a, (g.n_rows, F))
+    c = out if out is not None else torch.empty((g.n_cols, F), device=a.device, dtype=torch.float32)
+    _go()
+    _capi.call("athena_mp_reverse_kipf_propagate_fwd", g.handle, F, _p(a), _p(_chk(c, (g.n_cols, F))))
+    return c
+
+
+def reverse_kipf_propagate_partial(g: DeviceGraph, upstream, val_form=False, out=None):
+    """partial of reverse_kipf_propagate wrt its operand: the function form (:159-175) is kipf_propagate(upstream) WITH
+    the coefficient, the `_val` form (:176-205) is the coefficient-free scatter again -- the reference as written"""
+    F = upstream.shape[1]
+    if val_form:
+        _chk(upstream, (g.n_rows, F))
+        y = out if out is not None else torch.empty((g.n_cols, F), device=upstream.device, dtype=torch.float32)
+        _go()
+        _capi.call("athena_mp_reverse_kipf_propagate_partial_val", g.handle, F, _p(upstream), _p(_chk(y, (g.n_cols, F))))
+        return y
+    _chk(upstream, (g.n_cols, F))
+    y = out if out is not None else torch.empty((g.n_rows, F), device=upstream.device, dtype=torch.float32)
+    _go()
+    _capi.call("athena_mp_reverse_kipf_propagate_partial", g.handle, F, _p(upstream), _p(_chk(y, (g.n_rows, F))))
+    return y
+
+
 def kipf_propagate_bwd_dual(g: DeviceGraph, grad):
     """both reverse forms of kipf_propagate from one gather of the upstream rows: (coefficient-free scatter of the
     reference, adjoint of the forward)"""
@@ -121,6 +149,9 @@ def matmul(W, P, Fo, bias=None, act="none", out=None):
     if not (W.numel() == Fo * Fi):
         raise ValueError('expected: W.numel() == Fo * Fi')
     Z = out if out is not None else torch.empty((N, Fo), device=P.device, dtype=torch.float32)
+    _chk(Z, (N, Fo))
+    if bias is not None:
+        _chk(bias, (Fo,))
     _go()
     _capi.call("athena_mp_gemm_fwd", N, Fi, Fo, _p(P), _p(_chk(W)), _p(bias), ACT[act], _p(Z))
     return Z
@@ -132,6 +163,8 @@ def matmul_dw(P, dZ, out=None):
     Fo = dZ.shape[1]
     _chk(P); _chk(dZ, (N, Fo))
     dW = out if out is not None else torch.empty(Fo * Fi, device=P.device, dtype=torch.float32)
+    if _chk(dW).numel() != Fo * Fi:
+        raise ValueError(f"dW holds {dW.numel()} values, expected {Fo * Fi}")
     _go()
     _capi.call("athena_mp_gemm_dw", N, Fi, Fo, _p(P), _p(dZ), _p(dW))
     return dW
@@ -144,6 +177,7 @@ def matmul_dx(W, dZ, Fi, out=None):
     if not (W.numel() == Fo * Fi):
         raise ValueError('expected: W.numel() == Fo * Fi')
     dP = out if out is not None else torch.empty((N, Fi), device=dZ.device, dtype=torch.float32)
+    _chk(dP, (N, Fi))
     _go()
     _capi.call("athena_mp_gemm_dx", N, Fi, Fo, _p(dZ), _p(_chk(W)), _p(dP))
     return dP
@@ -155,6 +189,11 @@ def kipf_layer_fwd(g: DeviceGraph, x, W, Fo, bias=None, act="none", P=None, Z=No
     _chk(x, (g.n_cols, Fi))
     P = P if P is not None else torch.empty((g.n_rows, Fi), device=x.device, dtype=torch.float32)
     Z = Z if Z is not None else torch.empty((g.n_rows, Fo), device=x.device, dtype=torch.float32)
+    _chk(P, (g.n_rows, Fi)); _chk(Z, (g.n_rows, Fo))
+    if _chk(W).numel() != Fo * Fi:
+        raise ValueError(f"W holds {W.numel()} values, expected Fo*Fi = {Fo * Fi}")
+    if bias is not None:
+        _chk(bias, (Fo,))
     _go()
     _capi.call("athena_mp_kipf_layer_fwd", g.handle, Fi, Fo, _p(x), _p(_chk(W)), _p(bias), ACT[act], _p(P), _p(Z))
     return P, Z
@@ -165,6 +204,9 @@ def kipf_layer_bwd_x(g: DeviceGraph, dZ, W, Fi, exact=False, out=None):
     Fo = dZ.shape[1]
     _chk(dZ, (g.n_rows, Fo))
     dX = out if out is not None else torch.empty((g.n_cols, Fi), device=dZ.device, dtype=torch.float32)
+    _chk(dX, (g.n_cols, Fi))
+    if _chk(W).numel() != Fo * Fi:
+        raise ValueError(f"W holds {W.numel()} values, expected Fo*Fi = {Fo * Fi}")
     _go()
     _capi.call("athena_mp_kipf_layer_bwd_x", g.handle, Fi, Fo, _p(dZ), _p(_chk(W)), int(bool(exact)), _p(dX))
     return dX
@@ -175,6 +217,9 @@ def pull_gemm(g: DeviceGraph, dZ, W, Fi, exact=False, out=None):
     Fo = dZ.shape[1]
     _chk(dZ, (g.n_cols, Fo))
     dX = out if out is not None else torch.empty((g.n_rows, Fi), device=dZ.device, dtype=torch.float32)
+    _chk(dX, (g.n_rows, Fi))
+    if _chk(W).numel() != Fo * Fi:
+        raise ValueError(f"W holds {W.numel()} values, expected Fo*Fi = {Fo * Fi}")
     _go()
     _capi.call("athena_mp_pull_gemm", g.handle, Fi, Fo, _p(dZ), _p(_chk(W)), int(bool(exact)), _p(dX))
     return dX
@@ -325,8 +370,9 @@ def axpy(alpha, x, y):
 def duvenaud_propagate(g: DeviceGraph, x, e, out=None):
     """athena_diffstruc_extd_sub_duvenaud.f90:7-59"""
     Fv, Fe = x.shape[1], e.shape[1]
-    _chk(x, (g.n_cols, Fv)); _chk(e)
+    _chk(x, (g.n_cols, Fv)); _chk(e, (g.n_edge_cols, Fe))
     c = out if out is not None else torch.empty((g.n_rows, Fv + Fe), device=x.device, dtype=torch.float32)
+    _chk(c, (g.n_rows, Fv + Fe))
     _go()
     _capi.call("athena_mp_duvenaud_propagate_fwd", g.handle, Fv, Fe, _p(x), _p(e), _p(c))
     return c
@@ -475,7 +521,7 @@ def duvenaud_readout_bwd(R, z, p, seg, gout, act="none", dz_next=None):
 def gno_aggregate(g: DeviceGraph, theta, coords, x, d, H, Fo):
     """gno_kernel_eval + gno_aggregate (athena_diffstruc_extd_sub_nop.f90:26-115, :330-397) fused"""
     Fi = x.shape[1]
-    _chk(x, (g.n_cols, Fi)); _chk(coords); _chk(theta)
+    _chk(x, (g.n_cols, Fi)); _chk(coords, (g.n_edge_cols, d)); _chk(theta)
     if not (theta.numel() == H * d + H + Fo * Fi * H + Fo * Fi):
         raise ValueError('expected: theta.numel() == H * d + H + Fo * Fi * H + Fo * Fi')
     m = torch.empty((g.n_rows, Fo), device=x.device, dtype=torch.float32)
@@ -486,7 +532,9 @@ def gno_aggregate(g: DeviceGraph, theta, coords, x, d, H, Fo):
 
 def gno_aggregate_bwd_x(g: DeviceGraph, theta, coords, grad, d, H, Fi):
     Fo = grad.shape[1]
-    _chk(grad, (g.n_rows, Fo))
+    _chk(grad, (g.n_rows, Fo)); _chk(coords, (g.n_edge_cols, d))
+    if _chk(theta).numel() != H * d + H + Fo * Fi * H + Fo * Fi:
+        raise ValueError("theta: expected H*d + H + Fo*Fi*H + Fo*Fi values")
     dx = torch.empty((g.n_cols, Fi), device=grad.device, dtype=torch.float32)
     _go()
     _capi.call("athena_mp_gno_aggregate_bwd_x", g.handle, d, H, Fi, Fo, _p(theta), _p(coords), _p(grad), _p(dx))
@@ -495,6 +543,9 @@ def gno_aggregate_bwd_x(g: DeviceGraph, theta, coords, grad, d, H, Fi):
 
 def gno_aggregate_bwd_theta(g: DeviceGraph, theta, coords, x, grad, d, H):
     Fi, Fo = x.shape[1], grad.shape[1]
+    _chk(x, (g.n_cols, Fi)); _chk(grad, (g.n_rows, Fo)); _chk(coords, (g.n_edge_cols, d))
+    if _chk(theta).numel() != H * d + H + Fo * Fi * H + Fo * Fi:
+        raise ValueError("theta: expected H*d + H + Fo*Fi*H + Fo*Fi values")
     dth = torch.empty_like(theta)
     _go()
     _capi.call("athena_mp_gno_aggregate_bwd_theta", g.handle, d, H, Fi, Fo, _p(theta), _p(coords), _p(x), _p(grad), _p(dth))
@@ -503,6 +554,9 @@ def gno_aggregate_bwd_theta(g: DeviceGraph, theta, coords, x, grad, d, H):
 
 def gno_aggregate_bwd_coords(g: DeviceGraph, theta, coords, x, grad, d, H):
     Fi, Fo = x.shape[1], grad.shape[1]
+    _chk(x, (g.n_cols, Fi)); _chk(grad, (g.n_rows, Fo)); _chk(coords, (g.n_edge_cols, d))
+    if _chk(theta).numel() != H * d + H + Fo * Fi * H + Fo * Fi:
+        raise ValueError("theta: expected H*d + H + Fo*Fi*H + Fo*Fi values")
     dc = torch.empty_like(coords)
     _go()
     _capi.call("athena_mp_gno_aggregate_bwd_coords", g.handle, d, H, Fi, Fo, _p(theta), _p(coords), _p(x), _p(grad), _p(dc))

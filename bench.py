@@ -132,16 +132,25 @@ def cpu_baseline(ia, ja, x, w, dz, F, sample_rows):
     return out, dict(rows=rows, full=(rows == n), p=p, z=z, dw=dw, dx=dx)
 
 
-def parity_single(ref, P, Z, dW, dX):
-    """device results of the last timed step against the oracle's (whole workload when the oracle ran all rows)"""
+def parity_single(ref, P, Z, dW, dX, dz_host):
+    """device results of the last timed step against the oracle's (whole workload when the oracle ran all rows).
+    dW is a sum over 10^6 vertices: the oracle adds them sequentially in fp32 and is itself ~3e-5 from the exact sum,
+    so dW passes when it is within 1e-5 of the oracle OR no further from float64 than the oracle is plus 1e-5
+    (|gpu - f64| <= |oracle - f64| + 1e-5 scale); all three distances are reported."""
     import numpy as np
     r = ref["rows"]
     out = {"against": "oracle (C port of the reference loops), " + ("all rows" if ref["full"] else f"first {r} rows (dW, dX need all rows: null)"),
            "P_bit_exact": bool(np.array_equal(P[:r].cpu().numpy(), ref["p"])),
            "Z_rel": rel(Z[:r].cpu().numpy(), ref["z"]),
-           "dW_rel": rel(dW.cpu().numpy(), ref["dw"]) if ref["full"] else None,
+           "dW_rel": None, "dW_rel_vs_float64": None, "dW_oracle_rel_vs_float64": None,
            "dX_rel": rel(dX.cpu().numpy(), ref["dx"]) if ref["full"] else None, "tol": TOL}
-    out["ok"] = bool(out["P_bit_exact"] and all(v is None or v <= TOL for v in (out["Z_rel"], out["dW_rel"], out["dX_rel"])))
+    dw_ok = True
+    if ref["full"]:
+        dw = dW.cpu().numpy()
+        f64 = (ref["p"].astype(np.float64).T @ dz_host.astype(np.float64)).reshape(-1)   # dW(Fo,Fi) column-major = P^T dZ
+        out["dW_rel"], out["dW_rel_vs_float64"], out["dW_oracle_rel_vs_float64"] = rel(dw, ref["dw"]), rel(dw, f64), rel(ref["dw"], f64)
+        dw_ok = out["dW_rel"] <= TOL or out["dW_rel_vs_float64"] <= out["dW_oracle_rel_vs_float64"] + TOL
+    out["ok"] = bool(out["P_bit_exact"] and dw_ok and all(v is None or v <= TOL for v in (out["Z_rel"], out["dX_rel"])))
     return out
 
 
@@ -376,7 +385,7 @@ def main():
     if world == 1:
         if not args.no_cpu_baseline:
             out["cpu_baseline"], ref = cpu_baseline(ia, ja, x, w, dz, F, args.cpu_sample_rows)
-            out["parity"] = parity_single(ref, P, Z, dW, dX)
+            out["parity"] = parity_single(ref, P, Z, dW, dX, dz)
             ok = out["parity"]["ok"]
         else:
             out["parity"] = None

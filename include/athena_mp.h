@@ -110,6 +110,16 @@ int athena_mp_kipf_propagate_act_fwd(const athena_mp_graph *g, int32_t F, const 
  *   exact=1: multiplied by the coefficient, the mathematically exact adjoint) */
 int athena_mp_kipf_propagate_bwd(const athena_mp_graph *g, int32_t F, const float *grad_dev,
                                  float *dx_dev, int32_t exact);
+/* reverse_kipf_propagate, ..._sub_kipf.f90:116-158 (the node the higher-order path builds; grad_reverse does not
+ * reach it):   c[u,:] = sum_{(v,w): ja(1,w)=u} a[v,:]   -- the coefficient-free scatter again, a [n_rows,F] -> c [n_cols,F].
+ * Its partials: the FUNCTION form get_partial_left_reverse_kipf_propagate (:159-175) is kipf_propagate(upstream)
+ * (with the coefficient), upstream [n_cols,F] -> out [n_rows,F]; the _val form (:176-205) is the same scatter as the
+ * op itself.  Thin named entry points over the two kernels above. */
+int athena_mp_reverse_kipf_propagate_fwd(const athena_mp_graph *g, int32_t F, const float *a_dev, float *c_dev);
+int athena_mp_reverse_kipf_propagate_partial(const athena_mp_graph *g, int32_t F, const float *upstream_dev,
+                                             float *out_dev);
+int athena_mp_reverse_kipf_propagate_partial_val(const athena_mp_graph *g, int32_t F, const float *upstream_dev,
+                                                 float *out_dev);
 /* both reverse forms from ONE gather of the upstream rows: dx_plain = the reference's coefficient-free scatter
  * (exact = 0 above), dx_coef = the adjoint of the forward (exact = 1).  What a layer step needs when it applies
  * the dense step BEFORE the aggregation (F_out < F_in): dX = dx_plain . W,  dW = dx_coef^T . X */

@@ -38,6 +38,26 @@ def test_reference_kat_identity_graph(dev):
     assert np.abs(H(ops.kipf_propagate_bwd(g, torch.ones_like(x))) - np.array(k["grad_of_sum"])).max() <= k["tol_abs"]
     up = T(np.array(k["upstream"], np.float32), dev)
     assert np.abs(H(ops.kipf_propagate_bwd(g, up)) - np.array(k["reverse_partial"])).max() <= k["tol_abs"]
+    # reverse_kipf_propagate (..._sub_kipf.f90:116-206): value = the same scatter; its function-form partial is
+    # kipf_propagate itself (the KAT's forward_partial, test_diffstruc_extd_kipf.f90), its _val form the scatter
+    assert np.abs(H(ops.reverse_kipf_propagate(g, up)) - np.array(k["reverse_partial"])).max() <= k["tol_abs"]
+    up2 = T(np.array(k["second_upstream"], np.float32), dev)
+    assert np.abs(H(ops.reverse_kipf_propagate_partial(g, up2)) - np.array(k["forward_partial"])).max() <= k["tol_abs"]
+    assert np.array_equal(H(ops.reverse_kipf_propagate_partial(g, up2, val_form=True)), H(ops.kipf_propagate_bwd(g, up2)))
+
+
+def test_reverse_kipf_propagate_named_entry_points_on_a_random_graph(dev, oracle):
+    """a3 beyond the identity-graph KAT: on a random multigraph with hubs of degree > 1 the three named entry points
+    equal the oracle's scatter / propagate bit for bit (athena_diffstruc_extd_sub_kipf.f90:116-205)"""
+    from athena_amd import DeviceGraph, ops
+
+    ia, ja = random_graph(3000, 14000, seed=21)
+    g = DeviceGraph(ia, ja, n_edge_cols=0)
+    a = np.random.default_rng(2).uniform(-1, 1, (3000, 48)).astype(np.float32)
+    ad = T(a, dev)
+    assert np.array_equal(H(ops.reverse_kipf_propagate(g, ad)), oracle.kipf_propagate_bwd(a, ia, ja))
+    assert np.array_equal(H(ops.reverse_kipf_propagate_partial(g, ad)), oracle.kipf_propagate(a, ia, ja))
+    assert np.array_equal(H(ops.reverse_kipf_propagate_partial(g, ad, val_form=True)), oracle.kipf_propagate_bwd(a, ia, ja))
 
 
 def test_survey_recorded_reference_outputs(dev):
