@@ -88,6 +88,22 @@ _PROTOS = {
     "athena_mp_gno_aggregate_bwd_x": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "athena_mp_gno_aggregate_bwd_theta": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
     "athena_mp_gno_aggregate_bwd_coords": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
+    "athena_mp_comm_unique_id": [_vp],
+    "athena_mp_comm_create": [_i32, _i32, _vp, C.POINTER(_vp)],
+    "athena_mp_comm_create_from_file": [_i32, _i32, C.c_char_p, C.POINTER(_vp)],
+    "athena_mp_comm_destroy": [_vp],
+    "athena_mp_comm_info": [_vp, C.POINTER(_i32), C.POINTER(_i32), C.c_char_p, _i32],
+    "athena_mp_comm_barrier": [_vp],
+    "athena_mp_allreduce_start": [_vp, _vp, _i64],
+    "athena_mp_allreduce_finish": [_vp],
+    "athena_mp_allreduce": [_vp, _vp, _i64],
+    "athena_mp_shard_create": [_vp, _i32, _i64, _vp, _vp, C.POINTER(_vp)],
+    "athena_mp_shard_destroy": [_vp],
+    "athena_mp_shard_dims": [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)],
+    "athena_mp_shard_graph": [_vp, _i32, C.POINTER(_vp)],
+    "athena_mp_shard_export": [_vp, _i32, _vp, _i64, C.POINTER(_i64)],
+    "athena_mp_halo_start": [_vp, _i32, _i32, _vp],
+    "athena_mp_halo_finish": [_vp, _i32],
     "athena_mp_kipf_propagate_fwd_host": [_vp, _i32, _vp, _vp],
     "athena_mp_kipf_propagate_bwd_host": [_vp, _i32, _vp, _vp, _i32],
     "athena_mp_gemm_fwd_host": [_i64, _i32, _i32, _vp, _vp, _vp, _i32, _vp],

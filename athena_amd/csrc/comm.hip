@@ -1,0 +1,797 @@
+// Multi-GPU side of libathena_mp: communicator, row-partition shard and halo exchange behind the C ABI
+// (SURVEY.md 8b "multi-GPU: athena_mp_comm_create / graph_partition / halo_exchange", 8e).  The reference has nothing
+// distributed: this is new, one process per GPU.
+//
+//   transport      RCCL over xGMI: grouped ncclSend / ncclRecv to every peer (one transfer per xGMI link, not a ring) on a
+//                  communication stream of its own, event-ordered against the compute stream (amp::stream()); dW by
+//                  ncclAllReduce.  librccl is dlopen'ed on first use, so single-GPU users never load it and a process
+//                  that already carries a copy (PyTorch) shares it.
+//   test transport ATHENA_MP_COMM_TRANSPORT=shm: the same calls with the bytes staged through files under /dev/shm.
+//                  TEST INFRASTRUCTURE for boxes with ONE GPU (RCCL refuses two ranks on one device: "Duplicate GPU
+//                  detected"); it exercises everything here except the nccl* calls themselves.  Never selected by default.
+//   shard          rank r owns a contiguous block of vertex rows.  Columns are renumbered [local | halo], local vertices
+//                  INTERIOR FIRST (rows that reference no remote vertex), so rows [0, n_int) run while the halo is in
+//                  flight and only [n_int, n) wait.  The backward graph lists each row's entries by ascending global
+//                  source id -- the order the reference's scatter accumulates in
+//                  (athena_diffstruc_extd_sub_kipf.f90:101-109; athena's graphs are undirected, so the transposed row of
+//                  a vertex is its own row).  Degrees of halo columns come from their owners (the Kipf coefficient
+//                  needs deg of the remote endpoint, :39-42).
+#include <dlfcn.h>
+#include <errno.h>
+#include <fcntl.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include <rccl/rccl.h>
+
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// transports
+// ---------------------------------------------------------------------------------------------------------------------
+struct Transport {
+    int rank = 0, world = 1;
+    virtual ~Transport() {}
+    virtual const char *name() const = 0;
+    // device buffers; bytes may be 0 (skipped); entries for p == rank are ignored.  Enqueued on / ordered after `s`.
+    virtual int exchange(const void *const *sendp, const size_t *sendb, void *const *recvp, const size_t *recvb,
+                         hipStream_t s) = 0;
+    virtual int allreduce_f32(float *buf, size_t count, hipStream_t s) = 0;
+};
+
+struct RcclApi {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+};
+RcclApi g_rccl;
+
+int rccl_load()
+{
+    if (g_rccl.lib) return 0;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names)
+        if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) {
+        amp::set_error("comm: cannot load librccl (%s)", dlerror());
+        return 1;
+    }
+#define AMP_SYM(field, sym)                                                   \
+    *(void **)(&g_rccl.field) = dlsym(h, sym);                                \
+    if (!g_rccl.field) {                                                      \
+        amp::set_error("comm: librccl lacks %s", sym);                        \
+        return 1;                                                             \
+    }
+    AMP_SYM(GetUniqueId, "ncclGetUniqueId")
+    AMP_SYM(CommInitRank, "ncclCommInitRank")
+    AMP_SYM(CommDestroy, "ncclCommDestroy")
+    AMP_SYM(GetErrorString, "ncclGetErrorString")
+    AMP_SYM(AllReduce, "ncclAllReduce")
+    AMP_SYM(Send, "ncclSend")
+    AMP_SYM(Recv, "ncclRecv")
+    AMP_SYM(GroupStart, "ncclGroupStart")
+    AMP_SYM(GroupEnd, "ncclGroupEnd")
+#undef AMP_SYM
+    g_rccl.lib = h;
+    return 0;
+}
+
+#define AMP_NCCL(expr)                                                                                   \
+    do {                                                                                                 \
+        ncclResult_t _r = (expr);                                                                        \
+        if (_r != ncclSuccess) {                                                                         \
+            amp::set_error("%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(_r), __FILE__, __LINE__); \
+            return 1;                                                                                    \
+        }                                                                                                \
+    } while (0)
+
+struct RcclTransport : Transport {
+    ncclComm_t comm = nullptr;
+    const char *name() const override { return "rccl"; }
+    ~RcclTransport() override
+    {
+        if (comm) g_rccl.CommDestroy(comm);
+    }
+    int exchange(const void *const *sendp, const size_t *sendb, void *const *recvp, const size_t *recvb,
+                 hipStream_t s) override
+    {
+        AMP_NCCL(g_rccl.GroupStart());
+        for (int p = 0; p < world; ++p) {
+            if (p == rank) continue;
+            if (sendb[p]) AMP_NCCL(g_rccl.Send(sendp[p], sendb[p], ncclInt8, p, comm, s));
+            if (recvb[p]) AMP_NCCL(g_rccl.Recv(recvp[p], recvb[p], ncclInt8, p, comm, s));
+        }
+        AMP_NCCL(g_rccl.GroupEnd());
+        return 0;
+    }
+    int allreduce_f32(float *buf, size_t count, hipStream_t s) override
+    {
+        if (count) AMP_NCCL(g_rccl.AllReduce(buf, buf, count, ncclFloat32, ncclSum, comm, s));
+        return 0;
+    }
+};
+
+// test-only: bytes through /dev/shm files, one file per (sequence number, source, destination)
+struct ShmTransport : Transport {
+    std::string dir;
+    uint64_t seq = 0;
+    std::vector<char> host;
+    const char *name() const override { return "shm (test transport: host-staged files, not RCCL)"; }
+    std::string path(uint64_t q, int src, int dst) const
+    {
+        char b[96];
+        snprintf(b, sizeof(b), "/m_%llu_%d_%d", (unsigned long long)q, src, dst);
+        return dir + b;
+    }
+    int put(const std::string &file, const void *data, size_t bytes)
+    {
+        const std::string tmp = file + ".tmp";
+        int fd = open(tmp.c_str(), O_CREAT | O_WRONLY | O_TRUNC, 0600);
+        if (fd < 0) {
+            amp::set_error("comm(shm): cannot create %s: %s", tmp.c_str(), strerror(errno));
+            return 1;
+        }
+        const char *p = (const char *)data;
+        size_t left = bytes;
+        while (left) {
+            ssize_t w = write(fd, p, left);
+            if (w <= 0) {
+                close(fd);
+                amp::set_error("comm(shm): write failed: %s", strerror(errno));
+                return 1;
+            }
+            p += w;
+            left -= (size_t)w;
+        }
+        close(fd);
+        if (rename(tmp.c_str(), file.c_str())) {
+            amp::set_error("comm(shm): rename failed: %s", strerror(errno));
+            return 1;
+        }
+        return 0;
+    }
+    int get(const std::string &file, void *data, size_t bytes)
+    {
+        const double t0 = now();
+        int fd = -1;
+        while ((fd = open(file.c_str(), O_RDONLY)) < 0) {
+            if (now() - t0 > 300.0) {
+                amp::set_error("comm(shm): timed out waiting for %s", file.c_str());
+                return 1;
+            }
+            usleep(200);
+        }
+        char *p = (char *)data;
+        size_t left = bytes;
+        while (left) {
+            ssize_t r = read(fd, p, left);
+            if (r <= 0) {
+                close(fd);
+                amp::set_error("comm(shm): short read of %s", file.c_str());
+                return 1;
+            }
+            p += r;
+            left -= (size_t)r;
+        }
+        close(fd);
+        unlink(file.c_str());
+        return 0;
+    }
+    static double now()
+    {
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return ts.tv_sec + 1e-9 * ts.tv_nsec;
+    }
+    int exchange(const void *const *sendp, const size_t *sendb, void *const *recvp, const size_t *recvb,
+                 hipStream_t s) override
+    {
+        const uint64_t q = seq++;
+        AMP_HIP(hipStreamSynchronize(s));
+        for (int p = 0; p < world; ++p) {
+            if (p == rank || !sendb[p]) continue;
+            host.resize(sendb[p]);
+            AMP_HIP(hipMemcpy(host.data(), sendp[p], sendb[p], hipMemcpyDeviceToHost));
+            if (put(path(q, rank, p), host.data(), sendb[p])) return 1;
+        }
+        for (int p = 0; p < world; ++p) {
+            if (p == rank || !recvb[p]) continue;
+            host.resize(recvb[p]);
+            if (get(path(q, p, rank), host.data(), recvb[p])) return 1;
+            AMP_HIP(hipMemcpy(recvp[p], host.data(), recvb[p], hipMemcpyHostToDevice));
+        }
+        return 0;
+    }
+    int allreduce_f32(float *buf, size_t count, hipStream_t s) override
+    {
+        if (!count) return 0;
+        const uint64_t q = seq++;
+        AMP_HIP(hipStreamSynchronize(s));
+        std::vector<float> mine(count), other(count), sum(count, 0.0f);
+        AMP_HIP(hipMemcpy(mine.data(), buf, 4 * count, hipMemcpyDeviceToHost));
+        for (int p = 0; p < world; ++p)
+            if (p != rank && put(path(q, rank, p), mine.data(), 4 * count)) return 1;
+        for (int p = 0; p < world; ++p) {   // rank order: every rank forms the same sum
+            const float *src = mine.data();
+            if (p != rank) {
+                if (get(path(q, p, rank), other.data(), 4 * count)) return 1;
+                src = other.data();
+            }
+            for (size_t i = 0; i < count; ++i) sum[i] += src[i];
+        }
+        AMP_HIP(hipMemcpy(buf, sum.data(), 4 * count, hipMemcpyHostToDevice));
+        return 0;
+    }
+};
+
+bool want_shm()
+{
+    const char *t = getenv("ATHENA_MP_COMM_TRANSPORT");
+    return t && strcmp(t, "shm") == 0;
+}
+
+} // namespace
+
+struct athena_mp_comm {
+    Transport *t = nullptr;
+    hipStream_t cs = nullptr;       // communication stream
+    hipEvent_t ev_ready = nullptr;  // compute -> comm
+    hipEvent_t ev_done = nullptr;   // comm -> compute (all-reduce)
+    int device = 0;
+};
+
+struct athena_mp_shard {
+    athena_mp_comm *comm = nullptr;
+    int32_t n = 0, n_int = 0, n_halo = 0;
+    int64_t nnz = 0, row_offset = 0, n_total = 0;
+    std::vector<int64_t> row_off;          // [world+1] first global row of every rank
+    std::vector<int32_t> order;            // [n] original local id of the vertex now called k
+    std::vector<int64_t> halo_ids;         // [n_halo] global ids, ascending (grouped by owner)
+    std::vector<int64_t> recv_counts, send_counts, roff, soff;   // rows per peer
+    std::vector<int32_t> send_idx_h, col_deg, row_deg;
+    int32_t *send_idx = nullptr;           // device [n_send]: rows (new numbering) peers asked for, grouped by peer
+    int64_t n_send = 0;
+    athena_mp_graph *g[4] = {};            // fwd interior, fwd boundary, bwd interior, bwd boundary
+    hipEvent_t ev_halo[2] = {};            // comm -> compute, one per slot
+    float *send_buf[2] = {};
+    size_t send_cap[2] = {};
+};
+
+using namespace amp;
+
+namespace {
+
+// host metadata through the transport (device staging: RCCL moves device memory)
+int exchange_host(athena_mp_comm *c, const std::vector<const void *> &sp, const std::vector<size_t> &sb,
+                  const std::vector<void *> &rp, const std::vector<size_t> &rb)
+{
+    const int W = c->t->world;
+    size_t tot = 0;
+    for (int p = 0; p < W; ++p) tot += ((sb[p] + 255) & ~(size_t)255) + ((rb[p] + 255) & ~(size_t)255);
+    char *dev = nullptr;
+    AMP_HIP(hipMalloc((void **)&dev, tot ? tot : 256));
+    std::vector<const void *> dsp(W, nullptr);
+    std::vector<void *> drp(W, nullptr);
+    size_t off = 0;
+    for (int p = 0; p < W; ++p) {
+        dsp[p] = dev + off;
+        if (sb[p] && p != c->t->rank) AMP_HIP(hipMemcpy(dev + off, sp[p], sb[p], hipMemcpyHostToDevice));
+        off += (sb[p] + 255) & ~(size_t)255;
+        drp[p] = dev + off;
+        off += (rb[p] + 255) & ~(size_t)255;
+    }
+    int rc = c->t->exchange(dsp.data(), sb.data(), drp.data(), rb.data(), c->cs);
+    if (rc == 0 && hipStreamSynchronize(c->cs) != hipSuccess) {
+        set_error("comm: metadata exchange failed on the communication stream");
+        rc = 1;
+    }
+    if (rc == 0)
+        for (int p = 0; p < W; ++p)
+            if (rb[p] && p != c->t->rank && hipMemcpy(rp[p], drp[p], rb[p], hipMemcpyDeviceToHost) != hipSuccess) rc = 1;
+    (void)hipFree(dev);
+    if (rc && athena_mp_last_error()[0] == 0) set_error("comm: metadata exchange failed");
+    return rc;
+}
+
+// every rank contributes `bytes`; out [world * bytes]
+int allgather_host(athena_mp_comm *c, const void *mine, size_t bytes, void *out)
+{
+    const int W = c->t->world, r = c->t->rank;
+    std::vector<const void *> sp(W, mine);
+    std::vector<size_t> sb(W, bytes), rb(W, bytes);
+    std::vector<void *> rp(W);
+    for (int p = 0; p < W; ++p) rp[p] = (char *)out + (size_t)p * bytes;
+    sb[r] = rb[r] = 0;
+    memcpy((char *)out + (size_t)r * bytes, mine, bytes);
+    return exchange_host(c, sp, sb, rp, rb);
+}
+
+int make_graph(const std::vector<int32_t> &ia_all, const std::vector<int32_t> &col, int32_t r0, int32_t r1, int32_t n_cols,
+               const std::vector<int32_t> &row_deg, const std::vector<int32_t> &col_deg, athena_mp_graph **out)
+{
+    const int32_t e0 = ia_all[r0], e1 = ia_all[r1];
+    std::vector<int32_t> ia(r1 - r0 + 1), ja(2 * (size_t)(e1 - e0));
+    for (int32_t r = r0; r <= r1; ++r) ia[r - r0] = ia_all[r] - e0 + 1;
+    for (int32_t w = e0; w < e1; ++w) {
+        ja[2 * (size_t)(w - e0)] = col[w] + 1;
+        ja[2 * (size_t)(w - e0) + 1] = 0;
+    }
+    static const int32_t dummy[2] = {0, 0};
+    return athena_mp_graph_create(r1 - r0, n_cols, e1 - e0, ia.data(), ja.empty() ? dummy : ja.data(), 0,
+                                  row_deg.data() + r0, col_deg.data(), out);
+}
+
+} // namespace
+
+extern "C" {
+
+int athena_mp_comm_unique_id(void *id128)
+{
+    AMP_REQUIRE(id128 != nullptr, "comm_unique_id: null buffer");
+    memset(id128, 0, 128);
+    if (want_shm()) {
+        int fd = open("/dev/urandom", O_RDONLY);
+        AMP_REQUIRE(fd >= 0 && read(fd, id128, 16) == 16, "comm_unique_id: /dev/urandom unreadable");
+        close(fd);
+        return 0;
+    }
+    if (rccl_load()) return 1;
+    ncclUniqueId id;
+    AMP_NCCL(g_rccl.GetUniqueId(&id));
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    memcpy(id128, &id, 128);
+    return 0;
+}
+
+int athena_mp_comm_create(int32_t rank, int32_t world, const void *id128, athena_mp_comm **out)
+{
+    AMP_REQUIRE(out != nullptr, "comm_create: null out pointer");
+    *out = nullptr;
+    AMP_REQUIRE(world >= 1 && rank >= 0 && rank < world && id128 != nullptr, "comm_create: bad rank %d / world %d", rank, world);
+    athena_mp_comm *c = new athena_mp_comm();
+    c->device = amp::device();
+    if (want_shm()) {
+        ShmTransport *t = new ShmTransport();
+        char hex[40];
+        const unsigned char *b = (const unsigned char *)id128;
+        for (int i = 0; i < 16; ++i) snprintf(hex + 2 * i, 3, "%02x", b[i]);
+        t->dir = std::string("/dev/shm/athena_mp_") + hex;
+        if (mkdir(t->dir.c_str(), 0700) && errno != EEXIST) {
+            set_error("comm_create(shm): cannot create %s: %s", t->dir.c_str(), strerror(errno));
+            delete t;
+            delete c;
+            return 1;
+        }
+        c->t = t;
+    } else {
+        if (rccl_load()) {
+            delete c;
+            return 1;
+        }
+        RcclTransport *t = new RcclTransport();
+        ncclUniqueId id;
+        memcpy(&id, id128, 128);
+        ncclResult_t r = g_rccl.CommInitRank(&t->comm, world, id, rank);
+        if (r != ncclSuccess) {
+            set_error("ncclCommInitRank(rank %d of %d) failed: %s", rank, world, g_rccl.GetErrorString(r));
+            t->comm = nullptr;
+            delete t;
+            delete c;
+            return 1;
+        }
+        c->t = t;
+    }
+    c->t->rank = rank;
+    c->t->world = world;
+    if (hipStreamCreateWithFlags(&c->cs, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess) {
+        set_error("comm_create: cannot create the communication stream / events");
+        delete c->t;
+        delete c;
+        return 1;
+    }
+    *out = c;
+    return 0;
+}
+
+/* MPI-free bootstrap for a Fortran host: rank 0 draws the id and publishes it in `path` (write + rename); the other
+ * ranks wait for the file.  Rank 0 removes it after every rank has joined. */
+int athena_mp_comm_create_from_file(int32_t rank, int32_t world, const char *path, athena_mp_comm **out)
+{
+    AMP_REQUIRE(out != nullptr && path != nullptr, "comm_create_from_file: null argument");
+    *out = nullptr;
+    char id[128];
+    if (rank == 0) {
+        if (athena_mp_comm_unique_id(id)) return 1;
+        const std::string tmp = std::string(path) + ".tmp";
+        FILE *f = fopen(tmp.c_str(), "wb");
+        AMP_REQUIRE(f != nullptr, "comm_create_from_file: cannot write %s", tmp.c_str());
+        const size_t w = fwrite(id, 1, 128, f);
+        fclose(f);
+        AMP_REQUIRE(w == 128 && rename(tmp.c_str(), path) == 0, "comm_create_from_file: cannot publish %s", path);
+    } else {
+        FILE *f = nullptr;
+        for (int i = 0; i < 600000 && !(f = fopen(path, "rb")); ++i) usleep(500);
+        AMP_REQUIRE(f != nullptr, "comm_create_from_file: %s never appeared (is rank 0 running?)", path);
+        const size_t r = fread(id, 1, 128, f);
+        fclose(f);
+        AMP_REQUIRE(r == 128, "comm_create_from_file: %s is truncated", path);
+    }
+    int rc = athena_mp_comm_create(rank, world, id, out);
+    if (rc) return rc;
+    rc = athena_mp_comm_barrier(*out);
+    if (rank == 0) unlink(path);
+    return rc;
+}
+
+int athena_mp_comm_destroy(athena_mp_comm *c)
+{
+    if (!c) return 0;
+    if (c->cs) (void)hipStreamSynchronize(c->cs);
+    if (c->t && strncmp(c->t->name(), "shm", 3) == 0) {
+        ShmTransport *t = (ShmTransport *)c->t;
+        (void)rmdir(t->dir.c_str());   // succeeds for the last rank out (directory empty)
+    }
+    delete c->t;
+    if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
+    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+    if (c->cs) (void)hipStreamDestroy(c->cs);
+    delete c;
+    return 0;
+}
+
+int athena_mp_comm_info(const athena_mp_comm *c, int32_t *rank, int32_t *world, char *transport, int32_t transport_len)
+{
+    AMP_REQUIRE(c != nullptr, "comm_info: null communicator");
+    if (rank) *rank = c->t->rank;
+    if (world) *world = c->t->world;
+    if (transport && transport_len > 0) {
+        strncpy(transport, c->t->name(), (size_t)transport_len - 1);
+        transport[transport_len - 1] = 0;
+    }
+    return 0;
+}
+
+/* sum over ranks, in place, float32.  _start enqueues it on the communication stream behind everything the compute
+ * stream has queued so far; _finish makes the compute stream wait for it (host never blocks). */
+int athena_mp_allreduce_start(athena_mp_comm *c, float *buf_dev, int64_t count)
+{
+    AMP_REQUIRE(c && count >= 0 && (buf_dev || count == 0), "allreduce: bad arguments");
+    if (c->t->world == 1 || count == 0) return 0;
+    AMP_HIP(hipEventRecord(c->ev_ready, amp::stream()));
+    AMP_HIP(hipStreamWaitEvent(c->cs, c->ev_ready, 0));
+    if (c->t->allreduce_f32(buf_dev, (size_t)count, c->cs)) return 1;
+    AMP_HIP(hipEventRecord(c->ev_done, c->cs));
+    return 0;
+}
+int athena_mp_allreduce_finish(athena_mp_comm *c)
+{
+    AMP_REQUIRE(c != nullptr, "allreduce_finish: null communicator");
+    if (c->t->world == 1) return 0;
+    AMP_HIP(hipStreamWaitEvent(amp::stream(), c->ev_done, 0));
+    return 0;
+}
+int athena_mp_allreduce(athena_mp_comm *c, float *buf_dev, int64_t count)
+{
+    int rc = athena_mp_allreduce_start(c, buf_dev, count);
+    return rc ? rc : athena_mp_allreduce_finish(c);
+}
+
+int athena_mp_comm_barrier(athena_mp_comm *c)
+{
+    AMP_REQUIRE(c != nullptr, "comm_barrier: null communicator");
+    float *one = nullptr;
+    if (amp::named_buffer("comm.barrier_word", 256, true, (void **)&one)) return 1;
+    AMP_HIP(hipStreamSynchronize(amp::stream()));
+    if (c->t->world > 1 && c->t->allreduce_f32(one, 1, c->cs)) return 1;
+    AMP_HIP(hipStreamSynchronize(c->cs));
+    AMP_HIP(hipMemsetAsync(one, 0, 4, c->cs));
+    AMP_HIP(hipStreamSynchronize(c->cs));
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+int athena_mp_shard_destroy(athena_mp_shard *s)
+{
+    if (!s) return 0;
+    for (auto &g : s->g)
+        if (g) athena_mp_graph_destroy(g);
+    if (s->send_idx) (void)hipFree(s->send_idx);
+    for (int k = 0; k < 2; ++k) {
+        if (s->send_buf[k]) (void)hipFree(s->send_buf[k]);
+        if (s->ev_halo[k]) (void)hipEventDestroy(s->ev_halo[k]);
+    }
+    delete s;
+    return 0;
+}
+
+/* Build this rank's shard from its rows of the global graph.  adj_ia [n_local + 1] (1-based), adj_ja [2, nnz]
+ * column-major with adj_ja(1, w) = GLOBAL vertex id (1-based) of the neighbour; adj_ja(2, .) is ignored (Kipf).
+ * Collective: every rank of the communicator calls it. */
+int athena_mp_shard_create(athena_mp_comm *c, int32_t n_local, int64_t nnz, const int32_t *adj_ia, const int32_t *adj_ja,
+                           athena_mp_shard **out)
+{
+    AMP_REQUIRE(out != nullptr, "shard_create: null out pointer");
+    *out = nullptr;
+    AMP_REQUIRE(c && n_local >= 0 && nnz >= 0 && adj_ia && (adj_ja || nnz == 0), "shard_create: bad arguments");
+    AMP_REQUIRE(adj_ia[0] == 1 && (int64_t)adj_ia[n_local] - 1 == nnz, "shard_create: adj_ia does not span nnz = %lld",
+                (long long)nnz);
+    AMP_REQUIRE(nnz < (int64_t)INT32_MAX, "shard_create: nnz %lld exceeds the int32 CSR of one shard", (long long)nnz);
+    const int W = c->t->world, rank = c->t->rank;
+    athena_mp_shard *s = new athena_mp_shard();
+    s->comm = c;
+    s->n = n_local;
+    s->nnz = nnz;
+    const int32_t n = n_local;
+#define SH_FAIL(...)                \
+    do {                            \
+        set_error(__VA_ARGS__);     \
+        athena_mp_shard_destroy(s); \
+        return 2;                   \
+    } while (0)
+#define SH_RC(expr)                     \
+    do {                                \
+        if ((expr) != 0) {              \
+            athena_mp_shard_destroy(s); \
+            return 1;                   \
+        }                               \
+    } while (0)
+    // 1. row blocks of every rank
+    std::vector<int64_t> all_n(W);
+    const int64_t my_n = n;
+    SH_RC(allgather_host(c, &my_n, 8, all_n.data()));
+    s->row_off.assign(W + 1, 0);
+    for (int p = 0; p < W; ++p) s->row_off[p + 1] = s->row_off[p] + all_n[p];
+    s->n_total = s->row_off[W];
+    const int64_t lo = s->row_off[rank], hi = lo + n;
+    s->row_offset = lo;
+    // 2. interior-first numbering
+    std::vector<char> is_bnd(n, 0);
+    for (int32_t v = 0; v < n; ++v) {
+        if (adj_ia[v + 1] < adj_ia[v]) SH_FAIL("shard_create: adj_ia not monotone at row %d", v + 1);
+        for (int32_t w = adj_ia[v] - 1; w < adj_ia[v + 1] - 1; ++w) {
+            const int64_t u = (int64_t)adj_ja[2 * (size_t)w] - 1;
+            if (u < 0 || u >= s->n_total) SH_FAIL("shard_create: adj_ja(1,%d) = %lld outside [1,%lld]", w + 1, (long long)u + 1, (long long)s->n_total);
+            if (u < lo || u >= hi) is_bnd[v] = 1;
+        }
+    }
+    s->order.resize(n);
+    {
+        int32_t k = 0;
+        for (int32_t v = 0; v < n; ++v)
+            if (!is_bnd[v]) s->order[k++] = v;
+        s->n_int = k;
+        for (int32_t v = 0; v < n; ++v)
+            if (is_bnd[v]) s->order[k++] = v;
+    }
+    std::vector<int32_t> new_of_old(n);
+    for (int32_t k = 0; k < n; ++k) new_of_old[s->order[k]] = k;
+    // 3. rows in the new order (entry order inside a row kept), halo ids
+    std::vector<int32_t> ia(n + 1, 0);
+    s->row_deg.resize(n);
+    for (int32_t k = 0; k < n; ++k) {
+        const int32_t v = s->order[k];
+        s->row_deg[k] = adj_ia[v + 1] - adj_ia[v];
+        ia[k + 1] = ia[k] + s->row_deg[k];
+    }
+    std::vector<int64_t> cg(nnz);   // global column of every entry, new row order
+    for (int32_t k = 0; k < n; ++k) {
+        const int32_t v = s->order[k];
+        int32_t q = ia[k];
+        for (int32_t w = adj_ia[v] - 1; w < adj_ia[v + 1] - 1; ++w) cg[q++] = (int64_t)adj_ja[2 * (size_t)w] - 1;
+    }
+    for (int64_t w = 0; w < nnz; ++w)
+        if (cg[w] < lo || cg[w] >= hi) s->halo_ids.push_back(cg[w]);
+    std::sort(s->halo_ids.begin(), s->halo_ids.end());
+    s->halo_ids.erase(std::unique(s->halo_ids.begin(), s->halo_ids.end()), s->halo_ids.end());
+    if (s->halo_ids.size() + (size_t)n >= (size_t)INT32_MAX) SH_FAIL("shard_create: local + halo rows exceed int32");
+    s->n_halo = (int32_t)s->halo_ids.size();
+    s->recv_counts.assign(W, 0);
+    for (int64_t u : s->halo_ids) {
+        const int p = (int)(std::upper_bound(s->row_off.begin(), s->row_off.end(), u) - s->row_off.begin()) - 1;
+        s->recv_counts[p]++;
+    }
+    // 4. column renumbering [local | halo]; backward rows sorted by global source id (stable)
+    std::vector<int32_t> col(nnz), col_b(nnz);
+    for (int64_t w = 0; w < nnz; ++w) {
+        const int64_t u = cg[w];
+        col[w] = (u >= lo && u < hi) ? new_of_old[u - lo]
+                                     : n + (int32_t)(std::lower_bound(s->halo_ids.begin(), s->halo_ids.end(), u) - s->halo_ids.begin());
+    }
+    {
+        std::vector<int32_t> perm;
+        for (int32_t k = 0; k < n; ++k) {
+            const int32_t b = ia[k], e = ia[k + 1];
+            perm.resize(e - b);
+            std::iota(perm.begin(), perm.end(), b);
+            std::stable_sort(perm.begin(), perm.end(), [&](int32_t x, int32_t y) { return cg[x] < cg[y]; });
+            for (int32_t i = 0; i < e - b; ++i) col_b[b + i] = col[perm[i]];
+        }
+    }
+    // 5. the plan: who needs which of my rows
+    std::vector<int64_t> allc((size_t)W * W);
+    SH_RC(allgather_host(c, s->recv_counts.data(), 8 * (size_t)W, allc.data()));   // allc[q*W + p] = rows q needs from p
+    s->send_counts.assign(W, 0);
+    for (int q = 0; q < W; ++q)
+        if (q != rank) s->send_counts[q] = allc[(size_t)q * W + rank];
+    s->roff.assign(W + 1, 0);
+    s->soff.assign(W + 1, 0);
+    for (int p = 0; p < W; ++p) {
+        s->roff[p + 1] = s->roff[p] + s->recv_counts[p];
+        s->soff[p + 1] = s->soff[p] + s->send_counts[p];
+    }
+    s->n_send = s->soff[W];
+    std::vector<int32_t> want(s->n_halo), asked(s->n_send);
+    for (int32_t k = 0; k < s->n_halo; ++k) {
+        const int p = (int)(std::upper_bound(s->row_off.begin(), s->row_off.end(), s->halo_ids[k]) - s->row_off.begin()) - 1;
+        want[k] = (int32_t)(s->halo_ids[k] - s->row_off[p]);   // owner-local ORIGINAL id
+    }
+    {
+        std::vector<const void *> sp(W);
+        std::vector<void *> rp(W);
+        std::vector<size_t> sb(W), rb(W);
+        for (int p = 0; p < W; ++p) {
+            sp[p] = want.data() + s->roff[p];
+            sb[p] = 4 * (size_t)s->recv_counts[p];
+            rp[p] = asked.data() + s->soff[p];
+            rb[p] = 4 * (size_t)s->send_counts[p];
+        }
+        sb[rank] = rb[rank] = 0;
+        SH_RC(exchange_host(c, sp, sb, rp, rb));
+    }
+    s->send_idx_h.resize(s->n_send);
+    std::vector<int32_t> sdeg(s->n_send), hdeg(s->n_halo);
+    for (int64_t i = 0; i < s->n_send; ++i) {
+        if (asked[i] < 0 || asked[i] >= n) SH_FAIL("shard_create: a peer asked for row %d of %d", asked[i], n);
+        s->send_idx_h[i] = new_of_old[asked[i]];
+        sdeg[i] = s->row_deg[s->send_idx_h[i]];
+    }
+    {   // degrees of the halo columns from their owners
+        std::vector<const void *> sp(W);
+        std::vector<void *> rp(W);
+        std::vector<size_t> sb(W), rb(W);
+        for (int p = 0; p < W; ++p) {
+            sp[p] = sdeg.data() + s->soff[p];
+            sb[p] = 4 * (size_t)s->send_counts[p];
+            rp[p] = hdeg.data() + s->roff[p];
+            rb[p] = 4 * (size_t)s->recv_counts[p];
+        }
+        sb[rank] = rb[rank] = 0;
+        SH_RC(exchange_host(c, sp, sb, rp, rb));
+    }
+    s->col_deg = s->row_deg;
+    s->col_deg.insert(s->col_deg.end(), hdeg.begin(), hdeg.end());
+    if (hipMalloc((void **)&s->send_idx, 4 * (size_t)std::max<int64_t>(s->n_send, 1)) != hipSuccess)
+        SH_FAIL("shard_create: device allocation failed");
+    if (s->n_send && hipMemcpy(s->send_idx, s->send_idx_h.data(), 4 * (size_t)s->n_send, hipMemcpyHostToDevice) != hipSuccess)
+        SH_FAIL("shard_create: upload of the send list failed");
+    // 6. the four row blocks as graph handles (rectangular: n + n_halo columns, explicit degrees)
+    const int32_t ncols = n + s->n_halo;
+    SH_RC(make_graph(ia, col, 0, s->n_int, ncols, s->row_deg, s->col_deg, &s->g[0]));
+    SH_RC(make_graph(ia, col, s->n_int, n, ncols, s->row_deg, s->col_deg, &s->g[1]));
+    SH_RC(make_graph(ia, col_b, 0, s->n_int, ncols, s->row_deg, s->col_deg, &s->g[2]));
+    SH_RC(make_graph(ia, col_b, s->n_int, n, ncols, s->row_deg, s->col_deg, &s->g[3]));
+    for (int k = 0; k < 2; ++k)
+        if (hipEventCreateWithFlags(&s->ev_halo[k], hipEventDisableTiming) != hipSuccess) SH_FAIL("shard_create: cannot create events");
+#undef SH_FAIL
+#undef SH_RC
+    *out = s;
+    return 0;
+}
+
+int athena_mp_shard_dims(const athena_mp_shard *s, int32_t *n_local, int32_t *n_interior, int32_t *n_halo, int64_t *nnz,
+                         int64_t *row_offset, int64_t *n_total)
+{
+    AMP_REQUIRE(s != nullptr, "shard_dims: null shard");
+    if (n_local) *n_local = s->n;
+    if (n_interior) *n_interior = s->n_int;
+    if (n_halo) *n_halo = s->n_halo;
+    if (nnz) *nnz = s->nnz;
+    if (row_offset) *row_offset = s->row_offset;
+    if (n_total) *n_total = s->n_total;
+    return 0;
+}
+
+/* which: 0 fwd interior rows [0, n_int), 1 fwd boundary rows [n_int, n), 2 / 3 the same blocks of the backward (pull)
+ * graph.  Columns index x_ext = [n local rows | n_halo halo rows].  Owned by the shard. */
+int athena_mp_shard_graph(const athena_mp_shard *s, int32_t which, athena_mp_graph **g)
+{
+    AMP_REQUIRE(s && g && which >= 0 && which < 4, "shard_graph: bad arguments");
+    *g = s->g[which];
+    return 0;
+}
+
+/* arrays of the plan (tests, and hosts that keep their data in original order):
+ * 0 order [n] int32 (original local id, 0-based, of new row k)   1 halo_ids [n_halo] int64 (global, 0-based)
+ * 2 send_idx [n_send] int32   3 col_deg [n + n_halo] int32   4 send_counts [world] int64   5 recv_counts [world] int64
+ * count is in ELEMENTS; host_dst may be null for a size query. */
+int athena_mp_shard_export(const athena_mp_shard *s, int32_t which, void *host_dst, int64_t capacity, int64_t *count)
+{
+    AMP_REQUIRE(s && count, "shard_export: null argument");
+    const void *src = nullptr;
+    int64_t n = 0;
+    size_t el = 4;
+    switch (which) {
+    case 0: src = s->order.data(); n = (int64_t)s->order.size(); break;
+    case 1: src = s->halo_ids.data(); n = (int64_t)s->halo_ids.size(); el = 8; break;
+    case 2: src = s->send_idx_h.data(); n = (int64_t)s->send_idx_h.size(); break;
+    case 3: src = s->col_deg.data(); n = (int64_t)s->col_deg.size(); break;
+    case 4: src = s->send_counts.data(); n = (int64_t)s->send_counts.size(); el = 8; break;
+    case 5: src = s->recv_counts.data(); n = (int64_t)s->recv_counts.size(); el = 8; break;
+    default: AMP_REQUIRE(false, "shard_export: unknown array id %d", which);
+    }
+    *count = n;
+    if (!host_dst) return 0;
+    AMP_REQUIRE(capacity >= n, "shard_export: buffer holds %lld elements, array has %lld", (long long)capacity, (long long)n);
+    if (n) memcpy(host_dst, src, el * (size_t)n);
+    return 0;
+}
+
+/* Halo exchange of x_ext [n + n_halo, F] (row-major): packs the rows the peers need (HIP gather on the compute
+ * stream), then -- on the communication stream, ordered behind the pack -- one grouped send/recv per peer straight
+ * into the halo rows of x_ext.  Returns at once; kernels enqueued before athena_mp_halo_finish (the interior rows) run
+ * under the transfer.  slot 0 / 1: two exchanges may be outstanding (e.g. X and dZ). */
+int athena_mp_halo_start(athena_mp_shard *s, int32_t slot, int32_t F, float *x_ext_dev)
+{
+    AMP_REQUIRE(s && (slot == 0 || slot == 1) && F > 0 && (x_ext_dev || s->n + s->n_halo == 0), "halo_start: bad arguments");
+    athena_mp_comm *c = s->comm;
+    const int W = c->t->world, rank = c->t->rank;
+    if (W == 1) return 0;
+    const size_t need = sizeof(float) * (size_t)std::max<int64_t>(s->n_send, 1) * F;
+    if (s->send_cap[slot] < need) {
+        if (s->send_buf[slot]) {
+            AMP_HIP(hipStreamSynchronize(c->cs));
+            AMP_HIP(hipFree(s->send_buf[slot]));
+            s->send_buf[slot] = nullptr;
+        }
+        AMP_HIP(hipMalloc((void **)&s->send_buf[slot], need));
+        s->send_cap[slot] = need;
+    }
+    if (s->n_send) {
+        int rc = athena_mp_gather_rows(s->n_send, F, s->send_idx, x_ext_dev, s->send_buf[slot]);
+        if (rc) return rc;
+    }
+    AMP_HIP(hipEventRecord(c->ev_ready, amp::stream()));      // the pack, and every earlier reader of the halo rows
+    AMP_HIP(hipStreamWaitEvent(c->cs, c->ev_ready, 0));
+    std::vector<const void *> sp(W, nullptr);
+    std::vector<void *> rp(W, nullptr);
+    std::vector<size_t> sb(W, 0), rb(W, 0);
+    for (int p = 0; p < W; ++p) {
+        if (p == rank) continue;
+        sp[p] = s->send_buf[slot] + (size_t)s->soff[p] * F;
+        sb[p] = sizeof(float) * (size_t)s->send_counts[p] * F;
+        rp[p] = x_ext_dev + ((size_t)s->n + (size_t)s->roff[p]) * F;
+        rb[p] = sizeof(float) * (size_t)s->recv_counts[p] * F;
+    }
+    if (c->t->exchange(sp.data(), sb.data(), rp.data(), rb.data(), c->cs)) return 1;
+    AMP_HIP(hipEventRecord(s->ev_halo[slot], c->cs));
+    return 0;
+}
+
+int athena_mp_halo_finish(athena_mp_shard *s, int32_t slot)
+{
+    AMP_REQUIRE(s && (slot == 0 || slot == 1), "halo_finish: bad arguments");
+    if (s->comm->t->world == 1) return 0;
+    AMP_HIP(hipStreamWaitEvent(amp::stream(), s->ev_halo[slot], 0));
+    return 0;
+}
+
+} // extern "C"

@@ -115,6 +115,39 @@ class Shard:
         ia = (self.adj_ia[r0:r1 + 1] - e0).astype(np.int32)
         return ia, np.asfortranarray(adj_ja[:, e0:e1])
 
+    # -- the surface KipfShardStep drives (CShard offers the same, backed by the C ABI) -----------------------------
+    transport = "torch.distributed point-to-point (python plan)"
+
+    def graphs(self, backend):
+        """(fwd interior, fwd boundary, bwd interior, bwd boundary) row blocks as backend graphs"""
+        n, ni, nc = self.n, self.n_int, self.n + self.n_halo
+        def block(adj_ja, r0, r1):
+            ia, ja = self.row_block(adj_ja, r0, r1)
+            return backend.make_graph(ia, ja, nc, self.row_deg[r0:r1], self.col_deg)
+        return (block(self.adj_ja, 0, ni), block(self.adj_ja, ni, n), block(self.adj_ja_bwd, 0, ni), block(self.adj_ja_bwd, ni, n))
+
+    def exchange(self, F, device, backend):
+        return HaloExchange(self, F, device, backend)
+
+    def allreduce_start(self, t):
+        """sum t over the ranks; returns an object with wait() or None (already done)"""
+        if self.world == 1:
+            return None
+        if _host_staged(t):
+            h = t.cpu()
+            dist.all_reduce(h)
+            t.copy_(h)
+            return None
+        return dist.all_reduce(t, async_op=True)
+
+    @property
+    def interior_entries(self):
+        return int(self.adj_ia[self.n_int]) - 1
+
+    def csr(self, backward=False):
+        """(adj_ia [n+1] 1-based, neighbour ids [nnz] 1-based in [local | halo] numbering) of all n rows"""
+        return self.adj_ia, (self.adj_ja_bwd if backward else self.adj_ja)[0]
+
 
 def _host_staged(t):
     """gloo moves host memory only.  It is the transport of the CPU tests and of the single-GPU dry run of the
@@ -158,6 +191,170 @@ def _p2p_start(send_bufs, recv_bufs, rank, world):
 def _p2p_exchange(send_bufs, recv_bufs, rank, world):
     for r in _p2p_start(send_bufs, recv_bufs, rank, world):
         r.wait()
+
+
+# --------------------------------------------------------------------------------------------------
+# the product path: communicator, shard and halo exchange behind the C ABI (csrc/comm.hip, RCCL)
+# --------------------------------------------------------------------------------------------------
+_COMM = None
+
+
+def c_comm(device):
+    """the process's athena_mp_comm (created once).  The 128-byte id is drawn by rank 0 through the C ABI and handed
+    round with torch.distributed's object broadcast (any backend); the transport is RCCL when the process group is
+    "nccl", and the host-staged TEST transport (ATHENA_MP_COMM_TRANSPORT=shm) when the group is gloo -- the one-GPU
+    dry run of bench.py and tests/test_gpu_dist.py, where RCCL refuses several ranks on one device."""
+    global _COMM
+    if _COMM is not None:
+        return _COMM
+    import ctypes as C
+    import os
+    from . import _capi
+    _capi.init(device.index or 0)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if dist.get_backend() != "nccl":
+        os.environ["ATHENA_MP_COMM_TRANSPORT"] = "shm"
+    buf = C.create_string_buffer(128)
+    if rank == 0:
+        _capi.call("athena_mp_comm_unique_id", buf)
+    box = [bytes(buf.raw)]
+    dist.broadcast_object_list(box, src=0)
+    h = C.c_void_p()
+    _capi.call("athena_mp_comm_create", rank, world, C.create_string_buffer(box[0], 128), C.byref(h))
+    name = C.create_string_buffer(96)
+    _capi.call("athena_mp_comm_info", h, None, None, name, 96)
+    _COMM = type("CComm", (), {})()
+    _COMM.handle, _COMM.rank, _COMM.world, _COMM.transport = h, rank, world, name.value.decode()
+    return _COMM
+
+
+def c_comm_destroy():
+    global _COMM
+    if _COMM is not None:
+        from . import _capi
+        _capi.call("athena_mp_comm_destroy", _COMM.handle)
+        _COMM = None
+
+
+class _CExchange:
+    def __init__(self, shard, F, slot):
+        self.s, self.F, self.slot = shard, F, slot
+
+    def start(self, x_ext):
+        from . import _capi
+        import ctypes as C
+        if tuple(x_ext.shape) != (self.s.n + self.s.n_halo, self.F) or not x_ext.is_contiguous():
+            raise ValueError(f"halo exchange: x_ext must be contiguous [{self.s.n + self.s.n_halo}, {self.F}]")
+        _capi.use_torch_stream()
+        _capi.call("athena_mp_halo_start", self.s.handle, self.slot, self.F, C.c_void_p(x_ext.data_ptr()))
+        return self
+
+    def finish(self, _reqs=None):
+        from . import _capi
+        _capi.use_torch_stream()
+        _capi.call("athena_mp_halo_finish", self.s.handle, self.slot)
+
+    def __call__(self, x_ext):
+        self.start(x_ext)
+        self.finish()
+        return x_ext
+
+
+class _CReduce:
+    def __init__(self, comm):
+        self.comm = comm
+
+    def wait(self):
+        from . import _capi
+        _capi.use_torch_stream()
+        _capi.call("athena_mp_allreduce_finish", self.comm.handle)
+
+
+class CShard:
+    """athena_mp_shard: the [local | halo] renumbering, send lists, halo degrees and the four row-block graph handles
+    are built by the C ABI (athena_mp_shard_create); this class only holds the handle and reads its arrays back."""
+
+    def __init__(self, comm, adj_ia, cols_global):
+        import ctypes as C
+        from . import _capi
+        self.comm, self.rank, self.world = comm, comm.rank, comm.world
+        ia = np.ascontiguousarray(adj_ia, np.int32)
+        ja = np.zeros((2, cols_global.size), np.int32, order="F")
+        ja[0] = cols_global + 1
+        h = C.c_void_p()
+        _capi.call("athena_mp_shard_create", comm.handle, ia.size - 1, ja.shape[1], ia.ctypes.data_as(C.c_void_p),
+                   ja.ctypes.data_as(C.c_void_p), C.byref(h))
+        self.handle = h
+        n, ni, nh, nnz, roff, ntot = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64(), C.c_int64(), C.c_int64()
+        _capi.call("athena_mp_shard_dims", h, C.byref(n), C.byref(ni), C.byref(nh), C.byref(nnz), C.byref(roff), C.byref(ntot))
+        self.n, self.n_int, self.n_halo, self.nnz, self.row_offset = n.value, ni.value, nh.value, nnz.value, roff.value
+        self.order = self._export(0, np.int32).astype(np.int64)
+        self.halo_ids = self._export(1, np.int64)
+        self.col_deg = self._export(3, np.int32)
+        self.row_deg = self.col_deg[:self.n]
+        self.transport = comm.transport
+        self._graphs = None
+
+    def _export(self, which, dt):
+        import ctypes as C
+        from . import _capi
+        cnt = C.c_int64()
+        _capi.call("athena_mp_shard_export", self.handle, which, None, 0, C.byref(cnt))
+        out = np.empty(cnt.value, dt)
+        _capi.call("athena_mp_shard_export", self.handle, which, out.ctypes.data_as(C.c_void_p), cnt.value, C.byref(cnt))
+        return out
+
+    @property
+    def send_idx(self):
+        return torch.from_numpy(self._export(2, np.int32))
+
+    def graphs(self, backend=None):
+        import ctypes as C
+        from . import _capi
+        from .graph import DeviceGraph
+        if self._graphs is None:
+            out = []
+            for which in range(4):
+                g = C.c_void_p()
+                _capi.call("athena_mp_shard_graph", self.handle, which, C.byref(g))
+                out.append(DeviceGraph.borrow(g, owner=self))
+            self._graphs = tuple(out)
+        return self._graphs
+
+    def exchange(self, F, device, backend=None):
+        self._slots = getattr(self, "_slots", 0) + 1
+        return _CExchange(self, F, (self._slots - 1) % 2)
+
+    def allreduce_start(self, t):
+        import ctypes as C
+        from . import _capi
+        if self.world == 1:
+            return None
+        _capi.use_torch_stream()
+        _capi.call("athena_mp_allreduce_start", self.comm.handle, C.c_void_p(t.data_ptr()), t.numel())
+        return _CReduce(self.comm)
+
+    @property
+    def interior_entries(self):
+        return int(self.graphs()[0].nnz)
+
+    def csr(self, backward=False):
+        gi, gb = self.graphs()[2:4] if backward else self.graphs()[0:2]
+        rp = np.concatenate([gi.export("rowptr"), gb.export("rowptr")[1:] + gi.nnz])
+        return (rp + 1).astype(np.int32), np.concatenate([gi.export("col"), gb.export("col")]) + 1
+
+    def close(self):
+        if getattr(self, "handle", None):
+            from . import _capi
+            self._graphs = None
+            _capi.call("athena_mp_shard_destroy", self.handle)
+            self.handle = None
+
+
+def _use_c_abi(device):
+    import os
+    return (device is not None and torch.device(device).type == "cuda" and dist.is_initialized()
+            and os.environ.get("ATHENA_MP_DIST_IMPL", "c") != "python")
 
 
 def build_plan(shard, device):
@@ -248,9 +445,13 @@ class HipBackend:
 
 def make_weak_scaling_shard(rank, world, n, pairs, F, cut=None, device=None, seed=20260424):
     rows, cols, cut = shard_entries(rank, world, n, pairs, cut, seed)
-    sh = Shard(rank, world, n, rows, cols)
+    if _use_c_abi(device):
+        ia = np.concatenate([[1], 1 + np.cumsum(np.bincount(rows, minlength=n))])
+        sh = CShard(c_comm(torch.device(device)), ia, cols)
+    else:
+        sh = build_plan(Shard(rank, world, n, rows, cols), device)
     sh.cut = cut
-    return build_plan(sh, device)
+    return sh
 
 
 def make_global_shard(rank, world, n_total, pairs, device=None, seed=20260424, locality=None):
@@ -262,11 +463,14 @@ def make_global_shard(rank, world, n_total, pairs, device=None, seed=20260424, l
         raise ValueError(f"{n_total} vertices do not split into {world} equal row blocks")
     n = n_total // world
     ia, cols = synth.random_graph_csr_rows(n_total, pairs, rank * n, (rank + 1) * n, seed=seed, locality=locality)
-    rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(ia))
-    sh = Shard(rank, world, n, rows, cols)
+    if _use_c_abi(device):
+        sh = CShard(c_comm(torch.device(device)), ia, cols)
+    else:
+        rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(ia))
+        sh = build_plan(Shard(rank, world, n, rows, cols), device)
     sh.cut = None
     sh.n_total = n_total
-    return build_plan(sh, device)
+    return sh
 
 
 class KipfShardStep:
@@ -290,12 +494,8 @@ class KipfShardStep:
         self.b = backend or HipBackend(device)
         n, nh = shard.n, shard.n_halo
         ni = shard.n_int
-        def block(adj_ja, r0, r1):
-            ia, ja = shard.row_block(adj_ja, r0, r1)
-            return self.b.make_graph(ia, ja, n + nh, shard.row_deg[r0:r1], shard.col_deg)
         # interior rows touch no halo column: they run while the exchange is in flight
-        self.g_fwd_int, self.g_fwd_bnd = block(shard.adj_ja, 0, ni), block(shard.adj_ja, ni, n)
-        self.g_bwd_int, self.g_bwd_bnd = block(shard.adj_ja_bwd, 0, ni), block(shard.adj_ja_bwd, ni, n)
+        self.g_fwd_int, self.g_fwd_bnd, self.g_bwd_int, self.g_bwd_bnd = shard.graphs(self.b)
         self.exact = exact
         rng = np.random.Generator(np.random.PCG64([seed, shard.rank]))
         xw = Fo if self.transform_first else F            # width of the rows the forward exchange moves
@@ -325,21 +525,14 @@ class KipfShardStep:
             self.P = None
         else:
             self.P = torch.empty((n, F), dtype=torch.float32, device=device)
-        self.xchg = HaloExchange(shard, xw, device, self.b)               # forward rows
-        self.xchg_o = self.xchg if xw == Fo else HaloExchange(shard, Fo, device, self.b)   # dZ rows
+        self.xchg = shard.exchange(xw, device, self.b)                    # forward rows
+        self.xchg_o = self.xchg if xw == Fo else shard.exchange(Fo, device, self.b)       # dZ rows
 
     def _allreduce_dw(self):
         # asynchronous: a blocking all_reduce would make the compute stream wait for the collective, and the
-        # collective queues behind the halo transfer on the communicator's stream -- the interior rows
-        # would then start only after the exchange they are meant to hide
-        if self.s.world == 1:
-            return None
-        if _host_staged(self.dW):
-            h = self.dW.cpu()
-            dist.all_reduce(h)
-            self.dW.copy_(h)
-            return None
-        return dist.all_reduce(self.dW, async_op=True)
+        # collective queues behind the halo transfer on the communication stream -- the interior rows would then
+        # start only after the exchange they are meant to hide
+        return self.s.allreduce_start(self.dW)
 
     def __call__(self, events=None, events_bnd=None):
         """events / events_bnd: optional lists; a (start, end) pair of torch.cuda events around the interior / the
@@ -416,7 +609,8 @@ def build_kipf_step(shard, F, device, backend=None, Fo=None, order="auto", input
                  "pairs cross partitions at this N")
     info = {"graph": graph,
             "halo_rows_per_gpu": shard.n_halo, "halo_bytes_per_gpu_per_step": halo_bytes,
-            "interior_rows_per_gpu": shard.n_int, "interior_entries_per_gpu": int(shard.adj_ia[shard.n_int]) - 1}
+            "interior_rows_per_gpu": shard.n_int, "interior_entries_per_gpu": shard.interior_entries,
+            "transport": shard.transport}
     return step, shard.nnz, info
 
 

@@ -38,6 +38,11 @@ module athena_mp_c
   public :: athena_mp_kipf_layer_fwd, athena_mp_kipf_layer_bwd_x, athena_mp_activation_bwd
   public :: athena_mp_csr_from_edges, athena_mp_graph_export, athena_mp_graph_create_from_edges
   public :: athena_mp_error_message
+  public :: athena_mp_pull_gemm, athena_mp_dev_offset
+  public :: athena_mp_comm_create, athena_mp_comm_create_from_file, athena_mp_comm_destroy, athena_mp_comm_barrier
+  public :: athena_mp_comm_unique_id, athena_mp_allreduce, athena_mp_allreduce_start, athena_mp_allreduce_finish
+  public :: athena_mp_shard_create, athena_mp_shard_destroy, athena_mp_shard_dims, athena_mp_shard_graph
+  public :: athena_mp_shard_export, athena_mp_halo_start, athena_mp_halo_finish
 
   interface
      integer(c_int) function athena_mp_init(device) bind(C, name="athena_mp_init")
@@ -472,9 +477,109 @@ module athena_mp_c
        type(c_ptr), value :: graph, theta_dev, coords_dev, x_dev, grad_dev, dcoords_dev
        integer(c_int32_t), value :: d, H, Fi, Fo
      end function
+     !! ---- multi-GPU (csrc/comm.hip): one process per GPU, RCCL over xGMI ------------------------------------------
+     integer(c_int) function athena_mp_pull_gemm(graph, Fi, Fo, dZ_dev, W_dev, exact, dX_dev) &
+          bind(C, name="athena_mp_pull_gemm")
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: graph, dZ_dev, W_dev, dX_dev
+       integer(c_int32_t), value :: Fi, Fo, exact
+     end function
+     integer(c_int) function athena_mp_comm_unique_id(id128) bind(C, name="athena_mp_comm_unique_id")
+       import :: c_int, c_char
+       character(kind=c_char), intent(inout) :: id128(128)
+     end function
+     integer(c_int) function athena_mp_comm_create(rank, world, id128, comm) bind(C, name="athena_mp_comm_create")
+       import :: c_int, c_int32_t, c_char, c_ptr
+       integer(c_int32_t), value :: rank, world
+       character(kind=c_char), intent(in) :: id128(128)
+       type(c_ptr), intent(out) :: comm
+     end function
+     integer(c_int) function athena_mp_comm_create_from_file(rank, world, path, comm) &
+          bind(C, name="athena_mp_comm_create_from_file")
+       import :: c_int, c_int32_t, c_char, c_ptr
+       integer(c_int32_t), value :: rank, world
+       character(kind=c_char), intent(in) :: path(*)     !! null-terminated
+       type(c_ptr), intent(out) :: comm
+     end function
+     integer(c_int) function athena_mp_comm_destroy(comm) bind(C, name="athena_mp_comm_destroy")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: comm
+     end function
+     integer(c_int) function athena_mp_comm_barrier(comm) bind(C, name="athena_mp_comm_barrier")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: comm
+     end function
+     integer(c_int) function athena_mp_allreduce(comm, buf_dev, count) bind(C, name="athena_mp_allreduce")
+       import :: c_int, c_int64_t, c_ptr
+       type(c_ptr), value :: comm, buf_dev
+       integer(c_int64_t), value :: count
+     end function
+     integer(c_int) function athena_mp_allreduce_start(comm, buf_dev, count) bind(C, name="athena_mp_allreduce_start")
+       import :: c_int, c_int64_t, c_ptr
+       type(c_ptr), value :: comm, buf_dev
+       integer(c_int64_t), value :: count
+     end function
+     integer(c_int) function athena_mp_allreduce_finish(comm) bind(C, name="athena_mp_allreduce_finish")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: comm
+     end function
+     !! the rank's rows of graph_type%adj_ia / adj_ja (adj_ja(1,:) = GLOBAL neighbour ids)
+     integer(c_int) function athena_mp_shard_create(comm, n_local, nnz, adj_ia, adj_ja, shard) &
+          bind(C, name="athena_mp_shard_create")
+       import :: c_int, c_int32_t, c_int64_t, c_ptr
+       type(c_ptr), value :: comm
+       integer(c_int32_t), value :: n_local
+       integer(c_int64_t), value :: nnz
+       integer(c_int32_t), intent(in) :: adj_ia(*), adj_ja(2,*)
+       type(c_ptr), intent(out) :: shard
+     end function
+     integer(c_int) function athena_mp_shard_destroy(shard) bind(C, name="athena_mp_shard_destroy")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: shard
+     end function
+     integer(c_int) function athena_mp_shard_dims(shard, n_local, n_interior, n_halo, nnz, row_offset, n_total) &
+          bind(C, name="athena_mp_shard_dims")
+       import :: c_int, c_int32_t, c_int64_t, c_ptr
+       type(c_ptr), value :: shard
+       integer(c_int32_t), intent(out) :: n_local, n_interior, n_halo
+       integer(c_int64_t), intent(out) :: nnz, row_offset, n_total
+     end function
+     integer(c_int) function athena_mp_shard_graph(shard, which, graph) bind(C, name="athena_mp_shard_graph")
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: shard
+       integer(c_int32_t), value :: which
+       type(c_ptr), intent(out) :: graph
+     end function
+     integer(c_int) function athena_mp_shard_export(shard, which, host_dst, capacity, count) &
+          bind(C, name="athena_mp_shard_export")
+       import :: c_int, c_int32_t, c_int64_t, c_ptr
+       type(c_ptr), value :: shard
+       integer(c_int32_t), value :: which
+       type(*), dimension(*), intent(inout) :: host_dst
+       integer(c_int64_t), value :: capacity
+       integer(c_int64_t), intent(out) :: count
+     end function
+     integer(c_int) function athena_mp_halo_start(shard, slot, F, x_ext_dev) bind(C, name="athena_mp_halo_start")
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: shard, x_ext_dev
+       integer(c_int32_t), value :: slot, F
+     end function
+     integer(c_int) function athena_mp_halo_finish(shard, slot) bind(C, name="athena_mp_halo_finish")
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: shard
+       integer(c_int32_t), value :: slot
+     end function
   end interface
 
 contains
+
+  function athena_mp_dev_offset(p, elements) result(q)
+    !! device pointer `elements` float32 values past p (row blocks of a resident tensor)
+    type(c_ptr), intent(in) :: p
+    integer(c_int64_t), intent(in) :: elements
+    type(c_ptr) :: q
+    q = transfer(transfer(p, 0_c_intptr_t) + 4_c_intptr_t * int(elements, c_intptr_t), q)
+  end function athena_mp_dev_offset
 
   function athena_mp_error_message() result(msg)
     !! last C-side error as a Fortran string (what the layer hands to coreutils' stop_program)

@@ -238,13 +238,24 @@ class DeviceGraph:
         return self
 
     @classmethod
+    def borrow(cls, handle, owner=None):
+        """wrap a handle somebody else owns (the row blocks of an athena_mp_shard): never destroyed from here"""
+        self = cls.__new__(cls)
+        self.handle, self._borrowed, self._owner = handle, True, owner
+        nr, nc, nnz, ne = C.c_int32(), C.c_int32(), C.c_int64(), C.c_int32()
+        _capi.call("athena_mp_graph_dims", handle, C.byref(nr), C.byref(nc), C.byref(nnz), C.byref(ne))
+        self.n_rows, self.n_cols, self.nnz, self.n_edge_cols = nr.value, nc.value, nnz.value, ne.value
+        return self
+
+    @classmethod
     def from_graph(cls, g, device=0):
         return cls(g.adj_ia, g.adj_ja, n_edge_cols=max(g.num_edges, int(g.adj_ja[1].max()) if g.nnz else 0),
                    device=device)
 
     def close(self):
         if getattr(self, "handle", None):
-            _capi.load().athena_mp_graph_destroy(self.handle)
+            if not getattr(self, "_borrowed", False):
+                _capi.load().athena_mp_graph_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

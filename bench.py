@@ -180,20 +180,21 @@ def parity_sharded(step, shard, seeds, dev, n_sample=4000):
     rows = np.sort(rng.choice(n, min(n_sample, n), replace=False))
     W = step.W.cpu().numpy()
 
-    def sub(adj_ja):
-        ent = np.concatenate([np.arange(s.adj_ia[r] - 1, s.adj_ia[r + 1] - 1) for r in rows])
-        cols, inv = np.unique(adj_ja[0, ent].astype(np.int64) - 1, return_inverse=True)
-        sia = np.concatenate([[1], 1 + np.cumsum(s.adj_ia[rows + 1] - s.adj_ia[rows])]).astype(np.int32)
+    def sub(backward):
+        ia, nb = s.csr(backward)                      # the shard's own CSR ([local | halo] numbering), read back
+        ent = np.concatenate([np.arange(ia[r] - 1, ia[r + 1] - 1) for r in rows])
+        cols, inv = np.unique(nb[ent].astype(np.int64) - 1, return_inverse=True)
+        sia = np.concatenate([[1], 1 + np.cumsum(ia[rows + 1] - ia[rows])]).astype(np.int32)
         sja = np.zeros((2, ent.size), np.int32, order="F"); sja[0] = inv + 1
         return cols, sia, sja
 
     rsel = torch.from_numpy(rows).to(dev)
-    cols, sia, sja = sub(s.adj_ja)
+    cols, sia, sja = sub(False)
     xc = step.x_ext[torch.from_numpy(cols).to(dev)].cpu().numpy()
     p_ref = oracle.kipf_propagate_rect(xc, sia, sja, s.row_deg[rows], s.col_deg[cols])
     res["P_bit_exact"] = bool(np.array_equal(step.P[rsel].cpu().numpy(), p_ref))
     res["Z_rel"] = rel(step.Z[rsel].cpu().numpy(), oracle.matmul(W, p_ref, Fo))
-    cols, sia, sja = sub(s.adj_ja_bwd)
+    cols, sia, sja = sub(True)
     dzc = step.dZ_ext[torch.from_numpy(cols).to(dev)].cpu().numpy()
     dp = oracle.matmul_dx(W, dzc, F)                                            # reference order: W^T dZ, then the scatter
     ones = np.ones(max(rows.size, cols.size), np.int32)
@@ -400,6 +401,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
+        adist.c_comm_destroy()
         dist.destroy_process_group()
     if not ok:
         sys.exit("bench.py: parity against the oracle FAILED (see the 'parity' object of the line above)")

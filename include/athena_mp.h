@@ -342,6 +342,52 @@ int athena_mp_activation_param_fwd_host(int32_t kind, int64_t n, float scale, fl
 int athena_mp_activation_param_bwd_host(int32_t kind, int64_t n, float scale, float p0, float p1, const float *x,
                                         const float *g, float *dx);
 
+/* ---- multi-GPU: communicator, row-partition shard, halo exchange (comm.hip) -----------------------------------------
+ * The reference has no distributed code; these are the entry points SURVEY.md 8b/8e ask the
+ * boundary to export (athena_mp_comm_create / graph_partition / halo_exchange) so that a Fortran host reaches the
+ * 8-GPU Kipf step through ISO_C_BINDING, one process per GPU.  Transport: RCCL over xGMI -- grouped ncclSend /
+ * ncclRecv to every peer on a communication stream, event-ordered against the compute stream; ncclAllReduce for dW.
+ * (ATHENA_MP_COMM_TRANSPORT=shm swaps in a host-staged TEST transport for one-GPU boxes; never the default.)
+ * What the sharded step replaces: the per-sample loop of update_message_kipf, athena_kipf_msgpass_layer.f90:940-957,
+ * run on the rank's rows. */
+typedef struct athena_mp_comm athena_mp_comm;
+typedef struct athena_mp_shard athena_mp_shard;
+
+/* 128 opaque bytes (an ncclUniqueId) drawn by ONE rank and handed to all (MPI_Bcast, a file, a torch store ...) */
+int athena_mp_comm_unique_id(void *id128);
+/* collective; uses the device athena_mp_init selected */
+int athena_mp_comm_create(int32_t rank, int32_t world, const void *id128, athena_mp_comm **out);
+/* MPI-free bootstrap: rank 0 publishes the id in `path`, the others wait for it */
+int athena_mp_comm_create_from_file(int32_t rank, int32_t world, const char *path, athena_mp_comm **out);
+int athena_mp_comm_destroy(athena_mp_comm *c);
+int athena_mp_comm_info(const athena_mp_comm *c, int32_t *rank, int32_t *world, char *transport, int32_t transport_len);
+int athena_mp_comm_barrier(athena_mp_comm *c);
+/* in-place float32 sum over ranks (dW, d theta): _start enqueues it on the communication stream behind the work the
+ * compute stream holds so far, _finish makes the compute stream wait for it; the host never blocks */
+int athena_mp_allreduce_start(athena_mp_comm *c, float *buf_dev, int64_t count);
+int athena_mp_allreduce_finish(athena_mp_comm *c);
+int athena_mp_allreduce(athena_mp_comm *c, float *buf_dev, int64_t count);
+
+/* the rank's rows of the global graph: adj_ia [n_local+1] 1-based, adj_ja [2,nnz] column-major with adj_ja(1,w) = GLOBAL
+ * neighbour id (1-based; graph_type%adj_ja of the whole graph restricted to the rank's rows), adj_ja(2,.) ignored.
+ * Rows are contiguous blocks in rank order.  Builds the [local | halo] renumbering (interior rows first), the send
+ * lists, the halo degrees and the four row blocks as graph handles.  Collective. */
+int athena_mp_shard_create(athena_mp_comm *c, int32_t n_local, int64_t nnz, const int32_t *adj_ia, const int32_t *adj_ja,
+                           athena_mp_shard **out);
+int athena_mp_shard_destroy(athena_mp_shard *s);
+int athena_mp_shard_dims(const athena_mp_shard *s, int32_t *n_local, int32_t *n_interior, int32_t *n_halo, int64_t *nnz,
+                         int64_t *row_offset, int64_t *n_total);
+/* which: 0 / 1 = interior rows [0,n_int) / boundary rows [n_int,n) of the forward graph, 2 / 3 = the same blocks of the
+ * backward (pull) graph; columns index x_ext = [n local rows | n_halo halo rows]; owned by the shard */
+int athena_mp_shard_graph(const athena_mp_shard *s, int32_t which, athena_mp_graph **g);
+/* 0 order [n] int32 | 1 halo_ids [n_halo] int64 | 2 send_idx [n_send] int32 | 3 col_deg [n+n_halo] int32 |
+ * 4 send_counts [world] int64 | 5 recv_counts [world] int64;  host_dst NULL = size query (count in elements) */
+int athena_mp_shard_export(const athena_mp_shard *s, int32_t which, void *host_dst, int64_t capacity, int64_t *count);
+/* x_ext [n + n_halo, F]: pack + grouped send/recv into the halo rows; returns at once (kernels enqueued before _finish
+ * run under the transfer); slot 0 / 1 = two exchanges may be outstanding */
+int athena_mp_halo_start(athena_mp_shard *s, int32_t slot, int32_t F, float *x_ext_dev);
+int athena_mp_halo_finish(athena_mp_shard *s, int32_t slot);
+
 #ifdef __cplusplus
 }
 #endif
