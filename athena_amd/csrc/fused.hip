@@ -256,15 +256,248 @@ int launch_fused(const int32_t *rowptr, const int32_t *idx, const float *coef, c
     return 0;
 }
 
-bool fused_shape(int K, int N) { return K == N && (K == 64 || K == 128); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 256 -> 256 layers (BASELINE configs[4]'s width).  W is 256 KB: it does not fit the 160 KB of LDS, so it lives in
+// REGISTERS instead -- an 8-wave workgroup (two waves per SIMD, 256 registers per lane), wave w owning output columns
+// [32w, 32w+32): Wr[j][s] = B[k = 64 g4 + s][n = 32 w + 16 j + (lane & 15)] is exactly the B operand of MFMA step s of
+// column block j (128 registers), and only the gathered rows pass through LDS (two [16][260] tiles, 33 KB; pitch 260 with
+// k = 64 g4 + s is conflict-free for ds_read_b128).  A row is one whole wave (64 lanes x 16 B = 1 KB), a chunk is 16 rows =
+// two per wave, its [16 x 256] output is 16 column blocks = two per wave, 128 MFMAs (16x16x4) per wave per chunk, two
+// independent accumulators.  Same software pipeline as the LDS-resident kernel above: the first 8 row loads of each of the
+// wave's two NEXT rows are issued before the matrix work of the current chunk and consumed after it; rows are summed in CSR
+// order, so P is bit-identical to csr_gather_agg.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kFirst256 = 8;
+constexpr int kTail256 = 4;        // entries per row per round beyond the prefetched block (both rows together)
+
+template <bool COEF, int ACT>
+__global__ __launch_bounds__(512) void agg_gemm256_kernel(const int32_t *__restrict__ rowptr,
+                                                          const int32_t *__restrict__ idx,
+                                                          const float *__restrict__ coef,
+                                                          const float *__restrict__ x,
+                                                          const float *__restrict__ B, int b_nk,
+                                                          const float *__restrict__ bias,
+                                                          float *__restrict__ P, float *__restrict__ Z,
+                                                          int64_t n_rows, unsigned long long *__restrict__ ticket)
+{
+    constexpr int K = 256, N = 256, LD = 260, CH = 16, KG = 64, kF = kFirst256;
+    __shared__ __attribute__((aligned(16))) float Ts[2 * CH * LD];
+    __shared__ int64_t s_ticket[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int n0 = 32 * wave;
+
+    float Wr[2][64];
+    if (b_nk) {   // B stored [N][K]
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float *src = B + (int64_t)(n0 + 16 * j + l15) * K + KG * g4;
+#pragma unroll
+            for (int s4 = 0; s4 < 16; ++s4) {
+                const v4f t = *reinterpret_cast<const v4f *>(src + 4 * s4);
+                Wr[j][4 * s4 + 0] = t.x; Wr[j][4 * s4 + 1] = t.y; Wr[j][4 * s4 + 2] = t.z; Wr[j][4 * s4 + 3] = t.w;
+            }
+        }
+    } else {      // B stored [K][N]
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int s = 0; s < 64; ++s) Wr[j][s] = B[(int64_t)(KG * g4 + s) * N + n0 + 16 * j + l15];
+    }
+    float bv[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bv[j] = bias ? bias[n0 + 16 * j + l15] : 0.0f;
+
+    const int64_t n_chunks = (n_rows + CH - 1) / CH;
+    int start[2], len[2], idx0[2];
+    float c0[2];
+    auto load_state = [&](int64_t chunk) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            start[r] = 0; len[r] = 0; idx0[r] = -1; c0[r] = 0.0f;
+            const int64_t row = chunk * CH + 2 * wave + r;
+            if (chunk < n_chunks && row < n_rows) {
+                start[r] = rowptr[row];
+                len[r] = rowptr[row + 1] - start[r];
+            }
+            if (lane < len[r]) {
+                idx0[r] = idx[start[r] + lane];
+                if constexpr (COEF) c0[r] = coef[start[r] + lane];
+            }
+        }
+    };
+    v4f v[2][kF];
+    auto issue_first = [&]() {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int k = 0; k < kF; ++k) {
+                const int u = __shfl(idx0[r], k, 64);
+                v[r][k] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+                if (k < len[r] && u >= 0) v[r][k] = *reinterpret_cast<const v4f *>(x + (int64_t)u * K + 4 * lane);
+            }
+    };
+    // both rows of the wave advance TOGETHER through the entries beyond the prefetched block (two rows' loads in flight
+    // per round instead of one); each row still adds its entries in CSR order
+    auto store_rows = [&](int64_t chunk, int buf) {
+        v4f acc[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            acc[r] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int k = 0; k < kF; ++k) {
+                const int u = __shfl(idx0[r], k, 64);
+                const float c = COEF ? __shfl(c0[r], k, 64) : 1.0f;
+                if (k < len[r] && u >= 0) {
+                    if constexpr (COEF) { acc[r].x = acc[r].x + c * v[r][k].x; acc[r].y = acc[r].y + c * v[r][k].y; acc[r].z = acc[r].z + c * v[r][k].z; acc[r].w = acc[r].w + c * v[r][k].w; }
+                    else { acc[r].x = acc[r].x + v[r][k].x; acc[r].y = acc[r].y + v[r][k].y; acc[r].z = acc[r].z + v[r][k].z; acc[r].w = acc[r].w + v[r][k].w; }
+                }
+            }
+        }
+        const int nmax = max(len[0], len[1]);                // wave-uniform
+        for (int off = 0; off < nmax; off += 64) {
+            int my_idx[2];
+            float my_c[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                my_idx[r] = idx0[r]; my_c[r] = c0[r];
+                if (off > 0) {
+                    my_idx[r] = -1; my_c[r] = 0.0f;
+                    if (off + lane < len[r]) {
+                        my_idx[r] = idx[start[r] + off + lane];
+                        if constexpr (COEF) my_c[r] = coef[start[r] + off + lane];
+                    }
+                }
+            }
+            const int cnt = min(64, nmax - off);
+            for (int j = (off == 0 ? kF : 0); j < cnt; j += kTail256) {
+                int u[2][kTail256];
+                float c[2][kTail256];
+                v4f w[2][kTail256];
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int k = 0; k < kTail256; ++k) {
+                        u[r][k] = __shfl(my_idx[r], j + k, 64);
+                        if constexpr (COEF) c[r][k] = __shfl(my_c[r], j + k, 64);
+                        if (off + j + k >= len[r]) u[r][k] = -1;
+                    }
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int k = 0; k < kTail256; ++k) {
+                        w[r][k] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+                        if (u[r][k] >= 0) w[r][k] = *reinterpret_cast<const v4f *>(x + (int64_t)u[r][k] * K + 4 * lane);
+                    }
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int k = 0; k < kTail256; ++k) {
+                        if (u[r][k] >= 0) {
+                            if constexpr (COEF) { acc[r].x = acc[r].x + c[r][k] * w[r][k].x; acc[r].y = acc[r].y + c[r][k] * w[r][k].y; acc[r].z = acc[r].z + c[r][k] * w[r][k].z; acc[r].w = acc[r].w + c[r][k] * w[r][k].w; }
+                            else { acc[r].x = acc[r].x + w[r][k].x; acc[r].y = acc[r].y + w[r][k].y; acc[r].z = acc[r].z + w[r][k].z; acc[r].w = acc[r].w + w[r][k].w; }
+                        }
+                    }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int lrow = 2 * wave + r;
+            const int64_t row = chunk * CH + lrow;
+            *reinterpret_cast<v4f *>(Ts + (buf * CH + lrow) * LD + 4 * lane) = acc[r];
+            if (P != nullptr && chunk < n_chunks && row < n_rows) *reinterpret_cast<v4f *>(P + row * K + 4 * lane) = acc[r];
+        }
+    };
+    auto matrix_work = [&](int64_t chunk, int buf) {     // this wave's two 16x16 blocks of the chunk's [16 x 256] output
+        const float *arow = Ts + (buf * CH + l15) * LD + KG * g4;
+        f32x4 ca = {0.0f, 0.0f, 0.0f, 0.0f}, cb = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const v4f a4 = *reinterpret_cast<const v4f *>(arow + 4 * q);
+            ca = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, Wr[0][4 * q + 0], ca, 0, 0, 0);
+            cb = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, Wr[1][4 * q + 0], cb, 0, 0, 0);
+            ca = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, Wr[0][4 * q + 1], ca, 0, 0, 0);
+            cb = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, Wr[1][4 * q + 1], cb, 0, 0, 0);
+            ca = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, Wr[0][4 * q + 2], ca, 0, 0, 0);
+            cb = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, Wr[1][4 * q + 2], cb, 0, 0, 0);
+            ca = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, Wr[0][4 * q + 3], ca, 0, 0, 0);
+            cb = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, Wr[1][4 * q + 3], cb, 0, 0, 0);
+        }
+        const int64_t row0 = chunk * CH + 4 * g4;           // C/D: col = lane&15, row = 4*(lane>>4) + reg
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (row0 + r < n_rows) {
+                Z[(row0 + r) * N + n0 + l15] = act_f<ACT>(ca[r] + bv[0]);
+                Z[(row0 + r) * N + n0 + 16 + l15] = act_f<ACT>(cb[r] + bv[1]);
+            }
+    };
+
+    auto draw = [&]() -> int64_t { return (int64_t)atomicAdd(ticket, 1ull); };
+    if (tid == 0) { s_ticket[0] = draw(); s_ticket[1] = draw(); s_ticket[2] = draw(); }
+    __syncthreads();
+    int64_t k0 = s_ticket[0], k1 = s_ticket[1], k2 = s_ticket[2];
+    load_state(k0);
+    issue_first();
+    store_rows(k0, 0);
+    load_state(k1);
+    __syncthreads();
+    for (int it = 0; k0 < n_chunks; ++it) {
+        const int buf = it & 1;
+        issue_first();                                      // first kF row loads of both rows of k1 ...
+        matrix_work(k0, buf);                               // ... fly under the matrix work of k0
+        store_rows(k1, buf ^ 1);
+        load_state(k2);
+        if (tid == 0) s_ticket[it & 1] = draw();
+        __syncthreads();
+        k0 = k1;
+        k1 = k2;
+        k2 = s_ticket[it & 1];
+    }
+}
+
+template <bool COEF, int ACT>
+int launch_fused256(const int32_t *rowptr, const int32_t *idx, const float *coef, const float *x, const float *B, int b_nk,
+                    const float *bias, float *P, float *Z, int64_t n_rows, int grid)
+{
+    static int slot = 0;
+    unsigned long long *ring = nullptr;
+    if (amp::named_buffer("fused.ticket_ring", sizeof(unsigned long long) * 64, true, (void **)&ring)) return 1;
+    unsigned long long *ticket = ring + (slot++ & 63);
+    AMP_HIP(hipMemsetAsync(ticket, 0, sizeof(unsigned long long), amp::stream()));
+    hipLaunchKernelGGL((agg_gemm256_kernel<COEF, ACT>), dim3(grid), dim3(512), 0, amp::stream(), rowptr, idx, coef, x, B,
+                       b_nk, bias, P, Z, n_rows, ticket);
+    AMP_LAUNCH_CHECK();
+    return 0;
+}
+
+int fused256_dispatch(const int32_t *rowptr, const int32_t *idx, const float *coef, const float *x, const float *B, int b_nk,
+                      const float *bias, int act, float *P, float *Z, int64_t n_rows)
+{
+    const int grid = (int)std::min<int64_t>((n_rows + 15) / 16, amp::num_cus());
+    if (grid == 0) return 0;
+#define AMP_G(ACT_)                                                                                        \
+    return coef ? launch_fused256<true, ACT_>(rowptr, idx, coef, x, B, b_nk, bias, P, Z, n_rows, grid)    \
+                : launch_fused256<false, ACT_>(rowptr, idx, coef, x, B, b_nk, bias, P, Z, n_rows, grid)
+    switch (act) {
+    case ATHENA_MP_ACT_RELU: AMP_G(ATHENA_MP_ACT_RELU);
+    case ATHENA_MP_ACT_SIGMOID: AMP_G(ATHENA_MP_ACT_SIGMOID);
+    case ATHENA_MP_ACT_TANH: AMP_G(ATHENA_MP_ACT_TANH);
+    default: AMP_G(ATHENA_MP_ACT_NONE);
+    }
+#undef AMP_G
+}
+
+bool fused_shape(int K, int N) { return K == N && (K == 64 || K == 128 || K == 256); }
 
 int fused_dispatch(const int32_t *rowptr, const int32_t *idx, const float *coef, const float *x, int K, int N,
                    const float *B, int b_nk, const float *bias, int act, float *P, float *Z, int64_t n_rows)
 {
     if (!fused_shape(K, N)) {
-        amp::set_error("fused Kipf layer kernel: built for 64 -> 64 and 128 -> 128 features, got %d -> %d", K, N);
+        amp::set_error("fused Kipf layer kernel: built for 64 -> 64, 128 -> 128 and 256 -> 256 features, got %d -> %d", K, N);
         return 2;
     }
+    if (K == 256) return fused256_dispatch(rowptr, idx, coef, x, B, b_nk, bias, act, P, Z, n_rows);
     const int cus = amp::num_cus();
     const int ch = 16 * (64 / (N / 4));
     const int grid = (int)std::min<int64_t>((n_rows + ch - 1) / ch, cus);

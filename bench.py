@@ -308,6 +308,9 @@ def main():
         info = {}
 
     def barrier():
+        # drain this device first (compute AND the C ABI's communication stream), so that the process group's barrier
+        # never runs beside a transfer of the other communicator, then meet the other ranks
+        torch.cuda.synchronize()
         if world > 1:
             import torch.distributed as dist
             dist.barrier()

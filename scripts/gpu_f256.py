@@ -1,4 +1,4 @@
-"""C5-shaped shard on one GPU: Kipf layer fwd+bwd at F = 256 (two-kernel route: aggregation + tiled MFMA GEMM)."""
+"""C5-shaped shard on one GPU: Kipf layer fwd+bwd at F = 256: the two-kernel pieces, then the fused step (W in registers)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -28,4 +28,8 @@ print("gemm dw   %.3f ms" % t(lambda: ops.matmul_dw(P, dz)))
 print("agg bwd   %.3f ms" % t(lambda: ops.kipf_propagate_bwd(g, dz)))
 def step():
     p, z = ops.kipf_layer_fwd(g, x, w, F); ops.matmul_dw(p, dz); ops.kipf_layer_bwd_x(g, dz, w, F)
-print("step      %.3f ms" % t(step))
+print("fused fwd %.3f ms" % t(lambda: ops.kipf_layer_fwd(g, x, w, F)))
+print("fused bwd %.3f ms" % t(lambda: ops.kipf_layer_bwd_x(g, dz, w, F)))
+ts = t(step)
+nnz = ja.shape[1]
+print("step      %.3f ms  (%.2f G edges/s; fused fwd bytes %.1f GB)" % (ts, nnz / ts / 1e6, (nnz * (4 * F + 8) + N * (4 * F + 8) + N * 4 * F) / 1e9))

@@ -1,8 +1,10 @@
-"""GPU: the N > 1 row-partitioned Kipf step with the PRODUCT backend (HIP kernels), several ranks sharing the
-one GPU of the box and gloo (host-staged) as transport -- partition, halo plan, interior/boundary split, the two
-exchanges and the dW all-reduce drive real kernels; the assembled result is checked against the single-process
-oracle on the assembled global graph.  (RCCL itself needs one GPU per rank and is exercised by the driver's
-multi-GPU bench.)"""
+"""GPU: the N > 1 row-partitioned Kipf step with the PRODUCT path -- HIP kernels and the C ABI's communicator / shard /
+halo exchange (csrc/comm.hip) -- several ranks sharing the one GPU of the box.  RCCL refuses two ranks on one device
+("Duplicate GPU detected"), so these runs use comm.hip's host-staged TEST transport (ATHENA_MP_COMM_TRANSPORT=shm):
+partition, renumbering, send lists, halo degrees, interior/boundary split, both exchanges and the dW all-reduce are the
+product code; only the nccl* calls are replaced.  RCCL itself runs here with one rank (communicator, barrier,
+all-reduce) and with one GPU per rank in the driver's multi-GPU bench.  Results are checked against the single-process
+oracle on the assembled global graph."""
 import os
 import sys
 
@@ -35,8 +37,9 @@ def _worker(rank, world, port, n, pairs, F, cut, q, Fo=None):
                       P=step.P.cpu().numpy().copy() if step.P is not None else None, transform_first=step.transform_first,
                       Z=step.Z.cpu().numpy().copy(), dW=step.dW.cpu().numpy().copy(),
                       dX=dx, order=shard.order.copy(), n_int=shard.n_int, n_halo=shard.n_halo,
-                      fwd_ms=ev[0][0].elapsed_time(ev[0][1]))))
+                      fwd_ms=ev[0][0].elapsed_time(ev[0][1]), transport=shard.transport)))
     dist.barrier()
+    adist.c_comm_destroy()
     dist.destroy_process_group()
 
 
@@ -88,6 +91,7 @@ def test_multi_rank_step_with_hip_backend_matches_global_oracle(dev, oracle, wor
     for r in range(world):
         assert np.abs(res[r]["dW"] - dW).max() <= 1e-5 * np.abs(dW).max()
         assert res[r]["n_halo"] > 0 and res[r]["fwd_ms"] > 0
+        assert res[r]["transport"].startswith("shm")     # the C-ABI shard / exchange (comm.hip) over its test transport
 
 
 def _dp_worker(rank, world, port, q):

@@ -486,7 +486,7 @@ def torch_equal_twice(fn):
     return torch.equal(fn(), fn())
 
 
-@pytest.mark.parametrize("act,F", [("none", 128), ("relu", 128), ("none", 64), ("tanh", 64)])
+@pytest.mark.parametrize("act,F", [("none", 128), ("relu", 128), ("none", 64), ("tanh", 64), ("none", 256), ("sigmoid", 256)])
 def test_fused_kipf_layer_kernels(dev, oracle, act, F):
     """one-launch aggregation + dense step: P bit-exact vs the oracle's kipf_propagate, Z and dX within
     1e-5 of the oracle's unfused order (incl. a hub row, zero-degree rows, a ragged tail chunk)"""
@@ -532,6 +532,16 @@ def test_fused_kipf_layer_kernels(dev, oracle, act, F):
     Po3 = oracle.kipf_propagate(x, ia3, ja3)
     assert np.array_equal(H(P3), Po3)
     assert_close(H(Z3), oracle.activation(act, oracle.matmul(w, Po3, F)), 1e-5, "fused Z (dense rows)")
+    if F == 256:   # rows of 65..160 entries: the second 64-entry index block of the wave-per-row mapping (W in registers)
+        ia4, ja4 = random_graph(1500, 50 * 1500, seed=79, self_loops=True)
+        assert np.diff(ia4).max() > 64
+        g4 = DeviceGraph(ia4, ja4, n_edge_cols=0)
+        P4, Z4 = ops.kipf_layer_fwd(g4, T(x[:1500], dev), T(w, dev), F, act=act)
+        Po4 = oracle.kipf_propagate(x[:1500], ia4, ja4)
+        assert np.array_equal(H(P4), Po4)
+        assert_close(H(Z4), oracle.activation(act, oracle.matmul(w, Po4, F)), 1e-5, "fused Z (64+ entry rows)")
+        assert_close(H(ops.kipf_layer_bwd_x(g4, T(dz[:1500], dev), T(w, dev), F)),
+                     oracle.kipf_propagate_bwd(oracle.matmul_dx(w, dz[:1500], F), ia4, ja4), 1e-5, "fused dX (64+ entry rows)")
     # other widths take the two-kernel route behind the same entry points
     x2 = rng.uniform(-1, 1, (n, 64)).astype(np.float32); w2 = rng.standard_normal(64 * 32).astype(np.float32)
     P2, Z2 = ops.kipf_layer_fwd(g, T(x2, dev), T(w2, dev), 32)
