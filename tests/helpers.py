@@ -59,7 +59,32 @@ def rel_err(a, b):
     return float(np.abs(np.asarray(a, np.float64) - b).max() / max(np.abs(b).max(), 1e-30))
 
 
-def assert_close(a, b, rtol=1e-5, what=""):
-    """north-star tolerance: 1e-5 relative fp32 (relative to the tensor's scale)."""
+def assert_close(a, b, rtol=1e-5, what="", f64=None):
+    """north-star tolerance: 1e-5 relative fp32 (relative to the tensor's scale) against the fp32 oracle `b`.
+
+    f64 (an array, or a callable evaluated only when needed): the SAME reference formulas evaluated in float64
+    (oracle/oracle64.py).  Chains of fp32 roundings (a reduction over thousands of vertices, several layers in a row) can
+    put the fp32 oracle itself more than 1e-5 from exact arithmetic; the device result then passes when it is no further
+    from the float64 value than the oracle is, plus rtol:  |a - f64| <= |b - f64| + rtol * scale.  A device result that is
+    simply wrong fails both tests."""
     e = rel_err(a, b)
+    if e <= rtol:
+        return
+    if f64 is not None:
+        ref = np.asarray(f64() if callable(f64) else f64, np.float64)
+        scale = max(np.abs(ref).max(), 1e-30)
+        e_dev = float(np.abs(np.asarray(a, np.float64) - ref).max() / scale)
+        e_orc = float(np.abs(np.asarray(b, np.float64) - ref).max() / scale)
+        assert e_dev <= e_orc + rtol, (f"{what}: {e:.3e} from the fp32 oracle; {e_dev:.3e} from float64 where the oracle "
+                                       f"itself is {e_orc:.3e} (allowed: oracle's distance + {rtol})")
+        return
     assert e <= rtol, f"{what}: rel err {e:.3e} > {rtol}"
+
+
+def assert_close_elementwise(a, b, scale, rtol=1e-5, what=""):
+    """element-wise check for sums: |a - b| <= rtol * scale element by element, where `scale` is the sum of the
+    MAGNITUDES of the terms of each element (the quantity fp32 summation error is relative to; an element whose terms
+    cancel is not held to a relative error of its tiny value, and is not excused by the tensor's maximum either)."""
+    a, b, scale = (np.asarray(t, np.float64) for t in (a, b, scale))
+    bad = np.abs(a - b) > rtol * scale + 1e-30
+    assert not bad.any(), f"{what}: {int(bad.sum())} element(s) beyond {rtol} of their term magnitudes; worst {float((np.abs(a - b) / np.maximum(scale, 1e-30)).max()):.3e}"

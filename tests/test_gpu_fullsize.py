@@ -303,7 +303,7 @@ def test_tensors_beyond_2_31_elements_use_64_bit_offsets(dev, oracle):
     dz = torch.rand((N, 64), device=dev, generator=gen) - 0.5
     dw = ops.matmul_dw(y[:, :64].contiguous(), dz)                  # 64 x 64 reduction over 9 M rows
     ref = (y[:, :64].double().T @ dz.double()).reshape(-1)
-    assert (dw.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    assert (dw.double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()   # 9 M fp32 terms per element, vs float64
     # backward aggregation: coefficient-free scatter conserves mass per feature column
     del dz, dw
     dx = ops.kipf_propagate_bwd(g, x)

@@ -1,6 +1,8 @@
 """GPU: the three layer types end to end (forward, explicit reverse pass, accessor round trips)
 against the per-sample oracle restatement.  Mirrors the reference's layer tests
 (test/test_kipf_msgpass_layer.f90, test_duvenaud_msgpass_layer.f90, test_gno_layer.f90)."""
+import functools
+
 import numpy as np
 import pytest
 
@@ -93,9 +95,16 @@ def test_duvenaud_layer_msgpass_chemical_shape(dev, Fv, Fe, T, nout):
     gout = rng.uniform(-1, 1, out.shape).astype(np.float32)
     dx, de = layer.backward(gout, need_edge_grad=True)
     dxs, des, grads = ol.duvenaud_backward(gs, es, tapes, plist, nvf, Fe, 1, 10, nout, "sigmoid", gout)
-    assert_close(dx.cpu().numpy(), np.concatenate(dxs), 2e-5, "duvenaud dx")
-    assert_close(de.cpu().numpy(), np.concatenate(des), 2e-5, "duvenaud de")
-    assert_close(layer.get_gradients(), np.concatenate(grads), 2e-5, "duvenaud dparams")
+
+    @functools.lru_cache(None)
+    def hi():   # the same composition on the oracle's float64 twin: yardstick of the anchored 1e-5 (helpers.assert_close)
+        with ol.double_precision():
+            _, t64 = ol.duvenaud_forward(gs, xs, es, plist, nvf, Fe, 1, 10, nout, "sigmoid")
+            a, b, c = ol.duvenaud_backward(gs, es, t64, plist, nvf, Fe, 1, 10, nout, "sigmoid", gout)
+        return np.concatenate(a), np.concatenate(b), np.concatenate(c)
+    assert_close(dx.cpu().numpy(), np.concatenate(dxs), 1e-5, "duvenaud dx", f64=lambda: hi()[0])
+    assert_close(de.cpu().numpy(), np.concatenate(des), 1e-5, "duvenaud de", f64=lambda: hi()[1])
+    assert_close(layer.get_gradients(), np.concatenate(grads), 1e-5, "duvenaud dparams", f64=lambda: hi()[2])
 
 
 @pytest.mark.parametrize("Fi,Fo,d,H,bias,act", [(3, 5, 1, 8, True, "none"), (8, 8, 3, 16, False, "relu"), (32, 32, 3, 32, True, "tanh")])
@@ -125,9 +134,16 @@ def test_gno_layer(dev, Fi, Fo, d, H, bias, act):
     ups = [rng.uniform(-1, 1, o.shape).astype(np.float32) for o in outs]
     dx, dc = layer.backward(np.concatenate(ups), need_coord_grad=True)
     dxs, dcs, grads = ol.gno_backward(gs, xs, cs, tapes, plist, Fi, Fo, d, H, bias, act, ups)
-    assert_close(dx.cpu().numpy(), np.concatenate(dxs), 2e-5, "gno dx")
-    assert_close(dc.cpu().numpy(), np.concatenate(dcs), 2e-5, "gno dcoords")
-    assert_close(layer.get_gradients(), np.concatenate(grads), 2e-5, "gno dparams")
+
+    @functools.lru_cache(None)
+    def hi():
+        with ol.double_precision():
+            _, t64 = ol.gno_forward(gs, xs, cs, plist, Fi, Fo, d, H, bias, act)
+            a, b, c = ol.gno_backward(gs, xs, cs, t64, plist, Fi, Fo, d, H, bias, act, ups)
+        return np.concatenate(a), np.concatenate(b), np.concatenate(c)
+    assert_close(dx.cpu().numpy(), np.concatenate(dxs), 1e-5, "gno dx", f64=lambda: hi()[0])
+    assert_close(dc.cpu().numpy(), np.concatenate(dcs), 1e-5, "gno dcoords", f64=lambda: hi()[1])
+    assert_close(layer.get_gradients(), np.concatenate(grads), 1e-5, "gno dparams", f64=lambda: hi()[2])
     assert np.array_equal(layer.forward(xs, cs).cpu().numpy(), out)
 
 
@@ -201,12 +217,14 @@ def test_kipf_layers_on_the_euler_mesh(dev, oracle):
     layer.set_graph(g)
     out = layer.forward([x]).cpu().numpy()
     outs, tapes = ol.kipf_forward([g], [x], plist, nvf, "tanh")
-    assert_close(out, outs[0], 2e-5, "euler mesh forward (5 steps)")
+    assert_close(out, outs[0], 1e-5, "euler mesh forward (5 steps)",
+                 f64=ol.f64_lazy(lambda: ol.kipf_forward([g], [x], plist, nvf, "tanh")[0])(0))
     up = rng.uniform(-1, 1, out.shape).astype(np.float32)
     dx = layer.backward(up).cpu().numpy()
     dxs, grads = ol.kipf_backward([g], tapes, plist, nvf, "tanh", [up])
-    assert_close(dx, dxs[0], 5e-5, "euler mesh dX")
-    assert_close(layer.get_gradients(), np.concatenate(grads), 5e-5, "euler mesh dW")
+    hi = ol.f64_lazy(lambda: ol.kipf_backward([g], ol.kipf_forward([g], [x], plist, nvf, "tanh")[1], plist, nvf, "tanh", [up]))
+    assert_close(dx, dxs[0], 1e-5, "euler mesh dX", f64=hi(0))
+    assert_close(layer.get_gradients(), np.concatenate(grads), 1e-5, "euler mesh dW", f64=hi(1))
 
 
 def test_duvenaud_layer_on_the_all_graphs_fixture(dev, oracle):
@@ -303,8 +321,10 @@ def test_duvenaud_layer_with_another_readout_activation(dev, act_readout):
     up = rng.uniform(-1, 1, out.shape).astype(np.float32)
     dx = layer.backward(up).cpu().numpy()
     dxs, des, grads = ol.duvenaud_backward(gs, es, tapes, plist, nvf, Fe, 1, 6, nout, "sigmoid", up, act_readout=act_readout)
-    assert_close(dx, np.concatenate(dxs), 2e-5, f"readout activation {act_readout}: dx")
-    assert_close(layer.get_gradients(), np.concatenate(grads), 2e-5, f"readout activation {act_readout}: gradients")
+    hi = ol.f64_lazy(lambda: ol.duvenaud_backward(gs, es, ol.duvenaud_forward(gs, xs, es, plist, nvf, Fe, 1, 6, nout, "sigmoid", act_readout=act_readout)[1],
+                                                  plist, nvf, Fe, 1, 6, nout, "sigmoid", up, act_readout=act_readout))
+    assert_close(dx, np.concatenate(dxs), 1e-5, f"readout activation {act_readout}: dx", f64=hi(0))
+    assert_close(layer.get_gradients(), np.concatenate(grads), 1e-5, f"readout activation {act_readout}: gradients", f64=hi(2))
 
 
 @pytest.mark.parametrize("layer_kind", ["kipf", "duvenaud", "graph_nop"])
@@ -335,8 +355,9 @@ def test_layers_with_attributed_activations(dev, layer_kind, name, attrs):
         ups = [rng.uniform(-1, 1, o.shape).astype(np.float32) for o in outs]
         dx = layer.backward(np.concatenate(ups)).cpu().numpy()
         dxs, grads = ol.kipf_backward(gs, tapes, plist, nvf, act, ups)
-        assert_close(dx, np.concatenate(dxs), 2e-5, "dx")
-        assert_close(layer.get_gradients(), np.concatenate(grads), 2e-5, "dW")
+        hi = ol.f64_lazy(lambda: ol.kipf_backward(gs, ol.kipf_forward(gs, xs, plist, nvf, act)[1], plist, nvf, act, ups))
+        assert_close(dx, np.concatenate(dxs), 1e-5, "dx", f64=hi(0))
+        assert_close(layer.get_gradients(), np.concatenate(grads), 1e-5, "dW", f64=hi(1))
         # the card carries the attributes and reads back to the same layer
         from athena_amd.layers import read_layer
         card = layer.print()
@@ -365,8 +386,10 @@ def test_layers_with_attributed_activations(dev, layer_kind, name, attrs):
         up = rng.uniform(-1, 1, out.shape).astype(np.float32)
         dx = layer.backward(up).cpu().numpy()
         dxs, des, grads = ol.duvenaud_backward(gs, es, tapes, plist, nvf, Fe, 1, D, nout, act, up, act_readout=act)
-        assert_close(dx, np.concatenate(dxs), 2e-5, "dx")
-        assert_close(layer.get_gradients(), np.concatenate(grads), 2e-5, "gradients")
+        hi = ol.f64_lazy(lambda: ol.duvenaud_backward(gs, es, ol.duvenaud_forward(gs, xs, es, plist, nvf, Fe, 1, D, nout, act, act_readout=act)[1],
+                                                      plist, nvf, Fe, 1, D, nout, act, up, act_readout=act))
+        assert_close(dx, np.concatenate(dxs), 1e-5, "dx", f64=hi(0))
+        assert_close(layer.get_gradients(), np.concatenate(grads), 1e-5, "gradients", f64=hi(2))
         # default softmax readout with an attributed message activation: the fused readout reverse + separate factor
         layer2 = duvenaud_msgpass_layer_type(num_vertex_features=[Fv], num_edge_features=[Fe], num_time_steps=T_,
                                              max_vertex_degree=D, num_outputs=nout, min_vertex_degree=1,
@@ -378,8 +401,10 @@ def test_layers_with_attributed_activations(dev, layer_kind, name, attrs):
         assert_close(out2, outs2, 1e-5, "fwd (softmax readout)")
         dx2 = layer2.backward(up).cpu().numpy()
         dxs2, _, grads2 = ol.duvenaud_backward(gs, es, tapes2, plist, nvf, Fe, 1, D, nout, act, up)
-        assert_close(dx2, np.concatenate(dxs2), 2e-5, "dx (softmax readout)")
-        assert_close(layer2.get_gradients(), np.concatenate(grads2), 2e-5, "gradients (softmax readout)")
+        hi2 = ol.f64_lazy(lambda: ol.duvenaud_backward(gs, es, ol.duvenaud_forward(gs, xs, es, plist, nvf, Fe, 1, D, nout, act)[1],
+                                                       plist, nvf, Fe, 1, D, nout, act, up))
+        assert_close(dx2, np.concatenate(dxs2), 1e-5, "dx (softmax readout)", f64=hi2(0))
+        assert_close(layer2.get_gradients(), np.concatenate(grads2), 1e-5, "gradients (softmax readout)", f64=hi2(2))
     else:
         gs = _graphs(rng, [20, 11], self_loops=False)
         Fi, Fo, d, H_ = 4, 6, 2, 8
@@ -401,9 +426,11 @@ def test_layers_with_attributed_activations(dev, layer_kind, name, attrs):
         ups = [rng.uniform(-1, 1, o.shape).astype(np.float32) for o in outs]
         dx, dc = layer.backward(np.concatenate(ups), need_coord_grad=True)
         dxs, dcs, grads = ol.gno_backward(gs, xs, cs, tapes, plist, Fi, Fo, d, H_, True, act, ups)
-        assert_close(dx.cpu().numpy(), np.concatenate(dxs), 2e-5, "dx")
-        assert_close(dc.cpu().numpy(), np.concatenate(dcs), 2e-5, "dcoords")
-        assert_close(layer.get_gradients(), np.concatenate(grads), 2e-5, "dparams")
+        hi = ol.f64_lazy(lambda: ol.gno_backward(gs, xs, cs, ol.gno_forward(gs, xs, cs, plist, Fi, Fo, d, H_, True, act)[1],
+                                                 plist, Fi, Fo, d, H_, True, act, ups))
+        assert_close(dx.cpu().numpy(), np.concatenate(dxs), 1e-5, "dx", f64=hi(0))
+        assert_close(dc.cpu().numpy(), np.concatenate(dcs), 1e-5, "dcoords", f64=hi(1))
+        assert_close(layer.get_gradients(), np.concatenate(grads), 1e-5, "dparams", f64=hi(2))
 
 
 @pytest.mark.parametrize("act", ["none", "relu", "swish"])
@@ -434,12 +461,13 @@ def test_kipf_layer_dense_step_before_the_aggregation(dev, act, exact):
         ups = [np.random.default_rng(5).uniform(-1, 1, o.shape).astype(np.float32) for o in outs]
         dx = layer.backward(np.concatenate(ups), exact=exact).cpu().numpy()
         dxs, grads = ol.kipf_backward(gs, tapes, plist, nvf, act, ups, exact=exact)
-        assert_close(dx, np.concatenate(dxs), 2e-5, f"{order}: dx")
-        assert_close(layer.get_gradients(), np.concatenate(grads), 2e-5, f"{order}: dW")
+        hi = ol.f64_lazy(lambda: ol.kipf_backward(gs, ol.kipf_forward(gs, xs, plist, nvf, act)[1], plist, nvf, act, ups, exact=exact))
+        assert_close(dx, np.concatenate(dxs), 1e-5, f"{order}: dx", f64=hi(0))
+        assert_close(layer.get_gradients(), np.concatenate(grads), 1e-5, f"{order}: dW", f64=hi(1))
         # first layer of a network: no input gradient requested, dW still complete
         layer.forward(xs)
         assert layer.backward(np.concatenate(ups), need_input_grad=False, exact=exact) is None
-        assert_close(layer.get_gradients(), np.concatenate(grads), 2e-5, f"{order}: dW without dx")
+        assert_close(layer.get_gradients(), np.concatenate(grads), 1e-5, f"{order}: dW without dx", f64=hi(1))
 
 
 def test_layer_addition_and_reduction(dev):

@@ -107,8 +107,39 @@ def _oracle_net_forward(g, x, params):
 
 
 def oracle_concat(a, b):
-    from oracle import oracle as o
-    return o.concat(a, b)
+    return ol.o.concat(a, b)          # ol.o: the fp32 oracle, or its float64 twin under ol.double_precision()
+
+
+def _trajectory(host_pass):
+    """the host-side reference of a short training run, computed twice: with the fp32 oracle (what the device results are
+    held against) and -- lazily -- with its float64 twin, the yardstick of helpers.assert_close(..., f64=).
+    host_pass() runs ALL passes and returns a list of dicts (one per pass)."""
+    import contextlib
+
+    class _T:
+        ref = host_pass()
+        _hi = None
+
+        @classmethod
+        def hi(cls, it, key, k=None):
+            def get():
+                if cls._hi is None:
+                    with ol.double_precision():
+                        cls._hi = host_pass()
+                v = cls._hi[it][key]
+                return v if k is None else v[k]
+            return get
+    return _T
+
+
+def _scalar_close(a, b, rtol, f64=None):
+    """|a - b| <= rtol |b|, or (anchored) a no further from the float64 value than b is, plus rtol"""
+    if abs(a - b) <= rtol * abs(b):
+        return True
+    if f64 is None:
+        return False
+    h = float(f64())
+    return abs(a - h) <= abs(b - h) + rtol * abs(h)
 
 
 def _oracle_net_backward(g, params, tapes, up):
@@ -144,26 +175,38 @@ def test_msgpass_euler_network_resident_chain(dev, oracle):
     net.set_graph(g)
     net.compile(optim.adam_optimiser_type(learning_rate=0.005, clip_dict=optim.clip_type(clip_norm=1.0)))
     assert net.get_num_params() == sum(a * b for (a, b), _ in EULER)
-    params = [l.get_params().copy() for l in net.layers]
-    m = np.zeros(net.get_num_params(), np.float32); v = np.zeros_like(m)
+    params0 = [l.get_params().copy() for l in net.layers]
+
+    def host_pass():
+        params = [p.astype(ol._REAL) for p in params0]
+        m = np.zeros(net.get_num_params(), ol._REAL); v = np.zeros_like(m)
+        rec = []
+        for it in (1, 2):
+            outs, tapes = _oracle_net_forward(g, x, params)
+            lo, do = ol.o.mse(outs[-1], y)
+            grads = _oracle_net_backward(g, params, tapes, do)
+            flat = ol.o.clip(np.concatenate(grads), clip_norm=1.0)
+            pf, _, m, v = ol.o.adam_step(np.concatenate(params), flat, m, v, 0.005, it)
+            o_, new = 0, []
+            for k in range(len(params)):
+                new.append(pf[o_:o_ + params[k].size]); o_ += params[k].size
+            params = new
+            rec.append(dict(out=outs[-1], loss=lo, grads=grads, params=params))
+        return rec
+    tr = _trajectory(host_pass)
     for it in (1, 2):
+        ref = tr.ref[it - 1]
         out = net.forward([x])
-        outs, tapes = _oracle_net_forward(g, x, params)
-        assert_close(H(out), outs[-1], 2e-5, f"euler network forward, pass {it}")
+        assert_close(H(out), ref["out"], 1e-5, f"euler network forward, pass {it}", f64=tr.hi(it - 1, "out"))
         loss, dl = optim.mse_loss_type().compute(out, T(y, dev))
-        lo, do = oracle.mse(outs[-1], y)
-        assert abs(float(loss.item()) - lo) <= 2e-5 * abs(lo)
+        assert _scalar_close(float(loss.item()), ref["loss"], 1e-5, tr.hi(it - 1, "loss"))
         net.backward(dl)
-        grads = _oracle_net_backward(g, params, tapes, do)
         for k, l in enumerate(net.layers):
-            assert_close(l.get_gradients(), grads[k], 1e-4, f"dW of layer {k + 1}, pass {it}")
+            assert_close(l.get_gradients(), ref["grads"][k], 1e-5, f"dW of layer {k + 1}, pass {it}", f64=tr.hi(it - 1, "grads", k))
         net.update()
-        flat = oracle.clip(np.concatenate(grads), clip_norm=1.0)
-        pf, _, m, v = oracle.adam_step(np.concatenate(params), flat, m, v, 0.005, it)
-        o_ = 0
-        for k in range(len(params)):
-            params[k] = pf[o_:o_ + params[k].size]; o_ += params[k].size
-            assert_close(net.layers[k].get_params(), params[k], 1e-4, f"parameters of layer {k + 1} after update {it}")
+        for k in range(len(params0)):
+            assert_close(net.layers[k].get_params(), ref["params"][k], 1e-5, f"parameters of layer {k + 1} after update {it}",
+                         f64=tr.hi(it - 1, "params", k))
 
 
 def test_captured_step_replays_the_eager_step(dev, oracle):
@@ -255,38 +298,49 @@ def test_msgpass_chemical_network_resident(dev, oracle):
             pl.append(flat[o_:o_ + nd * nvf[t]]); o_ += nd * nvf[t]
         return pl
 
-    params = [l.get_params().copy() for l in net.layers]
-    m = np.zeros(net.get_num_params(), np.float32); v = np.zeros_like(m)
+    params0 = [l.get_params().copy() for l in net.layers]
+
+    def host_pass():
+        params = [p.astype(ol._REAL) for p in params0]
+        m = np.zeros(net.get_num_params(), ol._REAL); v = np.zeros_like(m)
+        rec = []
+        for it in (1, 2):
+            pl = split_duv(params[0])
+            h, tapes = ol.duvenaud_forward(gs, xs, es, pl, nvf, Fe, 1, D, nd, "sigmoid")
+            acts, keep = [h], []
+            for k, (fi, fo) in enumerate(dense):
+                W, b = params[1 + k][:fi * fo], params[1 + k][fi * fo:]
+                yk, zk = ol.full_forward(acts[-1], W, b, fo, "leaky_relu")
+                keep.append((W, b, yk, zk)); acts.append(yk)
+            lo, do = ol.o.mse(acts[-1], y)
+            gc, grads = do, [None] * 4
+            for k in range(2, -1, -1):
+                W, b, yk, zk = keep[k]
+                gc, gk = ol.full_backward(acts[k], W, b, yk, zk, "leaky_relu", gc)
+                grads[1 + k] = np.concatenate(gk)
+            _, _, gd = ol.duvenaud_backward(gs, es, tapes, pl, nvf, Fe, 1, D, nd, "sigmoid", gc)
+            grads[0] = np.concatenate(gd)
+            pf, _, m, v = ol.o.adam_step(np.concatenate(params), np.concatenate(grads), m, v, 0.01, it)
+            o_, new = 0, []
+            for k in range(len(params)):
+                new.append(pf[o_:o_ + params[k].size]); o_ += params[k].size
+            params = new
+            rec.append(dict(out=acts[-1], loss=lo, grads=grads, params=params))
+        return rec
+    tr = _trajectory(host_pass)
     for it in (1, 2):
+        ref = tr.ref[it - 1]
         out = net.forward(xs, es)
-        pl = split_duv(params[0])
-        h, tapes = ol.duvenaud_forward(gs, xs, es, pl, nvf, Fe, 1, D, nd, "sigmoid")
-        acts = [h]
-        keep = []
-        for k, (fi, fo) in enumerate(dense):
-            W, b = params[1 + k][:fi * fo], params[1 + k][fi * fo:]
-            yk, zk = ol.full_forward(acts[-1], W, b, fo, "leaky_relu")
-            keep.append((W, b, yk, zk)); acts.append(yk)
-        assert_close(H(out), acts[-1], 2e-5, f"chemical network forward, pass {it}")
+        assert_close(H(out), ref["out"], 1e-5, f"chemical network forward, pass {it}", f64=tr.hi(it - 1, "out"))
         loss, dl = optim.mse_loss_type().compute(out, T(y, dev))
-        lo, do = oracle.mse(acts[-1], y)
-        assert abs(float(loss.item()) - lo) <= 2e-5 * abs(lo)
+        assert _scalar_close(float(loss.item()), ref["loss"], 1e-5, tr.hi(it - 1, "loss"))
         net.backward(dl)
-        gc, grads = do, [None] * 4
-        for k in range(2, -1, -1):
-            W, b, yk, zk = keep[k]
-            gc, gk = ol.full_backward(acts[k], W, b, yk, zk, "leaky_relu", gc)
-            grads[1 + k] = np.concatenate(gk)
-        _, _, gd = ol.duvenaud_backward(gs, es, tapes, pl, nvf, Fe, 1, D, nd, "sigmoid", gc)
-        grads[0] = np.concatenate(gd)
         for k, l in enumerate(net.layers):
-            assert_close(l.get_gradients(), grads[k], 1e-4, f"gradients of layer {k + 1}, pass {it}")
+            assert_close(l.get_gradients(), ref["grads"][k], 1e-5, f"gradients of layer {k + 1}, pass {it}", f64=tr.hi(it - 1, "grads", k))
         net.update()
-        pf, _, m, v = oracle.adam_step(np.concatenate(params), np.concatenate(grads), m, v, 0.01, it)
-        o_ = 0
-        for k in range(len(params)):
-            params[k] = pf[o_:o_ + params[k].size]; o_ += params[k].size
-            assert_close(net.layers[k].get_params(), params[k], 1e-4, f"parameters of layer {k + 1} after update {it}")
+        for k in range(len(params0)):
+            assert_close(net.layers[k].get_params(), ref["params"][k], 1e-5, f"parameters of layer {k + 1} after update {it}",
+                         f64=tr.hi(it - 1, "params", k))
     # FULL card round trip (print_to_unit_full / read_full)
     card = net.layers[1].print()
     assert card.startswith("FULL\n   NUM_INPUTS = 10\n   NUM_OUTPUTS = 128\n   USE_BIAS = T\n   ACTIVATION\n      name = leaky_relu")
@@ -346,32 +400,41 @@ def test_gno_regression_network_resident(dev, oracle):
     rng = np.random.default_rng(3)
     for l in net.layers:
         l.set_params(l.get_params() + rng.standard_normal(l.get_num_params()).astype(np.float32) * 0.05)
-    params = [l.get_params().copy() for l in net.layers]
+    params0 = [l.get_params().copy() for l in net.layers]
+
+    def host_pass():
+        params = [p.astype(ol._REAL) for p in params0]
+        rec = []
+        for it in (1, 2, 3):
+            cur, keep = x, []
+            for (fi, fo, act), pf in zip(dims, params):
+                pl = split(pf, fi, fo)
+                o_, tp = ol.gno_forward([g], [cur], [ec], pl, fi, fo, d, Hk, True, act)
+                keep.append((pl, cur, tp)); cur = o_[0]
+            lo, do = ol.o.mse(cur, tgt)
+            gc, grads = do, [None, None]
+            for k in (1, 0):
+                fi, fo, act = dims[k]
+                pl, xin, tp = keep[k]
+                dxs, _, gk = ol.gno_backward([g], [xin], [ec], tp, pl, fi, fo, d, Hk, True, act, [gc])
+                grads[k] = np.concatenate(gk); gc = dxs[0]
+            params = [(params[k] - ol._REAL(np.float32(lr)) * grads[k]).astype(ol._REAL) for k in range(2)]   # minimise_base :396-418
+            rec.append(dict(out=cur, loss=lo, grads=grads, params=params))
+        return rec
+    tr = _trajectory(host_pass)
     for it in (1, 2, 3):
+        ref = tr.ref[it - 1]
         out = net.forward([x], [ec])
-        cur, keep = x, []
-        for (fi, fo, act), pf in zip(dims, params):
-            pl = split(pf, fi, fo)
-            o_, tp = ol.gno_forward([g], [cur], [ec], pl, fi, fo, d, Hk, True, act)
-            keep.append((pl, cur, tp)); cur = o_[0]
-        assert_close(H(out), cur, 2e-5, f"gno network forward, step {it}")
+        assert_close(H(out), ref["out"], 1e-5, f"gno network forward, step {it}", f64=tr.hi(it - 1, "out"))
         loss, dl = optim.mse_loss_type().compute(out, T(tgt, dev))
-        lo, do = oracle.mse(cur, tgt)
-        assert abs(float(loss.item()) - lo) <= 2e-5 * abs(lo)
+        assert _scalar_close(float(loss.item()), ref["loss"], 1e-5, tr.hi(it - 1, "loss"))
         net.backward(dl)
-        gc = do
-        grads = [None, None]
-        for k in (1, 0):
-            fi, fo, act = dims[k]
-            pl, xin, tp = keep[k]
-            dxs, _, gk = ol.gno_backward([g], [xin], [ec], tp, pl, fi, fo, d, Hk, True, act, [gc])
-            grads[k] = np.concatenate(gk); gc = dxs[0]
         for k, l in enumerate(net.layers):
-            assert_close(l.get_gradients(), grads[k], 1e-4, f"gradients of layer {k + 1}, step {it}")
+            assert_close(l.get_gradients(), ref["grads"][k], 1e-5, f"gradients of layer {k + 1}, step {it}", f64=tr.hi(it - 1, "grads", k))
         net.update()
         for k in range(2):
-            params[k] = (params[k] - np.float32(lr) * grads[k]).astype(np.float32)      # minimise_base :396-418
-            assert_close(net.layers[k].get_params(), params[k], 1e-5, f"parameters of layer {k + 1} after step {it}")
+            assert_close(net.layers[k].get_params(), ref["params"][k], 1e-5, f"parameters of layer {k + 1} after step {it}",
+                         f64=tr.hi(it - 1, "params", k))
 
 
 def test_network_accessors_of_the_reference_msgpass_network_test(dev):

@@ -87,14 +87,16 @@ def test_clip_and_lr_decay(dev, oracle):
     # the norm is a 300 001-term fp32 sum: the oracle adds sequentially (as Fortran's sum does), the device
     # pairwise; the two differ by the rounding noise of the sequential sum (~5e-5 here), and the device
     # value is the one closer to the float64 norm
-    assert_close(out, oracle.clip(g, clip_norm=10.0), 2e-4, "norm clip vs sequential fp32 sum")
     exact = g.astype(np.float64) * min(1.0, 10.0 / np.sqrt((g.astype(np.float64) ** 2).sum()))
+    assert_close(out, oracle.clip(g, clip_norm=10.0), 1e-5, "norm clip vs sequential fp32 sum (anchored on float64)", f64=exact)
     assert_close(out, exact.astype(np.float32), 1e-6, "norm clip vs float64")
     assert abs(float(np.sqrt((out.astype(np.float64) ** 2).sum())) - 10.0) < 1e-3
     small = (g * 1e-4).astype(np.float32)                      # already inside the ball: untouched
     assert np.array_equal(H(optim.clip_type(clip_norm=10.0).apply(T(small, dev))), small)
     both = H(optim.clip_type(clip_min=-1.0, clip_max=1.0, clip_norm=5.0).apply(T(g, dev)))
-    assert_close(both, oracle.clip(g, -1.0, 1.0, 5.0), 2e-4, "clamp then norm")
+    gc64 = np.clip(g.astype(np.float64), -1.0, 1.0)
+    assert_close(both, oracle.clip(g, -1.0, 1.0, 5.0), 1e-5, "clamp then norm (anchored on float64)",
+                 f64=gc64 * min(1.0, 5.0 / np.sqrt((gc64 ** 2).sum())))
     # learning-rate decays (athena_lr_decay.f90:200-272), real32 arithmetic
     assert optim.base_lr_decay_type().get_lr(0.1, 7) == float(np.float32(0.1))
     assert np.isclose(optim.exp_lr_decay_type(0.05).get_lr(0.1, 10), 0.1 * np.exp(-0.5), rtol=1e-6)
@@ -111,7 +113,8 @@ def test_mse_loss_and_gradient(dev, oracle):
     lo, do = oracle.mse(p, e)
     exact = float(((p.astype(np.float64) - e) ** 2).mean() / 2)
     assert abs(float(loss.item()) - exact) <= 1e-6 * exact          # pairwise device sum vs float64
-    assert abs(float(loss.item()) - lo) <= 2e-5 * abs(lo)           # vs the oracle's sequential fp32 sum
+    # vs the oracle's sequential fp32 sum: within 1e-5, or no further from float64 than the oracle is, plus 1e-5
+    assert abs(float(loss.item()) - lo) <= 1e-5 * abs(lo) or abs(float(loss.item()) - exact) <= abs(lo - exact) + 1e-5 * exact
     assert np.array_equal(H(d), do)
 
 
@@ -131,24 +134,33 @@ def test_train_steps_of_a_kipf_layer_follow_the_oracle(dev, oracle):
     y = rng.uniform(-1, 1, (n, 8)).astype(np.float32)
     opt = optim.adam_optimiser_type(learning_rate=0.01, clip_dict=optim.clip_type(clip_norm=0.5),
                                     regulariser=optim.l2_regulariser_type(1e-3, decoupled=True))
-    params = layer.get_params().copy()
-    m = np.zeros_like(params); v = np.zeros_like(params)
+    params0 = layer.get_params().copy()
+
+    def host_pass():     # the oracle restatement of the three updates (fp32 oracle, or its float64 twin as the yardstick)
+        params = params0.astype(ol._REAL)
+        m = np.zeros_like(params); v = np.zeros_like(params)
+        rec = []
+        for it in range(1, 4):
+            plist = [params[:16 * 32], params[16 * 32:]]
+            outs, tapes = ol.kipf_forward([g], [x], plist, nvf, "tanh")
+            lo, do = ol.o.mse(outs[0], y)
+            _, grads = ol.kipf_backward([g], tapes, plist, nvf, "tanh", [do])
+            gflat = ol.o.clip(np.concatenate(grads), clip_norm=0.5)
+            params, _, m, v = ol.o.adam_step(params, gflat, m, v, 0.01, it, reg="l2", l2=1e-3, decoupled=True)
+            rec.append((lo, params))
+        return rec
+    ref = host_pass()
+    hi = ol.f64_lazy(lambda: [p for _, p in host_pass()])
     losses = []
     for it in range(1, 4):
         out = layer.forward([x])
         loss, d = optim.mse_loss_type().compute(out, T(y, dev))
         layer.backward(d, need_input_grad=False)
         optim.update([layer], opt)
-        # oracle side
-        plist = [params[:16 * 32], params[16 * 32:]]
-        outs, tapes = ol.kipf_forward([g], [x], plist, nvf, "tanh")
-        lo, do = oracle.mse(outs[0], y)
-        _, grads = ol.kipf_backward([g], tapes, plist, nvf, "tanh", [do])
-        gflat = oracle.clip(np.concatenate(grads), clip_norm=0.5)
-        params, _, m, v = oracle.adam_step(params, gflat, m, v, 0.01, it, reg="l2", l2=1e-3, decoupled=True)
+        lo, params = ref[it - 1]
         losses.append(lo)
         assert abs(float(loss.item()) - lo) <= 1e-5 * abs(lo)
-        # Adam's m/sqrt(v) is scale-free in the first steps, so the 1e-5 differences of the MFMA gradients are
-        # carried (not damped) from update to update: 1e-5, 2e-5, 3e-5 ...
-        assert_close(layer.get_params(), params, 2e-5 * it, f"parameters after update {it}")
+        # Adam's m/sqrt(v) is scale-free in the first steps, so rounding differences of the gradients are carried (not
+        # damped) from update to update -- in the fp32 oracle as much as on the device: anchored on the float64 trajectory
+        assert_close(layer.get_params(), params, 1e-5, f"parameters after update {it}", f64=hi(it - 1))
     assert losses[2] < losses[0]

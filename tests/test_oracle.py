@@ -320,3 +320,36 @@ def test_attributed_activations_against_the_reference_test_formulas(oracle):
     for kind in ("sigmoid", "tanh"):
         assert np.abs(oracle.activation_param(kind, x, 1.0) - oracle.activation(kind, x)).max() == 0
         assert np.abs(oracle.activation_param_bwd(kind, x, g, 1.0) - oracle.activation_bwd(kind, oracle.activation(kind, x), g)).max() <= 1e-7
+
+
+def test_float64_twin_of_the_oracle_and_the_anchored_tolerance(oracle):
+    """oracle/oracle64.py is the same C source in double precision: it reproduces the reference's identity-graph KAT,
+    agrees with the fp32 oracle to fp32 rounding on every op family, and is what helpers.assert_close anchors on"""
+    from oracle import oracle64 as o64
+    from helpers import assert_close_elementwise
+
+    k = golden("reference_kat_kipf_identity.json")
+    ia, ja = np.array(k["adj_ia"], np.int32), np.array(k["adj_ja"], np.int32)
+    y = o64.kipf_propagate(np.array(k["x"], np.float32), ia, ja)
+    assert y.dtype == np.float64 and np.abs(y - np.array(k["forward"])).max() <= k["tol_abs"]
+    rng = np.random.default_rng(5)
+    ia, ja = random_graph(300, 1200, seed=9)
+    x = rng.uniform(-1, 1, (300, 12)).astype(np.float32)
+    w = rng.standard_normal(12 * 7).astype(np.float32)
+    p32, p64 = oracle.kipf_propagate(x, ia, ja), o64.kipf_propagate(x, ia, ja)
+    assert rel_err(p32, p64) < 1e-6 and rel_err(oracle.matmul(w, p32, 7), o64.matmul(w, p64, 7)) < 1e-6
+    assert rel_err(oracle.kipf_propagate_bwd(x, ia, ja), o64.kipf_propagate_bwd(x, ia, ja)) < 1e-6
+    assert rel_err(oracle.activation("tanh", x), o64.activation("tanh", x)) < 1e-6
+    th = rng.standard_normal(8 * 3 + 8 + 6 * 8 + 6).astype(np.float32); co = rng.standard_normal((40, 3)).astype(np.float32)
+    assert rel_err(oracle.gno_kernel_eval(co, th, 8, 6), o64.gno_kernel_eval(co, th, 8, 6)) < 1e-6
+    # anchored criterion: passes a result that sits between the oracle and float64, fails one that is simply wrong
+    ref64 = np.linspace(1.0, 2.0, 50)
+    orc = (ref64 * (1 + 4e-5)).astype(np.float32)                  # an fp32 oracle 4e-5 off exact arithmetic
+    assert_close((ref64 * (1 + 1e-6)).astype(np.float32), orc, 1e-5, "anchored", f64=ref64)
+    with pytest.raises(AssertionError):
+        assert_close((ref64 * (1 + 9e-5)).astype(np.float32), orc, 1e-5, "anchored", f64=ref64)
+    with pytest.raises(AssertionError):
+        assert_close((ref64 * (1 + 1e-6)).astype(np.float32), orc, 1e-5, "not anchored")
+    assert_close_elementwise(np.array([1.0, 1e-9]), np.array([1.0, 2e-9]), np.array([2.0, 1.0]))
+    with pytest.raises(AssertionError):
+        assert_close_elementwise(np.array([1.0, 1e-3]), np.array([1.0, 2e-3]), np.array([2.0, 1.0]))
