@@ -176,6 +176,94 @@ __global__ __launch_bounds__(kBlock) void csr_gather_agg(
     } // row blocks
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Short rows (molecule batches: 3-5 entries per vertex; BASELINE configs[2]).  The general kernel above spends such a
+// row on its set-up -- wave-wide length reductions, index broadcasts by shuffle, a second launch for the edge part that
+// writes 32 B slivers into 288 B rows -- while the neighbour rows themselves come from L2 (a block-diagonal batch keeps a
+// vertex and its neighbours in the same few cache lines).  Here a group of G = F/4 lanes owns a row with no cross-lane
+// traffic at all: every lane reads the row's bounds and entries itself (same address across the group: one request),
+// keeps UN independent 16 B row loads in flight and adds them in CSR order (bit-identical to the general kernel); the
+// first FE4 lanes of the group also gather the edge-feature part, so duvenaud_propagate is ONE launch that writes whole
+// rows.  Latency is covered by occupancy (about 30 registers: 8 waves per SIMD).  Measured on configs[2] (2.34 M vertices,
+// 7.14 M entries, F_v = 64, F_e = 8): 0.384 ms against 0.454 ms for the two general launches.  Two things measured and
+// dropped: a software pipeline over a grid-stride walk (bounds of row k+2, entries of k+1, rows of k in flight together)
+// took 0.42 ms -- the kernel is not waiting on its dependency chain -- and the same kernel on the reverse gather over the
+// transposed CSR (no edge part to merge) took 0.32 ms against 0.31 ms for the general kernel, which stays.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int G, int UN>
+__global__ __launch_bounds__(256) void csr_gather_short_rows(const int32_t *__restrict__ rowptr,
+                                                             const int32_t *__restrict__ idx,
+                                                             const int32_t *__restrict__ eidx,
+                                                             const float *__restrict__ x, int64_t ldx,
+                                                             const float *__restrict__ e, int64_t lde, int FE4,
+                                                             float *__restrict__ y, int64_t ldy, int32_t n_rows)
+{
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    const int gl = threadIdx.x & (G - 1);
+    const int64_t row = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G;
+    if (row >= n_rows) return;
+    const int w0 = rowptr[row], w1 = rowptr[row + 1];
+    const bool edge_lane = gl < FE4;
+    v4 acc = {0.0f, 0.0f, 0.0f, 0.0f}, acce = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int w = w0; w < w1; w += UN) {
+        int u[UN], ee[UN];
+#pragma unroll
+        for (int k = 0; k < UN; ++k) {
+            u[k] = ee[k] = -1;
+            if (w + k < w1) {
+                u[k] = idx[w + k];
+                if (FE4 > 0) ee[k] = eidx[w + k];
+            }
+        }
+        v4 v[UN], ve[UN];
+#pragma unroll
+        for (int k = 0; k < UN; ++k) {
+            v[k] = (v4){0.0f, 0.0f, 0.0f, 0.0f};
+            ve[k] = (v4){0.0f, 0.0f, 0.0f, 0.0f};
+            if (u[k] >= 0) v[k] = *reinterpret_cast<const v4 *>(x + (int64_t)u[k] * ldx + 4 * gl);
+            if (edge_lane && ee[k] >= 0) ve[k] = *reinterpret_cast<const v4 *>(e + (int64_t)ee[k] * lde + 4 * gl);
+        }
+#pragma unroll
+        for (int k = 0; k < UN; ++k) {
+            if (u[k] >= 0) acc = acc + v[k];
+            if (edge_lane && ee[k] >= 0) acce = acce + ve[k];
+        }
+    }
+    *reinterpret_cast<v4 *>(y + row * ldy + 4 * gl) = acc;
+    if (edge_lane) *reinterpret_cast<v4 *>(y + row * ldy + 4 * G + 4 * gl) = acce;
+}
+
+// rows of at most kShortRow entries, F a power-of-two multiple of 16 floats up to 256, 16 B aligned slices
+constexpr int kShortRow = 32;
+bool short_rows_ok(int32_t max_row_len, int F, int Fe, const float *x, int64_t ldx, const float *e, const float *y, int64_t ldy)
+{
+    static const bool off = getenv("ATHENA_MP_NO_SHORT_ROWS") != nullptr;   // A/B switch for measurements
+    const int G = F / 4;
+    return !off && max_row_len <= kShortRow && F % 16 == 0 && (G & (G - 1)) == 0 && G >= 4 && G <= 64 && Fe % 4 == 0 &&
+           Fe / 4 <= G && ldx % 4 == 0 && ldy % 4 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0 &&
+           (Fe == 0 || (uintptr_t)e % 16 == 0);
+}
+int gather_short_rows(const int32_t *rowptr, const int32_t *idx, const int32_t *eidx, const float *x, int64_t ldx,
+                      const float *e, int Fe, float *y, int64_t ldy, int32_t n_rows, int F)
+{
+    if (n_rows == 0) return 0;
+    const int G = F / 4;
+    const unsigned nb = (unsigned)(((int64_t)n_rows + 256 / G - 1) / (256 / G));
+#define AMP_SR(G_)                                                                                                 \
+    case G_:                                                                                                       \
+        hipLaunchKernelGGL((csr_gather_short_rows<G_, 4>), dim3(nb), dim3(256), 0, amp::stream(), rowptr, idx, eidx, x, ldx, \
+                           e, (int64_t)Fe, Fe / 4, y, ldy, n_rows);                                                \
+        break;
+    switch (G) {
+        AMP_SR(4) AMP_SR(8) AMP_SR(16) AMP_SR(32) AMP_SR(64)
+    default: amp::set_error("gather_short_rows: F = %d", F); return 2;
+    }
+#undef AMP_SR
+    AMP_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int G, int VEC>
 int launch_dual_gv(const int32_t *rowbeg, const int32_t *rowend, const int32_t *idx, const float *coef, const float *x,
                    int64_t ldx, float *y, float *y2, int64_t ldy, int32_t n_rows, int32_t F)
@@ -401,6 +489,8 @@ int athena_mp_duvenaud_propagate_fwd(const athena_mp_graph *g, int32_t Fv, int32
     AMP_REQUIRE(g && x && c && Fv > 0 && Fe >= 0, "duvenaud_propagate_fwd: bad arguments");
     AMP_REQUIRE(Fe == 0 || e, "duvenaud_propagate_fwd: null edge features");
     const int64_t Fc = (int64_t)Fv + Fe;
+    if (short_rows_ok(g->max_row_len, Fv, Fe, x, Fv, e, c, Fc))   // molecule-sized rows: one launch, whole rows written
+        return gather_short_rows(g->rowptr, g->col, g->eid, x, Fv, e, Fe, c, Fc, g->n_rows, Fv);
     int rc = gather_agg(g->rowptr, g->col, nullptr, x, Fv, c, Fc, g->n_rows, Fv, &g->lp_fwd);
     if (rc == 0 && Fe > 0) rc = gather_agg(g->rowptr, g->eid, nullptr, e, Fe, c + Fv, Fc, g->n_rows, Fe, &g->lp_fwd);
     return rc;

@@ -1,3 +1,3 @@
-mkdir -p gpurun_out/r2e
-timeout 2400 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | grep -v "RCCL version\|HIP version\|ROCm version\|Hostname\|Librccl\|amdgpu.ids" | tail -60 > gpurun_out/r2e/pytest.txt
-tail -60 gpurun_out/r2e/pytest.txt
+timeout 1200 python -m pytest tests -m gpu -x -q -k "duvenaud or c3 or fuzz or network or layer" 2>&1 | grep -E "passed|failed|Error|error" | tail -5
+timeout 600 python3 scripts/bench_configs.py --config c3 --no-cpu
+ATHENA_MP_NO_SHORT_ROWS=1 timeout 600 python3 scripts/bench_configs.py --config c3 --no-cpu

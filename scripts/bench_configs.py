@@ -59,7 +59,16 @@ if a.config == "c3":
            "propagate_bwd_x": nnz * (4 * Fv + 4) + N * (4 * Fv + 4),
            "update_sigmoid": N * 4 * (Fc + Fv), "update_bwd_a": N * 4 * (Fc + Fv), "update_bwd_w": N * 4 * (Fc + Fv),
            "readout": N * 4 * (Fv + O) + S * 4 * O, "readout_bwd": N * 4 * (2 * Fv + O + 1) + S * 4 * O}
-    roof = {k: {"GBps": round(alg[k] / (t[k] * 1e-3) / 1e9, 1), "frac_of_8TBps": round(alg[k] / (t[k] * 1e-3) / 8e12, 3)} for k in alg}
+    # A batch of ~18-vertex molecules is block-diagonal: the rows a vertex gathers sit in the same few cache lines as
+    # its own, so the per-entry model counts bytes that never leave L2.  The roofline of the two gather kernels is
+    # therefore taken on COMPULSORY bytes (every tensor read or written once, indices included); the per-entry figure
+    # stays beside it for comparison with configs[1] ("say so rather than claiming > 100 %").
+    comp = dict(alg)
+    comp["propagate"] = N * 4 * Fv + E * 4 * Fe + nnz * 8 + N * 4 + N * 4 * Fc
+    comp["propagate_bwd_x"] = N * 4 * Fc + nnz * 4 + N * 4 + N * 4 * Fv
+    roof = {k: {"GBps": round(comp[k] / (t[k] * 1e-3) / 1e9, 1), "frac_of_8TBps": round(comp[k] / (t[k] * 1e-3) / 8e12, 3),
+                "bytes": "compulsory" if comp[k] != alg[k] else "algorithmic = compulsory (streaming op)",
+                **({"per_entry_model_GBps": round(alg[k] / (t[k] * 1e-3) / 1e9, 1)} if comp[k] != alg[k] else {})} for k in alg}
     if a.no_cpu:
         print(json.dumps({"ms": {k: round(v, 4) for k, v in t.items()}, "total_ms": tot, "roofline": roof})); sys.exit(0)
     # CPU oracle (1 thread), same ops, same order
