@@ -55,6 +55,7 @@ _PROTOS = {
     "athena_mp_gemm_dx": [_i64, _i32, _i32, _vp, _vp, _vp],
     "athena_mp_kipf_layer_fwd": [_vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp],
     "athena_mp_kipf_layer_bwd_x": [_vp, _i32, _i32, _vp, _vp, _i32, _vp],
+    "athena_mp_kipf_layer_bwd": [_vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp],
     "athena_mp_pull_gemm": [_vp, _i32, _i32, _vp, _vp, _i32, _vp],
     "athena_mp_activation_fwd": [_i32, _i64, _vp, _vp],
     "athena_mp_activation_bwd": [_i32, _i64, _vp, _vp, _vp],

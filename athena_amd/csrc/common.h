@@ -134,6 +134,11 @@ int slab_reduce(const float *slabs, int n_slabs, int n, float *out, bool accumul
 int slab_reduce_segs(const float *slabs, int n, int n_segs, const int *first, const int *count, float *out,
                      int64_t out_stride, bool accumulate);
 
+// reverse pass of a square Kipf step with dW folded in (fused_dw.hip)
+bool fused_dw_shape(int Fi, int Fo);
+int fused_dw_dispatch(const int32_t *t_rowptr, const int32_t *t_src, const float *t_coef, const float *dZ, const float *W,
+                      const float *X, int exact, float *dX, float *dW, int64_t n_cols);
+
 // shape-generic tiled MFMA contraction (gemm_tiled.hip)
 struct TiledArgs {
     const float *A = nullptr; int64_t lda = 0; const int32_t *a_idx = nullptr; float a_div = 1.0f;

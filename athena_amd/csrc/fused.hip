@@ -41,7 +41,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // 32-row chunks, one row pair per wave; the first kFirst row loads of the NEXT chunk are issued before
 // the matrix work of the CURRENT chunk and consumed after it.
-constexpr int kFirst = 16;
+#ifndef FUSED_STAGGER
+#define FUSED_STAGGER 0   // measured at configs[1]: 0.936 / 0.884 ms with, 0.930 / 0.890 ms without (forward / reverse): no gain here
+#endif
+#ifndef KFIRST
+#define KFIRST 16
+#endif
+constexpr int kFirst = KFIRST;
 
 template <int N, bool COEF, int ACT>
 __global__ __launch_bounds__(1024) void agg_gemm_kernel(const int32_t *__restrict__ rowptr,
@@ -203,7 +209,7 @@ __global__ __launch_bounds__(1024) void agg_gemm_kernel(const int32_t *__restric
         const int64_t chunk = k0;
         const int buf = it & 1;
         issue_first();                                      // rows of k1
-        {
+        auto matrix_work = [&]() {
             const float *arow = Ts + (buf * CH + 16 * rb + l15) * LD + KG * g4;
             const float *brow = Bs + (16 * ct + l15) * LD + KG * g4;
             f32x4 c = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -221,8 +227,20 @@ __global__ __launch_bounds__(1024) void agg_gemm_kernel(const int32_t *__restric
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (row0 + r < n_rows) Z[(row0 + r) * N + col] = act_f<ACT>(c[r] + bv);
+        };
+#if FUSED_STAGGER
+        // Between two barriers a wave has two independent jobs: the matrix work of chunk k0 (reads tile `buf`) and the
+        // gather of its rows of chunk k1 (writes tile `buf ^ 1`).  Waves 4-7 and 12-15 run them in the opposite order, so
+        // every SIMD holds two waves on the matrix pipe and two waiting for rows instead of four doing the same thing.
+        if ((wave >> 2) & 1) {
+            store_row(k1, buf ^ 1, finish());
+            matrix_work();
+        } else
+#endif
+        {
+            matrix_work();
+            store_row(k1, buf ^ 1, finish());
         }
-        store_row(k1, buf ^ 1, finish());
         load_state(k2);
         if (tid == 0) s_ticket[it & 1] = draw();
         __syncthreads();
@@ -530,11 +548,16 @@ int athena_mp_kipf_layer_fwd(const athena_mp_graph *g, int32_t Fi, int32_t Fo, c
 {
     AMP_REQUIRE(g && Fi > 0 && Fo > 0, "kipf_layer_fwd: bad arguments");
     if (g->n_rows == 0) return 0;
-    AMP_REQUIRE(x && W && P && Z, "kipf_layer_fwd: null tensor");
+    AMP_REQUIRE(x && W && Z, "kipf_layer_fwd: null tensor");
     // hub rows (> kLongRow entries) would stall a whole workgroup at the chunk barrier: such graphs take
     // the two-kernel route, whose aggregation splits them into parallel segments
     if (fused_shape(Fi, Fo) && g->lp_fwd.n_long == 0)
         return fused_dispatch(g->rowptr, g->col, g->coef, x, Fi, Fo, W, 0, bias, act, P, Z, g->n_rows);
+    if (P == nullptr) {   // the caller keeps no tape of P (its reverse pass is athena_mp_kipf_layer_bwd)
+        void *ws = nullptr;
+        if (workspace(&ws, sizeof(float) * (size_t)g->n_rows * Fi, 5)) return 1;
+        P = (float *)ws;
+    }
     int rc = athena_mp_kipf_propagate_fwd(g, Fi, x, P);   // other widths: the two kernels back to back
     if (rc) return rc;
     return athena_mp_gemm_fwd(g->n_rows, Fi, Fo, P, W, bias, act, Z);
@@ -560,6 +583,35 @@ int athena_mp_kipf_layer_bwd_x(const athena_mp_graph *g, int32_t Fi, int32_t Fo,
     int rc = athena_mp_gemm_dx(g->n_rows, Fi, Fo, dZ, W, (float *)ws);
     if (rc) return rc;
     return athena_mp_kipf_propagate_bwd(g, Fi, (const float *)ws, dX, exact);
+}
+
+/* Whole reverse pass of one Kipf step from the step's INPUT X instead of a stored P:
+ *   dX = (A^T dZ) . W   (exact = 0: the reference's coefficient-free scatter; may be null: first layer of a network)
+ *   dW = dZ . P^T with P = A^ X, evaluated as sum_u (A^^T dZ)[u] (x) X[u]
+ * 128 -> 128 without hub rows: ONE launch (fused_dw.hip); otherwise one dual gather + two contractions. */
+int athena_mp_kipf_layer_bwd(const athena_mp_graph *g, int32_t Fi, int32_t Fo, const float *dZ, const float *W,
+                             const float *X, int32_t exact, float *dX, float *dW)
+{
+    AMP_REQUIRE(g && Fi > 0 && Fo > 0, "kipf_layer_bwd: bad arguments");
+    AMP_REQUIRE(g->n_rows == g->n_cols, "kipf_layer_bwd: needs a square graph (%d x %d); shards use athena_mp_pull_gemm", g->n_rows,
+                g->n_cols);
+    AMP_REQUIRE(dW != nullptr, "kipf_layer_bwd: null dW");
+    if (g->n_cols == 0) {
+        AMP_HIP(hipMemsetAsync(dW, 0, sizeof(float) * (size_t)Fi * Fo, stream()));
+        return 0;
+    }
+    AMP_REQUIRE(dZ && W && X, "kipf_layer_bwd: null tensor");
+    if (amp::fused_dw_shape(Fi, Fo) && g->lp_bwd.n_long == 0 && (uintptr_t)dZ % 16 == 0 && (uintptr_t)W % 16 == 0)
+        return amp::fused_dw_dispatch(g->t_rowptr, g->t_src, g->t_coef, dZ, W, X, exact, dX, dW, g->n_cols);
+    void *ws = nullptr;
+    const size_t rows = (size_t)g->n_cols * Fo;
+    if (workspace(&ws, sizeof(float) * rows * (exact ? 1 : 2), 5)) return 1;
+    float *qc = (float *)ws, *qp = exact ? qc : qc + rows;
+    int rc = exact ? athena_mp_kipf_propagate_bwd(g, Fo, dZ, qc, 1) : athena_mp_kipf_propagate_bwd_dual(g, Fo, dZ, qp, qc);
+    if (rc) return rc;
+    rc = athena_mp_gemm_dw(g->n_cols, Fi, Fo, X, qc, dW);            // dW(Fo,Fi) = sum_u Qc[u] (x) X[u]
+    if (rc || dX == nullptr) return rc;
+    return athena_mp_gemm_dx(g->n_cols, Fi, Fo, qp, W, dX);           // dX = Qp . W
 }
 
 /* pull form for a row shard whose FORWARD rows list the sources (athena_amd/dist.py g_bwd):

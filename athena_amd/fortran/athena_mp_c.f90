@@ -38,7 +38,7 @@ module athena_mp_c
   public :: athena_mp_kipf_layer_fwd, athena_mp_kipf_layer_bwd_x, athena_mp_activation_bwd
   public :: athena_mp_csr_from_edges, athena_mp_graph_export, athena_mp_graph_create_from_edges
   public :: athena_mp_error_message
-  public :: athena_mp_pull_gemm, athena_mp_dev_offset
+  public :: athena_mp_pull_gemm, athena_mp_dev_offset, athena_mp_kipf_layer_bwd
   public :: athena_mp_comm_create, athena_mp_comm_create_from_file, athena_mp_comm_destroy, athena_mp_comm_barrier
   public :: athena_mp_comm_unique_id, athena_mp_allreduce, athena_mp_allreduce_start, athena_mp_allreduce_finish
   public :: athena_mp_shard_create, athena_mp_shard_destroy, athena_mp_shard_dims, athena_mp_shard_graph
@@ -478,6 +478,13 @@ module athena_mp_c
        integer(c_int32_t), value :: d, H, Fi, Fo
      end function
      !! ---- multi-GPU (csrc/comm.hip): one process per GPU, RCCL over xGMI ------------------------------------------
+     !! whole reverse pass of one step from its input X (no stored P): dX (may be c_null_ptr) and dW
+     integer(c_int) function athena_mp_kipf_layer_bwd(graph, Fi, Fo, dZ_dev, W_dev, X_dev, exact, dX_dev, dW_dev) &
+          bind(C, name="athena_mp_kipf_layer_bwd")
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: graph, dZ_dev, W_dev, X_dev, dX_dev, dW_dev
+       integer(c_int32_t), value :: Fi, Fo, exact
+     end function
      integer(c_int) function athena_mp_pull_gemm(graph, Fi, Fo, dZ_dev, W_dev, exact, dX_dev) &
           bind(C, name="athena_mp_pull_gemm")
        import :: c_int, c_int32_t, c_ptr

@@ -183,13 +183,18 @@ def matmul_dx(W, dZ, Fi, out=None):
     return dP
 
 
-def kipf_layer_fwd(g: DeviceGraph, x, W, Fo, bias=None, act="none", P=None, Z=None):
-    """one Kipf time step in one launch: P = kipf_propagate(x), Z = act(P . Wt + bias)"""
+def kipf_layer_fwd(g: DeviceGraph, x, W, Fo, bias=None, act="none", P=None, Z=None, keep_P=True):
+    """one Kipf time step in one launch: P = kipf_propagate(x), Z = act(P . Wt + bias).  keep_P=False: P is not
+    stored (returns (None, Z)) -- for a reverse pass through kipf_layer_bwd, which works from x"""
     Fi = x.shape[1]
     _chk(x, (g.n_cols, Fi))
-    P = P if P is not None else torch.empty((g.n_rows, Fi), device=x.device, dtype=torch.float32)
+    if keep_P:
+        P = P if P is not None else torch.empty((g.n_rows, Fi), device=x.device, dtype=torch.float32)
+        _chk(P, (g.n_rows, Fi))
+    else:
+        P = None
     Z = Z if Z is not None else torch.empty((g.n_rows, Fo), device=x.device, dtype=torch.float32)
-    _chk(P, (g.n_rows, Fi)); _chk(Z, (g.n_rows, Fo))
+    _chk(Z, (g.n_rows, Fo))
     if _chk(W).numel() != Fo * Fi:
         raise ValueError(f"W holds {W.numel()} values, expected Fo*Fi = {Fo * Fi}")
     if bias is not None:
@@ -210,6 +215,26 @@ def kipf_layer_bwd_x(g: DeviceGraph, dZ, W, Fi, exact=False, out=None):
     _go()
     _capi.call("athena_mp_kipf_layer_bwd_x", g.handle, Fi, Fo, _p(dZ), _p(_chk(W)), int(bool(exact)), _p(dX))
     return dX
+
+
+def kipf_layer_bwd(g: DeviceGraph, dZ, W, x, exact=False, need_dx=True, dX=None, dW=None):
+    """the whole reverse pass of one Kipf step from its input x (no stored P): returns (dX or None, dW) with
+    dX = (A^T dZ) . W (exact=False: the reference's coefficient-free scatter) and dW = dZ . (A^ x)^T"""
+    Fo, Fi = dZ.shape[1], x.shape[1]
+    _chk(dZ, (g.n_rows, Fo)); _chk(x, (g.n_cols, Fi))
+    if _chk(W).numel() != Fo * Fi:
+        raise ValueError(f"W holds {W.numel()} values, expected Fo*Fi = {Fo * Fi}")
+    if need_dx:
+        dX = dX if dX is not None else torch.empty((g.n_cols, Fi), device=dZ.device, dtype=torch.float32)
+        _chk(dX, (g.n_cols, Fi))
+    else:
+        dX = None
+    dW = dW if dW is not None else torch.empty(Fo * Fi, device=dZ.device, dtype=torch.float32)
+    if _chk(dW).numel() != Fo * Fi:
+        raise ValueError(f"dW holds {dW.numel()} values, expected {Fo * Fi}")
+    _go()
+    _capi.call("athena_mp_kipf_layer_bwd", g.handle, Fi, Fo, _p(dZ), _p(W), _p(x), int(bool(exact)), _p(dX), _p(dW))
+    return dX, dW
 
 
 def pull_gemm(g: DeviceGraph, dZ, W, Fi, exact=False, out=None):

@@ -148,7 +148,8 @@ int athena_mp_gemm_dx(int64_t N, int32_t Fi, int32_t Fo, const float *dZ_dev, co
 
 /* ---- fused Kipf layer step (one launch: aggregation + dense contraction, W resident in LDS) ------
  * update_message_kipf, athena_kipf_msgpass_layer.f90:943-952, one time step:
- *   P = kipf_propagate(X) (returned: the reverse pass needs it for dW),  Z = act(P . Wt + bias)     */
+ *   P = kipf_propagate(X) (returned: the reverse pass needs it for dW; P_dev may be NULL when the reverse pass is
+ *   athena_mp_kipf_layer_bwd, which works from X),  Z = act(P . Wt + bias)     */
 int athena_mp_kipf_layer_fwd(const athena_mp_graph *g, int32_t Fi, int32_t Fo, const float *x_dev,
                              const float *W_dev, const float *bias_dev, int32_t act, float *P_dev,
                              float *Z_dev);
@@ -156,6 +157,13 @@ int athena_mp_kipf_layer_fwd(const athena_mp_graph *g, int32_t Fi, int32_t Fo, c
  * (dZ = gradient at the pre-activation; exact as in athena_mp_kipf_propagate_bwd) */
 int athena_mp_kipf_layer_bwd_x(const athena_mp_graph *g, int32_t Fi, int32_t Fo, const float *dZ_dev,
                                const float *W_dev, int32_t exact, float *dX_dev);
+
+/* the whole reverse pass of one step from the step's INPUT X (no stored P): dX as above (may be NULL) and
+ *   dW = dZ . P^T with P = A^ X (matmul reverse wrt params(t), athena_kipf_msgpass_layer.f90:951), evaluated as
+ *   sum_u (A^^T dZ)[u] (x) X[u] -- both sums come from ONE gather of dZ over the transposed CSR.  With it the forward call
+ *   may pass P_dev = NULL.  128 -> 128 without hub rows: one launch; otherwise a dual gather + two contractions. */
+int athena_mp_kipf_layer_bwd(const athena_mp_graph *g, int32_t Fi, int32_t Fo, const float *dZ_dev,
+                             const float *W_dev, const float *X_dev, int32_t exact, float *dX_dev, float *dW_dev);
 
 /* same contraction over the FORWARD rows of a (rectangular) shard graph: dX[v,:] = (sum_w [coef] dZ[col[w],:]) . W
  * -- the backward of a row partition whose rows list their sources (athena_amd/dist.py) */

@@ -172,6 +172,29 @@ def test_c2_fused_layer_kernels_match_oracle_at_full_size(dev, oracle, c2, F):
     assert torch.equal(P, P2) and torch.equal(Z, Z2) and torch.equal(dX, ops.kipf_layer_bwd_x(g, dz, w, F))
 
 
+def test_c2_reverse_pass_with_folded_dw_matches_oracle_at_full_size(dev, oracle, c2):
+    """the reverse launch bench.py times (agg_gemm_dw_kernel: dX and dW from one gather of dZ) on the full C2 graph:
+    dX on 5 000 sampled columns against the oracle; dW against the float64 contraction of the oracle-checked P (the fp32
+    oracle's own 10^6-term sequential sum is ~3e-5 from exact arithmetic, see bench.py's parity block) and within 1e-5 of
+    the stock dW kernel fed the stored P"""
+    from athena_amd import ops
+
+    g, N, ia, ja, F = c2["g"], c2["N"], c2["ia"], c2["ja"], c2["F"]
+    x, w, dz = (torch.from_numpy(c2[k]).to(dev) for k in ("x", "w", "dz"))
+    dX, dW = ops.kipf_layer_bwd(g, dz, w, x)
+    cols = np.sort(np.random.default_rng(6).choice(N, 5000, replace=False))
+    src, cia, cja = _column_sub_problem(ia, ja, cols)
+    dx_ref = oracle.kipf_propagate_bwd(oracle.matmul_dx(c2["w"], c2["dz"][src], F), cia, cja, n_out=cols.size)
+    assert np.abs(dX[torch.from_numpy(cols).to(dev)].cpu().numpy() - dx_ref).max() <= 1e-5 * np.abs(dx_ref).max()
+    assert (dX - ops.kipf_layer_bwd_x(g, dz, w, F)).abs().max().item() <= 1e-5 * dX.abs().max().item()
+    P = ops.kipf_propagate(g, x)                                   # bit-exact vs the oracle (test above)
+    ref64 = (P.double().T @ dz.double()).reshape(-1)
+    assert (dW.double() - ref64).abs().max().item() <= 1e-5 * ref64.abs().max().item()
+    assert (dW - ops.matmul_dw(P, dz)).abs().max().item() <= 1e-5 * ref64.abs().max().item()
+    d2, w2 = ops.kipf_layer_bwd(g, dz, w, x)
+    assert torch.equal(dX, d2) and torch.equal(dW, w2)
+
+
 # ---- BASELINE configs[2]: Duvenaud, ~130k QM9-shaped graphs (perf dims F_v=64, F_e=8) ----------------
 @pytest.fixture(scope="module")
 def c3(dev):

@@ -570,6 +570,53 @@ def test_fused_kipf_layer_kernels(dev, oracle, act, F):
                  oracle.kipf_propagate_bwd(oracle.matmul_dx(w2, dz2, 64), ia, ja), 1e-5)
 
 
+@pytest.mark.parametrize("F,exact", [(128, False), (128, True), (64, False), (24, True)])
+def test_kipf_layer_reverse_pass_with_dw_from_the_step_input(dev, oracle, F, exact):
+    """athena_mp_kipf_layer_bwd: dX and dW of one step from its INPUT x (no stored P) -- both sums from one gather of dZ
+    (128 -> 128: the one-launch kernel of fused_dw.hip; other widths and hub graphs: dual gather + two contractions).
+    Against the reference order: dW = dZ . kipf_propagate(x)^T, dX = scatter(W^T dZ) (athena_kipf_msgpass_layer.f90:951,
+    athena_diffstruc_extd_sub_kipf.f90:85-111)"""
+    from athena_amd import DeviceGraph, ops
+    from oracle import oracle64 as o64
+
+    rng = np.random.default_rng(300 + F)
+    n = 4133
+    ia, ja = random_graph(n, 5 * n, seed=81, self_loops=True, isolated=9)
+    x = rng.uniform(-1, 1, (n, F)).astype(np.float32)
+    w = (rng.standard_normal(F * F) * np.sqrt(2.0 / F)).astype(np.float32)
+    dz = rng.uniform(-1, 1, (n, F)).astype(np.float32)
+
+    def check(ia, ja, tag):
+        g = DeviceGraph(ia, ja, n_edge_cols=0)
+        dX, dW = ops.kipf_layer_bwd(g, T(dz, dev), T(w, dev), T(x, dev), exact=exact)
+        dx_ref = oracle.kipf_propagate_bwd(oracle.matmul_dx(w, dz, F), ia, ja, exact=exact)
+        assert_close(H(dX), dx_ref, 1e-5, f"{tag}: dX",
+                     f64=lambda: o64.kipf_propagate_bwd(o64.matmul_dx(w, dz, F), ia, ja, exact=exact))
+        dw_ref = oracle.matmul_dw(dz, oracle.kipf_propagate(x, ia, ja))
+        assert_close(H(dW), dw_ref, 1e-5, f"{tag}: dW", f64=lambda: o64.matmul_dw(dz, o64.kipf_propagate(x, ia, ja)))
+        _, dW2 = ops.kipf_layer_bwd(g, T(dz, dev), T(w, dev), T(x, dev), exact=exact, need_dx=False)
+        assert torch.equal(dW, dW2)                       # same weight gradient without the input gradient
+        d3, w3 = ops.kipf_layer_bwd(g, T(dz, dev), T(w, dev), T(x, dev), exact=exact)
+        assert torch.equal(dX, d3) and torch.equal(dW, w3)  # deterministic (ticket-scheduled chunks, ordered slab sum)
+        # forward without a stored P gives the same Z
+        P, Z = ops.kipf_layer_fwd(g, T(x, dev), T(w, dev), F)
+        none, Z2 = ops.kipf_layer_fwd(g, T(x, dev), T(w, dev), F, keep_P=False)
+        assert none is None and torch.equal(Z, Z2)
+
+    check(ia, ja, "random graph")
+    # rows of 40..90 entries (second index block of the half-wave mapping) and a hub column (> 512: two-kernel route)
+    ia2, ja2 = random_graph(1500, 30 * 1500, seed=82, self_loops=True)
+    x, dz = x[:1500], dz[:1500]
+    check(ia2, ja2, "dense rows")
+    extra = rng.integers(2, 1500, 700)
+    rows = np.repeat(np.arange(1, 1501), np.diff(ia2))
+    src = np.concatenate([rows, np.ones(700, np.int64), extra]); dst = np.concatenate([ja2[0], extra, np.ones(700, np.int64)])
+    order = np.argsort(src, kind="stable")
+    ia3 = np.concatenate([[1], 1 + np.cumsum(np.bincount(src - 1, minlength=1500))]).astype(np.int32)
+    ja3 = np.zeros((2, src.size), np.int32, order="F"); ja3[0] = dst[order]
+    check(ia3, ja3, "hub vertex")
+
+
 @pytest.mark.parametrize("Fi,Fo", [(48, 20), (20, 48), (64, 32), (32, 64), (7, 130)])
 def test_reverse_step_picks_the_narrower_side_for_the_scatter(dev, oracle, Fi, Fo):
     """kipf_layer_bwd_x / pull_gemm evaluate A^T(dZ W) or (A^T dZ) W -- whichever moves the narrower rows through
