@@ -41,6 +41,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // 32-row chunks, one row pair per wave; the first kFirst row loads of the NEXT chunk are issued before
 // the matrix work of the CURRENT chunk and consumed after it.
+#ifndef FUSED_LEAN
+#define FUSED_LEAN 1
+#endif
 #ifndef FUSED_STAGGER
 #define FUSED_STAGGER 0   // measured at configs[1]: 0.936 / 0.884 ms with, 0.930 / 0.890 ms without (forward / reverse): no gain here
 #endif
@@ -49,7 +52,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #endif
 constexpr int kFirst = KFIRST;
 
-template <int N, bool COEF, int ACT>
+template <int N, bool COEF, int ACT, bool BUF>
 __global__ __launch_bounds__(1024) void agg_gemm_kernel(const int32_t *__restrict__ rowptr,
                                                         const int32_t *__restrict__ idx,
                                                         const float *__restrict__ coef,
@@ -57,7 +60,8 @@ __global__ __launch_bounds__(1024) void agg_gemm_kernel(const int32_t *__restric
                                                         const float *__restrict__ B, int b_nk,
                                                         const float *__restrict__ bias,
                                                         float *__restrict__ P, float *__restrict__ Z,
-                                                        int64_t n_rows, unsigned long long *__restrict__ ticket)
+                                                        int64_t n_rows, unsigned long long *__restrict__ ticket,
+                                                        uint32_t x_bytes)
 {
     // square layers, N = K in {64, 128}: a row is K/4 lanes of float4, a wave holds 64/(K/4) rows, a chunk is
     // 16 waves' worth of rows, and its CH x N output is exactly 16 blocks of 16x16 -- one per wave
@@ -121,21 +125,45 @@ __global__ __launch_bounds__(1024) void agg_gemm_kernel(const int32_t *__restric
             if constexpr (COEF) c0 = coef[start + gl];
         }
     };
+    // Row loads.  BUF: the gathered tensor is below 4 GB, so a row is addressed by a 32-bit byte offset against a
+    // buffer descriptor held in scalar registers -- one v_lshl_add per load instead of a 64-bit multiply-add pair
+    // (the gather is bound by its instruction stream before it is bound by the fabric); offsets past
+    // x_bytes read as zero.
+    __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, BUF ? (int)x_bytes : 0, 0x00020000);
+    auto load_row = [&](int u) -> v4f {
+        if constexpr (BUF) {
+            typedef int v4i_ __attribute__((ext_vector_type(4)));
+            const v4i_ t = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (u << (K == 128 ? 9 : 8)) + 16 * gl, 0, 0);
+            return __builtin_bit_cast(v4f, t);
+        } else {
+            return *reinterpret_cast<const v4f *>(x + (int64_t)u * K + 4 * gl);
+        }
+    };
     constexpr int kF = kFirst < G ? kFirst : G;   // entries whose loads fly under the matrix work
     v4f v[kF];
     auto issue_first = [&]() {            // row loads of entries 0 .. kF-1 (no waits)
 #pragma unroll
         for (int k = 0; k < kF; ++k) {
             const int u = __shfl(idx0, k, G);
+#if FUSED_LEAN
+            // no zero fill: slot k is read (below, in finish) under the same `k < len` it is loaded under, and the Kipf
+            // CSR carries no negative ids -- one v_cndmask per component and one index broadcast per entry less
+            if (k < len) v[k] = load_row(u);
+#else
             v[k] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
-            if (k < len && u >= 0) v[k] = *reinterpret_cast<const v4f *>(x + (int64_t)u * K + 4 * gl);
+            if (k < len && u >= 0) v[k] = load_row(u);
+#endif
         }
     };
     auto finish = [&]() -> v4f {          // CSR-order accumulation: first block from registers, rest streamed
         v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int k = 0; k < kF; ++k) {
+#if FUSED_LEAN
+            const int u = 0;
+#else
             const int u = __shfl(idx0, k, G);
+#endif
             const float c = COEF ? __shfl(c0, k, G) : 1.0f;
             if (k < len && u >= 0) {
                 if constexpr (COEF) { acc.x = acc.x + c * v[k].x; acc.y = acc.y + c * v[k].y; acc.z = acc.z + c * v[k].z; acc.w = acc.w + c * v[k].w; }
@@ -169,7 +197,7 @@ __global__ __launch_bounds__(1024) void agg_gemm_kernel(const int32_t *__restric
 #pragma unroll
                 for (int k = 0; k < kUn; ++k) {
                     w[k] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
-                    if (u[k] >= 0) w[k] = *reinterpret_cast<const v4f *>(x + (int64_t)u[k] * K + 4 * gl);
+                    if (u[k] >= 0) w[k] = load_row(u[k]);
                 }
 #pragma unroll
                 for (int k = 0; k < kUn; ++k) {
@@ -250,15 +278,15 @@ __global__ __launch_bounds__(1024) void agg_gemm_kernel(const int32_t *__restric
     }
 }
 
-template <int N, bool COEF, int ACT>
-int launch_fused(const int32_t *rowptr, const int32_t *idx, const float *coef, const float *x, const float *B,
-                 int b_nk, const float *bias, float *P, float *Z, int64_t n_rows, int grid)
+template <int N, bool COEF, int ACT, bool BUF>
+int launch_fused_b(const int32_t *rowptr, const int32_t *idx, const float *coef, const float *x, const float *B,
+                   int b_nk, const float *bias, float *P, float *Z, int64_t n_rows, int grid, uint32_t x_bytes)
 {
     constexpr int CHr = 16 * (64 / (N / 4));
     constexpr size_t lds = sizeof(float) * ((size_t)N * (N + 4) + 2 * CHr * (N + 4));
     static amp::PerDeviceFlag attr;
     if (!attr.get()) {
-        AMP_HIP(hipFuncSetAttribute((const void *)agg_gemm_kernel<N, COEF, ACT>,
+        AMP_HIP(hipFuncSetAttribute((const void *)agg_gemm_kernel<N, COEF, ACT, BUF>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr.get() = true;
     }
@@ -268,10 +296,22 @@ int launch_fused(const int32_t *rowptr, const int32_t *idx, const float *coef, c
     if (amp::named_buffer("fused.ticket_ring", sizeof(unsigned long long) * 64, true, (void **)&ring)) return 1;
     unsigned long long *ticket = ring + (slot++ & 63);
     AMP_HIP(hipMemsetAsync(ticket, 0, sizeof(unsigned long long), amp::stream()));
-    hipLaunchKernelGGL((agg_gemm_kernel<N, COEF, ACT>), dim3(grid), dim3(1024), lds, amp::stream(), rowptr, idx, coef, x,
-                       B, b_nk, bias, P, Z, n_rows, ticket);
+    hipLaunchKernelGGL((agg_gemm_kernel<N, COEF, ACT, BUF>), dim3(grid), dim3(1024), lds, amp::stream(), rowptr, idx, coef, x,
+                       B, b_nk, bias, P, Z, n_rows, ticket, x_bytes);
     AMP_LAUNCH_CHECK();
     return 0;
+}
+
+// x_rows: rows of the gathered tensor (0 = unknown).  Below 4 GB the rows are addressed through a buffer descriptor.
+template <int N, bool COEF, int ACT>
+int launch_fused(const int32_t *rowptr, const int32_t *idx, const float *coef, const float *x, const float *B,
+                 int b_nk, const float *bias, float *P, float *Z, int64_t n_rows, int grid, int64_t x_rows)
+{
+    static const bool nobuf = getenv("ATHENA_MP_NO_BUFFER_LOADS") != nullptr;   // A/B switch for measurements
+    const int64_t bytes = x_rows * N * 4;
+    if (!nobuf && x_rows > 0 && bytes < ((int64_t)1 << 32) - 4096)
+        return launch_fused_b<N, COEF, ACT, true>(rowptr, idx, coef, x, B, b_nk, bias, P, Z, n_rows, grid, (uint32_t)bytes);
+    return launch_fused_b<N, COEF, ACT, false>(rowptr, idx, coef, x, B, b_nk, bias, P, Z, n_rows, grid, 0u);
 }
 
 
@@ -289,7 +329,7 @@ int launch_fused(const int32_t *rowptr, const int32_t *idx, const float *coef, c
 constexpr int kFirst256 = 8;
 constexpr int kTail256 = 4;        // entries per row per round beyond the prefetched block (both rows together)
 
-template <bool COEF, int ACT>
+template <bool COEF, int ACT, bool BUF>
 __global__ __launch_bounds__(512) void agg_gemm256_kernel(const int32_t *__restrict__ rowptr,
                                                           const int32_t *__restrict__ idx,
                                                           const float *__restrict__ coef,
@@ -297,7 +337,8 @@ __global__ __launch_bounds__(512) void agg_gemm256_kernel(const int32_t *__restr
                                                           const float *__restrict__ B, int b_nk,
                                                           const float *__restrict__ bias,
                                                           float *__restrict__ P, float *__restrict__ Z,
-                                                          int64_t n_rows, unsigned long long *__restrict__ ticket)
+                                                          int64_t n_rows, unsigned long long *__restrict__ ticket,
+                                                          uint32_t x_bytes)
 {
     constexpr int K = 256, N = 256, LD = 260, CH = 16, KG = 64, kF = kFirst256;
     __shared__ __attribute__((aligned(16))) float Ts[2 * CH * LD];
@@ -345,6 +386,18 @@ __global__ __launch_bounds__(512) void agg_gemm256_kernel(const int32_t *__restr
             }
         }
     };
+    // row loads: 32-bit byte offsets against a buffer descriptor when the gathered tensor is below 4 GB (see the
+    // 64/128-wide kernel above)
+    __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, BUF ? (int)x_bytes : 0, 0x00020000);
+    auto load_row = [&](int u) -> v4f {
+        if constexpr (BUF) {
+            typedef int v4i_ __attribute__((ext_vector_type(4)));
+            const v4i_ t = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (u << 10) + 16 * lane, 0, 0);
+            return __builtin_bit_cast(v4f, t);
+        } else {
+            return *reinterpret_cast<const v4f *>(x + (int64_t)u * K + 4 * lane);
+        }
+    };
     v4f v[2][kF];
     auto issue_first = [&]() {
 #pragma unroll
@@ -353,7 +406,7 @@ __global__ __launch_bounds__(512) void agg_gemm256_kernel(const int32_t *__restr
             for (int k = 0; k < kF; ++k) {
                 const int u = __shfl(idx0[r], k, 64);
                 v[r][k] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
-                if (k < len[r] && u >= 0) v[r][k] = *reinterpret_cast<const v4f *>(x + (int64_t)u * K + 4 * lane);
+                if (k < len[r]) v[r][k] = load_row(u);
             }
     };
     // both rows of the wave advance TOGETHER through the entries beyond the prefetched block (two rows' loads in flight
@@ -365,9 +418,8 @@ __global__ __launch_bounds__(512) void agg_gemm256_kernel(const int32_t *__restr
             acc[r] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int k = 0; k < kF; ++k) {
-                const int u = __shfl(idx0[r], k, 64);
                 const float c = COEF ? __shfl(c0[r], k, 64) : 1.0f;
-                if (k < len[r] && u >= 0) {
+                if (k < len[r]) {
                     if constexpr (COEF) { acc[r].x = acc[r].x + c * v[r][k].x; acc[r].y = acc[r].y + c * v[r][k].y; acc[r].z = acc[r].z + c * v[r][k].z; acc[r].w = acc[r].w + c * v[r][k].w; }
                     else { acc[r].x = acc[r].x + v[r][k].x; acc[r].y = acc[r].y + v[r][k].y; acc[r].z = acc[r].z + v[r][k].z; acc[r].w = acc[r].w + v[r][k].w; }
                 }
@@ -406,7 +458,7 @@ __global__ __launch_bounds__(512) void agg_gemm256_kernel(const int32_t *__restr
 #pragma unroll
                     for (int k = 0; k < kTail256; ++k) {
                         w[r][k] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
-                        if (u[r][k] >= 0) w[r][k] = *reinterpret_cast<const v4f *>(x + (int64_t)u[r][k] * K + 4 * lane);
+                        if (u[r][k] >= 0) w[r][k] = load_row(u[r][k]);
                     }
 #pragma unroll
                 for (int r = 0; r < 2; ++r)
@@ -476,27 +528,34 @@ __global__ __launch_bounds__(512) void agg_gemm256_kernel(const int32_t *__restr
 
 template <bool COEF, int ACT>
 int launch_fused256(const int32_t *rowptr, const int32_t *idx, const float *coef, const float *x, const float *B, int b_nk,
-                    const float *bias, float *P, float *Z, int64_t n_rows, int grid)
+                    const float *bias, float *P, float *Z, int64_t n_rows, int grid, int64_t x_rows)
 {
+    static const bool nobuf = getenv("ATHENA_MP_NO_BUFFER_LOADS") != nullptr;   // A/B switch for measurements
+    const int64_t bytes = x_rows * 1024;
+    const bool buf = !nobuf && x_rows > 0 && bytes < ((int64_t)1 << 32) - 4096;
     static int slot = 0;
     unsigned long long *ring = nullptr;
     if (amp::named_buffer("fused.ticket_ring", sizeof(unsigned long long) * 64, true, (void **)&ring)) return 1;
     unsigned long long *ticket = ring + (slot++ & 63);
     AMP_HIP(hipMemsetAsync(ticket, 0, sizeof(unsigned long long), amp::stream()));
-    hipLaunchKernelGGL((agg_gemm256_kernel<COEF, ACT>), dim3(grid), dim3(512), 0, amp::stream(), rowptr, idx, coef, x, B,
-                       b_nk, bias, P, Z, n_rows, ticket);
+    if (buf)
+        hipLaunchKernelGGL((agg_gemm256_kernel<COEF, ACT, true>), dim3(grid), dim3(512), 0, amp::stream(), rowptr, idx, coef, x, B,
+                           b_nk, bias, P, Z, n_rows, ticket, (uint32_t)bytes);
+    else
+        hipLaunchKernelGGL((agg_gemm256_kernel<COEF, ACT, false>), dim3(grid), dim3(512), 0, amp::stream(), rowptr, idx, coef, x, B,
+                           b_nk, bias, P, Z, n_rows, ticket, 0u);
     AMP_LAUNCH_CHECK();
     return 0;
 }
 
 int fused256_dispatch(const int32_t *rowptr, const int32_t *idx, const float *coef, const float *x, const float *B, int b_nk,
-                      const float *bias, int act, float *P, float *Z, int64_t n_rows)
+                      const float *bias, int act, float *P, float *Z, int64_t n_rows, int64_t x_rows)
 {
     const int grid = (int)std::min<int64_t>((n_rows + 15) / 16, amp::num_cus());
     if (grid == 0) return 0;
 #define AMP_G(ACT_)                                                                                        \
-    return coef ? launch_fused256<true, ACT_>(rowptr, idx, coef, x, B, b_nk, bias, P, Z, n_rows, grid)    \
-                : launch_fused256<false, ACT_>(rowptr, idx, coef, x, B, b_nk, bias, P, Z, n_rows, grid)
+    return coef ? launch_fused256<true, ACT_>(rowptr, idx, coef, x, B, b_nk, bias, P, Z, n_rows, grid, x_rows)    \
+                : launch_fused256<false, ACT_>(rowptr, idx, coef, x, B, b_nk, bias, P, Z, n_rows, grid, x_rows)
     switch (act) {
     case ATHENA_MP_ACT_RELU: AMP_G(ATHENA_MP_ACT_RELU);
     case ATHENA_MP_ACT_SIGMOID: AMP_G(ATHENA_MP_ACT_SIGMOID);
@@ -509,21 +568,22 @@ int fused256_dispatch(const int32_t *rowptr, const int32_t *idx, const float *co
 bool fused_shape(int K, int N) { return K == N && (K == 64 || K == 128 || K == 256); }
 
 int fused_dispatch(const int32_t *rowptr, const int32_t *idx, const float *coef, const float *x, int K, int N,
-                   const float *B, int b_nk, const float *bias, int act, float *P, float *Z, int64_t n_rows)
+                   const float *B, int b_nk, const float *bias, int act, float *P, float *Z, int64_t n_rows,
+                   int64_t x_rows = 0)
 {
     if (!fused_shape(K, N)) {
         amp::set_error("fused Kipf layer kernel: built for 64 -> 64, 128 -> 128 and 256 -> 256 features, got %d -> %d", K, N);
         return 2;
     }
-    if (K == 256) return fused256_dispatch(rowptr, idx, coef, x, B, b_nk, bias, act, P, Z, n_rows);
+    if (K == 256) return fused256_dispatch(rowptr, idx, coef, x, B, b_nk, bias, act, P, Z, n_rows, x_rows);
     const int cus = amp::num_cus();
     const int ch = 16 * (64 / (N / 4));
     const int grid = (int)std::min<int64_t>((n_rows + ch - 1) / ch, cus);
     if (grid == 0) return 0;
     const bool c = coef != nullptr;
 #define AMP_F2(NN_, ACT_)                                                                                    \
-    return c ? launch_fused<NN_, true, ACT_>(rowptr, idx, coef, x, B, b_nk, bias, P, Z, n_rows, grid)          \
-             : launch_fused<NN_, false, ACT_>(rowptr, idx, coef, x, B, b_nk, bias, P, Z, n_rows, grid)
+    return c ? launch_fused<NN_, true, ACT_>(rowptr, idx, coef, x, B, b_nk, bias, P, Z, n_rows, grid, x_rows)  \
+             : launch_fused<NN_, false, ACT_>(rowptr, idx, coef, x, B, b_nk, bias, P, Z, n_rows, grid, x_rows)
 #define AMP_F(ACT_)                    \
     if (N == 64) { AMP_F2(64, ACT_); } \
     AMP_F2(128, ACT_)
@@ -552,7 +612,7 @@ int athena_mp_kipf_layer_fwd(const athena_mp_graph *g, int32_t Fi, int32_t Fo, c
     // hub rows (> kLongRow entries) would stall a whole workgroup at the chunk barrier: such graphs take
     // the two-kernel route, whose aggregation splits them into parallel segments
     if (fused_shape(Fi, Fo) && g->lp_fwd.n_long == 0)
-        return fused_dispatch(g->rowptr, g->col, g->coef, x, Fi, Fo, W, 0, bias, act, P, Z, g->n_rows);
+        return fused_dispatch(g->rowptr, g->col, g->coef, x, Fi, Fo, W, 0, bias, act, P, Z, g->n_rows, g->n_cols);
     if (P == nullptr) {   // the caller keeps no tape of P (its reverse pass is athena_mp_kipf_layer_bwd)
         void *ws = nullptr;
         if (workspace(&ws, sizeof(float) * (size_t)g->n_rows * Fi, 5)) return 1;
@@ -571,7 +631,7 @@ int athena_mp_kipf_layer_bwd_x(const athena_mp_graph *g, int32_t Fi, int32_t Fo,
     AMP_REQUIRE(dZ && W && dX, "kipf_layer_bwd_x: null tensor");
     if (fused_shape(Fi, Fo) && g->lp_bwd.n_long == 0) // dX = (A^T dZ) . W : aggregate, then contract with B [N=Fi][K=Fo]
         return fused_dispatch(g->t_rowptr, g->t_src, exact ? g->t_coef : nullptr, dZ, Fo, Fi, W, 1, nullptr,
-                              ATHENA_MP_ACT_NONE, nullptr, dX, g->n_cols);
+                              ATHENA_MP_ACT_NONE, nullptr, dX, g->n_cols, g->n_rows);
     void *ws = nullptr;
     if (Fo < Fi) { // (A^T dZ) . W : the scatter moves the narrower rows
         if (workspace(&ws, sizeof(float) * (size_t)g->n_cols * Fo, 5)) return 1;
@@ -624,7 +684,7 @@ int athena_mp_pull_gemm(const athena_mp_graph *g, int32_t Fi, int32_t Fo, const 
     AMP_REQUIRE(dZ && W && dX, "pull_gemm: null tensor");
     if (fused_shape(Fi, Fo) && g->lp_fwd.n_long == 0)
         return fused_dispatch(g->rowptr, g->col, exact ? g->coef : nullptr, dZ, Fo, Fi, W, 1, nullptr,
-                              ATHENA_MP_ACT_NONE, nullptr, dX, g->n_rows);
+                              ATHENA_MP_ACT_NONE, nullptr, dX, g->n_rows, g->n_cols);
     void *ws = nullptr;
     if (Fi < Fo) { // A (dZ . W) : contract every source row first, gather the narrower result
         if (workspace(&ws, sizeof(float) * (size_t)g->n_cols * Fi, 5)) return 1;

@@ -68,7 +68,8 @@ __global__ __launch_bounds__(64 * kNW) void agg_gemm_dw_kernel(const int32_t *__
                                                           const float *__restrict__ X,     // [n_rows][Fi]
                                                           float *__restrict__ dX,          // [n_rows][Fi] or null
                                                           float *__restrict__ slabs,       // [grid][Fi * Fo]
-                                                          int64_t n_rows, unsigned long long *__restrict__ ticket)
+                                                          int64_t n_rows, unsigned long long *__restrict__ ticket,
+                                                          uint32_t dz_bytes)
 {
     constexpr int K = kN, N = kN, G = 32, KG = K / 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -110,6 +111,16 @@ __global__ __launch_bounds__(64 * kNW) void agg_gemm_dw_kernel(const int32_t *__
             }
         }
     };
+    // row loads: 32-bit byte offsets against a buffer descriptor when dZ is below 4 GB (fused.hip)
+    __amdgpu_buffer_rsrc_t zrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)dz, 0, dz_bytes ? (int)dz_bytes : 0, 0x00020000);
+    auto load_row = [&](int u) -> v4f {
+        if (dz_bytes) {   // workgroup-uniform
+            typedef int v4i_ __attribute__((ext_vector_type(4)));
+            const v4i_ t = __builtin_amdgcn_raw_buffer_load_b128(zrsrc, (u << 9) + 16 * gl, 0, 0);
+            return __builtin_bit_cast(v4f, t);
+        }
+        return *reinterpret_cast<const v4f *>(dz + (int64_t)u * K + 4 * gl);
+    };
     v4f v[kPairs][kFd];
     auto issue_first = [&]() {
 #pragma unroll
@@ -118,7 +129,7 @@ __global__ __launch_bounds__(64 * kNW) void agg_gemm_dw_kernel(const int32_t *__
             for (int k = 0; k < kFd; ++k) {
                 const int u = __shfl(idx0[p], k, G);
                 v[p][k] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
-                if (k < len[p] && u >= 0) v[p][k] = *reinterpret_cast<const v4f *>(dz + (int64_t)u * K + 4 * gl);
+                if (k < len[p]) v[p][k] = load_row(u);
             }
     };
     auto fma4 = [](v4f &a, float c, const v4f &x) { a.x = a.x + c * x.x; a.y = a.y + c * x.y; a.z = a.z + c * x.z; a.w = a.w + c * x.w; };
@@ -131,9 +142,8 @@ __global__ __launch_bounds__(64 * kNW) void agg_gemm_dw_kernel(const int32_t *__
             accc[p] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int k = 0; k < kFd; ++k) {
-                const int u = __shfl(idx0[p], k, G);
                 const float c = __shfl(c0[p], k, G);
-                if (k < len[p] && u >= 0) {
+                if (k < len[p]) {
                     if constexpr (!EXACT) add4(acc[p], v[p][k]);
                     fma4(accc[p], c, v[p][k]);
                 }
@@ -177,7 +187,7 @@ __global__ __launch_bounds__(64 * kNW) void agg_gemm_dw_kernel(const int32_t *__
 #pragma unroll
                     for (int k = 0; k < kTd; ++k) {
                         w[p][k] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
-                        if (u[p][k] >= 0) w[p][k] = *reinterpret_cast<const v4f *>(dz + (int64_t)u[p][k] * K + 4 * gl);
+                        if (u[p][k] >= 0) w[p][k] = load_row(u[p][k]);
                     }
 #pragma unroll
                 for (int p = 0; p < kPairs; ++p)
@@ -322,12 +332,14 @@ int fused_dw_dispatch(const int32_t *t_rowptr, const int32_t *t_src, const float
     AMP_HIP(hipMemsetAsync(ticket, 0, sizeof(unsigned long long), amp::stream()));
     void *slabs = nullptr;
     if (amp::workspace(&slabs, sizeof(float) * (size_t)grid * kN * kN, 6)) return 1;
+    const int64_t zb = n_cols * kN * 4;   // square graph: dZ has n_cols rows
+    const uint32_t dz_bytes = zb < ((int64_t)1 << 32) - 4096 ? (uint32_t)zb : 0u;
     if (exact)
         hipLaunchKernelGGL(agg_gemm_dw_kernel<true>, dim3(grid), dim3(64 * kNW), lds, amp::stream(), t_rowptr, t_src, t_coef, dZ, W, X,
-                           dX, (float *)slabs, n_cols, ticket);
+                           dX, (float *)slabs, n_cols, ticket, dz_bytes);
     else
         hipLaunchKernelGGL(agg_gemm_dw_kernel<false>, dim3(grid), dim3(64 * kNW), lds, amp::stream(), t_rowptr, t_src, t_coef, dZ, W, X,
-                           dX, (float *)slabs, n_cols, ticket);
+                           dX, (float *)slabs, n_cols, ticket, dz_bytes);
     AMP_LAUNCH_CHECK();
     return amp::slab_reduce((const float *)slabs, grid, kN * kN, dW, false);
 }

@@ -6,8 +6,8 @@ set -e
 src=$1; tag=$2; shift 2
 cd "$(dirname "$0")/../athena_amd/csrc"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off"
-mkdir -p ../../variants
-/opt/rocm/bin/hipcc $FLAGS "$@" -c $src -o ../../build/obj/${src%.hip}_$tag.o
-objs=$(ls ../../build/obj/*.o | grep -v "/${src%.hip}\(_[A-Za-z0-9]*\)\?\.o" | tr '\n' ' ')
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs ../../build/obj/${src%.hip}_$tag.o -o ../../variants/libathena_mp_$tag.so
+mkdir -p ../../variants ../../build/obj_variants
+/opt/rocm/bin/hipcc $FLAGS "$@" -c $src -o ../../build/obj_variants/${src%.hip}_$tag.o
+objs=$(ls ../../build/obj/*.o | grep -v "/${src%.hip}\.o$" | tr '\n' ' ')     # every stock object but this source's
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs ../../build/obj_variants/${src%.hip}_$tag.o -o ../../variants/libathena_mp_$tag.so
 echo "built variants/libathena_mp_$tag.so"
