@@ -41,9 +41,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // 32-row chunks, one row pair per wave; the first kFirst row loads of the NEXT chunk are issued before
 // the matrix work of the CURRENT chunk and consumed after it.
-#ifndef FUSED_LEAN
-#define FUSED_LEAN 1
-#endif
 #ifndef FUSED_STAGGER
 #define FUSED_STAGGER 0   // measured at configs[1]: 0.936 / 0.884 ms with, 0.930 / 0.890 ms without (forward / reverse): no gain here
 #endif
@@ -141,31 +138,26 @@ __global__ __launch_bounds__(1024) void agg_gemm_kernel(const int32_t *__restric
     };
     constexpr int kF = kFirst < G ? kFirst : G;   // entries whose loads fly under the matrix work
     v4f v[kF];
+    // Slots are predicated (a slot beyond the row's length issues nothing when neither row of the wave reaches it).
+    // Measured and dropped: unpredicated slots, with the byte offset 0xFFFFFFFF for a slot beyond the row so that the
+    // buffer bounds check returns zeros and the sum adds every slot unconditionally -- 616 -> 422 instructions per chunk
+    // iteration in the ISA, yet 2.06 ms per step against 2.05: the empty slots (rows average 10 of the 16) then cost a
+    // trip through the address unit each, which is more than the scalar exec-mask bookkeeping they replace.
     auto issue_first = [&]() {            // row loads of entries 0 .. kF-1 (no waits)
 #pragma unroll
         for (int k = 0; k < kF; ++k) {
             const int u = __shfl(idx0, k, G);
-#if FUSED_LEAN
-            // no zero fill: slot k is read (below, in finish) under the same `k < len` it is loaded under, and the Kipf
-            // CSR carries no negative ids -- one v_cndmask per component and one index broadcast per entry less
-            if (k < len) v[k] = load_row(u);
-#else
             v[k] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
-            if (k < len && u >= 0) v[k] = load_row(u);
-#endif
+            if (k < len) v[k] = load_row(u);      // the Kipf CSR carries no negative ids: no `u >= 0` test, and the sum
+                                                  // below needs no second broadcast of the index
         }
     };
     auto finish = [&]() -> v4f {          // CSR-order accumulation: first block from registers, rest streamed
         v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int k = 0; k < kF; ++k) {
-#if FUSED_LEAN
-            const int u = 0;
-#else
-            const int u = __shfl(idx0, k, G);
-#endif
             const float c = COEF ? __shfl(c0, k, G) : 1.0f;
-            if (k < len && u >= 0) {
+            if (k < len) {
                 if constexpr (COEF) { acc.x = acc.x + c * v[k].x; acc.y = acc.y + c * v[k].y; acc.z = acc.z + c * v[k].z; acc.w = acc.w + c * v[k].w; }
                 else { acc.x = acc.x + v[k].x; acc.y = acc.y + v[k].y; acc.z = acc.z + v[k].z; acc.w = acc.w + v[k].w; }
             }
