@@ -312,6 +312,9 @@ __global__ __launch_bounds__(1024) void gno_fused_kernel(const int32_t *__restri
             const int s_beg = wave * per_wave, s_end = min(n_steps, s_beg + per_wave);
             const float *vbase = Vaug + (size_t)half * 32 * kGF * kGF;     // rows (kq) of this half
             const float *sl = Sh + n * kGSP + g;
+            // (Measured and dropped in round 2: a software pipeline over two register sets, the V fragments and S words of
+            // round r+1 in flight under the MFMAs of round r -- 18.1-18.8 ms against 17.5 ms for this loop, with 4-11
+            // spilled registers at 3-4 steps per round; the contraction is not waiting for its operands.)
             constexpr int UN = 8;
             for (int s0 = s_beg; s0 < s_end; s0 += UN) {
                 v4f_g a[UN];

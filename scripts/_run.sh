@@ -1,6 +1,4 @@
-for v in 0 1 0 1; do
-  if [ $v = 1 ]; then export ATHENA_MP_NO_LENGTH_ORDER=1; else unset ATHENA_MP_NO_LENGTH_ORDER; fi
-  echo "noorder [$v]"; timeout 300 python3 bench.py --no-cpu-baseline --steps 40 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'], d['roofline']['avg_launch_ms'])"
+for v in "" un3 nopipe; do
+  if [ -n "$v" ]; then export ATHENA_MP_LIB=$PWD/variants/libathena_mp_$v.so; else unset ATHENA_MP_LIB; fi
+  echo "variant [$v]"; timeout 900 python3 scripts/bench_configs.py --config c4 --reps 3 --no-cpu 2>/dev/null | cut -c1-120
 done
-unset ATHENA_MP_NO_LENGTH_ORDER
-timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_fullsize.py tests/test_gpu_dist.py -x -q -k "fused or reverse_pass or multi_rank" 2>&1 | grep -E "passed|failed|Error|assert" | tail -5
