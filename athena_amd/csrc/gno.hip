@@ -210,6 +210,9 @@ __global__ __launch_bounds__(1024) void gno_fused_kernel(const int32_t *__restri
                                                          float *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) float Sh[];   // [16][kGSP]; reused for the final reduction
+    // (Measured and dropped in round 2: the sparse phase's row and coordinate loads through buffer descriptors with
+    // 32-bit offsets and dead slots pointed past the buffer -- 18.3 ms against 17.5: as in fused.hip, unpredicated loads
+    // of dead slots cost more than the address arithmetic they save.)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r31 = lane & 31, h = lane >> 5;
     const int n = lane & 15, g = lane >> 4;
     const int n_tiles = (n_rows + kGRows - 1) / kGRows;
@@ -315,23 +318,35 @@ __global__ __launch_bounds__(1024) void gno_fused_kernel(const int32_t *__restri
             // (Measured and dropped in round 2: a software pipeline over two register sets, the V fragments and S words of
             // round r+1 in flight under the MFMAs of round r -- 18.1-18.8 ms against 17.5 ms for this loop, with 4-11
             // spilled registers at 3-4 steps per round; the contraction is not waiting for its operands.)
+            // PMC (profiles/r02_c4_gno_pmc.txt): 3.5e9 vector instructions against 6.7e8 MFMAs per launch -- the kernel is
+            // bound by instruction ISSUE (matrix pipe busy 56 %, vector issue ~37 % of the SIMD cycles), so the loop below
+            // carries no per-step arithmetic: every wave has exactly 32 steps (+1 in the second half: 528 = 16 x 33), the
+            // operand addresses of a round are one base pointer plus compile-time offsets (1 KB apart in V, 16 B apart in
+            // S), no clamps, no per-step conditions.
             constexpr int UN = 8;
-            for (int s0 = s_beg; s0 < s_end; s0 += UN) {
+            const float *ap = vbase + (size_t)(4 * s_beg + g) * kGF + 4 * n;
+            const float *bp = sl + 4 * s_beg;
+#pragma unroll 1
+            for (int r = 0; r < 4; ++r) {
                 v4f_g a[UN];
                 float b[UN];
 #pragma unroll
                 for (int u = 0; u < UN; ++u) {
-                    const int s = min(s0 + u, s_end - 1);
-                    a[u] = *reinterpret_cast<const v4f_g *>(vbase + (size_t)(4 * s + g) * kGF + 4 * n);
-                    b[u] = sl[4 * s];
+                    a[u] = *reinterpret_cast<const v4f_g *>(ap + (size_t)u * 4 * kGF);
+                    b[u] = bp[4 * u];
                 }
 #pragma unroll
-                for (int u = 0; u < UN; ++u) {
-                    if (s0 + u < s_end) {
+                for (int u = 0; u < UN; ++u)
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) om[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][c], b[u], om[c], 0, 0, 0);
-                    }
-                }
+                    for (int c = 0; c < 4; ++c) om[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][c], b[u], om[c], 0, 0, 0);
+                ap += (size_t)UN * 4 * kGF;
+                bp += 4 * UN;
+            }
+            if (s_end - s_beg > 32) {   // second half: the 33rd step (bias row)
+                const v4f_g a1 = *reinterpret_cast<const v4f_g *>(ap);
+                const float b1 = bp[0];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) om[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[c], b1, om[c], 0, 0, 0);
             }
             __syncthreads();
         }

@@ -1,4 +1,5 @@
-for v in "" un3 nopipe; do
-  if [ -n "$v" ]; then export ATHENA_MP_LIB=$PWD/variants/libathena_mp_$v.so; else unset ATHENA_MP_LIB; fi
-  echo "variant [$v]"; timeout 900 python3 scripts/bench_configs.py --config c4 --reps 3 --no-cpu 2>/dev/null | cut -c1-120
+timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_fuzz.py tests/test_gpu_fullsize.py -x -q -k "gno" 2>&1 | grep -E "passed|failed|Error|assert" | tail -5
+for v in 0 1; do
+  if [ $v = 1 ]; then export ATHENA_MP_NO_BUFFER_LOADS=1; else unset ATHENA_MP_NO_BUFFER_LOADS; fi
+  echo "nobuf [$v]"; timeout 900 python3 scripts/bench_configs.py --config c4 --reps 3 --no-cpu 2>/dev/null | cut -c1-120
 done
