@@ -36,9 +36,18 @@ def kipf_weight(F, seed=2):
 
 def kipf_inputs(n, F, seed=1):
     """X ~ U(-1,1) (seed), W ~ N(0, 2/F) (seed+1), dZ ~ U(-1,1) (seed+2); fp32."""
-    x = np.random.Generator(np.random.PCG64(seed)).uniform(-1, 1, (n, F)).astype(np.float32)
+    def stream(sd):      # the same values as one (n, F) draw, produced 2^20 rows at a time (the float64 draw of a
+        out = np.empty((n, F), np.float32)          # configs[4]-sized tensor would take 20 GB of host memory at once)
+        for r0 in range(0, n, 1 << 20):
+            r1 = min(n, r0 + (1 << 20))
+            out[r0:r1] = feature_block(sd, r0, r1, F)
+        return out
+    if n * F <= (1 << 28):
+        x = np.random.Generator(np.random.PCG64(seed)).uniform(-1, 1, (n, F)).astype(np.float32)
+        dz = np.random.Generator(np.random.PCG64(seed + 2)).uniform(-1, 1, (n, F)).astype(np.float32)
+    else:
+        x, dz = stream(seed), stream(seed + 2)
     w = kipf_weight(F, seed + 1)
-    dz = np.random.Generator(np.random.PCG64(seed + 2)).uniform(-1, 1, (n, F)).astype(np.float32)
     return x, w, dz
 
 

@@ -379,7 +379,8 @@ def main():
         except Exception:
             traffic = None
     fused = F in (64, 128, 256)
-    kname = (f"agg_gemm_kernel<{F},coef> (fused kipf_propagate + matmul fwd)" if fused else
+    kname = ((f"agg_gemm_kernel<{F},coef>" if F != 256 else "agg_gemm256_kernel<coef> (W in registers)")
+             + " (fused kipf_propagate + matmul fwd)" if fused else
              "kipf_layer_fwd = csr_gather_agg + dense step (two launches at this width)") + part
     out["roofline"] = {"bound": "hbm", "kernel": kname,
                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
