@@ -24,8 +24,10 @@ struct NamedBuf {
     size_t bytes = 0;
 };
 struct DevCtx {
-    void *ws[8] = {};
-    size_t ws_bytes[8] = {};
+    void *ws[10] = {};
+    size_t ws_bytes[10] = {};
+    hipStream_t aux = nullptr;            // second stream of the library (producer / consumer pipelines inside one call)
+    hipEvent_t ev[6] = {};                // events of those pipelines
     std::map<std::string, NamedBuf> named;
     int cus = 0;
 };
@@ -42,6 +44,18 @@ void set_error(const char *fmt, ...)
     va_end(ap);
 }
 hipStream_t stream() { return g_stream; }
+void swap_stream(hipStream_t s) { g_stream = s; }
+int aux_stream(hipStream_t *s, hipEvent_t **events)
+{
+    DevCtx &c = g_ctx[g_device];
+    if (!c.aux) {
+        AMP_HIP(hipStreamCreateWithFlags(&c.aux, hipStreamNonBlocking));
+        for (auto &e : c.ev) AMP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    *s = c.aux;
+    *events = c.ev;
+    return 0;
+}
 int device() { return g_device; }
 int num_cus()
 {
@@ -123,7 +137,7 @@ int athena_mp_finalize(void)
     amp::host_pool_release();
     for (int d = 0; d < kMaxDevices; ++d) {       // every device this process initialised
         DevCtx &c = g_ctx[d];
-        for (int s = 0; s < 8; ++s) {
+        for (int s = 0; s < 10; ++s) {
             if (c.ws[s]) {
                 AMP_HIP(hipFree(c.ws[s]));
                 c.ws[s] = nullptr;
@@ -133,6 +147,9 @@ int athena_mp_finalize(void)
         for (auto &kv : c.named)
             if (kv.second.p) AMP_HIP(hipFree(kv.second.p));
         c.named.clear();
+        if (c.aux) { (void)hipStreamDestroy(c.aux); c.aux = nullptr; }
+        for (auto &e : c.ev)
+            if (e) { (void)hipEventDestroy(e); e = nullptr; }
     }
     return 0;
 }

@@ -13,6 +13,10 @@ namespace amp {
 // ---- error plumbing: C side never aborts, it returns a code + message ---------------------
 void set_error(const char *fmt, ...);
 hipStream_t stream();
+// a second, library-owned stream of the current device and six events (pipelines inside one API call); swap_stream
+// redirects the launchers of this library (they all launch on stream()) for the duration of such a pipeline
+void swap_stream(hipStream_t s);
+int aux_stream(hipStream_t *s, hipEvent_t **events);
 
 #define AMP_HIP(expr)                                                                        \
     do {                                                                                     \

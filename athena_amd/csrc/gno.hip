@@ -1067,16 +1067,50 @@ int athena_mp_gno_aggregate_bwd_theta(const athena_mp_graph *g, int32_t d, int32
     const size_t off_V = (size_t)H * d + H;
     const int R = (H + 1) * Fi;
     // dVaug = S^T g  (dV and db_v in one contraction; the bias row of S is s_i = sum_j x_j)
+    // S goes through HBM one super-tile at a time.  The two kernels of a super-tile lean on different resources -- the
+    // outer product is bound by its 2 GiB of writes, the contraction by the matrix pipe and reads -- so they are
+    // pipelined over two workspace slots: the outer product of tile t+1 runs on the library's second stream while the
+    // contraction of tile t runs on the caller's.
     const int tile = tile_rows_for(g->n_rows, R);
     if (g->n_rows == 0) AMP_HIP(hipMemsetAsync(dtheta + off_V, 0, sizeof(float) * (size_t)R * Fo, stream()));
-    for (int r0 = 0; r0 < g->n_rows; r0 += tile) {
-        const int rows = std::min(tile, g->n_rows - r0);
-        void *ws = nullptr;
-        if (workspace(&ws, sizeof(float) * (size_t)rows * R, 0)) return 1;
-        int rc = launch_outer(g->rowptr, g->col, g->eid, x, Fi, coords, theta, d, H, r0, rows, (float *)ws);
-        if (rc) return rc;
-        rc = gemm_dw_dispatch(rows, R, Fo, (const float *)ws, grad + (size_t)r0 * Fo, dtheta + off_V, r0 > 0);
-        if (rc) return rc;
+    static const bool serial = getenv("ATHENA_MP_GNO_SERIAL_TILES") != nullptr;   // A/B switch for measurements
+    const int n_tiles = g->n_rows > 0 ? (g->n_rows + tile - 1) / tile : 0;
+    if (serial || n_tiles < 2) {
+        for (int r0 = 0; r0 < g->n_rows; r0 += tile) {
+            const int rows = std::min(tile, g->n_rows - r0);
+            void *ws = nullptr;
+            if (workspace(&ws, sizeof(float) * (size_t)rows * R, 0)) return 1;
+            int rc = launch_outer(g->rowptr, g->col, g->eid, x, Fi, coords, theta, d, H, r0, rows, (float *)ws);
+            if (rc) return rc;
+            rc = gemm_dw_dispatch(rows, R, Fo, (const float *)ws, grad + (size_t)r0 * Fo, dtheta + off_V, r0 > 0);
+            if (rc) return rc;
+        }
+    } else {
+        hipStream_t main_s = stream(), aux = nullptr;
+        hipEvent_t *ev = nullptr;
+        if (amp::aux_stream(&aux, &ev)) return 1;
+        void *wsl[2] = {nullptr, nullptr};
+        if (workspace(&wsl[0], sizeof(float) * (size_t)tile * R, 0) || workspace(&wsl[1], sizeof(float) * (size_t)tile * R, 8)) return 1;
+        // ev[0]: inputs ready (main -> aux); ev[1 + slot]: S of the slot written (aux -> main); ev[3 + slot]: consumed
+        AMP_HIP(hipEventRecord(ev[0], main_s));
+        AMP_HIP(hipStreamWaitEvent(aux, ev[0], 0));
+        int rc = 0;
+        for (int t = 0; t < n_tiles && rc == 0; ++t) {
+            const int slot = t & 1, r0 = t * tile, rows = std::min(tile, g->n_rows - r0);
+            if (t >= 2) rc = hipStreamWaitEvent(aux, ev[3 + slot], 0) == hipSuccess ? 0 : 1;
+            amp::swap_stream(aux);
+            if (rc == 0) rc = launch_outer(g->rowptr, g->col, g->eid, x, Fi, coords, theta, d, H, r0, rows, (float *)wsl[slot]);
+            amp::swap_stream(main_s);
+            if (rc == 0 && hipEventRecord(ev[1 + slot], aux) != hipSuccess) rc = 1;
+            if (rc == 0 && hipStreamWaitEvent(main_s, ev[1 + slot], 0) != hipSuccess) rc = 1;
+            if (rc == 0) rc = gemm_dw_dispatch(rows, R, Fo, (const float *)wsl[slot], grad + (size_t)r0 * Fo, dtheta + off_V, t > 0);
+            if (rc == 0 && hipEventRecord(ev[3 + slot], main_s) != hipSuccess) rc = 1;
+        }
+        amp::swap_stream(main_s);
+        if (rc) {
+            if (athena_mp_last_error()[0] == 0) set_error("gno_aggregate_bwd_theta: stream pipeline failed");
+            return rc;
+        }
     }
     return gno_mlp_backward(g, d, H, Fi, Fo, theta, coords, x, grad, dtheta, nullptr);
 }
