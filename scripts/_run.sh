@@ -1,5 +1,5 @@
-timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_fuzz.py tests/test_gpu_fullsize.py tests/test_gpu_layers.py -x -q -k "gno" 2>&1 | grep -E "passed|failed|Error|assert" | tail -5
-for v in 0 1 0; do
-  if [ $v = 1 ]; then export ATHENA_MP_GNO_SERIAL_TILES=1; else unset ATHENA_MP_GNO_SERIAL_TILES; fi
-  echo "serial [$v]"; timeout 900 python3 scripts/bench_configs.py --config c4 --reps 3 --no-cpu 2>/dev/null | cut -c1-120
-done
+mkdir -p gpurun_out/r2g
+timeout 2400 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | grep -E "passed|failed|error" | tail -5
+timeout 300 python3 bench.py > gpurun_out/r2g/bench1.json 2> gpurun_out/r2g/bench1.err; python3 -c "
+import json; d=json.load(open('gpurun_out/r2g/bench1.json')); print(d['ms_per_step'], d['value']/1e9, d['roofline']['frac'], d['parity']['ok'], d['cpu_baseline']['value'])"
+python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
