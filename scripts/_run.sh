@@ -1,5 +1,5 @@
-mkdir -p gpurun_out/r2g
-timeout 2400 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | grep -E "passed|failed|error" | tail -5
-timeout 300 python3 bench.py > gpurun_out/r2g/bench1.json 2> gpurun_out/r2g/bench1.err; python3 -c "
-import json; d=json.load(open('gpurun_out/r2g/bench1.json')); print(d['ms_per_step'], d['value']/1e9, d['roofline']['frac'], d['parity']['ok'], d['cpu_baseline']['value'])"
-python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+timeout 900 python -m pytest tests -m gpu -x -q -k "duvenaud or c3 or fuzz or chemical" 2>&1 | grep -E "passed|failed|Error|assert" | tail -5
+for v in "" nofold ""; do
+  if [ -n "$v" ]; then export ATHENA_MP_LIB=$PWD/variants/libathena_mp_$v.so; else unset ATHENA_MP_LIB; fi
+  echo "variant [$v]"; timeout 600 python3 scripts/bench_configs.py --config c3 --no-cpu 2>/dev/null | cut -c1-260
+done
