@@ -351,6 +351,29 @@ class CShard:
             self.handle = None
 
 
+def _c_shard_or_none(device, adj_ia, cols_global):
+    """the C-ABI shard, or None when ANY rank failed to build its communicator / shard (every rank then takes dist.py's
+    python plan over torch point-to-point instead, and says so in `transport`).  Not a silent detour: the reason is
+    printed by the rank that failed and recorded in the shard's transport string."""
+    import sys
+    err = None
+    sh = None
+    try:
+        sh = CShard(c_comm(torch.device(device)), adj_ia, cols_global)
+    except Exception as exc:      # AthenaMPError from the C ABI, OSError from the loader ...
+        err = f"{type(exc).__name__}: {exc}"[:300]
+        print(f"[athena_mp dist] rank {dist.get_rank()}: C-ABI communicator / shard failed: {err}", file=sys.stderr, flush=True)
+    flag = torch.tensor([0 if err is None else 1], dtype=torch.int32)
+    if dist.get_backend() == "nccl":
+        flag = flag.to(device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if int(flag.item()) == 0:
+        return sh, None
+    if sh is not None:
+        sh.close()
+    return None, (err or "another rank failed")
+
+
 def _use_c_abi(device):
     import os
     return (device is not None and torch.device(device).type == "cuda" and dist.is_initialized()
@@ -445,11 +468,14 @@ class HipBackend:
 
 def make_weak_scaling_shard(rank, world, n, pairs, F, cut=None, device=None, seed=20260424):
     rows, cols, cut = shard_entries(rank, world, n, pairs, cut, seed)
+    sh, why = None, None
     if _use_c_abi(device):
         ia = np.concatenate([[1], 1 + np.cumsum(np.bincount(rows, minlength=n))])
-        sh = CShard(c_comm(torch.device(device)), ia, cols)
-    else:
+        sh, why = _c_shard_or_none(device, ia, cols)
+    if sh is None:
         sh = build_plan(Shard(rank, world, n, rows, cols), device)
+        if why:
+            sh.transport = Shard.transport + f" -- FALLBACK, the C-ABI path failed: {why}"
     sh.cut = cut
     return sh
 
@@ -463,11 +489,14 @@ def make_global_shard(rank, world, n_total, pairs, device=None, seed=20260424, l
         raise ValueError(f"{n_total} vertices do not split into {world} equal row blocks")
     n = n_total // world
     ia, cols = synth.random_graph_csr_rows(n_total, pairs, rank * n, (rank + 1) * n, seed=seed, locality=locality)
+    sh, why = None, None
     if _use_c_abi(device):
-        sh = CShard(c_comm(torch.device(device)), ia, cols)
-    else:
+        sh, why = _c_shard_or_none(device, ia, cols)
+    if sh is None:
         rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(ia))
         sh = build_plan(Shard(rank, world, n, rows, cols), device)
+        if why:
+            sh.transport = Shard.transport + f" -- FALLBACK, the C-ABI path failed: {why}"
     sh.cut = None
     sh.n_total = n_total
     return sh
