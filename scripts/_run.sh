@@ -1,11 +1,5 @@
-export TMPDIR=/tmp
-OUT=$PWD/gpurun_out/pmc_c3; mkdir -p $OUT
-HERE=$PWD
-cd /tmp; rm -rf /tmp/p1 /tmp/p2
-timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d /tmp/p1 -- python3 $HERE/scripts/bench_configs.py --config c3 --reps 2 --no-cpu > /dev/null 2> $OUT/e1.txt
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p2 -- python3 $HERE/scripts/bench_configs.py --config c3 --reps 5 --no-cpu > /dev/null 2>> $OUT/e1.txt
-cd $HERE
-python3 scripts/pmc_summarise.py /tmp/p1 > $OUT/c3_pmc.txt
-find /tmp/p2 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/c3_kernel_stats.csv
-grep -E "duv_|readout|csr_gather" $OUT/c3_pmc.txt | cut -c1-140
-head -12 $OUT/c3_kernel_stats.csv | cut -c1-150
+bash scripts/profile_round.sh r02b > gpurun_out/prof_r02b.log 2>&1
+tail -3 gpurun_out/prof_r02b.log; cat gpurun_out/prof_r02b/pmc_summary.txt | head -4; head -4 gpurun_out/prof_r02b/bench_kernel_stats.csv | cut -c1-60,180-260; tail -4 gpurun_out/prof_r02b/f256.txt; python3 -c "
+import json; d=json.load(open('gpurun_out/prof_r02b/bench.json')); print(d['ms_per_step'], d['value']/1e9, d['roofline']['frac'], d['roofline']['avg_launch_ms'], d['parity'])
+d=json.load(open('gpurun_out/prof_r02b/bench_profiled.json')); print('profiled', d['ms_per_step'], d['roofline']['avg_launch_ms'])"
+cat gpurun_out/prof_r02b/fortran_bench.txt | grep driver | cut -c1-200
