@@ -15,6 +15,7 @@
 //   dU,db_u,dcoords : per entry dh[k] = sum_q G_i[k,q] x_j[q], G = g . Vmat^T, masked by relu' (:303-318, :195-210)
 // S / T / G are produced per super-tile of vertices into a bounded HBM workspace.
 #include <algorithm>
+#include <type_traits>
 
 #include <stdlib.h>
 
@@ -197,6 +198,9 @@ __global__ __launch_bounds__(256) void gno_outer_mfma_kernel(const int32_t *__re
 //            outputs of its vertex; the 4 s-steps of a wave's slice are split over the 16 waves.
 // The per-wave partial sums are added through LDS in wave order (deterministic).
 typedef float v4f_g __attribute__((ext_vector_type(4)));
+#ifndef GNO_FV
+#define GNO_FV 0   // timing-only variants (scripts/build_variants.sh), bit mask: 1 no sparse loop, 2 no V loads, 4 no S reads, 8 no contraction, 16 no cross-wave reduction (gno_fused_kernel); 32 idle producers, 64 idle consumers (gno_pc_kernel)
+#endif
 constexpr int kGF = 64, kGH = 64, kGRows = 16, kGSP = 33 * kGF + 4;   // LDS row pitch of S_half
 
 __global__ __launch_bounds__(1024) void gno_fused_kernel(const int32_t *__restrict__ rowptr,
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(1024) void gno_fused_kernel(const int32_t *__restri
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[b][r] = 0.0f;
             float sb[2] = {0.0f, 0.0f};
-            for (int wb = cw0; wb < cw1; wb += 64) {
+            for (int wb = cw0; wb < ((GNO_FV & 1) ? cw0 : cw1); wb += 64) {
                 const int nb = min(64, cw1 - wb);
                 int bj = cj, be = ce;
                 if (wb != cw0) {   // rows longer than 64 entries: later blocks are fetched here
@@ -327,13 +331,23 @@ __global__ __launch_bounds__(1024) void gno_fused_kernel(const int32_t *__restri
             const float *ap = vbase + (size_t)(4 * s_beg + g) * kGF + 4 * n;
             const float *bp = sl + 4 * s_beg;
 #pragma unroll 1
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < ((GNO_FV & 8) ? 0 : 4); ++r) {
                 v4f_g a[UN];
                 float b[UN];
 #pragma unroll
                 for (int u = 0; u < UN; ++u) {
+#if GNO_FV & 2
+                    a[u] = v4f_g{(float)u, (float)r, (float)lane, 1.0f};
+                    asm volatile("" : "+v"(a[u]));
+#else
                     a[u] = *reinterpret_cast<const v4f_g *>(ap + (size_t)u * 4 * kGF);
+#endif
+#if GNO_FV & 4
+                    b[u] = (float)(u + r);
+                    asm volatile("" : "+v"(b[u]));
+#else
                     b[u] = bp[4 * u];
+#endif
                 }
 #pragma unroll
                 for (int u = 0; u < UN; ++u)
@@ -363,7 +377,7 @@ __global__ __launch_bounds__(1024) void gno_fused_kernel(const int32_t *__restri
             const int t = threadIdx.x;                 // 1024 threads = 16 vertices x 64 outputs
             float sum = red[t];
 #pragma unroll
-            for (int w = 1; w < 16; ++w) sum = sum + red[(size_t)w * kGRows * kGF + t];
+            for (int w = 1; w < ((GNO_FV & 16) ? 1 : 16); ++w) sum = sum + red[(size_t)w * kGRows * kGF + t];
             const int v = t >> 6;
             if (r0 + v < n_rows) out[(size_t)perm[r0 + v] * kGF + (t & 63)] = sum;
         }
@@ -395,11 +409,22 @@ int length_order(const int32_t *rowptr_dev, int n_rows, int32_t **perm_dev)
     return 0;
 }
 
+int launch_gno_pc(const int32_t *rowptr, const int32_t *idx, const int32_t *eidx, const float *y, const float *coords,
+                  const float *theta, int d, const float *Vaug, int n_rows, const int32_t *perm, float *out, size_t y_bytes,
+                  size_t c_bytes, size_t id_bytes);
+
 int launch_gno_fused(const int32_t *rowptr, const int32_t *idx, const int32_t *eidx, const float *y,
                      const float *coords, const float *theta, int d, const float *Vaug, int n_rows,
-                     int32_t **perm_cache, float *out)
+                     int32_t **perm_cache, float *out, int y_rows, int n_edge_cols, int64_t nnz)
 {
     if (n_rows > 0 && length_order(rowptr, n_rows, perm_cache)) return 1;
+    static const bool v1 = getenv("ATHENA_MP_GNO_FUSED_V1") != nullptr;   // A/B switch: the one-phase-at-a-time kernel
+    // the producer / consumer kernel addresses its gathers through buffer descriptors (32-bit byte offsets)
+    const size_t y_bytes = sizeof(float) * kGF * (size_t)y_rows, c_bytes = sizeof(float) * (size_t)d * n_edge_cols,
+                 id_bytes = sizeof(int32_t) * (size_t)nnz;
+    const size_t lim = 0xFFFFE000ull;   // below the kernel's dead-slot offset
+    if (d <= 3 && !v1 && y_bytes < lim && c_bytes < lim && id_bytes < lim)
+        return launch_gno_pc(rowptr, idx, eidx, y, coords, theta, d, Vaug, n_rows, *perm_cache, out, y_bytes, c_bytes, id_bytes);
     constexpr size_t lds = sizeof(float) * (size_t)kGRows * kGSP;
     static amp::PerDeviceFlag attr;
     if (!attr.get()) {
@@ -410,6 +435,412 @@ int launch_gno_fused(const int32_t *rowptr, const int32_t *idx, const int32_t *e
     const int n_tiles = (n_rows + kGRows - 1) / kGRows;
     hipLaunchKernelGGL(gno_fused_kernel, dim3(std::min(n_tiles, 256)), dim3(1024), lds, amp::stream(), rowptr, idx,
                        eidx, y, coords, theta, d, Vaug, n_rows, (const int32_t *)*perm_cache, out);
+    AMP_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- producer / consumer form of the fused aggregate (same shapes; d <= 3) -------------------------------------
+// Timing splits of gno_fused_kernel at C4 (GNO_FV builds, profiles/r02_c4_gno_variants.txt): its sparse loop costs
+// 5.2 ms, its contraction 8.1 ms on the matrix pipe alone (+1.8 ms of exposed V loads), the skeleton 2 ms -- and they ADD
+// (17.2 ms), because every wave of the one resident workgroup is in the same phase.  Here the two phases run side by
+// side in one 16-wave workgroup that owns 32 vertices per tile:
+//   waves 0-7   PRODUCERS, four vertices each.  S is built in eight PIECES per tile, piece (c, kh) = hidden units
+//               32 kh .. +31  x  gathered features 16 c .. +15 (512 words per vertex), on 16x16x4 MFMAs only:
+//                 h^T[slot][hid] = [dx_e ; 1] . [U ; b_u]      one MFMA per 16 entries and 16 hidden units (K = d + 1);
+//                                                              relu on its four result registers;
+//                 S[hid][q]     += h[hid][e] x_j[q]            the result registers ARE the A operand: register r of
+//                                                              lane group g is the entry in slot 4g + r, so MFMA step r
+//                                                              contracts entries 4r .. 4r+3 (slot i holds entry
+//                                                              4 (i & 3) + (i >> 2)) and a row of nb entries takes
+//                                                              ceil(nb / 4) steps per 16 hidden units.
+//               Per entry and piece the vector pipe sees one 4-byte load and a share of a shuffle -- the per-lane
+//               h arithmetic of gno_fused_kernel (20 vector instructions per entry and pass) is gone.
+//   waves 8-11  CONSUMERS, one per SIMD, wave = output tile ot of 16: out^T[o, v] += V[kq, o] S[v, kq] for both groups
+//               of 16 vertices per 16-byte V load, so V streams from L2 once per 32 vertices (1.06 MB per tile: half
+//               the L2 traffic per vertex of gno_fused_kernel); S comes from LDS as one ds_read_b128 per four steps
+//               (row pitch 520 words: conflict-free for the lane groups of b128 reads).  V is re-laid once per call in
+//               exactly the order the waves stream it (gno_vrelay_kernel), 1 KB per load instruction.
+// Pieces are double-buffered in LDS (2 x 65 KB) and handed over by ONE workgroup barrier per piece; the bias row
+// (sum of x_j) is a ninth, 64-word piece.  Twelve waves, not sixteen: 168 registers per lane hold a producer's four
+// operand sets without spilling (a spill reload is a vector-memory operation: its wait drains every prefetch).
+constexpr int kPV = 32, kPPitch = 520, kPBPitch = 72;
+constexpr int kPcLdsFloats = 2 * kPV * kPPitch + 2 * kPV * kPBPitch;
+constexpr int kPcThreads = 768;   // 8 producer + 4 consumer waves: three per SIMD, 168 registers each
+constexpr int kVpFloats = 64 * 64 * 64 + 64 * 64 + 1024;   // pieces, bias piece, slack for the look-ahead loads
+
+// Vp[pc][ot][gi][lane][s] = Vin[kq][o]:  o = 16 ot + lane % 16, L = 16 gi + 4 (lane / 16) + s (gi < 32) the position
+// inside the piece as the producers lay it down (row = L / 16 = 16 t + 4 r + g <-> hidden unit 32 kh + 16 t + 4 g + r).
+__global__ void gno_vrelay_kernel(const float *__restrict__ Vin, float *__restrict__ Vp)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= 65 * 64 * 64) return;
+    if (t < 64 * 64 * 64) {
+        const int s = t & 3, lane = (t >> 2) & 63, gi = (t >> 8) & 31, ot = (t >> 13) & 3, pc = t >> 15;
+        const int o = 16 * ot + (lane & 15), g = lane >> 4;
+        const int L = 16 * gi + 4 * g + s;
+        const int row = L >> 4, q = L & 15;
+        const int tp = row >> 4, r = (row >> 2) & 3, gg = row & 3;
+        const int k = 32 * (pc & 1) + 16 * tp + 4 * gg + r;
+        const int qg = 16 * (pc >> 1) + q;
+        Vp[t] = Vin[(size_t)(k * 64 + qg) * 64 + o];
+    } else {
+        const int u = t - 64 * 64 * 64;   // [ot][gi (4)][lane][s]
+        const int s = u & 3, lane = (u >> 2) & 63, gi = (u >> 8) & 3, ot = u >> 10;
+        const int o = 16 * ot + (lane & 15), g = lane >> 4;
+        const int qg = 16 * gi + 4 * g + s;
+        Vp[t] = Vin[(size_t)(64 * 64 + qg) * 64 + o];
+    }
+}
+
+struct GnoIds {   // one tile's rows as a producer wave holds them
+    int J0, J1, E0, E1;                       // first 32 (neighbour, edge column) ids: lane = (vertex lane / 16, entry lane % 16)
+    int row[4], w0[4], len[4];                // wave-uniform
+    bool ok[4];
+};
+struct GnoLoads {   // one vertex's operands for one piece: features of up to 32 entries, coordinates of their slots
+    float x[8], cv0, cv1;
+};
+
+__global__ __launch_bounds__(kPcThreads) void gno_pc_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ idx,
+                                                      const int32_t *__restrict__ eidx, const float *__restrict__ y,
+                                                      const float *__restrict__ coords, const float *__restrict__ theta,
+                                                      int d, const float *__restrict__ Vp, int n_rows,
+                                                      const int32_t *__restrict__ perm, float *__restrict__ out,
+                                                      uint32_t y_bytes, uint32_t c_bytes, uint32_t id_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) float Sh[];
+    float *Sbuf = Sh;                                   // [2][32][520]
+    float *Bbuf = Sh + 2 * kPV * kPPitch;               // [2][32][72]   bias rows, by tile parity
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int n_tiles = (n_rows + kPV - 1) / kPV;
+    const int nt = (n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles of this workgroup (>= 1)
+
+    if (wave < 8) {
+        // ======================================= producer =======================================
+        // Every load below is UNCONDITIONAL (buffer loads; a dead slot's offset lies beyond the buffer and reads 0):
+        // a load inside a branch makes the compiler's wait-count bookkeeping give up and drain the queue at every use
+        // (first version: 42 x s_waitcnt vmcnt(0), producers alone 9.9 ms), which is the latency this kernel exists to hide.
+        const int p = __builtin_amdgcn_readfirstlane(wave);
+        __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void *)y, 0, (int)y_bytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc((void *)coords, 0, (int)c_bytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t jrs = __builtin_amdgcn_make_buffer_rsrc((void *)idx, 0, (int)id_bytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t ers = __builtin_amdgcn_make_buffer_rsrc((void *)eidx, 0, (int)id_bytes, 0x00020000);
+        constexpr uint32_t kDead = 0xFFFFF000u;   // beyond every buffer, and still beyond with a lane's few bytes added
+        // h MFMA per 16 hidden units: A lane (slot n, K index g) = coordinate g of the slot's edge (1 at g = d), B lane
+        // (hid = n, K index g) = U[hid][g] (b_u[hid] at g = d, 0 beyond).  A dead slot's h is relu(b_u): finite, and it
+        // meets x = 0.
+        float Ub[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int hid = 16 * t + n;
+            Ub[t] = g < d ? theta[hid + kGH * g] : (g == d ? theta[(size_t)kGH * d + hid] : 0.0f);
+        }
+        const bool g_is_d = g == d;
+        const int eslot = 4 * (n & 3) + (n >> 2);   // the entry that sits in slot n of a 16-entry block
+        const uint32_t n4 = 4 * n, g4 = 4 * g;
+
+        // a tile's ids arrive in three dependent steps, each issued two pieces after the one it waits for; row numbers and
+        // row pointers are wave-uniform (scalar loads), the entries lane-parallel: lane (vertex g of the four, entry n).
+        // What is kept of an entry is its two BYTE OFFSETS (feature row, coordinate row), kDead for a slot beyond the row
+        // or an entry without an edge column (oracle: e < 0 contributes nothing).
+        auto ids_rows = [&](int tl, GnoIds &I) {
+#pragma unroll
+            for (int vi = 0; vi < 4; ++vi) {
+                const int slot = tl * kPV + 4 * p + vi;
+                I.ok[vi] = tl < n_tiles && slot < n_rows;
+                I.row[vi] = perm[I.ok[vi] ? slot : 0];
+            }
+        };
+        auto ids_ptrs = [&](GnoIds &I) {
+#pragma unroll
+            for (int vi = 0; vi < 4; ++vi) {
+                I.w0[vi] = rowptr[I.row[vi]];
+                I.len[vi] = I.ok[vi] ? rowptr[I.row[vi] + 1] - I.w0[vi] : 0;
+            }
+        };
+        auto ids_entries = [&](GnoIds &I) {
+            const int w0 = g == 0 ? I.w0[0] : g == 1 ? I.w0[1] : g == 2 ? I.w0[2] : I.w0[3];
+            const int len = g == 0 ? I.len[0] : g == 1 ? I.len[1] : g == 2 ? I.len[2] : I.len[3];
+            const uint32_t o0 = n < len ? 4u * (uint32_t)(w0 + n) : kDead, o1 = n + 16 < len ? 4u * (uint32_t)(w0 + n + 16) : kDead;
+            I.J0 = __builtin_amdgcn_raw_buffer_load_b32(jrs, (int)o0, 0, 0);
+            I.E0 = __builtin_amdgcn_raw_buffer_load_b32(ers, (int)o0, 0, 0);
+            I.J1 = __builtin_amdgcn_raw_buffer_load_b32(jrs, (int)o1, 0, 0);
+            I.E1 = __builtin_amdgcn_raw_buffer_load_b32(ers, (int)o1, 0, 0);
+        };
+        auto to_offsets = [&](int &J, int &E, bool inrow) {
+            const bool alive = inrow && E >= 0;
+            J = (int)(alive ? (uint32_t)J * (4u * kGF) : kDead);
+            E = (int)(alive ? (uint32_t)E * (4u * (uint32_t)d) : kDead);
+        };
+        auto ids_finish = [&](GnoIds &I) {
+            const int len = g == 0 ? I.len[0] : g == 1 ? I.len[1] : g == 2 ? I.len[2] : I.len[3];
+            to_offsets(I.J0, I.E0, n < len);
+            to_offsets(I.J1, I.E1, n + 16 < len);
+        };
+        // operand loads of one vertex for the feature quarter c; (J0, E0, J1, E1) hold the offsets of its 32 entries in
+        // lane group srcg.  Per load: one shuffle, one add.
+        auto issue = [&](GnoLoads &L, int J0, int E0, int J1, int E1, int srcg, int c) {
+            const int src = 16 * srcg;
+            const uint32_t es0 = (uint32_t)__shfl(E0, src + eslot) + g4, es1 = (uint32_t)__shfl(E1, src + eslot) + g4;
+            L.cv0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(crs, (int)es0, 0, 0));
+            L.cv1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(crs, (int)es1, 0, 0));
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const uint32_t j = (uint32_t)__shfl(r < 4 ? J0 : J1, src + 4 * (r & 3) + g) + n4;
+                L.x[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, (int)j, 64 * c, 0));
+            }
+        };
+        // one instruction per value, as an INTEGER max (a float with its sign bit set is a negative integer): fmaxf and
+        // fmed3 cost two (they quiet their operand first), and an inline-asm v_max is invisible to the hazard recogniser --
+        // no wait states between the MFMA and the read of its result (wrong rows at C4 size)
+        auto relu4 = [&](v4f_g &h) {
+#pragma unroll
+#if GNO_FV & 128
+            for (int r = 0; r < 4; ++r) h[r] = fmaxf(h[r], 0.0f);
+#else
+            for (int r = 0; r < 4; ++r) {
+                const float t = h[r];   // (__builtin_bit_cast of a vector ELEMENT reads element 0 whatever r is)
+                h[r] = __int_as_float(max(__float_as_int(t), 0));   // v_max_i32
+            }
+#endif
+        };
+        // S piece of one vertex from its operands: acc[t][r2] = S[hid = 16 t + 4 g + r2][q = n], NST groups of four entries.
+        // NST is a compile-time constant: branches around single steps (or a switch that falls through them) make the
+        // compiler copy the accumulators between register sets at every step.
+        auto compute = [&](auto K, const GnoLoads &L, float ub0, float ub1, v4f_g (&acc)[2], float &bs) {
+            constexpr int NST = decltype(K)::value;
+            const v4f_g z = {0.0f, 0.0f, 0.0f, 0.0f};
+            {
+                const float cv = g_is_d ? 1.0f : L.cv0;
+                v4f_g h0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cv, ub0, z, 0, 0, 0);
+                v4f_g h1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cv, ub1, z, 0, 0, 0);
+                relu4(h0);
+                relu4(h1);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(h0[0], L.x[0], z, 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(h1[0], L.x[0], z, 0, 0, 0);
+#pragma unroll
+                for (int r = 1; r < (NST < 4 ? NST : 4); ++r) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(h0[r], L.x[r], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(h1[r], L.x[r], acc[1], 0, 0, 0);
+                }
+                bs = (L.x[0] + L.x[1]) + (L.x[2] + L.x[3]);
+            }
+            if constexpr (NST > 4) {
+                const float cv = g_is_d ? 1.0f : L.cv1;
+                v4f_g h0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cv, ub0, z, 0, 0, 0);
+                v4f_g h1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cv, ub1, z, 0, 0, 0);
+                relu4(h0);
+                relu4(h1);
+#pragma unroll
+                for (int r = 0; r < NST - 4; ++r) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(h0[r], L.x[4 + r], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(h1[r], L.x[4 + r], acc[1], 0, 0, 0);
+                }
+                bs = bs + ((L.x[4] + L.x[5]) + (L.x[6] + L.x[7]));
+            }
+        };
+
+        GnoIds cur, nxt;
+        ids_rows(blockIdx.x, cur);
+        ids_ptrs(cur);
+        ids_entries(cur);
+        ids_finish(cur);
+        nxt = cur;
+        int pJ0 = cur.J0, pE0 = cur.E0, pJ1 = cur.J1, pE1 = cur.E1;   // the offsets the refills read: this tile's, from a tile's
+                                                                     // last piece on the next tile's
+        GnoLoads LS[4];   // one set per vertex: refilled for the NEXT piece right after this piece's MFMAs have read it,
+                          // so a load has a whole piece interval to land
+#pragma unroll
+        for (int vi = 0; vi < 4; ++vi) issue(LS[vi], pJ0, pE0, pJ1, pE1, vi, 0);
+        for (int ti = 0; ti < nt; ++ti) {
+            const int tile = blockIdx.x + ti * gridDim.x;
+            const bool more = ti + 1 < nt;
+            const int maxlen = max(max(cur.len[0], cur.len[1]), max(cur.len[2], cur.len[3]));
+            const int nstT = (GNO_FV & 256) ? 8 : min(8, (maxlen + 3) >> 2);
+#pragma unroll 1
+            for (int pc = 0; pc < 8; ++pc) {
+                const int c = pc >> 1, kh = pc & 1;
+                float *buf = Sbuf + (size_t)((ti * 8 + pc) & 1) * kPV * kPPitch;
+                float *bb = Bbuf + (size_t)(ti & 1) * kPV * kPBPitch;
+                const float ub0 = kh ? Ub[2] : Ub[0], ub1 = kh ? Ub[3] : Ub[1];
+                // the next tile's ids, one dependent step at a time
+                if (more) {
+                    if (pc == 0) ids_rows(tile + gridDim.x, nxt);
+                    if (pc == 2) ids_ptrs(nxt);
+                    if (pc == 4) ids_entries(nxt);
+                    if (pc == 6) ids_finish(nxt);
+                }
+                // the refill is unconditional: from a tile's last piece on it reads the next tile's rows (the last tile of
+                // all re-reads its own: harmless, nothing consumes them)
+                const int cn = ((pc + 1) & 7) >> 1;                       // feature quarter of the next piece
+                const bool last = pc == 7;
+                if (last) { pJ0 = nxt.J0; pE0 = nxt.E0; pJ1 = nxt.J1; pE1 = nxt.E1; }
+                // the four vertices of the wave with the step count of the longest of them as a compile-time constant
+                // (tiles hold vertices of nearly equal length, so the shorter rows' extra steps -- on zeros -- are few)
+                auto four = [&](auto K) {
+#pragma unroll
+                    for (int vi = 0; vi < ((GNO_FV & 32) ? 0 : 4); ++vi) {
+                        v4f_g acc[2];
+                        float bs;
+                        compute(K, LS[vi], ub0, ub1, acc, bs);
+                        issue(LS[vi], pJ0, pE0, pJ1, pE1, vi, cn);
+                        __builtin_amdgcn_sched_barrier(0);
+                        const int v = 4 * p + vi;
+                        float *srow = buf + (size_t)v * kPPitch;
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+#pragma unroll
+                            for (int r2 = 0; r2 < 4; ++r2) srow[(16 * t + 4 * r2 + g) * 16 + n] = acc[t][r2];
+                        if (kh == 0) {
+                            bs = bs + __shfl_xor(bs, 16);
+                            bs = bs + __shfl_xor(bs, 32);
+                            if (g == 0) bb[v * kPBPitch + 16 * c + n] = bs;
+                        }
+                    }
+                };
+                switch (nstT) {
+                case 0:
+                case 1: four(std::integral_constant<int, 1>{}); break;
+                case 2: four(std::integral_constant<int, 2>{}); break;
+                case 3: four(std::integral_constant<int, 3>{}); break;
+                case 4: four(std::integral_constant<int, 4>{}); break;
+                case 5: four(std::integral_constant<int, 5>{}); break;
+                case 6: four(std::integral_constant<int, 6>{}); break;
+                case 7: four(std::integral_constant<int, 7>{}); break;
+                default: four(std::integral_constant<int, 8>{}); break;
+                }
+                // rows longer than 32 entries (none at BASELINE configs[3]): the remaining blocks are added to the vertex's
+                // own LDS row; plain loads, nothing prefetched
+                if (maxlen > 32) {
+#pragma unroll 1
+                    for (int vi = 0; vi < 4; ++vi) {
+                        const int len = vi == 0 ? cur.len[0] : vi == 1 ? cur.len[1] : vi == 2 ? cur.len[2] : cur.len[3];
+                        const int w0 = vi == 0 ? cur.w0[0] : vi == 1 ? cur.w0[1] : vi == 2 ? cur.w0[2] : cur.w0[3];
+                        const int v = 4 * p + vi;
+                        float *srow = buf + (size_t)v * kPPitch;
+                        for (int e0 = 32; e0 < len; e0 += 32) {
+                            int J0 = 0, E0 = -1, J1 = 0, E1 = -1;
+                            if (e0 + n < len) { J0 = idx[w0 + e0 + n]; E0 = eidx[w0 + e0 + n]; }
+                            if (e0 + 16 + n < len) { J1 = idx[w0 + e0 + 16 + n]; E1 = eidx[w0 + e0 + 16 + n]; }
+                            to_offsets(J0, E0, true);
+                            to_offsets(J1, E1, true);
+                            GnoLoads Lx;
+                            issue(Lx, J0, E0, J1, E1, g, c);   // every lane group holds the same 32 entries
+                            v4f_g acc[2];
+                            float bs;
+                            compute(std::integral_constant<int, 8>{}, Lx, ub0, ub1, acc, bs);
+#pragma unroll
+                            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                                for (int r2 = 0; r2 < 4; ++r2) srow[(16 * t + 4 * r2 + g) * 16 + n] += acc[t][r2];
+                            if (kh == 0) {
+                                bs = bs + __shfl_xor(bs, 16);
+                                bs = bs + __shfl_xor(bs, 32);
+                                if (g == 0) bb[v * kPBPitch + 16 * c + n] += bs;
+                            }
+                        }
+                    }
+                }
+                if (last) cur = nxt;
+                __syncthreads();
+            }
+        }
+        __syncthreads();   // the consumers' last piece
+    } else {
+        // ======================================= consumer =======================================
+        // wave = output tile ot (16 outputs) over the whole K of a piece, both groups of 16 vertices: one wave per SIMD
+        // issues the contraction's MFMAs back to back (two independent accumulators), nothing to add across waves
+        const int ot = wave - 8;
+        const v4f_g z = {0.0f, 0.0f, 0.0f, 0.0f};
+        v4f_g acc0 = z, acc1 = z;
+        // this wave's stream of V: [pc][ot][gi][lane][4]; the bias piece behind the eight pieces
+        const float *vw = Vp + ((size_t)ot * 32) * 256 + lane * 4;
+        const float *vbias = Vp + 64 * 64 * 64 + ((size_t)ot * 4) * 256 + lane * 4;
+        auto vload = [&](const float *p) { return *reinterpret_cast<const v4f_g *>(p); };
+        constexpr int kPiece = 4 * 32 * 256;   // words of V per piece
+        v4f_g a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = vload(vw + (size_t)u * 256);
+        __syncthreads();
+        for (int ti = 0; ti < nt; ++ti) {
+            const int tile = blockIdx.x + ti * gridDim.x;
+            const int sa = tile * kPV + n, sb = sa + 16;
+            const int ra = perm[min(sa, n_rows - 1)], rb = perm[min(sb, n_rows - 1)];   // unconditional loads (see above)
+            acc0 = acc1 = z;
+#pragma unroll 1
+            for (int pc = 0; pc < 8; ++pc) {
+                const float *sb0 = Sbuf + (size_t)((ti * 8 + pc) & 1) * kPV * kPPitch + (size_t)n * kPPitch + 4 * g;
+                const float *sb1 = sb0 + 16 * kPPitch;
+                const float *vp = vw + (size_t)pc * kPiece;
+                const float *vnext = pc < 7 ? vp + kPiece : vbias;   // the piece after this one
+#pragma unroll
+                for (int rd = 0; rd < ((GNO_FV & 64) ? 0 : 8); ++rd) {
+                    v4f_g b0[4], b1[4], an[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        b0[u] = *reinterpret_cast<const v4f_g *>(sb0 + 16 * (4 * rd + u));
+                        b1[u] = *reinterpret_cast<const v4f_g *>(sb1 + 16 * (4 * rd + u));
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        an[u] = vload(rd < 7 ? vp + (size_t)(4 * (rd + 1) + u) * 256 : vnext + (size_t)u * 256);
+                    __builtin_amdgcn_sched_barrier(0);   // the scheduler otherwise sinks these loads to just before their use
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][s], b0[u][s], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][s], b1[u][s], acc1, 0, 0, 0);
+                        }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) a[u] = an[u];
+                }
+                if (pc == 7) {
+                    // the bias piece: 64 words = four groups of 16; a[0..3] hold its V rows
+                    const float *bb0 = Bbuf + (size_t)(ti & 1) * kPV * kPBPitch + (size_t)n * kPBPitch + 4 * g;
+                    const float *bb1 = bb0 + 16 * kPBPitch;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const v4f_g b0 = *reinterpret_cast<const v4f_g *>(bb0 + 16 * u);
+                        const v4f_g b1 = *reinterpret_cast<const v4f_g *>(bb1 + 16 * u);
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][s], b0[s], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][s], b1[s], acc1, 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) a[u] = vload(vw + (size_t)u * 256);   // first round of the next tile
+                    // lane (vertex n of its group, g): acc[r] = out[vertex][16 ot + 4 g + r]
+                    if (sa < n_rows) *reinterpret_cast<v4f_g *>(out + (size_t)ra * kGF + 16 * ot + 4 * g) = acc0;
+                    if (sb < n_rows) *reinterpret_cast<v4f_g *>(out + (size_t)rb * kGF + 16 * ot + 4 * g) = acc1;
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
+int launch_gno_pc(const int32_t *rowptr, const int32_t *idx, const int32_t *eidx, const float *y, const float *coords,
+                  const float *theta, int d, const float *Vaug, int n_rows, const int32_t *perm, float *out, size_t y_bytes,
+                  size_t c_bytes, size_t id_bytes)
+{
+    constexpr size_t lds = sizeof(float) * (size_t)kPcLdsFloats;
+    static amp::PerDeviceFlag attr;
+    if (!attr.get()) {
+        AMP_HIP(hipFuncSetAttribute((const void *)gno_pc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr.get() = true;
+    }
+    if (n_rows <= 0) return 0;
+    void *vp = nullptr;
+    if (amp::workspace(&vp, sizeof(float) * kVpFloats, 9)) return 1;
+    hipLaunchKernelGGL(gno_vrelay_kernel, dim3((65 * 64 * 64 + 255) / 256), dim3(256), 0, amp::stream(), Vaug, (float *)vp);
+    AMP_LAUNCH_CHECK();
+    const int n_tiles = (n_rows + kPV - 1) / kPV;
+    hipLaunchKernelGGL(gno_pc_kernel, dim3(std::min(n_tiles, amp::num_cus())), dim3(kPcThreads), lds, amp::stream(), rowptr, idx,
+                       eidx, y, coords, theta, d, (const float *)vp, n_rows, perm, out, (uint32_t)y_bytes, (uint32_t)c_bytes,
+                       (uint32_t)id_bytes);
     AMP_LAUNCH_CHECK();
     return 0;
 }
@@ -1011,7 +1442,8 @@ int athena_mp_gno_aggregate_fwd(const athena_mp_graph *g, int32_t d, int32_t H, 
     const size_t off_V = (size_t)H * d + H;
     const int R = (H + 1) * Fi;
     if (gno_fused_shape(H, Fi, Fo, d))
-        return launch_gno_fused(g->rowptr, g->col, g->eid, x, coords, theta, d, theta + off_V, g->n_rows, &g->len_perm_fwd, m);
+        return launch_gno_fused(g->rowptr, g->col, g->eid, x, coords, theta, d, theta + off_V, g->n_rows, &g->len_perm_fwd, m,
+                                g->n_cols, g->n_edge_cols, g->nnz);
     const int tile = tile_rows_for(g->n_rows, R);
     for (int r0 = 0; r0 < g->n_rows; r0 += tile) {
         const int rows = std::min(tile, g->n_rows - r0);
@@ -1043,7 +1475,8 @@ int athena_mp_gno_aggregate_bwd_x(const athena_mp_graph *g, int32_t d, int32_t H
         AMP_LAUNCH_CHECK();
     }
     if (gno_fused_shape(H, Fo, Fi, d))
-        return launch_gno_fused(g->t_rowptr, g->t_src, g->t_eid, grad, coords, theta, d, (const float *)b2, g->n_cols, &g->len_perm_bwd, dx);
+        return launch_gno_fused(g->t_rowptr, g->t_src, g->t_eid, grad, coords, theta, d, (const float *)b2, g->n_cols,
+                                &g->len_perm_bwd, dx, g->n_rows, g->n_edge_cols, g->nnz);
     const int tile = tile_rows_for(g->n_cols, R2);
     for (int r0 = 0; r0 < g->n_cols; r0 += tile) {
         const int rows = std::min(tile, g->n_cols - r0);

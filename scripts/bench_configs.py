@@ -20,6 +20,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="c3")
 ap.add_argument("--scale", type=float, default=1.0)
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--only", default="", help="c4: time only this leg (fwd | bwd_x | bwd_theta)")
 ap.add_argument("--no-cpu", action="store_true", help="skip the CPU oracle leg (for rocprofv3 runs)")
 a = ap.parse_args()
 _capi.init(0)
@@ -98,9 +99,12 @@ else:
     theta = T((0.3 * rng.standard_normal(H * d + H + Fo * Fi * H + Fo * Fi)).astype(np.float32))
     gup = T(rng.uniform(-1, 1, (N, Fo)).astype(np.float32))
     t = {}
-    t["fwd"] = timeit(lambda: ops.gno_aggregate(g, theta, co, x, d, H, Fo), a.reps)
-    t["bwd_x"] = timeit(lambda: ops.gno_aggregate_bwd_x(g, theta, co, gup, d, H, Fi), a.reps)
-    t["bwd_theta"] = timeit(lambda: ops.gno_aggregate_bwd_theta(g, theta, co, x, gup, d, H), a.reps)
+    legs = {"fwd": lambda: ops.gno_aggregate(g, theta, co, x, d, H, Fo),
+            "bwd_x": lambda: ops.gno_aggregate_bwd_x(g, theta, co, gup, d, H, Fi),
+            "bwd_theta": lambda: ops.gno_aggregate_bwd_theta(g, theta, co, x, gup, d, H)}
+    if a.only:
+        print(json.dumps({"only": a.only, "lib": os.environ.get("ATHENA_MP_LIB", ""), "ms": round(timeit(legs[a.only], a.reps), 3)})); sys.exit(0)
+    for k, fn in legs.items(): t[k] = timeit(fn, a.reps)
     tot = sum(t.values())
     R = (H + 1) * Fi
     # re-associated algorithm, fused (S stays on chip): the contraction N*2*Fo*(H+1)*Fi bounds it on the fp32 matrix pipe
