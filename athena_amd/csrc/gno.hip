@@ -497,8 +497,8 @@ struct GnoIds {   // one tile's rows as a producer wave holds them
     int row[4], w0[4], len[4];                // wave-uniform
     bool ok[4];
 };
-struct GnoLoads {   // one vertex's operands for one piece: features of up to 32 entries, coordinates of their slots
-    float x[8], cv0, cv1;
+struct GnoLoads {   // one vertex's operands for one piece: features of up to 32 entries
+    float x[8];
 };
 
 __global__ __launch_bounds__(kPcThreads) void gno_pc_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ idx,
@@ -522,6 +522,7 @@ __global__ __launch_bounds__(kPcThreads) void gno_pc_kernel(const int32_t *__res
         // a load inside a branch makes the compiler's wait-count bookkeeping give up and drain the queue at every use
         // (first version: 42 x s_waitcnt vmcnt(0), producers alone 9.9 ms), which is the latency this kernel exists to hide.
         const int p = __builtin_amdgcn_readfirstlane(wave);
+        __builtin_amdgcn_s_setprio(3);   // the producers' instructions first (worth 1 %)
         __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void *)y, 0, (int)y_bytes, 0x00020000);
         __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc((void *)coords, 0, (int)c_bytes, 0x00020000);
         __amdgpu_buffer_rsrc_t jrs = __builtin_amdgcn_make_buffer_rsrc((void *)idx, 0, (int)id_bytes, 0x00020000);
@@ -580,39 +581,46 @@ __global__ __launch_bounds__(kPcThreads) void gno_pc_kernel(const int32_t *__res
         };
         // operand loads of one vertex for the feature quarter c; (J0, E0, J1, E1) hold the offsets of its 32 entries in
         // lane group srcg.  Per load: one shuffle, one add.
-        auto issue = [&](GnoLoads &L, int J0, int E0, int J1, int E1, int srcg, int c) {
+        auto issue = [&](GnoLoads &L, int J0, int J1, int srcg, int c, bool second) {
             const int src = 16 * srcg;
-            const uint32_t es0 = (uint32_t)__shfl(E0, src + eslot) + g4, es1 = (uint32_t)__shfl(E1, src + eslot) + g4;
-            L.cv0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(crs, (int)es0, 0, 0));
-            L.cv1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(crs, (int)es1, 0, 0));
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const uint32_t j = (uint32_t)__shfl(r < 4 ? J0 : J1, src + 4 * (r & 3) + g) + n4;
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t j = (uint32_t)__shfl(J0, src + 4 * r + g) + n4;
                 L.x[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, (int)j, 64 * c, 0));
             }
+            if (second) {   // entries 16 .. 31: only tiles whose rows are that long ask for them
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t j = (uint32_t)__shfl(J1, src + 4 * r + g) + n4;
+                    L.x[4 + r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, (int)j, 64 * c, 0));
+                }
+            }
+        };
+        // the edge coordinates of a vertex's 32 slots do not depend on the piece: loaded once per tile
+        auto load_cv = [&](float (&cv)[2], int E0, int E1, int srcg) {
+            const int src = 16 * srcg;
+            const uint32_t es0 = (uint32_t)__shfl(E0, src + eslot) + g4, es1 = (uint32_t)__shfl(E1, src + eslot) + g4;
+            cv[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(crs, (int)es0, 0, 0));
+            cv[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(crs, (int)es1, 0, 0));
         };
         // one instruction per value, as an INTEGER max (a float with its sign bit set is a negative integer): fmaxf and
         // fmed3 cost two (they quiet their operand first), and an inline-asm v_max is invisible to the hazard recogniser --
         // no wait states between the MFMA and the read of its result (wrong rows at C4 size)
         auto relu4 = [&](v4f_g &h) {
 #pragma unroll
-#if GNO_FV & 128
-            for (int r = 0; r < 4; ++r) h[r] = fmaxf(h[r], 0.0f);
-#else
             for (int r = 0; r < 4; ++r) {
                 const float t = h[r];   // (__builtin_bit_cast of a vector ELEMENT reads element 0 whatever r is)
                 h[r] = __int_as_float(max(__float_as_int(t), 0));   // v_max_i32
             }
-#endif
         };
         // S piece of one vertex from its operands: acc[t][r2] = S[hid = 16 t + 4 g + r2][q = n], NST groups of four entries.
         // NST is a compile-time constant: branches around single steps (or a switch that falls through them) make the
         // compiler copy the accumulators between register sets at every step.
-        auto compute = [&](auto K, const GnoLoads &L, float ub0, float ub1, v4f_g (&acc)[2], float &bs) {
+        auto compute = [&](auto K, const GnoLoads &L, const float (&cvs)[2], float ub0, float ub1, v4f_g (&acc)[2], float &bs) {
             constexpr int NST = decltype(K)::value;
             const v4f_g z = {0.0f, 0.0f, 0.0f, 0.0f};
             {
-                const float cv = g_is_d ? 1.0f : L.cv0;
+                const float cv = g_is_d ? 1.0f : cvs[0];
                 v4f_g h0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cv, ub0, z, 0, 0, 0);
                 v4f_g h1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cv, ub1, z, 0, 0, 0);
                 relu4(h0);
@@ -627,7 +635,7 @@ __global__ __launch_bounds__(kPcThreads) void gno_pc_kernel(const int32_t *__res
                 bs = (L.x[0] + L.x[1]) + (L.x[2] + L.x[3]);
             }
             if constexpr (NST > 4) {
-                const float cv = g_is_d ? 1.0f : L.cv1;
+                const float cv = g_is_d ? 1.0f : cvs[1];
                 v4f_g h0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cv, ub0, z, 0, 0, 0);
                 v4f_g h1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cv, ub1, z, 0, 0, 0);
                 relu4(h0);
@@ -647,17 +655,21 @@ __global__ __launch_bounds__(kPcThreads) void gno_pc_kernel(const int32_t *__res
         ids_entries(cur);
         ids_finish(cur);
         nxt = cur;
-        int pJ0 = cur.J0, pE0 = cur.E0, pJ1 = cur.J1, pE1 = cur.E1;   // the offsets the refills read: this tile's, from a tile's
+        int pJ0 = cur.J0, pJ1 = cur.J1;                                  // the offsets the refills read: this tile's, from a tile's
                                                                      // last piece on the next tile's
         GnoLoads LS[4];   // one set per vertex: refilled for the NEXT piece right after this piece's MFMAs have read it,
                           // so a load has a whole piece interval to land
 #pragma unroll
-        for (int vi = 0; vi < 4; ++vi) issue(LS[vi], pJ0, pE0, pJ1, pE1, vi, 0);
+        for (int vi = 0; vi < 4; ++vi) issue(LS[vi], pJ0, pJ1, vi, 0, true);
+        float CV[4][2];   // coordinates of the tile's slots; refilled for the next tile after the last piece has read them
+#pragma unroll
+        for (int vi = 0; vi < 4; ++vi) load_cv(CV[vi], cur.E0, cur.E1, vi);
         for (int ti = 0; ti < nt; ++ti) {
             const int tile = blockIdx.x + ti * gridDim.x;
             const bool more = ti + 1 < nt;
             const int maxlen = max(max(cur.len[0], cur.len[1]), max(cur.len[2], cur.len[3]));
-            const int nstT = (GNO_FV & 256) ? 8 : min(8, (maxlen + 3) >> 2);
+            const int nstT = min(8, (maxlen + 3) >> 2);
+            int nstN = nstT;   // the next tile's (known from its third piece on; its rows are not longer than this tile's)
 #pragma unroll 1
             for (int pc = 0; pc < 8; ++pc) {
                 const int c = pc >> 1, kh = pc & 1;
@@ -667,7 +679,10 @@ __global__ __launch_bounds__(kPcThreads) void gno_pc_kernel(const int32_t *__res
                 // the next tile's ids, one dependent step at a time
                 if (more) {
                     if (pc == 0) ids_rows(tile + gridDim.x, nxt);
-                    if (pc == 2) ids_ptrs(nxt);
+                    if (pc == 2) {
+                        ids_ptrs(nxt);
+                        nstN = min(8, (max(max(nxt.len[0], nxt.len[1]), max(nxt.len[2], nxt.len[3])) + 3) >> 2);
+                    }
                     if (pc == 4) ids_entries(nxt);
                     if (pc == 6) ids_finish(nxt);
                 }
@@ -675,7 +690,8 @@ __global__ __launch_bounds__(kPcThreads) void gno_pc_kernel(const int32_t *__res
                 // all re-reads its own: harmless, nothing consumes them)
                 const int cn = ((pc + 1) & 7) >> 1;                       // feature quarter of the next piece
                 const bool last = pc == 7;
-                if (last) { pJ0 = nxt.J0; pE0 = nxt.E0; pJ1 = nxt.J1; pE1 = nxt.E1; }
+                if (last) { pJ0 = nxt.J0; pJ1 = nxt.J1; }
+                const bool second = (last ? nstN : nstT) > 4;   // does the piece being requested read entries 16 .. 31
                 // the four vertices of the wave with the step count of the longest of them as a compile-time constant
                 // (tiles hold vertices of nearly equal length, so the shorter rows' extra steps -- on zeros -- are few)
                 auto four = [&](auto K) {
@@ -683,9 +699,9 @@ __global__ __launch_bounds__(kPcThreads) void gno_pc_kernel(const int32_t *__res
                     for (int vi = 0; vi < ((GNO_FV & 32) ? 0 : 4); ++vi) {
                         v4f_g acc[2];
                         float bs;
-                        compute(K, LS[vi], ub0, ub1, acc, bs);
-                        issue(LS[vi], pJ0, pE0, pJ1, pE1, vi, cn);
-                        __builtin_amdgcn_sched_barrier(0);
+                        compute(K, LS[vi], CV[vi], ub0, ub1, acc, bs);
+                        issue(LS[vi], pJ0, pJ1, vi, cn, second);
+                        if (last) load_cv(CV[vi], nxt.E0, nxt.E1, vi);
                         const int v = 4 * p + vi;
                         float *srow = buf + (size_t)v * kPPitch;
 #pragma unroll
@@ -726,10 +742,12 @@ __global__ __launch_bounds__(kPcThreads) void gno_pc_kernel(const int32_t *__res
                             to_offsets(J0, E0, true);
                             to_offsets(J1, E1, true);
                             GnoLoads Lx;
-                            issue(Lx, J0, E0, J1, E1, g, c);   // every lane group holds the same 32 entries
+                            float cvx[2];
+                            issue(Lx, J0, J1, g, c, true);   // every lane group holds the same 32 entries
+                            load_cv(cvx, E0, E1, g);
                             v4f_g acc[2];
                             float bs;
-                            compute(std::integral_constant<int, 8>{}, Lx, ub0, ub1, acc, bs);
+                            compute(std::integral_constant<int, 8>{}, Lx, cvx, ub0, ub1, acc, bs);
 #pragma unroll
                             for (int t = 0; t < 2; ++t)
 #pragma unroll
