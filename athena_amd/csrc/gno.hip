@@ -501,6 +501,177 @@ struct GnoLoads {   // one vertex's operands for one piece: features of up to 32
     float x[8];
 };
 
+// What a producer wave of the fused GNO kernels knows and does (gno_pc_kernel: aggregate / dx; gno_stg_kernel: S^T g).
+// Every gather below is UNCONDITIONAL (buffer loads; a dead slot's offset lies beyond the buffer and reads 0): a load
+// inside a branch makes the compiler's wait-count bookkeeping give up and drain the queue at every use (first version:
+// 42 x s_waitcnt vmcnt(0), producers alone 9.9 ms), which is the latency these kernels exist to hide.
+struct GnoProd {
+    static constexpr uint32_t kDead = 0xFFFFF000u;   // beyond every buffer, and still beyond with a lane's few bytes added
+    int lane, n, g, p, d, n_rows, n_tiles;
+    const int32_t *perm, *rowptr, *idx, *eidx;
+    __amdgpu_buffer_rsrc_t yrs, crs, jrs, ers;
+    // h MFMA per 16 hidden units: A lane (slot n, K index g) = coordinate g of the slot's edge (1 at g = d), B lane
+    // (hid = n, K index g) = U[hid][g] (b_u[hid] at g = d, 0 beyond).  A dead slot's h is relu(b_u): finite, and it
+    // meets x = 0.
+    float Ub[4];
+    bool g_is_d;
+    int eslot;            // the entry that sits in slot n of a 16-entry block
+    uint32_t n4, g4;
+
+    __device__ __forceinline__ void init(int wave, int lane_, const int32_t *rowptr_, const int32_t *idx_, const int32_t *eidx_,
+                                         const float *y, const float *coords, const float *theta, int d_, int n_rows_,
+                                         const int32_t *perm_, uint32_t y_bytes, uint32_t c_bytes, uint32_t id_bytes)
+    {
+        lane = lane_; n = lane & 15; g = lane >> 4; d = d_; n_rows = n_rows_; n_tiles = (n_rows + kPV - 1) / kPV;
+        perm = perm_; rowptr = rowptr_; idx = idx_; eidx = eidx_;
+        p = __builtin_amdgcn_readfirstlane(wave);
+        yrs = __builtin_amdgcn_make_buffer_rsrc((void *)y, 0, (int)y_bytes, 0x00020000);
+        crs = __builtin_amdgcn_make_buffer_rsrc((void *)coords, 0, (int)c_bytes, 0x00020000);
+        jrs = __builtin_amdgcn_make_buffer_rsrc((void *)idx, 0, (int)id_bytes, 0x00020000);
+        ers = __builtin_amdgcn_make_buffer_rsrc((void *)eidx, 0, (int)id_bytes, 0x00020000);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int hid = 16 * t + n;
+            Ub[t] = g < d ? theta[hid + kGH * g] : (g == d ? theta[(size_t)kGH * d + hid] : 0.0f);
+        }
+        g_is_d = g == d;
+        eslot = 4 * (n & 3) + (n >> 2);
+        n4 = 4 * n; g4 = 4 * g;
+    }
+    // a tile's ids arrive in three dependent steps; row numbers and row pointers are wave-uniform (scalar loads), the
+    // entries lane-parallel: lane (vertex g of the four, entry n).  What is kept of an entry is its two BYTE OFFSETS
+    // (feature row, coordinate row), kDead for a slot beyond the row or an entry without an edge column (oracle: e < 0
+    // contributes nothing).
+    __device__ __forceinline__ void ids_rows(int tl, GnoIds &I) const
+    {
+#pragma unroll
+        for (int vi = 0; vi < 4; ++vi) {
+            const int slot = tl * kPV + 4 * p + vi;
+            I.ok[vi] = tl < n_tiles && slot < n_rows;
+            I.row[vi] = perm[I.ok[vi] ? slot : 0];
+        }
+    }
+    __device__ __forceinline__ void ids_ptrs(GnoIds &I) const
+    {
+#pragma unroll
+        for (int vi = 0; vi < 4; ++vi) {
+            I.w0[vi] = rowptr[I.row[vi]];
+            I.len[vi] = I.ok[vi] ? rowptr[I.row[vi] + 1] - I.w0[vi] : 0;
+        }
+    }
+    __device__ __forceinline__ void ids_entries(GnoIds &I) const
+    {
+        const int w0 = g == 0 ? I.w0[0] : g == 1 ? I.w0[1] : g == 2 ? I.w0[2] : I.w0[3];
+        const int len = g == 0 ? I.len[0] : g == 1 ? I.len[1] : g == 2 ? I.len[2] : I.len[3];
+        const uint32_t o0 = n < len ? 4u * (uint32_t)(w0 + n) : kDead, o1 = n + 16 < len ? 4u * (uint32_t)(w0 + n + 16) : kDead;
+        I.J0 = __builtin_amdgcn_raw_buffer_load_b32(jrs, (int)o0, 0, 0);
+        I.E0 = __builtin_amdgcn_raw_buffer_load_b32(ers, (int)o0, 0, 0);
+        I.J1 = __builtin_amdgcn_raw_buffer_load_b32(jrs, (int)o1, 0, 0);
+        I.E1 = __builtin_amdgcn_raw_buffer_load_b32(ers, (int)o1, 0, 0);
+    }
+    __device__ __forceinline__ void to_offsets(int &J, int &E, bool inrow) const
+    {
+        const bool alive = inrow && E >= 0;
+        J = (int)(alive ? (uint32_t)J * (4u * kGF) : kDead);
+        E = (int)(alive ? (uint32_t)E * (4u * (uint32_t)d) : kDead);
+    }
+    __device__ __forceinline__ void ids_finish(GnoIds &I) const
+    {
+        const int len = g == 0 ? I.len[0] : g == 1 ? I.len[1] : g == 2 ? I.len[2] : I.len[3];
+        to_offsets(I.J0, I.E0, n < len);
+        to_offsets(I.J1, I.E1, n + 16 < len);
+    }
+    // operand loads of one vertex for the feature quarter c; (J0, J1) hold the offsets of its 32 entries in lane group
+    // srcg.  Per load: one shuffle, one add.
+    __device__ __forceinline__ void issue(GnoLoads &L, int J0, int J1, int srcg, int c, bool second) const
+    {
+        const int src = 16 * srcg;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t j = (uint32_t)__shfl(J0, src + 4 * r + g) + n4;
+            L.x[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, (int)j, 64 * c, 0));
+        }
+        if (second) {   // entries 16 .. 31: only tiles whose rows are that long ask for them
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t j = (uint32_t)__shfl(J1, src + 4 * r + g) + n4;
+                L.x[4 + r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, (int)j, 64 * c, 0));
+            }
+        }
+    }
+    // the edge coordinates of a vertex's 32 slots (they do not depend on the piece)
+    __device__ __forceinline__ void load_cv(float (&cv)[2], int E0, int E1, int srcg) const
+    {
+        const int src = 16 * srcg;
+        const uint32_t es0 = (uint32_t)__shfl(E0, src + eslot) + g4, es1 = (uint32_t)__shfl(E1, src + eslot) + g4;
+        cv[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(crs, (int)es0, 0, 0));
+        cv[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(crs, (int)es1, 0, 0));
+    }
+    // one instruction per value, as an INTEGER max (a float with its sign bit set is a negative integer): fmaxf and
+    // fmed3 cost two (they quiet their operand first), and an inline-asm v_max is invisible to the hazard recogniser --
+    // no wait states between the MFMA and the read of its result (wrong rows at C4 size)
+    static __device__ __forceinline__ void relu4(v4f_g &h)
+    {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float t = h[r];   // (__builtin_bit_cast of a vector ELEMENT reads element 0 whatever r is)
+            h[r] = __int_as_float(max(__float_as_int(t), 0));   // v_max_i32
+        }
+    }
+    // S piece of one vertex from its operands: acc[t][r2] = S[hid = 16 t + 4 g + r2][q = n], NST groups of four entries.
+    // NST is a compile-time constant: branches around single steps (or a switch that falls through them) make the
+    // compiler copy the accumulators between register sets at every step.
+    template <int NST>
+    __device__ __forceinline__ void compute(const GnoLoads &L, const float (&cvs)[2], float ub0, float ub1, v4f_g (&acc)[2],
+                                            float &bs) const
+    {
+        const v4f_g z = {0.0f, 0.0f, 0.0f, 0.0f};
+        {
+            const float cv = g_is_d ? 1.0f : cvs[0];
+            v4f_g h0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cv, ub0, z, 0, 0, 0);
+            v4f_g h1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cv, ub1, z, 0, 0, 0);
+            relu4(h0);
+            relu4(h1);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(h0[0], L.x[0], z, 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(h1[0], L.x[0], z, 0, 0, 0);
+#pragma unroll
+            for (int r = 1; r < (NST < 4 ? NST : 4); ++r) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(h0[r], L.x[r], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(h1[r], L.x[r], acc[1], 0, 0, 0);
+            }
+            bs = (L.x[0] + L.x[1]) + (L.x[2] + L.x[3]);
+        }
+        if constexpr (NST > 4) {
+            const float cv = g_is_d ? 1.0f : cvs[1];
+            v4f_g h0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cv, ub0, z, 0, 0, 0);
+            v4f_g h1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cv, ub1, z, 0, 0, 0);
+            relu4(h0);
+            relu4(h1);
+#pragma unroll
+            for (int r = 0; r < NST - 4; ++r) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(h0[r], L.x[4 + r], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(h1[r], L.x[4 + r], acc[1], 0, 0, 0);
+            }
+            bs = bs + ((L.x[4] + L.x[5]) + (L.x[6] + L.x[7]));
+        }
+    }
+    // rows longer than 32 entries: one further block of 32 (entries e0 ..) of a row, plain loads, nothing prefetched
+    __device__ __forceinline__ void extra_block(int w0, int len, int e0, int c, float ub0, float ub1, v4f_g (&acc)[2], float &bs) const
+    {
+        int J0 = 0, E0 = -1, J1 = 0, E1 = -1;
+        if (e0 + n < len) { J0 = idx[w0 + e0 + n]; E0 = eidx[w0 + e0 + n]; }
+        if (e0 + 16 + n < len) { J1 = idx[w0 + e0 + 16 + n]; E1 = eidx[w0 + e0 + 16 + n]; }
+        to_offsets(J0, E0, true);
+        to_offsets(J1, E1, true);
+        GnoLoads Lx;
+        float cvx[2];
+        issue(Lx, J0, J1, g, c, true);   // every lane group holds the same 32 entries
+        load_cv(cvx, E0, E1, g);
+        compute<8>(Lx, cvx, ub0, ub1, acc, bs);
+    }
+};
+
+
 __global__ __launch_bounds__(kPcThreads) void gno_pc_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ idx,
                                                       const int32_t *__restrict__ eidx, const float *__restrict__ y,
                                                       const float *__restrict__ coords, const float *__restrict__ theta,
@@ -518,152 +689,27 @@ __global__ __launch_bounds__(kPcThreads) void gno_pc_kernel(const int32_t *__res
 
     if (wave < 8) {
         // ======================================= producer =======================================
-        // Every load below is UNCONDITIONAL (buffer loads; a dead slot's offset lies beyond the buffer and reads 0):
-        // a load inside a branch makes the compiler's wait-count bookkeeping give up and drain the queue at every use
-        // (first version: 42 x s_waitcnt vmcnt(0), producers alone 9.9 ms), which is the latency this kernel exists to hide.
-        const int p = __builtin_amdgcn_readfirstlane(wave);
         __builtin_amdgcn_s_setprio(3);   // the producers' instructions first (worth 1 %)
-        __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void *)y, 0, (int)y_bytes, 0x00020000);
-        __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc((void *)coords, 0, (int)c_bytes, 0x00020000);
-        __amdgpu_buffer_rsrc_t jrs = __builtin_amdgcn_make_buffer_rsrc((void *)idx, 0, (int)id_bytes, 0x00020000);
-        __amdgpu_buffer_rsrc_t ers = __builtin_amdgcn_make_buffer_rsrc((void *)eidx, 0, (int)id_bytes, 0x00020000);
-        constexpr uint32_t kDead = 0xFFFFF000u;   // beyond every buffer, and still beyond with a lane's few bytes added
-        // h MFMA per 16 hidden units: A lane (slot n, K index g) = coordinate g of the slot's edge (1 at g = d), B lane
-        // (hid = n, K index g) = U[hid][g] (b_u[hid] at g = d, 0 beyond).  A dead slot's h is relu(b_u): finite, and it
-        // meets x = 0.
-        float Ub[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int hid = 16 * t + n;
-            Ub[t] = g < d ? theta[hid + kGH * g] : (g == d ? theta[(size_t)kGH * d + hid] : 0.0f);
-        }
-        const bool g_is_d = g == d;
-        const int eslot = 4 * (n & 3) + (n >> 2);   // the entry that sits in slot n of a 16-entry block
-        const uint32_t n4 = 4 * n, g4 = 4 * g;
-
-        // a tile's ids arrive in three dependent steps, each issued two pieces after the one it waits for; row numbers and
-        // row pointers are wave-uniform (scalar loads), the entries lane-parallel: lane (vertex g of the four, entry n).
-        // What is kept of an entry is its two BYTE OFFSETS (feature row, coordinate row), kDead for a slot beyond the row
-        // or an entry without an edge column (oracle: e < 0 contributes nothing).
-        auto ids_rows = [&](int tl, GnoIds &I) {
-#pragma unroll
-            for (int vi = 0; vi < 4; ++vi) {
-                const int slot = tl * kPV + 4 * p + vi;
-                I.ok[vi] = tl < n_tiles && slot < n_rows;
-                I.row[vi] = perm[I.ok[vi] ? slot : 0];
-            }
-        };
-        auto ids_ptrs = [&](GnoIds &I) {
-#pragma unroll
-            for (int vi = 0; vi < 4; ++vi) {
-                I.w0[vi] = rowptr[I.row[vi]];
-                I.len[vi] = I.ok[vi] ? rowptr[I.row[vi] + 1] - I.w0[vi] : 0;
-            }
-        };
-        auto ids_entries = [&](GnoIds &I) {
-            const int w0 = g == 0 ? I.w0[0] : g == 1 ? I.w0[1] : g == 2 ? I.w0[2] : I.w0[3];
-            const int len = g == 0 ? I.len[0] : g == 1 ? I.len[1] : g == 2 ? I.len[2] : I.len[3];
-            const uint32_t o0 = n < len ? 4u * (uint32_t)(w0 + n) : kDead, o1 = n + 16 < len ? 4u * (uint32_t)(w0 + n + 16) : kDead;
-            I.J0 = __builtin_amdgcn_raw_buffer_load_b32(jrs, (int)o0, 0, 0);
-            I.E0 = __builtin_amdgcn_raw_buffer_load_b32(ers, (int)o0, 0, 0);
-            I.J1 = __builtin_amdgcn_raw_buffer_load_b32(jrs, (int)o1, 0, 0);
-            I.E1 = __builtin_amdgcn_raw_buffer_load_b32(ers, (int)o1, 0, 0);
-        };
-        auto to_offsets = [&](int &J, int &E, bool inrow) {
-            const bool alive = inrow && E >= 0;
-            J = (int)(alive ? (uint32_t)J * (4u * kGF) : kDead);
-            E = (int)(alive ? (uint32_t)E * (4u * (uint32_t)d) : kDead);
-        };
-        auto ids_finish = [&](GnoIds &I) {
-            const int len = g == 0 ? I.len[0] : g == 1 ? I.len[1] : g == 2 ? I.len[2] : I.len[3];
-            to_offsets(I.J0, I.E0, n < len);
-            to_offsets(I.J1, I.E1, n + 16 < len);
-        };
-        // operand loads of one vertex for the feature quarter c; (J0, E0, J1, E1) hold the offsets of its 32 entries in
-        // lane group srcg.  Per load: one shuffle, one add.
-        auto issue = [&](GnoLoads &L, int J0, int J1, int srcg, int c, bool second) {
-            const int src = 16 * srcg;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const uint32_t j = (uint32_t)__shfl(J0, src + 4 * r + g) + n4;
-                L.x[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, (int)j, 64 * c, 0));
-            }
-            if (second) {   // entries 16 .. 31: only tiles whose rows are that long ask for them
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const uint32_t j = (uint32_t)__shfl(J1, src + 4 * r + g) + n4;
-                    L.x[4 + r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, (int)j, 64 * c, 0));
-                }
-            }
-        };
-        // the edge coordinates of a vertex's 32 slots do not depend on the piece: loaded once per tile
-        auto load_cv = [&](float (&cv)[2], int E0, int E1, int srcg) {
-            const int src = 16 * srcg;
-            const uint32_t es0 = (uint32_t)__shfl(E0, src + eslot) + g4, es1 = (uint32_t)__shfl(E1, src + eslot) + g4;
-            cv[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(crs, (int)es0, 0, 0));
-            cv[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(crs, (int)es1, 0, 0));
-        };
-        // one instruction per value, as an INTEGER max (a float with its sign bit set is a negative integer): fmaxf and
-        // fmed3 cost two (they quiet their operand first), and an inline-asm v_max is invisible to the hazard recogniser --
-        // no wait states between the MFMA and the read of its result (wrong rows at C4 size)
-        auto relu4 = [&](v4f_g &h) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float t = h[r];   // (__builtin_bit_cast of a vector ELEMENT reads element 0 whatever r is)
-                h[r] = __int_as_float(max(__float_as_int(t), 0));   // v_max_i32
-            }
-        };
-        // S piece of one vertex from its operands: acc[t][r2] = S[hid = 16 t + 4 g + r2][q = n], NST groups of four entries.
-        // NST is a compile-time constant: branches around single steps (or a switch that falls through them) make the
-        // compiler copy the accumulators between register sets at every step.
-        auto compute = [&](auto K, const GnoLoads &L, const float (&cvs)[2], float ub0, float ub1, v4f_g (&acc)[2], float &bs) {
-            constexpr int NST = decltype(K)::value;
-            const v4f_g z = {0.0f, 0.0f, 0.0f, 0.0f};
-            {
-                const float cv = g_is_d ? 1.0f : cvs[0];
-                v4f_g h0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cv, ub0, z, 0, 0, 0);
-                v4f_g h1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cv, ub1, z, 0, 0, 0);
-                relu4(h0);
-                relu4(h1);
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(h0[0], L.x[0], z, 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(h1[0], L.x[0], z, 0, 0, 0);
-#pragma unroll
-                for (int r = 1; r < (NST < 4 ? NST : 4); ++r) {
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(h0[r], L.x[r], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(h1[r], L.x[r], acc[1], 0, 0, 0);
-                }
-                bs = (L.x[0] + L.x[1]) + (L.x[2] + L.x[3]);
-            }
-            if constexpr (NST > 4) {
-                const float cv = g_is_d ? 1.0f : cvs[1];
-                v4f_g h0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cv, ub0, z, 0, 0, 0);
-                v4f_g h1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cv, ub1, z, 0, 0, 0);
-                relu4(h0);
-                relu4(h1);
-#pragma unroll
-                for (int r = 0; r < NST - 4; ++r) {
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(h0[r], L.x[4 + r], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(h1[r], L.x[4 + r], acc[1], 0, 0, 0);
-                }
-                bs = bs + ((L.x[4] + L.x[5]) + (L.x[6] + L.x[7]));
-            }
-        };
+        GnoProd P;
+        P.init(wave, lane, rowptr, idx, eidx, y, coords, theta, d, n_rows, perm, y_bytes, c_bytes, id_bytes);
+        const int p = P.p;
+        const float(&Ub)[4] = P.Ub;
 
         GnoIds cur, nxt;
-        ids_rows(blockIdx.x, cur);
-        ids_ptrs(cur);
-        ids_entries(cur);
-        ids_finish(cur);
+        P.ids_rows(blockIdx.x, cur);
+        P.ids_ptrs(cur);
+        P.ids_entries(cur);
+        P.ids_finish(cur);
         nxt = cur;
         int pJ0 = cur.J0, pJ1 = cur.J1;                                  // the offsets the refills read: this tile's, from a tile's
                                                                      // last piece on the next tile's
         GnoLoads LS[4];   // one set per vertex: refilled for the NEXT piece right after this piece's MFMAs have read it,
                           // so a load has a whole piece interval to land
 #pragma unroll
-        for (int vi = 0; vi < 4; ++vi) issue(LS[vi], pJ0, pJ1, vi, 0, true);
+        for (int vi = 0; vi < 4; ++vi) P.issue(LS[vi], pJ0, pJ1, vi, 0, true);
         float CV[4][2];   // coordinates of the tile's slots; refilled for the next tile after the last piece has read them
 #pragma unroll
-        for (int vi = 0; vi < 4; ++vi) load_cv(CV[vi], cur.E0, cur.E1, vi);
+        for (int vi = 0; vi < 4; ++vi) P.load_cv(CV[vi], cur.E0, cur.E1, vi);
         for (int ti = 0; ti < nt; ++ti) {
             const int tile = blockIdx.x + ti * gridDim.x;
             const bool more = ti + 1 < nt;
@@ -678,13 +724,13 @@ __global__ __launch_bounds__(kPcThreads) void gno_pc_kernel(const int32_t *__res
                 const float ub0 = kh ? Ub[2] : Ub[0], ub1 = kh ? Ub[3] : Ub[1];
                 // the next tile's ids, one dependent step at a time
                 if (more) {
-                    if (pc == 0) ids_rows(tile + gridDim.x, nxt);
+                    if (pc == 0) P.ids_rows(tile + gridDim.x, nxt);
                     if (pc == 2) {
-                        ids_ptrs(nxt);
+                        P.ids_ptrs(nxt);
                         nstN = min(8, (max(max(nxt.len[0], nxt.len[1]), max(nxt.len[2], nxt.len[3])) + 3) >> 2);
                     }
-                    if (pc == 4) ids_entries(nxt);
-                    if (pc == 6) ids_finish(nxt);
+                    if (pc == 4) P.ids_entries(nxt);
+                    if (pc == 6) P.ids_finish(nxt);
                 }
                 // the refill is unconditional: from a tile's last piece on it reads the next tile's rows (the last tile of
                 // all re-reads its own: harmless, nothing consumes them)
@@ -699,9 +745,9 @@ __global__ __launch_bounds__(kPcThreads) void gno_pc_kernel(const int32_t *__res
                     for (int vi = 0; vi < ((GNO_FV & 32) ? 0 : 4); ++vi) {
                         v4f_g acc[2];
                         float bs;
-                        compute(K, LS[vi], CV[vi], ub0, ub1, acc, bs);
-                        issue(LS[vi], pJ0, pJ1, vi, cn, second);
-                        if (last) load_cv(CV[vi], nxt.E0, nxt.E1, vi);
+                        P.compute<decltype(K)::value>(LS[vi], CV[vi], ub0, ub1, acc, bs);
+                        P.issue(LS[vi], pJ0, pJ1, vi, cn, second);
+                        if (last) P.load_cv(CV[vi], nxt.E0, nxt.E1, vi);
                         const int v = 4 * p + vi;
                         float *srow = buf + (size_t)v * kPPitch;
 #pragma unroll
@@ -736,18 +782,9 @@ __global__ __launch_bounds__(kPcThreads) void gno_pc_kernel(const int32_t *__res
                         const int v = 4 * p + vi;
                         float *srow = buf + (size_t)v * kPPitch;
                         for (int e0 = 32; e0 < len; e0 += 32) {
-                            int J0 = 0, E0 = -1, J1 = 0, E1 = -1;
-                            if (e0 + n < len) { J0 = idx[w0 + e0 + n]; E0 = eidx[w0 + e0 + n]; }
-                            if (e0 + 16 + n < len) { J1 = idx[w0 + e0 + 16 + n]; E1 = eidx[w0 + e0 + 16 + n]; }
-                            to_offsets(J0, E0, true);
-                            to_offsets(J1, E1, true);
-                            GnoLoads Lx;
-                            float cvx[2];
-                            issue(Lx, J0, J1, g, c, true);   // every lane group holds the same 32 entries
-                            load_cv(cvx, E0, E1, g);
                             v4f_g acc[2];
                             float bs;
-                            compute(std::integral_constant<int, 8>{}, Lx, cvx, ub0, ub1, acc, bs);
+                            P.extra_block(w0, len, e0, c, ub0, ub1, acc, bs);
 #pragma unroll
                             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -838,6 +875,268 @@ __global__ __launch_bounds__(kPcThreads) void gno_pc_kernel(const int32_t *__res
             }
         }
     }
+}
+
+// ---- dVaug = S^T g with S never in HBM (H = 64, widths 64, d <= 3) ------------------------------------------------
+// The same producers, the contraction turned round: out[kq][o] = sum_v S[v][kq] g[v][o] contracts over the VERTICES, so
+// its 4160 x 64 accumulators must stay put while the vertices stream by.  A workgroup therefore owns ONE piece (c, kh) of
+// S for its whole life -- 512 x 64 sums = 128 registers per lane of its four consumer waves -- and every 32nd tile:
+// workgroup b: piece b % 8, tiles b / 8, b / 8 + 32, ...  Per tile its producers build just that piece (the gathers of a
+// tile are shared out over the eight workgroups that visit it: each reads its own 64-byte quarter of the feature rows), and
+// put the tile's 32 gradient rows beside it in LDS.  The bias row (sum of x_j) meets g on the producers' own MFMAs
+// (K = the four vertices of a wave).  256 partial slabs (33 MB) are summed in a fixed order by gno_stg_reduce_kernel,
+// which also undoes the producers' row order.  Replaces: outer product -> 33 GB of S through HBM -> contraction.
+constexpr int kGPitch = 72;
+constexpr int kStgLdsFloats = 2 * kPV * kPPitch + 2 * kPV * kGPitch;
+constexpr int kStgGrid = 256;   // 8 pieces x 32 tile classes
+
+__global__ __launch_bounds__(kPcThreads) void gno_stg_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ idx,
+                                                       const int32_t *__restrict__ eidx, const float *__restrict__ y,
+                                                       const float *__restrict__ coords, const float *__restrict__ theta,
+                                                       int d, const float *__restrict__ grad, int n_rows,
+                                                       const int32_t *__restrict__ perm, float *__restrict__ slab,
+                                                       float *__restrict__ slabB, uint32_t y_bytes, uint32_t c_bytes,
+                                                       uint32_t id_bytes, uint32_t g_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) float Sh[];
+    float *Sbuf = Sh;                                   // [2][32][520]
+    float *Gbuf = Sh + 2 * kPV * kPPitch;               // [2][32][72]   gradient rows of the tile
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int pc = blockIdx.x & 7, sub = blockIdx.x >> 3, c = pc >> 1, kh = pc & 1;
+    const int n_tiles = (n_rows + kPV - 1) / kPV;
+    const int nt = sub < n_tiles ? (n_tiles - sub + 31) / 32 : 0;   // tiles of this workgroup
+
+    if (wave < 8) {
+        // ======================================= producer =======================================
+        __builtin_amdgcn_s_setprio(3);
+        GnoProd P;
+        P.init(wave, lane, rowptr, idx, eidx, y, coords, theta, d, n_rows, perm, y_bytes, c_bytes, id_bytes);
+        const int p = P.p;
+        const float ub0 = kh ? P.Ub[2] : P.Ub[0], ub1 = kh ? P.Ub[3] : P.Ub[1];
+        __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void *)grad, 0, (int)g_bytes, 0x00020000);
+        // gradient rows of the wave's four vertices as the bias MFMA's A operand: lane (o = 16 ot + n, vertex g)
+        auto load_g = [&](float (&GV)[4], const GnoIds &I) {
+            const int row = g == 0 ? I.row[0] : g == 1 ? I.row[1] : g == 2 ? I.row[2] : I.row[3];
+            const bool ok = g == 0 ? I.ok[0] : g == 1 ? I.ok[1] : g == 2 ? I.ok[2] : I.ok[3];
+            const uint32_t off = ok ? (uint32_t)row * (4u * kGF) + P.n4 : GnoProd::kDead;
+#pragma unroll
+            for (int ot = 0; ot < 4; ++ot)
+                GV[ot] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, (int)off, 64 * ot, 0));
+        };
+        // the ids of the workgroup's tiles: a four-deep queue, one dependent step per tile interval
+        //   T4 row numbers (issued now) | T3 row pointers | T2 entries | T1 offsets: the tile whose operands are requested
+        //   during this interval | T0 the tile being built
+        GnoIds T0, T1, T2, T3, T4;
+        P.ids_rows(sub, T0); P.ids_ptrs(T0); P.ids_entries(T0); P.ids_finish(T0);
+        P.ids_rows(sub + 32, T1); P.ids_ptrs(T1); P.ids_entries(T1);
+        P.ids_rows(sub + 64, T2); P.ids_ptrs(T2);
+        P.ids_rows(sub + 96, T3);
+        T4 = T3;
+        GnoLoads LS[4];
+        float CV[4][2], GV[4];
+#pragma unroll
+        for (int vi = 0; vi < 4; ++vi) {
+            P.issue(LS[vi], T0.J0, T0.J1, vi, c, true);
+            P.load_cv(CV[vi], T0.E0, T0.E1, vi);
+        }
+        load_g(GV, T0);
+        const v4f_g z = {0.0f, 0.0f, 0.0f, 0.0f};
+        v4f_g accB[4] = {z, z, z, z};   // bias rows: [o = 16 ot + 4 g + r][q = 16 c + n], kh = 0 workgroups only
+#pragma unroll 1
+        for (int j = 0; j < nt; ++j) {
+            P.ids_rows(sub + 32 * (j + 4), T4);
+            P.ids_ptrs(T3);
+            P.ids_entries(T2);
+            P.ids_finish(T1);
+            const int maxlen = max(max(T0.len[0], T0.len[1]), max(T0.len[2], T0.len[3]));
+            const int nstT = min(8, (maxlen + 3) >> 2);
+            const bool second = max(max(T1.len[0], T1.len[1]), max(T1.len[2], T1.len[3])) > 16;
+            float *buf = Sbuf + (size_t)(j & 1) * kPV * kPPitch;
+            float *gb = Gbuf + (size_t)(j & 1) * kPV * kGPitch;
+            float bsv[4];
+            auto four = [&](auto K) {
+#pragma unroll
+                for (int vi = 0; vi < 4; ++vi) {
+                    v4f_g acc[2];
+                    float bs;
+                    P.compute<decltype(K)::value>(LS[vi], CV[vi], ub0, ub1, acc, bs);
+                    P.issue(LS[vi], T1.J0, T1.J1, vi, c, second);
+                    P.load_cv(CV[vi], T1.E0, T1.E1, vi);
+                    float *srow = buf + (size_t)(4 * p + vi) * kPPitch;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r2 = 0; r2 < 4; ++r2) srow[(16 * t + 4 * r2 + g) * 16 + n] = acc[t][r2];
+                    bsv[vi] = bs;
+                }
+            };
+            switch (nstT) {
+            case 0:
+            case 1: four(std::integral_constant<int, 1>{}); break;
+            case 2: four(std::integral_constant<int, 2>{}); break;
+            case 3: four(std::integral_constant<int, 3>{}); break;
+            case 4: four(std::integral_constant<int, 4>{}); break;
+            case 5: four(std::integral_constant<int, 5>{}); break;
+            case 6: four(std::integral_constant<int, 6>{}); break;
+            case 7: four(std::integral_constant<int, 7>{}); break;
+            default: four(std::integral_constant<int, 8>{}); break;
+            }
+            if (maxlen > 32) {   // rows longer than 32 entries: the remaining blocks are added to the vertex's own LDS row
+#pragma unroll 1
+                for (int vi = 0; vi < 4; ++vi) {
+                    const int len = vi == 0 ? T0.len[0] : vi == 1 ? T0.len[1] : vi == 2 ? T0.len[2] : T0.len[3];
+                    const int w0 = vi == 0 ? T0.w0[0] : vi == 1 ? T0.w0[1] : vi == 2 ? T0.w0[2] : T0.w0[3];
+                    float *srow = buf + (size_t)(4 * p + vi) * kPPitch;
+                    for (int e0 = 32; e0 < len; e0 += 32) {
+                        v4f_g acc[2];
+                        float bs;
+                        P.extra_block(w0, len, e0, c, ub0, ub1, acc, bs);
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+#pragma unroll
+                            for (int r2 = 0; r2 < 4; ++r2) srow[(16 * t + 4 * r2 + g) * 16 + n] += acc[t][r2];
+                        if (vi == 0) bsv[0] += bs; else if (vi == 1) bsv[1] += bs; else if (vi == 2) bsv[2] += bs; else bsv[3] += bs;
+                    }
+                }
+            }
+            // the tile's gradient rows: beside S in LDS for the consumers, and against the bias sums here
+#pragma unroll
+            for (int ot = 0; ot < 4; ++ot) gb[(4 * p + g) * kGPitch + 16 * ot + n] = GV[ot];
+            if (kh == 0) {
+#pragma unroll
+                for (int vi = 0; vi < 4; ++vi) {   // column sums of the feature quarter: every lane (n, any g) ends with the total
+                    bsv[vi] = bsv[vi] + __shfl_xor(bsv[vi], 16);
+                    bsv[vi] = bsv[vi] + __shfl_xor(bsv[vi], 32);
+                }
+                const float bsel = g == 0 ? bsv[0] : g == 1 ? bsv[1] : g == 2 ? bsv[2] : bsv[3];
+#pragma unroll
+                for (int ot = 0; ot < 4; ++ot) accB[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(GV[ot], bsel, accB[ot], 0, 0, 0);
+            }
+            load_g(GV, T1);
+            __syncthreads();
+            T0 = T1; T1 = T2; T2 = T3; T3 = T4;
+        }
+        __syncthreads();   // the consumers' last tile
+        if (kh == 0) {     // bias rows: the eight waves' parts meet in LDS (S is done with), waves 0-3 add them up
+            float *sc = Sh + (size_t)p * 1024;
+#pragma unroll
+            for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sc[(16 * ot + 4 * g + r) * 16 + n] = accB[ot][r];
+        }
+        __syncthreads();
+        if (kh == 0 && p < 4) {
+            const int t0 = p * 256 + lane * 4;
+            v4f_g sum = *reinterpret_cast<const v4f_g *>(Sh + t0);
+#pragma unroll
+            for (int w = 1; w < 8; ++w) {
+                const v4f_g v = *reinterpret_cast<const v4f_g *>(Sh + (size_t)w * 1024 + t0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sum[r] = sum[r] + v[r];
+            }
+            *reinterpret_cast<v4f_g *>(slabB + (size_t)blockIdx.x * 1024 + t0) = sum;
+        }
+    } else {
+        // ======================================= consumer =======================================
+        // wave w: positions L = 128 w .. + 127 of the piece x all 64 outputs = 32 tiles of 16 x 16.  Per four vertices:
+        // A = S[v][L0 + 4 n .. + 3] (one 16-byte LDS read feeds four tiles, L = L0 + 4 m + j), B = g[v][4 n .. + 3].
+        const int w = wave - 8;
+        const v4f_g z = {0.0f, 0.0f, 0.0f, 0.0f};
+        v4f_g acc[2][4][4];
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[sp][a][b] = z;
+        __syncthreads();
+#pragma unroll 1
+        for (int j = 0; j < nt; ++j) {
+            const float *sb = Sbuf + (size_t)(j & 1) * kPV * kPPitch + (size_t)g * kPPitch + 128 * w + 4 * n;
+            const float *gb = Gbuf + (size_t)(j & 1) * kPV * kGPitch + (size_t)g * kGPitch + 4 * n;
+#pragma unroll
+            for (int s4 = 0; s4 < 8; ++s4) {
+                const v4f_g a0 = *reinterpret_cast<const v4f_g *>(sb + (size_t)(4 * s4) * kPPitch);
+                const v4f_g a1 = *reinterpret_cast<const v4f_g *>(sb + (size_t)(4 * s4) * kPPitch + 64);
+                const v4f_g bv = *reinterpret_cast<const v4f_g *>(gb + (size_t)(4 * s4) * kGPitch);
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        acc[0][a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[a], bv[b], acc[0][a][b], 0, 0, 0);
+                        acc[1][a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[a], bv[b], acc[1][a][b], 0, 0, 0);
+                    }
+            }
+            __syncthreads();
+        }
+        // lane (o = 4 n + b, g): acc[sp][a][b][r] = out[L = 128 w + 64 sp + 4 (4 g + r) + a][o]
+        float *sl = slab + (size_t)blockIdx.x * 512 * kGF;
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int L = 128 * w + 64 * sp + 4 * (4 * g + r) + a;
+                    const v4f_g v = {acc[sp][a][0][r], acc[sp][a][1][r], acc[sp][a][2][r], acc[sp][a][3][r]};
+                    *reinterpret_cast<v4f_g *>(sl + (size_t)L * kGF + 4 * n) = v;
+                }
+        __syncthreads();   // the producers' bias rows
+    }
+}
+
+// dVaug[kq][o] = the 32 slabs of kq's piece, in workgroup order; kq = k * 64 + q sits at position L of piece (q / 16, k / 32)
+__global__ void gno_stg_reduce_kernel(const float *__restrict__ slab, const float *__restrict__ slabB, float *__restrict__ dV)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= 65 * 64 * 64) return;
+    const int kq = t >> 6, o = t & 63;
+    float sum = 0.0f;
+    if (kq < 64 * 64) {
+        const int k = kq >> 6, q = kq & 63, c = q >> 4, q16 = q & 15, kh = k >> 5, kl = k & 31;
+        const int tp = kl >> 4, gg = (kl >> 2) & 3, r = kl & 3;
+        const int L = (16 * tp + 4 * r + gg) * 16 + q16, pc = 2 * c + kh;
+        for (int sub = 0; sub < 32; ++sub) sum = sum + slab[((size_t)(sub * 8 + pc) * 512 + L) * kGF + o];
+    } else {
+        const int q = kq - 64 * 64, c = q >> 4, q16 = q & 15;
+        for (int sub = 0; sub < 32; ++sub) sum = sum + slabB[((size_t)(sub * 8 + 2 * c) * 64 + o) * 16 + q16];
+    }
+    dV[t] = sum;
+}
+
+bool gno_stg_shape(int H, int Fi, int Fo, int d)
+{
+    static const bool off = getenv("ATHENA_MP_GNO_UNFUSED_STG") != nullptr;   // A/B switch: S through HBM
+    return !off && H == kGH && Fi == kGF && Fo == kGF && d <= 3;
+}
+
+int launch_gno_stg(const athena_mp_graph *g, const float *x, const float *coords, const float *theta, int d, const float *grad,
+                   float *dV)
+{
+    const size_t y_bytes = sizeof(float) * kGF * (size_t)g->n_cols, c_bytes = sizeof(float) * (size_t)d * g->n_edge_cols,
+                 id_bytes = sizeof(int32_t) * (size_t)g->nnz, g_bytes = sizeof(float) * kGF * (size_t)g->n_rows;
+    const size_t lim = 0xFFFFE000ull;
+    if (!(y_bytes < lim && c_bytes < lim && id_bytes < lim && g_bytes < lim)) return -1;   // caller takes the other route
+    if (length_order(g->rowptr, g->n_rows, &g->len_perm_fwd)) return 1;
+    constexpr size_t lds = sizeof(float) * (size_t)kStgLdsFloats;
+    static amp::PerDeviceFlag attr;
+    if (!attr.get()) {
+        AMP_HIP(hipFuncSetAttribute((const void *)gno_stg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr.get() = true;
+    }
+    void *slab = nullptr, *slabB = nullptr;
+    if (amp::workspace(&slab, sizeof(float) * (size_t)kStgGrid * 512 * kGF, 0) ||
+        amp::workspace(&slabB, sizeof(float) * (size_t)kStgGrid * 1024, 8))
+        return 1;
+    hipLaunchKernelGGL(gno_stg_kernel, dim3(kStgGrid), dim3(kPcThreads), lds, amp::stream(), g->rowptr, g->col, g->eid, x, coords,
+                       theta, d, grad, g->n_rows, (const int32_t *)g->len_perm_fwd, (float *)slab, (float *)slabB,
+                       (uint32_t)y_bytes, (uint32_t)c_bytes, (uint32_t)id_bytes, (uint32_t)g_bytes);
+    AMP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gno_stg_reduce_kernel, dim3((65 * 64 * 64 + 255) / 256), dim3(256), 0, amp::stream(), (const float *)slab,
+                       (const float *)slabB, dV);
+    AMP_LAUNCH_CHECK();
+    return 0;
 }
 
 int launch_gno_pc(const int32_t *rowptr, const int32_t *idx, const int32_t *eidx, const float *y, const float *coords,
@@ -1524,6 +1823,11 @@ int athena_mp_gno_aggregate_bwd_theta(const athena_mp_graph *g, int32_t d, int32
     // contraction of tile t runs on the caller's.
     const int tile = tile_rows_for(g->n_rows, R);
     if (g->n_rows == 0) AMP_HIP(hipMemsetAsync(dtheta + off_V, 0, sizeof(float) * (size_t)R * Fo, stream()));
+    if (g->n_rows > 0 && gno_stg_shape(H, Fi, Fo, d)) {   // S stays on chip (gno_stg_kernel)
+        const int rc = launch_gno_stg(g, x, coords, theta, d, grad, dtheta + off_V);
+        if (rc == 0) return gno_mlp_backward(g, d, H, Fi, Fo, theta, coords, x, grad, dtheta, nullptr);
+        if (rc > 0) return rc;
+    }
     static const bool serial = getenv("ATHENA_MP_GNO_SERIAL_TILES") != nullptr;   // A/B switch for measurements
     const int n_tiles = g->n_rows > 0 ? (g->n_rows + tile - 1) / tile : 0;
     if (serial || n_tiles < 2) {
