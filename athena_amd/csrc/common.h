@@ -101,6 +101,8 @@ struct athena_mp_graph {
     // rows ordered by length (longest first), built on first use by the fused GNO kernel: the 16 rows of a
     // tile then have (nearly) equal entry counts, so no wave waits at the tile barrier for a longer row
     mutable int32_t *len_perm_fwd = nullptr;     // [n_rows] device, forward CSR
+    mutable int32_t n_long_fwd = 0;              // rows of the forward CSR with more than 32 entries (the first slots of len_perm_fwd)
+    mutable int32_t n_mid_fwd = 0;               // ... with more than 16 entries (n_long_fwd included)
     mutable int32_t *len_perm_bwd = nullptr;     // [n_cols] device, transposed CSR
     // the same runs cut into 16-vertex tiles (one MFMA column block each), bucket-major
     mutable int32_t n_btiles = 0;

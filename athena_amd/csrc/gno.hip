@@ -392,14 +392,21 @@ bool gno_fused_shape(int H, int Fy, int Fout, int d)
 }
 
 // vertices ordered by row length, longest first (stable counting sort on the host, once per graph and CSR)
-int length_order(const int32_t *rowptr_dev, int n_rows, int32_t **perm_dev)
+int length_order(const int32_t *rowptr_dev, int n_rows, int32_t **perm_dev, int32_t *n_long = nullptr, int32_t *n_mid = nullptr)
 {
     if (*perm_dev) return 0;
     std::vector<int32_t> rp((size_t)n_rows + 1);
     AMP_HIP(hipMemcpyAsync(rp.data(), rowptr_dev, sizeof(int32_t) * rp.size(), hipMemcpyDeviceToHost, amp::stream()));
     AMP_HIP(hipStreamSynchronize(amp::stream()));
     int32_t mx = 0;
-    for (int i = 0; i < n_rows; ++i) mx = std::max(mx, rp[i + 1] - rp[i]);
+    int32_t longer = 0, mid = 0;
+    for (int i = 0; i < n_rows; ++i) {
+        mx = std::max(mx, rp[i + 1] - rp[i]);
+        longer += rp[i + 1] - rp[i] > 32;
+        mid += rp[i + 1] - rp[i] > 16;
+    }
+    if (n_long) *n_long = longer;
+    if (n_mid) *n_mid = mid;
     std::vector<int32_t> start((size_t)mx + 2, 0), perm((size_t)std::max(n_rows, 1));
     for (int i = 0; i < n_rows; ++i) start[(size_t)(mx - (rp[i + 1] - rp[i])) + 1]++;
     for (int l = 0; l <= mx; ++l) start[(size_t)l + 1] += start[l];
@@ -415,9 +422,10 @@ int launch_gno_pc(const int32_t *rowptr, const int32_t *idx, const int32_t *eidx
 
 int launch_gno_fused(const int32_t *rowptr, const int32_t *idx, const int32_t *eidx, const float *y,
                      const float *coords, const float *theta, int d, const float *Vaug, int n_rows,
-                     int32_t **perm_cache, float *out, int y_rows, int n_edge_cols, int64_t nnz)
+                     int32_t **perm_cache, float *out, int y_rows, int n_edge_cols, int64_t nnz, int32_t *n_long = nullptr,
+                     int32_t *n_mid = nullptr)
 {
-    if (n_rows > 0 && length_order(rowptr, n_rows, perm_cache)) return 1;
+    if (n_rows > 0 && length_order(rowptr, n_rows, perm_cache, n_long, n_mid)) return 1;
     static const bool v1 = getenv("ATHENA_MP_GNO_FUSED_V1") != nullptr;   // A/B switch: the one-phase-at-a-time kernel
     // the producer / consumer kernel addresses its gathers through buffer descriptors (32-bit byte offsets)
     const size_t y_bytes = sizeof(float) * kGF * (size_t)y_rows, c_bytes = sizeof(float) * (size_t)d * n_edge_cols,
@@ -507,7 +515,7 @@ struct GnoLoads {   // one vertex's operands for one piece: features of up to 32
 // 42 x s_waitcnt vmcnt(0), producers alone 9.9 ms), which is the latency these kernels exist to hide.
 struct GnoProd {
     static constexpr uint32_t kDead = 0xFFFFF000u;   // beyond every buffer, and still beyond with a lane's few bytes added
-    int lane, n, g, p, d, n_rows, n_tiles;
+    int lane, n, g, p, d, n_rows, n_tiles, vpw;   // vpw: vertices of a tile per producer wave (4; 2 in gno_dh_pc_kernel<2, 2>)
     const int32_t *perm, *rowptr, *idx, *eidx;
     __amdgpu_buffer_rsrc_t yrs, crs, jrs, ers;
     // h MFMA per 16 hidden units: A lane (slot n, K index g) = coordinate g of the slot's edge (1 at g = d), B lane
@@ -520,9 +528,9 @@ struct GnoProd {
 
     __device__ __forceinline__ void init(int wave, int lane_, const int32_t *rowptr_, const int32_t *idx_, const int32_t *eidx_,
                                          const float *y, const float *coords, const float *theta, int d_, int n_rows_,
-                                         const int32_t *perm_, uint32_t y_bytes, uint32_t c_bytes, uint32_t id_bytes)
+                                         const int32_t *perm_, uint32_t y_bytes, uint32_t c_bytes, uint32_t id_bytes, int vpw_ = 4)
     {
-        lane = lane_; n = lane & 15; g = lane >> 4; d = d_; n_rows = n_rows_; n_tiles = (n_rows + kPV - 1) / kPV;
+        lane = lane_; n = lane & 15; g = lane >> 4; d = d_; n_rows = n_rows_; vpw = vpw_; n_tiles = (n_rows + 8 * vpw - 1) / (8 * vpw);
         perm = perm_; rowptr = rowptr_; idx = idx_; eidx = eidx_;
         p = __builtin_amdgcn_readfirstlane(wave);
         yrs = __builtin_amdgcn_make_buffer_rsrc((void *)y, 0, (int)y_bytes, 0x00020000);
@@ -546,8 +554,8 @@ struct GnoProd {
     {
 #pragma unroll
         for (int vi = 0; vi < 4; ++vi) {
-            const int slot = tl * kPV + 4 * p + vi;
-            I.ok[vi] = tl < n_tiles && slot < n_rows;
+            const int slot = tl * (8 * vpw) + vpw * p + vi;
+            I.ok[vi] = vi < vpw && tl < n_tiles && slot < n_rows;
             I.row[vi] = perm[I.ok[vi] ? slot : 0];
         }
     }
@@ -1118,7 +1126,7 @@ int launch_gno_stg(const athena_mp_graph *g, const float *x, const float *coords
                  id_bytes = sizeof(int32_t) * (size_t)g->nnz, g_bytes = sizeof(float) * kGF * (size_t)g->n_rows;
     const size_t lim = 0xFFFFE000ull;
     if (!(y_bytes < lim && c_bytes < lim && id_bytes < lim && g_bytes < lim)) return -1;   // caller takes the other route
-    if (length_order(g->rowptr, g->n_rows, &g->len_perm_fwd)) return 1;
+    if (length_order(g->rowptr, g->n_rows, &g->len_perm_fwd, &g->n_long_fwd, &g->n_mid_fwd)) return 1;
     constexpr size_t lds = sizeof(float) * (size_t)kStgLdsFloats;
     static amp::PerDeviceFlag attr;
     if (!attr.get()) {
@@ -1643,6 +1651,257 @@ bool gno_args_ok(const athena_mp_graph *g, int d, int H, int Fi, int Fo)
 }
 
 // shared backward of the kernel MLP: dU, db_u (want_theta) and/or dcoords (want_coords)
+// ---- kernel-MLP backward, dense and sparse halves side by side (H = 64, widths 64, d <= 3, rows of <= 32 entries) ---
+// dh[e][k] = sum_q G_i[k][q] x_j[q] with G_i = g_i . Vmat^T (4096 values per vertex) is where dU, db_u and dcoords come
+// from.  gno_gdh_kernel builds G half by half and then walks the entries, every wave in the same phase (22.6 ms at C4:
+// 15.9 + 8.2 alone).  Here, as in gno_pc_kernel with the roles swapped, G is cut in eight pieces per 32-vertex tile --
+// piece (kh, c) = hidden units 32 kh .. +31 x features 16 c .. +15 -- double-buffered in LDS, and
+//   waves 8-11  (one per SIMD) are DENSE: G[v][kq] = sum_o g[v][o] V[kq][o] on 16x16x4 MFMAs, V streamed from L2 in
+//               the order gno_vrelay_dense_kernel lays down (one 16-byte load per eight MFMAs), the tile's gradient
+//               rows in registers; a finished 16 x 16 block is four hidden units x four features per lane group, so
+//               it goes to LDS as one 16-byte store per vertex;
+//   waves 0-7   are SPARSE, four vertices each: dh^T[e][k] += x_j[e][16 c ..] . G[..][k] on MFMAs (A = one 16-byte load
+//               of the neighbour's feature quarter, B = one 16-byte LDS read of G), accumulated in registers over the
+//               four c of a kh; then the relu' mask from the h MFMA of the forward pass (same layout), the entry's
+//               masked dh to HBM when dcoords wants it, and [dU | db_u] += dh^T . [dx_e ; 1] on one more MFMA whose A
+//               operand IS the masked accumulator (register r of lane group g = entry 4 g + r).
+// The few rows longer than 32 entries (they head the length-ordered vertex list) stay with gno_gdh_kernel.
+constexpr int kDhLdsFloats = 2 * kPV * kPPitch;
+
+// Vd[pc'][w][mt][sg][lane][i] = Vmat[kq][o]: pc' = 4 kh + c; block (w, mt) = hidden units 4 (2 w + mt / 4) .. +3 x
+// features 4 (mt % 4) .. +3 of the piece; lane (m, ok): row m = (hid m / 4, feature m % 4), o = 16 sg + 4 ok + i
+__global__ void gno_vrelay_dense_kernel(const float *__restrict__ Vin, float *__restrict__ Vd)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= 64 * 64 * 64) return;
+    const int i = t & 3, lane = (t >> 2) & 63, sg = (t >> 8) & 3, mt = (t >> 10) & 7, w = (t >> 13) & 3, pcp = t >> 15;
+    const int m = lane & 15, ok = lane >> 4, kh = pcp >> 2, c = pcp & 3;
+    const int hidl = 4 * (2 * w + (mt >> 2)) + (m >> 2), q = 16 * c + 4 * (mt & 3) + (m & 3);
+    const int o = 16 * sg + 4 * ok + i;
+    Vd[t] = Vin[(size_t)((32 * kh + hidl) * 64 + q) * 64 + o];
+}
+
+// position of G[hid][4 chunk ..] inside a vertex's row of a piece: chunks of the hidden units 8 .. 15 (mod 16) swapped
+// pairwise, so that the sparse waves' 16-byte reads (lane = hidden unit, lane group = chunk) fall on 16 different banks
+__device__ __forceinline__ int gno_gpos(int hidl, int chunk) { return hidl * 16 + ((chunk ^ ((hidl >> 2) & 2)) << 2); }
+
+// VPW vertices of a tile per sparse wave (tile = 8 VPW vertices), NB blocks of 16 entries per row: <4, 1> for rows of at most
+// 16 entries, <2, 2> for rows of 17 .. 32 -- the register file holds 4 x 1 or 2 x 2 sets of dh accumulators, not 4 x 2
+template <bool WRITE_GH, int VPW, int NB>
+__global__ __launch_bounds__(kPcThreads) void gno_dh_pc_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ idx,
+                                                         const int32_t *__restrict__ eidx, const float *__restrict__ y,
+                                                         const float *__restrict__ coords, const float *__restrict__ theta,
+                                                         int d, const float *__restrict__ Vd, const float *__restrict__ grad,
+                                                         int n_rows, const int32_t *__restrict__ perm, float *__restrict__ slabs,
+                                                         float *__restrict__ ghbuf, uint32_t y_bytes, uint32_t c_bytes,
+                                                         uint32_t id_bytes, uint32_t g_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) float Sh[];
+    constexpr int TV = 8 * VPW, NG = VPW / 2;          // vertices per tile, groups of 16 of them
+    float *Gbuf = Sh;                                   // [2][TV][520]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int n_tiles = (n_rows + TV - 1) / TV;
+    const int nt = (n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles of this workgroup (>= 1)
+
+    if (wave >= 8) {
+        // ======================================= dense =======================================
+        const int w = wave - 8;
+        __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void *)grad, 0, (int)g_bytes, 0x00020000);
+        // the tile's gradient rows as B operands: lane (vertex n [+ 16], ok = g) holds g[v][16 j + 4 ok .. + 3], j = 0 .. 3
+        auto load_gt = [&](v4f_g (&G0)[4], v4f_g (&G1)[4], int tile) {
+            const int sa = tile * TV + n, sb = sa + 16;
+            const bool oka = tile < n_tiles && sa < n_rows, okb = NG > 1 && tile < n_tiles && sb < n_rows;
+            const int ra = perm[oka ? sa : 0], rb = perm[okb ? sb : 0];
+            const uint32_t oa = oka ? (uint32_t)ra * (4u * kGF) + 16u * g : GnoProd::kDead;
+            const uint32_t ob = okb ? (uint32_t)rb * (4u * kGF) + 16u * g : GnoProd::kDead;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                G0[j] = __builtin_bit_cast(v4f_g, __builtin_amdgcn_raw_buffer_load_b128(grs, (int)oa, 64 * j, 0));
+                G1[j] = __builtin_bit_cast(v4f_g, __builtin_amdgcn_raw_buffer_load_b128(grs, (int)ob, 64 * j, 0));
+            }
+        };
+        v4f_g G0[4], G1[4], G0n[4], G1n[4];
+        load_gt(G0, G1, blockIdx.x);
+        const float *vw = Vd + ((size_t)w * 8) * 1024 + lane * 4;      // + pc' * 32768 + mt * 1024 + sg * 256
+        auto vload = [&](const float *p) { return *reinterpret_cast<const v4f_g *>(p); };
+        v4f_g a[4];
+#pragma unroll
+        for (int sg = 0; sg < 4; ++sg) a[sg] = vload(vw + (size_t)sg * 256);
+        const v4f_g z = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int ti = 0; ti < nt; ++ti) {
+            const int tile = blockIdx.x + ti * gridDim.x;
+#pragma unroll 1
+            for (int pcp = 0; pcp < 8; ++pcp) {
+                float *buf = Gbuf + (size_t)((ti * 8 + pcp) & 1) * TV * kPPitch;
+                const float *vp = vw + (size_t)pcp * 32768;
+                const float *vnext = vw + (size_t)((pcp + 1) & 7) * 32768;
+                if (pcp == 0) load_gt(G0n, G1n, tile + gridDim.x);   // the next tile's rows: seven pieces to land
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt) {
+                    v4f_g an[4];
+#pragma unroll
+                    for (int sg = 0; sg < 4; ++sg) an[sg] = vload(mt < 7 ? vp + (size_t)(mt + 1) * 1024 + (size_t)sg * 256 : vnext + (size_t)sg * 256);
+                    __builtin_amdgcn_sched_barrier(0);
+                    v4f_g c0 = z, c1 = z;
+#pragma unroll
+                    for (int sg = 0; sg < 4; ++sg)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sg][i], G0[sg][i], c0, 0, 0, 0);
+                            if (NG > 1) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sg][i], G1[sg][i], c1, 0, 0, 0);
+                        }
+                    // lane (vertex n, g): c[r] = G[v][hid = 4 (2 w + mt / 4) + g][feature 4 (mt % 4) + r]
+                    const int pos = gno_gpos(4 * (2 * w + (mt >> 2)) + g, mt & 3);
+                    *reinterpret_cast<v4f_g *>(buf + (size_t)n * kPPitch + pos) = c0;
+                    if (NG > 1) *reinterpret_cast<v4f_g *>(buf + (size_t)(n + 16) * kPPitch + pos) = c1;
+#pragma unroll
+                    for (int sg = 0; sg < 4; ++sg) a[sg] = an[sg];
+                }
+                if (pcp == 7) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { G0[j] = G0n[j]; G1[j] = G1n[j]; }
+                }
+                __syncthreads();
+            }
+        }
+        __syncthreads();   // the sparse waves' last piece
+    } else {
+        // ======================================= sparse =======================================
+        __builtin_amdgcn_s_setprio(3);
+        GnoProd P;
+        P.init(wave, lane, rowptr, idx, eidx, y, coords, theta, d, n_rows, perm, y_bytes, c_bytes, id_bytes, VPW);
+        const int p = P.p;
+        GnoIds cur, nxt;
+        P.ids_rows(blockIdx.x, cur); P.ids_ptrs(cur); P.ids_entries(cur); P.ids_finish(cur);
+        nxt = cur;
+        // per vertex and block of 16 entries, for the whole tile: the byte offset of entry n's feature chunk g, and the
+        // h MFMA's A operand (coordinate g of entry n's edge; 1 at g = d)
+        uint32_t xoff[VPW][NB];
+        float cvv[VPW][NB];
+        auto derive = [&](int vi, const GnoIds &I) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                xoff[vi][b] = (uint32_t)__shfl(b ? I.J1 : I.J0, 16 * vi + n) + 16u * g;
+                const uint32_t e = (uint32_t)__shfl(b ? I.E1 : I.E0, 16 * vi + n) + P.g4;
+                cvv[vi][b] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(P.crs, (int)e, 0, 0));
+            }
+        };
+        v4f_g XL[VPW][NB];   // the neighbours' feature chunks of the piece being consumed next
+        auto xload = [&](int vi, int c) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+                XL[vi][b] = __builtin_bit_cast(v4f_g, __builtin_amdgcn_raw_buffer_load_b128(P.yrs, (int)xoff[vi][b], 64 * c, 0));
+        };
+#pragma unroll
+        for (int vi = 0; vi < VPW; ++vi) {
+            derive(vi, cur);
+            xload(vi, 0);
+        }
+        const v4f_g z = {0.0f, 0.0f, 0.0f, 0.0f};
+        v4f_g dacc[VPW][NB][2];   // [vertex][block][16 hidden units]: dh^T[entry 4 g + r][hid n], summed over the four c of a kh
+        v4f_g accU[4] = {z, z, z, z};   // [16 hidden units]: lane (coordinate n, g): [dU | db_u][hid 4 g + r][n]
+#pragma unroll
+        for (int vi = 0; vi < VPW; ++vi)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) dacc[vi][b][0] = dacc[vi][b][1] = z;
+        __syncthreads();
+        for (int ti = 0; ti < nt; ++ti) {
+            const int tile = blockIdx.x + ti * gridDim.x;
+            const bool more = ti + 1 < nt;
+#pragma unroll 1
+            for (int pcp = 0; pcp < 8; ++pcp) {
+                const int kh = pcp >> 2, c = pcp & 3;
+                const float *buf = Gbuf + (size_t)((ti * 8 + pcp) & 1) * TV * kPPitch;
+                if (more) {
+                    if (pcp == 0) P.ids_rows(tile + gridDim.x, nxt);
+                    if (pcp == 2) P.ids_ptrs(nxt);
+                    if (pcp == 4) P.ids_entries(nxt);
+                    if (pcp == 6) P.ids_finish(nxt);
+                }
+                const bool last = pcp == 7;
+                const float ub0 = kh ? P.Ub[2] : P.Ub[0], ub1 = kh ? P.Ub[3] : P.Ub[1];
+                {
+#pragma unroll
+                    for (int vi = 0; vi < VPW; ++vi) {
+                        // G of the vertex: lane (hid n [+ 16], chunk g)
+                        const float *grow = buf + (size_t)(VPW * p + vi) * kPPitch;
+                        const v4f_g b0 = *reinterpret_cast<const v4f_g *>(grow + gno_gpos(n, g));
+                        const v4f_g b1 = *reinterpret_cast<const v4f_g *>(grow + gno_gpos(16 + n, g));
+#pragma unroll
+                        for (int b = 0; b < NB; ++b)
+#pragma unroll
+                            for (int s4 = 0; s4 < 4; ++s4) {
+                                dacc[vi][b][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(XL[vi][b][s4], b0[s4], dacc[vi][b][0], 0, 0, 0);
+                                dacc[vi][b][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(XL[vi][b][s4], b1[s4], dacc[vi][b][1], 0, 0, 0);
+                            }
+                        if (c == 3) {
+                            // the kh's 32 hidden units are complete for this vertex: mask, store, fold into dU / db_u
+                            const int w0 = cur.w0[vi], len = cur.len[vi];
+#pragma unroll
+                            for (int b = 0; b < NB; ++b) {
+                                const float cv = P.g_is_d ? 1.0f : cvv[vi][b];
+                                const v4f_g h0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cv, ub0, z, 0, 0, 0);
+                                const v4f_g h1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cv, ub1, z, 0, 0, 0);
+                                // [dx_e ; 1] as the B operand of the dU MFMA: lane (coordinate n, g), step r = entry 4 g + r
+                                float dxT[4];
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const uint32_t eo = (uint32_t)__shfl(b ? cur.E1 : cur.E0, 16 * vi + 4 * g + r) + P.n4;
+                                    dxT[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(P.crs, (int)(n < d ? eo : GnoProd::kDead), 0, 0));
+                                }
+                                v4f_g m0, m1;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    m0[r] = h0[r] > 0.0f ? dacc[vi][b][0][r] : 0.0f;
+                                    m1[r] = h1[r] > 0.0f ? dacc[vi][b][1][r] : 0.0f;
+                                    if (WRITE_GH) {
+                                        const int e = 16 * b + 4 * g + r;
+                                        if (e < len) {
+                                            float *gp = ghbuf + (size_t)(w0 + e) * kGH + 32 * kh + n;
+                                            gp[0] = m0[r];
+                                            gp[16] = m1[r];
+                                        }
+                                    }
+                                }
+                                if (kh == 0) {   // (static register names: a run-time index would put accU in scratch)
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) {
+                                        const float bx = n == d ? 1.0f : dxT[r];
+                                        accU[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(m0[r], bx, accU[0], 0, 0, 0);
+                                        accU[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(m1[r], bx, accU[1], 0, 0, 0);
+                                    }
+                                } else {
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) {
+                                        const float bx = n == d ? 1.0f : dxT[r];
+                                        accU[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(m0[r], bx, accU[2], 0, 0, 0);
+                                        accU[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(m1[r], bx, accU[3], 0, 0, 0);
+                                    }
+                                }
+                                dacc[vi][b][0] = dacc[vi][b][1] = z;
+                            }
+                        }
+                        // the next piece's feature chunks (from a tile's last piece on: the next tile's)
+                        if (last) derive(vi, nxt);
+                        xload(vi, (c + 1) & 3);
+                    }
+                }
+                if (last) cur = nxt;
+                __syncthreads();
+            }
+        }
+        // lane (coordinate n, g): accU[t][r] = [dU | db_u][hid 16 t + 4 g + r][n]; theta keeps U as [k + 64 j], b_u behind it
+        float *sl = slabs + (size_t)(blockIdx.x * 8 + p) * (kGH * d + kGH);
+        if (n <= d) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sl[16 * t + 4 * g + r + kGH * n] = accU[t][r];
+        }
+    }
+}
+
 int gno_mlp_backward(const athena_mp_graph *g, int d, int H, int Fi, int Fo, const float *theta,
                      const float *coords, const float *x, const float *grad, float *dtheta, float *dcoords)
 {
@@ -1656,33 +1915,76 @@ int gno_mlp_backward(const athena_mp_graph *g, int d, int H, int Fi, int Fo, con
         ghbuf = (float *)p;
     }
     if (gno_gdh_shape(H, Fi, Fo, d) && g->n_rows > 0) {
-        // one launch over all vertices: G is produced and consumed inside the workgroup
-        if (length_order(g->rowptr, g->n_rows, &g->len_perm_fwd)) return 1;
-        void *vp = nullptr, *sl = nullptr;
-        if (amp::workspace(&vp, sizeof(float) * 64 * 64 * 64, 1)) return 1;
-        hipLaunchKernelGGL(gno_vperm_okq_kernel, dim3(64 * 64 * 64 / 256), dim3(256), 0, amp::stream(), theta + off_V, (float *)vp);
-        AMP_LAUNCH_CHECK();
-        const int n_tiles = (g->n_rows + kGRows - 1) / kGRows;
-        const int nwg = std::min(n_tiles, 256);
-        if (amp::workspace(&sl, sizeof(float) * (size_t)nwg * 16 * np, 3)) return 1;
-        constexpr size_t glds = sizeof(float) * ((size_t)kGRows * kDVtx + 16 * 128);   // G half + per-wave coordinates
-        static amp::PerDeviceFlag gattr;
-        if (!gattr.get()) {
-            AMP_HIP(hipFuncSetAttribute((const void *)gno_gdh_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
-            AMP_HIP(hipFuncSetAttribute((const void *)gno_gdh_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
-            gattr.get() = true;
+        // G is produced and consumed inside the workgroup.  Rows of at most 32 entries (all but a handful) go through the
+        // dense / sparse kernel, the longer ones -- they head the length-ordered list -- through gno_gdh_kernel.
+        if (length_order(g->rowptr, g->n_rows, &g->len_perm_fwd, &g->n_long_fwd, &g->n_mid_fwd)) return 1;
+        static const bool v1 = getenv("ATHENA_MP_GNO_GDH_V1") != nullptr;   // A/B switch: every row through gno_gdh_kernel
+        const size_t y_bytes = sizeof(float) * kGF * (size_t)g->n_cols, c_bytes = sizeof(float) * (size_t)d * g->n_edge_cols,
+                     id_bytes = sizeof(int32_t) * (size_t)g->nnz, g_bytes = sizeof(float) * kGF * (size_t)g->n_rows;
+        const size_t lim = 0xFFFFE000ull;
+        const bool pc_ok = !v1 && d <= 3 && y_bytes < lim && c_bytes < lim && id_bytes < lim && g_bytes < lim;
+        // three classes of the length-ordered list: > 32 entries | 17 .. 32 (2 vertices per sparse wave, 2 blocks) | <= 16 (4, 1)
+        const int n_old = pc_ok ? g->n_long_fwd : g->n_rows, n_mid = pc_ok ? g->n_mid_fwd - g->n_long_fwd : 0,
+                  n_short = g->n_rows - n_old - n_mid;
+        void *vp = nullptr, *vd = nullptr, *sl = nullptr;
+        const int nwg_old = std::min((n_old + kGRows - 1) / kGRows, 256), nwg_mid = std::min((n_mid + 15) / 16, amp::num_cus()),
+                  nwg_short = std::min((n_short + 31) / 32, amp::num_cus());
+        const int n_slabs = nwg_old * 16 + (nwg_mid + nwg_short) * 8;
+        if (amp::workspace(&sl, sizeof(float) * (size_t)n_slabs * np, 3)) return 1;
+        const int32_t *perm = (const int32_t *)g->len_perm_fwd;
+        if (n_old > 0) {
+            if (amp::workspace(&vp, sizeof(float) * 64 * 64 * 64, 1)) return 1;
+            hipLaunchKernelGGL(gno_vperm_okq_kernel, dim3(64 * 64 * 64 / 256), dim3(256), 0, amp::stream(), theta + off_V, (float *)vp);
+            AMP_LAUNCH_CHECK();
+            constexpr size_t glds = sizeof(float) * ((size_t)kGRows * kDVtx + 16 * 128);   // G half + per-wave coordinates
+            static amp::PerDeviceFlag gattr;
+            if (!gattr.get()) {
+                AMP_HIP(hipFuncSetAttribute((const void *)gno_gdh_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
+                AMP_HIP(hipFuncSetAttribute((const void *)gno_gdh_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
+                gattr.get() = true;
+            }
+            if (ghbuf)
+                hipLaunchKernelGGL(gno_gdh_kernel<true>, dim3(nwg_old), dim3(1024), glds, amp::stream(), g->rowptr, g->col, g->eid, x,
+                                   coords, theta, d, (const float *)vp, grad, n_old, perm, (float *)sl, ghbuf);
+            else
+                hipLaunchKernelGGL(gno_gdh_kernel<false>, dim3(nwg_old), dim3(1024), glds, amp::stream(), g->rowptr, g->col, g->eid, x,
+                                   coords, theta, d, (const float *)vp, grad, n_old, perm, (float *)sl, ghbuf);
+            AMP_LAUNCH_CHECK();
         }
-        if (ghbuf)
-            hipLaunchKernelGGL(gno_gdh_kernel<true>, dim3(nwg), dim3(1024), glds, amp::stream(), g->rowptr, g->col, g->eid, x,
-                               coords, theta, d, (const float *)vp, grad, g->n_rows, (const int32_t *)g->len_perm_fwd,
-                               (float *)sl, ghbuf);
-        else
-            hipLaunchKernelGGL(gno_gdh_kernel<false>, dim3(nwg), dim3(1024), glds, amp::stream(), g->rowptr, g->col, g->eid, x,
-                               coords, theta, d, (const float *)vp, grad, g->n_rows, (const int32_t *)g->len_perm_fwd,
-                               (float *)sl, ghbuf);
-        AMP_LAUNCH_CHECK();
+        if (n_mid + n_short > 0) {
+            if (amp::workspace(&vd, sizeof(float) * 64 * 64 * 64, 9)) return 1;
+            hipLaunchKernelGGL(gno_vrelay_dense_kernel, dim3(64 * 64 * 64 / 256), dim3(256), 0, amp::stream(), theta + off_V, (float *)vd);
+            AMP_LAUNCH_CHECK();
+            constexpr size_t dlds = sizeof(float) * (size_t)kDhLdsFloats;
+            static amp::PerDeviceFlag dattr;
+            if (!dattr.get()) {
+                AMP_HIP(hipFuncSetAttribute((const void *)gno_dh_pc_kernel<false, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds));
+                AMP_HIP(hipFuncSetAttribute((const void *)gno_dh_pc_kernel<true, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds));
+                AMP_HIP(hipFuncSetAttribute((const void *)gno_dh_pc_kernel<false, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds));
+                AMP_HIP(hipFuncSetAttribute((const void *)gno_dh_pc_kernel<true, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds));
+                dattr.get() = true;
+            }
+#define AMP_DHPC(GH_, VPW_, NB_, NWG_, NROWS_, PERM_, SL_)                                                                          \
+    hipLaunchKernelGGL((gno_dh_pc_kernel<GH_, VPW_, NB_>), dim3(NWG_), dim3(kPcThreads), dlds, amp::stream(), g->rowptr, g->col, g->eid, \
+                       x, coords, theta, d, (const float *)vd, grad, NROWS_, PERM_, SL_, ghbuf, (uint32_t)y_bytes, (uint32_t)c_bytes, \
+                       (uint32_t)id_bytes, (uint32_t)g_bytes)
+            float *sl_mid = (float *)sl + (size_t)nwg_old * 16 * np, *sl_short = sl_mid + (size_t)nwg_mid * 8 * np;
+            if (n_mid > 0) {
+                if (ghbuf) AMP_DHPC(true, 2, 2, nwg_mid, n_mid, perm + n_old, sl_mid);
+                else AMP_DHPC(false, 2, 2, nwg_mid, n_mid, perm + n_old, sl_mid);
+                AMP_LAUNCH_CHECK();
+            }
+            if (n_short > 0) {
+                if (ghbuf) AMP_DHPC(true, 4, 1, nwg_short, n_short, perm + n_old + n_mid, sl_short);
+                else AMP_DHPC(false, 4, 1, nwg_short, n_short, perm + n_old + n_mid, sl_short);
+                AMP_LAUNCH_CHECK();
+            }
+#undef AMP_DHPC
+        }
+        const int nwg = n_slabs / 16;   // (slab_reduce below takes the slab count)
+        (void)nwg;
         if (dtheta) {
-            if (int rc2 = amp::slab_reduce((const float *)sl, nwg * 16, np, dtheta, false)) return rc2;
+            if (int rc2 = amp::slab_reduce((const float *)sl, n_slabs, np, dtheta, false)) return rc2;
         }
         if (dcoords && g->n_edge_cols > 0) {
             int64_t n = (int64_t)g->n_edge_cols * d;
@@ -1760,7 +2062,7 @@ int athena_mp_gno_aggregate_fwd(const athena_mp_graph *g, int32_t d, int32_t H, 
     const int R = (H + 1) * Fi;
     if (gno_fused_shape(H, Fi, Fo, d))
         return launch_gno_fused(g->rowptr, g->col, g->eid, x, coords, theta, d, theta + off_V, g->n_rows, &g->len_perm_fwd, m,
-                                g->n_cols, g->n_edge_cols, g->nnz);
+                                g->n_cols, g->n_edge_cols, g->nnz, &g->n_long_fwd, &g->n_mid_fwd);
     const int tile = tile_rows_for(g->n_rows, R);
     for (int r0 = 0; r0 < g->n_rows; r0 += tile) {
         const int rows = std::min(tile, g->n_rows - r0);

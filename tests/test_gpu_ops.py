@@ -497,6 +497,48 @@ def test_gno_fused_kernel_hub_rows_tail_tiles_and_self_loops(dev, oracle, d, loo
     assert torch_equal_twice(lambda: ops.gno_aggregate(dg, th, co, T(x, dev), d, Hh, Fo))   # deterministic
 
 
+@pytest.mark.parametrize("d,loops", [(3, False), (2, True)])
+def test_gno_fused_kernels_many_tiles_per_workgroup(dev, oracle, d, loops):
+    """the producer / consumer GNO kernels (aggregate, dx, and the S^T g half of dtheta) on a graph whose 32-vertex
+    tiles outnumber the workgroups' tile classes (several tiles per workgroup, id queue in steady state), with rows
+    of 33 .. 150 entries (blocks beyond the 32 prefetched ones), isolated vertices and a ragged last tile; forward,
+    dx, dtheta and dcoords against the materialising oracle"""
+    from athena_amd import DeviceGraph, ops
+    from oracle import oracle64 as o64
+
+    rng = np.random.default_rng(70 + d)
+    N = 2101
+    pairs = [[i, i + 1] for i in range(1, N - 6)]
+    pairs += [[11, int(v)] for v in rng.choice(np.arange(13, N - 6), 150, replace=False)]
+    for hub in (400, 900, 1500):
+        pairs += [[hub, int(v)] for v in rng.choice(np.arange(hub + 2, N - 6), 33 + hub % 7, replace=False)]
+    pairs += [[int(a), int(b)] for a, b in rng.integers(1, N - 5, (2500, 2)) if a != b]
+    pairs = np.array(pairs).T
+    g = csr_from_index_list(N, pairs, self_loops=loops)
+    E = pairs.shape[1]
+    deg = np.diff(g.adj_ia)
+    assert deg.max() > 128 and ((deg > 32) & (deg < 64)).any() and N % 32 != 0 and N // 32 > 64
+    Hh = Fi = Fo = 64
+    coords = rng.standard_normal((E, d)).astype(np.float32)
+    x = rng.uniform(-1, 1, (N, Fi)).astype(np.float32)
+    theta = (0.3 * rng.standard_normal(Hh * d + Hh + Fo * Fi * Hh + Fo * Fi)).astype(np.float32)
+    up = rng.uniform(-1, 1, (N, Fo)).astype(np.float32)
+    ia, ja = g.adj_ia, g.adj_ja
+    dg = DeviceGraph(ia, ja, n_edge_cols=E)
+    kap = oracle.gno_kernel_eval(coords, theta, Hh, Fo * Fi)
+    th, co, xd, gd = T(theta, dev), T(coords, dev), T(x, dev), T(up, dev)
+    assert_close(H_(ops.gno_aggregate(dg, th, co, xd, d, Hh, Fo)), oracle.gno_aggregate(x, kap, ia, ja, Fo), 1e-5, "gno fwd")
+    assert_close(H_(ops.gno_aggregate_bwd_x(dg, th, co, gd, d, Hh, Fi)), oracle.gno_aggregate_bwd_x(up, kap, ia, ja, Fi), 1e-5, "gno dx")
+    dk = oracle.gno_aggregate_bwd_k(up, x, E, ia, ja)
+    dk64 = lambda: o64.gno_aggregate_bwd_k(up, x, E, ia, ja)
+    dth = ops.gno_aggregate_bwd_theta(dg, th, co, xd, gd, d, Hh)
+    assert_close(H_(dth), oracle.gno_kernel_bwd_theta(coords, theta, dk, Hh), 1e-5, "gno dtheta",
+                 f64=lambda: o64.gno_kernel_bwd_theta(coords, theta, dk64(), Hh))
+    assert torch.equal(dth, ops.gno_aggregate_bwd_theta(dg, th, co, xd, gd, d, Hh))     # deterministic
+    assert_close(H_(ops.gno_aggregate_bwd_coords(dg, th, co, xd, gd, d, Hh)), oracle.gno_kernel_bwd_coords(coords, theta, dk, Hh), 1e-5,
+                 "gno dcoords", f64=lambda: o64.gno_kernel_bwd_coords(coords, theta, dk64(), Hh))
+
+
 def torch_equal_twice(fn):
     import torch
     return torch.equal(fn(), fn())
