@@ -110,9 +110,12 @@ else:
     # re-associated algorithm, fused (S stays on chip): the contraction N*2*Fo*(H+1)*Fi bounds it on the fp32 matrix pipe
     alg_fwd = nnz * (4 * Fi + 4 * d + 8) + N * (4 * Fo + 4)
     flops_fwd = nnz * 2 * H * (Fi + d) + N * 2 * Fo * R
-    roof = {"fwd": {"bound": "mfma", "TFLOPs": round(flops_fwd / (t["fwd"] * 1e-3) / 1e12, 1),
-                    "frac_of_157_TFLOPs_fp32_mfma": round(flops_fwd / (t["fwd"] * 1e-3) / 157e12, 3),
-                    "algorithmic_GB": round(alg_fwd / 1e9, 1), "GBps": round(alg_fwd / (t["fwd"] * 1e-3) / 1e9, 1)}}
+    # dx: the same two pieces over the transposed CSR.  dtheta: outer product + S^T g, and G = g Vmat^T + per-entry dh
+    flops = {"fwd": flops_fwd, "bwd_x": nnz * 2 * H * (Fo + d) + N * 2 * Fi * (H + 1) * Fo,
+             "bwd_theta": nnz * 2 * H * (Fi + d) + N * 2 * Fo * R + N * 2 * Fo * H * Fi + nnz * 2 * H * (Fi + d + 1)}
+    roof = {k: {"bound": "mfma", "TFLOP": round(flops[k] / 1e12, 3), "TFLOPs": round(flops[k] / (t[k] * 1e-3) / 1e12, 1),
+                "frac_of_157_TFLOPs_fp32_mfma": round(flops[k] / (t[k] * 1e-3) / 157e12, 3)} for k in t}
+    roof["fwd"].update({"algorithmic_GB": round(alg_fwd / 1e9, 1), "GBps": round(alg_fwd / (t["fwd"] * 1e-3) / 1e9, 1)})
     if a.no_cpu:
         print(json.dumps({"ms": {k: round(v, 3) for k, v in t.items()}, "total_ms": tot, "roofline": roof})); sys.exit(0)
     # CPU: the reference's MATERIALISING algorithm is infeasible at this size (246 GB kernel tensor); time it
