@@ -488,8 +488,8 @@ __global__ void gno_vrelay_kernel(const float *__restrict__ Vin, float *__restri
         const int L = 16 * gi + 4 * g + s;
         const int row = L >> 4, q = L & 15;
         const int tp = row >> 4, r = (row >> 2) & 3, gg = row & 3;
-        const int k = 32 * (pc & 1) + 16 * tp + 4 * gg + r;
-        const int qg = 16 * (pc >> 1) + q;
+        const int k = 32 * (pc >> 2) + 16 * tp + 4 * gg + r;   // pieces in the order (kh, c): pc = 4 kh + c
+        const int qg = 16 * (pc & 3) + q;
         Vp[t] = Vin[(size_t)(k * 64 + qg) * 64 + o];
     } else {
         const int u = t - 64 * 64 * 64;   // [ot][gi (4)][lane][s]
@@ -629,17 +629,29 @@ struct GnoProd {
     // S piece of one vertex from its operands: acc[t][r2] = S[hid = 16 t + 4 g + r2][q = n], NST groups of four entries.
     // NST is a compile-time constant: branches around single steps (or a switch that falls through them) make the
     // compiler copy the accumulators between register sets at every step.
-    template <int NST>
+    // HC: the relu'd h of the first 16 entries depends on kh only -- 0: computed here; 1: computed here and kept in hc;
+    //     2: taken from hc (the pieces of one kh follow each other in gno_pc_kernel)
+    template <int NST, int HC = 0>
     __device__ __forceinline__ void compute(const GnoLoads &L, const float (&cvs)[2], float ub0, float ub1, v4f_g (&acc)[2],
-                                            float &bs) const
+                                            float &bs, v4f_g *hc = nullptr) const
     {
         const v4f_g z = {0.0f, 0.0f, 0.0f, 0.0f};
         {
-            const float cv = g_is_d ? 1.0f : cvs[0];
-            v4f_g h0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cv, ub0, z, 0, 0, 0);
-            v4f_g h1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cv, ub1, z, 0, 0, 0);
-            relu4(h0);
-            relu4(h1);
+            v4f_g h0, h1;
+            if constexpr (HC == 2) {
+                h0 = hc[0];
+                h1 = hc[1];
+            } else {
+                const float cv = g_is_d ? 1.0f : cvs[0];
+                h0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cv, ub0, z, 0, 0, 0);
+                h1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cv, ub1, z, 0, 0, 0);
+                relu4(h0);
+                relu4(h1);
+                if constexpr (HC == 1) {
+                    hc[0] = h0;
+                    hc[1] = h1;
+                }
+            }
             acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(h0[0], L.x[0], z, 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(h1[0], L.x[0], z, 0, 0, 0);
 #pragma unroll
@@ -716,6 +728,8 @@ __global__ __launch_bounds__(kPcThreads) void gno_pc_kernel(const int32_t *__res
 #pragma unroll
         for (int vi = 0; vi < 4; ++vi) P.issue(LS[vi], pJ0, pJ1, vi, 0, true);
         float CV[4][2];   // coordinates of the tile's slots; refilled for the next tile after the last piece has read them
+        constexpr int kHCache = 2;   // vertices of the wave whose h (first 16 entries) is kept over the four pieces of a kh:
+        v4f_g HCc[kHCache][2];       // 8 registers each -- the 168 do not hold all four
 #pragma unroll
         for (int vi = 0; vi < 4; ++vi) P.load_cv(CV[vi], cur.E0, cur.E1, vi);
         for (int ti = 0; ti < nt; ++ti) {
@@ -726,7 +740,7 @@ __global__ __launch_bounds__(kPcThreads) void gno_pc_kernel(const int32_t *__res
             int nstN = nstT;   // the next tile's (known from its third piece on; its rows are not longer than this tile's)
 #pragma unroll 1
             for (int pc = 0; pc < 8; ++pc) {
-                const int c = pc >> 1, kh = pc & 1;
+                const int c = pc & 3, kh = pc >> 2;   // the four feature quarters of a kh follow each other: h is kept
                 float *buf = Sbuf + (size_t)((ti * 8 + pc) & 1) * kPV * kPPitch;
                 float *bb = Bbuf + (size_t)(ti & 1) * kPV * kPBPitch;
                 const float ub0 = kh ? Ub[2] : Ub[0], ub1 = kh ? Ub[3] : Ub[1];
@@ -742,18 +756,19 @@ __global__ __launch_bounds__(kPcThreads) void gno_pc_kernel(const int32_t *__res
                 }
                 // the refill is unconditional: from a tile's last piece on it reads the next tile's rows (the last tile of
                 // all re-reads its own: harmless, nothing consumes them)
-                const int cn = ((pc + 1) & 7) >> 1;                       // feature quarter of the next piece
+                const int cn = (pc + 1) & 3;                              // feature quarter of the next piece
                 const bool last = pc == 7;
                 if (last) { pJ0 = nxt.J0; pJ1 = nxt.J1; }
                 const bool second = (last ? nstN : nstT) > 4;   // does the piece being requested read entries 16 .. 31
                 // the four vertices of the wave with the step count of the longest of them as a compile-time constant
                 // (tiles hold vertices of nearly equal length, so the shorter rows' extra steps -- on zeros -- are few)
-                auto four = [&](auto K) {
+                auto four = [&](auto K, auto FILL) {
 #pragma unroll
                     for (int vi = 0; vi < ((GNO_FV & 32) ? 0 : 4); ++vi) {
                         v4f_g acc[2];
                         float bs;
-                        P.compute<decltype(K)::value>(LS[vi], CV[vi], ub0, ub1, acc, bs);
+                        if (vi < kHCache) P.compute<decltype(K)::value, decltype(FILL)::value ? 1 : 2>(LS[vi], CV[vi], ub0, ub1, acc, bs, HCc[vi]);
+                        else P.compute<decltype(K)::value>(LS[vi], CV[vi], ub0, ub1, acc, bs);
                         P.issue(LS[vi], pJ0, pJ1, vi, cn, second);
                         if (last) P.load_cv(CV[vi], nxt.E0, nxt.E1, vi);
                         const int v = 4 * p + vi;
@@ -769,17 +784,20 @@ __global__ __launch_bounds__(kPcThreads) void gno_pc_kernel(const int32_t *__res
                         }
                     }
                 };
-                switch (nstT) {
-                case 0:
-                case 1: four(std::integral_constant<int, 1>{}); break;
-                case 2: four(std::integral_constant<int, 2>{}); break;
-                case 3: four(std::integral_constant<int, 3>{}); break;
-                case 4: four(std::integral_constant<int, 4>{}); break;
-                case 5: four(std::integral_constant<int, 5>{}); break;
-                case 6: four(std::integral_constant<int, 6>{}); break;
-                case 7: four(std::integral_constant<int, 7>{}); break;
-                default: four(std::integral_constant<int, 8>{}); break;
-                }
+#define GNO_FOUR(FILL_)                                                             \
+    switch (nstT) {                                                                \
+    case 0:                                                                        \
+    case 1: four(std::integral_constant<int, 1>{}, std::integral_constant<bool, FILL_>{}); break; \
+    case 2: four(std::integral_constant<int, 2>{}, std::integral_constant<bool, FILL_>{}); break; \
+    case 3: four(std::integral_constant<int, 3>{}, std::integral_constant<bool, FILL_>{}); break; \
+    case 4: four(std::integral_constant<int, 4>{}, std::integral_constant<bool, FILL_>{}); break; \
+    case 5: four(std::integral_constant<int, 5>{}, std::integral_constant<bool, FILL_>{}); break; \
+    case 6: four(std::integral_constant<int, 6>{}, std::integral_constant<bool, FILL_>{}); break; \
+    case 7: four(std::integral_constant<int, 7>{}, std::integral_constant<bool, FILL_>{}); break; \
+    default: four(std::integral_constant<int, 8>{}, std::integral_constant<bool, FILL_>{}); break; \
+    }
+                if (c == 0) { GNO_FOUR(true) } else { GNO_FOUR(false) }
+#undef GNO_FOUR
                 // rows longer than 32 entries (none at BASELINE configs[3]): the remaining blocks are added to the vertex's
                 // own LDS row; plain loads, nothing prefetched
                 if (maxlen > 32) {
