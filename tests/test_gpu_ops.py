@@ -497,7 +497,7 @@ def test_gno_fused_kernel_hub_rows_tail_tiles_and_self_loops(dev, oracle, d, loo
     assert torch_equal_twice(lambda: ops.gno_aggregate(dg, th, co, T(x, dev), d, Hh, Fo))   # deterministic
 
 
-@pytest.mark.parametrize("d,loops", [(3, False), (2, True)])
+@pytest.mark.parametrize("d,loops", [(3, False), (2, True), (1, False)])
 def test_gno_fused_kernels_many_tiles_per_workgroup(dev, oracle, d, loops):
     """the producer / consumer GNO kernels (aggregate, dx, and the S^T g half of dtheta) on a graph whose 32-vertex
     tiles outnumber the workgroups' tile classes (several tiles per workgroup, id queue in steady state), with rows
