@@ -539,6 +539,46 @@ def test_gno_fused_kernels_many_tiles_per_workgroup(dev, oracle, d, loops):
                  "gno dcoords", f64=lambda: o64.gno_kernel_bwd_coords(coords, theta, dk64(), Hh))
 
 
+def test_gno_fused_kernels_rectangular_rows_subset(dev, oracle):
+    """the fused GNO kernels on a RECTANGULAR graph (a shard's rows against all columns: gathered features have n_cols
+    rows, gradients n_rows): aggregate, dx (n_cols rows out) and dtheta against the oracle on the same graph padded
+    with empty rows to square"""
+    from athena_amd import DeviceGraph, ops
+
+    rng = np.random.default_rng(91)
+    N, d, Hh, Fi, Fo = 1500, 3, 64, 64, 64
+    pairs = [[i, i + 1] for i in range(1, N)]
+    pairs += [[20, int(v)] for v in rng.choice(np.arange(30, N), 40, replace=False)]
+    pairs += [[int(a), int(b)] for a, b in rng.integers(1, N + 1, (2600, 2)) if a != b]
+    pairs = np.array(pairs).T
+    g = csr_from_index_list(N, pairs)
+    E = pairs.shape[1]
+    R = 701                                                   # the shard: the first R rows
+    ia, ja = g.adj_ia, g.adj_ja
+    ia_r = ia[: R + 1].copy()
+    ja_r = np.asfortranarray(ja[:, : ia_r[-1] - 1])
+    ia_sq = np.concatenate([ia_r, np.full(N - R, ia_r[-1], np.int32)])
+    coords = rng.standard_normal((E, d)).astype(np.float32)
+    x = rng.uniform(-1, 1, (N, Fi)).astype(np.float32)
+    theta = (0.3 * rng.standard_normal(Hh * d + Hh + Fo * Fi * Hh + Fo * Fi)).astype(np.float32)
+    up = rng.uniform(-1, 1, (R, Fo)).astype(np.float32)
+    up_sq = np.zeros((N, Fo), np.float32); up_sq[:R] = up
+    dg = DeviceGraph(ia_r, ja_r, n_cols=N, n_edge_cols=E, row_deg=np.diff(ia_r), col_deg=np.diff(ia))   # (degrees: unused by GNO)
+    kap = oracle.gno_kernel_eval(coords, theta, Hh, Fo * Fi)
+    th, co, xd, gd = T(theta, dev), T(coords, dev), T(x, dev), T(up, dev)
+    m = H_(ops.gno_aggregate(dg, th, co, xd, d, Hh, Fo))
+    assert m.shape == (R, Fo)
+    assert_close(m, oracle.gno_aggregate(x, kap, ia_sq, ja_r, Fo)[:R], 1e-5, "gno fwd, rectangular")
+    dx = H_(ops.gno_aggregate_bwd_x(dg, th, co, gd, d, Hh, Fi))
+    assert dx.shape == (N, Fi)
+    assert_close(dx, oracle.gno_aggregate_bwd_x(up_sq, kap, ia_sq, ja_r, Fi), 1e-5, "gno dx, rectangular")
+    dk = oracle.gno_aggregate_bwd_k(up_sq, x, E, ia_sq, ja_r)
+    from oracle import oracle64 as o64
+    assert_close(H_(ops.gno_aggregate_bwd_theta(dg, th, co, xd, gd, d, Hh)), oracle.gno_kernel_bwd_theta(coords, theta, dk, Hh), 1e-5,
+                 "gno dtheta, rectangular",
+                 f64=lambda: o64.gno_kernel_bwd_theta(coords, theta, o64.gno_aggregate_bwd_k(up_sq, x, E, ia_sq, ja_r), Hh))
+
+
 def torch_equal_twice(fn):
     import torch
     return torch.equal(fn(), fn())
