@@ -907,7 +907,7 @@ __global__ __launch_bounds__(kPcThreads) void gno_pc_kernel(const int32_t *__res
 // The same producers, the contraction turned round: out[kq][o] = sum_v S[v][kq] g[v][o] contracts over the VERTICES, so
 // its 4160 x 64 accumulators must stay put while the vertices stream by.  A workgroup therefore owns ONE piece (c, kh) of
 // S for its whole life -- 512 x 64 sums = 128 registers per lane of its four consumer waves -- and every 32nd tile:
-// workgroup b: piece b % 8, tiles b / 8, b / 8 + 32, ...  Per tile its producers build just that piece (the gathers of a
+// workgroup b: piece b % 8, tiles b / 8, b / 8 + nsub, ... (nsub = 32 tile classes on a full-size graph)  Per tile its producers build just that piece (the gathers of a
 // tile are shared out over the eight workgroups that visit it: each reads its own 64-byte quarter of the feature rows), and
 // put the tile's 32 gradient rows beside it in LDS.  The bias row (sum of x_j) meets g on the producers' own MFMAs
 // (K = the four vertices of a wave).  256 partial slabs (33 MB) are summed in a fixed order by gno_stg_reduce_kernel,
@@ -922,7 +922,7 @@ __global__ __launch_bounds__(kPcThreads) void gno_stg_kernel(const int32_t *__re
                                                        int d, const float *__restrict__ grad, int n_rows,
                                                        const int32_t *__restrict__ perm, float *__restrict__ slab,
                                                        float *__restrict__ slabB, uint32_t y_bytes, uint32_t c_bytes,
-                                                       uint32_t id_bytes, uint32_t g_bytes)
+                                                       uint32_t id_bytes, uint32_t g_bytes, int nsub)
 {
     extern __shared__ __attribute__((aligned(16))) float Sh[];
     float *Sbuf = Sh;                                   // [2][32][520]
@@ -931,7 +931,7 @@ __global__ __launch_bounds__(kPcThreads) void gno_stg_kernel(const int32_t *__re
     const int n = lane & 15, g = lane >> 4;
     const int pc = blockIdx.x & 7, sub = blockIdx.x >> 3, c = pc >> 1, kh = pc & 1;
     const int n_tiles = (n_rows + kPV - 1) / kPV;
-    const int nt = sub < n_tiles ? (n_tiles - sub + 31) / 32 : 0;   // tiles of this workgroup
+    const int nt = sub < n_tiles ? (n_tiles - sub + nsub - 1) / nsub : 0;   // tiles of this workgroup: sub, sub + nsub, ...
 
     if (wave < 8) {
         // ======================================= producer =======================================
@@ -955,9 +955,9 @@ __global__ __launch_bounds__(kPcThreads) void gno_stg_kernel(const int32_t *__re
         //   during this interval | T0 the tile being built
         GnoIds T0, T1, T2, T3, T4;
         P.ids_rows(sub, T0); P.ids_ptrs(T0); P.ids_entries(T0); P.ids_finish(T0);
-        P.ids_rows(sub + 32, T1); P.ids_ptrs(T1); P.ids_entries(T1);
-        P.ids_rows(sub + 64, T2); P.ids_ptrs(T2);
-        P.ids_rows(sub + 96, T3);
+        P.ids_rows(sub + nsub, T1); P.ids_ptrs(T1); P.ids_entries(T1);
+        P.ids_rows(sub + 2 * nsub, T2); P.ids_ptrs(T2);
+        P.ids_rows(sub + 3 * nsub, T3);
         T4 = T3;
         GnoLoads LS[4];
         float CV[4][2], GV[4];
@@ -971,7 +971,7 @@ __global__ __launch_bounds__(kPcThreads) void gno_stg_kernel(const int32_t *__re
         v4f_g accB[4] = {z, z, z, z};   // bias rows: [o = 16 ot + 4 g + r][q = 16 c + n], kh = 0 workgroups only
 #pragma unroll 1
         for (int j = 0; j < nt; ++j) {
-            P.ids_rows(sub + 32 * (j + 4), T4);
+            P.ids_rows(sub + nsub * (j + 4), T4);
             P.ids_ptrs(T3);
             P.ids_entries(T2);
             P.ids_finish(T1);
@@ -1112,8 +1112,8 @@ __global__ __launch_bounds__(kPcThreads) void gno_stg_kernel(const int32_t *__re
     }
 }
 
-// dVaug[kq][o] = the 32 slabs of kq's piece, in workgroup order; kq = k * 64 + q sits at position L of piece (q / 16, k / 32)
-__global__ void gno_stg_reduce_kernel(const float *__restrict__ slab, const float *__restrict__ slabB, float *__restrict__ dV)
+// dVaug[kq][o] = the nsub slabs of kq's piece, in workgroup order; kq = k * 64 + q sits at position L of piece (q / 16, k / 32)
+__global__ void gno_stg_reduce_kernel(const float *__restrict__ slab, const float *__restrict__ slabB, float *__restrict__ dV, int nsub)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= 65 * 64 * 64) return;
@@ -1123,10 +1123,10 @@ __global__ void gno_stg_reduce_kernel(const float *__restrict__ slab, const floa
         const int k = kq >> 6, q = kq & 63, c = q >> 4, q16 = q & 15, kh = k >> 5, kl = k & 31;
         const int tp = kl >> 4, gg = (kl >> 2) & 3, r = kl & 3;
         const int L = (16 * tp + 4 * r + gg) * 16 + q16, pc = 2 * c + kh;
-        for (int sub = 0; sub < 32; ++sub) sum = sum + slab[((size_t)(sub * 8 + pc) * 512 + L) * kGF + o];
+        for (int sub = 0; sub < nsub; ++sub) sum = sum + slab[((size_t)(sub * 8 + pc) * 512 + L) * kGF + o];
     } else {
         const int q = kq - 64 * 64, c = q >> 4, q16 = q & 15;
-        for (int sub = 0; sub < 32; ++sub) sum = sum + slabB[((size_t)(sub * 8 + 2 * c) * 64 + o) * 16 + q16];
+        for (int sub = 0; sub < nsub; ++sub) sum = sum + slabB[((size_t)(sub * 8 + 2 * c) * 64 + o) * 16 + q16];
     }
     dV[t] = sum;
 }
@@ -1155,12 +1155,14 @@ int launch_gno_stg(const athena_mp_graph *g, const float *x, const float *coords
     if (amp::workspace(&slab, sizeof(float) * (size_t)kStgGrid * 512 * kGF, 0) ||
         amp::workspace(&slabB, sizeof(float) * (size_t)kStgGrid * 1024, 8))
         return 1;
-    hipLaunchKernelGGL(gno_stg_kernel, dim3(kStgGrid), dim3(kPcThreads), lds, amp::stream(), g->rowptr, g->col, g->eid, x, coords,
+    // 8 pieces x nsub tile classes: 32 classes fill the chip's 256 CUs; a small graph takes one class per tile
+    const int nsub = std::max(1, std::min(kStgGrid / 8, (g->n_rows + kPV - 1) / kPV));
+    hipLaunchKernelGGL(gno_stg_kernel, dim3(8 * nsub), dim3(kPcThreads), lds, amp::stream(), g->rowptr, g->col, g->eid, x, coords,
                        theta, d, grad, g->n_rows, (const int32_t *)g->len_perm_fwd, (float *)slab, (float *)slabB,
-                       (uint32_t)y_bytes, (uint32_t)c_bytes, (uint32_t)id_bytes, (uint32_t)g_bytes);
+                       (uint32_t)y_bytes, (uint32_t)c_bytes, (uint32_t)id_bytes, (uint32_t)g_bytes, nsub);
     AMP_LAUNCH_CHECK();
     hipLaunchKernelGGL(gno_stg_reduce_kernel, dim3((65 * 64 * 64 + 255) / 256), dim3(256), 0, amp::stream(), (const float *)slab,
-                       (const float *)slabB, dV);
+                       (const float *)slabB, dV, nsub);
     AMP_LAUNCH_CHECK();
     return 0;
 }
