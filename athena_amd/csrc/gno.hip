@@ -728,15 +728,22 @@ __global__ __launch_bounds__(kPcThreads) void gno_pc_kernel(const int32_t *__res
 #pragma unroll
         for (int vi = 0; vi < 4; ++vi) P.issue(LS[vi], pJ0, pJ1, vi, 0, true);
         float CV[4][2];   // coordinates of the tile's slots; refilled for the next tile after the last piece has read them
-        constexpr int kHCache = 2;   // vertices of the wave whose h (first 16 entries) is kept over the four pieces of a kh:
-        v4f_g HCc[kHCache][2];       // 8 registers each -- the 168 do not hold all four
+        // h (first 16 entries) of a vertex kept over the four pieces of a kh: 8 registers per vertex.  Tiles whose rows have more
+        // than 16 entries keep it for two of the wave's four vertices (the second operand block fills the register file);
+        // the tiles after them -- a workgroup's tiles come in falling order of length -- for all four, in a loop of their own
+        // in which the second block's registers are dead.
+        v4f_g HCc[4][2];
 #pragma unroll
         for (int vi = 0; vi < 4; ++vi) P.load_cv(CV[vi], cur.E0, cur.E1, vi);
-        for (int ti = 0; ti < nt; ++ti) {
+        auto run_tiles = [&](auto SHORT_, int &ti) {
+        constexpr bool SHORT = decltype(SHORT_)::value;
+        constexpr int kHCache = SHORT ? 4 : 2;
+        for (; ti < nt; ++ti) {
             const int tile = blockIdx.x + ti * gridDim.x;
             const bool more = ti + 1 < nt;
             const int maxlen = max(max(cur.len[0], cur.len[1]), max(cur.len[2], cur.len[3]));
             const int nstT = min(8, (maxlen + 3) >> 2);
+            if (!SHORT && nstT <= 4) break;   // the rest of the workgroup's tiles: the loop that keeps h for all four vertices
             int nstN = nstT;   // the next tile's (known from its third piece on; its rows are not longer than this tile's)
 #pragma unroll 1
             for (int pc = 0; pc < 8; ++pc) {
@@ -759,7 +766,7 @@ __global__ __launch_bounds__(kPcThreads) void gno_pc_kernel(const int32_t *__res
                 const int cn = (pc + 1) & 3;                              // feature quarter of the next piece
                 const bool last = pc == 7;
                 if (last) { pJ0 = nxt.J0; pJ1 = nxt.J1; }
-                const bool second = (last ? nstN : nstT) > 4;   // does the piece being requested read entries 16 .. 31
+                const bool second = !SHORT && (last ? nstN : nstT) > 4;   // does the piece being requested read entries 16 .. 31
                 // the four vertices of the wave with the step count of the longest of them as a compile-time constant
                 // (tiles hold vertices of nearly equal length, so the shorter rows' extra steps -- on zeros -- are few)
                 auto four = [&](auto K, auto FILL) {
@@ -785,16 +792,21 @@ __global__ __launch_bounds__(kPcThreads) void gno_pc_kernel(const int32_t *__res
                     }
                 };
 #define GNO_FOUR(FILL_)                                                             \
-    switch (nstT) {                                                                \
-    case 0:                                                                        \
-    case 1: four(std::integral_constant<int, 1>{}, std::integral_constant<bool, FILL_>{}); break; \
-    case 2: four(std::integral_constant<int, 2>{}, std::integral_constant<bool, FILL_>{}); break; \
-    case 3: four(std::integral_constant<int, 3>{}, std::integral_constant<bool, FILL_>{}); break; \
-    case 4: four(std::integral_constant<int, 4>{}, std::integral_constant<bool, FILL_>{}); break; \
-    case 5: four(std::integral_constant<int, 5>{}, std::integral_constant<bool, FILL_>{}); break; \
-    case 6: four(std::integral_constant<int, 6>{}, std::integral_constant<bool, FILL_>{}); break; \
-    case 7: four(std::integral_constant<int, 7>{}, std::integral_constant<bool, FILL_>{}); break; \
-    default: four(std::integral_constant<int, 8>{}, std::integral_constant<bool, FILL_>{}); break; \
+    if (SHORT) {                                                                   \
+        switch (nstT) {                                                            \
+        case 0:                                                                    \
+        case 1: four(std::integral_constant<int, 1>{}, std::integral_constant<bool, FILL_>{}); break; \
+        case 2: four(std::integral_constant<int, 2>{}, std::integral_constant<bool, FILL_>{}); break; \
+        case 3: four(std::integral_constant<int, 3>{}, std::integral_constant<bool, FILL_>{}); break; \
+        default: four(std::integral_constant<int, 4>{}, std::integral_constant<bool, FILL_>{}); break; \
+        }                                                                          \
+    } else {                                                                       \
+        switch (nstT) {                                                            \
+        case 5: four(std::integral_constant<int, 5>{}, std::integral_constant<bool, FILL_>{}); break; \
+        case 6: four(std::integral_constant<int, 6>{}, std::integral_constant<bool, FILL_>{}); break; \
+        case 7: four(std::integral_constant<int, 7>{}, std::integral_constant<bool, FILL_>{}); break; \
+        default: four(std::integral_constant<int, 8>{}, std::integral_constant<bool, FILL_>{}); break; \
+        }                                                                          \
     }
                 if (c == 0) { GNO_FOUR(true) } else { GNO_FOUR(false) }
 #undef GNO_FOUR
@@ -827,6 +839,10 @@ __global__ __launch_bounds__(kPcThreads) void gno_pc_kernel(const int32_t *__res
                 __syncthreads();
             }
         }
+        };
+        int ti = 0;
+        run_tiles(std::integral_constant<bool, false>{}, ti);
+        run_tiles(std::integral_constant<bool, true>{}, ti);
         __syncthreads();   // the consumers' last piece
     } else {
         // ======================================= consumer =======================================
