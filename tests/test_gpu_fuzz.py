@@ -177,3 +177,41 @@ def test_kipf_layer_order_fuzz(dev, seed):
         dx = layer.backward(np.concatenate(ups), exact=exact)
         assert_close(H(dx), np.concatenate(dxs), 1e-5, f"seed {seed} {order} {nvf} dx", f64=lambda: hi()[0])
         assert_close(layer.get_gradients(), np.concatenate(grads), 1e-5, f"seed {seed} {order} {nvf} dW", f64=lambda: hi()[1])
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_gno_fused_shape_fuzz(dev, oracle, seed):
+    """the producer / consumer GNO kernels (H = 64, widths 64) over random vertex counts, average row lengths from 1 to 40
+    (every step-count variant of the sparse waves, the 17..32 and the > 32 entry row classes of the kernel-MLP backward),
+    d = 1..3, with and without self-loop entries (no edge column); all four entry points against the oracle"""
+    from athena_amd import DeviceGraph, ops
+    from helpers import csr_from_index_list
+    from oracle import oracle64 as o64
+
+    rng = np.random.default_rng(9100 + seed)
+    N = int(rng.integers(40, 900))
+    avg = float(rng.choice([0.6, 2.0, 4.5, 8.0, 12.0, 20.0]))
+    n_pairs = max(1, int(N * avg / 2))
+    pairs = rng.integers(1, N + 1, (n_pairs, 2))
+    if seed % 2:                                        # a few long rows on top
+        hub = int(rng.integers(1, N + 1))
+        pairs = np.concatenate([pairs, np.stack([np.full(50, hub), rng.integers(1, N + 1, 50)], 1)])
+    pairs = pairs[pairs[:, 0] != pairs[:, 1]].T
+    g0 = csr_from_index_list(N, pairs, self_loops=bool(seed % 3 == 0))
+    ia, ja, E = g0.adj_ia, g0.adj_ja, pairs.shape[1]
+    d = int(rng.integers(1, 4)); Hh = Fi = Fo = 64
+    g = DeviceGraph(ia, ja, n_edge_cols=E)
+    coords = rng.standard_normal((E, d)).astype(np.float32)
+    x = rng.uniform(-1, 1, (N, Fi)).astype(np.float32)
+    theta = (0.3 * rng.standard_normal(Hh * d + Hh + Fo * Fi * Hh + Fo * Fi)).astype(np.float32)
+    up = rng.uniform(-1, 1, (N, Fo)).astype(np.float32)
+    kap = oracle.gno_kernel_eval(coords, theta, Hh, Fo * Fi)
+    th, co, xd, gd = T(theta, dev), T(coords, dev), T(x, dev), T(up, dev)
+    assert_close(H(ops.gno_aggregate(g, th, co, xd, d, Hh, Fo)), oracle.gno_aggregate(x, kap, ia, ja, Fo), 1e-5, "gno fwd")
+    assert_close(H(ops.gno_aggregate_bwd_x(g, th, co, gd, d, Hh, Fi)), oracle.gno_aggregate_bwd_x(up, kap, ia, ja, Fi), 1e-5, "gno dx")
+    dk = oracle.gno_aggregate_bwd_k(up, x, E, ia, ja)
+    dk64 = lambda: o64.gno_aggregate_bwd_k(up, x, E, ia, ja)
+    assert_close(H(ops.gno_aggregate_bwd_theta(g, th, co, xd, gd, d, Hh)), oracle.gno_kernel_bwd_theta(coords, theta, dk, Hh), 1e-5,
+                 "gno dtheta", f64=lambda: o64.gno_kernel_bwd_theta(coords, theta, dk64(), Hh))
+    assert_close(H(ops.gno_aggregate_bwd_coords(g, th, co, xd, gd, d, Hh)), oracle.gno_kernel_bwd_coords(coords, theta, dk, Hh), 1e-5,
+                 "gno dcoords", f64=lambda: o64.gno_kernel_bwd_coords(coords, theta, dk64(), Hh))
