@@ -18,6 +18,9 @@ module athena_mp_c
   public :: athena_mp_gemm_fwd_host
   public :: athena_mp_duvenaud_propagate_fwd_host, athena_mp_duvenaud_propagate_bwd_x_host
   public :: athena_mp_duvenaud_update_fwd_host
+  public :: athena_mp_duvenaud_propagate_bwd_e_host, athena_mp_duvenaud_update_bwd_a_host, athena_mp_duvenaud_update_bwd_w_host
+  public :: athena_mp_gno_aggregate_fwd_host, athena_mp_gno_aggregate_bwd_x_host, athena_mp_gno_aggregate_bwd_theta_host
+  public :: athena_mp_gno_aggregate_bwd_coords_host
   public :: athena_mp_malloc, athena_mp_free, athena_mp_memcpy_h2d, athena_mp_memcpy_d2h
   public :: athena_mp_kipf_propagate_fwd, athena_mp_kipf_propagate_bwd
   public :: athena_mp_gemm_fwd, athena_mp_gemm_dw, athena_mp_gemm_dx
@@ -129,6 +132,71 @@ module athena_mp_c
        integer(c_int32_t), value :: Fi, Fo, min_deg, max_deg
        real(c_float), intent(in) :: a(*), w(*)
        real(c_float), intent(inout) :: c(*)
+     end function
+
+     !! get_partial_duvenaud_propagate_right_val, :143-171
+     pure integer(c_int) function athena_mp_duvenaud_propagate_bwd_e_host(graph, Fv, Fe, grad, de) &
+          bind(C, name="athena_mp_duvenaud_propagate_bwd_e_host")
+       import :: c_int, c_int32_t, c_ptr, c_float
+       type(c_ptr), value :: graph
+       integer(c_int32_t), value :: Fv, Fe
+       real(c_float), intent(in) :: grad(*)
+       real(c_float), intent(inout) :: de(*)
+     end function
+     !! get_partial_duvenaud_update_val, :284-324
+     pure integer(c_int) function athena_mp_duvenaud_update_bwd_a_host(graph, Fi, Fo, min_deg, max_deg, grad, w, da) &
+          bind(C, name="athena_mp_duvenaud_update_bwd_a_host")
+       import :: c_int, c_int32_t, c_ptr, c_float
+       type(c_ptr), value :: graph
+       integer(c_int32_t), value :: Fi, Fo, min_deg, max_deg
+       real(c_float), intent(in) :: grad(*), w(*)
+       real(c_float), intent(inout) :: da(*)
+     end function
+     !! get_partial_duvenaud_update_weight_val, :326-368
+     pure integer(c_int) function athena_mp_duvenaud_update_bwd_w_host(graph, Fi, Fo, min_deg, max_deg, grad, a, dw) &
+          bind(C, name="athena_mp_duvenaud_update_bwd_w_host")
+       import :: c_int, c_int32_t, c_ptr, c_float
+       type(c_ptr), value :: graph
+       integer(c_int32_t), value :: Fi, Fo, min_deg, max_deg
+       real(c_float), intent(in) :: grad(*), a(*)
+       real(c_float), intent(inout) :: dw(*)
+     end function
+     !! gno_kernel_eval + gno_aggregate in one op (athena_diffstruc_extd_sub_nop.f90:26-115, :330-397): the per-edge kernel
+     !! tensor is never formed; theta = U | b_u | V | b_v as gno_kernel_eval packs it (:74-82)
+     pure integer(c_int) function athena_mp_gno_aggregate_fwd_host(graph, d, H, Fi, Fo, theta, coords, x, m) &
+          bind(C, name="athena_mp_gno_aggregate_fwd_host")
+       import :: c_int, c_int32_t, c_ptr, c_float
+       type(c_ptr), value :: graph
+       integer(c_int32_t), value :: d, H, Fi, Fo
+       real(c_float), intent(in) :: theta(*), coords(*), x(*)
+       real(c_float), intent(inout) :: m(*)
+     end function
+     !! get_partial_gno_aggregate_features_val, :419-458 (through the kernels)
+     pure integer(c_int) function athena_mp_gno_aggregate_bwd_x_host(graph, d, H, Fi, Fo, theta, coords, grad, dx) &
+          bind(C, name="athena_mp_gno_aggregate_bwd_x_host")
+       import :: c_int, c_int32_t, c_ptr, c_float
+       type(c_ptr), value :: graph
+       integer(c_int32_t), value :: d, H, Fi, Fo
+       real(c_float), intent(in) :: theta(*), coords(*), grad(*)
+       real(c_float), intent(inout) :: dx(*)
+     end function
+     !! agg -> kernels (:480-526) chained with kernel -> params (:235-325)
+     pure integer(c_int) function athena_mp_gno_aggregate_bwd_theta_host(graph, d, H, Fi, Fo, theta, coords, x, grad, dtheta) &
+          bind(C, name="athena_mp_gno_aggregate_bwd_theta_host")
+       import :: c_int, c_int32_t, c_ptr, c_float
+       type(c_ptr), value :: graph
+       integer(c_int32_t), value :: d, H, Fi, Fo
+       real(c_float), intent(in) :: theta(*), coords(*), x(*), grad(*)
+       real(c_float), intent(inout) :: dtheta(*)
+     end function
+     !! agg -> kernels chained with kernel -> coords (:137-216)
+     pure integer(c_int) function athena_mp_gno_aggregate_bwd_coords_host(graph, d, H, Fi, Fo, theta, coords, x, grad, &
+          dcoords) bind(C, name="athena_mp_gno_aggregate_bwd_coords_host")
+       import :: c_int, c_int32_t, c_ptr, c_float
+       type(c_ptr), value :: graph
+       integer(c_int32_t), value :: d, H, Fi, Fo
+       real(c_float), intent(in) :: theta(*), coords(*), x(*), grad(*)
+       real(c_float), intent(inout) :: dcoords(*)
      end function
 
      !! device-resident variants (phase 2: tensors stay in HBM between consecutive HIP layers)

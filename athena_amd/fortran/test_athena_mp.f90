@@ -20,6 +20,7 @@ program test_athena_mp
   call identity_kat()
   call six_vertex_graph()
   call duvenaud_five_vertex_graph()
+  call gno_five_vertex_graph()
   call adam_update_resident()
   call train_loop_resident()
   call csr_from_edges_on_device()
@@ -390,7 +391,168 @@ contains
        success = .false.
        write(0,*) "duvenaud propagate gradient differs", maxval(abs(dx - dxref))
     end if
+    ! the other three reverse callbacks (athena_diffstruc_extd_sub_duvenaud.f90:143-171, :284-324, :326-368), restated inline
+    block
+      real(real32) :: de(fe,ne), deref(fe,ne), gz(fo,nv), da(fv+fe,nv), daref(fv+fe,nv)
+      real(real32) :: dw(fo*(fv+fe)*(maxd-mind+1)), dwref(fo*(fv+fe)*(maxd-mind+1))
+      integer :: j, off
+      deref = 0._real32
+      do v = 1, nv
+         do w = adj_ia(v), adj_ia(v+1)-1
+            deref(:,adj_ja(2,w)) = deref(:,adj_ja(2,w)) + g(fv+1:fv+fe, v)
+         end do
+      end do
+      rc = athena_mp_duvenaud_propagate_bwd_e_host(graph, fv, fe, g, de)
+      call check(rc, "duvenaud propagate bwd (edge features)")
+      if(any(abs(de - deref) .gt. 1.e-6_real32 * maxval(abs(deref))))then
+         success = .false.
+         write(0,*) "duvenaud propagate edge-feature gradient differs", maxval(abs(de - deref))
+      end if
+      do v = 1, nv
+         do i = 1, fo
+            gz(i,v) = 0.25_real32 * real(i, real32) - 0.07_real32 * real(mod(3*v + i, 5), real32)
+         end do
+      end do
+      daref = 0._real32; dwref = 0._real32
+      do v = 1, nv
+         dd = max(mind, min(adj_ia(v+1) - adj_ia(v), maxd)) - mind + 1
+         off = fo*(fv+fe)*(dd-1)
+         do j = 1, fv+fe
+            do i = 1, fo
+               daref(j,v) = daref(j,v) + gz(i,v) * wgt(off + i + fo*(j-1)) / real(dd, real32)
+               dwref(off + i + fo*(j-1)) = dwref(off + i + fo*(j-1)) + gz(i,v) * cref(j,v) / real(dd, real32)
+            end do
+         end do
+      end do
+      rc = athena_mp_duvenaud_update_bwd_a_host(graph, fv+fe, fo, mind, maxd, gz, wgt, da)
+      call check(rc, "duvenaud update bwd (a)")
+      if(any(abs(da - daref) .gt. 1.e-5_real32 * maxval(abs(daref))))then
+         success = .false.
+         write(0,*) "duvenaud update gradient w.r.t. a differs", maxval(abs(da - daref))
+      end if
+      rc = athena_mp_duvenaud_update_bwd_w_host(graph, fv+fe, fo, mind, maxd, gz, cref, dw)
+      call check(rc, "duvenaud update bwd (weight)")
+      if(any(abs(dw - dwref) .gt. 1.e-5_real32 * maxval(abs(dwref))))then
+         success = .false.
+         write(0,*) "duvenaud update gradient w.r.t. the weights differs", maxval(abs(dw - dwref))
+      end if
+    end block
     rc = athena_mp_graph_destroy(graph)
   end subroutine duvenaud_five_vertex_graph
+
+  subroutine gno_five_vertex_graph()
+    !! the same 5-vertex / 6-edge graph through the GNO entry points the drop-in ops bind
+    !! (scripts/integration_check/hip_duvenaud_gno_ops.f90), against gno_kernel_eval + gno_aggregate and their partials
+    !! (athena_diffstruc_extd_sub_nop.f90:88-93, :367-378, :235-325, :419-458, :480-526) restated inline with the
+    !! per-edge kernel tensor the device path never forms
+    integer, parameter :: nv = 5, ne = 6, d = 2, hh = 4, fi = 3, fo = 2, ff = fo*fi, np = hh*d + hh + ff*hh + ff
+    integer :: index_list(2,ne), deg(nv), pos(nv), v, w, e, u, i, k, f, o, q
+    integer(c_int32_t) :: adj_ia(nv+1), adj_ja(2,2*ne)
+    real(real32) :: theta(np), coords(d,ne), x(fi,nv), gup(fo,nv), m(fo,nv), mref(fo,nv), dx(fi,nv), dxref(fi,nv)
+    real(real32) :: dth(np), dthref(np), hid(hh,ne), kap(ff,ne), dkap(ff,ne), dh(hh), s
+    index_list(:,1) = [1, 2]; index_list(:,2) = [1, 3]; index_list(:,3) = [2, 3]
+    index_list(:,4) = [2, 4]; index_list(:,5) = [3, 5]; index_list(:,6) = [4, 5]
+    deg = 0
+    do e = 1, ne
+       deg(index_list(1,e)) = deg(index_list(1,e)) + 1
+       deg(index_list(2,e)) = deg(index_list(2,e)) + 1
+    end do
+    adj_ia(1) = 1
+    do v = 1, nv
+       adj_ia(v+1) = adj_ia(v) + deg(v)
+    end do
+    pos = adj_ia(1:nv)
+    do e = 1, ne
+       u = index_list(1,e); v = index_list(2,e)
+       adj_ja(:,pos(u)) = [v, e]; pos(u) = pos(u) + 1
+       adj_ja(:,pos(v)) = [u, e]; pos(v) = pos(v) + 1
+    end do
+    do i = 1, np
+       theta(i) = 0.05_real32 * real(mod(11*i, 17), real32) - 0.4_real32
+    end do
+    do e = 1, ne
+       do i = 1, d
+          coords(i,e) = 0.3_real32 * real(mod(5*e + 3*i, 7), real32) - 0.8_real32
+       end do
+    end do
+    do v = 1, nv
+       do i = 1, fi
+          x(i,v) = 0.2_real32 * real(i, real32) - 0.15_real32 * real(mod(v*i, 4), real32)
+       end do
+       do i = 1, fo
+          gup(i,v) = 0.4_real32 - 0.1_real32 * real(mod(2*v + i, 5), real32)
+       end do
+    end do
+    ! kernel per edge column: h = relu(U dx + b_u), kappa = V h + b_v (params packed U | b_u | V | b_v, :74-82)
+    do e = 1, ne
+       do k = 1, hh
+          s = theta(hh*d + k)
+          do i = 1, d
+             s = s + theta(k + hh*(i-1)) * coords(i,e)
+          end do
+          hid(k,e) = max(s, 0._real32)
+       end do
+       do f = 1, ff
+          s = theta(hh*d + hh + ff*hh + f)
+          do k = 1, hh
+             s = s + theta(hh*d + hh + f + ff*(k-1)) * hid(k,e)
+          end do
+          kap(f,e) = s
+       end do
+    end do
+    mref = 0._real32; dxref = 0._real32; dkap = 0._real32
+    do v = 1, nv
+       do w = adj_ia(v), adj_ia(v+1)-1
+          u = adj_ja(1,w); e = adj_ja(2,w)
+          do q = 1, fi
+             do o = 1, fo
+                mref(o,v) = mref(o,v) + kap(o + fo*(q-1), e) * x(q,u)
+                dxref(q,u) = dxref(q,u) + kap(o + fo*(q-1), e) * gup(o,v)
+                dkap(o + fo*(q-1), e) = dkap(o + fo*(q-1), e) + gup(o,v) * x(q,u)
+             end do
+          end do
+       end do
+    end do
+    dthref = 0._real32
+    do e = 1, ne
+       dh = 0._real32
+       do f = 1, ff
+          dthref(hh*d + hh + ff*hh + f) = dthref(hh*d + hh + ff*hh + f) + dkap(f,e)
+          do k = 1, hh
+             dthref(hh*d + hh + f + ff*(k-1)) = dthref(hh*d + hh + f + ff*(k-1)) + dkap(f,e) * hid(k,e)
+             dh(k) = dh(k) + theta(hh*d + hh + f + ff*(k-1)) * dkap(f,e)
+          end do
+       end do
+       do k = 1, hh
+          if(hid(k,e) .gt. 0._real32)then
+             dthref(hh*d + k) = dthref(hh*d + k) + dh(k)
+             do i = 1, d
+                dthref(k + hh*(i-1)) = dthref(k + hh*(i-1)) + dh(k) * coords(i,e)
+             end do
+          end if
+       end do
+    end do
+    rc = athena_mp_graph_create(nv, nv, int(2*ne, c_int64_t), adj_ia, adj_ja, ne, c_null_ptr, c_null_ptr, graph)
+    call check(rc, "graph_create 5v (gno)")
+    rc = athena_mp_gno_aggregate_fwd_host(graph, d, hh, fi, fo, theta, coords, x, m)
+    call check(rc, "gno aggregate")
+    if(any(abs(m - mref) .gt. 1.e-5_real32 * maxval(abs(mref))))then
+       success = .false.
+       write(0,*) "gno aggregate differs from the reference loops", maxval(abs(m - mref))
+    end if
+    rc = athena_mp_gno_aggregate_bwd_x_host(graph, d, hh, fi, fo, theta, coords, gup, dx)
+    call check(rc, "gno aggregate bwd (features)")
+    if(any(abs(dx - dxref) .gt. 1.e-5_real32 * maxval(abs(dxref))))then
+       success = .false.
+       write(0,*) "gno feature gradient differs", maxval(abs(dx - dxref))
+    end if
+    rc = athena_mp_gno_aggregate_bwd_theta_host(graph, d, hh, fi, fo, theta, coords, x, gup, dth)
+    call check(rc, "gno aggregate bwd (kernel parameters)")
+    if(any(abs(dth - dthref) .gt. 1.e-5_real32 * maxval(abs(dthref))))then
+       success = .false.
+       write(0,*) "gno kernel-parameter gradient differs", maxval(abs(dth - dthref))
+    end if
+    rc = athena_mp_graph_destroy(graph)
+  end subroutine gno_five_vertex_graph
 
 end program test_athena_mp

@@ -18,4 +18,6 @@ done
 "$FC" -cpp -c "$ROOT/athena_amd/fortran/athena_mp_c.f90" -o athena_mp_c.o
 "$FC" -cpp -c "$HERE/hip_kipf_msgpass.f90" -o hip_kipf_msgpass.o
 ls athena_mp__hip_kipf.mod >/dev/null
+"$FC" -cpp -c "$HERE/hip_duvenaud_gno_ops.f90" -o hip_duvenaud_gno_ops.o   # the Duvenaud and GNO autodiff ops
+ls athena_mp__hip_ops.mod >/dev/null
 echo "integration shim compiles against athena__msgpass_layer / athena__base_layer / diffstruc surface: OK"

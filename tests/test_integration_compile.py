@@ -1,5 +1,6 @@
 """CPU, build container only: the drop-in shim INTEGRATION.md describes (scripts/integration_check/hip_kipf_msgpass.f90 --
-an autodiff op with kipf_propagate's contract and a type that extends(msgpass_layer_type)) goes through the Fortran
+an autodiff op with kipf_propagate's contract and a type that extends(msgpass_layer_type) -- and hip_duvenaud_gno_ops.f90,
+the Duvenaud and GNO autodiff ops) goes through the Fortran
 compiler against athena's REAL module sources, read in place from the reference checkout, plus compile-only stand-ins for
 coreutils / diffstruc / graphstruc (which this image lacks).  Syntax and interface evidence only: nothing is linked or
 run and no number comes from it.  Skipped where the reference checkout or the compiler is absent (e.g. on the GPU box)."""
@@ -22,3 +23,4 @@ def test_integration_shim_compiles_against_the_reference_modules():
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     assert "OK" in r.stdout
     assert os.path.exists(os.path.join(ROOT, "build", "integration_check", "athena_mp__hip_kipf.mod"))
+    assert os.path.exists(os.path.join(ROOT, "build", "integration_check", "athena_mp__hip_ops.mod"))   # Duvenaud + GNO ops
