@@ -945,9 +945,15 @@ __global__ __launch_bounds__(kPcThreads) void gno_stg_kernel(const int32_t *__re
     float *Gbuf = Sh + 2 * kPV * kPPitch;               // [2][32][72]   gradient rows of the tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, g = lane >> 4;
-    // (Measured and dropped: the eight workgroups of a tile class nsub apart, i.e. on ONE XCD whose L2 would serve seven of the
-    // eight reads of a tile's ids and rows -- dtheta 27.8 ms against 27.1 with them spread over the eight XCDs as here.)
+    // The eight workgroups that visit a tile sit on eight different XCDs (workgroup b runs on XCD b % 8), so every 64-byte
+    // quarter row costs its own 128-byte line from the fabric: 57 GB per launch at configs[3] (2 x FETCH_SIZE; L2 hit rate 2 %)
+    // against 8.7 GB algorithmic -- and the kernel is not bound by it.  -DGNO_STG_GROUPED puts the eight on ONE XCD (nsub
+    // apart): 10.9 GB, L2 hit rate 81 %, and dtheta 27.7 ms instead of 27.0 (profiles/r02_c4_gno_pmc_traffic.txt).
+#ifdef GNO_STG_GROUPED
+    const int pc = blockIdx.x / nsub, sub = blockIdx.x % nsub, c = pc >> 1, kh = pc & 1;
+#else
     const int pc = blockIdx.x & 7, sub = blockIdx.x >> 3, c = pc >> 1, kh = pc & 1;
+#endif
     const int n_tiles = (n_rows + kPV - 1) / kPV;
     const int nt = sub < n_tiles ? (n_tiles - sub + nsub - 1) / nsub : 0;   // tiles of this workgroup: sub, sub + nsub, ...
 
@@ -1079,7 +1085,7 @@ __global__ __launch_bounds__(kPcThreads) void gno_stg_kernel(const int32_t *__re
 #pragma unroll
                 for (int r = 0; r < 4; ++r) sum[r] = sum[r] + v[r];
             }
-            *reinterpret_cast<v4f_g *>(slabB + (size_t)blockIdx.x * 1024 + t0) = sum;
+            *reinterpret_cast<v4f_g *>(slabB + (size_t)(sub * 8 + pc) * 1024 + t0) = sum;
         }
     } else {
         // ======================================= consumer =======================================
@@ -1115,7 +1121,7 @@ __global__ __launch_bounds__(kPcThreads) void gno_stg_kernel(const int32_t *__re
             __syncthreads();
         }
         // lane (o = 4 n + b, g): acc[sp][a][b][r] = out[L = 128 w + 64 sp + 4 (4 g + r) + a][o]
-        float *sl = slab + (size_t)blockIdx.x * 512 * kGF;
+        float *sl = slab + (size_t)(sub * 8 + pc) * 512 * kGF;
 #pragma unroll
         for (int sp = 0; sp < 2; ++sp)
 #pragma unroll
