@@ -286,6 +286,19 @@ def test_c4_gno_properties_full_size(dev, oracle):
     offV = H * d + H
     assert abs(lhs - (theta[offV:].double() * dth[offV:].double()).sum().item()) <= 1e-5 * scale
     assert torch.isfinite(dth).all()
+    # the kernel MLP's own parameters (gno_dh_pc_kernel, all three row-length classes): relu is positively homogeneous, so
+    # <g, m> without its b_v part is of degree one in V and of degree one in (U, b_u) together -- Euler's identity on both
+    # sides: <V, dV> = <(U, b_u), (dU, db_u)>
+    nV = Fo * Fi * H
+    via_V = (theta[offV:offV + nV].double() * dth[offV:offV + nV].double()).sum().item()
+    via_U = (theta[:offV].double() * dth[:offV].double()).sum().item()
+    assert abs(via_V - via_U) <= 1e-5 * scale
+    # dcoords (the WRITE_GH form of the same kernel): the kernel depends on U dx_e only through U . dx_e, so scaling all
+    # coordinates is scaling U: <coords, dcoords> = <U, dU>
+    dco = ops.gno_aggregate_bwd_coords(g, theta, co, x, gup, d, H)
+    via_c = (co.double() * dco.double()).sum().item()
+    via_Uonly = (theta[:H * d].double() * dth[:H * d].double()).sum().item()
+    assert abs(via_c - via_Uonly) <= 1e-5 * scale
 
 
 def test_tensors_beyond_2_31_elements_use_64_bit_offsets(dev, oracle):
