@@ -1,0 +1,36 @@
+"""Soak of the producer / consumer GNO kernels: radius graphs from 50 to 300 000 vertices, every entry point launched
+REPS times; every launch must reproduce the first one bit for bit (the barrier protocol, the slab reductions and the id
+queues are deterministic by construction) and stay finite.  Run under `timeout`: a lost barrier would hang."""
+import os, sys, time
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from athena_amd import ops, synth
+from athena_amd.graph import DeviceGraph
+
+REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+dev = torch.device("cuda:0")
+T = lambda a: torch.from_numpy(a).to(dev)
+Fi = Fo = H = 64
+tot = 0
+t0 = time.time()
+for N, d in [(50, 3), (777, 2), (4099, 3), (33000, 1), (300000, 3)]:
+    ia, ja, coords3 = synth.radius_graph(N)
+    coords = np.ascontiguousarray(coords3[:, :d])
+    rng = np.random.default_rng(N)
+    g = DeviceGraph(ia, ja, n_edge_cols=coords.shape[0])
+    x = T(rng.uniform(-1, 1, (N, Fi)).astype(np.float32)); co = T(coords)
+    theta = T((0.3 * rng.standard_normal(H * d + H + Fo * Fi * H + Fo * Fi)).astype(np.float32))
+    gup = T(rng.uniform(-1, 1, (N, Fo)).astype(np.float32))
+    legs = {"fwd": lambda: ops.gno_aggregate(g, theta, co, x, d, H, Fo),
+            "dx": lambda: ops.gno_aggregate_bwd_x(g, theta, co, gup, d, H, Fi),
+            "dtheta": lambda: ops.gno_aggregate_bwd_theta(g, theta, co, x, gup, d, H),
+            "dcoords": lambda: ops.gno_aggregate_bwd_coords(g, theta, co, x, gup, d, H)}
+    for name, fn in legs.items():
+        first = fn()
+        assert torch.isfinite(first).all(), (N, name)
+        for _ in range(REPS - 1):
+            assert torch.equal(fn(), first), (N, name, "differs between launches")
+        tot += REPS
+    print(f"N={N} d={d}: {4 * REPS} launches identical", flush=True)
+print(f"soak ok: {tot} launches in {time.time() - t0:.1f} s")
