@@ -135,6 +135,7 @@ int athena_mp_init(int device)
 int athena_mp_finalize(void)
 {
     amp::host_pool_release();
+    amp::graph_cache_clear();
     for (int d = 0; d < kMaxDevices; ++d) {       // every device this process initialised
         DevCtx &c = g_ctx[d];
         for (int s = 0; s < 10; ++s) {
@@ -257,9 +258,17 @@ static int build_long_plan(const std::vector<int32_t> &rowptr, int32_t n_rows, L
 
 extern "C" {
 
+static int graph_free(athena_mp_graph *g);
+
 int athena_mp_graph_destroy(athena_mp_graph *g)
 {
     if (!g) return 0;
+    if (g->cache_refs >= 0) return athena_mp_graph_release(g);   // a handle of the cache: one user less
+    return graph_free(g);
+}
+
+static int graph_free(athena_mp_graph *g)
+{
     void *ptrs[] = {g->rowptr, g->col,   g->eid,      g->coef,  g->t_rowptr, g->t_src,  g->t_eid,
                     g->t_coef, g->e_rowptr, g->e_row, g->e_col, g->deg_row,  g->deg_col};
     for (void *p : ptrs)
@@ -361,7 +370,208 @@ int athena_mp_graph_create_from_edges(int32_t n_vertices, int64_t n_pairs, const
     return rc;
 }
 
+static int graph_create_body(int32_t n_rows, int32_t n_cols, int64_t nnz, const int32_t *adj_ia,
+                             const int32_t *adj_ja, const int32_t *adj_ja_dev, int32_t n_edge_cols,
+                             const int32_t *row_deg, const int32_t *col_deg, athena_mp_graph **out);
+
+static int64_t g_graph_builds = 0;
+
 static int graph_create_impl(int32_t n_rows, int32_t n_cols, int64_t nnz, const int32_t *adj_ia,
+                             const int32_t *adj_ja, const int32_t *adj_ja_dev, int32_t n_edge_cols,
+                             const int32_t *row_deg, const int32_t *col_deg, athena_mp_graph **out)
+{
+    int rc = graph_create_body(n_rows, n_cols, nnz, adj_ia, adj_ja, adj_ja_dev, n_edge_cols, row_deg, col_deg, out);
+    if (rc == 0) ++g_graph_builds;
+    return rc;
+}
+
+/* ---- content key of a CSR (what a cached handle is valid for) ------------------------------------------------- */
+namespace {
+struct KeyHash {   // MurmurHash3's 64-bit lane: multiply-rotate per 8-byte word, fmix64 at the end
+    uint64_t h;
+    explicit KeyHash(uint64_t seed) : h(seed) {}
+    inline void word(uint64_t k)
+    {
+        k *= 0x87c37b91114253d5ull;
+        k = (k << 31) | (k >> 33);
+        k *= 0x4cf5ad432745937full;
+        h ^= k;
+        h = ((h << 27) | (h >> 37)) * 5 + 0x52dce729;
+    }
+    void ints(const int32_t *p, int64_t count)   // count int32 values (pairs packed into one word)
+    {
+        int64_t i = 0;
+        for (; i + 1 < count; i += 2) {
+            uint64_t k;
+            memcpy(&k, p + i, 8);
+            word(k);
+        }
+        if (i < count) word((uint64_t)(uint32_t)p[i] | 0xa5a5a5a500000000ull);
+    }
+    uint64_t digest() const
+    {
+        uint64_t k = h;
+        k ^= k >> 33;
+        k *= 0xff51afd7ed558ccdull;
+        k ^= k >> 33;
+        k *= 0xc4ceb9fe1a85ec53ull;
+        k ^= k >> 33;
+        return k;
+    }
+};
+}   // namespace
+
+int athena_mp_graph_key(int32_t n_rows, int64_t nnz, const int32_t *adj_ia, const int32_t *adj_ja, uint64_t *key)
+{
+    AMP_REQUIRE(key != nullptr, "graph_key: null key pointer");
+    AMP_REQUIRE(n_rows >= 0 && nnz >= 0, "graph_key: negative size");
+    AMP_REQUIRE(adj_ia != nullptr && (nnz == 0 || adj_ja != nullptr), "graph_key: null CSR arrays");
+    static const int full = [] {
+        const char *e = getenv("ATHENA_MP_GRAPH_KEY_FULL");
+        return (e && e[0] && e[0] != '0') ? 1 : 0;
+    }();
+    KeyHash h(0x9e3779b97f4a7c15ull);
+    h.word((uint64_t)(uint32_t)n_rows);
+    h.word((uint64_t)nnz);
+    const int64_t ni = (int64_t)n_rows + 1;
+    if (full || nnz < ((int64_t)1 << 18)) {
+        h.ints(adj_ia, ni);
+        h.ints(adj_ja, 2 * nnz);
+    } else {
+        const int64_t head = 1024;
+        // row pointers: head, tail, every (ni / 4096)-th
+        h.ints(adj_ia, std::min(head, ni));
+        h.ints(adj_ia + std::max<int64_t>(0, ni - head), std::min(head, ni));
+        const int64_t st_i = std::max<int64_t>(1, ni / 4096);
+        for (int64_t i = 0; i < ni; i += st_i) {   // cold lines: keep 16 misses in flight
+            if (i + 16 * st_i < ni) __builtin_prefetch(adj_ia + i + 16 * st_i);
+            h.word((uint64_t)(uint32_t)adj_ia[i] ^ ((uint64_t)i << 32));
+        }
+        // entries (neighbour, edge id) as one 8-byte column each
+        h.ints(adj_ja, 2 * head);
+        h.ints(adj_ja + 2 * (nnz - head), 2 * head);
+        const int64_t st_j = std::max<int64_t>(1, nnz / 4096);
+        for (int64_t w = 0; w < nnz; w += st_j) {
+            if (w + 16 * st_j < nnz) __builtin_prefetch(adj_ja + 2 * (w + 16 * st_j));
+            uint64_t k;
+            memcpy(&k, adj_ja + 2 * w, 8);
+            h.word(k);
+        }
+    }
+    *key = h.digest();
+    return 0;
+}
+
+/* ---- handle cache: set_graph before every forward costs a key, not a build -------------------------------------- */
+namespace {
+struct CacheId {
+    uint64_t key;
+    int64_t nnz;
+    int32_t n, n_edge_cols, device;
+    bool operator<(const CacheId &o) const
+    {
+        if (key != o.key) return key < o.key;
+        if (nnz != o.nnz) return nnz < o.nnz;
+        if (n != o.n) return n < o.n;
+        if (n_edge_cols != o.n_edge_cols) return n_edge_cols < o.n_edge_cols;
+        return device < o.device;
+    }
+};
+std::map<CacheId, athena_mp_graph *> g_cache;
+uint64_t g_cache_tick = 0;
+int64_t g_cache_hits = 0;
+
+int64_t cache_idle_cap()   // entries (nnz + n) the idle handles may hold together; 0 = free on last release
+{
+    static const int64_t cap = [] {
+        const char *e = getenv("ATHENA_MP_GRAPH_CACHE_ENTRIES");
+        return e ? (int64_t)atoll(e) : ((int64_t)1 << 28);
+    }();
+    return cap;
+}
+
+void cache_trim()   // least recently used idle handles go first
+{
+    for (;;) {
+        int64_t idle = 0, n_idle = 0;
+        auto victim = g_cache.end();
+        for (auto it = g_cache.begin(); it != g_cache.end(); ++it) {
+            if (it->second->cache_refs != 0) continue;
+            idle += it->second->nnz + it->second->n_rows;
+            ++n_idle;
+            if (victim == g_cache.end() || it->second->cache_tick < victim->second->cache_tick) victim = it;
+        }
+        if (victim == g_cache.end() || (idle <= cache_idle_cap() && n_idle <= 4096)) return;
+        athena_mp_graph *g = victim->second;
+        g_cache.erase(victim);
+        g->cache_refs = -1;
+        (void)graph_free(g);
+    }
+}
+}   // namespace
+
+extern "C++" {
+void amp::graph_cache_clear()
+{
+    for (auto &kv : g_cache) {
+        kv.second->cache_refs = -1;
+        (void)graph_free(kv.second);
+    }
+    g_cache.clear();
+}
+}
+
+int athena_mp_graph_acquire(int32_t n, int64_t nnz, const int32_t *adj_ia, const int32_t *adj_ja, int32_t n_edge_cols,
+                            athena_mp_graph **out)
+{
+    AMP_REQUIRE(out != nullptr, "graph_acquire: null out pointer");
+    *out = nullptr;
+    CacheId id;
+    int rc = athena_mp_graph_key(n, nnz, adj_ia, adj_ja, &id.key);
+    if (rc) return rc;
+    id.nnz = nnz;
+    id.n = n;
+    id.n_edge_cols = n_edge_cols;
+    id.device = amp::device();
+    auto it = g_cache.find(id);
+    if (it != g_cache.end()) {
+        it->second->cache_refs++;
+        it->second->cache_tick = ++g_cache_tick;
+        ++g_cache_hits;
+        *out = it->second;
+        return 0;
+    }
+    athena_mp_graph *g = nullptr;
+    rc = athena_mp_graph_create(n, n, nnz, adj_ia, adj_ja, n_edge_cols, nullptr, nullptr, &g);
+    if (rc) return rc;
+    g->cache_refs = 1;
+    g->cache_key = id.key;
+    g->cache_tick = ++g_cache_tick;
+    g->cache_device = id.device;
+    g_cache[id] = g;
+    *out = g;
+    return 0;
+}
+
+int athena_mp_graph_release(athena_mp_graph *g)
+{
+    if (!g) return 0;
+    AMP_REQUIRE(g->cache_refs > 0, "graph_release: handle is not an acquired one (refs %d)", g->cache_refs);
+    g->cache_refs--;
+    g->cache_tick = ++g_cache_tick;
+    if (g->cache_refs == 0) cache_trim();
+    return 0;
+}
+
+int athena_mp_graph_cache_stats(int64_t *handles, int64_t *hits, int64_t *builds)
+{
+    if (handles) *handles = (int64_t)g_cache.size();
+    if (hits) *hits = g_cache_hits;
+    if (builds) *builds = g_graph_builds;
+    return 0;
+}
+
+static int graph_create_body(int32_t n_rows, int32_t n_cols, int64_t nnz, const int32_t *adj_ia,
                              const int32_t *adj_ja, const int32_t *adj_ja_dev, int32_t n_edge_cols,
                              const int32_t *row_deg, const int32_t *col_deg, athena_mp_graph **out)
 {

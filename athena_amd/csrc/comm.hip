@@ -46,6 +46,8 @@ struct Transport {
     virtual int exchange(const void *const *sendp, const size_t *sendb, void *const *recvp, const size_t *recvb,
                          hipStream_t s) = 0;
     virtual int allreduce_f32(float *buf, size_t count, hipStream_t s) = 0;
+    // every rank contributes `bytes` from send; recv holds world * bytes, block p at p * bytes (send may be recv + rank * bytes)
+    virtual int allgather(const void *send, void *recv, size_t bytes, hipStream_t s) = 0;
 };
 
 struct RcclApi {
@@ -55,6 +57,7 @@ struct RcclApi {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
@@ -84,6 +87,7 @@ int rccl_load()
     AMP_SYM(CommDestroy, "ncclCommDestroy")
     AMP_SYM(GetErrorString, "ncclGetErrorString")
     AMP_SYM(AllReduce, "ncclAllReduce")
+    AMP_SYM(AllGather, "ncclAllGather")
     AMP_SYM(Send, "ncclSend")
     AMP_SYM(Recv, "ncclRecv")
     AMP_SYM(GroupStart, "ncclGroupStart")
@@ -124,6 +128,11 @@ struct RcclTransport : Transport {
     int allreduce_f32(float *buf, size_t count, hipStream_t s) override
     {
         if (count) AMP_NCCL(g_rccl.AllReduce(buf, buf, count, ncclFloat32, ncclSum, comm, s));
+        return 0;
+    }
+    int allgather(const void *send, void *recv, size_t bytes, hipStream_t s) override
+    {
+        if (bytes) AMP_NCCL(g_rccl.AllGather(send, recv, bytes, ncclInt8, comm, s));
         return 0;
     }
 };
@@ -239,6 +248,24 @@ struct ShmTransport : Transport {
         AMP_HIP(hipMemcpy(buf, sum.data(), 4 * count, hipMemcpyHostToDevice));
         return 0;
     }
+    int allgather(const void *send, void *recv, size_t bytes, hipStream_t s) override
+    {
+        if (!bytes) return 0;
+        const uint64_t q = seq++;
+        AMP_HIP(hipStreamSynchronize(s));
+        host.resize(bytes);
+        AMP_HIP(hipMemcpy(host.data(), send, bytes, hipMemcpyDeviceToHost));
+        for (int p = 0; p < world; ++p)
+            if (p != rank && put(path(q, rank, p), host.data(), bytes)) return 1;
+        if ((const char *)send != (char *)recv + (size_t)rank * bytes)
+            AMP_HIP(hipMemcpy((char *)recv + (size_t)rank * bytes, send, bytes, hipMemcpyDeviceToDevice));
+        for (int p = 0; p < world; ++p) {
+            if (p == rank) continue;
+            if (get(path(q, p, rank), host.data(), bytes)) return 1;
+            AMP_HIP(hipMemcpy((char *)recv + (size_t)p * bytes, host.data(), bytes, hipMemcpyHostToDevice));
+        }
+        return 0;
+    }
 };
 
 bool want_shm()
@@ -266,6 +293,13 @@ struct athena_mp_shard {
     std::vector<int64_t> halo_ids;         // [n_halo] global ids, ascending (grouped by owner)
     std::vector<int64_t> recv_counts, send_counts, roff, soff;   // rows per peer
     std::vector<int32_t> send_idx_h, col_deg, row_deg;
+    // how the halo travels: 0 = grouped send / recv of the rows peers asked for (packed by a gather kernel), 1 = one
+    // all-gather of every rank's whole block (no pack, no send lists): x_ext = [max_n local slots | world x max_n]
+    int mode = 0;
+    int64_t max_n = 0;                     // largest block (all-gather slots)
+    int32_t ext_rows = 0;                  // rows of x_ext beyond the n local ones (== n_halo in mode 0)
+    double halo_fraction = 0.0, tau = 0.7; // (sum of distinct halo rows over ranks) / ((world - 1) * n_total), threshold
+    std::vector<int64_t> ext_ids;          // [ext_rows] global id held by each row beyond the local ones, -1 = padding
     int32_t *send_idx = nullptr;           // device [n_send]: rows (new numbering) peers asked for, grouped by peer
     int64_t n_send = 0;
     athena_mp_graph *g[4] = {};            // fwd interior, fwd boundary, bwd interior, bwd boundary
@@ -310,17 +344,54 @@ int exchange_host(athena_mp_comm *c, const std::vector<const void *> &sp, const 
     return rc;
 }
 
-// every rank contributes `bytes`; out [world * bytes]
+// every rank contributes `bytes`; out [world * bytes].  One in-place all-gather of a device staging buffer.
 int allgather_host(athena_mp_comm *c, const void *mine, size_t bytes, void *out)
 {
     const int W = c->t->world, r = c->t->rank;
-    std::vector<const void *> sp(W, mine);
-    std::vector<size_t> sb(W, bytes), rb(W, bytes);
-    std::vector<void *> rp(W);
-    for (int p = 0; p < W; ++p) rp[p] = (char *)out + (size_t)p * bytes;
-    sb[r] = rb[r] = 0;
     memcpy((char *)out + (size_t)r * bytes, mine, bytes);
-    return exchange_host(c, sp, sb, rp, rb);
+    if (W == 1 || bytes == 0) return 0;
+    char *dev = nullptr;
+    AMP_HIP(hipMalloc((void **)&dev, (size_t)W * bytes));
+    int rc = 0;
+    if (hipMemcpy(dev + (size_t)r * bytes, mine, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = 1;
+    if (rc == 0) rc = c->t->allgather(dev + (size_t)r * bytes, dev, bytes, c->cs);
+    if (rc == 0 && hipStreamSynchronize(c->cs) != hipSuccess) rc = 1;
+    if (rc == 0 && hipMemcpy(out, dev, (size_t)W * bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = 1;
+    (void)hipFree(dev);
+    if (rc && athena_mp_last_error()[0] == 0) set_error("comm: metadata all-gather failed");
+    return rc;
+}
+
+// every rank reports a status word; returns 0 only when all are 0 -- so that a rank whose arguments are bad takes
+// every rank out of a collective call together instead of leaving its peers blocked in the next exchange
+int agree_ok(athena_mp_comm *c, int32_t mine, const char *what)
+{
+    const int W = c->t->world;
+    std::vector<int32_t> all(W, 0);
+    if (allgather_host(c, &mine, 4, all.data())) return 1;
+    for (int p = 0; p < W; ++p)
+        if (all[p] != 0) {
+            if (mine == 0) set_error("%s: rank %d rejected its arguments (all ranks return together)", what, p);
+            return 2;
+        }
+    return 0;
+}
+
+// how the halo travels: grouped send / recv of the distinct rows each peer needs, or -- when the ranks
+// together need more than `tau` of all remote rows anyway -- one all-gather of whole blocks (no pack kernel, no send
+// lists).  ATHENA_MP_HALO_MODE = auto (default) | p2p | allgather;  ATHENA_MP_HALO_ALLGATHER_FRACTION = tau (0.7).
+double halo_tau()
+{
+    const char *e = getenv("ATHENA_MP_HALO_ALLGATHER_FRACTION");
+    const double t = e ? atof(e) : 0.7;
+    return t > 0.0 ? t : 0.7;
+}
+int halo_mode_env()   // -1 auto, 0 p2p, 1 allgather
+{
+    const char *e = getenv("ATHENA_MP_HALO_MODE");
+    if (!e || !e[0] || strcmp(e, "auto") == 0) return -1;
+    if (strcmp(e, "allgather") == 0) return 1;
+    return 0;
 }
 
 int make_graph(const std::vector<int32_t> &ia_all, const std::vector<int32_t> &col, int32_t r0, int32_t r1, int32_t n_cols,
@@ -554,23 +625,48 @@ int athena_mp_shard_create(athena_mp_comm *c, int32_t n_local, int64_t nnz, cons
             return 1;                   \
         }                               \
     } while (0)
-    // 1. row blocks of every rank
+    // 1. row blocks of every rank; local validation first, agreed on before any data collective (a rank that bails
+    //    out alone would leave its peers blocked in the next exchange)
+    int32_t bad = 0;
+    for (int32_t v = 0; v < n && !bad; ++v)
+        if (adj_ia[v + 1] < adj_ia[v]) {
+            set_error("shard_create: adj_ia not monotone at row %d", v + 1);
+            bad = 1;
+        }
+    {
+        const int arc = agree_ok(c, bad, "shard_create");
+        if (arc) {
+            athena_mp_shard_destroy(s);
+            return arc;
+        }
+    }
     std::vector<int64_t> all_n(W);
     const int64_t my_n = n;
     SH_RC(allgather_host(c, &my_n, 8, all_n.data()));
     s->row_off.assign(W + 1, 0);
     for (int p = 0; p < W; ++p) s->row_off[p + 1] = s->row_off[p] + all_n[p];
     s->n_total = s->row_off[W];
+    s->max_n = *std::max_element(all_n.begin(), all_n.end());
     const int64_t lo = s->row_off[rank], hi = lo + n;
     s->row_offset = lo;
     // 2. interior-first numbering
     std::vector<char> is_bnd(n, 0);
-    for (int32_t v = 0; v < n; ++v) {
-        if (adj_ia[v + 1] < adj_ia[v]) SH_FAIL("shard_create: adj_ia not monotone at row %d", v + 1);
+    for (int32_t v = 0; v < n && !bad; ++v) {
         for (int32_t w = adj_ia[v] - 1; w < adj_ia[v + 1] - 1; ++w) {
             const int64_t u = (int64_t)adj_ja[2 * (size_t)w] - 1;
-            if (u < 0 || u >= s->n_total) SH_FAIL("shard_create: adj_ja(1,%d) = %lld outside [1,%lld]", w + 1, (long long)u + 1, (long long)s->n_total);
+            if (u < 0 || u >= s->n_total) {
+                set_error("shard_create: adj_ja(1,%d) = %lld outside [1,%lld]", w + 1, (long long)u + 1, (long long)s->n_total);
+                bad = 1;
+                break;
+            }
             if (u < lo || u >= hi) is_bnd[v] = 1;
+        }
+    }
+    {
+        const int arc = agree_ok(c, bad, "shard_create");
+        if (arc) {
+            athena_mp_shard_destroy(s);
+            return arc;
         }
     }
     s->order.resize(n);
@@ -609,14 +705,130 @@ int athena_mp_shard_create(athena_mp_comm *c, int32_t n_local, int64_t nnz, cons
         const int p = (int)(std::upper_bound(s->row_off.begin(), s->row_off.end(), u) - s->row_off.begin()) - 1;
         s->recv_counts[p]++;
     }
-    // 4. column renumbering [local | halo]; backward rows sorted by global source id (stable)
-    std::vector<int32_t> col(nnz), col_b(nnz);
-    for (int64_t w = 0; w < nnz; ++w) {
-        const int64_t u = cg[w];
-        col[w] = (u >= lo && u < hi) ? new_of_old[u - lo]
-                                     : n + (int32_t)(std::lower_bound(s->halo_ids.begin(), s->halo_ids.end(), u) - s->halo_ids.begin());
-    }
+    // 4. who needs how much of whom, and from that the way the halo travels
+    std::vector<int64_t> allc((size_t)W * W);
+    SH_RC(allgather_host(c, s->recv_counts.data(), 8 * (size_t)W, allc.data()));   // allc[q*W + p] = rows q needs from p
     {
+        int64_t need = 0;
+        for (int64_t v : allc) need += v;
+        const double remote = (double)(W - 1) * (double)s->n_total;
+        s->halo_fraction = remote > 0 ? (double)need / remote : 0.0;
+        s->tau = halo_tau();
+        const int forced = halo_mode_env();
+        s->mode = W > 1 && (forced >= 0 ? forced : (s->halo_fraction > s->tau ? 1 : 0));
+        if (s->mode == 1 && (s->max_n * (int64_t)(W + 1) >= (int64_t)INT32_MAX)) s->mode = 0;   // int32 column ids
+    }
+    s->send_counts.assign(W, 0);
+    s->roff.assign(W + 1, 0);
+    s->soff.assign(W + 1, 0);
+    std::vector<int32_t> col(nnz), col_b(nnz);
+    if (s->mode == 0) {
+        // 5a. grouped send / recv: columns [local | distinct halo rows], send lists learnt from the peers
+        for (int64_t w = 0; w < nnz; ++w) {
+            const int64_t u = cg[w];
+            col[w] = (u >= lo && u < hi) ? new_of_old[u - lo]
+                                         : n + (int32_t)(std::lower_bound(s->halo_ids.begin(), s->halo_ids.end(), u) - s->halo_ids.begin());
+        }
+        for (int q = 0; q < W; ++q)
+            if (q != rank) s->send_counts[q] = allc[(size_t)q * W + rank];
+        for (int p = 0; p < W; ++p) {
+            s->roff[p + 1] = s->roff[p] + s->recv_counts[p];
+            s->soff[p + 1] = s->soff[p] + s->send_counts[p];
+        }
+        s->n_send = s->soff[W];
+        std::vector<int32_t> want(s->n_halo), asked(s->n_send);
+        for (int32_t k = 0; k < s->n_halo; ++k) {
+            const int p = (int)(std::upper_bound(s->row_off.begin(), s->row_off.end(), s->halo_ids[k]) - s->row_off.begin()) - 1;
+            want[k] = (int32_t)(s->halo_ids[k] - s->row_off[p]);   // owner-local ORIGINAL id
+        }
+        {
+            std::vector<const void *> sp(W);
+            std::vector<void *> rp(W);
+            std::vector<size_t> sb(W), rb(W);
+            for (int p = 0; p < W; ++p) {
+                sp[p] = want.data() + s->roff[p];
+                sb[p] = 4 * (size_t)s->recv_counts[p];
+                rp[p] = asked.data() + s->soff[p];
+                rb[p] = 4 * (size_t)s->send_counts[p];
+            }
+            sb[rank] = rb[rank] = 0;
+            SH_RC(exchange_host(c, sp, sb, rp, rb));
+        }
+        s->send_idx_h.resize(s->n_send);
+        std::vector<int32_t> sdeg(s->n_send), hdeg(s->n_halo);
+        bad = 0;
+        for (int64_t i = 0; i < s->n_send; ++i) {
+            if (asked[i] < 0 || asked[i] >= n) {
+                set_error("shard_create: a peer asked for row %d of %d", asked[i], n);
+                bad = 1;
+                break;
+            }
+            s->send_idx_h[i] = new_of_old[asked[i]];
+            sdeg[i] = s->row_deg[s->send_idx_h[i]];
+        }
+        {
+            const int arc = agree_ok(c, bad, "shard_create");
+            if (arc) {
+                athena_mp_shard_destroy(s);
+                return arc;
+            }
+        }
+        {   // degrees of the halo columns from their owners
+            std::vector<const void *> sp(W);
+            std::vector<void *> rp(W);
+            std::vector<size_t> sb(W), rb(W);
+            for (int p = 0; p < W; ++p) {
+                sp[p] = sdeg.data() + s->soff[p];
+                sb[p] = 4 * (size_t)s->send_counts[p];
+                rp[p] = hdeg.data() + s->roff[p];
+                rb[p] = 4 * (size_t)s->recv_counts[p];
+            }
+            sb[rank] = rb[rank] = 0;
+            SH_RC(exchange_host(c, sp, sb, rp, rb));
+        }
+        s->col_deg = s->row_deg;
+        s->col_deg.insert(s->col_deg.end(), hdeg.begin(), hdeg.end());
+        s->ext_rows = s->n_halo;
+        s->ext_ids = s->halo_ids;
+    } else {
+        // 5b. all-gather of whole blocks: x_ext = [max_n local slots (n used) | world blocks of max_n slots, block p in
+        //     rank p's OWN interior-first order] -- the halo rows are a view into the gathered blocks by block offset.
+        //     Every rank publishes where its vertices went (new_of_old) and their degrees; nothing else is needed.
+        const int64_t M = s->max_n;
+        std::vector<int32_t> mine(2 * (size_t)M, -1), all(2 * (size_t)M * W);
+        for (int32_t v = 0; v < n; ++v) {
+            mine[v] = new_of_old[v];                        // [0, M): position of original local vertex v
+            mine[(size_t)M + new_of_old[v]] = adj_ia[v + 1] - adj_ia[v];   // [M, 2M): degree of the vertex at each position
+        }
+        SH_RC(allgather_host(c, mine.data(), 8 * (size_t)M, all.data()));
+        s->ext_rows = (int32_t)(M - n + M * W);
+        s->col_deg.assign((size_t)n + s->ext_rows, 0);
+        std::copy(s->row_deg.begin(), s->row_deg.end(), s->col_deg.begin());
+        s->ext_ids.assign(s->ext_rows, -1);
+        for (int p = 0; p < W; ++p) {
+            const int32_t *pos = all.data() + 2 * (size_t)M * p, *deg = pos + M;
+            const int64_t base = M + M * p;                 // first row of block p in x_ext
+            for (int64_t i = 0; i < all_n[p]; ++i) {
+                s->col_deg[base + i] = deg[i];
+                s->ext_ids[base - n + pos[i]] = s->row_off[p] + i;
+            }
+        }
+        for (int64_t w = 0; w < nnz; ++w) {
+            const int64_t u = cg[w];
+            if (u >= lo && u < hi) {
+                col[w] = new_of_old[u - lo];
+            } else {
+                const int p = (int)(std::upper_bound(s->row_off.begin(), s->row_off.end(), u) - s->row_off.begin()) - 1;
+                col[w] = (int32_t)(M + M * p + all[2 * (size_t)M * p + (u - s->row_off[p])]);
+            }
+        }
+        for (int p = 0; p < W; ++p) {                       // what crosses a link per exchange: every other rank's block
+            s->roff[p + 1] = s->roff[p] + (p == rank ? 0 : all_n[p]);
+            s->soff[p + 1] = s->soff[p];
+        }
+        s->n_send = 0;
+    }
+    {   // backward rows: entries sorted by global source id (stable) -- the reference's scatter order
         std::vector<int32_t> perm;
         for (int32_t k = 0; k < n; ++k) {
             const int32_t b = ia[k], e = ia[k + 1];
@@ -626,65 +838,12 @@ int athena_mp_shard_create(athena_mp_comm *c, int32_t n_local, int64_t nnz, cons
             for (int32_t i = 0; i < e - b; ++i) col_b[b + i] = col[perm[i]];
         }
     }
-    // 5. the plan: who needs which of my rows
-    std::vector<int64_t> allc((size_t)W * W);
-    SH_RC(allgather_host(c, s->recv_counts.data(), 8 * (size_t)W, allc.data()));   // allc[q*W + p] = rows q needs from p
-    s->send_counts.assign(W, 0);
-    for (int q = 0; q < W; ++q)
-        if (q != rank) s->send_counts[q] = allc[(size_t)q * W + rank];
-    s->roff.assign(W + 1, 0);
-    s->soff.assign(W + 1, 0);
-    for (int p = 0; p < W; ++p) {
-        s->roff[p + 1] = s->roff[p] + s->recv_counts[p];
-        s->soff[p + 1] = s->soff[p] + s->send_counts[p];
-    }
-    s->n_send = s->soff[W];
-    std::vector<int32_t> want(s->n_halo), asked(s->n_send);
-    for (int32_t k = 0; k < s->n_halo; ++k) {
-        const int p = (int)(std::upper_bound(s->row_off.begin(), s->row_off.end(), s->halo_ids[k]) - s->row_off.begin()) - 1;
-        want[k] = (int32_t)(s->halo_ids[k] - s->row_off[p]);   // owner-local ORIGINAL id
-    }
-    {
-        std::vector<const void *> sp(W);
-        std::vector<void *> rp(W);
-        std::vector<size_t> sb(W), rb(W);
-        for (int p = 0; p < W; ++p) {
-            sp[p] = want.data() + s->roff[p];
-            sb[p] = 4 * (size_t)s->recv_counts[p];
-            rp[p] = asked.data() + s->soff[p];
-            rb[p] = 4 * (size_t)s->send_counts[p];
-        }
-        sb[rank] = rb[rank] = 0;
-        SH_RC(exchange_host(c, sp, sb, rp, rb));
-    }
-    s->send_idx_h.resize(s->n_send);
-    std::vector<int32_t> sdeg(s->n_send), hdeg(s->n_halo);
-    for (int64_t i = 0; i < s->n_send; ++i) {
-        if (asked[i] < 0 || asked[i] >= n) SH_FAIL("shard_create: a peer asked for row %d of %d", asked[i], n);
-        s->send_idx_h[i] = new_of_old[asked[i]];
-        sdeg[i] = s->row_deg[s->send_idx_h[i]];
-    }
-    {   // degrees of the halo columns from their owners
-        std::vector<const void *> sp(W);
-        std::vector<void *> rp(W);
-        std::vector<size_t> sb(W), rb(W);
-        for (int p = 0; p < W; ++p) {
-            sp[p] = sdeg.data() + s->soff[p];
-            sb[p] = 4 * (size_t)s->send_counts[p];
-            rp[p] = hdeg.data() + s->roff[p];
-            rb[p] = 4 * (size_t)s->recv_counts[p];
-        }
-        sb[rank] = rb[rank] = 0;
-        SH_RC(exchange_host(c, sp, sb, rp, rb));
-    }
-    s->col_deg = s->row_deg;
-    s->col_deg.insert(s->col_deg.end(), hdeg.begin(), hdeg.end());
     if (hipMalloc((void **)&s->send_idx, 4 * (size_t)std::max<int64_t>(s->n_send, 1)) != hipSuccess)
         SH_FAIL("shard_create: device allocation failed");
     if (s->n_send && hipMemcpy(s->send_idx, s->send_idx_h.data(), 4 * (size_t)s->n_send, hipMemcpyHostToDevice) != hipSuccess)
         SH_FAIL("shard_create: upload of the send list failed");
-    // 6. the four row blocks as graph handles (rectangular: n + n_halo columns, explicit degrees)
-    const int32_t ncols = n + s->n_halo;
+    // 6. the four row blocks as graph handles (rectangular: n + ext_rows columns, explicit degrees)
+    const int32_t ncols = n + s->ext_rows;
     SH_RC(make_graph(ia, col, 0, s->n_int, ncols, s->row_deg, s->col_deg, &s->g[0]));
     SH_RC(make_graph(ia, col, s->n_int, n, ncols, s->row_deg, s->col_deg, &s->g[1]));
     SH_RC(make_graph(ia, col_b, 0, s->n_int, ncols, s->row_deg, s->col_deg, &s->g[2]));

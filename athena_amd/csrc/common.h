@@ -74,6 +74,11 @@ struct athena_mp_graph {
     int32_t n_rows = 0, n_cols = 0, n_edge_cols = 0;
     int64_t nnz = 0;
     int32_t max_row_len = 0, max_col_len = 0;
+    // handle cache (athena_mp_graph_acquire / _release): users of a cached handle, -1 = not cached
+    int32_t cache_refs = -1;
+    uint64_t cache_key = 0;
+    uint64_t cache_tick = 0;
+    int cache_device = 0;
     // forward CSR, 0-based
     int32_t *rowptr = nullptr;  // [n_rows+1]
     int32_t *col = nullptr;     // [nnz]  neighbour u
@@ -122,6 +127,7 @@ int graph_build_device(athena_mp_graph *g, const int32_t *adj_ja, const std::vec
 int csr_from_edges_core(int32_t n_vertices, int64_t n_pairs, const int32_t *index_list, int32_t add_self_loops,
                         int32_t *adj_ia_out, int32_t *adj_ja_out, int64_t capacity, int64_t *nnz_out,
                         int32_t **keep_ja_dev);
+void graph_cache_clear(); // idle and live handles of athena_mp_graph_acquire (capi.hip)
 void host_pool_release();   // staging buffers of the *_host entry points (host.hip)
 int agg_blocks_cap();
 void set_agg_blocks_cap(int n);

@@ -13,7 +13,8 @@ module athena_mp_c
        ATHENA_MP_ACT_SIGMOID = 2, ATHENA_MP_ACT_TANH = 3
 
   public :: athena_mp_init, athena_mp_finalize, athena_mp_last_error, athena_mp_synchronize
-  public :: athena_mp_graph_create, athena_mp_graph_destroy
+  public :: athena_mp_graph_create, athena_mp_graph_destroy, athena_mp_graph_key
+  public :: athena_mp_graph_acquire, athena_mp_graph_release, athena_mp_graph_cache_stats
   public :: athena_mp_kipf_propagate_fwd_host, athena_mp_kipf_propagate_bwd_host
   public :: athena_mp_gemm_fwd_host
   public :: athena_mp_duvenaud_propagate_fwd_host, athena_mp_duvenaud_propagate_bwd_x_host
@@ -75,6 +76,35 @@ module athena_mp_c
      integer(c_int) function athena_mp_graph_destroy(graph) bind(C, name="athena_mp_graph_destroy")
        import :: c_int, c_ptr
        type(c_ptr), value :: graph
+     end function
+     !! content key of (adj_ia, adj_ja): what a cached handle is valid for (SURVEY.md 8b "Ownership");
+     !! key is C's uint64_t -- compared for equality only, so its bit pattern in an int64 serves
+     pure integer(c_int) function athena_mp_graph_key(n_rows, nnz, adj_ia, adj_ja, key) &
+          bind(C, name="athena_mp_graph_key")
+       import :: c_int, c_int32_t, c_int64_t
+       integer(c_int32_t), value :: n_rows
+       integer(c_int64_t), value :: nnz
+       integer(c_int32_t), intent(in) :: adj_ia(*), adj_ja(2,*)
+       integer(c_int64_t), intent(out) :: key
+     end function
+     !! set_graph as a cache lookup (athena_network_sub.f90:2727-2730 calls set_graph before every forward):
+     !! the shared, reference-counted handle of this CSR; built only when no live or idle handle matches
+     integer(c_int) function athena_mp_graph_acquire(n, nnz, adj_ia, adj_ja, n_edge_cols, graph) &
+          bind(C, name="athena_mp_graph_acquire")
+       import :: c_int, c_int32_t, c_int64_t, c_ptr
+       integer(c_int32_t), value :: n, n_edge_cols
+       integer(c_int64_t), value :: nnz
+       integer(c_int32_t), intent(in) :: adj_ia(*), adj_ja(2,*)
+       type(c_ptr), intent(out) :: graph
+     end function
+     integer(c_int) function athena_mp_graph_release(graph) bind(C, name="athena_mp_graph_release")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: graph
+     end function
+     integer(c_int) function athena_mp_graph_cache_stats(handles, hits, builds) &
+          bind(C, name="athena_mp_graph_cache_stats")
+       import :: c_int, c_int64_t
+       integer(c_int64_t), intent(out) :: handles, hits, builds
      end function
 
      !! kipf_propagate, athena_diffstruc_extd_sub_kipf.f90:7-59 (host arrays, staged)

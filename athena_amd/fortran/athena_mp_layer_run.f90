@@ -46,6 +46,8 @@ program athena_mp_layer_run
      call run_gno()
   case(4)
      call run_kipf_chain()
+  case(5)
+     call run_kipf_graph_swap()
   case default
      write(0,*) "unknown layer kind", kind
      stop 4
@@ -225,5 +227,67 @@ contains
     call l1%destroy()
     call l2%destroy()
   end subroutine run_kipf_chain
+
+  subroutine run_kipf_graph_swap()
+    !! set_graph before every forward, as athena_network_sub.f90:2727-2730 does: batch A, batch B (same vertex and entry
+    !! counts, different adjacency), A again, A a fourth time, then A's arrays OVERWRITTEN IN PLACE with B's.  Every
+    !! forward must see the graph it was given; only real changes may rebuild the device handle.
+    type(kipf_mp_layer_type) :: layer, twin
+    type(mp_actv_type) :: act
+    type(mp_graph_type), allocatable :: other(:)
+    integer :: t, nf
+    integer, allocatable :: nvf(:)
+    integer(c_int64_t) :: handles, hits, builds0, builds1
+    integer :: counts(6)
+
+    read(uin) t, nf
+    allocate(nvf(nf))
+    read(uin) nvf
+    act = read_actv()
+    layer = kipf_mp_layer_type(num_vertex_features=nvf, num_time_steps=t, activation=act)
+    twin = kipf_mp_layer_type(num_vertex_features=nvf, num_time_steps=t, activation=act)
+    read(uin) nparams
+    allocate(params(nparams))
+    read(uin) params
+    call layer%set_params(params)
+    call twin%set_params(params)
+    allocate(other(batch))
+    do s = 1, batch
+       read(uin) nv, ne, nnz
+       other(s)%num_vertices = nv
+       other(s)%num_edges = ne
+       allocate(other(s)%adj_ia(nv + 1), other(s)%adj_ja(2, nnz))
+       read(uin) other(s)%adj_ia
+       if(nnz .gt. 0) read(uin) other(s)%adj_ja
+    end do
+    call read_matrix(x)
+    if(athena_mp_graph_cache_stats(handles, hits, builds0) .ne. 0) stop 8
+
+    call layer%set_graph(graphs)
+    call write_matrix(layer%forward(x))                      ! A
+    counts(1) = layer%graph_builds
+    call layer%set_graph(other)
+    call write_matrix(layer%forward(x))                      ! B: same sizes, other adjacency
+    counts(2) = layer%graph_builds
+    call layer%set_graph(graphs)
+    call write_matrix(layer%forward(x))                      ! A again
+    counts(3) = layer%graph_builds
+    call layer%set_graph(graphs)
+    call twin%set_graph(graphs)                              ! a second layer on the same batch shares the handle
+    call write_matrix(twin%forward(x))
+    counts(4) = layer%graph_builds
+    do s = 1, batch                                          ! in-place edit: same arrays, B's content
+       graphs(s)%adj_ia = other(s)%adj_ia
+       graphs(s)%adj_ja = other(s)%adj_ja
+    end do
+    call layer%set_graph(graphs)
+    call write_matrix(layer%forward(x))
+    counts(5) = layer%graph_builds
+    if(athena_mp_graph_cache_stats(handles, hits, builds1) .ne. 0) stop 8
+    counts(6) = int(builds1 - builds0)                       ! device handles actually built: A and B, once each
+    write(uout) int(counts, c_int32_t)
+    call layer%destroy()
+    call twin%destroy()
+  end subroutine run_kipf_graph_swap
 
 end program athena_mp_layer_run

@@ -61,6 +61,11 @@ module athena_mp_layers
      integer, allocatable :: vertex_offset(:)          ! (batch+1), 0-based starts of each graph's vertices
      type(dbuf) :: seg                                 ! the same offsets on the device (int32)
      logical :: keep_edges = .false.
+     ! what the handle was built from: per graph of the batch its sizes and the content key of its CSR
+     ! (athena_mp_graph_key).  set_graph compares these and keeps the handle when nothing changed.
+     integer, allocatable :: key_n(:), key_nnz(:), key_ne(:)
+     integer(c_int64_t), allocatable :: key_hash(:)
+     integer :: graph_builds = 0                       ! times set_graph had to (re)build -- the cache tests read it
      integer :: num_tensors = 0
      integer, allocatable :: psize(:)                  ! size of params(i)%val(:,1)
      type(dbuf), allocatable :: params(:), grads(:)
@@ -69,6 +74,7 @@ module athena_mp_layers
    contains
      procedure, pass(this) :: set_graph => layer_set_graph
      procedure, pass(this) :: set_graph_from_edges => layer_set_graph_from_edges
+     procedure, pass(this) :: invalidate_graph => layer_invalidate_graph
      procedure, pass(this) :: get_num_params => layer_get_num_params
      procedure, pass(this) :: get_params => layer_get_params
      procedure, pass(this) :: set_params => layer_set_params
@@ -365,51 +371,93 @@ contains
   subroutine layer_set_graph(this, graph)
     !! athena_msgpass_layer_sub.f90:144-174.  The batch becomes ONE block-diagonal device graph: vertex
     !! ids shifted by the vertices before, edge ids (where > 0) by the edge columns before.
+    !! The reference calls this before EVERY forward (athena_network_sub.f90:2727-2730) and copies the CSR each
+    !! time; here it costs one content key per graph (athena_mp_graph_key: all of a mini-batch graph, a sample of a
+    !! 10 M-entry one) -- the handle is rebuilt only when a size or a key differs from what it was built from, and a
+    !! rebuilt batch goes through athena_mp_graph_acquire, so layers that are given the same batch share one handle.
+    !! A large graph edited IN PLACE outside the sampled elements needs invalidate_graph() (or
+    !! ATHENA_MP_GRAPH_KEY_FULL=1).
     class(mp_layer_type), intent(inout) :: this
     type(mp_graph_type), intent(in) :: graph(:)
     integer(c_int32_t), allocatable :: ia(:), ja(:,:)
-    integer :: s, nnz, v0, e0, w0, k, n
+    integer, allocatable :: kn(:), knnz(:), kne(:)
+    integer(c_int64_t), allocatable :: kh(:)
+    integer :: s, nnz, v0, e0, w0, n, m, b
+    logical :: same
 
-    if(c_associated(this%graph)) call chk(athena_mp_graph_destroy(this%graph), "graph_destroy")
-    this%graph = c_null_ptr
-    this%batch = size(graph)
-    if(allocated(this%vertex_offset)) deallocate(this%vertex_offset)
-    allocate(this%vertex_offset(this%batch + 1))
-    nnz = 0
-    this%vertex_offset(1) = 0
-    this%ne = 0
-    do s = 1, this%batch
+    b = size(graph)
+    allocate(kn(b), knnz(b), kne(b), kh(b))
+    do s = 1, b
        if(.not. allocated(graph(s)%adj_ia) .or. .not. allocated(graph(s)%adj_ja)) &
             call stop_program("set_graph: graph has no adjacency (call generate_adjacency first)")
-       nnz = nnz + size(graph(s)%adj_ja, 2)
-       this%vertex_offset(s + 1) = this%vertex_offset(s) + graph(s)%num_vertices
-       this%ne = this%ne + graph(s)%num_edges
+       kn(s) = graph(s)%num_vertices
+       knnz(s) = size(graph(s)%adj_ja, 2)
+       kne(s) = graph(s)%num_edges
+       if(size(graph(s)%adj_ia) .ne. kn(s) + 1) call stop_program("set_graph: adj_ia must hold num_vertices + 1 row pointers")
+       call chk(athena_mp_graph_key(int(kn(s), c_int32_t), int(knnz(s), c_int64_t), graph(s)%adj_ia, graph(s)%adj_ja, &
+            kh(s)), "graph_key")
     end do
-    this%nv = this%vertex_offset(this%batch + 1)
-    allocate(ia(this%nv + 1), ja(2, max(nnz, 1)))
-    ia(1) = 1
-    v0 = 0
-    e0 = 0
-    w0 = 0
-    do s = 1, this%batch
-       n = graph(s)%num_vertices
-       do k = 1, n
-          ia(v0 + k + 1) = graph(s)%adj_ia(k + 1) + w0
-       end do
-       do k = 1, size(graph(s)%adj_ja, 2)
-          ja(1, w0 + k) = graph(s)%adj_ja(1, k) + v0
-          ! edge ids only where the layer reads edge features (a Kipf handle carries none)
-          ja(2, w0 + k) = merge(graph(s)%adj_ja(2, k) + e0, 0_c_int32_t, graph(s)%adj_ja(2, k) .gt. 0 .and. this%keep_edges)
-       end do
-       v0 = v0 + n
-       e0 = e0 + graph(s)%num_edges
-       w0 = w0 + size(graph(s)%adj_ja, 2)
+    same = c_associated(this%graph) .and. allocated(this%key_hash)
+    if(same) same = size(this%key_hash) .eq. b
+    if(same) same = all(this%key_n .eq. kn) .and. all(this%key_nnz .eq. knnz) .and. all(this%key_ne .eq. kne) &
+         .and. all(this%key_hash .eq. kh)
+    if(same) return                                    ! the handle, offsets and device segments are still valid
+
+    call layer_invalidate_graph(this)
+    this%batch = b
+    if(allocated(this%vertex_offset)) deallocate(this%vertex_offset)
+    allocate(this%vertex_offset(b + 1))
+    this%vertex_offset(1) = 0
+    do s = 1, b
+       this%vertex_offset(s + 1) = this%vertex_offset(s) + kn(s)
     end do
-    call chk(athena_mp_graph_create(int(this%nv, c_int32_t), int(this%nv, c_int32_t), int(nnz, c_int64_t), ia, ja, &
-         int(merge(this%ne, 0, this%keep_edges), c_int32_t), c_null_ptr, c_null_ptr, this%graph), "graph_create")
+    nnz = sum(knnz)
+    this%ne = sum(kne)
+    this%nv = this%vertex_offset(b + 1)
+    if(b .eq. 1 .and. this%keep_edges)then
+       ! one graph with its edge ids: the caller's arrays are the block-diagonal batch
+       call chk(athena_mp_graph_acquire(int(this%nv, c_int32_t), int(nnz, c_int64_t), graph(1)%adj_ia, graph(1)%adj_ja, &
+            int(this%ne, c_int32_t), this%graph), "graph_acquire")
+    else
+       allocate(ia(this%nv + 1), ja(2, max(nnz, 1)))
+       ia(1) = 1
+       v0 = 0
+       e0 = 0
+       w0 = 0
+       do s = 1, b                                     ! whole-array shifts (vectorised), no per-entry branches
+          n = kn(s)
+          m = knnz(s)
+          ia(v0 + 2:v0 + n + 1) = graph(s)%adj_ia(2:n + 1) + w0
+          ja(1, w0 + 1:w0 + m) = graph(s)%adj_ja(1, 1:m) + v0
+          if(this%keep_edges)then
+             ja(2, w0 + 1:w0 + m) = merge(graph(s)%adj_ja(2, 1:m) + e0, 0_c_int32_t, graph(s)%adj_ja(2, 1:m) .gt. 0)
+          else
+             ja(2, w0 + 1:w0 + m) = 0_c_int32_t        ! a Kipf handle carries no edge ids
+          end if
+          v0 = v0 + n
+          e0 = e0 + kne(s)
+          w0 = w0 + m
+       end do
+       call chk(athena_mp_graph_acquire(int(this%nv, c_int32_t), int(nnz, c_int64_t), ia, ja, &
+            int(merge(this%ne, 0, this%keep_edges), c_int32_t), this%graph), "graph_acquire")
+    end if
+    this%graph_builds = this%graph_builds + 1
+    call move_alloc(kn, this%key_n)
+    call move_alloc(knnz, this%key_nnz)
+    call move_alloc(kne, this%key_ne)
+    call move_alloc(kh, this%key_hash)
     call need(this%seg, i8(this%batch + 1))
     call chk(athena_mp_memcpy_h2d(this%seg%p, this%vertex_offset, 4_c_int64_t * i8(this%batch + 1)), "h2d")
   end subroutine layer_set_graph
+
+  subroutine layer_invalidate_graph(this)
+    !! drop the handle: the next set_graph rebuilds whatever its keys say (for in-place edits of a large adjacency
+    !! that the sampled key may not see)
+    class(mp_layer_type), intent(inout) :: this
+    if(c_associated(this%graph)) call chk(athena_mp_graph_destroy(this%graph), "graph_destroy")
+    this%graph = c_null_ptr
+    if(allocated(this%key_hash)) deallocate(this%key_n, this%key_nnz, this%key_ne, this%key_hash)
+  end subroutine layer_invalidate_graph
 
   subroutine layer_set_graph_from_edges(this, num_vertices, index_list, add_self_loops)
     !! one graph given as its edge list (what generate_adjacency takes): CSR and device handle are built on the GPU in
@@ -425,8 +473,8 @@ contains
     if(size(index_list, 1) .ne. 2) call stop_program("set_graph_from_edges: index_list must be (2, num_edges)")
     loops = 0
     if(present(add_self_loops)) loops = merge(1_c_int32_t, 0_c_int32_t, add_self_loops)
-    if(c_associated(this%graph)) call chk(athena_mp_graph_destroy(this%graph), "graph_destroy")
-    this%graph = c_null_ptr
+    call layer_invalidate_graph(this)
+    this%graph_builds = this%graph_builds + 1
     this%batch = 1
     this%nv = num_vertices
     this%ne = size(index_list, 2)
@@ -552,8 +600,7 @@ contains
   subroutine layer_release_base(this)
     class(mp_layer_type), intent(inout) :: this
     integer :: i
-    if(c_associated(this%graph)) call chk(athena_mp_graph_destroy(this%graph), "graph_destroy")
-    this%graph = c_null_ptr
+    call layer_invalidate_graph(this)
     call release(this%seg)
     do i = 1, this%num_tensors
        call release(this%params(i))

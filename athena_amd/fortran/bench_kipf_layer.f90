@@ -15,6 +15,10 @@ program bench_kipf_layer
   character(32) :: arg
   type(kipf_mp_layer_type) :: layer
   integer(c_int32_t), allocatable :: index_list(:,:)
+  type(mp_graph_type), allocatable :: graphs(:)
+  integer(c_int32_t), allocatable, target :: ja_host(:,:)
+  integer(c_int64_t) :: handles, hits, builds0, builds1
+  real(c_double) :: ms_set, ms_first
   real(real32), allocatable :: x(:,:), u(:)
   type(c_ptr) :: x_dev, dz_dev, y_dev, dx_dev
   real(real32) :: r(2)
@@ -50,6 +54,14 @@ program bench_kipf_layer
   call system_clock(c1)
   nnz = 2_c_int64_t * pairs + n
   write(*,'(A,F8.2,A)') "# graph handle from the edge list: ", real(c1 - c0, c_double) / real(rate, c_double) * 1.d3, " ms"
+  ! the same graph as a graph_type's host arrays, for the set_graph-before-every-forward measurement below
+  allocate(graphs(1))
+  graphs(1)%num_vertices = n
+  graphs(1)%num_edges = int(pairs)
+  allocate(graphs(1)%adj_ia(n + 1), ja_host(2, nnz))
+  call must(athena_mp_csr_from_edges(int(n, c_int32_t), pairs, index_list, 1_c_int32_t, graphs(1)%adj_ia, c_loc(ja_host), &
+       nnz, c1), "csr_from_edges")
+  call move_alloc(ja_host, graphs(1)%adj_ja)
   deallocate(index_list)
 
   allocate(x(f, n))
@@ -75,12 +87,38 @@ program bench_kipf_layer
   call system_clock(c1)
   ms = real(c1 - c0, c_double) / real(rate, c_double) * 1.d3 / steps
 
+  ! set_graph before EVERY forward, as athena_network_sub.f90:2727-2730 does: the first call builds the handle from the
+  ! host arrays, the others cost one content key each (athena_mp_graph_key) and keep it
+  call must(athena_mp_graph_cache_stats(handles, hits, builds0), "cache_stats")
+  call system_clock(c0, rate)
+  call layer%set_graph(graphs)
+  call must(athena_mp_synchronize(), "sync")
+  call system_clock(c1)
+  ms_first = real(c1 - c0, c_double) / real(rate, c_double) * 1.d3
+  do k = 1, 3
+     call layer%set_graph(graphs)
+     y_dev = layer%forward_dev(x_dev)
+     dx_dev = layer%backward_dev(dz_dev)
+  end do
+  call must(athena_mp_synchronize(), "sync")
+  call system_clock(c0, rate)
+  do k = 1, steps
+     call layer%set_graph(graphs)
+     y_dev = layer%forward_dev(x_dev)
+     dx_dev = layer%backward_dev(dz_dev)
+  end do
+  call must(athena_mp_synchronize(), "sync")
+  call system_clock(c1)
+  ms_set = real(c1 - c0, c_double) / real(rate, c_double) * 1.d3 / steps
+  call must(athena_mp_graph_cache_stats(handles, hits, builds1), "cache_stats")
+
   ! one sanity value back on the host: the gradient of the first weight
   u = layer%get_gradients()
-  write(*,'(A,I0,A,I0,A,I0,A,I0,A,F9.4,A,ES12.5,A,ES12.5,A)') &
+  write(*,'(A,I0,A,I0,A,I0,A,I0,A,F9.4,A,ES12.5,A,ES12.5,A,F9.4,A,F9.3,A,I0,A)') &
        '{"driver": "fortran kipf_mp_layer_type%forward_dev/backward_dev", "vertices": ', n, ', "entries": ', nnz, &
        ', "features": ', f, ', "steps": ', steps, ', "ms_per_step": ', ms, ', "edges_per_s": ', &
-       real(nnz, c_double) / (ms * 1.d-3), ', "dW(1)": ', u(1), '}'
+       real(nnz, c_double) / (ms * 1.d-3), ', "dW(1)": ', u(1), ', "ms_per_step_set_graph_every_forward": ', ms_set, &
+       ', "first_set_graph_ms": ', ms_first, ', "handles_built_by_the_set_graph_calls": ', builds1 - builds0, '}'
   call layer%destroy()
   call must(athena_mp_free(x_dev), "free")
   call must(athena_mp_free(dz_dev), "free")

@@ -55,19 +55,23 @@ class graph_type:
 
     def topology_key(self):
         """what a cached device handle of this graph is valid for: the object, its version (bumped by every assignment
-        of adj_ia / adj_ja), the sizes and a checksum of the arrays' CONTENT -- all of it below 2^18 entries, a strided
-        sample plus head and tail above (in-place edits of a mini-batch graph are always seen; hashing 80 MB per
-        forward on a 10 M-entry graph would cost more than the layer step)."""
-        import xxhash
-        ia, ja = np.ascontiguousarray(self._adj_ia), self._adj_ja
-        h = xxhash.xxh3_64()
-        if ja.shape[1] < (1 << 18):
-            h.update(ia.tobytes()); h.update(np.asfortranarray(ja).tobytes(order="F"))
-        else:
-            st_i, st_j = max(1, ia.size // 4096), max(1, ja.shape[1] // 4096)
-            for part in (ia[:1024], ia[-1024:], ia[::st_i], ja[:, :1024], ja[:, -1024:], ja[:, ::st_j]):
-                h.update(np.ascontiguousarray(part).tobytes())
-        return (id(self), self._version, int(self.num_vertices), int(ja.shape[1]), h.intdigest())
+        of adj_ia / adj_ja), the sizes and the C ABI's content key of the arrays (athena_mp_graph_key: all of the
+        content below 2^18 entries, a strided sample plus head and tail above -- in-place edits of a mini-batch graph
+        are always seen; hashing 80 MB per forward on a 10 M-entry graph would cost more than the layer step.  After
+        an in-place edit of a LARGE adjacency call touch(), or run with ATHENA_MP_GRAPH_KEY_FULL=1)."""
+        import ctypes as C
+
+        from . import _capi
+
+        ia = np.ascontiguousarray(self._adj_ia, dtype=np.int32)
+        ja = np.asfortranarray(self._adj_ja, dtype=np.int32)
+        key = C.c_uint64(0)
+        _capi.call("athena_mp_graph_key", int(ia.size - 1), int(ja.shape[1]), ia.ctypes.data, ja.ctypes.data, C.byref(key))
+        return (id(self), self._version, int(self.num_vertices), int(ja.shape[1]), int(key.value))
+
+    def touch(self):
+        """the adjacency arrays were edited in place: cached device handles of this graph are stale"""
+        self._version += 1
 
     # -- graphstruc API used by the reference's tests (test_kipf_msgpass_layer.f90:71-100) -------
     def set_num_vertices(self, n, num_features=0):

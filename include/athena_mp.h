@@ -97,6 +97,28 @@ int athena_mp_graph_export(const athena_mp_graph *g, int32_t which, void *host_d
 int athena_mp_graph_destroy(athena_mp_graph *g);
 int athena_mp_graph_dims(const athena_mp_graph *g, int32_t *n_rows, int32_t *n_cols, int64_t *nnz,
                          int32_t *n_edge_cols);
+/* What a cached handle of (adj_ia, adj_ja) is valid for -- the key a layer's set_graph compares before it rebuilds
+ * (SURVEY.md 8b "Ownership", F12; the reference re-copies the CSR in every set_graph_msgpass,
+ * athena_msgpass_layer_sub.f90:144-174, called before every forward, athena_network_sub.f90:2727-2730).
+ * 64-bit hash of the sizes and of the arrays' CONTENT: all of it below 2^18 entries (mini-batch graphs: an in-place
+ * edit is always seen); above, the first and last 1024 elements / columns plus a strided sample of 4096 of each array
+ * (hashing 80 MB per forward at 10 M entries would cost more than the layer step) -- set the environment variable
+ * ATHENA_MP_GRAPH_KEY_FULL=1 to hash everything at every size.  Host-only, no device call, no library state: the
+ * Fortran interface is declared `pure`.  Two different graphs of equal n and nnz get different keys (up to 2^-64). */
+int athena_mp_graph_key(int32_t n_rows, int64_t nnz, const int32_t *adj_ia, const int32_t *adj_ja, uint64_t *key);
+/* set_graph as a cache lookup: returns the handle of this CSR (square graph, degrees = row lengths -- what
+ * set_graph_msgpass hands a layer), building it only when no handle with the same (device, n, nnz, n_edge_cols,
+ * athena_mp_graph_key) is alive.  Handles are shared and reference counted: every layer of a network that is given
+ * the same graph gets the same device arrays; a released handle stays cached (least recently used ones are freed once
+ * the idle handles hold more than ATHENA_MP_GRAPH_CACHE_ENTRIES entries, default 2^28; 0 = free on the last release)
+ * so the mini-batches of the next epoch find theirs.  athena_mp_graph_destroy on an acquired handle releases it.
+ * The calling pattern it serves: athena_network_sub.f90:2727-2730 (set_graph before EVERY forward). */
+int athena_mp_graph_acquire(int32_t n, int64_t nnz, const int32_t *adj_ia, const int32_t *adj_ja,
+                            int32_t n_edge_cols, athena_mp_graph **out);
+int athena_mp_graph_release(athena_mp_graph *g);
+/* cached handles alive or idle, lookups served from the cache, and device graph handles BUILT by this process so far
+ * (graph_create / _from_edges / _acquire misses / shard blocks): what the cache tests count */
+int athena_mp_graph_cache_stats(int64_t *handles, int64_t *hits, int64_t *builds);
 
 /* ---- Kipf --------------------------------------------------------------- */
 /* kipf_propagate, athena_diffstruc_extd_sub_kipf.f90:7-59

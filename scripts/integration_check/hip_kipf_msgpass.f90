@@ -21,8 +21,8 @@ module athena_mp__hip_kipf
   public :: kipf_propagate_hip, hip_kipf_msgpass_layer_type
 
   type, extends(msgpass_layer_type) :: hip_kipf_msgpass_layer_type
-     type(c_ptr), allocatable :: handle(:)               !! one device graph per sample, built once (SURVEY F12)
-     integer, allocatable :: handle_nnz(:)                !! what the cached handle was built for
+     type(c_ptr), allocatable :: handle(:)               !! one device graph per sample: a reference-counted handle of the
+                                                         !! library's content-keyed cache (athena_mp_graph_acquire, SURVEY F12)
    contains
      procedure, pass(this) :: set_graph => set_graph_hip_kipf
      procedure, pass(this) :: update_message => update_message_hip_kipf
@@ -76,6 +76,7 @@ contains
     type(graph_type), dimension(:), intent(in) :: graph
     integer :: s
     integer(c_int) :: rc
+    type(c_ptr) :: fresh
 
     ! the parent type is abstract, so its set_graph cannot be called through the parent component
     ! (this%msgpass_layer_type%set_graph is illegal): the copies of set_graph_msgpass are restated here
@@ -93,18 +94,19 @@ contains
        if(size(this%handle) .ne. size(graph)) call release_handles(this)
     end if
     if(.not.allocated(this%handle))then
-       allocate(this%handle(size(graph)), this%handle_nnz(size(graph)))
+       allocate(this%handle(size(graph)))
        this%handle = c_null_ptr
-       this%handle_nnz = -1
     end if
+    ! set_graph runs before EVERY forward (athena_network_sub.f90:2727-2730).  athena_mp_graph_acquire keys on
+    ! (n, nnz, edge columns, a hash of the CONTENT of adj_ia / adj_ja): an unchanged sample gets its handle back for the
+    ! price of the key, a different graph -- also one with the same vertex and entry counts -- gets its own.  Acquire
+    ! before release, so a sample that did not change never drops to zero users in between.
     do s = 1, size(graph)
-       if(c_associated(this%handle(s)) .and. this%handle_nnz(s) .eq. size(graph(s)%adj_ja, 2)) cycle
-       if(c_associated(this%handle(s))) rc = athena_mp_graph_destroy(this%handle(s))
-       rc = athena_mp_graph_create(int(graph(s)%num_vertices, c_int32_t), int(graph(s)%num_vertices, c_int32_t), &
-            int(size(graph(s)%adj_ja, 2), c_int64_t), graph(s)%adj_ia, graph(s)%adj_ja, &
-            int(graph(s)%num_edges, c_int32_t), c_null_ptr, c_null_ptr, this%handle(s))
+       rc = athena_mp_graph_acquire(int(graph(s)%num_vertices, c_int32_t), int(size(graph(s)%adj_ja, 2), c_int64_t), &
+            graph(s)%adj_ia, graph(s)%adj_ja, int(graph(s)%num_edges, c_int32_t), fresh)
        if(rc .ne. 0) call stop_program("set_graph: "//athena_mp_error_message())
-       this%handle_nnz(s) = size(graph(s)%adj_ja, 2)
+       if(c_associated(this%handle(s))) rc = athena_mp_graph_release(this%handle(s))
+       this%handle(s) = fresh
     end do
   end subroutine set_graph_hip_kipf
 
@@ -147,9 +149,9 @@ contains
     integer(c_int) :: rc
     if(.not.allocated(this%handle)) return
     do s = 1, size(this%handle)
-       if(c_associated(this%handle(s))) rc = athena_mp_graph_destroy(this%handle(s))
+       if(c_associated(this%handle(s))) rc = athena_mp_graph_release(this%handle(s))
     end do
-    deallocate(this%handle, this%handle_nnz)
+    deallocate(this%handle)
   end subroutine release_handles
 
   subroutine finalise_hip_kipf(this)

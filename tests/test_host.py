@@ -182,3 +182,49 @@ def test_fortran_host_side_is_built():
         pytest.skip("Fortran host side not built here (run __graft_entry__.build())")
     r = subprocess.run([runner], capture_output=True, text=True, timeout=60)
     assert r.returncode == 2 and "usage" in r.stderr
+
+
+def test_graph_key_is_a_content_key():
+    """athena_mp_graph_key (host only, no device call): what a cached handle is valid for.  Equal content -> equal key;
+    same vertex and entry counts with another adjacency -> another key (round 2's Fortran shim keyed on nnz alone);
+    in-place edits of a mini-batch graph are always seen; above 2^18 entries head, tail and the strided sample are."""
+    import ctypes as C
+
+    from athena_amd import _capi
+
+    def key(ia, ja):
+        ia = np.ascontiguousarray(ia, np.int32)
+        ja = np.asfortranarray(ja, np.int32)
+        k = C.c_uint64(0)
+        _capi.call("athena_mp_graph_key", ia.size - 1, ja.shape[1], ia.ctypes.data, ja.ctypes.data, C.byref(k))
+        return k.value
+
+    g = csr_from_index_list(6, golden("reference_test_topologies.json")["kipf_layer_6v8e"]["index_list"])
+    k0 = key(g.adj_ia, g.adj_ja)
+    assert k0 == key(g.adj_ia.copy(), g.adj_ja.copy())
+    perm = np.array([2, 1, 3, 4, 5, 6])                      # rename two vertices: same counts, other adjacency
+    idx = perm[np.asarray(golden("reference_test_topologies.json")["kipf_layer_6v8e"]["index_list"]) - 1]
+    h = csr_from_index_list(6, idx)
+    assert h.nnz == g.nnz and h.num_vertices == g.num_vertices
+    assert key(h.adj_ia, h.adj_ja) != k0
+    ja = np.array(g.adj_ja, order="F")
+    for w in range(ja.shape[1]):                             # any single in-place change is seen
+        for r in range(2):
+            old = ja[r, w]
+            ja[r, w] = old + 1
+            assert key(g.adj_ia, ja) != k0
+            ja[r, w] = old
+    assert key(g.adj_ia, ja) == k0
+    # a large graph: sampled key -- head, tail and stride positions are covered, sizes are part of the key
+    n, nnz = 300_000, 1 << 19
+    rng = np.random.default_rng(0)
+    ia = np.concatenate([[1], 1 + np.sort(rng.integers(0, nnz + 1, n - 1)), [nnz + 1]]).astype(np.int32)
+    jb = np.asfortranarray(rng.integers(1, n + 1, (2, nnz)).astype(np.int32))
+    kb = key(ia, jb)
+    for w in (0, 1023, nnz - 1, (nnz // 4096) * 7):
+        old = jb[0, w]
+        jb[0, w] = old % n + 1
+        assert key(ia, jb) != kb, w
+        jb[0, w] = old
+    assert key(ia, jb) == kb
+    assert key(ia[:-1], jb[:, : ia[-2] - 1]) != kb
