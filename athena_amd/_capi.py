@@ -106,6 +106,7 @@ _PROTOS = {
     "athena_mp_shard_destroy": [_vp],
     "athena_mp_shard_dims": [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)],
     "athena_mp_shard_graph": [_vp, _i32, C.POINTER(_vp)],
+    "athena_mp_shard_info": [_vp, C.POINTER(_i32), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)],
     "athena_mp_shard_export": [_vp, _i32, _vp, _i64, C.POINTER(_i64)],
     "athena_mp_halo_start": [_vp, _i32, _i32, _vp],
     "athena_mp_halo_finish": [_vp, _i32],

@@ -483,30 +483,107 @@ int athena_mp_comm_create(int32_t rank, int32_t world, const void *id128, athena
     return 0;
 }
 
-/* MPI-free bootstrap for a Fortran host: rank 0 draws the id and publishes it in `path` (write + rename); the other
- * ranks wait for the file.  Rank 0 removes it after every rank has joined. */
+/* MPI-free bootstrap for a Fortran host.  A file left behind by a run that crashed must never be taken for this
+ * launch's (ncclCommInitRank with mismatched ids does not return), so the rendezvous proves liveness both ways:
+ *   rank r > 0  draws a random nonce and keeps re-writing `path`.hello.r (same nonce, fresh file: a heartbeat) until
+ *               `path` carries that nonce in slot r; a `path` without it -- a stale one -- is ignored.
+ *   rank 0      removes any stale `path`, waits until it has seen every hello file CHANGE (a stale hello never does),
+ *               then publishes id + the nonces it read (write + rename).  It removes `path` after every rank has joined.
+ * Every wait is bounded (ATHENA_MP_BOOTSTRAP_TIMEOUT_S, default 300 s). */
+namespace {
+double boot_now()
+{
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+double boot_timeout()
+{
+    const char *e = getenv("ATHENA_MP_BOOTSTRAP_TIMEOUT_S");
+    const double t = e ? atof(e) : 300.0;
+    return t > 0 ? t : 300.0;
+}
+bool boot_write(const std::string &file, const void *data, size_t bytes)
+{
+    const std::string tmp = file + ".tmp";
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return false;
+    const size_t w = fwrite(data, 1, bytes, f);
+    fclose(f);
+    return w == bytes && rename(tmp.c_str(), file.c_str()) == 0;
+}
+// reads exactly `bytes`; *stamp identifies this version of the file (inode + mtime)
+bool boot_read(const std::string &file, void *data, size_t bytes, uint64_t *stamp)
+{
+    int fd = open(file.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    bool ok = fstat(fd, &st) == 0 && (size_t)st.st_size == bytes && read(fd, data, bytes) == (ssize_t)bytes;
+    close(fd);
+    if (ok && stamp) *stamp = (uint64_t)st.st_ino * 0x9e3779b97f4a7c15ull ^ ((uint64_t)st.st_mtim.tv_sec * 1000000000ull + (uint64_t)st.st_mtim.tv_nsec);
+    return ok;
+}
+}   // namespace
+
 int athena_mp_comm_create_from_file(int32_t rank, int32_t world, const char *path, athena_mp_comm **out)
 {
     AMP_REQUIRE(out != nullptr && path != nullptr, "comm_create_from_file: null argument");
     *out = nullptr;
-    char id[128];
+    AMP_REQUIRE(world >= 1 && rank >= 0 && rank < world, "comm_create_from_file: bad rank %d / world %d", rank, world);
+    const size_t rec = 128 + 8 * (size_t)world;
+    std::vector<char> buf(rec, 0);
+    const double t0 = boot_now(), limit = boot_timeout();
+    auto hello = [&](int r) { return std::string(path) + ".hello." + std::to_string(r); };
     if (rank == 0) {
-        if (athena_mp_comm_unique_id(id)) return 1;
-        const std::string tmp = std::string(path) + ".tmp";
-        FILE *f = fopen(tmp.c_str(), "wb");
-        AMP_REQUIRE(f != nullptr, "comm_create_from_file: cannot write %s", tmp.c_str());
-        const size_t w = fwrite(id, 1, 128, f);
-        fclose(f);
-        AMP_REQUIRE(w == 128 && rename(tmp.c_str(), path) == 0, "comm_create_from_file: cannot publish %s", path);
+        unlink(path);   // whatever is there now is not ours
+        std::vector<uint64_t> nonce(world, 0), first(world, 0);
+        std::vector<char> seen(world, 0), live(world, 0);
+        int n_live = 1;
+        while (n_live < world) {
+            for (int r = 1; r < world; ++r) {
+                if (live[r]) continue;
+                uint64_t v = 0, st = 0;
+                if (!boot_read(hello(r), &v, 8, &st)) continue;
+                if (!seen[r]) {
+                    seen[r] = 1;
+                    first[r] = st;
+                } else if (st != first[r]) {   // the file moved on: its writer is alive, this is its nonce
+                    live[r] = 1;
+                    nonce[r] = v;
+                    ++n_live;
+                }
+            }
+            AMP_REQUIRE(boot_now() - t0 < limit, "comm_create_from_file: %d of %d ranks never announced themselves at %s.hello.*",
+                        world - n_live, world, path);
+            if (n_live < world) usleep(5000);
+        }
+        if (athena_mp_comm_unique_id(buf.data())) return 1;
+        memcpy(buf.data() + 128, nonce.data(), 8 * (size_t)world);
+        AMP_REQUIRE(boot_write(path, buf.data(), rec), "comm_create_from_file: cannot publish %s", path);
     } else {
-        FILE *f = nullptr;
-        for (int i = 0; i < 600000 && !(f = fopen(path, "rb")); ++i) usleep(500);
-        AMP_REQUIRE(f != nullptr, "comm_create_from_file: %s never appeared (is rank 0 running?)", path);
-        const size_t r = fread(id, 1, 128, f);
-        fclose(f);
-        AMP_REQUIRE(r == 128, "comm_create_from_file: %s is truncated", path);
+        uint64_t mine = 0;
+        {
+            int fd = open("/dev/urandom", O_RDONLY);
+            AMP_REQUIRE(fd >= 0 && read(fd, &mine, 8) == 8, "comm_create_from_file: /dev/urandom unreadable");
+            close(fd);
+            mine |= 1;   // never 0
+        }
+        for (;;) {
+            AMP_REQUIRE(boot_write(hello(rank), &mine, 8), "comm_create_from_file: cannot write %s", hello(rank).c_str());
+            uint64_t got = 0;
+            if (boot_read(path, buf.data(), rec, nullptr)) {
+                memcpy(&got, buf.data() + 128 + 8 * (size_t)rank, 8);
+                if (got == mine) break;   // published for THIS launch
+            }
+            if (boot_now() - t0 >= limit) {
+                unlink(hello(rank).c_str());
+                AMP_REQUIRE(false, "comm_create_from_file: %s never carried this launch's id (is rank 0 running? stale file?)", path);
+            }
+            usleep(20000);
+        }
+        unlink(hello(rank).c_str());
     }
-    int rc = athena_mp_comm_create(rank, world, id, out);
+    int rc = athena_mp_comm_create(rank, world, buf.data(), out);
     if (rc) return rc;
     rc = athena_mp_comm_barrier(*out);
     if (rank == 0) unlink(path);
@@ -862,10 +939,24 @@ int athena_mp_shard_dims(const athena_mp_shard *s, int32_t *n_local, int32_t *n_
     AMP_REQUIRE(s != nullptr, "shard_dims: null shard");
     if (n_local) *n_local = s->n;
     if (n_interior) *n_interior = s->n_int;
-    if (n_halo) *n_halo = s->n_halo;
+    if (n_halo) *n_halo = s->ext_rows;   // rows of x_ext beyond the local ones (the distinct halo rows in p2p mode)
     if (nnz) *nnz = s->nnz;
     if (row_offset) *row_offset = s->row_offset;
     if (n_total) *n_total = s->n_total;
+    return 0;
+}
+
+/* how this shard's halo travels: *mode 0 = grouped send / recv of packed rows, 1 = all-gather of whole blocks;
+ * *fraction = (distinct halo rows, summed over the ranks) / ((world - 1) * n_total); *tau = the threshold in force;
+ * *recv_rows = rows that cross a link into this rank per exchange.  The choice is a property of the partition (it fixes
+ * the column numbering of the shard's graphs), identical on every rank. */
+int athena_mp_shard_info(const athena_mp_shard *s, int32_t *mode, double *fraction, double *tau, int64_t *recv_rows)
+{
+    AMP_REQUIRE(s != nullptr, "shard_info: null shard");
+    if (mode) *mode = s->mode;
+    if (fraction) *fraction = s->halo_fraction;
+    if (tau) *tau = s->tau;
+    if (recv_rows) *recv_rows = s->roff.empty() ? 0 : s->roff.back();
     return 0;
 }
 
@@ -881,6 +972,8 @@ int athena_mp_shard_graph(const athena_mp_shard *s, int32_t which, athena_mp_gra
 /* arrays of the plan (tests, and hosts that keep their data in original order):
  * 0 order [n] int32 (original local id, 0-based, of new row k)   1 halo_ids [n_halo] int64 (global, 0-based)
  * 2 send_idx [n_send] int32   3 col_deg [n + n_halo] int32   4 send_counts [world] int64   5 recv_counts [world] int64
+ * 6 ext_ids [n_halo of shard_dims] int64: global id (0-based) held by each row of x_ext beyond the local ones, -1 = a
+ *   padding slot of the all-gather layout (== array 1 in p2p mode; array 1 is always the DISTINCT remote rows referenced)
  * count is in ELEMENTS; host_dst may be null for a size query. */
 int athena_mp_shard_export(const athena_mp_shard *s, int32_t which, void *host_dst, int64_t capacity, int64_t *count)
 {
@@ -895,6 +988,7 @@ int athena_mp_shard_export(const athena_mp_shard *s, int32_t which, void *host_d
     case 3: src = s->col_deg.data(); n = (int64_t)s->col_deg.size(); break;
     case 4: src = s->send_counts.data(); n = (int64_t)s->send_counts.size(); el = 8; break;
     case 5: src = s->recv_counts.data(); n = (int64_t)s->recv_counts.size(); el = 8; break;
+    case 6: src = s->ext_ids.data(); n = (int64_t)s->ext_ids.size(); el = 8; break;
     default: AMP_REQUIRE(false, "shard_export: unknown array id %d", which);
     }
     *count = n;
@@ -904,16 +998,27 @@ int athena_mp_shard_export(const athena_mp_shard *s, int32_t which, void *host_d
     return 0;
 }
 
-/* Halo exchange of x_ext [n + n_halo, F] (row-major): packs the rows the peers need (HIP gather on the compute
- * stream), then -- on the communication stream, ordered behind the pack -- one grouped send/recv per peer straight
- * into the halo rows of x_ext.  Returns at once; kernels enqueued before athena_mp_halo_finish (the interior rows) run
+/* Halo exchange of x_ext [n + n_halo, F] (row-major; n_halo as athena_mp_shard_dims reports it).  p2p mode: packs the
+ * rows the peers need (HIP gather on the compute stream), then -- on the communication stream, ordered behind the pack --
+ * one grouped send/recv per peer straight into the halo rows of x_ext.  all-gather mode (athena_mp_shard_info): one
+ * ncclAllGather of every rank's block into the rows behind the local slots; nothing is packed.  Returns at once; kernels enqueued before athena_mp_halo_finish (the interior rows) run
  * under the transfer.  slot 0 / 1: two exchanges may be outstanding (e.g. X and dZ). */
 int athena_mp_halo_start(athena_mp_shard *s, int32_t slot, int32_t F, float *x_ext_dev)
 {
-    AMP_REQUIRE(s && (slot == 0 || slot == 1) && F > 0 && (x_ext_dev || s->n + s->n_halo == 0), "halo_start: bad arguments");
+    AMP_REQUIRE(s && (slot == 0 || slot == 1) && F > 0 && (x_ext_dev || s->n + s->ext_rows == 0), "halo_start: bad arguments");
     athena_mp_comm *c = s->comm;
     const int W = c->t->world, rank = c->t->rank;
     if (W == 1) return 0;
+    if (s->mode == 1) {
+        // whole blocks: the first max_n rows of x_ext (this rank's n rows + padding slots) go out as they lie, block p of
+        // every rank lands at row max_n * (1 + p).  No pack kernel, no send list, one collective.
+        AMP_HIP(hipEventRecord(c->ev_ready, amp::stream()));
+        AMP_HIP(hipStreamWaitEvent(c->cs, c->ev_ready, 0));
+        const size_t block = sizeof(float) * (size_t)s->max_n * F;
+        if (c->t->allgather(x_ext_dev, x_ext_dev + (size_t)s->max_n * F, block, c->cs)) return 1;
+        AMP_HIP(hipEventRecord(s->ev_halo[slot], c->cs));
+        return 0;
+    }
     const size_t need = sizeof(float) * (size_t)std::max<int64_t>(s->n_send, 1) * F;
     if (s->send_cap[slot] < need) {
         if (s->send_buf[slot]) {

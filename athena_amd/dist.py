@@ -62,6 +62,23 @@ def shard_entries(rank, world, n, pairs, cut=None, seed=20260424):
     return rows[order], cols[order], cut
 
 
+def halo_tau():
+    """threshold of the all-gather fallback: same environment variable as comm.hip"""
+    import os
+    try:
+        t = float(os.environ.get("ATHENA_MP_HALO_ALLGATHER_FRACTION", "0.7"))
+    except ValueError:
+        t = 0.7
+    return t if t > 0 else 0.7
+
+
+def halo_mode_env():
+    """ATHENA_MP_HALO_MODE: None = auto, else "p2p" / "allgather" (comm.hip reads the same variable)"""
+    import os
+    m = os.environ.get("ATHENA_MP_HALO_MODE", "auto")
+    return None if m in ("", "auto") else ("allgather" if m == "allgather" else "p2p")
+
+
 class Shard:
     """One rank's rows with columns renumbered [local | halo] and the halo exchange plan.
 
@@ -94,20 +111,48 @@ class Shard:
         col = np.where(local, new_of_old[np.where(local, cols_global - lo, 0)],
                        n + np.searchsorted(self.halo_ids, cols_global))
         self.n_halo = int(self.halo_ids.size)
+        self.ext_ids = self.halo_ids          # global id held by each row of x_ext beyond the local ones (-1: padding)
         self.nnz = int(cols_global.size)
+        self._local, self._rows_new = local, rows_new
+        self._set_columns(col)
+        self.halo_mode, self.halo_fraction, self.halo_tau = "p2p", 0.0, halo_tau()
+        self.recv_rows = self.n_halo          # rows that cross a link into this rank per exchange
+        self.send_idx = None     # filled by build_plan
+        self.send_counts = None
+        self.col_deg = None
+
+    def _set_columns(self, col):
+        n, world = self.n, self.world
         ja = np.zeros((2, self.nnz), np.int32, order="F")
         ja[0] = col + 1
         self.adj_ja = ja
         # backward (pull) graph: same rows, entries ordered by global source id (the order the
         # reference's scatter accumulates in, athena_diffstruc_extd_sub_kipf.f90:101-109)
-        key = rows_new * (np.int64(world) * n) + cols_global
+        key = self._rows_new * (np.int64(world) * n) + self.cols_global
         order = np.argsort(key, kind="stable")
         jb = np.zeros((2, self.nnz), np.int32, order="F")
         jb[0] = col[order] + 1
         self.adj_ja_bwd = jb
-        self.send_idx = None     # filled by build_plan
-        self.send_counts = None
-        self.col_deg = None
+
+    def use_allgather(self, all_new_of_old, all_deg_new):
+        """switch to the all-gather layout (comm.hip, mode 1): x_ext = [n local | world blocks of n rows, block p in
+        rank p's own interior-first order]; a halo row is a view into its owner's block -- no pack, no send lists.
+        all_new_of_old[p] = rank p's new position of each of its original local vertices, all_deg_new[p] = the degrees
+        of rank p's vertices in their new order."""
+        n, world, lo = self.n, self.world, self.rank * self.n
+        cg, local = self.cols_global, self._local
+        owner = cg // n
+        pos = np.stack(all_new_of_old)[owner, cg - owner * n]
+        col = np.where(local, self.new_of_old[np.where(local, cg - lo, 0)], n + owner * n + pos)
+        self._set_columns(col)
+        self.n_halo = world * n
+        ext = np.empty(world * n, np.int64)
+        for p in range(world):
+            ext[p * n + all_new_of_old[p]] = p * n + np.arange(n)
+        self.ext_ids = ext
+        self.col_deg = np.concatenate([self.row_deg] + [np.asarray(d, np.int32) for d in all_deg_new])
+        self.halo_mode = "allgather"
+        self.recv_rows = (world - 1) * n
 
     def row_block(self, adj_ja, r0, r1):
         """CSR of rows [r0, r1) as its own (adj_ia, adj_ja) pair"""
@@ -164,6 +209,16 @@ class _StagedRecv:
         self.req.wait()
         if self.host is not None:
             self.dst.copy_(self.host)
+
+
+class _StagedGather:
+    def __init__(self, req, hosts, dsts):
+        self.req, self.hosts, self.dsts = req, hosts, dsts
+
+    def wait(self):
+        self.req.wait()
+        for h, d in zip(self.hosts, self.dsts):
+            d.copy_(h)
 
 
 def _p2p_start(send_bufs, recv_bufs, rank, world):
@@ -272,7 +327,9 @@ class _CReduce:
 
 class CShard:
     """athena_mp_shard: the [local | halo] renumbering, send lists, halo degrees and the four row-block graph handles
-    are built by the C ABI (athena_mp_shard_create); this class only holds the handle and reads its arrays back."""
+    are built by the C ABI (athena_mp_shard_create); this class only holds the handle and reads its arrays back.
+    n_halo = rows of x_ext beyond the local ones: the distinct remote rows in p2p mode, the padded blocks of every rank
+    in all-gather mode (halo_mode; the C ABI decides from the halo fraction)."""
 
     def __init__(self, comm, adj_ia, cols_global):
         import ctypes as C
@@ -289,7 +346,12 @@ class CShard:
         _capi.call("athena_mp_shard_dims", h, C.byref(n), C.byref(ni), C.byref(nh), C.byref(nnz), C.byref(roff), C.byref(ntot))
         self.n, self.n_int, self.n_halo, self.nnz, self.row_offset = n.value, ni.value, nh.value, nnz.value, roff.value
         self.order = self._export(0, np.int32).astype(np.int64)
-        self.halo_ids = self._export(1, np.int64)
+        self.halo_ids = self._export(1, np.int64)            # the distinct remote rows referenced
+        self.ext_ids = self._export(6, np.int64)             # what each row of x_ext beyond the local ones holds (-1: padding)
+        mode, frac, tau, rr = C.c_int32(), C.c_double(), C.c_double(), C.c_int64()
+        _capi.call("athena_mp_shard_info", h, C.byref(mode), C.byref(frac), C.byref(tau), C.byref(rr))
+        self.halo_mode = "allgather" if mode.value == 1 else "p2p"
+        self.halo_fraction, self.halo_tau, self.recv_rows = frac.value, tau.value, rr.value
         self.col_deg = self._export(3, np.int32)
         self.row_deg = self.col_deg[:self.n]
         self.transport = comm.transport
@@ -395,6 +457,21 @@ def build_plan(shard, device):
     allc = [torch.empty_like(rc) for _ in range(world)]
     dist.all_gather(allc, rc)
     allc = torch.stack(allc).cpu().numpy()                 # allc[q][p] = rows q needs from p
+    # how the halo travels (same rule as comm.hip): all-gather of whole blocks when the ranks together need more than
+    # tau of all remote rows anyway
+    shard.halo_fraction = float(allc.sum()) / float((world - 1) * world * n)
+    forced = halo_mode_env()
+    if (forced or ("allgather" if shard.halo_fraction > shard.halo_tau else "p2p")) == "allgather":
+        mine = torch.from_numpy(np.stack([shard.new_of_old, shard.row_deg.astype(np.int64)]))
+        if dist.get_backend() != "gloo":
+            mine = mine.to(device)
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        parts = [t.cpu().numpy() for t in parts]
+        shard.use_allgather([t[0] for t in parts], [t[1] for t in parts])
+        shard.send_counts = np.zeros(world, np.int64)
+        shard.send_idx = torch.zeros(0, dtype=torch.int32, device=device)
+        return shard
     shard.send_counts = allc[:, rank].copy()
     shard.send_counts[rank] = 0
     roff = np.concatenate([[0], np.cumsum(shard.recv_counts)])
@@ -431,6 +508,12 @@ class HaloExchange:
         if s.world == 1:
             return []
         n = s.n
+        if s.halo_mode == "allgather":     # whole blocks, as they lie: no pack
+            outs = [x_ext[n + p * n:n + (p + 1) * n] for p in range(s.world)]
+            if _host_staged(x_ext):
+                hs = [torch.empty(o.shape, dtype=o.dtype) for o in outs]
+                return [_StagedGather(dist.all_gather(hs, x_ext[:n].cpu(), async_op=True), hs, outs)]
+            return [dist.all_gather(outs, x_ext[:n], async_op=True)]
         if self.send_buf.shape[0]:
             self.backend.gather_rows(x_ext[:n], s.send_idx, out=self.send_buf)   # pack (HIP gather kernel)
         roff, soff = s._roff, s._soff
@@ -628,7 +711,7 @@ class KipfShardStep:
 
 def build_kipf_step(shard, F, device, backend=None, Fo=None, order="auto", inputs=None):
     step = KipfShardStep(shard, F, device, backend, Fo=Fo, order=order, inputs=inputs)
-    halo_bytes = shard.n_halo * 4 * ((step.Fo if step.transform_first else F) + step.Fo)
+    halo_bytes = shard.recv_rows * 4 * ((step.Fo if step.transform_first else F) + step.Fo)
     if getattr(shard, "n_total", None) is not None:
         graph = f"contiguous row block of ONE fixed graph of {shard.n_total} vertices (the single-GPU workload, strong scaling)"
     elif shard.world > 1 and abs(shard.cut - (shard.world - 1) / shard.world) < 1e-9:
@@ -637,7 +720,10 @@ def build_kipf_step(shard, F, device, backend=None, Fo=None, order="auto", input
         graph = (f"stochastic block model, one block per GPU, fixed inter-block density: {shard.cut:.4f} of the undirected "
                  "pairs cross partitions at this N")
     info = {"graph": graph,
-            "halo_rows_per_gpu": shard.n_halo, "halo_bytes_per_gpu_per_step": halo_bytes,
+            "halo_rows_per_gpu": int(shard.halo_ids.size), "halo_recv_rows_per_gpu": int(shard.recv_rows),
+            "halo_bytes_per_gpu_per_step": halo_bytes,
+            "halo_mode": shard.halo_mode, "halo_fraction": round(float(shard.halo_fraction), 4),
+            "halo_allgather_threshold": shard.halo_tau,
             "interior_rows_per_gpu": shard.n_int, "interior_entries_per_gpu": shard.interior_entries,
             "transport": shard.transport}
     return step, shard.nnz, info
@@ -682,7 +768,8 @@ def measure_breakdown(step, iters=5):
 
     out = {"halo_ms": timed(halo) if s.world > 1 else 0.0, "interior_ms": timed(interior), "boundary_ms": timed(boundary),
            "dw_ms": timed(dw)}
-    recv_bytes = s.n_halo * 4 * (F + Fo)
+    recv_bytes = s.recv_rows * 4 * (F + Fo)
+    out["halo_mode"], out["halo_fraction"], out["halo_allgather_threshold"] = s.halo_mode, round(float(s.halo_fraction), 4), s.halo_tau
     out["halo_recv_bytes_per_gpu_per_step"] = recv_bytes
     out["xgmi_recv_GBps_per_gpu"] = (recv_bytes / (out["halo_ms"] * 1e-3) / 1e9) if out["halo_ms"] > 0 else None
     return out

@@ -46,7 +46,7 @@ module athena_mp_c
   public :: athena_mp_comm_create, athena_mp_comm_create_from_file, athena_mp_comm_destroy, athena_mp_comm_barrier
   public :: athena_mp_comm_unique_id, athena_mp_allreduce, athena_mp_allreduce_start, athena_mp_allreduce_finish
   public :: athena_mp_shard_create, athena_mp_shard_destroy, athena_mp_shard_dims, athena_mp_shard_graph
-  public :: athena_mp_shard_export, athena_mp_halo_start, athena_mp_halo_finish
+  public :: athena_mp_shard_export, athena_mp_halo_start, athena_mp_halo_finish, athena_mp_shard_info
 
   interface
      integer(c_int) function athena_mp_init(device) bind(C, name="athena_mp_init")
@@ -648,6 +648,14 @@ module athena_mp_c
        type(c_ptr), value :: shard
        integer(c_int32_t), intent(out) :: n_local, n_interior, n_halo
        integer(c_int64_t), intent(out) :: nnz, row_offset, n_total
+     end function
+     !! how the halo travels: mode 0 = grouped send / recv of packed rows, 1 = all-gather of whole blocks
+     integer(c_int) function athena_mp_shard_info(shard, mode, fraction, tau, recv_rows) bind(C, name="athena_mp_shard_info")
+       import :: c_int, c_int32_t, c_int64_t, c_double, c_ptr
+       type(c_ptr), value :: shard
+       integer(c_int32_t), intent(out) :: mode
+       real(c_double), intent(out) :: fraction, tau
+       integer(c_int64_t), intent(out) :: recv_rows
      end function
      integer(c_int) function athena_mp_shard_graph(shard, which, graph) bind(C, name="athena_mp_shard_graph")
        import :: c_int, c_int32_t, c_ptr

@@ -40,6 +40,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md "Chip-level parameters")
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32-input MFMA peak (MI355X_MICROARCH.md)
 TOL = 1e-5             # north_star: 1e-5 relative fp32
 
 CONFIGS = {
@@ -85,6 +86,16 @@ def self_launch(args):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "8")
     return subprocess.call(cmd, env=env)
+
+
+def transport_error(transport, one_device):
+    """N > 1 lines must have moved their halos over RCCL.  comm.hip's host-staged test transport ("shm ...") and the
+    python fallback plan exist for boxes with one GPU; a line that used them without the one-device dry-run switch
+    (say, a typo'd ATHENA_MP_BENCH_BACKEND on a real node) is an error, not a slow measurement."""
+    if transport.startswith("rccl") or one_device:
+        return None
+    return (f"transport is '{transport}', not RCCL: only the one-device dry run (ATHENA_MP_BENCH_ONE_DEVICE=1) may use "
+            "the test transport")
 
 
 def rel(a, b):
@@ -170,11 +181,13 @@ def parity_sharded(step, shard, seeds, dev, n_sample=4000):
     torch.cuda.synchronize()
     # (1) transported rows
     ok_halo = True
-    if s.n_halo and seeds is not None:
-        k = np.sort(rng.choice(s.n_halo, min(500, s.n_halo), replace=False))
+    held = np.flatnonzero(s.ext_ids >= 0)         # rows behind the local ones that hold a vertex (all-gather layout: not the padding slots)
+    if held.size and seeds is not None:
+        k = np.sort(rng.choice(held, min(500, held.size), replace=False))
         kd = torch.from_numpy(n + k).to(dev)
-        ok_halo = bool(np.array_equal(step.x_ext[kd].cpu().numpy(), synth.feature_rows(seeds[0], s.halo_ids[k], F)) and
-                       np.array_equal(step.dZ_ext[kd].cpu().numpy(), synth.feature_rows(seeds[1], s.halo_ids[k], Fo)))
+        ok_halo = bool(np.array_equal(step.x_ext[kd].cpu().numpy(), synth.feature_rows(seeds[0], s.ext_ids[k], F)) and
+                       np.array_equal(step.dZ_ext[kd].cpu().numpy(), synth.feature_rows(seeds[1], s.ext_ids[k], Fo)) and
+                       np.isin(s.halo_ids, s.ext_ids[held]).all())
     res["halo_rows_bit_exact"] = ok_halo
     # (2) sampled rows
     rows = np.sort(rng.choice(n, min(n_sample, n), replace=False))
@@ -253,7 +266,7 @@ def main():
     _capi.init(local_rank)
     F = args.feat
     weak = args.config == "c2-weak-sbm"
-    ev, ev_bnd = [], []
+    ev, ev_bnd, ev_dw = [], [], []
     breakdown, seeds = None, None
 
     if world > 1:
@@ -304,6 +317,9 @@ def main():
             if record:
                 e1.record(); ev.append((e0, e1))
             ops.matmul_dw(P, dzd, out=dW)
+            if record:
+                e2 = torch.cuda.Event(enable_timing=True)
+                e2.record(); ev_dw.append((e1, e2))
             ops.kipf_layer_bwd_x(g, dzd, wd, F, out=dX)
         info = {}
 
@@ -386,6 +402,16 @@ def main():
                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                        "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": agg_ms}
+    # the dense contraction of the step that is a launch of its own: dW = dZ . P^T (2 N F^2 flops on the fp32 matrix
+    # cores; the other two dense steps ride inside the fused gather launches).  HIP events in the timed loop at N = 1.
+    if world == 1 and ev_dw:
+        dw_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_dw]))
+        flops = 2.0 * args.nodes * F * F
+        out["roofline"]["dense"] = {"bound": "mfma", "kernel": (f"gemm_dw_full_kernel<{F},{F}> + slab_reduce_kernel" if F in (64, 128) else
+                                                                  "gemm_atb_tiled (dW)") + " (matmul reverse wrt the weights, dW = dZ . P^T)",
+                                    "achieved": flops / (dw_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": flops / (dw_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "flops_per_launch": flops,
+                                    "avg_launch_ms": dw_ms, "dtype": "f32 (v_mfma_f32_32x32x2_f32, exact fp32 products)"}
     ok = True
     if world == 1:
         if not args.no_cpu_baseline:
@@ -400,6 +426,18 @@ def main():
         out["breakdown"] = adist.measure_breakdown(shard_step)
         out["breakdown"]["note"] = ("each part timed alone after the timed loop, rank 0 (events); in the step the exchanges "
                                     "run under the interior launches")
+        if out["breakdown"].get("dw_ms"):
+            flops = 2.0 * shard.n * F * shard_step.Fo
+            tf = flops / (out["breakdown"]["dw_ms"] * 1e-3) / 1e12
+            out["roofline"]["dense"] = {"bound": "mfma", "kernel": "dW = dZ . P^T on rank 0's rows (timed alone after the loop)",
+                                        "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                        "frac": tf / MFMA_F32_PEAK_TFLOPS, "flops_per_launch": flops,
+                                        "avg_launch_ms": out["breakdown"]["dw_ms"]}
+        # a line that "scaled" through the host-staged TEST transport (or the python fallback plan) is not a measurement
+        # of RCCL over xGMI: outside the one-device dry run it is an error, stated in the line and in the exit code
+        err = transport_error(str(info.get("transport", "")), one_device)
+        if err:
+            out["ok"], out["error"], ok = False, err, False
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

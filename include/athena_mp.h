@@ -387,7 +387,10 @@ typedef struct athena_mp_shard athena_mp_shard;
 int athena_mp_comm_unique_id(void *id128);
 /* collective; uses the device athena_mp_init selected */
 int athena_mp_comm_create(int32_t rank, int32_t world, const void *id128, athena_mp_comm **out);
-/* MPI-free bootstrap: rank 0 publishes the id in `path`, the others wait for it */
+/* MPI-free bootstrap: rank 0 publishes the id in `path`, the others wait for it.  Safe against files a crashed run left
+ * behind: ranks > 0 announce themselves with a random nonce in `path`.hello.<rank> (re-written as a heartbeat), rank 0
+ * accepts only hello files it has seen change and publishes id + nonces, a rank accepts `path` only when it carries its
+ * own nonce.  Every wait is bounded by ATHENA_MP_BOOTSTRAP_TIMEOUT_S (default 300). */
 int athena_mp_comm_create_from_file(int32_t rank, int32_t world, const char *path, athena_mp_comm **out);
 int athena_mp_comm_destroy(athena_mp_comm *c);
 int athena_mp_comm_info(const athena_mp_comm *c, int32_t *rank, int32_t *world, char *transport, int32_t transport_len);
@@ -400,21 +403,36 @@ int athena_mp_allreduce(athena_mp_comm *c, float *buf_dev, int64_t count);
 
 /* the rank's rows of the global graph: adj_ia [n_local+1] 1-based, adj_ja [2,nnz] column-major with adj_ja(1,w) = GLOBAL
  * neighbour id (1-based; graph_type%adj_ja of the whole graph restricted to the rank's rows), adj_ja(2,.) ignored.
- * Rows are contiguous blocks in rank order.  Builds the [local | halo] renumbering (interior rows first), the send
- * lists, the halo degrees and the four row blocks as graph handles.  Collective. */
+ * Rows are contiguous blocks in rank order.  Builds the [local | halo] renumbering (interior rows first), the halo
+ * degrees and the four row blocks as graph handles, and decides HOW the halo travels:
+ *   p2p        grouped ncclSend / ncclRecv of the distinct rows each peer needs, packed by a gather kernel;
+ *              x_ext = [n local | n_halo distinct remote rows, grouped by owner]
+ *   all-gather when the ranks together need more than tau (default 0.7, ATHENA_MP_HALO_ALLGATHER_FRACTION) of all remote
+ *              rows anyway: ONE ncclAllGather of whole blocks, no pack kernel, no send lists;
+ *              x_ext = [max_n local slots, n used | world blocks of max_n slots, block p in rank p's own row order] --
+ *              a halo row is a view into its owner's block
+ *   ATHENA_MP_HALO_MODE = auto | p2p | allgather overrides the choice.  Either way a caller allocates n_local + n_halo
+ *   rows (athena_mp_shard_dims) and uses the shard's graphs; nothing else differs on its side.
+ * Collective: argument errors are agreed on before any data moves, so all ranks return the error together. */
 int athena_mp_shard_create(athena_mp_comm *c, int32_t n_local, int64_t nnz, const int32_t *adj_ia, const int32_t *adj_ja,
                            athena_mp_shard **out);
 int athena_mp_shard_destroy(athena_mp_shard *s);
 int athena_mp_shard_dims(const athena_mp_shard *s, int32_t *n_local, int32_t *n_interior, int32_t *n_halo, int64_t *nnz,
                          int64_t *row_offset, int64_t *n_total);
+/* *mode 0 = p2p, 1 = all-gather; *fraction = distinct halo rows summed over the ranks / ((world-1) * n_total); *tau = the
+ * threshold in force; *recv_rows = rows that cross a link into this rank per exchange */
+int athena_mp_shard_info(const athena_mp_shard *s, int32_t *mode, double *fraction, double *tau, int64_t *recv_rows);
 /* which: 0 / 1 = interior rows [0,n_int) / boundary rows [n_int,n) of the forward graph, 2 / 3 = the same blocks of the
  * backward (pull) graph; columns index x_ext = [n local rows | n_halo halo rows]; owned by the shard */
 int athena_mp_shard_graph(const athena_mp_shard *s, int32_t which, athena_mp_graph **g);
-/* 0 order [n] int32 | 1 halo_ids [n_halo] int64 | 2 send_idx [n_send] int32 | 3 col_deg [n+n_halo] int32 |
- * 4 send_counts [world] int64 | 5 recv_counts [world] int64;  host_dst NULL = size query (count in elements) */
+/* 0 order [n] int32 | 1 halo_ids [distinct remote rows referenced] int64 | 2 send_idx [n_send] int32 |
+ * 3 col_deg [n+n_halo] int32 | 4 send_counts [world] int64 | 5 recv_counts [world] int64 |
+ * 6 ext_ids [n_halo] int64: global id held by each row of x_ext beyond the local ones, -1 = padding slot (== 1 in p2p mode);
+ * host_dst NULL = size query (count in elements) */
 int athena_mp_shard_export(const athena_mp_shard *s, int32_t which, void *host_dst, int64_t capacity, int64_t *count);
-/* x_ext [n + n_halo, F]: pack + grouped send/recv into the halo rows; returns at once (kernels enqueued before _finish
- * run under the transfer); slot 0 / 1 = two exchanges may be outstanding */
+/* x_ext [n + n_halo, F]: p2p mode packs + posts the grouped send/recv into the halo rows, all-gather mode posts one
+ * ncclAllGather of the blocks; returns at once (kernels enqueued before _finish run under the transfer); slot 0 / 1 = two
+ * exchanges may be outstanding */
 int athena_mp_halo_start(athena_mp_shard *s, int32_t slot, int32_t F, float *x_ext_dev);
 int athena_mp_halo_finish(athena_mp_shard *s, int32_t slot);
 

@@ -68,9 +68,9 @@ class OracleBackend:
         out.copy_(x[idx.long()])
 
 
-def _worker(rank, world, port, n, pairs, F, cut, q, Fo=None, order="auto"):
+def _worker(rank, world, port, n, pairs, F, cut, q, Fo=None, order="auto", mode="p2p"):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ATHENA_MP_HALO_MODE=mode)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from athena_amd import dist as adist
 
@@ -83,7 +83,7 @@ def _worker(rank, world, port, n, pairs, F, cut, q, Fo=None, order="auto"):
                       P=step.P.numpy().copy() if step.P is not None else None, transform_first=step.transform_first,
                       Z=step.Z.numpy().copy(), dW=step.dW.numpy().copy(), dX=dx, n_halo=shard.n_halo,
                       send=int(shard.send_idx.numel()), col_deg=shard.col_deg.copy(), order=shard.order.copy(),
-                      n_int=shard.n_int)))
+                      n_int=shard.n_int, halo_mode=shard.halo_mode, halo_fraction=shard.halo_fraction)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -92,20 +92,26 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-@pytest.mark.parametrize("world,cut,Fo,order", [(2, None, None, "auto"), (2, 0.1, None, "auto"), (4, 0.05, None, "auto"),
-                                                (8, 0.05, None, "auto"),           # the 8-way split of BASELINE configs[4]
-                                                (3, None, None, "auto"),
-                                                (2, 0.1, 3, "auto"),               # 8 -> 3: dense step before the exchange
-                                                (3, None, 7, "auto"),              # 8 -> 7: rectangular, aggregate first
-                                                (2, None, 8, "transform_first")])
-def test_multi_rank_kipf_step_matches_global_oracle(oracle, world, cut, Fo, order):
+@pytest.mark.parametrize("world,cut,Fo,order,mode", [
+    (2, None, None, "auto", "p2p"), (2, 0.1, None, "auto", "p2p"), (4, 0.05, None, "auto", "p2p"),
+    (8, 0.05, None, "auto", "p2p"),           # the 8-way split of BASELINE configs[4]
+    (3, None, None, "auto", "p2p"),
+    (2, 0.1, 3, "auto", "p2p"),               # 8 -> 3: dense step before the exchange
+    (3, None, 7, "auto", "p2p"),              # 8 -> 7: rectangular, aggregate first
+    (2, None, 8, "transform_first", "p2p"),
+    # the halo as ONE all-gather of whole blocks (the fallback above a halo fraction of ~0.7)
+    (2, None, None, "auto", "allgather"), (3, None, None, "auto", "allgather"), (8, None, None, "auto", "allgather"),
+    (2, 0.1, 3, "auto", "allgather"), (3, None, 7, "auto", "allgather"),
+    # the rule itself: a uniform graph on 2 ranks needs nearly every remote row -> all-gather; planted partitions -> p2p
+    (2, None, None, "auto", "auto"), (4, 0.05, None, "auto", "auto")])
+def test_multi_rank_kipf_step_matches_global_oracle(oracle, world, cut, Fo, order, mode):
     from athena_amd import dist as adist
 
     n, pairs, F = 400, 1500, 8
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, pairs, F, cut, q, Fo, order)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, pairs, F, cut, q, Fo, order, mode)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=120) for _ in range(world))
@@ -149,7 +155,13 @@ def test_multi_rank_kipf_step_matches_global_oracle(oracle, world, cut, Fo, orde
     dW = oracle.matmul_dw(dz, P)
     for r in range(world):
         assert np.abs(res[r]["dW"] - dW).max() <= 1e-5 * np.abs(dW).max()                  # all-reduced
-        assert res[r]["n_halo"] > 0 and res[r]["send"] > 0
+        assert res[r]["n_halo"] > 0
+        want = mode if mode != "auto" else ("allgather" if res[r]["halo_fraction"] > 0.7 else "p2p")
+        assert res[r]["halo_mode"] == want, (res[r]["halo_mode"], res[r]["halo_fraction"])
+        assert (res[r]["send"] > 0) == (want == "p2p")                 # the all-gather needs no send list
+        assert res[r]["n_halo"] == world * n or want == "p2p"
+    if mode == "auto":
+        assert res[0]["halo_mode"] == ("allgather" if cut is None else "p2p"), res[0]["halo_fraction"]
     deg = np.diff(ia)
     assert np.array_equal(res[0]["col_deg"][:n], deg[:n][res[0]["order"]])
     assert all(0 <= res[r]["n_int"] < n for r in range(world))
@@ -157,9 +169,9 @@ def test_multi_rank_kipf_step_matches_global_oracle(oracle, world, cut, Fo, orde
         assert all(res[r]["n_int"] > n // 4 for r in range(world))   # planted partitions leave interior rows
 
 
-def _worker_global(rank, world, port, n_total, pairs, F, locality, q):
+def _worker_global(rank, world, port, n_total, pairs, F, locality, q, mode="p2p"):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ATHENA_MP_HALO_MODE=mode)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from athena_amd import dist as adist, synth
 
@@ -170,16 +182,20 @@ def _worker_global(rank, world, port, n_total, pairs, F, locality, q):
               synth.kipf_weight(F))
     step, nnz, info = adist.build_kipf_step(shard, F, dev, backend=OracleBackend(), inputs=inputs)
     dx = step().clone().numpy()
-    halo_ok = bool(np.array_equal(step.x_ext[n:].numpy(), synth.feature_rows(1, shard.halo_ids, F)) and
-                   np.array_equal(step.dZ_ext[n:].numpy(), synth.feature_rows(3, shard.halo_ids, F)))
+    held = shard.ext_ids >= 0                      # every row behind the local ones that holds a vertex (not a padding slot)
+    halo_ok = bool(np.array_equal(step.x_ext[n:].numpy()[held], synth.feature_rows(1, shard.ext_ids[held], F)) and
+                   np.array_equal(step.dZ_ext[n:].numpy()[held], synth.feature_rows(3, shard.ext_ids[held], F)) and
+                   np.isin(shard.halo_ids, shard.ext_ids[held]).all())
     q.put((rank, dict(P=step.P.numpy().copy(), Z=step.Z.numpy().copy(), dW=step.dW.numpy().copy(), dX=dx,
-                      order=shard.order.copy(), nnz=nnz, halo_ok=halo_ok, n_int=shard.n_int, info=info)))
+                      order=shard.order.copy(), nnz=nnz, halo_ok=halo_ok, n_int=shard.n_int, info=info,
+                      halo_mode=shard.halo_mode)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,locality", [(2, None), (8, None), (4, (60, 0.95))])
-def test_strong_scaling_shards_of_one_fixed_graph_match_the_single_process_oracle(oracle, world, locality):
+@pytest.mark.parametrize("world,locality,mode", [(2, None, "p2p"), (8, None, "p2p"), (4, (60, 0.95), "p2p"),
+                                                 (8, None, "allgather"), (4, (60, 0.95), "auto"), (2, None, "auto")])
+def test_strong_scaling_shards_of_one_fixed_graph_match_the_single_process_oracle(oracle, world, locality, mode):
     """bench.py's N > 1 default: every rank builds its row block of ONE graph (the C2 generator, here 1 600 vertices)
     from the shared pair stream and takes its rows of the SAME X / dZ the single-GPU run uses; assembled results equal
     the oracle on the whole graph, P bit for bit.  8 ranks = the partition of BASELINE configs[4]."""
@@ -189,7 +205,7 @@ def test_strong_scaling_shards_of_one_fixed_graph_match_the_single_process_oracl
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_global, args=(r, world, port, n_total, pairs, F, locality, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_global, args=(r, world, port, n_total, pairs, F, locality, q, mode)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=180) for _ in range(world))
@@ -220,6 +236,10 @@ def test_strong_scaling_shards_of_one_fixed_graph_match_the_single_process_oracl
     for r in range(world):
         assert np.abs(res[r]["dW"] - dW).max() <= 1e-5 * np.abs(dW).max()
         assert res[r]["halo_ok"]
+        if mode != "auto":
+            assert res[r]["halo_mode"] == mode
+        else:   # banded graph: a rank needs a sliver of its neighbours' rows -> p2p; uniform on 2 ranks -> all-gather
+            assert res[r]["halo_mode"] == ("p2p" if locality is not None else "allgather")
     if locality is not None:
         assert all(res[r]["n_int"] > 0 for r in range(world))       # a banded graph leaves interior rows
 

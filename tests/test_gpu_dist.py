@@ -19,9 +19,9 @@ from test_dist_gloo import ROOT, _free_port
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, n, pairs, F, cut, q, Fo=None):
+def _worker(rank, world, port, n, pairs, F, cut, q, Fo=None, mode="p2p"):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ATHENA_MP_HALO_MODE=mode)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from athena_amd import dist as adist
 
@@ -37,24 +37,30 @@ def _worker(rank, world, port, n, pairs, F, cut, q, Fo=None):
                       P=step.P.cpu().numpy().copy() if step.P is not None else None, transform_first=step.transform_first,
                       Z=step.Z.cpu().numpy().copy(), dW=step.dW.cpu().numpy().copy(),
                       dX=dx, order=shard.order.copy(), n_int=shard.n_int, n_halo=shard.n_halo,
-                      fwd_ms=ev[0][0].elapsed_time(ev[0][1]), transport=shard.transport)))
+                      fwd_ms=ev[0][0].elapsed_time(ev[0][1]), transport=shard.transport, halo_mode=shard.halo_mode,
+                      halo_fraction=shard.halo_fraction)))
     dist.barrier()
     adist.c_comm_destroy()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,cut,F,Fo", [(2, 0.1, 128, None), (3, None, 64, None), (2, 0.05, 24, None),
-                                            (2, 0.1, 128, 32),     # narrowing step: dense step before the exchange
-                                            (3, None, 64, 96),     # widening step: rectangular, aggregate first
-                                            (2, 0.1, 256, None)])  # BASELINE configs[4] width (two-kernel route per shard)
-def test_multi_rank_step_with_hip_backend_matches_global_oracle(dev, oracle, world, cut, F, Fo):
+@pytest.mark.parametrize("world,cut,F,Fo,mode", [
+    (2, 0.1, 128, None, "p2p"), (3, None, 64, None, "p2p"), (2, 0.05, 24, None, "p2p"),
+    (2, 0.1, 128, 32, "p2p"),     # narrowing step: dense step before the exchange
+    (3, None, 64, 96, "p2p"),     # widening step: rectangular, aggregate first
+    (2, 0.1, 256, None, "p2p"),   # BASELINE configs[4] width (two-kernel route per shard)
+    # the halo as one all-gather of whole blocks (comm.hip mode 1)
+    (2, None, 128, None, "allgather"), (3, None, 64, None, "allgather"), (8, None, 64, None, "allgather"),
+    (2, 0.1, 128, 32, "allgather"), (2, None, 256, None, "allgather"),
+    (3, None, 64, None, "auto"), (2, 0.05, 24, None, "auto")])
+def test_multi_rank_step_with_hip_backend_matches_global_oracle(dev, oracle, world, cut, F, Fo, mode):
     from athena_amd import dist as adist
 
-    n, pairs = 3000, 12000
+    n, pairs = (3000, 12000) if world < 8 else (1000, 4000)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, pairs, F, cut, q, Fo)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, pairs, F, cut, q, Fo, mode)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=300) for _ in range(world))
@@ -92,6 +98,8 @@ def test_multi_rank_step_with_hip_backend_matches_global_oracle(dev, oracle, wor
         assert np.abs(res[r]["dW"] - dW).max() <= 1e-5 * np.abs(dW).max()
         assert res[r]["n_halo"] > 0 and res[r]["fwd_ms"] > 0
         assert res[r]["transport"].startswith("shm")     # the C-ABI shard / exchange (comm.hip) over its test transport
+        want = mode if mode != "auto" else ("allgather" if cut is None else "p2p")   # uniform on 3 ranks: fraction ~0.9
+        assert res[r]["halo_mode"] == want, (res[r]["halo_mode"], res[r]["halo_fraction"])
 
 
 def _dp_worker(rank, world, port, q):
@@ -151,10 +159,10 @@ def test_graph_sharded_duvenaud_layer_all_reduce_equals_single_process(dev):
 
 
 # ---- the C-ABI communicator / shard / halo exchange (csrc/comm.hip) ---------------------------------------------------
-def _xcheck_worker(rank, world, port, q):
+def _xcheck_worker(rank, world, port, q, mode):
     """both plans on the same rows: the C ABI's shard (shm test transport) and the python mirror (torch p2p over gloo)"""
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ATHENA_MP_HALO_MODE=mode)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from athena_amd import dist as adist
 
@@ -168,6 +176,8 @@ def _xcheck_worker(rank, world, port, q):
     same = dict(
         dims=(cs.n, cs.n_int, cs.n_halo, cs.nnz) == (py.n, py.n_int, py.n_halo, py.nnz),
         order=bool(np.array_equal(cs.order, py.order)), halo_ids=bool(np.array_equal(cs.halo_ids, py.halo_ids)),
+        ext_ids=bool(np.array_equal(cs.ext_ids, py.ext_ids)), mode=cs.halo_mode == py.halo_mode == mode,
+        fraction=abs(cs.halo_fraction - py.halo_fraction) < 1e-12, recv_rows=cs.recv_rows == py.recv_rows,
         col_deg=bool(np.array_equal(cs.col_deg, py.col_deg)),
         send_idx=bool(np.array_equal(cs.send_idx.numpy(), py.send_idx.cpu().numpy())),
         fwd=all(np.array_equal(a, b) for a, b in zip(cs.csr(False), py.csr(False))),
@@ -179,7 +189,8 @@ def _xcheck_worker(rank, world, port, q):
     cs.exchange(8, dev)(x)
     py.exchange(8, dev, adist.HipBackend(dev))(x2)
     torch.cuda.synchronize()
-    same["halo_rows"] = bool(torch.equal(x, x2)) and bool((x[n:] >= 0).all())
+    held = torch.from_numpy(cs.ext_ids >= 0).to(dev)
+    same["halo_rows"] = bool(torch.equal(x[n:][held], x2[n:][held])) and bool((x[n:][held] >= 0).all())
     q.put((rank, same))
     dist.barrier()
     cs.close()
@@ -187,12 +198,13 @@ def _xcheck_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_c_abi_shard_equals_the_python_plan_and_moves_the_same_halo_rows(dev):
+@pytest.mark.parametrize("mode", ["p2p", "allgather"])
+def test_c_abi_shard_equals_the_python_plan_and_moves_the_same_halo_rows(dev, mode):
     world = 3
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_xcheck_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_xcheck_worker, args=(r, world, port, q, mode)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=300) for _ in range(world))
@@ -240,8 +252,10 @@ def test_rccl_communicator_single_rank_through_the_c_abi(dev):
     _capi.call("athena_mp_comm_destroy", h)
 
 
-@pytest.mark.parametrize("world,transport", [(1, "rccl"), (2, "shm"), (3, "shm")])
-def test_fortran_processes_run_the_sharded_step_through_the_c_abi(dev, oracle, tmp_path, world, transport):
+@pytest.mark.parametrize("world,transport,mode,nv", [(1, "rccl", "auto", 6000), (2, "shm", "p2p", 6000), (3, "shm", "p2p", 6000),
+                                                     (3, "shm", "allgather", 6001),    # blocks of 2000 / 2000 / 2001 rows: padded slots
+                                                     (8, "shm", "allgather", 6001), (2, "shm", "auto", 6000)])
+def test_fortran_processes_run_the_sharded_step_through_the_c_abi(dev, oracle, tmp_path, world, transport, mode, nv):
     """kipf_shard_run.f90: one FORTRAN process per rank -- communicator from an id file, shard, halo exchange of X and
     dZ under the interior rows, dW all-reduce, all through ISO_C_BINDING; assembled results against the oracle on the
     whole graph (P bit for bit).  world = 1 uses RCCL itself; 2 and 3 ranks share the box's one GPU over the test
@@ -251,9 +265,15 @@ def test_fortran_processes_run_the_sharded_step_through_the_c_abi(dev, oracle, t
     exe = os.path.join(ROOT, "athena_amd", "fortran", "kipf_shard_run")
     if not os.path.exists(exe):
         pytest.skip("Fortran driver not built (no amdflang)")
-    nv, pairs, F = 6000, 24000, 64
+    pairs, F = 24000, 64
     env = dict(os.environ)
     env.pop("ATHENA_MP_COMM_TRANSPORT", None)
+    env["ATHENA_MP_HALO_MODE"] = mode
+    # a file a crashed launch left behind at the rendezvous path (and a stale hello) must not be taken for this launch's
+    with open(tmp_path / "id", "wb") as fh:
+        fh.write(b"\x5a" * (128 + 8 * world))
+    with open(str(tmp_path / "id") + ".hello.1", "wb") as fh:
+        fh.write(b"\x11" * 8)
     if transport == "shm":
         env["ATHENA_MP_COMM_TRANSPORT"] = "shm"
     prefix = str(tmp_path / "run")
@@ -287,3 +307,42 @@ def test_fortran_processes_run_the_sharded_step_through_the_c_abi(dev, oracle, t
     dw_ref = oracle.matmul_dw(dz, p_ref)
     for r in range(world):
         assert np.abs(dWs[r] - dw_ref).max() <= 1e-5 * np.abs(dw_ref).max()
+
+
+@pytest.mark.parametrize("argv,mode", [(["--gpus", "2"], "auto"),                        # the command the driver issues, C2 graph
+                                       (["--gpus", "8", "--nodes", "200000", "--pairs", "900000"], "auto"),
+                                       (["--gpus", "4", "--nodes", "200000", "--pairs", "900000"], "p2p"),
+                                       (["--gpus", "2", "--config", "c5-local", "--nodes", "400000", "--pairs", "2800000"], "auto")])
+def test_bench_py_multi_gpu_command_dry_run_on_one_device(dev, argv, mode):
+    """`python bench.py --gpus N` -- what the driver launches on an 8-GPU node -- through the one-device dry run
+    (ATHENA_MP_BENCH_ONE_DEVICE=1, gloo process group, comm.hip's host-staged test transport): self-launch, strong-scaling
+    shards of the metric's own graph, both exchanges, parity of every rank against the oracle, the breakdown.  The
+    numbers mean nothing here; the line's structure and its parity do."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, ATHENA_MP_BENCH_ONE_DEVICE="1", ATHENA_MP_BENCH_BACKEND="gloo", ATHENA_MP_HALO_MODE=mode)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1"] + argv,
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    n = int(argv[1])
+    assert line["n_gpus"] == n and line["scaling"] == "strong" and line["unit"] == "edges/s"
+    assert line["parity"]["ok"] and line["parity"]["P_bit_exact"] and line["parity"]["halo_rows_bit_exact"]
+    assert max(line["parity"]["Z_rel"], line["parity"]["dX_rel"], line["parity"]["dW_rel_vs_float64"]) <= 1e-5
+    bd = line["breakdown"]
+    for k in ("halo_ms", "interior_ms", "boundary_ms", "dw_ms", "halo_recv_bytes_per_gpu_per_step", "xgmi_recv_GBps_per_gpu",
+              "halo_mode", "halo_fraction", "halo_allgather_threshold"):
+        assert k in bd, k
+    cfg = line["config"]
+    assert cfg["transport"].startswith("shm") and cfg["halo_mode"] == bd["halo_mode"]
+    if mode == "auto":   # the rule of SURVEY.md 8e: whole blocks above a halo fraction of 0.7
+        assert bd["halo_mode"] == ("allgather" if bd["halo_fraction"] > bd["halo_allgather_threshold"] else "p2p")
+        if "c5-local" in argv:
+            assert bd["halo_mode"] == "p2p"                 # a banded graph needs a sliver of its neighbours' blocks
+        elif n == 2:
+            assert bd["halo_mode"] == "allgather"           # uniform graph, 2 ranks: ~0.99 of the other block
+    else:
+        assert bd["halo_mode"] == mode
+    assert line["roofline"]["frac"] > 0 and line["roofline"]["dense"]["bound"] == "mfma"

@@ -228,3 +228,18 @@ def test_graph_key_is_a_content_key():
         jb[0, w] = old
     assert key(ia, jb) == kb
     assert key(ia[:-1], jb[:, : ia[-2] - 1]) != kb
+
+
+def test_bench_line_refuses_the_test_transport_outside_the_dry_run():
+    """a typo'd backend on a real node must not "scale" through /dev/shm files: bench.py marks such a line ok = false
+    and exits non-zero unless the one-device dry-run switch is set"""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.transport_error("rccl", False) is None
+    assert bench.transport_error("shm (test transport: host-staged files, not RCCL)", True) is None
+    assert "not RCCL" in bench.transport_error("shm (test transport: host-staged files, not RCCL)", False)
+    assert bench.transport_error("torch.distributed point-to-point (python plan) -- FALLBACK, the C-ABI path failed: x", False)
