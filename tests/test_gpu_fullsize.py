@@ -346,3 +346,183 @@ def test_tensors_beyond_2_31_elements_use_64_bit_offsets(dev, oracle):
     degd = torch.from_numpy(np.diff(ia).astype(np.float64)).to(dev)
     a = dx[:, :8].double().sum(0); b = (x[:, :8].double() * degd[:, None]).sum(0)
     assert torch.allclose(a, b, rtol=1e-6, atol=1e-6 * b.abs().max().item())
+
+
+# ---- BASELINE configs[4]: Kipf GCN 10 M vertices / 150 M entries / 256 features, 8-way row partition -------------------
+# reference call site: the per-sample loop of update_message_kipf, athena_kipf_msgpass_layer.f90:943-952
+_C5 = {}
+
+
+def _c5_graph(variant):
+    """the whole configs[4] graph on the host (SURVEY.md 8d generator; "local" = its locality variant,
+    |u - v| <= 50 000 with probability 0.95), built once per module"""
+    from athena_amd import synth
+
+    if variant not in _C5:
+        N, pairs = 10_000_000, 70_000_000
+        if variant == "uniform":
+            ia, ja = synth.random_graph_csr(N, pairs)
+        else:
+            ia64, cols = synth.random_graph_csr_rows(N, pairs, 0, N, locality=(50_000, 0.95))
+            ia = ia64.astype(np.int32)
+            ja = np.zeros((2, cols.size), np.int32, order="F")
+            ja[0] = cols + 1
+        assert ja.shape[1] == 150_000_000
+        _C5.clear()                                     # one 1.8 GB graph on the host at a time
+        _C5[variant] = (ia, ja)
+    return _C5[variant]
+
+
+def _device_uniform(dev, n, F, seed):
+    """U(-1, 1) fp32 [n, F] drawn on the device (a host draw of 2.56e9 values would take minutes)"""
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    t = torch.rand((n, F), device=dev, generator=gen)
+    return t.mul_(2.0).sub_(1.0)
+
+
+def _rows_sub_problem(ia, cols_of_entry, rows):
+    """compact CSR of the rows `rows`: (distinct columns, sia, sja) with sja(1,:) indexing the distinct columns"""
+    ent = np.concatenate([np.arange(ia[r] - 1, ia[r + 1] - 1) for r in rows])
+    cols, inv = np.unique(cols_of_entry[ent].astype(np.int64), return_inverse=True)
+    sia = np.concatenate([[1], 1 + np.cumsum(ia[rows + 1] - ia[rows])]).astype(np.int32)
+    sja = np.zeros((2, ent.size), np.int32, order="F")
+    sja[0] = inv + 1
+    return cols, sia, sja
+
+
+def test_c5_fused_step_on_one_gpu_matches_oracle_at_full_size(dev, oracle):
+    """configs[4] at its real size on ONE GPU (10 M / 150 M / 256; 50 GB of resident tensors): the fused forward launch
+    (agg_gemm256_kernel: W in registers) and its reverse.  P bit-exact and Z <= 1e-5 on 20 000 sampled rows (the last rows
+    included: the highest 64-bit offsets), dX <= 1e-5 on 3 000 sampled COLUMNS against the reference order (matmul reverse,
+    then the coefficient-free scatter) on the sub-CSR of the entries that point at them."""
+    from athena_amd import DeviceGraph, ops, synth
+
+    N, F = 10_000_000, 256
+    ia, ja = _c5_graph("uniform")
+    g = DeviceGraph(ia, ja, n_edge_cols=0)
+    x = _device_uniform(dev, N, F, 1)
+    w_h = synth.kipf_weight(F)
+    w = torch.from_numpy(w_h).to(dev)
+    P, Z = ops.kipf_layer_fwd(g, x, w, F)
+    rows = np.unique(np.concatenate([np.random.default_rng(21).choice(N, 20000, replace=False), np.arange(N - 64, N), np.arange(64)]))
+    cols, sia, sja = _rows_sub_problem(ia, ja[0] - 1, rows)
+    deg = np.diff(ia).astype(np.int32)
+    xs = x[torch.from_numpy(cols).to(dev)].cpu().numpy()
+    p_ref = oracle.kipf_propagate_rect(xs, sia, sja, deg[rows], deg[cols])
+    rsel = torch.from_numpy(rows).to(dev)
+    assert np.array_equal(P[rsel].cpu().numpy(), p_ref), "configs[4] fused forward: P differs from the oracle"
+    z_ref = oracle.matmul(w_h, p_ref, F)
+    assert np.abs(Z[rsel].cpu().numpy() - z_ref).max() <= 1e-5 * np.abs(z_ref).max()
+    P2, Z2 = ops.kipf_layer_fwd(g, x, w, F)
+    assert torch.equal(P, P2) and torch.equal(Z, Z2)              # ticket-scheduled kernel: deterministic all the same
+    del P2, Z2, P, Z, x
+    # reverse wrt the input: dX = (A^T dZ) . W
+    dz = _device_uniform(dev, N, F, 3)
+    dX = ops.kipf_layer_bwd_x(g, dz, w, F)
+    csel = np.sort(np.random.default_rng(22).choice(N, 3000, replace=False))
+    src, cia, cja = _column_sub_problem(ia, ja, csel)
+    dzs = dz[torch.from_numpy(src).to(dev)].cpu().numpy()
+    dx_ref = oracle.kipf_propagate_bwd(oracle.matmul_dx(w_h, dzs, F), cia, cja, n_out=csel.size)
+    got = dX[torch.from_numpy(csel).to(dev)].cpu().numpy()
+    assert np.abs(got - dx_ref).max() <= 1e-5 * np.abs(dx_ref).max()
+    # the coefficient-free scatter conserves mass per feature: sum_u dX[u,:] = (sum_v deg_v dZ[v,:]) . W
+    degd = torch.from_numpy(deg.astype(np.float64)).to(dev)
+    lhs = dX.double().sum(0)
+    rhs = ((dz.double() * degd[:, None]).sum(0)[None, :] @ w.double().reshape(F, F).T).reshape(-1)   # W(Fo,Fi) col-major == Wt[Fi][Fo]
+    assert torch.allclose(lhs, rhs, rtol=1e-6, atol=1e-6 * rhs.abs().max().item())
+
+
+@pytest.mark.parametrize("variant,mode,rank", [("uniform", "allgather", 5), ("local", "p2p", 3)])
+def test_c5_one_real_shard_of_the_eight_way_partition(dev, oracle, variant, mode, rank):
+    """ONE real shard of configs[4]: rank `rank` of the contiguous 8-way row partition of the 10 M / 150 M graph (and of its
+    locality variant), 1.25 M rows / ~18.75 M entries / 256 features, in the layout the multi-GPU step uses -- vertices
+    numbered interior first, columns [local | halo] (the plan tests/test_gpu_dist.py holds equal to
+    athena_mp_shard_create's), halo rows filled with what the exchange would deliver, degrees of halo columns from their
+    owners.  uniform: 0.80 of all remote rows are needed -> the all-gather layout (whole blocks of the 8 ranks behind the
+    local rows); local: a sliver of the neighbouring blocks -> packed rows.  Interior and boundary launches of the
+    forward (fused 256-wide kernel on a RECTANGULAR block) and of the reverse pull; sampled rows of both blocks against the
+    oracle: P bit for bit, Z and dX <= 1e-5."""
+    from athena_amd import dist as adist, synth
+
+    N, F, world = 10_000_000, 256, 8
+    n = N // world
+    ia, ja = _c5_graph(variant)
+    lo, hi = rank * n, (rank + 1) * n
+    e0, e1 = int(ia[lo]) - 1, int(ia[hi]) - 1
+    rows_local = np.repeat(np.arange(n, dtype=np.int64), np.diff(ia[lo:hi + 1]))
+    cols_global = ja[0, e0:e1].astype(np.int64) - 1
+    sh = adist.Shard(rank, world, n, rows_local, cols_global)
+    deg = np.diff(ia).astype(np.int32)
+    frac = None
+    if mode == "allgather":
+        # every rank's interior-first order (what the ranks publish in athena_mp_shard_create's all-gather mode)
+        owner_row = np.repeat(np.arange(N, dtype=np.int64), deg) // n
+        bnd = np.zeros(N, bool)
+        bnd[np.repeat(np.arange(N, dtype=np.int64), deg)[(ja[0].astype(np.int64) - 1) // n != owner_row]] = True
+        new_of_old, deg_new = [], []
+        for p in range(world):
+            order = np.argsort(bnd[p * n:(p + 1) * n], kind="stable")
+            noo = np.empty(n, np.int64); noo[order] = np.arange(n)
+            new_of_old.append(noo); deg_new.append(deg[p * n:(p + 1) * n][order])
+        assert np.array_equal(new_of_old[rank], sh.new_of_old)
+        sh.use_allgather(new_of_old, deg_new)
+        ext_ids = sh.ext_ids
+        del owner_row, bnd
+    else:
+        sh.col_deg = np.concatenate([sh.row_deg, deg[sh.halo_ids]])
+        ext_ids = sh.halo_ids
+        frac = sh.halo_ids.size / float(N - n)
+        assert frac < 0.2                                          # banded graph: p2p is the right call
+    assert np.array_equal(sh.row_deg, deg[lo:hi][sh.order])
+    b = adist.HipBackend(dev)
+    g_fi, g_fb, g_bi, g_bb = sh.graphs(b)
+    ni = sh.n_int
+    assert 0 <= ni <= n and g_fi.n_rows == ni and g_fb.n_rows == n - ni
+    # what the exchanges deliver: the global tensors' rows, local part in the shard's order
+    xg = _device_uniform(dev, N, F, 1)
+    ids = torch.from_numpy(np.concatenate([lo + sh.order, np.maximum(ext_ids, 0)])).to(dev)
+    x_ext = xg[ids]
+    del xg
+    dzg = _device_uniform(dev, N, F, 3)
+    dz_ext = dzg[ids]
+    del dzg, ids
+    w_h = synth.kipf_weight(F)
+    w = torch.from_numpy(w_h).to(dev)
+    P = torch.empty((n, F), device=dev); Z = torch.empty((n, F), device=dev); dX = torch.empty((n, F), device=dev)
+    b.kipf_layer_fwd(g_fi, x_ext, w, F, P=P[:ni], Z=Z[:ni])
+    b.kipf_layer_fwd(g_fb, x_ext, w, F, P=P[ni:], Z=Z[ni:])
+    b.pull_gemm(g_bi, dz_ext, w, F, exact=False, out=dX[:ni])
+    b.pull_gemm(g_bb, dz_ext, w, F, exact=False, out=dX[ni:])
+    rng = np.random.default_rng(30 + rank)
+    pick = [rng.choice(ni, min(3000, ni), replace=False)] if ni else []
+    if n - ni:
+        pick.append(ni + rng.choice(n - ni, min(3000, n - ni), replace=False))
+    rows = np.unique(np.concatenate(pick + [np.arange(max(n - 32, 0), n)]))
+    rsel = torch.from_numpy(rows).to(dev)
+    ia_s, nb = sh.csr(False)
+    cols, sia, sja = _rows_sub_problem(ia_s, nb.astype(np.int64) - 1, rows)
+    xc = x_ext[torch.from_numpy(cols).to(dev)].cpu().numpy()
+    p_ref = oracle.kipf_propagate_rect(xc, sia, sja, sh.row_deg[rows], sh.col_deg[cols])
+    assert np.array_equal(P[rsel].cpu().numpy(), p_ref), "shard forward: P differs from the oracle"
+    z_ref = oracle.matmul(w_h, p_ref, F)
+    assert np.abs(Z[rsel].cpu().numpy() - z_ref).max() <= 1e-5 * np.abs(z_ref).max()
+    # the same rows through the WHOLE graph's numbering give the same P (the shard layout changes nothing)
+    grow = lo + sh.order[rows]
+    gcols, gia, gja = _rows_sub_problem(ia, ja[0] - 1, grow)
+    lut = np.full(N, -1, np.int64)
+    held = ext_ids >= 0
+    lut[ext_ids[held]] = n + np.flatnonzero(held)
+    lut[lo + sh.order] = np.arange(n)
+    assert (lut[gcols] >= 0).all()
+    xg_rows = x_ext[torch.from_numpy(lut[gcols]).to(dev)].cpu().numpy()
+    assert np.array_equal(oracle.kipf_propagate_rect(xg_rows, gia, gja, deg[grow], deg[gcols]), p_ref)
+    # reverse: the pull over the shard's rows sorted by source id, reference order W^T dZ then the plain sums
+    ia_b, nbb = sh.csr(True)
+    cols, sia, sja = _rows_sub_problem(ia_b, nbb.astype(np.int64) - 1, rows)
+    dzc = dz_ext[torch.from_numpy(cols).to(dev)].cpu().numpy()
+    ones = np.ones(max(rows.size, cols.size), np.int32)
+    dx_ref = oracle.kipf_propagate_rect(oracle.matmul_dx(w_h, dzc, F), sia, sja, ones[:rows.size], ones[:cols.size])
+    assert np.abs(dX[rsel].cpu().numpy() - dx_ref).max() <= 1e-5 * np.abs(dx_ref).max()
+    if mode == "allgather":
+        need = sh.halo_ids.size / float(N - n)
+        assert need > 0.7, need                                    # why this shard travels as whole blocks (SURVEY.md 8e)
