@@ -112,7 +112,7 @@ struct athena_mp_graph {
     // the same runs cut into 16-vertex tiles (one MFMA column block each), bucket-major
     mutable int32_t n_btiles = 0;
     mutable int32_t *btile_start = nullptr;      // [n_btiles] device: first index into bucket_perm
-    mutable int32_t *btile_rows = nullptr;       // [16*n_btiles] device: vertex of each tile slot; padding slots hold
+    mutable int32_t *btile_rows = nullptr;       // [4][16*n_btiles] device: vertex of each tile slot (copies: see duvenaud_buckets); in copy 0 padding slots hold
                                                  //   ~(first vertex of the tile) (negative: load from it, never store)
     mutable int32_t *btile_info = nullptr;       // [n_btiles] device: bucket << 8 | vertices in the tile (1..16)
     mutable int32_t *btile_off_dev = nullptr;    // [n_buckets+1] device: first tile of each bucket

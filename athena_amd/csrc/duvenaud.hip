@@ -176,13 +176,27 @@ int duvenaud_buckets(const athena_mp_graph *g, int min_deg, int max_deg)
         g->bucket_perm = g->btile_start = g->btile_info = g->btile_rows = g->btile_off_dev = nullptr;
     }
     const size_t nt = tstart.size();
-    std::vector<int32_t> trows(16 * nt);
+    // four copies back to back, [16 nt] each:
+    //   0  padding slots as ~(first vertex of the tile): the weight-gradient kernel zeroes their gradient rows
+    //   1  padding slots as the first vertex itself: the row kernels load and store them as benign duplicates
+    //   2  copy 1 transposed 4 x 4 inside each tile (slot 4 i + r at position 4 r + i): a lane that serves rows r, 4 + r,
+    //      8 + r, 12 + r of a tile in four coalesced loads fetches its four ids with one 16-byte load
+    //   3  copy 0 transposed the same way
+    std::vector<int32_t> trows(64 * nt);
     for (size_t t = 0; t < nt; ++t) {
         const int cnt = tinfo[t] & 255;
-        for (int i = 0; i < 16; ++i) trows[16 * t + i] = i < cnt ? perm[tstart[t] + i] : ~perm[tstart[t]];
+        for (int i = 0; i < 16; ++i) {
+            const int32_t v = i < cnt ? perm[tstart[t] + i] : perm[tstart[t]];
+            const int32_t sv = i < cnt ? v : ~v;
+            const int tp = 4 * (i & 3) + (i >> 2);
+            trows[16 * t + i] = sv;
+            trows[16 * (nt + t) + i] = v;
+            trows[16 * (2 * nt + t) + tp] = v;
+            trows[16 * (3 * nt + t) + tp] = sv;
+        }
     }
-    AMP_HIP(hipMalloc((void **)&g->btile_rows, sizeof(int32_t) * (nt ? 16 * nt : 1)));
-    if (nt) AMP_HIP(hipMemcpy(g->btile_rows, trows.data(), sizeof(int32_t) * 16 * nt, hipMemcpyHostToDevice));
+    AMP_HIP(hipMalloc((void **)&g->btile_rows, sizeof(int32_t) * (nt ? 64 * nt : 1)));
+    if (nt) AMP_HIP(hipMemcpy(g->btile_rows, trows.data(), sizeof(int32_t) * 64 * nt, hipMemcpyHostToDevice));
     AMP_HIP(hipMalloc((void **)&g->bucket_perm, sizeof(int32_t) * (n ? n : 1)));
     AMP_HIP(hipMalloc((void **)&g->btile_start, sizeof(int32_t) * (nt ? nt : 1)));
     AMP_HIP(hipMalloc((void **)&g->btile_info, sizeof(int32_t) * (nt ? nt : 1)));
