@@ -110,6 +110,12 @@ _PROTOS = {
     "athena_mp_shard_export": [_vp, _i32, _vp, _i64, C.POINTER(_i64)],
     "athena_mp_halo_start": [_vp, _i32, _i32, _vp],
     "athena_mp_halo_finish": [_vp, _i32],
+    "athena_mp_resident_mode": [_i32],
+    "athena_mp_resident_acquire": [_vp, C.c_uint64, _i32, C.POINTER(_vp)],
+    "athena_mp_resident_release": [_vp, _i32],
+    "athena_mp_resident_flush": [_vp],
+    "athena_mp_resident_drop": [_vp],
+    "athena_mp_resident_stats": [C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)],
     "athena_mp_kipf_propagate_fwd_host": [_vp, _i32, _vp, _vp],
     "athena_mp_kipf_propagate_bwd_host": [_vp, _i32, _vp, _vp, _i32],
     "athena_mp_gemm_fwd_host": [_i64, _i32, _i32, _vp, _vp, _vp, _i32, _vp],

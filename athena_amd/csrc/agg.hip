@@ -531,33 +531,4 @@ int athena_mp_gather_rows(int64_t n, int32_t F, const int32_t *idx, const float 
     return gather_agg(iota, idx, nullptr, x, F, out, F, (int32_t)n, F);
 }
 
-int athena_mp_kipf_propagate_fwd_host(const athena_mp_graph *g, int32_t F, const float *xh, float *yh)
-{
-    AMP_REQUIRE(g && xh && yh && F > 0, "kipf_propagate_fwd_host: bad arguments");
-    size_t bx = sizeof(float) * (size_t)g->n_cols * F, by = sizeof(float) * (size_t)g->n_rows * F;
-    void *dx = nullptr, *dy = nullptr;
-    if (workspace(&dx, bx, 0) || workspace(&dy, by, 1)) return 1;
-    AMP_HIP(hipMemcpyAsync(dx, xh, bx, hipMemcpyHostToDevice, stream()));
-    int rc = athena_mp_kipf_propagate_fwd(g, F, (const float *)dx, (float *)dy);
-    if (rc) return rc;
-    AMP_HIP(hipMemcpyAsync(yh, dy, by, hipMemcpyDeviceToHost, stream()));
-    AMP_HIP(hipStreamSynchronize(stream()));
-    return 0;
-}
-
-int athena_mp_kipf_propagate_bwd_host(const athena_mp_graph *g, int32_t F, const float *gh, float *dxh,
-                                      int32_t exact)
-{
-    AMP_REQUIRE(g && gh && dxh && F > 0, "kipf_propagate_bwd_host: bad arguments");
-    size_t bg = sizeof(float) * (size_t)g->n_rows * F, bx = sizeof(float) * (size_t)g->n_cols * F;
-    void *dg = nullptr, *dx = nullptr;
-    if (workspace(&dg, bg, 0) || workspace(&dx, bx, 1)) return 1;
-    AMP_HIP(hipMemcpyAsync(dg, gh, bg, hipMemcpyHostToDevice, stream()));
-    int rc = athena_mp_kipf_propagate_bwd(g, F, (const float *)dg, (float *)dx, exact);
-    if (rc) return rc;
-    AMP_HIP(hipMemcpyAsync(dxh, dx, bx, hipMemcpyDeviceToHost, stream()));
-    AMP_HIP(hipStreamSynchronize(stream()));
-    return 0;
-}
-
 } // extern "C"

@@ -688,26 +688,4 @@ int athena_mp_gemm_dw(int64_t N, int32_t Fi, int32_t Fo, const float *P, const f
     return gemm_dw_dispatch(N, Fi, Fo, P, dZ, dW, false);
 }
 
-int athena_mp_gemm_fwd_host(int64_t N, int32_t Fi, int32_t Fo, const float *Ph, const float *Wh,
-                            const float *bh, int32_t act, float *Zh)
-{
-    AMP_REQUIRE(N >= 0 && Fi > 0 && Fo > 0 && Ph && Wh && Zh, "gemm_fwd_host: bad arguments");
-    size_t bp = sizeof(float) * (size_t)N * Fi, bz = sizeof(float) * (size_t)N * Fo,
-           bw = sizeof(float) * (size_t)Fi * Fo, bb = sizeof(float) * (size_t)Fo;
-    void *dp = nullptr, *dz = nullptr, *dw = nullptr;
-    if (workspace(&dp, bp, 0) || workspace(&dz, bz, 1) || workspace(&dw, bw + bb, 3)) return 1;
-    AMP_HIP(hipMemcpyAsync(dp, Ph, bp, hipMemcpyHostToDevice, stream()));
-    AMP_HIP(hipMemcpyAsync(dw, Wh, bw, hipMemcpyHostToDevice, stream()));
-    float *db = nullptr;
-    if (bh) {
-        db = (float *)((char *)dw + bw);
-        AMP_HIP(hipMemcpyAsync(db, bh, bb, hipMemcpyHostToDevice, stream()));
-    }
-    int rc = athena_mp_gemm_fwd(N, Fi, Fo, (const float *)dp, (const float *)dw, db, act, (float *)dz);
-    if (rc) return rc;
-    AMP_HIP(hipMemcpyAsync(Zh, dz, bz, hipMemcpyDeviceToHost, stream()));
-    AMP_HIP(hipStreamSynchronize(stream()));
-    return 0;
-}
-
 } // extern "C"

@@ -1,7 +1,10 @@
 // Host-pointer variants of the op-level entry points ("phase 1" of SURVEY.md 7.4): a Fortran caller
 // that only holds array_type%val passes host arrays; the shim stages them through HBM around the same
 // device entry point.  Plumbing, never timed -- device-resident callers use the *_dev entry points.
+#include <string.h>
+
 #include <initializer_list>
+#include <map>
 
 #include "common.h"
 
@@ -40,7 +43,114 @@ int pool_get(int slot, size_t bytes, void **out)
     return 0;
 }
 
-// takes a pooled device buffer per argument, uploads inputs, runs body(dev pointers), downloads outputs
+// ---- residency table (SURVEY.md 7.4 phase 2 for callers that only ever hold host arrays) ---------------------------------
+// Opt-in (athena_mp_resident_mode(1)): the result of a *_host call stays in HBM, registered under the host array's
+// address and byte length, and is NOT copied back; a later *_host call that is handed the same host array as an input
+// takes the device copy.  The host array is materialised by athena_mp_resident_flush at the edge of the HIP island
+// (athena's forward_generic2d reads layer%output, athena_network_sub.f90:2752,2761; the optimiser reads the gradients,
+// :2856).  While a result lives only on the device its host array carries a 16-byte sentinel at both ends: if host code
+// (or a re-allocated array at the same address) writes there, the next use sees the sentinel gone and uploads the host
+// content instead of trusting the device copy.  An argument that only OVERLAPS a registered array (a slice) makes that
+// array materialise first.
+struct Resident {
+    void *dev = nullptr;
+    size_t bytes = 0;
+    bool dev_newer = false;   // the device copy is the only valid one (host holds the sentinel)
+    bool trusted = false;     // caller promised (acquire with dirty_host = 0) that host code does not change the array
+    uint64_t id = 0;
+};
+std::map<const char *, Resident> g_res;
+bool g_res_on = false;
+uint64_t g_res_next_id = 1;
+struct ResidentStats {
+    int64_t h2d_bytes = 0, d2h_bytes = 0, reused_inputs = 0, lazy_outputs = 0;
+} g_res_stats;
+
+constexpr size_t kResidentMin = 64;   // smaller arguments are staged as before
+void sentinel_words(const Resident &r, uint32_t w[4])
+{
+    w[0] = 0x7fc0a7e1u;   // quiet NaNs with a payload no computation produces
+    w[1] = 0x7fc0a7e2u;
+    w[2] = (uint32_t)r.id;
+    w[3] = (uint32_t)(r.id >> 32) ^ 0x5a5a5a5au;
+}
+void sentinel_write(const Resident &r, void *host)
+{
+    uint32_t w[4];
+    sentinel_words(r, w);
+    memcpy(host, w, 16);
+    memcpy((char *)host + r.bytes - 16, w, 16);
+}
+bool sentinel_intact(const Resident &r, const void *host)
+{
+    uint32_t w[4];
+    sentinel_words(r, w);
+    return memcmp(host, w, 16) == 0 && memcmp((const char *)host + r.bytes - 16, w, 16) == 0;
+}
+int resident_flush_one(const char *host, Resident &r)
+{
+    if (r.dev_newer) {
+        AMP_HIP(hipMemcpyAsync((void *)host, r.dev, r.bytes, hipMemcpyDeviceToHost, stream()));
+        AMP_HIP(hipStreamSynchronize(stream()));
+        g_res_stats.d2h_bytes += (int64_t)r.bytes;
+        r.dev_newer = false;
+    }
+    return 0;
+}
+void resident_free(Resident &r)
+{
+    if (r.dev) (void)hipFree(r.dev);
+    r.dev = nullptr;
+}
+// every registered array that overlaps [p, p + bytes) other than an exact match: materialise and forget it
+int resident_evict_overlaps(const char *p, size_t bytes)
+{
+    for (auto it = g_res.begin(); it != g_res.end();) {
+        const char *b = it->first, *e = b + it->second.bytes;
+        const bool exact = b == p && it->second.bytes == bytes;
+        if (!exact && b < p + bytes && p < e) {
+            if (resident_flush_one(b, it->second)) return 1;
+            resident_free(it->second);
+            it = g_res.erase(it);
+        } else {
+            ++it;
+        }
+    }
+    return 0;
+}
+// device pointer for a host array; *uploaded says whether host content went up now
+int resident_get(const void *host, size_t bytes, bool as_input, void **dev)
+{
+    const char *p = (const char *)host;
+    if (resident_evict_overlaps(p, bytes)) return 1;
+    auto it = g_res.find(p);
+    if (it == g_res.end()) {
+        Resident r;
+        r.bytes = bytes;
+        r.id = g_res_next_id++;
+        AMP_HIP(hipMalloc(&r.dev, bytes));
+        it = g_res.emplace(p, r).first;
+    } else if (as_input) {
+        Resident &r = it->second;
+        const bool device_valid = (r.dev_newer && sentinel_intact(r, host)) || (!r.dev_newer && r.trusted);
+        if (device_valid) {
+            ++g_res_stats.reused_inputs;
+            *dev = r.dev;
+            return 0;
+        }
+    }
+    Resident &r = it->second;
+    if (as_input) {   // first touch, or host code wrote the array since: the host content is the valid one
+        AMP_HIP(hipMemcpyAsync(r.dev, host, bytes, hipMemcpyHostToDevice, stream()));
+        g_res_stats.h2d_bytes += (int64_t)bytes;
+        r.dev_newer = false;
+    }
+    *dev = r.dev;
+    return 0;
+}
+
+// takes a device buffer per argument (pooled staging, or the residency table in resident mode), uploads inputs, runs
+// body(dev pointers), downloads outputs (resident mode: leaves them in HBM behind a sentinel)
 template <typename Body> int staged(std::initializer_list<Stage> args, Body &&body)
 {
     std::vector<Stage> a(args);
@@ -49,7 +159,16 @@ template <typename Body> int staged(std::initializer_list<Stage> args, Body &&bo
         return 1;
     }
     int rc = 0, slot = 0;
-    for (auto &s : a) {
+    std::vector<char> resident(a.size(), 0);
+    for (size_t k = 0; k < a.size() && rc == 0; ++k) {
+        Stage &s = a[k];
+        const void *host = s.in ? s.in : s.out;
+        if (g_res_on && host && s.bytes >= kResidentMin) {
+            resident[k] = 1;
+            ++slot;
+            if (resident_get(host, s.bytes, s.in != nullptr, &s.dev)) rc = 1;
+            continue;
+        }
         if (pool_get(slot++, s.bytes, &s.dev)) {
             if (rc == 0) set_error("host staging: device allocation of %zu bytes failed", s.bytes);
             rc = 1;
@@ -67,11 +186,20 @@ template <typename Body> int staged(std::initializer_list<Stage> args, Body &&bo
         rc = body(d);
     }
     if (rc == 0) {
-        for (auto &s : a)
-            if (s.out && s.bytes && hipMemcpyAsync(s.out, s.dev, s.bytes, hipMemcpyDeviceToHost, stream()) != hipSuccess) {
+        for (size_t k = 0; k < a.size(); ++k) {
+            Stage &s = a[k];
+            if (!s.out || !s.bytes) continue;
+            if (resident[k]) {   // stays in HBM; the host array is materialised by athena_mp_resident_flush
+                Resident &r = g_res[(const char *)s.out];
+                r.dev_newer = true;
+                r.trusted = false;
+                sentinel_write(r, s.out);
+                ++g_res_stats.lazy_outputs;
+            } else if (hipMemcpyAsync(s.out, s.dev, s.bytes, hipMemcpyDeviceToHost, stream()) != hipSuccess) {
                 set_error("host staging: download failed");
                 rc = 1;
             }
+        }
         if (hipStreamSynchronize(stream()) != hipSuccess && rc == 0) {
             set_error("host staging: synchronize failed");
             rc = 1;
@@ -89,6 +217,9 @@ inline size_t fb(int64_t rows, int64_t cols) { return sizeof(float) * (size_t)ro
 namespace amp {
 void host_pool_release()
 {
+    for (auto &kv : g_res) resident_free(kv.second);   // finalize: no flush, the process is letting go of the device
+    g_res.clear();
+    g_res_on = false;
     for (int i = 0; i < kMaxStaged; ++i) {
         if (g_pool[i]) (void)hipFree(g_pool[i]);
         g_pool[i] = nullptr;
@@ -98,6 +229,116 @@ void host_pool_release()
 } // namespace amp
 
 extern "C" {
+
+/* ---- residency of host arrays (phase 2 for the *_host entry points) ---------------------------------------------------- */
+int athena_mp_resident_mode(int32_t on)
+{
+    if (!on) {   // leaving the island: every result goes home, every device copy is released
+        int rc = 0;
+        for (auto &kv : g_res) rc |= resident_flush_one(kv.first, kv.second);
+        for (auto &kv : g_res) resident_free(kv.second);
+        g_res.clear();
+        g_res_on = false;
+        return rc;
+    }
+    g_res_on = true;
+    return 0;
+}
+int athena_mp_resident_acquire(const void *host_ptr, uint64_t bytes, int32_t dirty_host, void **dev_ptr)
+{
+    AMP_REQUIRE(host_ptr && dev_ptr && bytes >= kResidentMin, "resident_acquire: null pointer or fewer than %zu bytes", kResidentMin);
+    *dev_ptr = nullptr;
+    const char *p = (const char *)host_ptr;
+    if (resident_evict_overlaps(p, (size_t)bytes)) return 1;
+    auto it = g_res.find(p);
+    if (it == g_res.end()) {
+        Resident r;
+        r.bytes = (size_t)bytes;
+        r.id = g_res_next_id++;
+        AMP_HIP(hipMalloc(&r.dev, (size_t)bytes));
+        it = g_res.emplace(p, r).first;
+    }
+    Resident &r = it->second;
+    if (dirty_host) {
+        AMP_HIP(hipMemcpyAsync(r.dev, host_ptr, (size_t)bytes, hipMemcpyHostToDevice, stream()));
+        g_res_stats.h2d_bytes += (int64_t)bytes;
+        r.dev_newer = false;
+    }
+    r.trusted = true;   // until a release says the device copy changed, or a *_host call writes it
+    *dev_ptr = r.dev;
+    return 0;
+}
+int athena_mp_resident_release(const void *host_ptr, int32_t dirty_dev)
+{
+    auto it = g_res.find((const char *)host_ptr);
+    AMP_REQUIRE(it != g_res.end(), "resident_release: %p is not a registered host array", host_ptr);
+    if (dirty_dev) {
+        it->second.dev_newer = true;
+        it->second.trusted = false;
+        sentinel_write(it->second, (void *)host_ptr);
+    }
+    return 0;
+}
+int athena_mp_resident_flush(const void *host_ptr)
+{
+    if (!host_ptr) {
+        int rc = 0;
+        for (auto &kv : g_res) rc |= resident_flush_one(kv.first, kv.second);
+        return rc;
+    }
+    auto it = g_res.find((const char *)host_ptr);
+    if (it == g_res.end()) return 0;   // never left the host, or already home
+    return resident_flush_one(it->first, it->second);
+}
+int athena_mp_resident_drop(const void *host_ptr)
+{
+    if (!host_ptr) {
+        for (auto &kv : g_res) resident_free(kv.second);
+        g_res.clear();
+        return 0;
+    }
+    auto it = g_res.find((const char *)host_ptr);
+    if (it != g_res.end()) {
+        resident_free(it->second);
+        g_res.erase(it);
+    }
+    return 0;
+}
+int athena_mp_resident_stats(int64_t *arrays, int64_t *h2d_bytes, int64_t *d2h_bytes, int64_t *reused_inputs,
+                             int64_t *lazy_outputs)
+{
+    if (arrays) *arrays = (int64_t)g_res.size();
+    if (h2d_bytes) *h2d_bytes = g_res_stats.h2d_bytes;
+    if (d2h_bytes) *d2h_bytes = g_res_stats.d2h_bytes;
+    if (reused_inputs) *reused_inputs = g_res_stats.reused_inputs;
+    if (lazy_outputs) *lazy_outputs = g_res_stats.lazy_outputs;
+    return 0;
+}
+
+int athena_mp_kipf_propagate_fwd_host(const athena_mp_graph *g, int32_t F, const float *xh, float *yh)
+{
+    AMP_REQUIRE(g && xh && yh && F > 0, "kipf_propagate_fwd_host: bad arguments");
+    return staged({{xh, nullptr, fb(g->n_cols, F)}, {nullptr, yh, fb(g->n_rows, F)}}, [&](std::vector<void *> &d) {
+        return athena_mp_kipf_propagate_fwd(g, F, (const float *)d[0], (float *)d[1]);
+    });
+}
+int athena_mp_kipf_propagate_bwd_host(const athena_mp_graph *g, int32_t F, const float *gh, float *dxh, int32_t exact)
+{
+    AMP_REQUIRE(g && gh && dxh && F > 0, "kipf_propagate_bwd_host: bad arguments");
+    return staged({{gh, nullptr, fb(g->n_rows, F)}, {nullptr, dxh, fb(g->n_cols, F)}}, [&](std::vector<void *> &d) {
+        return athena_mp_kipf_propagate_bwd(g, F, (const float *)d[0], (float *)d[1], exact);
+    });
+}
+int athena_mp_gemm_fwd_host(int64_t N, int32_t Fi, int32_t Fo, const float *Ph, const float *Wh, const float *bh, int32_t act,
+                            float *Zh)
+{
+    AMP_REQUIRE(N >= 0 && Fi > 0 && Fo > 0 && Ph && Wh && Zh, "gemm_fwd_host: bad arguments");
+    return staged({{Ph, nullptr, fb(N, Fi)}, {Wh, nullptr, fb(Fi, Fo)}, {bh, nullptr, bh ? fb(Fo, 1) : 0}, {nullptr, Zh, fb(N, Fo)}},
+                  [&](std::vector<void *> &d) {
+                      return athena_mp_gemm_fwd(N, Fi, Fo, (const float *)d[0], (const float *)d[1], bh ? (const float *)d[2] : nullptr,
+                                                act, (float *)d[3]);
+                  });
+}
 
 int athena_mp_gemm_dw_host(int64_t N, int32_t Fi, int32_t Fo, const float *P, const float *dZ, float *dW)
 {

@@ -47,6 +47,8 @@ module athena_mp_c
   public :: athena_mp_comm_unique_id, athena_mp_allreduce, athena_mp_allreduce_start, athena_mp_allreduce_finish
   public :: athena_mp_shard_create, athena_mp_shard_destroy, athena_mp_shard_dims, athena_mp_shard_graph
   public :: athena_mp_shard_export, athena_mp_halo_start, athena_mp_halo_finish, athena_mp_shard_info
+  public :: athena_mp_resident_mode, athena_mp_resident_acquire, athena_mp_resident_release, athena_mp_resident_flush
+  public :: athena_mp_resident_drop, athena_mp_resident_stats
 
   interface
      integer(c_int) function athena_mp_init(device) bind(C, name="athena_mp_init")
@@ -61,6 +63,39 @@ module athena_mp_c
      end function
      type(c_ptr) function athena_mp_last_error() bind(C, name="athena_mp_last_error")
        import :: c_ptr
+     end function
+
+     !! residency of host arrays (phase 2 for the *_host entry points): results stay in HBM until flushed at the edge of
+     !! the HIP island (athena_network_sub.f90:2752,2761,2856); host_ptr = c_loc(array_type%val)
+     integer(c_int) function athena_mp_resident_mode(on) bind(C, name="athena_mp_resident_mode")
+       import :: c_int, c_int32_t
+       integer(c_int32_t), value :: on
+     end function
+     integer(c_int) function athena_mp_resident_acquire(host_ptr, bytes, dirty_host, dev_ptr) &
+          bind(C, name="athena_mp_resident_acquire")
+       import :: c_int, c_int32_t, c_int64_t, c_ptr
+       type(c_ptr), value :: host_ptr
+       integer(c_int64_t), value :: bytes
+       integer(c_int32_t), value :: dirty_host
+       type(c_ptr), intent(out) :: dev_ptr
+     end function
+     integer(c_int) function athena_mp_resident_release(host_ptr, dirty_dev) bind(C, name="athena_mp_resident_release")
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: host_ptr
+       integer(c_int32_t), value :: dirty_dev
+     end function
+     integer(c_int) function athena_mp_resident_flush(host_ptr) bind(C, name="athena_mp_resident_flush")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: host_ptr              !! c_null_ptr: every array
+     end function
+     integer(c_int) function athena_mp_resident_drop(host_ptr) bind(C, name="athena_mp_resident_drop")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: host_ptr
+     end function
+     integer(c_int) function athena_mp_resident_stats(arrays, h2d_bytes, d2h_bytes, reused_inputs, lazy_outputs) &
+          bind(C, name="athena_mp_resident_stats")
+       import :: c_int, c_int64_t
+       integer(c_int64_t), intent(out) :: arrays, h2d_bytes, d2h_bytes, reused_inputs, lazy_outputs
      end function
 
      !! athena_msgpass_layer_sub.f90:144-174 (set_graph) -- build once, keep the handle

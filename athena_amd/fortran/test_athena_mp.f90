@@ -24,6 +24,7 @@ program test_athena_mp
   call adam_update_resident()
   call train_loop_resident()
   call csr_from_edges_on_device()
+  call resident_chain_on_host_arrays()
 
   rc = athena_mp_finalize()
   if(success)then
@@ -207,6 +208,123 @@ contains
     end if
     if(.not. success) write(0,*) "csr_from_edges_on_device failed"
   end subroutine csr_from_edges_on_device
+
+  subroutine resident_chain_on_host_arrays()
+    !! The drop-in path without a PCIe round trip per op: three Kipf time steps -- kipf_propagate then matmul, the loop of
+    !! update_message_kipf (athena_kipf_msgpass_layer.f90:943-952) -- through the *_host entry points on plain host arrays,
+    !! once staged op by op and once with the residency table on.  Same bits; in resident mode the input X goes up ONCE,
+    !! the three weight matrices go up, no intermediate crosses PCIe in either direction, and only the final Z comes
+    !! down, when it is flushed at the edge of the HIP island.  Then the safety rules: an array host code overwrote is
+    !! uploaded again, a slice of a resident array materialises it first.
+    integer, parameter :: n = 3000, f = 64, npairs = 9000
+    integer(c_int32_t), allocatable :: ia(:), ja(:,:), deg(:)
+    integer(c_int32_t) :: eu(npairs), ev(npairs)
+    real(real32), allocatable, target :: x(:,:), p1(:,:), z1(:,:), p2(:,:), z2(:,:), p3(:,:), z3(:,:), w(:,:), zref(:,:), y(:,:)
+    type(c_ptr) :: g
+    integer :: i, k, v, pass
+    integer(c_int64_t) :: arrays, h2d, d2h, reused, lazy, h2d0, d2h0, reused0, lazy0, nb, wb
+    real(real32) :: r
+
+    allocate(ia(n + 1), deg(n), x(f, n), p1(f, n), z1(f, n), p2(f, n), z2(f, n), p3(f, n), z3(f, n), w(f * f, 3), zref(f, n), y(f, n))
+    deg = 1
+    do i = 1, npairs                                  ! a fixed pseudo-random multigraph + self loops
+       eu(i) = 1 + mod(i * 7919, n)
+       ev(i) = 1 + mod(i * 104729 + 17, n)
+       if(eu(i) .eq. ev(i)) ev(i) = 1 + mod(ev(i), n)
+       deg(eu(i)) = deg(eu(i)) + 1
+       deg(ev(i)) = deg(ev(i)) + 1
+    end do
+    ia(1) = 1
+    do v = 1, n
+       ia(v + 1) = ia(v) + deg(v)
+    end do
+    allocate(ja(2, ia(n + 1) - 1))
+    do v = 1, n
+       ja(1, ia(v)) = v; ja(2, ia(v)) = 0
+       deg(v) = ia(v) + 1
+    end do
+    do i = 1, npairs
+       ja(1, deg(eu(i))) = ev(i); ja(2, deg(eu(i))) = 0; deg(eu(i)) = deg(eu(i)) + 1
+       ja(1, deg(ev(i))) = eu(i); ja(2, deg(ev(i))) = 0; deg(ev(i)) = deg(ev(i)) + 1
+    end do
+    do v = 1, n
+       do k = 1, f
+          x(k, v) = sin(0.37_real32 * real(k, real32) + 0.011_real32 * real(v, real32))
+       end do
+    end do
+    do k = 1, 3
+       do i = 1, f * f
+          r = real(mod(i * 37 + k * 11, 97), real32) / 97._real32 - 0.5_real32
+          w(i, k) = r * 0.25_real32
+       end do
+    end do
+    call check(athena_mp_graph_create(int(n, c_int32_t), int(n, c_int32_t), int(size(ja, 2), c_int64_t), ia, ja, 0_c_int32_t, &
+         c_null_ptr, c_null_ptr, g), "graph_create")
+    nb = 4_c_int64_t * f * n
+    wb = 4_c_int64_t * f * f
+
+    do pass = 1, 2
+       if(pass .eq. 2)then
+          call check(athena_mp_resident_mode(1_c_int32_t), "resident_mode(1)")
+          call check(athena_mp_resident_stats(arrays, h2d0, d2h0, reused0, lazy0), "resident_stats")
+       end if
+       call check(athena_mp_kipf_propagate_fwd_host(g, int(f, c_int32_t), x, p1), "kipf_fwd_host")
+       call check(athena_mp_gemm_fwd_host(int(n, c_int64_t), int(f, c_int32_t), int(f, c_int32_t), p1, w(:, 1), c_null_ptr, &
+            ATHENA_MP_ACT_NONE, z1), "gemm_fwd_host")
+       call check(athena_mp_kipf_propagate_fwd_host(g, int(f, c_int32_t), z1, p2), "kipf_fwd_host")
+       call check(athena_mp_gemm_fwd_host(int(n, c_int64_t), int(f, c_int32_t), int(f, c_int32_t), p2, w(:, 2), c_null_ptr, &
+            ATHENA_MP_ACT_NONE, z2), "gemm_fwd_host")
+       call check(athena_mp_kipf_propagate_fwd_host(g, int(f, c_int32_t), z2, p3), "kipf_fwd_host")
+       call check(athena_mp_gemm_fwd_host(int(n, c_int64_t), int(f, c_int32_t), int(f, c_int32_t), p3, w(:, 3), c_null_ptr, &
+            ATHENA_MP_ACT_NONE, z3), "gemm_fwd_host")
+       if(pass .eq. 1)then
+          zref = z3                                    ! op-by-op staging: every array crossed PCIe both ways
+          z3 = 0._real32
+       else
+          call check(athena_mp_resident_stats(arrays, h2d, d2h, reused, lazy), "resident_stats")
+          if(h2d - h2d0 .ne. nb + 3 * wb .or. d2h - d2h0 .ne. 0 .or. reused - reused0 .ne. 5 .or. lazy - lazy0 .ne. 6)then
+             write(0,*) "resident chain: traffic", h2d - h2d0, "up (expected", nb + 3 * wb, ")", d2h - d2h0, &
+                  "down (expected 0), inputs reused", reused - reused0, "(expected 5), lazy outputs", lazy - lazy0
+             success = .false.
+          end if
+          call check(athena_mp_resident_flush(c_loc(z3)), "resident_flush")   ! the edge of the HIP island
+          call check(athena_mp_resident_stats(arrays, h2d, d2h, reused, lazy), "resident_stats")
+          if(d2h - d2h0 .ne. nb)then
+             write(0,*) "resident chain: flush moved", d2h - d2h0, "bytes, expected", nb
+             success = .false.
+          end if
+          if(any(z3 .ne. zref))then
+             write(0,*) "resident chain: Z differs from the op-by-op staged result"
+             success = .false.
+          end if
+          ! host code overwrites an array whose valid copy was on the device: the next use must take the host values
+          z2 = 0.5_real32
+          call check(athena_mp_kipf_propagate_fwd_host(g, int(f, c_int32_t), z2, p3), "kipf_fwd_host")
+          call check(athena_mp_resident_flush(c_loc(p3)), "resident_flush")
+          call check(athena_mp_resident_mode(0_c_int32_t), "resident_mode(0)")
+          call check(athena_mp_kipf_propagate_fwd_host(g, int(f, c_int32_t), z2, y), "kipf_fwd_host")
+          if(any(p3 .ne. y))then
+             write(0,*) "resident chain: an array overwritten by host code was not uploaded again"
+             success = .false.
+          end if
+          ! a slice of a resident array as the next input: the array comes home first
+          call check(athena_mp_resident_mode(1_c_int32_t), "resident_mode(1)")
+          call check(athena_mp_kipf_propagate_fwd_host(g, int(f, c_int32_t), x, p1), "kipf_fwd_host")     ! p1 lives on the device
+          call check(athena_mp_gemm_fwd_host(int(n / 2, c_int64_t), int(f, c_int32_t), int(f, c_int32_t), p1(:, n / 4 + 1:), &
+               w(:, 1), c_null_ptr, ATHENA_MP_ACT_NONE, z1), "gemm_fwd_host")                           ! rows n/4+1 .. 3n/4 of it
+          call check(athena_mp_resident_mode(0_c_int32_t), "resident_mode(0)")                          ! everything home
+          call check(athena_mp_kipf_propagate_fwd_host(g, int(f, c_int32_t), x, p2), "kipf_fwd_host")
+          call check(athena_mp_gemm_fwd_host(int(n / 2, c_int64_t), int(f, c_int32_t), int(f, c_int32_t), p2(:, n / 4 + 1:), &
+               w(:, 1), c_null_ptr, ATHENA_MP_ACT_NONE, z2), "gemm_fwd_host")
+          if(any(p1 .ne. p2) .or. any(z1(:, 1:n / 2) .ne. z2(:, 1:n / 2)))then
+             write(0,*) "resident chain: a slice of a resident array was not materialised before use"
+             success = .false.
+          end if
+       end if
+    end do
+    call check(athena_mp_graph_destroy(g), "graph_destroy")
+    write(*,*) "resident chain on host arrays: X up once, Z down once -- ok"
+  end subroutine resident_chain_on_host_arrays
 
   subroutine check(rc, what)
     integer(c_int), intent(in) :: rc

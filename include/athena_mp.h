@@ -436,6 +436,27 @@ int athena_mp_shard_export(const athena_mp_shard *s, int32_t which, void *host_d
 int athena_mp_halo_start(athena_mp_shard *s, int32_t slot, int32_t F, float *x_ext_dev);
 int athena_mp_halo_finish(athena_mp_shard *s, int32_t slot);
 
+/* ---- residency of host arrays: the *_host entry points without the PCIe round trip per op ---------------------------- *
+ * athena's layers exchange array_type nodes whose %val lives on the host (athena_network_sub.f90:2752,2761: forward_generic2d
+ * hands layer%output on; :2856: the optimiser reads the gradients).  With athena_mp_resident_mode(1) the result of a *_host
+ * call stays in HBM, registered under its host array's (address, byte length), and a later *_host call that receives the
+ * same array as an input uses the device copy: a chain of HIP ops moves its first input up once and nothing else until
+ * athena_mp_resident_flush(host_ptr) materialises an array at the edge of the HIP island (NULL: all of them).
+ * Safety: an array whose only valid copy is on the device carries a 16-byte sentinel at both ends of its host storage; if
+ * host code wrote it (or the allocator handed the address to another array) the sentinel is gone and the host content is
+ * uploaded instead.  An argument that merely overlaps a registered array (a slice) materialises that array first.
+ * Arrays under 64 bytes are always staged.  athena_mp_resident_mode(0) flushes everything and releases the device copies.
+ * Explicit form for a shim that manages an array itself: _acquire (dirty_host = 1: upload now; 0: allocate / trust the
+ * device copy) -> device pointer for the *_dev entry points; _release(dirty_dev = 1) marks the device copy as the valid
+ * one; _drop forgets an array WITHOUT copying back (call it when the host array is deallocated). */
+int athena_mp_resident_mode(int32_t on);
+int athena_mp_resident_acquire(const void *host_ptr, uint64_t bytes, int32_t dirty_host, void **dev_ptr);
+int athena_mp_resident_release(const void *host_ptr, int32_t dirty_dev);
+int athena_mp_resident_flush(const void *host_ptr);
+int athena_mp_resident_drop(const void *host_ptr);
+int athena_mp_resident_stats(int64_t *arrays, int64_t *h2d_bytes, int64_t *d2h_bytes, int64_t *reused_inputs,
+                             int64_t *lazy_outputs);
+
 #ifdef __cplusplus
 }
 #endif

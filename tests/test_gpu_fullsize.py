@@ -7,6 +7,8 @@ import numpy as np
 import pytest
 import torch
 
+from helpers import assert_close
+
 pytestmark = pytest.mark.gpu
 
 
@@ -173,7 +175,9 @@ def test_c2_fused_layer_kernels_match_oracle_at_full_size(dev, oracle, c2, F):
 
 
 def test_c2_reverse_pass_with_folded_dw_matches_oracle_at_full_size(dev, oracle, c2):
-    """the reverse launch bench.py times (agg_gemm_dw_kernel: dX and dW from one gather of dZ) on the full C2 graph:
+    """the folded reverse launch (agg_gemm_dw_kernel behind athena_mp_kipf_layer_bwd: dX and dW from one gather of dZ; bench.py
+    times the three-launch step kipf_layer_fwd + matmul_dw + kipf_layer_bwd_x, held to the oracle in the test above) on the
+    full C2 graph:
     dX on 5 000 sampled columns against the oracle; dW against the float64 contraction of the oracle-checked P (the fp32
     oracle's own 10^6-term sequential sum is ~3e-5 from exact arithmetic, see bench.py's parity block) and within 1e-5 of
     the stock dW kernel fed the stored P"""
@@ -244,6 +248,64 @@ def test_c3_duvenaud_step_properties(dev, oracle, c3):
     assert abs(l2 - r2) <= 1e-6 * (a.double().abs() * g2.double().abs()).sum().item()
 
 
+def test_c3_duvenaud_reverse_ops_match_oracle_at_full_size(dev, oracle, c3):
+    """the reverse kernels of configs[2] at its real size (130 k graphs, F_v = 64, F_e = 8) against the ORACLE, not only
+    through adjoint identities: the batch is block-diagonal, so the first 3 000 graphs are an exact sub-problem for every
+    per-vertex / per-entry op (get_partial_duvenaud_update_val, athena_diffstruc_extd_sub_duvenaud.f90:284-324, and the
+    two propagate partials, :115-171); the weight gradient (:326-368) sums over ALL vertices, so it is held on a
+    3 000-graph batch of its own."""
+    from athena_amd import DeviceGraph, ops
+    from oracle import oracle64 as o64
+
+    rng = np.random.default_rng(7)
+    N, E, g = c3["N"], c3["E"], c3["g"]
+    Fv, Fe, mn, mx = 64, 8, 1, 10
+    Fc = Fv + Fe
+    W_h = (rng.standard_normal(Fv * Fc * 10) * 0.1).astype(np.float32)
+    W = torch.from_numpy(W_h).to(dev)
+    gup = torch.from_numpy(rng.uniform(-1, 1, (N, Fv)).astype(np.float32)).to(dev)
+    g2 = torch.from_numpy(rng.uniform(-1, 1, (N, Fc)).astype(np.float32)).to(dev)
+    nv = int(c3["voff"][3000]); ne = int(c3["ja"][1, : c3["ia"][nv] - 1].max())
+    ia_s, ja_s = c3["ia"][: nv + 1], np.asfortranarray(c3["ja"][:, : c3["ia"][nv] - 1])
+    # update reverse w.r.t. a: per vertex
+    da = ops.duvenaud_update_bwd_a(g, gup, W, mn, mx, Fc)
+    g_s = gup[:nv].cpu().numpy()
+    da_ref = oracle.duvenaud_update_bwd_a(g_s, W_h, ia_s, mn, mx, Fc)
+    assert np.abs(da[:nv].cpu().numpy() - da_ref).max() <= 1e-5 * np.abs(da_ref).max()
+    # propagate reverse: scatters inside each graph -> rows / edge columns of the first 3 000 graphs
+    dx = ops.duvenaud_propagate_bwd_x(g, g2, Fv)
+    de = ops.duvenaud_propagate_bwd_e(g, g2, Fv)
+    g2_s = g2[:nv].cpu().numpy()
+    assert np.array_equal(dx[:nv].cpu().numpy(), oracle.duvenaud_propagate_bwd_x(g2_s, Fv, ia_s, ja_s))
+    eids = np.unique(ja_s[1][ja_s[1] > 0]).astype(np.int64) - 1     # the edge columns of these graphs (tree bonds and ring closures
+    de_ref = oracle.duvenaud_propagate_bwd_e(g2_s, Fv, ne, ia_s, ja_s)    # are numbered in two passes over the batch: not one range)
+    assert np.array_equal(de[torch.from_numpy(eids).to(dev)].cpu().numpy(), de_ref[eids])
+    # weight gradient: a 3 000-graph batch of its own, through the same kernels (all ten degree buckets occur)
+    gs = DeviceGraph(ia_s, ja_s, n_edge_cols=ne)
+    a_s = torch.from_numpy(rng.random((nv, Fc), np.float32)).to(dev)
+    dW = ops.duvenaud_update_bwd_w(gs, gup[:nv].contiguous(), a_s, mn, mx)
+    dW_ref = oracle.duvenaud_update_bwd_w(g_s, a_s.cpu().numpy(), ia_s, mn, mx)
+    assert_close(dW.cpu().numpy(), dW_ref, 1e-5, "configs[2] dW", f64=lambda: o64.duvenaud_update_bwd_w(g_s, a_s.cpu().numpy(), ia_s, mn, mx))
+    # ... and the full batch's weight gradient is the sum of per-slice gradients (linearity over vertices), slice by slice
+    # through the same entry point on 4 disjoint ranges of graphs
+    a_full = torch.from_numpy(rng.random((N, Fc), np.float32)).to(dev)
+    dW_full = ops.duvenaud_update_bwd_w(g, gup, a_full, mn, mx)
+    acc = torch.zeros_like(dW_full, dtype=torch.float64)
+    cuts = [0, 30000, 65000, 100000, 130000]
+    for k in range(4):
+        v0, v1 = int(c3["voff"][cuts[k]]), int(c3["voff"][cuts[k + 1]])
+        w0, w1 = int(c3["ia"][v0]) - 1, int(c3["ia"][v1]) - 1
+        ia_k = (c3["ia"][v0:v1 + 1] - w0).astype(np.int32)
+        ja_k = np.array(c3["ja"][:, w0:w1], order="F")
+        ja_k[0] -= v0
+        e_used = ja_k[1][ja_k[1] > 0]
+        e0 = int(e_used.min()) - 1
+        ja_k[1] = np.where(ja_k[1] > 0, ja_k[1] - e0, 0)
+        gk = DeviceGraph(ia_k, ja_k, n_edge_cols=int(ja_k[1].max()))
+        acc += ops.duvenaud_update_bwd_w(gk, gup[v0:v1].contiguous(), a_full[v0:v1].contiguous(), mn, mx).double()
+    assert (dW_full.double() - acc).abs().max().item() <= 1e-5 * acc.abs().max().item()
+
+
 # ---- BASELINE configs[3]: GNO on a 2M-point radius graph, ~30M CSR entries, F = H = 64 ------------------
 def test_c4_gno_properties_full_size(dev, oracle):
     from athena_amd import DeviceGraph, ops, synth
@@ -279,6 +341,23 @@ def test_c4_gno_properties_full_size(dev, oracle):
     # linear in x; adjoint <m, g> = <x, dx>; linear in Vaug: <m, g> = <Vaug, dVaug>
     assert torch.allclose(ops.gno_aggregate(g, theta, co, 2.0 * x, d, H, Fo), 2.0 * m, rtol=1e-5, atol=1e-5 * m.abs().max().item())
     dx = ops.gno_aggregate_bwd_x(g, theta, co, gup, d, H, Fi)
+    # get_partial_gno_aggregate (agg -> features, athena_diffstruc_extd_sub_nop.f90:419-458) on 300 sampled COLUMNS against
+    # the materialising oracle: the entries of the whole CSR that point at them, as a compact sub-problem (sources ascending:
+    # the reference's accumulation order), kappa only for the edge columns those entries carry
+    csel = np.sort(rng.choice(N, 300, replace=False))
+    src, cia, cja = _column_sub_problem(ia, ja, csel)
+    lut = np.full(N, -1, np.int64); lut[csel] = np.arange(csel.size)
+    hit = np.nonzero(lut[ja[0].astype(np.int64) - 1] >= 0)[0]
+    ecols_c, einv = np.unique(ja[1, hit], return_inverse=True)
+    cja[1] = einv + 1
+    kap_c = oracle.gno_kernel_eval(coords[ecols_c - 1], theta.cpu().numpy(), H, Fo * Fi)
+    g_src = gup[torch.from_numpy(src).to(dev)].cpu().numpy()
+    nsq = max(src.size, csel.size)                                   # the square oracle: pad rows / columns
+    cia_sq = np.concatenate([cia, np.full(nsq - src.size, cia[-1], np.int32)])
+    g_sq = np.zeros((nsq, Fo), np.float32); g_sq[: src.size] = g_src
+    dx_ref = oracle.gno_aggregate_bwd_x(g_sq, kap_c, cia_sq, cja, Fi)[: csel.size]
+    got_dx = dx[torch.from_numpy(csel).to(dev)].cpu().numpy()
+    assert np.abs(got_dx - dx_ref).max() <= 1e-5 * np.abs(dx_ref).max()
     lhs = (m.double() * gup.double()).sum().item()
     scale = (m.double().abs() * gup.double().abs()).sum().item()
     assert abs(lhs - (x.double() * dx.double()).sum().item()) <= 1e-5 * scale

@@ -167,9 +167,11 @@ def test_kipf_reverse_both_forms_from_one_gather(dev, oracle, F):
         p1, c1 = ops.kipf_propagate_bwd(g, T(up, dev)), ops.kipf_propagate_bwd(g, T(up, dev), exact=True)
         assert torch.equal(plain, p1) and torch.equal(coef, c1)
         po, co = oracle.kipf_propagate_bwd(up, ia, ja), oracle.kipf_propagate_bwd(up, ia, ja, exact=True)
-        if hubs:      # segmented hub sums: a 1200-term fp32 sum in another order than the sequential oracle's --
-            # 3e-5 of the largest value (the hub itself) is that sum's own rounding noise
-            assert_close(H(plain), po, 3e-5, "plain"); assert_close(H(coef), co, 3e-5, "coef")
+        if hubs:      # segmented hub sums: a 1200-term fp32 sum in another order than the sequential oracle's.  1e-5, anchored
+            # on the float64 evaluation of the same loops where the fp32 oracle's own rounding is larger than that
+            from oracle import oracle64 as o64
+            assert_close(H(plain), po, 1e-5, "plain", f64=lambda: o64.kipf_propagate_bwd(up, ia, ja))
+            assert_close(H(coef), co, 1e-5, "coef", f64=lambda: o64.kipf_propagate_bwd(up, ia, ja, exact=True))
         else:
             assert np.array_equal(H(plain), po) and np.array_equal(H(coef), co)
 
