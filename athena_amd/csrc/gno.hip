@@ -18,6 +18,7 @@
 #include <type_traits>
 
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 
@@ -938,22 +939,22 @@ __global__ __launch_bounds__(kPcThreads) void gno_stg_kernel(const int32_t *__re
                                                        int d, const float *__restrict__ grad, int n_rows,
                                                        const int32_t *__restrict__ perm, float *__restrict__ slab,
                                                        float *__restrict__ slabB, uint32_t y_bytes, uint32_t c_bytes,
-                                                       uint32_t id_bytes, uint32_t g_bytes, int nsub)
+                                                       uint32_t id_bytes, uint32_t g_bytes, int nsub, int grouped)
 {
     extern __shared__ __attribute__((aligned(16))) float Sh[];
     float *Sbuf = Sh;                                   // [2][32][520]
     float *Gbuf = Sh + 2 * kPV * kPPitch;               // [2][32][72]   gradient rows of the tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, g = lane >> 4;
-    // The eight workgroups that visit a tile sit on eight different XCDs (workgroup b runs on XCD b % 8), so every 64-byte
-    // quarter row costs its own 128-byte line from the fabric: 57 GB per launch at configs[3] (2 x FETCH_SIZE; L2 hit rate 2 %)
-    // against 8.7 GB algorithmic -- and the kernel is not bound by it.  -DGNO_STG_GROUPED puts the eight on ONE XCD (nsub
-    // apart): 10.9 GB, L2 hit rate 81 %, and dtheta 27.7 ms instead of 27.0 (profiles/r02_c4_gno_pmc_traffic.txt).
-#ifdef GNO_STG_GROUPED
-    const int pc = blockIdx.x / nsub, sub = blockIdx.x % nsub, c = pc >> 1, kh = pc & 1;
-#else
-    const int pc = blockIdx.x & 7, sub = blockIdx.x >> 3, c = pc >> 1, kh = pc & 1;
-#endif
+    // Where the eight workgroups (pieces) that visit the same tiles sit.  Workgroup b runs on XCD b % 8.  Spread order (round 2:
+    // piece = b % 8): the eight are on eight different XCDs, every 64-byte quarter row costs each of them its own 128-byte line
+    // from the fabric -- 57 GB per launch at configs[3] (2 x FETCH_SIZE; L2 hit rate 2 %) against 8.7 GB algorithmic.  Grouped
+    // order (round 3, the product path whenever the tile classes divide by 8): piece = b / nsub, so the eight workgroups of a
+    // tile class share ONE XCD's L2 -- 10.9 GB, L2 hit rate 81 % (profiles/r02_c4_gno_pmc_traffic.txt, r03_c4_*).  The
+    // kernel is bound by its matrix and vector work, not by either figure; the grouped order leaves the fabric to whatever
+    // runs beside it.  ATHENA_MP_GNO_STG_ORDER=spread restores round 2's mapping for A/B runs.
+    const int pc = grouped ? blockIdx.x / nsub : blockIdx.x & 7, sub = grouped ? blockIdx.x % nsub : blockIdx.x >> 3;
+    const int c = pc >> 1, kh = pc & 1;
     const int n_tiles = (n_rows + kPV - 1) / kPV;
     const int nt = sub < n_tiles ? (n_tiles - sub + nsub - 1) / nsub : 0;   // tiles of this workgroup: sub, sub + nsub, ...
 
@@ -1181,9 +1182,14 @@ int launch_gno_stg(const athena_mp_graph *g, const float *x, const float *coords
         return 1;
     // 8 pieces x nsub tile classes: 32 classes fill the chip's 256 CUs; a small graph takes one class per tile
     const int nsub = std::max(1, std::min(kStgGrid / 8, (g->n_rows + kPV - 1) / kPV));
+    static const bool want_spread = [] {
+        const char *e = getenv("ATHENA_MP_GNO_STG_ORDER");
+        return e && strcmp(e, "spread") == 0;
+    }();
+    const int grouped = (!want_spread && nsub % 8 == 0) ? 1 : 0;   // the eight pieces of a tile class on one XCD (one L2)
     hipLaunchKernelGGL(gno_stg_kernel, dim3(8 * nsub), dim3(kPcThreads), lds, amp::stream(), g->rowptr, g->col, g->eid, x, coords,
                        theta, d, grad, g->n_rows, (const int32_t *)g->len_perm_fwd, (float *)slab, (float *)slabB,
-                       (uint32_t)y_bytes, (uint32_t)c_bytes, (uint32_t)id_bytes, (uint32_t)g_bytes, nsub);
+                       (uint32_t)y_bytes, (uint32_t)c_bytes, (uint32_t)id_bytes, (uint32_t)g_bytes, nsub, grouped);
     AMP_LAUNCH_CHECK();
     hipLaunchKernelGGL(gno_stg_reduce_kernel, dim3((65 * 64 * 64 + 255) / 256), dim3(256), 0, amp::stream(), (const float *)slab,
                        (const float *)slabB, dV, nsub);
