@@ -169,4 +169,7 @@ int duvenaud_buckets(const athena_mp_graph *g, int min_deg, int max_deg);
 int duv_mfma_fwd(const athena_mp_graph *g, int Fi, int Fo, const float *a, const float *w, int act, float *c);
 int duv_mfma_bwd_a(const athena_mp_graph *g, int Fi, int Fo, const float *grad, const float *w, float *da);
 int duv_mfma_bwd_w(const athena_mp_graph *g, int Fi, int Fo, const float *grad, const float *a, float *dw);
+int duv_mfma_fwd_readout(const athena_mp_graph *g, int Fi, int Fo, const float *a, const float *w, int act, float *z,
+                         const float *R, int O, float *p);
+int duv_mfma_bwd(const athena_mp_graph *g, int Fi, int Fo, const float *grad, const float *a, const float *w, float *da, float *dw);
 } // namespace amp

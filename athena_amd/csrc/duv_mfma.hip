@@ -433,15 +433,24 @@ struct WideTail {
 };
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-template <int KJ, int OT>
+// RO: the Duvenaud readout of the same time step rides in the epilogue (athena_duvenaud_msgpass_layer.f90:838-855):
+//     p[v,:] = softmax_over_outputs(R z[v,:])  with z = the activated rows this kernel has just produced.
+// The activated tile sits in the accumulators in exactly the B-operand layout of the logits product (lane (v, q) holds
+// z[v, 16 ot + 4 q + c], i.e. k = 16 ot + 4 q + c), so logits^T[o, v] costs OT x 4 more MFMAs per tile with R's fragments read
+// from LDS, the softmax is two cross-lane steps (readout.hip), and z is not read back from HBM by a readout launch
+// (600 MB at configs[2]).  p rows are 4 O bytes: written with bounds-checked buffer stores, lanes beyond O pointed past it.
+template <int KJ, int OT, bool RO>
 __global__ __launch_bounds__(256, 2) void duv_rows_wide_kernel(BucketSplit sp, const int32_t *__restrict__ trows,
                                                             const int32_t *__restrict__ trows_t,
                                                             const float *__restrict__ X, int K,
                                                             const float *__restrict__ W, int64_t wb, int so, int sk,
-                                                            float *__restrict__ Y, int NO, int act)
+                                                            float *__restrict__ Y, int NO, int act,
+                                                            const float *__restrict__ R, int O, float *__restrict__ P,
+                                                            uint32_t p_bytes)
 {
     constexpr int PI = 16 * KJ + 4, PO = 16 * OT + 4, TI = KJ - 4, TO = OT - 4;
-    __shared__ __attribute__((aligned(16))) float lds[4 * 16 * (PI + PO)];
+    __shared__ __attribute__((aligned(16))) float lds[4 * 16 * (PI + PO) + (RO ? 64 * 4 * OT : 4)];
+    float *rl = lds + 4 * 16 * (PI + PO);           // R fragments: [ot][lane][c] = R(o = lane & 15, k = 16 ot + 4 (lane >> 4) + c)
     const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4, wave = threadIdx.x >> 6;
     float *tin = lds + wave * 16 * (PI + PO), *tout = tin + 16 * PI;
     const int gw = blockIdx.x * 4 + wave;
@@ -474,6 +483,17 @@ __global__ __launch_bounds__(256, 2) void duv_rows_wide_kernel(BucketSplit sp, c
     ti.init(lane, K);
     to.init(lane, NO);
     for (int e = lane; e < 16 * PI; e += 64) tin[e] = 0.0f;   // the K tail columns stay zero for the whole launch
+    __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc((void *)P, 0, RO ? (int)p_bytes : 0, 0x00020000);
+    if constexpr (RO) {   // params(T + t)%val(:,1) = R(O, F_v) column-major: flat o + O k.  Every wave fills the same values.
+        for (int e = lane; e < 64 * OT; e += 64) {
+            const int ot = e >> 6;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int k = 16 * ot + 4 * q + c;
+                rl[(ot * 64 + lane) * 4 + c] = (n < O && k < NO) ? R[(int64_t)k * O + n] : 0.0f;
+            }
+        }
+    }
 
     struct Stage {
         v4f f[4], t[TI > 0 ? TI : 1];
@@ -572,6 +592,41 @@ __global__ __launch_bounds__(256, 2) void duv_rows_wide_kernel(BucketSplit sp, c
 #pragma unroll
             for (int ot = 0; ot < OT; ++ot) accs[ot] = div4(accs[ot], d, inv);
             break;
+        }
+        if constexpr (RO) {
+            v4f lg = {0.0f, 0.0f, 0.0f, 0.0f};           // lane (v, q): logits[v, 4 q + r]
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot) {
+                const v4f rf = *reinterpret_cast<const v4f *>(rl + (ot * 64 + lane) * 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) lg = __builtin_amdgcn_mfma_f32_16x16x4f32(rf[c], accs[ot][c], lg, 0, 0, 0);
+            }
+            // softmax over the O outputs of a vertex: hardware exp2 / rcp (1 ulp each; the route is held to 1e-5), two
+            // cross-lane steps over the four lanes of a vertex
+            const int nv = O - 4 * q;                    // valid outputs in this lane's four: <= 0 none, >= 4 all
+            float m = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, r < nv ? lg[r] : -INFINITY);
+            m = fmaxf(m, __shfl_xor(m, 16));
+            m = fmaxf(m, __shfl_xor(m, 32));
+            float e[4], sum = 0.0f;                      // scalars: __builtin_bit_cast of a vector ELEMENT reads element 0
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                e[r] = r < nv ? __builtin_amdgcn_exp2f((lg[r] - m) * 1.4426950408889634f) : 0.0f;
+                sum = sum + e[r];
+            }
+            sum = sum + __shfl_xor(sum, 16);
+            sum = sum + __shfl_xor(sum, 32);
+            const float rs = __builtin_amdgcn_rcpf(sum);
+            const int p0 = __builtin_bit_cast(int, e[0] * rs), p1 = __builtin_bit_cast(int, e[1] * rs),
+                      p2 = __builtin_bit_cast(int, e[2] * rs), p3 = __builtin_bit_cast(int, e[3] * rs);
+            // p[v, 4 q .. 4 q + nv): as few, as wide stores as the count allows -- 16 bytes where all four outputs exist,
+            // then 8, then 4; a lane with nothing to write in a pass points past the buffer (the store is dropped)
+            const uint32_t base = ((uint32_t)trows[tb + n] * (uint32_t)O + 4u * (uint32_t)q) * 4u, dead = 0xFFFFFFF0u;
+            typedef int v2i_ __attribute__((ext_vector_type(2)));
+            __builtin_amdgcn_raw_buffer_store_b128(v4i{p0, p1, p2, p3}, prs, (int)(nv >= 4 ? base : dead), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(v2i_{p0, p1}, prs, (int)((nv == 2 || nv == 3) ? base : dead), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(nv == 3 ? p2 : p0, prs, (int)(nv == 3 ? base + 8u : nv == 1 ? base : dead), 0, 0);
         }
         // results: operand layout -> LDS tile -> coalesced rows
 #pragma unroll
@@ -732,6 +787,195 @@ __global__ __launch_bounds__(256, 2) void duv_dw_wide_kernel(BucketSplit sp, con
     }
 }
 
+// ---- both reverse products of the update from ONE pass over the gradient rows --------------------------------------------
+//   da[v,i] = (sum_o g[v,o] W_d(o,i)) / d          get_partial_duvenaud_update_val        (..._sub_duvenaud.f90:284-324)
+//   dW_d(o,i) += g[v,o] a[v,i] / d                 get_partial_duvenaud_update_weight_val (:326-368)
+// The two launches above each read g (600 MB at configs[2]); the pair is bound by the bytes it moves, so one launch that
+// reads g and a once and writes da does 1.95 GB instead of 2.55 GB.  A workgroup serves one bucket: W_d sits in LDS (the A
+// operand of the da product is one 16-byte LDS read per four MFMAs -- 80 weight fragments in registers beside 80 weight-
+// gradient accumulators would leave one wave per SIMD), the rows of a tile arrive in the coalesced numbering and are turned
+// in the wave's LDS tiles as in duv_dw_wide_kernel, and da leaves through the tile that held a.  Padding slots repeat the
+// tile's first vertex: their a row is zeroed (no weight gradient), their g row is not, so their da row is that vertex's
+// own -- a benign duplicate store.
+template <int IT, int OT>
+__global__ __launch_bounds__(256, 2) void duv_bwd_wide_kernel(BucketSplit sp, const int32_t *__restrict__ trows,
+                                                              const int32_t *__restrict__ trows_t,
+                                                              const float *__restrict__ A, int Fi,
+                                                              const float *__restrict__ G, int Fo,
+                                                              const float *__restrict__ W, float *__restrict__ DA,
+                                                              float *__restrict__ slabs)
+{
+    constexpr int AP = 16 * IT + 4, GP = 16 * OT + 4, FOP = 16 * OT, WP = 16 * OT + 4, TA = IT - 4, TG = OT - 4;
+    constexpr int kW = 16 * IT * WP, kTurn = 4 * 16 * (AP + GP), kRed = 16 * IT * FOP;
+    __shared__ __attribute__((aligned(16))) float buf[kW + (kTurn > kRed ? kTurn : kRed)];
+    float *wl = buf, *red = buf + kW;
+    const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4, wave = threadIdx.x >> 6;
+    float *al = red + wave * 16 * (AP + GP), *gl = al + 16 * AP;
+    int b = 0;
+    while ((int)blockIdx.x >= sp.unit_off[b + 1]) ++b;
+    const int nwg = sp.unit_off[b + 1] - sp.unit_off[b];
+    const int stride = 4 * nwg;
+    const int t0 = sp.tile_off[b] + 4 * ((int)blockIdx.x - sp.unit_off[b]) + wave, t1 = sp.tile_off[b + 1];
+    const int cnt = t0 < t1 ? (t1 - t0 + stride - 1) / stride : 0;
+    const float d = (float)(b + 1), inv = 1.0f / d;
+    // W_d(o,i) flat o + Fo i == [i][o] rows of Fo floats -> LDS rows of pitch WP, zero beyond Fi / Fo
+    {
+        const float *wd = W + (int64_t)b * Fi * Fo;
+        for (int e = threadIdx.x; e < 16 * IT * WP; e += 256) {
+            const int i = e / WP, o = e - i * WP;
+            wl[e] = (i < Fi && o < Fo) ? wd[(int64_t)i * Fo + o] : 0.0f;
+        }
+    }
+    WideTail<IT> ta;
+    WideTail<OT> tg;
+    ta.init(lane, Fi);
+    tg.init(lane, Fo);
+    for (int e = lane; e < 16 * (AP + GP); e += 64) al[e] = 0.0f;    // tail columns stay zero
+    __syncthreads();
+
+    v4f acc[IT][OT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i)
+#pragma unroll
+        for (int o = 0; o < OT; ++o) acc[i][o] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+
+    struct Ids {
+        v4i f;                                          // rows 4 i + q of the tile, padding slots negative
+        int a[TA > 0 ? TA : 1], g[TG > 0 ? TG : 1];
+    };
+    auto issue_ids = [&](Ids &id, int i) {
+        const int64_t tb = (int64_t)(t0 + (i < cnt ? i : cnt - 1) * stride) * 16;
+        id.f = *reinterpret_cast<const v4i *>(trows_t + tb + 4 * q);
+#pragma unroll
+        for (int u = 0; u < TA; ++u) id.a[u] = trows[tb + ta.row[u]];
+#pragma unroll
+        for (int u = 0; u < TG; ++u) id.g[u] = trows[tb + tg.row[u]];
+    };
+    v4f an[4 + (TA > 0 ? TA : 0) + 1], gn[4 + (TG > 0 ? TG : 0) + 1];
+    auto issue_rows = [&](const Ids &id) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = id.f[i] ^ (id.f[i] >> 31);
+            an[i] = *reinterpret_cast<const v4f *>(A + (int64_t)r * Fi + 4 * n);
+            gn[i] = *reinterpret_cast<const v4f *>(G + (int64_t)r * Fo + 4 * n);
+        }
+#pragma unroll
+        for (int u = 0; u < TA; ++u) {
+            const int r = id.a[u] ^ (id.a[u] >> 31);
+            an[4 + u] = *reinterpret_cast<const v4f *>(A + (int64_t)r * Fi + ta.col[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < TG; ++u) {
+            const int r = id.g[u] ^ (id.g[u] >> 31);
+            gn[4 + u] = *reinterpret_cast<const v4f *>(G + (int64_t)r * Fo + tg.col[u]);
+        }
+    };
+    if (cnt > 0) {
+        Ids I0, I1;
+        issue_ids(I0, 0);
+        issue_ids(I1, 1);
+        issue_rows(I0);
+        auto body = [&](Ids &cur, Ids &nxt, int i) {
+            const v4f zero = {0.0f, 0.0f, 0.0f, 0.0f};
+            // store addresses of this tile's da rows (the rows of a it was loaded from), before the id registers move on
+            int srow[4 + (TA > 0 ? TA : 1)];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) srow[k] = cur.f[k] ^ (cur.f[k] >> 31);
+#pragma unroll
+            for (int u = 0; u < TA; ++u) srow[4 + u] = cur.a[u] ^ (cur.a[u] >> 31);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                *reinterpret_cast<v4f *>(al + (4 * k + q) * AP + 4 * n) = cur.f[k] >= 0 ? an[k] : zero;
+                *reinterpret_cast<v4f *>(gl + (4 * k + q) * GP + 4 * n) = gn[k];
+            }
+#pragma unroll
+            for (int u = 0; u < TA; ++u) *reinterpret_cast<v4f *>(al + ta.row[u] * AP + ta.col[u]) = cur.a[u] >= 0 ? an[4 + u] : zero;
+#pragma unroll
+            for (int u = 0; u < TG; ++u) *reinterpret_cast<v4f *>(gl + tg.row[u] * GP + tg.col[u]) = gn[4 + u];
+            issue_ids(cur, i + 2);             // ids of tile i+2 ...
+            issue_rows(nxt);                   // ... and the rows of tile i+1
+            asm volatile("" ::: "memory");
+            // weight gradient: contraction over the tile's vertices (both operands read turned)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float aa[IT], bb[OT];
+#pragma unroll
+                for (int ii = 0; ii < IT; ++ii) aa[ii] = al[(4 * q + r) * AP + 16 * ii + n];
+#pragma unroll
+                for (int o = 0; o < OT; ++o) bb[o] = gl[(4 * q + r) * GP + 16 * o + n];
+#pragma unroll
+                for (int ii = 0; ii < IT; ++ii)
+#pragma unroll
+                    for (int o = 0; o < OT; ++o)
+                        acc[ii][o] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[ii], bb[o], acc[ii][o], 0, 0, 0);
+            }
+            // da^T[i, v] = sum_o W_d(o, i) g[v, o]: the vertex on the column axis, W fragments from LDS
+            v4f xg[OT], da[IT];
+#pragma unroll
+            for (int j = 0; j < OT; ++j) xg[j] = *reinterpret_cast<const v4f *>(gl + n * GP + 16 * j + 4 * q);
+#pragma unroll
+            for (int it = 0; it < IT; ++it) da[it] = zero;
+#pragma unroll
+            for (int j = 0; j < OT; ++j) {
+                v4f wf[IT];
+#pragma unroll
+                for (int it = 0; it < IT; ++it) wf[it] = *reinterpret_cast<const v4f *>(wl + (16 * it + n) * WP + 16 * j + 4 * q);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int it = 0; it < IT; ++it) da[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[it][c], xg[j][c], da[it], 0, 0, 0);
+            }
+            asm volatile("" ::: "memory");     // the turned reads of a are done: its tile now carries da out
+#pragma unroll
+            for (int it = 0; it < IT; ++it) *reinterpret_cast<v4f *>(al + n * AP + 16 * it + 4 * q) = div4(da[it], d, inv);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const v4f y = *reinterpret_cast<const v4f *>(al + (4 * k + q) * AP + 4 * n);
+                *reinterpret_cast<v4f *>(DA + (int64_t)srow[k] * Fi + 4 * n) = y;
+            }
+#pragma unroll
+            for (int u = 0; u < TA; ++u) {
+                const v4f y = *reinterpret_cast<const v4f *>(al + ta.row[u] * AP + ta.col[u]);
+                *reinterpret_cast<v4f *>(DA + (int64_t)srow[4 + u] * Fi + ta.col[u]) = y;
+            }
+            asm volatile("" ::: "memory");
+            // the tail columns of the a tile must read zero again for the next tile's weight gradient
+            if (Fi < 16 * IT) {
+#pragma unroll
+                for (int it = IT - 1; it < IT; ++it)
+                    if (16 * it + 4 * q >= Fi) *reinterpret_cast<v4f *>(al + n * AP + 16 * it + 4 * q) = zero;
+            }
+        };
+        int i = 0;
+        for (; i + 2 <= cnt; i += 2) {
+            body(I0, I1, i);
+            body(I1, I0, i + 1);
+        }
+        if (i < cnt) body(I0, I1, i);
+    }
+    __syncthreads();
+    for (int p = 0; p < 4; ++p) {
+        if (wave == p) {
+#pragma unroll
+            for (int i = 0; i < IT; ++i)
+#pragma unroll
+                for (int o = 0; o < OT; ++o)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float *dst = red + (16 * i + 4 * q + r) * FOP + 16 * o + n;
+                        *dst = (p == 0 ? 0.0f : *dst) + acc[i][o][r];
+                    }
+        }
+        __syncthreads();
+    }
+    float *slab = slabs + (size_t)blockIdx.x * Fi * Fo;
+    for (int t = threadIdx.x; t < Fi * Fo; t += 256) {
+        const int i = t / Fo, o = t - i * Fo;
+        slab[t] = red[i * FOP + o] / d;
+    }
+}
+
 // proportional split of `units` waves / workgroups over the buckets (every non-empty bucket gets >= 1)
 BucketSplit make_split(const athena_mp_graph *g, int units, int tiles_per_unit_step)
 {
@@ -757,9 +1001,16 @@ BucketSplit make_split(const athena_mp_graph *g, int units, int tiles_per_unit_s
 inline int ceil16(int x) { return (x + 15) / 16; }
 inline bool frag_shape(int kj, int ot) { return kj >= 1 && ot >= 1 && kj <= 6 && ot <= 6 && kj * ot <= 24; }
 
+struct ReadoutArgs {   // the readout of the same time step in the epilogue (duv_rows_wide_kernel<.., true>)
+    const float *R;
+    int O;
+    float *P;
+};
+
 int launch_rows(const athena_mp_graph *g, const float *X, int K, const float *W, int64_t wb, int so, int sk, float *Y,
-                int NO, int act)
+                int NO, int act, const ReadoutArgs *ro = nullptr)
 {
+    if (ro && (ro->O < 1 || ro->O > 16 || (size_t)g->n_rows * ro->O * sizeof(float) >= ((size_t)1 << 32) - 4096)) return -1;
     const int kj = ceil16(K), ot = ceil16(NO);
     if ((K & 3) || (NO & 3) || !frag_shape(kj, ot)) return -1;
     const int nt = g->n_btiles;
@@ -770,15 +1021,22 @@ int launch_rows(const athena_mp_graph *g, const float *X, int K, const float *W,
     const dim3 grid((sp.unit_off[sp.n_buckets] + 3) / 4);
     if (K >= 64 && NO >= 64) {   // 16+ chunks per row on both sides: the structured numbering (two waves per SIMD at 80 fragments)
         const int32_t *trows_t = g->btile_rows + (size_t)32 * nt;
+        const uint32_t p_bytes = ro ? (uint32_t)((size_t)g->n_rows * ro->O * sizeof(float)) : 0u;
 #define AMP_WIDE(KJ_, OT_)                                                                                            \
-    if (kj == KJ_ && ot == OT_)                                                                                       \
-        hipLaunchKernelGGL((duv_rows_wide_kernel<KJ_, OT_>), grid, dim3(256), 0, amp::stream(), sp, trows_abs, trows_t, \
-                           X, K, W, wb, so, sk, Y, NO, act);
+    if (kj == KJ_ && ot == OT_) {                                                                                     \
+        if (ro)                                                                                                       \
+            hipLaunchKernelGGL((duv_rows_wide_kernel<KJ_, OT_, true>), grid, dim3(256), 0, amp::stream(), sp, trows_abs, \
+                               trows_t, X, K, W, wb, so, sk, Y, NO, act, ro->R, ro->O, ro->P, p_bytes);                \
+        else                                                                                                          \
+            hipLaunchKernelGGL((duv_rows_wide_kernel<KJ_, OT_, false>), grid, dim3(256), 0, amp::stream(), sp, trows_abs, \
+                               trows_t, X, K, W, wb, so, sk, Y, NO, act, nullptr, 0, nullptr, 0u);                     \
+    }
         AMP_WIDE(4, 4) AMP_WIDE(4, 5) AMP_WIDE(5, 4) AMP_WIDE(4, 6) AMP_WIDE(6, 4)
 #undef AMP_WIDE
         AMP_LAUNCH_CHECK();
         return 0;
     }
+    if (ro) return -1;   // the readout epilogue exists in the wide kernel only
 #define AMP_CASE(KJ_, OT_)                                                                                         \
     if (kj == KJ_ && ot == OT_) {                                                                                  \
         hipLaunchKernelGGL((duv_rows_any_kernel<KJ_, OT_>), grid, dim3(256), 0, amp::stream(), sp, trows_abs, X,      \
@@ -842,6 +1100,45 @@ int duv_mfma_bwd_w(const athena_mp_graph *g, int Fi, int Fo, const float *grad, 
 #undef AMP_ROW
 #undef AMP_CASE
     }
+    AMP_LAUNCH_CHECK();
+    std::vector<int> first(nb, 0), count(nb, 0);
+    for (int b = 0; b < nb; ++b) first[b] = sp.unit_off[b], count[b] = sp.unit_off[b + 1] - sp.unit_off[b];
+    return slab_reduce_segs((const float *)slabs, n, nb, first.data(), count.data(), dw, n, false);
+}
+
+// update + activation + the readout's p = softmax(R z) in one launch; -1: shape outside the wide kernel
+int duv_mfma_fwd_readout(const athena_mp_graph *g, int Fi, int Fo, const float *a, const float *w, int act, float *z,
+                         const float *R, int O, float *p)
+{
+    const ReadoutArgs ro{R, O, p};
+    return launch_rows(g, a, Fi, w, (int64_t)Fo * Fi, 1, Fo, z, Fo, act, &ro);
+}
+
+// da and dW from one pass over grad (both widths 64 .. 96); -1: shape outside the fused kernel
+int duv_mfma_bwd(const athena_mp_graph *g, int Fi, int Fo, const float *grad, const float *a, const float *w, float *da, float *dw)
+{
+    const int it = ceil16(Fi), ot = ceil16(Fo);
+    if ((Fi & 3) || (Fo & 3) || Fi < 64 || Fo < 64 || !frag_shape(it, ot)) return -1;
+    const int nt = g->n_btiles, nb = (int)g->btile_off.size() - 1, n = Fi * Fo;
+    if (nt == 0) {
+        AMP_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)nb * n, stream()));
+        return 0;
+    }
+    if (nb > kMaxBuckets) return -1;
+    const BucketSplit sp = make_split(g, 512, 4);
+    const int nwg = sp.unit_off[nb];
+    void *slabs = nullptr;
+    if (workspace(&slabs, sizeof(float) * (size_t)nwg * n, 2)) return 1;
+    bool launched = false;
+#define AMP_WIDE(IT_, OT_)                                                                                            \
+    if (it == IT_ && ot == OT_) {                                                                                     \
+        hipLaunchKernelGGL((duv_bwd_wide_kernel<IT_, OT_>), dim3(nwg), dim3(256), 0, stream(), sp, g->btile_rows,     \
+                           g->btile_rows + (size_t)48 * nt, a, Fi, grad, Fo, w, da, (float *)slabs);                  \
+        launched = true;                                                                                              \
+    }
+    AMP_WIDE(4, 4) AMP_WIDE(5, 4) AMP_WIDE(4, 5) AMP_WIDE(6, 4) AMP_WIDE(4, 6)
+#undef AMP_WIDE
+    if (!launched) return -1;
     AMP_LAUNCH_CHECK();
     std::vector<int> first(nb, 0), count(nb, 0);
     for (int b = 0; b < nb; ++b) first[b] = sp.unit_off[b], count[b] = sp.unit_off[b + 1] - sp.unit_off[b];

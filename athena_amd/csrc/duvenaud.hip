@@ -330,6 +330,42 @@ int athena_mp_duvenaud_update_bwd_w(const athena_mp_graph *g, int32_t Fi, int32_
     return 0;
 }
 
+/* z = act(duvenaud_update(a)) AND the readout's per-vertex p = softmax_over_outputs(R z) (update_readout_duvenaud,
+ * athena_duvenaud_msgpass_layer.f90:838-855, default softmax readout) from one launch: the activated rows feed the logits
+ * product straight from the accumulators, so the readout does not read z back.  The per-graph sums stay with
+ * athena_mp_segment_sum (p is [n_rows, O]).  Shapes outside the fused kernel run update_act_fwd and the readout launch. */
+int athena_mp_duvenaud_update_readout_fwd(const athena_mp_graph *g, int32_t Fi, int32_t Fo, int32_t min_deg, int32_t max_deg,
+                                          const float *a, const float *weight, int32_t act, float *z, int32_t O,
+                                          const float *R, float *p)
+{
+    AMP_REQUIRE(g && a && weight && z && R && p && Fi > 0 && Fo > 0 && O > 0 && max_deg >= min_deg,
+                "duvenaud_update_readout_fwd: bad arguments");
+    AMP_REQUIRE(act >= 0 && act <= ATHENA_MP_ACT_TANH, "duvenaud_update_readout_fwd: unknown activation %d", act);
+    if (g->n_rows == 0) return 0;
+    if (duv_use_mfma(Fi, Fo, g->n_rows) && max_deg - min_deg + 1 <= 32) {
+        if (duvenaud_buckets(g, min_deg, max_deg)) return 1;
+        if (const int rc = duv_mfma_fwd_readout(g, Fi, Fo, a, weight, act, z, R, O, p); rc >= 0) return rc;
+    }
+    if (int rc = athena_mp_duvenaud_update_act_fwd(g, Fi, Fo, min_deg, max_deg, a, weight, act, z)) return rc;
+    // S = 0: logits + softmax only (the segment pointer is not read)
+    return athena_mp_duvenaud_readout_fwd(g->n_rows, Fo, O, 0, (const int32_t *)g->rowptr, z, R, p, p, 0);
+}
+
+/* both reverse products of duvenaud_update from one pass over the upstream gradient: da (w.r.t. the aggregated features)
+ * and dweight.  Same results as the two entry points above; where the fused kernel does not cover the shape they run. */
+int athena_mp_duvenaud_update_bwd(const athena_mp_graph *g, int32_t Fi, int32_t Fo, int32_t min_deg, int32_t max_deg,
+                                  const float *grad, const float *a, const float *weight, float *da, float *dweight)
+{
+    AMP_REQUIRE(g && grad && a && weight && da && dweight && Fi > 0 && Fo > 0 && max_deg >= min_deg,
+                "duvenaud_update_bwd: bad arguments");
+    if (g->n_rows > 0 && duv_use_mfma(Fi, Fo, g->n_rows) && max_deg - min_deg + 1 <= 32) {
+        if (duvenaud_buckets(g, min_deg, max_deg)) return 1;
+        if (const int rc = duv_mfma_bwd(g, Fi, Fo, grad, a, weight, da, dweight); rc >= 0) return rc;
+    }
+    if (int rc = athena_mp_duvenaud_update_bwd_w(g, Fi, Fo, min_deg, max_deg, grad, a, dweight)) return rc;
+    return athena_mp_duvenaud_update_bwd_a(g, Fi, Fo, min_deg, max_deg, grad, weight, da);
+}
+
 int athena_mp_softmax_segsum_fwd(int32_t O, int64_t N, int32_t S, const int32_t *seg, const float *logits,
                                  float *p, float *out, int32_t accumulate)
 {

@@ -34,7 +34,8 @@ module athena_mp_c
   public :: athena_mp_reverse_kipf_propagate_fwd, athena_mp_reverse_kipf_propagate_partial
   public :: athena_mp_reverse_kipf_propagate_partial_val
   public :: athena_mp_duvenaud_propagate_fwd, athena_mp_duvenaud_propagate_bwd_x, athena_mp_duvenaud_propagate_bwd_e
-  public :: athena_mp_duvenaud_update_bwd_a, athena_mp_duvenaud_update_bwd_w
+  public :: athena_mp_duvenaud_update_bwd_a, athena_mp_duvenaud_update_bwd_w, athena_mp_duvenaud_update_bwd
+  public :: athena_mp_duvenaud_update_readout_fwd
   public :: athena_mp_segment_sum, athena_mp_segment_sum_bwd
   public :: athena_mp_gno_aggregate_fwd, athena_mp_gno_aggregate_bwd_x, athena_mp_gno_aggregate_bwd_theta
   public :: athena_mp_gno_aggregate_bwd_coords
@@ -570,6 +571,20 @@ module athena_mp_c
           a_dev, dweight_dev) bind(C, name="athena_mp_duvenaud_update_bwd_w")
        import :: c_int, c_int32_t, c_ptr
        type(c_ptr), value :: graph, grad_dev, a_dev, dweight_dev
+       integer(c_int32_t), value :: Fi, Fo, min_deg, max_deg
+     end function
+     !! update + activation + the readout's p = softmax(R z) in one launch (athena_duvenaud_msgpass_layer.f90:790-803,838-855)
+     integer(c_int) function athena_mp_duvenaud_update_readout_fwd(graph, Fi, Fo, min_deg, max_deg, a_dev, weight_dev, act, &
+          z_dev, O, R_dev, p_dev) bind(C, name="athena_mp_duvenaud_update_readout_fwd")
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: graph, a_dev, weight_dev, z_dev, R_dev, p_dev
+       integer(c_int32_t), value :: Fi, Fo, min_deg, max_deg, act, O
+     end function
+     !! both partials of duvenaud_update from one pass over grad (:284-368)
+     integer(c_int) function athena_mp_duvenaud_update_bwd(graph, Fi, Fo, min_deg, max_deg, grad_dev, a_dev, weight_dev, &
+          da_dev, dweight_dev) bind(C, name="athena_mp_duvenaud_update_bwd")
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: graph, grad_dev, a_dev, weight_dev, da_dev, dweight_dev
        integer(c_int32_t), value :: Fi, Fo, min_deg, max_deg
      end function
      integer(c_int) function athena_mp_segment_sum(O, N, S, seg_dev, p_dev, out_dev, accumulate) &

@@ -950,6 +950,7 @@ contains
     type(c_ptr) :: cur
     integer :: t, tt, n, fv, fe, fin, fo, o
     integer(c_int32_t) :: code, acc
+    logical :: softmax_ro
 
     if(.not. c_associated(this%graph)) call stop_program("set_graph must be called before forward")
     n = this%nv
@@ -957,6 +958,7 @@ contains
     fe = this%num_edge_features(0)
     o = this%num_outputs
     code = fused_code(this%activation)
+    softmax_ro = trim(this%activation_readout%name) .eq. "softmax" .and. .not. apply_scaling(this%activation_readout)
     cur = x_dev
     do t = 1, tt
        fv = this%num_vertex_features(t - 1)
@@ -966,7 +968,15 @@ contains
        call need(this%tape_z(t), i8(n) * i8(fo))
        call chk(athena_mp_duvenaud_propagate_fwd(this%graph, int(fv, c_int32_t), int(fe, c_int32_t), cur, e_dev, &
             this%tape_a(t)%p), "duvenaud_propagate")
-       if(code .ge. 0)then
+       if(code .ge. 0 .and. softmax_ro .and. o .le. 16)then
+          ! the bucket contraction with the activation AND the readout's p = softmax(R z) in its epilogue: the readout
+          ! loop below then only sums p per graph
+          call need(this%tape_p(t), i8(n) * i8(o))
+          call chk(athena_mp_duvenaud_update_readout_fwd(this%graph, int(fin, c_int32_t), int(fo, c_int32_t), &
+               int(this%min_vertex_degree, c_int32_t), int(this%max_vertex_degree, c_int32_t), this%tape_a(t)%p, &
+               this%params(t)%p, code, this%tape_z(t)%p, int(o, c_int32_t), this%params(tt + t)%p, this%tape_p(t)%p), &
+               "duvenaud_update + readout")
+       else if(code .ge. 0)then
           call chk(athena_mp_duvenaud_update_act_fwd(this%graph, int(fin, c_int32_t), int(fo, c_int32_t), &
                int(this%min_vertex_degree, c_int32_t), int(this%max_vertex_degree, c_int32_t), this%tape_a(t)%p, &
                this%params(t)%p, code, this%tape_z(t)%p), "duvenaud_update")
@@ -984,7 +994,10 @@ contains
        fo = this%num_vertex_features(t)
        acc = merge(1_c_int32_t, 0_c_int32_t, t .gt. 1)
        call need(this%tape_p(t), i8(n) * i8(o))
-       if(trim(this%activation_readout%name) .eq. "softmax" .and. .not. apply_scaling(this%activation_readout))then
+       if(softmax_ro .and. code .ge. 0 .and. o .le. 16)then
+          call chk(athena_mp_segment_sum(int(o, c_int32_t), i8(n), int(this%batch, c_int32_t), this%seg%p, this%tape_p(t)%p, &
+               this%out_dev%p, acc), "segment_sum")            ! p came out of the update launch
+       else if(softmax_ro)then
           call chk(athena_mp_duvenaud_readout_fwd(i8(n), int(fo, c_int32_t), int(o, c_int32_t), int(this%batch, c_int32_t), &
                this%seg%p, this%tape_z(t)%p, this%params(tt + t)%p, this%tape_p(t)%p, this%out_dev%p, acc), "readout")
        else
@@ -1102,14 +1115,17 @@ contains
           call copy_dev(dc, tmp, i8(n) * i8(fo))
        end if
        ! message branch
-       call chk(athena_mp_duvenaud_update_bwd_w(this%graph, int(fin, c_int32_t), int(fo, c_int32_t), &
-            int(this%min_vertex_degree, c_int32_t), int(this%max_vertex_degree, c_int32_t), dc, this%tape_a(t)%p, &
-            this%grads(t)%p), "duvenaud_update reverse (weights)")
        this%has_grad(t) = .true.
-       if(t .eq. 1 .and. .not. (present(dx_dev) .or. present(de_dev))) exit
-       call chk(athena_mp_duvenaud_update_bwd_a(this%graph, int(fin, c_int32_t), int(fo, c_int32_t), &
-            int(this%min_vertex_degree, c_int32_t), int(this%max_vertex_degree, c_int32_t), dc, this%params(t)%p, da), &
-            "duvenaud_update reverse (input)")
+       if(t .eq. 1 .and. .not. (present(dx_dev) .or. present(de_dev)))then
+          call chk(athena_mp_duvenaud_update_bwd_w(this%graph, int(fin, c_int32_t), int(fo, c_int32_t), &
+               int(this%min_vertex_degree, c_int32_t), int(this%max_vertex_degree, c_int32_t), dc, this%tape_a(t)%p, &
+               this%grads(t)%p), "duvenaud_update reverse (weights)")
+          exit
+       end if
+       ! both reverse products of the update from one pass over dc
+       call chk(athena_mp_duvenaud_update_bwd(this%graph, int(fin, c_int32_t), int(fo, c_int32_t), &
+            int(this%min_vertex_degree, c_int32_t), int(this%max_vertex_degree, c_int32_t), dc, this%tape_a(t)%p, &
+            this%params(t)%p, da, this%grads(t)%p), "duvenaud_update reverse")
        if(present(de_dev) .and. this%ne .gt. 0)then
           if(first_de)then
              call chk(athena_mp_duvenaud_propagate_bwd_e(this%graph, int(fv, c_int32_t), int(fe, c_int32_t), da, &

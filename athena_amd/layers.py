@@ -346,10 +346,18 @@ class duvenaud_msgpass_layer_type(msgpass_layer_type):
             raise ValueError("edge feature shape mismatch")
         self._e = e
         self._a, self.z, self._c = [], [], []
+        self._p_early = [None] * T            # the readout's per-vertex p where it rode in the update launch
         cur = x
         for t in range(1, T + 1):
             a = ops.duvenaud_propagate(g, cur, e)
-            if _fusable(self.activation):     # the bucket contraction with the activation in its epilogue
+            if _fusable(self.activation) and self.activation_readout == "softmax" and self.num_outputs <= 16:
+                # the bucket contraction with the activation AND the readout's softmax(R z) in its epilogue: the readout of
+                # this time step then only sums p per graph (update_readout below)
+                zt, self._p_early[t - 1] = ops.duvenaud_update_act_readout(
+                    g, a, self.params[t - 1], self.min_vertex_degree, self.max_vertex_degree, self.num_vertex_features[t],
+                    self.params[T + t - 1], self.num_outputs, act=self.activation)
+                c = None
+            elif _fusable(self.activation):   # the bucket contraction with the activation in its epilogue
                 zt = ops.duvenaud_update_act(g, a, self.params[t - 1], self.min_vertex_degree, self.max_vertex_degree,
                                              self.num_vertex_features[t], act=self.activation)
                 c = None
@@ -370,7 +378,10 @@ class duvenaud_msgpass_layer_type(msgpass_layer_type):
         out = None
         self._p = []
         for t in range(1, T + 1):
-            if self.activation_readout == "softmax":      # the default: one launch incl. the logits contraction
+            if self.activation_readout == "softmax" and getattr(self, "_p_early", [None] * T)[t - 1] is not None:
+                p = self._p_early[t - 1]                  # computed beside z in update_message: only the per-graph sums are left
+                out = ops.segment_sum(p, self._seg, out=out)
+            elif self.activation_readout == "softmax":    # one launch incl. the logits contraction
                 p, out = ops.duvenaud_readout(self.params[T + t - 1], self.z[t - 1], self._seg, self.num_outputs, out=out)
             else:                                         # any other readout activation: op by op
                 logits = ops.matmul(self.params[T + t - 1], self.z[t - 1], self.num_outputs)
@@ -411,11 +422,12 @@ class duvenaud_msgpass_layer_type(msgpass_layer_type):
                     ops.axpy(1.0, dz_next, dz)
                 dc = ops.activation_bwd(self.activation, self.z[t - 1], dz, z=self._c[t - 1]) if not _identity(self.activation) else dz
             # message branch
-            self.grads[t - 1] = ops.duvenaud_update_bwd_w(g, dc, self._a[t - 1], self.min_vertex_degree, self.max_vertex_degree)
             if t == 1 and not (need_input_grad or need_edge_grad):
+                self.grads[t - 1] = ops.duvenaud_update_bwd_w(g, dc, self._a[t - 1], self.min_vertex_degree, self.max_vertex_degree)
                 break
-            da = ops.duvenaud_update_bwd_a(g, dc, self.params[t - 1], self.min_vertex_degree, self.max_vertex_degree,
-                                           self._a[t - 1].shape[1])
+            # both reverse products of the update from one pass over dc (one launch where the fused kernel covers the widths)
+            da, self.grads[t - 1] = ops.duvenaud_update_bwd(g, dc, self._a[t - 1], self.params[t - 1], self.min_vertex_degree,
+                                                            self.max_vertex_degree)
             Fv = self.num_vertex_features[t - 1]
             if need_edge_grad:
                 d = ops.duvenaud_propagate_bwd_e(g, da, Fv)

@@ -445,6 +445,20 @@ def duvenaud_update_act(g: DeviceGraph, a, weight, min_deg, max_deg, Fo, act="no
     return z
 
 
+def duvenaud_update_act_readout(g: DeviceGraph, a, weight, min_deg, max_deg, Fo, R, O, act="none"):
+    """(z, p): z = act(duvenaud_update(a)) and the readout's p = softmax(z R^T) per vertex from one launch"""
+    Fi = a.shape[1]
+    _chk(a, (g.n_rows, Fi))
+    if not (weight.numel() == Fo * Fi * (max_deg - min_deg + 1) and R.numel() == O * Fo):
+        raise ValueError('expected: weight.numel() == Fo * Fi * D and R.numel() == O * Fo')
+    z = torch.empty((g.n_rows, Fo), device=a.device, dtype=torch.float32)
+    p = torch.empty((g.n_rows, O), device=a.device, dtype=torch.float32)
+    _go()
+    _capi.call("athena_mp_duvenaud_update_readout_fwd", g.handle, Fi, Fo, min_deg, max_deg, _p(a), _p(_chk(weight)), ACT[act],
+               _p(z), O, _p(_chk(R)), _p(p))
+    return z, p
+
+
 def duvenaud_update_bwd_a(g: DeviceGraph, grad, weight, min_deg, max_deg, Fi):
     Fo = grad.shape[1]
     _chk(grad, (g.n_rows, Fo))
@@ -461,6 +475,19 @@ def duvenaud_update_bwd_w(g: DeviceGraph, grad, a, min_deg, max_deg):
     _go()
     _capi.call("athena_mp_duvenaud_update_bwd_w", g.handle, Fi, Fo, min_deg, max_deg, _p(grad), _p(a), _p(dW))
     return dW
+
+
+def duvenaud_update_bwd(g: DeviceGraph, grad, a, weight, min_deg, max_deg):
+    """(da, dW): both reverse products of duvenaud_update from one pass over grad (athena_mp_duvenaud_update_bwd)"""
+    Fo, Fi = grad.shape[1], a.shape[1]
+    _chk(grad, (g.n_rows, Fo)); _chk(a, (g.n_rows, Fi))
+    if not (weight.numel() == Fo * Fi * (max_deg - min_deg + 1)):
+        raise ValueError('expected: weight.numel() == Fo * Fi * (max_deg - min_deg + 1)')
+    da = torch.empty((g.n_rows, Fi), device=grad.device, dtype=torch.float32)
+    dW = torch.empty(Fo * Fi * (max_deg - min_deg + 1), device=grad.device, dtype=torch.float32)
+    _go()
+    _capi.call("athena_mp_duvenaud_update_bwd", g.handle, Fi, Fo, min_deg, max_deg, _p(grad), _p(a), _p(_chk(weight)), _p(da), _p(dW))
+    return da, dW
 
 
 def softmax_segsum(logits, seg, out=None):

@@ -224,6 +224,17 @@ int athena_mp_duvenaud_update_bwd_a(const athena_mp_graph *g, int32_t Fi, int32_
 int athena_mp_duvenaud_update_bwd_w(const athena_mp_graph *g, int32_t Fi, int32_t Fo, int32_t min_deg,
                                     int32_t max_deg, const float *grad_dev, const float *a_dev,
                                     float *dweight_dev);
+/* update + activation + the per-vertex part of the readout, p = softmax_over_outputs(R z) (update_readout_duvenaud,
+ * athena_duvenaud_msgpass_layer.f90:838-855), in one launch; z [n_rows, Fo], R = params(T+t)%val(:,1) = R(O, Fo) flat,
+ * p [n_rows, O].  The per-graph sums: athena_mp_segment_sum(O, n_rows, S, seg, p, out, accumulate). */
+int athena_mp_duvenaud_update_readout_fwd(const athena_mp_graph *g, int32_t Fi, int32_t Fo, int32_t min_deg, int32_t max_deg,
+                                          const float *a_dev, const float *weight_dev, int32_t act, float *z_dev, int32_t O,
+                                          const float *R_dev, float *p_dev);
+/* both partials above from ONE pass over grad (the pair is bound by the bytes it moves: 1.95 GB instead of 2.55 GB at
+ * configs[2]); da [n_rows, Fi], dweight [Fo*Fi*D].  Shapes outside the fused kernel run the two entry points above. */
+int athena_mp_duvenaud_update_bwd(const athena_mp_graph *g, int32_t Fi, int32_t Fo, int32_t min_deg, int32_t max_deg,
+                                  const float *grad_dev, const float *a_dev, const float *weight_dev, float *da_dev,
+                                  float *dweight_dev);
 /* readout, athena_duvenaud_msgpass_layer.f90:838-855 over a block-diagonal batch:
  *   p[v,:] = softmax_over_outputs(logits[v,:]); out[s,:] (+)= sum_{v in seg s} p[v,:]
  *   seg_dev [S+1] 0-based vertex offsets of the graphs */

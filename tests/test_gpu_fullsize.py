@@ -280,12 +280,21 @@ def test_c3_duvenaud_reverse_ops_match_oracle_at_full_size(dev, oracle, c3):
     eids = np.unique(ja_s[1][ja_s[1] > 0]).astype(np.int64) - 1     # the edge columns of these graphs (tree bonds and ring closures
     de_ref = oracle.duvenaud_propagate_bwd_e(g2_s, Fv, ne, ia_s, ja_s)    # are numbered in two passes over the batch: not one range)
     assert np.array_equal(de[torch.from_numpy(eids).to(dev)].cpu().numpy(), de_ref[eids])
+    # the fused reverse launch (da and dW from one pass over the gradient rows) at full size: da on the same rows
+    a_chk = torch.from_numpy(rng.random((N, Fc), np.float32)).to(dev)
+    da_f, dW_f = ops.duvenaud_update_bwd(g, gup, a_chk, W, mn, mx)
+    assert np.abs(da_f[:nv].cpu().numpy() - da_ref).max() <= 1e-5 * np.abs(da_ref).max()
+    dW_sep = ops.duvenaud_update_bwd_w(g, gup, a_chk, mn, mx)
+    assert (dW_f - dW_sep).abs().max().item() <= 1e-5 * dW_sep.abs().max().item()
+    del a_chk, da_f
     # weight gradient: a 3 000-graph batch of its own, through the same kernels (all ten degree buckets occur)
     gs = DeviceGraph(ia_s, ja_s, n_edge_cols=ne)
     a_s = torch.from_numpy(rng.random((nv, Fc), np.float32)).to(dev)
     dW = ops.duvenaud_update_bwd_w(gs, gup[:nv].contiguous(), a_s, mn, mx)
     dW_ref = oracle.duvenaud_update_bwd_w(g_s, a_s.cpu().numpy(), ia_s, mn, mx)
     assert_close(dW.cpu().numpy(), dW_ref, 1e-5, "configs[2] dW", f64=lambda: o64.duvenaud_update_bwd_w(g_s, a_s.cpu().numpy(), ia_s, mn, mx))
+    _, dW2 = ops.duvenaud_update_bwd(gs, gup[:nv].contiguous(), a_s, W, mn, mx)
+    assert_close(dW2.cpu().numpy(), dW_ref, 1e-5, "configs[2] dW (fused reverse)", f64=lambda: o64.duvenaud_update_bwd_w(g_s, a_s.cpu().numpy(), ia_s, mn, mx))
     # ... and the full batch's weight gradient is the sum of per-slice gradients (linearity over vertices), slice by slice
     # through the same entry point on 4 disjoint ranges of graphs
     a_full = torch.from_numpy(rng.random((N, Fc), np.float32)).to(dev)

@@ -308,7 +308,33 @@ def test_duvenaud_update_and_grads(dev, oracle, Fi, Fo, mn, mx, n):
         assert_close(c, co, 1e-5, "update fwd")
         assert_close(da, dao, 1e-5, "update bwd_a")
     dw = H(ops.duvenaud_update_bwd_w(g, T(up, dev), T(a, dev), mn, mx))
-    assert_close(dw, oracle.duvenaud_update_bwd_w(up, a, ia, mn, mx), 1e-5, "dW")
+    dwo = oracle.duvenaud_update_bwd_w(up, a, ia, mn, mx)
+    assert_close(dw, dwo, 1e-5, "dW")
+    # both reverse products from one pass over the gradient rows (one launch at 64 .. 96 features on both sides,
+    # the two launches above elsewhere): same partials, and the same bits on a second call
+    da2, dw2 = ops.duvenaud_update_bwd(g, T(up, dev), T(a, dev), T(w, dev), mn, mx)
+    if Fi < 16 or Fo < 16:
+        assert np.array_equal(H(da2), dao)
+    else:
+        assert_close(H(da2), dao, 1e-5, "fused reverse: da")
+    assert_close(H(dw2), dwo, 1e-5, "fused reverse: dW")
+    da3, dw3 = ops.duvenaud_update_bwd(g, T(up, dev), T(a, dev), T(w, dev), mn, mx)
+    assert torch.equal(da2, da3) and torch.equal(dw2, dw3)
+    if Fi >= 16 and Fo >= 16:            # update + activation + the readout's softmax(R z) in one launch == the two launches
+        O = 10
+        R = rng.standard_normal(O * Fo).astype(np.float32) * 0.3
+        for act in ("sigmoid", "none"):
+            z2, p2 = ops.duvenaud_update_act_readout(g, T(a, dev), T(w, dev), mn, mx, Fo, T(R, dev), O, act=act)
+            z1 = ops.duvenaud_update_act(g, T(a, dev), T(w, dev), mn, mx, Fo, act=act)
+            assert torch.equal(z1, z2)
+            zo = oracle.activation(act, co)
+            po = oracle.softmax_cols(oracle.matmul(R, zo, O))
+            from oracle import oracle64 as o64
+            assert_close(H(p2), po, 1e-5, "update+readout p", f64=lambda: o64.softmax_cols(o64.matmul(R, o64.activation(act, o64.duvenaud_update(a, w, ia, mn, mx, Fo)), O)))
+            seg = torch.from_numpy(np.array([0, 3, 3, n // 2, n], np.int32)).to(dev)
+            p1, out1 = ops.duvenaud_readout(T(R, dev), z1, seg, O)
+            assert_close(H(p2), H(p1), 2e-5, "p: fused against the readout launch (each within 1e-5 of the oracle)")
+            assert_close(H(ops.segment_sum(p2, seg)), oracle.segment_sum(H(p2), H(seg)), 1e-5, "per-graph sums of the fused p")
     for act in ("sigmoid", "relu"):      # activation in the epilogue == update followed by the activation op
         z = H(ops.duvenaud_update_act(g, T(a, dev), T(w, dev), mn, mx, Fo, act=act))
         from oracle import oracle64 as o64   # float64 twin: yardstick of the anchored 1e-5 (helpers.assert_close)
