@@ -274,8 +274,11 @@ static int graph_free(athena_mp_graph *g)
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (g->bucket_perm) (void)hipFree(g->bucket_perm);
-    if (g->len_perm_fwd) (void)hipFree(g->len_perm_fwd);
-    if (g->len_perm_bwd) (void)hipFree(g->len_perm_bwd);
+    for (int32_t *lp : {g->len_perm_fwd, g->len_perm_bwd})
+        if (lp) {
+            amp::gno_forget_perm(lp);
+            (void)hipFree(lp);
+        }
     if (g->btile_start) (void)hipFree(g->btile_start);
     if (g->btile_info) (void)hipFree(g->btile_info);
     if (g->btile_rows) (void)hipFree(g->btile_rows);

@@ -127,6 +127,7 @@ int graph_build_device(athena_mp_graph *g, const int32_t *adj_ja, const std::vec
 int csr_from_edges_core(int32_t n_vertices, int64_t n_pairs, const int32_t *index_list, int32_t add_self_loops,
                         int32_t *adj_ia_out, int32_t *adj_ja_out, int64_t capacity, int64_t *nnz_out,
                         int32_t **keep_ja_dev);
+void gno_forget_perm(const int32_t *perm_dev);   // gno.hip: counts cached beside a row-length order
 void graph_cache_clear(); // idle and live handles of athena_mp_graph_acquire (capi.hip)
 void host_pool_release();   // staging buffers of the *_host entry points (host.hip)
 int agg_blocks_cap();

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(1024) void agg_gemm_kernel(const int32_t *__restric
     auto load_row = [&](int u) -> v4f {
         if constexpr (BUF) {
             typedef int v4i_ __attribute__((ext_vector_type(4)));
-            const v4i_ t = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (u << (K == 128 ? 9 : 8)) + 16 * gl, 0, 0);
+            const v4i_ t = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(((uint32_t)u << (K == 128 ? 9 : 8)) + 16u * (uint32_t)gl), 0, 0);   // byte offset in uint32: tensors of 2 .. 4 GB
             return __builtin_bit_cast(v4f, t);
         } else {
             return *reinterpret_cast<const v4f *>(x + (int64_t)u * K + 4 * gl);
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(512) void agg_gemm256_kernel(const int32_t *__restr
     auto load_row = [&](int u) -> v4f {
         if constexpr (BUF) {
             typedef int v4i_ __attribute__((ext_vector_type(4)));
-            const v4i_ t = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (u << 10) + 16 * lane, 0, 0);
+            const v4i_ t = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(((uint32_t)u << 10) + 16u * (uint32_t)lane), 0, 0);   // byte offset in uint32: tensors of 2 .. 4 GB
             return __builtin_bit_cast(v4f, t);
         } else {
             return *reinterpret_cast<const v4f *>(x + (int64_t)u * K + 4 * lane);

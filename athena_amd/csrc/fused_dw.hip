@@ -116,7 +116,7 @@ __global__ __launch_bounds__(64 * kNW) void agg_gemm_dw_kernel(const int32_t *__
     auto load_row = [&](int u) -> v4f {
         if (dz_bytes) {   // workgroup-uniform
             typedef int v4i_ __attribute__((ext_vector_type(4)));
-            const v4i_ t = __builtin_amdgcn_raw_buffer_load_b128(zrsrc, (u << 9) + 16 * gl, 0, 0);
+            const v4i_ t = __builtin_amdgcn_raw_buffer_load_b128(zrsrc, (int)(((uint32_t)u << 9) + 16u * (uint32_t)gl), 0, 0);   // byte offset in uint32: tensors of 2 .. 4 GB
             return __builtin_bit_cast(v4f, t);
         }
         return *reinterpret_cast<const v4f *>(dz + (int64_t)u * K + 4 * gl);

@@ -15,6 +15,8 @@
 //   dU,db_u,dcoords : per entry dh[k] = sum_q G_i[k,q] x_j[q], G = g . Vmat^T, masked by relu' (:303-318, :195-210)
 // S / T / G are produced per super-tile of vertices into a bounded HBM workspace.
 #include <algorithm>
+#include <iterator>
+#include <map>
 #include <type_traits>
 
 #include <stdlib.h>
@@ -392,10 +394,26 @@ bool gno_fused_shape(int H, int Fy, int Fout, int d)
     return !off && H == kGH && Fy == kGF && Fout == kGF && d <= 4;
 }
 
-// vertices ordered by row length, longest first (stable counting sort on the host, once per graph and CSR)
+// vertices ordered by row length, longest first (stable counting sort on the host, once per graph and CSR).  The permutation
+// and the two class counts that go with it (rows of more than 32 / more than 16 entries: the first slots of the permutation)
+// are ONE cached unit: a caller that asks for the counts gets them whether or not it was the one that built the permutation.
+struct LenCounts {
+    int32_t n_long, n_mid;
+};
+std::map<const int32_t *, LenCounts> g_len_counts;   // keyed by the cached device permutation
+
 int length_order(const int32_t *rowptr_dev, int n_rows, int32_t **perm_dev, int32_t *n_long = nullptr, int32_t *n_mid = nullptr)
 {
-    if (*perm_dev) return 0;
+    if (*perm_dev) {
+        const auto it = g_len_counts.find(*perm_dev);
+        if (it != g_len_counts.end()) {
+            if (n_long) *n_long = it->second.n_long;
+            if (n_mid) *n_mid = it->second.n_mid;
+            return 0;
+        }
+        (void)hipFree(*perm_dev);   // a permutation without its counts (never left by this function): rebuild both
+        *perm_dev = nullptr;
+    }
     std::vector<int32_t> rp((size_t)n_rows + 1);
     AMP_HIP(hipMemcpyAsync(rp.data(), rowptr_dev, sizeof(int32_t) * rp.size(), hipMemcpyDeviceToHost, amp::stream()));
     AMP_HIP(hipStreamSynchronize(amp::stream()));
@@ -406,14 +424,23 @@ int length_order(const int32_t *rowptr_dev, int n_rows, int32_t **perm_dev, int3
         longer += rp[i + 1] - rp[i] > 32;
         mid += rp[i + 1] - rp[i] > 16;
     }
-    if (n_long) *n_long = longer;
-    if (n_mid) *n_mid = mid;
     std::vector<int32_t> start((size_t)mx + 2, 0), perm((size_t)std::max(n_rows, 1));
     for (int i = 0; i < n_rows; ++i) start[(size_t)(mx - (rp[i + 1] - rp[i])) + 1]++;
     for (int l = 0; l <= mx; ++l) start[(size_t)l + 1] += start[l];
     for (int i = 0; i < n_rows; ++i) perm[start[(size_t)(mx - (rp[i + 1] - rp[i]))]++] = i;
-    AMP_HIP(hipMalloc((void **)perm_dev, sizeof(int32_t) * perm.size()));
-    AMP_HIP(hipMemcpy(*perm_dev, perm.data(), sizeof(int32_t) * perm.size(), hipMemcpyHostToDevice));
+    int32_t *dev = nullptr;
+    AMP_HIP(hipMalloc((void **)&dev, sizeof(int32_t) * perm.size()));
+    if (hipMemcpy(dev, perm.data(), sizeof(int32_t) * perm.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(dev);         // nothing half-built stays behind
+        amp::set_error("gno: upload of the row-length order failed");
+        return 1;
+    }
+    for (auto it = g_len_counts.begin(); it != g_len_counts.end();)   // a freed permutation's address may come back
+        it = it->first == dev ? g_len_counts.erase(it) : std::next(it);
+    g_len_counts[dev] = LenCounts{longer, mid};
+    *perm_dev = dev;
+    if (n_long) *n_long = longer;
+    if (n_mid) *n_mid = mid;
     return 0;
 }
 
@@ -2232,3 +2259,8 @@ int athena_mp_gno_aggregate_bwd_coords(const athena_mp_graph *g, int32_t d, int3
 }
 
 } // extern "C"
+
+namespace amp {
+// a graph handle is being freed: its cached row-length orders take their counts with them (capi.hip)
+void gno_forget_perm(const int32_t *perm_dev) { g_len_counts.erase(perm_dev); }
+} // namespace amp

@@ -614,3 +614,38 @@ def test_c5_one_real_shard_of_the_eight_way_partition(dev, oracle, variant, mode
     if mode == "allgather":
         need = sh.halo_ids.size / float(N - n)
         assert need > 0.7, need                                    # why this shard travels as whole blocks
+
+
+def test_fused_step_on_a_gathered_tensor_between_2_and_4_GiB(dev, oracle):
+    """the fused kernels address their gathers through a buffer descriptor with 32-bit BYTE offsets while the gathered
+    tensor is below 4 GiB: a 6.2 M x 128 fp32 tensor (3.2 GB) puts the offsets of the upper rows beyond INT_MAX, where a
+    signed shift would be undefined.  Sparse graph (the point is addressing); sampled rows including the last ones against
+    the oracle on the compacted sub-problem, forward (P bit-exact, Z) and reverse."""
+    from athena_amd import DeviceGraph, ops, synth
+
+    N, F = 6_200_000, 128
+    assert 2 ** 31 < N * F * 4 < 2 ** 32 - 4096
+    ia, ja = synth.random_graph_csr(N, 2 * N)
+    g = DeviceGraph(ia, ja, n_edge_cols=0)
+    x = _device_uniform(dev, N, F, 5)
+    w_h = synth.kipf_weight(F)
+    w = torch.from_numpy(w_h).to(dev)
+    P, Z = ops.kipf_layer_fwd(g, x, w, F)
+    rows = np.unique(np.concatenate([np.random.default_rng(2).choice(N, 4000, replace=False), np.arange(N - 64, N)]))
+    # rows whose neighbours lie in the upper half of the tensor are the ones that exercise the high offsets
+    cols, sia, sja = _rows_sub_problem(ia, ja[0] - 1, rows)
+    assert (cols.astype(np.int64) * F * 4 > 2 ** 31).any()
+    deg = np.diff(ia).astype(np.int32)
+    xs = x[torch.from_numpy(cols).to(dev)].cpu().numpy()
+    p_ref = oracle.kipf_propagate_rect(xs, sia, sja, deg[rows], deg[cols])
+    rsel = torch.from_numpy(rows).to(dev)
+    assert np.array_equal(P[rsel].cpu().numpy(), p_ref)
+    z_ref = oracle.matmul(w_h, p_ref, F)
+    assert np.abs(Z[rsel].cpu().numpy() - z_ref).max() <= 1e-5 * np.abs(z_ref).max()
+    del P, Z
+    dX = ops.kipf_layer_bwd_x(g, x, w, F)                         # x doubles as the upstream gradient
+    csel = np.unique(np.concatenate([np.random.default_rng(3).choice(N, 1500, replace=False), np.arange(N - 32, N)]))
+    src, cia, cja = _column_sub_problem(ia, ja, csel)
+    gs = x[torch.from_numpy(src).to(dev)].cpu().numpy()
+    dx_ref = oracle.kipf_propagate_bwd(oracle.matmul_dx(w_h, gs, F), cia, cja, n_out=csel.size)
+    assert np.abs(dX[torch.from_numpy(csel).to(dev)].cpu().numpy() - dx_ref).max() <= 1e-5 * np.abs(dx_ref).max()
