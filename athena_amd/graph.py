@@ -169,7 +169,10 @@ class DeviceGraph:
     Built once and reused: the reference re-copies the CSR on every forward
     (athena_network_sub.f90:2727-2730); the handle is what `set_graph` caches."""
 
-    def __init__(self, adj_ia, adj_ja, n_cols=None, n_edge_cols=None, row_deg=None, col_deg=None, device=0):
+    def __init__(self, adj_ia, adj_ja, n_cols=None, n_edge_cols=None, row_deg=None, col_deg=None, device=0, shared=False):
+        """shared=True (square graph, degrees = row lengths): the handle comes from the library's content-keyed cache
+        (athena_mp_graph_acquire) -- every layer of a network that is given the same graph gets the same device arrays,
+        and close() releases a reference instead of freeing them"""
         _capi.init(device)
         ia = np.ascontiguousarray(adj_ia, np.int32)
         ja = np.asfortranarray(adj_ja, np.int32)
@@ -191,11 +194,15 @@ class DeviceGraph:
             if not (rd.size == self.n_rows and cd.size == self.n_cols):
                 raise ValueError('expected: rd.size == self.n_rows and cd.size == self.n_cols')
         h = C.c_void_p()
-        _capi.call(
-            "athena_mp_graph_create", self.n_rows, self.n_cols, self.nnz,
-            ia.ctypes.data_as(C.c_void_p), ja.ctypes.data_as(C.c_void_p), self.n_edge_cols,
-            rd.ctypes.data_as(C.c_void_p) if rd is not None else None,
-            cd.ctypes.data_as(C.c_void_p) if cd is not None else None, C.byref(h))
+        if shared and rd is None and self.n_cols == self.n_rows:
+            _capi.call("athena_mp_graph_acquire", self.n_rows, self.nnz, ia.ctypes.data_as(C.c_void_p),
+                       ja.ctypes.data_as(C.c_void_p), self.n_edge_cols, C.byref(h))
+        else:
+            _capi.call(
+                "athena_mp_graph_create", self.n_rows, self.n_cols, self.nnz,
+                ia.ctypes.data_as(C.c_void_p), ja.ctypes.data_as(C.c_void_p), self.n_edge_cols,
+                rd.ctypes.data_as(C.c_void_p) if rd is not None else None,
+                cd.ctypes.data_as(C.c_void_p) if cd is not None else None, C.byref(h))
         self.handle = h
 
     _ARRAYS = {"rowptr": (0, np.int32), "col": (1, np.int32), "eid": (2, np.int32), "coef": (3, np.float32),

@@ -88,8 +88,10 @@ class _batched_graph:
         self.num_vertices = int(self.vertex_offsets[-1])
         self.num_edges = int(self.edge_offsets[-1])
         self.batch = len(graphs)
+        # shared: the layers of a network are all handed the same batch (athena_network_sub.f90:2727-2730) -- one set of
+        # device arrays behind all of them (athena_mp_graph_acquire keys on the content of the assembled CSR)
         self.device = DeviceGraph(self.adj_ia, self.adj_ja, n_edge_cols=self.num_edges if keep_edges else 0,
-                                  device=device_index)
+                                  device=device_index, shared=True)
 
 
 class msgpass_layer_type:

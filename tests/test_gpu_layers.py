@@ -5,6 +5,7 @@ import functools
 
 import numpy as np
 import pytest
+import torch
 
 import oracle_layers as ol
 from helpers import assert_close, csr_from_index_list, golden
@@ -522,3 +523,43 @@ def test_reading_a_duvenaud_card_returns_the_reference_placeholder(dev):
     with pytest.warns(UserWarning, match="empty stub"):
         back = read_layer(card)
     assert back.name == "duvenaud" and back.num_time_steps == 1 and back.get_num_params() == 0
+
+
+def test_layers_given_the_same_batch_share_one_device_handle(dev):
+    """athena_network_sub.f90:2727-2730 hands every msgpass layer of a network the same batch before every forward.  The
+    layer mirrors take their handle from the library's content-keyed cache (athena_mp_graph_acquire): one set of device
+    arrays for all of them, a second one only for a batch with other content -- equal sizes included -- and a Kipf
+    layer (no edge ids in its handle) never shares with a layer that reads edge features."""
+    import ctypes as C
+
+    from athena_amd import _capi
+    from athena_amd.layers import duvenaud_msgpass_layer_type, kipf_msgpass_layer_type
+
+    def stats():
+        h, hit, b = C.c_int64(), C.c_int64(), C.c_int64()
+        _capi.call("athena_mp_graph_cache_stats", C.byref(h), C.byref(hit), C.byref(b))
+        return h.value, hit.value, b.value
+
+    t = golden("reference_test_topologies.json")["kipf_layer_6v8e"]
+    g1 = csr_from_index_list(6, t["index_list"])
+    perm = np.array([2, 1, 3, 4, 5, 6])
+    g2 = csr_from_index_list(6, perm[np.asarray(t["index_list"]) - 1])          # same counts, other adjacency
+    assert g1.nnz == g2.nnz
+    _, hits0, builds0 = stats()
+    layers = [kipf_msgpass_layer_type(num_vertex_features=[4], num_time_steps=1) for _ in range(3)]
+    for l in layers:
+        l.set_graph([g1, g2])
+    assert len({l.graph.device.handle.value for l in layers}) == 1
+    _, hits1, builds1 = stats()
+    assert builds1 - builds0 == 1 and hits1 - hits0 == 2
+    layers[0].set_graph([g2, g1])                                               # another batch of the same sizes
+    assert layers[0].graph.device.handle.value != layers[1].graph.device.handle.value
+    d = duvenaud_msgpass_layer_type(num_vertex_features=[4], num_edge_features=[1], num_time_steps=1, max_vertex_degree=4,
+                                    num_outputs=2)
+    d.set_graph([g1, g2])                                                       # keeps the edge ids: a handle of its own
+    assert d.graph.device.handle.value != layers[1].graph.device.handle.value
+    _, _, builds2 = stats()
+    assert builds2 - builds1 == 2
+    x = torch.rand((12, 4), device=dev)
+    y1, y2 = layers[1].forward(x), layers[2].forward(x)                         # shared arrays, independent layers
+    assert y1.shape == (12, 4) and y2.shape == (12, 4)
