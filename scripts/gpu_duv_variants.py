@@ -25,6 +25,9 @@ out["update_sigmoid"] = timeit(lambda: ops.duvenaud_update_act(g, a_, W, mn, mx,
 out["update_none"] = timeit(lambda: ops.duvenaud_update_act(g, a_, W, mn, mx, Fv, act="none"))
 out["update_bwd_a"] = timeit(lambda: ops.duvenaud_update_bwd_a(g, dc, W, mn, mx, Fv + Fe))
 out["update_bwd_w"] = timeit(lambda: ops.duvenaud_update_bwd_w(g, dc, a_, mn, mx))
+R = T(rng.standard_normal(10 * Fv).astype(np.float32) * 0.1)
+if hasattr(_capi.load(), "athena_mp_duvenaud_update_readout_fwd"):
+    out["update_sigmoid_readout"] = timeit(lambda: ops.duvenaud_update_act_readout(g, a_, W, mn, mx, Fv, R, 10, act="sigmoid"))
 if hasattr(ops, "duvenaud_update_bwd") and hasattr(_capi.load(), "athena_mp_duvenaud_update_bwd"):
     out["update_bwd_fused"] = timeit(lambda: ops.duvenaud_update_bwd(g, dc, a_, W, mn, mx))
 print(json.dumps(out))
