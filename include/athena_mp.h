@@ -457,6 +457,10 @@ int athena_mp_halo_finish(athena_mp_shard *s, int32_t slot);
  * host code wrote it (or the allocator handed the address to another array) the sentinel is gone and the host content is
  * uploaded instead.  An argument that merely overlaps a registered array (a slice) materialises that array first.
  * Arrays under 64 bytes are always staged.  athena_mp_resident_mode(0) flushes everything and releases the device copies.
+ * LIFETIME CONTRACT: the table holds host ADDRESSES.  An array must be dropped (athena_mp_resident_drop) before its host
+ * storage is deallocated -- in the finaliser of the node / layer that owns it -- because a flush (explicit, at
+ * athena_mp_resident_mode(0), or forced by an overlapping argument) WRITES to that address.  athena_mp_resident_drop(NULL)
+ * forgets everything without touching host memory (the safe way out when lifetimes are unknown: flush what you read first).
  * Explicit form for a shim that manages an array itself: _acquire (dirty_host = 1: upload now; 0: allocate / trust the
  * device copy) -> device pointer for the *_dev entry points; _release(dirty_dev = 1) marks the device copy as the valid
  * one; _drop forgets an array WITHOUT copying back (call it when the host array is deallocated). */
