@@ -346,3 +346,105 @@ def test_bench_py_multi_gpu_command_dry_run_on_one_device(dev, argv, mode):
     else:
         assert bd["halo_mode"] == mode
     assert line["roofline"]["frac"] > 0 and line["roofline"]["dense"]["bound"] == "mfma"
+
+
+def _c5_shard_worker(rank, world, port, variant, check_rank, q):
+    """one rank of the 8-way partition of BASELINE configs[4]: builds its row block from the shared pair stream and its shard
+    through athena_mp_shard_create (all ranks: it is collective); `check_rank` then runs the layer step's launches on the
+    shard's own graph handles and holds sampled rows against the oracle"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ATHENA_MP_HALO_MODE="auto")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from athena_amd import dist as adist, synth
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    N, pairs, F = 10_000_000, 70_000_000, 256
+    locality = (50_000, 0.95) if variant == "local" else None
+    shard = adist.make_global_shard(rank, world, N, pairs, device=dev, locality=locality)
+    assert isinstance(shard, adist.CShard), shard.transport
+    out = dict(mode=shard.halo_mode, fraction=shard.halo_fraction, n_int=shard.n_int, n_halo=shard.n_halo)
+    if rank == check_rank:
+        from oracle import oracle
+        n = shard.n
+        g_fi, g_fb, g_bi, g_bb = shard.graphs()
+        ni = shard.n_int
+        gen = torch.Generator(device=dev).manual_seed(1)
+        xg = torch.rand((N, F), device=dev, generator=gen).mul_(2.0).sub_(1.0)
+        ids = torch.from_numpy(np.concatenate([rank * n + shard.order, np.maximum(shard.ext_ids, 0)])).to(dev)
+        x_ext = xg[ids]                                    # what the exchange delivers: the owners' rows
+        del xg
+        w_h = synth.kipf_weight(F)
+        w = torch.from_numpy(w_h).to(dev)
+        b = adist.HipBackend(dev)
+        P = torch.empty((n, F), device=dev); Z = torch.empty((n, F), device=dev); dX = torch.empty((n, F), device=dev)
+        b.kipf_layer_fwd(g_fi, x_ext, w, F, P=P[:ni], Z=Z[:ni])
+        b.kipf_layer_fwd(g_fb, x_ext, w, F, P=P[ni:], Z=Z[ni:])
+        b.pull_gemm(g_bi, x_ext, w, F, exact=False, out=dX[:ni])          # x_ext doubles as the exchanged dZ
+        b.pull_gemm(g_bb, x_ext, w, F, exact=False, out=dX[ni:])
+        rng = np.random.default_rng(40 + rank)
+        pick = [rng.choice(ni, min(2000, ni), replace=False)] if ni else []
+        if n - ni:
+            pick.append(ni + rng.choice(n - ni, min(2000, n - ni), replace=False))
+        rows = np.unique(np.concatenate(pick + [np.arange(max(n - 16, 0), n)]))
+        rsel = torch.from_numpy(rows).to(dev)
+
+        def sub(backward):
+            ia, nb = shard.csr(backward)
+            ent = np.concatenate([np.arange(ia[r] - 1, ia[r + 1] - 1) for r in rows])
+            cols, inv = np.unique(nb[ent].astype(np.int64) - 1, return_inverse=True)
+            sia = np.concatenate([[1], 1 + np.cumsum(ia[rows + 1] - ia[rows])]).astype(np.int32)
+            sja = np.zeros((2, ent.size), np.int32, order="F"); sja[0] = inv + 1
+            return cols, sia, sja
+
+        cols, sia, sja = sub(False)
+        xc = x_ext[torch.from_numpy(cols).to(dev)].cpu().numpy()
+        p_ref = oracle.kipf_propagate_rect(xc, sia, sja, shard.row_deg[rows], shard.col_deg[cols])
+        out["P_bit_exact"] = bool(np.array_equal(P[rsel].cpu().numpy(), p_ref))
+        z_ref = oracle.matmul(w_h, p_ref, F)
+        out["Z_rel"] = float(np.abs(Z[rsel].cpu().numpy() - z_ref).max() / np.abs(z_ref).max())
+        cols, sia, sja = sub(True)
+        dzc = x_ext[torch.from_numpy(cols).to(dev)].cpu().numpy()
+        ones = np.ones(max(rows.size, cols.size), np.int32)
+        dx_ref = oracle.kipf_propagate_rect(oracle.matmul_dx(w_h, dzc, F), sia, sja, ones[:rows.size], ones[:cols.size])
+        out["dX_rel"] = float(np.abs(dX[rsel].cpu().numpy() - dx_ref).max() / np.abs(dx_ref).max())
+        # the degrees of the halo columns came from their owners: equal to the generator's
+        ia_all, _ = None, None
+        held = shard.ext_ids >= 0
+        out["halo_ids_in_layout"] = bool(np.isin(shard.halo_ids, shard.ext_ids[held]).all())
+        torch.cuda.synchronize()
+    q.put((rank, out))
+    dist.barrier()
+    shard.close()
+    adist.c_comm_destroy()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("variant,check_rank,want_mode", [("uniform", 5, "allgather"), ("local", 3, "p2p")])
+def test_c5_shard_from_shard_create_with_eight_ranks(dev, variant, check_rank, want_mode):
+    """BASELINE configs[4] (10 M / 150 M / 256) partitioned 8 ways by athena_mp_shard_create ITSELF: eight processes on
+    the one GPU (shm test transport for the metadata collectives; no feature rows are exchanged -- the checked rank fills
+    its halo rows with what the exchange would deliver), every rank builds its real 1.25 M-row shard, the halo rule picks
+    the whole-block all-gather on the uniform graph (fraction 0.80) and packed rows on the locality variant, and one rank
+    runs the interior + boundary launches of the forward and of the reverse pull on the shard's own handles: P bit for
+    bit, Z and dX <= 1e-5 on sampled rows of both blocks against the oracle."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_c5_shard_worker, args=(r, world, port, variant, check_rank, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=1500) for _ in range(world))
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert res[r]["mode"] == want_mode, (r, res[r])
+        assert (res[r]["fraction"] > 0.7) == (want_mode == "allgather")
+    c = res[check_rank]
+    assert c["P_bit_exact"] and c["halo_ids_in_layout"]
+    assert c["Z_rel"] <= 1e-5 and c["dX_rel"] <= 1e-5, c
+    if variant == "local":
+        assert all(res[r]["n_int"] > 0 for r in range(world))
