@@ -310,6 +310,7 @@ def test_fortran_processes_run_the_sharded_step_through_the_c_abi(dev, oracle, t
 
 
 @pytest.mark.parametrize("argv,mode", [(["--gpus", "2"], "auto"),                        # the command the driver issues, C2 graph
+                                       (["--gpus", "8"], "auto"),                        # ... at N = 8 (halo fraction 0.68: packed rows)
                                        (["--gpus", "8", "--nodes", "200000", "--pairs", "900000"], "auto"),
                                        (["--gpus", "4", "--nodes", "200000", "--pairs", "900000"], "p2p"),
                                        (["--gpus", "2", "--config", "c5-local", "--nodes", "400000", "--pairs", "2800000"], "auto")])
@@ -343,6 +344,8 @@ def test_bench_py_multi_gpu_command_dry_run_on_one_device(dev, argv, mode):
             assert bd["halo_mode"] == "p2p"                 # a banded graph needs a sliver of its neighbours' blocks
         elif n == 2:
             assert bd["halo_mode"] == "allgather"           # uniform graph, 2 ranks: ~0.99 of the other block
+        elif argv == ["--gpus", "8"]:                       # configs[1] at N = 8: 1 - exp(-1.125) = 0.675 of the remote rows
+            assert 0.6 < bd["halo_fraction"] < 0.7 and bd["halo_mode"] == "p2p"
     else:
         assert bd["halo_mode"] == mode
     assert line["roofline"]["frac"] > 0 and line["roofline"]["dense"]["bound"] == "mfma"
