@@ -128,6 +128,10 @@ contains
        call this%output(1, s)%zero_grad()
        call this%output(1, s)%assign_and_deallocate_source(ptr3)
        this%output(1, s)%is_temporary = .false.
+       ! the edge of the HIP island: with athena_mp_resident_mode(1) the ops above left their results in HBM (P never
+       ! crossed PCIe); what the next layer reads on the host is materialised here.  A no-op when the mode is off.
+       if(athena_mp_resident_flush(c_loc(this%output(1, s)%val)) .ne. 0) &
+            call stop_program("update_message: "//athena_mp_error_message())
     end do
   end subroutine update_message_hip_kipf
 
