@@ -95,6 +95,9 @@ _PROTOS = {
     "athena_mp_gno_aggregate_bwd_x": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "athena_mp_gno_aggregate_bwd_theta": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
     "athena_mp_gno_aggregate_bwd_coords": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
+    "athena_mp_gno_saved_bytes": [_vp, _i32, _i32, _i32, _i32, C.POINTER(C.c_int64)],
+    "athena_mp_gno_aggregate_fwd_save": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
+    "athena_mp_gno_aggregate_bwd_theta_saved": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "athena_mp_comm_unique_id": [_vp],
     "athena_mp_comm_create": [_i32, _i32, _vp, C.POINTER(_vp)],
     "athena_mp_comm_create_from_file": [_i32, _i32, C.c_char_p, C.POINTER(_vp)],

@@ -201,7 +201,19 @@ __global__ __launch_bounds__(256) void gno_outer_mfma_kernel(const int32_t *__re
 //            outputs of its vertex; the 4 s-steps of a wave's slice are split over the 16 waves.
 // The per-wave partial sums are added through LDS in wave order (deterministic).
 typedef float v4f_g __attribute__((ext_vector_type(4)));
+typedef unsigned int v4u_g __attribute__((ext_vector_type(4)));
 #ifndef GNO_FV
+// how gno_pc_kernel<true> writes the S it keeps: 0 nontemporal global stores, 1 plain stores, 2 buffer stores with the cache
+// bits GNO_SAVE_AUX (1 sc0, 2 nt, 16 sc1), 3 none (timing only).  configs[3], ms per launch, two runs each on one box
+// (scripts/gpu_keeps_ab.sh): plain 14.65 / 14.74, nt global 14.21 / 14.28, buffer nt 14.05 / 14.08, buffer sc0 sc1 nt 14.07 / 14.09,
+// buffer sc0 sc1 14.39 / 14.40, none 11.88 / 11.89 (= the kernel without the copy: the LDS reads of the copy cost nothing,
+// the 33 GB of writes make the launch HBM bound: 63 GB in 14.05 ms = 4.5 TB/s)
+#ifndef GNO_SAVE_MODE
+#define GNO_SAVE_MODE 2
+#endif
+#ifndef GNO_SAVE_AUX
+#define GNO_SAVE_AUX 2
+#endif
 #define GNO_FV 0   // timing-only variants (scripts/build_variants.sh), bit mask: 1 no sparse loop, 2 no V loads, 4 no S reads, 8 no contraction, 16 no cross-wave reduction (gno_fused_kernel); 32 idle producers, 64 idle consumers (gno_pc_kernel)
 #endif
 constexpr int kGF = 64, kGH = 64, kGRows = 16, kGSP = 33 * kGF + 4;   // LDS row pitch of S_half
@@ -446,21 +458,33 @@ int length_order(const int32_t *rowptr_dev, int n_rows, int32_t **perm_dev, int3
 
 int launch_gno_pc(const int32_t *rowptr, const int32_t *idx, const int32_t *eidx, const float *y, const float *coords,
                   const float *theta, int d, const float *Vaug, int n_rows, const int32_t *perm, float *out, size_t y_bytes,
-                  size_t c_bytes, size_t id_bytes);
+                  size_t c_bytes, size_t id_bytes, float *save = nullptr);
+
+// the producer / consumer kernels address their gathers through buffer descriptors (32-bit byte offsets, d <= 3)
+bool gno_pc_route(int d, int y_rows, int n_edge_cols, int64_t nnz)
+{
+    static const bool v1 = getenv("ATHENA_MP_GNO_FUSED_V1") != nullptr;   // A/B switch: the one-phase-at-a-time kernel
+    const size_t y_bytes = sizeof(float) * kGF * (size_t)y_rows, c_bytes = sizeof(float) * (size_t)d * n_edge_cols,
+                 id_bytes = sizeof(int32_t) * (size_t)nnz;
+    const size_t lim = 0xFFFFE000ull;   // below the kernel's dead-slot offset
+    return d <= 3 && !v1 && y_bytes < lim && c_bytes < lim && id_bytes < lim;
+}
 
 int launch_gno_fused(const int32_t *rowptr, const int32_t *idx, const int32_t *eidx, const float *y,
                      const float *coords, const float *theta, int d, const float *Vaug, int n_rows,
                      int32_t **perm_cache, float *out, int y_rows, int n_edge_cols, int64_t nnz, int32_t *n_long = nullptr,
-                     int32_t *n_mid = nullptr)
+                     int32_t *n_mid = nullptr, float *save = nullptr)
 {
     if (n_rows > 0 && length_order(rowptr, n_rows, perm_cache, n_long, n_mid)) return 1;
-    static const bool v1 = getenv("ATHENA_MP_GNO_FUSED_V1") != nullptr;   // A/B switch: the one-phase-at-a-time kernel
-    // the producer / consumer kernel addresses its gathers through buffer descriptors (32-bit byte offsets)
     const size_t y_bytes = sizeof(float) * kGF * (size_t)y_rows, c_bytes = sizeof(float) * (size_t)d * n_edge_cols,
                  id_bytes = sizeof(int32_t) * (size_t)nnz;
-    const size_t lim = 0xFFFFE000ull;   // below the kernel's dead-slot offset
-    if (d <= 3 && !v1 && y_bytes < lim && c_bytes < lim && id_bytes < lim)
-        return launch_gno_pc(rowptr, idx, eidx, y, coords, theta, d, Vaug, n_rows, *perm_cache, out, y_bytes, c_bytes, id_bytes);
+    if (gno_pc_route(d, y_rows, n_edge_cols, nnz))
+        return launch_gno_pc(rowptr, idx, eidx, y, coords, theta, d, Vaug, n_rows, *perm_cache, out, y_bytes, c_bytes, id_bytes,
+                             save);
+    if (save) {
+        amp::set_error("gno_aggregate_fwd_save: this shape does not take the kernel that keeps S (athena_mp_gno_saved_bytes says so)");
+        return 2;
+    }
     constexpr size_t lds = sizeof(float) * (size_t)kGRows * kGSP;
     static amp::PerDeviceFlag attr;
     if (!attr.get()) {
@@ -720,12 +744,20 @@ struct GnoProd {
 };
 
 
+// SAVE (training-mode forward, athena_mp_gno_aggregate_fwd_save): the consumers also copy every piece of S, as it lies in
+// LDS, to `save` -- [tile][piece][vertex slot 32][512] + bias rows [tile][32][64] behind the pieces -- so that the reverse
+// pass's S^T g needs no producers (gno_stg_kernel<true>).  33 GB at BASELINE configs[3]: HBM capacity bought back as time.
+// Wave ot copies slots 8 ot .. 8 ot + 7 of the piece in the last two rounds (one contiguous KB per store); the MFMA
+// rounds themselves are untouched, so `out` has the same bits as without the copy.
+constexpr size_t kSavePiece = 32 * 512, kSaveTile = 8 * kSavePiece + 32 * 64;   // words
+template <bool SAVE>
 __global__ __launch_bounds__(kPcThreads) void gno_pc_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ idx,
                                                       const int32_t *__restrict__ eidx, const float *__restrict__ y,
                                                       const float *__restrict__ coords, const float *__restrict__ theta,
                                                       int d, const float *__restrict__ Vp, int n_rows,
                                                       const int32_t *__restrict__ perm, float *__restrict__ out,
-                                                      uint32_t y_bytes, uint32_t c_bytes, uint32_t id_bytes)
+                                                      uint32_t y_bytes, uint32_t c_bytes, uint32_t id_bytes,
+                                                      float *__restrict__ save)
 {
     extern __shared__ __attribute__((aligned(16))) float Sh[];
     float *Sbuf = Sh;                                   // [2][32][520]
@@ -920,6 +952,36 @@ __global__ __launch_bounds__(kPcThreads) void gno_pc_kernel(const int32_t *__res
                         }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) a[u] = an[u];
+                    if constexpr (SAVE) {
+                        if (rd >= 6) {   // this wave's quarter of the piece: slots 8 ot + 4 (rd - 6) .. + 3, 2 KB each
+                            const float *src = Sbuf + (size_t)((ti * 8 + pc) & 1) * kPV * kPPitch + 4 * lane;
+                            float *dst = save + (size_t)tile * kSaveTile + (size_t)pc * kSavePiece + 4 * lane;
+                            // (a descriptor per tile: the 33 GB lie beyond what one descriptor addresses)
+                            [[maybe_unused]] const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
+                                (void *)(save + (size_t)tile * kSaveTile), 0, (int)(kSaveTile * 4), 0x00020000);
+                            v4f_g cp[8];
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                const int v = 8 * ot + 4 * (rd - 6) + (i >> 1);
+                                cp[i] = *reinterpret_cast<const v4f_g *>(src + (size_t)v * kPPitch + 256 * (i & 1));
+                            }
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                const int v = 8 * ot + 4 * (rd - 6) + (i >> 1);
+#if GNO_SAVE_MODE == 0
+                                __builtin_nontemporal_store(cp[i], reinterpret_cast<v4f_g *>(dst + (size_t)v * 512 + 256 * (i & 1)));
+#elif GNO_SAVE_MODE == 1
+                                *reinterpret_cast<v4f_g *>(dst + (size_t)v * 512 + 256 * (i & 1)) = cp[i];
+#elif GNO_SAVE_MODE == 3
+                                (void)dst;
+                                asm volatile("" ::"v"(cp[i]));
+#else
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_g, cp[i]), srs,
+                                    (int)(((size_t)pc * kSavePiece + (size_t)v * 512 + 256 * (i & 1) + 4 * lane) * 4), 0, GNO_SAVE_AUX);
+#endif
+                            }
+                        }
+                    }
                 }
                 if (pc == 7) {
                     // the bias piece: 64 words = four groups of 16; a[0..3] hold its V rows
@@ -933,6 +995,16 @@ __global__ __launch_bounds__(kPcThreads) void gno_pc_kernel(const int32_t *__res
                         for (int s = 0; s < 4; ++s) {
                             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][s], b0[s], acc0, 0, 0, 0);
                             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][s], b1[s], acc1, 0, 0, 0);
+                        }
+                    }
+                    if constexpr (SAVE) {   // the tile's bias rows: slots 8 ot .. + 7, 256 B each
+                        const float *src = Bbuf + (size_t)(ti & 1) * kPV * kPBPitch + 4 * n;
+                        float *dst = save + (size_t)tile * kSaveTile + 8 * kSavePiece + 4 * n;
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            const int v = 8 * ot + 4 * i + g;
+                            const v4f_g t = *reinterpret_cast<const v4f_g *>(src + (size_t)v * kPBPitch);
+                            __builtin_nontemporal_store(t, reinterpret_cast<v4f_g *>(dst + (size_t)v * 64));
                         }
                     }
 #pragma unroll
@@ -960,13 +1032,18 @@ constexpr int kGPitch = 72;
 constexpr int kStgLdsFloats = 2 * kPV * kPPitch + 2 * kPV * kGPitch;
 constexpr int kStgGrid = 256;   // 8 pieces x 32 tile classes
 
+// SAVED: S was kept by the forward pass (gno_pc_kernel<true>); the producers only copy the workgroup's piece of each tile
+// (64 KB, one contiguous 2 KB row per slot) and the tile's gradient rows into LDS one tile ahead -- no ids, no gathers, no
+// MFMAs of their own except the bias row's.  The consumers are the same code, so dV has the same bits either way.
+template <bool SAVED>
 __global__ __launch_bounds__(kPcThreads) void gno_stg_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ idx,
                                                        const int32_t *__restrict__ eidx, const float *__restrict__ y,
                                                        const float *__restrict__ coords, const float *__restrict__ theta,
                                                        int d, const float *__restrict__ grad, int n_rows,
                                                        const int32_t *__restrict__ perm, float *__restrict__ slab,
                                                        float *__restrict__ slabB, uint32_t y_bytes, uint32_t c_bytes,
-                                                       uint32_t id_bytes, uint32_t g_bytes, int nsub, int grouped)
+                                                       uint32_t id_bytes, uint32_t g_bytes, int nsub, int grouped,
+                                                       const float *__restrict__ save)
 {
     extern __shared__ __attribute__((aligned(16))) float Sh[];
     float *Sbuf = Sh;                                   // [2][32][520]
@@ -1002,6 +1079,46 @@ __global__ __launch_bounds__(kPcThreads) void gno_stg_kernel(const int32_t *__re
             for (int ot = 0; ot < 4; ++ot)
                 GV[ot] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, (int)off, 64 * ot, 0));
         };
+        const v4f_g z = {0.0f, 0.0f, 0.0f, 0.0f};
+        v4f_g accB[4] = {z, z, z, z};   // bias rows: [o = 16 ot + 4 g + r][q = 16 c + n], kh = 0 workgroups only
+        if constexpr (SAVED) {
+            const int pcF = 4 * kh + c;   // the piece's number in the forward kernel's order
+            GnoIds T0, T1, T2;            // row numbers only (for the gradient rows), two tiles ahead
+            P.ids_rows(sub, T0);
+            P.ids_rows(sub + nsub, T1);
+            T2 = T1;
+            v4f_g R[8];
+            float bsel, GV[4];
+            auto load_tile = [&](int tl) {   // beyond the last tile: the last tile again (never consumed)
+                const float *base = save + (size_t)min(tl, n_tiles - 1) * kSaveTile;
+                const float *src = base + (size_t)pcF * kSavePiece + 4 * lane;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    R[i] = __builtin_nontemporal_load(reinterpret_cast<const v4f_g *>(src + (size_t)(4 * p + (i >> 1)) * 512 + 256 * (i & 1)));
+                bsel = base[8 * kSavePiece + (size_t)(4 * p + g) * 64 + 16 * c + n];
+            };
+            load_tile(sub);
+            load_g(GV, T0);
+#pragma unroll 1
+            for (int j = 0; j < nt; ++j) {
+                P.ids_rows(sub + nsub * (j + 2), T2);
+                float *buf = Sbuf + (size_t)(j & 1) * kPV * kPPitch + 4 * lane;
+                float *gb = Gbuf + (size_t)(j & 1) * kPV * kGPitch;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    *reinterpret_cast<v4f_g *>(buf + (size_t)(4 * p + (i >> 1)) * kPPitch + 256 * (i & 1)) = R[i];
+#pragma unroll
+                for (int ot = 0; ot < 4; ++ot) gb[(4 * p + g) * kGPitch + 16 * ot + n] = GV[ot];
+                if (kh == 0) {
+#pragma unroll
+                    for (int ot = 0; ot < 4; ++ot) accB[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(GV[ot], bsel, accB[ot], 0, 0, 0);
+                }
+                load_tile(sub + nsub * (j + 1));
+                load_g(GV, T1);
+                __syncthreads();
+                T0 = T1; T1 = T2;
+            }
+        } else {
         // the ids of the workgroup's tiles: a four-deep queue, one dependent step per tile interval
         //   T4 row numbers (issued now) | T3 row pointers | T2 entries | T1 offsets: the tile whose operands are requested
         //   during this interval | T0 the tile being built
@@ -1019,8 +1136,6 @@ __global__ __launch_bounds__(kPcThreads) void gno_stg_kernel(const int32_t *__re
             P.load_cv(CV[vi], T0.E0, T0.E1, vi);
         }
         load_g(GV, T0);
-        const v4f_g z = {0.0f, 0.0f, 0.0f, 0.0f};
-        v4f_g accB[4] = {z, z, z, z};   // bias rows: [o = 16 ot + 4 g + r][q = 16 c + n], kh = 0 workgroups only
 #pragma unroll 1
         for (int j = 0; j < nt; ++j) {
             P.ids_rows(sub + nsub * (j + 4), T4);
@@ -1060,6 +1175,16 @@ __global__ __launch_bounds__(kPcThreads) void gno_stg_kernel(const int32_t *__re
             case 7: four(std::integral_constant<int, 7>{}); break;
             default: four(std::integral_constant<int, 8>{}); break;
             }
+            // column sums of the feature quarter (the bias row of S): every lane (n, any g) ends with the total.  A row's first
+            // 32 entries and each further block are reduced across the lane groups BEFORE they are added up -- the order of
+            // gno_pc_kernel, so that the S it keeps and the S built here give the same bits
+            if (kh == 0) {
+#pragma unroll
+                for (int vi = 0; vi < 4; ++vi) {
+                    bsv[vi] = bsv[vi] + __shfl_xor(bsv[vi], 16);
+                    bsv[vi] = bsv[vi] + __shfl_xor(bsv[vi], 32);
+                }
+            }
             if (maxlen > 32) {   // rows longer than 32 entries: the remaining blocks are added to the vertex's own LDS row
 #pragma unroll 1
                 for (int vi = 0; vi < 4; ++vi) {
@@ -1074,6 +1199,8 @@ __global__ __launch_bounds__(kPcThreads) void gno_stg_kernel(const int32_t *__re
                         for (int t = 0; t < 2; ++t)
 #pragma unroll
                             for (int r2 = 0; r2 < 4; ++r2) srow[(16 * t + 4 * r2 + g) * 16 + n] += acc[t][r2];
+                        bs = bs + __shfl_xor(bs, 16);
+                        bs = bs + __shfl_xor(bs, 32);
                         if (vi == 0) bsv[0] += bs; else if (vi == 1) bsv[1] += bs; else if (vi == 2) bsv[2] += bs; else bsv[3] += bs;
                     }
                 }
@@ -1082,11 +1209,6 @@ __global__ __launch_bounds__(kPcThreads) void gno_stg_kernel(const int32_t *__re
 #pragma unroll
             for (int ot = 0; ot < 4; ++ot) gb[(4 * p + g) * kGPitch + 16 * ot + n] = GV[ot];
             if (kh == 0) {
-#pragma unroll
-                for (int vi = 0; vi < 4; ++vi) {   // column sums of the feature quarter: every lane (n, any g) ends with the total
-                    bsv[vi] = bsv[vi] + __shfl_xor(bsv[vi], 16);
-                    bsv[vi] = bsv[vi] + __shfl_xor(bsv[vi], 32);
-                }
                 const float bsel = g == 0 ? bsv[0] : g == 1 ? bsv[1] : g == 2 ? bsv[2] : bsv[3];
 #pragma unroll
                 for (int ot = 0; ot < 4; ++ot) accB[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(GV[ot], bsel, accB[ot], 0, 0, 0);
@@ -1094,6 +1216,7 @@ __global__ __launch_bounds__(kPcThreads) void gno_stg_kernel(const int32_t *__re
             load_g(GV, T1);
             __syncthreads();
             T0 = T1; T1 = T2; T2 = T3; T3 = T4;
+        }
         }
         __syncthreads();   // the consumers' last tile
         if (kh == 0) {     // bias rows: the eight waves' parts meet in LDS (S is done with), waves 0-3 add them up
@@ -1190,7 +1313,7 @@ bool gno_stg_shape(int H, int Fi, int Fo, int d)
 }
 
 int launch_gno_stg(const athena_mp_graph *g, const float *x, const float *coords, const float *theta, int d, const float *grad,
-                   float *dV)
+                   float *dV, const float *save = nullptr)
 {
     const size_t y_bytes = sizeof(float) * kGF * (size_t)g->n_cols, c_bytes = sizeof(float) * (size_t)d * g->n_edge_cols,
                  id_bytes = sizeof(int32_t) * (size_t)g->nnz, g_bytes = sizeof(float) * kGF * (size_t)g->n_rows;
@@ -1200,7 +1323,8 @@ int launch_gno_stg(const athena_mp_graph *g, const float *x, const float *coords
     constexpr size_t lds = sizeof(float) * (size_t)kStgLdsFloats;
     static amp::PerDeviceFlag attr;
     if (!attr.get()) {
-        AMP_HIP(hipFuncSetAttribute((const void *)gno_stg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        AMP_HIP(hipFuncSetAttribute((const void *)gno_stg_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        AMP_HIP(hipFuncSetAttribute((const void *)gno_stg_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr.get() = true;
     }
     void *slab = nullptr, *slabB = nullptr;
@@ -1214,9 +1338,15 @@ int launch_gno_stg(const athena_mp_graph *g, const float *x, const float *coords
         return e && strcmp(e, "spread") == 0;
     }();
     const int grouped = (!want_spread && nsub % 8 == 0) ? 1 : 0;   // the eight pieces of a tile class on one XCD (one L2)
-    hipLaunchKernelGGL(gno_stg_kernel, dim3(8 * nsub), dim3(kPcThreads), lds, amp::stream(), g->rowptr, g->col, g->eid, x, coords,
-                       theta, d, grad, g->n_rows, (const int32_t *)g->len_perm_fwd, (float *)slab, (float *)slabB,
-                       (uint32_t)y_bytes, (uint32_t)c_bytes, (uint32_t)id_bytes, (uint32_t)g_bytes, nsub, grouped);
+    if (save)
+        hipLaunchKernelGGL(gno_stg_kernel<true>, dim3(8 * nsub), dim3(kPcThreads), lds, amp::stream(), g->rowptr, g->col, g->eid, x,
+                           coords, theta, d, grad, g->n_rows, (const int32_t *)g->len_perm_fwd, (float *)slab, (float *)slabB,
+                           (uint32_t)y_bytes, (uint32_t)c_bytes, (uint32_t)id_bytes, (uint32_t)g_bytes, nsub, grouped, save);
+    else
+        hipLaunchKernelGGL(gno_stg_kernel<false>, dim3(8 * nsub), dim3(kPcThreads), lds, amp::stream(), g->rowptr, g->col, g->eid, x,
+                           coords, theta, d, grad, g->n_rows, (const int32_t *)g->len_perm_fwd, (float *)slab, (float *)slabB,
+                           (uint32_t)y_bytes, (uint32_t)c_bytes, (uint32_t)id_bytes, (uint32_t)g_bytes, nsub, grouped,
+                           (const float *)nullptr);
     AMP_LAUNCH_CHECK();
     hipLaunchKernelGGL(gno_stg_reduce_kernel, dim3((65 * 64 * 64 + 255) / 256), dim3(256), 0, amp::stream(), (const float *)slab,
                        (const float *)slabB, dV, nsub);
@@ -1226,12 +1356,13 @@ int launch_gno_stg(const athena_mp_graph *g, const float *x, const float *coords
 
 int launch_gno_pc(const int32_t *rowptr, const int32_t *idx, const int32_t *eidx, const float *y, const float *coords,
                   const float *theta, int d, const float *Vaug, int n_rows, const int32_t *perm, float *out, size_t y_bytes,
-                  size_t c_bytes, size_t id_bytes)
+                  size_t c_bytes, size_t id_bytes, float *save)
 {
     constexpr size_t lds = sizeof(float) * (size_t)kPcLdsFloats;
     static amp::PerDeviceFlag attr;
     if (!attr.get()) {
-        AMP_HIP(hipFuncSetAttribute((const void *)gno_pc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        AMP_HIP(hipFuncSetAttribute((const void *)gno_pc_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        AMP_HIP(hipFuncSetAttribute((const void *)gno_pc_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr.get() = true;
     }
     if (n_rows <= 0) return 0;
@@ -1240,9 +1371,14 @@ int launch_gno_pc(const int32_t *rowptr, const int32_t *idx, const int32_t *eidx
     hipLaunchKernelGGL(gno_vrelay_kernel, dim3((65 * 64 * 64 + 255) / 256), dim3(256), 0, amp::stream(), Vaug, (float *)vp);
     AMP_LAUNCH_CHECK();
     const int n_tiles = (n_rows + kPV - 1) / kPV;
-    hipLaunchKernelGGL(gno_pc_kernel, dim3(std::min(n_tiles, amp::num_cus())), dim3(kPcThreads), lds, amp::stream(), rowptr, idx,
-                       eidx, y, coords, theta, d, (const float *)vp, n_rows, perm, out, (uint32_t)y_bytes, (uint32_t)c_bytes,
-                       (uint32_t)id_bytes);
+    if (save)
+        hipLaunchKernelGGL(gno_pc_kernel<true>, dim3(std::min(n_tiles, amp::num_cus())), dim3(kPcThreads), lds, amp::stream(), rowptr,
+                           idx, eidx, y, coords, theta, d, (const float *)vp, n_rows, perm, out, (uint32_t)y_bytes,
+                           (uint32_t)c_bytes, (uint32_t)id_bytes, save);
+    else
+        hipLaunchKernelGGL(gno_pc_kernel<false>, dim3(std::min(n_tiles, amp::num_cus())), dim3(kPcThreads), lds, amp::stream(), rowptr,
+                           idx, eidx, y, coords, theta, d, (const float *)vp, n_rows, perm, out, (uint32_t)y_bytes,
+                           (uint32_t)c_bytes, (uint32_t)id_bytes, (float *)nullptr);
     AMP_LAUNCH_CHECK();
     return 0;
 }
@@ -2153,6 +2289,50 @@ int athena_mp_gno_aggregate_fwd(const athena_mp_graph *g, int32_t d, int32_t H, 
         if (rc) return rc;
     }
     return 0;
+}
+
+// ---- training-mode pair: the forward pass keeps S for the reverse pass's S^T g ---------------------------------------
+int athena_mp_gno_saved_bytes(const athena_mp_graph *g, int32_t d, int32_t H, int32_t Fi, int32_t Fo, int64_t *bytes)
+{
+    if (!gno_args_ok(g, d, H, Fi, Fo)) return 2;
+    AMP_REQUIRE(bytes, "gno_saved_bytes: null pointer");
+    const bool ok = g->n_rows > 0 && gno_fused_shape(H, Fi, Fo, d) && gno_stg_shape(H, Fi, Fo, d) &&
+                    gno_pc_route(d, g->n_cols, g->n_edge_cols, g->nnz) &&
+                    sizeof(float) * kGF * (size_t)g->n_rows < 0xFFFFE000ull;
+    const int64_t n_tiles = (g->n_rows + kPV - 1) / kPV;
+    *bytes = ok ? (int64_t)sizeof(float) * n_tiles * (int64_t)kSaveTile : 0;
+    return 0;
+}
+
+int athena_mp_gno_aggregate_fwd_save(const athena_mp_graph *g, int32_t d, int32_t H, int32_t Fi, int32_t Fo,
+                                     const float *theta, const float *coords, const float *x, float *m, float *s_save)
+{
+    if (!gno_args_ok(g, d, H, Fi, Fo)) return 2;
+    AMP_REQUIRE(theta && coords && x && m && s_save, "gno_aggregate_fwd_save: null pointer");
+    int64_t bytes = 0;
+    if (int rc = athena_mp_gno_saved_bytes(g, d, H, Fi, Fo, &bytes)) return rc;
+    AMP_REQUIRE(bytes > 0, "gno_aggregate_fwd_save: this shape does not keep S (athena_mp_gno_saved_bytes returned 0)");
+    const size_t off_V = (size_t)H * d + H;
+    return launch_gno_fused(g->rowptr, g->col, g->eid, x, coords, theta, d, theta + off_V, g->n_rows, &g->len_perm_fwd, m,
+                            g->n_cols, g->n_edge_cols, g->nnz, &g->n_long_fwd, &g->n_mid_fwd, s_save);
+}
+
+int athena_mp_gno_aggregate_bwd_theta_saved(const athena_mp_graph *g, int32_t d, int32_t H, int32_t Fi, int32_t Fo,
+                                            const float *theta, const float *coords, const float *x, const float *grad,
+                                            const float *s_save, float *dtheta)
+{
+    if (!gno_args_ok(g, d, H, Fi, Fo)) return 2;
+    AMP_REQUIRE(theta && coords && x && grad && s_save && dtheta, "gno_aggregate_bwd_theta_saved: null pointer");
+    int64_t bytes = 0;
+    if (int rc = athena_mp_gno_saved_bytes(g, d, H, Fi, Fo, &bytes)) return rc;
+    AMP_REQUIRE(bytes > 0, "gno_aggregate_bwd_theta_saved: this shape does not keep S (athena_mp_gno_saved_bytes returned 0)");
+    const size_t off_V = (size_t)H * d + H;
+    const int rc = launch_gno_stg(g, x, coords, theta, d, grad, dtheta + off_V, s_save);
+    if (rc) {
+        if (rc < 0) set_error("gno_aggregate_bwd_theta_saved: tensors beyond the 4 GB a buffer descriptor addresses");
+        return rc < 0 ? 2 : rc;
+    }
+    return gno_mlp_backward(g, d, H, Fi, Fo, theta, coords, x, grad, dtheta, nullptr);
 }
 
 int athena_mp_gno_aggregate_bwd_x(const athena_mp_graph *g, int32_t d, int32_t H, int32_t Fi, int32_t Fo,

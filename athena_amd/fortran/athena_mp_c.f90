@@ -39,6 +39,7 @@ module athena_mp_c
   public :: athena_mp_segment_sum, athena_mp_segment_sum_bwd
   public :: athena_mp_gno_aggregate_fwd, athena_mp_gno_aggregate_bwd_x, athena_mp_gno_aggregate_bwd_theta
   public :: athena_mp_gno_aggregate_bwd_coords
+  public :: athena_mp_gno_saved_bytes, athena_mp_gno_aggregate_fwd_save, athena_mp_gno_aggregate_bwd_theta_saved
   public :: athena_mp_duvenaud_readout_fwd, athena_mp_duvenaud_readout_bwd, athena_mp_duvenaud_update_act_fwd
   public :: athena_mp_kipf_layer_fwd, athena_mp_kipf_layer_bwd_x, athena_mp_activation_bwd
   public :: athena_mp_csr_from_edges, athena_mp_graph_export, athena_mp_graph_create_from_edges
@@ -623,6 +624,25 @@ module athena_mp_c
           grad_dev, dcoords_dev) bind(C, name="athena_mp_gno_aggregate_bwd_coords")
        import :: c_int, c_int32_t, c_ptr
        type(c_ptr), value :: graph, theta_dev, coords_dev, x_dev, grad_dev, dcoords_dev
+       integer(c_int32_t), value :: d, H, Fi, Fo
+     end function
+     !! training-mode pair: the forward pass keeps S (bytes from _saved_bytes; 0 = shape not served) for dVaug = S^T g
+     integer(c_int) function athena_mp_gno_saved_bytes(graph, d, H, Fi, Fo, bytes) bind(C, name="athena_mp_gno_saved_bytes")
+       import :: c_int, c_int32_t, c_int64_t, c_ptr
+       type(c_ptr), value :: graph
+       integer(c_int32_t), value :: d, H, Fi, Fo
+       integer(c_int64_t), intent(out) :: bytes
+     end function
+     integer(c_int) function athena_mp_gno_aggregate_fwd_save(graph, d, H, Fi, Fo, theta_dev, coords_dev, x_dev, m_dev, &
+          s_save_dev) bind(C, name="athena_mp_gno_aggregate_fwd_save")
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: graph, theta_dev, coords_dev, x_dev, m_dev, s_save_dev
+       integer(c_int32_t), value :: d, H, Fi, Fo
+     end function
+     integer(c_int) function athena_mp_gno_aggregate_bwd_theta_saved(graph, d, H, Fi, Fo, theta_dev, coords_dev, x_dev, &
+          grad_dev, s_save_dev, dtheta_dev) bind(C, name="athena_mp_gno_aggregate_bwd_theta_saved")
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: graph, theta_dev, coords_dev, x_dev, grad_dev, s_save_dev, dtheta_dev
        integer(c_int32_t), value :: d, H, Fi, Fo
      end function
      !! ---- multi-GPU (csrc/comm.hip): one process per GPU, RCCL over xGMI ------------------------------------------

@@ -130,6 +130,13 @@ module athena_mp_layers
      type(mp_actv_type) :: activation
      type(dbuf) :: x_in, c_in, up_in, z_pre, y_out, ones, dc_out, scratch(3)
      type(c_ptr) :: x_tape = c_null_ptr, c_tape = c_null_ptr     ! the forward inputs (caller-owned in forward_dev)
+     !! keep_s: the forward pass keeps S = sum_e [h_e;1] x_j^T per vertex for the reverse pass's dVaug = S^T g (the
+     !! reference keeps every forward intermediate on its tape) whenever the shape takes the kernels that do and S is at
+     !! most ATHENA_MP_GNO_KEEP_S_MAX_GB (default 64; BASELINE configs[3]: 33 of the 288 GB).  Same results bit for bit.
+     logical :: keep_s = .true.
+     logical :: s_valid = .false.
+     type(dbuf) :: s_save
+     type(c_ptr) :: s_graph = c_null_ptr                         ! the handle s_save was built on
    contains
      procedure, pass(this) :: forward => gno_forward
      procedure, pass(this) :: backward => gno_backward
@@ -176,6 +183,18 @@ contains
     b%p = c_null_ptr
     b%cap = 0_c_int64_t
   end subroutine release
+
+  real function keep_s_max_gb()
+    !! ATHENA_MP_GNO_KEEP_S_MAX_GB: the largest S a graph_nop layer keeps between forward and backward (default 64)
+    character(32) :: v
+    integer :: stat, ios
+    keep_s_max_gb = 64.
+    call get_environment_variable("ATHENA_MP_GNO_KEEP_S_MAX_GB", v, status=stat)
+    if(stat .eq. 0)then
+       read(v, *, iostat=ios) keep_s_max_gb
+       if(ios .ne. 0) keep_s_max_gb = 64.
+    end if
+  end function keep_s_max_gb
 
   pure integer(c_int64_t) function i8(n)
     integer, intent(in) :: n
@@ -1236,6 +1255,7 @@ contains
     type(c_ptr) :: y_dev
     type(c_ptr) :: bias
     integer :: n, fi, fo
+    integer(c_int64_t) :: s_bytes
 
     if(.not. c_associated(this%graph)) call stop_program("set_graph must be called before forward")
     n = this%nv
@@ -1246,8 +1266,21 @@ contains
     call need(this%z_pre, i8(n) * i8(fo))
     call need(this%y_out, i8(n) * i8(fo))
     call need(this%scratch(1), i8(n) * i8(max(fi, fo)))
-    call chk(athena_mp_gno_aggregate_fwd(this%graph, int(this%coord_dim, c_int32_t), int(this%kernel_hidden, c_int32_t), &
-         int(fi, c_int32_t), int(fo, c_int32_t), this%params(1)%p, coords_dev, x_dev, this%scratch(1)%p), "gno_aggregate")
+    this%s_valid = .false.
+    s_bytes = 0_c_int64_t
+    if(this%keep_s) call chk(athena_mp_gno_saved_bytes(this%graph, int(this%coord_dim, c_int32_t), &
+         int(this%kernel_hidden, c_int32_t), int(fi, c_int32_t), int(fo, c_int32_t), s_bytes), "gno_saved_bytes")
+    if(s_bytes .gt. 0_c_int64_t .and. real(s_bytes) .le. keep_s_max_gb() * 1.e9)then
+       call need(this%s_save, s_bytes / 4_c_int64_t)
+       call chk(athena_mp_gno_aggregate_fwd_save(this%graph, int(this%coord_dim, c_int32_t), int(this%kernel_hidden, c_int32_t), &
+            int(fi, c_int32_t), int(fo, c_int32_t), this%params(1)%p, coords_dev, x_dev, this%scratch(1)%p, this%s_save%p), &
+            "gno_aggregate (S kept)")
+       this%s_valid = .true.
+       this%s_graph = this%graph
+    else
+       call chk(athena_mp_gno_aggregate_fwd(this%graph, int(this%coord_dim, c_int32_t), int(this%kernel_hidden, c_int32_t), &
+            int(fi, c_int32_t), int(fo, c_int32_t), this%params(1)%p, coords_dev, x_dev, this%scratch(1)%p), "gno_aggregate")
+    end if
     bias = c_null_ptr
     if(this%use_bias) bias = this%params(3)%p
     call chk(athena_mp_gemm_fwd(i8(n), int(fi, c_int32_t), int(fo, c_int32_t), x_dev, this%params(2)%p, bias, &
@@ -1333,8 +1366,14 @@ contains
        this%has_grad(3) = .true.
     end if
     call chk(athena_mp_gemm_dw(i8(n), int(fi, c_int32_t), int(fo, c_int32_t), this%x_tape, dz, this%grads(2)%p), "gemm_dw")
-    call chk(athena_mp_gno_aggregate_bwd_theta(this%graph, int(d, c_int32_t), int(h, c_int32_t), int(fi, c_int32_t), &
-         int(fo, c_int32_t), this%params(1)%p, this%c_tape, this%x_tape, dz, this%grads(1)%p), "gno reverse (theta)")
+    if(this%s_valid .and. c_associated(this%s_graph, this%graph))then
+       call chk(athena_mp_gno_aggregate_bwd_theta_saved(this%graph, int(d, c_int32_t), int(h, c_int32_t), int(fi, c_int32_t), &
+            int(fo, c_int32_t), this%params(1)%p, this%c_tape, this%x_tape, dz, this%s_save%p, this%grads(1)%p), &
+            "gno reverse (theta, S kept)")
+    else
+       call chk(athena_mp_gno_aggregate_bwd_theta(this%graph, int(d, c_int32_t), int(h, c_int32_t), int(fi, c_int32_t), &
+            int(fo, c_int32_t), this%params(1)%p, this%c_tape, this%x_tape, dz, this%grads(1)%p), "gno reverse (theta)")
+    end if
     this%has_grad(1:2) = .true.
     if(present(dx_dev))then
        call chk(athena_mp_gemm_dx(i8(n), int(fi, c_int32_t), int(fo, c_int32_t), dz, this%params(2)%p, this%scratch(3)%p), "gemm_dx")
@@ -1358,7 +1397,8 @@ contains
     class(graph_nop_mp_layer_type), intent(inout) :: this
     integer :: t
     call release(this%x_in); call release(this%c_in); call release(this%z_pre); call release(this%y_out)
-    call release(this%up_in); call release(this%ones); call release(this%dc_out)
+    call release(this%up_in); call release(this%ones); call release(this%dc_out); call release(this%s_save)
+    this%s_valid = .false.
     do t = 1, 3
        call release(this%scratch(t))
     end do

@@ -16,6 +16,8 @@ callbacks diffstruc's `grad_reverse` would invoke for this layer
 
 No CPU fallback: every op goes through libathena_mp.so.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -448,8 +450,14 @@ class graph_nop_layer_type(msgpass_layer_type):
 
     def __init__(self, num_outputs, coord_dim, kernel_hidden=None, num_inputs=None, use_bias=True,
                  activation="none", kernel_initialiser=None, bias_initialiser=None, verbose=0,
-                 device="cuda:0", seed=0):
+                 device="cuda:0", seed=0, keep_s=None):
         super().__init__(device, seed)
+        # keep_s: the forward pass keeps S = sum_e [h_e;1] x_j^T per vertex for the reverse pass (the reference keeps every
+        # forward intermediate on its tape).  None: whenever the shape takes the kernels that do and S is at most
+        # ATHENA_MP_GNO_KEEP_S_MAX_GB (default 64: BASELINE configs[3] needs 33 of the 288 GB); True / False: always / never.
+        self.keep_s = keep_s
+        self._s_save = None       # the buffer, reused from step to step
+        self._s_valid = False     # it holds the S of the forward pass the next backward pass belongs to
         self.num_outputs = int(num_outputs)
         self.coord_dim = int(coord_dim)
         self.kernel_hidden = int(kernel_hidden) if kernel_hidden else 16
@@ -486,7 +494,13 @@ class graph_nop_layer_type(msgpass_layer_type):
         if not (x.shape == (g.n_cols, Fi) and coords.shape == (g.n_edge_cols, self.coord_dim)):
             raise ValueError('expected: x.shape == (g.n_cols, Fi) and coords.shape == (g.n_edge_cols, self.coord_dim)')
         self._x, self._coords = x, coords
-        m = ops.gno_aggregate(g, self.params[0], coords, x, self.coord_dim, self.kernel_hidden, Fo)   # steps 1+2
+        self._s_valid = False
+        if self._keeps_s(g, Fi, Fo):
+            m, self._s_save = ops.gno_aggregate_save(g, self.params[0], coords, x, self.coord_dim, self.kernel_hidden, Fo,
+                                                     s_save=self._s_save)                                # steps 1+2, S kept
+            self._s_valid = True
+        else:
+            m = ops.gno_aggregate(g, self.params[0], coords, x, self.coord_dim, self.kernel_hidden, Fo)   # steps 1+2
         z = ops.matmul(self.params[1], x, Fo, bias=self.params[2] if self.use_bias else None)          # steps 3+5
         ops.axpy(1.0, m, z)                                                                            # step 4
         out = ops.activation(self.activation, z) if not _identity(self.activation) else z               # step 6
@@ -496,6 +510,16 @@ class graph_nop_layer_type(msgpass_layer_type):
 
     def update_readout(self):
         pass
+
+    def _keeps_s(self, g, Fi, Fo):
+        if self.keep_s is False:
+            return False
+        nbytes = ops.gno_saved_bytes(g, self.coord_dim, self.kernel_hidden, Fi, Fo)
+        if nbytes == 0:
+            if self.keep_s is True:
+                raise ValueError("keep_s=True, but this shape does not take the kernels that keep S (H = F_in = F_out = 64, d <= 3)")
+            return False
+        return self.keep_s is True or nbytes <= float(os.environ.get("ATHENA_MP_GNO_KEEP_S_MAX_GB", "64")) * 1e9
 
     def backward(self, upstream, need_input_grad=True, need_coord_grad=False):
         g = self.graph.device
@@ -507,7 +531,8 @@ class graph_nop_layer_type(msgpass_layer_type):
             ones = torch.ones((dz.shape[0], 1), device=self.device)
             self.grads[2] = ops.matmul_dw(ones, dz)          # db[o] = sum_v dz[v,o]
         self.grads[1] = ops.matmul_dw(self._x, dz)
-        self.grads[0] = ops.gno_aggregate_bwd_theta(g, self.params[0], self._coords, self._x, dz, d, H)
+        self.grads[0] = ops.gno_aggregate_bwd_theta(g, self.params[0], self._coords, self._x, dz, d, H,
+                                                    s_save=self._s_save if self._s_valid else None)
         dx = dc = None
         if need_input_grad:
             dx = ops.matmul_dx(self.params[1], dz, Fi)

@@ -582,6 +582,34 @@ def gno_aggregate(g: DeviceGraph, theta, coords, x, d, H, Fo):
     return m
 
 
+def gno_saved_bytes(g: DeviceGraph, d, H, Fi, Fo) -> int:
+    """size of the S the training-mode forward keeps for this graph and shape; 0: the shape does not keep S"""
+    import ctypes
+    b = ctypes.c_int64(0)
+    _capi.call("athena_mp_gno_saved_bytes", g.handle, d, H, Fi, Fo, ctypes.byref(b))
+    return int(b.value)
+
+
+def gno_aggregate_save(g: DeviceGraph, theta, coords, x, d, H, Fo, s_save=None):
+    """`gno_aggregate` that also keeps S = sum_e [h_e;1] x_j^T per vertex for `gno_aggregate_bwd_theta(..., s_save=)`
+    (the reference keeps kappa [Fo*Fi, E] on its tape, athena_diffstruc_extd_sub_nop.f90:330-397).  Returns (m, s_save);
+    `s_save` may be a buffer from an earlier step of at least gno_saved_bytes() bytes."""
+    Fi = x.shape[1]
+    _chk(x, (g.n_cols, Fi)); _chk(coords, (g.n_edge_cols, d)); _chk(theta)
+    if not (theta.numel() == H * d + H + Fo * Fi * H + Fo * Fi):
+        raise ValueError('expected: theta.numel() == H * d + H + Fo * Fi * H + Fo * Fi')
+    nbytes = gno_saved_bytes(g, d, H, Fi, Fo)
+    if nbytes == 0:
+        raise ValueError("gno_aggregate_save: this shape does not keep S (gno_saved_bytes() == 0)")
+    if s_save is None or s_save.numel() * 4 < nbytes:
+        s_save = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+    _chk(s_save)
+    m = torch.empty((g.n_rows, Fo), device=x.device, dtype=torch.float32)
+    _go()
+    _capi.call("athena_mp_gno_aggregate_fwd_save", g.handle, d, H, Fi, Fo, _p(theta), _p(coords), _p(x), _p(m), _p(s_save))
+    return m, s_save
+
+
 def gno_aggregate_bwd_x(g: DeviceGraph, theta, coords, grad, d, H, Fi):
     Fo = grad.shape[1]
     _chk(grad, (g.n_rows, Fo)); _chk(coords, (g.n_edge_cols, d))
@@ -593,13 +621,19 @@ def gno_aggregate_bwd_x(g: DeviceGraph, theta, coords, grad, d, H, Fi):
     return dx
 
 
-def gno_aggregate_bwd_theta(g: DeviceGraph, theta, coords, x, grad, d, H):
+def gno_aggregate_bwd_theta(g: DeviceGraph, theta, coords, x, grad, d, H, s_save=None):
     Fi, Fo = x.shape[1], grad.shape[1]
     _chk(x, (g.n_cols, Fi)); _chk(grad, (g.n_rows, Fo)); _chk(coords, (g.n_edge_cols, d))
     if _chk(theta).numel() != H * d + H + Fo * Fi * H + Fo * Fi:
         raise ValueError("theta: expected H*d + H + Fo*Fi*H + Fo*Fi values")
     dth = torch.empty_like(theta)
     _go()
+    if s_save is not None:   # S of the forward pass of the SAME graph, theta, coords, x (gno_aggregate_save)
+        if _chk(s_save).numel() * 4 < gno_saved_bytes(g, d, H, Fi, Fo):
+            raise ValueError("s_save: smaller than gno_saved_bytes()")
+        _capi.call("athena_mp_gno_aggregate_bwd_theta_saved", g.handle, d, H, Fi, Fo, _p(theta), _p(coords), _p(x), _p(grad),
+                   _p(s_save), _p(dth))
+        return dth
     _capi.call("athena_mp_gno_aggregate_bwd_theta", g.handle, d, H, Fi, Fo, _p(theta), _p(coords), _p(x), _p(grad), _p(dth))
     return dth
 

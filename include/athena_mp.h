@@ -283,6 +283,24 @@ int athena_mp_gno_aggregate_bwd_theta(const athena_mp_graph *g, int32_t d, int32
 int athena_mp_gno_aggregate_bwd_coords(const athena_mp_graph *g, int32_t d, int32_t H, int32_t Fi,
                                        int32_t Fo, const float *theta_dev, const float *coords_dev,
                                        const float *x_dev, const float *grad_dev, float *dcoords_dev);
+/* Training-mode pair (the reference keeps every forward intermediate on its tape for grad_reverse:
+ * gno_aggregate's result node holds kappa [Fo*Fi, E], athena_diffstruc_extd_sub_nop.f90:330-397 -- 246 GB at
+ * BASELINE configs[3]).  Here the forward pass may keep the re-associated S = sum_e [h_e;1] x_j^T per vertex
+ * (n_tiles * 133120 floats: 33 GB at configs[3], sized for 288 GB of HBM) so that the reverse pass's
+ * dVaug = S^T g streams it instead of rebuilding it.  Same m, same dtheta (bit for bit) as the pair above.
+ *   _saved_bytes: *bytes = size of s_save_dev for this graph and shape, 0 if the shape does not take the
+ *                 kernels that keep S (then use the pair above);
+ *   _fwd_save:    athena_mp_gno_aggregate_fwd that also fills s_save_dev;
+ *   _bwd_theta_saved: athena_mp_gno_aggregate_bwd_theta reading the s_save_dev of the SAME graph, theta, coords, x. */
+int athena_mp_gno_saved_bytes(const athena_mp_graph *g, int32_t d, int32_t H, int32_t Fi, int32_t Fo,
+                              int64_t *bytes);
+int athena_mp_gno_aggregate_fwd_save(const athena_mp_graph *g, int32_t d, int32_t H, int32_t Fi, int32_t Fo,
+                                     const float *theta_dev, const float *coords_dev, const float *x_dev,
+                                     float *m_dev, float *s_save_dev);
+int athena_mp_gno_aggregate_bwd_theta_saved(const athena_mp_graph *g, int32_t d, int32_t H, int32_t Fi,
+                                            int32_t Fo, const float *theta_dev, const float *coords_dev,
+                                            const float *x_dev, const float *grad_dev,
+                                            const float *s_save_dev, float *dtheta_dev);
 
 /* ---- activations with their own shape and the 'concatenate' merge (8f-2) -----
  * swish_array / get_partial_swish_val, athena_diffstruc_extd_sub.f90:424-492: y = x/(1+exp(-beta x));

@@ -108,10 +108,22 @@ else:
     legs = {"fwd": lambda: ops.gno_aggregate(g, theta, co, x, d, H, Fo),
             "bwd_x": lambda: ops.gno_aggregate_bwd_x(g, theta, co, gup, d, H, Fi),
             "bwd_theta": lambda: ops.gno_aggregate_bwd_theta(g, theta, co, x, gup, d, H)}
+    # training-mode pair: the forward pass keeps S (33 GB here) and the reverse pass's S^T g streams it
+    s_keep = [None]
+    def fwd_save():
+        m, s_keep[0] = ops.gno_aggregate_save(g, theta, co, x, d, H, Fo, s_save=s_keep[0])
+        return m
+    legs["fwd_save"] = fwd_save
+    legs["bwd_theta_saved"] = lambda: ops.gno_aggregate_bwd_theta(g, theta, co, x, gup, d, H, s_save=s_keep[0])
     if a.only:
+        if a.only == "bwd_theta_saved": fwd_save()
         print(json.dumps({"only": a.only, "lib": os.environ.get("ATHENA_MP_LIB", ""), "ms": round(timeit(legs[a.only], a.reps), 3)})); sys.exit(0)
     for k, fn in legs.items(): t[k] = timeit(fn, a.reps)
+    t_keep = {"fwd_save": t.pop("fwd_save"), "bwd_theta_saved": t.pop("bwd_theta_saved")}
     tot = sum(t.values())
+    tot_keep = t_keep["fwd_save"] + t["bwd_x"] + t_keep["bwd_theta_saved"]
+    keep = {"ms": {k: round(v, 3) for k, v in t_keep.items()}, "total_ms": round(tot_keep, 3),
+            "s_save_GB": round(ops.gno_saved_bytes(g, d, H, Fi, Fo) / 1e9, 2)}
     R = (H + 1) * Fi
     # re-associated algorithm, fused (S stays on chip): the contraction N*2*Fo*(H+1)*Fi bounds it on the fp32 matrix pipe
     alg_fwd = nnz * (4 * Fi + 4 * d + 8) + N * (4 * Fo + 4)
@@ -123,7 +135,7 @@ else:
                 "frac_of_157_TFLOPs_fp32_mfma": round(flops[k] / (t[k] * 1e-3) / 157e12, 3)} for k in t}
     roof["fwd"].update({"algorithmic_GB": round(alg_fwd / 1e9, 1), "GBps": round(alg_fwd / (t["fwd"] * 1e-3) / 1e9, 1)})
     if a.no_cpu:
-        print(json.dumps({"ms": {k: round(v, 3) for k, v in t.items()}, "total_ms": tot, "roofline": roof})); sys.exit(0)
+        print(json.dumps({"ms": {k: round(v, 3) for k, v in t.items()}, "total_ms": tot, "keep_s": keep, "roofline": roof})); sys.exit(0)
     # CPU: the reference's MATERIALISING algorithm is infeasible at this size (246 GB kernel tensor); time it
     # with the oracle on the first 20 000 vertices of the same graph
     from oracle import oracle as o
@@ -137,7 +149,7 @@ else:
     tc = time.perf_counter() - t0
     res = {"config": "C4 GNO aggregate fwd + dx + dtheta", "vertices": N, "entries": nnz, "edge_columns": E, "F": Fi, "H": H,
            "synthetic_graph_generation_host_s": tg, "ms": {k: round(v, 3) for k, v in t.items()}, "total_ms": tot, "entries_per_s": nnz / tot * 1e3,
-           "roofline": roof,
+           "keep_s": keep, "roofline": roof,
            "cpu_baseline": {"value": sja.shape[1] / tc, "unit": "entries/s", "cores": 1, "kind": "port",
                             "sample": f"materialising oracle (the reference's algorithm), radius graph of {ns} vertices = {sja.shape[1]} entries / {cs.shape[0]} edge columns, same widths, {tc:.1f} s"}}
 print(json.dumps(res))

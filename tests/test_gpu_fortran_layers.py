@@ -93,13 +93,13 @@ class _reader:
         return v
 
 
-def _run(tmp_path, blob):
+def _run(tmp_path, blob, env=None):
     if not os.path.exists(RUNNER):
         pytest.fail("athena_mp_layer_run is not built: __graft_entry__.build() compiles the Fortran host side")
     case, res = str(tmp_path / "case.bin"), str(tmp_path / "result.bin")
     with open(case, "wb") as f:
         f.write(blob)
-    r = subprocess.run([RUNNER, case, res], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([RUNNER, case, res], capture_output=True, text=True, timeout=300, env={**os.environ, **(env or {})})
     assert r.returncode == 0, f"athena_mp_layer_run failed ({r.returncode}): {r.stderr[-2000:]}"
     return _reader(res)
 
@@ -181,7 +181,8 @@ def test_fortran_duvenaud_layer(dev, tmp_path, act, act_r):
 
 
 @pytest.mark.parametrize("Fi,Fo,d,H,bias,act", [(3, 5, 1, 8, 1, _actv("none")), (8, 8, 3, 16, 0, _actv("relu")),
-                                               (32, 32, 3, 32, 1, _actv("tanh")), (4, 6, 2, 8, 1, _actv("piecewise", p0=0.3, p1=0.4))])
+                                               (32, 32, 3, 32, 1, _actv("tanh")), (4, 6, 2, 8, 1, _actv("piecewise", p0=0.3, p1=0.4)),
+                                               (64, 64, 3, 64, 1, _actv("relu"))])   # the widths whose forward pass keeps S
 def test_fortran_graph_nop_layer(dev, tmp_path, Fi, Fo, d, H, bias, act):
     rng = np.random.default_rng(Fi + H)
     gs = _graphs(rng, [20, 11, 33], self_loops=False)
@@ -208,7 +209,12 @@ def test_fortran_graph_nop_layer(dev, tmp_path, Fi, Fo, d, H, bias, act):
         return np.concatenate(a), np.concatenate(b), np.concatenate(c)
     assert_close(r.matrix(), np.concatenate(dxs), 1e-5, "fortran graph_nop dx", f64=lambda: hi()[0])
     assert_close(r.matrix(), np.concatenate(dcs), 1e-5, "fortran graph_nop dcoords", f64=lambda: hi()[1])
-    assert_close(r.vector(), np.concatenate(grads), 1e-5, "fortran graph_nop gradients", f64=lambda: hi()[2])
+    gv = r.vector()
+    assert_close(gv, np.concatenate(grads), 1e-5, "fortran graph_nop gradients", f64=lambda: hi()[2])
+    if H == 64:   # S kept by the forward pass (the default) against S rebuilt by the reverse pass: the same bits
+        r2 = _run(tmp_path, blob, env={"ATHENA_MP_GNO_KEEP_S_MAX_GB": "0"})
+        r2.matrix(); r2.matrix(); r2.matrix()
+        assert np.array_equal(r2.vector(), gv)
 
 
 def _relabelled(rng, g, self_loops):

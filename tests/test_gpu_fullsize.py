@@ -387,6 +387,13 @@ def test_c4_gno_properties_full_size(dev, oracle):
     via_c = (co.double() * dco.double()).sum().item()
     via_Uonly = (theta[:H * d].double() * dth[:H * d].double()).sum().item()
     assert abs(via_c - via_Uonly) <= 1e-5 * scale
+    # the training-mode pair at size: the forward pass keeps S (33 GB, beyond what one buffer descriptor addresses), the
+    # reverse pass streams it -- same m, same dtheta, bit for bit
+    del dco, dx
+    assert ops.gno_saved_bytes(g, d, H, Fi, Fo) == 4 * (N // 32) * (8 * 32 * 512 + 32 * 64)
+    m2, s_save = ops.gno_aggregate_save(g, theta, co, x, d, H, Fo)
+    assert torch.equal(m2, m)
+    assert torch.equal(ops.gno_aggregate_bwd_theta(g, theta, co, x, gup, d, H, s_save=s_save), dth)
 
 
 def test_tensors_beyond_2_31_elements_use_64_bit_offsets(dev, oracle):

@@ -146,6 +146,61 @@ def test_gno_layer(dev, Fi, Fo, d, H, bias, act):
     assert_close(dc.cpu().numpy(), np.concatenate(dcs), 1e-5, "gno dcoords", f64=lambda: hi()[1])
     assert_close(layer.get_gradients(), np.concatenate(grads), 1e-5, "gno dparams", f64=lambda: hi()[2])
     assert np.array_equal(layer.forward(xs, cs).cpu().numpy(), out)
+    assert not layer._s_valid          # these widths do not take the kernels that keep S
+
+
+def test_gno_layer_keeps_s_between_forward_and_backward(dev):
+    """H = F_in = F_out = 64 (BASELINE configs[3]'s widths): the layer's forward pass keeps S for the reverse pass by default
+    (keep_s=None), keep_s=False rebuilds it; same output, same gradients bit for bit, both against the layer oracle"""
+    from athena_amd.layers import graph_nop_layer_type
+
+    Fi = Fo = H = 64; d = 3
+    rng = np.random.default_rng(64)
+    gs = _graphs(rng, [40, 70, 9], self_loops=False)
+    xs = [rng.uniform(-1, 1, (g.num_vertices, Fi)).astype(np.float32) for g in gs]
+    cs = [rng.standard_normal((g.num_edges, d)).astype(np.float32) for g in gs]
+    got = {}
+    for keep in (None, False):
+        layer = graph_nop_layer_type(num_outputs=Fo, coord_dim=d, kernel_hidden=H, num_inputs=Fi, use_bias=True, activation="relu",
+                                     seed=3, keep_s=keep)
+        params = layer.get_params() + np.random.default_rng(1).standard_normal(layer.get_num_params()).astype(np.float32) * 0.05
+        layer.set_params(params)
+        layer.set_graph(gs)
+        out = layer.forward(xs, cs)
+        assert layer._s_valid == (keep is None)
+        ups = np.random.default_rng(2).uniform(-1, 1, tuple(out.shape)).astype(np.float32)
+        dx = layer.backward(ups)
+        got[keep] = (out.cpu().numpy(), dx.cpu().numpy(), layer.get_gradients())
+        # a second step reuses the buffer
+        buf = layer._s_save
+        layer.forward(xs, cs); layer.backward(ups)
+        assert layer._s_save is buf
+    for a, b in zip(got[None], got[False]):
+        assert np.array_equal(a, b)
+    F = Fo * Fi
+    sizes = [H * d + H + F * H + F, F, Fo]
+    plist, o_ = [], 0
+    for n in sizes:
+        plist.append(params[o_:o_ + n]); o_ += n
+    outs, tapes = ol.gno_forward(gs, xs, cs, plist, Fi, Fo, d, H, True, "relu")
+    assert_close(got[None][0], np.concatenate(outs), 1e-5, "gno fwd (S kept)")
+    o_ = 0; upl = []
+    for o in outs:
+        upl.append(ups[o_:o_ + o.shape[0]]); o_ += o.shape[0]
+    dxs, dcs, grads = ol.gno_backward(gs, xs, cs, tapes, plist, Fi, Fo, d, H, True, "relu", upl)
+
+    @functools.lru_cache(None)
+    def hi():
+        with ol.double_precision():
+            _, t64 = ol.gno_forward(gs, xs, cs, plist, Fi, Fo, d, H, True, "relu")
+            a, b, c = ol.gno_backward(gs, xs, cs, t64, plist, Fi, Fo, d, H, True, "relu", upl)
+        return np.concatenate(a), np.concatenate(c)
+    assert_close(got[None][1], np.concatenate(dxs), 1e-5, "gno dx", f64=lambda: hi()[0])
+    assert_close(got[None][2], np.concatenate(grads), 1e-5, "gno dparams (S kept)", f64=lambda: hi()[1])
+    with pytest.raises(ValueError, match="keep_s=True"):
+        lay = graph_nop_layer_type(num_outputs=8, coord_dim=3, kernel_hidden=16, num_inputs=8, keep_s=True)
+        lay.set_graph(gs)
+        lay.forward([x[:, :8].copy() for x in xs], cs)
 
 
 def test_reference_network_graph_through_layers(dev):

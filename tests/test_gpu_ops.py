@@ -607,6 +607,68 @@ def test_gno_fused_kernels_rectangular_rows_subset(dev, oracle):
                  f64=lambda: o64.gno_kernel_bwd_theta(coords, theta, o64.gno_aggregate_bwd_k(up_sq, x, E, ia_sq, ja_r), Hh))
 
 
+@pytest.mark.parametrize("d,loops,N", [(3, False, 2101), (2, True, 2101), (1, False, 203), (3, False, 8200)])
+def test_gno_training_pair_keeps_s_for_the_reverse_pass(dev, oracle, d, loops, N):
+    """athena_mp_gno_aggregate_fwd_save / _bwd_theta_saved: the forward pass keeps S (every piece as it lies in LDS, bias
+    rows behind them), the reverse pass's S^T g streams it.  Same bits as the pair that rebuilds S -- m, and dtheta -- and
+    dtheta against the materialising oracle; hub rows (blocks beyond the 32 prefetched entries), isolated vertices, a
+    ragged last tile, several tiles per workgroup, a reused buffer"""
+    from athena_amd import DeviceGraph, ops
+    from oracle import oracle64 as o64
+
+    rng = np.random.default_rng(170 + d + N)
+    pairs = [[i, i + 1] for i in range(1, N - 6)]
+    pairs += [[11, int(v)] for v in rng.choice(np.arange(13, N - 6), 150, replace=False)]
+    pairs += [[90, int(v)] for v in rng.choice(np.arange(92, N - 6), 37, replace=False)]
+    pairs += [[int(a), int(b)] for a, b in rng.integers(1, N - 5, (int(1.2 * N), 2)) if a != b]
+    pairs = np.array(pairs).T
+    g = csr_from_index_list(N, pairs, self_loops=loops)
+    E = pairs.shape[1]
+    Hh = Fi = Fo = 64
+    coords = rng.standard_normal((E, d)).astype(np.float32)
+    x = rng.uniform(-1, 1, (N, Fi)).astype(np.float32)
+    theta = (0.3 * rng.standard_normal(Hh * d + Hh + Fo * Fi * Hh + Fo * Fi)).astype(np.float32)
+    up = rng.uniform(-1, 1, (N, Fo)).astype(np.float32)
+    ia, ja = g.adj_ia, g.adj_ja
+    dg = DeviceGraph(ia, ja, n_edge_cols=E)
+    th, co, xd, gd = T(theta, dev), T(coords, dev), T(x, dev), T(up, dev)
+    nbytes = ops.gno_saved_bytes(dg, d, Hh, Fi, Fo)
+    assert nbytes == 4 * ((N + 31) // 32) * (8 * 32 * 512 + 32 * 64)
+    m, s_save = ops.gno_aggregate_save(dg, th, co, xd, d, Hh, Fo)
+    assert torch.equal(m, ops.gno_aggregate(dg, th, co, xd, d, Hh, Fo))
+    dth = ops.gno_aggregate_bwd_theta(dg, th, co, xd, gd, d, Hh, s_save=s_save)
+    assert torch.equal(dth, ops.gno_aggregate_bwd_theta(dg, th, co, xd, gd, d, Hh))
+    dk = oracle.gno_aggregate_bwd_k(up, x, E, ia, ja)
+    assert_close(H_(dth), oracle.gno_kernel_bwd_theta(coords, theta, dk, Hh), 1e-5, "gno dtheta from the kept S",
+                 f64=lambda: o64.gno_kernel_bwd_theta(coords, theta, o64.gno_aggregate_bwd_k(up, x, E, ia, ja), Hh))
+    # the buffer of one step serves the next (other features): nothing of the old S survives
+    x2 = T(rng.uniform(-1, 1, (N, Fi)).astype(np.float32), dev)
+    s_save.fill_(float("nan"))
+    m2, s2 = ops.gno_aggregate_save(dg, th, co, x2, d, Hh, Fo, s_save=s_save)
+    assert s2.data_ptr() == s_save.data_ptr() and torch.isfinite(s2[: nbytes // 4]).all()
+    assert torch.equal(ops.gno_aggregate_bwd_theta(dg, th, co, x2, gd, d, Hh, s_save=s2),
+                       ops.gno_aggregate_bwd_theta(dg, th, co, x2, gd, d, Hh))
+
+
+def test_gno_training_pair_says_which_shapes_it_serves(dev):
+    """shapes that do not take the kernels that keep S: zero bytes, and the pair refuses them with a message"""
+    import ctypes as C
+    from athena_amd import DeviceGraph, ops, _capi
+
+    g, E, coords, x, theta, up = _gno_case(5, 40, 4, 64, 64, 64, 30)          # d = 4: the round-1 kernel
+    dg = DeviceGraph(g.adj_ia, g.adj_ja, n_edge_cols=E)
+    assert ops.gno_saved_bytes(dg, 4, 64, 64, 64) == 0
+    g2, E2, coords2, x2, theta2, up2 = _gno_case(6, 40, 3, 16, 8, 8, 30)      # small widths: generic kernels
+    dg2 = DeviceGraph(g2.adj_ia, g2.adj_ja, n_edge_cols=E2)
+    assert ops.gno_saved_bytes(dg2, 3, 16, 8, 8) == 0
+    with pytest.raises(ValueError, match="does not keep S"):
+        ops.gno_aggregate_save(dg2, T(theta2, dev), T(coords2, dev), T(x2, dev), 3, 16, 8)
+    buf = torch.zeros(16, device=dev)
+    with pytest.raises(_capi.AthenaMPError, match="does not keep S"):
+        _capi.call("athena_mp_gno_aggregate_fwd_save", dg2.handle, 3, 16, 8, 8, C.c_void_p(buf.data_ptr()), C.c_void_p(buf.data_ptr()),
+                   C.c_void_p(buf.data_ptr()), C.c_void_p(buf.data_ptr()), C.c_void_p(buf.data_ptr()))
+
+
 def torch_equal_twice(fn):
     import torch
     return torch.equal(fn(), fn())
