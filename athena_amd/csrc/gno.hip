@@ -1087,6 +1087,8 @@ __global__ __launch_bounds__(kPcThreads) void gno_stg_kernel(const int32_t *__re
             P.ids_rows(sub, T0);
             P.ids_rows(sub + nsub, T1);
             T2 = T1;
+            // (one tile ahead is enough: the same copy two tiles ahead, in two register sets, measured 21.4 ms per dtheta against
+            // 20.8 -- three A/B pairs on one box)
             v4f_g R[8];
             float bsel, GV[4];
             auto load_tile = [&](int tl) {   // beyond the last tile: the last tile again (never consumed)
