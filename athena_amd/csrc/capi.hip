@@ -23,9 +23,10 @@ struct NamedBuf {
     void *p = nullptr;
     size_t bytes = 0;
 };
+constexpr int kWsSlots = 12;
 struct DevCtx {
-    void *ws[10] = {};
-    size_t ws_bytes[10] = {};
+    void *ws[kWsSlots] = {};
+    size_t ws_bytes[kWsSlots] = {};
     hipStream_t aux = nullptr;            // second stream of the library (producer / consumer pipelines inside one call)
     hipEvent_t ev[6] = {};                // events of those pipelines
     std::map<std::string, NamedBuf> named;
@@ -89,6 +90,10 @@ int named_buffer(const char *name, size_t bytes, bool zero_fill, void **ptr, boo
 
 int workspace(void **ptr, size_t bytes, int slot)
 {
+    if (slot < 0 || slot >= kWsSlots) {
+        set_error("workspace: slot %d out of range", slot);
+        return 1;
+    }
     if (bytes > g_ws_bytes[slot]) {
         if (g_ws[slot]) {
             AMP_HIP(hipStreamSynchronize(g_stream));
@@ -138,7 +143,7 @@ int athena_mp_finalize(void)
     amp::graph_cache_clear();
     for (int d = 0; d < kMaxDevices; ++d) {       // every device this process initialised
         DevCtx &c = g_ctx[d];
-        for (int s = 0; s < 10; ++s) {
+        for (int s = 0; s < kWsSlots; ++s) {
             if (c.ws[s]) {
                 AMP_HIP(hipFree(c.ws[s]));
                 c.ws[s] = nullptr;

@@ -358,15 +358,16 @@ template <> struct FragLoadV<4> {
 
 template <bool MASK, int U, int TI, int TJ, int FI, int FO>
 __device__ __forceinline__ void dwf_load(float (&a)[U][TI], float (&b)[U][TJ], const float *__restrict__ pa,
-                                         const float *__restrict__ pb, int64_t v, int64_t v1, int h)
+                                         const float *__restrict__ pb, int64_t v, int64_t v1, int h, int64_t ldp = FI,
+                                         int64_t ldz = FO)
 {
 #pragma unroll
     for (int s = 0; s < U; ++s) {
         const int64_t vv = v + 2 * s + h;
         const bool ok = vv < v1;
         const int64_t vc = ok ? vv : v1 - 1;
-        FragLoadV<TI>::ld(a[s], pa + vc * FI);
-        FragLoadV<TJ>::ld(b[s], pb + vc * FO);
+        FragLoadV<TI>::ld(a[s], pa + vc * ldp);
+        FragLoadV<TJ>::ld(b[s], pb + vc * ldz);
         if constexpr (MASK) {
             if (!ok) {
 #pragma unroll
@@ -376,17 +377,33 @@ __device__ __forceinline__ void dwf_load(float (&a)[U][TI], float (&b)[U][TJ], c
     }
 }
 
-template <int FI, int FO>
+// BLOCKED (widths that are multiples of 128 beyond 128: BASELINE configs[4]'s 256 x 256): dW is cut in nbi x nbo blocks of
+// FI x FO = 128 x 128, one workgroup per (row range x, block y); P and dZ keep their own row pitch (ldp, ldz) and the block
+// reads its 128 columns of each.  Workgroup id = x_lo + 8 (x_hi nb + y): the nb blocks of a row range sit on ONE XCD
+// (workgroup b runs on XCD b % 8) next to each other in dispatch order, so each half row of P / dZ comes from HBM once.
+template <int FI, int FO, bool BLOCKED = false>
 __global__ __launch_bounds__(256, 1) void gemm_dw_full_kernel(const float *__restrict__ P,
                                                                const float *__restrict__ dZ,
                                                                float *__restrict__ slabs, int64_t M,
-                                                               int64_t rows_per_wave)
+                                                               int64_t rows_per_wave, int64_t ldp = FI, int64_t ldz = FO,
+                                                               int nbo = 1, int nb = 1)
 {
     constexpr int TI = FI / 32, TJ = FO / 32;
     constexpr int U = 4;
     __shared__ __attribute__((aligned(16))) float red[FI * FO];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 31, h = lane >> 5;
+    int64_t bx = blockIdx.x;          // the row range
+    size_t slab_id = blockIdx.x;
+    if constexpr (BLOCKED) {
+        const int x_lo = blockIdx.x & 7, rest = blockIdx.x >> 3, y = rest % nb, x_hi = rest / nb;
+        bx = x_hi * 8 + x_lo;
+        P += (size_t)FI * (y / nbo);
+        dZ += (size_t)FO * (y % nbo);
+        slab_id = (size_t)y * (gridDim.x / nb) + bx;   // slabs of one block contiguous: [y][x]
+    } else {
+        ldp = FI; ldz = FO;
+    }
 
     f32x16 acc[TI][TJ];
 #pragma unroll
@@ -396,7 +413,7 @@ __global__ __launch_bounds__(256, 1) void gemm_dw_full_kernel(const float *__res
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-    const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t gw = bx * 4 + wave;
     const int64_t v0 = min(M, gw * rows_per_wave);
     const int64_t v1 = min(M, v0 + rows_per_wave);
     const float *pa = P + TI * m;
@@ -406,19 +423,19 @@ __global__ __launch_bounds__(256, 1) void gemm_dw_full_kernel(const float *__res
         float a0[U][TI], b0[U][TJ], a1[U][TI], b1[U][TJ];
         const int64_t n_pairs = (v1 - v0) / (4 * U);
         int64_t v = v0;
-        if (n_pairs > 0) dwf_load<false, U, TI, TJ, FI, FO>(a0, b0, pa, pb, v, v1, h);
+        if (n_pairs > 0) dwf_load<false, U, TI, TJ, FI, FO>(a0, b0, pa, pb, v, v1, h, ldp, ldz);
         for (int64_t p = 0; p < n_pairs; ++p, v += 4 * U) {
-            dwf_load<false, U, TI, TJ, FI, FO>(a1, b1, pa, pb, v + 2 * U, v1, h);
+            dwf_load<false, U, TI, TJ, FI, FO>(a1, b1, pa, pb, v + 2 * U, v1, h, ldp, ldz);
             __builtin_amdgcn_sched_barrier(0);
             dw_mfma<U, TI, TJ>(acc, a0, b0);
             __builtin_amdgcn_sched_barrier(0);
-            dwf_load<false, U, TI, TJ, FI, FO>(a0, b0, pa, pb, v + 4 * U, v1, h);
+            dwf_load<false, U, TI, TJ, FI, FO>(a0, b0, pa, pb, v + 4 * U, v1, h, ldp, ldz);
             __builtin_amdgcn_sched_barrier(0);
             dw_mfma<U, TI, TJ>(acc, a1, b1);
             __builtin_amdgcn_sched_barrier(0);
         }
         for (; v < v1; v += 2 * U) {
-            dwf_load<true, U, TI, TJ, FI, FO>(a0, b0, pa, pb, v, v1, h);
+            dwf_load<true, U, TI, TJ, FI, FO>(a0, b0, pa, pb, v, v1, h, ldp, ldz);
             dw_mfma<U, TI, TJ>(acc, a0, b0);
         }
     }
@@ -438,9 +455,19 @@ __global__ __launch_bounds__(256, 1) void gemm_dw_full_kernel(const float *__res
         }
         __syncthreads();
     }
-    float *slab = slabs + (size_t)blockIdx.x * FI * FO;
+    float *slab = slabs + slab_id * FI * FO;
     for (int t = threadIdx.x; t < FI * FO / 4; t += 256)
         reinterpret_cast<v4f *>(slab)[t] = reinterpret_cast<const v4f *>(red)[t];
+}
+
+// dW[(128 bi + i) Fo + 128 bo + o] (+)= blocks[bi nbo + bo][i][o]
+__global__ void dw_blocks_place_kernel(const float *__restrict__ blocks, float *__restrict__ dW, int Fi, int Fo, int accumulate)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= Fi * Fo) return;
+    const int i = t / Fo, o = t - i * Fo, nbo = Fo / 128;
+    const float v = blocks[((size_t)((i >> 7) * nbo + (o >> 7)) * 128 + (i & 127)) * 128 + (o & 127)];
+    dW[t] = accumulate ? dW[t] + v : v;
 }
 
 // out[seg][t] = sum_b slabs[first_seg + b][t]: b ascending inside each of 16 interleaved groups, the groups
@@ -632,6 +659,30 @@ int gemm_dw_dispatch(int64_t N, int Fi, int Fo, const float *P, const float *dZ,
     }
     bool mf = (Fi == 64 || Fi == 128) && (Fo == 64 || Fo == 128) && ((uintptr_t)P % 16 == 0) &&
               ((uintptr_t)dZ % 16 == 0);
+    static const bool no_blocks = getenv("ATHENA_MP_DW_NO_BLOCKS") != nullptr;   // A/B switch: the generic tiled kernel
+    if (!mf && !no_blocks && Fi % 128 == 0 && Fo % 128 == 0 && Fi <= 512 && Fo <= 512 && N >= 4096 &&
+        (uintptr_t)P % 16 == 0 && (uintptr_t)dZ % 16 == 0) {
+        // 128 x 128 blocks of dW on the register-resident kernel (BASELINE configs[4]: 256 x 256 = four blocks)
+        const int nbi = Fi / 128, nbo = Fo / 128, nb = nbi * nbo;
+        int nx = (int)std::min<int64_t>((N + 127) / 128, num_cu());
+        int64_t rpw = (N + (int64_t)nx * 4 - 1) / ((int64_t)nx * 4);
+        rpw = (rpw + 1) & ~(int64_t)1;
+        nx = (int)((N + rpw * 4 - 1) / (rpw * 4));
+        nx = (nx + 7) & ~7;                       // whole groups of eight row ranges (the workgroup order above)
+        void *ws = nullptr, *blk = nullptr;
+        if (workspace(&ws, sizeof(float) * (size_t)nx * nb * 16384, 2) || workspace(&blk, sizeof(float) * (size_t)nb * 16384, 10))
+            return 1;
+        hipLaunchKernelGGL((gemm_dw_full_kernel<128, 128, true>), dim3(nx * nb), dim3(256), 0, stream(), P, dZ, (float *)ws, N, rpw,
+                           (int64_t)Fi, (int64_t)Fo, nbo, nb);
+        AMP_LAUNCH_CHECK();
+        std::vector<int> first(nb), count(nb, nx);
+        for (int y = 0; y < nb; ++y) first[y] = y * nx;
+        if (int rc = slab_reduce_segs((const float *)ws, 16384, nb, first.data(), count.data(), (float *)blk, 16384, false)) return rc;
+        hipLaunchKernelGGL(dw_blocks_place_kernel, dim3((n + 255) / 256), dim3(256), 0, stream(), (const float *)blk, dW, Fi, Fo,
+                           accumulate ? 1 : 0);
+        AMP_LAUNCH_CHECK();
+        return 0;
+    }
     if (!mf && (int64_t)Fi * Fo >= 256 && N >= 256)
         return gemm_atb_tiled(P, Fi, dZ, Fo, nullptr, 1.0f, N, Fi, Fo, dW, accumulate);
     int nblk;

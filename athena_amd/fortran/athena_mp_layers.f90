@@ -1271,7 +1271,18 @@ contains
     if(this%keep_s) call chk(athena_mp_gno_saved_bytes(this%graph, int(this%coord_dim, c_int32_t), &
          int(this%kernel_hidden, c_int32_t), int(fi, c_int32_t), int(fo, c_int32_t), s_bytes), "gno_saved_bytes")
     if(s_bytes .gt. 0_c_int64_t .and. real(s_bytes) .le. keep_s_max_gb() * 1.e9)then
-       call need(this%s_save, s_bytes / 4_c_int64_t)
+       if(s_bytes / 4_c_int64_t .gt. this%s_save%cap)then       ! no room for S beside the model: rebuild it from now on
+          call release(this%s_save)
+          if(athena_mp_malloc(this%s_save%p, s_bytes) .eq. 0)then
+             this%s_save%cap = s_bytes / 4_c_int64_t
+          else
+             this%s_save%p = c_null_ptr
+             this%keep_s = .false.
+             s_bytes = 0_c_int64_t
+          end if
+       end if
+    end if
+    if(s_bytes .gt. 0_c_int64_t .and. real(s_bytes) .le. keep_s_max_gb() * 1.e9)then
        call chk(athena_mp_gno_aggregate_fwd_save(this%graph, int(this%coord_dim, c_int32_t), int(this%kernel_hidden, c_int32_t), &
             int(fi, c_int32_t), int(fo, c_int32_t), this%params(1)%p, coords_dev, x_dev, this%scratch(1)%p, this%s_save%p), &
             "gno_aggregate (S kept)")

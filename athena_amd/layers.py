@@ -495,11 +495,17 @@ class graph_nop_layer_type(msgpass_layer_type):
             raise ValueError('expected: x.shape == (g.n_cols, Fi) and coords.shape == (g.n_edge_cols, self.coord_dim)')
         self._x, self._coords = x, coords
         self._s_valid = False
+        m = None
         if self._keeps_s(g, Fi, Fo):
-            m, self._s_save = ops.gno_aggregate_save(g, self.params[0], coords, x, self.coord_dim, self.kernel_hidden, Fo,
-                                                     s_save=self._s_save)                                # steps 1+2, S kept
-            self._s_valid = True
-        else:
+            try:
+                m, self._s_save = ops.gno_aggregate_save(g, self.params[0], coords, x, self.coord_dim, self.kernel_hidden, Fo,
+                                                         s_save=self._s_save)                            # steps 1+2, S kept
+                self._s_valid = True
+            except torch.OutOfMemoryError:
+                if self.keep_s is True:
+                    raise
+                self.keep_s, self._s_save = False, None        # no room for S beside the model: rebuild it from now on
+        if m is None:
             m = ops.gno_aggregate(g, self.params[0], coords, x, self.coord_dim, self.kernel_hidden, Fo)   # steps 1+2
         z = ops.matmul(self.params[1], x, Fo, bias=self.params[2] if self.use_bias else None)          # steps 3+5
         ops.axpy(1.0, m, z)                                                                            # step 4

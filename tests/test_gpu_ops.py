@@ -223,7 +223,9 @@ def test_kipf_rectangular_block_with_explicit_degrees(dev, oracle):
 @pytest.mark.parametrize("N,Fi,Fo", [(1000, 128, 128), (4097, 64, 128), (333, 128, 64), (31, 32, 32), (5000, 64, 64),
                                      (700, 6, 10), (513, 7, 6), (100, 256, 256), (257, 96, 40), (2000, 128, 32),
                                      (3001, 256, 256), (2000, 72, 64), (5000, 64, 10), (5000, 10, 64), (1500, 4160, 64),
-                                     (900, 130, 258), (129, 9, 33)])
+                                     (900, 130, 258), (129, 9, 33),
+                                     # dW in 128 x 128 blocks on the register-resident kernel (N >= 4096; configs[4]'s 256 x 256)
+                                     (4099, 256, 256), (5001, 256, 128), (4100, 128, 384), (6000, 512, 256)])
 def test_gemm_family_vs_float64(dev, oracle, N, Fi, Fo):
     """matmul is diffstruc's (unpinned by the reference's tests): exact-math fp32 GEMM, checked
     against float64 at 1e-5 and against the oracle's k-ordered fp32 sum"""
@@ -244,6 +246,24 @@ def test_gemm_family_vs_float64(dev, oracle, N, Fi, Fo):
     b = rng.standard_normal(Fo).astype(np.float32)
     Zb = H(ops.matmul(T(W, dev), T(P, dev), Fo, bias=T(b, dev), act="relu"))
     assert_close(Zb, np.maximum(P @ Wt + b, 0), 1e-5, "fused bias+relu")
+
+
+def test_weight_gradient_in_blocks_repeats_and_agrees_with_the_tiled_kernel(dev):
+    """gemm_dw_dispatch's blocked form (Fi, Fo multiples of 128 beyond 128): the same bits on every launch, and the generic
+    tiled kernel (the route below 4096 rows) agrees on the same data"""
+    from athena_amd import ops
+
+    rng = np.random.default_rng(9)
+    N, Fi, Fo = 9000, 256, 256
+    P = T(rng.uniform(-1, 1, (N, Fi)).astype(np.float32), dev)
+    dZ = T(rng.uniform(-1, 1, (N, Fo)).astype(np.float32), dev)
+    dW = ops.matmul_dw(P, dZ)
+    assert torch.equal(dW, ops.matmul_dw(P, dZ))
+    ref = (P.double().T @ dZ.double()).reshape(-1)
+    assert (dW.double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+    lo = ops.matmul_dw(P[:4000].contiguous(), dZ[:4000].contiguous()) + ops.matmul_dw(P[4000:8000].contiguous(), dZ[4000:8000].contiguous()) \
+        + ops.matmul_dw(P[8000:].contiguous(), dZ[8000:].contiguous())         # three launches of the generic kernel
+    assert (lo.double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
 
 
 @pytest.mark.parametrize("kind", ["none", "relu", "sigmoid", "tanh"])
