@@ -1054,8 +1054,9 @@ __global__ __launch_bounds__(kPcThreads) void gno_stg_kernel(const int32_t *__re
     // piece = b % 8): the eight are on eight different XCDs, every 64-byte quarter row costs each of them its own 128-byte line
     // from the fabric -- 57 GB per launch at configs[3] (2 x FETCH_SIZE; L2 hit rate 2 %) against 8.7 GB algorithmic.  Grouped
     // order (round 3, the product path whenever the tile classes divide by 8): piece = b / nsub, so the eight workgroups of a
-    // tile class share ONE XCD's L2 -- 19.5 GB, L2 hit rate 66 % (profiles/r03_c4_gno_pmc_traffic.txt; 10.9 GB / 81 % in round 2's A/B build: the eight drift apart over a launch, by how much varies).  The
-    // kernel is bound by its matrix and vector work, not by either figure; the grouped order leaves the fabric to whatever
+    // tile class share ONE XCD's L2 -- 19.5 GB, L2 hit rate 66 % (profiles/r03_c4_gno_pmc_traffic.txt; 10.9 GB / 81 % in round 2's
+    // A/B build: the eight drift apart over a launch, by how much varies).  The kernel is bound by its matrix and vector work,
+    // not by either figure; the grouped order leaves the fabric to whatever
     // runs beside it.  ATHENA_MP_GNO_STG_ORDER=spread restores round 2's mapping for A/B runs.
     const int pc = grouped ? blockIdx.x / nsub : blockIdx.x & 7, sub = grouped ? blockIdx.x % nsub : blockIdx.x >> 3;
     const int c = pc >> 1, kh = pc & 1;
