@@ -26,11 +26,20 @@ for N, d in [(50, 3), (777, 2), (4099, 3), (33000, 1), (300000, 3)]:
             "dx": lambda: ops.gno_aggregate_bwd_x(g, theta, co, gup, d, H, Fi),
             "dtheta": lambda: ops.gno_aggregate_bwd_theta(g, theta, co, x, gup, d, H),
             "dcoords": lambda: ops.gno_aggregate_bwd_coords(g, theta, co, x, gup, d, H)}
+    # the training-mode pair: the forward pass keeps S (buffer reused, poisoned in between), the reverse pass streams it
+    keep = [None]
+    def fwd_save():
+        if keep[0] is not None: keep[0].fill_(float("nan"))
+        m, keep[0] = ops.gno_aggregate_save(g, theta, co, x, d, H, Fo, s_save=keep[0])
+        return m
+    legs["fwd_save"] = fwd_save
+    legs["dtheta_saved"] = lambda: ops.gno_aggregate_bwd_theta(g, theta, co, x, gup, d, H, s_save=keep[0])
     for name, fn in legs.items():
         first = fn()
         assert torch.isfinite(first).all(), (N, name)
         for _ in range(REPS - 1):
             assert torch.equal(fn(), first), (N, name, "differs between launches")
         tot += REPS
-    print(f"N={N} d={d}: {4 * REPS} launches identical", flush=True)
+    assert torch.equal(legs["fwd_save"](), legs["fwd"]()) and torch.equal(legs["dtheta_saved"](), legs["dtheta"]())
+    print(f"N={N} d={d}: {len(legs) * REPS} launches identical", flush=True)
 print(f"soak ok: {tot} launches in {time.time() - t0:.1f} s")
