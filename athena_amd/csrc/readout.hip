@@ -127,7 +127,9 @@ __global__ void readout_bcast_kernel(int O, int64_t N, const int32_t *__restrict
 // whose accumulator comes out in the z-fragment layout, so dc = act'(z)(dz + dz_next) is formed in
 // place and stored 16 B per lane.  dR contracts over VERTICES, so z and dl are turned once through a
 // wave-private LDS tile to put the vertex on the k axis.
-template <int J, int ACT>
+// DIN: a dz_next arrives from step t + 1; its rows are prefetched one tile ahead beside z's (loaded where they are used they
+// cost a latency per tile: 0.443 ms per launch at configs[2]; prefetched 0.365 ms; 0.272 ms without dz_next)
+template <int J, int ACT, bool DIN>
 __global__ __launch_bounds__(256) void readout_bwd_kernel(int O, int64_t N, const float *__restrict__ z,
                                                           const float *__restrict__ R, const float *__restrict__ p,
                                                           const int32_t *__restrict__ gid,
@@ -156,6 +158,7 @@ __global__ __launch_bounds__(256) void readout_bwd_kernel(int O, int64_t N, cons
     for (int ft = 0; ft < J; ++ft) accR[ft] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
 
     v4f zf[J], zn[J];
+    [[maybe_unused]] v4f df[J], dn[J];
     float pf[4], pn[4], gf[4], gn[4];
     // software pipeline: graph ids two tiles ahead, rows one tile ahead, so no load waits on a load of its own stage
     auto load = [&](v4f(&zd)[J], float(&pd)[4], float(&gd)[4], int64_t tile, int g) {
@@ -163,6 +166,11 @@ __global__ __launch_bounds__(256) void readout_bwd_kernel(int O, int64_t N, cons
         const float *src = z + row * FV + 4 * q;
 #pragma unroll
         for (int j = 0; j < J; ++j) zd[j] = *reinterpret_cast<const v4f *>(src + 16 * j);
+        if constexpr (DIN) {
+            const float *dsrc = dz_in + row * FV + 4 * q;
+#pragma unroll
+            for (int j = 0; j < J; ++j) dn[j] = *reinterpret_cast<const v4f *>(dsrc + 16 * j);
+        }
         const float *ps = p + row * O + 4 * q;
         const float *gs = gout + (size_t)g * O + 4 * q;
 #pragma unroll
@@ -178,6 +186,10 @@ __global__ __launch_bounds__(256) void readout_bwd_kernel(int O, int64_t N, cons
     for (int64_t tile = gw; tile < tiles; tile += nw) {
 #pragma unroll
         for (int j = 0; j < J; ++j) zf[j] = zn[j];
+        if constexpr (DIN) {
+#pragma unroll
+            for (int j = 0; j < J; ++j) df[j] = dn[j];
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) pf[r] = pn[r], gf[r] = gn[r];
         g_n = g_nn;
@@ -203,13 +215,12 @@ __global__ __launch_bounds__(256) void readout_bwd_kernel(int O, int64_t N, cons
         // dz[row n][16 ft + 4q .. +3] = sum_o dl[row][o] R[o][f]
         // rows past the end repeat row N-1 (same loads, same values): duplicate stores instead of a branch
         float *dst = dc + min(row, N - 1) * FV + 4 * q;
-        const float *din = dz_in ? dz_in + min(row, N - 1) * FV + 4 * q : nullptr;
 #pragma unroll
         for (int ft = 0; ft < J; ++ft) {
             v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Ra[ft][r], dl[r], acc, 0, 0, 0);
-            if (din) acc = acc + *reinterpret_cast<const v4f *>(din + 16 * ft);
+            if constexpr (DIN) acc = acc + df[ft];
             v4f o4;
 #pragma unroll
             for (int c = 0; c < 4; ++c) o4[c] = act_back<ACT>(zf[ft][c], acc[c]);
@@ -310,16 +321,22 @@ int athena_mp_duvenaud_readout_bwd(int64_t N, int32_t Fv, int32_t O, int32_t S, 
         return rc;
     }
     void *gid = nullptr, *slabs = nullptr;
-    const int nblk = readout_grid(N, 4);      // ~110 VGPRs at Fv = 64: four waves per SIMD, one slab each
+    const int nblk = readout_grid(N, 4);      // 132 / 168 VGPRs at Fv = 64 (without / with dz_next): three waves per SIMD; one slab
+                                              // per workgroup (three workgroups per CU measured the same as four)
     if (workspace(&gid, sizeof(int32_t) * (size_t)N, 4) || workspace(&slabs, sizeof(float) * (size_t)nblk * n, 3))
         return 1;
     hipLaunchKernelGGL(readout_gid_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, stream(), S, seg,
                        (int32_t *)gid);
     AMP_LAUNCH_CHECK();
 #define AMP_CASE(J_, A_)                                                                                           \
-    if (Fv == 16 * J_ && act == A_)                                                                                \
-        hipLaunchKernelGGL((readout_bwd_kernel<J_, A_>), dim3(nblk), dim3(256), 0, stream(), O, N, z, R, p,        \
-                           (const int32_t *)gid, gout, dz_next, dc, (float *)slabs);
+    if (Fv == 16 * J_ && act == A_) {                                                                              \
+        if (dz_next)                                                                                               \
+            hipLaunchKernelGGL((readout_bwd_kernel<J_, A_, true>), dim3(nblk), dim3(256), 0, stream(), O, N, z, R, p, \
+                               (const int32_t *)gid, gout, dz_next, dc, (float *)slabs);                           \
+        else                                                                                                       \
+            hipLaunchKernelGGL((readout_bwd_kernel<J_, A_, false>), dim3(nblk), dim3(256), 0, stream(), O, N, z, R, p, \
+                               (const int32_t *)gid, gout, dz_next, dc, (float *)slabs);                           \
+    }
 #define AMP_ACTS(J_) AMP_CASE(J_, 0) AMP_CASE(J_, 1) AMP_CASE(J_, 2) AMP_CASE(J_, 3)
     AMP_ACTS(1) AMP_ACTS(2) AMP_ACTS(4) AMP_ACTS(8)
 #undef AMP_ACTS
