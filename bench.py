@@ -407,8 +407,10 @@ def main():
     if world == 1 and ev_dw:
         dw_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_dw]))
         flops = 2.0 * args.nodes * F * F
-        out["roofline"]["dense"] = {"bound": "mfma", "kernel": (f"gemm_dw_full_kernel<{F},{F}> + slab_reduce_kernel" if F in (64, 128) else
-                                                                  "gemm_atb_tiled (dW)") + " (matmul reverse wrt the weights, dW = dZ . P^T)",
+        dw_kernel = (f"gemm_dw_full_kernel<{F},{F}> + slab_reduce_kernel" if F in (64, 128) else
+                     f"gemm_dw_full_kernel<128,128,blocked> on {(F // 128) ** 2} blocks of dW + slab_reduce_kernel" if F % 128 == 0 and F <= 512 else
+                     "gemm_atb_tiled (dW)")
+        out["roofline"]["dense"] = {"bound": "mfma", "kernel": dw_kernel + " (matmul reverse wrt the weights, dW = dZ . P^T)",
                                     "achieved": flops / (dw_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                     "frac": flops / (dw_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "flops_per_launch": flops,
                                     "avg_launch_ms": dw_ms, "dtype": "f32 (v_mfma_f32_32x32x2_f32, exact fp32 products)"}
