@@ -243,3 +243,20 @@ def test_bench_line_refuses_the_test_transport_outside_the_dry_run():
     assert bench.transport_error("shm (test transport: host-staged files, not RCCL)", True) is None
     assert "not RCCL" in bench.transport_error("shm (test transport: host-staged files, not RCCL)", False)
     assert bench.transport_error("torch.distributed point-to-point (python plan) -- FALLBACK, the C-ABI path failed: x", False)
+
+
+def test_experiment_patches_still_apply():
+    """scripts/experiments/*.patch (round-3 kernels that were measured and not adopted) must keep applying to the product
+    source, or the 'measured and dropped' lines of DESIGN.md cannot be re-run"""
+    import glob
+    import shutil
+    import subprocess
+
+    if shutil.which("git") is None:
+        pytest.skip("git not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    patches = sorted(glob.glob(os.path.join(root, "scripts", "experiments", "*.patch")))
+    assert len(patches) >= 3
+    for pth in patches:
+        r = subprocess.run(["git", "apply", "--check", pth], cwd=root, capture_output=True, text=True)
+        assert r.returncode == 0, f"{os.path.basename(pth)}: {r.stderr[-500:]}"
