@@ -61,6 +61,7 @@ module athena_mp_layers
      integer, allocatable :: vertex_offset(:)          ! (batch+1), 0-based starts of each graph's vertices
      type(dbuf) :: seg                                 ! the same offsets on the device (int32)
      logical :: keep_edges = .false.
+     logical :: inference = .false.                    ! base_layer_type%inference (athena_base_layer.f90:48): no reverse pass follows
      ! what the handle was built from: per graph of the batch its sizes and the content key of its CSR
      ! (athena_mp_graph_key).  set_graph compares these and keeps the handle when nothing changed.
      integer, allocatable :: key_n(:), key_nnz(:), key_ne(:)
@@ -1268,7 +1269,7 @@ contains
     call need(this%scratch(1), i8(n) * i8(max(fi, fo)))
     this%s_valid = .false.
     s_bytes = 0_c_int64_t
-    if(this%keep_s) call chk(athena_mp_gno_saved_bytes(this%graph, int(this%coord_dim, c_int32_t), &
+    if(this%keep_s .and. .not. this%inference) call chk(athena_mp_gno_saved_bytes(this%graph, int(this%coord_dim, c_int32_t), &
          int(this%kernel_hidden, c_int32_t), int(fi, c_int32_t), int(fo, c_int32_t), s_bytes), "gno_saved_bytes")
     if(s_bytes .gt. 0_c_int64_t .and. real(s_bytes) .le. keep_s_max_gb() * 1.e9)then
        if(s_bytes / 4_c_int64_t .gt. this%s_save%cap)then       ! no room for S beside the model: rebuild it from now on

@@ -109,6 +109,8 @@ class msgpass_layer_type:
         self.grads = []    # params(i)%grad%val(:,1) or None
         self.graph = None
         self.output = None
+        self.inference = False   # base_layer_type%inference (athena_base_layer.f90:48; network%set_training / inference,
+                                 # athena_network_sub.f90:1882-1915): a forward pass that no reverse pass follows
 
     # -- graph ---------------------------------------------------------------------------------
     def set_graph(self, graphs):
@@ -518,7 +520,7 @@ class graph_nop_layer_type(msgpass_layer_type):
         pass
 
     def _keeps_s(self, g, Fi, Fo):
-        if self.keep_s is False:
+        if self.keep_s is False or self.inference:      # inference mode: no reverse pass will ask for S
             return False
         nbytes = ops.gno_saved_bytes(g, self.coord_dim, self.kernel_hidden, Fi, Fo)
         if nbytes == 0:

@@ -177,6 +177,9 @@ def test_gno_layer_keeps_s_between_forward_and_backward(dev):
         assert layer._s_save is buf
     for a, b in zip(got[None], got[False]):
         assert np.array_equal(a, b)
+    layer.keep_s, layer.inference = None, True      # base_layer_type%inference: a forward pass no reverse pass follows keeps nothing
+    assert np.array_equal(layer.forward(xs, cs).cpu().numpy(), got[None][0]) and not layer._s_valid
+    layer.inference = False
     F = Fo * Fi
     sizes = [H * d + H + F * H + F, F, Fo]
     plist, o_ = [], 0
