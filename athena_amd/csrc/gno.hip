@@ -202,7 +202,6 @@ __global__ __launch_bounds__(256) void gno_outer_mfma_kernel(const int32_t *__re
 // The per-wave partial sums are added through LDS in wave order (deterministic).
 typedef float v4f_g __attribute__((ext_vector_type(4)));
 typedef unsigned int v4u_g __attribute__((ext_vector_type(4)));
-#ifndef GNO_FV
 // how gno_pc_kernel<true> writes the S it keeps: 0 nontemporal global stores, 1 plain stores, 2 buffer stores with the cache
 // bits GNO_SAVE_AUX (1 sc0, 2 nt, 16 sc1), 3 none (timing only).  configs[3], ms per launch, two runs each on one box
 // (scripts/gpu_keeps_ab.sh): plain 14.65 / 14.74, nt global 14.21 / 14.28, buffer nt 14.05 / 14.08, buffer sc0 sc1 nt 14.07 / 14.09,
@@ -214,6 +213,7 @@ typedef unsigned int v4u_g __attribute__((ext_vector_type(4)));
 #ifndef GNO_SAVE_AUX
 #define GNO_SAVE_AUX 2
 #endif
+#ifndef GNO_FV
 #define GNO_FV 0   // timing-only variants (scripts/build_variants.sh), bit mask: 1 no sparse loop, 2 no V loads, 4 no S reads, 8 no contraction, 16 no cross-wave reduction (gno_fused_kernel); 32 idle producers, 64 idle consumers (gno_pc_kernel)
 #endif
 constexpr int kGF = 64, kGH = 64, kGRows = 16, kGSP = 33 * kGF + 4;   // LDS row pitch of S_half
@@ -827,6 +827,8 @@ __global__ __launch_bounds__(kPcThreads) void gno_pc_kernel(const int32_t *__res
                 const bool last = pc == 7;
                 if (last) { pJ0 = nxt.J0; pJ1 = nxt.J1; }
                 const bool second = !SHORT && (last ? nstN : nstT) > 4;   // does the piece being requested read entries 16 .. 31
+                // (asking for them unconditionally in this loop -- no branch, no register copies around it -- measured 11.81
+                // against 11.85 ms: not worth a second code path)
                 // the four vertices of the wave with the step count of the longest of them as a compile-time constant
                 // (tiles hold vertices of nearly equal length, so the shorter rows' extra steps -- on zeros -- are few)
                 auto four = [&](auto K, auto FILL) {
