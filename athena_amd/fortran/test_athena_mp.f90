@@ -25,6 +25,7 @@ program test_athena_mp
   call train_loop_resident()
   call csr_from_edges_on_device()
   call resident_chain_on_host_arrays()
+  call gno_training_pair()
 
   rc = athena_mp_finalize()
   if(success)then
@@ -325,6 +326,82 @@ contains
     call check(athena_mp_graph_destroy(g), "graph_destroy")
     write(*,*) "resident chain on host arrays: X up once, Z down once -- ok"
   end subroutine resident_chain_on_host_arrays
+
+  subroutine gno_training_pair()
+    !! athena_mp_gno_saved_bytes / _aggregate_fwd_save / _aggregate_bwd_theta_saved from Fortran: a 40-vertex ring with
+    !! chords at the widths whose forward pass can keep S (H = F_in = F_out = 64, d = 3); the pair that keeps S against
+    !! the pair that rebuilds it, bit for bit
+    integer, parameter :: nv = 40, ne = 60, d = 3, h = 64, f = 64
+    integer, parameter :: nth = h*d + h + f*f*h + f*f
+    integer(c_int32_t) :: adj_ia(nv+1), adj_ja(2, 2*ne), index_list(2, ne)
+    real(real32), allocatable :: theta(:), x(:,:), coords(:,:), up(:,:), m1(:,:), m2(:,:), dt1(:), dt2(:)
+    type(c_ptr) :: g2, d_theta, d_x, d_c, d_up, d_m, d_dt, d_s
+    integer(c_int64_t) :: bytes
+    integer :: deg(nv), pos(nv), e, u, v, i
+
+    do e = 1, nv
+       index_list(:, e) = [e, mod(e, nv) + 1]
+    end do
+    do e = nv + 1, ne
+       index_list(:, e) = [e - nv, mod(e - nv + 6, nv) + 1]
+    end do
+    deg = 0
+    do e = 1, ne
+       deg(index_list(1,e)) = deg(index_list(1,e)) + 1
+       deg(index_list(2,e)) = deg(index_list(2,e)) + 1
+    end do
+    adj_ia(1) = 1
+    do v = 1, nv
+       adj_ia(v+1) = adj_ia(v) + deg(v)
+    end do
+    pos = adj_ia(1:nv)
+    do e = 1, ne
+       u = index_list(1,e); v = index_list(2,e)
+       adj_ja(:,pos(u)) = [v, e]; pos(u) = pos(u) + 1
+       adj_ja(:,pos(v)) = [u, e]; pos(v) = pos(v) + 1
+    end do
+    allocate(theta(nth), x(f,nv), coords(d,ne), up(f,nv), m1(f,nv), m2(f,nv), dt1(nth), dt2(nth))
+    do i = 1, nth
+       theta(i) = 0.3_real32 * sin(real(7*i, real32) * 0.37_real32)
+    end do
+    do v = 1, nv
+       do i = 1, f
+          x(i,v) = sin(real(i + 3*v, real32)); up(i,v) = cos(real(2*i + v, real32))
+       end do
+    end do
+    do e = 1, ne
+       coords(:, e) = [sin(real(e, real32)), cos(real(2*e, real32)), sin(real(3*e, real32) + 1._real32)]
+    end do
+    call check(athena_mp_graph_create(nv, nv, int(2*ne, c_int64_t), adj_ia, adj_ja, ne, c_null_ptr, c_null_ptr, g2), "graph")
+    call check(athena_mp_gno_saved_bytes(g2, d, h, f, f, bytes), "gno_saved_bytes")
+    if(bytes .ne. 4_c_int64_t * 2_c_int64_t * (8*32*512 + 32*64))then
+       write(0,*) "gno_saved_bytes:", bytes; success = .false.
+    end if
+    call check(athena_mp_malloc(d_theta, int(4*nth, c_int64_t)), "malloc"); call check(athena_mp_malloc(d_x, int(4*f*nv, c_int64_t)), "malloc")
+    call check(athena_mp_malloc(d_c, int(4*d*ne, c_int64_t)), "malloc"); call check(athena_mp_malloc(d_up, int(4*f*nv, c_int64_t)), "malloc")
+    call check(athena_mp_malloc(d_m, int(4*f*nv, c_int64_t)), "malloc"); call check(athena_mp_malloc(d_dt, int(4*nth, c_int64_t)), "malloc")
+    call check(athena_mp_malloc(d_s, max(bytes, 16_c_int64_t)), "malloc")
+    call check(athena_mp_memcpy_h2d(d_theta, theta, int(4*nth, c_int64_t)), "h2d"); call check(athena_mp_memcpy_h2d(d_x, x, int(4*f*nv, c_int64_t)), "h2d")
+    call check(athena_mp_memcpy_h2d(d_c, coords, int(4*d*ne, c_int64_t)), "h2d"); call check(athena_mp_memcpy_h2d(d_up, up, int(4*f*nv, c_int64_t)), "h2d")
+    call check(athena_mp_gno_aggregate_fwd(g2, d, h, f, f, d_theta, d_c, d_x, d_m), "gno_aggregate_fwd")
+    call check(athena_mp_memcpy_d2h(m1, d_m, int(4*f*nv, c_int64_t)), "d2h")
+    call check(athena_mp_gno_aggregate_fwd_save(g2, d, h, f, f, d_theta, d_c, d_x, d_m, d_s), "gno_aggregate_fwd_save")
+    call check(athena_mp_memcpy_d2h(m2, d_m, int(4*f*nv, c_int64_t)), "d2h")
+    call check(athena_mp_gno_aggregate_bwd_theta(g2, d, h, f, f, d_theta, d_c, d_x, d_up, d_dt), "gno_aggregate_bwd_theta")
+    call check(athena_mp_memcpy_d2h(dt1, d_dt, int(4*nth, c_int64_t)), "d2h")
+    call check(athena_mp_gno_aggregate_bwd_theta_saved(g2, d, h, f, f, d_theta, d_c, d_x, d_up, d_s, d_dt), "gno_aggregate_bwd_theta_saved")
+    call check(athena_mp_memcpy_d2h(dt2, d_dt, int(4*nth, c_int64_t)), "d2h")
+    if(any(m1 .ne. m2) .or. maxval(abs(m1)) .le. 0._real32)then
+       write(0,*) "gno training pair: forward differs", maxval(abs(m1 - m2)); success = .false.
+    end if
+    if(any(dt1 .ne. dt2) .or. maxval(abs(dt1)) .le. 0._real32)then
+       write(0,*) "gno training pair: dtheta differs", maxval(abs(dt1 - dt2)); success = .false.
+    end if
+    call check(athena_mp_graph_destroy(g2), "destroy")
+    call check(athena_mp_free(d_theta), "free"); call check(athena_mp_free(d_x), "free"); call check(athena_mp_free(d_c), "free")
+    call check(athena_mp_free(d_up), "free"); call check(athena_mp_free(d_m), "free"); call check(athena_mp_free(d_dt), "free")
+    call check(athena_mp_free(d_s), "free")
+  end subroutine gno_training_pair
 
   subroutine check(rc, what)
     integer(c_int), intent(in) :: rc
