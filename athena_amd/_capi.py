@@ -43,6 +43,7 @@ _PROTOS = {
     "athena_mp_graph_key": [_i32, _i64, _vp, _vp, C.POINTER(C.c_uint64)],
     "athena_mp_graph_acquire": [_i32, _i64, _vp, _vp, _i32, C.POINTER(_vp)],
     "athena_mp_graph_release": [_vp],
+    "athena_mp_graph_evict": [_vp],
     "athena_mp_graph_cache_stats": [C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)],
     "athena_mp_graph_dims": [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i32)],
     "athena_mp_kipf_propagate_fwd": [_vp, _i32, _vp, _vp],

@@ -10,7 +10,9 @@
 
 #include <algorithm>
 #include <map>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -173,7 +175,16 @@ int athena_mp_synchronize(void)
 int athena_mp_malloc(void **p, uint64_t bytes)
 {
     AMP_REQUIRE(p != nullptr, "athena_mp_malloc: null out pointer");
-    AMP_HIP(hipMalloc(p, bytes ? bytes : 4));
+    *p = nullptr;
+    const hipError_t e = hipMalloc(p, bytes ? bytes : 4);
+    if (e != hipSuccess) {
+        // callers with a fallback (the S buffer of a training-mode GNO layer) go on after a refusal: the error must not
+        // stay behind as the thread's last error for the next AMP_LAUNCH_CHECK to find
+        (void)hipGetLastError();
+        *p = nullptr;
+        amp::set_error("athena_mp_malloc: %llu bytes: %s", (unsigned long long)bytes, hipGetErrorString(e));
+        return 1;
+    }
     return 0;
 }
 int athena_mp_free(void *p)
@@ -429,23 +440,82 @@ struct KeyHash {   // MurmurHash3's 64-bit lane: multiply-rotate per 8-byte word
 };
 }   // namespace
 
+/* Chunked, lane-parallel form of the hash for large arrays: the array is cut into fixed chunks of kKeyChunk int32
+ * values, every chunk is hashed by four interleaved lanes (four independent multiply chains per core instead of one),
+ * chunks are handed to up to ATHENA_MP_GRAPH_KEY_THREADS host threads (default 8) and the chunk digests are folded in
+ * chunk order -- the key does not depend on the thread count.  EVERY word of adj_ia / adj_ja enters the key. */
+namespace {
+constexpr int64_t kKeyChunk = (int64_t)1 << 20;
+uint64_t key_chunk(const int32_t *p, int64_t count, uint64_t seed)
+{
+    KeyHash l0(seed), l1(seed ^ 0x243f6a8885a308d3ull), l2(seed ^ 0x13198a2e03707344ull), l3(seed ^ 0xa4093822299f31d0ull);
+    int64_t i = 0;
+    for (; i + 8 <= count; i += 8) {
+        uint64_t k[4];
+        memcpy(k, p + i, 32);
+        l0.word(k[0]);
+        l1.word(k[1]);
+        l2.word(k[2]);
+        l3.word(k[3]);
+    }
+    l0.ints(p + i, count - i);
+    l0.word(l1.digest());
+    l0.word(l2.digest());
+    l0.word(l3.digest());
+    return l0.digest();
+}
+void key_array(KeyHash &h, const int32_t *p, int64_t count)
+{
+    if (count <= 0) return;
+    const int64_t n_chunks = (count + kKeyChunk - 1) / kKeyChunk;
+    std::vector<uint64_t> dig((size_t)n_chunks);
+    static const int max_threads = [] {
+        const char *e = getenv("ATHENA_MP_GRAPH_KEY_THREADS");
+        int t = e ? atoi(e) : 8;
+        const int hw = (int)std::thread::hardware_concurrency();
+        if (hw > 0) t = std::min(t, hw);
+        return std::max(1, t);
+    }();
+    const int n_thr = (int)std::min<int64_t>(max_threads, n_chunks);
+    auto work = [&](int t) {
+        for (int64_t c = t; c < n_chunks; c += n_thr) {
+            const int64_t b = c * kKeyChunk;
+            dig[(size_t)c] = key_chunk(p + b, std::min(kKeyChunk, count - b), 0x9e3779b97f4a7c15ull + (uint64_t)c);
+        }
+    };
+    if (n_thr == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < n_thr; ++t) pool.emplace_back(work, t);
+        work(0);
+        for (auto &th : pool) th.join();
+    }
+    for (uint64_t d : dig) h.word(d);
+}
+}   // namespace
+
 int athena_mp_graph_key(int32_t n_rows, int64_t nnz, const int32_t *adj_ia, const int32_t *adj_ja, uint64_t *key)
 {
     AMP_REQUIRE(key != nullptr, "graph_key: null key pointer");
     AMP_REQUIRE(n_rows >= 0 && nnz >= 0, "graph_key: negative size");
     AMP_REQUIRE(adj_ia != nullptr && (nnz == 0 || adj_ja != nullptr), "graph_key: null CSR arrays");
-    static const int full = [] {
-        const char *e = getenv("ATHENA_MP_GRAPH_KEY_FULL");
+    // The reference re-copies the CSR on every set_graph (athena_msgpass_layer_sub.f90:144-174) and is always current:
+    // the DEFAULT key therefore covers every word.  ATHENA_MP_GRAPH_KEY_SAMPLED=1 opts into the cheap sampled key for
+    // callers that promise to invalidate_graph() after an in-place edit.
+    static const int sampled = [] {
+        const char *e = getenv("ATHENA_MP_GRAPH_KEY_SAMPLED");
         return (e && e[0] && e[0] != '0') ? 1 : 0;
     }();
     KeyHash h(0x9e3779b97f4a7c15ull);
     h.word((uint64_t)(uint32_t)n_rows);
     h.word((uint64_t)nnz);
     const int64_t ni = (int64_t)n_rows + 1;
-    if (full || nnz < ((int64_t)1 << 18)) {
-        h.ints(adj_ia, ni);
-        h.ints(adj_ja, 2 * nnz);
+    if (!sampled || nnz < ((int64_t)1 << 18)) {
+        key_array(h, adj_ia, ni);
+        key_array(h, adj_ja, 2 * nnz);
     } else {
+        h.word(0x5a3b1edull);   // a sampled key never equals a full one
         const int64_t head = 1024;
         // row pointers: head, tail, every (ni / 4096)-th
         h.ints(adj_ia, std::min(head, ni));
@@ -486,6 +556,7 @@ struct CacheId {
     }
 };
 std::map<CacheId, athena_mp_graph *> g_cache;
+std::mutex g_cache_mu;   // acquire / release / evict / clear may come from different host threads (one per layer is legal)
 uint64_t g_cache_tick = 0;
 int64_t g_cache_hits = 0;
 
@@ -496,6 +567,16 @@ int64_t cache_idle_cap()   // entries (nnz + n) the idle handles may hold togeth
         return e ? (int64_t)atoll(e) : ((int64_t)1 << 28);
     }();
     return cap;
+}
+
+void cache_unlink(athena_mp_graph *g)   // the map forgets g; g stays alive for the users it still has
+{
+    for (auto it = g_cache.begin(); it != g_cache.end(); ++it)
+        if (it->second == g) {
+            g_cache.erase(it);
+            break;
+        }
+    g->cache_linked = false;
 }
 
 void cache_trim()   // least recently used idle handles go first
@@ -519,11 +600,19 @@ void cache_trim()   // least recently used idle handles go first
 }   // namespace
 
 extern "C++" {
+/* athena_mp_finalize: idle handles are freed; a handle somebody still holds is only unlinked -- its owner's
+ * athena_mp_graph_destroy / _release frees it (it used to be freed here, under its owner's feet). */
 void amp::graph_cache_clear()
 {
+    std::lock_guard<std::mutex> lock(g_cache_mu);
     for (auto &kv : g_cache) {
-        kv.second->cache_refs = -1;
-        (void)graph_free(kv.second);
+        athena_mp_graph *g = kv.second;
+        if (g->cache_refs > 0) {
+            g->cache_linked = false;
+            continue;
+        }
+        g->cache_refs = -1;
+        (void)graph_free(g);
     }
     g_cache.clear();
 }
@@ -541,6 +630,7 @@ int athena_mp_graph_acquire(int32_t n, int64_t nnz, const int32_t *adj_ia, const
     id.n = n;
     id.n_edge_cols = n_edge_cols;
     id.device = amp::device();
+    std::lock_guard<std::mutex> lock(g_cache_mu);
     auto it = g_cache.find(id);
     if (it != g_cache.end()) {
         it->second->cache_refs++;
@@ -553,6 +643,7 @@ int athena_mp_graph_acquire(int32_t n, int64_t nnz, const int32_t *adj_ia, const
     rc = athena_mp_graph_create(n, n, nnz, adj_ia, adj_ja, n_edge_cols, nullptr, nullptr, &g);
     if (rc) return rc;
     g->cache_refs = 1;
+    g->cache_linked = true;
     g->cache_key = id.key;
     g->cache_tick = ++g_cache_tick;
     g->cache_device = id.device;
@@ -561,18 +652,43 @@ int athena_mp_graph_acquire(int32_t n, int64_t nnz, const int32_t *adj_ia, const
     return 0;
 }
 
-int athena_mp_graph_release(athena_mp_graph *g)
+static int graph_release_locked(athena_mp_graph *g)
 {
-    if (!g) return 0;
     AMP_REQUIRE(g->cache_refs > 0, "graph_release: handle is not an acquired one (refs %d)", g->cache_refs);
     g->cache_refs--;
     g->cache_tick = ++g_cache_tick;
-    if (g->cache_refs == 0) cache_trim();
+    if (g->cache_refs == 0) {
+        if (!g->cache_linked) {   // evicted, or the cache was cleared, while this user held it: the last user frees
+            g->cache_refs = -1;
+            return graph_free(g);
+        }
+        cache_trim();
+    }
     return 0;
+}
+
+int athena_mp_graph_release(athena_mp_graph *g)
+{
+    if (!g) return 0;
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    return graph_release_locked(g);
+}
+
+/* invalidate_graph() / graph_type%touch(): the caller edited adj_ia / adj_ja in place and says so.  The handle leaves
+ * the cache NOW -- the next acquire of whatever key the arrays hash to builds from the arrays -- and the caller's
+ * reference is dropped; other holders keep a valid (old-topology) handle until they release it. */
+int athena_mp_graph_evict(athena_mp_graph *g)
+{
+    if (!g) return 0;
+    if (g->cache_refs < 0) return graph_free(g);   // never cached: plain destroy
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    if (g->cache_linked) cache_unlink(g);
+    return graph_release_locked(g);
 }
 
 int athena_mp_graph_cache_stats(int64_t *handles, int64_t *hits, int64_t *builds)
 {
+    std::lock_guard<std::mutex> lock(g_cache_mu);
     if (handles) *handles = (int64_t)g_cache.size();
     if (hits) *hits = g_cache_hits;
     if (builds) *builds = g_graph_builds;

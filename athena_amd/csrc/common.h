@@ -76,6 +76,7 @@ struct athena_mp_graph {
     int32_t max_row_len = 0, max_col_len = 0;
     // handle cache (athena_mp_graph_acquire / _release): users of a cached handle, -1 = not cached
     int32_t cache_refs = -1;
+    bool cache_linked = false;   // still findable by key (false after athena_mp_graph_evict / athena_mp_finalize)
     uint64_t cache_key = 0;
     uint64_t cache_tick = 0;
     int cache_device = 0;

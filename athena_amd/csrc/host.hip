@@ -50,7 +50,9 @@ int pool_get(int slot, size_t bytes, void **out)
 // (athena's forward_generic2d reads layer%output, athena_network_sub.f90:2752,2761; the optimiser reads the gradients,
 // :2856).  While a result lives only on the device its host array carries a 16-byte sentinel at both ends: if host code
 // (or a re-allocated array at the same address) writes there, the next use sees the sentinel gone and uploads the host
-// content instead of trusting the device copy.  An argument that only OVERLAPS a registered array (a slice) makes that
+// content instead of trusting the device copy; a flush (explicit, forced by an overlapping argument, or on leaving
+// resident mode) sees it gone and leaves the host array alone.  The sentinel guards the two ENDS of the array: host code
+// that rewrites only interior elements of a parked result is outside the contract (include/athena_mp.h, residency).  An argument that only OVERLAPS a registered array (a slice) makes that
 // array materialise first.
 struct Resident {
     void *dev = nullptr;
@@ -64,6 +66,7 @@ bool g_res_on = false;
 uint64_t g_res_next_id = 1;
 struct ResidentStats {
     int64_t h2d_bytes = 0, d2h_bytes = 0, reused_inputs = 0, lazy_outputs = 0;
+    int64_t stale_dropped = 0;   // flushes skipped because the host array had been overwritten (sentinel gone)
 } g_res_stats;
 
 constexpr size_t kResidentMin = 64;   // smaller arguments are staged as before
@@ -89,6 +92,15 @@ bool sentinel_intact(const Resident &r, const void *host)
 }
 int resident_flush_one(const char *host, Resident &r)
 {
+    if (r.dev_newer && !sentinel_intact(r, host)) {
+        // host code wrote the array (or the address now belongs to another allocation) after the result was parked on the
+        // device: the HOST content is the newer one.  Copying r.bytes down would overwrite it -- and, for a re-allocated
+        // smaller array, memory beyond it.  The device copy is stale: forget that it was ever newer.
+        r.dev_newer = false;
+        r.trusted = false;
+        ++g_res_stats.stale_dropped;
+        return 0;
+    }
     if (r.dev_newer) {
         AMP_HIP(hipMemcpyAsync((void *)host, r.dev, r.bytes, hipMemcpyDeviceToHost, stream()));
         AMP_HIP(hipStreamSynchronize(stream()));

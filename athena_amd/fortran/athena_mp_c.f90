@@ -14,7 +14,7 @@ module athena_mp_c
 
   public :: athena_mp_init, athena_mp_finalize, athena_mp_last_error, athena_mp_synchronize
   public :: athena_mp_graph_create, athena_mp_graph_destroy, athena_mp_graph_key
-  public :: athena_mp_graph_acquire, athena_mp_graph_release, athena_mp_graph_cache_stats
+  public :: athena_mp_graph_acquire, athena_mp_graph_release, athena_mp_graph_evict, athena_mp_graph_cache_stats
   public :: athena_mp_kipf_propagate_fwd_host, athena_mp_kipf_propagate_bwd_host
   public :: athena_mp_gemm_fwd_host
   public :: athena_mp_duvenaud_propagate_fwd_host, athena_mp_duvenaud_propagate_bwd_x_host
@@ -135,6 +135,11 @@ module athena_mp_c
        type(c_ptr), intent(out) :: graph
      end function
      integer(c_int) function athena_mp_graph_release(graph) bind(C, name="athena_mp_graph_release")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: graph
+     end function
+     !! release + the cache forgets the handle: after an in-place edit the caller announces (invalidate_graph)
+     integer(c_int) function athena_mp_graph_evict(graph) bind(C, name="athena_mp_graph_evict")
        import :: c_int, c_ptr
        type(c_ptr), value :: graph
      end function

@@ -392,11 +392,11 @@ contains
     !! athena_msgpass_layer_sub.f90:144-174.  The batch becomes ONE block-diagonal device graph: vertex
     !! ids shifted by the vertices before, edge ids (where > 0) by the edge columns before.
     !! The reference calls this before EVERY forward (athena_network_sub.f90:2727-2730) and copies the CSR each
-    !! time; here it costs one content key per graph (athena_mp_graph_key: all of a mini-batch graph, a sample of a
-    !! 10 M-entry one) -- the handle is rebuilt only when a size or a key differs from what it was built from, and a
+    !! time; here it costs one content key per graph (athena_mp_graph_key: every word of adj_ia / adj_ja, hashed by a
+    !! few host threads) -- the handle is rebuilt only when a size or a key differs from what it was built from, and a
     !! rebuilt batch goes through athena_mp_graph_acquire, so layers that are given the same batch share one handle.
-    !! A large graph edited IN PLACE outside the sampled elements needs invalidate_graph() (or
-    !! ATHENA_MP_GRAPH_KEY_FULL=1).
+    !! An in-place edit is therefore always seen, as in the reference.  Only under ATHENA_MP_GRAPH_KEY_SAMPLED=1 (the
+    !! cheap sampled key for graphs of 2^18 entries and more) does an in-place edit need invalidate_graph().
     class(mp_layer_type), intent(inout) :: this
     type(mp_graph_type), intent(in) :: graph(:)
     integer(c_int32_t), allocatable :: ia(:), ja(:,:)
@@ -423,7 +423,7 @@ contains
          .and. all(this%key_hash .eq. kh)
     if(same) return                                    ! the handle, offsets and device segments are still valid
 
-    call layer_invalidate_graph(this)
+    call layer_drop_graph(this)
     this%batch = b
     if(allocated(this%vertex_offset)) deallocate(this%vertex_offset)
     allocate(this%vertex_offset(b + 1))
@@ -470,11 +470,19 @@ contains
     call chk(athena_mp_memcpy_h2d(this%seg%p, this%vertex_offset, 4_c_int64_t * i8(this%batch + 1)), "h2d")
   end subroutine layer_set_graph
 
-  subroutine layer_invalidate_graph(this)
-    !! drop the handle: the next set_graph rebuilds whatever its keys say (for in-place edits of a large adjacency
-    !! that the sampled key may not see)
+  subroutine layer_drop_graph(this)
+    !! one user less of the handle (it stays in the library's cache for the next epoch's batch of the same content)
     class(mp_layer_type), intent(inout) :: this
     if(c_associated(this%graph)) call chk(athena_mp_graph_destroy(this%graph), "graph_destroy")
+    this%graph = c_null_ptr
+    if(allocated(this%key_hash)) deallocate(this%key_n, this%key_nnz, this%key_ne, this%key_hash)
+  end subroutine layer_drop_graph
+
+  subroutine layer_invalidate_graph(this)
+    !! the caller edited the adjacency in place and says so: the handle is dropped AND leaves the library's cache
+    !! (athena_mp_graph_evict), so the next set_graph builds from the arrays whatever their key is
+    class(mp_layer_type), intent(inout) :: this
+    if(c_associated(this%graph)) call chk(athena_mp_graph_evict(this%graph), "graph_evict")
     this%graph = c_null_ptr
     if(allocated(this%key_hash)) deallocate(this%key_n, this%key_nnz, this%key_ne, this%key_hash)
   end subroutine layer_invalidate_graph
@@ -493,7 +501,7 @@ contains
     if(size(index_list, 1) .ne. 2) call stop_program("set_graph_from_edges: index_list must be (2, num_edges)")
     loops = 0
     if(present(add_self_loops)) loops = merge(1_c_int32_t, 0_c_int32_t, add_self_loops)
-    call layer_invalidate_graph(this)
+    call layer_drop_graph(this)
     this%graph_builds = this%graph_builds + 1
     this%batch = 1
     this%nv = num_vertices
@@ -620,7 +628,7 @@ contains
   subroutine layer_release_base(this)
     class(mp_layer_type), intent(inout) :: this
     integer :: i
-    call layer_invalidate_graph(this)
+    call layer_drop_graph(this)
     call release(this%seg)
     do i = 1, this%num_tensors
        call release(this%params(i))
@@ -1254,7 +1262,7 @@ contains
     class(graph_nop_mp_layer_type), intent(inout) :: this
     type(c_ptr), intent(in) :: x_dev, coords_dev
     type(c_ptr) :: y_dev
-    type(c_ptr) :: bias
+    type(c_ptr) :: bias, s_new
     integer :: n, fi, fo
     integer(c_int64_t) :: s_bytes
 
@@ -1273,11 +1281,20 @@ contains
          int(this%kernel_hidden, c_int32_t), int(fi, c_int32_t), int(fo, c_int32_t), s_bytes), "gno_saved_bytes")
     if(s_bytes .gt. 0_c_int64_t .and. real(s_bytes) .le. keep_s_max_gb() * 1.e9)then
        if(s_bytes / 4_c_int64_t .gt. this%s_save%cap)then       ! no room for S beside the model: rebuild it from now on
+          ! the new buffer first, the old one only once the new one is known to exist; when both do not fit side by
+          ! side, once more with the old one gone; a refusal leaves no error behind (athena_mp_malloc clears it) and
+          ! the layer rebuilds S in the reverse pass from now on
+          s_new = c_null_ptr
+          if(athena_mp_malloc(s_new, s_bytes) .ne. 0)then
+             call release(this%s_save)
+             s_new = c_null_ptr
+             if(athena_mp_malloc(s_new, s_bytes) .ne. 0) s_new = c_null_ptr
+          end if
           call release(this%s_save)
-          if(athena_mp_malloc(this%s_save%p, s_bytes) .eq. 0)then
+          if(c_associated(s_new))then
+             this%s_save%p = s_new
              this%s_save%cap = s_bytes / 4_c_int64_t
           else
-             this%s_save%p = c_null_ptr
              this%keep_s = .false.
              s_bytes = 0_c_int64_t
           end if

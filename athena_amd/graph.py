@@ -55,10 +55,11 @@ class graph_type:
 
     def topology_key(self):
         """what a cached device handle of this graph is valid for: the object, its version (bumped by every assignment
-        of adj_ia / adj_ja), the sizes and the C ABI's content key of the arrays (athena_mp_graph_key: all of the
-        content below 2^18 entries, a strided sample plus head and tail above -- in-place edits of a mini-batch graph
-        are always seen; hashing 80 MB per forward on a 10 M-entry graph would cost more than the layer step.  After
-        an in-place edit of a LARGE adjacency call touch(), or run with ATHENA_MP_GRAPH_KEY_FULL=1)."""
+        of adj_ia / adj_ja), the sizes and the C ABI's content key of the arrays (athena_mp_graph_key: EVERY word of
+        both arrays, hashed by a few host threads -- an in-place edit is always seen, as in the reference, which
+        re-copies the CSR on every set_graph.  Only under ATHENA_MP_GRAPH_KEY_SAMPLED=1 does a graph of 2^18 entries
+        or more get the cheap sampled key; then an in-place edit needs touch(), which also evicts the stale handle
+        from the library's cache)."""
         import ctypes as C
 
         from . import _capi
@@ -262,6 +263,14 @@ class DeviceGraph:
     def from_graph(cls, g, device=0):
         return cls(g.adj_ia, g.adj_ja, n_edge_cols=max(g.num_edges, int(g.adj_ja[1].max()) if g.nnz else 0),
                    device=device)
+
+    def evict(self):
+        """close(), and the library's handle cache forgets this handle (athena_mp_graph_evict): the next acquire of the
+        same key builds from the arrays.  What a layer does with its old handle after graph_type.touch()."""
+        if getattr(self, "handle", None):
+            if not getattr(self, "_borrowed", False):
+                _capi.call("athena_mp_graph_evict", self.handle)
+            self.handle = None
 
     def close(self):
         if getattr(self, "handle", None):

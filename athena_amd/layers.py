@@ -120,7 +120,13 @@ class msgpass_layer_type:
         # the cache is keyed on CONTENT (object, version, sizes, checksum of adj_ia / adj_ja), and the layer holds the
         # graph objects so that an id cannot be recycled for a new graph while the key is alive
         key = tuple(g.topology_key() for g in graphs)
-        if getattr(self, "_graph_key", None) != key:
+        old = getattr(self, "_graph_key", None)
+        if old != key:
+            if (self.graph is not None and old is not None and len(old) == len(key)
+                    and all(a[0] == b[0] and a[2:] == b[2:] for a, b in zip(old, key))):
+                # same objects, same sizes, same content key, newer version: graph_type.touch() (or a re-assignment)
+                # says the arrays changed although the key does not -- the cached handle must not be found again
+                self.graph.device.evict()
             self.graph = _batched_graph(graphs, self.device.index or 0, self._needs_edges)
             self._graph_key = key
             self._graph_refs = list(graphs)

@@ -100,11 +100,14 @@ int athena_mp_graph_dims(const athena_mp_graph *g, int32_t *n_rows, int32_t *n_c
 /* What a cached handle of (adj_ia, adj_ja) is valid for -- the key a layer's set_graph compares before it rebuilds
  * (SURVEY.md 8b "Ownership", F12; the reference re-copies the CSR in every set_graph_msgpass,
  * athena_msgpass_layer_sub.f90:144-174, called before every forward, athena_network_sub.f90:2727-2730).
- * 64-bit hash of the sizes and of the arrays' CONTENT: all of it below 2^18 entries (mini-batch graphs: an in-place
- * edit is always seen); above, the first and last 1024 elements / columns plus a strided sample of 4096 of each array
- * (hashing 80 MB per forward at 10 M entries would cost more than the layer step) -- set the environment variable
- * ATHENA_MP_GRAPH_KEY_FULL=1 to hash everything at every size.  Host-only, no device call, no library state: the
- * Fortran interface is declared `pure`.  Two different graphs of equal n and nnz get different keys (up to 2^-64). */
+ * 64-bit hash of the sizes and of EVERY word of both arrays (chunks of 2^20 values hashed by up to
+ * ATHENA_MP_GRAPH_KEY_THREADS host threads, default 8, folded in chunk order: the key does not depend on the thread
+ * count; about 2 ms for configs[1]'s 80 MB adj_ja on the GPU box's host): an in-place edit is always seen, which is what
+ * the reference's copy-per-call guarantees.  Two different graphs of equal n and nnz get different keys (up to 2^-64).
+ * ATHENA_MP_GRAPH_KEY_SAMPLED=1 opts into the cheap key for graphs of 2^18 entries and more (head, tail and 4096
+ * strided samples of each array): then an in-place edit outside the samples is NOT seen and the caller must announce it
+ * (invalidate_graph / graph_type.touch -> athena_mp_graph_evict).  Host-only, no device call, no library state: the
+ * Fortran interface is declared `pure`. */
 int athena_mp_graph_key(int32_t n_rows, int64_t nnz, const int32_t *adj_ia, const int32_t *adj_ja, uint64_t *key);
 /* set_graph as a cache lookup: returns the handle of this CSR (square graph, degrees = row lengths -- what
  * set_graph_msgpass hands a layer), building it only when no handle with the same (device, n, nnz, n_edge_cols,
@@ -116,6 +119,11 @@ int athena_mp_graph_key(int32_t n_rows, int64_t nnz, const int32_t *adj_ia, cons
 int athena_mp_graph_acquire(int32_t n, int64_t nnz, const int32_t *adj_ia, const int32_t *adj_ja,
                             int32_t n_edge_cols, athena_mp_graph **out);
 int athena_mp_graph_release(athena_mp_graph *g);
+/* release, and the cache forgets the handle at once: the next athena_mp_graph_acquire of the same key BUILDS from the
+ * arrays.  For callers that announce an in-place edit (layer%invalidate_graph, graph_type.touch) -- needed only under
+ * the sampled key, harmless otherwise.  Other holders of the handle keep it (old topology) until they release it; the
+ * last one frees it.  A handle that never came from the cache is destroyed. */
+int athena_mp_graph_evict(athena_mp_graph *g);
 /* cached handles alive or idle, lookups served from the cache, and device graph handles BUILT by this process so far
  * (graph_create / _from_edges / _acquire misses / shard blocks): what the cache tests count */
 int athena_mp_graph_cache_stats(int64_t *handles, int64_t *hits, int64_t *builds);

@@ -2,6 +2,7 @@
 against the per-sample oracle restatement.  Mirrors the reference's layer tests
 (test/test_kipf_msgpass_layer.f90, test_duvenaud_msgpass_layer.f90, test_gno_layer.f90)."""
 import functools
+import os
 
 import numpy as np
 import pytest
@@ -9,6 +10,8 @@ import torch
 
 import oracle_layers as ol
 from helpers import assert_close, csr_from_index_list, golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -621,3 +624,107 @@ def test_layers_given_the_same_batch_share_one_device_handle(dev):
     x = torch.rand((12, 4), device=dev)
     y1, y2 = layers[1].forward(x), layers[2].forward(x)                         # shared arrays, independent layers
     assert y1.shape == (12, 4) and y2.shape == (12, 4)
+
+
+def test_in_place_edit_of_a_large_adjacency_is_seen_by_default(dev):
+    """The reference re-copies the CSR on every set_graph (athena_msgpass_layer_sub.f90:144-174, called before every
+    forward: athena_network_sub.f90:2727-2730) and is therefore always current.  Here set_graph costs a content key of
+    EVERY word: one entry of a 10 M-entry adj_ja edited in place, between the positions the old sampled key looked at,
+    gives the edited graph's result with no environment variable and no touch()."""
+    import time
+
+    from athena_amd import synth
+    from athena_amd.graph import graph_type
+    from athena_amd.layers import kipf_msgpass_layer_type
+    from oracle import oracle
+
+    n, pairs, F = 1_000_000, 4_500_000, 4
+    ia, ja = synth.random_graph_csr(n, pairs, seed=11)
+    g = graph_type.from_csr(ia, ja, num_edges=pairs)
+    layer = kipf_msgpass_layer_type(num_vertex_features=[F, F], num_time_steps=1, seed=1)
+    x = torch.rand((n, F), device=dev)
+    layer.set_graph(g)
+    y0 = layer.forward(x).cpu().numpy()
+    nnz = g.nnz
+    st = nnz // 4096
+    w = st * 1234 + st // 2                                   # not head, not tail, not a stride position
+    v = int(np.searchsorted(g.adj_ia, w + 1, side="right"))   # 1-based row of entry w
+    old = int(g.adj_ja[0, w])
+    new = old % n + 1
+    while new == v or new == old:
+        new = new % n + 1
+    g.adj_ja[0, w] = new                                      # IN PLACE: no assignment, no version bump
+    t0 = time.perf_counter()
+    layer.set_graph(g)
+    t_set = time.perf_counter() - t0
+    y1 = layer.forward(x).cpu().numpy()
+    w_t = layer.get_params().reshape(F, F)                    # flat column-major W[F_out,F_in] == C row-major Wt[F_in][F_out]
+    p = oracle.kipf_propagate(x.cpu().numpy(), g.adj_ia, g.adj_ja)
+    rows = np.array([v - 1, old - 1, new - 1, 0, n - 1])
+    ref = p[rows] @ w_t
+    assert np.allclose(y1[rows], ref, rtol=1e-5, atol=1e-6)
+    assert not np.array_equal(y0[v - 1], y1[v - 1])           # the edit changed row v, and the layer saw it
+    t0 = time.perf_counter()
+    layer.set_graph(g)                                        # unchanged: one key, no rebuild
+    t_same = time.perf_counter() - t0
+    print(f"set_graph on 10 M entries: rebuilt {t_set * 1e3:.1f} ms, unchanged (full content key) {t_same * 1e3:.2f} ms")
+
+
+def test_touch_evicts_the_stale_handle_under_the_sampled_key(dev):
+    """ATHENA_MP_GRAPH_KEY_SAMPLED=1 is the opt-in cheap key; with it an in-place edit between the samples is invisible
+    and graph_type.touch() is how the caller announces it.  touch() used to bump only the python-side version: the new
+    DeviceGraph then re-acquired the SAME key and got the stale cached handle back.  Now the layer
+    evicts its old handle (athena_mp_graph_evict) before acquiring.  Runs in a child process: the key mode is read once."""
+    import subprocess
+    import sys
+
+    prog = r'''
+import sys
+sys.path.insert(0, %r)
+sys.path.insert(0, %r)
+import ctypes as C
+import numpy as np, torch
+from athena_amd import _capi, synth
+from athena_amd.graph import graph_type
+from athena_amd.layers import kipf_msgpass_layer_type
+from oracle import oracle
+n, pairs, F = 100_000, 200_000, 4
+ia, ja = synth.random_graph_csr(n, pairs, seed=5)
+g = graph_type.from_csr(ia, ja, num_edges=pairs)
+assert g.nnz >= 1 << 18
+layer = kipf_msgpass_layer_type(num_vertex_features=[F, F], num_time_steps=1, seed=1)
+other = kipf_msgpass_layer_type(num_vertex_features=[F, F], num_time_steps=1, seed=2)
+x = torch.rand((n, F), device="cuda:0")
+layer.set_graph(g); other.set_graph(g)
+assert layer.graph.device.handle.value == other.graph.device.handle.value
+def stats():
+    h, hit, b = C.c_int64(), C.c_int64(), C.c_int64()
+    _capi.call("athena_mp_graph_cache_stats", C.byref(h), C.byref(hit), C.byref(b))
+    return h.value, hit.value, b.value
+st = g.nnz // 4096
+keep = np.zeros(g.nnz, bool); keep[:1024] = keep[-1024:] = True; keep[::st] = True
+rows = np.repeat(np.arange(1, n + 1), np.diff(g.adj_ia))
+edit = ~keep & (g.adj_ja[0] != rows)                       # leave self loops alone
+g.adj_ja[0, edit] = g.adj_ja[0, edit] %% n + 1             # rewire nearly everything, in place
+k_before = g.topology_key()
+b0 = stats()[2]
+layer.set_graph(g)                                         # sampled key: the edit is NOT seen (documented opt-in risk)
+assert stats()[2] == b0
+g.touch()
+layer.set_graph(g)                                         # announced: evict + rebuild
+assert stats()[2] == b0 + 1, stats()
+assert layer.graph.device.handle.value != other.graph.device.handle.value
+y = layer.forward(x).cpu().numpy()
+w_t = layer.get_params().reshape(F, F)
+ref = oracle.kipf_propagate(x.cpu().numpy(), g.adj_ia, g.adj_ja) @ w_t
+assert np.allclose(y, ref, rtol=1e-5, atol=1e-6)
+other.set_graph(g)                                         # its key tuple changed too (version): finds the NEW handle
+assert other.graph.device.handle.value == layer.graph.device.handle.value
+# finalize with a live acquired handle: the owner's close() afterwards must not touch freed memory
+_capi.call("athena_mp_finalize")
+layer.graph.device.close(); other.graph.device.close()
+print("OK")
+''' % (ROOT, os.path.join(ROOT, "tests"))
+    env = dict(os.environ, ATHENA_MP_GRAPH_KEY_SAMPLED="1")
+    out = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout[-1500:] + out.stderr[-3000:]

@@ -215,19 +215,72 @@ def test_graph_key_is_a_content_key():
             assert key(g.adj_ia, ja) != k0
             ja[r, w] = old
     assert key(g.adj_ia, ja) == k0
-    # a large graph: sampled key -- head, tail and stride positions are covered, sizes are part of the key
-    n, nnz = 300_000, 1 << 19
+    # a large graph: EVERY word enters the key by default (the reference re-copies the CSR per set_graph and is always
+    # current) -- positions between the old sample points, chunk borders of the threaded hash, row pointers
+    n, nnz = 300_000, (1 << 21) + 12345
     rng = np.random.default_rng(0)
     ia = np.concatenate([[1], 1 + np.sort(rng.integers(0, nnz + 1, n - 1)), [nnz + 1]]).astype(np.int32)
     jb = np.asfortranarray(rng.integers(1, n + 1, (2, nnz)).astype(np.int32))
     kb = key(ia, jb)
-    for w in (0, 1023, nnz - 1, (nnz // 4096) * 7):
-        old = jb[0, w]
-        jb[0, w] = old % n + 1
-        assert key(ia, jb) != kb, w
-        jb[0, w] = old
+    st = nnz // 4096
+    for w in (0, 1023, 1500, st * 7, st * 7 + 1, st * 7 + st // 2, (1 << 19) - 1, 1 << 19, (1 << 19) + 1, nnz - 1025, nnz - 1,
+              *rng.integers(0, nnz, 40).tolist()):
+        for r in range(2):
+            old = jb[r, w]
+            jb[r, w] = old % n + 1
+            assert key(ia, jb) != kb, (r, w)
+            jb[r, w] = old
+    for i in (1, 1500, n // 2, n - 2):                        # two rows trade one entry: same nnz, other row pointers
+        ia[i] += 1
+        assert key(ia, jb) != kb, i
+        ia[i] -= 1
     assert key(ia, jb) == kb
     assert key(ia[:-1], jb[:, : ia[-2] - 1]) != kb
+    # the ADVICE reproduction: rewire everything BETWEEN the sampled positions of the opt-in key
+    jc = np.array(jb, order="F")
+    keep = np.zeros(nnz, bool)
+    keep[:1024] = keep[-1024:] = True
+    keep[::st] = True
+    jc[0, ~keep] = jc[0, ~keep] % n + 1
+    assert key(ia, jc) != kb
+
+
+def test_graph_key_does_not_depend_on_the_thread_count_and_sampling_is_opt_in():
+    """the key of a large CSR is folded from fixed 2^20-value chunks in chunk order: 1 thread and 8 threads agree; the
+    sampled key exists only behind ATHENA_MP_GRAPH_KEY_SAMPLED=1 (and then misses an edit between its samples -- which
+    is why it is not the default)."""
+    import subprocess
+    import sys
+
+    prog = r'''
+import ctypes as C, numpy as np, sys
+sys.path.insert(0, %r)
+from athena_amd import _capi
+n, nnz = 200_000, (1 << 22) + 77
+rng = np.random.default_rng(3)
+ia = np.concatenate([[1], 1 + np.sort(rng.integers(0, nnz + 1, n - 1)), [nnz + 1]]).astype(np.int32)
+ja = np.asfortranarray(rng.integers(1, n + 1, (2, nnz)).astype(np.int32))
+def key():
+    k = C.c_uint64(0)
+    _capi.call("athena_mp_graph_key", n, nnz, ia.ctypes.data, ja.ctypes.data, C.byref(k))
+    return k.value
+k0 = key()
+w = (nnz // 4096) * 9 + 5          # between two sample positions
+ja[0, w] = ja[0, w] %% n + 1
+print(k0, key())
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    def run(env):
+        e = dict(os.environ)
+        e.update(env)
+        out = subprocess.run([sys.executable, "-c", prog], env=e, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return [int(t) for t in out.stdout.split()]
+
+    a = run({"ATHENA_MP_GRAPH_KEY_THREADS": "1"})
+    b = run({"ATHENA_MP_GRAPH_KEY_THREADS": "8"})
+    assert a == b and a[0] != a[1]
+    s = run({"ATHENA_MP_GRAPH_KEY_SAMPLED": "1"})
+    assert s[0] == s[1] and s[0] != a[0]
 
 
 def test_bench_line_refuses_the_test_transport_outside_the_dry_run():
