@@ -94,6 +94,7 @@ _PROTOS = {
     "athena_mp_duvenaud_readout_bwd": [_i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32],
     "athena_mp_gno_aggregate_fwd": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "athena_mp_gno_aggregate_bwd_x": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
+    "athena_mp_gno_aggregate_bwd_x_pull": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "athena_mp_gno_aggregate_bwd_theta": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
     "athena_mp_gno_aggregate_bwd_coords": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
     "athena_mp_gno_saved_bytes": [_vp, _i32, _i32, _i32, _i32, C.POINTER(C.c_int64)],
@@ -109,6 +110,8 @@ _PROTOS = {
     "athena_mp_allreduce_finish": [_vp],
     "athena_mp_allreduce": [_vp, _vp, _i64],
     "athena_mp_shard_create": [_vp, _i32, _i64, _vp, _vp, C.POINTER(_vp)],
+    "athena_mp_shard_create_edges": [_vp, _i32, _i64, _vp, _vp, C.POINTER(_vp)],
+    "athena_mp_shard_edge_cols": [_vp, C.POINTER(_i32)],
     "athena_mp_shard_destroy": [_vp],
     "athena_mp_shard_dims": [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)],
     "athena_mp_shard_graph": [_vp, _i32, C.POINTER(_vp)],

@@ -303,6 +303,10 @@ struct athena_mp_shard {
     int32_t *send_idx = nullptr;           // device [n_send]: rows (new numbering) peers asked for, grouped by peer
     int64_t n_send = 0;
     athena_mp_graph *g[4] = {};            // fwd interior, fwd boundary, bwd interior, bwd boundary
+    // shards that keep adj_ja(2,.) (Duvenaud / GNO on ONE partitioned graph): the rank's edge-feature columns are the
+    // distinct global edge ids its rows reference, renumbered 1 .. n_edge_cols in ascending global order
+    int32_t with_edges = 0, n_edge_cols = 0;
+    std::vector<int64_t> edge_ids;         // [n_edge_cols] global edge id (0-based) of each local edge column
     hipEvent_t ev_halo[2] = {};            // comm -> compute, one per slot
     float *send_buf[2] = {};
     size_t send_cap[2] = {};
@@ -394,18 +398,20 @@ int halo_mode_env()   // -1 auto, 0 p2p, 1 allgather
     return 0;
 }
 
-int make_graph(const std::vector<int32_t> &ia_all, const std::vector<int32_t> &col, int32_t r0, int32_t r1, int32_t n_cols,
-               const std::vector<int32_t> &row_deg, const std::vector<int32_t> &col_deg, athena_mp_graph **out)
+// eid: local edge column (1-based, 0 = none) of every entry, or null for a shard without edge features
+int make_graph(const std::vector<int32_t> &ia_all, const std::vector<int32_t> &col, const std::vector<int32_t> *eid, int32_t n_edge_cols,
+               int32_t r0, int32_t r1, int32_t n_cols, const std::vector<int32_t> &row_deg, const std::vector<int32_t> &col_deg,
+               athena_mp_graph **out)
 {
     const int32_t e0 = ia_all[r0], e1 = ia_all[r1];
     std::vector<int32_t> ia(r1 - r0 + 1), ja(2 * (size_t)(e1 - e0));
     for (int32_t r = r0; r <= r1; ++r) ia[r - r0] = ia_all[r] - e0 + 1;
     for (int32_t w = e0; w < e1; ++w) {
         ja[2 * (size_t)(w - e0)] = col[w] + 1;
-        ja[2 * (size_t)(w - e0) + 1] = 0;
+        ja[2 * (size_t)(w - e0) + 1] = eid ? (*eid)[w] : 0;
     }
     static const int32_t dummy[2] = {0, 0};
-    return athena_mp_graph_create(r1 - r0, n_cols, e1 - e0, ia.data(), ja.empty() ? dummy : ja.data(), 0,
+    return athena_mp_graph_create(r1 - r0, n_cols, e1 - e0, ia.data(), ja.empty() ? dummy : ja.data(), eid ? n_edge_cols : 0,
                                   row_deg.data() + r0, col_deg.data(), out);
 }
 
@@ -672,10 +678,12 @@ int athena_mp_shard_destroy(athena_mp_shard *s)
 }
 
 /* Build this rank's shard from its rows of the global graph.  adj_ia [n_local + 1] (1-based), adj_ja [2, nnz]
- * column-major with adj_ja(1, w) = GLOBAL vertex id (1-based) of the neighbour; adj_ja(2, .) is ignored (Kipf).
+ * column-major with adj_ja(1, w) = GLOBAL vertex id (1-based) of the neighbour.  with_edges = 0: adj_ja(2, .) is ignored
+ * (Kipf).  with_edges = 1 (athena_mp_shard_create_edges): adj_ja(2, w) = GLOBAL edge id (1-based, 0 = none) -- the
+ * rank's edge-feature columns become the distinct ids its rows reference.
  * Collective: every rank of the communicator calls it. */
-int athena_mp_shard_create(athena_mp_comm *c, int32_t n_local, int64_t nnz, const int32_t *adj_ia, const int32_t *adj_ja,
-                           athena_mp_shard **out)
+static int shard_create_impl(athena_mp_comm *c, int32_t n_local, int64_t nnz, const int32_t *adj_ia, const int32_t *adj_ja,
+                             int32_t with_edges, athena_mp_shard **out)
 {
     AMP_REQUIRE(out != nullptr, "shard_create: null out pointer");
     *out = nullptr;
@@ -781,6 +789,63 @@ int athena_mp_shard_create(athena_mp_comm *c, int32_t n_local, int64_t nnz, cons
     for (int64_t u : s->halo_ids) {
         const int p = (int)(std::upper_bound(s->row_off.begin(), s->row_off.end(), u) - s->row_off.begin()) - 1;
         s->recv_counts[p]++;
+    }
+    // 3b. edge-feature columns (shards of ONE graph with edge features: GNO on a mesh).  The reverse pass
+    //     of such a shard is a PULL over the rank's own rows -- dx_v = sum_{(u,e) in row v} K_e^T g_u -- which equals the
+    //     reference's scatter (athena_diffstruc_extd_sub_nop.f90:419-458) exactly when row u lists (v, e) whenever row v
+    //     lists (u, e): athena's undirected graphs, both directions sharing one edge column (:369-376).  That property
+    //     is CHECKED here over all ranks: every entry adds +h(v,u,e) or -h(u,v,e) to a 64-bit sum that must cancel.
+    std::vector<int32_t> el(with_edges ? (size_t)nnz : 0), el_b(with_edges ? (size_t)nnz : 0);
+    if (with_edges) {
+        s->with_edges = 1;
+        std::vector<int64_t> eg(nnz);   // global edge id (0-based, -1 = none) of every entry, new row order
+        uint64_t signed_sum = 0;
+        bad = 0;
+        for (int32_t k = 0; k < n; ++k) {
+            const int32_t v = s->order[k];
+            const int64_t vg = lo + v;
+            int32_t q = ia[k];
+            for (int32_t w = adj_ia[v] - 1; w < adj_ia[v + 1] - 1; ++w, ++q) {
+                const int64_t e = (int64_t)adj_ja[2 * (size_t)w + 1] - 1;
+                if (e < -1) {
+                    if (!bad) set_error("shard_create_edges: adj_ja(2,%d) = %lld is negative", w + 1, (long long)e + 1);
+                    bad = 1;
+                }
+                eg[q] = e;
+                const int64_t ug = cg[q];
+                if (ug != vg) {
+                    uint64_t h = (uint64_t)std::min(ug, vg) * 0x9e3779b97f4a7c15ull;
+                    h = (h ^ (h >> 29)) + (uint64_t)std::max(ug, vg) * 0xbf58476d1ce4e5b9ull;
+                    h = (h ^ (h >> 31)) + (uint64_t)(e + 1) * 0x94d049bb133111ebull;
+                    h ^= h >> 30;
+                    signed_sum += vg < ug ? h : (uint64_t)0 - h;
+                }
+            }
+        }
+        std::vector<uint64_t> sums(W);
+        SH_RC(allgather_host(c, &signed_sum, 8, sums.data()));
+        uint64_t tot = 0;
+        for (uint64_t x : sums) tot += x;
+        if (tot != 0 && !bad) {
+            set_error("shard_create_edges: the graph is not undirected with shared edge columns (row u must list (v, e) whenever row v "
+                      "lists (u, e)): the pull form of the reverse pass would not equal the reference's scatter");
+            bad = 1;
+        }
+        {
+            const int arc = agree_ok(c, bad, "shard_create_edges");
+            if (arc) {
+                athena_mp_shard_destroy(s);
+                return arc;
+            }
+        }
+        for (int64_t w = 0; w < nnz; ++w)
+            if (eg[w] >= 0) s->edge_ids.push_back(eg[w]);
+        std::sort(s->edge_ids.begin(), s->edge_ids.end());
+        s->edge_ids.erase(std::unique(s->edge_ids.begin(), s->edge_ids.end()), s->edge_ids.end());
+        if (s->edge_ids.size() >= (size_t)INT32_MAX) SH_FAIL("shard_create_edges: edge columns exceed int32");
+        s->n_edge_cols = (int32_t)s->edge_ids.size();
+        for (int64_t w = 0; w < nnz; ++w)
+            el[w] = eg[w] < 0 ? 0 : 1 + (int32_t)(std::lower_bound(s->edge_ids.begin(), s->edge_ids.end(), eg[w]) - s->edge_ids.begin());
     }
     // 4. who needs how much of whom, and from that the way the halo travels
     std::vector<int64_t> allc((size_t)W * W);
@@ -913,6 +978,8 @@ int athena_mp_shard_create(athena_mp_comm *c, int32_t n_local, int64_t nnz, cons
             std::iota(perm.begin(), perm.end(), b);
             std::stable_sort(perm.begin(), perm.end(), [&](int32_t x, int32_t y) { return cg[x] < cg[y]; });
             for (int32_t i = 0; i < e - b; ++i) col_b[b + i] = col[perm[i]];
+            if (with_edges)
+                for (int32_t i = 0; i < e - b; ++i) el_b[b + i] = el[perm[i]];
         }
     }
     if (hipMalloc((void **)&s->send_idx, 4 * (size_t)std::max<int64_t>(s->n_send, 1)) != hipSuccess)
@@ -921,15 +988,41 @@ int athena_mp_shard_create(athena_mp_comm *c, int32_t n_local, int64_t nnz, cons
         SH_FAIL("shard_create: upload of the send list failed");
     // 6. the four row blocks as graph handles (rectangular: n + ext_rows columns, explicit degrees)
     const int32_t ncols = n + s->ext_rows;
-    SH_RC(make_graph(ia, col, 0, s->n_int, ncols, s->row_deg, s->col_deg, &s->g[0]));
-    SH_RC(make_graph(ia, col, s->n_int, n, ncols, s->row_deg, s->col_deg, &s->g[1]));
-    SH_RC(make_graph(ia, col_b, 0, s->n_int, ncols, s->row_deg, s->col_deg, &s->g[2]));
-    SH_RC(make_graph(ia, col_b, s->n_int, n, ncols, s->row_deg, s->col_deg, &s->g[3]));
+    const std::vector<int32_t> *pe = with_edges ? &el : nullptr, *pe_b = with_edges ? &el_b : nullptr;
+    SH_RC(make_graph(ia, col, pe, s->n_edge_cols, 0, s->n_int, ncols, s->row_deg, s->col_deg, &s->g[0]));
+    SH_RC(make_graph(ia, col, pe, s->n_edge_cols, s->n_int, n, ncols, s->row_deg, s->col_deg, &s->g[1]));
+    SH_RC(make_graph(ia, col_b, pe_b, s->n_edge_cols, 0, s->n_int, ncols, s->row_deg, s->col_deg, &s->g[2]));
+    SH_RC(make_graph(ia, col_b, pe_b, s->n_edge_cols, s->n_int, n, ncols, s->row_deg, s->col_deg, &s->g[3]));
     for (int k = 0; k < 2; ++k)
         if (hipEventCreateWithFlags(&s->ev_halo[k], hipEventDisableTiming) != hipSuccess) SH_FAIL("shard_create: cannot create events");
 #undef SH_FAIL
 #undef SH_RC
     *out = s;
+    return 0;
+}
+
+int athena_mp_shard_create(athena_mp_comm *c, int32_t n_local, int64_t nnz, const int32_t *adj_ia, const int32_t *adj_ja,
+                           athena_mp_shard **out)
+{
+    return shard_create_impl(c, n_local, nnz, adj_ia, adj_ja, 0, out);
+}
+
+/* The shard of ONE graph with edge features (graph_nop_layer on a partitioned mesh, SURVEY.md 8e: "GNO: as Kipf plus
+ * replicated theta and all-reduce of dtheta"; duvenaud_propagate's edge half takes the same handles).  adj_ja(2, w) =
+ * global edge id (1-based; 0 = none) as graph_type%adj_ja carries it.  The four row-block handles then keep the edge
+ * columns, renumbered to the rank's own set: the rank holds coords / edge features for exactly the columns
+ * athena_mp_shard_export(7) lists (ascending global id), n_edge_cols of them (athena_mp_shard_edge_cols).  The graph must be
+ * undirected with both directions of a pair sharing one column -- checked over all ranks, an error on every rank if not. */
+int athena_mp_shard_create_edges(athena_mp_comm *c, int32_t n_local, int64_t nnz, const int32_t *adj_ia, const int32_t *adj_ja,
+                                 athena_mp_shard **out)
+{
+    return shard_create_impl(c, n_local, nnz, adj_ia, adj_ja, 1, out);
+}
+
+int athena_mp_shard_edge_cols(const athena_mp_shard *s, int32_t *n_edge_cols)
+{
+    AMP_REQUIRE(s && n_edge_cols, "shard_edge_cols: null argument");
+    *n_edge_cols = s->n_edge_cols;
     return 0;
 }
 
@@ -974,6 +1067,7 @@ int athena_mp_shard_graph(const athena_mp_shard *s, int32_t which, athena_mp_gra
  * 2 send_idx [n_send] int32   3 col_deg [n + n_halo] int32   4 send_counts [world] int64   5 recv_counts [world] int64
  * 6 ext_ids [n_halo of shard_dims] int64: global id (0-based) held by each row of x_ext beyond the local ones, -1 = a
  *   padding slot of the all-gather layout (== array 1 in p2p mode; array 1 is always the DISTINCT remote rows referenced)
+ * 7 edge_ids [n_edge_cols] int64: global edge id (0-based) of each local edge column (athena_mp_shard_create_edges)
  * count is in ELEMENTS; host_dst may be null for a size query. */
 int athena_mp_shard_export(const athena_mp_shard *s, int32_t which, void *host_dst, int64_t capacity, int64_t *count)
 {
@@ -989,6 +1083,7 @@ int athena_mp_shard_export(const athena_mp_shard *s, int32_t which, void *host_d
     case 4: src = s->send_counts.data(); n = (int64_t)s->send_counts.size(); el = 8; break;
     case 5: src = s->recv_counts.data(); n = (int64_t)s->recv_counts.size(); el = 8; break;
     case 6: src = s->ext_ids.data(); n = (int64_t)s->ext_ids.size(); el = 8; break;
+    case 7: src = s->edge_ids.data(); n = (int64_t)s->edge_ids.size(); el = 8; break;
     default: AMP_REQUIRE(false, "shard_export: unknown array id %d", which);
     }
     *count = n;

@@ -2372,6 +2372,46 @@ int athena_mp_gno_aggregate_bwd_x(const athena_mp_graph *g, int32_t d, int32_t H
     return 0;
 }
 
+/* The reverse pass of gno_aggregate towards the features in PULL form over the graph's OWN rows:
+ *     dx[v,:] = sum_{w in row v} K_{eid[w]}^T grad_ext[col[w],:]          v < n_rows, grad_ext [n_cols, Fo]
+ * For an undirected graph whose two directions share one edge column (athena's graphs: row u lists (v, e) whenever row v
+ * lists (u, e), athena_diffstruc_extd_sub_nop.f90:369-376) this is the reference's scatter dx_j += K_e^T g_i
+ * (:419-458) read from the receiving side.  It is what a row block of a partitioned graph can evaluate: the block holds
+ * its own rows, and the gradient rows of the remote neighbours arrive by the same halo exchange as the features
+ * (athena_mp_shard_create_edges checks the symmetry).  Same kernels as athena_mp_gno_aggregate_bwd_x, walking
+ * rowptr / col / eid instead of the transposed arrays. */
+int athena_mp_gno_aggregate_bwd_x_pull(const athena_mp_graph *g, int32_t d, int32_t H, int32_t Fi, int32_t Fo,
+                                       const float *theta, const float *coords, const float *grad_ext, float *dx)
+{
+    if (!gno_args_ok(g, d, H, Fi, Fo)) return 2;
+    AMP_REQUIRE(theta && coords && grad_ext && dx, "gno_aggregate_bwd_x_pull: null pointer");
+    const size_t off_V = (size_t)H * d + H;
+    const int R2 = (H + 1) * Fo;
+    void *b2 = nullptr;
+    if (workspace(&b2, sizeof(float) * (size_t)R2 * Fi, 3)) return 1;
+    {
+        int n = R2 * Fi;
+        hipLaunchKernelGGL(gno_perm_kernel, dim3((n + 255) / 256), dim3(256), 0, stream(), theta + off_V, H + 1, Fi,
+                           Fo, (float *)b2);
+        AMP_LAUNCH_CHECK();
+    }
+    if (gno_fused_shape(H, Fo, Fi, d))
+        return launch_gno_fused(g->rowptr, g->col, g->eid, grad_ext, coords, theta, d, (const float *)b2, g->n_rows,
+                                &g->len_perm_fwd, dx, g->n_cols, g->n_edge_cols, g->nnz, &g->n_long_fwd, &g->n_mid_fwd);
+    const int tile = tile_rows_for(g->n_rows, R2);
+    for (int r0 = 0; r0 < g->n_rows; r0 += tile) {
+        const int rows = std::min(tile, g->n_rows - r0);
+        void *ws = nullptr;
+        if (workspace(&ws, sizeof(float) * (size_t)rows * R2, 0)) return 1;
+        int rc = launch_outer(g->rowptr, g->col, g->eid, grad_ext, Fo, coords, theta, d, H, r0, rows, (float *)ws);
+        if (rc) return rc;
+        rc = gemm_dispatch((const float *)ws, (const float *)b2, 0, nullptr, ATHENA_MP_ACT_NONE,
+                           dx + (size_t)r0 * Fi, rows, R2, Fi);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 int athena_mp_gno_aggregate_bwd_theta(const athena_mp_graph *g, int32_t d, int32_t H, int32_t Fi, int32_t Fo,
                                       const float *theta, const float *coords, const float *x, const float *grad,
                                       float *dtheta)

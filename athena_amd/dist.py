@@ -87,7 +87,10 @@ class Shard:
     `order[k]` = original local id of the vertex now called k (a layout choice of the partition; the
     original order is recovered with `order`)."""
 
-    def __init__(self, rank, world, n, rows, cols_global):
+    def __init__(self, rank, world, n, rows, cols_global, eids_global=None):
+        """eids_global: optional GLOBAL edge id (1-based, 0 = none) of every entry -- graph_type%adj_ja(2,:) of a graph
+        with edge features cut by rows (GNO on a mesh).  The shard's graphs then keep the edge columns, renumbered to
+        the rank's own set (`edge_ids`: their global ids, 0-based, ascending), as athena_mp_shard_create_edges does."""
         self.rank, self.world, self.n = rank, world, n
         lo = rank * n
         local = (cols_global >= lo) & (cols_global < lo + n)
@@ -101,6 +104,13 @@ class Shard:
         rows_new = new_of_old[rows]
         perm = np.argsort(rows_new, kind="stable")                          # entry order inside a row is kept
         rows_new, cols_global, local = rows_new[perm], cols_global[perm], local[perm]
+        if eids_global is not None:
+            eg = np.asarray(eids_global, np.int64)[perm]
+            self.edge_ids = np.unique(eg[eg > 0]) - 1
+            self._eid_local = np.where(eg > 0, 1 + np.searchsorted(self.edge_ids, eg - 1), 0).astype(np.int32)
+        else:
+            self.edge_ids, self._eid_local = np.zeros(0, np.int64), None
+        self.n_edge_cols = int(self.edge_ids.size)
         counts = np.bincount(rows_new, minlength=n)
         self.adj_ia = np.concatenate([[1], 1 + np.cumsum(counts)]).astype(np.int32)
         self.cols_global = cols_global
@@ -125,6 +135,8 @@ class Shard:
         n, world = self.n, self.world
         ja = np.zeros((2, self.nnz), np.int32, order="F")
         ja[0] = col + 1
+        if self._eid_local is not None:
+            ja[1] = self._eid_local
         self.adj_ja = ja
         # backward (pull) graph: same rows, entries ordered by global source id (the order the
         # reference's scatter accumulates in, athena_diffstruc_extd_sub_kipf.f90:101-109)
@@ -132,6 +144,8 @@ class Shard:
         order = np.argsort(key, kind="stable")
         jb = np.zeros((2, self.nnz), np.int32, order="F")
         jb[0] = col[order] + 1
+        if self._eid_local is not None:
+            jb[1] = self._eid_local[order]
         self.adj_ja_bwd = jb
 
     def use_allgather(self, all_new_of_old, all_deg_new):
@@ -168,6 +182,8 @@ class Shard:
         n, ni, nc = self.n, self.n_int, self.n + self.n_halo
         def block(adj_ja, r0, r1):
             ia, ja = self.row_block(adj_ja, r0, r1)
+            if self.n_edge_cols:
+                return backend.make_graph(ia, ja, nc, self.row_deg[r0:r1], self.col_deg, n_edge_cols=self.n_edge_cols)
             return backend.make_graph(ia, ja, nc, self.row_deg[r0:r1], self.col_deg)
         return (block(self.adj_ja, 0, ni), block(self.adj_ja, ni, n), block(self.adj_ja_bwd, 0, ni), block(self.adj_ja_bwd, ni, n))
 
@@ -331,17 +347,23 @@ class CShard:
     n_halo = rows of x_ext beyond the local ones: the distinct remote rows in p2p mode, the padded blocks of every rank
     in all-gather mode (halo_mode; the C ABI decides from the halo fraction)."""
 
-    def __init__(self, comm, adj_ia, cols_global):
+    def __init__(self, comm, adj_ia, cols_global, eids_global=None):
+        """eids_global (1-based GLOBAL edge ids, 0 = none): athena_mp_shard_create_edges -- the row blocks keep their edge
+        columns, renumbered to the rank's own set (`edge_ids`)"""
         import ctypes as C
         from . import _capi
         self.comm, self.rank, self.world = comm, comm.rank, comm.world
         ia = np.ascontiguousarray(adj_ia, np.int32)
         ja = np.zeros((2, cols_global.size), np.int32, order="F")
         ja[0] = cols_global + 1
+        if eids_global is not None:
+            ja[1] = eids_global
         h = C.c_void_p()
-        _capi.call("athena_mp_shard_create", comm.handle, ia.size - 1, ja.shape[1], ia.ctypes.data_as(C.c_void_p),
-                   ja.ctypes.data_as(C.c_void_p), C.byref(h))
+        _capi.call("athena_mp_shard_create_edges" if eids_global is not None else "athena_mp_shard_create", comm.handle,
+                   ia.size - 1, ja.shape[1], ia.ctypes.data_as(C.c_void_p), ja.ctypes.data_as(C.c_void_p), C.byref(h))
         self.handle = h
+        self.edge_ids = self._export(7, np.int64) if eids_global is not None else np.zeros(0, np.int64)
+        self.n_edge_cols = int(self.edge_ids.size)
         n, ni, nh, nnz, roff, ntot = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64(), C.c_int64(), C.c_int64()
         _capi.call("athena_mp_shard_dims", h, C.byref(n), C.byref(ni), C.byref(nh), C.byref(nnz), C.byref(roff), C.byref(ntot))
         self.n, self.n_int, self.n_halo, self.nnz, self.row_offset = n.value, ni.value, nh.value, nnz.value, roff.value
@@ -413,7 +435,7 @@ class CShard:
             self.handle = None
 
 
-def _c_shard_or_none(device, adj_ia, cols_global):
+def _c_shard_or_none(device, adj_ia, cols_global, eids_global=None):
     """the C-ABI shard, or None when ANY rank failed to build its communicator / shard (every rank then takes dist.py's
     python plan over torch point-to-point instead, and says so in `transport`).  Not a silent detour: the reason is
     printed by the rank that failed and recorded in the shard's transport string."""
@@ -421,7 +443,7 @@ def _c_shard_or_none(device, adj_ia, cols_global):
     err = None
     sh = None
     try:
-        sh = CShard(c_comm(torch.device(device)), adj_ia, cols_global)
+        sh = CShard(c_comm(torch.device(device)), adj_ia, cols_global, eids_global)
     except Exception as exc:      # AthenaMPError from the C ABI, OSError from the loader ...
         err = f"{type(exc).__name__}: {exc}"[:300]
         print(f"[athena_mp dist] rank {dist.get_rank()}: C-ABI communicator / shard failed: {err}", file=sys.stderr, flush=True)
@@ -539,9 +561,9 @@ class HipBackend:
         _capi.init(device.index or 0)
         self.device = device
 
-    def make_graph(self, adj_ia, adj_ja, n_cols, row_deg, col_deg):
+    def make_graph(self, adj_ia, adj_ja, n_cols, row_deg, col_deg, n_edge_cols=0):
         from .graph import DeviceGraph
-        return DeviceGraph(adj_ia, adj_ja, n_cols=n_cols, n_edge_cols=0, row_deg=row_deg, col_deg=col_deg,
+        return DeviceGraph(adj_ia, adj_ja, n_cols=n_cols, n_edge_cols=n_edge_cols, row_deg=row_deg, col_deg=col_deg,
                            device=self.device.index or 0)
 
     def __getattr__(self, name):
@@ -773,6 +795,168 @@ def measure_breakdown(step, iters=5):
     out["halo_recv_bytes_per_gpu_per_step"] = recv_bytes
     out["xgmi_recv_GBps_per_gpu"] = (recv_bytes / (out["halo_ms"] * 1e-3) / 1e9) if out["halo_ms"] > 0 else None
     return out
+
+
+# --------------------------------------------------------------------------------------------------
+# ONE graph with edge features cut by rows: the graph neural operator on a partitioned mesh (SURVEY.md 8e:
+# "GNO: as Kipf plus replicated theta and all-reduce of dtheta"; BASELINE configs[3] is one 2 M-vertex mesh)
+# --------------------------------------------------------------------------------------------------
+def make_mesh_shard(rank, world, n_points, device=None, mean_degree=15.0, seed=4, mesh=None):
+    """rank's contiguous row block of the radius mesh synth.radius_graph(n_points, order="cells") -- BASELINE configs[3]'s
+    generator with the points numbered in Morton order of their cell, so a block is a compact region and its halo a thin
+    shell (SURVEY.md 8e "locality graphs: near-linear").  n_points must divide by world.  Returns (shard, coords_local):
+    the rank's edge geometry [n_edge_cols, d], i.e. the rows `shard.edge_ids` of the global coords.
+    mesh: optional prebuilt (adj_ia, adj_ja, coords) of the whole graph (tests)."""
+    from . import synth
+    if n_points % world:
+        raise ValueError(f"{n_points} vertices do not split into {world} equal row blocks")
+    n = n_points // world
+    ia, ja, coords = mesh if mesh is not None else synth.radius_graph(n_points, mean_degree, seed, order="cells")
+    e0, e1 = int(ia[rank * n]) - 1, int(ia[(rank + 1) * n]) - 1
+    ia_l = (ia[rank * n:(rank + 1) * n + 1].astype(np.int64) - e0).astype(np.int32)
+    cols = ja[0, e0:e1].astype(np.int64) - 1
+    eids = ja[1, e0:e1].astype(np.int64)
+    sh, why = None, None
+    if _use_c_abi(device):
+        sh, why = _c_shard_or_none(device, ia_l, cols, eids)
+    if sh is None:
+        rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(ia_l))
+        sh = build_plan(Shard(rank, world, n, rows, cols, eids), device)
+        if why:
+            sh.transport = Shard.transport + f" -- FALLBACK, the C-ABI path failed: {why}"
+    sh.cut = None
+    sh.n_total = n_points
+    return sh, np.ascontiguousarray(coords[sh.edge_ids], np.float32)
+
+
+class GnoShardStep:
+    """graph_nop_layer forward + reverse on a row shard of ONE mesh (update_message_gno, athena_graph_nop_layer.f90:690-788,
+    and the _val gradients of athena_diffstruc_extd_sub_nop.f90 composed as the layer mirror composes them):
+        forward   exchange(x);  m = gno_aggregate(kappa(coords), x_ext): interior rows under the transfer, boundary rows
+                  after it;  out = act(m + W x + b)
+        reverse   dz = act'(.) up;  exchange(dz);  under the transfer everything that needs LOCAL rows of dz only:
+                  db, dW = dz^T x, dtheta = the two blocks' S^T dz + kernel-MLP halves, and the interior rows of
+                  dx = sum_{(u,e) in row v} K_e^T dz_u (the pull over the rank's own rows: both directions of a pair share
+                  one edge column, :369-376);  then the boundary rows of dx, dx += dz W.
+                  theta, W, b are replicated; [dtheta | dW | db] is summed over the ranks in ONE all-reduce.
+    The edge geometry stays where its rows are: a rank holds coords for the edge columns its rows reference."""
+
+    def __init__(self, shard, Fi, Fo, d, H, device, backend=None, inputs=None, activation="none", use_bias=True, keep_s=None,
+                 seed=1):
+        """inputs: (x [n, Fi], up [n, Fo], theta, W [Fo*Fi], b [Fo] or None, coords [n_edge_cols, d]) host arrays, x / up
+        for the rank's rows in their ORIGINAL local order; default: seeded random (theta, W, b identical on every rank)"""
+        self.s, self.Fi, self.Fo, self.d, self.H, self.device = shard, Fi, Fo, d, H, device
+        self.b = backend or HipBackend(device)
+        self.act, self.use_bias = activation, use_bias
+        n, nh, ne = shard.n, shard.n_halo, shard.n_edge_cols
+        self.g_fwd_int, self.g_fwd_bnd, self.g_bwd_int, self.g_bwd_bnd = shard.graphs(self.b)
+        nth = H * d + H + Fo * Fi * H + Fo * Fi
+        if inputs is not None:
+            x_h, up_h, th_h, w_h, b_h, c_h = inputs
+            x_h, up_h = np.asarray(x_h, np.float32)[shard.order], np.asarray(up_h, np.float32)[shard.order]
+        else:
+            rng = np.random.Generator(np.random.PCG64([seed, shard.rank]))
+            x_h = rng.uniform(-1, 1, (n, Fi)).astype(np.float32)
+            up_h = rng.uniform(-1, 1, (n, Fo)).astype(np.float32)
+            c_h = rng.uniform(-0.05, 0.05, (ne, d)).astype(np.float32)
+            wr = np.random.Generator(np.random.PCG64(seed + 1))
+            th_h = (wr.standard_normal(nth) * 0.1).astype(np.float32)
+            w_h = (wr.standard_normal(Fo * Fi) * np.sqrt(2.0 / Fi)).astype(np.float32)
+            b_h = (wr.standard_normal(Fo) * 0.1).astype(np.float32)
+        if not (x_h.shape == (n, Fi) and up_h.shape == (n, Fo) and th_h.size == nth and w_h.size == Fo * Fi and c_h.shape == (ne, d)):
+            raise ValueError("inputs: expected x [n, Fi], up [n, Fo], theta, W [Fo*Fi], b, coords [n_edge_cols, d]")
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(device)
+        self.x_ext = torch.empty((n + nh, Fi), dtype=torch.float32, device=device)
+        self.x_ext[:n] = t(x_h)
+        self.g_ext = torch.empty((n + nh, Fo), dtype=torch.float32, device=device)     # dz: local rows | halo rows
+        self.up = t(up_h)
+        self.theta, self.W, self.coords = t(th_h).reshape(-1), t(w_h).reshape(-1), t(c_h)
+        self.bias = t(b_h).reshape(-1) if use_bias else None
+        self.m = torch.empty((n, Fo), dtype=torch.float32, device=device)
+        self.out = None
+        self.dX = torch.empty((n, Fi), dtype=torch.float32, device=device)
+        self.grad_flat = torch.zeros(nth + Fo * Fi + (Fo if use_bias else 0), dtype=torch.float32, device=device)
+        self.dtheta, self.dW = self.grad_flat[:nth], self.grad_flat[nth:nth + Fo * Fi]
+        self.db = self.grad_flat[nth + Fo * Fi:] if use_bias else None
+        self.ones = torch.ones((n, 1), dtype=torch.float32, device=device)
+        self.xchg = shard.exchange(Fi, device, self.b)
+        self.xchg_o = self.xchg if Fi == Fo else shard.exchange(Fo, device, self.b)
+        # the forward pass may keep S per block for the reverse pass's S^T dz (DESIGN.md 3.5); None: when the backend offers it
+        self.keep_s = keep_s
+        self._s = [None, None]
+
+    def _keeps(self, g):
+        if self.keep_s is False or not hasattr(self.b, "gno_saved_bytes") or g.n_rows == 0:
+            return False
+        return self.b.gno_saved_bytes(g, self.d, self.H, self.Fi, self.Fo) > 0
+
+    def _fwd_block(self, k, g, r0, r1):
+        b = self.b
+        if r1 == r0:
+            return
+        if self._keeps(g):
+            _, self._s[k] = b.gno_aggregate_save(g, self.theta, self.coords, self.x_ext, self.d, self.H, self.Fo, s_save=self._s[k],
+                                                 out=self.m[r0:r1])
+        else:
+            self._s[k] = None
+            b.gno_aggregate(g, self.theta, self.coords, self.x_ext, self.d, self.H, self.Fo, out=self.m[r0:r1])
+
+    def forward(self, events=None):
+        s, b, n, ni = self.s, self.b, self.s.n, self.s.n_int
+        reqs = self.xchg.start(self.x_ext)                                         # halo of x in flight ...
+        if events is not None:
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+        self._fwd_block(0, self.g_fwd_int, 0, ni)                                  # ... under the interior rows
+        if events is not None:
+            e1.record()
+            events.append((e0, e1))
+        z = b.matmul(self.W, self.x_ext[:n], self.Fo, bias=self.bias)              # ... and the bypass W x + b
+        self.xchg.finish(reqs)
+        self._fwd_block(1, self.g_fwd_bnd, ni, n)
+        b.axpy(1.0, self.m, z)
+        self.z = z
+        self.out = z if self.act in ("none", "linear") else b.activation(self.act, z)
+        return self.out
+
+    def backward(self):
+        s, b, n, ni = self.s, self.b, self.s.n, self.s.n_int
+        d, H, Fi, Fo = self.d, self.H, self.Fi, self.Fo
+        dz = self.g_ext[:n]
+        if self.act in ("none", "linear"):
+            dz.copy_(self.up)
+        else:
+            dz.copy_(b.activation_bwd(self.act, self.out, self.up, z=self.z))
+        reqs = self.xchg_o.start(self.g_ext)                                       # halo of dz in flight; under it:
+        if self.use_bias:
+            b.matmul_dw(self.ones, dz, out=self.db)                                # db[o] = sum_v dz[v,o]
+        b.matmul_dw(self.x_ext[:n], dz, out=self.dW)
+        first = True
+        for k, (g, r0, r1) in enumerate(((self.g_fwd_int, 0, ni), (self.g_fwd_bnd, ni, n))):
+            if r1 == r0:
+                continue
+            part = b.gno_aggregate_bwd_theta(g, self.theta, self.coords, self.x_ext, dz[r0:r1], d, H, s_save=self._s[k])
+            if first:
+                self.dtheta.copy_(part)
+            else:
+                self.dtheta.add_(part)
+            first = False
+        if first:
+            self.dtheta.zero_()
+        red = s.allreduce_start(self.grad_flat)                                    # [dtheta | dW | db]: one collective
+        if ni:
+            b.gno_aggregate_bwd_x_pull(self.g_bwd_int, self.theta, self.coords, self.g_ext, d, H, Fi, out=self.dX[:ni])
+        self.xchg_o.finish(reqs)
+        if n - ni:
+            b.gno_aggregate_bwd_x_pull(self.g_bwd_bnd, self.theta, self.coords, self.g_ext, d, H, Fi, out=self.dX[ni:])
+        b.axpy(1.0, b.matmul_dx(self.W, dz, Fi), self.dX)
+        if red is not None:
+            red.wait()
+        return self.dX
+
+    def __call__(self, events=None):
+        self.forward(events)
+        return self.backward()
 
 
 # --------------------------------------------------------------------------------------------------

@@ -49,6 +49,7 @@ module athena_mp_c
   public :: athena_mp_comm_unique_id, athena_mp_allreduce, athena_mp_allreduce_start, athena_mp_allreduce_finish
   public :: athena_mp_shard_create, athena_mp_shard_destroy, athena_mp_shard_dims, athena_mp_shard_graph
   public :: athena_mp_shard_export, athena_mp_halo_start, athena_mp_halo_finish, athena_mp_shard_info
+  public :: athena_mp_shard_create_edges, athena_mp_shard_edge_cols, athena_mp_gno_aggregate_bwd_x_pull
   public :: athena_mp_resident_mode, athena_mp_resident_acquire, athena_mp_resident_release, athena_mp_resident_flush
   public :: athena_mp_resident_drop, athena_mp_resident_stats
 
@@ -619,6 +620,14 @@ module athena_mp_c
        type(c_ptr), value :: graph, theta_dev, coords_dev, grad_dev, dx_dev
        integer(c_int32_t), value :: d, H, Fi, Fo
      end function
+     !! the same gradient as a PULL over the graph's own rows (row blocks of a partitioned undirected graph):
+     !! dx [n_rows, Fi] from grad_ext [n_cols, Fo] -- athena_diffstruc_extd_sub_nop.f90:419-458 read from the receiving side
+     integer(c_int) function athena_mp_gno_aggregate_bwd_x_pull(graph, d, H, Fi, Fo, theta_dev, coords_dev, grad_ext_dev, &
+          dx_dev) bind(C, name="athena_mp_gno_aggregate_bwd_x_pull")
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: graph, theta_dev, coords_dev, grad_ext_dev, dx_dev
+       integer(c_int32_t), value :: d, H, Fi, Fo
+     end function
      integer(c_int) function athena_mp_gno_aggregate_bwd_theta(graph, d, H, Fi, Fo, theta_dev, coords_dev, x_dev, &
           grad_dev, dtheta_dev) bind(C, name="athena_mp_gno_aggregate_bwd_theta")
        import :: c_int, c_int32_t, c_ptr
@@ -712,6 +721,22 @@ module athena_mp_c
        integer(c_int64_t), value :: nnz
        integer(c_int32_t), intent(in) :: adj_ia(*), adj_ja(2,*)
        type(c_ptr), intent(out) :: shard
+     end function
+     !! ... of a graph WITH edge features: adj_ja(2,:) = GLOBAL edge ids (0 = none); the shard's graphs keep the edge
+     !! columns renumbered to the rank's own set (athena_mp_shard_export(7) lists their global ids)
+     integer(c_int) function athena_mp_shard_create_edges(comm, n_local, nnz, adj_ia, adj_ja, shard) &
+          bind(C, name="athena_mp_shard_create_edges")
+       import :: c_int, c_int32_t, c_int64_t, c_ptr
+       type(c_ptr), value :: comm
+       integer(c_int32_t), value :: n_local
+       integer(c_int64_t), value :: nnz
+       integer(c_int32_t), intent(in) :: adj_ia(*), adj_ja(2,*)
+       type(c_ptr), intent(out) :: shard
+     end function
+     integer(c_int) function athena_mp_shard_edge_cols(shard, n_edge_cols) bind(C, name="athena_mp_shard_edge_cols")
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: shard
+       integer(c_int32_t), intent(out) :: n_edge_cols
      end function
      integer(c_int) function athena_mp_shard_destroy(shard) bind(C, name="athena_mp_shard_destroy")
        import :: c_int, c_ptr

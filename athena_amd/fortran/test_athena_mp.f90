@@ -321,6 +321,28 @@ contains
              write(0,*) "resident chain: a slice of a resident array was not materialised before use"
              success = .false.
           end if
+          ! host code overwrites a PARKED result (its valid copy was on the device), then the island ends: neither the
+          ! explicit flush, nor a flush forced by an overlapping argument, nor resident_mode(0) may write the stale device
+          ! copy over the newer host values
+          call check(athena_mp_resident_mode(1_c_int32_t), "resident_mode(1)")
+          call check(athena_mp_kipf_propagate_fwd_host(g, int(f, c_int32_t), x, p1), "kipf_fwd_host")     ! p1 parked
+          p1 = 0.25_real32
+          call check(athena_mp_resident_flush(c_loc(p1)), "resident_flush")
+          if(any(p1 .ne. 0.25_real32))then
+             write(0,*) "resident chain: flush wrote a stale device copy over host values"
+             success = .false.
+          end if
+          call check(athena_mp_kipf_propagate_fwd_host(g, int(f, c_int32_t), x, p2), "kipf_fwd_host")     ! p2 parked
+          p2 = 0.75_real32
+          call check(athena_mp_gemm_fwd_host(int(n / 2, c_int64_t), int(f, c_int32_t), int(f, c_int32_t), p2(:, n / 4 + 1:), &
+               w(:, 1), c_null_ptr, ATHENA_MP_ACT_NONE, z1), "gemm_fwd_host")                           ! overlap: forced flush
+          call check(athena_mp_kipf_propagate_fwd_host(g, int(f, c_int32_t), x, p3), "kipf_fwd_host")     ! p3 parked
+          p3 = -1.5_real32
+          call check(athena_mp_resident_mode(0_c_int32_t), "resident_mode(0)")
+          if(any(p2 .ne. 0.75_real32) .or. any(p3 .ne. -1.5_real32))then
+             write(0,*) "resident chain: a forced flush / resident_mode(0) wrote a stale device copy over host values"
+             success = .false.
+          end if
        end if
     end do
     call check(athena_mp_graph_destroy(g), "graph_destroy")

@@ -570,13 +570,14 @@ def duvenaud_readout_bwd(R, z, p, seg, gout, act="none", dz_next=None):
 
 
 # ---- graph neural operator -----------------------------------------------------------------------
-def gno_aggregate(g: DeviceGraph, theta, coords, x, d, H, Fo):
+def gno_aggregate(g: DeviceGraph, theta, coords, x, d, H, Fo, out=None):
     """gno_kernel_eval + gno_aggregate (athena_diffstruc_extd_sub_nop.f90:26-115, :330-397) fused"""
     Fi = x.shape[1]
     _chk(x, (g.n_cols, Fi)); _chk(coords, (g.n_edge_cols, d)); _chk(theta)
     if not (theta.numel() == H * d + H + Fo * Fi * H + Fo * Fi):
         raise ValueError('expected: theta.numel() == H * d + H + Fo * Fi * H + Fo * Fi')
-    m = torch.empty((g.n_rows, Fo), device=x.device, dtype=torch.float32)
+    m = out if out is not None else torch.empty((g.n_rows, Fo), device=x.device, dtype=torch.float32)
+    _chk(m, (g.n_rows, Fo))
     _go()
     _capi.call("athena_mp_gno_aggregate_fwd", g.handle, d, H, Fi, Fo, _p(theta), _p(coords), _p(x), _p(m))
     return m
@@ -590,7 +591,7 @@ def gno_saved_bytes(g: DeviceGraph, d, H, Fi, Fo) -> int:
     return int(b.value)
 
 
-def gno_aggregate_save(g: DeviceGraph, theta, coords, x, d, H, Fo, s_save=None):
+def gno_aggregate_save(g: DeviceGraph, theta, coords, x, d, H, Fo, s_save=None, out=None):
     """`gno_aggregate` that also keeps S = sum_e [h_e;1] x_j^T per vertex for `gno_aggregate_bwd_theta(..., s_save=)`
     (the reference keeps kappa [Fo*Fi, E] on its tape, athena_diffstruc_extd_sub_nop.f90:330-397).  Returns (m, s_save);
     `s_save` may be a buffer from an earlier step of at least gno_saved_bytes() bytes."""
@@ -604,7 +605,8 @@ def gno_aggregate_save(g: DeviceGraph, theta, coords, x, d, H, Fo, s_save=None):
     if s_save is None or s_save.numel() * 4 < nbytes:
         s_save = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
     _chk(s_save)
-    m = torch.empty((g.n_rows, Fo), device=x.device, dtype=torch.float32)
+    m = out if out is not None else torch.empty((g.n_rows, Fo), device=x.device, dtype=torch.float32)
+    _chk(m, (g.n_rows, Fo))
     _go()
     _capi.call("athena_mp_gno_aggregate_fwd_save", g.handle, d, H, Fi, Fo, _p(theta), _p(coords), _p(x), _p(m), _p(s_save))
     return m, s_save
@@ -618,6 +620,20 @@ def gno_aggregate_bwd_x(g: DeviceGraph, theta, coords, grad, d, H, Fi):
     dx = torch.empty((g.n_cols, Fi), device=grad.device, dtype=torch.float32)
     _go()
     _capi.call("athena_mp_gno_aggregate_bwd_x", g.handle, d, H, Fi, Fo, _p(theta), _p(coords), _p(grad), _p(dx))
+    return dx
+
+
+def gno_aggregate_bwd_x_pull(g: DeviceGraph, theta, coords, grad_ext, d, H, Fi, out=None):
+    """the same gradient as a pull over the graph's OWN rows: dx[v] = sum_{w in row v} K_e^T grad_ext[col[w]] -- what a
+    row block of a partitioned undirected graph evaluates once the halo rows of grad have arrived (dist.GnoShardStep)"""
+    Fo = grad_ext.shape[1]
+    _chk(grad_ext, (g.n_cols, Fo)); _chk(coords, (g.n_edge_cols, d))
+    if _chk(theta).numel() != H * d + H + Fo * Fi * H + Fo * Fi:
+        raise ValueError("theta: expected H*d + H + Fo*Fi*H + Fo*Fi values")
+    dx = out if out is not None else torch.empty((g.n_rows, Fi), device=grad_ext.device, dtype=torch.float32)
+    _chk(dx, (g.n_rows, Fi))
+    _go()
+    _capi.call("athena_mp_gno_aggregate_bwd_x_pull", g.handle, d, H, Fi, Fo, _p(theta), _p(coords), _p(grad_ext), _p(dx))
     return dx
 
 

@@ -99,15 +99,35 @@ def molecule_batch(n_graphs, seed=3):
     return adj_ia, adj_ja, voff.astype(np.int32), E
 
 
-def radius_graph(n_points, mean_degree=15.0, seed=4, dim=3):
+def morton_order(pts, bits=7):
+    """permutation that sorts points of the unit cube by the Morton (Z-order) code of their cell on a 2^bits grid per
+    axis: consecutive vertex ids are spatial neighbours, so a contiguous row block is a compact region of the mesh
+    (what a mesher's own numbering, or any partitioner, gives a real mesh; 2^k equal blocks are the octants)"""
+    g = np.minimum((np.asarray(pts) * (1 << bits)).astype(np.int64), (1 << bits) - 1)
+    code = np.zeros(g.shape[0], np.int64)
+    dim = g.shape[1]
+    for b in range(bits):
+        for a in range(dim):
+            code |= ((g[:, a] >> b) & 1) << (b * dim + (dim - 1 - a))
+    return np.argsort(code, kind="stable")
+
+
+def radius_graph(n_points, mean_degree=15.0, seed=4, dim=3, order=None):
     """C4: points uniform in the unit cube, undirected radius graph with the radius
     chosen for the requested mean degree, no self-loops; edge feature = x_i - x_j for the pair as
     generated, shared by both directions (the reference's convention).
+    order=None: vertices numbered as drawn (the single-GPU workload of BASELINE configs[3]: every gather is a random
+    row); order="cells": the SAME points numbered in Morton order of their cell (`morton_order`) -- the mesh as a row
+    partition wants it: a contiguous block is a compact region and its halo a thin shell.
     Returns (adj_ia, adj_ja, coords[E, dim])."""
     from scipy.spatial import cKDTree
 
     rng = np.random.Generator(np.random.PCG64(seed))
     pts = rng.random((n_points, dim))
+    if order == "cells":
+        pts = pts[morton_order(pts)]
+    elif order is not None:
+        raise ValueError("order: None or 'cells'")
     r = (mean_degree / (n_points * 4.0 / 3.0 * np.pi)) ** (1.0 / 3.0)
     pairs = cKDTree(pts).query_pairs(r, output_type="ndarray")
     i, j = pairs[:, 0].astype(np.int64), pairs[:, 1].astype(np.int64)

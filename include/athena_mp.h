@@ -285,6 +285,13 @@ int athena_mp_gno_aggregate_fwd(const athena_mp_graph *g, int32_t d, int32_t H, 
 int athena_mp_gno_aggregate_bwd_x(const athena_mp_graph *g, int32_t d, int32_t H, int32_t Fi, int32_t Fo,
                                   const float *theta_dev, const float *coords_dev,
                                   const float *grad_dev, float *dx_dev);
+/* get_partial_gno_agg_features_val (:419-458) in PULL form over the graph's own rows:
+ *   dx[v,:] = sum_{w in row v} K_{eid[w]}^T grad_ext[col[w],:]      dx [n_rows, Fi], grad_ext [n_cols, Fo]
+ * equal to the scatter of athena_mp_gno_aggregate_bwd_x on an undirected graph whose two directions share one edge column
+ * (athena's graphs, :369-376) -- the form a row block of a partitioned graph evaluates after the halo exchange of grad */
+int athena_mp_gno_aggregate_bwd_x_pull(const athena_mp_graph *g, int32_t d, int32_t H, int32_t Fi, int32_t Fo,
+                                       const float *theta_dev, const float *coords_dev,
+                                       const float *grad_ext_dev, float *dx_dev);
 int athena_mp_gno_aggregate_bwd_theta(const athena_mp_graph *g, int32_t d, int32_t H, int32_t Fi,
                                       int32_t Fo, const float *theta_dev, const float *coords_dev,
                                       const float *x_dev, const float *grad_dev, float *dtheta_dev);
@@ -453,6 +460,20 @@ int athena_mp_allreduce(athena_mp_comm *c, float *buf_dev, int64_t count);
  * Collective: argument errors are agreed on before any data moves, so all ranks return the error together. */
 int athena_mp_shard_create(athena_mp_comm *c, int32_t n_local, int64_t nnz, const int32_t *adj_ia, const int32_t *adj_ja,
                            athena_mp_shard **out);
+/* The same for ONE graph WITH edge features cut by rows (graph_nop_layer on a partitioned mesh -- SURVEY.md 8e "GNO: as
+ * Kipf plus replicated theta and all-reduce of dtheta"; BASELINE configs[3] is one 2 M-vertex mesh, which sharding by whole
+ * graphs cannot split).  adj_ja(2,w) = GLOBAL edge id (1-based, 0 = none) as graph_type%adj_ja carries it
+ * (athena_diffstruc_extd_sub_nop.f90:367-378 reads it as the kernel column).  The four row-block handles keep the edge
+ * columns, renumbered to the rank's own set: the distinct ids its rows reference, ascending -- athena_mp_shard_export(7)
+ * lists them, athena_mp_shard_edge_cols counts them, and the rank holds coords [n_edge_cols, d] for exactly those.
+ * Forward:  halo exchange of x, athena_mp_gno_aggregate_fwd on blocks 0 / 1 (interior rows under the transfer).
+ * Reverse:  halo exchange of g = dL/dm, athena_mp_gno_aggregate_bwd_x_pull on blocks 2 / 3 (the pull over the rank's own
+ *           rows -- requires row u to list (v, e) whenever row v lists (u, e), which is CHECKED here across all ranks and
+ *           is an error on every rank otherwise); athena_mp_gno_aggregate_bwd_theta on blocks 0 / 1 needs local g rows
+ *           only; theta is replicated and d theta (+ dW, db) all-reduced (athena_mp_allreduce). */
+int athena_mp_shard_create_edges(athena_mp_comm *c, int32_t n_local, int64_t nnz, const int32_t *adj_ia,
+                                 const int32_t *adj_ja, athena_mp_shard **out);
+int athena_mp_shard_edge_cols(const athena_mp_shard *s, int32_t *n_edge_cols);
 int athena_mp_shard_destroy(athena_mp_shard *s);
 int athena_mp_shard_dims(const athena_mp_shard *s, int32_t *n_local, int32_t *n_interior, int32_t *n_halo, int64_t *nnz,
                          int64_t *row_offset, int64_t *n_total);
@@ -465,6 +486,7 @@ int athena_mp_shard_graph(const athena_mp_shard *s, int32_t which, athena_mp_gra
 /* 0 order [n] int32 | 1 halo_ids [distinct remote rows referenced] int64 | 2 send_idx [n_send] int32 |
  * 3 col_deg [n+n_halo] int32 | 4 send_counts [world] int64 | 5 recv_counts [world] int64 |
  * 6 ext_ids [n_halo] int64: global id held by each row of x_ext beyond the local ones, -1 = padding slot (== 1 in p2p mode);
+ * 7 edge_ids [n_edge_cols] int64: global edge id (0-based) of each local edge column (shards built by _create_edges);
  * host_dst NULL = size query (count in elements) */
 int athena_mp_shard_export(const athena_mp_shard *s, int32_t which, void *host_dst, int64_t capacity, int64_t *count);
 /* x_ext [n + n_halo, F]: p2p mode packs + posts the grouped send/recv into the halo rows, all-gather mode posts one

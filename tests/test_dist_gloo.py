@@ -17,9 +17,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 class OracleGraph:
-    def __init__(self, ia, ja, n_cols, row_deg, col_deg):
+    def __init__(self, ia, ja, n_cols, row_deg, col_deg, n_edge_cols=0):
         self.ia, self.ja, self.n_cols, self.row_deg, self.col_deg = ia, np.asfortranarray(ja), n_cols, row_deg, col_deg
         self.n_rows = ia.size - 1
+        self.n_edge_cols = n_edge_cols
+
+    def square(self):
+        """the block as a square graph of n_cols vertices (rows beyond n_rows are empty): what the oracle's loops take"""
+        ia = np.concatenate([self.ia, np.full(self.n_cols - self.n_rows, self.ia[-1], self.ia.dtype)]).astype(np.int32)
+        return ia, self.ja
 
 
 class OracleBackend:
@@ -29,8 +35,8 @@ class OracleBackend:
         from oracle import oracle
         self.o = oracle
 
-    def make_graph(self, ia, ja, n_cols, row_deg, col_deg):
-        return OracleGraph(ia, ja, n_cols, row_deg, col_deg)
+    def make_graph(self, ia, ja, n_cols, row_deg, col_deg, n_edge_cols=0):
+        return OracleGraph(ia, ja, n_cols, row_deg, col_deg, n_edge_cols)
 
     def kipf_propagate(self, g, x, out):
         out.copy_(torch.from_numpy(self.o.kipf_propagate_rect(x.numpy(), g.ia, g.ja, g.row_deg, g.col_deg)))
@@ -54,15 +60,71 @@ class OracleBackend:
     def matmul_dw(self, P, dZ, out):
         out.copy_(torch.from_numpy(self.o.matmul_dw(dZ.numpy(), P.numpy())))
 
-    def matmul(self, W, P, Fo, out):
-        out.copy_(torch.from_numpy(self.o.matmul(W.numpy(), P.numpy(), Fo)))
+    def matmul(self, W, P, Fo, bias=None, out=None):
+        z = self.o.matmul(W.numpy(), P.numpy(), Fo)
+        if bias is not None:
+            z = self.o.add_bias_rows(z, bias.numpy())
+        z = torch.from_numpy(z)
+        if out is None:
+            return z
+        out.copy_(z)
+        return out
 
     def pull_dual(self, g, x, plain, coef):
         self.neighbour_sum(g, x, plain)
         self.kipf_propagate(g, x, coef)
 
-    def matmul_dx(self, W, dZ, Fi, out):
-        out.copy_(torch.from_numpy(self.o.matmul_dx(W.numpy(), dZ.numpy(), Fi)))
+    def matmul_dx(self, W, dZ, Fi, out=None):
+        r = torch.from_numpy(self.o.matmul_dx(W.numpy(), dZ.numpy(), Fi))
+        if out is None:
+            return r
+        out.copy_(r)
+        return out
+
+    def axpy(self, alpha, x, y):
+        y.add_(x, alpha=alpha)
+        return y
+
+    def activation(self, kind, z):
+        return torch.from_numpy(self.o.activation(kind, z.numpy()))
+
+    def activation_bwd(self, kind, y, g, z=None):
+        return torch.from_numpy(self.o.activation_bwd(kind, y.numpy(), g.numpy()))
+
+    # -- graph neural operator on a row block (the MATERIALISING oracle: kappa [E, Fo*Fi] exists here) ----------------------
+    def gno_aggregate(self, g, theta, coords, x, d, H, Fo, out=None):
+        Fi = x.shape[1]
+        kap = self.o.gno_kernel_eval(coords.numpy(), theta.numpy(), H, Fo * Fi)
+        ia, ja = g.square()
+        m = torch.from_numpy(self.o.gno_aggregate(x.numpy(), kap, ia, ja, Fo)[:g.n_rows])
+        if out is None:
+            return m
+        out.copy_(m)
+        return out
+
+    def gno_aggregate_bwd_theta(self, g, theta, coords, x, grad, d, H, s_save=None):
+        ia, ja = g.square()
+        gp = np.zeros((g.n_cols, grad.shape[1]), np.float32)
+        gp[:g.n_rows] = grad.numpy()
+        dk = self.o.gno_aggregate_bwd_k(gp, x.numpy(), coords.shape[0], ia, ja)
+        return torch.from_numpy(self.o.gno_kernel_bwd_theta(coords.numpy(), theta.numpy(), dk, H))
+
+    def gno_aggregate_bwd_x_pull(self, g, theta, coords, grad_ext, d, H, Fi, out=None):
+        """dx[v] = sum_{w in row v} K_e^T grad_ext[col[w]] in entry order, fp32 (the pull the product path evaluates)"""
+        Fo = grad_ext.shape[1]
+        kap = self.o.gno_kernel_eval(coords.numpy(), theta.numpy(), H, Fo * Fi).reshape(-1, Fi, Fo)   # K_e[q, o] = kappa[o + Fo q]
+        ge = grad_ext.numpy()
+        dx = np.zeros((g.n_rows, Fi), np.float32)
+        for v in range(g.n_rows):
+            for w in range(g.ia[v] - 1, g.ia[v + 1] - 1):
+                e = g.ja[1, w] - 1
+                if e >= 0:
+                    dx[v] += (kap[e] @ ge[g.ja[0, w] - 1]).astype(np.float32)
+        dx = torch.from_numpy(dx)
+        if out is None:
+            return dx
+        out.copy_(dx)
+        return out
 
     def gather_rows(self, x, idx, out):
         out.copy_(x[idx.long()])
@@ -256,3 +318,95 @@ def test_shard_generator_balances_entries():
             if world > 1:
                 frac = 1 - (local.sum() - 1000) / (r.size - 1000)
                 assert abs(frac - used) < 0.03
+
+
+# ---- ONE mesh with edge features cut by rows: the graph neural operator ------------------------------------
+def gno_problem(n_points, Fi, Fo, d, H, mean_degree=6.0, seed=9):
+    """the global problem every rank (and the checking process) derives from the seed: mesh, features, upstream gradient,
+    parameters"""
+    sys.path.insert(0, ROOT)
+    from athena_amd import synth
+    ia, ja, coords = synth.radius_graph(n_points, mean_degree, seed, dim=d, order="cells")
+    rng = np.random.Generator(np.random.PCG64(seed + 100))
+    x = rng.uniform(-1, 1, (n_points, Fi)).astype(np.float32)
+    up = rng.uniform(-1, 1, (n_points, Fo)).astype(np.float32)
+    theta = (rng.standard_normal(H * d + H + Fo * Fi * H + Fo * Fi) * 0.3).astype(np.float32)
+    w = (rng.standard_normal(Fo * Fi) * 0.5).astype(np.float32)
+    b = (rng.standard_normal(Fo) * 0.1).astype(np.float32)
+    return ia, ja, coords, x, up, theta, w, b
+
+
+def _worker_gno(rank, world, port, dims, act, mode, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ATHENA_MP_HALO_MODE=mode)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from athena_amd import dist as adist
+
+    n_points, Fi, Fo, d, H = dims
+    ia, ja, coords, x, up, theta, w, b = gno_problem(*dims)
+    dev = torch.device("cpu")
+    shard, c_loc = adist.make_mesh_shard(rank, world, n_points, device=dev, mesh=(ia, ja, coords))
+    n = shard.n
+    sl = slice(rank * n, (rank + 1) * n)
+    step = adist.GnoShardStep(shard, Fi, Fo, d, H, dev, backend=OracleBackend(), inputs=(x[sl], up[sl], theta, w, b, c_loc),
+                              activation=act)
+    out = step.forward().clone().numpy()
+    dx = step.backward().clone().numpy()
+    held = shard.ext_ids >= 0
+    halo_ok = bool(np.array_equal(step.x_ext[n:].numpy()[held], x[shard.ext_ids[held]]) and
+                   np.isin(shard.halo_ids, shard.ext_ids[held]).all())
+    q.put((rank, dict(out=out, dX=dx, grads=step.grad_flat.numpy().copy(), order=shard.order.copy(), n_int=shard.n_int,
+                      n_halo=shard.n_halo, halo_mode=shard.halo_mode, halo_fraction=shard.halo_fraction, halo_ok=halo_ok,
+                      n_edge_cols=shard.n_edge_cols, coords_ok=bool(np.array_equal(c_loc, coords[shard.edge_ids])))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def gno_reference(dims, act):
+    """the single-process MATERIALISING oracle on the whole mesh (tests/oracle_layers.py composes the layer as
+    athena_graph_nop_layer.f90:690-788 does)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_layers as ol
+    from athena_amd.graph import graph_type
+
+    n_points, Fi, Fo, d, H = dims
+    ia, ja, coords, x, up, theta, w, b = gno_problem(*dims)
+    g = graph_type.from_csr(ia, ja, num_edges=coords.shape[0])
+    outs, tapes = ol.gno_forward([g], [x], [coords], [theta, w, b], Fi, Fo, d, H, True, act)
+    dxs, _, grads = ol.gno_backward([g], [x], [coords], tapes, [theta, w, b], Fi, Fo, d, H, True, act, [up])
+    return outs[0], dxs[0], np.concatenate([np.asarray(a, np.float32).reshape(-1) for a in grads])
+
+
+@pytest.mark.parametrize("world,act,mode", [(2, "none", "p2p"), (3, "none", "p2p"), (8, "none", "p2p"), (2, "relu", "p2p"),
+                                            (3, "sigmoid", "allgather"), (8, "none", "allgather"), (4, "none", "auto")])
+def test_node_partitioned_gno_layer_matches_the_single_process_oracle(oracle, world, act, mode):
+    """graph_nop_layer on ONE mesh cut by rows (halo exchange of x forward and of dz in reverse, theta
+    replicated, d theta / dW / db all-reduced): assembled out and dx, and every rank's all-reduced gradients, equal the
+    materialising oracle on the whole mesh; the rank holds exactly the coords its rows reference."""
+    dims = (960, 3, 5, 3, 4)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_gno, args=(r, world, port, dims, act, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    out_ref, dx_ref, g_ref = gno_reference(dims, act)
+
+    def unperm(key):
+        parts = []
+        for r in range(world):
+            a = np.empty_like(res[r][key]); a[res[r]["order"]] = res[r][key]; parts.append(a)
+        return np.concatenate(parts)
+
+    assert np.abs(unperm("out") - out_ref).max() <= 1e-5 * np.abs(out_ref).max()
+    assert np.abs(unperm("dX") - dx_ref).max() <= 1e-5 * np.abs(dx_ref).max()
+    for r in range(world):
+        assert np.abs(res[r]["grads"] - g_ref).max() <= 2e-5 * np.abs(g_ref).max(), r
+        assert res[r]["halo_ok"] and res[r]["coords_ok"] and res[r]["n_halo"] > 0 and res[r]["n_edge_cols"] > 0
+        want = mode if mode != "auto" else ("allgather" if res[r]["halo_fraction"] > 0.7 else "p2p")
+        assert res[r]["halo_mode"] == want
+    assert sum(res[r]["n_int"] for r in range(world)) > 0 or world == 8      # compact blocks keep interior rows

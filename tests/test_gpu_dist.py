@@ -451,3 +451,183 @@ def test_c5_shard_from_shard_create_with_eight_ranks(dev, variant, check_rank, w
     assert c["Z_rel"] <= 1e-5 and c["dX_rel"] <= 1e-5, c
     if variant == "local":
         assert all(res[r]["n_int"] > 0 for r in range(world))
+
+
+# ---- ONE mesh with edge features cut by rows: graph_nop_layer through the C-ABI shard (athena_mp_shard_create_edges) ----------
+def _gno_worker(rank, world, port, dims, act, mode, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ATHENA_MP_HALO_MODE=mode)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from athena_amd import dist as adist
+    from test_dist_gloo import gno_problem
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    n_points, Fi, Fo, d, H = dims
+    ia, ja, coords, x, up, theta, w, b = gno_problem(*dims)
+    shard, c_loc = adist.make_mesh_shard(rank, world, n_points, device=dev, mesh=(ia, ja, coords))
+    assert isinstance(shard, adist.CShard), shard.transport
+    n = shard.n
+    sl = slice(rank * n, (rank + 1) * n)
+    # the python plan on the same rows: both must number the edge columns alike
+    rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(ia[rank * n:(rank + 1) * n + 1]))
+    e0, e1 = int(ia[rank * n]) - 1, int(ia[(rank + 1) * n]) - 1
+    py = adist.Shard(rank, world, n, rows, ja[0, e0:e1].astype(np.int64) - 1, ja[1, e0:e1].astype(np.int64))
+    gi, gb = shard.graphs()[0:2]
+    eid_c = np.concatenate([gi.export("eid"), gb.export("eid")]) + 1
+    same_plan = bool(np.array_equal(shard.edge_ids, py.edge_ids) and np.array_equal(shard.order, py.order)
+                     and np.array_equal(eid_c, py.adj_ja[1]))
+    step = adist.GnoShardStep(shard, Fi, Fo, d, H, dev, inputs=(x[sl], up[sl], theta, w, b, c_loc), activation=act)
+    out = step.forward().clone().cpu().numpy()
+    dx = step.backward().clone().cpu().numpy()
+    torch.cuda.synchronize()
+    held = shard.ext_ids >= 0
+    halo_ok = bool(np.array_equal(step.x_ext[n:].cpu().numpy()[held], x[shard.ext_ids[held]]))
+    q.put((rank, dict(out=out, dX=dx, grads=step.grad_flat.cpu().numpy().copy(), order=shard.order.copy(), n_int=shard.n_int,
+                      n_halo=shard.n_halo, halo_mode=shard.halo_mode, halo_ok=halo_ok, same_plan=same_plan,
+                      kept_s=[t is not None for t in step._s], transport=shard.transport, n_edge_cols=shard.n_edge_cols)))
+    dist.barrier()
+    shard.close()
+    adist.c_comm_destroy()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,dims,act,mode", [
+    (2, (1536, 64, 64, 3, 64), "none", "p2p"),        # BASELINE configs[3]'s widths: the producer / consumer kernels, S kept
+    (3, (1536, 64, 64, 3, 64), "relu", "p2p"),
+    (2, (1536, 64, 64, 3, 64), "none", "allgather"),
+    (8, (2048, 64, 64, 3, 64), "none", "auto"),
+    (2, (960, 3, 5, 3, 4), "sigmoid", "p2p"),         # generic shapes: the VALU / tiled route
+    (3, (960, 32, 32, 2, 32), "none", "p2p")])
+def test_node_partitioned_gno_layer_with_hip_backend_matches_the_oracle(dev, world, dims, act, mode):
+    """graph_nop_layer forward + reverse on ONE mesh cut by rows, the product path: athena_mp_shard_create_edges (edge
+    columns renumbered per rank, symmetry checked across ranks), halo exchange of x and of dz through comm.hip (shm test
+    transport: the ranks share the box's one GPU), athena_mp_gno_aggregate_fwd / _bwd_theta on the forward blocks,
+    athena_mp_gno_aggregate_bwd_x_pull on the backward blocks, ONE all-reduce of [dtheta | dW | db].  Assembled results
+    against the materialising oracle on the whole mesh (1e-5; 2e-5 for the parameter gradients)."""
+    from test_dist_gloo import gno_reference
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gno_worker, args=(r, world, port, dims, act, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    out_ref, dx_ref, g_ref = gno_reference(dims, act)
+
+    def unperm(key):
+        parts = []
+        for r in range(world):
+            a = np.empty_like(res[r][key]); a[res[r]["order"]] = res[r][key]; parts.append(a)
+        return np.concatenate(parts)
+
+    assert np.abs(unperm("out") - out_ref).max() <= 1e-5 * np.abs(out_ref).max()
+    assert np.abs(unperm("dX") - dx_ref).max() <= 1e-5 * np.abs(dx_ref).max()
+    for r in range(world):
+        assert np.abs(res[r]["grads"] - g_ref).max() <= 2e-5 * np.abs(g_ref).max(), r
+        assert res[r]["halo_ok"] and res[r]["same_plan"] and res[r]["transport"].startswith("shm")
+        assert res[r]["n_halo"] > 0 and res[r]["n_edge_cols"] > 0
+        if mode != "auto":
+            assert res[r]["halo_mode"] == mode
+    if dims[1:] == (64, 64, 3, 64):
+        assert any(any(res[r]["kept_s"]) for r in range(world))     # the training-mode forward kept S on the blocks
+
+
+def _asym_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from athena_amd import dist as adist
+    from athena_amd._capi import AthenaMPError
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    # 4 vertices, 2 per rank; pair (1, 3) carries edge column 1 in row 1 but column 2 in row 3: not a shared column
+    ia = np.array([1, 2, 2], np.int32) if rank == 0 else np.array([1, 2, 2], np.int32)
+    cols = np.array([2], np.int64) if rank == 0 else np.array([0], np.int64)
+    eids = np.array([1], np.int64) if rank == 0 else np.array([2], np.int64)
+    try:
+        adist.CShard(adist.c_comm(dev), ia, cols, eids)
+        msg = "no error"
+    except AthenaMPError as exc:
+        msg = str(exc)
+    q.put((rank, msg))
+    dist.barrier()
+    adist.c_comm_destroy()
+    dist.destroy_process_group()
+
+
+def test_shard_create_edges_refuses_a_graph_whose_directions_do_not_share_an_edge_column(dev):
+    """the pull form of the reverse pass equals the reference's scatter only on an undirected graph whose two directions
+    share one edge column (athena_diffstruc_extd_sub_nop.f90:369-376): athena_mp_shard_create_edges checks it over all
+    ranks and every rank gets the error"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_asym_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert "shared edge columns" in res[0] and "shared edge columns" in res[1], res
+    assert all("no error" not in res[r] for r in range(world)), res
+
+
+@pytest.mark.parametrize("world,transport,mode,dims", [(1, "rccl", "auto", (1536, 64, 64, 3, 64)), (2, "shm", "p2p", (1536, 64, 64, 3, 64)),
+                                                       (3, "shm", "allgather", (1537, 64, 64, 3, 64)),   # blocks of 512 / 512 / 513
+                                                       (3, "shm", "p2p", (961, 3, 5, 3, 4))])
+def test_fortran_processes_run_the_node_partitioned_gno_layer_through_the_c_abi(dev, tmp_path, world, transport, mode, dims):
+    """gno_shard_run.f90: one FORTRAN process per rank -- communicator from an id file, athena_mp_shard_create_edges on the
+    rank's rows of graph_type%adj_ia / adj_ja (global vertex AND edge ids), the rank's own edge geometry, halo exchange of
+    x and of dz under the interior rows, dtheta / dW / db in one all-reduce, all through ISO_C_BINDING; assembled results
+    against the materialising oracle on the whole mesh.  world = 1 uses RCCL itself."""
+    import subprocess
+
+    from test_dist_gloo import gno_problem, gno_reference
+
+    exe = os.path.join(ROOT, "athena_amd", "fortran", "gno_shard_run")
+    if not os.path.exists(exe):
+        pytest.skip("Fortran driver not built (no amdflang)")
+    n_points, Fi, Fo, d, H = dims
+    ia, ja, coords, x, up, theta, w, b = gno_problem(*dims)
+    with open(tmp_path / "problem.bin", "wb") as fh:
+        np.array([n_points, ja.shape[1], coords.shape[0], Fi, Fo, d, H], np.int32).tofile(fh)
+        ia.astype(np.int32).tofile(fh)
+        np.asfortranarray(ja, np.int32).T.copy().tofile(fh)        # column-major (2, nnz)
+        for a in (coords, x, up, theta, w, b):
+            np.ascontiguousarray(a, np.float32).tofile(fh)
+    env = dict(os.environ)
+    env.pop("ATHENA_MP_COMM_TRANSPORT", None)
+    env["ATHENA_MP_HALO_MODE"] = mode
+    if transport == "shm":
+        env["ATHENA_MP_COMM_TRANSPORT"] = "shm"
+    prefix = str(tmp_path / "run")
+    procs = [subprocess.Popen([exe, str(r), str(world), "0", str(tmp_path / "id"), str(tmp_path / "problem.bin"), prefix],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    out, dx, grads, halos = [], [], [], []
+    ng = H * d + H + Fo * Fi * H + Fo * Fi + Fo * Fi + Fo
+    for r in range(world):
+        with open(f"{prefix}_r{r}.bin", "rb") as fh:
+            n, n_int, n_halo, n_ec = np.fromfile(fh, np.int32, 4)
+            out.append(np.fromfile(fh, np.float32, n * Fo).reshape(n, Fo)); dx.append(np.fromfile(fh, np.float32, n * Fi).reshape(n, Fi))
+            grads.append(np.fromfile(fh, np.float32, ng))
+            halos.append(n_halo)
+            assert n_ec > 0
+    out_ref, dx_ref, g_ref = gno_reference(dims, "none")
+    assert all(h > 0 for h in halos) or world == 1
+    assert np.abs(np.concatenate(out) - out_ref).max() <= 1e-5 * np.abs(out_ref).max()
+    assert np.abs(np.concatenate(dx) - dx_ref).max() <= 1e-5 * np.abs(dx_ref).max()
+    for r in range(world):
+        assert np.abs(grads[r] - g_ref).max() <= 2e-5 * np.abs(g_ref).max(), r
+    if dims[1:] == (64, 64, 3, 64):
+        assert all("S kept T" in o for o in outs), outs
