@@ -65,6 +65,7 @@ _PROTOS = {
     "athena_mp_activation_fwd": [_i32, _i64, _vp, _vp],
     "athena_mp_activation_bwd": [_i32, _i64, _vp, _vp, _vp],
     "athena_mp_axpy": [_i64, _f32, _vp, _vp],
+    "athena_mp_device_copy": [_vp, _vp, C.c_uint64],
     "athena_mp_duvenaud_propagate_fwd": [_vp, _i32, _i32, _vp, _vp, _vp],
     "athena_mp_duvenaud_propagate_bwd_x": [_vp, _i32, _i32, _vp, _vp],
     "athena_mp_duvenaud_propagate_bwd_e": [_vp, _i32, _i32, _vp, _vp],

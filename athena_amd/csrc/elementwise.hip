@@ -192,11 +192,43 @@ __global__ void concat_bwd_kernel(int64_t N, int Fa, int Fb, const float *__rest
 
 inline dim3 grid_for(int64_t n) { return dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048 * 4)); }
 
+// one 16-byte element per thread in launch order: the access pattern that reaches this HBM's streaming ceiling (6.2 TB/s
+// on the pool's boxes against 4.4 - 5.0 for persistent grid-stride loops; profiles/r03_ubench_stream_rows.txt)
+typedef float copy_v4f __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void copy16_kernel(const copy_v4f *__restrict__ src, copy_v4f *__restrict__ dst, size_t n16)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+}
+__global__ __launch_bounds__(256) void copy1_kernel(const char *__restrict__ src, char *__restrict__ dst, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
 } // namespace
 
 using namespace amp;
 
 extern "C" {
+
+int athena_mp_device_copy(void *dst, const void *src, uint64_t bytes)
+{
+    AMP_REQUIRE(bytes == 0 || (dst && src), "device_copy: null pointer");
+    AMP_REQUIRE((((uintptr_t)dst | (uintptr_t)src) & 15) == 0, "device_copy: pointers must be 16-byte aligned");
+    const size_t n16 = (size_t)(bytes / 16), tail = (size_t)(bytes % 16);
+    AMP_REQUIRE((n16 + 255) / 256 < ((size_t)1 << 31), "device_copy: %llu bytes exceed one launch", (unsigned long long)bytes);
+    if (n16) {
+        hipLaunchKernelGGL(copy16_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, stream(), (const copy_v4f *)src,
+                           (copy_v4f *)dst, n16);
+        AMP_LAUNCH_CHECK();
+    }
+    if (tail) {
+        hipLaunchKernelGGL(copy1_kernel, dim3(1), dim3(256), 0, stream(), (const char *)src + 16 * n16, (char *)dst + 16 * n16, tail);
+        AMP_LAUNCH_CHECK();
+    }
+    return 0;
+}
 
 int athena_mp_activation_fwd(int32_t act, int64_t n, const float *z, float *y)
 {

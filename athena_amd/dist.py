@@ -265,6 +265,91 @@ def _p2p_exchange(send_bufs, recv_bufs, rank, world):
 
 
 # --------------------------------------------------------------------------------------------------
+# a deadline around everything that waits for another rank
+# --------------------------------------------------------------------------------------------------
+class Watchdog:
+    """No RCCL collective has a completion deadline of its own: two ranks that disagree about a transfer wait for each
+    other until whoever launched them gives up (the driver: 1800 s).  A monitor thread per rank arms a deadline around
+    every phase that waits for a peer -- process group, communicator, shard build, first contact of each exchange, the
+    timed loop, parity -- and on expiry prints ONE json line {"ok": false, "error": "rank r stalled in <phase> ..."} and
+    leaves with os._exit(3): no retry, no re-exec, no cleanup that could itself block.
+    ATHENA_MP_COLLECTIVE_TIMEOUT_S (default 120) is the deadline of one phase; phases that also do host work proportional
+    to the graph (shard build) pass their own factor."""
+
+    def __init__(self, rank, timeout_s=None, exit_fn=None):
+        import os
+        import threading
+        self.rank = rank
+        try:
+            self.timeout = float(os.environ.get("ATHENA_MP_COLLECTIVE_TIMEOUT_S", "120")) if timeout_s is None else float(timeout_s)
+        except ValueError:
+            self.timeout = 120.0
+        self._lock = threading.Lock()
+        self._stack = []          # (phase, deadline)
+        self._exit = exit_fn or self._die
+        self._stop = False
+        self._thread = threading.Thread(target=self._watch, name="athena_mp-watchdog", daemon=True)
+        self._thread.start()
+
+    def _die(self, phase, waited):
+        import json
+        import os
+        import sys
+        msg = {"ok": False, "error": f"rank {self.rank} stalled in {phase} for more than {waited:.0f} s "
+                                     "(ATHENA_MP_COLLECTIVE_TIMEOUT_S); a peer is missing, late or in another collective"}
+        try:
+            sys.stdout.write(json.dumps(msg) + "\n"); sys.stdout.flush()
+            sys.stderr.write(f"[athena_mp watchdog] {msg['error']}\n"); sys.stderr.flush()
+        finally:
+            os._exit(3)
+
+    def _watch(self):
+        import time
+        while not self._stop:
+            time.sleep(0.25)
+            with self._lock:
+                top = self._stack[-1] if self._stack else None
+            if top is not None and time.monotonic() > top[1]:
+                self._exit(top[0], top[2])
+                return
+
+    def phase(self, name, factor=1.0):
+        """context manager: `name` must finish within factor * timeout seconds"""
+        wd = self
+
+        class _P:
+            def __enter__(self_inner):
+                import time
+                with wd._lock:
+                    wd._stack.append((name, time.monotonic() + wd.timeout * factor, wd.timeout * factor))
+
+            def __exit__(self_inner, *exc):
+                with wd._lock:
+                    wd._stack.pop()
+                return False
+        return _P()
+
+    def close(self):
+        self._stop = True
+
+
+class _NoWatch:
+    def phase(self, name, factor=1.0):
+        import contextlib
+        return contextlib.nullcontext()
+
+
+_WATCH = _NoWatch()
+
+
+def set_watchdog(wd):
+    """bench.py (and any multi-rank driver) installs its Watchdog here: communicator creation and the collective part of
+    the shard build arm it themselves"""
+    global _WATCH
+    _WATCH = wd if wd is not None else _NoWatch()
+
+
+# --------------------------------------------------------------------------------------------------
 # the product path: communicator, shard and halo exchange behind the C ABI (csrc/comm.hip, RCCL)
 # --------------------------------------------------------------------------------------------------
 _COMM = None
@@ -289,9 +374,10 @@ def c_comm(device):
     if rank == 0:
         _capi.call("athena_mp_comm_unique_id", buf)
     box = [bytes(buf.raw)]
-    dist.broadcast_object_list(box, src=0)
     h = C.c_void_p()
-    _capi.call("athena_mp_comm_create", rank, world, C.create_string_buffer(box[0], 128), C.byref(h))
+    with _WATCH.phase("communicator creation (id broadcast + athena_mp_comm_create / ncclCommInitRank)"):
+        dist.broadcast_object_list(box, src=0)
+        _capi.call("athena_mp_comm_create", rank, world, C.create_string_buffer(box[0], 128), C.byref(h))
     name = C.create_string_buffer(96)
     _capi.call("athena_mp_comm_info", h, None, None, name, 96)
     _COMM = type("CComm", (), {})()
@@ -443,14 +529,18 @@ def _c_shard_or_none(device, adj_ia, cols_global, eids_global=None):
     err = None
     sh = None
     try:
-        sh = CShard(c_comm(torch.device(device)), adj_ia, cols_global, eids_global)
+        comm = c_comm(torch.device(device))
+        # collective, plus host work proportional to the shard (renumbering, four graph handles): a longer leash
+        with _WATCH.phase("athena_mp_shard_create (collective plan + graph handles)", factor=5.0):
+            sh = CShard(comm, adj_ia, cols_global, eids_global)
     except Exception as exc:      # AthenaMPError from the C ABI, OSError from the loader ...
         err = f"{type(exc).__name__}: {exc}"[:300]
         print(f"[athena_mp dist] rank {dist.get_rank()}: C-ABI communicator / shard failed: {err}", file=sys.stderr, flush=True)
     flag = torch.tensor([0 if err is None else 1], dtype=torch.int32)
     if dist.get_backend() == "nccl":
         flag = flag.to(device)
-    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    with _WATCH.phase("agreeing on the shard build (all_reduce of the error flag)", factor=5.0):
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
     if int(flag.item()) == 0:
         return sh, None
     if sh is not None:
@@ -729,6 +819,30 @@ class KipfShardStep:
             self.b.kipf_propagate(g, self.dZ_ext, out=self.Qp[r0:r1])
         else:
             self.b.pull_dual(g, self.dZ_ext, plain=self.Qp[r0:r1], coef=self.Qc[r0:r1])
+
+
+def first_contact(step, watch, sync):
+    """every transfer of a sharded step (KipfShardStep / GnoShardStep) ONCE on its own, each under the watchdog and with
+    the device drained behind it (`sync`): the first time two ranks meet in a collective is where a mismatch shows, and a
+    stall then names the rank and the transfer instead of hanging the whole launch in its first step"""
+    s = step.s
+    if s.world == 1:
+        return
+    fwd = getattr(step, "y_ext", None) if getattr(step, "transform_first", False) else step.x_ext
+    with watch.phase("first halo exchange (forward rows)"):
+        step.xchg.finish(step.xchg.start(fwd))
+        sync()
+    rev = step.dZ_ext if hasattr(step, "dZ_ext") else step.g_ext
+    with watch.phase("first halo exchange (gradient rows)"):
+        step.xchg_o.finish(step.xchg_o.start(rev))
+        sync()
+    grads = step.dW if hasattr(step, "dZ_ext") else step.grad_flat
+    with watch.phase("first all-reduce of the parameter gradients"):
+        grads.zero_()
+        red = s.allreduce_start(grads)
+        if red is not None:
+            red.wait()
+        sync()
 
 
 def build_kipf_step(shard, F, device, backend=None, Fo=None, order="auto", inputs=None):

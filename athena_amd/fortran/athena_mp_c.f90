@@ -49,6 +49,7 @@ module athena_mp_c
   public :: athena_mp_comm_unique_id, athena_mp_allreduce, athena_mp_allreduce_start, athena_mp_allreduce_finish
   public :: athena_mp_shard_create, athena_mp_shard_destroy, athena_mp_shard_dims, athena_mp_shard_graph
   public :: athena_mp_shard_export, athena_mp_halo_start, athena_mp_halo_finish, athena_mp_shard_info
+  public :: athena_mp_device_copy
   public :: athena_mp_shard_create_edges, athena_mp_shard_edge_cols, athena_mp_gno_aggregate_bwd_x_pull
   public :: athena_mp_resident_mode, athena_mp_resident_acquire, athena_mp_resident_release, athena_mp_resident_flush
   public :: athena_mp_resident_drop, athena_mp_resident_stats
@@ -531,6 +532,11 @@ module athena_mp_c
        integer(c_int32_t), value :: act
        integer(c_int64_t), value :: n
        type(c_ptr), value :: z_dev, y_dev
+     end function
+     integer(c_int) function athena_mp_device_copy(dst_dev, src_dev, bytes) bind(C, name="athena_mp_device_copy")
+       import :: c_int, c_ptr, c_int64_t
+       type(c_ptr), value :: dst_dev, src_dev
+       integer(c_int64_t), value :: bytes
      end function
      integer(c_int) function athena_mp_axpy(n, alpha, x_dev, y_dev) bind(C, name="athena_mp_axpy")
        import :: c_int, c_int64_t, c_float, c_ptr

@@ -65,7 +65,11 @@ def parse_args():
                          "density; the fraction at N blocks is cut8*(N-1)/7).  -1: structure-free uniform random graph")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle (no cpu_baseline, N=1 parity null)")
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000,
-                    help="rows of the workload the 1-thread CPU oracle runs (default: all of C2, ~7-15 s)")
+                    help="rows of the workload the 1-thread CPU oracle runs (default: all of C2, ~7 s per run)")
+    ap.add_argument("--cpu-runs", type=int, default=3, help="timed runs of the CPU oracle after one warm-up (median reported)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="N = 1: skip the `secondary` block (configs[2], configs[3], configs[4] on one GPU; ~2-4 min of child processes)")
+    ap.add_argument("--secondary", default="c3,c4,c5", help="which secondary configurations to run (comma separated)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     args.custom = any(v is not None for v in (args.nodes, args.pairs, args.feat))
@@ -88,6 +92,14 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
+def _stall_for_test(rank, where):
+    """test hook (tests/test_gpu_dist.py): ATHENA_MP_BENCH_STALL="<rank>:<where>" makes that rank sleep at `where`, so the
+    OTHER ranks' watchdogs can be seen to fire.  Never set outside the tests."""
+    spec = os.environ.get("ATHENA_MP_BENCH_STALL", "")
+    if spec and spec == f"{rank}:{where}":
+        time.sleep(3600)
+
+
 def transport_error(transport, one_device):
     """N > 1 lines must have moved their halos over RCCL.  comm.hip's host-staged test transport ("shm ...") and the
     python fallback plan exist for boxes with one GPU; a line that used them without the one-device dry-run switch
@@ -104,7 +116,7 @@ def rel(a, b):
     return float(np.abs(np.asarray(a, np.float64) - b).max() / max(np.abs(b).max(), 1e-30))
 
 
-def cpu_baseline(ia, ja, x, w, dz, F, sample_rows):
+def cpu_baseline(ia, ja, x, w, dz, F, sample_rows, runs=3):
     """The oracle (a line-by-line C port of the reference's loops), 1 thread, on the first
     `sample_rows` rows of the same workload (they gather from / scatter into the full tensors).
     Returns (the cpu_baseline object, the oracle's results for the parity block)."""
@@ -117,17 +129,30 @@ def cpu_baseline(ia, ja, x, w, dz, F, sample_rows):
     sja = np.asfortranarray(ja[:, : sia[-1] - 1])
     deg = np.diff(ia).astype(np.int32)
     ent = int(sia[-1] - 1)
-    oracle.kipf_propagate_rect(x[:1000], sia[:2], sja[:, : sia[1] - 1], deg[:1], deg)  # warm the library
-    t0 = time.perf_counter()
-    p = oracle.kipf_propagate_rect(x, sia, sja, deg[:rows], deg)
-    z = oracle.matmul(w, p, F)
-    dw = oracle.matmul_dw(dz[:rows], p)
-    dp = oracle.matmul_dx(w, dz[:rows], F)
-    dx = oracle.kipf_propagate_bwd(dp, sia, sja, n_out=n)
-    t = time.perf_counter() - t0
+    def one_run(r, keep):
+        ria = sia[: r + 1]
+        rja = sja[:, : ria[-1] - 1]
+        t0 = time.perf_counter()
+        p = oracle.kipf_propagate_rect(x, ria, rja, deg[:r], deg)
+        z = oracle.matmul(w, p, F)
+        dw = oracle.matmul_dw(dz[:r], p)
+        dp = oracle.matmul_dx(w, dz[:r], F)
+        dx = oracle.kipf_propagate_bwd(dp, ria, rja, n_out=n)
+        return time.perf_counter() - t0, (dict(p=p, z=z, dw=dw, dx=dx) if keep else None)
+
+    one_run(min(rows, 50_000), False)                 # warm-up: library, page tables, caches ("after 1 warm-up")
+    times, res = [], None
+    for k in range(max(1, runs)):
+        t, r_ = one_run(rows, k == 0)
+        times.append(t)
+        res = res or r_
+    t = float(np.median(times))
+    p, z, dw, dx = res["p"], res["z"], res["dw"], res["dx"]
     out = {"value": ent / t, "unit": "edges/s", "cores": 1, "kind": "port",
            "sample": f"oracle (C port of the reference loops), first {rows} of {n} rows = {ent} of {ja.shape[1]} entries, "
-                     f"full fwd+bwd step, {t:.1f} s on {os.cpu_count()}-core host, 1 thread"}
+                     f"full fwd+bwd step, median of {len(times)} timed runs after 1 warm-up "
+                     f"({', '.join(f'{v:.2f}' for v in times)} s) on {os.cpu_count()}-core host, 1 thread",
+           "runs_s": [round(v, 3) for v in times]}
     # context only: the same step threaded over rows on ALL host cores.  The reference itself has no
     # threading, so the single-thread figure above is the baseline; this one shows what the whole socket pair reaches.
     try:
@@ -234,6 +259,70 @@ def parity_sharded(step, shard, seeds, dev, n_sample=4000):
     return out
 
 
+def measure_copy_ceiling(dev, gib=1, reps=10):
+    """the streaming ceiling of THIS box, measured in this run: a 1 GiB device copy, one 16-byte element per thread in
+    launch order (athena_mp_device_copy: the form that reaches the ceiling, profiles/r03_ubench_stream_rows.txt), read +
+    written bytes over the mean launch time of `reps` launches after one warm-up (HIP events on the launch stream)"""
+    import ctypes as C
+
+    import torch
+    from athena_amd import _capi
+
+    n = gib << 30
+    src = torch.empty(n, dtype=torch.uint8, device=dev)
+    dst = torch.empty(n, dtype=torch.uint8, device=dev)
+    src.zero_(); dst.zero_()
+    _capi.use_torch_stream()
+    cp = lambda: _capi.call("athena_mp_device_copy", C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), n)
+    cp()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        cp()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    del src, dst
+    torch.cuda.empty_cache()
+    return 2.0 * n / (ms * 1e-3) / 1e9
+
+
+def run_secondary(which, budget_s=540.0):
+    """configs[2], configs[3] and configs[4]-on-one-GPU as CHILD processes (scripts/bench_secondary.py) after the
+    headline's timed loop: step ms, per-op roofline fractions and a parity flag against the oracle each.  Anything that
+    goes wrong in a child -- a crash, a timeout, a parity failure -- is recorded here and changes neither the headline
+    nor the exit code."""
+    out = {"note": "measured after the headline's timed loop, each configuration in a child process of its own; "
+                   "never part of `value`"}
+    names = {"c3": "configs[2]", "c4": "configs[3]", "c5": "configs[4]_one_gpu"}
+    t_start = time.perf_counter()
+    for key in which:
+        if key not in names:
+            continue
+        left = budget_s - (time.perf_counter() - t_start)
+        if left < 30:
+            out[names[key]] = {"error": "skipped: the secondary block's time budget is spent"}
+            continue
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "bench_secondary.py"), "--config", key],
+                               capture_output=True, text=True, timeout=left)
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not lines:
+                out[names[key]] = {"error": f"rc {r.returncode}: " + (r.stderr.strip().splitlines() or ["no output"])[-1][:300]}
+            else:
+                out[names[key]] = json.loads(lines[-1])
+        except subprocess.TimeoutExpired:
+            out[names[key]] = {"error": f"timed out after {left:.0f} s"}
+        except Exception as exc:      # a broken child must never take the headline with it
+            out[names[key]] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+    bad = [k for k, v in out.items() if isinstance(v, dict) and ("error" in v or not v.get("parity", {}).get("ok", False))]
+    if bad:
+        out["error"] = "failed or parity not ok: " + ", ".join(bad)
+    out["wall_s"] = round(time.perf_counter() - t_start, 1)
+    return out
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -275,10 +364,16 @@ def main():
         from athena_amd import dist as adist
 
         backend = os.environ.get("ATHENA_MP_BENCH_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        # every wait for a peer from here on has a deadline (ATHENA_MP_COLLECTIVE_TIMEOUT_S, default 120 s per phase): a
+        # stalled rank prints {"ok": false, "error": "rank r stalled in <phase>"} and leaves with exit code 3
+        watch = adist.Watchdog(rank)
+        adist.set_watchdog(watch)
+        with watch.phase("process group creation"):
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(backend)
+        _stall_for_test(rank, "setup")
         if weak:
             cut = None if args.cut < 0 else args.cut * (world - 1) / 7.0
             shard = adist.make_weak_scaling_shard(rank, world, args.nodes, args.pairs, F, cut=cut, device=dev)
@@ -290,8 +385,11 @@ def main():
             inputs = (synth.feature_block(1, rank * n, (rank + 1) * n, F), synth.feature_block(3, rank * n, (rank + 1) * n, F),
                       synth.kipf_weight(F))
         shard_step, nnz_local, info = adist.build_kipf_step(shard, F, dev, inputs=inputs)
+        _stall_for_test(rank, "halo")
+        adist.first_contact(shard_step, watch, torch.cuda.synchronize)
         tt = torch.tensor([nnz_local], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(tt)
+        with watch.phase("all-reduce of the entry counts"):
+            dist.all_reduce(tt)
         nnz_total = int(tt.item())
         x = w = dz = ia = ja = None
 
@@ -322,6 +420,12 @@ def main():
                 e2.record(); ev_dw.append((e1, e2))
             ops.kipf_layer_bwd_x(g, dzd, wd, F, out=dX)
         info = {}
+        watch = None
+
+    import contextlib
+
+    def phase(name, factor=1.0):
+        return watch.phase(name, factor) if watch is not None else contextlib.nullcontext()
 
     def barrier():
         # drain this device first (compute AND the C ABI's communication stream), so that the process group's barrier
@@ -332,18 +436,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(record=True)
-    barrier()
-    dt = time.perf_counter() - t0
+    with phase("warm-up steps"):
+        for _ in range(args.warmup):
+            step()
+        barrier()
+    with phase("timed loop", factor=max(1.0, args.steps / 50.0)):
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(record=True)
+        barrier()
+        dt = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
         tt = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        with phase("max of the step time over the ranks"):
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
 
     ms_per_step = dt / args.steps * 1e3
@@ -416,16 +523,28 @@ def main():
                                     "avg_launch_ms": dw_ms, "dtype": "f32 (v_mfma_f32_32x32x2_f32, exact fp32 products)"}
     ok = True
     if world == 1:
+        try:
+            ceil = measure_copy_ceiling(dev)
+            out["roofline"]["measured_copy_ceiling_GBps"] = round(ceil, 1)
+            out["roofline"]["frac_of_measured_copy_ceiling"] = round(achieved / ceil, 4)
+            out["roofline"]["measured_copy_ceiling_note"] = ("1 GiB device copy on this box in this run (athena_mp_device_copy, one 16-byte "
+                                                             "element per thread, read + written bytes / mean of 10 launches); the gather runs "
+                                                             "above it because part of X lives in the 256 MiB Infinity Cache")
+        except Exception as exc:
+            out["roofline"]["measured_copy_ceiling_GBps"] = None
+            out["roofline"]["measured_copy_ceiling_note"] = f"not measured: {type(exc).__name__}: {exc}"[:200]
         if not args.no_cpu_baseline:
-            out["cpu_baseline"], ref = cpu_baseline(ia, ja, x, w, dz, F, args.cpu_sample_rows)
+            out["cpu_baseline"], ref = cpu_baseline(ia, ja, x, w, dz, F, args.cpu_sample_rows, args.cpu_runs)
             out["parity"] = parity_single(ref, P, Z, dW, dX, dz)
             ok = out["parity"]["ok"]
         else:
             out["parity"] = None
     else:
-        out["parity"] = parity_sharded(shard_step, shard, seeds, dev) if not shard_step.transform_first else None
+        with phase("parity of every rank against the oracle", factor=3.0):
+            out["parity"] = parity_sharded(shard_step, shard, seeds, dev) if not shard_step.transform_first else None
         ok = out["parity"] is None or out["parity"]["ok"]
-        out["breakdown"] = adist.measure_breakdown(shard_step)
+        with phase("breakdown (each part timed alone)", factor=2.0):
+            out["breakdown"] = adist.measure_breakdown(shard_step)
         out["breakdown"]["note"] = ("each part timed alone after the timed loop, rank 0 (events); in the step the exchanges "
                                     "run under the interior launches")
         if out["breakdown"].get("dw_ms"):
@@ -440,11 +559,18 @@ def main():
         err = transport_error(str(info.get("transport", "")), one_device)
         if err:
             out["ok"], out["error"], ok = False, err, False
+    if world == 1 and not args.no_secondary and not args.custom and args.config == "c2":
+        # free the headline's tensors first: configs[3] keeps 33 GB of S and configs[4] holds 50 GB in the children
+        P = Z = dW = dX = xd = dzd = g = None
+        torch.cuda.empty_cache()
+        out["secondary"] = run_secondary([k.strip() for k in args.secondary.split(",") if k.strip()])
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
-        dist.barrier()
+        with phase("final barrier"):
+            dist.barrier()
+        watch.close()
         adist.c_comm_destroy()
         dist.destroy_process_group()
     if not ok:

@@ -204,6 +204,10 @@ int athena_mp_pull_gemm(const athena_mp_graph *g, int32_t Fi, int32_t Fo, const 
 int athena_mp_activation_fwd(int32_t act, int64_t n, const float *z_dev, float *y_dev);
 int athena_mp_activation_bwd(int32_t act, int64_t n, const float *y_dev, const float *g_dev, float *dz_dev);
 int athena_mp_axpy(int64_t n, float alpha, const float *x_dev, float *y_dev); /* y += alpha x */
+/* dst = src on the device, one 16-byte element per thread in launch order (stream-ordered; 16-byte aligned pointers): the
+ * copy form that reaches the HBM's streaming ceiling -- bench.py times it on 1 GiB and prints the rate beside the roofline
+ * as the measured ceiling of the box it ran on (SURVEY.md 8d "report the measured stream ceiling alongside") */
+int athena_mp_device_copy(void *dst_dev, const void *src_dev, uint64_t bytes);
 
 /* ---- Duvenaud ------------------------------------------------------------ */
 /* duvenaud_propagate, athena_diffstruc_extd_sub_duvenaud.f90:7-59

@@ -1,0 +1,270 @@
+#!/usr/bin/env python3
+"""The secondary BASELINE configurations as ONE json object each, for bench.py's `secondary` block (N = 1 only):
+
+    python scripts/bench_secondary.py --config c3     configs[2]: Duvenaud, 130 k QM9-shaped graphs, F_v = 64, F_e = 8
+    python scripts/bench_secondary.py --config c4     configs[3]: GNO layer step on a 2 M-point radius mesh, 64 features
+    python scripts/bench_secondary.py --config c5     configs[4] on ONE GPU: Kipf 10 M / 150 M / 256 (the 8-GPU config's
+                                                      whole graph on one device: 50 GB of resident tensors)
+
+Each prints {"config", "workload", "step_ms", "ops": {name: {"ms", "bound", "frac", ...}}, "parity": {"ok", ...}}:
+per-op times from HIP events (median of --reps launches after one warm-up), the roofline fraction of every op against
+the bound SURVEY.md 8d names for it (HBM 8 TB/s on algorithmic bytes; fp32 MFMA 157.3 TFLOP/s for the GNO contractions),
+and a parity flag of the SAME device results against the CPU oracle on a sample (block-diagonal batches: the first
+graphs are an exact sub-problem; meshes and the random graph: sampled rows / columns as compact sub-problems).
+bench.py runs this as a CHILD process after its timed loop, so that a failure here is `secondary.error` in the line and
+never touches the headline value or the exit code.  The oracle is the checker here, never the thing measured."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+from athena_amd import DeviceGraph, _capi, ops, synth
+
+HBM, MFMA = 8000.0, 157.3
+TOL = 1e-5
+
+
+def timeit(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+        s.record(); fn(); e.record()
+        torch.cuda.synchronize()
+        ts.append(s.elapsed_time(e))
+    return float(np.median(ts))
+
+
+def rel(a, b):
+    b = np.asarray(b, np.float64)
+    return float(np.abs(np.asarray(a, np.float64) - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def hbm_op(ms, nbytes, note=None):
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    out = {"ms": round(ms, 4), "bound": "hbm", "GBps": round(gbs, 1), "frac": round(gbs / HBM, 3), "bytes": int(nbytes)}
+    if note:
+        out["bytes_model"] = note
+    return out
+
+
+def mfma_op(ms, flops):
+    tf = flops / (ms * 1e-3) / 1e12
+    return {"ms": round(ms, 3), "bound": "mfma", "TFLOPs": round(tf, 1), "frac": round(tf / MFMA, 3), "TFLOP": round(flops / 1e12, 3)}
+
+
+def run_c3(dev, reps):
+    """one Duvenaud time step as the layer mirror runs it (update_message_duvenaud + update_readout_duvenaud,
+    athena_duvenaud_msgpass_layer.f90:755-859, and its reverse pass): 7 launches"""
+    from oracle import oracle as o
+
+    S = 130_000
+    ia, ja, voff, E = synth.molecule_batch(S)
+    N, nnz = ia.size - 1, ja.shape[1]
+    Fv, Fe, O, mn, mx = 64, 8, 10, 1, 10
+    Fc, D = Fv + Fe, 10
+    rng = np.random.default_rng(0)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    g = DeviceGraph(ia, ja, n_edge_cols=E)
+    x, e = T(rng.random((N, Fv), np.float32)), T(rng.random((E, Fe), np.float32))
+    W = T(rng.standard_normal(Fv * Fc * D).astype(np.float32) * 0.1)
+    R = T(rng.standard_normal(O * Fv).astype(np.float32) * 0.1)
+    seg = T(voff)
+    gout = T(rng.standard_normal((S, O)).astype(np.float32))
+    a_ = ops.duvenaud_propagate(g, x, e)
+    z, p = ops.duvenaud_update_act_readout(g, a_, W, mn, mx, Fv, R, O, act="sigmoid")
+    out = ops.segment_sum(p, seg)
+    dc, dR = ops.duvenaud_readout_bwd(R, z, p, seg, gout, act="sigmoid")
+    da, dW = ops.duvenaud_update_bwd(g, dc, a_, W, mn, mx)
+    dx = ops.duvenaud_propagate_bwd_x(g, da, Fv)
+    de = ops.duvenaud_propagate_bwd_e(g, da, Fv)
+    t = {"propagate": timeit(lambda: ops.duvenaud_propagate(g, x, e, out=a_), reps),
+         "update_sigmoid_readout_p(fused)": timeit(lambda: ops.duvenaud_update_act_readout(g, a_, W, mn, mx, Fv, R, O, act="sigmoid"), reps),
+         "segment_sum": timeit(lambda: ops.segment_sum(p, seg), reps),
+         "readout_bwd": timeit(lambda: ops.duvenaud_readout_bwd(R, z, p, seg, gout, act="sigmoid"), reps),
+         "update_bwd_fused(w+a)": timeit(lambda: ops.duvenaud_update_bwd(g, dc, a_, W, mn, mx), reps),
+         "propagate_bwd_x": timeit(lambda: ops.duvenaud_propagate_bwd_x(g, da, Fv), reps),
+         "propagate_bwd_e": timeit(lambda: ops.duvenaud_propagate_bwd_e(g, da, Fv), reps)}
+    # a batch of ~18-vertex molecules is block-diagonal: a vertex's neighbours sit in the cache lines next to its own, so the
+    # two gathers are priced on COMPULSORY bytes (every tensor once, indices included), the streaming ops on their tensors
+    comp = {"propagate": N * 4 * Fv + E * 4 * Fe + nnz * 8 + N * 4 + N * 4 * Fc,
+            "update_sigmoid_readout_p(fused)": N * 4 * (Fc + Fv + O), "segment_sum": N * 4 * O + S * 4 * O,
+            "readout_bwd": N * 4 * (2 * Fv + O + 1) + S * 4 * O, "update_bwd_fused(w+a)": N * 4 * (2 * Fc + Fv),
+            "propagate_bwd_x": N * 4 * Fc + nnz * 4 + N * 4 + N * 4 * Fv, "propagate_bwd_e": N * 4 * Fe + nnz * 8 + E * 4 * Fe}
+    opsd = {k: hbm_op(t[k], comp[k], "compulsory" if k.startswith("propagate") else "tensors read + written once") for k in t}
+    # parity: the first 2 000 graphs are an exact sub-problem of every op (dW / dR sum over all vertices: a float64 device sum)
+    NG = 2000
+    nv = int(voff[NG]); ias = ia[:nv + 1]; jas = np.asfortranarray(ja[:, :ia[nv] - 1]); ne = int(jas[1].max())
+    Wh, Rh = W.cpu().numpy(), R.cpu().numpy()
+    a_h = o.duvenaud_propagate(x[:nv].cpu().numpy(), e[:ne].cpu().numpy(), ias, jas)
+    z_h = o.activation("sigmoid", o.duvenaud_update(a_h, Wh, ias, mn, mx, Fv))
+    p_h = o.softmax_cols(o.matmul(Rh, z_h, O))
+    out_h = o.segment_sum(p_h, voff[:NG + 1])
+    dl_h = o.softmax_cols_bwd(p_h, np.repeat(gout[:NG].cpu().numpy(), np.diff(voff[:NG + 1]), axis=0))
+    dc_h = o.activation_bwd("sigmoid", z_h, o.matmul_dx(Rh, dl_h, Fv))
+    da_h = o.duvenaud_update_bwd_a(dc_h, Wh, ias, mn, mx, Fc)
+    dx_h = o.duvenaud_propagate_bwd_x(da_h, Fv, ias, jas)
+    de_h = o.duvenaud_propagate_bwd_e(da_h, Fv, ne, ias, jas)
+    eids = np.unique(jas[1][jas[1] > 0]).astype(np.int64) - 1
+    par = {"against": f"oracle on the first {NG} graphs ({nv} vertices) of the same batch",
+           "propagate_bit_exact": bool(np.array_equal(a_[:nv].cpu().numpy(), a_h)),
+           "z_rel": rel(z[:nv].cpu().numpy(), z_h), "readout_rel": rel(out[:NG].cpu().numpy(), out_h),
+           "dc_rel": rel(dc[:nv].cpu().numpy(), dc_h), "da_rel": rel(da[:nv].cpu().numpy(), da_h),
+           "dx_rel": rel(dx[:nv].cpu().numpy(), dx_h), "de_rel": rel(de[torch.from_numpy(eids).to(dev)].cpu().numpy(), de_h[eids]), "tol": TOL}
+    par["ok"] = bool(par["propagate_bit_exact"] and all(par[k] <= TOL for k in ("z_rel", "readout_rel", "dc_rel", "da_rel", "dx_rel", "de_rel")))
+    step = sum(t.values())
+    return {"config": "configs[2]", "workload": f"Duvenaud msgpass, {S} QM9-shaped graphs = {N} vertices / {nnz} entries, F_v = {Fv}, F_e = {Fe}, "
+            f"{O} outputs, one time step + readout, fwd+bwd", "step_ms": round(step, 4), "entries_per_s": nnz / step * 1e3, "ops": opsd, "parity": par}
+
+
+def run_c4(dev, reps):
+    """graph_nop_layer's aggregation, training mode (S kept): forward, reverse to x, reverse to theta"""
+    from oracle import oracle as o
+
+    N = 2_000_000
+    ia, ja, coords = synth.radius_graph(N)
+    nnz, E = ja.shape[1], coords.shape[0]
+    Fi = Fo = H = 64; d = 3
+    rng = np.random.default_rng(0)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    g = DeviceGraph(ia, ja, n_edge_cols=E)
+    x, co = T(rng.uniform(-1, 1, (N, Fi)).astype(np.float32)), T(coords)
+    theta = T((0.3 * rng.standard_normal(H * d + H + Fo * Fi * H + Fo * Fi)).astype(np.float32))
+    gup = T(rng.uniform(-1, 1, (N, Fo)).astype(np.float32))
+    keep = [None]
+
+    def fwd_save():
+        m, keep[0] = ops.gno_aggregate_save(g, theta, co, x, d, H, Fo, s_save=keep[0])
+        return m
+
+    t = {"fwd_inference": timeit(lambda: ops.gno_aggregate(g, theta, co, x, d, H, Fo), reps),
+         "fwd_keeps_S": timeit(fwd_save, reps),
+         "bwd_x": timeit(lambda: ops.gno_aggregate_bwd_x(g, theta, co, gup, d, H, Fi), reps),
+         "bwd_theta_S_kept": timeit(lambda: ops.gno_aggregate_bwd_theta(g, theta, co, x, gup, d, H, s_save=keep[0]), reps)}
+    R = (H + 1) * Fi
+    f_fwd = nnz * 2 * H * (Fi + d) + N * 2 * Fo * R
+    flops = {"fwd_inference": f_fwd, "fwd_keeps_S": f_fwd, "bwd_x": nnz * 2 * H * (Fo + d) + N * 2 * Fi * (H + 1) * Fo,
+             "bwd_theta_S_kept": N * 2 * Fo * R + N * 2 * Fo * H * Fi + nnz * 2 * H * (Fi + d + 1)}
+    opsd = {k: mfma_op(t[k], flops[k]) for k in t}
+    s_bytes = ops.gno_saved_bytes(g, d, H, Fi, Fo)
+    alg_fwd = nnz * (4 * Fi + 4 * d + 8) + N * (4 * Fo + 4)
+    opsd["fwd_keeps_S"]["hbm"] = hbm_op(t["fwd_keeps_S"], alg_fwd + s_bytes, "algorithmic + the S it writes")
+    # parity: 300 sampled rows of m and 300 sampled columns of dx against the MATERIALISING oracle (kappa only for the edge
+    # columns they touch); d theta by the adjoint identity <m, g> = <Vaug, dVaug> (a global sum: the oracle is infeasible)
+    m = fwd_save()
+    th = theta.cpu().numpy()
+    rows = np.sort(rng.choice(N, 300, replace=False))
+    ent = np.concatenate([np.arange(ia[r] - 1, ia[r + 1] - 1) for r in rows])
+    ecols, einv = np.unique(ja[1, ent], return_inverse=True)
+    ncols, cinv = np.unique(ja[0, ent], return_inverse=True)
+    sia = np.concatenate([[1], 1 + np.cumsum(ia[rows + 1] - ia[rows])]).astype(np.int32)
+    sja = np.zeros((2, ent.size), np.int32, order="F"); sja[0] = cinv + 1; sja[1] = einv + 1
+    kap = o.gno_kernel_eval(coords[ecols - 1], th, H, Fo * Fi)
+    nsq = max(rows.size, ncols.size)
+    xs = np.zeros((nsq, Fi), np.float32); xs[:ncols.size] = x[torch.from_numpy(ncols - 1).to(dev)].cpu().numpy()
+    sia_sq = np.concatenate([sia, np.full(nsq - rows.size, sia[-1], np.int32)])
+    m_ref = o.gno_aggregate(xs, kap, sia_sq, sja, Fo)[:rows.size]
+    par = {"against": "materialising oracle on 300 sampled rows (m) and 300 sampled columns (dx); dtheta: adjoint identity",
+           "m_rel": rel(m[torch.from_numpy(rows).to(dev)].cpu().numpy(), m_ref), "tol": TOL}
+    dx = ops.gno_aggregate_bwd_x(g, theta, co, gup, d, H, Fi)
+    csel = np.sort(rng.choice(N, 300, replace=False))
+    lut = np.full(N, -1, np.int64); lut[csel] = np.arange(csel.size)
+    hit = np.nonzero(lut[ja[0].astype(np.int64) - 1] >= 0)[0]
+    src_rows = np.searchsorted(ia, hit + 1, side="right") - 1          # row of every entry that points at a chosen column
+    src, sinv = np.unique(src_rows, return_inverse=True)
+    order = np.argsort(sinv, kind="stable")
+    cia = np.concatenate([[1], 1 + np.cumsum(np.bincount(sinv, minlength=src.size))]).astype(np.int32)
+    ecols_c, einv_c = np.unique(ja[1, hit], return_inverse=True)
+    cja = np.zeros((2, hit.size), np.int32, order="F")
+    cja[0] = lut[ja[0, hit[order]].astype(np.int64) - 1] + 1; cja[1] = einv_c[order] + 1
+    kap_c = o.gno_kernel_eval(coords[ecols_c - 1], th, H, Fo * Fi)
+    nsq = max(src.size, csel.size)
+    cia_sq = np.concatenate([cia, np.full(nsq - src.size, cia[-1], np.int32)])
+    g_sq = np.zeros((nsq, Fo), np.float32); g_sq[:src.size] = gup[torch.from_numpy(src).to(dev)].cpu().numpy()
+    dx_ref = o.gno_aggregate_bwd_x(g_sq, kap_c, cia_sq, cja, Fi)[:csel.size]
+    par["dx_rel"] = rel(dx[torch.from_numpy(csel).to(dev)].cpu().numpy(), dx_ref)
+    dth = ops.gno_aggregate_bwd_theta(g, theta, co, x, gup, d, H, s_save=keep[0])
+    offV = H * d + H
+    lhs = (m.double() * gup.double()).sum().item()
+    scale = (m.double().abs() * gup.double().abs()).sum().item()
+    par["dtheta_adjoint_rel"] = abs(lhs - (theta[offV:].double() * dth[offV:].double()).sum().item()) / scale
+    par["ok"] = bool(par["m_rel"] <= TOL and par["dx_rel"] <= TOL and par["dtheta_adjoint_rel"] <= TOL and torch.isfinite(dth).all().item())
+    step = t["fwd_keeps_S"] + t["bwd_x"] + t["bwd_theta_S_kept"]
+    return {"config": "configs[3]", "workload": f"GNO aggregation, radius mesh {N} vertices / {nnz} entries / {E} edge columns, F_in = F_out = H = 64, d = 3, "
+            "training step = forward (keeps S) + reverse to x + reverse to theta", "step_ms": round(step, 3), "entries_per_s": nnz / step * 1e3,
+            "s_kept_GB": round(s_bytes / 1e9, 2), "ops": opsd, "parity": par}
+
+
+def run_c5(dev, reps):
+    """BASELINE configs[4]'s whole graph on ONE GPU (the 8-GPU run is the driver's): the headline's step at 10 M / 150 M / 256"""
+    from oracle import oracle as o
+
+    N, pairs, F = 10_000_000, 70_000_000, 256
+    ia, ja = synth.random_graph_csr(N, pairs)
+    nnz = ja.shape[1]
+    g = DeviceGraph(ia, ja, n_edge_cols=0)
+    gen = torch.Generator(device=dev).manual_seed(1)
+    x = torch.rand((N, F), device=dev, generator=gen).mul_(2.0).sub_(1.0)
+    dz = torch.rand((N, F), device=dev, generator=gen).mul_(2.0).sub_(1.0)
+    w_h = synth.kipf_weight(F)
+    w = torch.from_numpy(w_h).to(dev)
+    P = torch.empty((N, F), device=dev); Z = torch.empty((N, F), device=dev); dX = torch.empty((N, F), device=dev)
+    dW = torch.empty(F * F, device=dev)
+    t = {"fwd (kipf_propagate + matmul, fused)": timeit(lambda: ops.kipf_layer_fwd(g, x, w, F, P=P, Z=Z), reps),
+         "dW = dZ . P^T": timeit(lambda: ops.matmul_dw(P, dz, out=dW), reps),
+         "dX = (A^T dZ) W (fused pull)": timeit(lambda: ops.kipf_layer_bwd_x(g, dz, w, F, out=dX), reps)}
+    names = list(t)
+    agg = nnz * (4 * F + 8) + N * (4 * F + 8)
+    opsd = {names[0]: hbm_op(t[names[0]], agg + N * 4 * F, "SURVEY.md 8d per-entry model + the Z rows written"),
+            names[1]: mfma_op(t[names[1]], 2.0 * N * F * F),
+            names[2]: hbm_op(t[names[2]], nnz * (4 * F + 4) + N * (4 * F + 4), "SURVEY.md 8d per-entry model (pull over the transposed CSR)")}
+    rng = np.random.default_rng(3)
+    rows = np.sort(rng.choice(N, 4000, replace=False))
+    deg = np.diff(ia).astype(np.int32)
+    ent = np.concatenate([np.arange(ia[r] - 1, ia[r + 1] - 1) for r in rows])
+    cols, inv = np.unique(ja[0, ent].astype(np.int64) - 1, return_inverse=True)
+    sia = np.concatenate([[1], 1 + np.cumsum(ia[rows + 1] - ia[rows])]).astype(np.int32)
+    sja = np.zeros((2, ent.size), np.int32, order="F"); sja[0] = inv + 1
+    rsel = torch.from_numpy(rows).to(dev)
+    xc = x[torch.from_numpy(cols).to(dev)].cpu().numpy()
+    p_ref = o.kipf_propagate_rect(xc, sia, sja, deg[rows], deg[cols])
+    par = {"against": "oracle on 4 000 sampled rows (compact sub-problems); dW against float64 on the device",
+           "P_bit_exact": bool(np.array_equal(P[rsel].cpu().numpy(), p_ref)), "Z_rel": rel(Z[rsel].cpu().numpy(), o.matmul(w_h, p_ref, F)), "tol": TOL}
+    # the reverse pull of the sampled rows: the graph is symmetric as a multiset, so column v's sources are row v's neighbours
+    dzc = dz[torch.from_numpy(cols).to(dev)].cpu().numpy()
+    ones = np.ones(max(rows.size, cols.size), np.int32)
+    dx_ref = o.kipf_propagate_rect(o.matmul_dx(w_h, dzc, F), sia, sja, ones[:rows.size], ones[:cols.size])
+    par["dX_rel"] = rel(dX[rsel].cpu().numpy(), dx_ref)
+    d64 = torch.zeros((F, F), device=dev, dtype=torch.float64)
+    for r0 in range(0, N, 1 << 20):
+        d64 += P[r0:r0 + (1 << 20)].double().T @ dz[r0:r0 + (1 << 20)].double()
+    par["dW_rel_vs_float64"] = float((dW.double() - d64.reshape(-1)).abs().max().item() / d64.abs().max().item())
+    par["ok"] = bool(par["P_bit_exact"] and max(par["Z_rel"], par["dX_rel"], par["dW_rel_vs_float64"]) <= TOL)
+    step = sum(t.values())
+    return {"config": "configs[4] on one GPU", "workload": f"Kipf GCN layer fwd+bwd, random graph {N} vertices / {nnz} entries, {F} features, fp32, ONE GPU "
+            "(the 8-way partition is the driver's multi-GPU run)", "step_ms": round(step, 3), "entries_per_s": nnz / step * 1e3, "ops": opsd, "parity": par}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", choices=["c3", "c4", "c5"], required=True)
+    ap.add_argument("--reps", type=int, default=5)
+    a = ap.parse_args()
+    _capi.init(0)
+    dev = torch.device("cuda:0")
+    t0 = time.perf_counter()
+    res = {"c3": run_c3, "c4": run_c4, "c5": run_c5}[a.config](dev, a.reps)
+    res["wall_s"] = round(time.perf_counter() - t0, 1)
+    print(json.dumps(res), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -765,3 +765,27 @@ def test_c4_mesh_cut_eight_ways_by_shard_create_edges(dev, tmp_path):
         assert res[r]["n_int"] > res[r]["n"] // 2 and 0 < res[r]["n_halo"] < res[r]["n"] // 4, res[r]
     c = res[check_rank]
     assert c["m_rel"] <= 1e-5 and c["dx_rel"] <= 1e-5 and c["dtheta_kept_equals_rebuilt"], c
+
+
+@pytest.mark.parametrize("where,phase", [("halo", "first halo exchange"), ("setup", "communicator creation")])
+def test_bench_py_fails_fast_when_a_rank_stalls(dev, where, phase):
+    """no RCCL collective has a completion deadline of its own; bench.py's per-rank watchdog (athena_amd.dist.Watchdog) does:
+    rank 1 is put to sleep on purpose before its first halo exchange (or before the communicator is built), and the launch
+    ends within the deadline with {"ok": false, "error": "rank 0 stalled in <phase> ..."} and a non-zero exit code instead
+    of hanging until the driver's limit"""
+    import json
+    import subprocess
+    import time
+
+    env = dict(os.environ, ATHENA_MP_BENCH_ONE_DEVICE="1", ATHENA_MP_BENCH_BACKEND="gloo", ATHENA_MP_COLLECTIVE_TIMEOUT_S="6",
+               ATHENA_MP_BENCH_STALL=f"1:{where}")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--nodes", "20000", "--pairs", "90000"], env=env, capture_output=True, text=True, timeout=600)
+    took = time.time() - t0
+    assert r.returncode != 0, r.stdout[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert lines and lines[-1]["ok"] is False, (r.stdout[-1500:], r.stderr[-1500:])
+    assert "rank 0 stalled in" in lines[-1]["error"] and phase in lines[-1]["error"], lines[-1]
+    assert took < 240, took
