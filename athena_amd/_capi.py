@@ -96,6 +96,7 @@ _PROTOS = {
     "athena_mp_gno_aggregate_fwd": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "athena_mp_gno_aggregate_bwd_x": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "athena_mp_gno_aggregate_bwd_x_pull": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
+    "athena_mp_gno_aggregate_bwd": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i32)],
     "athena_mp_gno_aggregate_bwd_theta": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
     "athena_mp_gno_aggregate_bwd_coords": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
     "athena_mp_gno_saved_bytes": [_vp, _i32, _i32, _i32, _i32, C.POINTER(C.c_int64)],

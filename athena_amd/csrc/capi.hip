@@ -25,7 +25,7 @@ struct NamedBuf {
     void *p = nullptr;
     size_t bytes = 0;
 };
-constexpr int kWsSlots = 12;
+constexpr int kWsSlots = 16;
 struct DevCtx {
     void *ws[kWsSlots] = {};
     size_t ws_bytes[kWsSlots] = {};
@@ -290,6 +290,7 @@ static int graph_free(athena_mp_graph *g)
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (g->bucket_perm) (void)hipFree(g->bucket_perm);
+    if (g->t_entry) (void)hipFree(g->t_entry);
     for (int32_t *lp : {g->len_perm_fwd, g->len_perm_bwd})
         if (lp) {
             amp::gno_forget_perm(lp);

@@ -110,6 +110,8 @@ struct athena_mp_graph {
     mutable int32_t n_long_fwd = 0;              // rows of the forward CSR with more than 32 entries (the first slots of len_perm_fwd)
     mutable int32_t n_mid_fwd = 0;               // ... with more than 16 entries (n_long_fwd included)
     mutable int32_t *len_perm_bwd = nullptr;     // [n_cols] device, transposed CSR
+    // forward entry of every transposed entry (-1: no edge column), built on first use by athena_mp_gno_aggregate_bwd
+    mutable int32_t *t_entry = nullptr;          // [nnz] device
     // the same runs cut into 16-vertex tiles (one MFMA column block each), bucket-major
     mutable int32_t n_btiles = 0;
     mutable int32_t *btile_start = nullptr;      // [n_btiles] device: first index into bucket_perm

@@ -1885,6 +1885,7 @@ bool gno_args_ok(const athena_mp_graph *g, int d, int H, int Fi, int Fo)
 //               operand IS the masked accumulator (register r of lane group g = entry 4 g + r).
 // The few rows longer than 32 entries (they head the length-ordered vertex list) stay with gno_gdh_kernel.
 constexpr int kDhLdsFloats = 2 * kPV * kPPitch;
+constexpr int kDhCStrip = 2 * 4 * kGF;   // PX: per sparse wave, two tiles' worth of its vertices' b_v^T g rows (4 x 64 floats each)
 
 // Vd[pc'][w][mt][sg][lane][i] = Vmat[kq][o]: pc' = 4 kh + c; block (w, mt) = hidden units 4 (2 w + mt / 4) .. +3 x
 // features 4 (mt % 4) .. +3 of the piece; lane (m, ok): row m = (hid m / 4, feature m % 4), o = 16 sg + 4 ok + i
@@ -1905,14 +1906,25 @@ __device__ __forceinline__ int gno_gpos(int hidl, int chunk) { return hidl * 16 
 
 // VPW vertices of a tile per sparse wave (tile = 8 VPW vertices), NB blocks of 16 entries per row: <4, 1> for rows of at most
 // 16 entries, <2, 2> for rows of 17 .. 32 -- the register file holds 4 x 1 or 2 x 2 sets of dh accumulators, not 4 x 2
-template <bool WRITE_GH, int VPW, int NB>
+// PX (athena_mp_gno_aggregate_bwd: dx AND dtheta from ONE G = g . Vmat^T): while a piece of G_i lies in LDS the sparse waves
+// also take the feature gradient's per-entry partial from it,
+//     px[kh][w][16 c + q] = sum_{k in the kh's 32 hidden units} h_e[k] G_i[k][16 c + q]   (+ (b_v^T g_i)[16 c + q] at kh = 0),
+// i.e. entry w = (i -> j, e)'s contribution to dx_j = sum K_e^T g_i (athena_diffstruc_extd_sub_nop.f90:419-458) -- eight
+// more 16x16x4 MFMAs per 16 entries and piece (K = hidden units; A = G^T read from LDS one word per lane, B = h^T from an
+// h MFMA with its operands swapped, whose result registers ARE the B operand: register r of lane (entry n, g) is hidden
+// unit pi(4 g + r), pi chosen so that the A reads of a half wave fall on 32 different banks).  The partials go to HBM
+// ([2][nnz][64], stored through one buffer descriptor per vertex: lanes beyond the row's length fall outside it and are
+// dropped by the bounds check, so the store is unconditional) and gno_px_gather_kernel sums them over the transposed CSR:
+// the second 1.07 TFLOP contraction of the reverse pass (T . B2 in the dx launch) is gone.
+template <bool WRITE_GH, int VPW, int NB, bool PX = false>
 __global__ __launch_bounds__(kPcThreads) void gno_dh_pc_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ idx,
                                                          const int32_t *__restrict__ eidx, const float *__restrict__ y,
                                                          const float *__restrict__ coords, const float *__restrict__ theta,
                                                          int d, const float *__restrict__ Vd, const float *__restrict__ grad,
                                                          int n_rows, const int32_t *__restrict__ perm, float *__restrict__ slabs,
                                                          float *__restrict__ ghbuf, uint32_t y_bytes, uint32_t c_bytes,
-                                                         uint32_t id_bytes, uint32_t g_bytes)
+                                                         uint32_t id_bytes, uint32_t g_bytes, float *__restrict__ px = nullptr,
+                                                         size_t px_half = 0, const float *__restrict__ cvec = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) float Sh[];
     constexpr int TV = 8 * VPW, NG = VPW / 2;          // vertices per tile, groups of 16 of them
@@ -2017,12 +2029,30 @@ __global__ __launch_bounds__(kPcThreads) void gno_dh_pc_kernel(const int32_t *__
             xload(vi, 0);
         }
         const v4f_g z = {0.0f, 0.0f, 0.0f, 0.0f};
+        // PX: pi(m) = (m & ~3) | ((m & 3) ^ ((m >> 2) & 1)) -- lane (n, g) of the swapped h MFMA carries [U ; b_u] of hidden
+        // unit pi(n); its result register r is then hidden unit pi(4 g + r), whose parity alternates with g: the four
+        // G rows a half wave reads per step lie in both halves of the 32 banks
+        const int pi_src = 16 * g + ((n & ~3) | ((n & 3) ^ ((n >> 2) & 1)));
+        int gq_off[4];            // word offset of G[hid pi(4 g + r)][feature n] inside a vertex's row of the piece
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gq_off[r] = gno_gpos(4 * g + (r ^ (g & 1)), n >> 2) + (n & 3);
         v4f_g dacc[VPW][NB][2];   // [vertex][block][16 hidden units]: dh^T[entry 4 g + r][hid n], summed over the four c of a kh
         v4f_g accU[4] = {z, z, z, z};   // [16 hidden units]: lane (coordinate n, g): [dU | db_u][hid 4 g + r][n]
 #pragma unroll
         for (int vi = 0; vi < VPW; ++vi)
 #pragma unroll
             for (int b = 0; b < NB; ++b) dacc[vi][b][0] = dacc[vi][b][1] = z;
+        // PX: c = b_v^T g of the wave's vertices, laid out by SLOT of the length-ordered list (cvec[slot][64]): a tile's
+        // VPW rows are one contiguous KB -- one 16-byte load per lane per tile, fetched a tile ahead, parked in a private
+        // LDS strip (no load sits in front of the partial MFMAs: a load there would make their wait drain every prefetch)
+        float *cstrip = Sh + kDhLdsFloats + p * kDhCStrip;
+        __amdgpu_buffer_rsrc_t cvrs = __builtin_amdgcn_make_buffer_rsrc((void *)cvec, 0, PX ? n_rows * (4 * kGF) : 0, 0x00020000);
+        v4f_g cnext = z;
+        if constexpr (PX) {
+            const uint32_t o = ((uint32_t)blockIdx.x * TV + VPW * p) * (4u * kGF) + 16u * lane;
+            const v4f_g c0 = __builtin_bit_cast(v4f_g, __builtin_amdgcn_raw_buffer_load_b128(cvrs, (int)o, 0, 0));
+            *reinterpret_cast<v4f_g *>(cstrip + 4 * lane) = c0;
+        }
         __syncthreads();
         for (int ti = 0; ti < nt; ++ti) {
             const int tile = blockIdx.x + ti * gridDim.x;
@@ -2039,6 +2069,16 @@ __global__ __launch_bounds__(kPcThreads) void gno_dh_pc_kernel(const int32_t *__
                 }
                 const bool last = pcp == 7;
                 const float ub0 = kh ? P.Ub[2] : P.Ub[0], ub1 = kh ? P.Ub[3] : P.Ub[1];
+                float ubp0 = 0.0f, ubp1 = 0.0f;
+                if constexpr (PX) {
+                    ubp0 = __shfl(ub0, pi_src);
+                    ubp1 = __shfl(ub1, pi_src);
+                    if (pcp == 4) {   // the next tile's c rows (beyond the list: the descriptor returns 0)
+                        const uint32_t o = ((uint32_t)(tile + gridDim.x) * TV + VPW * p) * (4u * kGF) + 16u * lane;
+                        cnext = __builtin_bit_cast(v4f_g, __builtin_amdgcn_raw_buffer_load_b128(cvrs, (int)(more ? o : GnoProd::kDead), 0, 0));
+                    }
+                }
+                const float *cs = cstrip + (ti & 1) * (4 * kGF);
                 {
 #pragma unroll
                     for (int vi = 0; vi < VPW; ++vi) {
@@ -2100,12 +2140,50 @@ __global__ __launch_bounds__(kPcThreads) void gno_dh_pc_kernel(const int32_t *__
                                 dacc[vi][b][0] = dacc[vi][b][1] = z;
                             }
                         }
+                        if constexpr (PX) {
+                            // G^T of the vertex as the A operand: lane (feature n, g), step (t, r) = hidden unit 16 t + pi(4 g + r)
+                            float gq[2][4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                gq[0][r] = grow[gq_off[r]];
+                                gq[1][r] = grow[gq_off[r] + 256];
+                            }
+                            // (b_v^T g_i)[16 c + 4 g ..] rides in the kh = 0 partial as the accumulator's start value
+                            const v4f_g cq = *reinterpret_cast<const v4f_g *>(cs + vi * kGF + 16 * c + 4 * g);
+                            const v4f_g a0 = kh ? z : cq;
+                            // one descriptor per vertex: its len rows of px[kh] -- a lane beyond the row's length is out of range
+                            __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+                                (void *)(px + (size_t)kh * px_half + (size_t)cur.w0[vi] * kGF), 0, cur.len[vi] * (4 * kGF), 0x00020000);
+#pragma unroll
+                            for (int b = 0; b < NB; ++b) {
+                                const float cv = P.g_is_d ? 1.0f : cvv[vi][b];
+                                v4f_g hT0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ubp0, cv, z, 0, 0, 0);
+                                v4f_g hT1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ubp1, cv, z, 0, 0, 0);
+                                GnoProd::relu4(hT0);
+                                GnoProd::relu4(hT1);
+                                v4f_g acc = a0;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(gq[0][r], hT0[r], acc, 0, 0, 0);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(gq[1][r], hT1[r], acc, 0, 0, 0);
+                                // lane (entry n, g): acc[r] = partial of entry 16 b + n, feature 16 c + 4 g + r
+                                // (the piece's 64 c bytes ride in the VECTOR offset, the scalar offset stays an immediate 0: with a
+                                // register there the compiler's hazard recogniser assumes the store's data registers may be rewritten
+                                // at once -- on gfx950 a VALU write straight behind the store then replaced the first dword of the
+                                // last 16 lanes' data: wrong partials for entries 12 .. 15 of some rows, found with the oracle)
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_g, acc), prs,
+                                                                       (16 * b + n) * (4 * kGF) + 16 * g + 64 * c, 0, 0);
+                            }
+                        }
                         // the next piece's feature chunks (from a tile's last piece on: the next tile's)
                         if (last) derive(vi, nxt);
                         xload(vi, (c + 1) & 3);
                     }
                 }
                 if (last) cur = nxt;
+                if constexpr (PX) {
+                    if (last) *reinterpret_cast<v4f_g *>(cstrip + ((ti + 1) & 1) * (4 * kGF) + 4 * lane) = cnext;
+                }
                 __syncthreads();
             }
         }
@@ -2120,8 +2198,106 @@ __global__ __launch_bounds__(kPcThreads) void gno_dh_pc_kernel(const int32_t *__
     }
 }
 
+// ---- athena_mp_gno_aggregate_bwd: the pieces around gno_dh_pc_kernel<.., PX = true> ------------------------------------------
+// rows of more than 32 entries (they head the length-ordered list; a handful on a mesh): one workgroup per row builds
+// G_i = g_i . Vmat^T in LDS and walks the row's entries -- px[0][w] = h_e^T G_i + b_v^T g_i, px[1][w] = 0.  Plain VALU.
+__global__ __launch_bounds__(256) void gno_px_long_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ eidx,
+                                                          const float *__restrict__ coords, const float *__restrict__ theta, int d,
+                                                          const float *__restrict__ grad, int n_long, const int32_t *__restrict__ perm,
+                                                          float *__restrict__ px, size_t px_half, const float *__restrict__ cvec)
+{
+    __shared__ float G[kGH][kGF + 1];
+    __shared__ float gi[kGF], hs[4][kGH];
+    const int row = perm[blockIdx.x], t = threadIdx.x;
+    const float *V = theta + (size_t)kGH * d + kGH;
+    if (t < kGF) gi[t] = grad[(size_t)row * kGF + t];
+    __syncthreads();
+    for (int kq = t; kq < kGH * kGF; kq += 256) {            // G[k][q] = sum_o V[o + 64 q + 4096 k] g[o]
+        const float *v = V + (size_t)kq * kGF;
+        float sacc = 0.0f;
+        for (int o = 0; o < kGF; ++o) sacc = fmaf(v[o], gi[o], sacc);
+        G[kq >> 6][kq & 63] = sacc;
+    }
+    __syncthreads();
+    const int w0 = rowptr[row], len = rowptr[row + 1] - w0;
+    const int slot = t >> 6, k = t & 63;
+    for (int e0 = 0; e0 < len; e0 += 4) {
+        const int w = w0 + e0 + slot;
+        const bool in = e0 + slot < len;
+        const int e = in ? eidx[w] : -1;
+        float h = theta[(size_t)kGH * d + k];
+        if (e >= 0)
+            for (int j = 0; j < d; ++j) h = fmaf(theta[k + (size_t)kGH * j], coords[(size_t)e * d + j], h);
+        hs[slot][k] = h > 0.0f ? h : 0.0f;
+        __syncthreads();
+        if (in) {
+            float sacc = cvec[(size_t)blockIdx.x * kGF + k];   // cvec is in SLOT order (the long rows head the list); k doubles as q
+            for (int kk = 0; kk < kGH; ++kk) sacc = fmaf(hs[slot][kk], G[kk][k], sacc);
+            px[(size_t)w * kGF + k] = e >= 0 ? sacc : 0.0f;
+            px[px_half + (size_t)w * kGF + k] = 0.0f;
+        }
+        __syncthreads();
+    }
+}
+
+// where the forward entry w = (v -> u) sits in the transposed CSR: t_entry[t] = w, or -1 when the entry carries no edge
+// column (it contributes nothing, oracle: e < 0).  Deterministic: position of v in column u's ascending source list plus
+// the rank of w among the row's earlier entries with the same neighbour.  One thread per row.
+__global__ void gno_t_entry_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const int32_t *__restrict__ eid,
+                                   const int32_t *__restrict__ t_rowptr, const int32_t *__restrict__ t_src, int n_rows,
+                                   int32_t *__restrict__ t_entry)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_rows) return;
+    const int b = rowptr[v], e = rowptr[v + 1];
+    for (int w = b; w < e; ++w) {
+        const int u = col[w];
+        int lo = t_rowptr[u], hi = t_rowptr[u + 1];
+        while (lo < hi) {                                     // first t with t_src[t] >= v
+            const int mid = (lo + hi) >> 1;
+            if (t_src[mid] < v) lo = mid + 1;
+            else hi = mid;
+        }
+        int rank = 0;
+        for (int w2 = b; w2 < w; ++w2) rank += col[w2] == u;
+        t_entry[lo + rank] = eid[w] >= 0 ? w : -1;
+    }
+}
+
+// dx[u,:] = sum over the transposed row of u of px[0][w] + px[1][w] (64 floats each): 16 lanes x 16 bytes per column,
+// sources ascending (the reference's accumulation order, athena_diffstruc_extd_sub_nop.f90:441-452)
+__global__ __launch_bounds__(256) void gno_px_gather_kernel(const int32_t *__restrict__ t_rowptr, const int32_t *__restrict__ t_entry,
+                                                            const float *__restrict__ px, size_t px_half, int n_cols,
+                                                            float *__restrict__ dx)
+{
+    const int l = threadIdx.x & 15;
+    const int u = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (u >= n_cols) return;
+    const int b = t_rowptr[u], e = t_rowptr[u + 1];
+    const v4f_g z = {0.0f, 0.0f, 0.0f, 0.0f};
+    v4f_g acc = z;
+    int t = b;
+    for (; t + 1 < e; t += 2) {
+        const int wa = t_entry[t], wb = t_entry[t + 1];
+        const float *pa = px + (size_t)(wa < 0 ? 0 : wa) * kGF + 4 * l, *pb = px + (size_t)(wb < 0 ? 0 : wb) * kGF + 4 * l;
+        const v4f_g a0 = *reinterpret_cast<const v4f_g *>(pa), a1 = *reinterpret_cast<const v4f_g *>(pa + px_half);
+        const v4f_g b0 = *reinterpret_cast<const v4f_g *>(pb), b1 = *reinterpret_cast<const v4f_g *>(pb + px_half);
+        if (wa >= 0) acc = acc + (a0 + a1);
+        if (wb >= 0) acc = acc + (b0 + b1);
+    }
+    if (t < e) {
+        const int wa = t_entry[t];
+        if (wa >= 0) {
+            const float *pa = px + (size_t)wa * kGF + 4 * l;
+            acc = acc + (*reinterpret_cast<const v4f_g *>(pa) + *reinterpret_cast<const v4f_g *>(pa + px_half));
+        }
+    }
+    *reinterpret_cast<v4f_g *>(dx + (size_t)u * kGF + 4 * l) = acc;
+}
+
 int gno_mlp_backward(const athena_mp_graph *g, int d, int H, int Fi, int Fo, const float *theta,
-                     const float *coords, const float *x, const float *grad, float *dtheta, float *dcoords)
+                     const float *coords, const float *x, const float *grad, float *dtheta, float *dcoords,
+                     float *px = nullptr, size_t px_half = 0, const float *cvec = nullptr)
 {
     const size_t off_V = (size_t)H * d + H;
     const int np = H * d + H;
@@ -2141,6 +2317,10 @@ int gno_mlp_backward(const athena_mp_graph *g, int d, int H, int Fi, int Fo, con
                      id_bytes = sizeof(int32_t) * (size_t)g->nnz, g_bytes = sizeof(float) * kGF * (size_t)g->n_rows;
         const size_t lim = 0xFFFFE000ull;
         const bool pc_ok = !v1 && d <= 3 && y_bytes < lim && c_bytes < lim && id_bytes < lim && g_bytes < lim;
+        if (px && !pc_ok) {
+            amp::set_error("gno_aggregate_bwd: this size does not take the producer / consumer kernels (caller must check gno_bwd_fused_ok)");
+            return 2;
+        }
         // three classes of the length-ordered list: > 32 entries | 17 .. 32 (2 vertices per sparse wave, 2 blocks) | <= 16 (4, 1)
         const int n_old = pc_ok ? g->n_long_fwd : g->n_rows, n_mid = pc_ok ? g->n_mid_fwd - g->n_long_fwd : 0,
                   n_short = g->n_rows - n_old - n_mid;
@@ -2168,24 +2348,38 @@ int gno_mlp_backward(const athena_mp_graph *g, int d, int H, int Fi, int Fo, con
                 hipLaunchKernelGGL(gno_gdh_kernel<false>, dim3(nwg_old), dim3(1024), glds, amp::stream(), g->rowptr, g->col, g->eid, x,
                                    coords, theta, d, (const float *)vp, grad, n_old, perm, (float *)sl, ghbuf);
             AMP_LAUNCH_CHECK();
+            if (px) {   // their share of the feature gradient's partials
+                hipLaunchKernelGGL(gno_px_long_kernel, dim3(n_old), dim3(256), 0, amp::stream(), g->rowptr, g->eid, coords, theta, d, grad,
+                                   n_old, perm, px, px_half, cvec);
+                AMP_LAUNCH_CHECK();
+            }
         }
         if (n_mid + n_short > 0) {
             if (amp::workspace(&vd, sizeof(float) * 64 * 64 * 64, 9)) return 1;
             hipLaunchKernelGGL(gno_vrelay_dense_kernel, dim3(64 * 64 * 64 / 256), dim3(256), 0, amp::stream(), theta + off_V, (float *)vd);
             AMP_LAUNCH_CHECK();
-            constexpr size_t dlds = sizeof(float) * (size_t)kDhLdsFloats;
+            constexpr size_t dlds = sizeof(float) * ((size_t)kDhLdsFloats + 8 * kDhCStrip);
             static amp::PerDeviceFlag dattr;
             if (!dattr.get()) {
                 AMP_HIP(hipFuncSetAttribute((const void *)gno_dh_pc_kernel<false, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds));
                 AMP_HIP(hipFuncSetAttribute((const void *)gno_dh_pc_kernel<true, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds));
                 AMP_HIP(hipFuncSetAttribute((const void *)gno_dh_pc_kernel<false, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds));
                 AMP_HIP(hipFuncSetAttribute((const void *)gno_dh_pc_kernel<true, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds));
+                AMP_HIP(hipFuncSetAttribute((const void *)gno_dh_pc_kernel<false, 4, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds));
+                AMP_HIP(hipFuncSetAttribute((const void *)gno_dh_pc_kernel<true, 4, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds));
+                AMP_HIP(hipFuncSetAttribute((const void *)gno_dh_pc_kernel<false, 2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds));
+                AMP_HIP(hipFuncSetAttribute((const void *)gno_dh_pc_kernel<true, 2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds));
                 dattr.get() = true;
             }
-#define AMP_DHPC(GH_, VPW_, NB_, NWG_, NROWS_, PERM_, SL_)                                                                          \
-    hipLaunchKernelGGL((gno_dh_pc_kernel<GH_, VPW_, NB_>), dim3(NWG_), dim3(kPcThreads), dlds, amp::stream(), g->rowptr, g->col, g->eid, \
+#define AMP_DHPC_(GH_, VPW_, NB_, PX_, NWG_, NROWS_, PERM_, SL_)                                                                    \
+    hipLaunchKernelGGL((gno_dh_pc_kernel<GH_, VPW_, NB_, PX_>), dim3(NWG_), dim3(kPcThreads), dlds, amp::stream(), g->rowptr, g->col, g->eid, \
                        x, coords, theta, d, (const float *)vd, grad, NROWS_, PERM_, SL_, ghbuf, (uint32_t)y_bytes, (uint32_t)c_bytes, \
-                       (uint32_t)id_bytes, (uint32_t)g_bytes)
+                       (uint32_t)id_bytes, (uint32_t)g_bytes, px, px_half, cvec ? cvec + (size_t)((PERM_) - perm) * kGF : nullptr)
+#define AMP_DHPC(GH_, VPW_, NB_, NWG_, NROWS_, PERM_, SL_)                \
+    do {                                                                  \
+        if (px) AMP_DHPC_(GH_, VPW_, NB_, true, NWG_, NROWS_, PERM_, SL_); \
+        else AMP_DHPC_(GH_, VPW_, NB_, false, NWG_, NROWS_, PERM_, SL_);   \
+    } while (0)
             float *sl_mid = (float *)sl + (size_t)nwg_old * 16 * np, *sl_short = sl_mid + (size_t)nwg_mid * 8 * np;
             if (n_mid > 0) {
                 if (ghbuf) AMP_DHPC(true, 2, 2, nwg_mid, n_mid, perm + n_old, sl_mid);
@@ -2198,6 +2392,7 @@ int gno_mlp_backward(const athena_mp_graph *g, int d, int H, int Fi, int Fo, con
                 AMP_LAUNCH_CHECK();
             }
 #undef AMP_DHPC
+#undef AMP_DHPC_
         }
         const int nwg = n_slabs / 16;   // (slab_reduce below takes the slab count)
         (void)nwg;
@@ -2472,6 +2667,80 @@ int athena_mp_gno_aggregate_bwd_theta(const athena_mp_graph *g, int32_t d, int32
         }
     }
     return gno_mlp_backward(g, d, H, Fi, Fo, theta, coords, x, grad, dtheta, nullptr);
+}
+
+/* The whole reverse pass of gno_aggregate from ONE G = g . Vmat^T (athena_diffstruc_extd_sub_nop.f90:419-458 features,
+ * :235-325 kernel parameters, :137-216 coordinates): any of dx / dtheta / dcoords may be NULL.  Shapes and sizes that take
+ * the producer / consumer kernels (H = F_in = F_out = 64, d <= 3, tensors below 4 GB, at most 1 row in 64 longer than 32
+ * entries) run:  S^T g (streamed from s_save when given, rebuilt otherwise) -> dVaug;  gno_dh_pc_kernel<PX> -> dU, db_u,
+ * the per-entry partials of dx [2][nnz][64] (and the per-entry dh for dcoords);  gno_px_gather_kernel -> dx.  Everything
+ * else is the three separate entry points, one after the other.  *fused (may be NULL) says which it was. */
+int athena_mp_gno_aggregate_bwd(const athena_mp_graph *g, int32_t d, int32_t H, int32_t Fi, int32_t Fo, const float *theta,
+                                const float *coords, const float *x, const float *grad, const float *s_save, float *dx,
+                                float *dtheta, float *dcoords, int32_t *fused)
+{
+    if (!gno_args_ok(g, d, H, Fi, Fo)) return 2;
+    AMP_REQUIRE(theta && coords && x && grad, "gno_aggregate_bwd: null pointer");
+    if (fused) *fused = 0;
+    static const bool off = getenv("ATHENA_MP_GNO_BWD_UNFUSED") != nullptr;   // A/B switch for measurements
+    bool ok = !off && dx && g->n_rows > 0 && gno_gdh_shape(H, Fi, Fo, d) && gno_stg_shape(H, Fi, Fo, d) &&
+              gno_pc_route(d, g->n_cols, g->n_edge_cols, g->nnz) && sizeof(float) * kGF * (size_t)g->n_rows < 0xFFFFE000ull &&
+              sizeof(float) * kGF * (size_t)g->n_cols < 0xFFFFE000ull;
+    if (ok) {
+        if (length_order(g->rowptr, g->n_rows, &g->len_perm_fwd, &g->n_long_fwd, &g->n_mid_fwd)) return 1;
+        ok = (int64_t)g->n_long_fwd * 64 <= (int64_t)g->n_rows;   // the long rows' partials come from a plain VALU kernel
+    }
+    if (!ok) {
+        if (dtheta) {
+            const int rc = s_save ? athena_mp_gno_aggregate_bwd_theta_saved(g, d, H, Fi, Fo, theta, coords, x, grad, s_save, dtheta)
+                                  : athena_mp_gno_aggregate_bwd_theta(g, d, H, Fi, Fo, theta, coords, x, grad, dtheta);
+            if (rc) return rc;
+        }
+        if (dx)
+            if (const int rc = athena_mp_gno_aggregate_bwd_x(g, d, H, Fi, Fo, theta, coords, grad, dx)) return rc;
+        if (dcoords)
+            if (const int rc = athena_mp_gno_aggregate_bwd_coords(g, d, H, Fi, Fo, theta, coords, x, grad, dcoords)) return rc;
+        return 0;
+    }
+    const size_t off_V = (size_t)H * d + H;
+    const size_t px_half = (size_t)std::max<int64_t>(g->nnz, 1) * kGF;
+    void *pxp = nullptr, *cvp = nullptr, *dth_tmp = nullptr;
+    if (workspace(&pxp, sizeof(float) * 2 * px_half, 13)) return 1;
+    if (workspace(&cvp, sizeof(float) * kGF * (size_t)g->n_rows, 14)) return 1;
+    if (!g->t_entry && g->nnz > 0) {
+        AMP_HIP(hipMalloc((void **)&g->t_entry, sizeof(int32_t) * (size_t)g->nnz));
+        hipLaunchKernelGGL(gno_t_entry_kernel, dim3((g->n_rows + 255) / 256), dim3(256), 0, stream(), g->rowptr, g->col, g->eid,
+                           g->t_rowptr, g->t_src, g->n_rows, g->t_entry);
+        AMP_LAUNCH_CHECK();
+    }
+    // c_i = b_v^T g_i in SLOT order of the length-ordered list (a tile's rows contiguous): rows of grad gathered through
+    // the permutation, b_v viewed [q][o]
+    {
+        amp::TiledArgs ta;
+        ta.A = grad; ta.lda = Fo; ta.a_idx = g->len_perm_fwd;
+        ta.B = theta + off_V + (size_t)Fo * Fi * H; ta.ldb = Fo; ta.b_nk = 1;
+        ta.C = (float *)cvp; ta.ldc = Fi;
+        ta.M = g->n_rows; ta.N = Fi; ta.K = Fo;
+        if (int rc = amp::gemm_tiled(ta)) return rc;
+    }
+    float *dth = dtheta;
+    if (!dth) {   // dx alone still runs the fused kernel; its parameter sums go to a scratch vector
+        if (workspace(&dth_tmp, sizeof(float) * (off_V + (size_t)Fo * Fi * (H + 1)), 15)) return 1;
+        dth = (float *)dth_tmp;
+    }
+    if (dtheta) {
+        const int rc = launch_gno_stg(g, x, coords, theta, d, grad, dtheta + off_V, s_save);
+        if (rc) {
+            if (rc < 0) set_error("gno_aggregate_bwd: tensors beyond the 4 GB a buffer descriptor addresses");
+            return rc < 0 ? 2 : rc;
+        }
+    }
+    if (int rc = gno_mlp_backward(g, d, H, Fi, Fo, theta, coords, x, grad, dth, dcoords, (float *)pxp, px_half, (const float *)cvp)) return rc;
+    hipLaunchKernelGGL(gno_px_gather_kernel, dim3((g->n_cols + 15) / 16), dim3(256), 0, stream(), g->t_rowptr, g->t_entry,
+                       (const float *)pxp, px_half, g->n_cols, dx);
+    AMP_LAUNCH_CHECK();
+    if (fused) *fused = 1;
+    return 0;
 }
 
 int athena_mp_gno_aggregate_bwd_coords(const athena_mp_graph *g, int32_t d, int32_t H, int32_t Fi, int32_t Fo,

@@ -49,7 +49,7 @@ module athena_mp_c
   public :: athena_mp_comm_unique_id, athena_mp_allreduce, athena_mp_allreduce_start, athena_mp_allreduce_finish
   public :: athena_mp_shard_create, athena_mp_shard_destroy, athena_mp_shard_dims, athena_mp_shard_graph
   public :: athena_mp_shard_export, athena_mp_halo_start, athena_mp_halo_finish, athena_mp_shard_info
-  public :: athena_mp_device_copy
+  public :: athena_mp_device_copy, athena_mp_gno_aggregate_bwd
   public :: athena_mp_shard_create_edges, athena_mp_shard_edge_cols, athena_mp_gno_aggregate_bwd_x_pull
   public :: athena_mp_resident_mode, athena_mp_resident_acquire, athena_mp_resident_release, athena_mp_resident_flush
   public :: athena_mp_resident_drop, athena_mp_resident_stats
@@ -633,6 +633,15 @@ module athena_mp_c
        import :: c_int, c_int32_t, c_ptr
        type(c_ptr), value :: graph, theta_dev, coords_dev, grad_ext_dev, dx_dev
        integer(c_int32_t), value :: d, H, Fi, Fo
+     end function
+     !! the whole reverse pass of gno_aggregate from ONE G = g . Vmat^T: dx, dtheta and (on request) dcoords; any output
+     !! may be c_null_ptr; s_save_dev = the S of athena_mp_gno_aggregate_fwd_save or c_null_ptr
+     integer(c_int) function athena_mp_gno_aggregate_bwd(graph, d, H, Fi, Fo, theta_dev, coords_dev, x_dev, grad_dev, &
+          s_save_dev, dx_dev, dtheta_dev, dcoords_dev, fused) bind(C, name="athena_mp_gno_aggregate_bwd")
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: graph, theta_dev, coords_dev, x_dev, grad_dev, s_save_dev, dx_dev, dtheta_dev, dcoords_dev
+       integer(c_int32_t), value :: d, H, Fi, Fo
+       integer(c_int32_t), intent(out) :: fused
      end function
      integer(c_int) function athena_mp_gno_aggregate_bwd_theta(graph, d, H, Fi, Fo, theta_dev, coords_dev, x_dev, &
           grad_dev, dtheta_dev) bind(C, name="athena_mp_gno_aggregate_bwd_theta")

@@ -1364,9 +1364,10 @@ contains
     class(graph_nop_mp_layer_type), intent(inout) :: this
     type(c_ptr), intent(in) :: upstream_dev
     type(c_ptr), intent(out), optional :: dx_dev, dcoords_dev
-    type(c_ptr) :: dz, y
+    type(c_ptr) :: dz, y, s_arg, dx_arg, dc_arg
     real(real32), allocatable :: ones(:)
     integer :: n, fi, fo, d, h
+    integer(c_int32_t) :: fused
 
     n = this%nv
     fi = this%num_inputs
@@ -1395,30 +1396,28 @@ contains
        this%has_grad(3) = .true.
     end if
     call chk(athena_mp_gemm_dw(i8(n), int(fi, c_int32_t), int(fo, c_int32_t), this%x_tape, dz, this%grads(2)%p), "gemm_dw")
-    if(this%s_valid .and. c_associated(this%s_graph, this%graph))then
-       call chk(athena_mp_gno_aggregate_bwd_theta_saved(this%graph, int(d, c_int32_t), int(h, c_int32_t), int(fi, c_int32_t), &
-            int(fo, c_int32_t), this%params(1)%p, this%c_tape, this%x_tape, dz, this%s_save%p, this%grads(1)%p), &
-            "gno reverse (theta, S kept)")
-    else
-       call chk(athena_mp_gno_aggregate_bwd_theta(this%graph, int(d, c_int32_t), int(h, c_int32_t), int(fi, c_int32_t), &
-            int(fo, c_int32_t), this%params(1)%p, this%c_tape, this%x_tape, dz, this%grads(1)%p), "gno reverse (theta)")
-    end if
-    this%has_grad(1:2) = .true.
-    if(present(dx_dev))then
-       call chk(athena_mp_gemm_dx(i8(n), int(fi, c_int32_t), int(fo, c_int32_t), dz, this%params(2)%p, this%scratch(3)%p), "gemm_dx")
-       call chk(athena_mp_gno_aggregate_bwd_x(this%graph, int(d, c_int32_t), int(h, c_int32_t), int(fi, c_int32_t), &
-            int(fo, c_int32_t), this%params(1)%p, this%c_tape, dz, this%scratch(1)%p), "gno reverse (features)")
-       call chk(athena_mp_axpy(i8(n) * i8(fi), 1._real32, this%scratch(1)%p, this%scratch(3)%p), "axpy")
-       dx_dev = this%scratch(3)%p
-    end if
+    ! the whole reverse pass of gno_aggregate from ONE G = dz . Vmat^T (athena_mp_gno_aggregate_bwd): dtheta always, the
+    ! feature gradient and the coordinate gradient when asked for; S of the forward pass when it was kept
+    s_arg = c_null_ptr
+    if(this%s_valid .and. c_associated(this%s_graph, this%graph)) s_arg = this%s_save%p
+    dx_arg = c_null_ptr
+    if(present(dx_dev)) dx_arg = this%scratch(1)%p
+    dc_arg = c_null_ptr
     if(present(dcoords_dev))then
        dcoords_dev = c_null_ptr
        if(this%ne .gt. 0)then
           call need(this%dc_out, i8(this%ne) * i8(d))
-          call chk(athena_mp_gno_aggregate_bwd_coords(this%graph, int(d, c_int32_t), int(h, c_int32_t), int(fi, c_int32_t), &
-               int(fo, c_int32_t), this%params(1)%p, this%c_tape, this%x_tape, dz, this%dc_out%p), "gno reverse (coords)")
+          dc_arg = this%dc_out%p
           dcoords_dev = this%dc_out%p
        end if
+    end if
+    call chk(athena_mp_gno_aggregate_bwd(this%graph, int(d, c_int32_t), int(h, c_int32_t), int(fi, c_int32_t), int(fo, c_int32_t), &
+         this%params(1)%p, this%c_tape, this%x_tape, dz, s_arg, dx_arg, this%grads(1)%p, dc_arg, fused), "gno reverse pass")
+    this%has_grad(1:2) = .true.
+    if(present(dx_dev))then
+       call chk(athena_mp_gemm_dx(i8(n), int(fi, c_int32_t), int(fo, c_int32_t), dz, this%params(2)%p, this%scratch(3)%p), "gemm_dx")
+       call chk(athena_mp_axpy(i8(n) * i8(fi), 1._real32, this%scratch(1)%p, this%scratch(3)%p), "axpy")
+       dx_dev = this%scratch(3)%p
     end if
   end subroutine gno_backward_dev
 

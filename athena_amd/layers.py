@@ -545,14 +545,15 @@ class graph_nop_layer_type(msgpass_layer_type):
             ones = torch.ones((dz.shape[0], 1), device=self.device)
             self.grads[2] = ops.matmul_dw(ones, dz)          # db[o] = sum_v dz[v,o]
         self.grads[1] = ops.matmul_dw(self._x, dz)
-        self.grads[0] = ops.gno_aggregate_bwd_theta(g, self.params[0], self._coords, self._x, dz, d, H,
-                                                    s_save=self._s_save if self._s_valid else None)
-        dx = dc = None
+        # the whole reverse pass of gno_aggregate from ONE G = dz . Vmat^T (athena_mp_gno_aggregate_bwd: the kernel that
+        # holds a piece of G_i in LDS for the kernel MLP's gradient also emits every entry's partial of dx)
+        dxa, self.grads[0], dc, _ = ops.gno_aggregate_bwd(g, self.params[0], self._coords, self._x, dz, d, H,
+                                                          s_save=self._s_save if self._s_valid else None,
+                                                          need_dx=need_input_grad, need_dcoords=need_coord_grad)
+        dx = None
         if need_input_grad:
             dx = ops.matmul_dx(self.params[1], dz, Fi)
-            ops.axpy(1.0, ops.gno_aggregate_bwd_x(g, self.params[0], self._coords, dz, d, H, Fi), dx)
-        if need_coord_grad:
-            dc = ops.gno_aggregate_bwd_coords(g, self.params[0], self._coords, self._x, dz, d, H)
+            ops.axpy(1.0, dxa, dx)
         return (dx, dc) if need_coord_grad else dx
 
 

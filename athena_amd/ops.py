@@ -654,6 +654,26 @@ def gno_aggregate_bwd_theta(g: DeviceGraph, theta, coords, x, grad, d, H, s_save
     return dth
 
 
+def gno_aggregate_bwd(g: DeviceGraph, theta, coords, x, grad, d, H, s_save=None, need_dx=True, need_dtheta=True, need_dcoords=False):
+    """the whole reverse pass of gno_aggregate from ONE G = g . Vmat^T (athena_mp_gno_aggregate_bwd): returns
+    (dx, dtheta, dcoords, fused) with None for what was not asked; `fused` says whether the shape took the fused kernels"""
+    import ctypes
+    Fi, Fo = x.shape[1], grad.shape[1]
+    _chk(x, (g.n_cols, Fi)); _chk(grad, (g.n_rows, Fo)); _chk(coords, (g.n_edge_cols, d))
+    if _chk(theta).numel() != H * d + H + Fo * Fi * H + Fo * Fi:
+        raise ValueError("theta: expected H*d + H + Fo*Fi*H + Fo*Fi values")
+    if s_save is not None and _chk(s_save).numel() * 4 < gno_saved_bytes(g, d, H, Fi, Fo):
+        raise ValueError("s_save: smaller than gno_saved_bytes()")
+    dx = torch.empty((g.n_cols, Fi), device=x.device, dtype=torch.float32) if need_dx else None
+    dth = torch.empty_like(theta) if need_dtheta else None
+    dc = torch.empty_like(coords) if need_dcoords else None
+    fused = ctypes.c_int32(0)
+    _go()
+    _capi.call("athena_mp_gno_aggregate_bwd", g.handle, d, H, Fi, Fo, _p(theta), _p(coords), _p(x), _p(grad), _p(s_save), _p(dx), _p(dth),
+               _p(dc), ctypes.byref(fused))
+    return dx, dth, dc, bool(fused.value)
+
+
 def gno_aggregate_bwd_coords(g: DeviceGraph, theta, coords, x, grad, d, H):
     Fi, Fo = x.shape[1], grad.shape[1]
     _chk(x, (g.n_cols, Fi)); _chk(grad, (g.n_rows, Fo)); _chk(coords, (g.n_edge_cols, d))

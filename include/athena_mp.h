@@ -321,6 +321,19 @@ int athena_mp_gno_aggregate_bwd_theta_saved(const athena_mp_graph *g, int32_t d,
                                             const float *x_dev, const float *grad_dev,
                                             const float *s_save_dev, float *dtheta_dev);
 
+/* The whole reverse pass of gno_aggregate in ONE call, from one G = g . Vmat^T: dx (get_partial_gno_agg_features_val,
+ * athena_diffstruc_extd_sub_nop.f90:419-458), dtheta (:480-526 composed with get_partial_gno_kernel_params_val :235-325) and,
+ * on request, dcoords (:137-216).  Any of the three outputs may be NULL; s_save_dev is the S of
+ * athena_mp_gno_aggregate_fwd_save (NULL: S is rebuilt).  The separate entry points above compute G twice -- once inside
+ * the dx launch (as T . B2), once for the kernel MLP's gradient; here the kernel that holds a piece of G_i in LDS also
+ * emits every entry's partial h_e^T G_i of dx, and a gather over the transposed CSR sums them.  Shapes
+ * outside the fused kernels run the separate entry points; *fused_out (may be NULL) reports which it was.  Same values
+ * as the separate entry points to fp32 rounding (the sums associate differently). */
+int athena_mp_gno_aggregate_bwd(const athena_mp_graph *g, int32_t d, int32_t H, int32_t Fi, int32_t Fo,
+                                const float *theta_dev, const float *coords_dev, const float *x_dev,
+                                const float *grad_dev, const float *s_save_dev, float *dx_dev, float *dtheta_dev,
+                                float *dcoords_dev, int32_t *fused_out);
+
 /* ---- activations with their own shape and the 'concatenate' merge (8f-2) -----
  * swish_array / get_partial_swish_val, athena_diffstruc_extd_sub.f90:424-492: y = x/(1+exp(-beta x));
  * the reverse pass differentiates at the INPUT x */

@@ -29,6 +29,7 @@ from athena_amd import DeviceGraph, _capi, ops, synth
 
 HBM, MFMA = 8000.0, 157.3
 TOL = 1e-5
+TIMING_ONLY = False
 
 
 def timeit(fn, reps):
@@ -148,12 +149,17 @@ def run_c4(dev, reps):
     t = {"fwd_inference": timeit(lambda: ops.gno_aggregate(g, theta, co, x, d, H, Fo), reps),
          "fwd_keeps_S": timeit(fwd_save, reps),
          "bwd_x": timeit(lambda: ops.gno_aggregate_bwd_x(g, theta, co, gup, d, H, Fi), reps),
-         "bwd_theta_S_kept": timeit(lambda: ops.gno_aggregate_bwd_theta(g, theta, co, x, gup, d, H, s_save=keep[0]), reps)}
+         "bwd_theta_S_kept": timeit(lambda: ops.gno_aggregate_bwd_theta(g, theta, co, x, gup, d, H, s_save=keep[0]), reps),
+         "bwd_x+theta_one_contraction": timeit(lambda: ops.gno_aggregate_bwd(g, theta, co, x, gup, d, H, s_save=keep[0]), reps)}
     R = (H + 1) * Fi
     f_fwd = nnz * 2 * H * (Fi + d) + N * 2 * Fo * R
     flops = {"fwd_inference": f_fwd, "fwd_keeps_S": f_fwd, "bwd_x": nnz * 2 * H * (Fo + d) + N * 2 * Fi * (H + 1) * Fo,
-             "bwd_theta_S_kept": N * 2 * Fo * R + N * 2 * Fo * H * Fi + nnz * 2 * H * (Fi + d + 1)}
+             "bwd_theta_S_kept": N * 2 * Fo * R + N * 2 * Fo * H * Fi + nnz * 2 * H * (Fi + d + 1),
+             # S^T g + G = g Vmat^T + per entry: dh = G x_j, the partial h^T G of dx, the h MFMAs
+             "bwd_x+theta_one_contraction": N * 2 * Fo * R + N * 2 * Fo * H * Fi + nnz * 2 * H * (2 * Fi + 2 * (d + 1))}
     opsd = {k: mfma_op(t[k], flops[k]) for k in t}
+    if TIMING_ONLY:
+        return {"config": "configs[3]", "ops": opsd}
     s_bytes = ops.gno_saved_bytes(g, d, H, Fi, Fo)
     alg_fwd = nnz * (4 * Fi + 4 * d + 8) + N * (4 * Fo + 4)
     opsd["fwd_keeps_S"]["hbm"] = hbm_op(t["fwd_keeps_S"], alg_fwd + s_bytes, "algorithmic + the S it writes")
@@ -174,7 +180,7 @@ def run_c4(dev, reps):
     m_ref = o.gno_aggregate(xs, kap, sia_sq, sja, Fo)[:rows.size]
     par = {"against": "materialising oracle on 300 sampled rows (m) and 300 sampled columns (dx); dtheta: adjoint identity",
            "m_rel": rel(m[torch.from_numpy(rows).to(dev)].cpu().numpy(), m_ref), "tol": TOL}
-    dx = ops.gno_aggregate_bwd_x(g, theta, co, gup, d, H, Fi)
+    dx, dth, _, fused = ops.gno_aggregate_bwd(g, theta, co, x, gup, d, H, s_save=keep[0])      # what the layer's reverse pass calls
     csel = np.sort(rng.choice(N, 300, replace=False))
     lut = np.full(N, -1, np.int64); lut[csel] = np.arange(csel.size)
     hit = np.nonzero(lut[ja[0].astype(np.int64) - 1] >= 0)[0]
@@ -191,15 +197,21 @@ def run_c4(dev, reps):
     g_sq = np.zeros((nsq, Fo), np.float32); g_sq[:src.size] = gup[torch.from_numpy(src).to(dev)].cpu().numpy()
     dx_ref = o.gno_aggregate_bwd_x(g_sq, kap_c, cia_sq, cja, Fi)[:csel.size]
     par["dx_rel"] = rel(dx[torch.from_numpy(csel).to(dev)].cpu().numpy(), dx_ref)
-    dth = ops.gno_aggregate_bwd_theta(g, theta, co, x, gup, d, H, s_save=keep[0])
+    par["reverse_pass"] = "athena_mp_gno_aggregate_bwd: dx and dtheta from one G" if fused else "separate entry points"
+    dx_sep = ops.gno_aggregate_bwd_x(g, theta, co, gup, d, H, Fi)
+    par["dx_fused_vs_separate_rel"] = float((dx - dx_sep).abs().max().item() / dx_sep.abs().max().item())
+    del dx_sep
     offV = H * d + H
     lhs = (m.double() * gup.double()).sum().item()
     scale = (m.double().abs() * gup.double().abs()).sum().item()
     par["dtheta_adjoint_rel"] = abs(lhs - (theta[offV:].double() * dth[offV:].double()).sum().item()) / scale
-    par["ok"] = bool(par["m_rel"] <= TOL and par["dx_rel"] <= TOL and par["dtheta_adjoint_rel"] <= TOL and torch.isfinite(dth).all().item())
-    step = t["fwd_keeps_S"] + t["bwd_x"] + t["bwd_theta_S_kept"]
+    par["ok"] = bool(par["m_rel"] <= TOL and par["dx_rel"] <= TOL and par["dx_fused_vs_separate_rel"] <= TOL
+                     and par["dtheta_adjoint_rel"] <= TOL and torch.isfinite(dth).all().item())
+    step = t["fwd_keeps_S"] + t["bwd_x+theta_one_contraction"]
+    step_sep = t["fwd_keeps_S"] + t["bwd_x"] + t["bwd_theta_S_kept"]
     return {"config": "configs[3]", "workload": f"GNO aggregation, radius mesh {N} vertices / {nnz} entries / {E} edge columns, F_in = F_out = H = 64, d = 3, "
-            "training step = forward (keeps S) + reverse to x + reverse to theta", "step_ms": round(step, 3), "entries_per_s": nnz / step * 1e3,
+            "training step = forward (keeps S) + reverse pass (dx and dtheta from one contraction)", "step_ms": round(step, 3),
+            "step_ms_separate_reverse_launches": round(step_sep, 3), "entries_per_s": nnz / step * 1e3,
             "s_kept_GB": round(s_bytes / 1e9, 2), "ops": opsd, "parity": par}
 
 
@@ -257,7 +269,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", choices=["c3", "c4", "c5"], required=True)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--timing-only", action="store_true", help="c4: stop after the timed launches (rocprofv3 runs)")
     a = ap.parse_args()
+    global TIMING_ONLY
+    TIMING_ONLY = a.timing_only
     _capi.init(0)
     dev = torch.device("cuda:0")
     t0 = time.perf_counter()

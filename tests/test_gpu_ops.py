@@ -946,3 +946,78 @@ def test_kipf_fuzz_shapes_and_degree_distributions(dev, oracle, seed):
     assert np.array_equal(d[cdeg <= 512], do[cdeg <= 512])
     if nnz:
         assert_close(d, do, 1e-5, "bwd")
+
+
+@pytest.mark.parametrize("d,loops,N,hubs,directed", [(3, False, 2101, (150, 37), False), (2, True, 2101, (40,), False), (1, False, 203, (), False),
+                                                     (3, False, 8200, (33,), False), (3, False, 2101, (), True), (3, True, 70, (), False)])
+def test_gno_reverse_pass_from_one_contraction(dev, oracle, d, loops, N, hubs, directed):
+    """athena_mp_gno_aggregate_bwd: dx, dtheta and dcoords from ONE G = g . Vmat^T -- the kernel that holds a piece of G_i in
+    LDS also emits every entry's partial of dx ([2][nnz][64]) and a gather over the transposed CSR sums them
+    (athena_diffstruc_extd_sub_nop.f90:419-458 features, :235-325 parameters, :137-216 coordinates).  Against the
+    materialising oracle and against the separate entry points; rows of 17 .. 32 and of more than 32 entries (the plain
+    kernel for the few long rows), self-loop entries without an edge column, isolated vertices, a ragged last tile, a
+    DIRECTED graph (the entry point does not assume symmetry), S kept and S rebuilt; deterministic."""
+    from athena_amd import DeviceGraph, ops
+    from oracle import oracle64 as o64
+
+    rng = np.random.default_rng(300 + d + N)
+    pairs = [[i, i + 1] for i in range(1, N - 6)]
+    for k, h in enumerate(hubs):
+        hub = 11 + 80 * k
+        pairs += [[hub, int(v)] for v in rng.choice(np.arange(hub + 2, N - 6), h, replace=False)]
+    pairs += [[int(a), int(b)] for a, b in rng.integers(1, N - 5, (int(3.5 * N), 2)) if a != b]
+    pairs = np.array(pairs).T
+    g = csr_from_index_list(N, pairs, self_loops=loops)
+    E = pairs.shape[1]
+    ia, ja = g.adj_ia, g.adj_ja
+    if directed:       # keep only the entries that point "upwards" (+ a few back): rows and columns differ
+        rows = np.repeat(np.arange(1, N + 1), np.diff(ia))
+        keep = (ja[0] > rows) | (rng.random(ja.shape[1]) < 0.2)
+        ja = np.asfortranarray(ja[:, keep])
+        ia = np.concatenate([[1], 1 + np.cumsum(np.bincount(rows[keep] - 1, minlength=N))]).astype(np.int32)
+    Hh = Fi = Fo = 64
+    coords = rng.standard_normal((E, d)).astype(np.float32)
+    x = rng.uniform(-1, 1, (N, Fi)).astype(np.float32)
+    theta = (0.3 * rng.standard_normal(Hh * d + Hh + Fo * Fi * Hh + Fo * Fi)).astype(np.float32)
+    up = rng.uniform(-1, 1, (N, Fo)).astype(np.float32)
+    dg = DeviceGraph(ia, ja, n_edge_cols=E)
+    th, co, xd, gd = T(theta, dev), T(coords, dev), T(x, dev), T(up, dev)
+    dx, dth, dc, fused = ops.gno_aggregate_bwd(dg, th, co, xd, gd, d, Hh, need_dcoords=True)
+    assert fused
+    kap = oracle.gno_kernel_eval(coords, theta, Hh, Fo * Fi)
+    assert_close(H_(dx), oracle.gno_aggregate_bwd_x(up, kap, ia, ja, Fi), 1e-5, "gno dx (one contraction)")
+    dk = oracle.gno_aggregate_bwd_k(up, x, E, ia, ja)
+    dk64 = lambda: o64.gno_aggregate_bwd_k(up, x, E, ia, ja)
+    assert_close(H_(dth), oracle.gno_kernel_bwd_theta(coords, theta, dk, Hh), 1e-5, "gno dtheta (one contraction)",
+                 f64=lambda: o64.gno_kernel_bwd_theta(coords, theta, dk64(), Hh))
+    assert_close(H_(dc), oracle.gno_kernel_bwd_coords(coords, theta, dk, Hh), 1e-5, "gno dcoords (one contraction)",
+                 f64=lambda: o64.gno_kernel_bwd_coords(coords, theta, dk64(), Hh))
+    # the parameter gradient is the SAME launches as the separate entry point's: same bits; dx associates differently
+    assert torch.equal(dth, ops.gno_aggregate_bwd_theta(dg, th, co, xd, gd, d, Hh))
+    dx_sep = ops.gno_aggregate_bwd_x(dg, th, co, gd, d, Hh, Fi)
+    assert (dx - dx_sep).abs().max().item() <= 1e-5 * dx_sep.abs().max().item()
+    # S kept by the forward pass: the same dtheta bits, the same dx bits
+    _, s_save = ops.gno_aggregate_save(dg, th, co, xd, d, Hh, Fo)
+    dx2, dth2, _, fused2 = ops.gno_aggregate_bwd(dg, th, co, xd, gd, d, Hh, s_save=s_save)
+    assert fused2 and torch.equal(dx2, dx) and torch.equal(dth2, dth)
+    # dx alone / dtheta alone
+    dx3, none, _, _ = ops.gno_aggregate_bwd(dg, th, co, xd, gd, d, Hh, need_dtheta=False)
+    assert none is None and torch.equal(dx3, dx)
+    none, dth3, _, f3 = ops.gno_aggregate_bwd(dg, th, co, xd, gd, d, Hh, need_dx=False)
+    assert none is None and not f3 and torch.equal(dth3, dth)
+
+
+def test_gno_reverse_pass_falls_back_outside_the_fused_shapes(dev, oracle):
+    """shapes the fused kernels do not serve (d = 4; generic widths; a graph where more than 1 row in 64 is longer than 32
+    entries) run the separate entry points behind the same call"""
+    from athena_amd import DeviceGraph, ops
+
+    for (N, d, H, Fi, Fo, extra) in ((40, 4, 64, 64, 64, 30), (50, 3, 7, 5, 9, 60), (64, 3, 64, 64, 64, 1800)):
+        g, E, coords, x, theta, up = _gno_case(N + d, N, d, H, Fi, Fo, extra)
+        dg = DeviceGraph(g.adj_ia, g.adj_ja, n_edge_cols=E)
+        th, co, xd, gd = T(theta, dev), T(coords, dev), T(x, dev), T(up, dev)
+        dx, dth, dc, fused = ops.gno_aggregate_bwd(dg, th, co, xd, gd, d, H, need_dcoords=True)
+        assert not fused
+        assert torch.equal(dx, ops.gno_aggregate_bwd_x(dg, th, co, gd, d, H, Fi))
+        assert torch.equal(dth, ops.gno_aggregate_bwd_theta(dg, th, co, xd, gd, d, H))
+        assert torch.equal(dc, ops.gno_aggregate_bwd_coords(dg, th, co, xd, gd, d, H))
