@@ -30,6 +30,7 @@ from athena_amd import DeviceGraph, _capi, ops, synth
 HBM, MFMA = 8000.0, 157.3
 TOL = 1e-5
 TIMING_ONLY = False
+MESH_ORDER = None
 
 
 def timeit(fn, reps):
@@ -131,7 +132,7 @@ def run_c4(dev, reps):
     from oracle import oracle as o
 
     N = 2_000_000
-    ia, ja, coords = synth.radius_graph(N)
+    ia, ja, coords = synth.radius_graph(N, order=MESH_ORDER)
     nnz, E = ja.shape[1], coords.shape[0]
     Fi = Fo = H = 64; d = 3
     rng = np.random.default_rng(0)
@@ -209,7 +210,7 @@ def run_c4(dev, reps):
                      and par["dtheta_adjoint_rel"] <= TOL and torch.isfinite(dth).all().item())
     step = t["fwd_keeps_S"] + t["bwd_x+theta_one_contraction"]
     step_sep = t["fwd_keeps_S"] + t["bwd_x"] + t["bwd_theta_S_kept"]
-    return {"config": "configs[3]", "workload": f"GNO aggregation, radius mesh {N} vertices / {nnz} entries / {E} edge columns, F_in = F_out = H = 64, d = 3, "
+    return {"config": "configs[3]" + (" (vertices in cell order)" if MESH_ORDER else ""), "workload": f"GNO aggregation, radius mesh {N} vertices / {nnz} entries / {E} edge columns, F_in = F_out = H = 64, d = 3, "
             "training step = forward (keeps S) + reverse pass (dx and dtheta from one contraction)", "step_ms": round(step, 3),
             "step_ms_separate_reverse_launches": round(step_sep, 3), "entries_per_s": nnz / step * 1e3,
             "s_kept_GB": round(s_bytes / 1e9, 2), "ops": opsd, "parity": par}
@@ -270,9 +271,13 @@ def main():
     ap.add_argument("--config", choices=["c3", "c4", "c5"], required=True)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--timing-only", action="store_true", help="c4: stop after the timed launches (rocprofv3 runs)")
+    ap.add_argument("--mesh-order", choices=["drawn", "cells"], default="drawn",
+                    help="c4: vertices numbered as drawn (BASELINE configs[3]: every gather a random row) or in Morton order of "
+                         "their cell (the numbering a mesher / partitioner gives; what the 8-way row partition uses)")
     a = ap.parse_args()
-    global TIMING_ONLY
+    global TIMING_ONLY, MESH_ORDER
     TIMING_ONLY = a.timing_only
+    MESH_ORDER = None if a.mesh_order == "drawn" else "cells"
     _capi.init(0)
     dev = torch.device("cuda:0")
     t0 = time.perf_counter()

@@ -345,6 +345,7 @@ def test_c4_gno_properties_full_size(dev, oracle):
     sia_sq = np.concatenate([sia, np.full(nsq - rows.size, sia[-1], np.int32)])
     xs_sq = np.zeros((nsq, Fi), np.float32); xs_sq[: ncols.size] = xs
     ref = oracle.gno_aggregate(xs_sq, kap, sia_sq, sja, Fo)[: rows.size]
+    nsq_rows = nsq                                                   # (the column sub-problem below re-uses the name)
     got = m[torch.from_numpy(rows).to(dev)].cpu().numpy()
     assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
     # linear in x; adjoint <m, g> = <x, dx>; linear in Vaug: <m, g> = <Vaug, dVaug>
@@ -387,6 +388,35 @@ def test_c4_gno_properties_full_size(dev, oracle):
     via_c = (co.double() * dco.double()).sum().item()
     via_Uonly = (theta[:H * d].double() * dth[:H * d].double()).sum().item()
     assert abs(via_c - via_Uonly) <= 1e-5 * scale
+    # d theta and dcoords at size AGAINST THE ORACLE (not only through identities): both are linear in the upstream gradient,
+    # so with g non-zero on 300 sampled rows only they are the sums over those rows' entries -- a compact sub-problem the
+    # materialising oracle can hold (kappa for the edge columns those rows touch).  The kernels still walk the whole graph:
+    # a permutation error in the tile / slot / piece bookkeeping at this size would put the sampled rows' sums elsewhere.
+    from oracle import oracle64 as o64
+    g_sp = torch.zeros_like(gup)
+    rsel = torch.from_numpy(rows).to(dev)
+    g_sp[rsel] = gup[rsel]
+    dx_sp, dth_sp, dco_sp, fused = ops.gno_aggregate_bwd(g, theta, co, x, g_sp, d, H, need_dcoords=True)
+    assert fused
+    up_sq = np.zeros((nsq_rows, Fo), np.float32); up_sq[: rows.size] = gup[rsel].cpu().numpy()
+    dk = oracle.gno_aggregate_bwd_k(up_sq, xs_sq, ecols.size, sia_sq, sja)
+    dk64 = lambda: o64.gno_aggregate_bwd_k(up_sq, xs_sq, ecols.size, sia_sq, sja)
+    th_h = theta.cpu().numpy()
+    assert_close(dth_sp.cpu().numpy(), oracle.gno_kernel_bwd_theta(coords[ecols - 1], th_h, dk, H), 1e-5, "configs[3] dtheta of 300 rows",
+                 f64=lambda: o64.gno_kernel_bwd_theta(coords[ecols - 1], th_h, dk64(), H))
+    dco_ref = oracle.gno_kernel_bwd_coords(coords[ecols - 1], th_h, dk, H)
+    got_dco = dco_sp[torch.from_numpy(ecols - 1).to(dev)].cpu().numpy()
+    assert_close(got_dco, dco_ref, 1e-5, "configs[3] dcoords of 300 rows",
+                 f64=lambda: o64.gno_kernel_bwd_coords(coords[ecols - 1], th_h, dk64(), H))
+    other = torch.ones(E, dtype=torch.bool, device=dev); other[torch.from_numpy(ecols - 1).to(dev)] = False
+    assert not dco_sp[other].any()                                   # edge columns no sampled row touches: exact zeros
+    # ... and the feature gradient of the same sparse upstream through the ONE-contraction reverse pass: non-zero exactly on the
+    # neighbours of the sampled rows, equal to the separate entry point
+    dx_sep = ops.gno_aggregate_bwd_x(g, theta, co, g_sp, d, H, Fi)
+    assert (dx_sp - dx_sep).abs().max().item() <= 1e-5 * dx_sep.abs().max().item()
+    nb = torch.zeros(N, dtype=torch.bool, device=dev); nb[torch.from_numpy(ncols - 1).to(dev)] = True
+    assert not dx_sp[~nb].any()
+    del g_sp, dx_sp, dx_sep, dco_sp
     # the training-mode pair at size: the forward pass keeps S (33 GB, beyond what one buffer descriptor addresses), the
     # reverse pass streams it -- same m, same dtheta, bit for bit
     del dco, dx
