@@ -313,3 +313,33 @@ def test_experiment_patches_still_apply():
     for pth in patches:
         r = subprocess.run(["git", "apply", "--check", pth], cwd=root, capture_output=True, text=True)
         assert r.returncode == 0, f"{os.path.basename(pth)}: {r.stderr[-500:]}"
+
+
+def test_watchdog_ends_a_stalled_rank_with_a_message_and_exit_code_3():
+    """athena_amd.dist.Watchdog (bench.py's guard around every wait for a peer): a phase that outlives its deadline ends the
+    PROCESS -- one json line {"ok": false, "error": "rank r stalled in <phase> ..."} on stdout, exit code 3, no cleanup that
+    could block; a phase that finishes in time leaves nothing behind; nested phases report the innermost."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = r'''
+import sys, time
+sys.path.insert(0, %r)
+from athena_amd.dist import Watchdog
+wd = Watchdog(5, timeout_s=0.6)
+with wd.phase("quick phase"):
+    time.sleep(0.05)
+print("still here", flush=True)
+with wd.phase("outer phase", factor=50.0):
+    with wd.phase("halo exchange of the forward rows"):
+        time.sleep(30)
+print("never printed", flush=True)
+''' % root
+    r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3, (r.returncode, r.stdout, r.stderr[-500:])
+    lines = r.stdout.strip().splitlines()
+    assert lines[0] == "still here" and "never printed" not in r.stdout
+    msg = json.loads(lines[-1])
+    assert msg["ok"] is False and "rank 5 stalled in halo exchange of the forward rows" in msg["error"]
