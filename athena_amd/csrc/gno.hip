@@ -214,7 +214,7 @@ typedef unsigned int v4u_g __attribute__((ext_vector_type(4)));
 #define GNO_SAVE_AUX 2
 #endif
 #ifndef GNO_FV
-#define GNO_FV 0   // timing-only variants (scripts/build_variants.sh), bit mask: 1 no sparse loop, 2 no V loads, 4 no S reads, 8 no contraction, 16 no cross-wave reduction (gno_fused_kernel); 32 idle producers, 64 idle consumers (gno_pc_kernel)
+#define GNO_FV 0   // timing-only variants (scripts/build_variants.sh), bit mask: 1 no sparse loop, 2 no V loads, 4 no S reads, 8 no contraction, 16 no cross-wave reduction (gno_fused_kernel); 32 idle producers, 64 idle consumers, 8192 half the gathers (gno_pc_kernel)
 #endif
 constexpr int kGF = 64, kGH = 64, kGRows = 16, kGSP = 33 * kGF + 4;   // LDS row pitch of S_half
 
@@ -838,7 +838,9 @@ __global__ __launch_bounds__(kPcThreads) void gno_pc_kernel(const int32_t *__res
                         float bs;
                         if (vi < kHCache) P.compute<decltype(K)::value, decltype(FILL)::value ? 1 : 2>(LS[vi], CV[vi], ub0, ub1, acc, bs, HCc[vi]);
                         else P.compute<decltype(K)::value>(LS[vi], CV[vi], ub0, ub1, acc, bs);
-                        P.issue(LS[vi], pJ0, pJ1, vi, cn, second);
+                        // (GNO_FV & 8192, timing only: no gathers during pieces 3 .. 6 -- what the launch costs when a feature quarter
+                        // is gathered once per tile instead of once per kh; the results are wrong)
+                        if (!(GNO_FV & 8192) || pc < 3 || pc == 7) P.issue(LS[vi], pJ0, pJ1, vi, cn, second);
                         if (last) P.load_cv(CV[vi], nxt.E0, nxt.E1, vi);
                         const int v = 4 * p + vi;
                         float *srow = buf + (size_t)v * kPPitch;
