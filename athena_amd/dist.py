@@ -1041,6 +1041,18 @@ class GnoShardStep:
             dz.copy_(self.up)
         else:
             dz.copy_(b.activation_bwd(self.act, self.out, self.up, z=self.z))
+        if s.world == 1 and ni == n and hasattr(b, "gno_aggregate_bwd"):
+            # one rank, nothing to exchange: the whole reverse pass of the aggregation from ONE contraction
+            # (athena_mp_gno_aggregate_bwd) -- on a shard its per-entry partials would have to travel to the
+            # column's owner, so the ranks of a partition take the pull below
+            if self.use_bias:
+                b.matmul_dw(self.ones, dz, out=self.db)
+            b.matmul_dw(self.x_ext[:n], dz, out=self.dW)
+            dxa, dth, _, _ = b.gno_aggregate_bwd(self.g_fwd_int, self.theta, self.coords, self.x_ext, dz, d, H, s_save=self._s[0])
+            self.dtheta.copy_(dth)
+            self.dX.copy_(dxa)
+            b.axpy(1.0, b.matmul_dx(self.W, dz, Fi), self.dX)
+            return self.dX
         reqs = self.xchg_o.start(self.g_ext)                                       # halo of dz in flight; under it:
         if self.use_bias:
             b.matmul_dw(self.ones, dz, out=self.db)                                # db[o] = sum_v dz[v,o]

@@ -24,6 +24,9 @@ Workloads (--config):
   c5, c5-local   BASELINE configs[4]: 10M vertices / 150M entries / 256 features split over the ranks (8-way in the
                  config; any N that divides 10M runs); c5-local = the locality variant of SURVEY.md 8d
                  (|u-v| <= 50 000 with probability 0.95).
+  c4-mesh        BASELINE configs[3] as a LAYER step at any N: graph_nop_layer forward + reverse (aggregation with the kernel
+                 MLP, bypass W x + b) on the 2M-point radius mesh numbered in cell order, cut by rows
+                 (athena_mp_shard_create_edges); a step = forward + reverse, "edges" = CSR entries.  Not the headline.
 Every line carries "parity": the device results of the LAST timed step against the CPU oracle (N = 1: the whole
 workload; N > 1: sampled rows of every rank + the transported halo rows against the generator); the process exits
 non-zero when parity is above 1e-5 (or P is not bit-exact).
@@ -48,6 +51,9 @@ CONFIGS = {
     "c2-weak-sbm": dict(nodes=1_000_000, pairs=4_500_000, feat=128, locality=None),
     "c5": dict(nodes=10_000_000, pairs=70_000_000, feat=256, locality=None),
     "c5-local": dict(nodes=10_000_000, pairs=70_000_000, feat=256, locality=(50_000, 0.95)),
+    # BASELINE configs[3]: graph_nop_layer fwd+bwd on the 2 M-point radius mesh (points numbered in cell order), row-partitioned
+    # over the ranks (athena_mp_shard_create_edges; halo of x and of dz, [dtheta | dW | db] all-reduced); --nodes = points
+    "c4-mesh": dict(nodes=2_000_000, pairs=0, feat=64, locality=None),
 }
 
 
@@ -323,6 +329,181 @@ def run_secondary(which, budget_s=540.0):
     return out
 
 
+def main_gno(args, world, rank, dev, one_device):
+    """--config c4-mesh: graph_nop_layer forward + reverse on the configs[3] mesh, row-partitioned over the ranks
+    (dist.GnoShardStep over athena_mp_shard_create_edges).  One json line: whole-job entries/s, the interior forward launch
+    against the fp32-MFMA peak, parity of sampled rows of every rank against the MATERIALISING oracle, the halo's share."""
+    import contextlib
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from athena_amd import dist as adist
+    from athena_amd import synth
+
+    Fi = Fo = H = args.feat
+    d = 3
+    watch = None
+    backend = os.environ.get("ATHENA_MP_BENCH_BACKEND", "nccl")
+    if world > 1:
+        watch = adist.Watchdog(rank)
+        adist.set_watchdog(watch)
+        with watch.phase("process group creation"):
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(backend)
+
+    def phase(name, factor=1.0):
+        return watch.phase(name, factor) if watch is not None else contextlib.nullcontext()
+
+    N = args.nodes
+    mesh = synth.radius_graph(N, order="cells")                  # every rank derives the same mesh from the seed
+    ia, ja, coords = mesh
+    if world > 1:
+        shard, c_loc = adist.make_mesh_shard(rank, world, N, device=dev, mesh=mesh)
+    else:
+        # one rank: the same code path with an empty halo (python plan; nothing to exchange)
+        rows = np.repeat(np.arange(N, dtype=np.int64), np.diff(ia))
+        shard = adist.build_plan(adist.Shard(0, 1, N, rows, ja[0].astype(np.int64) - 1, ja[1].astype(np.int64)), dev)
+        shard.n_total = N
+        c_loc = np.ascontiguousarray(coords[shard.edge_ids], np.float32)
+    n = shard.n
+    rng = np.random.Generator(np.random.PCG64(7))                 # the global problem, the same on every rank
+    theta = (0.3 * rng.standard_normal(H * d + H + Fo * Fi * H + Fo * Fi)).astype(np.float32)
+    w = (rng.standard_normal(Fo * Fi) * np.sqrt(2.0 / Fi)).astype(np.float32)
+    b = (rng.standard_normal(Fo) * 0.1).astype(np.float32)
+    lo = rank * n
+    x_l = synth.feature_block(1, lo, lo + n, Fi)
+    up_l = synth.feature_block(3, lo, lo + n, Fo)
+    step = adist.GnoShardStep(shard, Fi, Fo, d, H, dev, inputs=(x_l, up_l, theta, w, b, c_loc))
+    nnz_local = int(shard.nnz)
+    tt = torch.tensor([nnz_local], dtype=torch.int64, device=dev if (world > 1 and backend == "nccl") else "cpu")
+    if world > 1:
+        adist.first_contact(step, watch, torch.cuda.synchronize)
+        with phase("all-reduce of the entry counts"):
+            dist.all_reduce(tt)
+    nnz_total = int(tt.item())
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ev = []
+    with phase("warm-up steps"):
+        for _ in range(args.warmup):
+            step()
+        barrier()
+    with phase("timed loop", factor=max(1.0, args.steps / 10.0)):
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(events=ev)
+        barrier()
+        dt = time.perf_counter() - t0
+    if world > 1:
+        t_ = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        with phase("max of the step time over the ranks"):
+            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+        dt = t_.item()
+    ms = dt / args.steps * 1e3
+    # roofline: the interior rows' forward aggregation launch of rank 0 (fp32 MFMA; SURVEY.md 8d's flop count)
+    ni = shard.n_int
+    int_nnz = int(step.g_fwd_int.nnz)
+    fwd_ms = float(np.mean([a.elapsed_time(b_) for a, b_ in ev])) if ev else float("nan")
+    flops = int_nnz * 2 * H * (Fi + d) + ni * 2 * Fo * (H + 1) * Fi
+    tf = flops / (fwd_ms * 1e-3) / 1e12
+    # parity: sampled rows of both blocks of `out` and of dx against the materialising oracle on the compact sub-problem
+    from oracle import oracle
+    r2 = np.random.default_rng(100 + rank)
+    pick = [r2.choice(ni, min(100, ni), replace=False)] if ni else []
+    if n - ni:
+        pick.append(ni + r2.choice(n - ni, min(100, n - ni), replace=False))
+    rows = np.unique(np.concatenate(pick))
+    rsel = torch.from_numpy(rows).to(dev)
+
+    def sub(backward):
+        gi, gb = (step.g_bwd_int, step.g_bwd_bnd) if backward else (step.g_fwd_int, step.g_fwd_bnd)
+        rp = np.concatenate([gi.export("rowptr"), gb.export("rowptr")[1:] + gi.nnz]).astype(np.int64)
+        col = np.concatenate([gi.export("col"), gb.export("col")])
+        eid = np.concatenate([gi.export("eid"), gb.export("eid")])
+        ent = np.concatenate([np.arange(rp[r], rp[r + 1]) for r in rows])
+        cols, cinv = np.unique(col[ent], return_inverse=True)
+        ecols, einv = np.unique(eid[ent], return_inverse=True)
+        sia = np.concatenate([[1], 1 + np.cumsum(rp[rows + 1] - rp[rows])]).astype(np.int32)
+        sja = np.zeros((2, ent.size), np.int32, order="F"); sja[0] = cinv + 1; sja[1] = einv + 1
+        return cols, ecols, sia, sja
+
+    torch.cuda.synchronize()
+    cols, ecols, sia, sja = sub(False)
+    kap = oracle.gno_kernel_eval(c_loc[ecols], theta, H, Fo * Fi)
+    nsq = max(rows.size, cols.size)
+    xs = np.zeros((nsq, Fi), np.float32); xs[:cols.size] = step.x_ext[torch.from_numpy(cols).to(dev)].cpu().numpy()
+    sia_sq = np.concatenate([sia, np.full(nsq - rows.size, sia[-1], np.int32)])
+    m_ref = oracle.gno_aggregate(xs, kap, sia_sq, sja, Fo)[:rows.size]
+    x_rows = step.x_ext[rsel].cpu().numpy()
+    out_ref = oracle.add_bias_rows(m_ref + oracle.matmul(w, x_rows, Fo), b)
+    res = {"out_rel": rel(step.out[rsel].cpu().numpy(), out_ref)}
+    cols, ecols, sia, sja = sub(True)
+    kap64 = oracle.gno_kernel_eval(c_loc[ecols], theta, H, Fo * Fi).reshape(-1, Fi, Fo).astype(np.float64)
+    gs = step.g_ext[torch.from_numpy(cols).to(dev)].cpu().numpy().astype(np.float64)
+    dref = np.zeros((rows.size, Fi))
+    for k in range(rows.size):
+        for w_ in range(sia[k] - 1, sia[k + 1] - 1):
+            dref[k] += kap64[sja[1, w_] - 1] @ gs[sja[0, w_] - 1]
+    dref += oracle.matmul_dx(w, step.g_ext[rsel].cpu().numpy(), Fi).astype(np.float64)
+    res["dX_rel"] = rel(step.dX[rsel].cpu().numpy(), dref)
+    held = np.flatnonzero(shard.ext_ids >= 0)
+    halo_ok = True
+    if held.size:
+        k = np.sort(r2.choice(held, min(300, held.size), replace=False))
+        halo_ok = bool(np.array_equal(step.x_ext[torch.from_numpy(n + k).to(dev)].cpu().numpy(), synth.feature_rows(1, shard.ext_ids[k], Fi)))
+    flags = torch.tensor([0.0 if halo_ok else 1.0, res["out_rel"], res["dX_rel"]], dtype=torch.float64)
+    if world > 1:
+        if backend == "nccl":
+            flags = flags.to(dev)
+        with phase("parity of every rank against the oracle", factor=3.0):
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+    flags = flags.cpu().tolist()
+    parity = {"against": f"materialising oracle on {rows.size} sampled rows of both blocks of every rank (max over ranks); halo rows "
+                         "against the generator; the all-reduced gradients are held by tests/test_gpu_dist.py, not here",
+              "halo_rows_bit_exact": flags[0] == 0.0, "out_rel": flags[1], "dX_rel": flags[2], "tol": TOL}
+    parity["ok"] = bool(flags[0] == 0.0 and max(flags[1:]) <= TOL)
+    out = {"metric": "msgpass fwd+bwd edges/sec", "value": nnz_total * args.steps / dt, "unit": "edges/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+           "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"BASELINE configs[3] as a layer step: graph_nop_layer fwd+bwd, radius mesh {N} vertices / {nnz_total} CSR "
+                                  f"entries in cell order, {Fi} features, d = 3, H = {H}, fp32"
+                                  + (f", row-partitioned over {world} GPUs" if world > 1 else ""),
+                      "vertices": N, "entries": nnz_total, "entries_per_gpu": nnz_local, "features": Fi,
+                      "parallelism": f"row-partition x{world}" if world > 1 else "single GPU",
+                      "halo_rows_per_gpu": int(shard.halo_ids.size), "halo_mode": shard.halo_mode,
+                      "halo_fraction": round(float(shard.halo_fraction), 4), "interior_rows_per_gpu": int(ni),
+                      "edge_columns_per_gpu": int(shard.n_edge_cols), "transport": shard.transport,
+                      "S_kept_per_block": [t is not None for t in step._s]},
+           "roofline": {"bound": "mfma", "kernel": "gno_pc_kernel<true> (gno_aggregate of rank 0's interior rows, S kept; the halo exchange in flight)",
+                        "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
+                        "traffic": None, "flops_per_launch": flops, "avg_launch_ms": fwd_ms},
+           "parity": parity}
+    ok = parity["ok"]
+    if world > 1:
+        err = transport_error(str(shard.transport), one_device)
+        if err:
+            out["ok"], out["error"], ok = False, err, False
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        with phase("final barrier"):
+            dist.barrier()
+        watch.close()
+        adist.c_comm_destroy()
+        dist.destroy_process_group()
+    if not ok:
+        sys.exit("bench.py: parity against the oracle FAILED (see the 'parity' object of the line above)")
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -353,6 +534,8 @@ def main():
     from athena_amd import DeviceGraph, _capi, ops, synth
 
     _capi.init(local_rank)
+    if args.config == "c4-mesh":
+        return main_gno(args, world, rank, dev, one_device)
     F = args.feat
     weak = args.config == "c2-weak-sbm"
     ev, ev_bnd, ev_dw = [], [], []

@@ -789,3 +789,28 @@ def test_bench_py_fails_fast_when_a_rank_stalls(dev, where, phase):
     assert lines and lines[-1]["ok"] is False, (r.stdout[-1500:], r.stderr[-1500:])
     assert "rank 0 stalled in" in lines[-1]["error"] and phase in lines[-1]["error"], lines[-1]
     assert took < 240, took
+
+
+@pytest.mark.parametrize("gpus", [1, 2, 8])
+def test_bench_py_gno_mesh_config(dev, gpus):
+    """`python bench.py --config c4-mesh --gpus N`: graph_nop_layer forward + reverse on the configs[3] mesh generator (here
+    48 000 points) cut by rows -- one rank (empty halo) and the one-device dry run at 2 and 8 ranks (shm test transport);
+    the line's structure, the parity of every rank against the materialising oracle, S kept on the blocks."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, ATHENA_MP_BENCH_ONE_DEVICE="1", ATHENA_MP_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c4-mesh", "--gpus", str(gpus), "--nodes", "48000",
+                        "--steps", "2", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == gpus and line["unit"] == "edges/s" and line["roofline"]["bound"] == "mfma"
+    assert line["parity"]["ok"] and line["parity"]["halo_rows_bit_exact"]
+    assert max(line["parity"]["out_rel"], line["parity"]["dX_rel"]) <= 1e-5
+    cfg = line["config"]
+    assert cfg["vertices"] == 48000 and any(cfg["S_kept_per_block"]) and cfg["edge_columns_per_gpu"] > 0
+    if gpus > 1:
+        assert cfg["transport"].startswith("shm") and cfg["halo_rows_per_gpu"] > 0 and line["scaling"] == "strong"
+    else:
+        assert cfg["halo_rows_per_gpu"] == 0
