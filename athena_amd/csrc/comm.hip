@@ -25,8 +25,11 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <mutex>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <rccl/rccl.h>
@@ -276,6 +279,121 @@ bool want_shm()
 
 } // namespace
 
+// ---- a deadline for every transfer this library puts on a communication stream -------------------------------------------
+// No RCCL collective has a completion deadline: two ranks that disagree about a transfer wait for each other until whoever
+// launched them gives up.  The host never blocks in athena_mp_halo_start / _allreduce_start (the stall would surface in the
+// caller's next synchronize, far from its cause), so a monitor thread watches the completion EVENT of every transfer that
+// was started: one that is still pending ATHENA_MP_COLLECTIVE_TIMEOUT_S seconds later (default 120; 0 = no monitor) ends the
+// process -- a message naming the rank and the transfer on stderr, {"ok": false, "error": ...} on stdout, _exit(3): no retry,
+// no cleanup that could block in the same communicator.  Fortran drivers get the protection bench.py's python watchdog
+// gives the bench.  ATHENA_MP_COMM_TEST_DELAY_MS (tests only) parks a bounded spin kernel in front of the completion event.
+namespace {
+struct Watched {
+    hipEvent_t ev;
+    double t0, limit;
+    int rank, device;
+    char what[96];
+};
+std::mutex g_watch_mu;
+std::vector<Watched> g_watch;
+std::atomic<bool> g_watch_started{false};
+double watch_now()
+{
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+double watch_timeout()
+{
+    static const double t = [] {
+        const char *e = getenv("ATHENA_MP_COLLECTIVE_TIMEOUT_S");
+        const double v = e ? atof(e) : 120.0;
+        return v > 0.0 ? v : 0.0;
+    }();
+    return t;
+}
+void watch_loop()
+{
+    int cur_dev = -1;
+    for (;;) {
+        usleep(100000);
+        std::lock_guard<std::mutex> lock(g_watch_mu);
+        const double now = watch_now();
+        for (size_t i = 0; i < g_watch.size();) {
+            Watched &w = g_watch[i];
+            if (w.device != cur_dev) {
+                (void)hipSetDevice(w.device);
+                cur_dev = w.device;
+            }
+            const hipError_t q = hipEventQuery(w.ev);
+            if (q == hipSuccess) {
+                g_watch[i] = g_watch.back();
+                g_watch.pop_back();
+                continue;
+            }
+            (void)hipGetLastError();
+            if (q == hipErrorNotReady && now - w.t0 > w.limit) {
+                fprintf(stderr, "[athena_mp] rank %d stalled in %s for more than %.0f s (ATHENA_MP_COLLECTIVE_TIMEOUT_S): a peer is "
+                                "missing, late or in another collective\n", w.rank, w.what, w.limit);
+                printf("{\"ok\": false, \"error\": \"rank %d stalled in %s for more than %.0f s\"}\n", w.rank, w.what, w.limit);
+                fflush(stdout);
+                fflush(stderr);
+                _exit(3);
+            }
+            ++i;
+        }
+    }
+}
+// the transfer whose completion `ev` marks has just been enqueued
+void watch_arm(hipEvent_t ev, int rank, int device, const char *what, double factor = 1.0)
+{
+    if (watch_timeout() <= 0.0) return;
+    {
+        std::lock_guard<std::mutex> lock(g_watch_mu);
+        bool found = false;
+        for (Watched &w : g_watch)
+            if (w.ev == ev) {   // the event was re-recorded: the newest transfer is the one it now stands for
+                w.t0 = watch_now();
+                w.limit = watch_timeout() * factor;
+                snprintf(w.what, sizeof(w.what), "%s", what);
+                found = true;
+            }
+        if (!found) {
+            Watched w;
+            w.ev = ev; w.t0 = watch_now(); w.limit = watch_timeout() * factor; w.rank = rank; w.device = device;
+            snprintf(w.what, sizeof(w.what), "%s", what);
+            g_watch.push_back(w);
+        }
+    }
+    bool expected = false;
+    if (g_watch_started.compare_exchange_strong(expected, true)) std::thread(watch_loop).detach();
+}
+void watch_forget(hipEvent_t ev)   // before the event is destroyed
+{
+    std::lock_guard<std::mutex> lock(g_watch_mu);
+    for (size_t i = 0; i < g_watch.size();)
+        if (g_watch[i].ev == ev) {
+            g_watch[i] = g_watch.back();
+            g_watch.pop_back();
+        } else {
+            ++i;
+        }
+}
+__global__ void comm_test_delay_kernel(long long ticks)
+{
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+void test_delay(hipStream_t s)   // tests only: a BOUNDED wait in front of a completion event (100 MHz wall clock)
+{
+    static const long long ms = [] {
+        const char *e = getenv("ATHENA_MP_COMM_TEST_DELAY_MS");
+        return e ? atoll(e) : 0ll;
+    }();
+    if (ms > 0) hipLaunchKernelGGL(comm_test_delay_kernel, dim3(1), dim3(1), 0, s, std::min(ms, 20000ll) * 100000ll);
+}
+}   // namespace
+
 struct athena_mp_comm {
     Transport *t = nullptr;
     hipStream_t cs = nullptr;       // communication stream
@@ -336,6 +454,8 @@ int exchange_host(athena_mp_comm *c, const std::vector<const void *> &sp, const 
         off += (rb[p] + 255) & ~(size_t)255;
     }
     int rc = c->t->exchange(dsp.data(), sb.data(), drp.data(), rb.data(), c->cs);
+    if (rc == 0 && hipEventRecord(c->ev_done, c->cs) == hipSuccess)
+        watch_arm(c->ev_done, c->t->rank, c->device, "a metadata exchange of the shard build (athena_mp_shard_create)", 5.0);
     if (rc == 0 && hipStreamSynchronize(c->cs) != hipSuccess) {
         set_error("comm: metadata exchange failed on the communication stream");
         rc = 1;
@@ -359,6 +479,8 @@ int allgather_host(athena_mp_comm *c, const void *mine, size_t bytes, void *out)
     int rc = 0;
     if (hipMemcpy(dev + (size_t)r * bytes, mine, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = 1;
     if (rc == 0) rc = c->t->allgather(dev + (size_t)r * bytes, dev, bytes, c->cs);
+    if (rc == 0 && hipEventRecord(c->ev_done, c->cs) == hipSuccess)
+        watch_arm(c->ev_done, c->t->rank, c->device, "a metadata all-gather of the shard build (athena_mp_shard_create)", 5.0);
     if (rc == 0 && hipStreamSynchronize(c->cs) != hipSuccess) rc = 1;
     if (rc == 0 && hipMemcpy(out, dev, (size_t)W * bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = 1;
     (void)hipFree(dev);
@@ -606,7 +728,10 @@ int athena_mp_comm_destroy(athena_mp_comm *c)
     }
     delete c->t;
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
-    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+    if (c->ev_done) {
+        watch_forget(c->ev_done);
+        (void)hipEventDestroy(c->ev_done);
+    }
     if (c->cs) (void)hipStreamDestroy(c->cs);
     delete c;
     return 0;
@@ -633,7 +758,9 @@ int athena_mp_allreduce_start(athena_mp_comm *c, float *buf_dev, int64_t count)
     AMP_HIP(hipEventRecord(c->ev_ready, amp::stream()));
     AMP_HIP(hipStreamWaitEvent(c->cs, c->ev_ready, 0));
     if (c->t->allreduce_f32(buf_dev, (size_t)count, c->cs)) return 1;
+    test_delay(c->cs);
     AMP_HIP(hipEventRecord(c->ev_done, c->cs));
+    watch_arm(c->ev_done, c->t->rank, c->device, "the all-reduce of the parameter gradients (athena_mp_allreduce_start)");
     return 0;
 }
 int athena_mp_allreduce_finish(athena_mp_comm *c)
@@ -656,6 +783,10 @@ int athena_mp_comm_barrier(athena_mp_comm *c)
     if (amp::named_buffer("comm.barrier_word", 256, true, (void **)&one)) return 1;
     AMP_HIP(hipStreamSynchronize(amp::stream()));
     if (c->t->world > 1 && c->t->allreduce_f32(one, 1, c->cs)) return 1;
+    if (c->t->world > 1) {
+        AMP_HIP(hipEventRecord(c->ev_done, c->cs));
+        watch_arm(c->ev_done, c->t->rank, c->device, "athena_mp_comm_barrier", 5.0);
+    }
     AMP_HIP(hipStreamSynchronize(c->cs));
     AMP_HIP(hipMemsetAsync(one, 0, 4, c->cs));
     AMP_HIP(hipStreamSynchronize(c->cs));
@@ -671,7 +802,10 @@ int athena_mp_shard_destroy(athena_mp_shard *s)
     if (s->send_idx) (void)hipFree(s->send_idx);
     for (int k = 0; k < 2; ++k) {
         if (s->send_buf[k]) (void)hipFree(s->send_buf[k]);
-        if (s->ev_halo[k]) (void)hipEventDestroy(s->ev_halo[k]);
+        if (s->ev_halo[k]) {
+            watch_forget(s->ev_halo[k]);
+            (void)hipEventDestroy(s->ev_halo[k]);
+        }
     }
     delete s;
     return 0;
@@ -1111,7 +1245,9 @@ int athena_mp_halo_start(athena_mp_shard *s, int32_t slot, int32_t F, float *x_e
         AMP_HIP(hipStreamWaitEvent(c->cs, c->ev_ready, 0));
         const size_t block = sizeof(float) * (size_t)s->max_n * F;
         if (c->t->allgather(x_ext_dev, x_ext_dev + (size_t)s->max_n * F, block, c->cs)) return 1;
+        test_delay(c->cs);
         AMP_HIP(hipEventRecord(s->ev_halo[slot], c->cs));
+        watch_arm(s->ev_halo[slot], rank, c->device, slot ? "the halo exchange in slot 1 (all-gather of whole blocks)" : "the halo exchange in slot 0 (all-gather of whole blocks)");
         return 0;
     }
     const size_t need = sizeof(float) * (size_t)std::max<int64_t>(s->n_send, 1) * F;
@@ -1141,7 +1277,9 @@ int athena_mp_halo_start(athena_mp_shard *s, int32_t slot, int32_t F, float *x_e
         rb[p] = sizeof(float) * (size_t)s->recv_counts[p] * F;
     }
     if (c->t->exchange(sp.data(), sb.data(), rp.data(), rb.data(), c->cs)) return 1;
+    test_delay(c->cs);
     AMP_HIP(hipEventRecord(s->ev_halo[slot], c->cs));
+    watch_arm(s->ev_halo[slot], rank, c->device, slot ? "the halo exchange in slot 1 (grouped send / recv)" : "the halo exchange in slot 0 (grouped send / recv)");
     return 0;
 }
 

@@ -2261,7 +2261,8 @@ __global__ void gno_t_entry_kernel(const int32_t *__restrict__ rowptr, const int
             else hi = mid;
         }
         int rank = 0;
-        for (int w2 = b; w2 < w; ++w2) rank += col[w2] == u;
+        if (lo + 1 < t_rowptr[u + 1] && t_src[lo + 1] == v)   // the pair (v, u) occurs more than once (multigraph): only then scan
+            for (int w2 = b; w2 < w; ++w2) rank += col[w2] == u;
         t_entry[lo + rank] = eid[w] >= 0 ? w : -1;
     }
 }
@@ -2710,10 +2711,16 @@ int athena_mp_gno_aggregate_bwd(const athena_mp_graph *g, int32_t d, int32_t H, 
     if (workspace(&pxp, sizeof(float) * 2 * px_half, 13)) return 1;
     if (workspace(&cvp, sizeof(float) * kGF * (size_t)g->n_rows, 14)) return 1;
     if (!g->t_entry && g->nnz > 0) {
-        AMP_HIP(hipMalloc((void **)&g->t_entry, sizeof(int32_t) * (size_t)g->nnz));
+        int32_t *te = nullptr;
+        AMP_HIP(hipMalloc((void **)&te, sizeof(int32_t) * (size_t)g->nnz));
         hipLaunchKernelGGL(gno_t_entry_kernel, dim3((g->n_rows + 255) / 256), dim3(256), 0, stream(), g->rowptr, g->col, g->eid,
-                           g->t_rowptr, g->t_src, g->n_rows, g->t_entry);
-        AMP_LAUNCH_CHECK();
+                           g->t_rowptr, g->t_src, g->n_rows, te);
+        if (hipGetLastError() != hipSuccess) {   // the handle only ever holds a map that was built
+            (void)hipFree(te);
+            set_error("gno_aggregate_bwd: launch of the transposed-entry map failed");
+            return 1;
+        }
+        g->t_entry = te;
     }
     // c_i = b_v^T g_i in SLOT order of the length-ordered list (a tile's rows contiguous): rows of grad gathered through
     // the permutation, b_v viewed [q][o]

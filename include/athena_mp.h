@@ -328,7 +328,9 @@ int athena_mp_gno_aggregate_bwd_theta_saved(const athena_mp_graph *g, int32_t d,
  * the dx launch (as T . B2), once for the kernel MLP's gradient; here the kernel that holds a piece of G_i in LDS also
  * emits every entry's partial h_e^T G_i of dx, and a gather over the transposed CSR sums them.  Shapes
  * outside the fused kernels run the separate entry points; *fused_out (may be NULL) reports which it was.  Same values
- * as the separate entry points to fp32 rounding (the sums associate differently). */
+ * as the separate entry points to fp32 rounding (the sums associate differently).  The per-entry partials live in a
+ * library workspace of 2 * nnz * 256 bytes (15 GB at BASELINE configs[3]; grown on demand, reused by every call, released
+ * by athena_mp_finalize), the transposed-entry map (nnz int32) in the graph handle. */
 int athena_mp_gno_aggregate_bwd(const athena_mp_graph *g, int32_t d, int32_t H, int32_t Fi, int32_t Fo,
                                 const float *theta_dev, const float *coords_dev, const float *x_dev,
                                 const float *grad_dev, const float *s_save_dev, float *dx_dev, float *dtheta_dev,
@@ -510,6 +512,14 @@ int athena_mp_shard_export(const athena_mp_shard *s, int32_t which, void *host_d
  * ncclAllGather of the blocks; returns at once (kernels enqueued before _finish run under the transfer); slot 0 / 1 = two
  * exchanges may be outstanding */
 int athena_mp_halo_start(athena_mp_shard *s, int32_t slot, int32_t F, float *x_ext_dev);
+/* DEADLINES.  No RCCL collective has a completion deadline of its own, and the host never blocks in _halo_start /
+ * _allreduce_start, so a rank whose peer is missing would hang in its next synchronize, far from the cause.  Every transfer
+ * this library starts (halo exchange, gradient all-reduce, the metadata collectives of athena_mp_shard_create,
+ * athena_mp_comm_barrier) is therefore watched through its completion event by a monitor thread: still pending after
+ * ATHENA_MP_COLLECTIVE_TIMEOUT_S seconds (default 120; x5 for the metadata collectives and the barrier; 0 = no monitor) the
+ * PROCESS ends -- "[athena_mp] rank r stalled in <transfer> ..." on stderr, {"ok": false, "error": ...} on stdout, exit code
+ * 3; no retry, no cleanup that could block in the same communicator.  (The bootstrap of _comm_create_from_file has its own
+ * ATHENA_MP_BOOTSTRAP_TIMEOUT_S.) */
 int athena_mp_halo_finish(athena_mp_shard *s, int32_t slot);
 
 /* ---- residency of host arrays: the *_host entry points without the PCIe round trip per op ---------------------------- *

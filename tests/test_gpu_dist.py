@@ -814,3 +814,32 @@ def test_bench_py_gno_mesh_config(dev, gpus):
         assert cfg["transport"].startswith("shm") and cfg["halo_rows_per_gpu"] > 0 and line["scaling"] == "strong"
     else:
         assert cfg["halo_rows_per_gpu"] == 0
+
+
+def test_c_abi_transfers_have_a_deadline_of_their_own(dev, tmp_path):
+    """comm.hip's monitor thread (for hosts that are not bench.py: the Fortran drivers): every transfer put on the communication
+    stream is watched through its completion event, and one still pending after ATHENA_MP_COLLECTIVE_TIMEOUT_S ends the process
+    with a message naming the rank and the transfer and exit code 3.  Exercised with kipf_shard_run on two ranks (shm test
+    transport) and the test hook that parks a BOUNDED 6 s spin kernel in front of the completion event, deadline 2 s."""
+    import subprocess
+
+    exe = os.path.join(ROOT, "athena_amd", "fortran", "kipf_shard_run")
+    if not os.path.exists(exe):
+        pytest.skip("Fortran driver not built (no amdflang)")
+    env = dict(os.environ, ATHENA_MP_COMM_TRANSPORT="shm", ATHENA_MP_COLLECTIVE_TIMEOUT_S="2", ATHENA_MP_COMM_TEST_DELAY_MS="6000",
+               ATHENA_MP_HALO_MODE="p2p")
+    prefix = str(tmp_path / "run")
+    procs = [subprocess.Popen([exe, str(r), "2", "0", str(tmp_path / "id"), "4000", "16000", "64", prefix], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 3, (r, p.returncode, so.decode()[-500:], se.decode()[-800:])
+        assert f"rank {r} stalled in the halo exchange in slot 0" in se.decode()
+        assert '"ok": false' in so.decode()
+    # ... and with the deadline above the delay the same run completes
+    env["ATHENA_MP_COLLECTIVE_TIMEOUT_S"] = "60"
+    env["ATHENA_MP_COMM_TEST_DELAY_MS"] = "300"
+    procs = [subprocess.Popen([exe, str(r), "2", "0", str(tmp_path / "id2"), "4000", "16000", "64", prefix], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
