@@ -1085,6 +1085,52 @@ class GnoShardStep:
         return self.backward()
 
 
+def measure_breakdown_gno(step, iters=3):
+    """the parts of a GnoShardStep timed ALONE (device events, after the timed loop): both halo exchanges, the interior and the
+    boundary launches of the forward aggregation, the reverse pass's local part (d theta of both blocks, dW, db) and its two
+    pulls.  In the step the exchanges run under the interior work; timed apart, a scaling curve can be read."""
+    s, b, n, ni = step.s, step.b, step.s.n, step.s.n_int
+    d, H, Fi, Fo = step.d, step.H, step.Fi, step.Fo
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        if s.world > 1:
+            dist.barrier()
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    def halo():
+        step.xchg.finish(step.xchg.start(step.x_ext))
+        step.xchg_o.finish(step.xchg_o.start(step.g_ext))
+
+    dz = step.g_ext[:n]
+
+    def dtheta():
+        for k, (g, r0, r1) in enumerate(((step.g_fwd_int, 0, ni), (step.g_fwd_bnd, ni, n))):
+            if r1 > r0:
+                b.gno_aggregate_bwd_theta(g, step.theta, step.coords, step.x_ext, dz[r0:r1], d, H, s_save=step._s[k])
+
+    out = {"halo_ms": timed(halo) if s.world > 1 else 0.0,
+           "fwd_interior_ms": timed(lambda: step._fwd_block(0, step.g_fwd_int, 0, ni)),
+           "fwd_boundary_ms": timed(lambda: step._fwd_block(1, step.g_fwd_bnd, ni, n)),
+           "bwd_dtheta_ms": timed(dtheta),
+           "bwd_pull_interior_ms": timed(lambda: b.gno_aggregate_bwd_x_pull(step.g_bwd_int, step.theta, step.coords, step.g_ext, d, H, Fi,
+                                                                           out=step.dX[:ni])) if ni else 0.0,
+           "bwd_pull_boundary_ms": timed(lambda: b.gno_aggregate_bwd_x_pull(step.g_bwd_bnd, step.theta, step.coords, step.g_ext, d, H, Fi,
+                                                                           out=step.dX[ni:])) if n - ni else 0.0}
+    recv = s.recv_rows * 4 * (Fi + Fo)
+    out["halo_recv_bytes_per_gpu_per_step"] = int(recv)
+    out["xgmi_recv_GBps_per_gpu"] = (recv / (out["halo_ms"] * 1e-3) / 1e9) if out["halo_ms"] > 0 else None
+    out["halo_mode"], out["halo_fraction"] = s.halo_mode, round(float(s.halo_fraction), 4)
+    return out
+
+
 # --------------------------------------------------------------------------------------------------
 # data parallelism over independent graphs (Duvenaud / GNO mini-batches; SURVEY.md 8e)
 # --------------------------------------------------------------------------------------------------

@@ -489,6 +489,9 @@ def main_gno(args, world, rank, dev, one_device):
            "parity": parity}
     ok = parity["ok"]
     if world > 1:
+        with phase("breakdown (each part timed alone)", factor=2.0):
+            out["breakdown"] = adist.measure_breakdown_gno(step)
+        out["breakdown"]["note"] = "each part timed alone after the timed loop, rank 0 (events); in the step the exchanges run under the interior work"
         err = transport_error(str(shard.transport), one_device)
         if err:
             out["ok"], out["error"], ok = False, err, False

@@ -812,6 +812,9 @@ def test_bench_py_gno_mesh_config(dev, gpus):
     assert cfg["vertices"] == 48000 and any(cfg["S_kept_per_block"]) and cfg["edge_columns_per_gpu"] > 0
     if gpus > 1:
         assert cfg["transport"].startswith("shm") and cfg["halo_rows_per_gpu"] > 0 and line["scaling"] == "strong"
+        for k in ("halo_ms", "fwd_interior_ms", "fwd_boundary_ms", "bwd_dtheta_ms", "bwd_pull_interior_ms", "bwd_pull_boundary_ms",
+                  "halo_recv_bytes_per_gpu_per_step", "xgmi_recv_GBps_per_gpu"):
+            assert k in line["breakdown"], k
     else:
         assert cfg["halo_rows_per_gpu"] == 0
 
