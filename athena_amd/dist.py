@@ -915,6 +915,38 @@ def measure_breakdown(step, iters=5):
 # ONE graph with edge features cut by rows: the graph neural operator on a partitioned mesh (SURVEY.md 8e:
 # "GNO: as Kipf plus replicated theta and all-reduce of dtheta"; BASELINE configs[3] is one 2 M-vertex mesh)
 # --------------------------------------------------------------------------------------------------
+def locality_order(adj_ia, adj_ja):
+    """A vertex numbering under which a CONTIGUOUS row block is a compact piece of the graph, for graphs that arrive in an
+    arbitrary order and carry no coordinates (the layers only see edge geometry): reverse Cuthill-McKee on the CSR pattern
+    (scipy, host, 0.05 s per 200 k vertices) -- the optional offline reordering SURVEY.md 8e names.  Returns `perm` with
+    perm[k] = old id (0-based) of the vertex numbered k.  On the configs[3] generator's mesh numbered as drawn, 8 row blocks
+    need 5.8 x their own row count as halo rows; under this order 0.12 - 0.44 x; under the Morton order of the points' cells
+    (synth.radius_graph(order="cells"), which needs the coordinates) 0.11 - 0.13 x."""
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
+    ia = np.asarray(adj_ia, np.int64) - 1
+    n = ia.size - 1
+    a = sp.csr_matrix((np.ones(ia[-1], np.int8), np.asarray(adj_ja[0], np.int64) - 1, ia), shape=(n, n))
+    return np.asarray(reverse_cuthill_mckee(a, symmetric_mode=True), np.int64)
+
+
+def permute_csr(adj_ia, adj_ja, perm):
+    """the same graph with vertex perm[k] renamed k: rows re-ordered, neighbour ids renamed, the order of the entries inside a
+    row and their edge ids kept (edge features are untouched; vertex features follow as x[perm]).  Fortran-convention arrays."""
+    perm = np.asarray(perm, np.int64)
+    n = perm.size
+    inv = np.empty(n, np.int64)
+    inv[perm] = np.arange(n)
+    ia = np.asarray(adj_ia, np.int64) - 1
+    counts = (ia[1:] - ia[:-1])[perm]
+    new_ia = np.concatenate([[0], np.cumsum(counts)])
+    src = np.repeat(ia[:-1][perm], counts) + (np.arange(new_ia[-1]) - np.repeat(new_ia[:-1], counts))   # old entry of each new entry
+    ja = np.empty((2, src.size), np.int32, order="F")
+    ja[0] = inv[np.asarray(adj_ja[0], np.int64)[src] - 1] + 1
+    ja[1] = np.asarray(adj_ja[1])[src]
+    return (new_ia + 1).astype(np.int32), ja
+
+
 def make_mesh_shard(rank, world, n_points, device=None, mean_degree=15.0, seed=4, mesh=None):
     """rank's contiguous row block of the radius mesh synth.radius_graph(n_points, order="cells") -- BASELINE configs[3]'s
     generator with the points numbered in Morton order of their cell, so a block is a compact region and its halo a thin

@@ -410,3 +410,31 @@ def test_node_partitioned_gno_layer_matches_the_single_process_oracle(oracle, wo
         want = mode if mode != "auto" else ("allgather" if res[r]["halo_fraction"] > 0.7 else "p2p")
         assert res[r]["halo_mode"] == want
     assert sum(res[r]["n_int"] for r in range(world)) > 0 or world == 8      # compact blocks keep interior rows
+
+
+def test_locality_order_shrinks_the_halo_of_a_mesh_numbered_at_random(oracle):
+    """dist.locality_order (reverse Cuthill-McKee on the CSR pattern: no coordinates needed) + dist.permute_csr: the renamed
+    graph is the same graph (kipf_propagate of the permuted features is the permuted result, bit for bit; edge ids travel with
+    their entries), and contiguous row blocks of it need a fraction of the halo rows of the random numbering."""
+    from athena_amd import dist as adist, synth
+
+    n, world = 24000, 8
+    ia, ja, coords = synth.radius_graph(n, mean_degree=10.0, seed=6)          # numbered as drawn: no locality at all
+    perm = adist.locality_order(ia, ja)
+    assert np.array_equal(np.sort(perm), np.arange(n))
+    ia2, ja2 = adist.permute_csr(ia, ja, perm)
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-1, 1, (n, 5)).astype(np.float32)
+    assert np.array_equal(oracle.kipf_propagate(x[perm], ia2, ja2), oracle.kipf_propagate(x, ia, ja)[perm])
+    # the multiset of (edge id) per renamed row is the old row's
+    for k in (0, 17, n - 1):
+        a = np.sort(ja2[1, ia2[k] - 1:ia2[k + 1] - 1]); b = np.sort(ja[1, ia[perm[k]] - 1:ia[perm[k] + 1] - 1])
+        assert np.array_equal(a, b)
+
+    def halo_rows(ia_, ja_):
+        blk = n // world
+        rows = np.repeat(np.arange(n), np.diff(ia_)); cols = ja_[0].astype(np.int64) - 1
+        return sum(np.unique(cols[(rows // blk == r) & (cols // blk != r)]).size for r in range(world))
+
+    before, after = halo_rows(ia, ja), halo_rows(ia2, ja2)
+    assert after < 0.25 * before, (before, after)
