@@ -289,8 +289,9 @@ bool want_shm()
 // gives the bench.  ATHENA_MP_COMM_TEST_DELAY_MS (tests only) parks a bounded spin kernel in front of the completion event.
 namespace {
 struct Watched {
-    hipEvent_t ev;
-    double t0, limit;
+    hipEvent_t ev, begin;   // begin (may be null): recorded on the communication stream just in front of the transfer -- the clock
+    bool started;           // starts when IT has completed, not at enqueue time (a host that runs many steps ahead of the device
+    double t0, limit;       // must not be mistaken for a stall)
     int rank, device;
     char what[96];
 };
@@ -332,7 +333,15 @@ void watch_loop()
                 continue;
             }
             (void)hipGetLastError();
-            if (q == hipErrorNotReady && now - w.t0 > w.limit) {
+            if (!w.started) {
+                if (hipEventQuery(w.begin) == hipSuccess) {
+                    w.started = true;
+                    w.t0 = now;
+                } else {
+                    (void)hipGetLastError();
+                }
+            }
+            if (q == hipErrorNotReady && w.started && now - w.t0 > w.limit) {
                 fprintf(stderr, "[athena_mp] rank %d stalled in %s for more than %.0f s (ATHENA_MP_COLLECTIVE_TIMEOUT_S): a peer is "
                                 "missing, late or in another collective\n", w.rank, w.what, w.limit);
                 printf("{\"ok\": false, \"error\": \"rank %d stalled in %s for more than %.0f s\"}\n", w.rank, w.what, w.limit);
@@ -345,7 +354,7 @@ void watch_loop()
     }
 }
 // the transfer whose completion `ev` marks has just been enqueued
-void watch_arm(hipEvent_t ev, int rank, int device, const char *what, double factor = 1.0)
+void watch_arm(hipEvent_t ev, int rank, int device, const char *what, double factor = 1.0, hipEvent_t begin = nullptr)
 {
     if (watch_timeout() <= 0.0) return;
     {
@@ -355,12 +364,15 @@ void watch_arm(hipEvent_t ev, int rank, int device, const char *what, double fac
             if (w.ev == ev) {   // the event was re-recorded: the newest transfer is the one it now stands for
                 w.t0 = watch_now();
                 w.limit = watch_timeout() * factor;
+                w.begin = begin;
+                w.started = begin == nullptr;
                 snprintf(w.what, sizeof(w.what), "%s", what);
                 found = true;
             }
         if (!found) {
             Watched w;
-            w.ev = ev; w.t0 = watch_now(); w.limit = watch_timeout() * factor; w.rank = rank; w.device = device;
+            w.ev = ev; w.begin = begin; w.started = begin == nullptr;
+            w.t0 = watch_now(); w.limit = watch_timeout() * factor; w.rank = rank; w.device = device;
             snprintf(w.what, sizeof(w.what), "%s", what);
             g_watch.push_back(w);
         }
@@ -399,6 +411,7 @@ struct athena_mp_comm {
     hipStream_t cs = nullptr;       // communication stream
     hipEvent_t ev_ready = nullptr;  // compute -> comm
     hipEvent_t ev_done = nullptr;   // comm -> compute (all-reduce)
+    hipEvent_t ev_begin = nullptr;  // in front of the all-reduce on the communication stream (the deadline's clock)
     int device = 0;
 };
 
@@ -426,6 +439,7 @@ struct athena_mp_shard {
     int32_t with_edges = 0, n_edge_cols = 0;
     std::vector<int64_t> edge_ids;         // [n_edge_cols] global edge id (0-based) of each local edge column
     hipEvent_t ev_halo[2] = {};            // comm -> compute, one per slot
+    hipEvent_t ev_halo_b[2] = {};          // in front of each slot's transfer (the deadline's clock)
     float *send_buf[2] = {};
     size_t send_cap[2] = {};
 };
@@ -601,7 +615,8 @@ int athena_mp_comm_create(int32_t rank, int32_t world, const void *id128, athena
     c->t->world = world;
     if (hipStreamCreateWithFlags(&c->cs, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_begin, hipEventDisableTiming) != hipSuccess) {
         set_error("comm_create: cannot create the communication stream / events");
         delete c->t;
         delete c;
@@ -732,6 +747,7 @@ int athena_mp_comm_destroy(athena_mp_comm *c)
         watch_forget(c->ev_done);
         (void)hipEventDestroy(c->ev_done);
     }
+    if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
     if (c->cs) (void)hipStreamDestroy(c->cs);
     delete c;
     return 0;
@@ -757,10 +773,11 @@ int athena_mp_allreduce_start(athena_mp_comm *c, float *buf_dev, int64_t count)
     if (c->t->world == 1 || count == 0) return 0;
     AMP_HIP(hipEventRecord(c->ev_ready, amp::stream()));
     AMP_HIP(hipStreamWaitEvent(c->cs, c->ev_ready, 0));
+    AMP_HIP(hipEventRecord(c->ev_begin, c->cs));
     if (c->t->allreduce_f32(buf_dev, (size_t)count, c->cs)) return 1;
     test_delay(c->cs);
     AMP_HIP(hipEventRecord(c->ev_done, c->cs));
-    watch_arm(c->ev_done, c->t->rank, c->device, "the all-reduce of the parameter gradients (athena_mp_allreduce_start)");
+    watch_arm(c->ev_done, c->t->rank, c->device, "the all-reduce of the parameter gradients (athena_mp_allreduce_start)", 1.0, c->ev_begin);
     return 0;
 }
 int athena_mp_allreduce_finish(athena_mp_comm *c)
@@ -806,6 +823,7 @@ int athena_mp_shard_destroy(athena_mp_shard *s)
             watch_forget(s->ev_halo[k]);
             (void)hipEventDestroy(s->ev_halo[k]);
         }
+        if (s->ev_halo_b[k]) (void)hipEventDestroy(s->ev_halo_b[k]);
     }
     delete s;
     return 0;
@@ -1128,7 +1146,9 @@ static int shard_create_impl(athena_mp_comm *c, int32_t n_local, int64_t nnz, co
     SH_RC(make_graph(ia, col_b, pe_b, s->n_edge_cols, 0, s->n_int, ncols, s->row_deg, s->col_deg, &s->g[2]));
     SH_RC(make_graph(ia, col_b, pe_b, s->n_edge_cols, s->n_int, n, ncols, s->row_deg, s->col_deg, &s->g[3]));
     for (int k = 0; k < 2; ++k)
-        if (hipEventCreateWithFlags(&s->ev_halo[k], hipEventDisableTiming) != hipSuccess) SH_FAIL("shard_create: cannot create events");
+        if (hipEventCreateWithFlags(&s->ev_halo[k], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s->ev_halo_b[k], hipEventDisableTiming) != hipSuccess)
+            SH_FAIL("shard_create: cannot create events");
 #undef SH_FAIL
 #undef SH_RC
     *out = s;
@@ -1243,11 +1263,13 @@ int athena_mp_halo_start(athena_mp_shard *s, int32_t slot, int32_t F, float *x_e
         // every rank lands at row max_n * (1 + p).  No pack kernel, no send list, one collective.
         AMP_HIP(hipEventRecord(c->ev_ready, amp::stream()));
         AMP_HIP(hipStreamWaitEvent(c->cs, c->ev_ready, 0));
+        AMP_HIP(hipEventRecord(s->ev_halo_b[slot], c->cs));
         const size_t block = sizeof(float) * (size_t)s->max_n * F;
         if (c->t->allgather(x_ext_dev, x_ext_dev + (size_t)s->max_n * F, block, c->cs)) return 1;
         test_delay(c->cs);
         AMP_HIP(hipEventRecord(s->ev_halo[slot], c->cs));
-        watch_arm(s->ev_halo[slot], rank, c->device, slot ? "the halo exchange in slot 1 (all-gather of whole blocks)" : "the halo exchange in slot 0 (all-gather of whole blocks)");
+        watch_arm(s->ev_halo[slot], rank, c->device, slot ? "the halo exchange in slot 1 (all-gather of whole blocks)" : "the halo exchange in slot 0 (all-gather of whole blocks)",
+                  1.0, s->ev_halo_b[slot]);
         return 0;
     }
     const size_t need = sizeof(float) * (size_t)std::max<int64_t>(s->n_send, 1) * F;
@@ -1266,6 +1288,7 @@ int athena_mp_halo_start(athena_mp_shard *s, int32_t slot, int32_t F, float *x_e
     }
     AMP_HIP(hipEventRecord(c->ev_ready, amp::stream()));      // the pack, and every earlier reader of the halo rows
     AMP_HIP(hipStreamWaitEvent(c->cs, c->ev_ready, 0));
+    AMP_HIP(hipEventRecord(s->ev_halo_b[slot], c->cs));
     std::vector<const void *> sp(W, nullptr);
     std::vector<void *> rp(W, nullptr);
     std::vector<size_t> sb(W, 0), rb(W, 0);
@@ -1279,7 +1302,8 @@ int athena_mp_halo_start(athena_mp_shard *s, int32_t slot, int32_t F, float *x_e
     if (c->t->exchange(sp.data(), sb.data(), rp.data(), rb.data(), c->cs)) return 1;
     test_delay(c->cs);
     AMP_HIP(hipEventRecord(s->ev_halo[slot], c->cs));
-    watch_arm(s->ev_halo[slot], rank, c->device, slot ? "the halo exchange in slot 1 (grouped send / recv)" : "the halo exchange in slot 0 (grouped send / recv)");
+    watch_arm(s->ev_halo[slot], rank, c->device, slot ? "the halo exchange in slot 1 (grouped send / recv)" : "the halo exchange in slot 0 (grouped send / recv)", 1.0,
+              s->ev_halo_b[slot]);
     return 0;
 }
 

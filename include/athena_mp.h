@@ -515,8 +515,10 @@ int athena_mp_halo_start(athena_mp_shard *s, int32_t slot, int32_t F, float *x_e
 /* DEADLINES.  No RCCL collective has a completion deadline of its own, and the host never blocks in _halo_start /
  * _allreduce_start, so a rank whose peer is missing would hang in its next synchronize, far from the cause.  Every transfer
  * this library starts (halo exchange, gradient all-reduce, the metadata collectives of athena_mp_shard_create,
- * athena_mp_comm_barrier) is therefore watched through its completion event by a monitor thread: still pending after
- * ATHENA_MP_COLLECTIVE_TIMEOUT_S seconds (default 120; x5 for the metadata collectives and the barrier; 0 = no monitor) the
+ * athena_mp_comm_barrier) is therefore watched through its completion event by a monitor thread: still pending
+ * ATHENA_MP_COLLECTIVE_TIMEOUT_S seconds (default 120; x5 for the metadata collectives and the barrier; 0 = no monitor) after
+ * it actually STARTED (an event just in front of it on the communication stream has completed: a host that enqueues many
+ * steps ahead of the device is not mistaken for a stall) the
  * PROCESS ends -- "[athena_mp] rank r stalled in <transfer> ..." on stderr, {"ok": false, "error": ...} on stdout, exit code
  * 3; no retry, no cleanup that could block in the same communicator.  (The bootstrap of _comm_create_from_file has its own
  * ATHENA_MP_BOOTSTRAP_TIMEOUT_S.) */
