@@ -123,8 +123,23 @@ def run_c3(dev, reps):
            "dx_rel": rel(dx[:nv].cpu().numpy(), dx_h), "de_rel": rel(de[torch.from_numpy(eids).to(dev)].cpu().numpy(), de_h[eids]), "tol": TOL}
     par["ok"] = bool(par["propagate_bit_exact"] and all(par[k] <= TOL for k in ("z_rel", "readout_rel", "dc_rel", "da_rel", "dx_rel", "de_rel")))
     step = sum(t.values())
+    # the CPU path beside it: the same ops, same order, the oracle on one thread, first 20 000 graphs
+    NC = 20000
+    nvc = int(voff[NC]); iac = ia[:nvc + 1]; jac = np.asfortranarray(ja[:, :ia[nvc] - 1]); nec = int(jac[1].max())
+    xc, ec, gc = x[:nvc].cpu().numpy(), e[:nec].cpu().numpy(), gout[:NC].cpu().numpy()
+    t0 = time.perf_counter()
+    a_c = o.duvenaud_propagate(xc, ec, iac, jac); z_c = o.activation("sigmoid", o.duvenaud_update(a_c, Wh, iac, mn, mx, Fv))
+    p_c = o.softmax_cols(o.matmul(Rh, z_c, O)); o.segment_sum(p_c, voff[:NC + 1])
+    dl_c = o.softmax_cols_bwd(p_c, np.repeat(gc, np.diff(voff[:NC + 1]), axis=0)); o.matmul_dw(dl_c, z_c)
+    dc_c = o.activation_bwd("sigmoid", z_c, o.matmul_dx(Rh, dl_c, Fv)); o.duvenaud_update_bwd_w(dc_c, a_c, iac, mn, mx)
+    da_c = o.duvenaud_update_bwd_a(dc_c, Wh, iac, mn, mx, Fc); o.duvenaud_propagate_bwd_x(da_c, Fv, iac, jac); o.duvenaud_propagate_bwd_e(da_c, Fv, nec, iac, jac)
+    tc = time.perf_counter() - t0
+    entc = int(iac[-1] - 1)
+    cpu = {"value": entc / tc, "unit": "entries/s", "cores": 1, "kind": "port",
+           "sample": f"oracle, first {NC} graphs = {entc} entries, one time step fwd+bwd, {tc:.2f} s"}
     return {"config": "configs[2]", "workload": f"Duvenaud msgpass, {S} QM9-shaped graphs = {N} vertices / {nnz} entries, F_v = {Fv}, F_e = {Fe}, "
-            f"{O} outputs, one time step + readout, fwd+bwd", "step_ms": round(step, 4), "entries_per_s": nnz / step * 1e3, "ops": opsd, "parity": par}
+            f"{O} outputs, one time step + readout, fwd+bwd", "step_ms": round(step, 4), "entries_per_s": nnz / step * 1e3, "ops": opsd, "parity": par,
+            "cpu_baseline": cpu}
 
 
 def run_c4(dev, reps):
@@ -210,10 +225,24 @@ def run_c4(dev, reps):
                      and par["dtheta_adjoint_rel"] <= TOL and torch.isfinite(dth).all().item())
     step = t["fwd_keeps_S"] + t["bwd_x+theta_one_contraction"]
     step_sep = t["fwd_keeps_S"] + t["bwd_x"] + t["bwd_theta_S_kept"]
+    # the CPU path beside it: the reference's MATERIALISING algorithm (kappa [F_out F_in, E]) is infeasible at this size (246 GB);
+    # the oracle runs it on a 2 000-vertex mesh of the same generator and widths
+    ns = 2000
+    sia_c, sja_c, cs_c = synth.radius_graph(ns, seed=9)
+    rs = np.random.default_rng(5)
+    xs_c = rs.uniform(-1, 1, (ns, Fi)).astype(np.float32); gs_c = rs.uniform(-1, 1, (ns, Fo)).astype(np.float32)
+    t0 = time.perf_counter()
+    kap_s = o.gno_kernel_eval(cs_c, th, H, Fo * Fi); o.gno_aggregate(xs_c, kap_s, sia_c, sja_c, Fo)
+    o.gno_aggregate_bwd_x(gs_c, kap_s, sia_c, sja_c, Fi); dk_s = o.gno_aggregate_bwd_k(gs_c, xs_c, cs_c.shape[0], sia_c, sja_c)
+    o.gno_kernel_bwd_theta(cs_c, th, dk_s, H)
+    tc = time.perf_counter() - t0
+    cpu = {"value": sja_c.shape[1] / tc, "unit": "entries/s", "cores": 1, "kind": "port",
+           "sample": f"materialising oracle (the reference's algorithm), radius mesh of {ns} vertices = {sja_c.shape[1]} entries / {cs_c.shape[0]} edge "
+                     f"columns, same widths, forward + dx + dtheta, {tc:.1f} s"}
     return {"config": "configs[3]" + (" (vertices in cell order)" if MESH_ORDER else ""), "workload": f"GNO aggregation, radius mesh {N} vertices / {nnz} entries / {E} edge columns, F_in = F_out = H = 64, d = 3, "
             "training step = forward (keeps S) + reverse pass (dx and dtheta from one contraction)", "step_ms": round(step, 3),
             "step_ms_separate_reverse_launches": round(step_sep, 3), "entries_per_s": nnz / step * 1e3,
-            "s_kept_GB": round(s_bytes / 1e9, 2), "ops": opsd, "parity": par}
+            "s_kept_GB": round(s_bytes / 1e9, 2), "ops": opsd, "parity": par, "cpu_baseline": cpu}
 
 
 def run_c5(dev, reps):
