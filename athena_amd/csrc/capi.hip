@@ -487,9 +487,19 @@ void key_array(KeyHash &h, const int32_t *p, int64_t count)
     if (n_thr == 1) {
         work(0);
     } else {
+        // a thread that cannot be started (process limits) must not become an exception across the C ABI: the chunks it
+        // would have taken are hashed here instead -- same digests, same key
         std::vector<std::thread> pool;
-        for (int t = 1; t < n_thr; ++t) pool.emplace_back(work, t);
+        std::vector<int> orphan;
+        for (int t = 1; t < n_thr; ++t) {
+            try {
+                pool.emplace_back(work, t);
+            } catch (...) {
+                orphan.push_back(t);
+            }
+        }
         work(0);
+        for (int t : orphan) work(t);
         for (auto &th : pool) th.join();
     }
     for (uint64_t d : dig) h.word(d);

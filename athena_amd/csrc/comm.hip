@@ -378,7 +378,13 @@ void watch_arm(hipEvent_t ev, int rank, int device, const char *what, double fac
         }
     }
     bool expected = false;
-    if (g_watch_started.compare_exchange_strong(expected, true)) std::thread(watch_loop).detach();
+    if (g_watch_started.compare_exchange_strong(expected, true)) {
+        try {
+            std::thread(watch_loop).detach();
+        } catch (...) {   // no thread to be had: the transfers run unwatched, as before round 4
+            fprintf(stderr, "[athena_mp] the deadline monitor could not be started; collectives run without a deadline\n");
+        }
+    }
 }
 void watch_forget(hipEvent_t ev)   // before the event is destroyed
 {
