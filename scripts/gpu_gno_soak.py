@@ -34,6 +34,13 @@ for N, d in [(50, 3), (777, 2), (4099, 3), (33000, 1), (300000, 3)]:
         return m
     legs["fwd_save"] = fwd_save
     legs["dtheta_saved"] = lambda: ops.gno_aggregate_bwd_theta(g, theta, co, x, gup, d, H, s_save=keep[0])
+    # round 4: the reverse pass from ONE contraction (per-entry partials of dx through HBM + gather); its three outputs as one
+    # tensor so that every launch is compared in full
+    def bwd_one():
+        dx1, dth1, dc1, fused = ops.gno_aggregate_bwd(g, theta, co, x, gup, d, H, s_save=keep[0], need_dcoords=True)
+        assert fused
+        return torch.cat([dx1.reshape(-1), dth1.reshape(-1), dc1.reshape(-1)])
+    legs["bwd_one_contraction"] = bwd_one
     for name, fn in legs.items():
         first = fn()
         assert torch.isfinite(first).all(), (N, name)
@@ -41,5 +48,9 @@ for N, d in [(50, 3), (777, 2), (4099, 3), (33000, 1), (300000, 3)]:
             assert torch.equal(fn(), first), (N, name, "differs between launches")
         tot += REPS
     assert torch.equal(legs["fwd_save"](), legs["fwd"]()) and torch.equal(legs["dtheta_saved"](), legs["dtheta"]())
+    one = legs["bwd_one_contraction"]()
+    dx_sep = legs["dx"]().reshape(-1)
+    assert (one[:dx_sep.numel()] - dx_sep).abs().max().item() <= 1e-5 * dx_sep.abs().max().item(), (N, "one-contraction dx vs the dx launch")
+    assert torch.equal(one[dx_sep.numel():dx_sep.numel() + theta.numel()], legs["dtheta"]()), (N, "dtheta bits")
     print(f"N={N} d={d}: {len(legs) * REPS} launches identical", flush=True)
 print(f"soak ok: {tot} launches in {time.time() - t0:.1f} s")
