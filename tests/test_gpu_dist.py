@@ -19,6 +19,20 @@ from test_dist_gloo import ROOT, _free_port
 pytestmark = pytest.mark.gpu
 
 
+def _shm_dirs():
+    try:
+        return {d for d in os.listdir("/dev/shm") if d.startswith("athena_mp_")}
+    except OSError:
+        return set()
+
+
+def _remove_shm_dirs(before):
+    """ranks that a watchdog ended on purpose (os._exit / _exit) cannot tidy the test transport's directory: the test does"""
+    import shutil
+    for d in _shm_dirs() - before:
+        shutil.rmtree(os.path.join("/dev/shm", d), ignore_errors=True)
+
+
 def _worker(rank, world, port, n, pairs, F, cut, q, Fo=None, mode="p2p"):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ATHENA_MP_HALO_MODE=mode)
@@ -781,9 +795,11 @@ def test_bench_py_fails_fast_when_a_rank_stalls(dev, where, phase):
                ATHENA_MP_BENCH_STALL=f"1:{where}")
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
     t0 = time.time()
+    shm_before = _shm_dirs()
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                         "--nodes", "20000", "--pairs", "90000"], env=env, capture_output=True, text=True, timeout=600)
     took = time.time() - t0
+    _remove_shm_dirs(shm_before)
     assert r.returncode != 0, r.stdout[-2000:]
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert lines and lines[-1]["ok"] is False, (r.stdout[-1500:], r.stderr[-1500:])
@@ -832,9 +848,11 @@ def test_c_abi_transfers_have_a_deadline_of_their_own(dev, tmp_path):
     env = dict(os.environ, ATHENA_MP_COMM_TRANSPORT="shm", ATHENA_MP_COLLECTIVE_TIMEOUT_S="2", ATHENA_MP_COMM_TEST_DELAY_MS="6000",
                ATHENA_MP_HALO_MODE="p2p")
     prefix = str(tmp_path / "run")
+    shm_before = _shm_dirs()
     procs = [subprocess.Popen([exe, str(r), "2", "0", str(tmp_path / "id"), "4000", "16000", "64", prefix], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in range(2)]
     outs = [p.communicate(timeout=300) for p in procs]
+    _remove_shm_dirs(shm_before)
     for r, (p, (so, se)) in enumerate(zip(procs, outs)):
         assert p.returncode == 3, (r, p.returncode, so.decode()[-500:], se.decode()[-800:])
         assert f"rank {r} stalled in the halo exchange in slot 0" in se.decode()
