@@ -745,6 +745,41 @@ def main():
         err = transport_error(str(info.get("transport", "")), one_device)
         if err:
             out["ok"], out["error"], ok = False, err, False
+    if world == 1:
+        # "activation = none for the headline; relu epilogue reported separately" -- the same step with the
+        # layer's activation: relu in the forward launch's store (athena_mp_kipf_layer_fwd, act = relu), its reverse factor as one
+        # elementwise launch in front of dW and the fused pull.  Timed after the headline's loop; never part of `value`.
+        try:
+            Y = torch.empty((N, F), device=dev)
+            dzr = torch.empty((N, F), device=dev)
+
+            def relu_step():
+                ops.kipf_layer_fwd(g, xd, wd, F, act="relu", P=P, Z=Y)
+                ops.activation_bwd("relu", Y, dzd, out=dzr)
+                ops.matmul_dw(P, dzr, out=dW)
+                ops.kipf_layer_bwd_x(g, dzr, wd, F, out=dX)
+
+            for _ in range(3):
+                relu_step()
+            torch.cuda.synchronize()
+            k = max(5, args.steps // 5)
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(k):
+                relu_step()
+            e1.record()
+            torch.cuda.synchronize()
+            relu_ms = e0.elapsed_time(e1) / k
+            out["relu_epilogue"] = {"ms_per_step": relu_ms, "value": nnz_total / (relu_ms * 1e-3), "unit": "edges/s", "steps": k,
+                                    "note": "the same step with activation relu: fused into the forward launch's store; reverse factor = one "
+                                            "elementwise launch (reads y and dz, writes dz') in front of dW and the fused pull"}
+            if not args.no_cpu_baseline and "parity" in out and out["parity"] and ref["full"]:
+                from oracle import oracle as _o
+                r_ = min(ref["rows"], 20000)
+                out["relu_epilogue"]["Z_rel_first_rows"] = rel(Y[:r_].cpu().numpy(), _o.activation("relu", ref["z"][:r_]))
+            del Y, dzr
+        except Exception as exc:      # reported beside the headline, never instead of it
+            out["relu_epilogue"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
     if world == 1 and not args.no_secondary and not args.custom and args.config == "c2":
         # free the headline's tensors first: configs[3] keeps 33 GB of S and configs[4] holds 50 GB in the children
         P = Z = dW = dX = xd = dzd = g = None

@@ -864,3 +864,36 @@ def test_c_abi_transfers_have_a_deadline_of_their_own(dev, tmp_path):
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
+
+
+def test_bench_line_on_one_gpu_carries_what_the_driver_reads(dev):
+    """`python bench.py` (N = 1, the command the driver issues; here with one CPU run and only configs[2] in the secondary block
+    to keep it short): ONE json line with the contract's fields, `roofline` incl. the copy ceiling measured in the same run,
+    `cpu_baseline` with its per-run times, `parity.ok`, the relu-epilogue step reported separately, and
+    `secondary` as a block of its own whose failure would not touch `value`."""
+    import json
+    import subprocess
+
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "ATHENA_MP_BENCH_ONE_DEVICE", "ATHENA_MP_BENCH_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--cpu-runs", "1",
+                        "--secondary", "c3"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "parity"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 10 and d["unit"] == "edges/s" and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert "configs[1]" in d["config"]["workload"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and 0.5 < rf["frac"] < 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert 3000 < rf["measured_copy_ceiling_GBps"] < 8000 and rf["dense"]["bound"] == "mfma"
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1 and len(d["cpu_baseline"]["runs_s"]) == 1
+    assert d["parity"]["ok"] and d["parity"]["P_bit_exact"]
+    assert d["relu_epilogue"]["ms_per_step"] > d["ms_per_step"] * 0.9 and d["relu_epilogue"]["Z_rel_first_rows"] <= 1e-5
+    sec = d["secondary"]
+    assert "error" not in sec and sec["configs[2]"]["parity"]["ok"] and sec["configs[2]"]["step_ms"] > 0
+    assert "cpu_baseline" in sec["configs[2]"] and set(sec) >= {"note", "configs[2]", "wall_s"}
