@@ -121,6 +121,8 @@ _PROTOS = {
     "athena_mp_shard_export": [_vp, _i32, _vp, _i64, C.POINTER(_i64)],
     "athena_mp_halo_start": [_vp, _i32, _i32, _vp],
     "athena_mp_halo_finish": [_vp, _i32],
+    "athena_mp_halo_reduce_start": [_vp, _i32, _i32, _vp],
+    "athena_mp_halo_reduce_finish": [_vp, _i32, _vp],
     "athena_mp_resident_mode": [_i32],
     "athena_mp_resident_acquire": [_vp, C.c_uint64, _i32, C.POINTER(_vp)],
     "athena_mp_resident_release": [_vp, _i32],

@@ -448,6 +448,9 @@ struct athena_mp_shard {
     hipEvent_t ev_halo_b[2] = {};          // in front of each slot's transfer (the deadline's clock)
     float *send_buf[2] = {};
     size_t send_cap[2] = {};
+    float *red_buf[2] = {};                // halo REDUCE: what the peers computed for this rank's rows, grouped by peer
+    size_t red_cap[2] = {};
+    int32_t red_F[2] = {};
 };
 
 using namespace amp;
@@ -558,6 +561,23 @@ int make_graph(const std::vector<int32_t> &ia_all, const std::vector<int32_t> &c
 }
 
 } // namespace
+
+// halo REDUCE, the transpose of the halo exchange: rows a rank computed FOR remote vertices travel to their owners and are added
+// there.  One launch per peer in peer order (a row may be owed by several peers: their shares are added one after the other,
+// the same order on every run), 16-byte lanes over F floats.
+__global__ void halo_add_rows_kernel(const float *__restrict__ recv, const int32_t *__restrict__ idx, int64_t n, int F, float *__restrict__ y)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = F / 4;
+    if (t >= n * q) return;
+    const int64_t r = t / q;
+    const int c = (int)(t - r * q);
+    const int64_t dst = idx ? idx[r] : r;
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    v4 a = *reinterpret_cast<const v4 *>(recv + r * F + 4 * c);
+    v4 *o = reinterpret_cast<v4 *>(y + dst * F + 4 * c);
+    *o = *o + a;
+}
 
 extern "C" {
 
@@ -825,6 +845,7 @@ int athena_mp_shard_destroy(athena_mp_shard *s)
     if (s->send_idx) (void)hipFree(s->send_idx);
     for (int k = 0; k < 2; ++k) {
         if (s->send_buf[k]) (void)hipFree(s->send_buf[k]);
+        if (s->red_buf[k]) (void)hipFree(s->red_buf[k]);
         if (s->ev_halo[k]) {
             watch_forget(s->ev_halo[k]);
             (void)hipEventDestroy(s->ev_halo[k]);
@@ -1310,6 +1331,80 @@ int athena_mp_halo_start(athena_mp_shard *s, int32_t slot, int32_t F, float *x_e
     AMP_HIP(hipEventRecord(s->ev_halo[slot], c->cs));
     watch_arm(s->ev_halo[slot], rank, c->device, slot ? "the halo exchange in slot 1 (grouped send / recv)" : "the halo exchange in slot 0 (grouped send / recv)", 1.0,
               s->ev_halo_b[slot]);
+    return 0;
+}
+
+/* Halo REDUCE (the transpose of the exchange): y_ext [n + n_halo, F] holds, in its rows beyond the local ones, what this rank
+ * computed for REMOTE vertices (e.g. the feature gradient of a scatter-form reverse pass); _start sends every such row to its
+ * owner (p2p mode: the contiguous segment of each owner; all-gather mode: the whole block of each owner) and receives what
+ * the peers computed for this rank's rows; _finish adds the received rows into y_local [n, F] on the compute stream, peer by
+ * peer in rank order (deterministic).  Same streams, events, deadline and slots as athena_mp_halo_start / _finish; a slot
+ * carries either an exchange or a reduce at a time.  F must be a multiple of 4. */
+int athena_mp_halo_reduce_start(athena_mp_shard *s, int32_t slot, int32_t F, const float *y_ext_dev)
+{
+    AMP_REQUIRE(s && (slot == 0 || slot == 1) && F > 0 && F % 4 == 0 && (y_ext_dev || s->n + s->ext_rows == 0), "halo_reduce_start: bad arguments");
+    athena_mp_comm *c = s->comm;
+    const int W = c->t->world, rank = c->t->rank;
+    s->red_F[slot] = F;
+    if (W == 1) return 0;
+    const int64_t recv_rows = s->mode == 1 ? s->max_n * (int64_t)W : s->n_send;
+    const size_t need = sizeof(float) * (size_t)std::max<int64_t>(recv_rows, 1) * F;
+    if (s->red_cap[slot] < need) {
+        if (s->red_buf[slot]) {
+            AMP_HIP(hipStreamSynchronize(c->cs));
+            AMP_HIP(hipStreamSynchronize(amp::stream()));
+            AMP_HIP(hipFree(s->red_buf[slot]));
+            s->red_buf[slot] = nullptr;
+        }
+        AMP_HIP(hipMalloc((void **)&s->red_buf[slot], need));
+        s->red_cap[slot] = need;
+    }
+    AMP_HIP(hipEventRecord(c->ev_ready, amp::stream()));      // the kernels that produced y_ext, and the last reader of red_buf
+    AMP_HIP(hipStreamWaitEvent(c->cs, c->ev_ready, 0));
+    AMP_HIP(hipEventRecord(s->ev_halo_b[slot], c->cs));
+    std::vector<const void *> sp(W, nullptr);
+    std::vector<void *> rp(W, nullptr);
+    std::vector<size_t> sb(W, 0), rb(W, 0);
+    for (int p = 0; p < W; ++p) {
+        if (p == rank) continue;
+        if (s->mode == 1) {   // whole blocks: block p of x_ext goes to rank p, every peer's block for this rank comes back
+            sp[p] = y_ext_dev + (size_t)s->max_n * (1 + p) * F;
+            sb[p] = sizeof(float) * (size_t)s->max_n * F;
+            rp[p] = s->red_buf[slot] + (size_t)s->max_n * p * F;
+            rb[p] = sizeof(float) * (size_t)s->max_n * F;
+        } else {              // the roles of the exchange's send and receive lists swapped
+            sp[p] = y_ext_dev + ((size_t)s->n + (size_t)s->roff[p]) * F;
+            sb[p] = sizeof(float) * (size_t)s->recv_counts[p] * F;
+            rp[p] = s->red_buf[slot] + (size_t)s->soff[p] * F;
+            rb[p] = sizeof(float) * (size_t)s->send_counts[p] * F;
+        }
+    }
+    if (c->t->exchange(sp.data(), sb.data(), rp.data(), rb.data(), c->cs)) return 1;
+    test_delay(c->cs);
+    AMP_HIP(hipEventRecord(s->ev_halo[slot], c->cs));
+    watch_arm(s->ev_halo[slot], rank, c->device, slot ? "the halo reduce in slot 1" : "the halo reduce in slot 0", 1.0, s->ev_halo_b[slot]);
+    return 0;
+}
+
+int athena_mp_halo_reduce_finish(athena_mp_shard *s, int32_t slot, float *y_local_dev)
+{
+    AMP_REQUIRE(s && (slot == 0 || slot == 1) && (y_local_dev || s->n == 0), "halo_reduce_finish: bad arguments");
+    athena_mp_comm *c = s->comm;
+    const int W = c->t->world, rank = c->t->rank, F = s->red_F[slot];
+    if (W == 1) return 0;
+    AMP_REQUIRE(F > 0, "halo_reduce_finish: no reduce was started in slot %d", slot);
+    AMP_HIP(hipStreamWaitEvent(amp::stream(), s->ev_halo[slot], 0));
+    for (int p = 0; p < W; ++p) {
+        if (p == rank) continue;
+        const int64_t rows = s->mode == 1 ? s->n : s->send_counts[p];
+        if (rows == 0) continue;
+        const float *src = s->red_buf[slot] + (size_t)(s->mode == 1 ? s->max_n * (int64_t)p : s->soff[p]) * F;
+        const int32_t *idx = s->mode == 1 ? nullptr : s->send_idx + s->soff[p];
+        const int64_t threads = rows * (F / 4);
+        hipLaunchKernelGGL(halo_add_rows_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, amp::stream(), src, idx, rows, F,
+                           y_local_dev);
+        AMP_LAUNCH_CHECK();
+    }
     return 0;
 }
 

@@ -416,6 +416,24 @@ class _CExchange:
         self.finish()
         return x_ext
 
+    # the transpose: rows computed for remote vertices go to their owners and are added there (athena_mp_halo_reduce_*)
+    def reduce_start(self, y_ext):
+        from . import _capi
+        import ctypes as C
+        if tuple(y_ext.shape) != (self.s.n + self.s.n_halo, self.F) or not y_ext.is_contiguous():
+            raise ValueError(f"halo reduce: y_ext must be contiguous [{self.s.n + self.s.n_halo}, {self.F}]")
+        _capi.use_torch_stream()
+        _capi.call("athena_mp_halo_reduce_start", self.s.handle, self.slot, self.F, C.c_void_p(y_ext.data_ptr()))
+        return self
+
+    def reduce_finish(self, y_local, _reqs=None):
+        from . import _capi
+        import ctypes as C
+        if tuple(y_local.shape) != (self.s.n, self.F) or not y_local.is_contiguous():
+            raise ValueError(f"halo reduce: y_local must be contiguous [{self.s.n}, {self.F}]")
+        _capi.use_torch_stream()
+        _capi.call("athena_mp_halo_reduce_finish", self.s.handle, self.slot, C.c_void_p(y_local.data_ptr()))
+
 
 class _CReduce:
     def __init__(self, comm):
@@ -641,6 +659,39 @@ class HaloExchange:
     def __call__(self, x_ext):
         self.finish(self.start(x_ext))
         return x_ext
+
+    # the transpose (mirror of athena_mp_halo_reduce_*): every rank sends what it computed for remote vertices to their owners
+    def reduce_start(self, y_ext):
+        s = self.s
+        if s.world == 1:
+            return []
+        n = s.n
+        if s.halo_mode == "allgather":       # whole blocks: block p of y_ext goes to rank p
+            self._red = torch.empty((s.world, n, self.F), dtype=y_ext.dtype, device=y_ext.device)
+            sends = [y_ext[n + p * n:n + (p + 1) * n] if p != s.rank else None for p in range(s.world)]
+            recvs = [self._red[p] if p != s.rank else None for p in range(s.world)]
+        else:
+            roff, soff = s._roff, s._soff
+            self._red = torch.empty((int(soff[-1]), self.F), dtype=y_ext.dtype, device=y_ext.device)
+            sends = [y_ext[n + roff[p]:n + roff[p + 1]] if p != s.rank else None for p in range(s.world)]
+            recvs = [self._red[soff[p]:soff[p + 1]] if p != s.rank else None for p in range(s.world)]
+        return _p2p_start([t.contiguous() if t is not None else None for t in sends], recvs, s.rank, s.world)
+
+    def reduce_finish(self, y_local, reqs=None):
+        s = self.s
+        if s.world == 1:
+            return
+        for r in reqs or []:
+            r.wait()
+        for p in range(s.world):               # peer by peer in rank order: the order the C ABI adds in
+            if p == s.rank:
+                continue
+            if s.halo_mode == "allgather":
+                y_local.add_(self._red[p])
+            else:
+                a, b = int(s._soff[p]), int(s._soff[p + 1])
+                if b > a:
+                    y_local.index_add_(0, s.send_idx[a:b].long(), self._red[a:b])
 
 
 class HipBackend:
@@ -988,7 +1039,7 @@ class GnoShardStep:
     The edge geometry stays where its rows are: a rank holds coords for the edge columns its rows reference."""
 
     def __init__(self, shard, Fi, Fo, d, H, device, backend=None, inputs=None, activation="none", use_bias=True, keep_s=None,
-                 seed=1):
+                 seed=1, reverse="auto"):
         """inputs: (x [n, Fi], up [n, Fo], theta, W [Fo*Fi], b [Fo] or None, coords [n_edge_cols, d]) host arrays, x / up
         for the rank's rows in their ORIGINAL local order; default: seeded random (theta, W, b identical on every rank)"""
         self.s, self.Fi, self.Fo, self.d, self.H, self.device = shard, Fi, Fo, d, H, device
@@ -1030,6 +1081,16 @@ class GnoShardStep:
         # the forward pass may keep S per block for the reverse pass's S^T dz; None: when the backend offers it
         self.keep_s = keep_s
         self._s = [None, None]
+        # how the feature gradient crosses the partition:
+        #   "pull"    halo exchange of dz, then dx_v = sum_{(u,e) in row v} K_e^T dz_u over the rank's own rows (needs the graph's
+        #             symmetry, checked at shard creation) -- dtheta and dx from separate launches;
+        #   "reduce"  no exchange of dz at all: athena_mp_gno_aggregate_bwd on each forward block gives dtheta AND the scatter-form
+        #             dx of every column the block's rows touch, local or not, from ONE contraction; the rows
+        #             computed for remote vertices travel to their owners (athena_mp_halo_reduce_*) under the interior block
+        if reverse not in ("auto", "pull", "reduce"):
+            raise ValueError('reverse: "auto", "pull" or "reduce"')
+        self.reverse = ("reduce" if hasattr(self.b, "gno_aggregate_bwd") and Fi % 4 == 0 else "pull") if reverse == "auto" else reverse
+        self.xchg_r = shard.exchange(Fi, device, self.b) if self.reverse == "reduce" else None
 
     def _keeps(self, g):
         if self.keep_s is False or not hasattr(self.b, "gno_saved_bytes") or g.n_rows == 0:
@@ -1085,6 +1146,8 @@ class GnoShardStep:
             self.dX.copy_(dxa)
             b.axpy(1.0, b.matmul_dx(self.W, dz, Fi), self.dX)
             return self.dX
+        if self.reverse == "reduce":
+            return self._backward_reduce(dz)
         reqs = self.xchg_o.start(self.g_ext)                                       # halo of dz in flight; under it:
         if self.use_bias:
             b.matmul_dw(self.ones, dz, out=self.db)                                # db[o] = sum_v dz[v,o]
@@ -1108,6 +1171,41 @@ class GnoShardStep:
         if n - ni:
             b.gno_aggregate_bwd_x_pull(self.g_bwd_bnd, self.theta, self.coords, self.g_ext, d, H, Fi, out=self.dX[ni:])
         b.axpy(1.0, b.matmul_dx(self.W, dz, Fi), self.dX)
+        if red is not None:
+            red.wait()
+        return self.dX
+
+    def _backward_reduce(self, dz):
+        s, b, n, ni = self.s, self.b, self.s.n, self.s.n_int
+        d, H, Fi, Fo = self.d, self.H, self.Fi, self.Fo
+        if self.use_bias:
+            b.matmul_dw(self.ones, dz, out=self.db)
+        b.matmul_dw(self.x_ext[:n], dz, out=self.dW)
+        # the boundary block first: its rows are the only ones that touch remote columns
+        if n - ni:
+            dx_b, dth_b, _, _ = b.gno_aggregate_bwd(self.g_fwd_bnd, self.theta, self.coords, self.x_ext, dz[ni:], d, H, s_save=self._s[1])
+        else:           # a rank without boundary rows sends nothing but still receives what its peers computed for it
+            dx_b = torch.zeros((n + s.n_halo, Fi), dtype=torch.float32, device=self.device)
+            dth_b = None
+        reqs = self.xchg_r.reduce_start(dx_b)                                      # remote rows on their way to their owners ...
+        dth_i = None
+        dx_i = None
+        if ni:                                                                     # ... under the interior block
+            dx_i, dth_i, _, _ = b.gno_aggregate_bwd(self.g_fwd_int, self.theta, self.coords, self.x_ext, dz[:ni], d, H, s_save=self._s[0])
+        if dth_b is not None:
+            self.dtheta.copy_(dth_b)
+            if dth_i is not None:
+                self.dtheta.add_(dth_i)
+        elif dth_i is not None:
+            self.dtheta.copy_(dth_i)
+        else:
+            self.dtheta.zero_()
+        red = s.allreduce_start(self.grad_flat)                                    # [dtheta | dW | db]: one collective
+        b.matmul_dx(self.W, dz, Fi, out=self.dX)                                   # the bypass
+        self.dX.add_(dx_b[:n])
+        if dx_i is not None:
+            self.dX.add_(dx_i[:n])
+        self.xchg_r.reduce_finish(self.dX, reqs)                                   # + what the peers computed for these rows
         if red is not None:
             red.wait()
         return self.dX
@@ -1156,7 +1254,17 @@ def measure_breakdown_gno(step, iters=3):
                                                                            out=step.dX[:ni])) if ni else 0.0,
            "bwd_pull_boundary_ms": timed(lambda: b.gno_aggregate_bwd_x_pull(step.g_bwd_bnd, step.theta, step.coords, step.g_ext, d, H, Fi,
                                                                            out=step.dX[ni:])) if n - ni else 0.0}
-    recv = s.recv_rows * 4 * (Fi + Fo)
+    if step.reverse == "reduce":
+        # the reverse pass the step actually runs: each block's dx and dtheta from ONE contraction, remote rows reduced at their owners
+        def red():
+            buf = torch.zeros((n + s.n_halo, Fi), dtype=torch.float32, device=step.device)
+            step.xchg_r.reduce_finish(step.dX, step.xchg_r.reduce_start(buf))
+        out["halo_reduce_ms"] = timed(red) if s.world > 1 else 0.0
+        out["bwd_one_contraction_interior_ms"] = timed(lambda: b.gno_aggregate_bwd(step.g_fwd_int, step.theta, step.coords, step.x_ext, dz[:ni],
+                                                                               d, H, s_save=step._s[0])) if ni else 0.0
+        out["bwd_one_contraction_boundary_ms"] = timed(lambda: b.gno_aggregate_bwd(step.g_fwd_bnd, step.theta, step.coords, step.x_ext, dz[ni:],
+                                                                               d, H, s_save=step._s[1])) if n - ni else 0.0
+    recv = s.recv_rows * 4 * (Fi + (Fi if step.reverse == "reduce" else Fo))
     out["halo_recv_bytes_per_gpu_per_step"] = int(recv)
     out["xgmi_recv_GBps_per_gpu"] = (recv / (out["halo_ms"] * 1e-3) / 1e9) if out["halo_ms"] > 0 else None
     out["halo_mode"], out["halo_fraction"] = s.halo_mode, round(float(s.halo_fraction), 4)

@@ -49,7 +49,7 @@ module athena_mp_c
   public :: athena_mp_comm_unique_id, athena_mp_allreduce, athena_mp_allreduce_start, athena_mp_allreduce_finish
   public :: athena_mp_shard_create, athena_mp_shard_destroy, athena_mp_shard_dims, athena_mp_shard_graph
   public :: athena_mp_shard_export, athena_mp_halo_start, athena_mp_halo_finish, athena_mp_shard_info
-  public :: athena_mp_device_copy, athena_mp_gno_aggregate_bwd
+  public :: athena_mp_device_copy, athena_mp_gno_aggregate_bwd, athena_mp_halo_reduce_start, athena_mp_halo_reduce_finish
   public :: athena_mp_shard_create_edges, athena_mp_shard_edge_cols, athena_mp_gno_aggregate_bwd_x_pull
   public :: athena_mp_resident_mode, athena_mp_resident_acquire, athena_mp_resident_release, athena_mp_resident_flush
   public :: athena_mp_resident_drop, athena_mp_resident_stats
@@ -786,6 +786,18 @@ module athena_mp_c
        type(*), dimension(*), intent(inout) :: host_dst
        integer(c_int64_t), value :: capacity
        integer(c_int64_t), intent(out) :: count
+     end function
+     !! the transpose of the exchange: rows computed for remote vertices (y_ext beyond the local rows) go to their owners and
+     !! are added into y_local there -- the reverse pass of a partitioned graph in scatter form
+     integer(c_int) function athena_mp_halo_reduce_start(shard, slot, F, y_ext_dev) bind(C, name="athena_mp_halo_reduce_start")
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: shard, y_ext_dev
+       integer(c_int32_t), value :: slot, F
+     end function
+     integer(c_int) function athena_mp_halo_reduce_finish(shard, slot, y_local_dev) bind(C, name="athena_mp_halo_reduce_finish")
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: shard, y_local_dev
+       integer(c_int32_t), value :: slot
      end function
      integer(c_int) function athena_mp_halo_start(shard, slot, F, x_ext_dev) bind(C, name="athena_mp_halo_start")
        import :: c_int, c_int32_t, c_ptr

@@ -9,7 +9,11 @@
 !!             dx_v = sum_{(u,e) in row v} K_e^T dz_u (athena_diffstruc_extd_sub_nop.f90:419-458 read from the receiving
 !!             side); [dtheta | dW | db] summed over the ranks in ONE all-reduce.
 !!
-!!   gno_shard_run <rank> <world> <device> <id-file> <problem-file> <out-prefix>
+!!   gno_shard_run <rank> <world> <device> <id-file> <problem-file> <out-prefix> [pull|reduce]
+!!
+!! reverse = pull (default): as above.  reverse = reduce: NO exchange of dz -- athena_mp_gno_aggregate_bwd on each forward block
+!! gives dtheta and the scatter-form dx of every column the block's rows touch from ONE contraction; the rows computed for
+!! remote vertices travel to their owners and are added there (athena_mp_halo_reduce_start / _finish), under the interior block.
 !!
 !! <problem-file> (written by the checker, read by every rank): int32 N, nnz, E, Fi, Fo, d, H; adj_ia(N+1); adj_ja(2,nnz);
 !! coords(d,E); x(Fi,N); up(Fo,N); theta; W(Fo*Fi); b(Fo).  Each rank writes <out-prefix>_r<rank>.bin = n, n_int, n_halo,
@@ -24,7 +28,10 @@ program gno_shard_run
   integer :: rank, world, device, unit, k, r0, r1, n, nth, ng
   integer(c_int32_t) :: nv, nnz_g, ne_g, fi, fo, d, h
   integer(int64) :: nnz
-  character(512) :: arg, idfile, problem, prefix
+  character(512) :: arg, idfile, problem, prefix, revmode
+  logical :: reduce_form
+  integer(c_int32_t) :: fused
+  type(c_ptr) :: dxb_dev, dxi_dev
   integer(c_int32_t), allocatable :: ia_g(:), ja_g(:,:), ia(:), ja(:,:), order(:)
   integer(c_int64_t), allocatable :: edge_ids(:)
   real(real32), allocatable :: coords(:,:), x(:,:), up(:,:), theta(:), w(:), b(:), xl(:,:), upl(:,:), cl(:,:)
@@ -41,6 +48,9 @@ program gno_shard_run
   call get_command_argument(4, idfile)
   call get_command_argument(5, problem)
   call get_command_argument(6, prefix)
+  revmode = "pull"
+  if(command_argument_count() .ge. 7) call get_command_argument(7, revmode)
+  reduce_form = trim(revmode) .eq. "reduce"
   call must(athena_mp_init(int(device, c_int)), "init")
 
   open(newunit=unit, file=trim(problem), access="stream", form="unformatted", status="old")
@@ -120,6 +130,35 @@ program gno_shard_run
   call aggregate(1, athena_mp_dev_offset(m_dev, elems(n_int, fo)))
   call must(athena_mp_axpy(elems(n, fo), 1._c_float, m_dev, z_dev), "axpy")                   ! out = m + W x + b
 
+  if(reduce_form)then
+     ! ---- reverse, scatter form: no exchange of dz; dx rows computed for remote vertices are reduced at their owners ------
+     call must(athena_mp_malloc(dxb_dev, bytes(n + n_halo, fi)), "malloc")
+     call must(athena_mp_malloc(dxi_dev, bytes(n + n_halo, fi)), "malloc")
+     call must(athena_mp_gemm_dw(int(n, c_int64_t), 1_c_int32_t, fo, ones_dev, g_ext, athena_mp_dev_offset(grad_dev, &
+          int(nth + fo * fi, c_int64_t))), "gemm_dw(db)")
+     call must(athena_mp_gemm_dw(int(n, c_int64_t), fi, fo, x_ext, g_ext, athena_mp_dev_offset(grad_dev, int(nth, c_int64_t))), &
+          "gemm_dw(dW)")
+     if(n_int .lt. n)then                               ! the boundary block first: only its rows touch remote columns
+        call must(athena_mp_gno_aggregate_bwd(g(1), d, h, fi, fo, th_dev, c_dev, x_ext, athena_mp_dev_offset(g_ext, elems(n_int, fo)), &
+             s_dev(1), dxb_dev, grad_dev, c_null_ptr, fused), "gno_aggregate_bwd(boundary)")
+     else
+        call must(athena_mp_memset_zero(dxb_dev, bytes(n + n_halo, fi)), "memset")
+        call must(athena_mp_memset_zero(grad_dev, bytes(nth, 1)), "memset")
+     end if
+     call must(athena_mp_halo_reduce_start(shard, 1_c_int32_t, fi, dxb_dev), "halo_reduce_start")
+     if(n_int .gt. 0)then                               ! the interior block under the transfer
+        call must(athena_mp_gno_aggregate_bwd(g(0), d, h, fi, fo, th_dev, c_dev, x_ext, g_ext, s_dev(0), dxi_dev, dth2_dev, &
+             c_null_ptr, fused), "gno_aggregate_bwd(interior)")
+        call must(athena_mp_axpy(int(nth, c_int64_t), 1._c_float, dth2_dev, grad_dev), "axpy(dtheta)")
+     end if
+     call must(athena_mp_allreduce_start(comm, grad_dev, int(ng, c_int64_t)), "allreduce_start")
+     call must(athena_mp_gemm_dx(int(n, c_int64_t), fi, fo, g_ext, w_dev, dx_dev), "gemm_dx")
+     call must(athena_mp_axpy(elems(n, fi), 1._c_float, dxb_dev, dx_dev), "axpy(dx boundary block)")
+     if(n_int .gt. 0) call must(athena_mp_axpy(elems(n, fi), 1._c_float, dxi_dev, dx_dev), "axpy(dx interior block)")
+     call must(athena_mp_halo_reduce_finish(shard, 1_c_int32_t, dx_dev), "halo_reduce_finish")
+     call must(athena_mp_allreduce_finish(comm), "allreduce_finish")
+     call must(athena_mp_synchronize(), "synchronize")
+  else
   ! ---- reverse: halo of dz in flight under everything that needs its LOCAL rows only -------------------------------------
   call must(athena_mp_halo_start(shard, 1_c_int32_t, fo, g_ext), "halo_start(dz)")
   call must(athena_mp_gemm_dw(int(n, c_int64_t), 1_c_int32_t, fo, ones_dev, g_ext, athena_mp_dev_offset(grad_dev, &
@@ -138,6 +177,7 @@ program gno_shard_run
   call must(athena_mp_axpy(elems(n, fi), 1._c_float, t_dev, dx_dev), "axpy(dx)")
   call must(athena_mp_allreduce_finish(comm), "allreduce_finish")
   call must(athena_mp_synchronize(), "synchronize")
+  end if
 
   ! ---- results back in the ORIGINAL local row order -------------------------------------------------------------------
   allocate(outv(fo, n), dxv(fi, n), grads(ng))

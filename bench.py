@@ -437,6 +437,12 @@ def main_gno(args, world, rank, dev, one_device):
         return cols, ecols, sia, sja
 
     torch.cuda.synchronize()
+    if world > 1:
+        # the checker needs dz of the remote neighbours of the sampled rows; the step itself may not have moved them (its
+        # scatter-form reverse pass sends dx rows to their owners instead): one exchange of dz, for the check only
+        with phase("halo exchange of dz for the parity check"):
+            step.xchg_o.finish(step.xchg_o.start(step.g_ext))
+            torch.cuda.synchronize()
     cols, ecols, sia, sja = sub(False)
     kap = oracle.gno_kernel_eval(c_loc[ecols], theta, H, Fo * Fi)
     nsq = max(rows.size, cols.size)
@@ -481,7 +487,7 @@ def main_gno(args, world, rank, dev, one_device):
                       "parallelism": f"row-partition x{world}" if world > 1 else "single GPU",
                       "halo_rows_per_gpu": int(shard.halo_ids.size), "halo_mode": shard.halo_mode,
                       "halo_fraction": round(float(shard.halo_fraction), 4), "interior_rows_per_gpu": int(ni),
-                      "edge_columns_per_gpu": int(shard.n_edge_cols), "transport": shard.transport,
+                      "edge_columns_per_gpu": int(shard.n_edge_cols), "transport": shard.transport, "reverse_pass": step.reverse,
                       "S_kept_per_block": [t is not None for t in step._s]},
            "roofline": {"bound": "mfma", "kernel": "gno_pc_kernel<true> (gno_aggregate of rank 0's interior rows, S kept; the halo exchange in flight)",
                         "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,

@@ -512,6 +512,17 @@ int athena_mp_shard_export(const athena_mp_shard *s, int32_t which, void *host_d
  * ncclAllGather of the blocks; returns at once (kernels enqueued before _finish run under the transfer); slot 0 / 1 = two
  * exchanges may be outstanding */
 int athena_mp_halo_start(athena_mp_shard *s, int32_t slot, int32_t F, float *x_ext_dev);
+int athena_mp_halo_finish(athena_mp_shard *s, int32_t slot);
+/* Halo REDUCE, the transpose of the exchange: y_ext [n + n_halo, F] (F a multiple of 4) holds in its rows beyond the local
+ * ones what this rank computed FOR remote vertices -- the feature gradient of a scatter-form reverse pass
+ * (athena_mp_gno_aggregate_bwd on a forward row block: get_partial_gno_agg_features_val, athena_diffstruc_extd_sub_nop.f90:419-458,
+ * writes dx of every neighbour, local or not).  _start sends each such row to its owner (p2p mode: the contiguous segment of
+ * every owner; all-gather mode: the whole block of every owner) and receives what the peers computed for this rank's rows;
+ * _finish adds them into y_local [n, F] on the compute stream, peer by peer in rank order (deterministic).  Streams, events,
+ * deadline and slots as athena_mp_halo_start / _finish; a slot carries one exchange OR one reduce at a time.  With it the
+ * reverse pass of a partitioned graph needs no exchange of the upstream gradient and no symmetry of the graph. */
+int athena_mp_halo_reduce_start(athena_mp_shard *s, int32_t slot, int32_t F, const float *y_ext_dev);
+int athena_mp_halo_reduce_finish(athena_mp_shard *s, int32_t slot, float *y_local_dev);
 /* DEADLINES.  No RCCL collective has a completion deadline of its own, and the host never blocks in _halo_start /
  * _allreduce_start, so a rank whose peer is missing would hang in its next synchronize, far from the cause.  Every transfer
  * this library starts (halo exchange, gradient all-reduce, the metadata collectives of athena_mp_shard_create,
@@ -522,7 +533,6 @@ int athena_mp_halo_start(athena_mp_shard *s, int32_t slot, int32_t F, float *x_e
  * PROCESS ends -- "[athena_mp] rank r stalled in <transfer> ..." on stderr, {"ok": false, "error": ...} on stdout, exit code
  * 3; no retry, no cleanup that could block in the same communicator.  (The bootstrap of _comm_create_from_file has its own
  * ATHENA_MP_BOOTSTRAP_TIMEOUT_S.) */
-int athena_mp_halo_finish(athena_mp_shard *s, int32_t slot);
 
 /* ---- residency of host arrays: the *_host entry points without the PCIe round trip per op ---------------------------- *
  * athena's layers exchange array_type nodes whose %val lives on the host (athena_network_sub.f90:2752,2761: forward_generic2d

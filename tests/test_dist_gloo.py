@@ -109,6 +109,17 @@ class OracleBackend:
         dk = self.o.gno_aggregate_bwd_k(gp, x.numpy(), coords.shape[0], ia, ja)
         return torch.from_numpy(self.o.gno_kernel_bwd_theta(coords.numpy(), theta.numpy(), dk, H))
 
+    def gno_aggregate_bwd(self, g, theta, coords, x, grad, d, H, s_save=None, need_dx=True, need_dtheta=True, need_dcoords=False):
+        """the scatter-form reverse pass of a row block: dx of EVERY column its rows touch (n_cols rows), dtheta of its rows"""
+        Fi, Fo = x.shape[1], grad.shape[1]
+        ia, ja = g.square()
+        gp = np.zeros((g.n_cols, Fo), np.float32)
+        gp[:g.n_rows] = grad.numpy()
+        kap = self.o.gno_kernel_eval(coords.numpy(), theta.numpy(), H, Fo * Fi)
+        dx = torch.from_numpy(self.o.gno_aggregate_bwd_x(gp, kap, ia, ja, Fi)) if need_dx else None
+        dth = self.gno_aggregate_bwd_theta(g, theta, coords, x, grad, d, H) if need_dtheta else None
+        return dx, dth, None, False
+
     def gno_aggregate_bwd_x_pull(self, g, theta, coords, grad_ext, d, H, Fi, out=None):
         """dx[v] = sum_{w in row v} K_e^T grad_ext[col[w]] in entry order, fp32 (the pull the product path evaluates)"""
         Fo = grad_ext.shape[1]
@@ -336,7 +347,7 @@ def gno_problem(n_points, Fi, Fo, d, H, mean_degree=6.0, seed=9):
     return ia, ja, coords, x, up, theta, w, b
 
 
-def _worker_gno(rank, world, port, dims, act, mode, q):
+def _worker_gno(rank, world, port, dims, act, mode, q, reverse="pull"):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ATHENA_MP_HALO_MODE=mode)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -349,7 +360,8 @@ def _worker_gno(rank, world, port, dims, act, mode, q):
     n = shard.n
     sl = slice(rank * n, (rank + 1) * n)
     step = adist.GnoShardStep(shard, Fi, Fo, d, H, dev, backend=OracleBackend(), inputs=(x[sl], up[sl], theta, w, b, c_loc),
-                              activation=act)
+                              activation=act, reverse=reverse)
+    assert step.reverse == reverse
     out = step.forward().clone().numpy()
     dx = step.backward().clone().numpy()
     held = shard.ext_ids >= 0
@@ -377,9 +389,13 @@ def gno_reference(dims, act):
     return outs[0], dxs[0], np.concatenate([np.asarray(a, np.float32).reshape(-1) for a in grads])
 
 
-@pytest.mark.parametrize("world,act,mode", [(2, "none", "p2p"), (3, "none", "p2p"), (8, "none", "p2p"), (2, "relu", "p2p"),
-                                            (3, "sigmoid", "allgather"), (8, "none", "allgather"), (4, "none", "auto")])
-def test_node_partitioned_gno_layer_matches_the_single_process_oracle(oracle, world, act, mode):
+@pytest.mark.parametrize("world,act,mode,reverse", [(2, "none", "p2p", "pull"), (3, "none", "p2p", "pull"), (8, "none", "p2p", "pull"),
+                                                    (2, "relu", "p2p", "pull"), (3, "sigmoid", "allgather", "pull"), (8, "none", "allgather", "pull"),
+                                                    (4, "none", "auto", "pull"),
+                                                    # the scatter-form reverse pass: rows computed for remote vertices travel to their owners
+                                                    (2, "none", "p2p", "reduce"), (3, "relu", "p2p", "reduce"), (8, "none", "p2p", "reduce"),
+                                                    (3, "none", "allgather", "reduce"), (8, "sigmoid", "allgather", "reduce")])
+def test_node_partitioned_gno_layer_matches_the_single_process_oracle(oracle, world, act, mode, reverse):
     """graph_nop_layer on ONE mesh cut by rows (halo exchange of x forward and of dz in reverse, theta
     replicated, d theta / dW / db all-reduced): assembled out and dx, and every rank's all-reduced gradients, equal the
     materialising oracle on the whole mesh; the rank holds exactly the coords its rows reference."""
@@ -387,7 +403,7 @@ def test_node_partitioned_gno_layer_matches_the_single_process_oracle(oracle, wo
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_gno, args=(r, world, port, dims, act, mode, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_gno, args=(r, world, port, dims, act, mode, q, reverse)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=240) for _ in range(world))

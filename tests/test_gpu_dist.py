@@ -468,7 +468,7 @@ def test_c5_shard_from_shard_create_with_eight_ranks(dev, variant, check_rank, w
 
 
 # ---- ONE mesh with edge features cut by rows: graph_nop_layer through the C-ABI shard (athena_mp_shard_create_edges) ----------
-def _gno_worker(rank, world, port, dims, act, mode, q):
+def _gno_worker(rank, world, port, dims, act, mode, q, reverse="pull"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ATHENA_MP_HALO_MODE=mode)
@@ -492,7 +492,8 @@ def _gno_worker(rank, world, port, dims, act, mode, q):
     eid_c = np.concatenate([gi.export("eid"), gb.export("eid")]) + 1
     same_plan = bool(np.array_equal(shard.edge_ids, py.edge_ids) and np.array_equal(shard.order, py.order)
                      and np.array_equal(eid_c, py.adj_ja[1]))
-    step = adist.GnoShardStep(shard, Fi, Fo, d, H, dev, inputs=(x[sl], up[sl], theta, w, b, c_loc), activation=act)
+    step = adist.GnoShardStep(shard, Fi, Fo, d, H, dev, inputs=(x[sl], up[sl], theta, w, b, c_loc), activation=act, reverse=reverse)
+    assert step.reverse == reverse
     out = step.forward().clone().cpu().numpy()
     dx = step.backward().clone().cpu().numpy()
     torch.cuda.synchronize()
@@ -507,14 +508,21 @@ def _gno_worker(rank, world, port, dims, act, mode, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,dims,act,mode", [
-    (2, (1536, 64, 64, 3, 64), "none", "p2p"),        # BASELINE configs[3]'s widths: the producer / consumer kernels, S kept
-    (3, (1536, 64, 64, 3, 64), "relu", "p2p"),
-    (2, (1536, 64, 64, 3, 64), "none", "allgather"),
-    (8, (2048, 64, 64, 3, 64), "none", "auto"),
-    (2, (960, 3, 5, 3, 4), "sigmoid", "p2p"),         # generic shapes: the VALU / tiled route
-    (3, (960, 32, 32, 2, 32), "none", "p2p")])
-def test_node_partitioned_gno_layer_with_hip_backend_matches_the_oracle(dev, world, dims, act, mode):
+@pytest.mark.parametrize("world,dims,act,mode,reverse", [
+    (2, (1536, 64, 64, 3, 64), "none", "p2p", "pull"),        # BASELINE configs[3]'s widths: the producer / consumer kernels, S kept
+    (3, (1536, 64, 64, 3, 64), "relu", "p2p", "pull"),
+    (2, (1536, 64, 64, 3, 64), "none", "allgather", "pull"),
+    (8, (2048, 64, 64, 3, 64), "none", "auto", "pull"),
+    (2, (960, 3, 5, 3, 4), "sigmoid", "p2p", "pull"),         # generic shapes: the VALU / tiled route
+    (3, (960, 32, 32, 2, 32), "none", "p2p", "pull"),
+    # the scatter-form reverse pass: dx and dtheta of each block from ONE contraction, remote rows reduced at their owners
+    # (athena_mp_halo_reduce_*), no exchange of dz
+    (2, (1536, 64, 64, 3, 64), "none", "p2p", "reduce"),
+    (3, (1536, 64, 64, 3, 64), "relu", "p2p", "reduce"),
+    (3, (1536, 64, 64, 3, 64), "none", "allgather", "reduce"),
+    (8, (2048, 64, 64, 3, 64), "sigmoid", "auto", "reduce"),
+    (3, (960, 32, 32, 2, 32), "none", "p2p", "reduce")])      # generic widths: the separate entry points behind the same call
+def test_node_partitioned_gno_layer_with_hip_backend_matches_the_oracle(dev, world, dims, act, mode, reverse):
     """graph_nop_layer forward + reverse on ONE mesh cut by rows, the product path: athena_mp_shard_create_edges (edge
     columns renumbered per rank, symmetry checked across ranks), halo exchange of x and of dz through comm.hip (shm test
     transport: the ranks share the box's one GPU), athena_mp_gno_aggregate_fwd / _bwd_theta on the forward blocks,
@@ -525,7 +533,7 @@ def test_node_partitioned_gno_layer_with_hip_backend_matches_the_oracle(dev, wor
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_gno_worker, args=(r, world, port, dims, act, mode, q)) for r in range(world)]
+    procs = [ctx.Process(target=_gno_worker, args=(r, world, port, dims, act, mode, q, reverse)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=600) for _ in range(world))
@@ -595,10 +603,14 @@ def test_shard_create_edges_refuses_a_graph_whose_directions_do_not_share_an_edg
     assert all("no error" not in res[r] for r in range(world)), res
 
 
-@pytest.mark.parametrize("world,transport,mode,dims", [(1, "rccl", "auto", (1536, 64, 64, 3, 64)), (2, "shm", "p2p", (1536, 64, 64, 3, 64)),
-                                                       (3, "shm", "allgather", (1537, 64, 64, 3, 64)),   # blocks of 512 / 512 / 513
-                                                       (3, "shm", "p2p", (961, 3, 5, 3, 4))])
-def test_fortran_processes_run_the_node_partitioned_gno_layer_through_the_c_abi(dev, tmp_path, world, transport, mode, dims):
+@pytest.mark.parametrize("world,transport,mode,dims,reverse", [
+    (1, "rccl", "auto", (1536, 64, 64, 3, 64), "pull"), (2, "shm", "p2p", (1536, 64, 64, 3, 64), "pull"),
+    (3, "shm", "allgather", (1537, 64, 64, 3, 64), "pull"),   # blocks of 512 / 512 / 513
+    (3, "shm", "p2p", (961, 3, 5, 3, 4), "pull"),
+    # the scatter-form reverse pass from Fortran: athena_mp_gno_aggregate_bwd per block + athena_mp_halo_reduce_*
+    (1, "rccl", "auto", (1536, 64, 64, 3, 64), "reduce"), (2, "shm", "p2p", (1536, 64, 64, 3, 64), "reduce"),
+    (3, "shm", "allgather", (1537, 64, 64, 3, 64), "reduce"), (3, "shm", "p2p", (1537, 64, 64, 3, 64), "reduce")])
+def test_fortran_processes_run_the_node_partitioned_gno_layer_through_the_c_abi(dev, tmp_path, world, transport, mode, dims, reverse):
     """gno_shard_run.f90: one FORTRAN process per rank -- communicator from an id file, athena_mp_shard_create_edges on the
     rank's rows of graph_type%adj_ia / adj_ja (global vertex AND edge ids), the rank's own edge geometry, halo exchange of
     x and of dz under the interior rows, dtheta / dW / db in one all-reduce, all through ISO_C_BINDING; assembled results
@@ -624,7 +636,7 @@ def test_fortran_processes_run_the_node_partitioned_gno_layer_through_the_c_abi(
     if transport == "shm":
         env["ATHENA_MP_COMM_TRANSPORT"] = "shm"
     prefix = str(tmp_path / "run")
-    procs = [subprocess.Popen([exe, str(r), str(world), "0", str(tmp_path / "id"), str(tmp_path / "problem.bin"), prefix],
+    procs = [subprocess.Popen([exe, str(r), str(world), "0", str(tmp_path / "id"), str(tmp_path / "problem.bin"), prefix, reverse],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
@@ -737,6 +749,30 @@ def _c4_shard_worker(rank, world, port, mesh_dir, check_rank, q):
                 b = ops.gno_aggregate_bwd_theta(g, theta, co, x_ext, gsl, d, H)
                 parts.append(bool(torch.equal(a, b) and torch.isfinite(a).all()))
         out["dtheta_kept_equals_rebuilt"] = all(parts)
+        # the scatter-form reverse pass of the two blocks (what GnoShardStep(reverse="reduce") launches): its local rows + what
+        # the pull delivers must agree where no peer contributes -- on the INTERIOR rows every neighbour is local
+        dxa_i, dth_i, _, fused_i = ops.gno_aggregate_bwd(g_fi, theta, co, x_ext, x_ext[:ni].contiguous(), d, H, s_save=s_int)
+        dxa_b, dth_b, _, fused_b = ops.gno_aggregate_bwd(g_fb, theta, co, x_ext, x_ext[ni:n].contiguous(), d, H, s_save=s_bnd)
+        out["fused"] = bool(fused_i and fused_b)
+
+        def timed(fn, reps=3):
+            fn(); torch.cuda.synchronize()
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+
+        gi_, gb_ = x_ext[:ni].contiguous(), x_ext[ni:n].contiguous()
+        out["reverse_pull_ms"] = timed(lambda: (ops.gno_aggregate_bwd_theta(g_fi, theta, co, x_ext, gi_, d, H, s_save=s_int),
+                                                ops.gno_aggregate_bwd_theta(g_fb, theta, co, x_ext, gb_, d, H, s_save=s_bnd),
+                                                ops.gno_aggregate_bwd_x_pull(g_bi, theta, co, x_ext, d, H, Fi, out=dx[:ni]),
+                                                ops.gno_aggregate_bwd_x_pull(g_bb, theta, co, x_ext, d, H, Fi, out=dx[ni:])))
+        out["reverse_reduce_ms"] = timed(lambda: (ops.gno_aggregate_bwd(g_fi, theta, co, x_ext, gi_, d, H, s_save=s_int),
+                                                  ops.gno_aggregate_bwd(g_fb, theta, co, x_ext, gb_, d, H, s_save=s_bnd)))
+        out["forward_ms"] = timed(lambda: (ops.gno_aggregate_save(g_fi, theta, co, x_ext, d, H, Fo, s_save=s_int, out=m[:ni]),
+                                           ops.gno_aggregate_save(g_fb, theta, co, x_ext, d, H, Fo, s_save=s_bnd, out=m[ni:])))
         torch.cuda.synchronize()
     q.put((rank, out))
     dist.barrier()
@@ -779,6 +815,9 @@ def test_c4_mesh_cut_eight_ways_by_shard_create_edges(dev, tmp_path):
         assert res[r]["n_int"] > res[r]["n"] // 2 and 0 < res[r]["n_halo"] < res[r]["n"] // 4, res[r]
     c = res[check_rank]
     assert c["m_rel"] <= 1e-5 and c["dx_rel"] <= 1e-5 and c["dtheta_kept_equals_rebuilt"], c
+    print(f"one real 1/8 shard of configs[3] (rank {check_rank}; eight processes share the GPU, so the times are upper bounds): forward "
+          f"{c['forward_ms']:.2f} ms, reverse by pull {c['reverse_pull_ms']:.2f} ms, reverse by one contraction + reduce {c['reverse_reduce_ms']:.2f} ms")
+    assert c["fused"]
 
 
 @pytest.mark.parametrize("where,phase", [("halo", "first halo exchange"), ("setup", "communicator creation")])
