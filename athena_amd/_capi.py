@@ -114,6 +114,7 @@ _PROTOS = {
     "athena_mp_shard_create": [_vp, _i32, _i64, _vp, _vp, C.POINTER(_vp)],
     "athena_mp_shard_create_edges": [_vp, _i32, _i64, _vp, _vp, C.POINTER(_vp)],
     "athena_mp_shard_edge_cols": [_vp, C.POINTER(_i32)],
+    "athena_mp_shard_edge_reduce": [_vp, _i32, _vp],
     "athena_mp_shard_destroy": [_vp],
     "athena_mp_shard_dims": [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)],
     "athena_mp_shard_graph": [_vp, _i32, C.POINTER(_vp)],

@@ -444,6 +444,13 @@ struct athena_mp_shard {
     // distinct global edge ids its rows reference, renumbered 1 .. n_edge_cols in ascending global order
     int32_t with_edges = 0, n_edge_cols = 0;
     std::vector<int64_t> edge_ids;         // [n_edge_cols] global edge id (0-based) of each local edge column
+    // edge columns CUT by the partition (an entry of this rank's rows points at a vertex of peer p): local column ids grouped
+    // by peer, ascending global id inside a group -- the peer holds the same columns in the same order (symmetry, checked)
+    std::vector<int64_t> eoff;             // [world+1]
+    std::vector<int32_t> eshare_h;         // [eoff[world]]
+    int32_t *eshare = nullptr;             // device copy
+    float *ered_buf = nullptr;             // [2][eoff[world] * F] pack + receive buffer of athena_mp_shard_edge_reduce
+    size_t ered_cap = 0;
     hipEvent_t ev_halo[2] = {};            // comm -> compute, one per slot
     hipEvent_t ev_halo_b[2] = {};          // in front of each slot's transfer (the deadline's clock)
     float *send_buf[2] = {};
@@ -565,6 +572,23 @@ int make_graph(const std::vector<int32_t> &ia_all, const std::vector<int32_t> &c
 // halo REDUCE, the transpose of the halo exchange: rows a rank computed FOR remote vertices travel to their owners and are added
 // there.  One launch per peer in peer order (a row may be owed by several peers: their shares are added one after the other,
 // the same order on every run), 16-byte lanes over F floats.
+// edge reduce: rows of any width F (coordinate gradients: F = d), one thread per value
+__global__ void edge_pack_kernel(const float *__restrict__ e, const int32_t *__restrict__ idx, int64_t n, int F, float *__restrict__ out)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * F) return;
+    const int64_t r = t / F;
+    out[t] = e[(int64_t)idx[r] * F + (t - r * F)];
+}
+__global__ void edge_add_kernel(const float *__restrict__ recv, const int32_t *__restrict__ idx, int64_t n, int F, float *__restrict__ e)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * F) return;
+    const int64_t r = t / F;
+    float *dst = e + (int64_t)idx[r] * F + (t - r * F);   // a cut column is shared with exactly ONE peer: no two rows collide
+    *dst = *dst + recv[t];
+}
+
 __global__ void halo_add_rows_kernel(const float *__restrict__ recv, const int32_t *__restrict__ idx, int64_t n, int F, float *__restrict__ y)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -846,6 +870,8 @@ int athena_mp_shard_destroy(athena_mp_shard *s)
     for (int k = 0; k < 2; ++k) {
         if (s->send_buf[k]) (void)hipFree(s->send_buf[k]);
         if (s->red_buf[k]) (void)hipFree(s->red_buf[k]);
+        if (k == 0 && s->eshare) (void)hipFree(s->eshare);
+        if (k == 0 && s->ered_buf) (void)hipFree(s->ered_buf);
         if (s->ev_halo[k]) {
             watch_forget(s->ev_halo[k]);
             (void)hipEventDestroy(s->ev_halo[k]);
@@ -1025,6 +1051,35 @@ static int shard_create_impl(athena_mp_comm *c, int32_t n_local, int64_t nnz, co
         s->n_edge_cols = (int32_t)s->edge_ids.size();
         for (int64_t w = 0; w < nnz; ++w)
             el[w] = eg[w] < 0 ? 0 : 1 + (int32_t)(std::lower_bound(s->edge_ids.begin(), s->edge_ids.end(), eg[w]) - s->edge_ids.begin());
+        // the columns the partition cuts, per peer (local ids ascend with the global ids: edge_ids is sorted)
+        std::vector<std::vector<int32_t>> share(W);
+        for (int64_t w = 0; w < nnz; ++w) {
+            if (el[w] == 0 || (cg[w] >= lo && cg[w] < hi)) continue;
+            const int p = (int)(std::upper_bound(s->row_off.begin(), s->row_off.end(), cg[w]) - s->row_off.begin()) - 1;
+            share[p].push_back(el[w] - 1);
+        }
+        s->eoff.assign(W + 1, 0);
+        for (int p = 0; p < W; ++p) {
+            std::sort(share[p].begin(), share[p].end());
+            share[p].erase(std::unique(share[p].begin(), share[p].end()), share[p].end());
+            s->eoff[p + 1] = s->eoff[p] + (int64_t)share[p].size();
+            s->eshare_h.insert(s->eshare_h.end(), share[p].begin(), share[p].end());
+        }
+        // both sides of a cut must list the same number of columns (they do when the symmetry check passed); agreed on
+        // here so that a mismatch is an error on every rank and not a hang in the first edge reduce
+        std::vector<int64_t> mine(W), theirs((size_t)W * W);
+        for (int p = 0; p < W; ++p) mine[p] = s->eoff[p + 1] - s->eoff[p];
+        SH_RC(allgather_host(c, mine.data(), 8 * (size_t)W, theirs.data()));
+        for (int q = 0; q < W; ++q)
+            for (int p = 0; p < W; ++p)
+                if (theirs[(size_t)q * W + p] != theirs[(size_t)p * W + q])
+                    SH_FAIL("shard_create_edges: ranks %d and %d disagree about the edge columns their cut shares (%lld / %lld)", q, p,
+                            (long long)theirs[(size_t)q * W + p], (long long)theirs[(size_t)p * W + q]);
+        if (!s->eshare_h.empty()) {
+            if (hipMalloc((void **)&s->eshare, 4 * s->eshare_h.size()) != hipSuccess ||
+                hipMemcpy(s->eshare, s->eshare_h.data(), 4 * s->eshare_h.size(), hipMemcpyHostToDevice) != hipSuccess)
+                SH_FAIL("shard_create_edges: upload of the cut edge columns failed");
+        }
     }
     // 4. who needs how much of whom, and from that the way the halo travels
     std::vector<int64_t> allc((size_t)W * W);
@@ -1249,6 +1304,7 @@ int athena_mp_shard_graph(const athena_mp_shard *s, int32_t which, athena_mp_gra
  * 6 ext_ids [n_halo of shard_dims] int64: global id (0-based) held by each row of x_ext beyond the local ones, -1 = a
  *   padding slot of the all-gather layout (== array 1 in p2p mode; array 1 is always the DISTINCT remote rows referenced)
  * 7 edge_ids [n_edge_cols] int64: global edge id (0-based) of each local edge column (athena_mp_shard_create_edges)
+ * 8 cut edge columns (local ids, int32) grouped by peer   9 their offsets per peer [world+1] int64
  * count is in ELEMENTS; host_dst may be null for a size query. */
 int athena_mp_shard_export(const athena_mp_shard *s, int32_t which, void *host_dst, int64_t capacity, int64_t *count)
 {
@@ -1265,6 +1321,8 @@ int athena_mp_shard_export(const athena_mp_shard *s, int32_t which, void *host_d
     case 5: src = s->recv_counts.data(); n = (int64_t)s->recv_counts.size(); el = 8; break;
     case 6: src = s->ext_ids.data(); n = (int64_t)s->ext_ids.size(); el = 8; break;
     case 7: src = s->edge_ids.data(); n = (int64_t)s->edge_ids.size(); el = 8; break;
+    case 8: src = s->eshare_h.data(); n = (int64_t)s->eshare_h.size(); break;
+    case 9: src = s->eoff.data(); n = (int64_t)s->eoff.size(); el = 8; break;
     default: AMP_REQUIRE(false, "shard_export: unknown array id %d", which);
     }
     *count = n;
@@ -1403,6 +1461,60 @@ int athena_mp_halo_reduce_finish(athena_mp_shard *s, int32_t slot, float *y_loca
         const int64_t threads = rows * (F / 4);
         hipLaunchKernelGGL(halo_add_rows_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, amp::stream(), src, idx, rows, F,
                            y_local_dev);
+        AMP_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+/* Sum over the partition of a per-edge-column quantity (the coordinate gradient of graph_nop_layer,
+ * athena_diffstruc_extd_sub_nop.f90:137-216): e_dev [n_edge_cols, F] holds this rank's share -- the sum over ITS rows' entries;
+ * an edge column the partition cuts receives a share on both sides.  Packs the cut columns per peer, exchanges them (grouped
+ * send / recv on the communication stream), adds the peer's rows in: afterwards both ranks hold the full sum for the columns
+ * they share (a + b on one side, b + a on the other: the same bits).  Stream-ordered on the compute stream; the host does
+ * not block.  Shards built by athena_mp_shard_create_edges only. */
+int athena_mp_shard_edge_reduce(athena_mp_shard *s, int32_t F, float *e_dev)
+{
+    AMP_REQUIRE(s && F > 0 && (e_dev || s->n_edge_cols == 0), "shard_edge_reduce: bad arguments");
+    AMP_REQUIRE(s->with_edges, "shard_edge_reduce: the shard was built without edge columns (athena_mp_shard_create)");
+    athena_mp_comm *c = s->comm;
+    const int W = c->t->world, rank = c->t->rank;
+    if (W == 1) return 0;
+    const int64_t tot = s->eoff[W];
+    const size_t need = sizeof(float) * 2 * (size_t)std::max<int64_t>(tot, 1) * F;
+    if (s->ered_cap < need) {
+        if (s->ered_buf) {
+            AMP_HIP(hipStreamSynchronize(c->cs));
+            AMP_HIP(hipStreamSynchronize(amp::stream()));
+            AMP_HIP(hipFree(s->ered_buf));
+            s->ered_buf = nullptr;
+        }
+        AMP_HIP(hipMalloc((void **)&s->ered_buf, need));
+        s->ered_cap = need;
+    }
+    float *pack = s->ered_buf, *recv = s->ered_buf + (size_t)std::max<int64_t>(tot, 1) * F;
+    if (tot) {
+        hipLaunchKernelGGL(edge_pack_kernel, dim3((unsigned)((tot * F + 255) / 256)), dim3(256), 0, amp::stream(), e_dev, s->eshare, tot, F, pack);
+        AMP_LAUNCH_CHECK();
+    }
+    AMP_HIP(hipEventRecord(c->ev_ready, amp::stream()));
+    AMP_HIP(hipStreamWaitEvent(c->cs, c->ev_ready, 0));
+    AMP_HIP(hipEventRecord(c->ev_begin, c->cs));
+    std::vector<const void *> sp(W, nullptr);
+    std::vector<void *> rp(W, nullptr);
+    std::vector<size_t> sb(W, 0), rb(W, 0);
+    for (int p = 0; p < W; ++p) {
+        if (p == rank) continue;
+        const size_t rows = (size_t)(s->eoff[p + 1] - s->eoff[p]);
+        sp[p] = pack + (size_t)s->eoff[p] * F;
+        rp[p] = recv + (size_t)s->eoff[p] * F;
+        sb[p] = rb[p] = sizeof(float) * rows * F;
+    }
+    if (c->t->exchange(sp.data(), sb.data(), rp.data(), rb.data(), c->cs)) return 1;
+    AMP_HIP(hipEventRecord(c->ev_done, c->cs));
+    watch_arm(c->ev_done, rank, c->device, "the edge-column reduce (athena_mp_shard_edge_reduce)", 1.0, c->ev_begin);
+    AMP_HIP(hipStreamWaitEvent(amp::stream(), c->ev_done, 0));
+    if (tot) {
+        hipLaunchKernelGGL(edge_add_kernel, dim3((unsigned)((tot * F + 255) / 256)), dim3(256), 0, amp::stream(), recv, s->eshare, tot, F, e_dev);
         AMP_LAUNCH_CHECK();
     }
     return 0;

@@ -111,6 +111,13 @@ class Shard:
         else:
             self.edge_ids, self._eid_local = np.zeros(0, np.int64), None
         self.n_edge_cols = int(self.edge_ids.size)
+        # edge columns the partition cuts, per peer (local ids, ascending global id: the peer lists the same columns in the same order)
+        self.edge_share = [np.zeros(0, np.int64) for _ in range(world)]
+        if eids_global is not None and world > 1:
+            rem = ~local & (self._eid_local > 0)
+            owner_e = (cols_global[rem] // n).astype(np.int64)
+            le = self._eid_local[rem].astype(np.int64) - 1
+            self.edge_share = [np.unique(le[owner_e == p]) for p in range(world)]
         counts = np.bincount(rows_new, minlength=n)
         self.adj_ia = np.concatenate([[1], 1 + np.cumsum(counts)]).astype(np.int32)
         self.cols_global = cols_global
@@ -200,6 +207,20 @@ class Shard:
             t.copy_(h)
             return None
         return dist.all_reduce(t, async_op=True)
+
+    def edge_reduce(self, e):
+        """sum over the partition of a per-edge-column quantity e [n_edge_cols, F] (mirror of athena_mp_shard_edge_reduce): cut
+        columns exchanged with the peer that shares them and added in"""
+        if self.world == 1:
+            return e
+        idx = [torch.from_numpy(a).to(e.device) for a in self.edge_share]
+        sends = [e[idx[p]].contiguous() if p != self.rank and idx[p].numel() else None for p in range(self.world)]
+        recvs = [torch.empty_like(t) if t is not None else None for t in sends]
+        _p2p_exchange(sends, recvs, self.rank, self.world)
+        for p in range(self.world):
+            if recvs[p] is not None:
+                e.index_add_(0, idx[p], recvs[p])
+        return e
 
     @property
     def interior_entries(self):
@@ -521,6 +542,15 @@ class CShard:
         _capi.use_torch_stream()
         _capi.call("athena_mp_allreduce_start", self.comm.handle, C.c_void_p(t.data_ptr()), t.numel())
         return _CReduce(self.comm)
+
+    def edge_reduce(self, e):
+        import ctypes as C
+        from . import _capi
+        if tuple(e.shape)[0] != self.n_edge_cols or not e.is_contiguous():
+            raise ValueError(f"edge reduce: e must be contiguous [{self.n_edge_cols}, F]")
+        _capi.use_torch_stream()
+        _capi.call("athena_mp_shard_edge_reduce", self.handle, int(e.shape[1]), C.c_void_p(e.data_ptr()))
+        return e
 
     @property
     def interior_entries(self):
@@ -1039,7 +1069,7 @@ class GnoShardStep:
     The edge geometry stays where its rows are: a rank holds coords for the edge columns its rows reference."""
 
     def __init__(self, shard, Fi, Fo, d, H, device, backend=None, inputs=None, activation="none", use_bias=True, keep_s=None,
-                 seed=1, reverse="auto"):
+                 seed=1, reverse="auto", need_coord_grad=False):
         """inputs: (x [n, Fi], up [n, Fo], theta, W [Fo*Fi], b [Fo] or None, coords [n_edge_cols, d]) host arrays, x / up
         for the rank's rows in their ORIGINAL local order; default: seeded random (theta, W, b identical on every rank)"""
         self.s, self.Fi, self.Fo, self.d, self.H, self.device = shard, Fi, Fo, d, H, device
@@ -1091,6 +1121,10 @@ class GnoShardStep:
             raise ValueError('reverse: "auto", "pull" or "reduce"')
         self.reverse = ("reduce" if hasattr(self.b, "gno_aggregate_bwd") and Fi % 4 == 0 else "pull") if reverse == "auto" else reverse
         self.xchg_r = shard.exchange(Fi, device, self.b) if self.reverse == "reduce" else None
+        # the coordinate gradient (athena_diffstruc_extd_sub_nop.f90:137-216) on request: each block's share over the rank's
+        # edge columns, summed, then the columns the partition cuts completed by the peer's share (shard.edge_reduce)
+        self.need_coord_grad = need_coord_grad
+        self.dcoords = None
 
     def _keeps(self, g):
         if self.keep_s is False or not hasattr(self.b, "gno_saved_bytes") or g.n_rows == 0:
@@ -1141,7 +1175,9 @@ class GnoShardStep:
             if self.use_bias:
                 b.matmul_dw(self.ones, dz, out=self.db)
             b.matmul_dw(self.x_ext[:n], dz, out=self.dW)
-            dxa, dth, _, _ = b.gno_aggregate_bwd(self.g_fwd_int, self.theta, self.coords, self.x_ext, dz, d, H, s_save=self._s[0])
+            dxa, dth, dc, _ = b.gno_aggregate_bwd(self.g_fwd_int, self.theta, self.coords, self.x_ext, dz, d, H, s_save=self._s[0],
+                                                  need_dcoords=self.need_coord_grad)
+            self.dcoords = dc
             self.dtheta.copy_(dth)
             self.dX.copy_(dxa)
             b.axpy(1.0, b.matmul_dx(self.W, dz, Fi), self.dX)
@@ -1164,6 +1200,12 @@ class GnoShardStep:
             first = False
         if first:
             self.dtheta.zero_()
+        if self.need_coord_grad:
+            self.dcoords = torch.zeros_like(self.coords)
+            for g, r0, r1 in ((self.g_fwd_int, 0, ni), (self.g_fwd_bnd, ni, n)):
+                if r1 > r0:
+                    self.dcoords.add_(b.gno_aggregate_bwd_coords(g, self.theta, self.coords, self.x_ext, dz[r0:r1], d, H))
+            s.edge_reduce(self.dcoords)
         red = s.allreduce_start(self.grad_flat)                                    # [dtheta | dW | db]: one collective
         if ni:
             b.gno_aggregate_bwd_x_pull(self.g_bwd_int, self.theta, self.coords, self.g_ext, d, H, Fi, out=self.dX[:ni])
@@ -1182,8 +1224,11 @@ class GnoShardStep:
             b.matmul_dw(self.ones, dz, out=self.db)
         b.matmul_dw(self.x_ext[:n], dz, out=self.dW)
         # the boundary block first: its rows are the only ones that touch remote columns
+        wc = self.need_coord_grad
+        dc_b = dc_i = None
         if n - ni:
-            dx_b, dth_b, _, _ = b.gno_aggregate_bwd(self.g_fwd_bnd, self.theta, self.coords, self.x_ext, dz[ni:], d, H, s_save=self._s[1])
+            dx_b, dth_b, dc_b, _ = b.gno_aggregate_bwd(self.g_fwd_bnd, self.theta, self.coords, self.x_ext, dz[ni:], d, H, s_save=self._s[1],
+                                                       need_dcoords=wc)
         else:           # a rank without boundary rows sends nothing but still receives what its peers computed for it
             dx_b = torch.zeros((n + s.n_halo, Fi), dtype=torch.float32, device=self.device)
             dth_b = None
@@ -1191,7 +1236,14 @@ class GnoShardStep:
         dth_i = None
         dx_i = None
         if ni:                                                                     # ... under the interior block
-            dx_i, dth_i, _, _ = b.gno_aggregate_bwd(self.g_fwd_int, self.theta, self.coords, self.x_ext, dz[:ni], d, H, s_save=self._s[0])
+            dx_i, dth_i, dc_i, _ = b.gno_aggregate_bwd(self.g_fwd_int, self.theta, self.coords, self.x_ext, dz[:ni], d, H, s_save=self._s[0],
+                                                       need_dcoords=wc)
+        if wc:
+            self.dcoords = torch.zeros_like(self.coords)
+            for t in (dc_b, dc_i):
+                if t is not None:
+                    self.dcoords.add_(t)
+            s.edge_reduce(self.dcoords)
         if dth_b is not None:
             self.dtheta.copy_(dth_b)
             if dth_i is not None:

@@ -50,6 +50,7 @@ module athena_mp_c
   public :: athena_mp_shard_create, athena_mp_shard_destroy, athena_mp_shard_dims, athena_mp_shard_graph
   public :: athena_mp_shard_export, athena_mp_halo_start, athena_mp_halo_finish, athena_mp_shard_info
   public :: athena_mp_device_copy, athena_mp_gno_aggregate_bwd, athena_mp_halo_reduce_start, athena_mp_halo_reduce_finish
+  public :: athena_mp_shard_edge_reduce
   public :: athena_mp_shard_create_edges, athena_mp_shard_edge_cols, athena_mp_gno_aggregate_bwd_x_pull
   public :: athena_mp_resident_mode, athena_mp_resident_acquire, athena_mp_resident_release, athena_mp_resident_flush
   public :: athena_mp_resident_drop, athena_mp_resident_stats
@@ -747,6 +748,12 @@ module athena_mp_c
        integer(c_int64_t), value :: nnz
        integer(c_int32_t), intent(in) :: adj_ia(*), adj_ja(2,*)
        type(c_ptr), intent(out) :: shard
+     end function
+     !! sum over the partition of a per-edge-column quantity (dcoords): cut columns exchanged with the peer that shares them
+     integer(c_int) function athena_mp_shard_edge_reduce(shard, F, e_dev) bind(C, name="athena_mp_shard_edge_reduce")
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: shard, e_dev
+       integer(c_int32_t), value :: F
      end function
      integer(c_int) function athena_mp_shard_edge_cols(shard, n_edge_cols) bind(C, name="athena_mp_shard_edge_cols")
        import :: c_int, c_int32_t, c_ptr

@@ -506,6 +506,7 @@ int athena_mp_shard_graph(const athena_mp_shard *s, int32_t which, athena_mp_gra
  * 3 col_deg [n+n_halo] int32 | 4 send_counts [world] int64 | 5 recv_counts [world] int64 |
  * 6 ext_ids [n_halo] int64: global id held by each row of x_ext beyond the local ones, -1 = padding slot (== 1 in p2p mode);
  * 7 edge_ids [n_edge_cols] int64: global edge id (0-based) of each local edge column (shards built by _create_edges);
+ * 8 cut edge columns [..] int32 (local ids grouped by peer) | 9 their offsets per peer [world+1] int64;
  * host_dst NULL = size query (count in elements) */
 int athena_mp_shard_export(const athena_mp_shard *s, int32_t which, void *host_dst, int64_t capacity, int64_t *count);
 /* x_ext [n + n_halo, F]: p2p mode packs + posts the grouped send/recv into the halo rows, all-gather mode posts one
@@ -523,6 +524,13 @@ int athena_mp_halo_finish(athena_mp_shard *s, int32_t slot);
  * reverse pass of a partitioned graph needs no exchange of the upstream gradient and no symmetry of the graph. */
 int athena_mp_halo_reduce_start(athena_mp_shard *s, int32_t slot, int32_t F, const float *y_ext_dev);
 int athena_mp_halo_reduce_finish(athena_mp_shard *s, int32_t slot, float *y_local_dev);
+/* Sum over the partition of a per-edge-column quantity -- the coordinate gradient of graph_nop_layer
+ * (get_partial_gno_kernel_coords_val, athena_diffstruc_extd_sub_nop.f90:137-216): e_dev [n_edge_cols, F] holds this rank's share
+ * (the sum over its own rows' entries); an edge column CUT by the partition has a share on both sides.  The cut columns are
+ * exchanged with the one peer that shares them and added in: afterwards both ranks hold the full sum (the same bits).
+ * Stream-ordered, the host does not block.  Shards of athena_mp_shard_create_edges only; athena_mp_shard_export(8 / 9) lists
+ * the cut columns per peer. */
+int athena_mp_shard_edge_reduce(athena_mp_shard *s, int32_t F, float *e_dev);
 /* DEADLINES.  No RCCL collective has a completion deadline of its own, and the host never blocks in _halo_start /
  * _allreduce_start, so a rank whose peer is missing would hang in its next synchronize, far from the cause.  Every transfer
  * this library starts (halo exchange, gradient all-reduce, the metadata collectives of athena_mp_shard_create,

@@ -118,7 +118,15 @@ class OracleBackend:
         kap = self.o.gno_kernel_eval(coords.numpy(), theta.numpy(), H, Fo * Fi)
         dx = torch.from_numpy(self.o.gno_aggregate_bwd_x(gp, kap, ia, ja, Fi)) if need_dx else None
         dth = self.gno_aggregate_bwd_theta(g, theta, coords, x, grad, d, H) if need_dtheta else None
-        return dx, dth, None, False
+        dc = self.gno_aggregate_bwd_coords(g, theta, coords, x, grad, d, H) if need_dcoords else None
+        return dx, dth, dc, False
+
+    def gno_aggregate_bwd_coords(self, g, theta, coords, x, grad, d, H):
+        ia, ja = g.square()
+        gp = np.zeros((g.n_cols, grad.shape[1]), np.float32)
+        gp[:g.n_rows] = grad.numpy()
+        dk = self.o.gno_aggregate_bwd_k(gp, x.numpy(), coords.shape[0], ia, ja)
+        return torch.from_numpy(self.o.gno_kernel_bwd_coords(coords.numpy(), theta.numpy(), dk, H))
 
     def gno_aggregate_bwd_x_pull(self, g, theta, coords, grad_ext, d, H, Fi, out=None):
         """dx[v] = sum_{w in row v} K_e^T grad_ext[col[w]] in entry order, fp32 (the pull the product path evaluates)"""
@@ -360,7 +368,7 @@ def _worker_gno(rank, world, port, dims, act, mode, q, reverse="pull"):
     n = shard.n
     sl = slice(rank * n, (rank + 1) * n)
     step = adist.GnoShardStep(shard, Fi, Fo, d, H, dev, backend=OracleBackend(), inputs=(x[sl], up[sl], theta, w, b, c_loc),
-                              activation=act, reverse=reverse)
+                              activation=act, reverse=reverse, need_coord_grad=True)
     assert step.reverse == reverse
     out = step.forward().clone().numpy()
     dx = step.backward().clone().numpy()
@@ -369,7 +377,9 @@ def _worker_gno(rank, world, port, dims, act, mode, q, reverse="pull"):
                    np.isin(shard.halo_ids, shard.ext_ids[held]).all())
     q.put((rank, dict(out=out, dX=dx, grads=step.grad_flat.numpy().copy(), order=shard.order.copy(), n_int=shard.n_int,
                       n_halo=shard.n_halo, halo_mode=shard.halo_mode, halo_fraction=shard.halo_fraction, halo_ok=halo_ok,
-                      n_edge_cols=shard.n_edge_cols, coords_ok=bool(np.array_equal(c_loc, coords[shard.edge_ids])))))
+                      n_edge_cols=shard.n_edge_cols, coords_ok=bool(np.array_equal(c_loc, coords[shard.edge_ids])),
+                      dcoords=step.dcoords.numpy().copy(), edge_ids=shard.edge_ids.copy(),
+                      cut_cols=int(sum(a.size for a in shard.edge_share)))))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -385,7 +395,8 @@ def gno_reference(dims, act):
     ia, ja, coords, x, up, theta, w, b = gno_problem(*dims)
     g = graph_type.from_csr(ia, ja, num_edges=coords.shape[0])
     outs, tapes = ol.gno_forward([g], [x], [coords], [theta, w, b], Fi, Fo, d, H, True, act)
-    dxs, _, grads = ol.gno_backward([g], [x], [coords], tapes, [theta, w, b], Fi, Fo, d, H, True, act, [up])
+    dxs, dcs, grads = ol.gno_backward([g], [x], [coords], tapes, [theta, w, b], Fi, Fo, d, H, True, act, [up])
+    gno_reference.dcoords = dcs[0]         # [E, d] of the whole mesh (the callers that check it read it from here)
     return outs[0], dxs[0], np.concatenate([np.asarray(a, np.float32).reshape(-1) for a in grads])
 
 
@@ -420,9 +431,13 @@ def test_node_partitioned_gno_layer_matches_the_single_process_oracle(oracle, wo
 
     assert np.abs(unperm("out") - out_ref).max() <= 1e-5 * np.abs(out_ref).max()
     assert np.abs(unperm("dX") - dx_ref).max() <= 1e-5 * np.abs(dx_ref).max()
+    dc_ref = gno_reference.dcoords
     for r in range(world):
         assert np.abs(res[r]["grads"] - g_ref).max() <= 2e-5 * np.abs(g_ref).max(), r
         assert res[r]["halo_ok"] and res[r]["coords_ok"] and res[r]["n_halo"] > 0 and res[r]["n_edge_cols"] > 0
+        # the coordinate gradient of every edge column the rank holds -- cut columns completed by the peer's share
+        assert res[r]["cut_cols"] > 0
+        assert np.abs(res[r]["dcoords"] - dc_ref[res[r]["edge_ids"]]).max() <= 2e-5 * np.abs(dc_ref).max(), r
         want = mode if mode != "auto" else ("allgather" if res[r]["halo_fraction"] > 0.7 else "p2p")
         assert res[r]["halo_mode"] == want
     assert sum(res[r]["n_int"] for r in range(world)) > 0 or world == 8      # compact blocks keep interior rows

@@ -492,7 +492,8 @@ def _gno_worker(rank, world, port, dims, act, mode, q, reverse="pull"):
     eid_c = np.concatenate([gi.export("eid"), gb.export("eid")]) + 1
     same_plan = bool(np.array_equal(shard.edge_ids, py.edge_ids) and np.array_equal(shard.order, py.order)
                      and np.array_equal(eid_c, py.adj_ja[1]))
-    step = adist.GnoShardStep(shard, Fi, Fo, d, H, dev, inputs=(x[sl], up[sl], theta, w, b, c_loc), activation=act, reverse=reverse)
+    step = adist.GnoShardStep(shard, Fi, Fo, d, H, dev, inputs=(x[sl], up[sl], theta, w, b, c_loc), activation=act, reverse=reverse,
+                              need_coord_grad=True)
     assert step.reverse == reverse
     out = step.forward().clone().cpu().numpy()
     dx = step.backward().clone().cpu().numpy()
@@ -501,7 +502,10 @@ def _gno_worker(rank, world, port, dims, act, mode, q, reverse="pull"):
     halo_ok = bool(np.array_equal(step.x_ext[n:].cpu().numpy()[held], x[shard.ext_ids[held]]))
     q.put((rank, dict(out=out, dX=dx, grads=step.grad_flat.cpu().numpy().copy(), order=shard.order.copy(), n_int=shard.n_int,
                       n_halo=shard.n_halo, halo_mode=shard.halo_mode, halo_ok=halo_ok, same_plan=same_plan,
-                      kept_s=[t is not None for t in step._s], transport=shard.transport, n_edge_cols=shard.n_edge_cols)))
+                      kept_s=[t is not None for t in step._s], transport=shard.transport, n_edge_cols=shard.n_edge_cols,
+                      dcoords=step.dcoords.cpu().numpy().copy(), edge_ids=shard.edge_ids.copy(),
+                      cut_same=bool(np.array_equal(shard._export(8, np.int32), np.concatenate(py.edge_share + [np.zeros(0, np.int64)])))
+                      and bool(np.array_equal(shard._export(9, np.int64), np.concatenate([[0], np.cumsum([a.size for a in py.edge_share])]))))))
     dist.barrier()
     shard.close()
     adist.c_comm_destroy()
@@ -550,9 +554,12 @@ def test_node_partitioned_gno_layer_with_hip_backend_matches_the_oracle(dev, wor
 
     assert np.abs(unperm("out") - out_ref).max() <= 1e-5 * np.abs(out_ref).max()
     assert np.abs(unperm("dX") - dx_ref).max() <= 1e-5 * np.abs(dx_ref).max()
+    dc_ref = gno_reference.dcoords
     for r in range(world):
         assert np.abs(res[r]["grads"] - g_ref).max() <= 2e-5 * np.abs(g_ref).max(), r
         assert res[r]["halo_ok"] and res[r]["same_plan"] and res[r]["transport"].startswith("shm")
+        assert res[r]["cut_same"]                      # the C shard and the python plan cut the same edge columns per peer
+        assert np.abs(res[r]["dcoords"] - dc_ref[res[r]["edge_ids"]]).max() <= 2e-5 * np.abs(dc_ref).max(), r   # athena_mp_shard_edge_reduce
         assert res[r]["n_halo"] > 0 and res[r]["n_edge_cols"] > 0
         if mode != "auto":
             assert res[r]["halo_mode"] == mode
