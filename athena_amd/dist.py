@@ -917,6 +917,11 @@ def first_contact(step, watch, sync):
     with watch.phase("first halo exchange (gradient rows)"):
         step.xchg_o.finish(step.xchg_o.start(rev))
         sync()
+    if getattr(step, "xchg_r", None) is not None:
+        with watch.phase("first halo reduce (feature-gradient rows to their owners)"):
+            buf = torch.zeros((s.n + s.n_halo, step.Fi), dtype=torch.float32, device=step.device)
+            step.xchg_r.reduce_finish(step.dX, step.xchg_r.reduce_start(buf))
+            sync()
     grads = step.dW if hasattr(step, "dZ_ext") else step.grad_flat
     with watch.phase("first all-reduce of the parameter gradients"):
         grads.zero_()
