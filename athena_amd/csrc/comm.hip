@@ -1001,6 +1001,28 @@ static int shard_create_impl(athena_mp_comm *c, int32_t n_local, int64_t nnz, co
     //     lists (u, e): athena's undirected graphs, both directions sharing one edge column (:369-376).  That property
     //     is CHECKED here over all ranks: every entry adds +h(v,u,e) or -h(u,v,e) to a 64-bit sum that must cancel.
     std::vector<int32_t> el(with_edges ? (size_t)nnz : 0), el_b(with_edges ? (size_t)nnz : 0);
+    if (!with_edges) {
+        // the Kipf shard's reverse pass is a pull over the rank's own rows too (get_partial_kipf_propagate_left_val,
+        // athena_diffstruc_extd_sub_kipf.f90:85-111, read from the receiving side): the same check, without edge columns --
+        // a directed graph is an error on every rank, not a silently different dX
+        uint64_t signed_sum = 0;
+        for (int64_t w = 0, k = 0; k < n; ++k)
+            for (; w < ia[k + 1]; ++w) {
+                const int64_t vg = lo + s->order[k], ug = cg[w];
+                if (ug == vg) continue;
+                uint64_t h = (uint64_t)std::min(ug, vg) * 0x9e3779b97f4a7c15ull;
+                h = (h ^ (h >> 29)) + (uint64_t)std::max(ug, vg) * 0xbf58476d1ce4e5b9ull;
+                h ^= h >> 30;
+                signed_sum += vg < ug ? h : (uint64_t)0 - h;
+            }
+        std::vector<uint64_t> sums(W);
+        SH_RC(allgather_host(c, &signed_sum, 8, sums.data()));
+        uint64_t tot = 0;
+        for (uint64_t x : sums) tot += x;
+        if (tot != 0)
+            SH_FAIL("shard_create: the graph is not undirected (row u must list v as often as row v lists u): the pull form of the "
+                    "reverse pass would not equal the reference's scatter");
+    }
     if (with_edges) {
         s->with_edges = 1;
         std::vector<int64_t> eg(nnz);   // global edge id (0-based, -1 = none) of every entry, new row order

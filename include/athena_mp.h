@@ -476,7 +476,9 @@ int athena_mp_allreduce(athena_mp_comm *c, float *buf_dev, int64_t count);
  *              a halo row is a view into its owner's block
  *   ATHENA_MP_HALO_MODE = auto | p2p | allgather overrides the choice.  Either way a caller allocates n_local + n_halo
  *   rows (athena_mp_shard_dims) and uses the shard's graphs; nothing else differs on its side.
- * Collective: argument errors are agreed on before any data moves, so all ranks return the error together. */
+ * Collective: argument errors are agreed on before any data moves, so all ranks return the error together.  The reverse
+ * pass of a shard is a pull over the rank's own rows (exact for undirected graphs: row u lists v as often as row v lists
+ * u) -- checked across all ranks with one 64-bit signed hash sum; a directed graph is an error on every rank. */
 int athena_mp_shard_create(athena_mp_comm *c, int32_t n_local, int64_t nnz, const int32_t *adj_ia, const int32_t *adj_ja,
                            athena_mp_shard **out);
 /* The same for ONE graph WITH edge features cut by rows (graph_nop_layer on a partitioned mesh -- SURVEY.md 8e "GNO: as

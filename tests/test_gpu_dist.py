@@ -943,3 +943,44 @@ def test_bench_line_on_one_gpu_carries_what_the_driver_reads(dev):
     sec = d["secondary"]
     assert "error" not in sec and sec["configs[2]"]["parity"]["ok"] and sec["configs[2]"]["step_ms"] > 0
     assert "cpu_baseline" in sec["configs[2]"] and set(sec) >= {"note", "configs[2]", "wall_s"}
+
+
+def _directed_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from athena_amd import dist as adist
+    from athena_amd._capi import AthenaMPError
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    # 4 vertices, 2 per rank; vertex 0 lists vertex 2, vertex 2 does not list vertex 0
+    ia = np.array([1, 2, 2], np.int32) if rank == 0 else np.array([1, 1, 1], np.int32)
+    cols = np.array([2], np.int64) if rank == 0 else np.zeros(0, np.int64)
+    try:
+        adist.CShard(adist.c_comm(dev), ia, cols)
+        msg = "no error"
+    except AthenaMPError as exc:
+        msg = str(exc)
+    q.put((rank, msg))
+    dist.barrier()
+    adist.c_comm_destroy()
+    dist.destroy_process_group()
+
+
+def test_shard_create_refuses_a_directed_graph(dev):
+    """the Kipf shard's reverse pass is a pull over the rank's own rows (athena_diffstruc_extd_sub_kipf.f90:85-111 read from the
+    receiving side), exact for undirected graphs only: athena_mp_shard_create checks it over all ranks -- an error on every
+    rank instead of a silently different dX"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_directed_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert all("not undirected" in res[r] for r in range(world)), res
