@@ -295,8 +295,10 @@ struct Watched {
     int rank, device;
     char what[96];
 };
-std::mutex g_watch_mu;
-std::vector<Watched> g_watch;
+// (heap-allocated and never destroyed: the detached monitor thread may still be polling while the process runs its static
+// destructors at exit)
+std::mutex &g_watch_mu = *new std::mutex;
+std::vector<Watched> &g_watch = *new std::vector<Watched>;
 std::atomic<bool> g_watch_started{false};
 double watch_now()
 {
