@@ -2280,6 +2280,21 @@ __global__ __launch_bounds__(256) void gno_px_gather_kernel(const int32_t *__res
     const v4f_g z = {0.0f, 0.0f, 0.0f, 0.0f};
     v4f_g acc = z;
     int t = b;
+    for (; t + 3 < e; t += 4) {   // eight 16-byte loads in flight per lane; the sums stay in source order
+        int w[4];
+        v4f_g p0[4], p1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = t_entry[t + i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float *pp = px + (size_t)(w[i] < 0 ? 0 : w[i]) * kGF + 4 * l;
+            p0[i] = *reinterpret_cast<const v4f_g *>(pp);
+            p1[i] = *reinterpret_cast<const v4f_g *>(pp + px_half);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (w[i] >= 0) acc = acc + (p0[i] + p1[i]);
+    }
     for (; t + 1 < e; t += 2) {
         const int wa = t_entry[t], wb = t_entry[t + 1];
         const float *pa = px + (size_t)(wa < 0 ? 0 : wa) * kGF + 4 * l, *pb = px + (size_t)(wb < 0 ? 0 : wb) * kGF + 4 * l;
