@@ -984,3 +984,101 @@ def test_shard_create_refuses_a_directed_graph(dev):
         p.join(timeout=120)
         assert p.exitcode == 0
     assert all("not undirected" in res[r] for r in range(world)), res
+
+
+def _fuzz_problem(seed, n_total, Fi, Fo, d, H):
+    """a random undirected MULTIgraph with edge columns: duplicate pairs carry distinct columns, every vertex a self loop without a
+    column (edge id 0, as add_self_loops leaves it), a few self loops WITH one, isolated vertices at the end"""
+    rng = np.random.default_rng(seed)
+    live = n_total - rng.integers(0, 6)
+    E = int(rng.integers(2, 5) * live)
+    u = rng.integers(0, live, E); v = rng.integers(0, live, E)
+    dup = rng.integers(0, E, E // 6)                       # repeat some pairs under new columns
+    u = np.concatenate([u, u[dup]]); v = np.concatenate([v, v[dup]])
+    E = u.size
+    eid = np.arange(1, E + 1)
+    loops = u == v                                         # a self pair is ONE entry carrying its column
+    src = np.concatenate([u, v[~loops], np.arange(live)]); dst = np.concatenate([v, u[~loops], np.arange(live)])
+    ee = np.concatenate([eid, eid[~loops], np.zeros(live, np.int64)])
+    order = np.lexsort((rng.random(src.size), src))        # random entry order inside a row
+    src, dst, ee = src[order], dst[order], ee[order]
+    ia = np.concatenate([[1], 1 + np.cumsum(np.bincount(src, minlength=n_total))]).astype(np.int32)
+    ja = np.zeros((2, src.size), np.int32, order="F"); ja[0] = dst + 1; ja[1] = ee
+    coords = rng.standard_normal((E, d)).astype(np.float32)
+    x = rng.uniform(-1, 1, (n_total, Fi)).astype(np.float32); up = rng.uniform(-1, 1, (n_total, Fo)).astype(np.float32)
+    theta = (0.4 * rng.standard_normal(H * d + H + Fo * Fi * H + Fo * Fi)).astype(np.float32)
+    w = (0.5 * rng.standard_normal(Fo * Fi)).astype(np.float32); b = (0.1 * rng.standard_normal(Fo)).astype(np.float32)
+    return ia, ja, coords, x, up, theta, w, b
+
+
+def _fuzz_worker(rank, world, port, seed, dims, reverse, mode, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ATHENA_MP_HALO_MODE=mode)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from athena_amd import dist as adist
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    n_total, Fi, Fo, d, H = dims
+    ia, ja, coords, x, up, theta, w, b = _fuzz_problem(seed, *dims)
+    shard, c_loc = adist.make_mesh_shard(rank, world, n_total, device=dev, mesh=(ia, ja, coords))
+    n = shard.n
+    sl = slice(rank * n, (rank + 1) * n)
+    rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(ia[rank * n:(rank + 1) * n + 1]))
+    e0, e1 = int(ia[rank * n]) - 1, int(ia[(rank + 1) * n]) - 1
+    py = adist.Shard(rank, world, n, rows, ja[0, e0:e1].astype(np.int64) - 1, ja[1, e0:e1].astype(np.int64))
+    gi, gb = shard.graphs()[0:2]
+    same = bool(np.array_equal(shard.edge_ids, py.edge_ids) and np.array_equal(shard.order, py.order)
+                and np.array_equal(np.concatenate([gi.export("eid"), gb.export("eid")]) + 1, py.adj_ja[1])
+                and np.array_equal(shard._export(8, np.int32), np.concatenate(py.edge_share + [np.zeros(0, np.int64)])))
+    step = adist.GnoShardStep(shard, Fi, Fo, d, H, dev, inputs=(x[sl], up[sl], theta, w, b, c_loc), reverse=reverse, need_coord_grad=True)
+    out = step.forward().clone().cpu().numpy()
+    dx = step.backward().clone().cpu().numpy()
+    q.put((rank, dict(out=out, dX=dx, grads=step.grad_flat.cpu().numpy().copy(), order=shard.order.copy(), same=same,
+                      dcoords=step.dcoords.cpu().numpy().copy(), edge_ids=shard.edge_ids.copy())))
+    dist.barrier()
+    shard.close()
+    adist.c_comm_destroy()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("seed,world,reverse,mode", [(1, 2, "pull", "p2p"), (2, 3, "reduce", "p2p"), (3, 2, "reduce", "allgather"),
+                                                     (4, 3, "pull", "allgather"), (5, 4, "reduce", "auto"), (6, 2, "pull", "auto")])
+def test_node_partitioned_gno_fuzz_multigraphs_with_self_loops(dev, seed, world, reverse, mode):
+    """random undirected MULTIgraphs cut by rows: duplicate pairs under distinct edge columns, self loops with and without a
+    column, random entry order inside the rows, isolated vertices -- the C shard against the python plan (order, edge columns,
+    per-entry columns, cut columns) and the layer step in both reverse forms against the materialising oracle, dcoords included"""
+    import oracle_layers as ol
+    from athena_amd.graph import graph_type
+
+    dims = (120 * world, 4, 8, 2, 4)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fuzz_worker, args=(r, world, port, seed, dims, reverse, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    n_total, Fi, Fo, d, H = dims
+    ia, ja, coords, x, up, theta, w, b = _fuzz_problem(seed, *dims)
+    g = graph_type.from_csr(ia, ja, num_edges=coords.shape[0])
+    outs, tapes = ol.gno_forward([g], [x], [coords], [theta, w, b], Fi, Fo, d, H, True, "none")
+    dxs, dcs, grads = ol.gno_backward([g], [x], [coords], tapes, [theta, w, b], Fi, Fo, d, H, True, "none", [up])
+    g_ref = np.concatenate([np.asarray(a, np.float32).reshape(-1) for a in grads])
+
+    def unperm(key):
+        parts = []
+        for r in range(world):
+            a = np.empty_like(res[r][key]); a[res[r]["order"]] = res[r][key]; parts.append(a)
+        return np.concatenate(parts)
+
+    assert np.abs(unperm("out") - outs[0]).max() <= 1e-5 * np.abs(outs[0]).max()
+    assert np.abs(unperm("dX") - dxs[0]).max() <= 1e-5 * np.abs(dxs[0]).max()
+    for r in range(world):
+        assert res[r]["same"], r
+        assert np.abs(res[r]["grads"] - g_ref).max() <= 2e-5 * np.abs(g_ref).max(), r
+        assert np.abs(res[r]["dcoords"] - dcs[0][res[r]["edge_ids"]]).max() <= 2e-5 * np.abs(dcs[0]).max(), r
