@@ -547,7 +547,7 @@ def main():
         return main_gno(args, world, rank, dev, one_device)
     F = args.feat
     weak = args.config == "c2-weak-sbm"
-    ev, ev_bnd, ev_dw = [], [], []
+    ev, ev_bnd, ev_dw, ev_bwd = [], [], [], []
     breakdown, seeds = None, None
 
     if world > 1:
@@ -611,6 +611,9 @@ def main():
                 e2 = torch.cuda.Event(enable_timing=True)
                 e2.record(); ev_dw.append((e1, e2))
             ops.kipf_layer_bwd_x(g, dzd, wd, F, out=dX)
+            if record:
+                e3 = torch.cuda.Event(enable_timing=True)
+                e3.record(); ev_bwd.append((e2, e3))
         info = {}
         watch = None
 
@@ -713,6 +716,16 @@ def main():
                                     "achieved": flops / (dw_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                     "frac": flops / (dw_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "flops_per_launch": flops,
                                     "avg_launch_ms": dw_ms, "dtype": "f32 (v_mfma_f32_32x32x2_f32, exact fp32 products)"}
+    if world == 1 and ev_bwd:
+        # the reverse launch (get_partial_kipf_propagate_left_val + the dense step's reverse in one pull over the transposed
+        # CSR): SURVEY.md 8d's per-entry bytes nnz*(4F+4) + N*(4F+4), + the dX rows it writes
+        bw_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_bwd]))
+        bw_bytes = nnz_local * (4 * F + 4) + args.nodes * (4 * F + 4) + args.nodes * 4 * F
+        out["roofline"]["reverse"] = {"bound": "hbm", "kernel": "agg_gemm_kernel<F,plain> (fused pull: dX = (A^T dZ) . W)",
+                                      "achieved": bw_bytes / (bw_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": bw_bytes / (bw_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bw_bytes,
+                                      "avg_launch_ms": bw_ms,
+                                      "note": "the gathered dZ rows (512 MB) partly live in the 256 MiB Infinity Cache: algorithmic bytes, not HBM bytes"}
     ok = True
     if world == 1:
         try:

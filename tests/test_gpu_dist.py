@@ -937,6 +937,7 @@ def test_bench_line_on_one_gpu_carries_what_the_driver_reads(dev):
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and 0.5 < rf["frac"] < 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert 3000 < rf["measured_copy_ceiling_GBps"] < 8000 and rf["dense"]["bound"] == "mfma"
+    assert rf["reverse"]["bound"] == "hbm" and 0.5 < rf["reverse"]["frac"] < 1.0
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1 and len(d["cpu_baseline"]["runs_s"]) == 1
     assert d["parity"]["ok"] and d["parity"]["P_bit_exact"]
     assert d["relu_epilogue"]["ms_per_step"] > d["ms_per_step"] * 0.9 and d["relu_epilogue"]["Z_rel_first_rows"] <= 1e-5
