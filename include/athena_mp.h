@@ -552,7 +552,11 @@ int athena_mp_shard_edge_reduce(athena_mp_shard *s, int32_t F, float *e_dev);
  * athena_mp_resident_flush(host_ptr) materialises an array at the edge of the HIP island (NULL: all of them).
  * Safety: an array whose only valid copy is on the device carries a 16-byte sentinel at both ends of its host storage; if
  * host code wrote it (or the allocator handed the address to another array) the sentinel is gone and the host content is
- * uploaded instead.  An argument that merely overlaps a registered array (a slice) materialises that array first.
+ * uploaded instead -- and a flush (explicit, forced by an overlapping argument, or athena_mp_resident_mode(0)) then leaves the
+ * host array ALONE: the host content is the newer one (round 3 copied the stale device data over it).  The sentinel guards
+ * the two ENDS of the array: host code that rewrites only interior elements of a parked result without touching its first
+ * or last 16 bytes is outside the contract (flush the array before writing into it).  An argument that merely overlaps a
+ * registered array (a slice) materialises that array first.
  * Arrays under 64 bytes are always staged.  athena_mp_resident_mode(0) flushes everything and releases the device copies.
  * LIFETIME CONTRACT: the table holds host ADDRESSES.  An array must be dropped (athena_mp_resident_drop) before its host
  * storage is deallocated -- in the finaliser of the node / layer that owns it -- because a flush (explicit, at
