@@ -951,6 +951,46 @@ def build_kipf_step(shard, F, device, backend=None, Fo=None, order="auto", input
     return step, shard.nnz, info
 
 
+def _serial_breakdown():
+    import os
+    return bool(os.environ.get("ATHENA_MP_BENCH_SERIAL_BREAKDOWN"))
+
+
+def _make_timed(s, iters):
+    """timed(fn, collective=False): mean device time of fn over `iters` calls after one warm-up.  Under
+    ATHENA_MP_BENCH_SERIAL_BREAKDOWN the NON-collective parts are timed one rank at a time (the others wait at a barrier), so
+    that the one-device dry run -- all ranks on one GPU -- still yields each shard's real compute times."""
+    serial = _serial_breakdown() and s.world > 1
+
+    def once(fn):
+        fn()
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    def timed(fn, collective=False):
+        if collective or not serial:
+            fn()
+            torch.cuda.synchronize()
+            if s.world > 1:
+                dist.barrier()
+            return once(fn)
+        t = 0.0
+        for r in range(s.world):
+            dist.barrier()
+            if r == s.rank:
+                t = once(fn)
+        dist.barrier()
+        return t
+
+    return timed
+
+
 def measure_breakdown(step, iters=5):
     """Each part of the sharded step timed ALONE (device events, after the timed loop of bench.py): the two halo
     exchanges (pack + grouped send/recv + wait), the interior launches and the boundary launches of both passes, the
@@ -960,18 +1000,7 @@ def measure_breakdown(step, iters=5):
         return {}
     s, b, F, Fo, n, ni = step.s, step.b, step.F, step.Fo, step.s.n, step.s.n_int
 
-    def timed(fn):
-        fn()
-        torch.cuda.synchronize()
-        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        if s.world > 1:
-            dist.barrier()
-        e0.record()
-        for _ in range(iters):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / iters
+    timed = _make_timed(s, iters)
 
     def halo():
         step.xchg.finish(step.xchg.start(step.x_ext))
@@ -988,8 +1017,10 @@ def measure_breakdown(step, iters=5):
     def dw():
         b.matmul_dw(step.P, step.dZ, out=step.dW)
 
-    out = {"halo_ms": timed(halo) if s.world > 1 else 0.0, "interior_ms": timed(interior), "boundary_ms": timed(boundary),
+    out = {"halo_ms": timed(halo, collective=True) if s.world > 1 else 0.0, "interior_ms": timed(interior), "boundary_ms": timed(boundary),
            "dw_ms": timed(dw)}
+    if _serial_breakdown():
+        out["compute_parts_timed"] = "one rank at a time (ATHENA_MP_BENCH_SERIAL_BREAKDOWN): valid per-shard numbers even when the ranks share a device"
     recv_bytes = s.recv_rows * 4 * (F + Fo)
     out["halo_mode"], out["halo_fraction"], out["halo_allgather_threshold"] = s.halo_mode, round(float(s.halo_fraction), 4), s.halo_tau
     out["halo_recv_bytes_per_gpu_per_step"] = recv_bytes
@@ -1279,18 +1310,7 @@ def measure_breakdown_gno(step, iters=3):
     s, b, n, ni = step.s, step.b, step.s.n, step.s.n_int
     d, H, Fi, Fo = step.d, step.H, step.Fi, step.Fo
 
-    def timed(fn):
-        fn()
-        torch.cuda.synchronize()
-        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        if s.world > 1:
-            dist.barrier()
-        e0.record()
-        for _ in range(iters):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / iters
+    timed = _make_timed(s, iters)
 
     def halo():
         step.xchg.finish(step.xchg.start(step.x_ext))
@@ -1303,7 +1323,7 @@ def measure_breakdown_gno(step, iters=3):
             if r1 > r0:
                 b.gno_aggregate_bwd_theta(g, step.theta, step.coords, step.x_ext, dz[r0:r1], d, H, s_save=step._s[k])
 
-    out = {"halo_ms": timed(halo) if s.world > 1 else 0.0,
+    out = {"halo_ms": timed(halo, collective=True) if s.world > 1 else 0.0,
            "fwd_interior_ms": timed(lambda: step._fwd_block(0, step.g_fwd_int, 0, ni)),
            "fwd_boundary_ms": timed(lambda: step._fwd_block(1, step.g_fwd_bnd, ni, n)),
            "bwd_dtheta_ms": timed(dtheta),
@@ -1316,7 +1336,7 @@ def measure_breakdown_gno(step, iters=3):
         def red():
             buf = torch.zeros((n + s.n_halo, Fi), dtype=torch.float32, device=step.device)
             step.xchg_r.reduce_finish(step.dX, step.xchg_r.reduce_start(buf))
-        out["halo_reduce_ms"] = timed(red) if s.world > 1 else 0.0
+        out["halo_reduce_ms"] = timed(red, collective=True) if s.world > 1 else 0.0
         out["bwd_one_contraction_interior_ms"] = timed(lambda: b.gno_aggregate_bwd(step.g_fwd_int, step.theta, step.coords, step.x_ext, dz[:ni],
                                                                                d, H, s_save=step._s[0])) if ni else 0.0
         out["bwd_one_contraction_boundary_ms"] = timed(lambda: b.gno_aggregate_bwd(step.g_fwd_bnd, step.theta, step.coords, step.x_ext, dz[ni:],
