@@ -2752,17 +2752,35 @@ int athena_mp_gno_aggregate_bwd(const athena_mp_graph *g, int32_t d, int32_t H, 
         if (workspace(&dth_tmp, sizeof(float) * (off_V + (size_t)Fo * Fi * (H + 1)), 15)) return 1;
         dth = (float *)dth_tmp;
     }
-    if (dtheta) {
-        const int rc = launch_gno_stg(g, x, coords, theta, d, grad, dtheta + off_V, s_save);
-        if (rc) {
-            if (rc < 0) set_error("gno_aggregate_bwd: tensors beyond the 4 GB a buffer descriptor addresses");
-            return rc < 0 ? 2 : rc;
-        }
-    }
+    // Order: the kernel MLP's launches (they write the partials) -> the gather of the partials and S^T g SIDE BY SIDE.  The two
+    // share nothing but grad: the gather is a stream of 16-byte loads without LDS in 56 registers, S^T g leaves exactly that
+    // many free per SIMD (3 waves x 152) and is bound by the matrix pipe, so the gather runs on the library's second stream in
+    // the slots S^T g cannot use.  ATHENA_MP_GNO_BWD_SERIAL keeps everything on the caller's stream (A/B switch).
     if (int rc = gno_mlp_backward(g, d, H, Fi, Fo, theta, coords, x, grad, dth, dcoords, (float *)pxp, px_half, (const float *)cvp)) return rc;
-    hipLaunchKernelGGL(gno_px_gather_kernel, dim3((g->n_cols + 15) / 16), dim3(256), 0, stream(), g->t_rowptr, g->t_entry,
+    static const bool serial = getenv("ATHENA_MP_GNO_BWD_SERIAL") != nullptr;
+    hipStream_t main_s = stream(), gs = main_s;
+    hipEvent_t *ev = nullptr;
+    if (dtheta && !serial) {
+        if (amp::aux_stream(&gs, &ev)) return 1;
+        AMP_HIP(hipEventRecord(ev[0], main_s));
+        AMP_HIP(hipStreamWaitEvent(gs, ev[0], 0));
+    }
+    hipLaunchKernelGGL(gno_px_gather_kernel, dim3((g->n_cols + 15) / 16), dim3(256), 0, gs, g->t_rowptr, g->t_entry,
                        (const float *)pxp, px_half, g->n_cols, dx);
-    AMP_LAUNCH_CHECK();
+    const bool launched = hipGetLastError() == hipSuccess;
+    if (gs != main_s) AMP_HIP(hipEventRecord(ev[1], gs));
+    int rc = 0;
+    if (launched && dtheta) rc = launch_gno_stg(g, x, coords, theta, d, grad, dtheta + off_V, s_save);
+    // joined whatever happened above: the caller's stream never leaves this call with work it cannot see
+    if (gs != main_s) AMP_HIP(hipStreamWaitEvent(main_s, ev[1], 0));
+    if (!launched) {
+        set_error("gno_aggregate_bwd: launch of the partials' gather failed");
+        return 1;
+    }
+    if (rc) {
+        if (rc < 0) set_error("gno_aggregate_bwd: tensors beyond the 4 GB a buffer descriptor addresses");
+        return rc < 0 ? 2 : rc;
+    }
     if (fused) *fused = 1;
     return 0;
 }
