@@ -120,12 +120,20 @@ struct RcclTransport : Transport {
                  hipStream_t s) override
     {
         AMP_NCCL(g_rccl.GroupStart());
-        for (int p = 0; p < world; ++p) {
+        ncclResult_t bad = ncclSuccess;
+        int bad_peer = -1;
+        for (int p = 0; p < world && bad == ncclSuccess; ++p) {
             if (p == rank) continue;
-            if (sendb[p]) AMP_NCCL(g_rccl.Send(sendp[p], sendb[p], ncclInt8, p, comm, s));
-            if (recvb[p]) AMP_NCCL(g_rccl.Recv(recvp[p], recvb[p], ncclInt8, p, comm, s));
+            if (sendb[p]) bad = g_rccl.Send(sendp[p], sendb[p], ncclInt8, p, comm, s);
+            if (bad == ncclSuccess && recvb[p]) bad = g_rccl.Recv(recvp[p], recvb[p], ncclInt8, p, comm, s);
+            if (bad != ncclSuccess) bad_peer = p;
         }
-        AMP_NCCL(g_rccl.GroupEnd());
+        const ncclResult_t end = g_rccl.GroupEnd();   // the group is closed whatever happened inside it
+        if (bad != ncclSuccess) {
+            amp::set_error("grouped ncclSend / ncclRecv with rank %d failed: %s", bad_peer, g_rccl.GetErrorString(bad));
+            return 1;
+        }
+        AMP_NCCL(end);
         return 0;
     }
     int allreduce_f32(float *buf, size_t count, hipStream_t s) override

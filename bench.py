@@ -41,6 +41,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the pool's host driver only supports dmabuf IPC: without this RCCL's peer-to-peer setup between the ranks' processes fails
+# with "hipIpcGetMemHandle: invalid argument" (already exported on the GPU boxes; kept here for launchers that scrub the env)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md "Chip-level parameters")
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32-input MFMA peak (MI355X_MICROARCH.md)
