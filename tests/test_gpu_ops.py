@@ -2,6 +2,8 @@
 with the CPU oracle on the same seeded inputs.  Tolerance: the north star's 1e-5 relative fp32;
 the aggregation kernels are additionally required to be BIT-EXACT (same summation order, strict
 fp32) against the oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -9,6 +11,7 @@ import torch
 from helpers import assert_close, assert_close_elementwise, csr_from_index_list, golden, random_graph, rel_err
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def T(a, dev):
@@ -1007,6 +1010,51 @@ def test_gno_reverse_pass_from_one_contraction(dev, oracle, d, loops, N, hubs, d
     assert none is None and torch.equal(dx3, dx)
     none, dth3, _, f3 = ops.gno_aggregate_bwd(dg, th, co, xd, gd, d, Hh, need_dx=False)
     assert none is None and not f3 and torch.equal(dth3, dth)
+
+
+_BWD_DIGEST = """
+import sys, hashlib, numpy as np, torch
+sys.path.insert(0, {root!r})
+from athena_amd import DeviceGraph, ops, synth
+ia, ja, c3 = synth.radius_graph({N})
+rng = np.random.default_rng(5)
+dev = torch.device("cuda:0")
+T = lambda a: torch.from_numpy(a).to(dev)
+g = DeviceGraph(ia, ja, n_edge_cols=c3.shape[0])
+x = T(rng.uniform(-1, 1, ({N}, 64)).astype(np.float32)); co = T(np.ascontiguousarray(c3))
+th = T((0.3 * rng.standard_normal(64 * 3 + 64 + 64 * 64 * 64 + 64 * 64)).astype(np.float32))
+up = T(rng.uniform(-1, 1, ({N}, 64)).astype(np.float32))
+_, keep = ops.gno_aggregate_save(g, th, co, x, 3, 64, 64)
+def run():
+    poison = torch.full(({N}, 64), float("nan"), device=dev); del poison          # the block torch.empty hands out next
+    dx, dth, dc, fused = ops.gno_aggregate_bwd(g, th, co, x, up, 3, 64, s_save=keep, need_dcoords=True)
+    assert fused
+    got = [t.clone() for t in (dx, dth, dc)]        # read on the caller's stream at once: the second stream must have joined
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(got, (dx, dth, dc))) and all(torch.isfinite(t).all() for t in got)
+    return hashlib.sha256(b"".join(t.cpu().numpy().tobytes() for t in got)).hexdigest()
+first = run()
+assert all(run() == first for _ in range(4))
+print("DIGEST", first)
+"""
+
+
+def test_gno_reverse_pass_second_stream_joins_and_changes_no_bit(dev):
+    """athena_mp_gno_aggregate_bwd runs the partials' gather on the library's second stream beside S^T g: (1) the caller's
+    stream has joined it when the call returns -- outputs read at once, from blocks poisoned just before, are complete;
+    (2) ATHENA_MP_GNO_BWD_SERIAL=1 (everything on the caller's stream) gives the same bits."""
+    import subprocess, sys
+    prog = _BWD_DIGEST.format(root=ROOT, N=60000)
+    out = {}
+    for mode in ("side by side", "serial"):
+        env = dict(os.environ)
+        env.pop("ATHENA_MP_GNO_BWD_SERIAL", None)
+        if mode == "serial":
+            env["ATHENA_MP_GNO_BWD_SERIAL"] = "1"
+        r = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (mode, r.stdout[-2000:], r.stderr[-2000:])
+        out[mode] = [l for l in r.stdout.splitlines() if l.startswith("DIGEST")][-1]
+    assert out["side by side"] == out["serial"]
 
 
 def test_gno_reverse_pass_falls_back_outside_the_fused_shapes(dev, oracle):
