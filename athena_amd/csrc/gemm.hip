@@ -529,7 +529,40 @@ __global__ void gemm_dw_small_kernel(const float *__restrict__ P, const float *_
 {
     const int64_t v0 = (int64_t)blockIdx.x * rows_per_block, v1 = min(M, v0 + rows_per_block);
     float *slab = slabs + (size_t)blockIdx.x * FI * FO;
-    for (int t = threadIdx.x; t < FI * FO; t += blockDim.x) {
+    const int n = FI * FO;
+    // few outputs (a bias gradient is FI = 1: the column sums of dZ): the block's 256 threads also split the ROWS, R row lanes
+    // per output, combined through LDS in lane order (deterministic) -- one thread per output left 3/4 of the block idle and
+    // walked its rows as one dependent chain (1.6 ms for the [2 M x 64] bias gradient of the configs[3] layer step)
+    const int R = 2 * n <= (int)blockDim.x ? (int)blockDim.x / n : 1;
+    if (R > 1) {
+        __shared__ float part[256];
+        const int r = threadIdx.x / n, t = threadIdx.x - r * n;
+        float s = 0.0f;
+        if (r < R) {
+            const int i = t / FO, o = t - i * FO;
+            float s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;   // four rows in flight per thread
+            int64_t v = v0 + r;
+            for (; v + 3 * R < v1; v += 4 * R) {
+                const float a0 = P[v * FI + i], a1 = P[(v + R) * FI + i], a2 = P[(v + 2 * R) * FI + i], a3 = P[(v + 3 * R) * FI + i];
+                const float b0 = dZ[v * FO + o], b1 = dZ[(v + R) * FO + o], b2 = dZ[(v + 2 * R) * FO + o], b3 = dZ[(v + 3 * R) * FO + o];
+                s = fmaf(a0, b0, s);
+                s1 = fmaf(a1, b1, s1);
+                s2 = fmaf(a2, b2, s2);
+                s3 = fmaf(a3, b3, s3);
+            }
+            for (; v < v1; v += R) s = fmaf(P[v * FI + i], dZ[v * FO + o], s);
+            s = (s + s1) + (s2 + s3);
+        }
+        part[threadIdx.x] = s;
+        __syncthreads();
+        if ((int)threadIdx.x < n) {
+            float a = part[threadIdx.x];
+            for (int q = 1; q < R; ++q) a += part[q * n + threadIdx.x];
+            slab[threadIdx.x] = a;
+        }
+        return;
+    }
+    for (int t = threadIdx.x; t < n; t += blockDim.x) {
         int i = t / FO, o = t - i * FO;
         float s = 0.0f;
         for (int64_t v = v0; v < v1; ++v) s = fmaf(P[v * FI + i], dZ[v * FO + o], s);
@@ -693,7 +726,7 @@ int gemm_dw_dispatch(int64_t N, int Fi, int Fo, const float *P, const float *dZ,
         rpw = (rpw + 1) & ~(int64_t)1;
         nblk = (int)((N + rpw * 4 - 1) / (rpw * 4));
     } else {
-        nblk = (int)std::min<int64_t>((N + 255) / 256, 2 * num_cu());
+        nblk = (int)std::min<int64_t>((N + 255) / 256, (2 * n <= 256 ? 8 : 2) * num_cu());   // few outputs: small slabs, more of them
         rpb = (N + nblk - 1) / nblk;
         rpb = (rpb + 1) & ~(int64_t)1; // even: the MFMA form consumes vertex pairs
         nblk = (int)((N + rpb - 1) / rpb);

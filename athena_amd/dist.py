@@ -726,6 +726,7 @@ class HaloExchange:
 
 class HipBackend:
     """the product path: hand-written HIP kernels behind the C ABI"""
+    writes_in_place = True   # gno_aggregate_bwd(dx_out=, dtheta_out=): results land in the step's own buffers
 
     def __init__(self, device):
         from . import _capi
@@ -1199,23 +1200,32 @@ class GnoShardStep:
     def backward(self):
         s, b, n, ni = self.s, self.b, self.s.n, self.s.n_int
         d, H, Fi, Fo = self.d, self.H, self.Fi, self.Fo
-        dz = self.g_ext[:n]
-        if self.act in ("none", "linear"):
-            dz.copy_(self.up)
-        else:
-            dz.copy_(b.activation_bwd(self.act, self.out, self.up, z=self.z))
-        if s.world == 1 and ni == n and hasattr(b, "gno_aggregate_bwd"):
+        one = s.world == 1 and ni == n and hasattr(b, "gno_aggregate_bwd")
+        if one:      # nothing travels: dz stays where it is
+            dz = self.up if self.act in ("none", "linear") else b.activation_bwd(self.act, self.out, self.up, z=self.z)
+        else:        # the ranks of a partition exchange (or reduce into) the rows behind the local ones
+            dz = self.g_ext[:n]
+            if self.act in ("none", "linear"):
+                dz.copy_(self.up)
+            else:
+                dz.copy_(b.activation_bwd(self.act, self.out, self.up, z=self.z))
+        self.dz = dz                                                               # (what a checker of dX reads)
+        if one:
             # one rank, nothing to exchange: the whole reverse pass of the aggregation from ONE contraction
             # (athena_mp_gno_aggregate_bwd) -- on a shard its per-entry partials would have to travel to the
             # column's owner, so the ranks of a partition take the pull below
             if self.use_bias:
                 b.matmul_dw(self.ones, dz, out=self.db)
             b.matmul_dw(self.x_ext[:n], dz, out=self.dW)
-            dxa, dth, dc, _ = b.gno_aggregate_bwd(self.g_fwd_int, self.theta, self.coords, self.x_ext, dz, d, H, s_save=self._s[0],
-                                                  need_dcoords=self.need_coord_grad)
+            if getattr(b, "writes_in_place", False):
+                _, _, dc, _ = b.gno_aggregate_bwd(self.g_fwd_int, self.theta, self.coords, self.x_ext, dz, d, H, s_save=self._s[0],
+                                                  need_dcoords=self.need_coord_grad, dx_out=self.dX, dtheta_out=self.dtheta)
+            else:
+                dxa, dth, dc, _ = b.gno_aggregate_bwd(self.g_fwd_int, self.theta, self.coords, self.x_ext, dz, d, H, s_save=self._s[0],
+                                                      need_dcoords=self.need_coord_grad)
+                self.dtheta.copy_(dth)
+                self.dX.copy_(dxa)
             self.dcoords = dc
-            self.dtheta.copy_(dth)
-            self.dX.copy_(dxa)
             b.axpy(1.0, b.matmul_dx(self.W, dz, Fi), self.dX)
             return self.dX
         if self.reverse == "reduce":

@@ -654,9 +654,11 @@ def gno_aggregate_bwd_theta(g: DeviceGraph, theta, coords, x, grad, d, H, s_save
     return dth
 
 
-def gno_aggregate_bwd(g: DeviceGraph, theta, coords, x, grad, d, H, s_save=None, need_dx=True, need_dtheta=True, need_dcoords=False):
+def gno_aggregate_bwd(g: DeviceGraph, theta, coords, x, grad, d, H, s_save=None, need_dx=True, need_dtheta=True, need_dcoords=False,
+                      dx_out=None, dtheta_out=None):
     """the whole reverse pass of gno_aggregate from ONE G = g . Vmat^T (athena_mp_gno_aggregate_bwd): returns
-    (dx, dtheta, dcoords, fused) with None for what was not asked; `fused` says whether the shape took the fused kernels"""
+    (dx, dtheta, dcoords, fused) with None for what was not asked; `fused` says whether the shape took the fused kernels.
+    dx_out [n_cols, Fi] / dtheta_out (theta's size): written in place of fresh tensors (a resident step keeps its buffers)"""
     import ctypes
     Fi, Fo = x.shape[1], grad.shape[1]
     _chk(x, (g.n_cols, Fi)); _chk(grad, (g.n_rows, Fo)); _chk(coords, (g.n_edge_cols, d))
@@ -664,8 +666,11 @@ def gno_aggregate_bwd(g: DeviceGraph, theta, coords, x, grad, d, H, s_save=None,
         raise ValueError("theta: expected H*d + H + Fo*Fi*H + Fo*Fi values")
     if s_save is not None and _chk(s_save).numel() * 4 < gno_saved_bytes(g, d, H, Fi, Fo):
         raise ValueError("s_save: smaller than gno_saved_bytes()")
-    dx = torch.empty((g.n_cols, Fi), device=x.device, dtype=torch.float32) if need_dx else None
-    dth = torch.empty_like(theta) if need_dtheta else None
+    dx = (_chk(dx_out, (g.n_cols, Fi)) if dx_out is not None else torch.empty((g.n_cols, Fi), device=x.device, dtype=torch.float32)) \
+        if need_dx else None
+    if dtheta_out is not None and _chk(dtheta_out).numel() != theta.numel():
+        raise ValueError("dtheta_out: expected theta's size")
+    dth = (dtheta_out if dtheta_out is not None else torch.empty_like(theta)) if need_dtheta else None
     dc = torch.empty_like(coords) if need_dcoords else None
     fused = ctypes.c_int32(0)
     _go()

@@ -457,12 +457,13 @@ def main_gno(args, world, rank, dev, one_device):
     res = {"out_rel": rel(step.out[rsel].cpu().numpy(), out_ref)}
     cols, ecols, sia, sja = sub(True)
     kap64 = oracle.gno_kernel_eval(c_loc[ecols], theta, H, Fo * Fi).reshape(-1, Fi, Fo).astype(np.float64)
-    gs = step.g_ext[torch.from_numpy(cols).to(dev)].cpu().numpy().astype(np.float64)
+    g_rows = step.g_ext if world > 1 else step.dz          # one rank: dz never went into the exchange buffer
+    gs = g_rows[torch.from_numpy(cols).to(dev)].cpu().numpy().astype(np.float64)
     dref = np.zeros((rows.size, Fi))
     for k in range(rows.size):
         for w_ in range(sia[k] - 1, sia[k + 1] - 1):
             dref[k] += kap64[sja[1, w_] - 1] @ gs[sja[0, w_] - 1]
-    dref += oracle.matmul_dx(w, step.g_ext[rsel].cpu().numpy(), Fi).astype(np.float64)
+    dref += oracle.matmul_dx(w, g_rows[rsel].cpu().numpy(), Fi).astype(np.float64)
     res["dX_rel"] = rel(step.dX[rsel].cpu().numpy(), dref)
     held = np.flatnonzero(shard.ext_ids >= 0)
     halo_ok = True

@@ -227,6 +227,8 @@ def test_kipf_rectangular_block_with_explicit_degrees(dev, oracle):
                                      (700, 6, 10), (513, 7, 6), (100, 256, 256), (257, 96, 40), (2000, 128, 32),
                                      (3001, 256, 256), (2000, 72, 64), (5000, 64, 10), (5000, 10, 64), (1500, 4160, 64),
                                      (900, 130, 258), (129, 9, 33),
+                                     # few outputs (a bias gradient is Fi = 1): the block's threads split the rows as well
+                                     (300000, 1, 64), (70001, 1, 100), (9000, 3, 5), (255, 1, 1),
                                      # dW in 128 x 128 blocks on the register-resident kernel (N >= 4096; configs[4]'s 256 x 256)
                                      (4099, 256, 256), (5001, 256, 128), (4100, 128, 384), (6000, 512, 256)])
 def test_gemm_family_vs_float64(dev, oracle, N, Fi, Fo):
