@@ -210,6 +210,12 @@ typedef unsigned int v4u_g __attribute__((ext_vector_type(4)));
 #ifndef GNO_SAVE_MODE
 #define GNO_SAVE_MODE 2
 #endif
+#ifndef GNO_PX_NT_LOAD
+#define GNO_PX_NT_LOAD 1   // gno_px_gather_kernel reads the partials (15 GB, read once) with nontemporal loads: A/B in profiles/r04_c4_px_store_ab.txt
+#endif
+#ifndef GNO_PX_AUX
+#define GNO_PX_AUX 2   // cache bits of the per-entry partials' stores (1 sc0, 2 nt, 16 sc1): nt, A/B in profiles/r04_c4_px_store_ab.txt
+#endif
 #ifndef GNO_SAVE_AUX
 #define GNO_SAVE_AUX 2
 #endif
@@ -2174,7 +2180,7 @@ __global__ __launch_bounds__(kPcThreads) void gno_dh_pc_kernel(const int32_t *__
                                 // at once -- on gfx950 a VALU write straight behind the store then replaced the first dword of the
                                 // last 16 lanes' data: wrong partials for entries 12 .. 15 of some rows, found with the oracle)
                                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_g, acc), prs,
-                                                                       (16 * b + n) * (4 * kGF) + 16 * g + 64 * c, 0, 0);
+                                                                       (16 * b + n) * (4 * kGF) + 16 * g + 64 * c, 0, GNO_PX_AUX);
                             }
                         }
                         // the next piece's feature chunks (from a tile's last piece on: the next tile's)
@@ -2288,8 +2294,13 @@ __global__ __launch_bounds__(256) void gno_px_gather_kernel(const int32_t *__res
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float *pp = px + (size_t)(w[i] < 0 ? 0 : w[i]) * kGF + 4 * l;
+#if GNO_PX_NT_LOAD
+            p0[i] = __builtin_nontemporal_load(reinterpret_cast<const v4f_g *>(pp));
+            p1[i] = __builtin_nontemporal_load(reinterpret_cast<const v4f_g *>(pp + px_half));
+#else
             p0[i] = *reinterpret_cast<const v4f_g *>(pp);
             p1[i] = *reinterpret_cast<const v4f_g *>(pp + px_half);
+#endif
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
