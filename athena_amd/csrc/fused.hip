@@ -49,6 +49,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #endif
 constexpr int kFirst = KFIRST;
 
+#ifndef KIPF_NT
+#define KIPF_NT 1   // nontemporal stores of P (1) and Z (2) in agg_gemm_kernel: P only -- A/B in profiles/r04_kipf_nt_ab.txt
+#endif
 template <int N, bool COEF, int ACT, bool BUF>
 __global__ __launch_bounds__(1024) void agg_gemm_kernel(const int32_t *__restrict__ rowptr,
                                                         const int32_t *__restrict__ idx,
@@ -205,7 +208,13 @@ __global__ __launch_bounds__(1024) void agg_gemm_kernel(const int32_t *__restric
     auto store_row = [&](int64_t chunk, int buf, const v4f &acc) {
         const int64_t row = chunk * CH + lrow;
         *reinterpret_cast<v4f *>(Ts + (buf * CH + lrow) * LD + 4 * gl) = acc;
-        if (P != nullptr && chunk < n_chunks && row < n_rows) *reinterpret_cast<v4f *>(P + row * K + 4 * gl) = acc;
+        if (P != nullptr && chunk < n_chunks && row < n_rows) {
+#if KIPF_NT & 1
+            __builtin_nontemporal_store(acc, reinterpret_cast<v4f *>(P + row * K + 4 * gl));
+#else
+            *reinterpret_cast<v4f *>(P + row * K + 4 * gl) = acc;
+#endif
+        }
     };
 
     // (Measured and dropped: walking the rows longest first so that the rows of a chunk have equal lengths -- 6 % slower,
@@ -250,7 +259,13 @@ __global__ __launch_bounds__(1024) void agg_gemm_kernel(const int32_t *__restric
             const int col = 16 * ct + l15;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (row0 + r < n_rows) Z[(row0 + r) * N + col] = act_f<ACT>(c[r] + bv);
+                if (row0 + r < n_rows) {
+#if KIPF_NT & 2
+                    __builtin_nontemporal_store(act_f<ACT>(c[r] + bv), &Z[(row0 + r) * N + col]);
+#else
+                    Z[(row0 + r) * N + col] = act_f<ACT>(c[r] + bv);
+#endif
+                }
         };
 #if FUSED_STAGGER
         // Between two barriers a wave has two independent jobs: the matrix work of chunk k0 (reads tile `buf`) and the
