@@ -50,7 +50,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kFirst = KFIRST;
 
 #ifndef KIPF_NT
-#define KIPF_NT 1   // nontemporal stores of P (1) and Z (2) in agg_gemm_kernel: P only -- A/B in profiles/r04_kipf_nt_ab.txt
+#define KIPF_NT 5   // nontemporal stores of P (1) and Z (2; 4 = agg_gemm256_kernel's Z) in agg_gemm_kernel: P, and Z of the 256-wide forward launch -- A/B in profiles/r04_kipf_nt_ab.txt
 #endif
 template <int N, bool COEF, int ACT, bool BUF>
 __global__ __launch_bounds__(1024) void agg_gemm_kernel(const int32_t *__restrict__ rowptr,
@@ -487,7 +487,13 @@ __global__ __launch_bounds__(512) void agg_gemm256_kernel(const int32_t *__restr
             const int lrow = 2 * wave + r;
             const int64_t row = chunk * CH + lrow;
             *reinterpret_cast<v4f *>(Ts + (buf * CH + lrow) * LD + 4 * lane) = acc[r];
-            if (P != nullptr && chunk < n_chunks && row < n_rows) *reinterpret_cast<v4f *>(P + row * K + 4 * lane) = acc[r];
+            if (P != nullptr && chunk < n_chunks && row < n_rows) {
+#if KIPF_NT & 1
+                __builtin_nontemporal_store(acc[r], reinterpret_cast<v4f *>(P + row * K + 4 * lane));
+#else
+                *reinterpret_cast<v4f *>(P + row * K + 4 * lane) = acc[r];
+#endif
+            }
         }
     };
     auto matrix_work = [&](int64_t chunk, int buf) {     // this wave's two 16x16 blocks of the chunk's [16 x 256] output
@@ -509,8 +515,15 @@ __global__ __launch_bounds__(512) void agg_gemm256_kernel(const int32_t *__restr
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             if (row0 + r < n_rows) {
-                Z[(row0 + r) * N + n0 + l15] = act_f<ACT>(ca[r] + bv[0]);
-                Z[(row0 + r) * N + n0 + 16 + l15] = act_f<ACT>(cb[r] + bv[1]);
+                // (the forward launch -- the one that also keeps P -- streams Z out nontemporal: - 1.4 % on it at configs[4];
+                // the reverse launch, whose output the next layer's reverse reads, does not: + 0.7 % there)
+                if ((KIPF_NT & 4) && P != nullptr) {
+                    __builtin_nontemporal_store(act_f<ACT>(ca[r] + bv[0]), &Z[(row0 + r) * N + n0 + l15]);
+                    __builtin_nontemporal_store(act_f<ACT>(cb[r] + bv[1]), &Z[(row0 + r) * N + n0 + 16 + l15]);
+                } else {
+                    Z[(row0 + r) * N + n0 + l15] = act_f<ACT>(ca[r] + bv[0]);
+                    Z[(row0 + r) * N + n0 + 16 + l15] = act_f<ACT>(cb[r] + bv[1]);
+                }
             }
     };
 
