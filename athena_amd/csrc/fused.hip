@@ -50,7 +50,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kFirst = KFIRST;
 
 #ifndef KIPF_NT
-#define KIPF_NT 5   // nontemporal stores of P (1) and Z (2; 4 = agg_gemm256_kernel's Z) in agg_gemm_kernel: P, and Z of the 256-wide forward launch -- A/B in profiles/r04_kipf_nt_ab.txt
+#define KIPF_NT 13   // bit mask, A/B in profiles/r04_kipf_nt_ab.txt: nontemporal stores of P (1), of Z (2; 4 = agg_gemm256_kernel's forward launch), nontemporal loads of agg_gemm_kernel's forward-launch entry ids + coefficients (8; the same in agg_gemm256_kernel measured slower, not in the tree)
 #endif
 template <int N, bool COEF, int ACT, bool BUF>
 __global__ __launch_bounds__(1024) void agg_gemm_kernel(const int32_t *__restrict__ rowptr,
@@ -121,8 +121,15 @@ __global__ __launch_bounds__(1024) void agg_gemm_kernel(const int32_t *__restric
             len = rowptr[row + 1] - start;
         }
         if (gl < len) {
-            idx0 = idx[start + gl];
-            if constexpr (COEF) c0 = coef[start + gl];
+            // (the forward launch reads its 80 MB of entry ids and coefficients nontemporal -- they are used once and would
+            // push rows of X out of the caches: + 1.8 % on it; the coefficient-free reverse launch lost 0.8 % with the same)
+            if constexpr (COEF && (KIPF_NT & 8)) {
+                idx0 = __builtin_nontemporal_load(idx + start + gl);
+                c0 = __builtin_nontemporal_load(coef + start + gl);
+            } else {
+                idx0 = idx[start + gl];
+                if constexpr (COEF) c0 = coef[start + gl];
+            }
         }
     };
     // Row loads.  BUF: the gathered tensor is below 4 GB, so a row is addressed by a 32-bit byte offset against a
@@ -174,8 +181,13 @@ __global__ __launch_bounds__(1024) void agg_gemm_kernel(const int32_t *__restric
             if (off > 0) {
                 my_idx = -1; my_c = 0.0f;
                 if (off + gl < len) {
-                    my_idx = idx[start + off + gl];
-                    if constexpr (COEF) my_c = coef[start + off + gl];
+                    if constexpr (COEF && (KIPF_NT & 8)) {
+                        my_idx = __builtin_nontemporal_load(idx + start + off + gl);
+                        my_c = __builtin_nontemporal_load(coef + start + off + gl);
+                    } else {
+                        my_idx = idx[start + off + gl];
+                        if constexpr (COEF) my_c = coef[start + off + gl];
+                    }
                 }
             }
             const int cntmax = min(G, maxlen - off);
