@@ -330,7 +330,11 @@ int athena_mp_gno_aggregate_bwd_theta_saved(const athena_mp_graph *g, int32_t d,
  * outside the fused kernels run the separate entry points; *fused_out (may be NULL) reports which it was.  Same values
  * as the separate entry points to fp32 rounding (the sums associate differently).  The per-entry partials live in a
  * library workspace of 2 * nnz * 256 bytes (15 GB at BASELINE configs[3]; grown on demand, reused by every call, released
- * by athena_mp_finalize), the transposed-entry map (nnz int32) in the graph handle. */
+ * by athena_mp_finalize), the transposed-entry map (nnz int32) in the graph handle.
+ * STREAMS: with dtheta requested, the gather of the partials runs on a second, library-owned stream beside the S^T g launch
+ * (fork after the kernel MLP's launches, join before the call returns: the caller's stream waits for it, so the outputs are
+ * ordered on the caller's stream like any other call's, and the pattern can be captured into a HIP graph).
+ * ATHENA_MP_GNO_BWD_SERIAL=1 keeps every launch on the caller's stream (same bits). */
 int athena_mp_gno_aggregate_bwd(const athena_mp_graph *g, int32_t d, int32_t H, int32_t Fi, int32_t Fo,
                                 const float *theta_dev, const float *coords_dev, const float *x_dev,
                                 const float *grad_dev, const float *s_save_dev, float *dx_dev, float *dtheta_dev,
