@@ -1059,6 +1059,37 @@ def test_gno_reverse_pass_second_stream_joins_and_changes_no_bit(dev):
     assert out["side by side"] == out["serial"]
 
 
+def test_gno_reverse_pass_second_stream_is_capturable(dev):
+    """the fork / join onto the library's second stream inside athena_mp_gno_aggregate_bwd records into a HIP graph (the
+    pattern network.capture_step relies on): the replayed graph refills poisoned output buffers with the eager call's bits"""
+    from athena_amd import DeviceGraph, ops, synth
+
+    N = 20000
+    ia, ja, c3 = synth.radius_graph(N)
+    rng = np.random.default_rng(11)
+    g = DeviceGraph(ia, ja, n_edge_cols=c3.shape[0])
+    x, co = T(rng.uniform(-1, 1, (N, 64)).astype(np.float32), dev), T(c3, dev)
+    th = T((0.3 * rng.standard_normal(64 * 3 + 64 + 64 * 64 * 64 + 64 * 64)).astype(np.float32), dev)
+    up = T(rng.uniform(-1, 1, (N, 64)).astype(np.float32), dev)
+    _, keep = ops.gno_aggregate_save(g, th, co, x, 3, 64, 64)
+    dx_ref, dth_ref, _, fused = ops.gno_aggregate_bwd(g, th, co, x, up, 3, 64, s_save=keep)     # eager: also grows the workspaces
+    assert fused
+    torch.cuda.synchronize()
+    dx_buf, dth_buf = torch.empty_like(dx_ref), torch.empty_like(dth_ref)
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            ops.gno_aggregate_bwd(g, th, co, x, up, 3, 64, s_save=keep, dx_out=dx_buf, dtheta_out=dth_buf)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    for _ in range(3):
+        dx_buf.fill_(float("nan")); dth_buf.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(dx_buf, dx_ref) and torch.equal(dth_buf, dth_ref)
+
+
 def test_gno_reverse_pass_falls_back_outside_the_fused_shapes(dev, oracle):
     """shapes the fused kernels do not serve (d = 4; generic widths; a graph where more than 1 row in 64 is longer than 32
     entries) run the separate entry points behind the same call"""
