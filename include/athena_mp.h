@@ -22,6 +22,13 @@
  *     (default: the null stream) and return without synchronising.
  *   - not thread-safe by design (the reference's layers are stateful and
  *     single-threaded, SURVEY.md 8b "Threading").
+ *   - ONE stream at a time per device: scratch workspaces (reduction slabs, the GNO partials, packed halo rows) belong
+ *     to the device, not to a stream, and are ordered by the stream the calls are enqueued on.  Switching streams with
+ *     athena_mp_set_stream is fine once the work enqueued so far on the old stream is ordered before the new stream's
+ *     (an event wait or a synchronize); two streams issuing calls for the same device side by side would share those
+ *     workspaces.  The second, library-owned stream some calls use inside (athena_mp_gno_aggregate_bwd, the tiled
+ *     athena_mp_gno_aggregate_bwd_theta, the communication stream of athena_mp_halo_*) is forked from and joined to the
+ *     caller's stream within the call.
  */
 #ifndef ATHENA_MP_H
 #define ATHENA_MP_H
