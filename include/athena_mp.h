@@ -27,8 +27,8 @@
  *     athena_mp_set_stream is fine once the work enqueued so far on the old stream is ordered before the new stream's
  *     (an event wait or a synchronize); two streams issuing calls for the same device side by side would share those
  *     workspaces.  The second, library-owned stream some calls use inside (athena_mp_gno_aggregate_bwd, the tiled
- *     athena_mp_gno_aggregate_bwd_theta, the communication stream of athena_mp_halo_*) is forked from and joined to the
- *     caller's stream within the call.
+ *     athena_mp_gno_aggregate_bwd_theta) is forked from and joined to the caller's stream within the call; the
+ *     communication stream is forked by the _start calls and joined by their _finish (athena_mp_halo_*, _allreduce_*).
  */
 #ifndef ATHENA_MP_H
 #define ATHENA_MP_H
