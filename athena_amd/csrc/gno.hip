@@ -625,10 +625,22 @@ struct GnoProd {
             I.len[vi] = I.ok[vi] ? rowptr[I.row[vi] + 1] - I.w0[vi] : 0;
         }
     }
+    // lane group g's element of a wave-uniform array of four.  Written as three selects with the compiler kept from seeing
+    // them as ONE indexed read: it otherwise parks the array in scratch memory and reads it back with a per-lane index --
+    // 2.7 GB of scratch writes per launch of gno_pc_kernel at configs[3] (WRITE_SIZE 3.1e6 KiB for 0.5 GB of output).
+    __device__ __forceinline__ int by_group(const int (&a)[4]) const
+    {
+        int v = a[0];
+        v = g >= 1 ? a[1] : v;
+        asm volatile("" : "+v"(v));
+        v = g >= 2 ? a[2] : v;
+        asm volatile("" : "+v"(v));
+        v = g >= 3 ? a[3] : v;
+        return v;
+    }
     __device__ __forceinline__ void ids_entries(GnoIds &I) const
     {
-        const int w0 = g == 0 ? I.w0[0] : g == 1 ? I.w0[1] : g == 2 ? I.w0[2] : I.w0[3];
-        const int len = g == 0 ? I.len[0] : g == 1 ? I.len[1] : g == 2 ? I.len[2] : I.len[3];
+        const int w0 = by_group(I.w0), len = by_group(I.len);
         const uint32_t o0 = n < len ? 4u * (uint32_t)(w0 + n) : kDead, o1 = n + 16 < len ? 4u * (uint32_t)(w0 + n + 16) : kDead;
         I.J0 = __builtin_amdgcn_raw_buffer_load_b32(jrs, (int)o0, 0, 0);
         I.E0 = __builtin_amdgcn_raw_buffer_load_b32(ers, (int)o0, 0, 0);
@@ -643,7 +655,7 @@ struct GnoProd {
     }
     __device__ __forceinline__ void ids_finish(GnoIds &I) const
     {
-        const int len = g == 0 ? I.len[0] : g == 1 ? I.len[1] : g == 2 ? I.len[2] : I.len[3];
+        const int len = by_group(I.len);
         to_offsets(I.J0, I.E0, n < len);
         to_offsets(I.J1, I.E1, n + 16 < len);
     }
