@@ -2062,15 +2062,16 @@ __global__ __launch_bounds__(kPcThreads) void gno_dh_pc_kernel(const int32_t *__
         for (int vi = 0; vi < VPW; ++vi)
 #pragma unroll
             for (int b = 0; b < NB; ++b) dacc[vi][b][0] = dacc[vi][b][1] = z;
-        // PX: c = b_v^T g of the wave's vertices, laid out by SLOT of the length-ordered list (cvec[slot][64]): a tile's
-        // VPW rows are one contiguous KB -- one 16-byte load per lane per tile, fetched a tile ahead, parked in a private
-        // LDS strip (no load sits in front of the partial MFMAs: a load there would make their wait drain every prefetch)
+        // PX: c = b_v^T g of the wave's vertices (cvec[row][64], the rows of grad's own order): lane (vertex lane / 16, chunk
+        // lane % 16) takes 16 bytes of its vertex's row -- one load per lane per tile, fetched a tile ahead (the row ids are
+        // known by then), parked in a private LDS strip (no load sits in front of the partial MFMAs: a load there would make
+        // their wait drain every prefetch).  A slot without a vertex reads some row; nothing of it is ever stored.
         float *cstrip = Sh + kDhLdsFloats + p * kDhCStrip;
-        __amdgpu_buffer_rsrc_t cvrs = __builtin_amdgcn_make_buffer_rsrc((void *)cvec, 0, PX ? n_rows * (4 * kGF) : 0, 0x00020000);
+        __amdgpu_buffer_rsrc_t cvrs = __builtin_amdgcn_make_buffer_rsrc((void *)cvec, 0, PX ? (int)g_bytes : 0, 0x00020000);
+        auto c_off = [&](const GnoIds &I) { return (uint32_t)P.by_group(I.row) * (4u * kGF) + 16u * (uint32_t)n; };
         v4f_g cnext = z;
         if constexpr (PX) {
-            const uint32_t o = ((uint32_t)blockIdx.x * TV + VPW * p) * (4u * kGF) + 16u * lane;
-            const v4f_g c0 = __builtin_bit_cast(v4f_g, __builtin_amdgcn_raw_buffer_load_b128(cvrs, (int)o, 0, 0));
+            const v4f_g c0 = __builtin_bit_cast(v4f_g, __builtin_amdgcn_raw_buffer_load_b128(cvrs, (int)c_off(cur), 0, 0));
             *reinterpret_cast<v4f_g *>(cstrip + 4 * lane) = c0;
         }
         __syncthreads();
@@ -2093,10 +2094,8 @@ __global__ __launch_bounds__(kPcThreads) void gno_dh_pc_kernel(const int32_t *__
                 if constexpr (PX) {
                     ubp0 = __shfl(ub0, pi_src);
                     ubp1 = __shfl(ub1, pi_src);
-                    if (pcp == 4) {   // the next tile's c rows (beyond the list: the descriptor returns 0)
-                        const uint32_t o = ((uint32_t)(tile + gridDim.x) * TV + VPW * p) * (4u * kGF) + 16u * lane;
-                        cnext = __builtin_bit_cast(v4f_g, __builtin_amdgcn_raw_buffer_load_b128(cvrs, (int)(more ? o : GnoProd::kDead), 0, 0));
-                    }
+                    if (pcp == 4)     // the next tile's c rows (its row ids arrived with piece 0)
+                        cnext = __builtin_bit_cast(v4f_g, __builtin_amdgcn_raw_buffer_load_b128(cvrs, (int)(more ? c_off(nxt) : GnoProd::kDead), 0, 0));
                 }
                 const float *cs = cstrip + (ti & 1) * (4 * kGF);
                 {
@@ -2251,7 +2250,7 @@ __global__ __launch_bounds__(256) void gno_px_long_kernel(const int32_t *__restr
         hs[slot][k] = h > 0.0f ? h : 0.0f;
         __syncthreads();
         if (in) {
-            float sacc = cvec[(size_t)blockIdx.x * kGF + k];   // cvec is in SLOT order (the long rows head the list); k doubles as q
+            float sacc = cvec[(size_t)row * kGF + k];   // k doubles as q
             for (int kk = 0; kk < kGH; ++kk) sacc = fmaf(hs[slot][kk], G[kk][k], sacc);
             px[(size_t)w * kGF + k] = e >= 0 ? sacc : 0.0f;
             px[px_half + (size_t)w * kGF + k] = 0.0f;
@@ -2415,7 +2414,7 @@ int gno_mlp_backward(const athena_mp_graph *g, int d, int H, int Fi, int Fo, con
 #define AMP_DHPC_(GH_, VPW_, NB_, PX_, NWG_, NROWS_, PERM_, SL_)                                                                    \
     hipLaunchKernelGGL((gno_dh_pc_kernel<GH_, VPW_, NB_, PX_>), dim3(NWG_), dim3(kPcThreads), dlds, amp::stream(), g->rowptr, g->col, g->eid, \
                        x, coords, theta, d, (const float *)vd, grad, NROWS_, PERM_, SL_, ghbuf, (uint32_t)y_bytes, (uint32_t)c_bytes, \
-                       (uint32_t)id_bytes, (uint32_t)g_bytes, px, px_half, cvec ? cvec + (size_t)((PERM_) - perm) * kGF : nullptr)
+                       (uint32_t)id_bytes, (uint32_t)g_bytes, px, px_half, cvec)
 #define AMP_DHPC(GH_, VPW_, NB_, NWG_, NROWS_, PERM_, SL_)                \
     do {                                                                  \
         if (px) AMP_DHPC_(GH_, VPW_, NB_, true, NWG_, NROWS_, PERM_, SL_); \
@@ -2760,16 +2759,10 @@ int athena_mp_gno_aggregate_bwd(const athena_mp_graph *g, int32_t d, int32_t H, 
         }
         g->t_entry = te;
     }
-    // c_i = b_v^T g_i in SLOT order of the length-ordered list (a tile's rows contiguous): rows of grad gathered through
-    // the permutation, b_v viewed [q][o]
-    {
-        amp::TiledArgs ta;
-        ta.A = grad; ta.lda = Fo; ta.a_idx = g->len_perm_fwd;
-        ta.B = theta + off_V + (size_t)Fo * Fi * H; ta.ldb = Fo; ta.b_nk = 1;
-        ta.C = (float *)cvp; ta.ldc = Fi;
-        ta.M = g->n_rows; ta.N = Fi; ta.K = Fo;
-        if (int rc = amp::gemm_tiled(ta)) return rc;
-    }
+    // c_i = b_v^T g_i for every row (b_v viewed [q][o]): one weight-resident GEMM launch
+    if (int rc = gemm_dispatch(grad, theta + off_V + (size_t)Fo * Fi * H, /*b_nk=*/1, nullptr, ATHENA_MP_ACT_NONE, (float *)cvp,
+                               g->n_rows, Fo, Fi))
+        return rc;
     float *dth = dtheta;
     if (!dth) {   // dx alone still runs the fused kernel; its parameter sums go to a scratch vector
         if (workspace(&dth_tmp, sizeof(float) * (off_V + (size_t)Fo * Fi * (H + 1)), 15)) return 1;
