@@ -214,7 +214,7 @@ typedef unsigned int v4u_g __attribute__((ext_vector_type(4)));
 #define GNO_PX_NT_LOAD 1   // gno_px_gather_kernel reads the partials (15 GB, read once) with nontemporal loads: A/B in profiles/r04_c4_px_store_ab.txt
 #endif
 #ifndef GNO_PX_AUX
-#define GNO_PX_AUX 2   // cache bits of the per-entry partials' stores (1 sc0, 2 nt, 16 sc1): nt, A/B in profiles/r04_c4_px_store_ab.txt
+#define GNO_PX_AUX 0   // cache bits of the per-entry partials' stores (1 sc0, 2 nt, 16 sc1): none -- A/B in profiles/r04_c4_px_one_array_ab.txt
 #endif
 #ifndef GNO_SAVE_AUX
 #define GNO_SAVE_AUX 2
@@ -1928,12 +1928,14 @@ __device__ __forceinline__ int gno_gpos(int hidl, int chunk) { return hidl * 16 
 // 16 entries, <2, 2> for rows of 17 .. 32 -- the register file holds 4 x 1 or 2 x 2 sets of dh accumulators, not 4 x 2
 // PX (athena_mp_gno_aggregate_bwd: dx AND dtheta from ONE G = g . Vmat^T): while a piece of G_i lies in LDS the sparse waves
 // also take the feature gradient's per-entry partial from it,
-//     px[kh][w][16 c + q] = sum_{k in the kh's 32 hidden units} h_e[k] G_i[k][16 c + q]   (+ (b_v^T g_i)[16 c + q] at kh = 0),
+//     px[w][16 c + q] = (b_v^T g_i)[16 c + q] + sum_k h_e[k] G_i[k][16 c + q]   (the kh = 0 pieces store the first 32 hidden
+//                       units' share, the kh = 1 pieces read it back -- two vertices ahead, from the L2 / Infinity Cache -- as
+//                       the start value of their accumulators and store the finished partial over it),
 // i.e. entry w = (i -> j, e)'s contribution to dx_j = sum K_e^T g_i (athena_diffstruc_extd_sub_nop.f90:419-458) -- eight
 // more 16x16x4 MFMAs per 16 entries and piece (K = hidden units; A = G^T read from LDS one word per lane, B = h^T from an
 // h MFMA with its operands swapped, whose result registers ARE the B operand: register r of lane (entry n, g) is hidden
 // unit pi(4 g + r), pi chosen so that the A reads of a half wave fall on 32 different banks).  The partials go to HBM
-// ([2][nnz][64], stored through one buffer descriptor per vertex: lanes beyond the row's length fall outside it and are
+// ([nnz][64], stored through one buffer descriptor per vertex: lanes beyond the row's length fall outside it and are
 // dropped by the bounds check, so the store is unconditional) and gno_px_gather_kernel sums them over the transposed CSR:
 // the second 1.07 TFLOP contraction of the reverse pass (T . B2 in the dx launch) is gone.
 template <bool WRITE_GH, int VPW, int NB, bool PX = false>
@@ -2070,6 +2072,9 @@ __global__ __launch_bounds__(kPcThreads) void gno_dh_pc_kernel(const int32_t *__
         __amdgpu_buffer_rsrc_t cvrs = __builtin_amdgcn_make_buffer_rsrc((void *)cvec, 0, PX ? (int)g_bytes : 0, 0x00020000);
         auto c_off = [&](const GnoIds &I) { return (uint32_t)P.by_group(I.row) * (4u * kGF) + 16u * (uint32_t)n; };
         v4f_g cnext = z;
+        v4f_g pprev[2][NB];       // the kh = 0 partials of the two vertices whose kh = 1 pieces come next
+#pragma unroll
+        for (int b = 0; b < NB; ++b) pprev[0][b] = pprev[1][b] = z;
         if constexpr (PX) {
             const v4f_g c0 = __builtin_bit_cast(v4f_g, __builtin_amdgcn_raw_buffer_load_b128(cvrs, (int)c_off(cur), 0, 0));
             *reinterpret_cast<v4f_g *>(cstrip + 4 * lane) = c0;
@@ -2167,12 +2172,13 @@ __global__ __launch_bounds__(kPcThreads) void gno_dh_pc_kernel(const int32_t *__
                                 gq[0][r] = grow[gq_off[r]];
                                 gq[1][r] = grow[gq_off[r] + 256];
                             }
-                            // (b_v^T g_i)[16 c + 4 g ..] rides in the kh = 0 partial as the accumulator's start value
+                            // (b_v^T g_i)[16 c + 4 g ..] rides in the kh = 0 partial as the accumulator's start value; the kh = 1
+                            // pieces start from the kh = 0 partial itself, read back a vertex ahead (pprev), so that ONE array
+                            // [nnz][64] holds the finished partial
                             const v4f_g cq = *reinterpret_cast<const v4f_g *>(cs + vi * kGF + 16 * c + 4 * g);
-                            const v4f_g a0 = kh ? z : cq;
-                            // one descriptor per vertex: its len rows of px[kh] -- a lane beyond the row's length is out of range
+                            // one descriptor per vertex: its len rows of px -- a lane beyond the row's length is out of range
                             __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
-                                (void *)(px + (size_t)kh * px_half + (size_t)cur.w0[vi] * kGF), 0, cur.len[vi] * (4 * kGF), 0x00020000);
+                                (void *)(px + (size_t)cur.w0[vi] * kGF), 0, cur.len[vi] * (4 * kGF), 0x00020000);
 #pragma unroll
                             for (int b = 0; b < NB; ++b) {
                                 const float cv = P.g_is_d ? 1.0f : cvv[vi][b];
@@ -2180,7 +2186,7 @@ __global__ __launch_bounds__(kPcThreads) void gno_dh_pc_kernel(const int32_t *__
                                 v4f_g hT1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ubp1, cv, z, 0, 0, 0);
                                 GnoProd::relu4(hT0);
                                 GnoProd::relu4(hT1);
-                                v4f_g acc = a0;
+                                v4f_g acc = kh ? pprev[vi & 1][b] : cq;
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(gq[0][r], hT0[r], acc, 0, 0, 0);
 #pragma unroll
@@ -2190,8 +2196,27 @@ __global__ __launch_bounds__(kPcThreads) void gno_dh_pc_kernel(const int32_t *__
                                 // register there the compiler's hazard recogniser assumes the store's data registers may be rewritten
                                 // at once -- on gfx950 a VALU write straight behind the store then replaced the first dword of the
                                 // last 16 lanes' data: wrong partials for entries 12 .. 15 of some rows, found with the oracle)
+                                // (plain stores: the kh = 0 partial is read back four pieces on.  The finished partial alone
+                                // nontemporal -- a scalar branch on kh around two stores -- measured 0.4 ms SLOWER per reverse pass)
                                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_g, acc), prs,
                                                                        (16 * b + n) * (4 * kGF) + 16 * g + 64 * c, 0, GNO_PX_AUX);
+                            }
+                            // the kh = 0 partial of the vertex that comes TWO vertices on (in this piece or the next), if that one
+                            // is a kh = 1 piece: an UNCONDITIONAL load -- a dead offset otherwise -- issued in front of this
+                            // vertex's feature prefetch, so that the wait for it leaves those in flight.  Two vertices of matrix
+                            // work cover its trip to the L2 / Infinity Cache, where the partial written four pieces ago still is.
+                            {
+                                static_assert(VPW % 2 == 0, "the two-slot ring of read-back partials");
+                                const int vn = (vi + 2) % VPW;
+                                const int pn = pcp + (vi + 2) / VPW;                // the piece that vertex belongs to
+                                const bool want = pn >= 4 && pn < 8;
+                                __amdgpu_buffer_rsrc_t nrs = __builtin_amdgcn_make_buffer_rsrc(
+                                    (void *)(px + (size_t)cur.w0[vn] * kGF), 0, cur.len[vn] * (4 * kGF), 0x00020000);
+#pragma unroll
+                                for (int b = 0; b < NB; ++b) {
+                                    const uint32_t o = (uint32_t)((16 * b + n) * (4 * kGF) + 16 * g + 64 * (pn & 3));
+                                    pprev[vi & 1][b] = __builtin_bit_cast(v4f_g, __builtin_amdgcn_raw_buffer_load_b128(nrs, (int)(want ? o : GnoProd::kDead), 0, 0));
+                                }
                             }
                         }
                         // the next piece's feature chunks (from a tile's last piece on: the next tile's)
@@ -2253,7 +2278,6 @@ __global__ __launch_bounds__(256) void gno_px_long_kernel(const int32_t *__restr
             float sacc = cvec[(size_t)row * kGF + k];   // k doubles as q
             for (int kk = 0; kk < kGH; ++kk) sacc = fmaf(hs[slot][kk], G[kk][k], sacc);
             px[(size_t)w * kGF + k] = e >= 0 ? sacc : 0.0f;
-            px[px_half + (size_t)w * kGF + k] = 0.0f;
         }
         __syncthreads();
     }
@@ -2284,11 +2308,19 @@ __global__ void gno_t_entry_kernel(const int32_t *__restrict__ rowptr, const int
     }
 }
 
-// dx[u,:] = sum over the transposed row of u of px[0][w] + px[1][w] (64 floats each): 16 lanes x 16 bytes per column,
+static __device__ __forceinline__ v4f_g px_load(const float *p)
+{
+#if GNO_PX_NT_LOAD
+    return __builtin_nontemporal_load(reinterpret_cast<const v4f_g *>(p));
+#else
+    return *reinterpret_cast<const v4f_g *>(p);
+#endif
+}
+
+// dx[u,:] = sum over the transposed row of u of px[w] (64 floats each): 16 lanes x 16 bytes per column,
 // sources ascending (the reference's accumulation order, athena_diffstruc_extd_sub_nop.f90:441-452)
 __global__ __launch_bounds__(256) void gno_px_gather_kernel(const int32_t *__restrict__ t_rowptr, const int32_t *__restrict__ t_entry,
-                                                            const float *__restrict__ px, size_t px_half, int n_cols,
-                                                            float *__restrict__ dx)
+                                                            const float *__restrict__ px, int n_cols, float *__restrict__ dx)
 {
     const int l = threadIdx.x & 15;
     const int u = blockIdx.x * 16 + (threadIdx.x >> 4);
@@ -2297,40 +2329,26 @@ __global__ __launch_bounds__(256) void gno_px_gather_kernel(const int32_t *__res
     const v4f_g z = {0.0f, 0.0f, 0.0f, 0.0f};
     v4f_g acc = z;
     int t = b;
-    for (; t + 3 < e; t += 4) {   // eight 16-byte loads in flight per lane; the sums stay in source order
-        int w[4];
-        v4f_g p0[4], p1[4];
+    for (; t + 7 < e; t += 8) {   // eight 16-byte loads in flight per lane; the sums stay in source order
+        int w[8];
+        v4f_g pv[8];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = t_entry[t + i];
+        for (int i = 0; i < 8; ++i) w[i] = t_entry[t + i];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float *pp = px + (size_t)(w[i] < 0 ? 0 : w[i]) * kGF + 4 * l;
-#if GNO_PX_NT_LOAD
-            p0[i] = __builtin_nontemporal_load(reinterpret_cast<const v4f_g *>(pp));
-            p1[i] = __builtin_nontemporal_load(reinterpret_cast<const v4f_g *>(pp + px_half));
-#else
-            p0[i] = *reinterpret_cast<const v4f_g *>(pp);
-            p1[i] = *reinterpret_cast<const v4f_g *>(pp + px_half);
-#endif
-        }
+        for (int i = 0; i < 8; ++i) pv[i] = px_load(px + (size_t)(w[i] < 0 ? 0 : w[i]) * kGF + 4 * l);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (w[i] >= 0) acc = acc + (p0[i] + p1[i]);
+        for (int i = 0; i < 8; ++i)
+            if (w[i] >= 0) acc = acc + pv[i];
     }
     for (; t + 1 < e; t += 2) {
         const int wa = t_entry[t], wb = t_entry[t + 1];
-        const float *pa = px + (size_t)(wa < 0 ? 0 : wa) * kGF + 4 * l, *pb = px + (size_t)(wb < 0 ? 0 : wb) * kGF + 4 * l;
-        const v4f_g a0 = *reinterpret_cast<const v4f_g *>(pa), a1 = *reinterpret_cast<const v4f_g *>(pa + px_half);
-        const v4f_g b0 = *reinterpret_cast<const v4f_g *>(pb), b1 = *reinterpret_cast<const v4f_g *>(pb + px_half);
-        if (wa >= 0) acc = acc + (a0 + a1);
-        if (wb >= 0) acc = acc + (b0 + b1);
+        const v4f_g pa = px_load(px + (size_t)(wa < 0 ? 0 : wa) * kGF + 4 * l), pb = px_load(px + (size_t)(wb < 0 ? 0 : wb) * kGF + 4 * l);
+        if (wa >= 0) acc = acc + pa;
+        if (wb >= 0) acc = acc + pb;
     }
     if (t < e) {
         const int wa = t_entry[t];
-        if (wa >= 0) {
-            const float *pa = px + (size_t)wa * kGF + 4 * l;
-            acc = acc + (*reinterpret_cast<const v4f_g *>(pa) + *reinterpret_cast<const v4f_g *>(pa + px_half));
-        }
+        if (wa >= 0) acc = acc + px_load(px + (size_t)wa * kGF + 4 * l);
     }
     *reinterpret_cast<v4f_g *>(dx + (size_t)u * kGF + 4 * l) = acc;
 }
@@ -2713,7 +2731,7 @@ int athena_mp_gno_aggregate_bwd_theta(const athena_mp_graph *g, int32_t d, int32
  * :235-325 kernel parameters, :137-216 coordinates): any of dx / dtheta / dcoords may be NULL.  Shapes and sizes that take
  * the producer / consumer kernels (H = F_in = F_out = 64, d <= 3, tensors below 4 GB, at most 1 row in 64 longer than 32
  * entries) run:  S^T g (streamed from s_save when given, rebuilt otherwise) -> dVaug;  gno_dh_pc_kernel<PX> -> dU, db_u,
- * the per-entry partials of dx [2][nnz][64] (and the per-entry dh for dcoords);  gno_px_gather_kernel -> dx.  Everything
+ * the per-entry partials of dx [nnz][64] (and the per-entry dh for dcoords);  gno_px_gather_kernel -> dx.  Everything
  * else is the three separate entry points, one after the other.  *fused (may be NULL) says which it was. */
 int athena_mp_gno_aggregate_bwd(const athena_mp_graph *g, int32_t d, int32_t H, int32_t Fi, int32_t Fo, const float *theta,
                                 const float *coords, const float *x, const float *grad, const float *s_save, float *dx,
@@ -2745,7 +2763,7 @@ int athena_mp_gno_aggregate_bwd(const athena_mp_graph *g, int32_t d, int32_t H, 
     const size_t off_V = (size_t)H * d + H;
     const size_t px_half = (size_t)std::max<int64_t>(g->nnz, 1) * kGF;
     void *pxp = nullptr, *cvp = nullptr, *dth_tmp = nullptr;
-    if (workspace(&pxp, sizeof(float) * 2 * px_half, 13)) return 1;
+    if (workspace(&pxp, sizeof(float) * px_half, 13)) return 1;
     if (workspace(&cvp, sizeof(float) * kGF * (size_t)g->n_rows, 14)) return 1;
     if (!g->t_entry && g->nnz > 0) {
         int32_t *te = nullptr;
@@ -2782,7 +2800,7 @@ int athena_mp_gno_aggregate_bwd(const athena_mp_graph *g, int32_t d, int32_t H, 
         AMP_HIP(hipStreamWaitEvent(gs, ev[0], 0));
     }
     hipLaunchKernelGGL(gno_px_gather_kernel, dim3((g->n_cols + 15) / 16), dim3(256), 0, gs, g->t_rowptr, g->t_entry,
-                       (const float *)pxp, px_half, g->n_cols, dx);
+                       (const float *)pxp, g->n_cols, dx);
     const bool launched = hipGetLastError() == hipSuccess;
     if (gs != main_s) AMP_HIP(hipEventRecord(ev[1], gs));
     int rc = 0;

@@ -336,7 +336,7 @@ int athena_mp_gno_aggregate_bwd_theta_saved(const athena_mp_graph *g, int32_t d,
  * emits every entry's partial h_e^T G_i of dx, and a gather over the transposed CSR sums them.  Shapes
  * outside the fused kernels run the separate entry points; *fused_out (may be NULL) reports which it was.  Same values
  * as the separate entry points to fp32 rounding (the sums associate differently).  The per-entry partials live in a
- * library workspace of 2 * nnz * 256 bytes (15 GB at BASELINE configs[3]; grown on demand, reused by every call, released
+ * library workspace of nnz * 256 bytes (7.6 GB at BASELINE configs[3]; grown on demand, reused by every call, released
  * by athena_mp_finalize), the transposed-entry map (nnz int32) in the graph handle.
  * STREAMS: with dtheta requested, the gather of the partials runs on a second, library-owned stream beside the S^T g launch
  * (fork after the kernel MLP's launches, join before the call returns: the caller's stream waits for it, so the outputs are
