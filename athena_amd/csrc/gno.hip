@@ -2072,9 +2072,17 @@ __global__ __launch_bounds__(kPcThreads) void gno_dh_pc_kernel(const int32_t *__
         __amdgpu_buffer_rsrc_t cvrs = __builtin_amdgcn_make_buffer_rsrc((void *)cvec, 0, PX ? (int)g_bytes : 0, 0x00020000);
         auto c_off = [&](const GnoIds &I) { return (uint32_t)P.by_group(I.row) * (4u * kGF) + 16u * (uint32_t)n; };
         v4f_g cnext = z;
-        v4f_g pprev[2][NB];       // the kh = 0 partials of the two vertices whose kh = 1 pieces come next
+        // the kh = 0 partials of the kAhead vertices whose kh = 1 pieces come next (a ring: VPW is a multiple of kAhead)
+#ifndef GNO_PX_AHEAD
+#define GNO_PX_AHEAD 2
+#endif
+        constexpr int kAhead = GNO_PX_AHEAD < VPW ? GNO_PX_AHEAD : VPW;
+        static_assert(VPW % kAhead == 0, "the ring of read-back partials");
+        v4f_g pprev[kAhead][NB];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) pprev[0][b] = pprev[1][b] = z;
+        for (int a = 0; a < kAhead; ++a)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) pprev[a][b] = z;
         if constexpr (PX) {
             const v4f_g c0 = __builtin_bit_cast(v4f_g, __builtin_amdgcn_raw_buffer_load_b128(cvrs, (int)c_off(cur), 0, 0));
             *reinterpret_cast<v4f_g *>(cstrip + 4 * lane) = c0;
@@ -2186,7 +2194,7 @@ __global__ __launch_bounds__(kPcThreads) void gno_dh_pc_kernel(const int32_t *__
                                 v4f_g hT1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ubp1, cv, z, 0, 0, 0);
                                 GnoProd::relu4(hT0);
                                 GnoProd::relu4(hT1);
-                                v4f_g acc = kh ? pprev[vi & 1][b] : cq;
+                                v4f_g acc = kh ? pprev[vi % kAhead][b] : cq;
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(gq[0][r], hT0[r], acc, 0, 0, 0);
 #pragma unroll
@@ -2206,16 +2214,15 @@ __global__ __launch_bounds__(kPcThreads) void gno_dh_pc_kernel(const int32_t *__
                             // vertex's feature prefetch, so that the wait for it leaves those in flight.  Two vertices of matrix
                             // work cover its trip to the L2 / Infinity Cache, where the partial written four pieces ago still is.
                             {
-                                static_assert(VPW % 2 == 0, "the two-slot ring of read-back partials");
-                                const int vn = (vi + 2) % VPW;
-                                const int pn = pcp + (vi + 2) / VPW;                // the piece that vertex belongs to
+                                const int vn = (vi + kAhead) % VPW;
+                                const int pn = pcp + (vi + kAhead) / VPW;           // the piece that vertex belongs to
                                 const bool want = pn >= 4 && pn < 8;
                                 __amdgpu_buffer_rsrc_t nrs = __builtin_amdgcn_make_buffer_rsrc(
                                     (void *)(px + (size_t)cur.w0[vn] * kGF), 0, cur.len[vn] * (4 * kGF), 0x00020000);
 #pragma unroll
                                 for (int b = 0; b < NB; ++b) {
                                     const uint32_t o = (uint32_t)((16 * b + n) * (4 * kGF) + 16 * g + 64 * (pn & 3));
-                                    pprev[vi & 1][b] = __builtin_bit_cast(v4f_g, __builtin_amdgcn_raw_buffer_load_b128(nrs, (int)(want ? o : GnoProd::kDead), 0, 0));
+                                    pprev[vi % kAhead][b] = __builtin_bit_cast(v4f_g, __builtin_amdgcn_raw_buffer_load_b128(nrs, (int)(want ? o : GnoProd::kDead), 0, 0));
                                 }
                             }
                         }
