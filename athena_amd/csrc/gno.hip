@@ -213,6 +213,9 @@ typedef unsigned int v4u_g __attribute__((ext_vector_type(4)));
 #ifndef GNO_PX_NT_LOAD
 #define GNO_PX_NT_LOAD 1   // gno_px_gather_kernel reads the partials (15 GB, read once) with nontemporal loads: A/B in profiles/r04_c4_px_store_ab.txt
 #endif
+#ifndef GNO_PX_RB_AUX
+#define GNO_PX_RB_AUX 0   // cache bits of the read-back of the kh = 0 partial (2 = nt: A/B in profiles/r04_c4_px_one_array_ab.txt)
+#endif
 #ifndef GNO_PX_AUX
 #define GNO_PX_AUX 0   // cache bits of the per-entry partials' stores (1 sc0, 2 nt, 16 sc1): none -- A/B in profiles/r04_c4_px_one_array_ab.txt
 #endif
@@ -2222,7 +2225,7 @@ __global__ __launch_bounds__(kPcThreads) void gno_dh_pc_kernel(const int32_t *__
 #pragma unroll
                                 for (int b = 0; b < NB; ++b) {
                                     const uint32_t o = (uint32_t)((16 * b + n) * (4 * kGF) + 16 * g + 64 * (pn & 3));
-                                    pprev[vi % kAhead][b] = __builtin_bit_cast(v4f_g, __builtin_amdgcn_raw_buffer_load_b128(nrs, (int)(want ? o : GnoProd::kDead), 0, 0));
+                                    pprev[vi % kAhead][b] = __builtin_bit_cast(v4f_g, __builtin_amdgcn_raw_buffer_load_b128(nrs, (int)(want ? o : GnoProd::kDead), 0, GNO_PX_RB_AUX));
                                 }
                             }
                         }
