@@ -440,7 +440,9 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 // from LDS, the softmax is two cross-lane steps (readout.hip), and z is not read back from HBM by a readout launch
 // (600 MB at configs[2]).  p rows are 4 O bytes: written with bounds-checked buffer stores, lanes beyond O pointed past it.
 template <int KJ, int OT, bool RO>
-__global__ __launch_bounds__(256, 2) void duv_rows_wide_kernel(BucketSplit sp, const int32_t *__restrict__ trows,
+// (two waves per SIMD wherever 256 registers hold the shape; the 96-wide shapes that do not -- 24 accumulators, or 24 input
+// fragments beside the readout's -- get the whole register file rather than spills inside the tile loop: scripts/isa_lint.py R2)
+__global__ __launch_bounds__(256, ((OT > 5 || (KJ > 5 && RO)) ? 1 : 2)) void duv_rows_wide_kernel(BucketSplit sp, const int32_t *__restrict__ trows,
                                                             const int32_t *__restrict__ trows_t,
                                                             const float *__restrict__ X, int K,
                                                             const float *__restrict__ W, int64_t wb, int so, int sk,
@@ -798,7 +800,7 @@ __global__ __launch_bounds__(256, 2) void duv_dw_wide_kernel(BucketSplit sp, con
 // tile's first vertex: their a row is zeroed (no weight gradient), their g row is not, so their da row is that vertex's
 // own -- a benign duplicate store.
 template <int IT, int OT>
-__global__ __launch_bounds__(256, 2) void duv_bwd_wide_kernel(BucketSplit sp, const int32_t *__restrict__ trows,
+__global__ __launch_bounds__(256, (IT * OT > 20 ? 1 : 2)) void duv_bwd_wide_kernel(BucketSplit sp, const int32_t *__restrict__ trows,
                                                               const int32_t *__restrict__ trows_t,
                                                               const float *__restrict__ A, int Fi,
                                                               const float *__restrict__ G, int Fo,

@@ -392,6 +392,7 @@ __global__ __launch_bounds__(256, 1) void gemm_dw_full_kernel(const float *__res
     constexpr int U = 4;
     __shared__ __attribute__((aligned(16))) float red[FI * FO];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);   // in an SGPR for the epilogue (see there)
     const int m = lane & 31, h = lane >> 5;
     int64_t bx = blockIdx.x;          // the row range
     size_t slab_id = blockIdx.x;
@@ -441,14 +442,20 @@ __global__ __launch_bounds__(256, 1) void gemm_dw_full_kernel(const float *__res
     }
     // wave-ordered reduction of the four tiles; element (ti, r) of lane (m,h) is dWt[i][TJ*m .. +TJ-1]
     // with i = TI*((r&3) + 8*(r>>2) + 4*h) + ti  -> one TJ-wide vector store per (ti, r)
+    // The lane index is derived AFRESH here (v_mbcnt through a volatile asm the compiler cannot merge with the value the main
+    // loop used) and the wave index travels in an SGPR: at 128 x 128 every vector register is taken inside the loop, and a
+    // thread index kept alive across it went to scratch (16 B per lane: scripts/isa_lint.py rule R1).
+    int lane_e;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    const int m_e = lane_e & 31, h_e = lane_e >> 5;
     for (int p = 0; p < 4; ++p) {
-        if (wave == p) {
+        if (wave_s == p) {
 #pragma unroll
             for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int i = TI * ((r & 3) + 8 * (r >> 2) + 4 * h) + ti;
-                    float *dst = red + i * FO + TJ * m;
+                    const int i = TI * ((r & 3) + 8 * (r >> 2) + 4 * h_e) + ti;
+                    float *dst = red + i * FO + TJ * m_e;
 #pragma unroll
                     for (int tj = 0; tj < TJ; ++tj) dst[tj] = (p == 0 ? 0.0f : dst[tj]) + acc[ti][tj][r];
                 }
@@ -456,7 +463,7 @@ __global__ __launch_bounds__(256, 1) void gemm_dw_full_kernel(const float *__res
         __syncthreads();
     }
     float *slab = slabs + slab_id * FI * FO;
-    for (int t = threadIdx.x; t < FI * FO / 4; t += 256)
+    for (int t = wave_s * 64 + lane_e; t < FI * FO / 4; t += 256)
         reinterpret_cast<v4f *>(slab)[t] = reinterpret_cast<const v4f *>(red)[t];
 }
 
