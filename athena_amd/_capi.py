@@ -158,6 +158,10 @@ _PROTOS = {
     "athena_mp_gno_aggregate_bwd_x_host": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "athena_mp_gno_aggregate_bwd_theta_host": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
     "athena_mp_gno_aggregate_bwd_coords_host": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
+    "athena_mp_duvenaud_update_readout_fwd_host": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp],
+    "athena_mp_duvenaud_update_bwd_pair_host": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp],
+    "athena_mp_gno_aggregate_bwd_pair_host": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp],
+    "athena_mp_pair_stats": [C.POINTER(_i64), C.POINTER(_i64)],
 }
 
 

@@ -19,6 +19,8 @@ for s in $SRCS; do
     pids="$pids $!"
   fi
 done
-for p in $pids; do wait $p; done
+fail=0
+for p in $pids; do wait $p || fail=1; done     # a failed compile must not link the stale object of the last good build
+[ $fail -eq 0 ] || { echo "build.sh: compilation failed" >&2; exit 1; }
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o $OUT
 echo "built $(readlink -f $OUT)"

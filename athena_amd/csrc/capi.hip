@@ -506,6 +506,22 @@ void key_array(KeyHash &h, const int32_t *p, int64_t count)
 }
 }   // namespace
 
+extern "C++" {
+namespace amp {
+// 64-bit hash of EVERY byte of a host array (the chunked, threaded hash of the graph key): the "same content" test of
+// the pair slots in host.hip
+uint64_t content_hash(const void *p, size_t bytes)
+{
+    KeyHash h(0x51ed270b1f2e4a13ull);
+    h.word((uint64_t)bytes);
+    key_array(h, (const int32_t *)p, (int64_t)(bytes / 4));
+    const unsigned char *t = (const unsigned char *)p + (bytes & ~(size_t)3);
+    for (size_t i = 0; i < (bytes & 3); ++i) h.word((uint64_t)t[i] | 0x7700ull);
+    return h.digest();
+}
+}   // namespace amp
+}   // extern "C++"
+
 int athena_mp_graph_key(int32_t n_rows, int64_t nnz, const int32_t *adj_ia, const int32_t *adj_ja, uint64_t *key)
 {
     AMP_REQUIRE(key != nullptr, "graph_key: null key pointer");

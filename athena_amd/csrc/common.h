@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include <atomic>
 #include <vector>
 
 #include "../../include/athena_mp.h"
@@ -70,10 +71,17 @@ struct LongPlan {
 };
 
 // ---- graph handle: everything the kernels need, resident in HBM --------------------------------
+inline uint64_t next_graph_serial()
+{
+    static std::atomic<uint64_t> n{0};
+    return ++n;
+}
 struct athena_mp_graph {
     int32_t n_rows = 0, n_cols = 0, n_edge_cols = 0;
     int64_t nnz = 0;
     int32_t max_row_len = 0, max_col_len = 0;
+    // unique per handle for the life of the process (a freed handle's ADDRESS can come back; its serial never does)
+    uint64_t serial = next_graph_serial();
     // handle cache (athena_mp_graph_acquire / _release): users of a cached handle, -1 = not cached
     int32_t cache_refs = -1;
     bool cache_linked = false;   // still findable by key (false after athena_mp_graph_evict / athena_mp_finalize)
@@ -133,6 +141,7 @@ int csr_from_edges_core(int32_t n_vertices, int64_t n_pairs, const int32_t *inde
 void gno_forget_perm(const int32_t *perm_dev);   // gno.hip: counts cached beside a row-length order
 void graph_cache_clear(); // idle and live handles of athena_mp_graph_acquire (capi.hip)
 void host_pool_release();   // staging buffers of the *_host entry points (host.hip)
+uint64_t content_hash(const void *p, size_t bytes);   // every byte of a host array (capi.hip)
 int agg_blocks_cap();
 void set_agg_blocks_cap(int n);
 // shared launchers (defined in agg.hip / gemm.hip)

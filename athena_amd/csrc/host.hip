@@ -60,10 +60,12 @@ struct Resident {
     bool dev_newer = false;   // the device copy is the only valid one (host holds the sentinel)
     bool trusted = false;     // caller promised (acquire with dirty_host = 0) that host code does not change the array
     uint64_t id = 0;
+    uint64_t version = 0;     // bumped whenever the device copy's content changes (upload, result of a call, release dirty)
 };
 std::map<const char *, Resident> g_res;
 bool g_res_on = false;
 uint64_t g_res_next_id = 1;
+uint64_t g_res_version = 1;
 struct ResidentStats {
     int64_t h2d_bytes = 0, d2h_bytes = 0, reused_inputs = 0, lazy_outputs = 0;
     int64_t stale_dropped = 0;   // flushes skipped because the host array had been overwritten (sentinel gone)
@@ -156,6 +158,7 @@ int resident_get(const void *host, size_t bytes, bool as_input, void **dev)
         AMP_HIP(hipMemcpyAsync(r.dev, host, bytes, hipMemcpyHostToDevice, stream()));
         g_res_stats.h2d_bytes += (int64_t)bytes;
         r.dev_newer = false;
+        r.version = ++g_res_version;
     }
     *dev = r.dev;
     return 0;
@@ -205,6 +208,7 @@ template <typename Body> int staged(std::initializer_list<Stage> args, Body &&bo
                 Resident &r = g_res[(const char *)s.out];
                 r.dev_newer = true;
                 r.trusted = false;
+                r.version = ++g_res_version;
                 sentinel_write(r, s.out);
                 ++g_res_stats.lazy_outputs;
             } else if (hipMemcpyAsync(s.out, s.dev, s.bytes, hipMemcpyDeviceToHost, stream()) != hipSuccess) {
@@ -224,6 +228,69 @@ template <typename Body> int staged(std::initializer_list<Stage> args, Body &&bo
 
 inline size_t fb(int64_t rows, int64_t cols) { return sizeof(float) * (size_t)rows * (size_t)cols; }
 
+// ---- pair slots: both partials of a two-operand node from ONE device pass, across two stateless callbacks ----------------
+// diffstruc's grad_reverse asks a node for its partials one at a time, each through a `pure` callback with an intent(in)
+// node: the callback can keep nothing.  The fused reverse kernels produce both partials from one pass over the upstream
+// gradient (athena_mp_duvenaud_update_bwd: 1.95 instead of 2.55 GB at BASELINE configs[2]; athena_mp_gno_aggregate_bwd: one
+// G = g Vmat^T for dx and dtheta).  A *_pair_host entry point therefore computes BOTH on the first request, hands over the one
+// asked for and parks the other on the device; the second request takes the parked one if -- and only if -- it names the
+// same graph handle, the same shapes and operand arrays with the same CONTENT.  "Same content" is a stamp per operand: for an
+// array that lives in the residency table behind an intact sentinel, the table entry's (id, version) -- the version moves
+// whenever the device copy is rewritten; for any other array a 64-bit hash of every byte (amp::content_hash, the graph key's
+// threaded hash).  A parked partial is handed over once, then the slot is empty; a request that does not match recomputes
+// and re-parks.  One slot per op kind: the two callbacks of a node run back to back in grad_reverse.
+uint64_t operand_stamp(const void *host, size_t bytes)
+{
+    if (g_res_on && bytes >= kResidentMin) {
+        auto it = g_res.find((const char *)host);
+        if (it != g_res.end() && it->second.bytes == bytes && it->second.dev_newer && sentinel_intact(it->second, host))
+            return 0x8000000000000000ull | (it->second.id << 24) ^ it->second.version;
+    }
+    return content_hash(host, bytes) & 0x7fffffffffffffffull;
+}
+struct PairSlot {
+    const athena_mp_graph *g = nullptr;
+    uint64_t serial = 0;                          // the handle's serial: its address may be reused, this is not
+    int32_t dims[4] = {0, 0, 0, 0};
+    uint64_t stamp[4] = {0, 0, 0, 0};
+    void *dev[3] = {nullptr, nullptr, nullptr};   // parked products
+    size_t cap[3] = {0, 0, 0};
+    bool ready[3] = {false, false, false};        // computed for (g, dims, stamp) and not handed over yet
+    bool matches(const athena_mp_graph *g_, const int32_t (&d)[4], const uint64_t (&st)[4]) const
+    {
+        return g == g_ && serial == g_->serial && memcmp(dims, d, sizeof(dims)) == 0 && memcmp(stamp, st, sizeof(stamp)) == 0;
+    }
+    int reserve(int k, size_t bytes)
+    {
+        if (cap[k] >= bytes) return 0;
+        if (dev[k]) {
+            AMP_HIP(hipStreamSynchronize(stream()));
+            AMP_HIP(hipFree(dev[k]));
+            dev[k] = nullptr;
+            cap[k] = 0;
+        }
+        AMP_HIP(hipMalloc(&dev[k], bytes));
+        cap[k] = bytes;
+        return 0;
+    }
+    void clear()
+    {
+        g = nullptr;
+        ready[0] = ready[1] = ready[2] = false;
+    }
+    void release()
+    {
+        for (int k = 0; k < 3; ++k) {
+            if (dev[k]) (void)hipFree(dev[k]);
+            dev[k] = nullptr;
+            cap[k] = 0;
+        }
+        clear();
+    }
+};
+PairSlot g_pair_duv, g_pair_gno;
+int64_t g_pair_fused = 0, g_pair_handed = 0;
+
 } // namespace
 
 namespace amp {
@@ -232,6 +299,8 @@ void host_pool_release()
     for (auto &kv : g_res) resident_free(kv.second);   // finalize: no flush, the process is letting go of the device
     g_res.clear();
     g_res_on = false;
+    g_pair_duv.release();
+    g_pair_gno.release();
     for (int i = 0; i < kMaxStaged; ++i) {
         if (g_pool[i]) (void)hipFree(g_pool[i]);
         g_pool[i] = nullptr;
@@ -275,6 +344,7 @@ int athena_mp_resident_acquire(const void *host_ptr, uint64_t bytes, int32_t dir
         AMP_HIP(hipMemcpyAsync(r.dev, host_ptr, (size_t)bytes, hipMemcpyHostToDevice, stream()));
         g_res_stats.h2d_bytes += (int64_t)bytes;
         r.dev_newer = false;
+        r.version = ++g_res_version;
     }
     r.trusted = true;   // until a release says the device copy changed, or a *_host call writes it
     *dev_ptr = r.dev;
@@ -287,6 +357,7 @@ int athena_mp_resident_release(const void *host_ptr, int32_t dirty_dev)
     if (dirty_dev) {
         it->second.dev_newer = true;
         it->second.trusted = false;
+        it->second.version = ++g_res_version;
         sentinel_write(it->second, (void *)host_ptr);
     }
     return 0;
@@ -581,6 +652,128 @@ int athena_mp_activation_param_bwd_host(int32_t kind, int64_t n, float scale, fl
     return staged({{x, nullptr, fb(n, 1)}, {g, nullptr, fb(n, 1)}, {nullptr, dx, fb(n, 1)}}, [&](std::vector<void *> &d) {
         return athena_mp_activation_param_bwd(kind, n, scale, p0, p1, (float *)d[0], (float *)d[1], (float *)d[2]);
     });
+}
+
+// update + activation + the readout's per-vertex softmax(R z) of the same time step (athena_mp_duvenaud_update_readout_fwd)
+int athena_mp_duvenaud_update_readout_fwd_host(const athena_mp_graph *g, int32_t Fi, int32_t Fo, int32_t mn, int32_t mx,
+                                               const float *a, const float *w, int32_t act, float *z, int32_t O, const float *R,
+                                               float *p)
+{
+    AMP_REQUIRE(g && a && w && z && R && p && Fi > 0 && Fo > 0 && O > 0 && mx >= mn, "duvenaud_update_readout_fwd_host: bad arguments");
+    const int64_t N = g->n_rows;
+    return staged({{a, nullptr, fb(N, Fi)}, {w, nullptr, fb((int64_t)Fi * Fo, mx - mn + 1)}, {R, nullptr, fb(O, Fo)},
+                   {nullptr, z, fb(N, Fo)}, {nullptr, p, fb(N, O)}},
+                  [&](std::vector<void *> &d) {
+                      return athena_mp_duvenaud_update_readout_fwd(g, Fi, Fo, mn, mx, (float *)d[0], (float *)d[1], act, (float *)d[3],
+                                                                   O, (float *)d[2], (float *)d[4]);
+                  });
+}
+
+// which = 0: da [n_rows, Fi] (get_partial_duvenaud_update_val, :284-324) | 1: dweight [Fo Fi D] (:326-368)
+// act != ATHENA_MP_ACT_NONE: the node is update + message activation in one (its value z = act(duvenaud_update(a, w)), what
+// athena_mp_duvenaud_update_act_fwd / _update_readout_fwd produce): grad is the gradient w.r.t. z and the activation's factor
+// act'(z) is applied on the device first (relu / sigmoid / tanh differentiate at the OUTPUT); z_or_null = z [n_rows, Fo]
+int athena_mp_duvenaud_update_bwd_pair_host(const athena_mp_graph *g, int32_t Fi, int32_t Fo, int32_t mn, int32_t mx, int32_t act,
+                                            const float *z_or_null, const float *grad, const float *a, const float *w,
+                                            int32_t which, float *out)
+{
+    AMP_REQUIRE(g && grad && a && w && out && Fi > 0 && Fo > 0 && mx >= mn && (which == 0 || which == 1),
+                "duvenaud_update_bwd_pair_host: bad arguments");
+    AMP_REQUIRE(act == ATHENA_MP_ACT_NONE || z_or_null, "duvenaud_update_bwd_pair_host: an activation needs the node's value z");
+    const bool has_act = act != ATHENA_MP_ACT_NONE;
+    const int64_t N = g->n_rows;
+    const int32_t D = mx - mn + 1;
+    const size_t bytes[2] = {fb(N, Fi), fb((int64_t)Fi * Fo, D)};
+    const int32_t dims[4] = {Fi, Fo, mn | (act << 16), mx};
+    const uint64_t st[4] = {operand_stamp(grad, fb(N, Fo)), operand_stamp(a, fb(N, Fi)), operand_stamp(w, bytes[1]),
+                            has_act ? operand_stamp(z_or_null, fb(N, Fo)) : 0};
+    PairSlot &S = g_pair_duv;
+    if (S.matches(g, dims, st) && S.ready[which]) {
+        S.ready[which] = false;
+        ++g_pair_handed;
+        return staged({{nullptr, out, bytes[which]}}, [&](std::vector<void *> &d) {
+            AMP_HIP(hipMemcpyAsync(d[0], S.dev[which], bytes[which], hipMemcpyDeviceToDevice, stream()));
+            return 0;
+        });
+    }
+    const int other = 1 - which;
+    S.clear();
+    if (S.reserve(other, bytes[other])) return 1;
+    if (has_act && S.reserve(2, fb(N, Fo))) return 1;   // dc = act'(z) * grad
+    const int rc = staged({{grad, nullptr, fb(N, Fo)}, {a, nullptr, fb(N, Fi)}, {w, nullptr, bytes[1]},
+                           {has_act ? z_or_null : nullptr, nullptr, has_act ? fb(N, Fo) : 0}, {nullptr, out, bytes[which]}},
+                          [&](std::vector<void *> &d) {
+                              const float *dc = (const float *)d[0];
+                              if (has_act) {
+                                  if (int e = athena_mp_activation_bwd(act, N * (int64_t)Fo, (const float *)d[3], (const float *)d[0], (float *)S.dev[2]))
+                                      return e;
+                                  dc = (const float *)S.dev[2];
+                              }
+                              float *da = which == 0 ? (float *)d[4] : (float *)S.dev[0];
+                              float *dw = which == 1 ? (float *)d[4] : (float *)S.dev[1];
+                              return athena_mp_duvenaud_update_bwd(g, Fi, Fo, mn, mx, dc, (float *)d[1], (float *)d[2], da, dw);
+                          });
+    if (rc) return rc;
+    S.g = g;
+    S.serial = g->serial;
+    memcpy(S.dims, dims, sizeof(dims));
+    memcpy(S.stamp, st, sizeof(st));
+    S.ready[other] = true;
+    ++g_pair_fused;
+    return 0;
+}
+
+// which = 0: dx [n_cols, Fi] (get_partial_gno_agg_features_val, athena_diffstruc_extd_sub_nop.f90:419-458)
+//         1: dtheta (:480-526 composed with get_partial_gno_kernel_params_val :235-325)
+//         2: dcoords [n_edge_cols, d] (:137-216) -- computed only when it is the one asked for
+int athena_mp_gno_aggregate_bwd_pair_host(const athena_mp_graph *g, int32_t d, int32_t H, int32_t Fi, int32_t Fo,
+                                          const float *theta, const float *coords, const float *x, const float *grad,
+                                          int32_t which, float *out)
+{
+    AMP_REQUIRE(g && d > 0 && H > 0 && Fi > 0 && Fo > 0 && theta && coords && x && grad && out && which >= 0 && which <= 2,
+                "gno_aggregate_bwd_pair_host: bad arguments");
+    const size_t tb = sizeof(float) * gno_theta_floats(d, H, Fi, Fo);
+    const size_t bytes[3] = {fb(g->n_cols, Fi), tb, fb(g->n_edge_cols, d)};
+    const int32_t dims[4] = {d, H, Fi, Fo};
+    const uint64_t st[4] = {operand_stamp(theta, tb), operand_stamp(coords, bytes[2]), operand_stamp(x, fb(g->n_cols, Fi)),
+                            operand_stamp(grad, fb(g->n_rows, Fo))};
+    PairSlot &S = g_pair_gno;
+    if (S.matches(g, dims, st) && S.ready[which]) {
+        S.ready[which] = false;
+        ++g_pair_handed;
+        return staged({{nullptr, out, bytes[which]}}, [&](std::vector<void *> &p) {
+            AMP_HIP(hipMemcpyAsync(p[0], S.dev[which], bytes[which], hipMemcpyDeviceToDevice, stream()));
+            return 0;
+        });
+    }
+    S.clear();
+    for (int k = 0; k < 2; ++k)
+        if (k != which && S.reserve(k, bytes[k])) return 1;
+    const int rc = staged({{theta, nullptr, tb}, {coords, nullptr, bytes[2]}, {x, nullptr, fb(g->n_cols, Fi)},
+                           {grad, nullptr, fb(g->n_rows, Fo)}, {nullptr, out, bytes[which]}},
+                          [&](std::vector<void *> &p) {
+                              float *dx = which == 0 ? (float *)p[4] : (float *)S.dev[0];
+                              float *dth = which == 1 ? (float *)p[4] : (float *)S.dev[1];
+                              float *dc = which == 2 ? (float *)p[4] : nullptr;
+                              return athena_mp_gno_aggregate_bwd(g, d, H, Fi, Fo, (float *)p[0], (float *)p[1], (float *)p[2], (float *)p[3],
+                                                                 nullptr, dx, dth, dc, nullptr);
+                          });
+    if (rc) return rc;
+    S.g = g;
+    S.serial = g->serial;
+    memcpy(S.dims, dims, sizeof(dims));
+    memcpy(S.stamp, st, sizeof(st));
+    S.ready[0] = which != 0;
+    S.ready[1] = which != 1;
+    ++g_pair_fused;
+    return 0;
+}
+
+int athena_mp_pair_stats(int64_t *fused_passes, int64_t *handed_over)
+{
+    if (fused_passes) *fused_passes = g_pair_fused;
+    if (handed_over) *handed_over = g_pair_handed;
+    return 0;
 }
 
 } // extern "C"

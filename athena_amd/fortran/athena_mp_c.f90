@@ -22,6 +22,10 @@ module athena_mp_c
   public :: athena_mp_duvenaud_propagate_bwd_e_host, athena_mp_duvenaud_update_bwd_a_host, athena_mp_duvenaud_update_bwd_w_host
   public :: athena_mp_gno_aggregate_fwd_host, athena_mp_gno_aggregate_bwd_x_host, athena_mp_gno_aggregate_bwd_theta_host
   public :: athena_mp_gno_aggregate_bwd_coords_host
+  public :: athena_mp_gemm_dw_host, athena_mp_gemm_dx_host, athena_mp_softmax_fwd_host, athena_mp_softmax_bwd_host
+  public :: athena_mp_activation_fwd_host, athena_mp_activation_bwd_host
+  public :: athena_mp_duvenaud_update_act_fwd_host, athena_mp_duvenaud_update_readout_fwd_host
+  public :: athena_mp_duvenaud_update_bwd_pair_host, athena_mp_gno_aggregate_bwd_pair_host, athena_mp_pair_stats
   public :: athena_mp_malloc, athena_mp_free, athena_mp_memcpy_h2d, athena_mp_memcpy_d2h
   public :: athena_mp_kipf_propagate_fwd, athena_mp_kipf_propagate_bwd
   public :: athena_mp_gemm_fwd, athena_mp_gemm_dw, athena_mp_gemm_dx
@@ -272,6 +276,94 @@ module athena_mp_c
        integer(c_int32_t), value :: d, H, Fi, Fo
        real(c_float), intent(in) :: theta(*), coords(*), x(*), grad(*)
        real(c_float), intent(inout) :: dcoords(*)
+     end function
+
+     !! ---- what a shim inside athena binds beyond the op-granular entry points (scripts/integration_check/) -----------
+     !! the reverse of matmul, for composite nodes that own a dense step: dW = P^T dZ, dP = dZ W^T
+     pure integer(c_int) function athena_mp_gemm_dw_host(N, Fi, Fo, P, dZ, dW) bind(C, name="athena_mp_gemm_dw_host")
+       import :: c_int, c_int32_t, c_int64_t, c_float
+       integer(c_int64_t), value :: N
+       integer(c_int32_t), value :: Fi, Fo
+       real(c_float), intent(in) :: P(*), dZ(*)
+       real(c_float), intent(inout) :: dW(*)
+     end function
+     pure integer(c_int) function athena_mp_gemm_dx_host(N, Fi, Fo, dZ, W, dP) bind(C, name="athena_mp_gemm_dx_host")
+       import :: c_int, c_int32_t, c_int64_t, c_float
+       integer(c_int64_t), value :: N
+       integer(c_int32_t), value :: Fi, Fo
+       real(c_float), intent(in) :: dZ(*), W(*)
+       real(c_float), intent(inout) :: dP(*)
+     end function
+     !! softmax over the features of every column (athena_diffstruc_extd_sub.f90:295-379) and its reverse at the OUTPUT
+     pure integer(c_int) function athena_mp_softmax_fwd_host(N, F, z, y) bind(C, name="athena_mp_softmax_fwd_host")
+       import :: c_int, c_int32_t, c_int64_t, c_float
+       integer(c_int64_t), value :: N
+       integer(c_int32_t), value :: F
+       real(c_float), intent(in) :: z(*)
+       real(c_float), intent(inout) :: y(*)
+     end function
+     pure integer(c_int) function athena_mp_softmax_bwd_host(N, F, y, g, dz) bind(C, name="athena_mp_softmax_bwd_host")
+       import :: c_int, c_int32_t, c_int64_t, c_float
+       integer(c_int64_t), value :: N
+       integer(c_int32_t), value :: F
+       real(c_float), intent(in) :: y(*), g(*)
+       real(c_float), intent(inout) :: dz(*)
+     end function
+     pure integer(c_int) function athena_mp_activation_fwd_host(act, n, z, y) bind(C, name="athena_mp_activation_fwd_host")
+       import :: c_int, c_int32_t, c_int64_t, c_float
+       integer(c_int32_t), value :: act
+       integer(c_int64_t), value :: n
+       real(c_float), intent(in) :: z(*)
+       real(c_float), intent(inout) :: y(*)
+     end function
+     pure integer(c_int) function athena_mp_activation_bwd_host(act, n, y, g, dz) bind(C, name="athena_mp_activation_bwd_host")
+       import :: c_int, c_int32_t, c_int64_t, c_float
+       integer(c_int32_t), value :: act
+       integer(c_int64_t), value :: n
+       real(c_float), intent(in) :: y(*), g(*)
+       real(c_float), intent(inout) :: dz(*)
+     end function
+     !! update + message activation (+ the readout's per-vertex softmax(R z)) of one Duvenaud time step in ONE launch
+     !! (athena_duvenaud_msgpass_layer.f90:790-803, 838-855)
+     pure integer(c_int) function athena_mp_duvenaud_update_act_fwd_host(graph, Fi, Fo, min_deg, max_deg, a, w, act, z) &
+          bind(C, name="athena_mp_duvenaud_update_act_fwd_host")
+       import :: c_int, c_int32_t, c_ptr, c_float
+       type(c_ptr), value :: graph
+       integer(c_int32_t), value :: Fi, Fo, min_deg, max_deg, act
+       real(c_float), intent(in) :: a(*), w(*)
+       real(c_float), intent(inout) :: z(*)
+     end function
+     pure integer(c_int) function athena_mp_duvenaud_update_readout_fwd_host(graph, Fi, Fo, min_deg, max_deg, a, w, act, z, &
+          O, R, p) bind(C, name="athena_mp_duvenaud_update_readout_fwd_host")
+       import :: c_int, c_int32_t, c_ptr, c_float
+       type(c_ptr), value :: graph
+       integer(c_int32_t), value :: Fi, Fo, min_deg, max_deg, act, O
+       real(c_float), intent(in) :: a(*), w(*), R(*)
+       real(c_float), intent(inout) :: z(*), p(*)
+     end function
+     !! BOTH partials of a two-operand node from one device pass, across diffstruc's two stateless `pure` callbacks: the first
+     !! request computes both and parks the other on the device, the second -- same handle, shapes and operand CONTENT -- takes
+     !! it (include/athena_mp.h).  which: 0 = left operand's partial, 1 = right operand's (GNO: 2 = coordinates).
+     !! act /= ATHENA_MP_ACT_NONE: the node is update + message activation in one; z = its value, grad the gradient w.r.t. z
+     pure integer(c_int) function athena_mp_duvenaud_update_bwd_pair_host(graph, Fi, Fo, min_deg, max_deg, act, z, grad, a, w, &
+          which, out) bind(C, name="athena_mp_duvenaud_update_bwd_pair_host")
+       import :: c_int, c_int32_t, c_ptr, c_float
+       type(c_ptr), value :: graph
+       integer(c_int32_t), value :: Fi, Fo, min_deg, max_deg, act, which
+       real(c_float), intent(in) :: z(*), grad(*), a(*), w(*)
+       real(c_float), intent(inout) :: out(*)
+     end function
+     pure integer(c_int) function athena_mp_gno_aggregate_bwd_pair_host(graph, d, H, Fi, Fo, theta, coords, x, grad, which, &
+          out) bind(C, name="athena_mp_gno_aggregate_bwd_pair_host")
+       import :: c_int, c_int32_t, c_ptr, c_float
+       type(c_ptr), value :: graph
+       integer(c_int32_t), value :: d, H, Fi, Fo, which
+       real(c_float), intent(in) :: theta(*), coords(*), x(*), grad(*)
+       real(c_float), intent(inout) :: out(*)
+     end function
+     integer(c_int) function athena_mp_pair_stats(fused_passes, handed_over) bind(C, name="athena_mp_pair_stats")
+       import :: c_int, c_int64_t
+       integer(c_int64_t), intent(out) :: fused_passes, handed_over
      end function
 
      !! device-resident variants (phase 2: tensors stay in HBM between consecutive HIP layers)

@@ -446,6 +446,36 @@ int athena_mp_activation_param_fwd_host(int32_t kind, int64_t n, float scale, fl
 int athena_mp_activation_param_bwd_host(int32_t kind, int64_t n, float scale, float p0, float p1, const float *x,
                                         const float *g, float *dx);
 
+/* ---- the FUSED entry points behind diffstruc's one-partial-at-a-time callbacks (host pointers) ------------------------
+ * update_message_duvenaud / update_readout_duvenaud (athena_duvenaud_msgpass_layer.f90:790-803, 838-855) in one launch:
+ * z = act(duvenaud_update(a, w)) and the readout's per-vertex p = softmax(R z) -- host form of
+ * athena_mp_duvenaud_update_readout_fwd; z becomes the value of the activation node, p the value of the readout's softmax node. */
+int athena_mp_duvenaud_update_readout_fwd_host(const athena_mp_graph *g, int32_t Fi, int32_t Fo, int32_t mn, int32_t mx,
+                                               const float *a, const float *w, int32_t act, float *z, int32_t O,
+                                               const float *R, float *p);
+/* grad_reverse asks a two-operand node for its partials ONE AT A TIME, each through a `pure` callback with an intent(in)
+ * node (get_partial_left_val / get_partial_right_val: athena_diffstruc_extd_sub_duvenaud.f90:284-368,
+ * athena_diffstruc_extd_sub_nop.f90:419-526) -- the callback can keep nothing, while the fused reverse kernels produce BOTH
+ * partials from one pass over the upstream gradient.  A *_pair_host entry point computes both on the first request, returns
+ * the one asked for (`which`) and parks the other on the device; the second request gets the parked one if and only if it
+ * names the same graph handle, the same shapes and operand arrays with the same CONTENT (a 64-bit hash of every byte of each
+ * operand, or the residency table's (id, version) for an array that lives on the device).  A request that does not match
+ * recomputes.  A parked partial is handed over once.
+ *   athena_mp_duvenaud_update_bwd_pair_host   which 0: da [n_rows, Fi] | 1: dweight [Fo Fi D]     (athena_mp_duvenaud_update_bwd)
+ *                                             act != ATHENA_MP_ACT_NONE: the node is update + message activation in one (value
+ *                                             z = act(duvenaud_update(a, w))); grad is then the gradient w.r.t. z and act'(z)
+ *                                             is applied on the device first (z_or_null = z [n_rows, Fo])
+ *   athena_mp_gno_aggregate_bwd_pair_host     which 0: dx [n_cols, Fi] | 1: dtheta | 2: dcoords [n_edge_cols, d]
+ *                                             (athena_mp_gno_aggregate_bwd; dcoords is computed only when asked for)
+ *   athena_mp_pair_stats                      fused passes run / partials handed over from a slot (tests, diagnostics) */
+int athena_mp_duvenaud_update_bwd_pair_host(const athena_mp_graph *g, int32_t Fi, int32_t Fo, int32_t mn, int32_t mx,
+                                            int32_t act, const float *z_or_null, const float *grad, const float *a,
+                                            const float *w, int32_t which, float *out);
+int athena_mp_gno_aggregate_bwd_pair_host(const athena_mp_graph *g, int32_t d, int32_t H, int32_t Fi, int32_t Fo,
+                                          const float *theta, const float *coords, const float *x, const float *grad,
+                                          int32_t which, float *out);
+int athena_mp_pair_stats(int64_t *fused_passes, int64_t *handed_over);
+
 /* ---- multi-GPU: communicator, row-partition shard, halo exchange (comm.hip) -----------------------------------------
  * The reference has no distributed code; these are the entry points SURVEY.md 8b/8e ask the
  * boundary to export (athena_mp_comm_create / graph_partition / halo_exchange) so that a Fortran host reaches the

@@ -18,6 +18,7 @@ module athena_mp__hip_ops
   implicit none
   private
   public :: duvenaud_propagate_hip, duvenaud_update_hip, gno_kernel_hip, gno_aggregate_hip
+  public :: handle_of, n_handle
 
   integer, parameter :: n_handle = storage_size(c_null_ptr) / storage_size(0)   !! default integers that hold a c_ptr
 
@@ -106,26 +107,32 @@ contains
   end function duvenaud_update_hip
 
   pure subroutine get_partial_duvenaud_update_hip_val(this, upstream_grad, output)
-    !! da[:, v] = (g[:, v]^T W_d) / d_v (:284-324); the weights are the node's right operand
+    !! da[:, v] = (g[:, v]^T W_d) / d_v (:284-324); the weights are the node's right operand, a its left operand.
+    !! grad_reverse asks for the two partials of this node one after the other; the fused reverse kernel produces both from one
+    !! pass over upstream_grad (athena_mp_duvenaud_update_bwd).  The pair entry point computes both on the first of the two
+    !! requests, returns the one asked for and parks the other on the device; the second request (same handle, shapes and
+    !! operand content) takes it.  Nothing is kept on the Fortran side: this callback is `pure` and `this` is intent(in).
     class(array_type), intent(in) :: this
     real(real32), dimension(:,:), intent(in) :: upstream_grad
     real(real32), dimension(:,:), intent(out) :: output
     integer(c_int) :: rc
-    rc = athena_mp_duvenaud_update_bwd_a_host(handle_of(this%indices), int(this%indices(n_handle + 1), c_int32_t), &
+    rc = athena_mp_duvenaud_update_bwd_pair_host(handle_of(this%indices), int(this%indices(n_handle + 1), c_int32_t), &
          int(this%indices(n_handle + 2), c_int32_t), int(this%indices(n_handle + 3), c_int32_t), &
-         int(this%indices(n_handle + 4), c_int32_t), upstream_grad, this%right_operand%val, output)
+         int(this%indices(n_handle + 4), c_int32_t), ATHENA_MP_ACT_NONE, this%val, upstream_grad, this%left_operand%val, &
+         this%right_operand%val, 0_c_int32_t, output)
     if(rc .ne. 0) error stop "duvenaud_update_hip: reverse pass (a) failed"
   end subroutine get_partial_duvenaud_update_hip_val
 
   pure subroutine get_partial_duvenaud_update_hip_weight_val(this, upstream_grad, output)
-    !! dW_d[i, j] += g[i, v] a[j, v] / d_v (:326-368); a is the node's left operand
+    !! dW_d[i, j] += g[i, v] a[j, v] / d_v (:326-368): the other half of the pair (which = 1)
     class(array_type), intent(in) :: this
     real(real32), dimension(:,:), intent(in) :: upstream_grad
     real(real32), dimension(:,:), intent(out) :: output
     integer(c_int) :: rc
-    rc = athena_mp_duvenaud_update_bwd_w_host(handle_of(this%indices), int(this%indices(n_handle + 1), c_int32_t), &
+    rc = athena_mp_duvenaud_update_bwd_pair_host(handle_of(this%indices), int(this%indices(n_handle + 1), c_int32_t), &
          int(this%indices(n_handle + 2), c_int32_t), int(this%indices(n_handle + 3), c_int32_t), &
-         int(this%indices(n_handle + 4), c_int32_t), upstream_grad, this%left_operand%val, output)
+         int(this%indices(n_handle + 4), c_int32_t), ATHENA_MP_ACT_NONE, this%val, upstream_grad, this%left_operand%val, &
+         this%right_operand%val, 1_c_int32_t, output)
     if(rc .ne. 0) error stop "duvenaud_update_hip: reverse pass (weight) failed"
   end subroutine get_partial_duvenaud_update_hip_weight_val
 
@@ -186,28 +193,31 @@ contains
   end function gno_aggregate_hip
 
   pure subroutine get_partial_gno_aggregate_hip_features_val(this, upstream_grad, output)
+    !! dx (get_partial_gno_agg_features_val, athena_diffstruc_extd_sub_nop.f90:419-458) -- one half of the pair: the whole
+    !! reverse pass of gno_aggregate comes from ONE G = g . Vmat^T (athena_mp_gno_aggregate_bwd); whichever of the node's two
+    !! partials grad_reverse asks for first triggers it, the other is handed over from the device
     class(array_type), intent(in) :: this
     real(real32), dimension(:,:), intent(in) :: upstream_grad
     real(real32), dimension(:,:), intent(out) :: output
     integer(c_int) :: rc
-    rc = athena_mp_gno_aggregate_bwd_x_host(handle_of(this%indices), int(this%indices(n_handle + 1), c_int32_t), &
+    rc = athena_mp_gno_aggregate_bwd_pair_host(handle_of(this%indices), int(this%indices(n_handle + 1), c_int32_t), &
          int(this%indices(n_handle + 2), c_int32_t), int(this%indices(n_handle + 3), c_int32_t), &
          int(this%indices(n_handle + 4), c_int32_t), this%right_operand%val, this%right_operand%left_operand%val, &
-         upstream_grad, output)
+         this%left_operand%val, upstream_grad, 0_c_int32_t, output)
     if(rc .ne. 0) error stop "gno_aggregate_hip: reverse pass (features) failed"
   end subroutine get_partial_gno_aggregate_hip_features_val
 
   pure subroutine get_partial_gno_aggregate_hip_kernel_val(this, upstream_grad, output)
     !! the gradient w.r.t. the kernel node's value, i.e. w.r.t. theta: agg -> kernels (:480-526) chained with
-    !! kernel -> params (:235-325) on the device
+    !! kernel -> params (:235-325) on the device -- the other half of the pair (which = 1)
     class(array_type), intent(in) :: this
     real(real32), dimension(:,:), intent(in) :: upstream_grad
     real(real32), dimension(:,:), intent(out) :: output
     integer(c_int) :: rc
-    rc = athena_mp_gno_aggregate_bwd_theta_host(handle_of(this%indices), int(this%indices(n_handle + 1), c_int32_t), &
+    rc = athena_mp_gno_aggregate_bwd_pair_host(handle_of(this%indices), int(this%indices(n_handle + 1), c_int32_t), &
          int(this%indices(n_handle + 2), c_int32_t), int(this%indices(n_handle + 3), c_int32_t), &
          int(this%indices(n_handle + 4), c_int32_t), this%right_operand%val, this%right_operand%left_operand%val, &
-         this%left_operand%val, upstream_grad, output)
+         this%left_operand%val, upstream_grad, 1_c_int32_t, output)
     if(rc .ne. 0) error stop "gno_aggregate_hip: reverse pass (kernel parameters) failed"
   end subroutine get_partial_gno_aggregate_hip_kernel_val
 

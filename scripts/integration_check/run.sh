@@ -20,4 +20,8 @@ done
 ls athena_mp__hip_kipf.mod >/dev/null
 "$FC" -cpp -c "$HERE/hip_duvenaud_gno_ops.f90" -o hip_duvenaud_gno_ops.o   # the Duvenaud and GNO autodiff ops
 ls athena_mp__hip_ops.mod >/dev/null
+# the two layer TYPES that extend(msgpass_layer_type): Duvenaud (update_message + update_readout, the fused entry points bound
+# inside the tape) and graph_nop (one-call reverse pass, forwarded edge geometry) -- INTEGRATION.md section 3
+"$FC" -cpp -c "$HERE/hip_duvenaud_gno_layers.f90" -o hip_duvenaud_gno_layers.o
+ls athena_mp__hip_layers.mod >/dev/null
 echo "integration shim compiles against athena__msgpass_layer / athena__base_layer / diffstruc surface: OK"

@@ -20,7 +20,7 @@ module diffstruc
   use coreutils, only: real32
   implicit none
   private
-  public :: array_type, matmul
+  public :: array_type, matmul, sum, operator(+)
 
   type :: array_type
      real(real32), allocatable :: val(:,:)
@@ -28,6 +28,7 @@ module diffstruc
      integer, allocatable :: indices(:)
      integer, allocatable :: adj_ja(:,:)
      integer :: rank = 2
+     logical :: allocated = .false.
      logical :: requires_grad = .false., is_forward = .false., is_temporary = .true.
      logical :: is_sample_dependent = .true., fix_pointer = .false.
      logical :: owns_left_operand = .false., owns_right_operand = .false.
@@ -41,6 +42,8 @@ module diffstruc
      procedure, pass(this) :: zero_grad
      procedure, pass(this) :: assign_and_deallocate_source
      procedure, pass(this) :: allocate => allocate_array
+     procedure, pass(this) :: deallocate => deallocate_array
+     procedure, pass(this) :: set_requires_grad
   end type array_type
 
   abstract interface
@@ -61,6 +64,12 @@ module diffstruc
   interface matmul
      module procedure matmul_arrays
   end interface matmul
+  interface sum
+     module procedure sum_array
+  end interface sum
+  interface operator(+)
+     module procedure add_arrays
+  end interface
 contains
   function create_result(this, array_shape) result(c)
     class(array_type), intent(in) :: this
@@ -80,10 +89,30 @@ contains
     class(array_type), intent(inout) :: this
     type(array_type), pointer, intent(inout) :: source
   end subroutine assign_and_deallocate_source
-  subroutine allocate_array(this, array_shape)
+  subroutine allocate_array(this, array_shape, source)
     class(array_type), intent(inout) :: this
-    integer, dimension(:), intent(in) :: array_shape
+    integer, dimension(:), intent(in), optional :: array_shape
+    real(real32), dimension(:,:), intent(in), optional :: source
   end subroutine allocate_array
+  subroutine deallocate_array(this)
+    class(array_type), intent(inout) :: this
+  end subroutine deallocate_array
+  subroutine set_requires_grad(this, requires_grad)
+    class(array_type), intent(inout) :: this
+    logical, intent(in) :: requires_grad
+  end subroutine set_requires_grad
+  function sum_array(a, dim, new_dim_index, new_dim_size) result(c)
+    class(array_type), intent(in), target :: a
+    integer, intent(in) :: dim
+    integer, intent(in), optional :: new_dim_index, new_dim_size
+    type(array_type), pointer :: c
+    c => a%create_result([size(a%val, 1), 1])
+  end function sum_array
+  function add_arrays(a, b) result(c)
+    class(array_type), intent(in), target :: a, b
+    type(array_type), pointer :: c
+    c => a%create_result()
+  end function add_arrays
   function matmul_arrays(a, b) result(c)
     class(array_type), intent(in), target :: a, b
     type(array_type), pointer :: c
@@ -100,6 +129,6 @@ module graphstruc
      integer :: num_vertices = 0, num_edges = 0, num_vertex_features = 0, num_edge_features = 0
      logical :: is_sparse = .true.
      integer, allocatable :: adj_ia(:), adj_ja(:,:)
-     real(real32), allocatable :: vertex_features(:,:), edge_features(:,:)
+     real(real32), allocatable :: vertex_features(:,:), edge_features(:,:), edge_weights(:)
   end type graph_type
 end module graphstruc

@@ -1,6 +1,6 @@
 """CPU, build container only: the drop-in shim INTEGRATION.md describes (scripts/integration_check/hip_kipf_msgpass.f90 --
-an autodiff op with kipf_propagate's contract and a type that extends(msgpass_layer_type) -- and hip_duvenaud_gno_ops.f90,
-the Duvenaud and GNO autodiff ops) goes through the Fortran
+an autodiff op with kipf_propagate's contract and a type that extends(msgpass_layer_type) -- hip_duvenaud_gno_ops.f90,
+the Duvenaud and GNO autodiff ops, and hip_duvenaud_gno_layers.f90, the Duvenaud and graph_nop layer TYPES) goes through the Fortran
 compiler against athena's REAL module sources, read in place from the reference checkout, plus compile-only stand-ins for
 coreutils / diffstruc / graphstruc (which this image lacks).  Syntax and interface evidence only: nothing is linked or
 run and no number comes from it.  Skipped where the reference checkout or the compiler is absent (e.g. on the GPU box)."""
@@ -24,3 +24,14 @@ def test_integration_shim_compiles_against_the_reference_modules():
     assert "OK" in r.stdout
     assert os.path.exists(os.path.join(ROOT, "build", "integration_check", "athena_mp__hip_kipf.mod"))
     assert os.path.exists(os.path.join(ROOT, "build", "integration_check", "athena_mp__hip_ops.mod"))   # Duvenaud + GNO ops
+    # the two layer TYPES that extend(msgpass_layer_type): hip_duvenaud_msgpass_layer_type (update_message + update_readout,
+    # fused entry points bound inside the tape) and hip_graph_nop_layer_type (one-call reverse, forwarded edge geometry)
+    assert os.path.exists(os.path.join(ROOT, "build", "integration_check", "athena_mp__hip_layers.mod"))
+    objs = os.path.join(ROOT, "build", "integration_check", "hip_duvenaud_gno_layers.o")
+    syms = subprocess.run(["nm", objs], capture_output=True, text=True).stdout
+    for needed in ("update_message_hip_duvenaud", "update_readout_hip_duvenaud", "update_message_hip_gno", "set_graph_hip_gno",
+                   "athena_mp_duvenaud_update_readout_fwd_host", "athena_mp_duvenaud_update_bwd_pair_host"):
+        assert needed in syms, needed
+    ops = subprocess.run(["nm", os.path.join(ROOT, "build", "integration_check", "hip_duvenaud_gno_ops.o")], capture_output=True,
+                         text=True).stdout
+    assert "athena_mp_gno_aggregate_bwd_pair_host" in ops and "athena_mp_duvenaud_update_bwd_pair_host" in ops
