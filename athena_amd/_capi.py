@@ -107,6 +107,8 @@ _PROTOS = {
     "athena_mp_comm_create_from_file": [_i32, _i32, C.c_char_p, C.POINTER(_vp)],
     "athena_mp_comm_destroy": [_vp],
     "athena_mp_comm_info": [_vp, C.POINTER(_i32), C.POINTER(_i32), C.c_char_p, _i32],
+    "athena_mp_comm_stats": [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i64), _vp, _i32],
+    "athena_mp_set_stall_handler": [_vp],
     "athena_mp_comm_barrier": [_vp],
     "athena_mp_allreduce_start": [_vp, _vp, _i64],
     "athena_mp_allreduce_finish": [_vp],

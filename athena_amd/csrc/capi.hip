@@ -104,7 +104,12 @@ int workspace(void **ptr, size_t bytes, int slot)
             g_ws_bytes[slot] = 0;
         }
         size_t want = bytes + (bytes >> 2) + 256;
-        AMP_HIP(hipMalloc(&g_ws[slot], want));
+        if (hipMalloc(&g_ws[slot], want) != hipSuccess) {   // no room for the 25 % headroom: exactly what was asked for
+            (void)hipGetLastError();
+            g_ws[slot] = nullptr;
+            want = bytes;
+            AMP_HIP(hipMalloc(&g_ws[slot], want));
+        }
         g_ws_bytes[slot] = want;
     }
     *ptr = g_ws[slot];

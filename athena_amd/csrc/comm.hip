@@ -43,14 +43,46 @@ namespace {
 // ---------------------------------------------------------------------------------------------------------------------
 struct Transport {
     int rank = 0, world = 1;
+    // what this rank has put on the wire, for athena_mp_comm_stats: bytes to every peer (grouped sends and its blocks of
+    // all-gathers), all-reduce payload, number of transfers started
+    std::vector<int64_t> sent;
+    int64_t allreduce_bytes = 0, transfers = 0;
+    void count_sent(int p, size_t bytes)
+    {
+        if ((int)sent.size() != world) sent.assign((size_t)world, 0);
+        if (p >= 0 && p < world) sent[(size_t)p] += (int64_t)bytes;
+    }
     virtual ~Transport() {}
     virtual const char *name() const = 0;
+    virtual int ranks_seen() const { return world; }   // how many ranks the transport's own communicator reports
+    virtual int version() const { return 0; }          // RCCL: ncclGetVersion
     // device buffers; bytes may be 0 (skipped); entries for p == rank are ignored.  Enqueued on / ordered after `s`.
     virtual int exchange(const void *const *sendp, const size_t *sendb, void *const *recvp, const size_t *recvb,
                          hipStream_t s) = 0;
     virtual int allreduce_f32(float *buf, size_t count, hipStream_t s) = 0;
     // every rank contributes `bytes` from send; recv holds world * bytes, block p at p * bytes (send may be recv + rank * bytes)
     virtual int allgather(const void *send, void *recv, size_t bytes, hipStream_t s) = 0;
+    // what every caller in this file uses: the same three, counted
+    int counted_exchange(const void *const *sendp, const size_t *sendb, void *const *recvp, const size_t *recvb, hipStream_t s)
+    {
+        for (int p = 0; p < world; ++p)
+            if (p != rank) count_sent(p, sendb[p]);
+        ++transfers;
+        return exchange(sendp, sendb, recvp, recvb, s);
+    }
+    int counted_allreduce_f32(float *buf, size_t count, hipStream_t s)
+    {
+        allreduce_bytes += (int64_t)(4 * count);
+        ++transfers;
+        return allreduce_f32(buf, count, s);
+    }
+    int counted_allgather(const void *send, void *recv, size_t bytes, hipStream_t s)
+    {
+        for (int p = 0; p < world; ++p)
+            if (p != rank) count_sent(p, bytes);
+        ++transfers;
+        return allgather(send, recv, bytes, s);
+    }
 };
 
 struct RcclApi {
@@ -65,6 +97,8 @@ struct RcclApi {
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;   // optional (diagnostics)
+    ncclResult_t (*GetVersion)(int *) = nullptr;                     // optional
 };
 RcclApi g_rccl;
 
@@ -96,6 +130,8 @@ int rccl_load()
     AMP_SYM(GroupStart, "ncclGroupStart")
     AMP_SYM(GroupEnd, "ncclGroupEnd")
 #undef AMP_SYM
+    *(void **)(&g_rccl.CommCount) = dlsym(h, "ncclCommCount");
+    *(void **)(&g_rccl.GetVersion) = dlsym(h, "ncclGetVersion");
     g_rccl.lib = h;
     return 0;
 }
@@ -112,6 +148,16 @@ int rccl_load()
 struct RcclTransport : Transport {
     ncclComm_t comm = nullptr;
     const char *name() const override { return "rccl"; }
+    int ranks_seen() const override
+    {
+        int n = 0;
+        return (g_rccl.CommCount && comm && g_rccl.CommCount(comm, &n) == ncclSuccess) ? n : -1;
+    }
+    int version() const override
+    {
+        int v = 0;
+        return (g_rccl.GetVersion && g_rccl.GetVersion(&v) == ncclSuccess) ? v : -1;
+    }
     ~RcclTransport() override
     {
         if (comm) g_rccl.CommDestroy(comm);
@@ -291,11 +337,15 @@ bool want_shm()
 // No RCCL collective has a completion deadline: two ranks that disagree about a transfer wait for each other until whoever
 // launched them gives up.  The host never blocks in athena_mp_halo_start / _allreduce_start (the stall would surface in the
 // caller's next synchronize, far from its cause), so a monitor thread watches the completion EVENT of every transfer that
-// was started: one that is still pending ATHENA_MP_COLLECTIVE_TIMEOUT_S seconds later (default 120; 0 = no monitor) ends the
-// process -- a message naming the rank and the transfer on stderr, {"ok": false, "error": ...} on stdout, _exit(3): no retry,
-// no cleanup that could block in the same communicator.  Fortran drivers get the protection bench.py's python watchdog
-// gives the bench.  ATHENA_MP_COMM_TEST_DELAY_MS (tests only) parks a bounded spin kernel in front of the completion event.
+// was started: one that is still pending ATHENA_MP_COLLECTIVE_TIMEOUT_S seconds later (default 1800 -- long enough for one rank to
+// write a checkpoint, run an evaluation pass or sit in a debugger; bench.py sets 120 for itself; 0 = no monitor) ends the
+// process -- a message naming the rank and the transfer on stderr and in athena_mp_last_error, the host's stall handler if one is
+// registered (athena_mp_set_stall_handler: its chance to flush state), then _exit(3): no retry, no cleanup that could block in the
+// same communicator, nothing written on the host program's stdout.  Fortran drivers get the protection bench.py's python
+// watchdog gives the bench.  ATHENA_MP_COMM_TEST_DELAY_MS (tests only) parks a bounded spin kernel in front of the completion event.
+typedef void (*athena_mp_stall_handler_fn)(int32_t rank, const char *what, double seconds);
 namespace {
+std::atomic<athena_mp_stall_handler_fn> g_stall_handler{nullptr};
 struct Watched {
     hipEvent_t ev, begin;   // begin (may be null): recorded on the communication stream just in front of the transfer -- the clock
     bool started;           // starts when IT has completed, not at enqueue time (a host that runs many steps ahead of the device
@@ -318,8 +368,8 @@ double watch_timeout()
 {
     static const double t = [] {
         const char *e = getenv("ATHENA_MP_COLLECTIVE_TIMEOUT_S");
-        const double v = e ? atof(e) : 120.0;
-        return v > 0.0 ? v : 0.0;
+        const double v = e ? atof(e) : 1800.0;   // a library default must outlast a checkpoint, an evaluation pass or a debugger
+        return v > 0.0 ? v : 0.0;                // stop on ONE rank; bench.py sets its own 120 s
     }();
     return t;
 }
@@ -352,11 +402,14 @@ void watch_loop()
                 }
             }
             if (q == hipErrorNotReady && w.started && now - w.t0 > w.limit) {
-                fprintf(stderr, "[athena_mp] rank %d stalled in %s for more than %.0f s (ATHENA_MP_COLLECTIVE_TIMEOUT_S): a peer is "
-                                "missing, late or in another collective\n", w.rank, w.what, w.limit);
-                printf("{\"ok\": false, \"error\": \"rank %d stalled in %s for more than %.0f s\"}\n", w.rank, w.what, w.limit);
-                fflush(stdout);
+                // stderr and athena_mp_last_error only: the host program's stdout is not this library's to write on
+                amp::set_error("rank %d stalled in %s for more than %.0f s (ATHENA_MP_COLLECTIVE_TIMEOUT_S): a peer is missing, late or "
+                               "in another collective", w.rank, w.what, w.limit);
+                fprintf(stderr, "[athena_mp] %s\n", athena_mp_last_error());
                 fflush(stderr);
+                // the host's chance to flush its own state (checkpoint, log): called on THIS monitor thread, once; the process
+                // ends when it returns -- a stalled communicator cannot be recovered, and a retry would hang in it again
+                if (athena_mp_stall_handler_fn h = g_stall_handler.load()) h(w.rank, w.what, w.limit);
                 _exit(3);
             }
             ++i;
@@ -493,7 +546,7 @@ int exchange_host(athena_mp_comm *c, const std::vector<const void *> &sp, const 
         drp[p] = dev + off;
         off += (rb[p] + 255) & ~(size_t)255;
     }
-    int rc = c->t->exchange(dsp.data(), sb.data(), drp.data(), rb.data(), c->cs);
+    int rc = c->t->counted_exchange(dsp.data(), sb.data(), drp.data(), rb.data(), c->cs);
     if (rc == 0 && hipEventRecord(c->ev_done, c->cs) == hipSuccess)
         watch_arm(c->ev_done, c->t->rank, c->device, "a metadata exchange of the shard build (athena_mp_shard_create)", 5.0);
     if (rc == 0 && hipStreamSynchronize(c->cs) != hipSuccess) {
@@ -518,7 +571,7 @@ int allgather_host(athena_mp_comm *c, const void *mine, size_t bytes, void *out)
     AMP_HIP(hipMalloc((void **)&dev, (size_t)W * bytes));
     int rc = 0;
     if (hipMemcpy(dev + (size_t)r * bytes, mine, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = 1;
-    if (rc == 0) rc = c->t->allgather(dev + (size_t)r * bytes, dev, bytes, c->cs);
+    if (rc == 0) rc = c->t->counted_allgather(dev + (size_t)r * bytes, dev, bytes, c->cs);
     if (rc == 0 && hipEventRecord(c->ev_done, c->cs) == hipSuccess)
         watch_arm(c->ev_done, c->t->rank, c->device, "a metadata all-gather of the shard build (athena_mp_shard_create)", 5.0);
     if (rc == 0 && hipStreamSynchronize(c->cs) != hipSuccess) rc = 1;
@@ -825,6 +878,25 @@ int athena_mp_comm_info(const athena_mp_comm *c, int32_t *rank, int32_t *world, 
     return 0;
 }
 
+int athena_mp_comm_stats(const athena_mp_comm *c, int32_t *ranks_seen, int32_t *library_version, int64_t *transfers,
+                         int64_t *allreduce_bytes, int64_t *sent_bytes_per_peer, int32_t n_peers)
+{
+    AMP_REQUIRE(c != nullptr, "comm_stats: null communicator");
+    AMP_REQUIRE(n_peers >= 0 && (n_peers == 0 || sent_bytes_per_peer), "comm_stats: bad peer array");
+    if (ranks_seen) *ranks_seen = c->t->ranks_seen();
+    if (library_version) *library_version = c->t->version();
+    if (transfers) *transfers = c->t->transfers;
+    if (allreduce_bytes) *allreduce_bytes = c->t->allreduce_bytes;
+    for (int p = 0; p < n_peers; ++p) sent_bytes_per_peer[p] = p < (int)c->t->sent.size() ? c->t->sent[(size_t)p] : 0;
+    return 0;
+}
+
+int athena_mp_set_stall_handler(void (*handler)(int32_t rank, const char *what, double seconds))
+{
+    g_stall_handler.store(handler);
+    return 0;
+}
+
 /* sum over ranks, in place, float32.  _start enqueues it on the communication stream behind everything the compute
  * stream has queued so far; _finish makes the compute stream wait for it (host never blocks). */
 int athena_mp_allreduce_start(athena_mp_comm *c, float *buf_dev, int64_t count)
@@ -834,7 +906,7 @@ int athena_mp_allreduce_start(athena_mp_comm *c, float *buf_dev, int64_t count)
     AMP_HIP(hipEventRecord(c->ev_ready, amp::stream()));
     AMP_HIP(hipStreamWaitEvent(c->cs, c->ev_ready, 0));
     AMP_HIP(hipEventRecord(c->ev_begin, c->cs));
-    if (c->t->allreduce_f32(buf_dev, (size_t)count, c->cs)) return 1;
+    if (c->t->counted_allreduce_f32(buf_dev, (size_t)count, c->cs)) return 1;
     test_delay(c->cs);
     AMP_HIP(hipEventRecord(c->ev_done, c->cs));
     watch_arm(c->ev_done, c->t->rank, c->device, "the all-reduce of the parameter gradients (athena_mp_allreduce_start)", 1.0, c->ev_begin);
@@ -859,7 +931,7 @@ int athena_mp_comm_barrier(athena_mp_comm *c)
     float *one = nullptr;
     if (amp::named_buffer("comm.barrier_word", 256, true, (void **)&one)) return 1;
     AMP_HIP(hipStreamSynchronize(amp::stream()));
-    if (c->t->world > 1 && c->t->allreduce_f32(one, 1, c->cs)) return 1;
+    if (c->t->world > 1 && c->t->counted_allreduce_f32(one, 1, c->cs)) return 1;
     if (c->t->world > 1) {
         AMP_HIP(hipEventRecord(c->ev_done, c->cs));
         watch_arm(c->ev_done, c->t->rank, c->device, "athena_mp_comm_barrier", 5.0);
@@ -1096,6 +1168,22 @@ static int shard_create_impl(athena_mp_comm *c, int32_t n_local, int64_t nnz, co
             share[p].erase(std::unique(share[p].begin(), share[p].end()), share[p].end());
             s->eoff[p + 1] = s->eoff[p] + (int64_t)share[p].size();
             s->eshare_h.insert(s->eshare_h.end(), share[p].begin(), share[p].end());
+        }
+        // athena_mp_shard_edge_reduce adds every peer's share in ONE launch, which is only race-free when a cut column is shared
+        // with exactly one peer.  An adj_ja(2,:) that reuses one edge id for vertex pairs on different ranks is legal in the
+        // reference (edge ids are just indices into the edge features) and would break that: refused here, on every rank.
+        {
+            std::vector<int32_t> all_cut(s->eshare_h);
+            std::sort(all_cut.begin(), all_cut.end());
+            const int dup = std::adjacent_find(all_cut.begin(), all_cut.end()) != all_cut.end();
+            if (dup)
+                set_error("shard_create_edges: an edge column of this rank is cut towards more than one peer (one edge id used for vertex "
+                          "pairs on different ranks): the edge-column reduce would add racing shares");
+            const int arc = agree_ok(c, dup, "shard_create_edges");
+            if (arc) {
+                athena_mp_shard_destroy(s);
+                return arc;
+            }
         }
         // both sides of a cut must list the same number of columns (they do when the symmetry check passed); agreed on
         // here so that a mismatch is an error on every rank and not a hang in the first edge reduce
@@ -1382,7 +1470,7 @@ int athena_mp_halo_start(athena_mp_shard *s, int32_t slot, int32_t F, float *x_e
         AMP_HIP(hipStreamWaitEvent(c->cs, c->ev_ready, 0));
         AMP_HIP(hipEventRecord(s->ev_halo_b[slot], c->cs));
         const size_t block = sizeof(float) * (size_t)s->max_n * F;
-        if (c->t->allgather(x_ext_dev, x_ext_dev + (size_t)s->max_n * F, block, c->cs)) return 1;
+        if (c->t->counted_allgather(x_ext_dev, x_ext_dev + (size_t)s->max_n * F, block, c->cs)) return 1;
         test_delay(c->cs);
         AMP_HIP(hipEventRecord(s->ev_halo[slot], c->cs));
         watch_arm(s->ev_halo[slot], rank, c->device, slot ? "the halo exchange in slot 1 (all-gather of whole blocks)" : "the halo exchange in slot 0 (all-gather of whole blocks)",
@@ -1416,7 +1504,7 @@ int athena_mp_halo_start(athena_mp_shard *s, int32_t slot, int32_t F, float *x_e
         rp[p] = x_ext_dev + ((size_t)s->n + (size_t)s->roff[p]) * F;
         rb[p] = sizeof(float) * (size_t)s->recv_counts[p] * F;
     }
-    if (c->t->exchange(sp.data(), sb.data(), rp.data(), rb.data(), c->cs)) return 1;
+    if (c->t->counted_exchange(sp.data(), sb.data(), rp.data(), rb.data(), c->cs)) return 1;
     test_delay(c->cs);
     AMP_HIP(hipEventRecord(s->ev_halo[slot], c->cs));
     watch_arm(s->ev_halo[slot], rank, c->device, slot ? "the halo exchange in slot 1 (grouped send / recv)" : "the halo exchange in slot 0 (grouped send / recv)", 1.0,
@@ -1469,7 +1557,7 @@ int athena_mp_halo_reduce_start(athena_mp_shard *s, int32_t slot, int32_t F, con
             rb[p] = sizeof(float) * (size_t)s->send_counts[p] * F;
         }
     }
-    if (c->t->exchange(sp.data(), sb.data(), rp.data(), rb.data(), c->cs)) return 1;
+    if (c->t->counted_exchange(sp.data(), sb.data(), rp.data(), rb.data(), c->cs)) return 1;
     test_delay(c->cs);
     AMP_HIP(hipEventRecord(s->ev_halo[slot], c->cs));
     watch_arm(s->ev_halo[slot], rank, c->device, slot ? "the halo reduce in slot 1" : "the halo reduce in slot 0", 1.0, s->ev_halo_b[slot]);
@@ -1541,7 +1629,7 @@ int athena_mp_shard_edge_reduce(athena_mp_shard *s, int32_t F, float *e_dev)
         rp[p] = recv + (size_t)s->eoff[p] * F;
         sb[p] = rb[p] = sizeof(float) * rows * F;
     }
-    if (c->t->exchange(sp.data(), sb.data(), rp.data(), rb.data(), c->cs)) return 1;
+    if (c->t->counted_exchange(sp.data(), sb.data(), rp.data(), rb.data(), c->cs)) return 1;
     AMP_HIP(hipEventRecord(c->ev_done, c->cs));
     watch_arm(c->ev_done, rank, c->device, "the edge-column reduce (athena_mp_shard_edge_reduce)", 1.0, c->ev_begin);
     AMP_HIP(hipStreamWaitEvent(amp::stream(), c->ev_done, 0));

@@ -2758,7 +2758,7 @@ int athena_mp_gno_aggregate_bwd(const athena_mp_graph *g, int32_t d, int32_t H, 
         if (length_order(g->rowptr, g->n_rows, &g->len_perm_fwd, &g->n_long_fwd, &g->n_mid_fwd)) return 1;
         ok = (int64_t)g->n_long_fwd * 64 <= (int64_t)g->n_rows;   // the long rows' partials come from a plain VALU kernel
     }
-    if (!ok) {
+    auto separate = [&]() -> int {   // the three entry points one after the other: no workspace of nnz * 256 bytes
         if (dtheta) {
             const int rc = s_save ? athena_mp_gno_aggregate_bwd_theta_saved(g, d, H, Fi, Fo, theta, coords, x, grad, s_save, dtheta)
                                   : athena_mp_gno_aggregate_bwd_theta(g, d, H, Fi, Fo, theta, coords, x, grad, dtheta);
@@ -2769,15 +2769,24 @@ int athena_mp_gno_aggregate_bwd(const athena_mp_graph *g, int32_t d, int32_t H, 
         if (dcoords)
             if (const int rc = athena_mp_gno_aggregate_bwd_coords(g, d, H, Fi, Fo, theta, coords, x, grad, dcoords)) return rc;
         return 0;
-    }
+    };
+    if (!ok) return separate();
     const size_t off_V = (size_t)H * d + H;
     const size_t px_half = (size_t)std::max<int64_t>(g->nnz, 1) * kGF;
     void *pxp = nullptr, *cvp = nullptr, *dth_tmp = nullptr;
-    if (workspace(&pxp, sizeof(float) * px_half, 13)) return 1;
-    if (workspace(&cvp, sizeof(float) * kGF * (size_t)g->n_rows, 14)) return 1;
+    // The fused route keeps nnz * 256 bytes of per-entry partials (7.6 GB at BASELINE configs[3]) and nnz int32 in the handle.
+    // When the device cannot give them -- a larger graph, a smaller device, a layer that also keeps S -- the call does what it
+    // did before the fused route existed: the separate entry points, which run in the memory there is.
+    if (workspace(&pxp, sizeof(float) * px_half, 13) || workspace(&cvp, sizeof(float) * kGF * (size_t)g->n_rows, 14)) {
+        (void)hipGetLastError();   // the failed allocation must not surface in the next launch check
+        return separate();
+    }
     if (!g->t_entry && g->nnz > 0) {
         int32_t *te = nullptr;
-        AMP_HIP(hipMalloc((void **)&te, sizeof(int32_t) * (size_t)g->nnz));
+        if (hipMalloc((void **)&te, sizeof(int32_t) * (size_t)g->nnz) != hipSuccess) {
+            (void)hipGetLastError();
+            return separate();
+        }
         hipLaunchKernelGGL(gno_t_entry_kernel, dim3((g->n_rows + 255) / 256), dim3(256), 0, stream(), g->rowptr, g->col, g->eid,
                            g->t_rowptr, g->t_src, g->n_rows, te);
         if (hipGetLastError() != hipSuccess) {   // the handle only ever holds a map that was built

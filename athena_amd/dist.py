@@ -328,10 +328,12 @@ class Watchdog:
         import time
         while not self._stop:
             time.sleep(0.25)
-            with self._lock:
-                top = self._stack[-1] if self._stack else None
-            if top is not None and time.monotonic() > top[1]:
-                self._exit(top[0], top[2])
+            now = time.monotonic()
+            with self._lock:     # an OUTER phase's earlier deadline counts too: the earliest expired one anywhere in the stack
+                late = [p for p in self._stack if now > p[1]]
+                hit = min(late, key=lambda p: p[1]) if late else None
+            if hit is not None:
+                self._exit(hit[0], hit[2])
                 return
 
     def phase(self, name, factor=1.0):
@@ -404,6 +406,21 @@ def c_comm(device):
     _COMM = type("CComm", (), {})()
     _COMM.handle, _COMM.rank, _COMM.world, _COMM.transport = h, rank, world, name.value.decode()
     return _COMM
+
+
+def c_comm_stats():
+    """What this rank's C-ABI communicator has done so far (athena_mp_comm_stats): {"transport", "ranks_seen" (RCCL's own
+    ncclCommCount), "version" (ncclGetVersion), "transfers", "allreduce_bytes", "sent_bytes_per_peer"} -- the N > 1 bench line
+    carries it so that the first real multi-GPU run proves what it used.  None before a communicator exists."""
+    if _COMM is None:
+        return None
+    import ctypes as C
+    from . import _capi
+    seen, ver, tr, arb = C.c_int32(0), C.c_int32(0), C.c_int64(0), C.c_int64(0)
+    per = (C.c_int64 * _COMM.world)()
+    _capi.call("athena_mp_comm_stats", _COMM.handle, C.byref(seen), C.byref(ver), C.byref(tr), C.byref(arb), per, _COMM.world)
+    return {"transport": _COMM.transport, "ranks_seen": int(seen.value), "version": int(ver.value), "transfers": int(tr.value),
+            "allreduce_bytes": int(arb.value), "sent_bytes_per_peer": [int(v) for v in per]}
 
 
 def c_comm_destroy():
@@ -569,11 +586,12 @@ class CShard:
             self.handle = None
 
 
-def _c_shard_or_none(device, adj_ia, cols_global, eids_global=None):
-    """the C-ABI shard, or None when ANY rank failed to build its communicator / shard (every rank then takes dist.py's
-    python plan over torch point-to-point instead, and says so in `transport`).  Not a silent detour: the reason is
-    printed by the rank that failed and recorded in the shard's transport string."""
-    import sys
+def _c_shard(device, adj_ia, cols_global, eids_global=None):
+    """The C-ABI shard of the product path (cuda).  A failure on ANY rank -- communicator, collective plan, graph handles --
+    ends the job at the point of failure: the failing rank raises with the C ABI's error text, the other ranks learn of it
+    from the agreement all-reduce below and raise too (a rank that died before reaching it is the watchdog's case: exit
+    code 3 naming the phase).  There is no second implementation to fall back to on a GPU: dist.py's python plan is the
+    CPU mirror the gloo tests hold the C ABI's arithmetic against."""
     err = None
     sh = None
     try:
@@ -582,24 +600,22 @@ def _c_shard_or_none(device, adj_ia, cols_global, eids_global=None):
         with _WATCH.phase("athena_mp_shard_create (collective plan + graph handles)", factor=5.0):
             sh = CShard(comm, adj_ia, cols_global, eids_global)
     except Exception as exc:      # AthenaMPError from the C ABI, OSError from the loader ...
-        err = f"{type(exc).__name__}: {exc}"[:300]
-        print(f"[athena_mp dist] rank {dist.get_rank()}: C-ABI communicator / shard failed: {err}", file=sys.stderr, flush=True)
+        err = f"{type(exc).__name__}: {exc}"[:600]
     flag = torch.tensor([0 if err is None else 1], dtype=torch.int32)
     if dist.get_backend() == "nccl":
         flag = flag.to(device)
     with _WATCH.phase("agreeing on the shard build (all_reduce of the error flag)", factor=5.0):
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
     if int(flag.item()) == 0:
-        return sh, None
+        return sh
     if sh is not None:
         sh.close()
-    return None, (err or "another rank failed")
+    raise RuntimeError(f"rank {dist.get_rank()}: C-ABI communicator / shard failed: {err}" if err else
+                       f"rank {dist.get_rank()}: another rank failed to build its C-ABI communicator / shard (its message names the cause)")
 
 
 def _use_c_abi(device):
-    import os
-    return (device is not None and torch.device(device).type == "cuda" and dist.is_initialized()
-            and os.environ.get("ATHENA_MP_DIST_IMPL", "c") != "python")
+    return device is not None and torch.device(device).type == "cuda" and dist.is_initialized()
 
 
 def build_plan(shard, device):
@@ -745,14 +761,11 @@ class HipBackend:
 
 def make_weak_scaling_shard(rank, world, n, pairs, F, cut=None, device=None, seed=20260424):
     rows, cols, cut = shard_entries(rank, world, n, pairs, cut, seed)
-    sh, why = None, None
     if _use_c_abi(device):
         ia = np.concatenate([[1], 1 + np.cumsum(np.bincount(rows, minlength=n))])
-        sh, why = _c_shard_or_none(device, ia, cols)
-    if sh is None:
+        sh = _c_shard(device, ia, cols)
+    else:                                                  # CPU mirror (gloo tests)
         sh = build_plan(Shard(rank, world, n, rows, cols), device)
-        if why:
-            sh.transport = Shard.transport + f" -- FALLBACK, the C-ABI path failed: {why}"
     sh.cut = cut
     return sh
 
@@ -766,14 +779,11 @@ def make_global_shard(rank, world, n_total, pairs, device=None, seed=20260424, l
         raise ValueError(f"{n_total} vertices do not split into {world} equal row blocks")
     n = n_total // world
     ia, cols = synth.random_graph_csr_rows(n_total, pairs, rank * n, (rank + 1) * n, seed=seed, locality=locality)
-    sh, why = None, None
     if _use_c_abi(device):
-        sh, why = _c_shard_or_none(device, ia, cols)
-    if sh is None:
+        sh = _c_shard(device, ia, cols)
+    else:                                                  # CPU mirror (gloo tests)
         rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(ia))
         sh = build_plan(Shard(rank, world, n, rows, cols), device)
-        if why:
-            sh.transport = Shard.transport + f" -- FALLBACK, the C-ABI path failed: {why}"
     sh.cut = None
     sh.n_total = n_total
     return sh
@@ -1080,14 +1090,11 @@ def make_mesh_shard(rank, world, n_points, device=None, mean_degree=15.0, seed=4
     ia_l = (ia[rank * n:(rank + 1) * n + 1].astype(np.int64) - e0).astype(np.int32)
     cols = ja[0, e0:e1].astype(np.int64) - 1
     eids = ja[1, e0:e1].astype(np.int64)
-    sh, why = None, None
     if _use_c_abi(device):
-        sh, why = _c_shard_or_none(device, ia_l, cols, eids)
-    if sh is None:
+        sh = _c_shard(device, ia_l, cols, eids)
+    else:                                                  # CPU mirror (gloo tests)
         rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(ia_l))
         sh = build_plan(Shard(rank, world, n, rows, cols, eids), device)
-        if why:
-            sh.transport = Shard.transport + f" -- FALLBACK, the C-ABI path failed: {why}"
     sh.cut = None
     sh.n_total = n_points
     return sh, np.ascontiguousarray(coords[sh.edge_ids], np.float32)

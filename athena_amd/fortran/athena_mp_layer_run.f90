@@ -48,6 +48,8 @@ program athena_mp_layer_run
      call run_kipf_chain()
   case(5)
      call run_kipf_graph_swap()
+  case(6)
+     call run_duvenaud(timed=.true.)
   case default
      write(0,*) "unknown layer kind", kind
      stop 4
@@ -125,10 +127,16 @@ contains
     call layer%destroy()
   end subroutine run_kipf
 
-  subroutine run_duvenaud()
+  subroutine run_duvenaud(timed)
+    !! timed: after the parity outputs, `reps` x (forward_dev + backward_dev) on tensors resident in HBM, timed with the
+    !! host clock around a device synchronize -- the T-step layer as BASELINE configs[2] states it, driven from Fortran
+    logical, intent(in), optional :: timed
     type(duvenaud_mp_layer_type) :: layer
     type(mp_actv_type) :: act, act_r
-    integer :: t, fv, fe, mn, mx, nout
+    integer :: t, fv, fe, mn, mx, nout, reps, k
+    type(c_ptr) :: x_dev, e_dev, up_dev, o_dev, dx_dev, de_dev
+    integer(c_int64_t) :: c0, c1, rate
+    real(c_double) :: ms
 
     read(uin) t, fv, fe, mn, mx, nout
     act = read_actv()
@@ -151,6 +159,33 @@ contains
     call write_matrix(dx)
     call write_matrix(de)
     call write_vector(layer%get_gradients())
+    if(present(timed))then
+       read(uin) reps
+       if(athena_mp_malloc(x_dev, 4_c_int64_t * size(x, kind=c_int64_t)) .ne. 0) stop 7
+       if(athena_mp_malloc(e_dev, 4_c_int64_t * max(size(e, kind=c_int64_t), 1_c_int64_t)) .ne. 0) stop 7
+       if(athena_mp_malloc(up_dev, 4_c_int64_t * size(up, kind=c_int64_t)) .ne. 0) stop 7
+       if(athena_mp_memcpy_h2d(x_dev, x, 4_c_int64_t * size(x, kind=c_int64_t)) .ne. 0) stop 7
+       if(size(e) .gt. 0)then
+          if(athena_mp_memcpy_h2d(e_dev, e, 4_c_int64_t * size(e, kind=c_int64_t)) .ne. 0) stop 7
+       end if
+       if(athena_mp_memcpy_h2d(up_dev, up, 4_c_int64_t * size(up, kind=c_int64_t)) .ne. 0) stop 7
+       do k = 1, 3
+          o_dev = layer%forward_dev(x_dev, e_dev)
+          call layer%backward_dev(up_dev, dx_dev=dx_dev, de_dev=de_dev)
+       end do
+       if(athena_mp_synchronize() .ne. 0) stop 7
+       call system_clock(c0, rate)
+       do k = 1, reps
+          o_dev = layer%forward_dev(x_dev, e_dev)
+          call layer%backward_dev(up_dev, dx_dev=dx_dev, de_dev=de_dev)
+       end do
+       if(athena_mp_synchronize() .ne. 0) stop 7
+       call system_clock(c1)
+       ms = real(c1 - c0, c_double) / real(rate, c_double) * 1.d3 / real(reps, c_double)
+       call write_vector([real(ms, real32)])
+       call write_vector(layer%get_gradients())                ! after the timed loop: the same gradients, bit for bit
+       if(athena_mp_free(x_dev) .ne. 0 .or. athena_mp_free(e_dev) .ne. 0 .or. athena_mp_free(up_dev) .ne. 0) stop 7
+    end if
     call layer%destroy()
   end subroutine run_duvenaud
 

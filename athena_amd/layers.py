@@ -133,6 +133,19 @@ class msgpass_layer_type:
             self._seg = torch.from_numpy(self.graph.vertex_offsets).to(self.device)
         return self
 
+    def set_graph_batched(self, graph, vertex_offsets):
+        """A batch that is ALREADY one block-diagonal graph (what set_graph assembles from a list): `graph` holds every sample's
+        vertices and edge columns back to back, vertex_offsets [batch + 1] (0-based) says where each sample's vertices start.
+        Same layer, same kernels; the per-sample graph objects never exist (130 000 of them at BASELINE configs[2])."""
+        vo = np.ascontiguousarray(vertex_offsets, dtype=np.int32)
+        if not (vo.ndim == 1 and vo.size >= 2 and vo[0] == 0 and vo[-1] == graph.num_vertices and np.all(np.diff(vo) >= 0)):
+            raise ValueError("set_graph_batched: vertex_offsets must run from 0 to graph.num_vertices, ascending")
+        self.set_graph([graph])
+        self.graph.vertex_offsets = vo
+        self.graph.batch = int(vo.size - 1)
+        self._seg = torch.from_numpy(vo).to(self.device)
+        return self
+
     # -- text card of the network file (print_base / read) -------------------------------------------
     def print(self, file=None):
         """the layer's card as athena writes it (athena_base_layer_sub_io.f90:14-65); appended to `file` if given"""

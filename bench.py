@@ -350,7 +350,8 @@ def main_gno(args, world, rank, dev, one_device):
     watch = None
     backend = os.environ.get("ATHENA_MP_BENCH_BACKEND", "nccl")
     if world > 1:
-        watch = adist.Watchdog(rank)
+        os.environ.setdefault("ATHENA_MP_COLLECTIVE_TIMEOUT_S", "120")   # the bench's own deadline, for the python watchdog AND
+        watch = adist.Watchdog(rank)                                     # comm.hip's monitor (library default: 1800 s)
         adist.set_watchdog(watch)
         with watch.phase("process group creation"):
             if backend == "nccl":
@@ -465,12 +466,35 @@ def main_gno(args, world, rank, dev, one_device):
             dref[k] += kap64[sja[1, w_] - 1] @ gs[sja[0, w_] - 1]
     dref += oracle.matmul_dx(w, g_rows[rsel].cpu().numpy(), Fi).astype(np.float64)
     res["dX_rel"] = rel(step.dX[rsel].cpu().numpy(), dref)
+    # ... and independently of the pull-form graphs the step itself uses: dx of sampled INTERIOR vertices as the
+    # reference forms it -- a SCATTER over the FORWARD graph, dx[u] += K_e^T g[v] for every entry (u, e) of every row v
+    # (athena_diffstruc_extd_sub_nop.f90:419-458).  An interior vertex is referenced by local rows only, so the rank's own
+    # forward blocks hold every entry that scatters into it; a symmetry bug in the backward blocks would show here.
+    res["dX_scatter_rel"] = 0.0
+    if ni:
+        ucols = np.sort(r2.choice(ni, min(60, ni), replace=False))
+        gi, gb = step.g_fwd_int, step.g_fwd_bnd
+        rp = np.concatenate([gi.export("rowptr"), gb.export("rowptr")[1:] + gi.nnz]).astype(np.int64)
+        col = np.concatenate([gi.export("col"), gb.export("col")])
+        eid = np.concatenate([gi.export("eid"), gb.export("eid")])
+        hit = np.flatnonzero(np.isin(col, ucols) & (eid >= 0))
+        vrow = np.searchsorted(rp, hit, side="right") - 1                  # the row each such entry sits in
+        ecs, einv = np.unique(eid[hit], return_inverse=True)
+        kap_s = oracle.gno_kernel_eval(c_loc[ecs], theta, H, Fo * Fi).reshape(-1, Fi, Fo).astype(np.float64)
+        gv = g_rows[torch.from_numpy(vrow).to(dev)].cpu().numpy().astype(np.float64)
+        dsc = np.zeros((ucols.size, Fi))
+        pos = np.searchsorted(ucols, col[hit])
+        for k in range(hit.size):
+            dsc[pos[k]] += kap_s[einv[k]] @ gv[k]
+        usel = torch.from_numpy(ucols).to(dev)
+        dsc += oracle.matmul_dx(w, g_rows[usel].cpu().numpy(), Fi).astype(np.float64)
+        res["dX_scatter_rel"] = rel(step.dX[usel].cpu().numpy(), dsc)
     held = np.flatnonzero(shard.ext_ids >= 0)
     halo_ok = True
     if held.size:
         k = np.sort(r2.choice(held, min(300, held.size), replace=False))
         halo_ok = bool(np.array_equal(step.x_ext[torch.from_numpy(n + k).to(dev)].cpu().numpy(), synth.feature_rows(1, shard.ext_ids[k], Fi)))
-    flags = torch.tensor([0.0 if halo_ok else 1.0, res["out_rel"], res["dX_rel"]], dtype=torch.float64)
+    flags = torch.tensor([0.0 if halo_ok else 1.0, res["out_rel"], res["dX_rel"], res["dX_scatter_rel"]], dtype=torch.float64)
     if world > 1:
         if backend == "nccl":
             flags = flags.to(dev)
@@ -479,7 +503,8 @@ def main_gno(args, world, rank, dev, one_device):
     flags = flags.cpu().tolist()
     parity = {"against": f"materialising oracle on {rows.size} sampled rows of both blocks of every rank (max over ranks); halo rows "
                          "against the generator; the all-reduced gradients are held by tests/test_gpu_dist.py, not here",
-              "halo_rows_bit_exact": flags[0] == 0.0, "out_rel": flags[1], "dX_rel": flags[2], "tol": TOL}
+              "halo_rows_bit_exact": flags[0] == 0.0, "out_rel": flags[1], "dX_rel": flags[2],
+              "dX_rel_vs_scatter_over_the_forward_graph": flags[3], "tol": TOL}
     parity["ok"] = bool(flags[0] == 0.0 and max(flags[1:]) <= TOL)
     out = {"metric": "msgpass fwd+bwd edges/sec", "value": nnz_total * args.steps / dt, "unit": "edges/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
@@ -502,6 +527,7 @@ def main_gno(args, world, rank, dev, one_device):
         with phase("breakdown (each part timed alone)", factor=2.0):
             out["breakdown"] = adist.measure_breakdown_gno(step)
         out["breakdown"]["note"] = "each part timed alone after the timed loop, rank 0 (events); in the step the exchanges run under the interior work"
+        out["rccl"] = adist.c_comm_stats()      # rank 0's communicator: ranks RCCL itself counts, its version, bytes to every peer
         err = transport_error(str(shard.transport), one_device)
         if err:
             out["ok"], out["error"], ok = False, err, False
@@ -562,7 +588,8 @@ def main():
         backend = os.environ.get("ATHENA_MP_BENCH_BACKEND", "nccl")
         # every wait for a peer from here on has a deadline (ATHENA_MP_COLLECTIVE_TIMEOUT_S, default 120 s per phase): a
         # stalled rank prints {"ok": false, "error": "rank r stalled in <phase>"} and leaves with exit code 3
-        watch = adist.Watchdog(rank)
+        os.environ.setdefault("ATHENA_MP_COLLECTIVE_TIMEOUT_S", "120")   # the bench's own deadline, for the python watchdog AND
+        watch = adist.Watchdog(rank)                                     # comm.hip's monitor (library default: 1800 s)
         adist.set_watchdog(watch)
         with watch.phase("process group creation"):
             if backend == "nccl":
@@ -763,8 +790,10 @@ def main():
                                         "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                         "frac": tf / MFMA_F32_PEAK_TFLOPS, "flops_per_launch": flops,
                                         "avg_launch_ms": out["breakdown"]["dw_ms"]}
-        # a line that "scaled" through the host-staged TEST transport (or the python fallback plan) is not a measurement
-        # of RCCL over xGMI: outside the one-device dry run it is an error, stated in the line and in the exit code
+        # what rank 0's communicator did: the ranks RCCL itself counts (ncclCommCount), its version, bytes to every peer
+        out["rccl"] = adist.c_comm_stats()
+        # a line that "scaled" through the host-staged TEST transport is not a measurement of RCCL over xGMI: outside the
+        # one-device dry run it is an error, stated in the line and in the exit code
         err = transport_error(str(info.get("transport", "")), one_device)
         if err:
             out["ok"], out["error"], ok = False, err, False

@@ -498,6 +498,18 @@ int athena_mp_comm_create(int32_t rank, int32_t world, const void *id128, athena
 int athena_mp_comm_create_from_file(int32_t rank, int32_t world, const char *path, athena_mp_comm **out);
 int athena_mp_comm_destroy(athena_mp_comm *c);
 int athena_mp_comm_info(const athena_mp_comm *c, int32_t *rank, int32_t *world, char *transport, int32_t transport_len);
+/* What this rank's communicator has actually done, so that a multi-GPU line proves what it used: ranks_seen = the
+ * transport's OWN count of ranks (RCCL: ncclCommCount; -1 unavailable), library_version (RCCL: ncclGetVersion, e.g. 22606),
+ * transfers started, all-reduce payload bytes, and the bytes put on the wire to every peer (grouped ncclSend rows and this
+ * rank's block of every whole-block all-gather); sent_bytes_per_peer [n_peers] may be NULL with n_peers 0. */
+int athena_mp_comm_stats(const athena_mp_comm *c, int32_t *ranks_seen, int32_t *library_version, int64_t *transfers,
+                         int64_t *allreduce_bytes, int64_t *sent_bytes_per_peer, int32_t n_peers);
+/* Every transfer these entry points start has a deadline (ATHENA_MP_COLLECTIVE_TIMEOUT_S seconds from the moment it actually
+ * starts on the device; default 1800, 0 = none): a rank whose peer is missing ends with a message on stderr / in
+ * athena_mp_last_error and exit code 3 instead of hanging in its next synchronize.  A handler registered here is called first,
+ * once, on the library's monitor thread -- the host's chance to flush its own state; the process ends when it returns.  Nothing
+ * is ever written on the host program's stdout. */
+int athena_mp_set_stall_handler(void (*handler)(int32_t rank, const char *what, double seconds));
 int athena_mp_comm_barrier(athena_mp_comm *c);
 /* in-place float32 sum over ranks (dW, d theta): _start enqueues it on the communication stream behind the work the
  * compute stream holds so far, _finish makes the compute stream wait for it; the host never blocks */

@@ -137,9 +137,138 @@ def run_c3(dev, reps):
     entc = int(iac[-1] - 1)
     cpu = {"value": entc / tc, "unit": "entries/s", "cores": 1, "kind": "port",
            "sample": f"oracle, first {NC} graphs = {entc} entries, one time step fwd+bwd, {tc:.2f} s"}
-    return {"config": "configs[2]", "workload": f"Duvenaud msgpass, {S} QM9-shaped graphs = {N} vertices / {nnz} entries, F_v = {Fv}, F_e = {Fe}, "
-            f"{O} outputs, one time step + readout, fwd+bwd", "step_ms": round(step, 4), "entries_per_s": nnz / step * 1e3, "ops": opsd, "parity": par,
-            "cpu_baseline": cpu}
+    res = {"config": "configs[2]", "workload": f"Duvenaud msgpass, {S} QM9-shaped graphs = {N} vertices / {nnz} entries, F_v = {Fv}, F_e = {Fe}, "
+           f"{O} outputs, one time step + readout, fwd+bwd", "step_ms": round(step, 4), "entries_per_s": nnz / step * 1e3, "ops": opsd, "parity": par,
+           "cpu_baseline": cpu}
+    del a_, z, p, dc, da, dx, de
+    res["layer_T4"] = c3_layer_T4(dev, reps, ia, ja, voff, E, x, e)
+    return res
+
+
+def c3_layer_T4(dev, reps, ia, ja, voff, E, x, e):
+    """BASELINE configs[2] as the config states it (T = 4 + readout, example/msgpass_chemical/src/main.f90:129-138):
+    duvenaud_msgpass_layer_type(F_v 64, F_e 8, 4 time steps, degrees 1..10, 10 outputs), forward + the whole reverse pass
+    (input, edge-feature and all 8 parameter gradients) through the layer mirror.  Parity of the layer output, dx, de and EVERY
+    parameter gradient against the oracle's per-sample composition (oracle/layers.py) on the first 2 000 graphs, run through
+    the same layer code; the full-size run is tied to it by the graph-local outputs of those graphs and by additivity of
+    the parameter gradients over chunks of the batch (float64 sum of 65 chunk runs against the one full-size run)."""
+    from athena_amd.graph import graph_type
+    from athena_amd.layers import duvenaud_msgpass_layer_type
+    from oracle import layers as ol
+
+    S, N, nnz = voff.size - 1, ia.size - 1, ja.shape[1]
+    Fv, Fe, O, T, mn, mx = 64, 8, 10, 4, 1, 10
+    rng = np.random.default_rng(7)
+
+    def make():
+        return duvenaud_msgpass_layer_type(num_vertex_features=[Fv], num_edge_features=[Fe], num_time_steps=T, max_vertex_degree=mx,
+                                           num_outputs=O, min_vertex_degree=mn, seed=1)
+
+    layer = make()
+    g = graph_type.from_csr(ia, ja, num_edges=E).freeze()
+    layer.set_graph_batched(g, voff)
+    up = torch.from_numpy(rng.standard_normal((S, O)).astype(np.float32)).to(dev)
+
+    def step():
+        layer.forward(x, e)
+        return layer.backward(up, need_input_grad=True, need_edge_grad=True)
+
+    ms = timeit(step, reps)
+    out_full = layer.output.cpu().numpy().copy()
+    dx_full, de_full = (t.cpu().numpy() for t in step())
+    grads_full = layer.get_gradients().astype(np.float64)
+    params = layer.get_params()
+    # bytes one step moves, per time step the seven launches of `ops` above (the last step's readout reverse has no dz_next; steps
+    # 2..T of the reverse read it): compulsory tensors only
+    Fc = Fv + Fe
+    per_t = (N * 4 * Fv + E * 4 * Fe + nnz * 8 + N * 4 + N * 4 * Fc) + N * 4 * (Fc + Fv + O) + (N * 4 * O + S * 4 * O) \
+        + (N * 4 * (2 * Fv + O + 1) + S * 4 * O) + N * 4 * (2 * Fc + Fv) + (N * 4 * Fc + nnz * 4 + N * 4 + N * 4 * Fv) \
+        + (N * 4 * Fe + nnz * 8 + E * 4 * Fe)
+    nbytes = T * per_t + (T - 1) * N * 4 * Fv
+
+    # --- the same layer code on the first NG graphs, against the oracle's per-sample composition
+    NG = 2000
+
+    def sub_batch(g0, g1):
+        v0, v1 = int(voff[g0]), int(voff[g1])
+        w0, w1 = int(ia[v0]) - 1, int(ia[v1]) - 1
+        js = ja[:, w0:w1].astype(np.int64)
+        eids = np.unique(js[1][js[1] > 0])                       # global edge ids (1-based) these graphs use, ascending
+        remap = np.zeros(int(eids.max()) + 1 if eids.size else 1, np.int64)
+        remap[eids] = np.arange(1, eids.size + 1)
+        jl = np.empty_like(js)
+        jl[0] = js[0] - v0
+        jl[1] = np.where(js[1] > 0, remap[np.minimum(js[1], remap.size - 1)], 0)
+        ias = (ia[v0:v1 + 1].astype(np.int64) - w0).astype(np.int32)
+        return v0, v1, ias, np.asfortranarray(jl.astype(np.int32)), eids - 1
+
+    v0, v1, ias, jas, eidx = sub_batch(0, NG)
+    sub = make()
+    sub.set_params(params)
+    gsub = graph_type.from_csr(ias, jas, num_edges=int(eidx.size))
+    sub.set_graph_batched(gsub, voff[:NG + 1] - voff[0])
+    xs, es = x[v0:v1].contiguous(), e[torch.from_numpy(eidx).to(dev)].contiguous()
+    sub.forward(xs, es)
+    dxs, des = (t.cpu().numpy() for t in sub.backward(up[:NG].contiguous(), need_input_grad=True, need_edge_grad=True))
+    out_s, gr_s = sub.output.cpu().numpy(), sub.get_gradients()
+    # oracle: the reference's loop over samples (athena_duvenaud_msgpass_layer.f90:792-855) and grad_reverse's walk over it
+    graphs, xl, el = [], [], []
+    xh, eh, uph = xs.cpu().numpy(), es.cpu().numpy(), up[:NG].cpu().numpy()
+    for s in range(NG):
+        a0, a1 = int(voff[s]), int(voff[s + 1])
+        w0, w1 = int(ias[a0]) - 1, int(ias[a1]) - 1
+        jj = jas[:, w0:w1].astype(np.int64)
+        ed = np.unique(jj[1][jj[1] > 0])
+        rm = np.zeros(int(ed.max()) + 1 if ed.size else 1, np.int64)
+        rm[ed] = np.arange(1, ed.size + 1)
+        gl = graph_type.from_csr((ias[a0:a1 + 1].astype(np.int64) - w0).astype(np.int32),
+                                 np.asfortranarray(np.stack([jj[0] - a0, np.where(jj[1] > 0, rm[np.minimum(jj[1], rm.size - 1)], 0)]).astype(np.int32)),
+                                 num_edges=int(ed.size))
+        graphs.append(gl); xl.append(xh[a0:a1]); el.append(eh[ed - 1])
+    sizes = [Fv * (Fv + Fe) * (mx - mn + 1)] * T + [O * Fv] * T
+    plist = np.split(params, np.cumsum(sizes)[:-1])
+    nvf = [Fv] * (T + 1)
+    t0 = time.perf_counter()
+    out_o, tapes = ol.duvenaud_forward(graphs, xl, el, plist, nvf, Fe, mn, mx, O, "sigmoid")
+    dx_o, de_o, gr_o = ol.duvenaud_backward(graphs, el, tapes, plist, nvf, Fe, mn, mx, O, "sigmoid", uph)
+    t_cpu = time.perf_counter() - t0
+    de_o_flat = np.zeros_like(des)
+    for s in range(NG):                                           # per-sample de back into the sub-batch's edge columns
+        a0, a1 = int(voff[s]), int(voff[s + 1])
+        jj = jas[1, int(ias[a0]) - 1:int(ias[a1]) - 1]
+        ed = np.unique(jj[jj > 0])
+        de_o_flat[ed - 1] = de_o[s]
+    gr_o = np.concatenate(gr_o)
+    names = [f"dW_{t}" for t in range(1, T + 1)] + [f"dR_{t}" for t in range(1, T + 1)]
+    gsplit_s, gsplit_o = np.split(gr_s, np.cumsum(sizes)[:-1]), np.split(gr_o, np.cumsum(sizes)[:-1])
+    par = {"against": f"oracle/layers.py (the reference's per-sample loop and grad_reverse's walk) on the first {NG} graphs through the same layer code",
+           "output_rel": rel(out_s, out_o), "dx_rel": rel(dxs, np.concatenate(dx_o)), "de_rel": rel(des, de_o_flat),
+           "param_grad_rel": {n: rel(a, b) for n, a, b in zip(names, gsplit_s, gsplit_o)}, "tol": TOL}
+    # --- the full-size run tied to it
+    par["full_size_output_of_those_graphs_rel"] = rel(out_full[:NG], out_o)
+    par["full_size_dx_of_those_graphs_rel"] = rel(dx_full[v0:v1], np.concatenate(dx_o))
+    acc = np.zeros(grads_full.size, np.float64)
+    CH = 2000
+    for g0 in range(0, S, CH):
+        g1 = min(S, g0 + CH)
+        c0, c1, iac, jac, ec = sub_batch(g0, g1)
+        sub.set_graph_batched(graph_type.from_csr(iac, jac, num_edges=int(ec.size)), voff[g0:g1 + 1] - voff[g0])
+        sub.forward(x[c0:c1].contiguous(), e[torch.from_numpy(ec).to(dev)].contiguous())
+        sub.backward(up[g0:g1].contiguous(), need_input_grad=False, need_edge_grad=False)
+        acc += sub.get_gradients().astype(np.float64)
+    fsplit, asplit = np.split(grads_full, np.cumsum(sizes)[:-1]), np.split(acc, np.cumsum(sizes)[:-1])
+    par["full_size_param_grads_vs_sum_of_chunk_runs_rel"] = {n: rel(a, b) for n, a, b in zip(names, fsplit, asplit)}
+    par["ok"] = bool(max(par["output_rel"], par["dx_rel"], par["de_rel"], par["full_size_output_of_those_graphs_rel"],
+                         par["full_size_dx_of_those_graphs_rel"], *par["param_grad_rel"].values(),
+                         *par["full_size_param_grads_vs_sum_of_chunk_runs_rel"].values()) <= TOL)
+    ent = int(ias[-1] - 1) * T
+    return {"workload": f"duvenaud_msgpass_layer_type, T = {T} time steps + readout, F_v = {Fv}, F_e = {Fe}, degrees {mn}..{mx}, {O} outputs, "
+            f"{S} graphs = {N} vertices / {nnz} entries; forward + reverse (dx, de, {2 * T} parameter gradients)",
+            "step_ms": round(ms, 4), "entries_per_s": T * nnz / ms * 1e3, "launches_per_step": 7 * T,
+            "hbm": hbm_op(ms, nbytes, "compulsory tensors of the 7 T launches"), "parity": par,
+            "cpu_baseline": {"value": ent / t_cpu, "unit": "entries/s (entries x time steps)", "cores": 1, "kind": "port",
+                             "sample": f"oracle/layers.py, the reference's loop over samples, first {NG} graphs x {T} time steps = {ent} entry visits, "
+                                       f"forward + reverse, {t_cpu:.2f} s"}}
 
 
 def run_c4(dev, reps):

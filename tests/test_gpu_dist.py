@@ -883,8 +883,8 @@ def test_bench_py_gno_mesh_config(dev, gpus):
 
 def test_c_abi_transfers_have_a_deadline_of_their_own(dev, tmp_path):
     """comm.hip's monitor thread (for hosts that are not bench.py: the Fortran drivers): every transfer put on the communication
-    stream is watched through its completion event, and one still pending after ATHENA_MP_COLLECTIVE_TIMEOUT_S ends the process
-    with a message naming the rank and the transfer and exit code 3.  Exercised with kipf_shard_run on two ranks (shm test
+    stream is watched through its completion event, and one still pending after ATHENA_MP_COLLECTIVE_TIMEOUT_S (library default
+    1800 s; here 2) ends the process with a message naming the rank and the transfer on STDERR and exit code 3.  Exercised with kipf_shard_run on two ranks (shm test
     transport) and the test hook that parks a BOUNDED 6 s spin kernel in front of the completion event, deadline 2 s."""
     import subprocess
 
@@ -902,7 +902,7 @@ def test_c_abi_transfers_have_a_deadline_of_their_own(dev, tmp_path):
     for r, (p, (so, se)) in enumerate(zip(procs, outs)):
         assert p.returncode == 3, (r, p.returncode, so.decode()[-500:], se.decode()[-800:])
         assert f"rank {r} stalled in the halo exchange in slot 0" in se.decode()
-        assert '"ok": false' in so.decode()
+        assert '"ok": false' not in so.decode()      # stderr + exit code only: the host program's stdout is not the library's
     # ... and with the deadline above the delay the same run completes
     env["ATHENA_MP_COLLECTIVE_TIMEOUT_S"] = "60"
     env["ATHENA_MP_COMM_TEST_DELAY_MS"] = "300"
@@ -1083,3 +1083,79 @@ def test_node_partitioned_gno_fuzz_multigraphs_with_self_loops(dev, seed, world,
         assert res[r]["same"], r
         assert np.abs(res[r]["grads"] - g_ref).max() <= 2e-5 * np.abs(g_ref).max(), r
         assert np.abs(res[r]["dcoords"] - dcs[0][res[r]["edge_ids"]]).max() <= 2e-5 * np.abs(dcs[0]).max(), r
+
+
+def _failing_shard_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from athena_amd import dist as adist
+    from athena_amd import synth
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    n_total, n = 4000, 4000 // world
+    ia, cols = synth.random_graph_csr_rows(n_total, 12000, rank * n, (rank + 1) * n)
+    if rank == 1:
+        cols = cols.copy()
+        cols[3] = n_total + 17                       # a neighbour that does not exist: athena_mp_shard_create refuses it
+    try:
+        adist._c_shard(dev, ia, cols)
+        q.put((rank, "no error"))
+    except RuntimeError as exc:
+        q.put((rank, str(exc)))
+    dist.barrier()
+    adist.c_comm_destroy()
+    dist.destroy_process_group()
+
+
+def test_a_c_abi_shard_failure_raises_on_every_rank_with_the_c_error_text(dev):
+    """no second implementation behind the product path: when one rank's athena_mp_shard_create fails,
+    that rank raises with the C ABI's message and the others raise too (told by the agreement all-reduce) -- nothing falls
+    back to dist.py's python plan, which is the CPU mirror of the gloo tests only"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    env_before = os.environ.get("ATHENA_MP_COMM_TRANSPORT")
+    procs = [ctx.Process(target=_failing_shard_worker, args=(r, world, port, q)) for r in range(world)]
+    shm_before = _shm_dirs()
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+    _remove_shm_dirs(shm_before)
+    if env_before is None:
+        os.environ.pop("ATHENA_MP_COMM_TRANSPORT", None)
+    assert "C-ABI communicator / shard failed" in got[1] and "AthenaMPError" in got[1], got
+    assert "another rank failed" in got[0], got
+    src = open(os.path.join(ROOT, "athena_amd", "dist.py")).read()
+    assert "FALLBACK" not in src and "_c_shard_or_none" not in src
+
+
+def test_comm_stats_count_what_went_on_the_wire(dev):
+    """athena_mp_comm_stats through dist.c_comm_stats(): one rank over RCCL -- ranks_seen is RCCL's own ncclCommCount, the
+    version its ncclGetVersion; the all-reduce payload is counted"""
+    import subprocess
+    prog = r"""
+import os, sys, json
+sys.path.insert(0, %r)
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=%r)
+import torch, torch.distributed as dist
+dist.init_process_group("nccl", rank=0, world_size=1)
+torch.cuda.set_device(0)
+from athena_amd import dist as adist, _capi
+c = adist.c_comm(torch.device("cuda", 0))
+buf = torch.ones(1000, device="cuda")
+_capi.call("athena_mp_allreduce", c.handle, buf.data_ptr(), 1000)
+torch.cuda.synchronize()
+print(json.dumps(adist.c_comm_stats()))
+adist.c_comm_destroy(); dist.destroy_process_group()
+""" % (ROOT, str(_free_port()))
+    r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    st = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert st["transport"] == "rccl" and st["ranks_seen"] == 1 and st["version"] > 20000, st
+    assert st["sent_bytes_per_peer"] == [0]

@@ -343,3 +343,42 @@ print("never printed", flush=True)
     assert lines[0] == "still here" and "never printed" not in r.stdout
     msg = json.loads(lines[-1])
     assert msg["ok"] is False and "rank 5 stalled in halo exchange of the forward rows" in msg["error"]
+    # an OUTER phase's earlier deadline is enforced while an inner phase with a longer leash is active
+    prog2 = r'''
+import sys, time
+sys.path.insert(0, %r)
+from athena_amd.dist import Watchdog
+wd = Watchdog(2, timeout_s=0.5)
+with wd.phase("timed loop"):
+    with wd.phase("shard build inside it", factor=100.0):
+        time.sleep(30)
+''' % root
+    r = subprocess.run([sys.executable, "-c", prog2], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3, (r.returncode, r.stdout, r.stderr[-500:])
+    assert "rank 2 stalled in timed loop" in json.loads(r.stdout.strip().splitlines()[-1])["error"]
+
+
+def test_frozen_graph_keeps_its_content_key_and_refuses_in_place_edits():
+    """graph_type.freeze(): read-only adjacency arrays -> topology_key() may memoise the full content key (set_graph before every
+    forward then costs a tuple compare, ADVICE r04); an in-place edit raises instead of going unseen; an assignment re-keys"""
+    from athena_amd import synth
+    from athena_amd.graph import graph_type
+
+    ia, ja = synth.random_graph_csr(2000, 9000)
+    g = graph_type.from_csr(ia, ja)
+    k0 = g.topology_key()
+    assert g.topology_key() == k0 and getattr(g, "_key_memo", None) is None      # writable arrays: hashed every time
+    g.adj_ja[0, 5] = g.adj_ja[0, 5] % 2000 + 1                                     # ... so an in-place edit is seen
+    assert g.topology_key()[4] != k0[4] or ja[0, 5] == g.adj_ja[0, 5]
+    g.freeze()
+    k1 = g.topology_key()
+    assert g._key_memo is not None and g.topology_key() is k1
+    with pytest.raises(ValueError):
+        g.adj_ja[0, 0] = 3
+    with pytest.raises(ValueError):
+        g.adj_ia[1] = 7
+    ja2 = np.asfortranarray(np.array(g.adj_ja))
+    ja2[0, 0] = ja2[0, 0] % 2000 + 1
+    g.adj_ja = ja2                                                                 # assignment: version bump, memo dropped
+    k2 = g.topology_key()
+    assert k2[1] != k1[1] and k2[4] != k1[4]
