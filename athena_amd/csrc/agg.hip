@@ -506,7 +506,7 @@ int athena_mp_duvenaud_propagate_bwd_x(const athena_mp_graph *g, int32_t Fv, int
 int athena_mp_duvenaud_propagate_bwd_e(const athena_mp_graph *g, int32_t Fv, int32_t Fe, const float *grad,
                                        float *de)
 {
-    AMP_REQUIRE(g && grad && de && Fv > 0 && Fe > 0, "duvenaud_propagate_bwd_e: bad arguments");
+    AMP_REQUIRE(g && grad && de && Fv >= 0 && Fe > 0, "duvenaud_propagate_bwd_e: bad arguments");   // Fv = 0: grad holds the edge part alone
     return gather_agg(g->e_rowptr, g->e_row, nullptr, grad + Fv, (int64_t)Fv + Fe, de, Fe, g->n_edge_cols, Fe);
 }
 

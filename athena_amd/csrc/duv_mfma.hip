@@ -17,6 +17,7 @@
 // wave-private LDS tile; per-bucket partial sums go to slab (workgroup + bucket) -- a contiguous slab
 // range per bucket, reduced in fixed order (deterministic, no atomics).
 #include <algorithm>
+#include <map>
 
 #include "common.h"
 
@@ -805,8 +806,10 @@ __global__ __launch_bounds__(256, (IT * OT > 20 ? 1 : 2)) void duv_bwd_wide_kern
                                                               const float *__restrict__ A, int Fi,
                                                               const float *__restrict__ G, int Fo,
                                                               const float *__restrict__ W, float *__restrict__ DA,
-                                                              float *__restrict__ slabs)
+                                                              float *__restrict__ slabs, int64_t da_rows)
 {
+    // da_rows > 0: da leaves SPLIT -- columns 0 .. 63 as rows of 64 floats (256-byte rows: whole cache lines in any order),
+    // the columns beyond as rows of Fi - 64 floats behind them at DA + 64 da_rows (experiment, DUV_SPLIT_DA)
     constexpr int AP = 16 * IT + 4, GP = 16 * OT + 4, FOP = 16 * OT, WP = 16 * OT + 4, TA = IT - 4, TG = OT - 4;
     constexpr int kW = 16 * IT * WP, kTurn = 4 * 16 * (AP + GP), kRed = 16 * IT * FOP;
     __shared__ __attribute__((aligned(16))) float buf[kW + (kTurn > kRed ? kTurn : kRed)];
@@ -931,15 +934,19 @@ __global__ __launch_bounds__(256, (IT * OT > 20 ? 1 : 2)) void duv_bwd_wide_kern
 #pragma unroll
             for (int it = 0; it < IT; ++it) *reinterpret_cast<v4f *>(al + n * AP + 16 * it + 4 * q) = div4(da[it], d, inv);
             asm volatile("" ::: "memory");
+            const int64_t pm = da_rows > 0 ? 64 : Fi, pt = da_rows > 0 ? Fi - 64 : Fi;
+            float *dat = da_rows > 0 ? DA + 64 * da_rows - 64 : DA;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const v4f y = *reinterpret_cast<const v4f *>(al + (4 * k + q) * AP + 4 * n);
-                *reinterpret_cast<v4f *>(DA + (int64_t)srow[k] * Fi + 4 * n) = y;
+                *reinterpret_cast<v4f *>(DA + (int64_t)srow[k] * pm + 4 * n) = y;
             }
 #pragma unroll
             for (int u = 0; u < TA; ++u) {
                 const v4f y = *reinterpret_cast<const v4f *>(al + ta.row[u] * AP + ta.col[u]);
-                *reinterpret_cast<v4f *>(DA + (int64_t)srow[4 + u] * Fi + ta.col[u]) = y;
+                // (a lane without a tail chunk repeats chunk 0 of row 0 -- column 0: that one belongs to the main part)
+                float *dst = ta.col[u] >= 64 ? dat + (int64_t)srow[4 + u] * pt : DA + (int64_t)srow[4 + u] * pm;
+                *reinterpret_cast<v4f *>(dst + ta.col[u]) = y;
             }
             asm volatile("" ::: "memory");
             // the tail columns of the a tile must read zero again for the next tile's weight gradient
@@ -1132,10 +1139,16 @@ int duv_mfma_bwd(const athena_mp_graph *g, int Fi, int Fo, const float *grad, co
     void *slabs = nullptr;
     if (workspace(&slabs, sizeof(float) * (size_t)nwg * n, 2)) return 1;
     bool launched = false;
+#ifdef DUV_SPLIT_DA
+    static const bool split_env = getenv("ATHENA_MP_DUV_SPLIT") != nullptr;     // experiment switch (variant build only)
+    const int64_t da_rows = (split_env && Fi > 64) ? g->n_rows : 0;
+#else
+    const int64_t da_rows = 0;
+#endif
 #define AMP_WIDE(IT_, OT_)                                                                                            \
     if (it == IT_ && ot == OT_) {                                                                                     \
         hipLaunchKernelGGL((duv_bwd_wide_kernel<IT_, OT_>), dim3(nwg), dim3(256), 0, stream(), sp, g->btile_rows,     \
-                           g->btile_rows + (size_t)48 * nt, a, Fi, grad, Fo, w, da, (float *)slabs);                  \
+                           g->btile_rows + (size_t)48 * nt, a, Fi, grad, Fo, w, da, (float *)slabs, da_rows);         \
         launched = true;                                                                                              \
     }
     AMP_WIDE(4, 4) AMP_WIDE(5, 4) AMP_WIDE(4, 5) AMP_WIDE(6, 4) AMP_WIDE(4, 6)
@@ -1147,4 +1160,6 @@ int duv_mfma_bwd(const athena_mp_graph *g, int Fi, int Fo, const float *grad, co
     return slab_reduce_segs((const float *)slabs, n, nb, first.data(), count.data(), dw, n, false);
 }
 
+
 } // namespace amp
+
