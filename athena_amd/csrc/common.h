@@ -184,5 +184,6 @@ int duv_mfma_bwd_a(const athena_mp_graph *g, int Fi, int Fo, const float *grad, 
 int duv_mfma_bwd_w(const athena_mp_graph *g, int Fi, int Fo, const float *grad, const float *a, float *dw);
 int duv_mfma_fwd_readout(const athena_mp_graph *g, int Fi, int Fo, const float *a, const float *w, int act, float *z,
                          const float *R, int O, float *p);
-int duv_mfma_bwd(const athena_mp_graph *g, int Fi, int Fo, const float *grad, const float *a, const float *w, float *da, float *dw);
+int duv_mfma_bwd(const athena_mp_graph *g, int Fi, int Fo, const float *grad, const float *a, const float *w, float *da, float *dw,
+                 float *da_tail = nullptr);
 } // namespace amp

@@ -806,10 +806,12 @@ __global__ __launch_bounds__(256, (IT * OT > 20 ? 1 : 2)) void duv_bwd_wide_kern
                                                               const float *__restrict__ A, int Fi,
                                                               const float *__restrict__ G, int Fo,
                                                               const float *__restrict__ W, float *__restrict__ DA,
-                                                              float *__restrict__ slabs, int64_t da_rows)
+                                                              float *__restrict__ slabs, float *__restrict__ DAT)
 {
-    // da_rows > 0: da leaves SPLIT -- columns 0 .. 63 as rows of 64 floats (256-byte rows: whole cache lines in any order),
-    // the columns beyond as rows of Fi - 64 floats behind them at DA + 64 da_rows (experiment, DUV_SPLIT_DA)
+    // DAT != null: da leaves SPLIT (athena_mp_duvenaud_update_bwd_split) -- columns 0 .. 63 to DA as rows of 64 floats (256-byte
+    // rows: whole cache lines whatever the order the buckets write them in), the columns beyond to DAT as rows of Fi - 64
+    // floats: the propagate reverse then gathers the edge part from a dense [N, F_e] array instead of 32-byte slivers of
+    // 288-byte rows (profiles/r05_c3_split_da_ab.txt: 0.075 -> 0.037 ms, the three reverse launches 0.936 -> 0.872 ms)
     constexpr int AP = 16 * IT + 4, GP = 16 * OT + 4, FOP = 16 * OT, WP = 16 * OT + 4, TA = IT - 4, TG = OT - 4;
     constexpr int kW = 16 * IT * WP, kTurn = 4 * 16 * (AP + GP), kRed = 16 * IT * FOP;
     __shared__ __attribute__((aligned(16))) float buf[kW + (kTurn > kRed ? kTurn : kRed)];
@@ -934,8 +936,8 @@ __global__ __launch_bounds__(256, (IT * OT > 20 ? 1 : 2)) void duv_bwd_wide_kern
 #pragma unroll
             for (int it = 0; it < IT; ++it) *reinterpret_cast<v4f *>(al + n * AP + 16 * it + 4 * q) = div4(da[it], d, inv);
             asm volatile("" ::: "memory");
-            const int64_t pm = da_rows > 0 ? 64 : Fi, pt = da_rows > 0 ? Fi - 64 : Fi;
-            float *dat = da_rows > 0 ? DA + 64 * da_rows - 64 : DA;
+            const int64_t pm = DAT ? 64 : Fi, pt = DAT ? Fi - 64 : Fi;
+            float *dat = DAT ? DAT - 64 : DA;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const v4f y = *reinterpret_cast<const v4f *>(al + (4 * k + q) * AP + 4 * n);
@@ -1124,8 +1126,11 @@ int duv_mfma_fwd_readout(const athena_mp_graph *g, int Fi, int Fo, const float *
 }
 
 // da and dW from one pass over grad (both widths 64 .. 96); -1: shape outside the fused kernel
-int duv_mfma_bwd(const athena_mp_graph *g, int Fi, int Fo, const float *grad, const float *a, const float *w, float *da, float *dw)
+// da_tail != null: da split into da [n, 64] and da_tail [n, Fi - 64] (Fi > 64 only)
+int duv_mfma_bwd(const athena_mp_graph *g, int Fi, int Fo, const float *grad, const float *a, const float *w, float *da, float *dw,
+                 float *da_tail)
 {
+    if (da_tail && Fi <= 64) return -1;
     const int it = ceil16(Fi), ot = ceil16(Fo);
     if ((Fi & 3) || (Fo & 3) || Fi < 64 || Fo < 64 || !frag_shape(it, ot)) return -1;
     const int nt = g->n_btiles, nb = (int)g->btile_off.size() - 1, n = Fi * Fo;
@@ -1139,16 +1144,10 @@ int duv_mfma_bwd(const athena_mp_graph *g, int Fi, int Fo, const float *grad, co
     void *slabs = nullptr;
     if (workspace(&slabs, sizeof(float) * (size_t)nwg * n, 2)) return 1;
     bool launched = false;
-#ifdef DUV_SPLIT_DA
-    static const bool split_env = getenv("ATHENA_MP_DUV_SPLIT") != nullptr;     // experiment switch (variant build only)
-    const int64_t da_rows = (split_env && Fi > 64) ? g->n_rows : 0;
-#else
-    const int64_t da_rows = 0;
-#endif
 #define AMP_WIDE(IT_, OT_)                                                                                            \
     if (it == IT_ && ot == OT_) {                                                                                     \
         hipLaunchKernelGGL((duv_bwd_wide_kernel<IT_, OT_>), dim3(nwg), dim3(256), 0, stream(), sp, g->btile_rows,     \
-                           g->btile_rows + (size_t)48 * nt, a, Fi, grad, Fo, w, da, (float *)slabs, da_rows);         \
+                           g->btile_rows + (size_t)48 * nt, a, Fi, grad, Fo, w, da, (float *)slabs, da_tail);         \
         launched = true;                                                                                              \
     }
     AMP_WIDE(4, 4) AMP_WIDE(5, 4) AMP_WIDE(4, 5) AMP_WIDE(6, 4) AMP_WIDE(4, 6)

@@ -366,6 +366,32 @@ int athena_mp_duvenaud_update_bwd(const athena_mp_graph *g, int32_t Fi, int32_t 
     return athena_mp_duvenaud_update_bwd_a(g, Fi, Fo, min_deg, max_deg, grad, weight, da);
 }
 
+/* the same pair with da SPLIT where it is written: da_x [n_rows, Fv] (the part athena_mp_duvenaud_propagate_bwd_x gathers, with
+ * Fe = 0) and da_e [n_rows, Fe] (the part _bwd_e gathers, with Fv = 0).  One launch for F_v = 64 and the widths of the fused
+ * kernel; any other shape computes the packed da into a workspace and copies the two parts out. */
+int athena_mp_duvenaud_update_bwd_split(const athena_mp_graph *g, int32_t Fv, int32_t Fe, int32_t Fo, int32_t min_deg, int32_t max_deg,
+                                        const float *grad, const float *a, const float *weight, float *da_x, float *da_e,
+                                        float *dweight)
+{
+    AMP_REQUIRE(g && grad && a && weight && da_x && da_e && dweight && Fv > 0 && Fe > 0 && Fo > 0 && max_deg >= min_deg,
+                "duvenaud_update_bwd_split: bad arguments");
+    const int32_t Fi = Fv + Fe;
+    if (g->n_rows > 0 && Fv == 64 && duv_use_mfma(Fi, Fo, g->n_rows) && max_deg - min_deg + 1 <= 32) {
+        if (duvenaud_buckets(g, min_deg, max_deg)) return 1;
+        if (const int rc = duv_mfma_bwd(g, Fi, Fo, grad, a, weight, da_x, dweight, da_e); rc >= 0) return rc;
+    }
+    void *tmp = nullptr;
+    if (workspace(&tmp, sizeof(float) * (size_t)std::max<int64_t>(g->n_rows, 1) * Fi, 11)) return 1;
+    if (int rc = athena_mp_duvenaud_update_bwd(g, Fi, Fo, min_deg, max_deg, grad, a, weight, (float *)tmp, dweight)) return rc;
+    if (g->n_rows > 0) {
+        AMP_HIP(hipMemcpy2DAsync(da_x, sizeof(float) * Fv, tmp, sizeof(float) * Fi, sizeof(float) * Fv, (size_t)g->n_rows,
+                                 hipMemcpyDeviceToDevice, stream()));
+        AMP_HIP(hipMemcpy2DAsync(da_e, sizeof(float) * Fe, (const float *)tmp + Fv, sizeof(float) * Fi, sizeof(float) * Fe,
+                                 (size_t)g->n_rows, hipMemcpyDeviceToDevice, stream()));
+    }
+    return 0;
+}
+
 int athena_mp_softmax_segsum_fwd(int32_t O, int64_t N, int32_t S, const int32_t *seg, const float *logits,
                                  float *p, float *out, int32_t accumulate)
 {

@@ -39,6 +39,7 @@ module athena_mp_c
   public :: athena_mp_reverse_kipf_propagate_partial_val
   public :: athena_mp_duvenaud_propagate_fwd, athena_mp_duvenaud_propagate_bwd_x, athena_mp_duvenaud_propagate_bwd_e
   public :: athena_mp_duvenaud_update_bwd_a, athena_mp_duvenaud_update_bwd_w, athena_mp_duvenaud_update_bwd
+  public :: athena_mp_duvenaud_update_bwd_split
   public :: athena_mp_duvenaud_update_readout_fwd
   public :: athena_mp_segment_sum, athena_mp_segment_sum_bwd
   public :: athena_mp_gno_aggregate_fwd, athena_mp_gno_aggregate_bwd_x, athena_mp_gno_aggregate_bwd_theta
@@ -692,6 +693,13 @@ module athena_mp_c
        import :: c_int, c_int32_t, c_ptr
        type(c_ptr), value :: graph, grad_dev, a_dev, weight_dev, da_dev, dweight_dev
        integer(c_int32_t), value :: Fi, Fo, min_deg, max_deg
+     end function
+     !! the same with da split where it is written: da_x (Fv, n) and da_e (Fe, n) instead of (Fv + Fe, n)
+     integer(c_int) function athena_mp_duvenaud_update_bwd_split(graph, Fv, Fe, Fo, min_deg, max_deg, grad_dev, a_dev, weight_dev, &
+          da_x_dev, da_e_dev, dweight_dev) bind(C, name="athena_mp_duvenaud_update_bwd_split")
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: graph, grad_dev, a_dev, weight_dev, da_x_dev, da_e_dev, dweight_dev
+       integer(c_int32_t), value :: Fv, Fe, Fo, min_deg, max_deg
      end function
      integer(c_int) function athena_mp_segment_sum(O, N, S, seg_dev, p_dev, out_dev, accumulate) &
           bind(C, name="athena_mp_segment_sum")

@@ -1085,9 +1085,9 @@ contains
     class(duvenaud_mp_layer_type), intent(inout) :: this
     type(c_ptr), intent(in) :: upstream_dev
     type(c_ptr), intent(out), optional :: dx_dev, de_dev
-    type(c_ptr) :: gout, dzn, dzn_arg, dc, da, dl, tmp
-    integer :: t, tt, n, o, fe, fv, fo, fin, fmax
-    logical :: have_next, fused_msg, first_de, softmax_readout
+    type(c_ptr) :: gout, dzn, dzn_arg, dc, da, da_e, dl, tmp
+    integer :: t, tt, n, o, fe, fv, fo, fin, fmax, fv_e, fe_x
+    logical :: have_next, fused_msg, first_de, softmax_readout, split
     integer(c_int32_t) :: code, code_arg
 
     n = this%nv
@@ -1150,23 +1150,38 @@ contains
                this%grads(t)%p), "duvenaud_update reverse (weights)")
           exit
        end if
-       ! both reverse products of the update from one pass over dc
-       call chk(athena_mp_duvenaud_update_bwd(this%graph, int(fin, c_int32_t), int(fo, c_int32_t), &
-            int(this%min_vertex_degree, c_int32_t), int(this%max_vertex_degree, c_int32_t), dc, this%tape_a(t)%p, &
-            this%params(t)%p, da, this%grads(t)%p), "duvenaud_update reverse")
+       ! both reverse products of the update from one pass over dc.  At F_v = 64 with edge features da is written SPLIT where
+       ! it is produced -- da_x (n, 64) in `da`, da_e (n, fe) behind it -- so that the two propagate partials gather whole cache
+       ! lines (bit-identical dx / de; profiles/r05_c3_split_da_ab.txt)
+       split = fv .eq. 64 .and. fe .gt. 0
+       if(split)then
+          da_e = athena_mp_dev_offset(da, i8(n) * i8(fv))
+          call chk(athena_mp_duvenaud_update_bwd_split(this%graph, int(fv, c_int32_t), int(fe, c_int32_t), int(fo, c_int32_t), &
+               int(this%min_vertex_degree, c_int32_t), int(this%max_vertex_degree, c_int32_t), dc, this%tape_a(t)%p, &
+               this%params(t)%p, da, da_e, this%grads(t)%p), "duvenaud_update reverse (split)")
+          fv_e = 0
+          fe_x = 0
+       else
+          da_e = da
+          call chk(athena_mp_duvenaud_update_bwd(this%graph, int(fin, c_int32_t), int(fo, c_int32_t), &
+               int(this%min_vertex_degree, c_int32_t), int(this%max_vertex_degree, c_int32_t), dc, this%tape_a(t)%p, &
+               this%params(t)%p, da, this%grads(t)%p), "duvenaud_update reverse")
+          fv_e = fv
+          fe_x = fe
+       end if
        if(present(de_dev) .and. this%ne .gt. 0)then
           if(first_de)then
-             call chk(athena_mp_duvenaud_propagate_bwd_e(this%graph, int(fv, c_int32_t), int(fe, c_int32_t), da, &
+             call chk(athena_mp_duvenaud_propagate_bwd_e(this%graph, int(fv_e, c_int32_t), int(fe, c_int32_t), da_e, &
                   this%de_acc%p), "duvenaud_propagate reverse (edges)")
              first_de = .false.
           else
-             call chk(athena_mp_duvenaud_propagate_bwd_e(this%graph, int(fv, c_int32_t), int(fe, c_int32_t), da, &
+             call chk(athena_mp_duvenaud_propagate_bwd_e(this%graph, int(fv_e, c_int32_t), int(fe, c_int32_t), da_e, &
                   this%scratch(1)%p), "duvenaud_propagate reverse (edges)")
              call chk(athena_mp_axpy(i8(this%ne) * i8(fe), 1._real32, this%scratch(1)%p, this%de_acc%p), "axpy")
           end if
        end if
        if(t .gt. 1 .or. present(dx_dev))then
-          call chk(athena_mp_duvenaud_propagate_bwd_x(this%graph, int(fv, c_int32_t), int(fe, c_int32_t), da, dzn), &
+          call chk(athena_mp_duvenaud_propagate_bwd_x(this%graph, int(fv, c_int32_t), int(fe_x, c_int32_t), da, dzn), &
                "duvenaud_propagate reverse (vertices)")
           have_next = .true.
        end if

@@ -451,14 +451,23 @@ class duvenaud_msgpass_layer_type(msgpass_layer_type):
                 self.grads[t - 1] = ops.duvenaud_update_bwd_w(g, dc, self._a[t - 1], self.min_vertex_degree, self.max_vertex_degree)
                 break
             # both reverse products of the update from one pass over dc (one launch where the fused kernel covers the widths)
-            da, self.grads[t - 1] = ops.duvenaud_update_bwd(g, dc, self._a[t - 1], self.params[t - 1], self.min_vertex_degree,
-                                                            self.max_vertex_degree)
             Fv = self.num_vertex_features[t - 1]
+            if Fv == 64 and self.num_edge_features[0] > 0:
+                # da split where it is written (256-byte vertex rows + a dense edge part): the two propagate partials then
+                # gather whole cache lines -- bit-identical dx / de (profiles/r05_c3_split_da_ab.txt)
+                da_x, da_e, self.grads[t - 1] = ops.duvenaud_update_bwd_split(g, dc, self._a[t - 1], self.params[t - 1],
+                                                                              self.min_vertex_degree, self.max_vertex_degree, Fv)
+                fv_e = 0
+            else:
+                da, self.grads[t - 1] = ops.duvenaud_update_bwd(g, dc, self._a[t - 1], self.params[t - 1], self.min_vertex_degree,
+                                                                self.max_vertex_degree)
+                da_x = da_e = da
+                fv_e = Fv
             if need_edge_grad:
-                d = ops.duvenaud_propagate_bwd_e(g, da, Fv)
+                d = ops.duvenaud_propagate_bwd_e(g, da_e, fv_e)
                 de = d if de is None else ops.axpy(1.0, d, de)
             if t > 1 or need_input_grad:
-                dz_next = ops.duvenaud_propagate_bwd_x(g, da, Fv)
+                dz_next = ops.duvenaud_propagate_bwd_x(g, da_x, Fv)
             if t == 1:
                 dx = dz_next
         return (dx, de) if need_edge_grad else dx

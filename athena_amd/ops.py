@@ -490,6 +490,26 @@ def duvenaud_update_bwd(g: DeviceGraph, grad, a, weight, min_deg, max_deg):
     return da, dW
 
 
+def duvenaud_update_bwd_split(g: DeviceGraph, grad, a, weight, min_deg, max_deg, Fv):
+    """(da_x [n, Fv], da_e [n, Fe], dW): duvenaud_update_bwd with da written split where it is produced
+    (athena_mp_duvenaud_update_bwd_split); duvenaud_propagate_bwd_x(g, da_x, Fv) and duvenaud_propagate_bwd_e(g, da_e, 0)
+    take the halves -- same sums in the same order as from the packed da"""
+    Fo, Fi = grad.shape[1], a.shape[1]
+    Fe = Fi - Fv
+    if not (0 < Fv < Fi):
+        raise ValueError("duvenaud_update_bwd_split: needs vertex AND edge columns")
+    _chk(grad, (g.n_rows, Fo)); _chk(a, (g.n_rows, Fi))
+    if not (weight.numel() == Fo * Fi * (max_deg - min_deg + 1)):
+        raise ValueError('expected: weight.numel() == Fo * Fi * (max_deg - min_deg + 1)')
+    da_x = torch.empty((g.n_rows, Fv), device=grad.device, dtype=torch.float32)
+    da_e = torch.empty((g.n_rows, Fe), device=grad.device, dtype=torch.float32)
+    dW = torch.empty(Fo * Fi * (max_deg - min_deg + 1), device=grad.device, dtype=torch.float32)
+    _go()
+    _capi.call("athena_mp_duvenaud_update_bwd_split", g.handle, Fv, Fe, Fo, min_deg, max_deg, _p(grad), _p(a), _p(_chk(weight)), _p(da_x),
+               _p(da_e), _p(dW))
+    return da_x, da_e, dW
+
+
 def softmax_segsum(logits, seg, out=None):
     """p = softmax over outputs per vertex; out[s] (+)= sum of p over graph s.  Returns (p, out)."""
     N, O = logits.shape

@@ -221,7 +221,8 @@ int athena_mp_device_copy(void *dst_dev, const void *src_dev, uint64_t bytes);
  *   c[v,:] = sum_w [ x[u,:] ; e[ja(2,w),:] ]     c [n_rows, Fv+Fe]; edge id 0 => zero vector */
 int athena_mp_duvenaud_propagate_fwd(const athena_mp_graph *g, int32_t Fv, int32_t Fe,
                                      const float *x_dev, const float *e_dev, float *c_dev);
-/* get_partial_duvenaud_propagate_left_val :115-141 / _right_val :143-171 */
+/* get_partial_duvenaud_propagate_left_val :115-141 / _right_val :143-171.  grad is [n_rows, Fv + Fe]; _bwd_x with Fe = 0 takes
+ * the vertex part alone [n_rows, Fv], _bwd_e with Fv = 0 the edge part alone [n_rows, Fe] (athena_mp_duvenaud_update_bwd_split) */
 int athena_mp_duvenaud_propagate_bwd_x(const athena_mp_graph *g, int32_t Fv, int32_t Fe,
                                        const float *grad_dev, float *dx_dev);
 int athena_mp_duvenaud_propagate_bwd_e(const athena_mp_graph *g, int32_t Fv, int32_t Fe,
@@ -254,6 +255,15 @@ int athena_mp_duvenaud_update_readout_fwd(const athena_mp_graph *g, int32_t Fi, 
 int athena_mp_duvenaud_update_bwd(const athena_mp_graph *g, int32_t Fi, int32_t Fo, int32_t min_deg, int32_t max_deg,
                                   const float *grad_dev, const float *a_dev, const float *weight_dev, float *da_dev,
                                   float *dweight_dev);
+/* the same pair with da SPLIT where it is written: da_x [n_rows, Fv] and da_e [n_rows, Fe] instead of [n_rows, Fv + Fe].  The
+ * reverse kernel visits the vertices in bucket order; rows of 288 bytes (64 + 8 floats) written in that order are partial
+ * cache lines, and the propagate reverse that follows gathers its edge part as 32-byte slivers of them.  Split, the vertex
+ * part is 256-byte rows and the edge part a dense array: athena_mp_duvenaud_propagate_bwd_x(g, Fv, 0, da_x, dx) and
+ * athena_mp_duvenaud_propagate_bwd_e(g, 0, Fe, da_e, de) take the two halves (same sums, same order: bit-identical dx / de).
+ * One launch at F_v = 64 and the fused kernel's widths (BASELINE configs[2]); other shapes go through the packed form. */
+int athena_mp_duvenaud_update_bwd_split(const athena_mp_graph *g, int32_t Fv, int32_t Fe, int32_t Fo, int32_t min_deg,
+                                        int32_t max_deg, const float *grad_dev, const float *a_dev, const float *weight_dev,
+                                        float *da_x_dev, float *da_e_dev, float *dweight_dev);
 /* readout, athena_duvenaud_msgpass_layer.f90:838-855 over a block-diagonal batch:
  *   p[v,:] = softmax_over_outputs(logits[v,:]); out[s,:] (+)= sum_{v in seg s} p[v,:]
  *   seg_dev [S+1] 0-based vertex offsets of the graphs */

@@ -50,6 +50,20 @@ def rel(a, b):
     return float(np.abs(np.asarray(a, np.float64) - b).max() / max(np.abs(b).max(), 1e-30))
 
 
+def ew_worst(a, b, scale):
+    """max over elements of |a - b| / scale, scale = the sum of the magnitudes of each element's own terms (oracle on |operands|)"""
+    a, b, scale = (np.asarray(t, np.float64) for t in (a, b, scale))
+    return float((np.abs(a - b) / np.maximum(scale, 1e-30)).max()) if a.size else 0.0
+
+
+def gno_kappa_magnitude(o, coords, th, d, H, F):
+    """sum_k |V[f,k]| h_k + |b_v[f]| per edge column: the kernel MLP with |V|, |b_v| (its hidden h = relu(U dx + b_u) >= 0 as is)"""
+    t2 = np.array(th, np.float32, copy=True)
+    offV = H * d + H
+    t2[offV:] = np.abs(t2[offV:])
+    return o.gno_kernel_eval(coords, t2, H, F)
+
+
 def hbm_op(ms, nbytes, note=None):
     gbs = nbytes / (ms * 1e-3) / 1e9
     out = {"ms": round(ms, 4), "bound": "hbm", "GBps": round(gbs, 1), "frac": round(gbs / HBM, 3), "bytes": int(nbytes)}
@@ -121,7 +135,13 @@ def run_c3(dev, reps):
            "z_rel": rel(z[:nv].cpu().numpy(), z_h), "readout_rel": rel(out[:NG].cpu().numpy(), out_h),
            "dc_rel": rel(dc[:nv].cpu().numpy(), dc_h), "da_rel": rel(da[:nv].cpu().numpy(), da_h),
            "dx_rel": rel(dx[:nv].cpu().numpy(), dx_h), "de_rel": rel(de[torch.from_numpy(eids).to(dev)].cpu().numpy(), de_h[eids]), "tol": TOL}
-    par["ok"] = bool(par["propagate_bit_exact"] and all(par[k] <= TOL for k in ("z_rel", "readout_rel", "dc_rel", "da_rel", "dx_rel", "de_rel")))
+    # element-wise against the magnitude of each element's own terms: the update c = W_d (a / d) behind the
+    # sigmoid (|dz| <= |dc| / 4) and its reverse da = (dc W_d) / d
+    mag_c = o.duvenaud_update(np.abs(a_h), np.abs(Wh), ias, mn, mx, Fv)
+    par["z_elementwise_worst"] = ew_worst(z[:nv].cpu().numpy(), z_h, 0.25 * mag_c + np.abs(z_h))
+    par["da_elementwise_worst"] = ew_worst(da[:nv].cpu().numpy(), da_h, o.duvenaud_update_bwd_a(np.abs(dc_h), np.abs(Wh), ias, mn, mx, Fc))
+    par["ok"] = bool(par["propagate_bit_exact"] and all(par[k] <= TOL for k in ("z_rel", "readout_rel", "dc_rel", "da_rel", "dx_rel", "de_rel",
+                                                                                 "z_elementwise_worst", "da_elementwise_worst")))
     step = sum(t.values())
     # the CPU path beside it: the same ops, same order, the oracle on one thread, first 20 000 graphs
     NC = 20000
@@ -325,6 +345,9 @@ def run_c4(dev, reps):
     m_ref = o.gno_aggregate(xs, kap, sia_sq, sja, Fo)[:rows.size]
     par = {"against": "materialising oracle on 300 sampled rows (m) and 300 sampled columns (dx); dtheta: adjoint identity",
            "m_rel": rel(m[torch.from_numpy(rows).to(dev)].cpu().numpy(), m_ref), "tol": TOL}
+    kmag = gno_kappa_magnitude(o, coords[ecols - 1], th, d, H, Fo * Fi)
+    par["m_elementwise_worst"] = ew_worst(m[torch.from_numpy(rows).to(dev)].cpu().numpy(), m_ref,
+                                          o.gno_aggregate(np.abs(xs), kmag, sia_sq, sja, Fo)[:rows.size])
     dx, dth, _, fused = ops.gno_aggregate_bwd(g, theta, co, x, gup, d, H, s_save=keep[0])      # what the layer's reverse pass calls
     csel = np.sort(rng.choice(N, 300, replace=False))
     lut = np.full(N, -1, np.int64); lut[csel] = np.arange(csel.size)
@@ -342,6 +365,9 @@ def run_c4(dev, reps):
     g_sq = np.zeros((nsq, Fo), np.float32); g_sq[:src.size] = gup[torch.from_numpy(src).to(dev)].cpu().numpy()
     dx_ref = o.gno_aggregate_bwd_x(g_sq, kap_c, cia_sq, cja, Fi)[:csel.size]
     par["dx_rel"] = rel(dx[torch.from_numpy(csel).to(dev)].cpu().numpy(), dx_ref)
+    par["dx_elementwise_worst"] = ew_worst(dx[torch.from_numpy(csel).to(dev)].cpu().numpy(), dx_ref,
+                                           o.gno_aggregate_bwd_x(np.abs(g_sq), gno_kappa_magnitude(o, coords[ecols_c - 1], th, d, H, Fo * Fi),
+                                                                 cia_sq, cja, Fi)[:csel.size])
     par["reverse_pass"] = "athena_mp_gno_aggregate_bwd: dx and dtheta from one G" if fused else "separate entry points"
     dx_sep = ops.gno_aggregate_bwd_x(g, theta, co, gup, d, H, Fi)
     par["dx_fused_vs_separate_rel"] = float((dx - dx_sep).abs().max().item() / dx_sep.abs().max().item())
@@ -351,6 +377,7 @@ def run_c4(dev, reps):
     scale = (m.double().abs() * gup.double().abs()).sum().item()
     par["dtheta_adjoint_rel"] = abs(lhs - (theta[offV:].double() * dth[offV:].double()).sum().item()) / scale
     par["ok"] = bool(par["m_rel"] <= TOL and par["dx_rel"] <= TOL and par["dx_fused_vs_separate_rel"] <= TOL
+                     and par["m_elementwise_worst"] <= TOL and par["dx_elementwise_worst"] <= TOL
                      and par["dtheta_adjoint_rel"] <= TOL and torch.isfinite(dth).all().item())
     step = t["fwd_keeps_S"] + t["bwd_x+theta_one_contraction"]
     step_sep = t["fwd_keeps_S"] + t["bwd_x"] + t["bwd_theta_S_kept"]
@@ -414,11 +441,18 @@ def run_c5(dev, reps):
     ones = np.ones(max(rows.size, cols.size), np.int32)
     dx_ref = o.kipf_propagate_rect(o.matmul_dx(w_h, dzc, F), sia, sja, ones[:rows.size], ones[:cols.size])
     par["dX_rel"] = rel(dX[rsel].cpu().numpy(), dx_ref)
+    # element-wise against the magnitude of each element's own terms (|P| |Wt|; the pull of |dZ| |W|)
+    wt_abs = np.abs(w_h.astype(np.float64)).reshape(F, F)
+    par["Z_elementwise_worst"] = ew_worst(Z[rsel].cpu().numpy(), o.matmul(w_h, p_ref, F), np.abs(p_ref.astype(np.float64)) @ wt_abs)
+    dp_mag = (np.abs(dzc.astype(np.float64)) @ wt_abs.T).astype(np.float32)
+    par["dX_elementwise_worst"] = ew_worst(dX[rsel].cpu().numpy(), dx_ref,
+                                           o.kipf_propagate_rect(dp_mag, sia, sja, ones[:rows.size], ones[:cols.size]))
     d64 = torch.zeros((F, F), device=dev, dtype=torch.float64)
     for r0 in range(0, N, 1 << 20):
         d64 += P[r0:r0 + (1 << 20)].double().T @ dz[r0:r0 + (1 << 20)].double()
     par["dW_rel_vs_float64"] = float((dW.double() - d64.reshape(-1)).abs().max().item() / d64.abs().max().item())
-    par["ok"] = bool(par["P_bit_exact"] and max(par["Z_rel"], par["dX_rel"], par["dW_rel_vs_float64"]) <= TOL)
+    par["ok"] = bool(par["P_bit_exact"] and max(par["Z_rel"], par["dX_rel"], par["dW_rel_vs_float64"], par["Z_elementwise_worst"],
+                                                par["dX_elementwise_worst"]) <= TOL)
     step = sum(t.values())
     return {"config": "configs[4] on one GPU", "workload": f"Kipf GCN layer fwd+bwd, random graph {N} vertices / {nnz} entries, {F} features, fp32, ONE GPU "
             "(the 8-way partition is the driver's multi-GPU run)", "step_ms": round(step, 3), "entries_per_s": nnz / step * 1e3, "ops": opsd, "parity": par}

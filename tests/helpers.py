@@ -88,3 +88,11 @@ def assert_close_elementwise(a, b, scale, rtol=1e-5, what=""):
     a, b, scale = (np.asarray(t, np.float64) for t in (a, b, scale))
     bad = np.abs(a - b) > rtol * scale + 1e-30
     assert not bad.any(), f"{what}: {int(bad.sum())} element(s) beyond {rtol} of their term magnitudes; worst {float((np.abs(a - b) / np.maximum(scale, 1e-30)).max()):.3e}"
+
+
+def elementwise_worst(a, b, scale):
+    """max over the elements of |a - b| / scale, scale = the sum of the MAGNITUDES of each element's terms (the oracle run on
+    |operands|): the strongest element-wise statement fp32 sums allow -- an element whose terms cancel is held to the size of
+    what was added, not to its tiny value, and no element hides behind the tensor's maximum"""
+    a, b, scale = (np.asarray(t, np.float64) for t in (a, b, scale))
+    return float((np.abs(a - b) / np.maximum(scale, 1e-30)).max()) if a.size else 0.0

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import assert_close
+from helpers import assert_close, assert_close_elementwise
 
 pytestmark = pytest.mark.gpu
 
@@ -154,6 +154,10 @@ def test_c2_fused_layer_kernels_match_oracle_at_full_size(dev, oracle, c2, F):
     assert np.array_equal(P[rsel].cpu().numpy(), p_ref), "fused forward: P differs from the oracle"
     z_ref = oracle.matmul(w_h, p_ref, F)
     assert np.abs(Z[rsel].cpu().numpy() - z_ref).max() <= 1e-5 * np.abs(z_ref).max()
+    # ... and ELEMENT by element against the magnitude of each element's own terms, |P| |Wt| (a wrong small element of Z cannot
+    # hide behind the tensor's maximum)
+    wt_abs = np.abs(w_h.astype(np.float64)).reshape(F, F)
+    assert_close_elementwise(Z[rsel].cpu().numpy(), z_ref, np.abs(p_ref.astype(np.float64)) @ wt_abs, 1e-5, f"Z at F = {F}")
     # the unfused entry point writes the same P everywhere, so the sampled check extends to all rows
     assert torch.equal(P, ops.kipf_propagate(g, x))
     # with bias + relu in the epilogue
@@ -169,6 +173,8 @@ def test_c2_fused_layer_kernels_match_oracle_at_full_size(dev, oracle, c2, F):
     dx_ref = oracle.kipf_propagate_bwd(dp, cia, cja, n_out=cols.size)
     got = dX[torch.from_numpy(cols).to(dev)].cpu().numpy()
     assert np.abs(got - dx_ref).max() <= 1e-5 * np.abs(dx_ref).max()
+    dp_mag = (np.abs(dz_h[src].astype(np.float64)) @ wt_abs.T).astype(np.float32)          # |dZ| |W|, then the same scatter
+    assert_close_elementwise(got, dx_ref, oracle.kipf_propagate_bwd(dp_mag, cia, cja, n_out=cols.size), 1e-5, f"dX at F = {F}")
     # deterministic (persistent ticket-scheduled kernels: the chunk -> workgroup map changes run to run)
     P2, Z2 = ops.kipf_layer_fwd(g, x, w, F)
     assert torch.equal(P, P2) and torch.equal(Z, Z2) and torch.equal(dX, ops.kipf_layer_bwd_x(g, dz, w, F))
@@ -226,6 +232,8 @@ def test_c3_duvenaud_step_properties(dev, oracle, c3):
     c = ops.duvenaud_update(g, a, W, mn, mx, Fv)
     c_ref = oracle.duvenaud_update(a_ref, W.cpu().numpy(), ia_s, mn, mx, Fv)
     assert np.abs(c[:nv].cpu().numpy() - c_ref).max() <= 1e-5 * np.abs(c_ref).max()
+    assert_close_elementwise(c[:nv].cpu().numpy(), c_ref, oracle.duvenaud_update(np.abs(a_ref), np.abs(W.cpu().numpy()), ia_s, mn, mx, Fv),
+                             1e-5, "configs[2] update, element by element")
     # adjoints of the bilinear update: <c, g> = <a, da> = <W, dW>
     gup = torch.from_numpy(rng.uniform(-1, 1, (N, Fv)).astype(np.float32)).to(dev)
     da = ops.duvenaud_update_bwd_a(g, gup, W, mn, mx, Fv + Fe)
@@ -272,6 +280,8 @@ def test_c3_duvenaud_reverse_ops_match_oracle_at_full_size(dev, oracle, c3):
     g_s = gup[:nv].cpu().numpy()
     da_ref = oracle.duvenaud_update_bwd_a(g_s, W_h, ia_s, mn, mx, Fc)
     assert np.abs(da[:nv].cpu().numpy() - da_ref).max() <= 1e-5 * np.abs(da_ref).max()
+    da_mag = oracle.duvenaud_update_bwd_a(np.abs(g_s), np.abs(W_h), ia_s, mn, mx, Fc)
+    assert_close_elementwise(da[:nv].cpu().numpy(), da_ref, da_mag, 1e-5, "configs[2] da, element by element")
     # propagate reverse: scatters inside each graph -> rows / edge columns of the first 3 000 graphs
     dx = ops.duvenaud_propagate_bwd_x(g, g2, Fv)
     de = ops.duvenaud_propagate_bwd_e(g, g2, Fv)
@@ -284,6 +294,7 @@ def test_c3_duvenaud_reverse_ops_match_oracle_at_full_size(dev, oracle, c3):
     a_chk = torch.from_numpy(rng.random((N, Fc), np.float32)).to(dev)
     da_f, dW_f = ops.duvenaud_update_bwd(g, gup, a_chk, W, mn, mx)
     assert np.abs(da_f[:nv].cpu().numpy() - da_ref).max() <= 1e-5 * np.abs(da_ref).max()
+    assert_close_elementwise(da_f[:nv].cpu().numpy(), da_ref, da_mag, 1e-5, "configs[2] da (fused reverse), element by element")
     dW_sep = ops.duvenaud_update_bwd_w(g, gup, a_chk, mn, mx)
     assert (dW_f - dW_sep).abs().max().item() <= 1e-5 * dW_sep.abs().max().item()
     del a_chk, da_f
@@ -348,6 +359,13 @@ def test_c4_gno_properties_full_size(dev, oracle):
     nsq_rows = nsq                                                   # (the column sub-problem below re-uses the name)
     got = m[torch.from_numpy(rows).to(dev)].cpu().numpy()
     assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
+    # element by element against the magnitude of each element's own terms: sum over the row's entries of |K_e| |x_j| with
+    # |K_e| <= |V| h_e + |b_v| (the kernel MLP evaluated with |V|, |b_v|; its hidden h = relu(.) >= 0 as it is)
+    th_mag = theta.cpu().numpy().copy()
+    th_mag[H * d + H:] = np.abs(th_mag[H * d + H:])
+    kap_mag = oracle.gno_kernel_eval(coords[ecols - 1], th_mag, H, Fo * Fi)
+    assert_close_elementwise(got, ref, oracle.gno_aggregate(np.abs(xs_sq), kap_mag, sia_sq, sja, Fo)[: rows.size], 1e-5,
+                             "configs[3] m, element by element")
     # linear in x; adjoint <m, g> = <x, dx>; linear in Vaug: <m, g> = <Vaug, dVaug>
     assert torch.allclose(ops.gno_aggregate(g, theta, co, 2.0 * x, d, H, Fo), 2.0 * m, rtol=1e-5, atol=1e-5 * m.abs().max().item())
     dx = ops.gno_aggregate_bwd_x(g, theta, co, gup, d, H, Fi)
@@ -368,6 +386,9 @@ def test_c4_gno_properties_full_size(dev, oracle):
     dx_ref = oracle.gno_aggregate_bwd_x(g_sq, kap_c, cia_sq, cja, Fi)[: csel.size]
     got_dx = dx[torch.from_numpy(csel).to(dev)].cpu().numpy()
     assert np.abs(got_dx - dx_ref).max() <= 1e-5 * np.abs(dx_ref).max()
+    kap_c_mag = oracle.gno_kernel_eval(coords[ecols_c - 1], th_mag, H, Fo * Fi)
+    assert_close_elementwise(got_dx, dx_ref, oracle.gno_aggregate_bwd_x(np.abs(g_sq), kap_c_mag, cia_sq, cja, Fi)[: csel.size], 1e-5,
+                             "configs[3] dx, element by element")
     lhs = (m.double() * gup.double()).sum().item()
     scale = (m.double().abs() * gup.double().abs()).sum().item()
     assert abs(lhs - (x.double() * dx.double()).sum().item()) <= 1e-5 * scale

@@ -1104,3 +1104,27 @@ def test_gno_reverse_pass_falls_back_outside_the_fused_shapes(dev, oracle):
         assert torch.equal(dx, ops.gno_aggregate_bwd_x(dg, th, co, gd, d, H, Fi))
         assert torch.equal(dth, ops.gno_aggregate_bwd_theta(dg, th, co, xd, gd, d, H))
         assert torch.equal(dc, ops.gno_aggregate_bwd_coords(dg, th, co, xd, gd, d, H))
+
+
+@pytest.mark.parametrize("Fv,Fe,Fo", [(64, 8, 64), (64, 16, 80), (32, 4, 48), (64, 8, 24), (6, 1, 7)])
+def test_duvenaud_update_bwd_split_matches_the_packed_form(dev, oracle, Fv, Fe, Fo):
+    """athena_mp_duvenaud_update_bwd_split: da written as da_x [n, Fv] + da_e [n, Fe] where it is produced (one launch at
+    F_v = 64 and the fused kernel's widths, the packed form + two strided copies elsewhere) -- the same bits as the packed da,
+    and the two propagate partials taken from the halves equal those taken from the packed rows"""
+    from athena_amd import DeviceGraph, ops, synth
+
+    rng = np.random.default_rng(Fv + Fe + Fo)
+    ia, ja, voff, E = synth.molecule_batch(300, seed=11)
+    N = ia.size - 1
+    g = DeviceGraph(ia, ja, n_edge_cols=E)
+    mn, mx = 1, 10
+    T = lambda a: torch.from_numpy(a).to(dev)
+    a = T(rng.uniform(-1, 1, (N, Fv + Fe)).astype(np.float32))
+    W = T((0.3 * rng.standard_normal(Fo * (Fv + Fe) * (mx - mn + 1))).astype(np.float32))
+    gup = T(rng.uniform(-1, 1, (N, Fo)).astype(np.float32))
+    da, dW = ops.duvenaud_update_bwd(g, gup, a, W, mn, mx)
+    da_x, da_e, dW2 = ops.duvenaud_update_bwd_split(g, gup, a, W, mn, mx, Fv)
+    assert torch.equal(da_x, da[:, :Fv]) and torch.equal(da_e, da[:, Fv:]) and torch.equal(dW2, dW)
+    assert_close(da_x.cpu().numpy(), oracle.duvenaud_update_bwd_a(gup.cpu().numpy(), W.cpu().numpy(), ia, mn, mx, Fv + Fe)[:, :Fv], 1e-5)
+    assert torch.equal(ops.duvenaud_propagate_bwd_x(g, da_x, Fv), ops.duvenaud_propagate_bwd_x(g, da, Fv))
+    assert torch.equal(ops.duvenaud_propagate_bwd_e(g, da_e, 0), ops.duvenaud_propagate_bwd_e(g, da, Fv))
