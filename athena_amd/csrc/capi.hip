@@ -448,7 +448,7 @@ struct KeyHash {   // MurmurHash3's 64-bit lane: multiply-rotate per 8-byte word
 
 /* Chunked, lane-parallel form of the hash for large arrays: the array is cut into fixed chunks of kKeyChunk int32
  * values, every chunk is hashed by four interleaved lanes (four independent multiply chains per core instead of one),
- * chunks are handed to up to ATHENA_MP_GRAPH_KEY_THREADS host threads (default 8) and the chunk digests are folded in
+ * chunks are handed to up to 8 host threads (fewer when the process's affinity mask holds fewer cores) and the chunk digests are folded in
  * chunk order -- the key does not depend on the thread count.  EVERY word of adj_ia / adj_ja enters the key. */
 namespace {
 constexpr int64_t kKeyChunk = (int64_t)1 << 20;
@@ -476,9 +476,8 @@ void key_array(KeyHash &h, const int32_t *p, int64_t count)
     const int64_t n_chunks = (count + kKeyChunk - 1) / kKeyChunk;
     std::vector<uint64_t> dig((size_t)n_chunks);
     static const int max_threads = [] {
-        const char *e = getenv("ATHENA_MP_GRAPH_KEY_THREADS");
-        int t = e ? atoi(e) : 8;
-        const int hw = (int)std::thread::hardware_concurrency();
+        int t = 8;
+        const int hw = (int)std::thread::hardware_concurrency();   // the cores this process may run on (honours its affinity mask)
         if (hw > 0) t = std::min(t, hw);
         return std::max(1, t);
     }();

@@ -745,7 +745,7 @@ int athena_mp_comm_create(int32_t rank, int32_t world, const void *id128, athena
  *               `path` carries that nonce in slot r; a `path` without it -- a stale one -- is ignored.
  *   rank 0      removes any stale `path`, waits until it has seen every hello file CHANGE (a stale hello never does),
  *               then publishes id + the nonces it read (write + rename).  It removes `path` after every rank has joined.
- * Every wait is bounded (ATHENA_MP_BOOTSTRAP_TIMEOUT_S, default 300 s). */
+ * Every wait is bounded (ATHENA_MP_COLLECTIVE_TIMEOUT_S when set, 300 s otherwise). */
 namespace {
 double boot_now()
 {
@@ -755,7 +755,9 @@ double boot_now()
 }
 double boot_timeout()
 {
-    const char *e = getenv("ATHENA_MP_BOOTSTRAP_TIMEOUT_S");
+    // the deadline of every other wait for a peer, when the caller set one; 300 s otherwise (ranks of a job start seconds apart,
+    // not the half hour the library allows a running collective by default)
+    const char *e = getenv("ATHENA_MP_COLLECTIVE_TIMEOUT_S");
     const double t = e ? atof(e) : 300.0;
     return t > 0 ? t : 300.0;
 }

@@ -41,17 +41,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // 32-row chunks, one row pair per wave; the first kFirst row loads of the NEXT chunk are issued before
 // the matrix work of the CURRENT chunk and consumed after it.
-#ifndef FUSED_STAGGER
 #define FUSED_STAGGER 0   // measured at configs[1]: 0.936 / 0.884 ms with, 0.930 / 0.890 ms without (forward / reverse): no gain here
-#endif
-#ifndef KFIRST
 #define KFIRST 16
-#endif
 constexpr int kFirst = KFIRST;
 
-#ifndef KIPF_NT
 #define KIPF_NT 13   // bit mask, A/B in profiles/r04_kipf_nt_ab.txt: nontemporal stores of P (1), of Z (2; 4 = agg_gemm256_kernel's forward launch), nontemporal loads of agg_gemm_kernel's forward-launch entry ids + coefficients (8; the same in agg_gemm256_kernel measured slower, not in the tree)
-#endif
 template <int N, bool COEF, int ACT, bool BUF>
 __global__ __launch_bounds__(1024) void agg_gemm_kernel(const int32_t *__restrict__ rowptr,
                                                         const int32_t *__restrict__ idx,
@@ -330,9 +324,9 @@ template <int N, bool COEF, int ACT>
 int launch_fused(const int32_t *rowptr, const int32_t *idx, const float *coef, const float *x, const float *B,
                  int b_nk, const float *bias, float *P, float *Z, int64_t n_rows, int grid, int64_t x_rows)
 {
-    static const bool nobuf = getenv("ATHENA_MP_NO_BUFFER_LOADS") != nullptr;   // A/B switch for measurements
+    // buffer-descriptor addressing wherever the tensor is below 4 GB (A/B in DESIGN.md 3.1b-bis; the switch is gone)
     const int64_t bytes = x_rows * N * 4;
-    if (!nobuf && x_rows > 0 && bytes < ((int64_t)1 << 32) - 4096)
+    if (x_rows > 0 && bytes < ((int64_t)1 << 32) - 4096)
         return launch_fused_b<N, COEF, ACT, true>(rowptr, idx, coef, x, B, b_nk, bias, P, Z, n_rows, grid, (uint32_t)bytes);
     return launch_fused_b<N, COEF, ACT, false>(rowptr, idx, coef, x, B, b_nk, bias, P, Z, n_rows, grid, 0u);
 }
@@ -566,9 +560,8 @@ template <bool COEF, int ACT>
 int launch_fused256(const int32_t *rowptr, const int32_t *idx, const float *coef, const float *x, const float *B, int b_nk,
                     const float *bias, float *P, float *Z, int64_t n_rows, int grid, int64_t x_rows)
 {
-    static const bool nobuf = getenv("ATHENA_MP_NO_BUFFER_LOADS") != nullptr;   // A/B switch for measurements
     const int64_t bytes = x_rows * 1024;
-    const bool buf = !nobuf && x_rows > 0 && bytes < ((int64_t)1 << 32) - 4096;
+    const bool buf = x_rows > 0 && bytes < ((int64_t)1 << 32) - 4096;
     static int slot = 0;
     unsigned long long *ring = nullptr;
     if (amp::named_buffer("fused.ticket_ring", sizeof(unsigned long long) * 64, true, (void **)&ring)) return 1;

@@ -42,18 +42,12 @@ constexpr int kN = 128;          // features (square step)
 constexpr int kLD = kN + 4;      // pitch of W and of the Q tile (k-contiguous 16 B reads)
 constexpr int kLQ = kN + 16;     // pitch of the Qc tile (one word per lane: rows 4s + g4, columns 16 t + l15)
 constexpr int kCH = 32;          // rows per chunk
-#ifndef KFD
 #define KFD 8
-#endif
 constexpr int kFd = KFD;         // row loads per row issued ahead of the matrix work
 constexpr int kTd = 4;           // entries per row per round beyond them
 
-#ifndef DW_STAGGER
 #define DW_STAGGER 1
-#endif
-#ifndef DW_WAVES
 #define DW_WAVES 16
-#endif
 constexpr int kNW = DW_WAVES;                  // waves per workgroup: 16 (one row pair, one dX block, 4 dW tiles per wave;
                                                // 128 registers) or 8 (two pairs, two blocks, 8 tiles; 256 registers)
 constexpr int kPairs = 16 / kNW;               // row pairs a wave gathers per 32-row chunk

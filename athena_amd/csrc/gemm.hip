@@ -602,8 +602,7 @@ template <int K, int N, int ACT, bool BIAS>
 int launch_bres2(const float *A, const float *B, int b_nk, const float *bias, float *Z, int64_t M)
 {
     if constexpr (K >= 64 && N >= 64) {
-        static const bool four = getenv("ATHENA_MP_GEMM_4WAVE") != nullptr; // A/B switch
-        if (!four) return launch_bres8<K, N, ACT, BIAS>(A, B, b_nk, bias, Z, M);
+        return launch_bres8<K, N, ACT, BIAS>(A, B, b_nk, bias, Z, M);   // eight waves: 0.72 against 0.55 of fp32 MFMA peak with four
     }
     constexpr size_t lds = sizeof(float) * ((size_t)N * (K + 4) + 4 * 32 * ((K > N ? K : N) + 4));
     static amp::PerDeviceFlag attr_done;
@@ -699,8 +698,7 @@ int gemm_dw_dispatch(int64_t N, int Fi, int Fo, const float *P, const float *dZ,
     }
     bool mf = (Fi == 64 || Fi == 128) && (Fo == 64 || Fo == 128) && ((uintptr_t)P % 16 == 0) &&
               ((uintptr_t)dZ % 16 == 0);
-    static const bool no_blocks = getenv("ATHENA_MP_DW_NO_BLOCKS") != nullptr;   // A/B switch: the generic tiled kernel
-    if (!mf && !no_blocks && Fi % 128 == 0 && Fo % 128 == 0 && Fi <= 512 && Fo <= 512 && N >= 4096 &&
+    if (!mf && Fi % 128 == 0 && Fo % 128 == 0 && Fi <= 512 && Fo <= 512 && N >= 4096 &&
         (uintptr_t)P % 16 == 0 && (uintptr_t)dZ % 16 == 0) {
         // 128 x 128 blocks of dW on the register-resident kernel (BASELINE configs[4]: 256 x 256 = four blocks)
         const int nbi = Fi / 128, nbo = Fo / 128, nb = nbi * nbo;

@@ -207,21 +207,11 @@ typedef unsigned int v4u_g __attribute__((ext_vector_type(4)));
 // (scripts/gpu_keeps_ab.sh): plain 14.65 / 14.74, nt global 14.21 / 14.28, buffer nt 14.05 / 14.08, buffer sc0 sc1 nt 14.07 / 14.09,
 // buffer sc0 sc1 14.39 / 14.40, none 11.88 / 11.89 (= the kernel without the copy: the LDS reads of the copy cost nothing,
 // the 33 GB of writes make the launch HBM bound: 63 GB in 14.05 ms = 4.5 TB/s)
-#ifndef GNO_SAVE_MODE
 #define GNO_SAVE_MODE 2
-#endif
-#ifndef GNO_PX_NT_LOAD
 #define GNO_PX_NT_LOAD 1   // gno_px_gather_kernel reads the partials (15 GB, read once) with nontemporal loads: A/B in profiles/r04_c4_px_store_ab.txt
-#endif
-#ifndef GNO_PX_RB_AUX
 #define GNO_PX_RB_AUX 0   // cache bits of the read-back of the kh = 0 partial (2 = nt: A/B in profiles/r04_c4_px_one_array_ab.txt)
-#endif
-#ifndef GNO_PX_AUX
 #define GNO_PX_AUX 0   // cache bits of the per-entry partials' stores (1 sc0, 2 nt, 16 sc1): none -- A/B in profiles/r04_c4_px_one_array_ab.txt
-#endif
-#ifndef GNO_SAVE_AUX
 #define GNO_SAVE_AUX 2
-#endif
 #ifndef GNO_FV
 #define GNO_FV 0   // timing-only variants (scripts/build_variants.sh), bit mask: 1 no sparse loop, 2 no V loads, 4 no S reads, 8 no contraction, 16 no cross-wave reduction (gno_fused_kernel); 32 idle producers, 64 idle consumers, 8192 half the gathers (gno_pc_kernel)
 #endif
@@ -411,8 +401,7 @@ __global__ __launch_bounds__(1024) void gno_fused_kernel(const int32_t *__restri
 
 bool gno_fused_shape(int H, int Fy, int Fout, int d)
 {
-    static const bool off = getenv("ATHENA_MP_GNO_UNFUSED") != nullptr;   // A/B switch for measurements
-    return !off && H == kGH && Fy == kGF && Fout == kGF && d <= 4;
+    return H == kGH && Fy == kGF && Fout == kGF && d <= 4;
 }
 
 // vertices ordered by row length, longest first (stable counting sort on the host, once per graph and CSR).  The permutation
@@ -472,11 +461,10 @@ int launch_gno_pc(const int32_t *rowptr, const int32_t *idx, const int32_t *eidx
 // the producer / consumer kernels address their gathers through buffer descriptors (32-bit byte offsets, d <= 3)
 bool gno_pc_route(int d, int y_rows, int n_edge_cols, int64_t nnz)
 {
-    static const bool v1 = getenv("ATHENA_MP_GNO_FUSED_V1") != nullptr;   // A/B switch: the one-phase-at-a-time kernel
     const size_t y_bytes = sizeof(float) * kGF * (size_t)y_rows, c_bytes = sizeof(float) * (size_t)d * n_edge_cols,
                  id_bytes = sizeof(int32_t) * (size_t)nnz;
     const size_t lim = 0xFFFFE000ull;   // below the kernel's dead-slot offset
-    return d <= 3 && !v1 && y_bytes < lim && c_bytes < lim && id_bytes < lim;
+    return d <= 3 && y_bytes < lim && c_bytes < lim && id_bytes < lim;   // (17.2 ms one phase at a time against 11.9: DESIGN.md 3.5)
 }
 
 int launch_gno_fused(const int32_t *rowptr, const int32_t *idx, const int32_t *eidx, const float *y,
@@ -1336,8 +1324,7 @@ __global__ void gno_stg_reduce_kernel(const float *__restrict__ slab, const floa
 
 bool gno_stg_shape(int H, int Fi, int Fo, int d)
 {
-    static const bool off = getenv("ATHENA_MP_GNO_UNFUSED_STG") != nullptr;   // A/B switch: S through HBM
-    return !off && H == kGH && Fi == kGF && Fo == kGF && d <= 3;
+    return H == kGH && Fi == kGF && Fo == kGF && d <= 3;
 }
 
 int launch_gno_stg(const athena_mp_graph *g, const float *x, const float *coords, const float *theta, int d, const float *grad,
@@ -1361,11 +1348,7 @@ int launch_gno_stg(const athena_mp_graph *g, const float *x, const float *coords
         return 1;
     // 8 pieces x nsub tile classes: 32 classes fill the chip's 256 CUs; a small graph takes one class per tile
     const int nsub = std::max(1, std::min(kStgGrid / 8, (g->n_rows + kPV - 1) / kPV));
-    static const bool want_spread = [] {
-        const char *e = getenv("ATHENA_MP_GNO_STG_ORDER");
-        return e && strcmp(e, "spread") == 0;
-    }();
-    const int grouped = (!want_spread && nsub % 8 == 0) ? 1 : 0;   // the eight pieces of a tile class on one XCD (one L2)
+    const int grouped = nsub % 8 == 0 ? 1 : 0;   // the eight pieces of a tile class on one XCD (one L2): profiles/r03_c4_stg_order_ab.txt
     if (save)
         hipLaunchKernelGGL(gno_stg_kernel<true>, dim3(8 * nsub), dim3(kPcThreads), lds, amp::stream(), g->rowptr, g->col, g->eid, x,
                            coords, theta, d, grad, g->n_rows, (const int32_t *)g->len_perm_fwd, (float *)slab, (float *)slabB,
@@ -1863,16 +1846,13 @@ __global__ __launch_bounds__(1024) void gno_gdh_kernel(const int32_t *__restrict
 
 bool gno_gdh_shape(int H, int Fi, int Fo, int d)
 {
-    static const bool off = getenv("ATHENA_MP_GNO_UNFUSED_DH") != nullptr;   // A/B switch for measurements
-    return !off && H == kGH && Fi == kGF && Fo == kGF && d <= 3;
+    return H == kGH && Fi == kGF && Fo == kGF && d <= 3;
 }
 
 int tile_rows_for(int64_t n_rows, int64_t floats_per_row)
 {
-    static const int64_t budget = [] {   // bytes of S / T / G per super-tile
-        const char *e = getenv("ATHENA_MP_GNO_TILE_MB");
-        return (int64_t)(e ? atoi(e) : 1024) << 20;   // 1 GiB: two slots are in flight (bwd_theta pipeline); 43.8 ms at C4 against 44.4 at 2 GiB
-    }();
+    constexpr int64_t budget = (int64_t)1024 << 20;   // bytes of S / T / G per super-tile: 1 GiB, two slots in flight (bwd_theta pipeline);
+                                                      // 43.8 ms at C4 against 44.4 at 2 GiB
     int64_t t = budget / (4 * std::max<int64_t>(floats_per_row, 1));
     t = std::max<int64_t>(1, std::min<int64_t>(t, n_rows));
     return (int)t;
@@ -2076,9 +2056,7 @@ __global__ __launch_bounds__(kPcThreads) void gno_dh_pc_kernel(const int32_t *__
         auto c_off = [&](const GnoIds &I) { return (uint32_t)P.by_group(I.row) * (4u * kGF) + 16u * (uint32_t)n; };
         v4f_g cnext = z;
         // the kh = 0 partials of the kAhead vertices whose kh = 1 pieces come next (a ring: VPW is a multiple of kAhead)
-#ifndef GNO_PX_AHEAD
 #define GNO_PX_AHEAD 2
-#endif
         constexpr int kAhead = GNO_PX_AHEAD < VPW ? GNO_PX_AHEAD : VPW;
         static_assert(VPW % kAhead == 0, "the ring of read-back partials");
         v4f_g pprev[kAhead][NB];
@@ -2380,11 +2358,10 @@ int gno_mlp_backward(const athena_mp_graph *g, int d, int H, int Fi, int Fo, con
         // G is produced and consumed inside the workgroup.  Rows of at most 32 entries (all but a handful) go through the
         // dense / sparse kernel, the longer ones -- they head the length-ordered list -- through gno_gdh_kernel.
         if (length_order(g->rowptr, g->n_rows, &g->len_perm_fwd, &g->n_long_fwd, &g->n_mid_fwd)) return 1;
-        static const bool v1 = getenv("ATHENA_MP_GNO_GDH_V1") != nullptr;   // A/B switch: every row through gno_gdh_kernel
         const size_t y_bytes = sizeof(float) * kGF * (size_t)g->n_cols, c_bytes = sizeof(float) * (size_t)d * g->n_edge_cols,
                      id_bytes = sizeof(int32_t) * (size_t)g->nnz, g_bytes = sizeof(float) * kGF * (size_t)g->n_rows;
         const size_t lim = 0xFFFFE000ull;
-        const bool pc_ok = !v1 && d <= 3 && y_bytes < lim && c_bytes < lim && id_bytes < lim && g_bytes < lim;
+        const bool pc_ok = d <= 3 && y_bytes < lim && c_bytes < lim && id_bytes < lim && g_bytes < lim;
         if (px && !pc_ok) {
             amp::set_error("gno_aggregate_bwd: this size does not take the producer / consumer kernels (caller must check gno_bwd_fused_ok)");
             return 2;
@@ -2695,9 +2672,8 @@ int athena_mp_gno_aggregate_bwd_theta(const athena_mp_graph *g, int32_t d, int32
         if (rc == 0) return gno_mlp_backward(g, d, H, Fi, Fo, theta, coords, x, grad, dtheta, nullptr);
         if (rc > 0) return rc;
     }
-    static const bool serial = getenv("ATHENA_MP_GNO_SERIAL_TILES") != nullptr;   // A/B switch for measurements
     const int n_tiles = g->n_rows > 0 ? (g->n_rows + tile - 1) / tile : 0;
-    if (serial || n_tiles < 2) {
+    if (n_tiles < 2) {
         for (int r0 = 0; r0 < g->n_rows; r0 += tile) {
             const int rows = std::min(tile, g->n_rows - r0);
             void *ws = nullptr;
@@ -2750,8 +2726,7 @@ int athena_mp_gno_aggregate_bwd(const athena_mp_graph *g, int32_t d, int32_t H, 
     if (!gno_args_ok(g, d, H, Fi, Fo)) return 2;
     AMP_REQUIRE(theta && coords && x && grad, "gno_aggregate_bwd: null pointer");
     if (fused) *fused = 0;
-    static const bool off = getenv("ATHENA_MP_GNO_BWD_UNFUSED") != nullptr;   // A/B switch for measurements
-    bool ok = !off && dx && g->n_rows > 0 && gno_gdh_shape(H, Fi, Fo, d) && gno_stg_shape(H, Fi, Fo, d) &&
+    bool ok = dx && g->n_rows > 0 && gno_gdh_shape(H, Fi, Fo, d) && gno_stg_shape(H, Fi, Fo, d) &&
               gno_pc_route(d, g->n_cols, g->n_edge_cols, g->nnz) && sizeof(float) * kGF * (size_t)g->n_rows < 0xFFFFE000ull &&
               sizeof(float) * kGF * (size_t)g->n_cols < 0xFFFFE000ull;
     if (ok) {
@@ -2810,10 +2785,9 @@ int athena_mp_gno_aggregate_bwd(const athena_mp_graph *g, int32_t d, int32_t H, 
     // many free per SIMD (3 waves x 152) and is bound by the matrix pipe, so the gather runs on the library's second stream in
     // the slots S^T g cannot use.  ATHENA_MP_GNO_BWD_SERIAL keeps everything on the caller's stream (A/B switch).
     if (int rc = gno_mlp_backward(g, d, H, Fi, Fo, theta, coords, x, grad, dth, dcoords, (float *)pxp, px_half, (const float *)cvp)) return rc;
-    static const bool serial = getenv("ATHENA_MP_GNO_BWD_SERIAL") != nullptr;
     hipStream_t main_s = stream(), gs = main_s;
     hipEvent_t *ev = nullptr;
-    if (dtheta && !serial) {
+    if (dtheta) {   // (side by side 26.6 - 27.3 ms against 28.9 with every launch on one stream: profiles/r04_c4_config.jsonl)
         if (amp::aux_stream(&gs, &ev)) return 1;
         AMP_HIP(hipEventRecord(ev[0], main_s));
         AMP_HIP(hipStreamWaitEvent(gs, ev[0], 0));

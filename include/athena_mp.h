@@ -107,8 +107,8 @@ int athena_mp_graph_dims(const athena_mp_graph *g, int32_t *n_rows, int32_t *n_c
 /* What a cached handle of (adj_ia, adj_ja) is valid for -- the key a layer's set_graph compares before it rebuilds
  * (SURVEY.md 8b "Ownership", F12; the reference re-copies the CSR in every set_graph_msgpass,
  * athena_msgpass_layer_sub.f90:144-174, called before every forward, athena_network_sub.f90:2727-2730).
- * 64-bit hash of the sizes and of EVERY word of both arrays (chunks of 2^20 values hashed by up to
- * ATHENA_MP_GRAPH_KEY_THREADS host threads, default 8, folded in chunk order: the key does not depend on the thread
+ * 64-bit hash of the sizes and of EVERY word of both arrays (chunks of 2^20 values hashed by up to 8 host threads -- fewer
+ * when the process's affinity mask holds fewer cores -- folded in chunk order: the key does not depend on the thread
  * count; about 2 ms for configs[1]'s 80 MB adj_ja on the GPU box's host): an in-place edit is always seen, which is what
  * the reference's copy-per-call guarantees.  Two different graphs of equal n and nnz get different keys (up to 2^-64).
  * ATHENA_MP_GRAPH_KEY_SAMPLED=1 opts into the cheap key for graphs of 2^18 entries and more (head, tail and 4096
@@ -350,8 +350,7 @@ int athena_mp_gno_aggregate_bwd_theta_saved(const athena_mp_graph *g, int32_t d,
  * by athena_mp_finalize), the transposed-entry map (nnz int32) in the graph handle.
  * STREAMS: with dtheta requested, the gather of the partials runs on a second, library-owned stream beside the S^T g launch
  * (fork after the kernel MLP's launches, join before the call returns: the caller's stream waits for it, so the outputs are
- * ordered on the caller's stream like any other call's, and the pattern can be captured into a HIP graph).
- * ATHENA_MP_GNO_BWD_SERIAL=1 keeps every launch on the caller's stream (same bits). */
+ * ordered on the caller's stream like any other call's, and the pattern can be captured into a HIP graph). */
 int athena_mp_gno_aggregate_bwd(const athena_mp_graph *g, int32_t d, int32_t H, int32_t Fi, int32_t Fo,
                                 const float *theta_dev, const float *coords_dev, const float *x_dev,
                                 const float *grad_dev, const float *s_save_dev, float *dx_dev, float *dtheta_dev,
@@ -504,7 +503,7 @@ int athena_mp_comm_create(int32_t rank, int32_t world, const void *id128, athena
 /* MPI-free bootstrap: rank 0 publishes the id in `path`, the others wait for it.  Safe against files a crashed run left
  * behind: ranks > 0 announce themselves with a random nonce in `path`.hello.<rank> (re-written as a heartbeat), rank 0
  * accepts only hello files it has seen change and publishes id + nonces, a rank accepts `path` only when it carries its
- * own nonce.  Every wait is bounded by ATHENA_MP_BOOTSTRAP_TIMEOUT_S (default 300). */
+ * own nonce.  Every wait is bounded by ATHENA_MP_COLLECTIVE_TIMEOUT_S when set, 300 s otherwise. */
 int athena_mp_comm_create_from_file(int32_t rank, int32_t world, const char *path, athena_mp_comm **out);
 int athena_mp_comm_destroy(athena_mp_comm *c);
 int athena_mp_comm_info(const athena_mp_comm *c, int32_t *rank, int32_t *world, char *transport, int32_t transport_len);
@@ -600,12 +599,13 @@ int athena_mp_shard_edge_reduce(athena_mp_shard *s, int32_t F, float *e_dev);
  * _allreduce_start, so a rank whose peer is missing would hang in its next synchronize, far from the cause.  Every transfer
  * this library starts (halo exchange, gradient all-reduce, the metadata collectives of athena_mp_shard_create,
  * athena_mp_comm_barrier) is therefore watched through its completion event by a monitor thread: still pending
- * ATHENA_MP_COLLECTIVE_TIMEOUT_S seconds (default 120; x5 for the metadata collectives and the barrier; 0 = no monitor) after
- * it actually STARTED (an event just in front of it on the communication stream has completed: a host that enqueues many
- * steps ahead of the device is not mistaken for a stall) the
- * PROCESS ends -- "[athena_mp] rank r stalled in <transfer> ..." on stderr, {"ok": false, "error": ...} on stdout, exit code
- * 3; no retry, no cleanup that could block in the same communicator.  (The bootstrap of _comm_create_from_file has its own
- * ATHENA_MP_BOOTSTRAP_TIMEOUT_S.) */
+ * ATHENA_MP_COLLECTIVE_TIMEOUT_S seconds (default 1800 -- one rank may legitimately write a checkpoint, run an evaluation pass or
+ * sit in a debugger; bench.py sets 120 for itself; x5 for the metadata collectives and the barrier; 0 = no monitor) after it
+ * actually STARTED (an event just in front of it on the communication stream has completed: a host that enqueues many steps
+ * ahead of the device is not mistaken for a stall) the PROCESS ends -- "[athena_mp] rank r stalled in <transfer> ..." on stderr
+ * and in athena_mp_last_error, the handler of athena_mp_set_stall_handler if one is registered, exit code 3; no retry, no
+ * cleanup that could block in the same communicator, nothing on the host program's stdout.  (The file bootstrap of
+ * _comm_create_from_file waits ATHENA_MP_COLLECTIVE_TIMEOUT_S when set, 300 s otherwise.) */
 
 /* ---- residency of host arrays: the *_host entry points without the PCIe round trip per op ---------------------------- *
  * athena's layers exchange array_type nodes whose %val lives on the host (athena_network_sub.f90:2752,2761: forward_generic2d

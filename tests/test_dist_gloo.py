@@ -469,3 +469,43 @@ def test_locality_order_shrinks_the_halo_of_a_mesh_numbered_at_random(oracle):
 
     before, after = halo_rows(ia, ja), halo_rows(ia2, ja2)
     assert after < 0.25 * before, (before, after)
+
+
+@pytest.mark.parametrize("tau,locality,want", [("0.001", (60, 0.95), "allgather"), ("0.999", None, "p2p")])
+def test_halo_allgather_fraction_moves_the_threshold(oracle, tau, locality, want):
+    """ATHENA_MP_HALO_ALLGATHER_FRACTION (the tau of SURVEY.md 8e, read by comm.hip and by the CPU mirror alike): in auto mode a
+    banded graph travels as packed rows and a uniform one as whole blocks (test above); with the threshold pushed to either
+    end the choice flips, and the results stay the oracle's"""
+    from athena_amd import synth
+
+    world, n_total, pairs, F = 2, 1600, 6000, 8
+    old = os.environ.get("ATHENA_MP_HALO_ALLGATHER_FRACTION")
+    os.environ["ATHENA_MP_HALO_ALLGATHER_FRACTION"] = tau          # spawned ranks inherit it
+    try:
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker_global, args=(r, world, port, n_total, pairs, F, locality, q, "auto")) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = dict(q.get(timeout=180) for _ in range(world))
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        if old is None:
+            os.environ.pop("ATHENA_MP_HALO_ALLGATHER_FRACTION", None)
+        else:
+            os.environ["ATHENA_MP_HALO_ALLGATHER_FRACTION"] = old
+    if locality is None:
+        ia, ja = synth.random_graph_csr(n_total, pairs, seed=11)
+    else:
+        ia64, cols = synth.random_graph_csr_rows(n_total, pairs, 0, n_total, seed=11, locality=locality)
+        ia = ia64.astype(np.int32)
+        ja = np.zeros((2, cols.size), np.int32, order="F"); ja[0] = cols + 1
+    x = synth.feature_block(1, 0, n_total, F)
+    out = []
+    for r in range(world):
+        assert res[r]["halo_mode"] == want and res[r]["halo_ok"]
+        a = np.empty_like(res[r]["P"]); a[res[r]["order"]] = res[r]["P"]; out.append(a)
+    assert np.array_equal(np.concatenate(out), oracle.kipf_propagate(x, ia, ja))

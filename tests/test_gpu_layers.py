@@ -728,3 +728,36 @@ print("OK")
     env = dict(os.environ, ATHENA_MP_GRAPH_KEY_SAMPLED="1")
     out = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout[-1500:] + out.stderr[-3000:]
+
+
+def test_graph_cache_entries_bounds_what_idle_handles_keep(dev):
+    """ATHENA_MP_GRAPH_CACHE_ENTRIES: released handles stay cached (the next epoch's mini-batches find theirs) up to that many
+    entries (nnz + n) in all; 0 = a handle is freed with its last user.  Read once per process: two child processes."""
+    import subprocess
+    prog = r'''
+import sys, ctypes as C, numpy as np
+sys.path.insert(0, %r)
+from athena_amd import _capi, synth
+_capi.init(0)
+def stats():
+    h, hit, b = C.c_int64(), C.c_int64(), C.c_int64()
+    _capi.call("athena_mp_graph_cache_stats", C.byref(h), C.byref(hit), C.byref(b))
+    return h.value, hit.value, b.value
+ia, ja = synth.random_graph_csr(500, 2000)
+def acquire():
+    h = C.c_void_p()
+    _capi.call("athena_mp_graph_acquire", 500, ja.shape[1], ia.ctypes.data, ja.ctypes.data, 0, C.byref(h))
+    return h
+h = acquire(); _capi.call("athena_mp_graph_release", h)
+held_after_release = stats()[0]
+h = acquire(); _capi.call("athena_mp_graph_release", h)
+print("RESULT", held_after_release, stats()[1], stats()[2])
+''' % ROOT
+    out = {}
+    for cap in ("0", "1000000"):
+        r = subprocess.run([sys.executable, "-c", prog], env=dict(os.environ, ATHENA_MP_GRAPH_CACHE_ENTRIES=cap), capture_output=True,
+                           text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-1500:]
+        out[cap] = [int(t) for t in [l for l in r.stdout.splitlines() if l.startswith("RESULT")][-1].split()[1:]]
+    assert out["0"] == [0, 0, 2]            # nothing kept: the second acquire builds again
+    assert out["1000000"] == [1, 1, 1]      # kept idle: the second acquire is a hit

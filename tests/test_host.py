@@ -253,7 +253,9 @@ def test_graph_key_does_not_depend_on_the_thread_count_and_sampling_is_opt_in():
     import sys
 
     prog = r'''
-import ctypes as C, numpy as np, sys
+import ctypes as C, numpy as np, sys, os
+if os.environ.get("KEY_TEST_ONE_CORE"):
+    os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[0]})     # std::thread::hardware_concurrency follows the mask
 sys.path.insert(0, %r)
 from athena_amd import _capi
 n, nnz = 200_000, (1 << 22) + 77
@@ -276,8 +278,8 @@ print(k0, key())
         assert out.returncode == 0, out.stderr[-2000:]
         return [int(t) for t in out.stdout.split()]
 
-    a = run({"ATHENA_MP_GRAPH_KEY_THREADS": "1"})
-    b = run({"ATHENA_MP_GRAPH_KEY_THREADS": "8"})
+    a = run({"KEY_TEST_ONE_CORE": "1"})      # affinity mask of one core: the key's chunks are hashed by one thread
+    b = run({})                              # ... and by up to eight
     assert a == b and a[0] != a[1]
     s = run({"ATHENA_MP_GRAPH_KEY_SAMPLED": "1"})
     assert s[0] == s[1] and s[0] != a[0]
