@@ -213,7 +213,7 @@ typedef unsigned int v4u_g __attribute__((ext_vector_type(4)));
 #define GNO_PX_AUX 0   // cache bits of the per-entry partials' stores (1 sc0, 2 nt, 16 sc1): none -- A/B in profiles/r04_c4_px_one_array_ab.txt
 #define GNO_SAVE_AUX 2
 #ifndef GNO_FV
-#define GNO_FV 0   // timing-only variants (scripts/build_variants.sh), bit mask: 1 no sparse loop, 2 no V loads, 4 no S reads, 8 no contraction, 16 no cross-wave reduction (gno_fused_kernel); 32 idle producers, 64 idle consumers, 8192 half the gathers (gno_pc_kernel)
+#define GNO_FV 0   // timing-only variants (scripts/build_variants.sh), bit mask: 1 no sparse loop, 2 no V loads, 4 no S reads, 8 no contraction, 16 no cross-wave reduction (gno_fused_kernel); 32 idle producers, 64 idle consumers, 8192 half the gathers (gno_pc_kernel); 16384 gno_px_gather_kernel reads the partials as one stream
 #endif
 constexpr int kGF = 64, kGH = 64, kGRows = 16, kGSP = 33 * kGF + 4;   // LDS row pitch of S_half
 
@@ -2322,6 +2322,11 @@ __global__ __launch_bounds__(256) void gno_px_gather_kernel(const int32_t *__res
         v4f_g pv[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) w[i] = t_entry[t + i];
+#if GNO_FV & 16384   // timing only: the partials read in the order the transposed CSR lists them (what a segment-ordered emission
+                     // would give the gather: one stream); the sums are wrong
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w[i] = w[i] < 0 ? w[i] : t + i;
+#endif
 #pragma unroll
         for (int i = 0; i < 8; ++i) pv[i] = px_load(px + (size_t)(w[i] < 0 ? 0 : w[i]) * kGF + 4 * l);
 #pragma unroll

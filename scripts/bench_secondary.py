@@ -99,16 +99,18 @@ def run_c3(dev, reps):
     z, p = ops.duvenaud_update_act_readout(g, a_, W, mn, mx, Fv, R, O, act="sigmoid")
     out = ops.segment_sum(p, seg)
     dc, dR = ops.duvenaud_readout_bwd(R, z, p, seg, gout, act="sigmoid")
-    da, dW = ops.duvenaud_update_bwd(g, dc, a_, W, mn, mx)
-    dx = ops.duvenaud_propagate_bwd_x(g, da, Fv)
-    de = ops.duvenaud_propagate_bwd_e(g, da, Fv)
+    # da split where it is written (da_x [N, 64] + da_e [N, 8], round 5): what both layer mirrors run at F_v = 64
+    da_x, da_e, dW = ops.duvenaud_update_bwd_split(g, dc, a_, W, mn, mx, Fv)
+    da = torch.cat([da_x, da_e], dim=1)                          # the packed form, for the parity block only
+    dx = ops.duvenaud_propagate_bwd_x(g, da_x, Fv)
+    de = ops.duvenaud_propagate_bwd_e(g, da_e, 0)
     t = {"propagate": timeit(lambda: ops.duvenaud_propagate(g, x, e, out=a_), reps),
          "update_sigmoid_readout_p(fused)": timeit(lambda: ops.duvenaud_update_act_readout(g, a_, W, mn, mx, Fv, R, O, act="sigmoid"), reps),
          "segment_sum": timeit(lambda: ops.segment_sum(p, seg), reps),
          "readout_bwd": timeit(lambda: ops.duvenaud_readout_bwd(R, z, p, seg, gout, act="sigmoid"), reps),
-         "update_bwd_fused(w+a)": timeit(lambda: ops.duvenaud_update_bwd(g, dc, a_, W, mn, mx), reps),
-         "propagate_bwd_x": timeit(lambda: ops.duvenaud_propagate_bwd_x(g, da, Fv), reps),
-         "propagate_bwd_e": timeit(lambda: ops.duvenaud_propagate_bwd_e(g, da, Fv), reps)}
+         "update_bwd_fused(w+a)": timeit(lambda: ops.duvenaud_update_bwd_split(g, dc, a_, W, mn, mx, Fv), reps),
+         "propagate_bwd_x": timeit(lambda: ops.duvenaud_propagate_bwd_x(g, da_x, Fv), reps),
+         "propagate_bwd_e": timeit(lambda: ops.duvenaud_propagate_bwd_e(g, da_e, 0), reps)}
     # a batch of ~18-vertex molecules is block-diagonal: a vertex's neighbours sit in the cache lines next to its own, so the
     # two gathers are priced on COMPULSORY bytes (every tensor once, indices included), the streaming ops on their tensors
     comp = {"propagate": N * 4 * Fv + E * 4 * Fe + nnz * 8 + N * 4 + N * 4 * Fc,
@@ -160,7 +162,7 @@ def run_c3(dev, reps):
     res = {"config": "configs[2]", "workload": f"Duvenaud msgpass, {S} QM9-shaped graphs = {N} vertices / {nnz} entries, F_v = {Fv}, F_e = {Fe}, "
            f"{O} outputs, one time step + readout, fwd+bwd", "step_ms": round(step, 4), "entries_per_s": nnz / step * 1e3, "ops": opsd, "parity": par,
            "cpu_baseline": cpu}
-    del a_, z, p, dc, da, dx, de
+    del a_, z, p, dc, da, da_x, da_e, dx, de
     res["layer_T4"] = c3_layer_T4(dev, reps, ia, ja, voff, E, x, e)
     return res
 

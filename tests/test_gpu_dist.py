@@ -1128,8 +1128,10 @@ def test_a_c_abi_shard_failure_raises_on_every_rank_with_the_c_error_text(dev):
     _remove_shm_dirs(shm_before)
     if env_before is None:
         os.environ.pop("ATHENA_MP_COMM_TRANSPORT", None)
-    assert "C-ABI communicator / shard failed" in got[1] and "AthenaMPError" in got[1], got
-    assert "another rank failed" in got[0], got
+    assert "C-ABI communicator / shard failed" in got[1] and "AthenaMPError" in got[1] and "outside [1,4000]" in got[1], got
+    # rank 0's own C call fails too (athena_mp_shard_create agrees on argument checks across ranks before its first data
+    # collective): it raises with the C ABI's text naming the rank at fault
+    assert "C-ABI communicator / shard failed" in got[0] and "rank 1 rejected its arguments" in got[0], got
     src = open(os.path.join(ROOT, "athena_amd", "dist.py")).read()
     assert "FALLBACK" not in src and "_c_shard_or_none" not in src
 

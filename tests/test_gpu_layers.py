@@ -734,6 +734,7 @@ def test_graph_cache_entries_bounds_what_idle_handles_keep(dev):
     """ATHENA_MP_GRAPH_CACHE_ENTRIES: released handles stay cached (the next epoch's mini-batches find theirs) up to that many
     entries (nnz + n) in all; 0 = a handle is freed with its last user.  Read once per process: two child processes."""
     import subprocess
+    import sys
     prog = r'''
 import sys, ctypes as C, numpy as np
 sys.path.insert(0, %r)
