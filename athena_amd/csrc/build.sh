@@ -14,7 +14,7 @@ for s in $SRCS; do
   [ -f "$s" ] || continue
   o=../../build/obj/${s%.hip}.o
   objs="$objs $o"
-  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ ../../include/athena_mp.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ transport.h -nt "$o" ] || [ ../../include/athena_mp.h -nt "$o" ]; then
     /opt/rocm/bin/hipcc $FLAGS -c "$s" -o "$o" &
     pids="$pids $!"
   fi
@@ -23,4 +23,8 @@ fail=0
 for p in $pids; do wait $p || fail=1; done     # a failed compile must not link the stale object of the last good build
 [ $fail -eq 0 ] || { echo "build.sh: compilation failed" >&2; exit 1; }
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o $OUT
+# the TEST transport of comm.hip: a plugin of its own, never linked into the product library
+if [ ! -f ../libathena_mp_testcomm.so ] || [ test_transport.cpp -nt ../libathena_mp_testcomm.so ] || [ transport.h -nt ../libathena_mp_testcomm.so ]; then
+  /opt/rocm/bin/hipcc -x hip --offload-arch=gfx950 -O2 -std=c++17 -fPIC -shared test_transport.cpp -o ../libathena_mp_testcomm.so
+fi
 echo "built $(readlink -f $OUT)"

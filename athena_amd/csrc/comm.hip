@@ -6,9 +6,9 @@
 //                  communication stream of its own, event-ordered against the compute stream (amp::stream()); dW by
 //                  ncclAllReduce.  librccl is dlopen'ed on first use, so single-GPU users never load it and a process
 //                  that already carries a copy (PyTorch) shares it.
-//   test transport ATHENA_MP_COMM_TRANSPORT=shm: the same calls with the bytes staged through files under /dev/shm.
-//                  TEST INFRASTRUCTURE for boxes with ONE GPU (RCCL refuses two ranks on one device: "Duplicate GPU
-//                  detected"); it exercises everything here except the nccl* calls themselves.  Never selected by default.
+//   test transport ATHENA_MP_COMM_TRANSPORT=shm loads the plugin libathena_mp_testcomm.so (test_transport.cpp; NOT part of this
+//                  library): the same calls with the bytes staged through files under /dev/shm -- for boxes with ONE GPU
+//                  (RCCL refuses two ranks on one device); it exercises everything here except the nccl* calls themselves.
 //   shard          rank r owns a contiguous block of vertex rows.  Columns are renumbered [local | halo], local vertices
 //                  INTERIOR FIRST (rows that reference no remote vertex), so rows [0, n_int) run while the halo is in
 //                  flight and only [n_int, n) wait.  The backward graph lists each row's entries by ascending global
@@ -35,55 +35,14 @@
 #include <rccl/rccl.h>
 
 #include "common.h"
+#include "transport.h"
 
 namespace {
 
 // ---------------------------------------------------------------------------------------------------------------------
-// transports
+// transports (the interface: transport.h)
 // ---------------------------------------------------------------------------------------------------------------------
-struct Transport {
-    int rank = 0, world = 1;
-    // what this rank has put on the wire, for athena_mp_comm_stats: bytes to every peer (grouped sends and its blocks of
-    // all-gathers), all-reduce payload, number of transfers started
-    std::vector<int64_t> sent;
-    int64_t allreduce_bytes = 0, transfers = 0;
-    void count_sent(int p, size_t bytes)
-    {
-        if ((int)sent.size() != world) sent.assign((size_t)world, 0);
-        if (p >= 0 && p < world) sent[(size_t)p] += (int64_t)bytes;
-    }
-    virtual ~Transport() {}
-    virtual const char *name() const = 0;
-    virtual int ranks_seen() const { return world; }   // how many ranks the transport's own communicator reports
-    virtual int version() const { return 0; }          // RCCL: ncclGetVersion
-    // device buffers; bytes may be 0 (skipped); entries for p == rank are ignored.  Enqueued on / ordered after `s`.
-    virtual int exchange(const void *const *sendp, const size_t *sendb, void *const *recvp, const size_t *recvb,
-                         hipStream_t s) = 0;
-    virtual int allreduce_f32(float *buf, size_t count, hipStream_t s) = 0;
-    // every rank contributes `bytes` from send; recv holds world * bytes, block p at p * bytes (send may be recv + rank * bytes)
-    virtual int allgather(const void *send, void *recv, size_t bytes, hipStream_t s) = 0;
-    // what every caller in this file uses: the same three, counted
-    int counted_exchange(const void *const *sendp, const size_t *sendb, void *const *recvp, const size_t *recvb, hipStream_t s)
-    {
-        for (int p = 0; p < world; ++p)
-            if (p != rank) count_sent(p, sendb[p]);
-        ++transfers;
-        return exchange(sendp, sendb, recvp, recvb, s);
-    }
-    int counted_allreduce_f32(float *buf, size_t count, hipStream_t s)
-    {
-        allreduce_bytes += (int64_t)(4 * count);
-        ++transfers;
-        return allreduce_f32(buf, count, s);
-    }
-    int counted_allgather(const void *send, void *recv, size_t bytes, hipStream_t s)
-    {
-        for (int p = 0; p < world; ++p)
-            if (p != rank) count_sent(p, bytes);
-        ++transfers;
-        return allgather(send, recv, bytes, s);
-    }
-};
+using amp_comm::Transport;
 
 struct RcclApi {
     void *lib = nullptr;
@@ -194,136 +153,41 @@ struct RcclTransport : Transport {
     }
 };
 
-// test-only: bytes through /dev/shm files, one file per (sequence number, source, destination)
-struct ShmTransport : Transport {
-    std::string dir;
-    uint64_t seq = 0;
-    std::vector<char> host;
-    const char *name() const override { return "shm (test transport: host-staged files, not RCCL)"; }
-    std::string path(uint64_t q, int src, int dst) const
-    {
-        char b[96];
-        snprintf(b, sizeof(b), "/m_%llu_%d_%d", (unsigned long long)q, src, dst);
-        return dir + b;
-    }
-    int put(const std::string &file, const void *data, size_t bytes)
-    {
-        const std::string tmp = file + ".tmp";
-        int fd = open(tmp.c_str(), O_CREAT | O_WRONLY | O_TRUNC, 0600);
-        if (fd < 0) {
-            amp::set_error("comm(shm): cannot create %s: %s", tmp.c_str(), strerror(errno));
-            return 1;
-        }
-        const char *p = (const char *)data;
-        size_t left = bytes;
-        while (left) {
-            ssize_t w = write(fd, p, left);
-            if (w <= 0) {
-                close(fd);
-                amp::set_error("comm(shm): write failed: %s", strerror(errno));
-                return 1;
-            }
-            p += w;
-            left -= (size_t)w;
-        }
-        close(fd);
-        if (rename(tmp.c_str(), file.c_str())) {
-            amp::set_error("comm(shm): rename failed: %s", strerror(errno));
-            return 1;
-        }
-        return 0;
-    }
-    int get(const std::string &file, void *data, size_t bytes)
-    {
-        const double t0 = now();
-        int fd = -1;
-        while ((fd = open(file.c_str(), O_RDONLY)) < 0) {
-            if (now() - t0 > 300.0) {
-                amp::set_error("comm(shm): timed out waiting for %s", file.c_str());
-                return 1;
-            }
-            usleep(200);
-        }
-        char *p = (char *)data;
-        size_t left = bytes;
-        while (left) {
-            ssize_t r = read(fd, p, left);
-            if (r <= 0) {
-                close(fd);
-                amp::set_error("comm(shm): short read of %s", file.c_str());
-                return 1;
-            }
-            p += r;
-            left -= (size_t)r;
-        }
-        close(fd);
-        unlink(file.c_str());
-        return 0;
-    }
-    static double now()
-    {
-        timespec ts;
-        clock_gettime(CLOCK_MONOTONIC, &ts);
-        return ts.tv_sec + 1e-9 * ts.tv_nsec;
-    }
-    int exchange(const void *const *sendp, const size_t *sendb, void *const *recvp, const size_t *recvb,
-                 hipStream_t s) override
-    {
-        const uint64_t q = seq++;
-        AMP_HIP(hipStreamSynchronize(s));
-        for (int p = 0; p < world; ++p) {
-            if (p == rank || !sendb[p]) continue;
-            host.resize(sendb[p]);
-            AMP_HIP(hipMemcpy(host.data(), sendp[p], sendb[p], hipMemcpyDeviceToHost));
-            if (put(path(q, rank, p), host.data(), sendb[p])) return 1;
-        }
-        for (int p = 0; p < world; ++p) {
-            if (p == rank || !recvb[p]) continue;
-            host.resize(recvb[p]);
-            if (get(path(q, p, rank), host.data(), recvb[p])) return 1;
-            AMP_HIP(hipMemcpy(recvp[p], host.data(), recvb[p], hipMemcpyHostToDevice));
-        }
-        return 0;
-    }
-    int allreduce_f32(float *buf, size_t count, hipStream_t s) override
-    {
-        if (!count) return 0;
-        const uint64_t q = seq++;
-        AMP_HIP(hipStreamSynchronize(s));
-        std::vector<float> mine(count), other(count), sum(count, 0.0f);
-        AMP_HIP(hipMemcpy(mine.data(), buf, 4 * count, hipMemcpyDeviceToHost));
-        for (int p = 0; p < world; ++p)
-            if (p != rank && put(path(q, rank, p), mine.data(), 4 * count)) return 1;
-        for (int p = 0; p < world; ++p) {   // rank order: every rank forms the same sum
-            const float *src = mine.data();
-            if (p != rank) {
-                if (get(path(q, p, rank), other.data(), 4 * count)) return 1;
-                src = other.data();
-            }
-            for (size_t i = 0; i < count; ++i) sum[i] += src[i];
-        }
-        AMP_HIP(hipMemcpy(buf, sum.data(), 4 * count, hipMemcpyHostToDevice));
-        return 0;
-    }
-    int allgather(const void *send, void *recv, size_t bytes, hipStream_t s) override
-    {
-        if (!bytes) return 0;
-        const uint64_t q = seq++;
-        AMP_HIP(hipStreamSynchronize(s));
-        host.resize(bytes);
-        AMP_HIP(hipMemcpy(host.data(), send, bytes, hipMemcpyDeviceToHost));
-        for (int p = 0; p < world; ++p)
-            if (p != rank && put(path(q, rank, p), host.data(), bytes)) return 1;
-        if ((const char *)send != (char *)recv + (size_t)rank * bytes)
-            AMP_HIP(hipMemcpy((char *)recv + (size_t)rank * bytes, send, bytes, hipMemcpyDeviceToDevice));
-        for (int p = 0; p < world; ++p) {
-            if (p == rank) continue;
-            if (get(path(q, p, rank), host.data(), bytes)) return 1;
-            AMP_HIP(hipMemcpy((char *)recv + (size_t)p * bytes, host.data(), bytes, hipMemcpyHostToDevice));
-        }
-        return 0;
-    }
+// The TEST transport (bytes staged through /dev/shm files: several ranks on ONE GPU, where RCCL refuses) is not in this library:
+// it is the plugin libathena_mp_testcomm.so (test_transport.cpp), looked for beside this library and loaded only when
+// ATHENA_MP_COMM_TRANSPORT=shm asks for it.
+struct TestPlugin {
+    void *lib = nullptr;
+    amp_comm::test_create_fn create = nullptr;
+    amp_comm::test_unique_id_fn unique_id = nullptr;
 };
+TestPlugin g_test;
+void test_plugin_error(const char *m) { amp::set_error("%s", m); }
+int test_plugin_load()
+{
+    if (g_test.lib) return 0;
+    std::string path = "libathena_mp_testcomm.so";
+    Dl_info info;
+    if (dladdr((const void *)&test_plugin_error, &info) && info.dli_fname) {
+        const std::string self(info.dli_fname);
+        const size_t slash = self.rfind('/');
+        if (slash != std::string::npos) path = self.substr(0, slash + 1) + path;
+    }
+    void *h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!h) {
+        amp::set_error("comm: ATHENA_MP_COMM_TRANSPORT=shm asks for the TEST transport, but its plugin %s cannot be loaded (%s)",
+                       path.c_str(), dlerror());
+        return 1;
+    }
+    *(void **)(&g_test.create) = dlsym(h, "athena_mp_test_transport_create");
+    *(void **)(&g_test.unique_id) = dlsym(h, "athena_mp_test_transport_unique_id");
+    if (!g_test.create || !g_test.unique_id) {
+        amp::set_error("comm: %s lacks the test transport's entry points", path.c_str());
+        return 1;
+    }
+    g_test.lib = h;
+    return 0;
+}
 
 bool want_shm()
 {
@@ -673,9 +537,8 @@ int athena_mp_comm_unique_id(void *id128)
     AMP_REQUIRE(id128 != nullptr, "comm_unique_id: null buffer");
     memset(id128, 0, 128);
     if (want_shm()) {
-        int fd = open("/dev/urandom", O_RDONLY);
-        AMP_REQUIRE(fd >= 0 && read(fd, id128, 16) == 16, "comm_unique_id: /dev/urandom unreadable");
-        close(fd);
+        if (test_plugin_load()) return 1;
+        AMP_REQUIRE(g_test.unique_id(id128) == 0, "comm_unique_id: /dev/urandom unreadable");
         return 0;
     }
     if (rccl_load()) return 1;
@@ -694,14 +557,8 @@ int athena_mp_comm_create(int32_t rank, int32_t world, const void *id128, athena
     athena_mp_comm *c = new athena_mp_comm();
     c->device = amp::device();
     if (want_shm()) {
-        ShmTransport *t = new ShmTransport();
-        char hex[40];
-        const unsigned char *b = (const unsigned char *)id128;
-        for (int i = 0; i < 16; ++i) snprintf(hex + 2 * i, 3, "%02x", b[i]);
-        t->dir = std::string("/dev/shm/athena_mp_") + hex;
-        if (mkdir(t->dir.c_str(), 0700) && errno != EEXIST) {
-            set_error("comm_create(shm): cannot create %s: %s", t->dir.c_str(), strerror(errno));
-            delete t;
+        Transport *t = test_plugin_load() ? nullptr : g_test.create(id128, test_plugin_error);
+        if (!t) {
             delete c;
             return 1;
         }
@@ -852,11 +709,7 @@ int athena_mp_comm_destroy(athena_mp_comm *c)
 {
     if (!c) return 0;
     if (c->cs) (void)hipStreamSynchronize(c->cs);
-    if (c->t && strncmp(c->t->name(), "shm", 3) == 0) {
-        ShmTransport *t = (ShmTransport *)c->t;
-        (void)rmdir(t->dir.c_str());   // succeeds for the last rank out (directory empty)
-    }
-    delete c->t;
+    delete c->t;   // (the test transport removes its directory in its destructor: succeeds for the last rank out)
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
     if (c->ev_done) {
         watch_forget(c->ev_done);

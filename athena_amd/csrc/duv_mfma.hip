@@ -814,6 +814,9 @@ __global__ __launch_bounds__(256, (IT * OT > 20 ? 1 : 2)) void duv_bwd_wide_kern
     // 288-byte rows (profiles/r05_c3_split_da_ab.txt: 0.075 -> 0.037 ms, the three reverse launches 0.936 -> 0.872 ms)
     constexpr int AP = 16 * IT + 4, GP = 16 * OT + 4, FOP = 16 * OT, WP = 16 * OT + 4, TA = IT - 4, TG = OT - 4;
     constexpr int kW = 16 * IT * WP, kTurn = 4 * 16 * (AP + GP), kRed = 16 * IT * FOP;
+    // (probe, round 5: padded to ONE workgroup per CU = one wave per SIMD this kernel takes 0.589 instead of 0.532 ms at configs[2] --
+    // it is bound by what a SIMD issues per tile (~8 700 cycles, 5 120 of them MFMA), not by latency; folding the readout's reverse
+    // in would add ~1 500 issue cycles per tile at one wave per SIMD: ~0.70 ms against 0.53 + 0.29 today -- sized, not built)
     __shared__ __attribute__((aligned(16))) float buf[kW + (kTurn > kRed ? kTurn : kRed)];
     float *wl = buf, *red = buf + kW;
     const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4, wave = threadIdx.x >> 6;
