@@ -747,7 +747,7 @@ def stats():
 ia, ja = synth.random_graph_csr(500, 2000)
 def acquire():
     h = C.c_void_p()
-    _capi.call("athena_mp_graph_acquire", 500, ja.shape[1], ia.ctypes.data, ja.ctypes.data, 0, C.byref(h))
+    _capi.call("athena_mp_graph_acquire", 500, ja.shape[1], ia.ctypes.data, ja.ctypes.data, 2000, C.byref(h))
     return h
 h = acquire(); _capi.call("athena_mp_graph_release", h)
 held_after_release = stats()[0]
