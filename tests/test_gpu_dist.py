@@ -1161,3 +1161,47 @@ adist.c_comm_destroy(); dist.destroy_process_group()
     st = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert st["transport"] == "rccl" and st["ranks_seen"] == 1 and st["version"] > 20000, st
     assert st["sent_bytes_per_peer"] == [0]
+
+
+def test_stall_handler_gets_the_hosts_last_word_before_exit_code_3(dev, tmp_path):
+    """athena_mp_set_stall_handler: when comm.hip's monitor finds a transfer past its deadline it calls the host's handler ONCE,
+    on the monitor thread, before the process leaves with exit code 3 -- the host's chance to flush its own state.  Two python
+    ranks over the test transport, a bounded 6 s spin kernel in front of the first halo exchange's completion event, deadline
+    2 s; the handler writes a file naming the rank and the transfer.  Nothing is printed on stdout by the library."""
+    import subprocess
+    port = _free_port()
+    prog = r'''
+import os, sys, ctypes as C
+rank = int(sys.argv[1]); out = sys.argv[2]
+sys.path.insert(0, %r)
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=%r, ATHENA_MP_HALO_MODE="p2p")
+import torch, torch.distributed as dist
+dist.init_process_group("gloo", rank=rank, world_size=2)
+torch.cuda.set_device(0)
+from athena_amd import dist as adist, _capi
+dev = torch.device("cuda", 0)
+lib = _capi.load()
+CB = C.CFUNCTYPE(None, C.c_int32, C.c_char_p, C.c_double)
+def on_stall(r, what, seconds):
+    with open(out, "w") as f:
+        f.write("rank %%d stalled in %%s after %%.0f s\n" %% (r, what.decode(), seconds))
+cb = CB(on_stall)
+lib.athena_mp_set_stall_handler.argtypes = [CB]
+assert lib.athena_mp_set_stall_handler(cb) == 0
+shard = adist.make_weak_scaling_shard(rank, 2, 4000, 16000, 64, cut=0.1, device=dev)
+step = adist.KipfShardStep(shard, 64, dev)
+step()
+torch.cuda.synchronize()
+print("finished without a stall", flush=True)
+''' % (ROOT, str(port))
+    env = dict(os.environ, ATHENA_MP_COLLECTIVE_TIMEOUT_S="2", ATHENA_MP_COMM_TEST_DELAY_MS="6000")
+    shm_before = _shm_dirs()
+    procs = [subprocess.Popen([sys.executable, "-c", prog, str(r), str(tmp_path / f"stall_{r}.txt")], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE) for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    _remove_shm_dirs(shm_before)
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 3, (r, p.returncode, so.decode()[-300:], se.decode()[-800:])
+        assert "finished without a stall" not in so.decode() and '"ok"' not in so.decode()
+        note = (tmp_path / f"stall_{r}.txt").read_text()
+        assert note.startswith(f"rank {r} stalled in") and "halo exchange" in note, note
