@@ -440,10 +440,12 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 // z[v, 16 ot + 4 q + c], i.e. k = 16 ot + 4 q + c), so logits^T[o, v] costs OT x 4 more MFMAs per tile with R's fragments read
 // from LDS, the softmax is two cross-lane steps (readout.hip), and z is not read back from HBM by a readout launch
 // (600 MB at configs[2]).  p rows are 4 O bytes: written with bounds-checked buffer stores, lanes beyond O pointed past it.
-// (Two waves per SIMD wherever 256 registers hold the shape; the 96-wide shapes that do not -- 24 accumulators, or 24 input
-// fragments beside the readout's -- get the whole register file rather than spills inside the tile loop: scripts/isa_lint.py R2.)
+// (Two waves per SIMD wherever 256 registers hold the shape.  96 OUTPUTS (24 accumulators) get one wave per SIMD and the whole
+// register file instead of spills inside the tile loop (scripts/isa_lint.py R2); 96 INPUTS with the readout epilogue keep two
+// waves and their 44 B of spills -- measured faster that way, 0.488 against 0.545 ms, while the fused reverse kernel of the same
+// shape gains 26 % from the whole file, 0.961 -> 0.707 ms: profiles/r05_duv_96wide_ab.txt.)
 template <int KJ, int OT, bool RO>
-__global__ __launch_bounds__(256, ((OT > 5 || (KJ > 5 && RO)) ? 1 : 2)) void duv_rows_wide_kernel(BucketSplit sp, const int32_t *__restrict__ trows,
+__global__ __launch_bounds__(256, (OT > 5 ? 1 : 2)) void duv_rows_wide_kernel(BucketSplit sp, const int32_t *__restrict__ trows,
                                                             const int32_t *__restrict__ trows_t,
                                                             const float *__restrict__ X, int K,
                                                             const float *__restrict__ W, int64_t wb, int so, int sk,
