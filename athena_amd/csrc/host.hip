@@ -16,6 +16,8 @@ struct Stage {
     const void *in;   // host source (nullptr: output only)
     void *out;        // host destination (nullptr: input only)
     size_t bytes;
+    bool through = false;   // output that is ALWAYS copied home, resident mode or not: the partials of the reverse callbacks, which
+                            // diffstruc's grad_reverse accumulates with host arithmetic the moment the callback returns
     void *dev = nullptr;
 };
 
@@ -204,7 +206,17 @@ template <typename Body> int staged(std::initializer_list<Stage> args, Body &&bo
         for (size_t k = 0; k < a.size(); ++k) {
             Stage &s = a[k];
             if (!s.out || !s.bytes) continue;
-            if (resident[k]) {   // stays in HBM; the host array is materialised by athena_mp_resident_flush
+            if (resident[k] && s.through) {   // a reverse partial: home at once; the device copy stays valid beside it
+                Resident &r = g_res[(const char *)s.out];
+                if (hipMemcpyAsync(s.out, s.dev, s.bytes, hipMemcpyDeviceToHost, stream()) != hipSuccess) {
+                    set_error("host staging: download failed");
+                    rc = 1;
+                }
+                r.dev_newer = false;
+                r.trusted = false;
+                r.version = ++g_res_version;
+                g_res_stats.d2h_bytes += (int64_t)s.bytes;
+            } else if (resident[k]) {   // stays in HBM; the host array is materialised by athena_mp_resident_flush
                 Resident &r = g_res[(const char *)s.out];
                 r.dev_newer = true;
                 r.trusted = false;
@@ -408,7 +420,7 @@ int athena_mp_kipf_propagate_fwd_host(const athena_mp_graph *g, int32_t F, const
 int athena_mp_kipf_propagate_bwd_host(const athena_mp_graph *g, int32_t F, const float *gh, float *dxh, int32_t exact)
 {
     AMP_REQUIRE(g && gh && dxh && F > 0, "kipf_propagate_bwd_host: bad arguments");
-    return staged({{gh, nullptr, fb(g->n_rows, F)}, {nullptr, dxh, fb(g->n_cols, F)}}, [&](std::vector<void *> &d) {
+    return staged({{gh, nullptr, fb(g->n_rows, F)}, {nullptr, dxh, fb(g->n_cols, F), true}}, [&](std::vector<void *> &d) {
         return athena_mp_kipf_propagate_bwd(g, F, (const float *)d[0], (float *)d[1], exact);
     });
 }
@@ -426,14 +438,14 @@ int athena_mp_gemm_fwd_host(int64_t N, int32_t Fi, int32_t Fo, const float *Ph, 
 int athena_mp_gemm_dw_host(int64_t N, int32_t Fi, int32_t Fo, const float *P, const float *dZ, float *dW)
 {
     AMP_REQUIRE(N >= 0 && Fi > 0 && Fo > 0 && P && dZ && dW, "gemm_dw_host: bad arguments");
-    return staged({{P, nullptr, fb(N, Fi)}, {dZ, nullptr, fb(N, Fo)}, {nullptr, dW, fb(Fi, Fo)}}, [&](std::vector<void *> &d) {
+    return staged({{P, nullptr, fb(N, Fi)}, {dZ, nullptr, fb(N, Fo)}, {nullptr, dW, fb(Fi, Fo), true}}, [&](std::vector<void *> &d) {
         return athena_mp_gemm_dw(N, Fi, Fo, (float *)d[0], (float *)d[1], (float *)d[2]);
     });
 }
 int athena_mp_gemm_dx_host(int64_t N, int32_t Fi, int32_t Fo, const float *dZ, const float *W, float *dP)
 {
     AMP_REQUIRE(N >= 0 && Fi > 0 && Fo > 0 && dZ && W && dP, "gemm_dx_host: bad arguments");
-    return staged({{dZ, nullptr, fb(N, Fo)}, {W, nullptr, fb(Fi, Fo)}, {nullptr, dP, fb(N, Fi)}}, [&](std::vector<void *> &d) {
+    return staged({{dZ, nullptr, fb(N, Fo)}, {W, nullptr, fb(Fi, Fo)}, {nullptr, dP, fb(N, Fi), true}}, [&](std::vector<void *> &d) {
         return athena_mp_gemm_dx(N, Fi, Fo, (float *)d[0], (float *)d[1], (float *)d[2]);
     });
 }
@@ -447,7 +459,7 @@ int athena_mp_activation_fwd_host(int32_t act, int64_t n, const float *z, float 
 int athena_mp_activation_bwd_host(int32_t act, int64_t n, const float *y, const float *g, float *dz)
 {
     AMP_REQUIRE(n >= 0 && y && g && dz, "activation_bwd_host: bad arguments");
-    return staged({{y, nullptr, fb(n, 1)}, {g, nullptr, fb(n, 1)}, {nullptr, dz, fb(n, 1)}}, [&](std::vector<void *> &d) {
+    return staged({{y, nullptr, fb(n, 1)}, {g, nullptr, fb(n, 1)}, {nullptr, dz, fb(n, 1), true}}, [&](std::vector<void *> &d) {
         return athena_mp_activation_bwd(act, n, (float *)d[0], (float *)d[1], (float *)d[2]);
     });
 }
@@ -464,14 +476,14 @@ int athena_mp_duvenaud_propagate_fwd_host(const athena_mp_graph *g, int32_t Fv, 
 int athena_mp_duvenaud_propagate_bwd_x_host(const athena_mp_graph *g, int32_t Fv, int32_t Fe, const float *grad, float *dx)
 {
     AMP_REQUIRE(g && Fv > 0 && Fe >= 0 && grad && dx, "duvenaud_propagate_bwd_x_host: bad arguments");
-    return staged({{grad, nullptr, fb(g->n_rows, Fv + Fe)}, {nullptr, dx, fb(g->n_cols, Fv)}}, [&](std::vector<void *> &d) {
+    return staged({{grad, nullptr, fb(g->n_rows, Fv + Fe)}, {nullptr, dx, fb(g->n_cols, Fv), true}}, [&](std::vector<void *> &d) {
         return athena_mp_duvenaud_propagate_bwd_x(g, Fv, Fe, (float *)d[0], (float *)d[1]);
     });
 }
 int athena_mp_duvenaud_propagate_bwd_e_host(const athena_mp_graph *g, int32_t Fv, int32_t Fe, const float *grad, float *de)
 {
     AMP_REQUIRE(g && Fv > 0 && Fe > 0 && grad && de, "duvenaud_propagate_bwd_e_host: bad arguments");
-    return staged({{grad, nullptr, fb(g->n_rows, Fv + Fe)}, {nullptr, de, fb(g->n_edge_cols, Fe)}}, [&](std::vector<void *> &d) {
+    return staged({{grad, nullptr, fb(g->n_rows, Fv + Fe)}, {nullptr, de, fb(g->n_edge_cols, Fe), true}}, [&](std::vector<void *> &d) {
         return athena_mp_duvenaud_propagate_bwd_e(g, Fv, Fe, (float *)d[0], (float *)d[1]);
     });
 }
@@ -488,7 +500,7 @@ int athena_mp_duvenaud_update_bwd_a_host(const athena_mp_graph *g, int32_t Fi, i
                                          const float *grad, const float *w, float *da)
 {
     AMP_REQUIRE(g && Fi > 0 && Fo > 0 && mx >= mn && grad && w && da, "duvenaud_update_bwd_a_host: bad arguments");
-    return staged({{grad, nullptr, fb(g->n_rows, Fo)}, {w, nullptr, fb((int64_t)Fi * Fo, mx - mn + 1)}, {nullptr, da, fb(g->n_rows, Fi)}},
+    return staged({{grad, nullptr, fb(g->n_rows, Fo)}, {w, nullptr, fb((int64_t)Fi * Fo, mx - mn + 1)}, {nullptr, da, fb(g->n_rows, Fi), true}},
                   [&](std::vector<void *> &d) {
                       return athena_mp_duvenaud_update_bwd_a(g, Fi, Fo, mn, mx, (float *)d[0], (float *)d[1], (float *)d[2]);
                   });
@@ -497,7 +509,7 @@ int athena_mp_duvenaud_update_bwd_w_host(const athena_mp_graph *g, int32_t Fi, i
                                          const float *grad, const float *a, float *dw)
 {
     AMP_REQUIRE(g && Fi > 0 && Fo > 0 && mx >= mn && grad && a && dw, "duvenaud_update_bwd_w_host: bad arguments");
-    return staged({{grad, nullptr, fb(g->n_rows, Fo)}, {a, nullptr, fb(g->n_rows, Fi)}, {nullptr, dw, fb((int64_t)Fi * Fo, mx - mn + 1)}},
+    return staged({{grad, nullptr, fb(g->n_rows, Fo)}, {a, nullptr, fb(g->n_rows, Fi)}, {nullptr, dw, fb((int64_t)Fi * Fo, mx - mn + 1), true}},
                   [&](std::vector<void *> &d) {
                       return athena_mp_duvenaud_update_bwd_w(g, Fi, Fo, mn, mx, (float *)d[0], (float *)d[1], (float *)d[2]);
                   });
@@ -517,7 +529,7 @@ int athena_mp_softmax_segsum_bwd_host(int32_t O, int64_t N, int32_t S, const int
 {
     AMP_REQUIRE(O > 0 && N >= 0 && S > 0 && seg && p && gout && dlogits, "softmax_segsum_bwd_host: bad arguments");
     return staged({{seg, nullptr, sizeof(int32_t) * (size_t)(S + 1)}, {p, nullptr, fb(N, O)}, {gout, nullptr, fb(S, O)},
-                   {nullptr, dlogits, fb(N, O)}},
+                   {nullptr, dlogits, fb(N, O), true}},
                   [&](std::vector<void *> &d) {
                       return athena_mp_softmax_segsum_bwd(O, N, S, (int32_t *)d[0], (float *)d[1], (float *)d[2], (float *)d[3]);
                   });
@@ -540,7 +552,7 @@ int athena_mp_gno_aggregate_bwd_x_host(const athena_mp_graph *g, int32_t d, int3
 {
     AMP_REQUIRE(g && d > 0 && H > 0 && Fi > 0 && Fo > 0 && theta && coords && grad && dx, "gno_aggregate_bwd_x_host: bad arguments");
     return staged({{theta, nullptr, sizeof(float) * gno_theta_floats(d, H, Fi, Fo)}, {coords, nullptr, fb(g->n_edge_cols, d)},
-                   {grad, nullptr, fb(g->n_rows, Fo)}, {nullptr, dx, fb(g->n_cols, Fi)}},
+                   {grad, nullptr, fb(g->n_rows, Fo)}, {nullptr, dx, fb(g->n_cols, Fi), true}},
                   [&](std::vector<void *> &p) {
                       return athena_mp_gno_aggregate_bwd_x(g, d, H, Fi, Fo, (float *)p[0], (float *)p[1], (float *)p[2], (float *)p[3]);
                   });
@@ -553,7 +565,7 @@ int athena_mp_gno_aggregate_bwd_theta_host(const athena_mp_graph *g, int32_t d, 
                 "gno_aggregate_bwd_theta_host: bad arguments");
     const size_t tb = sizeof(float) * gno_theta_floats(d, H, Fi, Fo);
     return staged({{theta, nullptr, tb}, {coords, nullptr, fb(g->n_edge_cols, d)}, {x, nullptr, fb(g->n_cols, Fi)},
-                   {grad, nullptr, fb(g->n_rows, Fo)}, {nullptr, dtheta, tb}},
+                   {grad, nullptr, fb(g->n_rows, Fo)}, {nullptr, dtheta, tb, true}},
                   [&](std::vector<void *> &p) {
                       return athena_mp_gno_aggregate_bwd_theta(g, d, H, Fi, Fo, (float *)p[0], (float *)p[1], (float *)p[2],
                                                                (float *)p[3], (float *)p[4]);
@@ -566,7 +578,7 @@ int athena_mp_gno_aggregate_bwd_coords_host(const athena_mp_graph *g, int32_t d,
     AMP_REQUIRE(g && d > 0 && H > 0 && Fi > 0 && Fo > 0 && theta && coords && x && grad && dcoords,
                 "gno_aggregate_bwd_coords_host: bad arguments");
     return staged({{theta, nullptr, sizeof(float) * gno_theta_floats(d, H, Fi, Fo)}, {coords, nullptr, fb(g->n_edge_cols, d)},
-                   {x, nullptr, fb(g->n_cols, Fi)}, {grad, nullptr, fb(g->n_rows, Fo)}, {nullptr, dcoords, fb(g->n_edge_cols, d)}},
+                   {x, nullptr, fb(g->n_cols, Fi)}, {grad, nullptr, fb(g->n_rows, Fo)}, {nullptr, dcoords, fb(g->n_edge_cols, d), true}},
                   [&](std::vector<void *> &p) {
                       return athena_mp_gno_aggregate_bwd_coords(g, d, H, Fi, Fo, (float *)p[0], (float *)p[1], (float *)p[2],
                                                                 (float *)p[3], (float *)p[4]);
@@ -604,7 +616,7 @@ int athena_mp_duvenaud_readout_bwd_host(int64_t N, int32_t Fv, int32_t O, int32_
                 "duvenaud_readout_bwd_host: bad arguments");
     return staged({{seg, nullptr, sizeof(int32_t) * (size_t)(S + 1)}, {z, nullptr, fb(N, Fv)}, {R, nullptr, fb(O, Fv)},
                    {p, nullptr, fb(N, O)}, {gout, nullptr, fb(S, O)}, {dz_next, nullptr, dz_next ? fb(N, Fv) : 0},
-                   {nullptr, dc, fb(N, Fv)}, {accumulate ? dR : nullptr, dR, fb(O, Fv)}},
+                   {nullptr, dc, fb(N, Fv), true}, {accumulate ? dR : nullptr, dR, fb(O, Fv), true}},
                   [&](std::vector<void *> &d) {
                       return athena_mp_duvenaud_readout_bwd(N, Fv, O, S, (int32_t *)d[0], (float *)d[1], (float *)d[2],
                                                             (float *)d[3], (float *)d[4], dz_next ? (float *)d[5] : nullptr,
@@ -620,7 +632,7 @@ int athena_mp_softmax_fwd_host(int64_t N, int32_t F, const float *z, float *y)
 int athena_mp_softmax_bwd_host(int64_t N, int32_t F, const float *y, const float *g, float *dz)
 {
     AMP_REQUIRE(N >= 0 && F > 0 && (N == 0 || (y && g && dz)), "softmax_bwd_host: bad arguments");
-    return staged({{y, nullptr, fb(N, F)}, {g, nullptr, fb(N, F)}, {nullptr, dz, fb(N, F)}}, [&](std::vector<void *> &d) {
+    return staged({{y, nullptr, fb(N, F)}, {g, nullptr, fb(N, F)}, {nullptr, dz, fb(N, F), true}}, [&](std::vector<void *> &d) {
         return athena_mp_softmax_bwd(N, F, (float *)d[0], (float *)d[1], (float *)d[2]);
     });
 }
@@ -633,7 +645,7 @@ int athena_mp_swish_fwd_host(int64_t n, float beta, const float *x, float *y)
 int athena_mp_swish_bwd_host(int64_t n, float beta, const float *x, const float *g, float *dx)
 {
     AMP_REQUIRE(n >= 0 && (n == 0 || (x && g && dx)), "swish_bwd_host: bad arguments");
-    return staged({{x, nullptr, fb(n, 1)}, {g, nullptr, fb(n, 1)}, {nullptr, dx, fb(n, 1)}}, [&](std::vector<void *> &d) {
+    return staged({{x, nullptr, fb(n, 1)}, {g, nullptr, fb(n, 1)}, {nullptr, dx, fb(n, 1), true}}, [&](std::vector<void *> &d) {
         return athena_mp_swish_bwd(n, beta, (float *)d[0], (float *)d[1], (float *)d[2]);
     });
 }
@@ -649,7 +661,7 @@ int athena_mp_activation_param_bwd_host(int32_t kind, int64_t n, float scale, fl
                                         const float *g, float *dx)
 {
     AMP_REQUIRE(n >= 0 && (n == 0 || (x && g && dx)), "activation_param_bwd_host: bad arguments");
-    return staged({{x, nullptr, fb(n, 1)}, {g, nullptr, fb(n, 1)}, {nullptr, dx, fb(n, 1)}}, [&](std::vector<void *> &d) {
+    return staged({{x, nullptr, fb(n, 1)}, {g, nullptr, fb(n, 1)}, {nullptr, dx, fb(n, 1), true}}, [&](std::vector<void *> &d) {
         return athena_mp_activation_param_bwd(kind, n, scale, p0, p1, (float *)d[0], (float *)d[1], (float *)d[2]);
     });
 }
@@ -691,7 +703,7 @@ int athena_mp_duvenaud_update_bwd_pair_host(const athena_mp_graph *g, int32_t Fi
     if (S.matches(g, dims, st) && S.ready[which]) {
         S.ready[which] = false;
         ++g_pair_handed;
-        return staged({{nullptr, out, bytes[which]}}, [&](std::vector<void *> &d) {
+        return staged({{nullptr, out, bytes[which], true}}, [&](std::vector<void *> &d) {
             AMP_HIP(hipMemcpyAsync(d[0], S.dev[which], bytes[which], hipMemcpyDeviceToDevice, stream()));
             return 0;
         });
@@ -701,7 +713,7 @@ int athena_mp_duvenaud_update_bwd_pair_host(const athena_mp_graph *g, int32_t Fi
     if (S.reserve(other, bytes[other])) return 1;
     if (has_act && S.reserve(2, fb(N, Fo))) return 1;   // dc = act'(z) * grad
     const int rc = staged({{grad, nullptr, fb(N, Fo)}, {a, nullptr, fb(N, Fi)}, {w, nullptr, bytes[1]},
-                           {has_act ? z_or_null : nullptr, nullptr, has_act ? fb(N, Fo) : 0}, {nullptr, out, bytes[which]}},
+                           {has_act ? z_or_null : nullptr, nullptr, has_act ? fb(N, Fo) : 0}, {nullptr, out, bytes[which], true}},
                           [&](std::vector<void *> &d) {
                               const float *dc = (const float *)d[0];
                               if (has_act) {
@@ -741,7 +753,7 @@ int athena_mp_gno_aggregate_bwd_pair_host(const athena_mp_graph *g, int32_t d, i
     if (S.matches(g, dims, st) && S.ready[which]) {
         S.ready[which] = false;
         ++g_pair_handed;
-        return staged({{nullptr, out, bytes[which]}}, [&](std::vector<void *> &p) {
+        return staged({{nullptr, out, bytes[which], true}}, [&](std::vector<void *> &p) {
             AMP_HIP(hipMemcpyAsync(p[0], S.dev[which], bytes[which], hipMemcpyDeviceToDevice, stream()));
             return 0;
         });
@@ -750,7 +762,7 @@ int athena_mp_gno_aggregate_bwd_pair_host(const athena_mp_graph *g, int32_t d, i
     for (int k = 0; k < 2; ++k)
         if (k != which && S.reserve(k, bytes[k])) return 1;
     const int rc = staged({{theta, nullptr, tb}, {coords, nullptr, bytes[2]}, {x, nullptr, fb(g->n_cols, Fi)},
-                           {grad, nullptr, fb(g->n_rows, Fo)}, {nullptr, out, bytes[which]}},
+                           {grad, nullptr, fb(g->n_rows, Fo)}, {nullptr, out, bytes[which], true}},
                           [&](std::vector<void *> &p) {
                               float *dx = which == 0 ? (float *)p[4] : (float *)S.dev[0];
                               float *dth = which == 1 ? (float *)p[4] : (float *)S.dev[1];

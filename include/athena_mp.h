@@ -613,6 +613,9 @@ int athena_mp_shard_edge_reduce(athena_mp_shard *s, int32_t F, float *e_dev);
  * call stays in HBM, registered under its host array's (address, byte length), and a later *_host call that receives the
  * same array as an input uses the device copy: a chain of HIP ops moves its first input up once and nothing else until
  * athena_mp_resident_flush(host_ptr) materialises an array at the edge of the HIP island (NULL: all of them).
+ * FORWARD results park; the outputs of the REVERSE entry points (every *_bwd_*_host, *_dw_host, *_dx_host and the *_pair_host
+ * calls) are always copied home as well: they are the partials diffstruc's grad_reverse accumulates with host arithmetic the
+ * moment a get_partial_*_val callback returns -- inside the island only as far as their INPUTS go.
  * Safety: an array whose only valid copy is on the device carries a 16-byte sentinel at both ends of its host storage; if
  * host code wrote it (or the allocator handed the address to another array) the sentinel is gone and the host content is
  * uploaded instead -- and a flush (explicit, forced by an overlapping argument, or athena_mp_resident_mode(0)) then leaves the
