@@ -33,11 +33,10 @@ module athena_mp__hip_layers
   use athena__diffstruc_extd, only: add_bias
   use athena_mp_c
   use athena_mp__hip_ops, only: duvenaud_propagate_hip, duvenaud_update_hip, gno_kernel_hip, gno_aggregate_hip, &
-       handle_of, n_handle
+       duvenaud_update_act_readout_hip, get_partial_readout_softmax_hip_z_val, get_partial_readout_softmax_hip_weight_val
   implicit none
   private
   public :: hip_duvenaud_msgpass_layer_type, hip_graph_nop_layer_type
-  public :: duvenaud_update_act_readout_hip
 
   type, extends(msgpass_layer_type) :: hip_duvenaud_msgpass_layer_type
      integer :: min_vertex_degree = 1
@@ -161,111 +160,6 @@ contains
     end do
     call acquire_handles(graph, this%handle, "set_graph (duvenaud)")
   end subroutine set_graph_hip_duvenaud
-
-  function duvenaud_update_act_readout_hip(a, weight, readout_weight, p, graph_handle, min_degree, max_degree, &
-       num_outputs, act) result(c)
-    !! ONE launch for three statements of the reference: duvenaud_update (athena_diffstruc_extd_sub_duvenaud.f90:176-228), the
-    !! message activation (athena_duvenaud_msgpass_layer.f90:800-802) and the readout's per-vertex softmax(matmul(R, z))
-    !! (:842-849).  The result node stands where the ACTIVATION's node stands in the reference's tape: value z, left operand a,
-    !! right operand the bucketed weights; its partials are the update's, with the activation's factor act'(z) applied on the
-    !! device in the same call.  p%val receives softmax(R z) and is wired up as a node by the caller (it needs z where the layer
-    !! keeps it).
-    class(array_type), intent(in), target :: a, weight, readout_weight
-    type(array_type), intent(inout) :: p
-    type(c_ptr), intent(in) :: graph_handle
-    integer, intent(in) :: min_degree, max_degree, num_outputs
-    integer(c_int32_t), intent(in) :: act
-    type(array_type), pointer :: c
-    integer(c_int) :: rc
-    integer :: Fi, O, N
-
-    Fi = size(a%val, 1); N = size(a%val, 2)
-    O = size(readout_weight%val, 1) / num_outputs            ! params(T+t)%val(:,1) = R(O, F_v) flat
-    c => a%create_result([num_outputs, N])
-    if(allocated(p%val))then
-       if(any(shape(p%val) .ne. [O, N])) deallocate(p%val)
-    end if
-    if(.not.allocated(p%val)) allocate(p%val(O, N))
-    rc = athena_mp_duvenaud_update_readout_fwd_host(graph_handle, int(Fi, c_int32_t), int(num_outputs, c_int32_t), &
-         int(min_degree, c_int32_t), int(max_degree, c_int32_t), a%val, weight%val, act, c%val, int(O, c_int32_t), &
-         readout_weight%val, p%val)
-    if(rc .ne. 0) call stop_program("duvenaud_update_act_readout_hip: "//athena_mp_error_message())
-    c%indices = [transfer(graph_handle, [0]), Fi, num_outputs, min_degree, max_degree, int(act)]
-    c%get_partial_left_val => get_partial_update_act_hip_val
-    c%get_partial_right_val => get_partial_update_act_hip_weight_val
-    if(a%requires_grad .or. weight%requires_grad)then
-       c%requires_grad = .true.
-       c%is_forward = a%is_forward .or. weight%is_forward
-       c%operation = 'duvenaud_update_act'
-       c%left_operand => a
-       c%right_operand => weight
-       c%owns_left_operand = a%is_temporary
-       c%owns_right_operand = weight%is_temporary
-    end if
-  end function duvenaud_update_act_readout_hip
-
-  pure subroutine get_partial_update_act_hip_val(this, upstream_grad, output)
-    !! da = ((act'(z) * g)^T W_d) / d  -- :284-324 behind the activation's reverse.  grad_reverse asks this node for its two
-    !! partials one after the other; athena_mp_duvenaud_update_bwd produces both from ONE pass over the gradient rows.  The
-    !! pair entry point runs that pass on the first request, returns the partial asked for and parks the other on the device;
-    !! the second request -- same handle, same shapes, same CONTENT of (upstream_grad, z, a, weights) -- is served from there.
-    class(array_type), intent(in) :: this
-    real(real32), dimension(:,:), intent(in) :: upstream_grad
-    real(real32), dimension(:,:), intent(out) :: output
-    integer(c_int) :: rc
-    rc = athena_mp_duvenaud_update_bwd_pair_host(handle_of(this%indices), int(this%indices(n_handle + 1), c_int32_t), &
-         int(this%indices(n_handle + 2), c_int32_t), int(this%indices(n_handle + 3), c_int32_t), &
-         int(this%indices(n_handle + 4), c_int32_t), int(this%indices(n_handle + 5), c_int32_t), this%val, upstream_grad, &
-         this%left_operand%val, this%right_operand%val, 0_c_int32_t, output)
-    if(rc .ne. 0) error stop "duvenaud_update_act_readout_hip: reverse pass (a) failed"
-  end subroutine get_partial_update_act_hip_val
-
-  pure subroutine get_partial_update_act_hip_weight_val(this, upstream_grad, output)
-    !! dW_d += (act'(z) * g) a^T / d  (:326-368): the other half of the same device pass (which = 1)
-    class(array_type), intent(in) :: this
-    real(real32), dimension(:,:), intent(in) :: upstream_grad
-    real(real32), dimension(:,:), intent(out) :: output
-    integer(c_int) :: rc
-    rc = athena_mp_duvenaud_update_bwd_pair_host(handle_of(this%indices), int(this%indices(n_handle + 1), c_int32_t), &
-         int(this%indices(n_handle + 2), c_int32_t), int(this%indices(n_handle + 3), c_int32_t), &
-         int(this%indices(n_handle + 4), c_int32_t), int(this%indices(n_handle + 5), c_int32_t), this%val, upstream_grad, &
-         this%left_operand%val, this%right_operand%val, 1_c_int32_t, output)
-    if(rc .ne. 0) error stop "duvenaud_update_act_readout_hip: reverse pass (weight) failed"
-  end subroutine get_partial_update_act_hip_weight_val
-
-  pure subroutine get_partial_readout_softmax_hip_z_val(this, upstream_grad, output)
-    !! the node p = softmax(matmul(R, z)) (athena_duvenaud_msgpass_layer.f90:842-849 as one node): partial w.r.t. z.
-    !!   dl = p * (g - <g, p>) per vertex  (softmax reverse at the output, athena_diffstruc_extd_sub.f90:331-379)
-    !!   dz = R^T dl                       (matmul reverse w.r.t. its right operand)
-    class(array_type), intent(in) :: this
-    real(real32), dimension(:,:), intent(in) :: upstream_grad
-    real(real32), dimension(:,:), intent(out) :: output
-    real(real32), allocatable :: dl(:,:)
-    integer(c_int) :: rc
-    integer :: O, N
-    O = size(this%val, 1); N = size(this%val, 2)
-    allocate(dl(O, N))
-    rc = athena_mp_softmax_bwd_host(int(N, c_int64_t), int(O, c_int32_t), this%val, upstream_grad, dl)
-    if(rc .eq. 0) rc = athena_mp_gemm_dx_host(int(N, c_int64_t), int(size(output, 1), c_int32_t), int(O, c_int32_t), dl, &
-         this%right_operand%val, output)
-    if(rc .ne. 0) error stop "duvenaud readout (hip): reverse pass (z) failed"
-  end subroutine get_partial_readout_softmax_hip_z_val
-
-  pure subroutine get_partial_readout_softmax_hip_weight_val(this, upstream_grad, output)
-    !! partial w.r.t. the readout matrix: dR = dl z^T, flat as params(T+t)%val(:,1) = R(O, F_v)
-    class(array_type), intent(in) :: this
-    real(real32), dimension(:,:), intent(in) :: upstream_grad
-    real(real32), dimension(:,:), intent(out) :: output
-    real(real32), allocatable :: dl(:,:)
-    integer(c_int) :: rc
-    integer :: O, N
-    O = size(this%val, 1); N = size(this%val, 2)
-    allocate(dl(O, N))
-    rc = athena_mp_softmax_bwd_host(int(N, c_int64_t), int(O, c_int32_t), this%val, upstream_grad, dl)
-    if(rc .eq. 0) rc = athena_mp_gemm_dw_host(int(N, c_int64_t), int(size(this%left_operand%val, 1), c_int32_t), &
-         int(O, c_int32_t), this%left_operand%val, dl, output)
-    if(rc .ne. 0) error stop "duvenaud readout (hip): reverse pass (weight) failed"
-  end subroutine get_partial_readout_softmax_hip_weight_val
 
   subroutine update_message_hip_duvenaud(this, input)
     !! update_message_duvenaud, athena_duvenaud_msgpass_layer.f90:755-813

@@ -1,6 +1,7 @@
 !! The drop-in shim of INTEGRATION.md sections 2-3, as ONE compilable source: what a maintainer adds to an athena
 !! checkout to run the Kipf message-passing layer on libathena_mp.so.
-!!   * kipf_propagate_hip      an autodiff op with the contract of kipf_propagate
+!!   * kipf_propagate_hip      (in hip_duvenaud_gno_ops.f90, module athena_mp__hip_ops, with the other layers' ops: that file is
+!!                             also linked and run on the GPU) an autodiff op with the contract of kipf_propagate
 !!                             (athena_diffstruc_extd_sub_kipf.f90:7-59): result node from create_result, value from the
 !!                             HIP kernel, `pure` get_partial_left_val callback (the coefficient-free scatter of :85-111)
 !!   * hip_kipf_msgpass_layer_type   extends(msgpass_layer_type) (athena_msgpass_layer.f90:19-76): set_graph builds the
@@ -16,6 +17,7 @@ module athena_mp__hip_kipf
   use diffstruc, only: array_type, matmul
   use athena__msgpass_layer, only: msgpass_layer_type
   use athena_mp_c
+  use athena_mp__hip_ops, only: kipf_propagate_hip
   implicit none
   private
   public :: kipf_propagate_hip, hip_kipf_msgpass_layer_type
@@ -32,43 +34,6 @@ module athena_mp__hip_kipf
   end type hip_kipf_msgpass_layer_type
 
 contains
-
-  function kipf_propagate_hip(vertex_features, graph_handle) result(c)
-    !! HIP-backed kipf_propagate: c%val = A^ x on the device graph `graph_handle`
-    class(array_type), intent(in), target :: vertex_features
-    type(c_ptr), intent(in) :: graph_handle
-    type(array_type), pointer :: c
-    integer(c_int) :: rc
-
-    c => vertex_features%create_result()
-    rc = athena_mp_kipf_propagate_fwd_host(graph_handle, int(size(vertex_features%val, 1), c_int32_t), &
-         vertex_features%val, c%val)
-    if(rc .ne. 0) call stop_program("kipf_propagate_hip: "//athena_mp_error_message())
-    ! the handle travels with the node in place of copies of adj_ia / adj_ja (athena_diffstruc_extd_sub_kipf.f90:48-49)
-    c%indices = transfer(graph_handle, [0])
-    c%get_partial_left_val => get_partial_kipf_propagate_hip_left_val
-    if(vertex_features%requires_grad)then
-       c%requires_grad = .true.
-       c%is_forward = vertex_features%is_forward
-       c%operation = 'kipf_propagate'
-       c%left_operand => vertex_features
-       c%owns_left_operand = vertex_features%is_temporary
-    end if
-  end function kipf_propagate_hip
-
-  pure subroutine get_partial_kipf_propagate_hip_left_val(this, upstream_grad, output)
-    !! get_partial_kipf_propagate_left_val (:85-111): the reference's coefficient-free scatter (exact = 0).
-    !! `pure`, as diffstruc's callback interface demands -- legal because the bind(C) interface is declared pure.
-    class(array_type), intent(in) :: this
-    real(real32), dimension(:,:), intent(in) :: upstream_grad
-    real(real32), dimension(:,:), intent(out) :: output
-    type(c_ptr) :: graph_handle
-    integer(c_int) :: rc
-    graph_handle = transfer(this%indices, graph_handle)
-    rc = athena_mp_kipf_propagate_bwd_host(graph_handle, int(size(upstream_grad, 1), c_int32_t), &
-         upstream_grad, output, 0_c_int32_t)
-    if(rc .ne. 0) error stop "kipf_propagate_hip: reverse pass failed"
-  end subroutine get_partial_kipf_propagate_hip_left_val
 
   subroutine set_graph_hip_kipf(this, graph)
     !! set_graph_msgpass (athena_msgpass_layer_sub.f90:144-174) + device handles, rebuilt only when the CSR changed

@@ -16,10 +16,10 @@ for f in athena_misc_types athena_diffstruc_extd athena_clipper athena_base_laye
   "$FC" -cpp -c "$R/$f.f90" -o "$f.o"          # athena's real modules (interfaces; bodies live in submodules)
 done
 "$FC" -cpp -c "$ROOT/athena_amd/fortran/athena_mp_c.f90" -o athena_mp_c.o
-"$FC" -cpp -c "$HERE/hip_kipf_msgpass.f90" -o hip_kipf_msgpass.o
-ls athena_mp__hip_kipf.mod >/dev/null
-"$FC" -cpp -c "$HERE/hip_duvenaud_gno_ops.f90" -o hip_duvenaud_gno_ops.o   # the Duvenaud and GNO autodiff ops
+"$FC" -cpp -c "$HERE/hip_duvenaud_gno_ops.f90" -o hip_duvenaud_gno_ops.o   # the autodiff ops of all three layers
 ls athena_mp__hip_ops.mod >/dev/null
+"$FC" -cpp -c "$HERE/hip_kipf_msgpass.f90" -o hip_kipf_msgpass.o           # the Kipf layer TYPE
+ls athena_mp__hip_kipf.mod >/dev/null
 # the two layer TYPES that extend(msgpass_layer_type): Duvenaud (update_message + update_readout, the fused entry points bound
 # inside the tape) and graph_nop (one-call reverse pass, forwarded edge geometry) -- INTEGRATION.md section 3
 "$FC" -cpp -c "$HERE/hip_duvenaud_gno_layers.f90" -o hip_duvenaud_gno_layers.o

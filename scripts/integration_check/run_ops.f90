@@ -19,13 +19,15 @@ program run_ops
   call duvenaud_case(n=40, fv=8, fe=2, fo=4, resident=.false.)          ! VALU kernels
   call duvenaud_case(n=3000, fv=64, fe=8, fo=64, resident=.false.)      ! the fused MFMA reverse kernel (configs[2]'s widths)
   call duvenaud_case(n=3000, fv=64, fe=8, fo=64, resident=.true.)       ! ... with every %val resident in HBM between the calls
+  call kipf_case(n=500, f=32)
+  call fused_duvenaud_case(n=3000, fv=64, fe=8, fo=64, no=10)           ! ONE launch for update + sigmoid + softmax(R z): z and p as nodes
   call gno_case(n=600, d=3, h=64, fi=64, fo=64)                         ! the one-contraction reverse pass
   call gno_case(n=50, d=2, h=7, fi=5, fo=9)                             ! generic shapes (separate entry points behind the pair)
   if(athena_mp_pair_stats(f1, h1) .ne. 0) call fail("pair_stats")
   fused_total = f1 - f0
   handed_total = h1 - h0
-  if(fused_total .ne. 5 .or. handed_total .ne. 5) then
-     write(0, *) "pair slots: fused passes", fused_total, " hand-overs", handed_total, " (expected 5 and 5)"
+  if(fused_total .ne. 7 .or. handed_total .ne. 7) then
+     write(0, *) "pair slots: fused passes", fused_total, " hand-overs", handed_total, " (expected 7 and 7)"
      error stop 1
   end if
   if(athena_mp_finalize() .ne. 0) call fail("finalize")
@@ -125,6 +127,77 @@ contains
     call close_to(e%grad%val, de, "duvenaud: de through the tape")
     if(athena_mp_graph_release(handle) .ne. 0) call fail("graph_release")
   end subroutine duvenaud_case
+
+  subroutine kipf_case(n, f)
+    integer, intent(in) :: n, f
+    integer, allocatable :: ia(:), ja(:,:)
+    integer :: ne
+    type(c_ptr) :: handle
+    type(array_type), target :: x
+    type(array_type), pointer :: c
+    real(real32), allocatable :: up(:,:), dx(:,:)
+
+    call chain_graph(n, ia, ja, ne)
+    ! as set_graph_hip_kipf acquires it: the handle carries graph%num_edges though Kipf reads no edge features
+    if(athena_mp_graph_acquire(int(n, c_int32_t), int(size(ja, 2), c_int64_t), ia, ja, int(ne, c_int32_t), handle) .ne. 0) call fail("graph_acquire")
+    allocate(x%val(f, n), up(f, n), dx(f, n))
+    call fill(x%val, 11); call fill(up, 12)
+    x%requires_grad = .true.; x%is_temporary = .false.
+    c => kipf_propagate_hip(x, handle)
+    call c%grad_reverse(up)
+    if(athena_mp_kipf_propagate_bwd_host(handle, int(f, c_int32_t), up, dx, 0_c_int32_t) .ne. 0) call fail("kipf_propagate_bwd_host")
+    call close_to(x%grad%val, dx, "kipf: dx through the tape")
+    if(athena_mp_graph_release(handle) .ne. 0) call fail("graph_release")
+  end subroutine kipf_case
+
+  subroutine fused_duvenaud_case(n, fv, fe, fo, no)
+    !! what hip_duvenaud_msgpass_layer_type's fused branch builds per time step: propagate -> ONE launch for update + sigmoid +
+    !! the readout's softmax(matmul(R, z)); z and p are both nodes; the gradient reaches z twice (directly, and through p)
+    integer, intent(in) :: n, fv, fe, fo, no
+    integer, allocatable :: ia(:), ja(:,:)
+    integer :: ne, mn, mx, fi
+    type(c_ptr) :: handle
+    type(array_type), target :: x, e, w, r, p
+    type(array_type), pointer :: a, z
+    real(real32), allocatable :: gz(:,:), gp(:,:), dl(:,:), dzp(:,:), dc1(:,:), dc2(:,:), da1(:,:), da2(:,:), dw1(:,:), dw2(:,:), dr(:,:)
+    integer(c_int) :: rc
+    integer(c_int32_t) :: sig
+
+    mn = 1; mx = 4; fi = fv + fe; sig = ATHENA_MP_ACT_SIGMOID
+    call chain_graph(n, ia, ja, ne)
+    if(athena_mp_graph_acquire(int(n, c_int32_t), int(size(ja, 2), c_int64_t), ia, ja, int(ne, c_int32_t), handle) .ne. 0) call fail("graph_acquire")
+    allocate(x%val(fv, n), e%val(fe, ne), w%val(fo * fi * (mx - mn + 1), 1), r%val(no * fo, 1), gz(fo, n), gp(no, n))
+    call fill(x%val, 21); call fill(e%val, 22); call fill(w%val, 23); call fill(r%val, 24); call fill(gz, 25); call fill(gp, 26)
+    x%requires_grad = .true.; e%requires_grad = .true.; w%requires_grad = .true.; r%requires_grad = .true.
+    x%is_temporary = .false.; e%is_temporary = .false.; w%is_temporary = .false.; r%is_temporary = .false.
+    a => duvenaud_propagate_hip(x, e, handle)
+    z => duvenaud_update_act_readout_hip(a, w, r, p, handle, mn, mx, fo, sig)
+    ! p = softmax(matmul(R, z)) holds its value already: wire it up as the layer type does
+    p%get_partial_left_val => get_partial_readout_softmax_hip_z_val
+    p%get_partial_right_val => get_partial_readout_softmax_hip_weight_val
+    p%left_operand => z
+    p%right_operand => r
+    p%requires_grad = .true.
+    call z%grad_reverse(gz)          ! the gradient arriving from the next time step
+    call p%grad_reverse(gp)          ! ... and the readout's: reaches z (and through it a, w, x, e) a second time, and R
+    ! expected, from the op-granular entry points
+    allocate(dl(no, n), dzp(fo, n), dc1(fo, n), dc2(fo, n), da1(fi, n), da2(fi, n), dw1(size(w%val, 1), 1), dw2(size(w%val, 1), 1), dr(no * fo, 1))
+    rc = athena_mp_softmax_bwd_host(int(n, c_int64_t), int(no, c_int32_t), p%val, gp, dl)
+    if(rc .eq. 0) rc = athena_mp_gemm_dx_host(int(n, c_int64_t), int(fo, c_int32_t), int(no, c_int32_t), dl, r%val, dzp)
+    if(rc .eq. 0) rc = athena_mp_gemm_dw_host(int(n, c_int64_t), int(fo, c_int32_t), int(no, c_int32_t), z%val, dl, dr)
+    if(rc .eq. 0) rc = athena_mp_activation_bwd_host(sig, int(fo, c_int64_t) * n, z%val, gz, dc1)
+    if(rc .eq. 0) rc = athena_mp_activation_bwd_host(sig, int(fo, c_int64_t) * n, z%val, dzp, dc2)
+    if(rc .eq. 0) rc = athena_mp_duvenaud_update_bwd_a_host(handle, int(fi, c_int32_t), int(fo, c_int32_t), int(mn, c_int32_t), int(mx, c_int32_t), dc1, w%val, da1)
+    if(rc .eq. 0) rc = athena_mp_duvenaud_update_bwd_a_host(handle, int(fi, c_int32_t), int(fo, c_int32_t), int(mn, c_int32_t), int(mx, c_int32_t), dc2, w%val, da2)
+    if(rc .eq. 0) rc = athena_mp_duvenaud_update_bwd_w_host(handle, int(fi, c_int32_t), int(fo, c_int32_t), int(mn, c_int32_t), int(mx, c_int32_t), dc1, a%val, dw1)
+    if(rc .eq. 0) rc = athena_mp_duvenaud_update_bwd_w_host(handle, int(fi, c_int32_t), int(fo, c_int32_t), int(mn, c_int32_t), int(mx, c_int32_t), dc2, a%val, dw2)
+    if(rc .ne. 0) call fail("direct entry points (fused duvenaud case)")
+    call close_to(r%grad%val, dr, "fused duvenaud: dR through the tape")
+    call close_to(a%grad%val, da1 + da2, "fused duvenaud: da through the tape")
+    call close_to(w%grad%val, dw1 + dw2, "fused duvenaud: dW through the tape")
+    if(z%partial_calls .ne. 4 .or. p%partial_calls .ne. 2) call fail("fused duvenaud: callbacks per node")
+    if(athena_mp_graph_release(handle) .ne. 0) call fail("graph_release")
+  end subroutine fused_duvenaud_case
 
   subroutine gno_case(n, d, h, fi, fo)
     integer, intent(in) :: n, d, h, fi, fo

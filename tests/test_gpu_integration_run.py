@@ -17,4 +17,4 @@ def test_drop_in_ops_run_through_a_tape_from_fortran(dev):
         pytest.fail("scripts/integration_check/run_ops is not built: __graft_entry__.build() compiles it (amdflang)")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    assert "RUN_OPS_OK 5 5" in r.stdout, r.stdout[-500:]
+    assert "RUN_OPS_OK 7 7" in r.stdout, r.stdout[-500:]

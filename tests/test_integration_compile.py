@@ -30,8 +30,11 @@ def test_integration_shim_compiles_against_the_reference_modules():
     objs = os.path.join(ROOT, "build", "integration_check", "hip_duvenaud_gno_layers.o")
     syms = subprocess.run(["nm", objs], capture_output=True, text=True).stdout
     for needed in ("update_message_hip_duvenaud", "update_readout_hip_duvenaud", "update_message_hip_gno", "set_graph_hip_gno",
-                   "athena_mp_duvenaud_update_readout_fwd_host", "athena_mp_duvenaud_update_bwd_pair_host"):
+                   "duvenaud_update_act_readout_hip"):
         assert needed in syms, needed
+    # every autodiff op -- the fused ones included -- lives in the ops file, the one that is also linked and run on the GPU
     ops = subprocess.run(["nm", os.path.join(ROOT, "build", "integration_check", "hip_duvenaud_gno_ops.o")], capture_output=True,
                          text=True).stdout
-    assert "athena_mp_gno_aggregate_bwd_pair_host" in ops and "athena_mp_duvenaud_update_bwd_pair_host" in ops
+    for needed in ("athena_mp_gno_aggregate_bwd_pair_host", "athena_mp_duvenaud_update_bwd_pair_host",
+                   "athena_mp_duvenaud_update_readout_fwd_host", "athena_mp_kipf_propagate_fwd_host", "kipf_propagate_hip"):
+        assert needed in ops, needed
