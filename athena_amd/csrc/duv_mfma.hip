@@ -832,10 +832,20 @@ __global__ __launch_bounds__(256, (IT * OT > 20 ? 1 : 2)) void duv_bwd_wide_kern
     const float d = (float)(b + 1), inv = 1.0f / d;
     // W_d(o,i) flat o + Fo i == [i][o] rows of Fo floats -> LDS rows of pitch WP, zero beyond Fi / Fo
     {
+        // every load first, then every LDS write: written as load-then-store per element the loop took one memory latency per
+        // trip (10.9 us of a 530 us launch with all 512 workgroups in it at once, profiles/r05_c3_bwd_timeline.txt)
         const float *wd = W + (int64_t)b * Fi * Fo;
-        for (int e = threadIdx.x; e < 16 * IT * WP; e += 256) {
-            const int i = e / WP, o = e - i * WP;
-            wl[e] = (i < Fi && o < Fo) ? wd[(int64_t)i * Fo + o] : 0.0f;
+        constexpr int kTrips = (16 * IT * WP + 255) / 256;
+        float wv[kTrips];
+#pragma unroll
+        for (int t = 0; t < kTrips; ++t) {
+            const int e = threadIdx.x + 256 * t, i = e / WP, o = e - i * WP;
+            wv[t] = (i < Fi && o < Fo) ? wd[(int64_t)i * Fo + o] : 0.0f;
+        }
+#pragma unroll
+        for (int t = 0; t < kTrips; ++t) {
+            const int e = threadIdx.x + 256 * t;
+            if (e < 16 * IT * WP) wl[e] = wv[t];
         }
     }
     WideTail<IT> ta;
@@ -992,21 +1002,42 @@ __global__ __launch_bounds__(256, (IT * OT > 20 ? 1 : 2)) void duv_bwd_wide_kern
     }
 }
 
-// proportional split of `units` waves / workgroups over the buckets (every non-empty bucket gets >= 1)
+// split of at most `units` waves / workgroups over the buckets: every non-empty bucket gets >= 1, the rest go one by one to the
+// bucket whose units carry the most tiles (min-max).  Never more than `units` in total: the launches size `units` to what is
+// resident at once, and a workgroup beyond that starts when the first one ends.  (Round 5, per-block stamps of the fused reverse
+// launch at configs[2], profiles/r05_c3_bwd_timeline.txt: rounding the proportional share to the nearest gave the bucket of 335 tiles
+// one workgroup -- 84 tiles per wave against 72 -- and two workgroups beyond the 512 resident ones; the launch ended with them.)
 BucketSplit make_split(const athena_mp_graph *g, int units, int tiles_per_unit_step)
 {
     BucketSplit sp;
-    const int nb = (int)g->btile_off.size() - 1, nt = g->n_btiles;
+    const int nb = (int)g->btile_off.size() - 1;
     sp.n_buckets = nb;
+    int u[kMaxBuckets + 1], steps[kMaxBuckets + 1], tb[kMaxBuckets + 1], used = 0;
+    for (int b = 0; b < nb; ++b) {
+        tb[b] = g->btile_off[b + 1] - g->btile_off[b];
+        steps[b] = (tb[b] + tiles_per_unit_step - 1) / tiles_per_unit_step;   // units that can be kept busy
+        u[b] = tb[b] > 0 ? 1 : 0;
+        used += u[b];
+    }
+    // start from the floor of the proportional share, then hand out what is left
+    const int nt = g->n_btiles;
+    for (int b = 0; b < nb && nt > 0; ++b) {
+        const int share = (int)std::min<int64_t>(steps[b], ((int64_t)(units - used) * tb[b]) / nt);
+        if (share > 0) u[b] += std::min(share, steps[b] - u[b]);
+    }
+    used = 0;
+    for (int b = 0; b < nb; ++b) used += u[b];
+    while (used < units) {
+        int best = -1;
+        for (int b = 0; b < nb; ++b)
+            if (u[b] > 0 && u[b] < steps[b] && (best < 0 || (int64_t)tb[b] * u[best] > (int64_t)tb[best] * u[b])) best = b;
+        if (best < 0) break;
+        ++u[best];
+        ++used;
+    }
     sp.unit_off[0] = 0;
     for (int b = 0; b < nb; ++b) {
-        const int tb = g->btile_off[b + 1] - g->btile_off[b];
-        int u = 0;
-        if (tb > 0) {
-            const int steps = (tb + tiles_per_unit_step - 1) / tiles_per_unit_step;   // units that can be kept busy
-            u = (int)std::min<int64_t>(steps, std::max<int64_t>(1, ((int64_t)units * tb + nt / 2) / nt));
-        }
-        sp.unit_off[b + 1] = sp.unit_off[b] + u;
+        sp.unit_off[b + 1] = sp.unit_off[b] + u[b];
         sp.tile_off[b] = g->btile_off[b];
     }
     sp.tile_off[nb] = g->btile_off[nb];

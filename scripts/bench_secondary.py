@@ -118,6 +118,13 @@ def run_c3(dev, reps):
             "readout_bwd": N * 4 * (2 * Fv + O + 1) + S * 4 * O, "update_bwd_fused(w+a)": N * 4 * (2 * Fc + Fv),
             "propagate_bwd_x": N * 4 * Fc + nnz * 4 + N * 4 + N * 4 * Fv, "propagate_bwd_e": N * 4 * Fe + nnz * 8 + E * 4 * Fe}
     opsd = {k: hbm_op(t[k], comp[k], "compulsory" if k.startswith("propagate") else "tensors read + written once") for k in t}
+    # the two update launches are bound by the fp32 matrix pipe, not by their bytes (timing-only builds without any HBM traffic keep
+    # 0.48 of 0.54 ms, profiles/r05_c3_bwd_probe.txt): both fractions are reported, "bound" names the one that holds
+    for k, fl in (("update_sigmoid_readout_p(fused)", 2.0 * N * Fv * (Fc + O)), ("update_bwd_fused(w+a)", 4.0 * N * Fv * Fc)):
+        m = mfma_op(t[k], fl)
+        opsd[k]["hbm_frac"] = opsd[k].pop("frac")
+        opsd[k].update({"bound": "mfma", "frac": m["frac"], "TFLOPs": m["TFLOPs"], "TFLOP": m["TFLOP"],
+                        "flops_model": "2 x vertices x outputs x inputs per product, unpadded (the 16-wide fragments pad 72 to 80)"})
     # parity: the first 2 000 graphs are an exact sub-problem of every op (dW / dR sum over all vertices: a float64 device sum)
     NG = 2000
     nv = int(voff[NG]); ias = ia[:nv + 1]; jas = np.asfortranarray(ja[:, :ia[nv] - 1]); ne = int(jas[1].max())
