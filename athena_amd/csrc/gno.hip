@@ -1070,7 +1070,7 @@ __global__ __launch_bounds__(kPcThreads) void gno_stg_kernel(const int32_t *__re
     // tile class share ONE XCD's L2 -- 19.5 GB, L2 hit rate 66 % (profiles/r03_c4_gno_pmc_traffic.txt; 10.9 GB / 81 % in round 2's
     // A/B build: the eight drift apart over a launch, by how much varies).  The kernel is bound by its matrix and vector work,
     // not by either figure; the grouped order leaves the fabric to whatever
-    // runs beside it.  ATHENA_MP_GNO_STG_ORDER=spread restores round 2's mapping for A/B runs.
+    // runs beside it.  (Round 2's spread mapping was an A/B switch until round 5; docs/history/DESIGN_r01-r04.md.)
     const int pc = grouped ? blockIdx.x / nsub : blockIdx.x & 7, sub = grouped ? blockIdx.x % nsub : blockIdx.x >> 3;
     const int c = pc >> 1, kh = pc & 1;
     const int n_tiles = (n_rows + kPV - 1) / kPV;
@@ -2788,7 +2788,7 @@ int athena_mp_gno_aggregate_bwd(const athena_mp_graph *g, int32_t d, int32_t H, 
     // Order: the kernel MLP's launches (they write the partials) -> the gather of the partials and S^T g SIDE BY SIDE.  The two
     // share nothing but grad: the gather is a stream of 16-byte loads without LDS in 56 registers, S^T g leaves exactly that
     // many free per SIMD (3 waves x 152) and is bound by the matrix pipe, so the gather runs on the library's second stream in
-    // the slots S^T g cannot use.  ATHENA_MP_GNO_BWD_SERIAL keeps everything on the caller's stream (A/B switch).
+    // the slots S^T g cannot use (A/B against everything on the caller's stream: docs/history/DESIGN_r01-r04.md, round 4).
     if (int rc = gno_mlp_backward(g, d, H, Fi, Fo, theta, coords, x, grad, dth, dcoords, (float *)pxp, px_half, (const float *)cvp)) return rc;
     hipStream_t main_s = stream(), gs = main_s;
     hipEvent_t *ev = nullptr;
