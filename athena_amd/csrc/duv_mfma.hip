@@ -1002,6 +1002,282 @@ __global__ __launch_bounds__(256, (IT * OT > 20 ? 1 : 2)) void duv_bwd_wide_kern
     }
 }
 
+// ---- one time step of the layer's reverse pass in ONE launch: the readout's reverse folded into the update's ---------------
+//   dl[v,:]  = p[v,:] (gout[graph(v),:] - <gout[graph(v),:], p[v,:]>)        softmax over the outputs (athena_diffstruc_extd_sub.f90:309-313)
+//   dR(o,f) += dl[v,o] z[v,f]                                                the readout matmul's weight partial
+//   dc[v,f]  = act'(z[v,f]) (sum_o dl[v,o] R(o,f) + dz_next[v,f])            its input partial + the next step's dx, through the activation
+//   da, dW_d   from dc as in duv_bwd_wide_kernel                             (athena_diffstruc_extd_sub_duvenaud.f90:284-368)
+// readout_bwd_kernel + duv_bwd_wide_kernel move dc out (600 MB at configs[2]) and back in; the second one is bound by the matrix
+// pipe with HBM to spare, the first by its bytes.  Here a tile's z / dz_next / p rows arrive beside its a rows (bucket order, the
+// coalesced numbering), dc is formed in the z-fragment layout (lane (v, q): columns 16 ft + 4 q ..) and written straight into the
+// wave's LDS tile where the update's reverse expects the gradient rows.  One wave per SIMD (the two accumulator sets, 80 + 16
+// registers, beside four row streams): one workgroup per CU.  F_o = F_v = 64 only (OT = 4, no tail chunks on the z side).
+template <int ACT>
+__device__ __forceinline__ float duv_act_back(float y, float g)
+{
+    if constexpr (ACT == ATHENA_MP_ACT_RELU) return y > 0.0f ? g : 0.0f;
+    if constexpr (ACT == ATHENA_MP_ACT_SIGMOID) return g * y * (1.0f - y);
+    if constexpr (ACT == ATHENA_MP_ACT_TANH) return g * (1.0f - y * y);
+    return g;
+}
+
+template <int IT, int ACT, bool DIN>
+__global__ __launch_bounds__(256, 1) void duv_bwd_ro_kernel(BucketSplit sp, const int32_t *__restrict__ trows,
+                                                            const int32_t *__restrict__ trows_t, const int32_t *__restrict__ tgid,
+                                                            const float *__restrict__ A, int Fi, const float *__restrict__ Z,
+                                                            const float *__restrict__ DZ, const float *__restrict__ P,
+                                                            const float *__restrict__ GOUT, const float *__restrict__ R, int O,
+                                                            const float *__restrict__ W, float *__restrict__ DA,
+                                                            float *__restrict__ DAT, float *__restrict__ slabs,
+                                                            float *__restrict__ rslabs)
+{
+    constexpr int OT = 4, Fo = 64;
+    constexpr int AP = 16 * IT + 4, GP = 16 * OT + 4, ZP = 16 * OT + 4, DP = 20, FOP = 16 * OT, WP = 16 * OT + 4, TA = IT - 4;
+    constexpr int kW = 16 * IT * WP, kWave = 16 * (AP + GP + ZP + DP), kRed = 16 * IT * FOP, kRedR = 4 * Fo * 16;
+    static_assert(4 * kWave >= kRed + kRedR, "the reduction images overlay the waves' tiles");
+    __shared__ __attribute__((aligned(16))) float buf[kW + 4 * kWave];
+    float *wl = buf, *red = buf + kW, *redr = red + kRed;
+    const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4, wave = threadIdx.x >> 6;
+    float *al = red + wave * kWave, *gl = al + 16 * AP, *zt = gl + 16 * GP, *dll = zt + 16 * ZP;
+    int b = 0;
+    while ((int)blockIdx.x >= sp.unit_off[b + 1]) ++b;
+    const int nwg = sp.unit_off[b + 1] - sp.unit_off[b];
+    const int stride = 4 * nwg;
+    const int t0 = sp.tile_off[b] + 4 * ((int)blockIdx.x - sp.unit_off[b]) + wave, t1 = sp.tile_off[b + 1];
+    const int cnt = t0 < t1 ? (t1 - t0 + stride - 1) / stride : 0;
+    const float d = (float)(b + 1), inv = 1.0f / d;
+    {
+        const float *wd = W + (int64_t)b * Fi * Fo;
+        constexpr int kTrips = (16 * IT * WP + 255) / 256;
+        float wv[kTrips];
+#pragma unroll
+        for (int t = 0; t < kTrips; ++t) {
+            const int e = threadIdx.x + 256 * t, i = e / WP, o = e - i * WP;
+            wv[t] = (i < Fi && o < Fo) ? wd[(int64_t)i * Fo + o] : 0.0f;
+        }
+#pragma unroll
+        for (int t = 0; t < kTrips; ++t) {
+            const int e = threadIdx.x + 256 * t;
+            if (e < 16 * IT * WP) wl[e] = wv[t];
+        }
+    }
+    // A operand of the dz product: (ft, r) -> R(o = 4 q + r, f = 16 ft + n), R flat o + O f (readout.hip)
+    float Ra[OT][4];
+#pragma unroll
+    for (int ft = 0; ft < OT; ++ft)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ra[ft][r] = 4 * q + r < O ? R[(size_t)(16 * ft + n) * O + 4 * q + r] : 0.0f;
+    WideTail<IT> ta;
+    ta.init(lane, Fi);
+    for (int e = lane; e < kWave; e += 64) al[e] = 0.0f;    // tail columns stay zero
+    __syncthreads();
+
+    v4f acc[IT][OT], accR[OT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i)
+#pragma unroll
+        for (int o = 0; o < OT; ++o) acc[i][o] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int o = 0; o < OT; ++o) accR[o] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+
+    struct Ids {
+        v4i f;                                          // rows 4 i + q of the tile, padding slots negative
+        int a[TA > 0 ? TA : 1];
+        int rn, gd;                                     // row n of the tile (padding negative) and its graph
+    };
+    auto issue_ids = [&](Ids &id, int i) {
+        const int64_t tb = (int64_t)(t0 + (i < cnt ? i : cnt - 1) * stride) * 16;
+        id.f = *reinterpret_cast<const v4i *>(trows_t + tb + 4 * q);
+#pragma unroll
+        for (int u = 0; u < TA; ++u) id.a[u] = trows[tb + ta.row[u]];
+        id.rn = trows[tb + n];
+        id.gd = tgid[tb + n];
+    };
+    v4f an[4 + (TA > 0 ? TA : 0) + 1], zn[4];
+    [[maybe_unused]] v4f dn[4];
+    float pn[4], gn[4];
+    auto issue_rows = [&](const Ids &id) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = id.f[i] ^ (id.f[i] >> 31);
+            an[i] = *reinterpret_cast<const v4f *>(A + (int64_t)r * Fi + 4 * n);
+            zn[i] = *reinterpret_cast<const v4f *>(Z + (int64_t)r * Fo + 4 * n);
+            if constexpr (DIN) dn[i] = *reinterpret_cast<const v4f *>(DZ + (int64_t)r * Fo + 4 * n);
+        }
+#pragma unroll
+        for (int u = 0; u < TA; ++u) {
+            const int r = id.a[u] ^ (id.a[u] >> 31);
+            an[4 + u] = *reinterpret_cast<const v4f *>(A + (int64_t)r * Fi + ta.col[u]);
+        }
+        const int rv = id.rn ^ (id.rn >> 31);
+        const float *ps = P + (int64_t)rv * O + 4 * q, *gs = GOUT + (int64_t)id.gd * O + 4 * q;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool ok = 4 * q + r < O;
+            pn[r] = ok ? ps[r] : 0.0f;
+            gn[r] = ok ? gs[r] : 0.0f;
+        }
+    };
+    if (cnt > 0) {
+        Ids I0, I1;
+        issue_ids(I0, 0);
+        issue_ids(I1, 1);
+        issue_rows(I0);
+        auto body = [&](Ids &cur, Ids &nxt, int i) {
+            const v4f zero = {0.0f, 0.0f, 0.0f, 0.0f};
+            int srow[4 + (TA > 0 ? TA : 1)];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) srow[k] = cur.f[k] ^ (cur.f[k] >> 31);
+#pragma unroll
+            for (int u = 0; u < TA; ++u) srow[4 + u] = cur.a[u] ^ (cur.a[u] >> 31);
+            const bool live = cur.rn >= 0;             // row n of this tile is a vertex, not a padding slot
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                *reinterpret_cast<v4f *>(al + (4 * k + q) * AP + 4 * n) = cur.f[k] >= 0 ? an[k] : zero;
+                *reinterpret_cast<v4f *>(zt + (4 * k + q) * ZP + 4 * n) = zn[k];
+                if constexpr (DIN) *reinterpret_cast<v4f *>(gl + (4 * k + q) * GP + 4 * n) = dn[k];
+            }
+#pragma unroll
+            for (int u = 0; u < TA; ++u) *reinterpret_cast<v4f *>(al + ta.row[u] * AP + ta.col[u]) = cur.a[u] >= 0 ? an[4 + u] : zero;
+            float pf[4], gf[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pf[r] = pn[r], gf[r] = gn[r];
+            issue_ids(cur, i + 2);             // ids of tile i+2 ...
+            issue_rows(nxt);                   // ... and the rows of tile i+1
+            asm volatile("" ::: "memory");
+            // ---- the readout's reverse on this tile: lane (v = n, q) holds columns 16 ft + 4 q .. + 3 of vertex row v
+            v4f zf[OT];
+            [[maybe_unused]] v4f df[OT];
+#pragma unroll
+            for (int ft = 0; ft < OT; ++ft) {
+                zf[ft] = *reinterpret_cast<const v4f *>(zt + n * ZP + 16 * ft + 4 * q);
+                if constexpr (DIN) df[ft] = *reinterpret_cast<const v4f *>(gl + n * GP + 16 * ft + 4 * q);
+            }
+            float dot = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dot = dot + gf[r] * pf[r];
+            dot = dot + __shfl_xor(dot, 16);
+            dot = dot + __shfl_xor(dot, 32);
+            float dl[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dl[r] = pf[r] * (gf[r] - dot);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dll[n * DP + 4 * q + r] = live ? dl[r] : 0.0f;   // a repeated row counts once in dR
+#pragma unroll
+            for (int ft = 0; ft < OT; ++ft) {
+                v4f dz = zero;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dz = __builtin_amdgcn_mfma_f32_16x16x4f32(Ra[ft][r], dl[r], dz, 0, 0, 0);
+                if constexpr (DIN) dz = dz + df[ft];
+                v4f o4;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o4[c] = duv_act_back<ACT>(zf[ft][c], dz[c]);
+                *reinterpret_cast<v4f *>(gl + n * GP + 16 * ft + 4 * q) = o4;   // the slot df came from: same lane, same address
+            }
+            asm volatile("" ::: "memory");
+            // dR(f, o) += sum_v z[v, f] dl[v, o]: the vertex on the k axis, both operands read turned
+            {
+                float db[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) db[r] = dll[(4 * q + r) * DP + n];
+#pragma unroll
+                for (int ft = 0; ft < OT; ++ft)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        accR[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(zt[(4 * q + r) * ZP + 16 * ft + n], db[r], accR[ft], 0, 0, 0);
+            }
+            // ---- from here on duv_bwd_wide_kernel with the gradient tile already in LDS
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float aa[IT], bb[OT];
+#pragma unroll
+                for (int ii = 0; ii < IT; ++ii) aa[ii] = al[(4 * q + r) * AP + 16 * ii + n];
+#pragma unroll
+                for (int o = 0; o < OT; ++o) bb[o] = gl[(4 * q + r) * GP + 16 * o + n];
+#pragma unroll
+                for (int ii = 0; ii < IT; ++ii)
+#pragma unroll
+                    for (int o = 0; o < OT; ++o)
+                        acc[ii][o] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[ii], bb[o], acc[ii][o], 0, 0, 0);
+            }
+            v4f xg[OT], da[IT];
+#pragma unroll
+            for (int j = 0; j < OT; ++j) xg[j] = *reinterpret_cast<const v4f *>(gl + n * GP + 16 * j + 4 * q);
+#pragma unroll
+            for (int it = 0; it < IT; ++it) da[it] = zero;
+#pragma unroll
+            for (int j = 0; j < OT; ++j) {
+                v4f wf[IT];
+#pragma unroll
+                for (int it = 0; it < IT; ++it) wf[it] = *reinterpret_cast<const v4f *>(wl + (16 * it + n) * WP + 16 * j + 4 * q);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int it = 0; it < IT; ++it) da[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[it][c], xg[j][c], da[it], 0, 0, 0);
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < IT; ++it) *reinterpret_cast<v4f *>(al + n * AP + 16 * it + 4 * q) = div4(da[it], d, inv);
+            asm volatile("" ::: "memory");
+            const int64_t pm = DAT ? 64 : Fi, pt = DAT ? Fi - 64 : Fi;
+            float *dat = DAT ? DAT - 64 : DA;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const v4f y = *reinterpret_cast<const v4f *>(al + (4 * k + q) * AP + 4 * n);
+                *reinterpret_cast<v4f *>(DA + (int64_t)srow[k] * pm + 4 * n) = y;
+            }
+#pragma unroll
+            for (int u = 0; u < TA; ++u) {
+                const v4f y = *reinterpret_cast<const v4f *>(al + ta.row[u] * AP + ta.col[u]);
+                float *dst = ta.col[u] >= 64 ? dat + (int64_t)srow[4 + u] * pt : DA + (int64_t)srow[4 + u] * pm;
+                *reinterpret_cast<v4f *>(dst + ta.col[u]) = y;
+            }
+            asm volatile("" ::: "memory");
+            if (Fi < 16 * IT) {
+#pragma unroll
+                for (int it = IT - 1; it < IT; ++it)
+                    if (16 * it + 4 * q >= Fi) *reinterpret_cast<v4f *>(al + n * AP + 16 * it + 4 * q) = zero;
+            }
+        };
+        int i = 0;
+        for (; i + 2 <= cnt; i += 2) {
+            body(I0, I1, i);
+            body(I1, I0, i + 1);
+        }
+        if (i < cnt) body(I0, I1, i);
+    }
+    __syncthreads();
+    // accR[ft][r] = dR(f = 16 ft + 4 q + r, o = n): the four waves' images side by side, added in wave order below
+#pragma unroll
+    for (int ft = 0; ft < OT; ++ft)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) redr[wave * Fo * 16 + (16 * ft + 4 * q + r) * 16 + n] = accR[ft][r];
+    for (int p = 0; p < 4; ++p) {
+        if (wave == p) {
+#pragma unroll
+            for (int i = 0; i < IT; ++i)
+#pragma unroll
+                for (int o = 0; o < OT; ++o)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float *dst = red + (16 * i + 4 * q + r) * FOP + 16 * o + n;
+                        *dst = (p == 0 ? 0.0f : *dst) + acc[i][o][r];
+                    }
+        }
+        __syncthreads();
+    }
+    float *slab = slabs + (size_t)blockIdx.x * Fi * Fo;
+    for (int t = threadIdx.x; t < Fi * Fo; t += 256) {
+        const int i = t / Fo, o = t - i * Fo;
+        slab[t] = red[i * FOP + o] / d;
+    }
+    float *rslab = rslabs + (size_t)blockIdx.x * Fo * O;
+    for (int t = threadIdx.x; t < Fo * O; t += 256) {
+        const int f = t / O, o = t - f * O;
+        rslab[t] = ((redr[f * 16 + o] + redr[Fo * 16 + f * 16 + o]) + redr[2 * Fo * 16 + f * 16 + o]) + redr[3 * Fo * 16 + f * 16 + o];
+    }
+}
+
 // split of at most `units` waves / workgroups over the buckets: every non-empty bucket gets >= 1, the rest go one by one to the
 // bucket whose units carry the most tiles (min-max).  Never more than `units` in total: the launches size `units` to what is
 // resident at once, and a workgroup beyond that starts when the first one ends.  (Round 5, per-block stamps of the fused reverse
@@ -1188,6 +1464,45 @@ int duv_mfma_bwd(const athena_mp_graph *g, int Fi, int Fo, const float *grad, co
     }
     AMP_WIDE(4, 4) AMP_WIDE(5, 4) AMP_WIDE(4, 5) AMP_WIDE(6, 4) AMP_WIDE(4, 6)
 #undef AMP_WIDE
+    if (!launched) return -1;
+    AMP_LAUNCH_CHECK();
+    std::vector<int> first(nb, 0), count(nb, 0);
+    for (int b = 0; b < nb; ++b) first[b] = sp.unit_off[b], count[b] = sp.unit_off[b + 1] - sp.unit_off[b];
+    return slab_reduce_segs((const float *)slabs, n, nb, first.data(), count.data(), dw, n, false);
+}
+
+// the readout's reverse and the update's reverse in one launch (F_o = 64, F_i = 64 .. 96, O <= 16); -1: shape outside it.
+// tgid: the graph of every tile slot, [16 tiles]; da_tail as in duv_mfma_bwd; dr_slabs: [workgroups][64 O]
+int duv_mfma_bwd_readout(const athena_mp_graph *g, int Fi, int Fo, int O, int act, const float *a, const float *w, const float *z,
+                         const float *dz_next, const float *p, const int32_t *tgid, const float *gout, const float *R, float *da,
+                         float *da_tail, float *dw, float *dr_slabs, int *n_slabs)
+{
+    const int it = ceil16(Fi);
+    if (!da_tail || (Fi & 3) || Fo != 64 || Fi <= 64 || it > 6 || O < 1 || O > 16 || act < 0 || act > ATHENA_MP_ACT_TANH) return -1;
+    const int nt = g->n_btiles, nb = (int)g->btile_off.size() - 1, n = Fi * Fo;
+    if (nt == 0 || nb > kMaxBuckets) return -1;
+    const BucketSplit sp = make_split(g, 256, 4);          // one workgroup per CU
+    const int nwg = sp.unit_off[nb];
+    *n_slabs = nwg;
+    void *slabs = nullptr;
+    if (workspace(&slabs, sizeof(float) * (size_t)nwg * n, 2)) return 1;
+    bool launched = false;
+#define AMP_RO(IT_, A_)                                                                                                      \
+    if (it == IT_ && act == A_) {                                                                                            \
+        if (dz_next)                                                                                                         \
+            hipLaunchKernelGGL((duv_bwd_ro_kernel<IT_, A_, true>), dim3(nwg), dim3(256), 0, stream(), sp, g->btile_rows,      \
+                               g->btile_rows + (size_t)48 * nt, tgid, a, Fi, z, dz_next, p, gout, R, O, w, da, da_tail,       \
+                               (float *)slabs, dr_slabs);                                                                    \
+        else                                                                                                                 \
+            hipLaunchKernelGGL((duv_bwd_ro_kernel<IT_, A_, false>), dim3(nwg), dim3(256), 0, stream(), sp, g->btile_rows,     \
+                               g->btile_rows + (size_t)48 * nt, tgid, a, Fi, z, dz_next, p, gout, R, O, w, da, da_tail,       \
+                               (float *)slabs, dr_slabs);                                                                    \
+        launched = true;                                                                                                     \
+    }
+#define AMP_RO_ACTS(IT_) AMP_RO(IT_, 0) AMP_RO(IT_, 1) AMP_RO(IT_, 2) AMP_RO(IT_, 3)
+    AMP_RO_ACTS(5) AMP_RO_ACTS(6)          // F_e > 0 with the split da: F_i = 68 .. 96
+#undef AMP_RO_ACTS
+#undef AMP_RO
     if (!launched) return -1;
     AMP_LAUNCH_CHECK();
     std::vector<int> first(nb, 0), count(nb, 0);

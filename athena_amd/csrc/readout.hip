@@ -255,6 +255,14 @@ __global__ __launch_bounds__(256) void readout_bwd_kernel(int O, int64_t N, cons
     }
 }
 
+// graph of every tile slot of the degree buckets (copy 1 of the tile ids: padding slots repeat the tile's first vertex)
+__global__ void readout_tile_gid_kernel(int64_t n_slots, const int32_t *__restrict__ trows_abs, const int32_t *__restrict__ gid,
+                                        int32_t *__restrict__ tgid)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_slots) tgid[t] = gid[trows_abs[t]];
+}
+
 bool fused_readout_shape(int Fv, int O) { return O <= 16 && (Fv == 16 || Fv == 32 || Fv == 64 || Fv == 128); }
 
 int readout_grid(int64_t N, int wg_per_cu)
@@ -345,6 +353,45 @@ int athena_mp_duvenaud_readout_bwd(int64_t N, int32_t Fv, int32_t O, int32_t S, 
     return slab_reduce((const float *)slabs, nblk, n, dR, accumulate != 0);
 }
 
+
+/* One time step of the Duvenaud layer's reverse pass in one call (update_readout_duvenaud's and update_message_duvenaud's
+ * reverse, athena_duvenaud_msgpass_layer.f90:755-859 through grad_reverse): the readout's reverse (softmax -> matmul(R, z) ->
+ * message activation) and the update's reverse (da split as athena_mp_duvenaud_update_bwd_split, dW) -- ONE launch where the
+ * shape allows it (F_v = 64, F_v + F_e <= 96, O <= 16: dc never reaches HBM), the two launches through a workspace otherwise.
+ * Same results as athena_mp_duvenaud_readout_bwd followed by athena_mp_duvenaud_update_bwd_split up to the order of the dR sum. */
+int athena_mp_duvenaud_readout_update_bwd(const athena_mp_graph *g, int32_t Fv, int32_t Fe, int32_t min_deg, int32_t max_deg,
+                                          int32_t O, int32_t S, const int32_t *seg, const float *z, const float *R, const float *p,
+                                          const float *gout, const float *dz_next, int32_t act, const float *a,
+                                          const float *weight, float *da_x, float *da_e, float *dweight, float *dR,
+                                          int32_t accumulate_dR)
+{
+    AMP_REQUIRE(g && Fv > 0 && Fe > 0 && O > 0 && S > 0 && seg && z && R && p && gout && a && weight && da_x && da_e && dweight && dR &&
+                    max_deg >= min_deg, "duvenaud_readout_update_bwd: bad arguments");
+    AMP_REQUIRE(act >= 0 && act <= ATHENA_MP_ACT_TANH, "duvenaud_readout_update_bwd: unknown activation %d", act);
+    const int64_t N = g->n_rows;
+    const int32_t Fi = Fv + Fe;
+    if (N >= 1024 && Fv == 64 && Fi <= 96 && (Fi & 3) == 0 && O <= 16 && max_deg - min_deg + 1 <= 32) {
+        if (duvenaud_buckets(g, min_deg, max_deg)) return 1;
+        const int64_t n_slots = (int64_t)16 * g->n_btiles;
+        void *gid = nullptr, *tgid = nullptr, *rslabs = nullptr;
+        if (workspace(&gid, sizeof(int32_t) * (size_t)N, 4) || workspace(&tgid, sizeof(int32_t) * (size_t)n_slots, 12) ||
+            workspace(&rslabs, sizeof(float) * (size_t)256 * Fv * O, 3))
+            return 1;
+        hipLaunchKernelGGL(readout_gid_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, stream(), S, seg, (int32_t *)gid);
+        hipLaunchKernelGGL(readout_tile_gid_kernel, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, stream(), n_slots,
+                           g->btile_rows + (size_t)n_slots, (const int32_t *)gid, (int32_t *)tgid);
+        AMP_LAUNCH_CHECK();
+        int n_slabs = 0;
+        const int rc = duv_mfma_bwd_readout(g, Fi, Fv, O, act, a, weight, z, dz_next, p, (const int32_t *)tgid, gout, R, da_x, da_e,
+                                            dweight, (float *)rslabs, &n_slabs);
+        if (rc > 0) return rc;
+        if (rc == 0) return slab_reduce((const float *)rslabs, n_slabs, Fv * O, dR, accumulate_dR != 0);
+    }
+    void *dc = nullptr;
+    if (workspace(&dc, sizeof(float) * (size_t)std::max<int64_t>(N, 1) * Fv, 13)) return 1;
+    if (const int rc = athena_mp_duvenaud_readout_bwd(N, Fv, O, S, seg, z, R, p, gout, dz_next, act, (float *)dc, dR, accumulate_dR)) return rc;
+    return athena_mp_duvenaud_update_bwd_split(g, Fv, Fe, Fv, min_deg, max_deg, (const float *)dc, a, weight, da_x, da_e, dweight);
+}
 
 /* per-graph sum of already-activated per-vertex values, and its reverse (a broadcast): the readout of
  * athena_duvenaud_msgpass_layer.f90:838-855 for a readout activation other than softmax */

@@ -1087,7 +1087,7 @@ contains
     type(c_ptr), intent(out), optional :: dx_dev, de_dev
     type(c_ptr) :: gout, dzn, dzn_arg, dc, da, da_e, dl, tmp
     integer :: t, tt, n, o, fe, fv, fo, fin, fmax, fv_e, fe_x
-    logical :: have_next, fused_msg, first_de, softmax_readout, split
+    logical :: have_next, fused_msg, first_de, softmax_readout, split, one_call
     integer(c_int32_t) :: code, code_arg
 
     n = this%nv
@@ -1116,6 +1116,24 @@ contains
        fv = this%num_vertex_features(t - 1)
        fo = this%num_vertex_features(t)
        fin = fv + fe
+       ! the readout's reverse and the update's reverse of this time step in ONE call where the library's fused launch covers the
+       ! shape: dc (n, 64) never reaches HBM (profiles/r05_c3_readout_update_fused_ab.txt)
+       one_call = softmax_readout .and. fused_msg .and. fv .eq. 64 .and. fo .eq. 64 .and. fe .gt. 0 .and. &
+            (t .gt. 1 .or. present(dx_dev) .or. present(de_dev))
+       if(one_call)then
+          dzn_arg = c_null_ptr
+          if(have_next) dzn_arg = dzn
+          da_e = athena_mp_dev_offset(da, i8(n) * i8(fv))
+          call chk(athena_mp_duvenaud_readout_update_bwd(this%graph, int(fv, c_int32_t), int(fe, c_int32_t), &
+               int(this%min_vertex_degree, c_int32_t), int(this%max_vertex_degree, c_int32_t), int(o, c_int32_t), &
+               int(this%batch, c_int32_t), this%seg%p, this%tape_z(t)%p, this%params(tt + t)%p, this%tape_p(t)%p, gout, dzn_arg, &
+               code_arg, this%tape_a(t)%p, this%params(t)%p, da, da_e, this%grads(t)%p, this%grads(tt + t)%p, 0_c_int32_t), &
+               "readout + update reverse (one call)")
+          this%has_grad(tt + t) = .true.
+          this%has_grad(t) = .true.
+          fv_e = 0
+          fe_x = 0
+       else
        if(softmax_readout)then
           dzn_arg = c_null_ptr
           if(have_next) dzn_arg = dzn
@@ -1168,6 +1186,7 @@ contains
                this%params(t)%p, da, this%grads(t)%p), "duvenaud_update reverse")
           fv_e = fv
           fe_x = fe
+       end if
        end if
        if(present(de_dev) .and. this%ne .gt. 0)then
           if(first_de)then

@@ -429,6 +429,22 @@ class duvenaud_msgpass_layer_type(msgpass_layer_type):
         for t in range(T, 0, -1):
             # readout branch of step t + the gradient arriving from step t+1, through the message activation
             fused_act = _fusable(self.activation)
+            Fv = self.num_vertex_features[t - 1]
+            if (self.activation_readout == "softmax" and fused_act and Fv == 64 and self.num_vertex_features[t] == 64
+                    and self.num_edge_features[0] > 0 and (t > 1 or need_input_grad or need_edge_grad)):
+                # the readout's reverse and the update's reverse of this time step in ONE call: dc [n, 64] never reaches HBM where
+                # the library's fused launch covers the shape (profiles/r05_c3_readout_update_fused_ab.txt: 0.825 -> 0.66 ms)
+                da_x, da_e, self.grads[t - 1], self.grads[T + t - 1] = ops.duvenaud_readout_update_bwd(
+                    g, self.params[T + t - 1], self.z[t - 1], self._p[t - 1], self._seg, gout, self._a[t - 1], self.params[t - 1],
+                    self.min_vertex_degree, self.max_vertex_degree, Fv, act=self.activation, dz_next=dz_next)
+                if need_edge_grad:
+                    d = ops.duvenaud_propagate_bwd_e(g, da_e, 0)
+                    de = d if de is None else ops.axpy(1.0, d, de)
+                if t > 1 or need_input_grad:
+                    dz_next = ops.duvenaud_propagate_bwd_x(g, da_x, Fv)
+                if t == 1:
+                    dx = dz_next
+                continue
             if self.activation_readout == "softmax":
                 dc, self.grads[T + t - 1] = ops.duvenaud_readout_bwd(self.params[T + t - 1], self.z[t - 1], self._p[t - 1],
                                                                      self._seg, gout, dz_next=dz_next,
@@ -451,7 +467,6 @@ class duvenaud_msgpass_layer_type(msgpass_layer_type):
                 self.grads[t - 1] = ops.duvenaud_update_bwd_w(g, dc, self._a[t - 1], self.min_vertex_degree, self.max_vertex_degree)
                 break
             # both reverse products of the update from one pass over dc (one launch where the fused kernel covers the widths)
-            Fv = self.num_vertex_features[t - 1]
             if Fv == 64 and self.num_edge_features[0] > 0:
                 # da split where it is written (256-byte vertex rows + a dense edge part): the two propagate partials then
                 # gather whole cache lines -- bit-identical dx / de (profiles/r05_c3_split_da_ab.txt)

@@ -589,6 +589,33 @@ def duvenaud_readout_bwd(R, z, p, seg, gout, act="none", dz_next=None):
     return dc, dR
 
 
+def duvenaud_readout_update_bwd(g: DeviceGraph, R, z, p, seg, gout, a, weight, min_deg, max_deg, Fv, act="none", dz_next=None,
+                                dR=None):
+    """One time step of the layer's reverse pass in one call: duvenaud_readout_bwd then duvenaud_update_bwd_split without dc in
+    HBM where the shape allows it.  Returns (da_x, da_e, dW, dR); dR given: added to."""
+    N, Fi = a.shape
+    Fe = Fi - Fv
+    O = p.shape[1]
+    S = seg.numel() - 1
+    _chk(a, (g.n_rows, Fi)); _chk(z, (N, Fv)); _chk(p, (N, O)); _chk(gout, (S, O)); _chk(R); _chk(weight)
+    if not (Fe > 0 and R.numel() == O * Fv and weight.numel() == (max_deg - min_deg + 1) * Fv * Fi):
+        raise ValueError('expected: Fe > 0, R.numel() == O * Fv, weight.numel() == buckets * Fv * (Fv + Fe)')
+    if dz_next is not None:
+        _chk(dz_next, (N, Fv))
+    da_x = torch.empty((N, Fv), device=a.device, dtype=torch.float32)
+    da_e = torch.empty((N, Fe), device=a.device, dtype=torch.float32)
+    dW = torch.empty(weight.numel(), device=a.device, dtype=torch.float32)
+    acc = dR is not None
+    if not acc:
+        dR = torch.empty(O * Fv, device=a.device, dtype=torch.float32)
+    else:
+        _chk(dR)
+    _go()
+    _capi.call("athena_mp_duvenaud_readout_update_bwd", g.handle, Fv, Fe, min_deg, max_deg, O, S, _p(seg), _p(z), _p(R), _p(p), _p(gout),
+               _p(dz_next) if dz_next is not None else None, ACT[act], _p(a), _p(weight), _p(da_x), _p(da_e), _p(dW), _p(dR), 1 if acc else 0)
+    return da_x, da_e, dW, dR
+
+
 # ---- graph neural operator -----------------------------------------------------------------------
 def gno_aggregate(g: DeviceGraph, theta, coords, x, d, H, Fo, out=None):
     """gno_kernel_eval + gno_aggregate (athena_diffstruc_extd_sub_nop.f90:26-115, :330-397) fused"""

@@ -264,6 +264,22 @@ int athena_mp_duvenaud_update_bwd(const athena_mp_graph *g, int32_t Fi, int32_t 
 int athena_mp_duvenaud_update_bwd_split(const athena_mp_graph *g, int32_t Fv, int32_t Fe, int32_t Fo, int32_t min_deg,
                                         int32_t max_deg, const float *grad_dev, const float *a_dev, const float *weight_dev,
                                         float *da_x_dev, float *da_e_dev, float *dweight_dev);
+
+/* One time step of the Duvenaud layer's reverse pass in one call: the readout's reverse (softmax over the outputs ->
+ * matmul(R, z) -> the message activation; athena_duvenaud_msgpass_layer.f90:838-855 through diffstruc's grad_reverse,
+ * athena_diffstruc_extd_sub.f90:309-313) and the update's reverse (get_partial_duvenaud_update_val / _weight_val,
+ * athena_diffstruc_extd_sub_duvenaud.f90:284-368) -- what athena_mp_duvenaud_readout_bwd followed by
+ * athena_mp_duvenaud_update_bwd_split compute, without dc [n_rows, Fv] between them where the shape allows it (F_v = 64,
+ * F_v + F_e <= 96, O <= 16: ONE launch); other shapes run the two through a workspace.  Device pointers.
+ * z [n_rows, Fv] the ACTIVATED update output of this time step, p [n_rows, O] its softmax(R z), gout [S, O] the gradient of the
+ * per-graph readout, dz_next [n_rows, Fv] or NULL the next time step's gradient with respect to z, a [n_rows, Fv + Fe],
+ * weight as athena_mp_duvenaud_update_fwd; out: da_x [n_rows, Fv], da_e [n_rows, Fe], dweight, dR [O, Fv] flat o + O f
+ * (accumulate_dR != 0: added to). */
+int athena_mp_duvenaud_readout_update_bwd(const athena_mp_graph *g, int32_t Fv, int32_t Fe, int32_t min_deg, int32_t max_deg,
+                                          int32_t O, int32_t S, const int32_t *seg, const float *z, const float *R, const float *p,
+                                          const float *gout, const float *dz_next, int32_t act, const float *a,
+                                          const float *weight, float *da_x, float *da_e, float *dweight, float *dR,
+                                          int32_t accumulate_dR);
 /* readout, athena_duvenaud_msgpass_layer.f90:838-855 over a block-diagonal batch:
  *   p[v,:] = softmax_over_outputs(logits[v,:]); out[s,:] (+)= sum_{v in seg s} p[v,:]
  *   seg_dev [S+1] 0-based vertex offsets of the graphs */

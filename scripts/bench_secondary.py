@@ -79,7 +79,7 @@ def mfma_op(ms, flops):
 
 def run_c3(dev, reps):
     """one Duvenaud time step as the layer mirror runs it (update_message_duvenaud + update_readout_duvenaud,
-    athena_duvenaud_msgpass_layer.f90:755-859, and its reverse pass): 7 launches"""
+    athena_duvenaud_msgpass_layer.f90:755-859, and its reverse pass): 6 launches"""
     from oracle import oracle as o
 
     S = 130_000
@@ -104,23 +104,31 @@ def run_c3(dev, reps):
     da = torch.cat([da_x, da_e], dim=1)                          # the packed form, for the parity block only
     dx = ops.duvenaud_propagate_bwd_x(g, da_x, Fv)
     de = ops.duvenaud_propagate_bwd_e(g, da_e, 0)
+    # the two reverse launches as ONE (round 5: dc never in HBM) -- what both layer mirrors run; the two above feed the parity block
+    one = lambda: ops.duvenaud_readout_update_bwd(g, R, z, p, seg, gout, a_, W, mn, mx, Fv, act="sigmoid")
+    o_dax, o_dae, o_dW, o_dR = one()
+    one_vs_two = {"da_bit_identical": bool(torch.equal(o_dax, da_x) and torch.equal(o_dae, da_e)),
+                  "dW_rel": rel(o_dW.cpu().numpy(), dW.cpu().numpy()), "dR_rel": rel(o_dR.cpu().numpy(), dR.cpu().numpy())}
+    del o_dax, o_dae, o_dW, o_dR
+    t_two = {"readout_bwd": timeit(lambda: ops.duvenaud_readout_bwd(R, z, p, seg, gout, act="sigmoid"), reps),
+             "update_bwd_fused(w+a)": timeit(lambda: ops.duvenaud_update_bwd_split(g, dc, a_, W, mn, mx, Fv), reps)}
     t = {"propagate": timeit(lambda: ops.duvenaud_propagate(g, x, e, out=a_), reps),
          "update_sigmoid_readout_p(fused)": timeit(lambda: ops.duvenaud_update_act_readout(g, a_, W, mn, mx, Fv, R, O, act="sigmoid"), reps),
          "segment_sum": timeit(lambda: ops.segment_sum(p, seg), reps),
-         "readout_bwd": timeit(lambda: ops.duvenaud_readout_bwd(R, z, p, seg, gout, act="sigmoid"), reps),
-         "update_bwd_fused(w+a)": timeit(lambda: ops.duvenaud_update_bwd_split(g, dc, a_, W, mn, mx, Fv), reps),
+         "readout_bwd+update_bwd(one launch)": timeit(one, reps),
          "propagate_bwd_x": timeit(lambda: ops.duvenaud_propagate_bwd_x(g, da_x, Fv), reps),
          "propagate_bwd_e": timeit(lambda: ops.duvenaud_propagate_bwd_e(g, da_e, 0), reps)}
     # a batch of ~18-vertex molecules is block-diagonal: a vertex's neighbours sit in the cache lines next to its own, so the
     # two gathers are priced on COMPULSORY bytes (every tensor once, indices included), the streaming ops on their tensors
     comp = {"propagate": N * 4 * Fv + E * 4 * Fe + nnz * 8 + N * 4 + N * 4 * Fc,
             "update_sigmoid_readout_p(fused)": N * 4 * (Fc + Fv + O), "segment_sum": N * 4 * O + S * 4 * O,
-            "readout_bwd": N * 4 * (2 * Fv + O + 1) + S * 4 * O, "update_bwd_fused(w+a)": N * 4 * (2 * Fc + Fv),
+            "readout_bwd+update_bwd(one launch)": N * 4 * (Fv + O + 1 + 2 * Fc) + S * 4 * O,
             "propagate_bwd_x": N * 4 * Fc + nnz * 4 + N * 4 + N * 4 * Fv, "propagate_bwd_e": N * 4 * Fe + nnz * 8 + E * 4 * Fe}
     opsd = {k: hbm_op(t[k], comp[k], "compulsory" if k.startswith("propagate") else "tensors read + written once") for k in t}
     # the two update launches are bound by the fp32 matrix pipe, not by their bytes (timing-only builds without any HBM traffic keep
     # 0.48 of 0.54 ms, profiles/r05_c3_bwd_probe.txt): both fractions are reported, "bound" names the one that holds
-    for k, fl in (("update_sigmoid_readout_p(fused)", 2.0 * N * Fv * (Fc + O)), ("update_bwd_fused(w+a)", 4.0 * N * Fv * Fc)):
+    for k, fl in (("update_sigmoid_readout_p(fused)", 2.0 * N * Fv * (Fc + O)),
+                  ("readout_bwd+update_bwd(one launch)", 4.0 * N * Fv * Fc + 4.0 * N * Fv * O)):
         m = mfma_op(t[k], fl)
         opsd[k]["hbm_frac"] = opsd[k].pop("frac")
         opsd[k].update({"bound": "mfma", "frac": m["frac"], "TFLOPs": m["TFLOPs"], "TFLOP": m["TFLOP"],
@@ -152,6 +160,10 @@ def run_c3(dev, reps):
     par["ok"] = bool(par["propagate_bit_exact"] and all(par[k] <= TOL for k in ("z_rel", "readout_rel", "dc_rel", "da_rel", "dx_rel", "de_rel",
                                                                                  "z_elementwise_worst", "da_elementwise_worst")))
     step = sum(t.values())
+    opsd["readout_bwd+update_bwd(one launch)"]["as_two_launches_ms"] = {k: round(v, 4) for k, v in t_two.items()}
+    opsd["readout_bwd+update_bwd(one launch)"]["against_the_two_launches"] = one_vs_two
+    par["one_launch_reverse"] = one_vs_two
+    par["ok"] = bool(par["ok"] and one_vs_two["da_bit_identical"] and one_vs_two["dW_rel"] <= TOL and one_vs_two["dR_rel"] <= TOL)
     # the CPU path beside it: the same ops, same order, the oracle on one thread, first 20 000 graphs
     NC = 20000
     nvc = int(voff[NC]); iac = ia[:nvc + 1]; jac = np.asfortranarray(ja[:, :ia[nvc] - 1]); nec = int(jac[1].max())
@@ -207,11 +219,11 @@ def c3_layer_T4(dev, reps, ia, ja, voff, E, x, e):
     dx_full, de_full = (t.cpu().numpy() for t in step())
     grads_full = layer.get_gradients().astype(np.float64)
     params = layer.get_params()
-    # bytes one step moves, per time step the seven launches of `ops` above (the last step's readout reverse has no dz_next; steps
-    # 2..T of the reverse read it): compulsory tensors only
+    # bytes one step moves, per time step the six launches of `ops` above (the last step's reverse has no dz_next; steps 2..T of the
+    # reverse read it; dc between the readout's and the update's reverse no longer exists): compulsory tensors only
     Fc = Fv + Fe
     per_t = (N * 4 * Fv + E * 4 * Fe + nnz * 8 + N * 4 + N * 4 * Fc) + N * 4 * (Fc + Fv + O) + (N * 4 * O + S * 4 * O) \
-        + (N * 4 * (2 * Fv + O + 1) + S * 4 * O) + N * 4 * (2 * Fc + Fv) + (N * 4 * Fc + nnz * 4 + N * 4 + N * 4 * Fv) \
+        + (N * 4 * (Fv + O + 1 + 2 * Fc) + S * 4 * O) + (N * 4 * Fc + nnz * 4 + N * 4 + N * 4 * Fv) \
         + (N * 4 * Fe + nnz * 8 + E * 4 * Fe)
     nbytes = T * per_t + (T - 1) * N * 4 * Fv
 
@@ -293,8 +305,8 @@ def c3_layer_T4(dev, reps, ia, ja, voff, E, x, e):
     ent = int(ias[-1] - 1) * T
     return {"workload": f"duvenaud_msgpass_layer_type, T = {T} time steps + readout, F_v = {Fv}, F_e = {Fe}, degrees {mn}..{mx}, {O} outputs, "
             f"{S} graphs = {N} vertices / {nnz} entries; forward + reverse (dx, de, {2 * T} parameter gradients)",
-            "step_ms": round(ms, 4), "entries_per_s": T * nnz / ms * 1e3, "launches_per_step": 7 * T,
-            "hbm": hbm_op(ms, nbytes, "compulsory tensors of the 7 T launches"), "parity": par,
+            "step_ms": round(ms, 4), "entries_per_s": T * nnz / ms * 1e3, "launches_per_step": 6 * T,
+            "hbm": hbm_op(ms, nbytes, "compulsory tensors of the 6 T launches"), "parity": par,
             "cpu_baseline": {"value": ent / t_cpu, "unit": "entries/s (entries x time steps)", "cores": 1, "kind": "port",
                              "sample": f"oracle/layers.py, the reference's loop over samples, first {NG} graphs x {T} time steps = {ent} entry visits, "
                                        f"forward + reverse, {t_cpu:.2f} s"}}

@@ -1124,3 +1124,56 @@ def test_duvenaud_update_bwd_split_matches_the_packed_form(dev, oracle, Fv, Fe, 
     assert_close(da_x.cpu().numpy(), oracle.duvenaud_update_bwd_a(gup.cpu().numpy(), W.cpu().numpy(), ia, mn, mx, Fv + Fe)[:, :Fv], 1e-5)
     assert torch.equal(ops.duvenaud_propagate_bwd_x(g, da_x, Fv), ops.duvenaud_propagate_bwd_x(g, da, Fv))
     assert torch.equal(ops.duvenaud_propagate_bwd_e(g, da_e, 0), ops.duvenaud_propagate_bwd_e(g, da, Fv))
+
+
+@pytest.mark.parametrize("Fv,Fe,O,act,dz", [(64, 8, 10, "sigmoid", True), (64, 8, 10, "sigmoid", False), (64, 4, 1, "relu", True),
+                                             (64, 16, 16, "tanh", True), (64, 32, 7, "none", False), (64, 8, 3, "relu", False),
+                                             (32, 8, 10, "sigmoid", True), (64, 8, 20, "sigmoid", True), (128, 8, 10, "tanh", False)])
+def test_duvenaud_readout_update_bwd_one_call(dev, oracle, Fv, Fe, O, act, dz):
+    """athena_mp_duvenaud_readout_update_bwd: the readout's reverse and the update's reverse of one time step in one call -- ONE
+    launch (dc never in HBM) at F_v = 64, F_v + F_e <= 96, O <= 16, the two launches through a workspace elsewhere (the last three
+    cases).  da_x / da_e have the bits of athena_mp_duvenaud_readout_bwd + athena_mp_duvenaud_update_bwd_split (the same dc, the same
+    products), dW / dR differ by the order of their sums only; everything against the oracle composed op by op."""
+    from athena_amd import DeviceGraph, ops, synth
+
+    rng = np.random.default_rng(Fv + 3 * Fe + 5 * O + (7 if dz else 0))
+    ia, ja, voff, E = synth.molecule_batch(400, seed=5)      # 7 000 vertices: several tiles in the big buckets, one in the small
+    N, S = ia.size - 1, voff.size - 1
+    g = DeviceGraph(ia, ja, n_edge_cols=E)
+    mn, mx = 1, 10
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    Fc = Fv + Fe
+    a_h = rng.uniform(-1, 1, (N, Fc)).astype(np.float32)
+    W_h = (0.3 * rng.standard_normal(Fv * Fc * (mx - mn + 1))).astype(np.float32)
+    R_h = (0.3 * rng.standard_normal(O * Fv)).astype(np.float32)
+    gout_h = rng.standard_normal((S, O)).astype(np.float32)
+    dzn_h = rng.standard_normal((N, Fv)).astype(np.float32) if dz else None
+    a, W, R, gout, seg = T(a_h), T(W_h), T(R_h), T(gout_h), T(voff)
+    dzn = T(dzn_h) if dz else None
+    if O <= 16:
+        z, p = ops.duvenaud_update_act_readout(g, a, W, mn, mx, Fv, R, O, act=act)
+    else:
+        z = ops.duvenaud_update_act(g, a, W, mn, mx, Fv, act=act)
+        p, _ = ops.duvenaud_readout(R, z, seg, O)
+    dc, dR2 = ops.duvenaud_readout_bwd(R, z, p, seg, gout, act=act, dz_next=dzn)
+    da_x2, da_e2, dW2 = ops.duvenaud_update_bwd_split(g, dc, a, W, mn, mx, Fv)
+    da_x, da_e, dW, dR = ops.duvenaud_readout_update_bwd(g, R, z, p, seg, gout, a, W, mn, mx, Fv, act=act, dz_next=dzn)
+    assert torch.equal(da_x, da_x2) and torch.equal(da_e, da_e2)
+    assert_close(dW.cpu().numpy(), dW2.cpu().numpy(), 1e-5)
+    assert_close(dR.cpu().numpy(), dR2.cpu().numpy(), 1e-5)
+    # accumulate_dR: added to what the caller holds
+    base = torch.full_like(dR, 0.5)
+    _, _, _, dR3 = ops.duvenaud_readout_update_bwd(g, R, z, p, seg, gout, a, W, mn, mx, Fv, act=act, dz_next=dzn, dR=base.clone())
+    assert_close((dR3 - 0.5).cpu().numpy(), dR.cpu().numpy(), 1e-5)
+    # the oracle, op by op, from the device's z and p
+    z_h, p_h = z.cpu().numpy(), p.cpu().numpy()
+    dl_h = oracle.softmax_cols_bwd(p_h, np.repeat(gout_h, np.diff(voff), axis=0))
+    dzt = oracle.matmul_dx(R_h, dl_h, Fv)
+    if dz:
+        dzt = dzt + dzn_h
+    dc_h = oracle.activation_bwd(act, z_h, dzt)
+    da_h = oracle.duvenaud_update_bwd_a(dc_h, W_h, ia, mn, mx, Fc)
+    assert_close(da_x.cpu().numpy(), da_h[:, :Fv], 1e-5)
+    assert_close(da_e.cpu().numpy(), da_h[:, Fv:], 1e-5)
+    assert_close(dW.cpu().numpy(), oracle.duvenaud_update_bwd_w(dc_h, a_h, ia, mn, mx), 2e-5)
+    assert_close(dR.cpu().numpy(), oracle.matmul_dw(dl_h, z_h), 2e-5)
