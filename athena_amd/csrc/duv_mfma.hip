@@ -1021,8 +1021,11 @@ __device__ __forceinline__ float duv_act_back(float y, float g)
     return g;
 }
 
+#ifndef DUV_RO_ATTR
+#define DUV_RO_ATTR
+#endif
 template <int IT, int ACT, bool DIN>
-__global__ __launch_bounds__(256, 1) void duv_bwd_ro_kernel(BucketSplit sp, const int32_t *__restrict__ trows,
+__global__ __launch_bounds__(256, 1) DUV_RO_ATTR void duv_bwd_ro_kernel(BucketSplit sp, const int32_t *__restrict__ trows,
                                                             const int32_t *__restrict__ trows_t, const int32_t *__restrict__ tgid,
                                                             const float *__restrict__ A, int Fi, const float *__restrict__ Z,
                                                             const float *__restrict__ DZ, const float *__restrict__ P,
