@@ -189,5 +189,5 @@ int duv_mfma_bwd(const athena_mp_graph *g, int Fi, int Fo, const float *grad, co
 // readout reverse + update reverse in one launch (duv_mfma.hip, duv_bwd_ro_kernel); -1: shape outside it
 int duv_mfma_bwd_readout(const athena_mp_graph *g, int Fi, int Fo, int O, int act, const float *a, const float *w, const float *z,
                          const float *dz_next, const float *p, const int32_t *tgid, const float *gout, const float *R, float *da,
-                         float *da_tail, float *dw, float *dr_slabs, int *n_slabs);
+                         float *da_tail, float *dw, float *dr_slabs, int *n_slabs, bool accumulate_tail);
 } // namespace amp

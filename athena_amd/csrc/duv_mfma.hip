@@ -1032,8 +1032,10 @@ __global__ __launch_bounds__(256, 1) DUV_RO_ATTR void duv_bwd_ro_kernel(BucketSp
                                                             const float *__restrict__ GOUT, const float *__restrict__ R, int O,
                                                             const float *__restrict__ W, float *__restrict__ DA,
                                                             float *__restrict__ DAT, float *__restrict__ slabs,
-                                                            float *__restrict__ rslabs)
+                                                            float *__restrict__ rslabs, int acc_e)
 {
+    // acc_e: the edge part of da is ADDED to what DAT holds (the layer sums da_e over its time steps and scatters the sum to the
+    // edge features once, instead of one scatter + one axpy per time step); the old values travel with the tile's rows
     constexpr int OT = 4, Fo = 64;
     constexpr int AP = 16 * IT + 4, GP = 16 * OT + 4, ZP = 16 * OT + 4, DP = 20, FOP = 16 * OT, WP = 16 * OT + 4, TA = IT - 4;
     constexpr int kW = 16 * IT * WP, kWave = 16 * (AP + GP + ZP + DP), kRed = 16 * IT * FOP, kRedR = 4 * Fo * 16;
@@ -1096,7 +1098,7 @@ __global__ __launch_bounds__(256, 1) DUV_RO_ATTR void duv_bwd_ro_kernel(BucketSp
         id.rn = trows[tb + n];
         id.gd = tgid[tb + n];
     };
-    v4f an[4 + (TA > 0 ? TA : 0) + 1], zn[4];
+    v4f an[4 + (TA > 0 ? TA : 0) + 1], zn[4], en[TA > 0 ? TA : 1];
     [[maybe_unused]] v4f dn[4];
     float pn[4], gn[4];
     auto issue_rows = [&](const Ids &id) {
@@ -1111,6 +1113,8 @@ __global__ __launch_bounds__(256, 1) DUV_RO_ATTR void duv_bwd_ro_kernel(BucketSp
         for (int u = 0; u < TA; ++u) {
             const int r = id.a[u] ^ (id.a[u] >> 31);
             an[4 + u] = *reinterpret_cast<const v4f *>(A + (int64_t)r * Fi + ta.col[u]);
+            en[u] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+            if (acc_e && ta.col[u] >= 64) en[u] = *reinterpret_cast<const v4f *>(DAT - 64 + (int64_t)r * (Fi - 64) + ta.col[u]);
         }
         const int rv = id.rn ^ (id.rn >> 31);
         const float *ps = P + (int64_t)rv * O + 4 * q, *gs = GOUT + (int64_t)id.gd * O + 4 * q;
@@ -1145,6 +1149,9 @@ __global__ __launch_bounds__(256, 1) DUV_RO_ATTR void duv_bwd_ro_kernel(BucketSp
             float pf[4], gf[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) pf[r] = pn[r], gf[r] = gn[r];
+            v4f ef[TA > 0 ? TA : 1];
+#pragma unroll
+            for (int u = 0; u < TA; ++u) ef[u] = en[u];
             issue_ids(cur, i + 2);             // ids of tile i+2 ...
             issue_rows(nxt);                   // ... and the rows of tile i+1
             asm volatile("" ::: "memory");
@@ -1231,7 +1238,8 @@ __global__ __launch_bounds__(256, 1) DUV_RO_ATTR void duv_bwd_ro_kernel(BucketSp
             }
 #pragma unroll
             for (int u = 0; u < TA; ++u) {
-                const v4f y = *reinterpret_cast<const v4f *>(al + ta.row[u] * AP + ta.col[u]);
+                v4f y = *reinterpret_cast<const v4f *>(al + ta.row[u] * AP + ta.col[u]);
+                if (acc_e && ta.col[u] >= 64) y = y + ef[u];
                 float *dst = ta.col[u] >= 64 ? dat + (int64_t)srow[4 + u] * pt : DA + (int64_t)srow[4 + u] * pm;
                 *reinterpret_cast<v4f *>(dst + ta.col[u]) = y;
             }
@@ -1478,7 +1486,7 @@ int duv_mfma_bwd(const athena_mp_graph *g, int Fi, int Fo, const float *grad, co
 // tgid: the graph of every tile slot, [16 tiles]; da_tail as in duv_mfma_bwd; dr_slabs: [workgroups][64 O]
 int duv_mfma_bwd_readout(const athena_mp_graph *g, int Fi, int Fo, int O, int act, const float *a, const float *w, const float *z,
                          const float *dz_next, const float *p, const int32_t *tgid, const float *gout, const float *R, float *da,
-                         float *da_tail, float *dw, float *dr_slabs, int *n_slabs)
+                         float *da_tail, float *dw, float *dr_slabs, int *n_slabs, bool accumulate_tail)
 {
     const int it = ceil16(Fi);
     if (!da_tail || (Fi & 3) || Fo != 64 || Fi <= 64 || it > 6 || O < 1 || O > 16 || act < 0 || act > ATHENA_MP_ACT_TANH) return -1;
@@ -1495,11 +1503,11 @@ int duv_mfma_bwd_readout(const athena_mp_graph *g, int Fi, int Fo, int O, int ac
         if (dz_next)                                                                                                         \
             hipLaunchKernelGGL((duv_bwd_ro_kernel<IT_, A_, true>), dim3(nwg), dim3(256), 0, stream(), sp, g->btile_rows,      \
                                g->btile_rows + (size_t)48 * nt, tgid, a, Fi, z, dz_next, p, gout, R, O, w, da, da_tail,       \
-                               (float *)slabs, dr_slabs);                                                                    \
+                               (float *)slabs, dr_slabs, accumulate_tail ? 1 : 0);                                          \
         else                                                                                                                 \
             hipLaunchKernelGGL((duv_bwd_ro_kernel<IT_, A_, false>), dim3(nwg), dim3(256), 0, stream(), sp, g->btile_rows,     \
                                g->btile_rows + (size_t)48 * nt, tgid, a, Fi, z, dz_next, p, gout, R, O, w, da, da_tail,       \
-                               (float *)slabs, dr_slabs);                                                                    \
+                               (float *)slabs, dr_slabs, accumulate_tail ? 1 : 0);                                          \
         launched = true;                                                                                                     \
     }
 #define AMP_RO_ACTS(IT_) AMP_RO(IT_, 0) AMP_RO(IT_, 1) AMP_RO(IT_, 2) AMP_RO(IT_, 3)

@@ -358,12 +358,14 @@ int athena_mp_duvenaud_readout_bwd(int64_t N, int32_t Fv, int32_t O, int32_t S, 
  * reverse, athena_duvenaud_msgpass_layer.f90:755-859 through grad_reverse): the readout's reverse (softmax -> matmul(R, z) ->
  * message activation) and the update's reverse (da split as athena_mp_duvenaud_update_bwd_split, dW) -- ONE launch where the
  * shape allows it (F_v = 64, F_v + F_e <= 96, O <= 16: dc never reaches HBM), the two launches through a workspace otherwise.
- * Same results as athena_mp_duvenaud_readout_bwd followed by athena_mp_duvenaud_update_bwd_split up to the order of the dR sum. */
+ * Same results as athena_mp_duvenaud_readout_bwd followed by athena_mp_duvenaud_update_bwd_split up to the order of the dR sum.
+ * accumulate_da_e: da_e is added to (the edge-feature gradient is linear in da_e: a layer sums da_e over its time steps and
+ * calls athena_mp_duvenaud_propagate_bwd_e once). */
 int athena_mp_duvenaud_readout_update_bwd(const athena_mp_graph *g, int32_t Fv, int32_t Fe, int32_t min_deg, int32_t max_deg,
                                           int32_t O, int32_t S, const int32_t *seg, const float *z, const float *R, const float *p,
                                           const float *gout, const float *dz_next, int32_t act, const float *a,
                                           const float *weight, float *da_x, float *da_e, float *dweight, float *dR,
-                                          int32_t accumulate_dR)
+                                          int32_t accumulate_dR, int32_t accumulate_da_e)
 {
     AMP_REQUIRE(g && Fv > 0 && Fe > 0 && O > 0 && S > 0 && seg && z && R && p && gout && a && weight && da_x && da_e && dweight && dR &&
                     max_deg >= min_deg, "duvenaud_readout_update_bwd: bad arguments");
@@ -383,14 +385,20 @@ int athena_mp_duvenaud_readout_update_bwd(const athena_mp_graph *g, int32_t Fv, 
         AMP_LAUNCH_CHECK();
         int n_slabs = 0;
         const int rc = duv_mfma_bwd_readout(g, Fi, Fv, O, act, a, weight, z, dz_next, p, (const int32_t *)tgid, gout, R, da_x, da_e,
-                                            dweight, (float *)rslabs, &n_slabs);
+                                            dweight, (float *)rslabs, &n_slabs, accumulate_da_e != 0);
         if (rc > 0) return rc;
         if (rc == 0) return slab_reduce((const float *)rslabs, n_slabs, Fv * O, dR, accumulate_dR != 0);
     }
     void *dc = nullptr;
     if (workspace(&dc, sizeof(float) * (size_t)std::max<int64_t>(N, 1) * Fv, 13)) return 1;
     if (const int rc = athena_mp_duvenaud_readout_bwd(N, Fv, O, S, seg, z, R, p, gout, dz_next, act, (float *)dc, dR, accumulate_dR)) return rc;
-    return athena_mp_duvenaud_update_bwd_split(g, Fv, Fe, Fv, min_deg, max_deg, (const float *)dc, a, weight, da_x, da_e, dweight);
+    if (!accumulate_da_e)
+        return athena_mp_duvenaud_update_bwd_split(g, Fv, Fe, Fv, min_deg, max_deg, (const float *)dc, a, weight, da_x, da_e, dweight);
+    void *et = nullptr;
+    if (workspace(&et, sizeof(float) * (size_t)std::max<int64_t>(N, 1) * Fe, 8)) return 1;
+    if (const int rc = athena_mp_duvenaud_update_bwd_split(g, Fv, Fe, Fv, min_deg, max_deg, (const float *)dc, a, weight, da_x, (float *)et, dweight))
+        return rc;
+    return athena_mp_axpy(N * Fe, 1.0f, (const float *)et, da_e);
 }
 
 /* per-graph sum of already-activated per-vertex values, and its reverse (a broadcast): the readout of

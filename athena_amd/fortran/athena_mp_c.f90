@@ -705,12 +705,12 @@ module athena_mp_c
      !! one time step of the layer's reverse pass in one call: the readout's reverse (softmax -> matmul(R, z) -> activation) and
      !! the update's reverse, dc never in HBM where the shape allows it (Fv = 64, Fv + Fe <= 96, O <= 16)
      integer(c_int) function athena_mp_duvenaud_readout_update_bwd(graph, Fv, Fe, min_deg, max_deg, O, S, seg_dev, z_dev, R_dev, &
-          p_dev, gout_dev, dz_next_dev, act, a_dev, weight_dev, da_x_dev, da_e_dev, dweight_dev, dR_dev, accumulate_dR) &
-          bind(C, name="athena_mp_duvenaud_readout_update_bwd")
+          p_dev, gout_dev, dz_next_dev, act, a_dev, weight_dev, da_x_dev, da_e_dev, dweight_dev, dR_dev, accumulate_dR, &
+          accumulate_da_e) bind(C, name="athena_mp_duvenaud_readout_update_bwd")
        import :: c_int, c_int32_t, c_ptr
        type(c_ptr), value :: graph, seg_dev, z_dev, R_dev, p_dev, gout_dev, dz_next_dev, a_dev, weight_dev, da_x_dev, da_e_dev, &
             dweight_dev, dR_dev
-       integer(c_int32_t), value :: Fv, Fe, min_deg, max_deg, O, S, act, accumulate_dR
+       integer(c_int32_t), value :: Fv, Fe, min_deg, max_deg, O, S, act, accumulate_dR, accumulate_da_e
      end function
      integer(c_int) function athena_mp_segment_sum(O, N, S, seg_dev, p_dev, out_dev, accumulate) &
           bind(C, name="athena_mp_segment_sum")

@@ -112,7 +112,7 @@ module athena_mp_layers
      integer, allocatable :: num_vertex_features(:), num_edge_features(:)   ! (0:T)
      type(mp_actv_type) :: activation, activation_readout
      type(dbuf), allocatable :: tape_a(:), tape_z(:), tape_c(:), tape_p(:), tape_l(:)
-     type(dbuf) :: x_in, e_in, out_dev, gout, de_acc, scratch(5)
+     type(dbuf) :: x_in, e_in, out_dev, gout, de_acc, dae_sum, scratch(5)
    contains
      procedure, pass(this) :: forward => duvenaud_forward
      procedure, pass(this) :: backward => duvenaud_backward
@@ -1087,7 +1087,8 @@ contains
     type(c_ptr), intent(out), optional :: dx_dev, de_dev
     type(c_ptr) :: gout, dzn, dzn_arg, dc, da, da_e, dl, tmp
     integer :: t, tt, n, o, fe, fv, fo, fin, fmax, fv_e, fe_x
-    logical :: have_next, fused_msg, first_de, softmax_readout, split, one_call
+    logical :: have_next, fused_msg, first_de, softmax_readout, split, one_call, have_e_sum
+    integer(c_int32_t) :: acc_e
     integer(c_int32_t) :: code, code_arg
 
     n = this%nv
@@ -1108,6 +1109,7 @@ contains
     softmax_readout = trim(this%activation_readout%name) .eq. "softmax" .and. .not. apply_scaling(this%activation_readout)
     have_next = .false.
     first_de = .true.
+    have_e_sum = .false.
     dc = this%scratch(2)%p
     da = this%scratch(3)%p
     dzn = this%scratch(4)%p
@@ -1123,12 +1125,18 @@ contains
        if(one_call)then
           dzn_arg = c_null_ptr
           if(have_next) dzn_arg = dzn
-          da_e = athena_mp_dev_offset(da, i8(n) * i8(fv))
+          ! ... and the edge part of da is SUMMED over these time steps in its own buffer (the scatter to the edge features is
+          ! linear in it): one duvenaud_propagate reverse (edges) after the loop instead of one + an axpy per time step
+          call need(this%dae_sum, i8(max(n, 1)) * i8(fe))
+          da_e = this%dae_sum%p
+          acc_e = 0_c_int32_t
+          if(have_e_sum) acc_e = 1_c_int32_t
           call chk(athena_mp_duvenaud_readout_update_bwd(this%graph, int(fv, c_int32_t), int(fe, c_int32_t), &
                int(this%min_vertex_degree, c_int32_t), int(this%max_vertex_degree, c_int32_t), int(o, c_int32_t), &
                int(this%batch, c_int32_t), this%seg%p, this%tape_z(t)%p, this%params(tt + t)%p, this%tape_p(t)%p, gout, dzn_arg, &
-               code_arg, this%tape_a(t)%p, this%params(t)%p, da, da_e, this%grads(t)%p, this%grads(tt + t)%p, 0_c_int32_t), &
-               "readout + update reverse (one call)")
+               code_arg, this%tape_a(t)%p, this%params(t)%p, da, da_e, this%grads(t)%p, this%grads(tt + t)%p, 0_c_int32_t, &
+               acc_e), "readout + update reverse (one call)")
+          have_e_sum = .true.
           this%has_grad(tt + t) = .true.
           this%has_grad(t) = .true.
           fv_e = 0
@@ -1188,7 +1196,7 @@ contains
           fe_x = fe
        end if
        end if
-       if(present(de_dev) .and. this%ne .gt. 0)then
+       if(present(de_dev) .and. this%ne .gt. 0 .and. .not. one_call)then
           if(first_de)then
              call chk(athena_mp_duvenaud_propagate_bwd_e(this%graph, int(fv_e, c_int32_t), int(fe, c_int32_t), da_e, &
                   this%de_acc%p), "duvenaud_propagate reverse (edges)")
@@ -1205,6 +1213,18 @@ contains
           have_next = .true.
        end if
     end do
+    ! the time steps that went through the one-call reverse left the SUM of their da_e: one scatter to the edge features
+    if(present(de_dev) .and. this%ne .gt. 0 .and. have_e_sum)then
+       if(first_de)then
+          call chk(athena_mp_duvenaud_propagate_bwd_e(this%graph, 0_c_int32_t, int(fe, c_int32_t), this%dae_sum%p, &
+               this%de_acc%p), "duvenaud_propagate reverse (edges, summed over the time steps)")
+          first_de = .false.
+       else
+          call chk(athena_mp_duvenaud_propagate_bwd_e(this%graph, 0_c_int32_t, int(fe, c_int32_t), this%dae_sum%p, &
+               this%scratch(1)%p), "duvenaud_propagate reverse (edges, summed over the time steps)")
+          call chk(athena_mp_axpy(i8(this%ne) * i8(fe), 1._real32, this%scratch(1)%p, this%de_acc%p), "axpy")
+       end if
+    end if
     if(present(dx_dev)) dx_dev = dzn
     if(present(de_dev)) de_dev = this%de_acc%p
   end subroutine duvenaud_backward_dev
@@ -1217,7 +1237,7 @@ contains
        call release(this%tape_p(t)); call release(this%tape_l(t))
     end do
     call release(this%x_in); call release(this%e_in); call release(this%out_dev)
-    call release(this%gout); call release(this%de_acc)
+    call release(this%gout); call release(this%de_acc); call release(this%dae_sum)
     do t = 1, 5
        call release(this%scratch(t))
     end do

@@ -426,6 +426,7 @@ class duvenaud_msgpass_layer_type(msgpass_layer_type):
         dz_next = None
         de = None
         dx = None
+        da_e_sum = None
         for t in range(T, 0, -1):
             # readout branch of step t + the gradient arriving from step t+1, through the message activation
             fused_act = _fusable(self.activation)
@@ -434,12 +435,12 @@ class duvenaud_msgpass_layer_type(msgpass_layer_type):
                     and self.num_edge_features[0] > 0 and (t > 1 or need_input_grad or need_edge_grad)):
                 # the readout's reverse and the update's reverse of this time step in ONE call: dc [n, 64] never reaches HBM where
                 # the library's fused launch covers the shape (profiles/r05_c3_readout_update_fused_ab.txt: 0.825 -> 0.66 ms)
-                da_x, da_e, self.grads[t - 1], self.grads[T + t - 1] = ops.duvenaud_readout_update_bwd(
+                # ... and the edge part of da is SUMMED over these time steps (the scatter to the edge features is linear in it):
+                # one duvenaud_propagate_bwd_e after the loop instead of one + an axpy per time step
+                da_x, da_e_sum, self.grads[t - 1], self.grads[T + t - 1] = ops.duvenaud_readout_update_bwd(
                     g, self.params[T + t - 1], self.z[t - 1], self._p[t - 1], self._seg, gout, self._a[t - 1], self.params[t - 1],
-                    self.min_vertex_degree, self.max_vertex_degree, Fv, act=self.activation, dz_next=dz_next)
-                if need_edge_grad:
-                    d = ops.duvenaud_propagate_bwd_e(g, da_e, 0)
-                    de = d if de is None else ops.axpy(1.0, d, de)
+                    self.min_vertex_degree, self.max_vertex_degree, Fv, act=self.activation, dz_next=dz_next,
+                    da_e=da_e_sum if need_edge_grad else None)
                 if t > 1 or need_input_grad:
                     dz_next = ops.duvenaud_propagate_bwd_x(g, da_x, Fv)
                 if t == 1:
@@ -485,6 +486,9 @@ class duvenaud_msgpass_layer_type(msgpass_layer_type):
                 dz_next = ops.duvenaud_propagate_bwd_x(g, da_x, Fv)
             if t == 1:
                 dx = dz_next
+        if need_edge_grad and da_e_sum is not None:
+            d = ops.duvenaud_propagate_bwd_e(g, da_e_sum, 0)
+            de = d if de is None else ops.axpy(1.0, d, de)
         return (dx, de) if need_edge_grad else dx
 
 

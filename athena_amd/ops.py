@@ -590,9 +590,10 @@ def duvenaud_readout_bwd(R, z, p, seg, gout, act="none", dz_next=None):
 
 
 def duvenaud_readout_update_bwd(g: DeviceGraph, R, z, p, seg, gout, a, weight, min_deg, max_deg, Fv, act="none", dz_next=None,
-                                dR=None):
+                                dR=None, da_e=None):
     """One time step of the layer's reverse pass in one call: duvenaud_readout_bwd then duvenaud_update_bwd_split without dc in
-    HBM where the shape allows it.  Returns (da_x, da_e, dW, dR); dR given: added to."""
+    HBM where the shape allows it.  Returns (da_x, da_e, dW, dR); dR given: added to; da_e given: added to (the edge-feature
+    gradient is linear in it: sum over the time steps, scatter once)."""
     N, Fi = a.shape
     Fe = Fi - Fv
     O = p.shape[1]
@@ -603,7 +604,11 @@ def duvenaud_readout_update_bwd(g: DeviceGraph, R, z, p, seg, gout, a, weight, m
     if dz_next is not None:
         _chk(dz_next, (N, Fv))
     da_x = torch.empty((N, Fv), device=a.device, dtype=torch.float32)
-    da_e = torch.empty((N, Fe), device=a.device, dtype=torch.float32)
+    acc_e = da_e is not None
+    if acc_e:
+        _chk(da_e, (N, Fe))
+    else:
+        da_e = torch.empty((N, Fe), device=a.device, dtype=torch.float32)
     dW = torch.empty(weight.numel(), device=a.device, dtype=torch.float32)
     acc = dR is not None
     if not acc:
@@ -612,7 +617,8 @@ def duvenaud_readout_update_bwd(g: DeviceGraph, R, z, p, seg, gout, a, weight, m
         _chk(dR)
     _go()
     _capi.call("athena_mp_duvenaud_readout_update_bwd", g.handle, Fv, Fe, min_deg, max_deg, O, S, _p(seg), _p(z), _p(R), _p(p), _p(gout),
-               _p(dz_next) if dz_next is not None else None, ACT[act], _p(a), _p(weight), _p(da_x), _p(da_e), _p(dW), _p(dR), 1 if acc else 0)
+               _p(dz_next) if dz_next is not None else None, ACT[act], _p(a), _p(weight), _p(da_x), _p(da_e), _p(dW), _p(dR), 1 if acc else 0,
+               1 if acc_e else 0)
     return da_x, da_e, dW, dR
 
 

@@ -274,12 +274,14 @@ int athena_mp_duvenaud_update_bwd_split(const athena_mp_graph *g, int32_t Fv, in
  * z [n_rows, Fv] the ACTIVATED update output of this time step, p [n_rows, O] its softmax(R z), gout [S, O] the gradient of the
  * per-graph readout, dz_next [n_rows, Fv] or NULL the next time step's gradient with respect to z, a [n_rows, Fv + Fe],
  * weight as athena_mp_duvenaud_update_fwd; out: da_x [n_rows, Fv], da_e [n_rows, Fe], dweight, dR [O, Fv] flat o + O f
- * (accumulate_dR != 0: added to). */
+ * (accumulate_dR != 0: added to; accumulate_da_e != 0: da_e is added to as well -- get_partial_duvenaud_propagate_right_val,
+ * athena_diffstruc_extd_sub_duvenaud.f90:143-171, is linear in its upstream, so a layer that owns its reverse pass sums da_e over
+ * its time steps and scatters the sum to the edge features once). */
 int athena_mp_duvenaud_readout_update_bwd(const athena_mp_graph *g, int32_t Fv, int32_t Fe, int32_t min_deg, int32_t max_deg,
                                           int32_t O, int32_t S, const int32_t *seg, const float *z, const float *R, const float *p,
                                           const float *gout, const float *dz_next, int32_t act, const float *a,
                                           const float *weight, float *da_x, float *da_e, float *dweight, float *dR,
-                                          int32_t accumulate_dR);
+                                          int32_t accumulate_dR, int32_t accumulate_da_e);
 /* readout, athena_duvenaud_msgpass_layer.f90:838-855 over a block-diagonal batch:
  *   p[v,:] = softmax_over_outputs(logits[v,:]); out[s,:] (+)= sum_{v in seg s} p[v,:]
  *   seg_dev [S+1] 0-based vertex offsets of the graphs */

@@ -1165,6 +1165,10 @@ def test_duvenaud_readout_update_bwd_one_call(dev, oracle, Fv, Fe, O, act, dz):
     base = torch.full_like(dR, 0.5)
     _, _, _, dR3 = ops.duvenaud_readout_update_bwd(g, R, z, p, seg, gout, a, W, mn, mx, Fv, act=act, dz_next=dzn, dR=base.clone())
     assert_close((dR3 - 0.5).cpu().numpy(), dR.cpu().numpy(), 1e-5)
+    # accumulate_da_e: the edge part of da is added to the caller's buffer (one fp32 add per element), da_x as before
+    base_e = T(rng.uniform(-1, 1, (N, Fe)).astype(np.float32))
+    da_x4, da_e4, _, _ = ops.duvenaud_readout_update_bwd(g, R, z, p, seg, gout, a, W, mn, mx, Fv, act=act, dz_next=dzn, da_e=base_e.clone())
+    assert torch.equal(da_x4, da_x) and torch.equal(da_e4, base_e + da_e)
     # the oracle, op by op, from the device's z and p
     z_h, p_h = z.cpu().numpy(), p.cpu().numpy()
     dl_h = oracle.softmax_cols_bwd(p_h, np.repeat(gout_h, np.diff(voff), axis=0))
