@@ -4,6 +4,7 @@ on both sides of every kernel-selection threshold (VALU kernels / register-resid
 fallback), random degree clamps."""
 import numpy as np
 import pytest
+import torch
 
 from helpers import assert_close
 
@@ -91,6 +92,46 @@ def test_duvenaud_chain_fuzz(dev, oracle, seed):
     assert_close(H(da), dao, 1e-5, "da", f64=lambda: o64.duvenaud_update_bwd_a(dco, w, ia, mn, mx, Fv + Fe))
     assert np.array_equal(H(ops.duvenaud_propagate_bwd_x(g, T(dao, dev), Fv)), oracle.duvenaud_propagate_bwd_x(dao, Fv, ia, ja))
     assert np.array_equal(H(ops.duvenaud_propagate_bwd_e(g, T(dao, dev), Fv)), oracle.duvenaud_propagate_bwd_e(dao, Fv, E, ia, ja))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_duvenaud_one_call_reverse_fuzz(dev, seed):
+    """athena_mp_duvenaud_readout_update_bwd on random batches (isolated vertices, self loops or none, random degree windows, every
+    F_e / O / activation the one launch takes and shapes it hands to the two launches): da_x / da_e carry the bits of
+    duvenaud_readout_bwd + duvenaud_update_bwd_split, dW / dR their sums in another order; accumulate_da_e adds exactly."""
+    from athena_amd import DeviceGraph, ops
+
+    rng = np.random.default_rng(9100 + seed)
+    big = seed % 3 != 2                                   # two in three draws reach the one launch (n >= 1024)
+    ia, ja, seg, E = _batch(rng, int(rng.integers(90, 260)) if big else int(rng.integers(1, 30)), 24 if big else 12,
+                            self_loops=bool(seed % 2), isolated_frac=0.15)
+    N = ia.size - 1
+    if N == 0 or E == 0:
+        pytest.skip("degenerate draw")
+    Fv = 64 if seed % 4 != 3 else int(rng.choice([16, 32, 128]))
+    Fe = int(rng.choice([4, 8, 12, 16, 24, 32, 36]))      # 36: F_v + F_e = 100 > 96 -> the two launches
+    O = int(rng.choice([1, 2, 5, 10, 13, 16, 20]))
+    mn = int(rng.integers(1, 3)); mx = mn + int(rng.integers(0, 8))
+    act = str(rng.choice(["sigmoid", "tanh", "relu", "none"]))
+    g = DeviceGraph(ia, ja, n_edge_cols=E)
+    Fc = Fv + Fe
+    a = T(rng.uniform(-1, 1, (N, Fc)).astype(np.float32), dev)
+    W = T((0.3 * rng.standard_normal(Fv * Fc * (mx - mn + 1))).astype(np.float32), dev)
+    R = T((0.5 * rng.standard_normal(O * Fv)).astype(np.float32), dev)
+    gout = T(rng.standard_normal((seg.size - 1, O)).astype(np.float32), dev)
+    segd = T(seg, dev)
+    dzn = T(rng.standard_normal((N, Fv)).astype(np.float32), dev) if seed % 2 else None
+    z = ops.duvenaud_update_act(g, a, W, mn, mx, Fv, act=act)
+    p, _ = ops.duvenaud_readout(R, z, segd, O)
+    dc, dR2 = ops.duvenaud_readout_bwd(R, z, p, segd, gout, act=act, dz_next=dzn)
+    da_x2, da_e2, dW2 = ops.duvenaud_update_bwd_split(g, dc, a, W, mn, mx, Fv)
+    da_x, da_e, dW, dR = ops.duvenaud_readout_update_bwd(g, R, z, p, segd, gout, a, W, mn, mx, Fv, act=act, dz_next=dzn)
+    assert torch.equal(da_x, da_x2) and torch.equal(da_e, da_e2)
+    assert_close(H(dW), H(dW2), 1e-5, "dW")
+    assert_close(H(dR), H(dR2), 1e-5, "dR")
+    base = T(rng.uniform(-1, 1, (N, Fe)).astype(np.float32), dev)
+    da_x3, da_e3, dW3, _ = ops.duvenaud_readout_update_bwd(g, R, z, p, segd, gout, a, W, mn, mx, Fv, act=act, dz_next=dzn, da_e=base.clone())
+    assert torch.equal(da_x3, da_x) and torch.equal(da_e3, base + da_e) and torch.equal(dW3, dW)
 
 
 @pytest.mark.parametrize("seed", range(10))
