@@ -77,7 +77,8 @@ _PROTOS = {
     "athena_mp_duvenaud_update_bwd": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
     "athena_mp_duvenaud_update_bwd_split": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "athena_mp_duvenaud_readout_update_bwd": [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp,
-                                              _vp, _vp, _vp, _i32, _i32],
+                                              _vp, _vp, _vp, _i32, _i32, _vp],
+    "athena_mp_duvenaud_update_readout_fwd_split": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp],
     "athena_mp_softmax_segsum_fwd": [_i32, _i64, _i32, _vp, _vp, _vp, _vp, _i32],
     "athena_mp_softmax_segsum_bwd": [_i32, _i64, _i32, _vp, _vp, _vp, _vp],
     "athena_mp_activation_param_fwd": [_i32, _i64, _f32, _f32, _f32, _vp, _vp],

@@ -483,9 +483,11 @@ int athena_mp_kipf_propagate_bwd_dual(const athena_mp_graph *g, int32_t F, const
 int athena_mp_duvenaud_propagate_fwd(const athena_mp_graph *g, int32_t Fv, int32_t Fe, const float *x,
                                      const float *e, float *c)
 {
-    AMP_REQUIRE(g && x && c && Fv > 0 && Fe >= 0, "duvenaud_propagate_fwd: bad arguments");
+    AMP_REQUIRE(g && c && Fv >= 0 && Fe >= 0 && Fv + Fe > 0 && (Fv == 0 || x), "duvenaud_propagate_fwd: bad arguments");
     AMP_REQUIRE(Fe == 0 || e, "duvenaud_propagate_fwd: null edge features");
     const int64_t Fc = (int64_t)Fv + Fe;
+    if (Fv == 0)   // the edge part alone, [n_rows, Fe]: the same sums in the same order as columns Fv .. of the packed form
+        return gather_agg(g->rowptr, g->eid, nullptr, e, Fe, c, Fe, g->n_rows, Fe, &g->lp_fwd);
     if (short_rows_ok(g->max_row_len, Fv, Fe, x, Fv, e, c, Fc))   // molecule-sized rows: one launch, whole rows written
         return gather_short_rows(g->rowptr, g->col, g->eid, x, Fv, e, Fe, c, Fc, g->n_rows, Fv);
     int rc = gather_agg(g->rowptr, g->col, nullptr, x, Fv, c, Fc, g->n_rows, Fv, &g->lp_fwd);

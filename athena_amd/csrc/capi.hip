@@ -25,7 +25,7 @@ struct NamedBuf {
     void *p = nullptr;
     size_t bytes = 0;
 };
-constexpr int kWsSlots = 16;
+constexpr int kWsSlots = 20;
 struct DevCtx {
     void *ws[kWsSlots] = {};
     size_t ws_bytes[kWsSlots] = {};

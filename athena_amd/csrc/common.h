@@ -177,17 +177,20 @@ int gemm_atb_tiled(const float *A, int64_t lda, const float *B, int64_t ldb, con
                    int KI, int NO, float *C, bool accumulate);
 // bucket-sorted vertex permutation of a graph for Duvenaud's degree buckets (duvenaud.hip)
 int duvenaud_buckets(const athena_mp_graph *g, int min_deg, int max_deg);
+// [a_x | a_e] -> a packed in the library's workspace (duvenaud.hip): split a for shapes outside the split kernels
+int duv_pack_a(const athena_mp_graph *g, int32_t Fv, int32_t Fe, const float *a_x, const float *a_e, const float **packed);
 // register-resident-weight MFMA kernels of the bucketed update (duv_mfma.hip); return -1 when the shape
 // is outside what they cover (caller falls back to the tiled route)
 int duv_mfma_fwd(const athena_mp_graph *g, int Fi, int Fo, const float *a, const float *w, int act, float *c);
 int duv_mfma_bwd_a(const athena_mp_graph *g, int Fi, int Fo, const float *grad, const float *w, float *da);
 int duv_mfma_bwd_w(const athena_mp_graph *g, int Fi, int Fo, const float *grad, const float *a, float *dw);
 int duv_mfma_fwd_readout(const athena_mp_graph *g, int Fi, int Fo, const float *a, const float *w, int act, float *z,
-                         const float *R, int O, float *p);
+                         const float *R, int O, float *p, const float *a_tail = nullptr);
 int duv_mfma_bwd(const athena_mp_graph *g, int Fi, int Fo, const float *grad, const float *a, const float *w, float *da, float *dw,
                  float *da_tail = nullptr);
 // readout reverse + update reverse in one launch (duv_mfma.hip, duv_bwd_ro_kernel); -1: shape outside it
 int duv_mfma_bwd_readout(const athena_mp_graph *g, int Fi, int Fo, int O, int act, const float *a, const float *w, const float *z,
                          const float *dz_next, const float *p, const int32_t *tgid, const float *gout, const float *R, float *da,
-                         float *da_tail, float *dw, float *dr_slabs, int *n_slabs, bool accumulate_tail);
+                         float *da_tail, float *dw, float *dr_slabs, int *n_slabs, bool accumulate_tail,
+                         const float *a_tail = nullptr);
 } // namespace amp

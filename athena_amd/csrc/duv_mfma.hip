@@ -451,9 +451,14 @@ __global__ __launch_bounds__(256, (OT > 5 ? 1 : 2)) void duv_rows_wide_kernel(Bu
                                                             const float *__restrict__ W, int64_t wb, int so, int sk,
                                                             float *__restrict__ Y, int NO, int act,
                                                             const float *__restrict__ R, int O, float *__restrict__ P,
-                                                            uint32_t p_bytes)
+                                                            uint32_t p_bytes, const float *__restrict__ XT)
 {
+    // XT != null: the input rows arrive SPLIT -- columns 0 .. 63 from X as rows of 64 floats, the columns beyond from XT as rows of
+    // K - 64 floats (the Duvenaud layer's a = [neighbour sum of x | neighbour sum of e]: the edge part is the same at every time
+    // step of a layer and is gathered once; round 5)
     constexpr int PI = 16 * KJ + 4, PO = 16 * OT + 4, TI = KJ - 4, TO = OT - 4;
+    const int64_t xpm = XT ? 64 : K, xpt = XT ? K - 64 : K;
+    const float *xt = XT ? XT - 64 : X;
     __shared__ __attribute__((aligned(16))) float lds[4 * 16 * (PI + PO) + (RO ? 64 * 4 * OT : 4)];
     float *rl = lds + 4 * 16 * (PI + PO);           // R fragments: [ot][lane][c] = R(o = lane & 15, k = 16 ot + 4 (lane >> 4) + c)
     const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4, wave = threadIdx.x >> 6;
@@ -524,9 +529,10 @@ __global__ __launch_bounds__(256, (OT > 5 ? 1 : 2)) void duv_rows_wide_kernel(Bu
         for (int u = 0; u < TI; ++u) s.t[u] = v4f{1.0f, 2.0f, 3.0f, (float)id.t[u]};
 #else
 #pragma unroll
-        for (int i = 0; i < 4; ++i) s.f[i] = *reinterpret_cast<const v4f *>(X + (int64_t)id.f[i] * K + 4 * n);
+        for (int i = 0; i < 4; ++i) s.f[i] = *reinterpret_cast<const v4f *>(X + (int64_t)id.f[i] * xpm + 4 * n);
 #pragma unroll
-        for (int u = 0; u < TI; ++u) s.t[u] = *reinterpret_cast<const v4f *>(X + (int64_t)id.t[u] * K + ti.col[u]);
+        for (int u = 0; u < TI; ++u)   // (a lane without a tail chunk repeats chunk 0 of row 0 -- column 0: the main part)
+            s.t[u] = *reinterpret_cast<const v4f *>((ti.col[u] >= 64 ? xt + (int64_t)id.t[u] * xpt : X + (int64_t)id.t[u] * xpm) + ti.col[u]);
 #endif
     };
     v4f xf[KJ];
@@ -1032,8 +1038,12 @@ __global__ __launch_bounds__(256, 1) DUV_RO_ATTR void duv_bwd_ro_kernel(BucketSp
                                                             const float *__restrict__ GOUT, const float *__restrict__ R, int O,
                                                             const float *__restrict__ W, float *__restrict__ DA,
                                                             float *__restrict__ DAT, float *__restrict__ slabs,
-                                                            float *__restrict__ rslabs, int acc_e)
+                                                            float *__restrict__ rslabs, int acc_e,
+                                                            const float *__restrict__ AT)
 {
+    // AT != null: a arrives split as in duv_rows_wide_kernel (A rows of 64 floats, AT rows of F_i - 64)
+    const int64_t apm = AT ? 64 : Fi, apt = AT ? Fi - 64 : Fi;
+    const float *at = AT ? AT - 64 : A;
     // acc_e: the edge part of da is ADDED to what DAT holds (the layer sums da_e over its time steps and scatters the sum to the
     // edge features once, instead of one scatter + one axpy per time step); the old values travel with the tile's rows
     constexpr int OT = 4, Fo = 64;
@@ -1105,14 +1115,14 @@ __global__ __launch_bounds__(256, 1) DUV_RO_ATTR void duv_bwd_ro_kernel(BucketSp
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = id.f[i] ^ (id.f[i] >> 31);
-            an[i] = *reinterpret_cast<const v4f *>(A + (int64_t)r * Fi + 4 * n);
+            an[i] = *reinterpret_cast<const v4f *>(A + (int64_t)r * apm + 4 * n);
             zn[i] = *reinterpret_cast<const v4f *>(Z + (int64_t)r * Fo + 4 * n);
             if constexpr (DIN) dn[i] = *reinterpret_cast<const v4f *>(DZ + (int64_t)r * Fo + 4 * n);
         }
 #pragma unroll
         for (int u = 0; u < TA; ++u) {
             const int r = id.a[u] ^ (id.a[u] >> 31);
-            an[4 + u] = *reinterpret_cast<const v4f *>(A + (int64_t)r * Fi + ta.col[u]);
+            an[4 + u] = *reinterpret_cast<const v4f *>((ta.col[u] >= 64 ? at + (int64_t)r * apt : A + (int64_t)r * apm) + ta.col[u]);
             en[u] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
             if (acc_e && ta.col[u] >= 64) en[u] = *reinterpret_cast<const v4f *>(DAT - 64 + (int64_t)r * (Fi - 64) + ta.col[u]);
         }
@@ -1342,8 +1352,9 @@ struct ReadoutArgs {   // the readout of the same time step in the epilogue (duv
 };
 
 int launch_rows(const athena_mp_graph *g, const float *X, int K, const float *W, int64_t wb, int so, int sk, float *Y,
-                int NO, int act, const ReadoutArgs *ro = nullptr)
+                int NO, int act, const ReadoutArgs *ro = nullptr, const float *XT = nullptr)
 {
+    if (XT && !(K > 64 && NO >= 64)) return -1;   // split input rows: the wide kernel only
     if (ro && (ro->O < 1 || ro->O > 16 || (size_t)g->n_rows * ro->O * sizeof(float) >= ((size_t)1 << 32) - 4096)) return -1;
     const int kj = ceil16(K), ot = ceil16(NO);
     if ((K & 3) || (NO & 3) || !frag_shape(kj, ot)) return -1;
@@ -1360,17 +1371,17 @@ int launch_rows(const athena_mp_graph *g, const float *X, int K, const float *W,
     if (kj == KJ_ && ot == OT_) {                                                                                     \
         if (ro)                                                                                                       \
             hipLaunchKernelGGL((duv_rows_wide_kernel<KJ_, OT_, true>), grid, dim3(256), 0, amp::stream(), sp, trows_abs, \
-                               trows_t, X, K, W, wb, so, sk, Y, NO, act, ro->R, ro->O, ro->P, p_bytes);                \
+                               trows_t, X, K, W, wb, so, sk, Y, NO, act, ro->R, ro->O, ro->P, p_bytes, XT);            \
         else                                                                                                          \
             hipLaunchKernelGGL((duv_rows_wide_kernel<KJ_, OT_, false>), grid, dim3(256), 0, amp::stream(), sp, trows_abs, \
-                               trows_t, X, K, W, wb, so, sk, Y, NO, act, nullptr, 0, nullptr, 0u);                     \
+                               trows_t, X, K, W, wb, so, sk, Y, NO, act, nullptr, 0, nullptr, 0u, XT);                 \
     }
         AMP_WIDE(4, 4) AMP_WIDE(4, 5) AMP_WIDE(5, 4) AMP_WIDE(4, 6) AMP_WIDE(6, 4)
 #undef AMP_WIDE
         AMP_LAUNCH_CHECK();
         return 0;
     }
-    if (ro) return -1;   // the readout epilogue exists in the wide kernel only
+    if (ro || XT) return -1;   // the readout epilogue and split input rows exist in the wide kernel only
 #define AMP_CASE(KJ_, OT_)                                                                                         \
     if (kj == KJ_ && ot == OT_) {                                                                                  \
         hipLaunchKernelGGL((duv_rows_any_kernel<KJ_, OT_>), grid, dim3(256), 0, amp::stream(), sp, trows_abs, X,      \
@@ -1441,11 +1452,12 @@ int duv_mfma_bwd_w(const athena_mp_graph *g, int Fi, int Fo, const float *grad, 
 }
 
 // update + activation + the readout's p = softmax(R z) in one launch; -1: shape outside the wide kernel
+// a_tail != null: a split into a [n, 64] and a_tail [n, Fi - 64]
 int duv_mfma_fwd_readout(const athena_mp_graph *g, int Fi, int Fo, const float *a, const float *w, int act, float *z,
-                         const float *R, int O, float *p)
+                         const float *R, int O, float *p, const float *a_tail)
 {
     const ReadoutArgs ro{R, O, p};
-    return launch_rows(g, a, Fi, w, (int64_t)Fo * Fi, 1, Fo, z, Fo, act, &ro);
+    return launch_rows(g, a, Fi, w, (int64_t)Fo * Fi, 1, Fo, z, Fo, act, &ro, a_tail);
 }
 
 // da and dW from one pass over grad (both widths 64 .. 96); -1: shape outside the fused kernel
@@ -1486,7 +1498,7 @@ int duv_mfma_bwd(const athena_mp_graph *g, int Fi, int Fo, const float *grad, co
 // tgid: the graph of every tile slot, [16 tiles]; da_tail as in duv_mfma_bwd; dr_slabs: [workgroups][64 O]
 int duv_mfma_bwd_readout(const athena_mp_graph *g, int Fi, int Fo, int O, int act, const float *a, const float *w, const float *z,
                          const float *dz_next, const float *p, const int32_t *tgid, const float *gout, const float *R, float *da,
-                         float *da_tail, float *dw, float *dr_slabs, int *n_slabs, bool accumulate_tail)
+                         float *da_tail, float *dw, float *dr_slabs, int *n_slabs, bool accumulate_tail, const float *a_tail)
 {
     const int it = ceil16(Fi);
     if (!da_tail || (Fi & 3) || Fo != 64 || Fi <= 64 || it > 6 || O < 1 || O > 16 || act < 0 || act > ATHENA_MP_ACT_TANH) return -1;
@@ -1503,11 +1515,11 @@ int duv_mfma_bwd_readout(const athena_mp_graph *g, int Fi, int Fo, int O, int ac
         if (dz_next)                                                                                                         \
             hipLaunchKernelGGL((duv_bwd_ro_kernel<IT_, A_, true>), dim3(nwg), dim3(256), 0, stream(), sp, g->btile_rows,      \
                                g->btile_rows + (size_t)48 * nt, tgid, a, Fi, z, dz_next, p, gout, R, O, w, da, da_tail,       \
-                               (float *)slabs, dr_slabs, accumulate_tail ? 1 : 0);                                          \
+                               (float *)slabs, dr_slabs, accumulate_tail ? 1 : 0, a_tail);                                  \
         else                                                                                                                 \
             hipLaunchKernelGGL((duv_bwd_ro_kernel<IT_, A_, false>), dim3(nwg), dim3(256), 0, stream(), sp, g->btile_rows,     \
                                g->btile_rows + (size_t)48 * nt, tgid, a, Fi, z, dz_next, p, gout, R, O, w, da, da_tail,       \
-                               (float *)slabs, dr_slabs, accumulate_tail ? 1 : 0);                                          \
+                               (float *)slabs, dr_slabs, accumulate_tail ? 1 : 0, a_tail);                                  \
         launched = true;                                                                                                     \
     }
 #define AMP_RO_ACTS(IT_) AMP_RO(IT_, 0) AMP_RO(IT_, 1) AMP_RO(IT_, 2) AMP_RO(IT_, 3)

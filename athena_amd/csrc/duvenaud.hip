@@ -214,6 +214,21 @@ int duvenaud_buckets(const athena_mp_graph *g, int min_deg, int max_deg)
     g->bucket_max = max_deg;
     return 0;
 }
+// a = [a_x | a_e] packed into the library's workspace (slot 16): the way shapes outside the split kernels take a split a
+int duv_pack_a(const athena_mp_graph *g, int32_t Fv, int32_t Fe, const float *a_x, const float *a_e, const float **packed)
+{
+    const int32_t Fi = Fv + Fe;
+    void *tmp = nullptr;
+    if (workspace(&tmp, sizeof(float) * (size_t)std::max<int64_t>(g->n_rows, 1) * Fi, 16)) return 1;
+    if (g->n_rows > 0) {
+        AMP_HIP(hipMemcpy2DAsync(tmp, sizeof(float) * Fi, a_x, sizeof(float) * Fv, sizeof(float) * Fv, (size_t)g->n_rows,
+                                 hipMemcpyDeviceToDevice, stream()));
+        AMP_HIP(hipMemcpy2DAsync((float *)tmp + Fv, sizeof(float) * Fi, a_e, sizeof(float) * Fe, sizeof(float) * Fe, (size_t)g->n_rows,
+                                 hipMemcpyDeviceToDevice, stream()));
+    }
+    *packed = (const float *)tmp;
+    return 0;
+}
 } // namespace amp
 
 using namespace amp;
@@ -349,6 +364,28 @@ int athena_mp_duvenaud_update_readout_fwd(const athena_mp_graph *g, int32_t Fi, 
     if (int rc = athena_mp_duvenaud_update_act_fwd(g, Fi, Fo, min_deg, max_deg, a, weight, act, z)) return rc;
     // S = 0: logits + softmax only (the segment pointer is not read)
     return athena_mp_duvenaud_readout_fwd(g->n_rows, Fo, O, 0, (const int32_t *)g->rowptr, z, R, p, p, 0);
+}
+
+/* athena_mp_duvenaud_update_readout_fwd with a SPLIT: a_x [n_rows, Fv] (the neighbour sums of the vertex features,
+ * athena_mp_duvenaud_propagate_fwd with Fe = 0) and a_e [n_rows, Fe] (those of the edge features, athena_mp_duvenaud_propagate_fwd
+ * with Fv = 0 -- the same at every time step of a layer, so a layer gathers it once).  One launch at F_v = 64 and the fused
+ * kernel's widths; other shapes pack a into a workspace first. */
+int athena_mp_duvenaud_update_readout_fwd_split(const athena_mp_graph *g, int32_t Fv, int32_t Fe, int32_t Fo, int32_t min_deg,
+                                                int32_t max_deg, const float *a_x, const float *a_e, const float *weight,
+                                                int32_t act, float *z, int32_t O, const float *R, float *p)
+{
+    AMP_REQUIRE(g && a_x && a_e && weight && z && R && p && Fv > 0 && Fe > 0 && Fo > 0 && O > 0 && max_deg >= min_deg,
+                "duvenaud_update_readout_fwd_split: bad arguments");
+    AMP_REQUIRE(act >= 0 && act <= ATHENA_MP_ACT_TANH, "duvenaud_update_readout_fwd_split: unknown activation %d", act);
+    if (g->n_rows == 0) return 0;
+    const int32_t Fi = Fv + Fe;
+    if (Fv == 64 && duv_use_mfma(Fi, Fo, g->n_rows) && max_deg - min_deg + 1 <= 32) {
+        if (duvenaud_buckets(g, min_deg, max_deg)) return 1;
+        if (const int rc = duv_mfma_fwd_readout(g, Fi, Fo, a_x, weight, act, z, R, O, p, a_e); rc >= 0) return rc;
+    }
+    const float *a = nullptr;
+    if (duv_pack_a(g, Fv, Fe, a_x, a_e, &a)) return 1;
+    return athena_mp_duvenaud_update_readout_fwd(g, Fi, Fo, min_deg, max_deg, a, weight, act, z, O, R, p);
 }
 
 /* both reverse products of duvenaud_update from one pass over the upstream gradient: da (w.r.t. the aggregated features)

@@ -360,12 +360,13 @@ int athena_mp_duvenaud_readout_bwd(int64_t N, int32_t Fv, int32_t O, int32_t S, 
  * shape allows it (F_v = 64, F_v + F_e <= 96, O <= 16: dc never reaches HBM), the two launches through a workspace otherwise.
  * Same results as athena_mp_duvenaud_readout_bwd followed by athena_mp_duvenaud_update_bwd_split up to the order of the dR sum.
  * accumulate_da_e: da_e is added to (the edge-feature gradient is linear in da_e: a layer sums da_e over its time steps and
- * calls athena_mp_duvenaud_propagate_bwd_e once). */
+ * calls athena_mp_duvenaud_propagate_bwd_e once).  a_e != NULL: a arrives split, a = a_x [n_rows, Fv] and a_e [n_rows, Fe]
+ * (athena_mp_duvenaud_update_readout_fwd_split). */
 int athena_mp_duvenaud_readout_update_bwd(const athena_mp_graph *g, int32_t Fv, int32_t Fe, int32_t min_deg, int32_t max_deg,
                                           int32_t O, int32_t S, const int32_t *seg, const float *z, const float *R, const float *p,
                                           const float *gout, const float *dz_next, int32_t act, const float *a,
                                           const float *weight, float *da_x, float *da_e, float *dweight, float *dR,
-                                          int32_t accumulate_dR, int32_t accumulate_da_e)
+                                          int32_t accumulate_dR, int32_t accumulate_da_e, const float *a_e)
 {
     AMP_REQUIRE(g && Fv > 0 && Fe > 0 && O > 0 && S > 0 && seg && z && R && p && gout && a && weight && da_x && da_e && dweight && dR &&
                     max_deg >= min_deg, "duvenaud_readout_update_bwd: bad arguments");
@@ -385,9 +386,12 @@ int athena_mp_duvenaud_readout_update_bwd(const athena_mp_graph *g, int32_t Fv, 
         AMP_LAUNCH_CHECK();
         int n_slabs = 0;
         const int rc = duv_mfma_bwd_readout(g, Fi, Fv, O, act, a, weight, z, dz_next, p, (const int32_t *)tgid, gout, R, da_x, da_e,
-                                            dweight, (float *)rslabs, &n_slabs, accumulate_da_e != 0);
+                                            dweight, (float *)rslabs, &n_slabs, accumulate_da_e != 0, a_e);
         if (rc > 0) return rc;
         if (rc == 0) return slab_reduce((const float *)rslabs, n_slabs, Fv * O, dR, accumulate_dR != 0);
+    }
+    if (a_e) {   // a arrived split (a = a_x [n_rows, Fv]): the two launches take it packed
+        if (duv_pack_a(g, Fv, Fe, a, a_e, &a)) return 1;
     }
     void *dc = nullptr;
     if (workspace(&dc, sizeof(float) * (size_t)std::max<int64_t>(N, 1) * Fv, 13)) return 1;

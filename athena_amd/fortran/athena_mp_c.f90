@@ -41,6 +41,7 @@ module athena_mp_c
   public :: athena_mp_duvenaud_update_bwd_a, athena_mp_duvenaud_update_bwd_w, athena_mp_duvenaud_update_bwd
   public :: athena_mp_duvenaud_update_bwd_split
   public :: athena_mp_duvenaud_readout_update_bwd
+  public :: athena_mp_duvenaud_update_readout_fwd_split
   public :: athena_mp_duvenaud_update_readout_fwd
   public :: athena_mp_segment_sum, athena_mp_segment_sum_bwd
   public :: athena_mp_gno_aggregate_fwd, athena_mp_gno_aggregate_bwd_x, athena_mp_gno_aggregate_bwd_theta
@@ -706,11 +707,18 @@ module athena_mp_c
      !! the update's reverse, dc never in HBM where the shape allows it (Fv = 64, Fv + Fe <= 96, O <= 16)
      integer(c_int) function athena_mp_duvenaud_readout_update_bwd(graph, Fv, Fe, min_deg, max_deg, O, S, seg_dev, z_dev, R_dev, &
           p_dev, gout_dev, dz_next_dev, act, a_dev, weight_dev, da_x_dev, da_e_dev, dweight_dev, dR_dev, accumulate_dR, &
-          accumulate_da_e) bind(C, name="athena_mp_duvenaud_readout_update_bwd")
+          accumulate_da_e, a_e_dev) bind(C, name="athena_mp_duvenaud_readout_update_bwd")
        import :: c_int, c_int32_t, c_ptr
        type(c_ptr), value :: graph, seg_dev, z_dev, R_dev, p_dev, gout_dev, dz_next_dev, a_dev, weight_dev, da_x_dev, da_e_dev, &
-            dweight_dev, dR_dev
+            dweight_dev, dR_dev, a_e_dev
        integer(c_int32_t), value :: Fv, Fe, min_deg, max_deg, O, S, act, accumulate_dR, accumulate_da_e
+     end function
+     !! update + activation + the readout's p with a SPLIT: a_x (Fv, n) and a_e (Fe, n), the edge part gathered once per layer
+     integer(c_int) function athena_mp_duvenaud_update_readout_fwd_split(graph, Fv, Fe, Fo, min_deg, max_deg, a_x_dev, a_e_dev, &
+          weight_dev, act, z_dev, O, R_dev, p_dev) bind(C, name="athena_mp_duvenaud_update_readout_fwd_split")
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: graph, a_x_dev, a_e_dev, weight_dev, z_dev, R_dev, p_dev
+       integer(c_int32_t), value :: Fv, Fe, Fo, min_deg, max_deg, act, O
      end function
      integer(c_int) function athena_mp_segment_sum(O, N, S, seg_dev, p_dev, out_dev, accumulate) &
           bind(C, name="athena_mp_segment_sum")

@@ -112,7 +112,8 @@ module athena_mp_layers
      integer, allocatable :: num_vertex_features(:), num_edge_features(:)   ! (0:T)
      type(mp_actv_type) :: activation, activation_readout
      type(dbuf), allocatable :: tape_a(:), tape_z(:), tape_c(:), tape_p(:), tape_l(:)
-     type(dbuf) :: x_in, e_in, out_dev, gout, de_acc, dae_sum, scratch(5)
+     type(dbuf) :: x_in, e_in, out_dev, gout, de_acc, dae_sum, a_e, scratch(5)
+     logical :: split_a = .false.    !! the tape holds a split: tape_a(t) = a_x (F_v, n), a_e (F_e, n) gathered once per forward
    contains
      procedure, pass(this) :: forward => duvenaud_forward
      procedure, pass(this) :: backward => duvenaud_backward
@@ -988,12 +989,34 @@ contains
     code = fused_code(this%activation)
     softmax_ro = trim(this%activation_readout%name) .eq. "softmax" .and. .not. apply_scaling(this%activation_readout)
     cur = x_dev
+    ! a = [a_x | a_e] kept split for the whole layer where every time step is in the widths of the split launches: the edge
+    ! features do not change from time step to time step (update_message_duvenaud passes the same edge_features to every
+    ! duvenaud_propagate), so their neighbour sums are gathered ONCE; each time step gathers the vertex part into 256-byte rows
+    this%split_a = code .ge. 0 .and. softmax_ro .and. o .le. 16 .and. all(this%num_vertex_features .eq. 64) .and. fe .gt. 0 &
+         .and. fe .le. 32
+    if(this%split_a)then
+       call need(this%a_e, i8(max(n, 1)) * i8(fe))
+       call chk(athena_mp_duvenaud_propagate_fwd(this%graph, 0_c_int32_t, int(fe, c_int32_t), c_null_ptr, e_dev, this%a_e%p), &
+            "duvenaud_propagate (edge part, once)")
+    end if
     do t = 1, tt
        fv = this%num_vertex_features(t - 1)
        fin = fv + fe
        fo = this%num_vertex_features(t)
-       call need(this%tape_a(t), i8(n) * i8(fin))
        call need(this%tape_z(t), i8(n) * i8(fo))
+       if(this%split_a)then
+          call need(this%tape_a(t), i8(n) * i8(fv))
+          call need(this%tape_p(t), i8(n) * i8(o))
+          call chk(athena_mp_duvenaud_propagate_fwd(this%graph, int(fv, c_int32_t), 0_c_int32_t, cur, c_null_ptr, &
+               this%tape_a(t)%p), "duvenaud_propagate (vertex part)")
+          call chk(athena_mp_duvenaud_update_readout_fwd_split(this%graph, int(fv, c_int32_t), int(fe, c_int32_t), &
+               int(fo, c_int32_t), int(this%min_vertex_degree, c_int32_t), int(this%max_vertex_degree, c_int32_t), &
+               this%tape_a(t)%p, this%a_e%p, this%params(t)%p, code, this%tape_z(t)%p, int(o, c_int32_t), &
+               this%params(tt + t)%p, this%tape_p(t)%p), "duvenaud_update + readout (split a)")
+          cur = this%tape_z(t)%p
+          cycle
+       end if
+       call need(this%tape_a(t), i8(n) * i8(fin))
        call chk(athena_mp_duvenaud_propagate_fwd(this%graph, int(fv, c_int32_t), int(fe, c_int32_t), cur, e_dev, &
             this%tape_a(t)%p), "duvenaud_propagate")
        if(code .ge. 0 .and. softmax_ro .and. o .le. 16)then
@@ -1089,6 +1112,7 @@ contains
     integer :: t, tt, n, o, fe, fv, fo, fin, fmax, fv_e, fe_x
     logical :: have_next, fused_msg, first_de, softmax_readout, split, one_call, have_e_sum
     integer(c_int32_t) :: acc_e
+    type(c_ptr) :: a_e_arg
     integer(c_int32_t) :: code, code_arg
 
     n = this%nv
@@ -1120,8 +1144,10 @@ contains
        fin = fv + fe
        ! the readout's reverse and the update's reverse of this time step in ONE call where the library's fused launch covers the
        ! shape: dc (n, 64) never reaches HBM (profiles/r05_c3_readout_update_fused_ab.txt)
-       one_call = softmax_readout .and. fused_msg .and. fv .eq. 64 .and. fo .eq. 64 .and. fe .gt. 0 .and. &
-            (t .gt. 1 .or. present(dx_dev) .or. present(de_dev))
+       one_call = this%split_a .or. (softmax_readout .and. fused_msg .and. fv .eq. 64 .and. fo .eq. 64 .and. fe .gt. 0 .and. &
+            (t .gt. 1 .or. present(dx_dev) .or. present(de_dev)))
+       a_e_arg = c_null_ptr
+       if(this%split_a) a_e_arg = this%a_e%p
        if(one_call)then
           dzn_arg = c_null_ptr
           if(have_next) dzn_arg = dzn
@@ -1135,7 +1161,7 @@ contains
                int(this%min_vertex_degree, c_int32_t), int(this%max_vertex_degree, c_int32_t), int(o, c_int32_t), &
                int(this%batch, c_int32_t), this%seg%p, this%tape_z(t)%p, this%params(tt + t)%p, this%tape_p(t)%p, gout, dzn_arg, &
                code_arg, this%tape_a(t)%p, this%params(t)%p, da, da_e, this%grads(t)%p, this%grads(tt + t)%p, 0_c_int32_t, &
-               acc_e), "readout + update reverse (one call)")
+               acc_e, a_e_arg), "readout + update reverse (one call)")
           have_e_sum = .true.
           this%has_grad(tt + t) = .true.
           this%has_grad(t) = .true.
@@ -1237,7 +1263,7 @@ contains
        call release(this%tape_p(t)); call release(this%tape_l(t))
     end do
     call release(this%x_in); call release(this%e_in); call release(this%out_dev)
-    call release(this%gout); call release(this%de_acc); call release(this%dae_sum)
+    call release(this%gout); call release(this%de_acc); call release(this%dae_sum); call release(this%a_e)
     do t = 1, 5
        call release(this%scratch(t))
     end do

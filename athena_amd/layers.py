@@ -363,6 +363,14 @@ class duvenaud_msgpass_layer_type(msgpass_layer_type):
                                                      self.activation, kernel_initialiser)))
         self.grads = [None] * len(self.params)
 
+    def _split_a(self):
+        """a = [a_x | a_e] kept split for the whole layer: every time step in the widths of the split launches (F_v = 64 throughout,
+        F_e <= 32, at most 16 outputs, fused message activation, softmax readout).  The edge features do not change from time step
+        to time step (update_message_duvenaud, :755-817, passes the same edge_features to every duvenaud_propagate), so their
+        neighbour sums a_e are gathered ONCE per forward pass; each time step gathers the vertex part alone into 256-byte rows."""
+        return (_fusable(self.activation) and self.activation_readout == "softmax" and self.num_outputs <= 16
+                and all(v == 64 for v in self.num_vertex_features) and 0 < self.num_edge_features[0] <= 32)
+
     def update_message(self, x, e):
         """athena_duvenaud_msgpass_layer.f90:755-817"""
         g = self.graph.device
@@ -372,8 +380,19 @@ class duvenaud_msgpass_layer_type(msgpass_layer_type):
         self._e = e
         self._a, self.z, self._c = [], [], []
         self._p_early = [None] * T            # the readout's per-vertex p where it rode in the update launch
+        self._a_e = ops.duvenaud_propagate_edges(g, e) if self._split_a() else None
         cur = x
         for t in range(1, T + 1):
+            if self._a_e is not None:
+                a = ops.neighbour_sum(g, cur)
+                zt, self._p_early[t - 1] = ops.duvenaud_update_act_readout_split(
+                    g, a, self._a_e, self.params[t - 1], self.min_vertex_degree, self.max_vertex_degree, 64,
+                    self.params[T + t - 1], self.num_outputs, act=self.activation)
+                self._a.append(a)
+                self.z.append(zt)
+                self._c.append(None)
+                cur = zt
+                continue
             a = ops.duvenaud_propagate(g, cur, e)
             if _fusable(self.activation) and self.activation_readout == "softmax" and self.num_outputs <= 16:
                 # the bucket contraction with the activation AND the readout's softmax(R z) in its epilogue: the readout of
@@ -431,8 +450,9 @@ class duvenaud_msgpass_layer_type(msgpass_layer_type):
             # readout branch of step t + the gradient arriving from step t+1, through the message activation
             fused_act = _fusable(self.activation)
             Fv = self.num_vertex_features[t - 1]
-            if (self.activation_readout == "softmax" and fused_act and Fv == 64 and self.num_vertex_features[t] == 64
-                    and self.num_edge_features[0] > 0 and (t > 1 or need_input_grad or need_edge_grad)):
+            split_a = getattr(self, "_a_e", None) is not None
+            if split_a or (self.activation_readout == "softmax" and fused_act and Fv == 64 and self.num_vertex_features[t] == 64
+                           and self.num_edge_features[0] > 0 and (t > 1 or need_input_grad or need_edge_grad)):
                 # the readout's reverse and the update's reverse of this time step in ONE call: dc [n, 64] never reaches HBM where
                 # the library's fused launch covers the shape (profiles/r05_c3_readout_update_fused_ab.txt: 0.825 -> 0.66 ms)
                 # ... and the edge part of da is SUMMED over these time steps (the scatter to the edge features is linear in it):
@@ -440,7 +460,7 @@ class duvenaud_msgpass_layer_type(msgpass_layer_type):
                 da_x, da_e_sum, self.grads[t - 1], self.grads[T + t - 1] = ops.duvenaud_readout_update_bwd(
                     g, self.params[T + t - 1], self.z[t - 1], self._p[t - 1], self._seg, gout, self._a[t - 1], self.params[t - 1],
                     self.min_vertex_degree, self.max_vertex_degree, Fv, act=self.activation, dz_next=dz_next,
-                    da_e=da_e_sum if need_edge_grad else None)
+                    da_e=da_e_sum if need_edge_grad else None, a_e=self._a_e if split_a else None)
                 if t > 1 or need_input_grad:
                     dz_next = ops.duvenaud_propagate_bwd_x(g, da_x, Fv)
                 if t == 1:

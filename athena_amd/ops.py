@@ -403,6 +403,18 @@ def duvenaud_propagate(g: DeviceGraph, x, e, out=None):
     return c
 
 
+def duvenaud_propagate_edges(g: DeviceGraph, e, out=None):
+    """the edge part of duvenaud_propagate alone: a_e[v, :] = sum of e[edge of entry w, :] over row v, [n_rows, Fe] -- the same sums in
+    the same order as columns Fv .. of the packed form (the x part alone: neighbour_sum)"""
+    Fe = e.shape[1]
+    _chk(e, (g.n_edge_cols, Fe))
+    c = out if out is not None else torch.empty((g.n_rows, Fe), device=e.device, dtype=torch.float32)
+    _chk(c, (g.n_rows, Fe))
+    _go()
+    _capi.call("athena_mp_duvenaud_propagate_fwd", g.handle, 0, Fe, None, _p(e), _p(c))
+    return c
+
+
 def duvenaud_propagate_bwd_x(g: DeviceGraph, grad, Fv):
     Fe = grad.shape[1] - Fv
     _chk(grad, (g.n_rows, Fv + Fe))
@@ -456,6 +468,21 @@ def duvenaud_update_act_readout(g: DeviceGraph, a, weight, min_deg, max_deg, Fo,
     _go()
     _capi.call("athena_mp_duvenaud_update_readout_fwd", g.handle, Fi, Fo, min_deg, max_deg, _p(a), _p(_chk(weight)), ACT[act],
                _p(z), O, _p(_chk(R)), _p(p))
+    return z, p
+
+
+def duvenaud_update_act_readout_split(g: DeviceGraph, a_x, a_e, weight, min_deg, max_deg, Fo, R, O, act="none"):
+    """duvenaud_update_act_readout with a split: a_x [n, Fv] (neighbour_sum of the vertex features) and a_e [n, Fe]
+    (duvenaud_propagate_edges: the same at every time step of a layer)"""
+    Fv, Fe = a_x.shape[1], a_e.shape[1]
+    _chk(a_x, (g.n_rows, Fv)); _chk(a_e, (g.n_rows, Fe))
+    if not (weight.numel() == Fo * (Fv + Fe) * (max_deg - min_deg + 1) and R.numel() == O * Fo):
+        raise ValueError('expected: weight.numel() == Fo * (Fv + Fe) * D and R.numel() == O * Fo')
+    z = torch.empty((g.n_rows, Fo), device=a_x.device, dtype=torch.float32)
+    p = torch.empty((g.n_rows, O), device=a_x.device, dtype=torch.float32)
+    _go()
+    _capi.call("athena_mp_duvenaud_update_readout_fwd_split", g.handle, Fv, Fe, Fo, min_deg, max_deg, _p(a_x), _p(a_e), _p(_chk(weight)),
+               ACT[act], _p(z), O, _p(_chk(R)), _p(p))
     return z, p
 
 
@@ -590,15 +617,22 @@ def duvenaud_readout_bwd(R, z, p, seg, gout, act="none", dz_next=None):
 
 
 def duvenaud_readout_update_bwd(g: DeviceGraph, R, z, p, seg, gout, a, weight, min_deg, max_deg, Fv, act="none", dz_next=None,
-                                dR=None, da_e=None):
+                                dR=None, da_e=None, a_e=None):
     """One time step of the layer's reverse pass in one call: duvenaud_readout_bwd then duvenaud_update_bwd_split without dc in
     HBM where the shape allows it.  Returns (da_x, da_e, dW, dR); dR given: added to; da_e given: added to (the edge-feature
-    gradient is linear in it: sum over the time steps, scatter once)."""
-    N, Fi = a.shape
+    gradient is linear in it: sum over the time steps, scatter once); a_e given: a arrives split, a = a_x [n, Fv]."""
+    N = a.shape[0]
+    if a_e is not None:
+        _chk(a_e, (N, a_e.shape[1]))
+        Fi = Fv + a_e.shape[1]
+        _chk(a, (g.n_rows, Fv))
+    else:
+        Fi = a.shape[1]
+        _chk(a, (g.n_rows, Fi))
     Fe = Fi - Fv
     O = p.shape[1]
     S = seg.numel() - 1
-    _chk(a, (g.n_rows, Fi)); _chk(z, (N, Fv)); _chk(p, (N, O)); _chk(gout, (S, O)); _chk(R); _chk(weight)
+    _chk(z, (N, Fv)); _chk(p, (N, O)); _chk(gout, (S, O)); _chk(R); _chk(weight)
     if not (Fe > 0 and R.numel() == O * Fv and weight.numel() == (max_deg - min_deg + 1) * Fv * Fi):
         raise ValueError('expected: Fe > 0, R.numel() == O * Fv, weight.numel() == buckets * Fv * (Fv + Fe)')
     if dz_next is not None:
@@ -618,7 +652,7 @@ def duvenaud_readout_update_bwd(g: DeviceGraph, R, z, p, seg, gout, a, weight, m
     _go()
     _capi.call("athena_mp_duvenaud_readout_update_bwd", g.handle, Fv, Fe, min_deg, max_deg, O, S, _p(seg), _p(z), _p(R), _p(p), _p(gout),
                _p(dz_next) if dz_next is not None else None, ACT[act], _p(a), _p(weight), _p(da_x), _p(da_e), _p(dW), _p(dR), 1 if acc else 0,
-               1 if acc_e else 0)
+               1 if acc_e else 0, _p(a_e) if a_e is not None else None)
     return da_x, da_e, dW, dR
 
 

@@ -276,12 +276,22 @@ int athena_mp_duvenaud_update_bwd_split(const athena_mp_graph *g, int32_t Fv, in
  * weight as athena_mp_duvenaud_update_fwd; out: da_x [n_rows, Fv], da_e [n_rows, Fe], dweight, dR [O, Fv] flat o + O f
  * (accumulate_dR != 0: added to; accumulate_da_e != 0: da_e is added to as well -- get_partial_duvenaud_propagate_right_val,
  * athena_diffstruc_extd_sub_duvenaud.f90:143-171, is linear in its upstream, so a layer that owns its reverse pass sums da_e over
- * its time steps and scatters the sum to the edge features once). */
+ * its time steps and scatters the sum to the edge features once).  a_e != NULL: a arrives split as
+ * athena_mp_duvenaud_update_readout_fwd_split takes it -- a = a_x [n_rows, Fv], a_e [n_rows, Fe]. */
 int athena_mp_duvenaud_readout_update_bwd(const athena_mp_graph *g, int32_t Fv, int32_t Fe, int32_t min_deg, int32_t max_deg,
                                           int32_t O, int32_t S, const int32_t *seg, const float *z, const float *R, const float *p,
                                           const float *gout, const float *dz_next, int32_t act, const float *a,
                                           const float *weight, float *da_x, float *da_e, float *dweight, float *dR,
-                                          int32_t accumulate_dR, int32_t accumulate_da_e);
+                                          int32_t accumulate_dR, int32_t accumulate_da_e, const float *a_e);
+
+/* athena_mp_duvenaud_update_readout_fwd with a split where duvenaud_propagate (athena_diffstruc_extd_sub_duvenaud.f90:7-59)
+ * concatenates: a_x [n_rows, Fv] = the neighbour sums of the vertex features (athena_mp_duvenaud_propagate_fwd with Fe = 0),
+ * a_e [n_rows, Fe] = those of the edge features (athena_mp_duvenaud_propagate_fwd with Fv = 0).  The edge features of a layer do
+ * not change from time step to time step (update_message_duvenaud, athena_duvenaud_msgpass_layer.f90:755-836, passes the same
+ * edge_features to every duvenaud_propagate), so a layer that owns its tape gathers a_e once.  Device pointers. */
+int athena_mp_duvenaud_update_readout_fwd_split(const athena_mp_graph *g, int32_t Fv, int32_t Fe, int32_t Fo, int32_t min_deg,
+                                                int32_t max_deg, const float *a_x, const float *a_e, const float *weight,
+                                                int32_t act, float *z, int32_t O, const float *R, float *p);
 /* readout, athena_duvenaud_msgpass_layer.f90:838-855 over a block-diagonal batch:
  *   p[v,:] = softmax_over_outputs(logits[v,:]); out[s,:] (+)= sum_{v in seg s} p[v,:]
  *   seg_dev [S+1] 0-based vertex offsets of the graphs */

@@ -1181,3 +1181,39 @@ def test_duvenaud_readout_update_bwd_one_call(dev, oracle, Fv, Fe, O, act, dz):
     assert_close(da_e.cpu().numpy(), da_h[:, Fv:], 1e-5)
     assert_close(dW.cpu().numpy(), oracle.duvenaud_update_bwd_w(dc_h, a_h, ia, mn, mx), 2e-5)
     assert_close(dR.cpu().numpy(), oracle.matmul_dw(dl_h, z_h), 2e-5)
+
+
+@pytest.mark.parametrize("Fv,Fe,O,act", [(64, 8, 10, "sigmoid"), (64, 32, 16, "tanh"), (64, 4, 3, "relu"), (32, 8, 10, "sigmoid"),
+                                         (64, 8, 20, "none"), (128, 8, 5, "sigmoid")])
+def test_duvenaud_split_a_matches_the_packed_form(dev, Fv, Fe, O, act):
+    """a = [a_x | a_e] kept split (round 5): the two halves of duvenaud_propagate on their own (neighbour_sum,
+    duvenaud_propagate_edges), the update + activation + readout launch and the one-call reverse reading them -- the bits of the
+    packed form everywhere (one launch at F_v = 64 and the fused kernels' widths, a packed copy in a workspace elsewhere)."""
+    from athena_amd import DeviceGraph, ops, synth
+
+    rng = np.random.default_rng(11 * Fv + 3 * Fe + O)
+    ia, ja, voff, E = synth.molecule_batch(400, seed=9)
+    N, S = ia.size - 1, voff.size - 1
+    g = DeviceGraph(ia, ja, n_edge_cols=E)
+    mn, mx = 1, 10
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    Fc = Fv + Fe
+    x, e = T(rng.uniform(-1, 1, (N, Fv)).astype(np.float32)), T(rng.uniform(-1, 1, (E, Fe)).astype(np.float32))
+    W = T((0.3 * rng.standard_normal(Fv * Fc * (mx - mn + 1))).astype(np.float32))
+    R = T((0.3 * rng.standard_normal(O * Fv)).astype(np.float32))
+    gout, seg = T(rng.standard_normal((S, O)).astype(np.float32)), T(voff)
+    dzn = T(rng.standard_normal((N, Fv)).astype(np.float32))
+    a = ops.duvenaud_propagate(g, x, e)
+    a_x, a_e = ops.neighbour_sum(g, x), ops.duvenaud_propagate_edges(g, e)
+    assert torch.equal(a_x, a[:, :Fv]) and torch.equal(a_e, a[:, Fv:])
+    if O <= 16:
+        z, p = ops.duvenaud_update_act_readout(g, a, W, mn, mx, Fv, R, O, act=act)
+        z2, p2 = ops.duvenaud_update_act_readout_split(g, a_x, a_e, W, mn, mx, Fv, R, O, act=act)
+        assert torch.equal(z, z2) and torch.equal(p, p2)
+    else:
+        z = ops.duvenaud_update_act(g, a, W, mn, mx, Fv, act=act)
+        p, _ = ops.duvenaud_readout(R, z, seg, O)
+    one = ops.duvenaud_readout_update_bwd(g, R, z, p, seg, gout, a, W, mn, mx, Fv, act=act, dz_next=dzn)
+    two = ops.duvenaud_readout_update_bwd(g, R, z, p, seg, gout, a_x, W, mn, mx, Fv, act=act, dz_next=dzn, a_e=a_e)
+    for u, v in zip(one, two):
+        assert torch.equal(u, v)
