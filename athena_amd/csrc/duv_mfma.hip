@@ -444,7 +444,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 // register file instead of spills inside the tile loop (scripts/isa_lint.py R2); 96 INPUTS with the readout epilogue keep two
 // waves and their 44 B of spills -- measured faster that way, 0.488 against 0.545 ms, while the fused reverse kernel of the same
 // shape gains 26 % from the whole file, 0.961 -> 0.707 ms: profiles/r05_duv_96wide_ab.txt.)
-template <int KJ, int OT, bool RO>
+template <int KJ, int OT, bool RO, bool XS = false>
 __global__ __launch_bounds__(256, (OT > 5 ? 1 : 2)) void duv_rows_wide_kernel(BucketSplit sp, const int32_t *__restrict__ trows,
                                                             const int32_t *__restrict__ trows_t,
                                                             const float *__restrict__ X, int K,
@@ -453,12 +453,12 @@ __global__ __launch_bounds__(256, (OT > 5 ? 1 : 2)) void duv_rows_wide_kernel(Bu
                                                             const float *__restrict__ R, int O, float *__restrict__ P,
                                                             uint32_t p_bytes, const float *__restrict__ XT)
 {
-    // XT != null: the input rows arrive SPLIT -- columns 0 .. 63 from X as rows of 64 floats, the columns beyond from XT as rows of
+    // XS: the input rows arrive SPLIT -- columns 0 .. 63 from X as rows of 64 floats, the columns beyond from XT as rows of
     // K - 64 floats (the Duvenaud layer's a = [neighbour sum of x | neighbour sum of e]: the edge part is the same at every time
-    // step of a layer and is gathered once; round 5)
+    // step of a layer and is gathered once; round 5).  An instantiation of its own: the packed kernels keep their registers.
     constexpr int PI = 16 * KJ + 4, PO = 16 * OT + 4, TI = KJ - 4, TO = OT - 4;
-    const int64_t xpm = XT ? 64 : K, xpt = XT ? K - 64 : K;
-    const float *xt = XT ? XT - 64 : X;
+    const int64_t xpm = XS ? 64 : K, xpt = XS ? K - 64 : K;
+    const float *xt = XS ? XT - 64 : X;
     __shared__ __attribute__((aligned(16))) float lds[4 * 16 * (PI + PO) + (RO ? 64 * 4 * OT : 4)];
     float *rl = lds + 4 * 16 * (PI + PO);           // R fragments: [ot][lane][c] = R(o = lane & 15, k = 16 ot + 4 (lane >> 4) + c)
     const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4, wave = threadIdx.x >> 6;
@@ -532,7 +532,8 @@ __global__ __launch_bounds__(256, (OT > 5 ? 1 : 2)) void duv_rows_wide_kernel(Bu
         for (int i = 0; i < 4; ++i) s.f[i] = *reinterpret_cast<const v4f *>(X + (int64_t)id.f[i] * xpm + 4 * n);
 #pragma unroll
         for (int u = 0; u < TI; ++u)   // (a lane without a tail chunk repeats chunk 0 of row 0 -- column 0: the main part)
-            s.t[u] = *reinterpret_cast<const v4f *>((ti.col[u] >= 64 ? xt + (int64_t)id.t[u] * xpt : X + (int64_t)id.t[u] * xpm) + ti.col[u]);
+            s.t[u] = XS ? *reinterpret_cast<const v4f *>((ti.col[u] >= 64 ? xt + (int64_t)id.t[u] * xpt : X + (int64_t)id.t[u] * xpm) + ti.col[u])
+                        : *reinterpret_cast<const v4f *>(X + (int64_t)id.t[u] * K + ti.col[u]);
 #endif
     };
     v4f xf[KJ];
@@ -1354,9 +1355,10 @@ struct ReadoutArgs {   // the readout of the same time step in the epilogue (duv
 int launch_rows(const athena_mp_graph *g, const float *X, int K, const float *W, int64_t wb, int so, int sk, float *Y,
                 int NO, int act, const ReadoutArgs *ro = nullptr, const float *XT = nullptr)
 {
-    if (XT && !(K > 64 && NO >= 64)) return -1;   // split input rows: the wide kernel only
     if (ro && (ro->O < 1 || ro->O > 16 || (size_t)g->n_rows * ro->O * sizeof(float) >= ((size_t)1 << 32) - 4096)) return -1;
     const int kj = ceil16(K), ot = ceil16(NO);
+    // split input rows: ONE instantiation, <5, 4, readout> (the 96-wide one spills inside its tile loop: scripts/isa_lint.py R2)
+    if (XT && !(kj == 5 && ot == 4 && ro)) return -1;
     if ((K & 3) || (NO & 3) || !frag_shape(kj, ot)) return -1;
     const int nt = g->n_btiles;
     if (nt == 0) return 0;
@@ -1369,7 +1371,11 @@ int launch_rows(const athena_mp_graph *g, const float *X, int K, const float *W,
         const uint32_t p_bytes = ro ? (uint32_t)((size_t)g->n_rows * ro->O * sizeof(float)) : 0u;
 #define AMP_WIDE(KJ_, OT_)                                                                                            \
     if (kj == KJ_ && ot == OT_) {                                                                                     \
-        if (ro)                                                                                                       \
+        if (ro && XT) {                                                                                               \
+            if constexpr (KJ_ == 5 && OT_ == 4)   /* the split input: 65 .. 80 columns -> 64 only */                          \
+                hipLaunchKernelGGL((duv_rows_wide_kernel<5, 4, true, true>), grid, dim3(256), 0, amp::stream(), sp, trows_abs, \
+                                   trows_t, X, K, W, wb, so, sk, Y, NO, act, ro->R, ro->O, ro->P, p_bytes, XT);        \
+        } else if (ro)                                                                                                  \
             hipLaunchKernelGGL((duv_rows_wide_kernel<KJ_, OT_, true>), grid, dim3(256), 0, amp::stream(), sp, trows_abs, \
                                trows_t, X, K, W, wb, so, sk, Y, NO, act, ro->R, ro->O, ro->P, p_bytes, XT);            \
         else                                                                                                          \

@@ -993,7 +993,7 @@ contains
     ! features do not change from time step to time step (update_message_duvenaud passes the same edge_features to every
     ! duvenaud_propagate), so their neighbour sums are gathered ONCE; each time step gathers the vertex part into 256-byte rows
     this%split_a = code .ge. 0 .and. softmax_ro .and. o .le. 16 .and. all(this%num_vertex_features .eq. 64) .and. fe .gt. 0 &
-         .and. fe .le. 32
+         .and. fe .le. 16
     if(this%split_a)then
        call need(this%a_e, i8(max(n, 1)) * i8(fe))
        call chk(athena_mp_duvenaud_propagate_fwd(this%graph, 0_c_int32_t, int(fe, c_int32_t), c_null_ptr, e_dev, this%a_e%p), &

@@ -365,11 +365,11 @@ class duvenaud_msgpass_layer_type(msgpass_layer_type):
 
     def _split_a(self):
         """a = [a_x | a_e] kept split for the whole layer: every time step in the widths of the split launches (F_v = 64 throughout,
-        F_e <= 32, at most 16 outputs, fused message activation, softmax readout).  The edge features do not change from time step
+        F_e <= 16, at most 16 outputs, fused message activation, softmax readout).  The edge features do not change from time step
         to time step (update_message_duvenaud, :755-817, passes the same edge_features to every duvenaud_propagate), so their
         neighbour sums a_e are gathered ONCE per forward pass; each time step gathers the vertex part alone into 256-byte rows."""
         return (_fusable(self.activation) and self.activation_readout == "softmax" and self.num_outputs <= 16
-                and all(v == 64 for v in self.num_vertex_features) and 0 < self.num_edge_features[0] <= 32)
+                and all(v == 64 for v in self.num_vertex_features) and 0 < self.num_edge_features[0] <= 16)
 
     def update_message(self, x, e):
         """athena_duvenaud_msgpass_layer.f90:755-817"""

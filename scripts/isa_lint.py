@@ -37,7 +37,7 @@ TIMED_EXACT = (
     "gno_pc_kernel<false>", "gno_pc_kernel<true>", "gno_stg_kernel<false>", "gno_stg_kernel<true>", "gno_px_gather_kernel",
     "gno_dh_pc_kernel<false, 4, 1, true>", "gno_dh_pc_kernel<true, 4, 1, true>", "gno_dh_pc_kernel<false, 2, 2, true>",
     "gno_dh_pc_kernel<true, 2, 2, true>",
-    "duv_rows_wide_kernel<5, 4, true>", "duv_rows_wide_kernel<5, 4, false>", "duv_bwd_wide_kernel<5, 4>",
+    "duv_rows_wide_kernel<5, 4, true, false>", "duv_rows_wide_kernel<5, 4, true, true>", "duv_rows_wide_kernel<5, 4, false, false>", "duv_bwd_wide_kernel<5, 4>",
     "duv_bwd_ro_kernel<5, 2, true>", "duv_bwd_ro_kernel<5, 2, false>",
     "csr_gather_short_rows<16, 4>", "csr_gather_short_rows<64, 4>", "readout_bwd_kernel<4, 2, false>", "readout_bwd_kernel<4, 2, true>",
 )
@@ -52,7 +52,7 @@ KNOWN_SPILLS = {
     "agg_gemm_kernel<64, true, 3, true>": 12, "agg_gemm_kernel<64, true, 3, false>": 12, "agg_gemm_kernel<128, true, 3, false>": 12,
     # 96 inputs + the readout epilogue: two waves per SIMD WITH these spills measured faster than one wave without
     # (0.488 against 0.545 ms, profiles/r05_duv_96wide_ab.txt)
-    "duv_rows_wide_kernel<6, 4, true>": 44,
+    "duv_rows_wide_kernel<6, 4, true, false>": 44,
 }
 
 

@@ -34,7 +34,7 @@ def test_shipped_library_is_clean(shipped):
         assert by[name]["scratch_in_loop"] == 0
     # the headline kernels carry no scratch segment at all
     for name in ("agg_gemm_kernel<128, true, 0, true>", "gemm_dw_full_kernel<128, 128, true>", "gemm_dw_full_kernel<128, 128, false>",
-                 "duv_rows_wide_kernel<5, 4, true>", "duv_bwd_wide_kernel<5, 4>", "gno_stg_kernel<false>", "gno_px_gather_kernel"):
+                 "duv_rows_wide_kernel<5, 4, true, false>", "duv_rows_wide_kernel<5, 4, true, true>", "duv_bwd_wide_kernel<5, 4>", "duv_bwd_ro_kernel<5, 2, true>", "gno_stg_kernel<false>", "gno_px_gather_kernel"):
         assert by[name]["scratch"] == 0, (name, by[name]["scratch"])
 
 
