@@ -231,6 +231,87 @@ __global__ __launch_bounds__(256) void csr_gather_short_rows(const int32_t *__re
     if (edge_lane) *reinterpret_cast<v4 *>(y + row * ldy + 4 * G + 4 * gl) = acce;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Banded graphs (a batch of small graphs is block-diagonal: every neighbour of row r lies within `band` rows of r; athena_mp_graph::band).
+// The two kernels above chase rows: bounds -> entry ids -> rows, three dependent memory latencies per wave.  Here a workgroup owns RB
+// consecutive rows and STREAMS what they can touch -- rows r0 - band .. r0 + RB + band of x, 16 bytes per lane, in launch order, no
+// address depending on a load -- into LDS beside the block's bounds and entry ids (one dependent pair of loads per workgroup), then
+// gathers from LDS: 16 lanes own a row and add its entries in CSR order (bit-identical to the kernels above).  Workgroup b takes
+// chunk (b % 8) * per + b / 8: the workgroups of one XCD walk neighbouring chunks, so the 2 band rows two chunks share are L2 hits.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kBandRows = 128, kBandMax = 32, kBandEntries = 8;   // rows per workgroup, widest band, entries per row
+__global__ __launch_bounds__(256) void csr_gather_banded64(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ idx,
+                                                           const float *__restrict__ x, float *__restrict__ y, int32_t n_rows,
+                                                           int32_t band, int32_t per)
+{
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    constexpr int RB = kBandRows, XR = RB + 2 * kBandMax, NL = XR * 16 / 256;   // 12 row slices of 16 bytes per thread
+    __shared__ __attribute__((aligned(16))) float xs[XR * 64];
+    __shared__ int32_t rp[RB + 1], es[RB * kBandEntries];
+    const int chunk = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    const int r0 = chunk * RB;
+    if (r0 >= n_rows) return;
+    const int r1 = min(r0 + RB, n_rows), c0 = max(0, r0 - band), c1 = min(n_rows, r1 + band);
+    const int nx = (c1 - c0) * 16;                 // 16-byte slices of x this workgroup stages
+    v4 xv[NL];
+    const v4 *x4 = reinterpret_cast<const v4 *>(x) + (int64_t)c0 * 16;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const int t = threadIdx.x + 256 * i;
+        xv[i] = t < nx ? x4[t] : (v4){0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    if ((int)threadIdx.x <= r1 - r0) rp[threadIdx.x] = rowptr[r0 + threadIdx.x];
+    __syncthreads();
+    const int w0 = rp[0], nw = rp[r1 - r0] - w0;
+    int32_t ev[RB * kBandEntries / 256];
+#pragma unroll
+    for (int i = 0; i < RB * kBandEntries / 256; ++i) {
+        const int t = threadIdx.x + 256 * i;
+        ev[i] = t < nw ? idx[w0 + t] : 0;
+    }
+    v4 *xs4 = reinterpret_cast<v4 *>(xs);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const int t = threadIdx.x + 256 * i;
+        if (t < nx) xs4[t] = xv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < RB * kBandEntries / 256; ++i) {
+        const int t = threadIdx.x + 256 * i;
+        if (t < nw) es[t] = ev[i];
+    }
+    __syncthreads();
+    const int gl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    v4 *y4 = reinterpret_cast<v4 *>(y);
+#pragma unroll 2
+    for (int pass = 0; pass < RB / 16; ++pass) {
+        const int r = 16 * pass + rl;
+        if (r0 + r >= r1) break;
+        const int a = rp[r] - w0, b = rp[r + 1] - w0;
+        v4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int w = a; w < b; ++w) acc = acc + xs4[(es[w] - c0) * 16 + gl];
+        y4[(int64_t)(r0 + r) * 16 + gl] = acc;
+    }
+}
+
+// F = 64 dense rows on both sides, every row at most kBandEntries entries, every neighbour within kBandMax rows
+bool banded_ok(const athena_mp_graph *g, bool transposed, int F, int64_t ldx, int64_t ldy, const float *x, const float *y)
+{
+#ifdef AGG_NO_BANDED
+    return false;
+#endif
+    return g->band <= kBandMax && g->n_rows == g->n_cols && F == 64 && ldx == 64 && ldy == 64 &&
+           (transposed ? g->max_col_len : g->max_row_len) <= kBandEntries && (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0;
+}
+int gather_banded(const athena_mp_graph *g, const int32_t *rowptr, const int32_t *idx, const float *x, float *y)
+{
+    if (g->n_rows == 0) return 0;
+    const int chunks = (g->n_rows + kBandRows - 1) / kBandRows, per = (chunks + 7) / 8;
+    hipLaunchKernelGGL(csr_gather_banded64, dim3(8 * per), dim3(256), 0, amp::stream(), rowptr, idx, x, y, g->n_rows, g->band, per);
+    AMP_LAUNCH_CHECK();
+    return 0;
+}
+
 // rows of at most kShortRow entries, F a power-of-two multiple of 16 floats up to 256, 16 B aligned slices
 constexpr int kShortRow = 32;
 bool short_rows_ok(int32_t max_row_len, int F, int Fe, const float *x, int64_t ldx, const float *e, const float *y, int64_t ldy)
@@ -486,6 +567,7 @@ int athena_mp_duvenaud_propagate_fwd(const athena_mp_graph *g, int32_t Fv, int32
     AMP_REQUIRE(g && c && Fv >= 0 && Fe >= 0 && Fv + Fe > 0 && (Fv == 0 || x), "duvenaud_propagate_fwd: bad arguments");
     AMP_REQUIRE(Fe == 0 || e, "duvenaud_propagate_fwd: null edge features");
     const int64_t Fc = (int64_t)Fv + Fe;
+    if (Fe == 0 && banded_ok(g, false, Fv, Fv, Fv, x, c)) return gather_banded(g, g->rowptr, g->col, x, c);
     if (Fv == 0)   // the edge part alone, [n_rows, Fe]: the same sums in the same order as columns Fv .. of the packed form
         return gather_agg(g->rowptr, g->eid, nullptr, e, Fe, c, Fe, g->n_rows, Fe, &g->lp_fwd);
     if (short_rows_ok(g->max_row_len, Fv, Fe, x, Fv, e, c, Fc))   // molecule-sized rows: one launch, whole rows written
@@ -499,6 +581,7 @@ int athena_mp_duvenaud_propagate_bwd_x(const athena_mp_graph *g, int32_t Fv, int
                                        float *dx)
 {
     AMP_REQUIRE(g && grad && dx && Fv > 0 && Fe >= 0, "duvenaud_propagate_bwd_x: bad arguments");
+    if (Fe == 0 && banded_ok(g, true, Fv, Fv, Fv, grad, dx)) return gather_banded(g, g->t_rowptr, g->t_src, grad, dx);
     return gather_agg(g->t_rowptr, g->t_src, nullptr, grad, (int64_t)Fv + Fe, dx, Fv, g->n_cols, Fv, &g->lp_bwd);
 }
 

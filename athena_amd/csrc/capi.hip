@@ -754,6 +754,16 @@ static int graph_create_body(int32_t n_rows, int32_t n_cols, int64_t nnz, const 
     }
     rowptr[n_rows] = (int32_t)nnz;
     for (int32_t u = 0; u < n_cols; ++u) degc[u] = col_deg ? col_deg[u] : degr[u];
+    int32_t band = INT32_MAX;
+    if (adj_ja && n_rows == n_cols) {   // one pass over the entries on the host (stops at the first wide one)
+        band = 0;
+        for (int32_t v = 0; v < n_rows && band <= 64; ++v)
+            for (int32_t w = rowptr[v]; w < rowptr[v + 1]; ++w) {
+                const int32_t dlt = adj_ja[2 * (size_t)w] - 1 - v;
+                band = std::max(band, dlt < 0 ? -dlt : dlt);
+            }
+        if (band > 64) band = INT32_MAX;
+    }
 
     // Large graphs are built on the device (graph_build.hip): one upload of the caller's arrays, radix sorts
     // in HBM.  Small ones (mini-batches: ~0.1 ms on the host) and graphs with too many distinct degrees for
@@ -769,6 +779,7 @@ static int graph_create_body(int32_t n_rows, int32_t n_cols, int64_t nnz, const 
             g->nnz = nnz;
             g->n_edge_cols = n_edge_cols;
             g->max_row_len = max_row;
+            g->band = band;
             std::vector<int32_t> t_rowptr_h;
             int rc = amp::graph_build_device(g, adj_ja, rowptr, degr, degc, &t_rowptr_h, adj_ja_dev);
             if (rc == 0) {
@@ -850,6 +861,7 @@ static int graph_create_body(int32_t n_rows, int32_t n_cols, int64_t nnz, const 
     g->n_edge_cols = n_edge_cols;
     g->max_row_len = max_row;
     g->max_col_len = max_col;
+    g->band = band;
     g->n_with_edge = n_with_edge;
     g->h_deg_row = degr;
     int rc = 0;

@@ -80,6 +80,9 @@ struct athena_mp_graph {
     int32_t n_rows = 0, n_cols = 0, n_edge_cols = 0;
     int64_t nnz = 0;
     int32_t max_row_len = 0, max_col_len = 0;
+    // max |column - row| over the entries of a square graph (INT32_MAX: not known): a batch of small graphs is block-diagonal, every
+    // neighbour of a vertex sits within a few rows of it, and the gathers stage a block's rows in LDS instead of chasing them (agg.hip)
+    int32_t band = INT32_MAX;
     // unique per handle for the life of the process (a freed handle's ADDRESS can come back; its serial never does)
     uint64_t serial = next_graph_serial();
     // handle cache (athena_mp_graph_acquire / _release): users of a cached handle, -1 = not cached

@@ -39,7 +39,7 @@ TIMED_EXACT = (
     "gno_dh_pc_kernel<true, 2, 2, true>",
     "duv_rows_wide_kernel<5, 4, true, false>", "duv_rows_wide_kernel<5, 4, true, true>", "duv_rows_wide_kernel<5, 4, false, false>", "duv_bwd_wide_kernel<5, 4>",
     "duv_bwd_ro_kernel<5, 2, true>", "duv_bwd_ro_kernel<5, 2, false>",
-    "csr_gather_short_rows<16, 4>", "csr_gather_short_rows<64, 4>", "readout_bwd_kernel<4, 2, false>", "readout_bwd_kernel<4, 2, true>",
+    "csr_gather_short_rows<16, 4>", "csr_gather_short_rows<64, 4>", "csr_gather_banded64", "readout_bwd_kernel<4, 2, false>", "readout_bwd_kernel<4, 2, true>",
 )
 # Loop-invariant values the register allocator parks across a WHOLE loop nest -- stored once in front of it, reloaded once behind
 # it, no scratch instruction inside any loop -- cost nothing and are accepted up to this many bytes on a bench-line kernel

@@ -1217,3 +1217,39 @@ def test_duvenaud_split_a_matches_the_packed_form(dev, Fv, Fe, O, act):
     two = ops.duvenaud_readout_update_bwd(g, R, z, p, seg, gout, a_x, W, mn, mx, Fv, act=act, dz_next=dzn, a_e=a_e)
     for u, v in zip(one, two):
         assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize("n,band,max_len", [(1, 0, 1), (127, 5, 8), (128, 32, 8), (129, 32, 3), (1000, 31, 8), (5000, 17, 6), (3001, 33, 4),
+                                            (3001, 12, 9), (70000, 29, 8)])
+def test_banded_gather_matches_the_oracle(dev, oracle, n, band, max_len):
+    """csr_gather_banded64 (agg.hip): graphs whose every neighbour lies within 32 rows and whose rows hold at most 8 entries take
+    the LDS-staged gather at F = 64 -- forward neighbour sums and the reverse pull over the transposed CSR, bit for bit the
+    oracle's CSR-order sums; a wider band (33) or a longer row (9) takes the general kernels, same bits.  Sizes on both sides of
+    the 128-row workgroup, empty rows, the first and last block."""
+    from athena_amd import DeviceGraph, ops
+
+    rng = np.random.default_rng(n + 7 * band + max_len)
+    rows, cols = [], []
+    for v in range(n):
+        k = int(rng.integers(0, max_len + 1)) if n > 1 else 1
+        lo, hi = max(0, v - band), min(n - 1, v + band)
+        c = rng.integers(lo, hi + 1, k)
+        if k and v % 97 == 0:
+            c[0] = lo                      # the band's edge is reached
+        if k and v % 89 == 0:
+            c[-1] = hi
+        rows += [v] * k; cols += list(c)
+    rows, cols = np.asarray(rows, np.int64), np.asarray(cols, np.int64)
+    ia = np.concatenate([[1], 1 + np.cumsum(np.bincount(rows, minlength=n))]).astype(np.int32)
+    ja = np.zeros((2, rows.size), np.int32, order="F"); ja[0] = cols + 1
+    g = DeviceGraph(ia, ja, n_edge_cols=0)
+    x = rng.uniform(-1, 1, (n, 64)).astype(np.float32)
+    xd = torch.from_numpy(x).to(dev)
+    y = ops.neighbour_sum(g, xd)
+    e0 = np.zeros((1, 1), np.float32)
+    want = oracle.duvenaud_propagate(x, e0, ia, ja)[:, :64] if rows.size else np.zeros_like(x)
+    assert np.array_equal(y.cpu().numpy(), want)
+    gup = rng.uniform(-1, 1, (n, 64)).astype(np.float32)
+    dx = ops.duvenaud_propagate_bwd_x(g, torch.from_numpy(gup).to(dev), 64)
+    want_dx = oracle.duvenaud_propagate_bwd_x(gup, 64, ia, ja) if rows.size else np.zeros_like(x)
+    assert np.array_equal(dx.cpu().numpy(), want_dx)
