@@ -59,11 +59,16 @@ if a.config == "c3":
     # round 5: the readout's reverse and the update's reverse as ONE launch (what the layer mirrors run; dc never in HBM)
     t["readout_bwd+update_bwd(one launch)"] = timeit(lambda: ops.duvenaud_readout_update_bwd(g, R, z, p, seg, gout, a_, W, mn, mx, Fv, act="sigmoid"), a.reps)
     t["readout_bwd+update_bwd(one launch, +dz_next)"] = timeit(lambda: ops.duvenaud_readout_update_bwd(g, R, z, p, seg, gout, a_, W, mn, mx, Fv, act="sigmoid", dz_next=dz), a.reps)
+    # round 5: a and da kept split -- the vertex parts alone, gathered from LDS on this banded batch (csr_gather_banded64)
+    a_x = ops.neighbour_sum(g, x); da_x = da[:, :Fv].contiguous()
+    t["propagate(vertex part)"] = timeit(lambda: ops.neighbour_sum(g, x, out=a_x), a.reps)
+    t["propagate_bwd_x(split da)"] = timeit(lambda: ops.duvenaud_propagate_bwd_x(g, da_x, Fv), a.reps)
     t["propagate_bwd_x"] = timeit(lambda: ops.duvenaud_propagate_bwd_x(g, da, Fv), a.reps)
     t["propagate_bwd_e"] = timeit(lambda: ops.duvenaud_propagate_bwd_e(g, da, Fv), a.reps)
     # the step as the layer mirrors run it: the two update partials in ONE launch (the separate launches stay listed)
     tot = sum(v for k, v in t.items() if k not in ("update_bwd_w", "update_bwd_a", "update_sigmoid", "readout", "readout_bwd(+dz_next)", "readout_bwd",
-                                                   "update_bwd_fused(w+a)", "readout_bwd+update_bwd(one launch, +dz_next)"))
+                                                   "update_bwd_fused(w+a)", "readout_bwd+update_bwd(one launch, +dz_next)",
+                                                   "propagate(vertex part)", "propagate_bwd_x(split da)"))
     tot_mid = tot - t["readout_bwd+update_bwd(one launch)"] + t["readout_bwd+update_bwd(one launch, +dz_next)"]   # a step that also receives the next step's dz
     Fc = Fv + Fe
     # algorithmic bytes: gather kernels per entry, dense/elementwise ops = tensors read + written once

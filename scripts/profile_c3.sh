@@ -12,5 +12,6 @@ for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTIVE
   D=/tmp/pmc3_$(echo $C | tr ' ' '_' | cut -c1-40); rm -rf $D
   (cd /tmp && timeout 600 rocprofv3 --pmc $C --output-format csv -d $D -- python3 $OLDPWD/scripts/bench_configs.py --config c3 --reps 2 --no-cpu > /dev/null 2>> $OUT/err.txt)
   python3 scripts/pmc_summarise.py $D duv_ >> $OUT/c3_pmc.txt
+  python3 scripts/pmc_summarise.py $D csr_gather >> $OUT/c3_pmc.txt
 done
 cat $OUT/c3_pmc.txt
