@@ -234,10 +234,11 @@ def c3_layer_T4(dev, reps, ia, ja, voff, E, x, e):
     # bytes one step moves, per time step the six launches of `ops` above (the last step's reverse has no dz_next; steps 2..T of the
     # reverse read it; dc between the readout's and the update's reverse no longer exists): compulsory tensors only
     Fc = Fv + Fe
-    per_t = (N * 4 * Fv + E * 4 * Fe + nnz * 8 + N * 4 + N * 4 * Fc) + N * 4 * (Fc + Fv + O) + (N * 4 * O + S * 4 * O) \
-        + (N * 4 * (Fv + O + 1 + 2 * Fc) + S * 4 * O) + (N * 4 * Fc + nnz * 4 + N * 4 + N * 4 * Fv) \
-        + (N * 4 * Fe + nnz * 8 + E * 4 * Fe)
-    nbytes = T * per_t + (T - 1) * N * 4 * Fv
+    # (a kept split: the vertex part of propagate per time step, the edge part and its reverse once per layer)
+    per_t = (N * 4 * Fv + nnz * 4 + N * 4 + N * 4 * Fv) + N * 4 * (Fc + Fv + O) + (N * 4 * O + S * 4 * O) \
+        + (N * 4 * (Fv + O + 1 + 2 * Fc) + S * 4 * O) + (N * 4 * Fv + nnz * 4 + N * 4 + N * 4 * Fv)
+    once = (E * 4 * Fe + nnz * 4 + N * 4 + N * 4 * Fe) + (N * 4 * Fe + nnz * 8 + E * 4 * Fe)
+    nbytes = T * per_t + once + (T - 1) * N * 4 * Fv
 
     # --- the same layer code on the first NG graphs, against the oracle's per-sample composition
     NG = 2000
