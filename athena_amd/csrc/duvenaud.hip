@@ -368,8 +368,8 @@ int athena_mp_duvenaud_update_readout_fwd(const athena_mp_graph *g, int32_t Fi, 
 
 /* athena_mp_duvenaud_update_readout_fwd with a SPLIT: a_x [n_rows, Fv] (the neighbour sums of the vertex features,
  * athena_mp_duvenaud_propagate_fwd with Fe = 0) and a_e [n_rows, Fe] (those of the edge features, athena_mp_duvenaud_propagate_fwd
- * with Fv = 0 -- the same at every time step of a layer, so a layer gathers it once).  One launch at F_v = 64 and the fused
- * kernel's widths; other shapes pack a into a workspace first. */
+ * with Fv = 0 -- the same at every time step of a layer, so a layer gathers it once).  One launch at F_v = F_o = 64, F_e <= 16,
+ * O <= 16 (duv_rows_wide_kernel<5, 4, readout, split>); other shapes pack a into a workspace first. */
 int athena_mp_duvenaud_update_readout_fwd_split(const athena_mp_graph *g, int32_t Fv, int32_t Fe, int32_t Fo, int32_t min_deg,
                                                 int32_t max_deg, const float *a_x, const float *a_e, const float *weight,
                                                 int32_t act, float *z, int32_t O, const float *R, float *p)

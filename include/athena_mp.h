@@ -288,7 +288,8 @@ int athena_mp_duvenaud_readout_update_bwd(const athena_mp_graph *g, int32_t Fv, 
  * concatenates: a_x [n_rows, Fv] = the neighbour sums of the vertex features (athena_mp_duvenaud_propagate_fwd with Fe = 0),
  * a_e [n_rows, Fe] = those of the edge features (athena_mp_duvenaud_propagate_fwd with Fv = 0).  The edge features of a layer do
  * not change from time step to time step (update_message_duvenaud, athena_duvenaud_msgpass_layer.f90:755-836, passes the same
- * edge_features to every duvenaud_propagate), so a layer that owns its tape gathers a_e once.  Device pointers. */
+ * edge_features to every duvenaud_propagate), so a layer that owns its tape gathers a_e once.  One launch at F_v = F_o = 64,
+ * F_e <= 16, O <= 16; other shapes pack a into a workspace and take athena_mp_duvenaud_update_readout_fwd.  Device pointers. */
 int athena_mp_duvenaud_update_readout_fwd_split(const athena_mp_graph *g, int32_t Fv, int32_t Fe, int32_t Fo, int32_t min_deg,
                                                 int32_t max_deg, const float *a_x, const float *a_e, const float *weight,
                                                 int32_t act, float *z, int32_t O, const float *R, float *p);
