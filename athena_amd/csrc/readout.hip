@@ -101,7 +101,17 @@ __global__ void readout_segsum_kernel(int O, int S, const int32_t *__restrict__ 
     if (t >= S * O) return;
     int s = t / O, o = t - s * O;
     float acc = 0.0f;
-    for (int v = seg[s]; v < seg[s + 1]; ++v) acc = acc + p[(size_t)v * O + o];
+    // eight loads in flight, added in vertex order (the same sum: the loop was one memory latency per vertex)
+    const int v1 = seg[s + 1];
+    int v = seg[s];
+    for (; v + 8 <= v1; v += 8) {
+        float q[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) q[k] = p[(size_t)(v + k) * O + o];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc = acc + q[k];
+    }
+    for (; v < v1; ++v) acc = acc + p[(size_t)v * O + o];
     out[t] = accumulate ? out[t] + acc : acc;
 }
 
