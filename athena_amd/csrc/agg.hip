@@ -241,9 +241,10 @@ __global__ __launch_bounds__(256) void csr_gather_short_rows(const int32_t *__re
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kBandRows = 128, kBandMax = 32, kBandEntries = 8;   // rows per workgroup, widest band, entries per row
 __global__ __launch_bounds__(256) void csr_gather_banded64(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ idx,
-                                                           const float *__restrict__ x, float *__restrict__ y, int32_t n_rows,
-                                                           int32_t band, int32_t per)
+                                                           const float *__restrict__ x, int32_t xp4, float *__restrict__ y,
+                                                           int32_t n_rows, int32_t band, int32_t per)
 {
+    // xp4: pitch of x in 16-byte slices (16 = dense rows of 64 floats; 18 = the vertex part of packed [N, 72] rows, ...)
     typedef float v4 __attribute__((ext_vector_type(4)));
     constexpr int RB = kBandRows, XR = RB + 2 * kBandMax, NL = XR * 16 / 256;   // 12 row slices of 16 bytes per thread
     __shared__ __attribute__((aligned(16))) float xs[XR * 64];
@@ -254,11 +255,11 @@ __global__ __launch_bounds__(256) void csr_gather_banded64(const int32_t *__rest
     const int r1 = min(r0 + RB, n_rows), c0 = max(0, r0 - band), c1 = min(n_rows, r1 + band);
     const int nx = (c1 - c0) * 16;                 // 16-byte slices of x this workgroup stages
     v4 xv[NL];
-    const v4 *x4 = reinterpret_cast<const v4 *>(x) + (int64_t)c0 * 16;
+    const v4 *x4 = reinterpret_cast<const v4 *>(x) + (int64_t)c0 * xp4;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
         const int t = threadIdx.x + 256 * i;
-        xv[i] = t < nx ? x4[t] : (v4){0.0f, 0.0f, 0.0f, 0.0f};
+        xv[i] = t < nx ? x4[(t >> 4) * xp4 + (t & 15)] : (v4){0.0f, 0.0f, 0.0f, 0.0f};
     }
     if ((int)threadIdx.x <= r1 - r0) rp[threadIdx.x] = rowptr[r0 + threadIdx.x];
     __syncthreads();
@@ -300,14 +301,14 @@ bool banded_ok(const athena_mp_graph *g, bool transposed, int F, int64_t ldx, in
 #ifdef AGG_NO_BANDED
     return false;
 #endif
-    return g->band <= kBandMax && g->n_rows == g->n_cols && F == 64 && ldx == 64 && ldy == 64 &&
+    return g->band <= kBandMax && g->n_rows == g->n_cols && F == 64 && ldx >= 64 && ldx % 4 == 0 && ldx <= 1024 && ldy == 64 &&
            (transposed ? g->max_col_len : g->max_row_len) <= kBandEntries && (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0;
 }
-int gather_banded(const athena_mp_graph *g, const int32_t *rowptr, const int32_t *idx, const float *x, float *y)
+int gather_banded(const athena_mp_graph *g, const int32_t *rowptr, const int32_t *idx, const float *x, int64_t ldx, float *y)
 {
     if (g->n_rows == 0) return 0;
     const int chunks = (g->n_rows + kBandRows - 1) / kBandRows, per = (chunks + 7) / 8;
-    hipLaunchKernelGGL(csr_gather_banded64, dim3(8 * per), dim3(256), 0, amp::stream(), rowptr, idx, x, y, g->n_rows, g->band, per);
+    hipLaunchKernelGGL(csr_gather_banded64, dim3(8 * per), dim3(256), 0, amp::stream(), rowptr, idx, x, (int32_t)(ldx / 4), y, g->n_rows, g->band, per);
     AMP_LAUNCH_CHECK();
     return 0;
 }
@@ -567,7 +568,7 @@ int athena_mp_duvenaud_propagate_fwd(const athena_mp_graph *g, int32_t Fv, int32
     AMP_REQUIRE(g && c && Fv >= 0 && Fe >= 0 && Fv + Fe > 0 && (Fv == 0 || x), "duvenaud_propagate_fwd: bad arguments");
     AMP_REQUIRE(Fe == 0 || e, "duvenaud_propagate_fwd: null edge features");
     const int64_t Fc = (int64_t)Fv + Fe;
-    if (Fe == 0 && banded_ok(g, false, Fv, Fv, Fv, x, c)) return gather_banded(g, g->rowptr, g->col, x, c);
+    if (Fe == 0 && banded_ok(g, false, Fv, Fv, Fv, x, c)) return gather_banded(g, g->rowptr, g->col, x, Fv, c);
     if (Fv == 0)   // the edge part alone, [n_rows, Fe]: the same sums in the same order as columns Fv .. of the packed form
         return gather_agg(g->rowptr, g->eid, nullptr, e, Fe, c, Fe, g->n_rows, Fe, &g->lp_fwd);
     if (short_rows_ok(g->max_row_len, Fv, Fe, x, Fv, e, c, Fc))   // molecule-sized rows: one launch, whole rows written
@@ -581,7 +582,8 @@ int athena_mp_duvenaud_propagate_bwd_x(const athena_mp_graph *g, int32_t Fv, int
                                        float *dx)
 {
     AMP_REQUIRE(g && grad && dx && Fv > 0 && Fe >= 0, "duvenaud_propagate_bwd_x: bad arguments");
-    if (Fe == 0 && banded_ok(g, true, Fv, Fv, Fv, grad, dx)) return gather_banded(g, g->t_rowptr, g->t_src, grad, dx);
+    // (the vertex part of packed rows [n, Fv + Fe] as well: the staging loads skip the edge part of every row)
+    if (banded_ok(g, true, Fv, (int64_t)Fv + Fe, Fv, grad, dx)) return gather_banded(g, g->t_rowptr, g->t_src, grad, (int64_t)Fv + Fe, dx);
     return gather_agg(g->t_rowptr, g->t_src, nullptr, grad, (int64_t)Fv + Fe, dx, Fv, g->n_cols, Fv, &g->lp_bwd);
 }
 

@@ -1253,3 +1253,7 @@ def test_banded_gather_matches_the_oracle(dev, oracle, n, band, max_len):
     dx = ops.duvenaud_propagate_bwd_x(g, torch.from_numpy(gup).to(dev), 64)
     want_dx = oracle.duvenaud_propagate_bwd_x(gup, 64, ia, ja) if rows.size else np.zeros_like(x)
     assert np.array_equal(dx.cpu().numpy(), want_dx)
+    # the vertex part of PACKED gradient rows [n, 64 + 8]: the staging loads skip the edge part of every row
+    packed = np.concatenate([gup, rng.uniform(-1, 1, (n, 8)).astype(np.float32)], axis=1)
+    dx_p = ops.duvenaud_propagate_bwd_x(g, torch.from_numpy(packed).to(dev), 64)
+    assert np.array_equal(dx_p.cpu().numpy(), want_dx)
