@@ -206,7 +206,11 @@ template <typename Body> int staged(std::initializer_list<Stage> args, Body &&bo
         for (size_t k = 0; k < a.size(); ++k) {
             Stage &s = a[k];
             if (!s.out || !s.bytes) continue;
-            if (resident[k] && s.through) {   // a reverse partial: home at once; the device copy stays valid beside it
+            if (resident[k] && s.through) {
+                // a reverse partial goes home at once: the tape ACCUMULATES into the host array it lands in (grad%val +=
+                // partial), so the device copy cannot be trusted beyond this call -- dev_newer / trusted off: the next call
+                // that names this array uploads it again.  The residency table saves nothing for reverse outputs; it is the
+                // forward values (read several times by the reverse pass) that stay in HBM.
                 Resident &r = g_res[(const char *)s.out];
                 if (hipMemcpyAsync(s.out, s.dev, s.bytes, hipMemcpyDeviceToHost, stream()) != hipSuccess) {
                     set_error("host staging: download failed");
@@ -249,14 +253,26 @@ inline size_t fb(int64_t rows, int64_t cols) { return sizeof(float) * (size_t)ro
 // same graph handle, the same shapes and operand arrays with the same CONTENT.  "Same content" is a stamp per operand: for an
 // array that lives in the residency table behind an intact sentinel, the table entry's (id, version) -- the version moves
 // whenever the device copy is rewritten; for any other array a 64-bit hash of every byte (amp::content_hash, the graph key's
-// threaded hash).  A parked partial is handed over once, then the slot is empty; a request that does not match recomputes
-// and re-parks.  One slot per op kind: the two callbacks of a node run back to back in grad_reverse.
+// threaded hash).  A parked partial is handed over once, then the slot is empty; a request that matches no slot recomputes
+// and parks.  kPairSlots slots per op kind, least recently parked replaced first: a tape that asks a node for its left partial,
+// walks the WHOLE left subtree (other two-partial nodes included: every earlier time step of a Duvenaud chain) and only then
+// comes back for the right partial finds it still parked, as does one that asks for both back to back -- the traversal order
+// of diffstruc's grad_reverse is not something this library may assume.  What is parked in the usual order (left partial
+// asked first) is the small one (dW, dtheta); a byte budget bounds the table when it is the other way round.
+inline uint64_t mix64(uint64_t x)
+{
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
+    x ^= x >> 27; x *= 0x94d049bb133111ebull;
+    return x ^ (x >> 31);
+}
 uint64_t operand_stamp(const void *host, size_t bytes)
 {
     if (g_res_on && bytes >= kResidentMin) {
         auto it = g_res.find((const char *)host);
         if (it != g_res.end() && it->second.bytes == bytes && it->second.dev_newer && sentinel_intact(it->second, host))
-            return 0x8000000000000000ull | (it->second.id << 24) ^ it->second.version;
+            // (id, version) of the table entry, both full 64-bit counters, folded into 63 bits by a mixing hash: neither can
+            // overflow into the other however long the process runs
+            return 0x8000000000000000ull | (mix64(mix64(it->second.id) ^ it->second.version) >> 1);
     }
     return content_hash(host, bytes) & 0x7fffffffffffffffull;
 }
@@ -268,23 +284,14 @@ struct PairSlot {
     void *dev[3] = {nullptr, nullptr, nullptr};   // parked products
     size_t cap[3] = {0, 0, 0};
     bool ready[3] = {false, false, false};        // computed for (g, dims, stamp) and not handed over yet
+    uint64_t parked_at = 0;                       // g_pair_clock when it was last parked: the oldest slot is replaced first
+    bool any_ready() const { return ready[0] || ready[1] || ready[2]; }
     bool matches(const athena_mp_graph *g_, const int32_t (&d)[4], const uint64_t (&st)[4]) const
     {
         return g == g_ && serial == g_->serial && memcmp(dims, d, sizeof(dims)) == 0 && memcmp(stamp, st, sizeof(stamp)) == 0;
     }
-    int reserve(int k, size_t bytes)
-    {
-        if (cap[k] >= bytes) return 0;
-        if (dev[k]) {
-            AMP_HIP(hipStreamSynchronize(stream()));
-            AMP_HIP(hipFree(dev[k]));
-            dev[k] = nullptr;
-            cap[k] = 0;
-        }
-        AMP_HIP(hipMalloc(&dev[k], bytes));
-        cap[k] = bytes;
-        return 0;
-    }
+    int reserve(int k, size_t bytes);
+    size_t held() const { return cap[0] + cap[1] + cap[2]; }
     void clear()
     {
         g = nullptr;
@@ -300,8 +307,66 @@ struct PairSlot {
         clear();
     }
 };
-PairSlot g_pair_duv, g_pair_gno;
+constexpr int kPairSlots = 16;
+constexpr size_t kPairBudget = (size_t)4 << 30;   // bytes parked over both tables before idle slots give theirs back
+struct PairTable {
+    PairSlot slot[kPairSlots];
+    // the slot that holds `which` for (g, dims, stamps), or nullptr
+    PairSlot *find(const athena_mp_graph *g, const int32_t (&d)[4], const uint64_t (&st)[4], int which)
+    {
+        for (auto &s : slot)
+            if (s.ready[which] && s.matches(g, d, st)) return &s;
+        return nullptr;
+    }
+    // where the next fused pass parks: an empty slot if there is one, else the one parked longest ago
+    PairSlot *victim()
+    {
+        PairSlot *best = nullptr;
+        for (auto &s : slot) {
+            if (!s.any_ready()) return &s;
+            if (!best || s.parked_at < best->parked_at) best = &s;
+        }
+        return best;
+    }
+    void release()
+    {
+        for (auto &s : slot) s.release();
+    }
+    size_t held() const
+    {
+        size_t b = 0;
+        for (auto &s : slot) b += s.held();
+        return b;
+    }
+    // give back the buffers of slots that hold nothing ready (all but `keep`)
+    void trim(const PairSlot *keep)
+    {
+        for (auto &s : slot)
+            if (&s != keep && !s.any_ready() && s.held()) s.release();
+    }
+};
+PairTable g_pair_duv, g_pair_gno;
+uint64_t g_pair_clock = 0;
 int64_t g_pair_fused = 0, g_pair_handed = 0;
+
+int PairSlot::reserve(int k, size_t bytes)
+{
+    if (cap[k] >= bytes) return 0;
+    if (dev[k]) {
+        AMP_HIP(hipStreamSynchronize(stream()));
+        AMP_HIP(hipFree(dev[k]));
+        dev[k] = nullptr;
+        cap[k] = 0;
+    }
+    if (g_pair_duv.held() + g_pair_gno.held() + bytes > kPairBudget) {
+        AMP_HIP(hipStreamSynchronize(stream()));
+        g_pair_duv.trim(this);
+        g_pair_gno.trim(this);
+    }
+    AMP_HIP(hipMalloc(&dev[k], bytes));
+    cap[k] = bytes;
+    return 0;
+}
 
 } // namespace
 
@@ -699,15 +764,15 @@ int athena_mp_duvenaud_update_bwd_pair_host(const athena_mp_graph *g, int32_t Fi
     const int32_t dims[4] = {Fi, Fo, mn | (act << 16), mx};
     const uint64_t st[4] = {operand_stamp(grad, fb(N, Fo)), operand_stamp(a, fb(N, Fi)), operand_stamp(w, bytes[1]),
                             has_act ? operand_stamp(z_or_null, fb(N, Fo)) : 0};
-    PairSlot &S = g_pair_duv;
-    if (S.matches(g, dims, st) && S.ready[which]) {
-        S.ready[which] = false;
+    if (PairSlot *hit = g_pair_duv.find(g, dims, st, which)) {
+        hit->ready[which] = false;
         ++g_pair_handed;
         return staged({{nullptr, out, bytes[which], true}}, [&](std::vector<void *> &d) {
-            AMP_HIP(hipMemcpyAsync(d[0], S.dev[which], bytes[which], hipMemcpyDeviceToDevice, stream()));
+            AMP_HIP(hipMemcpyAsync(d[0], hit->dev[which], bytes[which], hipMemcpyDeviceToDevice, stream()));
             return 0;
         });
     }
+    PairSlot &S = *g_pair_duv.victim();
     const int other = 1 - which;
     S.clear();
     if (S.reserve(other, bytes[other])) return 1;
@@ -731,6 +796,7 @@ int athena_mp_duvenaud_update_bwd_pair_host(const athena_mp_graph *g, int32_t Fi
     memcpy(S.dims, dims, sizeof(dims));
     memcpy(S.stamp, st, sizeof(st));
     S.ready[other] = true;
+    S.parked_at = ++g_pair_clock;
     ++g_pair_fused;
     return 0;
 }
@@ -749,15 +815,15 @@ int athena_mp_gno_aggregate_bwd_pair_host(const athena_mp_graph *g, int32_t d, i
     const int32_t dims[4] = {d, H, Fi, Fo};
     const uint64_t st[4] = {operand_stamp(theta, tb), operand_stamp(coords, bytes[2]), operand_stamp(x, fb(g->n_cols, Fi)),
                             operand_stamp(grad, fb(g->n_rows, Fo))};
-    PairSlot &S = g_pair_gno;
-    if (S.matches(g, dims, st) && S.ready[which]) {
-        S.ready[which] = false;
+    if (PairSlot *hit = g_pair_gno.find(g, dims, st, which)) {
+        hit->ready[which] = false;
         ++g_pair_handed;
         return staged({{nullptr, out, bytes[which], true}}, [&](std::vector<void *> &p) {
-            AMP_HIP(hipMemcpyAsync(p[0], S.dev[which], bytes[which], hipMemcpyDeviceToDevice, stream()));
+            AMP_HIP(hipMemcpyAsync(p[0], hit->dev[which], bytes[which], hipMemcpyDeviceToDevice, stream()));
             return 0;
         });
     }
+    PairSlot &S = *g_pair_gno.victim();
     S.clear();
     for (int k = 0; k < 2; ++k)
         if (k != which && S.reserve(k, bytes[k])) return 1;
@@ -777,6 +843,7 @@ int athena_mp_gno_aggregate_bwd_pair_host(const athena_mp_graph *g, int32_t d, i
     memcpy(S.stamp, st, sizeof(st));
     S.ready[0] = which != 0;
     S.ready[1] = which != 1;
+    S.parked_at = ++g_pair_clock;
     ++g_pair_fused;
     return 0;
 }

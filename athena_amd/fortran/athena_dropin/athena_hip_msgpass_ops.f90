@@ -1,27 +1,33 @@
-!! The autodiff ops of INTEGRATION.md section 2 for all three layers, as ONE source that needs nothing of athena but diffstruc's
-!! array_type: scripts/integration_check/run.sh puts it through the Fortran compiler against compile-only stand-ins for
-!! coreutils / diffstruc, and __graft_entry__.build() LINKS it against libathena_mp.so with a minimal working tape
-!! (mini_tape.f90) so that run_ops.f90 RUNS every op and every `pure` partial callback on the GPU.
+!! src/athena/athena_hip_msgpass_ops.f90 of an athena checkout (athena_dropin/install.sh puts it there): the autodiff ops of
+!! the three message-passing layers on libathena_mp.so.  Needs nothing of athena but diffstruc's array_type and the binding
+!! module athena_mp_c.  Every op keeps the contract of the procedure it stands in for -- a result node from create_result, the
+!! value from one device call, `pure` get_partial_*_val callbacks (legal: the bind(C) interfaces are declared pure) -- so the
+!! tape diffstruc builds over them has the shape of the reference's:
 !!   * kipf_propagate_hip      contract of kipf_propagate            (athena_diffstruc_extd_sub_kipf.f90:7-59), partial :85-111
-!!   * duvenaud_update_act_readout_hip   update + message activation + the readout's softmax(matmul(R, z)) in ONE launch; the
-!!                             readout node's two partials (softmax reverse, then the matmul's) as callbacks of their own
+!!   * matmul_hip              the dense step matmul(params(t), ptr2) (athena_kipf_msgpass_layer.f90:951, athena_graph_nop_layer
+!!                             .f90:761, athena_duvenaud_msgpass_layer.f90:842) on the MFMA kernels, with the activation as the
+!!                             GEMM's epilogue when the device applies it (none / relu / sigmoid / tanh)
 !!   * duvenaud_propagate_hip  contract of duvenaud_propagate        (athena_diffstruc_extd_sub_duvenaud.f90:7-59),
 !!                             partials of :115-141 (vertex features) and :143-171 (edge features)
 !!   * duvenaud_update_hip     contract of duvenaud_update           (:176-228), partials of :284-324 (a) and :326-368 (weight)
+!!   * duvenaud_update_act_readout_hip   update + message activation + the readout's softmax(matmul(R, z)) in ONE launch; the
+!!                             readout node's two partials (softmax reverse, then the matmul's) as callbacks of their own
 !!   * gno_kernel_hip + gno_aggregate_hip   the pair gno_kernel_eval / gno_aggregate (athena_diffstruc_extd_sub_nop.f90:26-115,
 !!                             :330-397; call site athena_graph_nop_layer.f90:743-758) WITHOUT the [F_out F_in, E] tensor
 !!                             between them: the first node's value is the parameter vector itself (identity), the second
 !!                             does kernel evaluation and aggregation in one device call and differentiates w.r.t. theta
 !! The device graph handle and the op's integer arguments travel with the result node in `indices`, where the reference
 !! keeps its copies of adj_ia / adj_ja, so that the `pure` partial callbacks find them.
-module athena_mp__hip_ops
+!! scripts/integration_check/run.sh compiles this file against athena's real modules and links it into run_ops / run_layers,
+!! which run every op and every callback on the GPU (tests/test_gpu_integration_run.py).
+module athena__hip_msgpass_ops
   use, intrinsic :: iso_c_binding
   use coreutils, only: real32, stop_program
   use diffstruc, only: array_type
   use athena_mp_c
   implicit none
   private
-  public :: kipf_propagate_hip
+  public :: kipf_propagate_hip, matmul_hip
   public :: duvenaud_propagate_hip, duvenaud_update_hip, gno_kernel_hip, gno_aggregate_hip
   public :: duvenaud_update_act_readout_hip, get_partial_readout_softmax_hip_z_val, get_partial_readout_softmax_hip_weight_val
   public :: handle_of, n_handle
@@ -73,6 +79,84 @@ contains
          upstream_grad, output, 0_c_int32_t)
     if(rc .ne. 0) error stop "kipf_propagate_hip: reverse pass failed"
   end subroutine get_partial_kipf_propagate_hip_left_val
+
+  ! ---------------------------------------------------------------- the dense step
+  function matmul_hip(weight, input, act) result(c)
+    !! c = act(W input) with W = params(t) held flat as [F_out F_in, 1] (column-major W(F_out, F_in), which is the row-major
+    !! Wt[F_in][F_out] the kernel reads) and input [F_in, N]: matmul(params(t), ptr2), athena_kipf_msgpass_layer.f90:951,
+    !! followed by this%activation%apply(ptr3) (:952) when `act` is one of the device's epilogues.  Left operand = the
+    !! weights, right operand = the features, as diffstruc's matmul orders them.
+    class(array_type), intent(in), target :: weight, input
+    integer(c_int32_t), intent(in), optional :: act
+    type(array_type), pointer :: c
+    integer(c_int) :: rc
+    integer(c_int32_t) :: act_
+    integer :: Fi, Fo
+
+    act_ = ATHENA_MP_ACT_NONE
+    if(present(act)) act_ = act
+    Fi = size(input%val, 1)
+    Fo = size(weight%val, 1) / Fi
+    if(Fo * Fi .ne. size(weight%val, 1)) call stop_program("matmul_hip: the weights do not hold [F_out, F_in]")
+    c => input%create_result([Fo, size(input%val, 2)])
+    rc = athena_mp_gemm_fwd_host(int(size(input%val, 2), c_int64_t), int(Fi, c_int32_t), int(Fo, c_int32_t), input%val, &
+         weight%val, c_null_ptr, act_, c%val)
+    if(rc .ne. 0) call stop_program("matmul_hip: "//athena_mp_error_message())
+    c%indices = [Fi, Fo, int(act_)]
+    c%get_partial_left_val => get_partial_matmul_hip_weight_val
+    c%get_partial_right_val => get_partial_matmul_hip_input_val
+    if(weight%requires_grad .or. input%requires_grad)then
+       c%requires_grad = .true.
+       c%is_forward = weight%is_forward .or. input%is_forward
+       c%operation = 'matmul'
+       c%left_operand => weight
+       c%right_operand => input
+       c%owns_left_operand = weight%is_temporary
+       c%owns_right_operand = input%is_temporary
+    end if
+  end function matmul_hip
+
+  pure subroutine get_partial_matmul_hip_weight_val(this, upstream_grad, output)
+    !! dW = (act'(y) * g) P^T, flat as params(t)%val(:,1)
+    class(array_type), intent(in) :: this
+    real(real32), dimension(:,:), intent(in) :: upstream_grad
+    real(real32), dimension(:,:), intent(out) :: output
+    real(real32), allocatable :: dz(:,:)
+    integer(c_int) :: rc
+    integer(c_int64_t) :: N
+    N = int(size(upstream_grad, 2), c_int64_t)
+    if(this%indices(3) .eq. ATHENA_MP_ACT_NONE)then
+       rc = athena_mp_gemm_dw_host(N, int(this%indices(1), c_int32_t), int(this%indices(2), c_int32_t), &
+            this%right_operand%val, upstream_grad, output)
+    else
+       allocate(dz(size(upstream_grad, 1), size(upstream_grad, 2)))
+       rc = athena_mp_activation_bwd_host(int(this%indices(3), c_int32_t), N * size(upstream_grad, 1), this%val, upstream_grad, dz)
+       if(rc .eq. 0) rc = athena_mp_gemm_dw_host(N, int(this%indices(1), c_int32_t), int(this%indices(2), c_int32_t), &
+            this%right_operand%val, dz, output)
+    end if
+    if(rc .ne. 0) error stop "matmul_hip: reverse pass (weights) failed"
+  end subroutine get_partial_matmul_hip_weight_val
+
+  pure subroutine get_partial_matmul_hip_input_val(this, upstream_grad, output)
+    !! dP = W^T (act'(y) * g)
+    class(array_type), intent(in) :: this
+    real(real32), dimension(:,:), intent(in) :: upstream_grad
+    real(real32), dimension(:,:), intent(out) :: output
+    real(real32), allocatable :: dz(:,:)
+    integer(c_int) :: rc
+    integer(c_int64_t) :: N
+    N = int(size(upstream_grad, 2), c_int64_t)
+    if(this%indices(3) .eq. ATHENA_MP_ACT_NONE)then
+       rc = athena_mp_gemm_dx_host(N, int(this%indices(1), c_int32_t), int(this%indices(2), c_int32_t), upstream_grad, &
+            this%left_operand%val, output)
+    else
+       allocate(dz(size(upstream_grad, 1), size(upstream_grad, 2)))
+       rc = athena_mp_activation_bwd_host(int(this%indices(3), c_int32_t), N * size(upstream_grad, 1), this%val, upstream_grad, dz)
+       if(rc .eq. 0) rc = athena_mp_gemm_dx_host(N, int(this%indices(1), c_int32_t), int(this%indices(2), c_int32_t), dz, &
+            this%left_operand%val, output)
+    end if
+    if(rc .ne. 0) error stop "matmul_hip: reverse pass (features) failed"
+  end subroutine get_partial_matmul_hip_input_val
 
   ! ---------------------------------------------------------------- duvenaud_propagate
   function duvenaud_propagate_hip(vertex_features, edge_features, graph_handle) result(c)
@@ -371,4 +455,4 @@ contains
     if(rc .ne. 0) error stop "gno_aggregate_hip: reverse pass (kernel parameters) failed"
   end subroutine get_partial_gno_aggregate_hip_kernel_val
 
-end module athena_mp__hip_ops
+end module athena__hip_msgpass_ops

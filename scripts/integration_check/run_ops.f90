@@ -1,15 +1,16 @@
-!! LINKED AND RUN on the GPU (tests/test_gpu_integration_run.py): the autodiff ops of hip_duvenaud_gno_ops.f90 -- the source a
-!! maintainer adds to athena -- driven from Fortran through a working minimal tape (mini_tape.f90) with diffstruc's callback
-!! protocol.  For a Duvenaud step (propagate -> update) and a graph-neural-operator aggregate it builds the nodes, calls
-!! grad_reverse (left partial, then right partial, each through its `pure` callback) and holds every leaf gradient against the
-!! op-granular C entry points called directly; athena_mp_pair_stats must show ONE fused device pass and ONE hand-over per
+!! LINKED AND RUN on the GPU (tests/test_gpu_integration_run.py): the autodiff ops of
+!! athena_amd/fortran/athena_dropin/athena_hip_msgpass_ops.f90 -- the source a maintainer adds to athena -- driven from Fortran
+!! through the stand-in's working tape (standins.f90) with diffstruc's callback protocol.  For a Duvenaud step (propagate ->
+!! update), the dense step and a graph-neural-operator aggregate it builds the nodes, runs the reverse pass (every node asked
+!! once for its left partial, then for its right one, each through its `pure` callback) and holds every leaf gradient against
+!! the op-granular C entry points called directly; athena_mp_pair_stats must show ONE fused device pass and ONE hand-over per
 !! two-partial node.  Prints "RUN_OPS_OK <fused passes> <hand-overs>" or stops with a message.
 program run_ops
   use, intrinsic :: iso_c_binding
   use coreutils, only: real32
-  use diffstruc, only: array_type
+  use diffstruc, only: array_type, weighted_sum, operator(+)
   use athena_mp_c
-  use athena_mp__hip_ops
+  use athena__hip_msgpass_ops
   implicit none
   integer(c_int64_t) :: f0, h0, f1, h1
   integer(c_int64_t) :: fused_total, handed_total
@@ -20,14 +21,16 @@ program run_ops
   call duvenaud_case(n=3000, fv=64, fe=8, fo=64, resident=.false.)      ! the fused MFMA reverse kernel (configs[2]'s widths)
   call duvenaud_case(n=3000, fv=64, fe=8, fo=64, resident=.true.)       ! ... with every %val resident in HBM between the calls
   call kipf_case(n=500, f=32)
+  call matmul_case(n=2000, fi=64, fo=128, act=ATHENA_MP_ACT_RELU)             ! the MFMA dense step with its epilogue
+  call matmul_case(n=37, fi=6, fo=10, act=ATHENA_MP_ACT_NONE)
   call fused_duvenaud_case(n=3000, fv=64, fe=8, fo=64, no=10)           ! ONE launch for update + sigmoid + softmax(R z): z and p as nodes
   call gno_case(n=600, d=3, h=64, fi=64, fo=64)                         ! the one-contraction reverse pass
   call gno_case(n=50, d=2, h=7, fi=5, fo=9)                             ! generic shapes (separate entry points behind the pair)
   if(athena_mp_pair_stats(f1, h1) .ne. 0) call fail("pair_stats")
   fused_total = f1 - f0
   handed_total = h1 - h0
-  if(fused_total .ne. 7 .or. handed_total .ne. 7) then
-     write(0, *) "pair slots: fused passes", fused_total, " hand-overs", handed_total, " (expected 7 and 7)"
+  if(fused_total .ne. 6 .or. handed_total .ne. 6) then
+     write(0, *) "pair slots: fused passes", fused_total, " hand-overs", handed_total, " (expected 6 and 6)"
      error stop 1
   end if
   if(athena_mp_finalize() .ne. 0) call fail("finalize")
@@ -108,7 +111,7 @@ contains
     end if
     a => duvenaud_propagate_hip(x, e, handle)
     c => duvenaud_update_hip(a, w, handle, mn, mx, fo)
-    call c%grad_reverse(up)                                     ! left partial, then right partial, of every node
+    call c%grad_reverse_from(up)                                ! left partial, then right partial, of every node
     if(resident)then
        if(athena_mp_resident_mode(0_c_int32_t) .ne. 0) call fail("resident_mode off")     ! everything goes home
     end if
@@ -144,11 +147,38 @@ contains
     call fill(x%val, 11); call fill(up, 12)
     x%requires_grad = .true.; x%is_temporary = .false.
     c => kipf_propagate_hip(x, handle)
-    call c%grad_reverse(up)
+    call c%grad_reverse_from(up)
     if(athena_mp_kipf_propagate_bwd_host(handle, int(f, c_int32_t), up, dx, 0_c_int32_t) .ne. 0) call fail("kipf_propagate_bwd_host")
     call close_to(x%grad%val, dx, "kipf: dx through the tape")
     if(athena_mp_graph_release(handle) .ne. 0) call fail("graph_release")
   end subroutine kipf_case
+
+  subroutine matmul_case(n, fi, fo, act)
+    !! matmul_hip: c = act(W p), dW and dp through the tape against gemm_dw / gemm_dx behind activation_bwd called directly
+    integer, intent(in) :: n, fi, fo
+    integer(c_int32_t), intent(in) :: act
+    type(array_type), target :: w, p
+    type(array_type), pointer :: c
+    real(real32), allocatable :: up(:,:), dz(:,:), dw(:,:), dp(:,:), z(:,:)
+    integer(c_int) :: rc
+
+    allocate(w%val(fo * fi, 1), p%val(fi, n), up(fo, n), dz(fo, n), dw(fo * fi, 1), dp(fi, n), z(fo, n))
+    w%shape = [fo, fi]
+    call fill(w%val, 31); call fill(p%val, 32); call fill(up, 33)
+    w%requires_grad = .true.; p%requires_grad = .true.
+    w%is_temporary = .false.; p%is_temporary = .false.
+    c => matmul_hip(w, p, act)
+    z = matmul(reshape(w%val(:, 1), [fo, fi]), p%val)
+    if(act .eq. ATHENA_MP_ACT_RELU) z = max(z, 0._real32)
+    call close_to(c%val, z, "matmul_hip: value against the intrinsic matmul")
+    call c%grad_reverse_from(up)
+    rc = athena_mp_activation_bwd_host(act, int(fo, c_int64_t) * n, c%val, up, dz)
+    if(rc .eq. 0) rc = athena_mp_gemm_dw_host(int(n, c_int64_t), int(fi, c_int32_t), int(fo, c_int32_t), p%val, dz, dw)
+    if(rc .eq. 0) rc = athena_mp_gemm_dx_host(int(n, c_int64_t), int(fi, c_int32_t), int(fo, c_int32_t), dz, w%val, dp)
+    if(rc .ne. 0) call fail("direct dense entry points")
+    call close_to(w%grad%val, dw, "matmul_hip: dW through the tape")
+    call close_to(p%grad%val, dp, "matmul_hip: dP through the tape")
+  end subroutine matmul_case
 
   subroutine fused_duvenaud_case(n, fv, fe, fo, no)
     !! what hip_duvenaud_msgpass_layer_type's fused branch builds per time step: propagate -> ONE launch for update + sigmoid +
@@ -158,7 +188,7 @@ contains
     integer :: ne, mn, mx, fi
     type(c_ptr) :: handle
     type(array_type), target :: x, e, w, r, p
-    type(array_type), pointer :: a, z
+    type(array_type), pointer :: a, z, loss
     real(real32), allocatable :: gz(:,:), gp(:,:), dl(:,:), dzp(:,:), dc1(:,:), dc2(:,:), da1(:,:), da2(:,:), dw1(:,:), dw2(:,:), dr(:,:)
     integer(c_int) :: rc
     integer(c_int32_t) :: sig
@@ -178,8 +208,10 @@ contains
     p%left_operand => z
     p%right_operand => r
     p%requires_grad = .true.
-    call z%grad_reverse(gz)          ! the gradient arriving from the next time step
-    call p%grad_reverse(gp)          ! ... and the readout's: reaches z (and through it a, w, x, e) a second time, and R
+    ! the gradient arriving from the next time step (gz, on z) and the readout's (gp, on p) as ONE scalar loss: z collects both
+    ! before it is asked for its partials -- one fused device pass for the node, not one per arriving gradient
+    loss => weighted_sum(z, gz) + weighted_sum(p, gp)
+    call loss%grad_reverse()
     ! expected, from the op-granular entry points
     allocate(dl(no, n), dzp(fo, n), dc1(fo, n), dc2(fo, n), da1(fi, n), da2(fi, n), dw1(size(w%val, 1), 1), dw2(size(w%val, 1), 1), dr(no * fo, 1))
     rc = athena_mp_softmax_bwd_host(int(n, c_int64_t), int(no, c_int32_t), p%val, gp, dl)
@@ -195,7 +227,7 @@ contains
     call close_to(r%grad%val, dr, "fused duvenaud: dR through the tape")
     call close_to(a%grad%val, da1 + da2, "fused duvenaud: da through the tape")
     call close_to(w%grad%val, dw1 + dw2, "fused duvenaud: dW through the tape")
-    if(z%partial_calls .ne. 4 .or. p%partial_calls .ne. 2) call fail("fused duvenaud: callbacks per node")
+    if(z%partial_calls .ne. 2 .or. p%partial_calls .ne. 2) call fail("fused duvenaud: callbacks per node")
     if(athena_mp_graph_release(handle) .ne. 0) call fail("graph_release")
   end subroutine fused_duvenaud_case
 
@@ -223,7 +255,7 @@ contains
     x%is_temporary = .false.; coords%is_temporary = .false.; theta%is_temporary = .false.
     k => gno_kernel_hip(coords, theta)
     m => gno_aggregate_hip(x, k, handle, d, h, fi, fo)
-    call m%grad_reverse(up)
+    call m%grad_reverse_from(up)
     if(m%partial_calls .ne. 2) call fail("grad_reverse did not ask the aggregate node for both partials")
     allocate(dx(fi, n), dth(size(theta%val, 1), 1))
     rc = athena_mp_gno_aggregate_bwd_x_host(handle, int(d, c_int32_t), int(h, c_int32_t), int(fi, c_int32_t), int(fo, c_int32_t), theta%val, &

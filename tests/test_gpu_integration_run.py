@@ -1,20 +1,152 @@
-"""GPU: the drop-in autodiff ops a maintainer adds to athena (scripts/integration_check/hip_duvenaud_gno_ops.f90), LINKED against
-libathena_mp.so and RUN from Fortran through a minimal working tape with diffstruc's callback protocol (mini_tape.f90; diffstruc
-itself is not in this image): result nodes, operand links, `pure` get_partial_*_val callbacks asked one at a time by grad_reverse.
-Every leaf gradient against the op-granular entry points; ONE fused device pass and ONE hand-over per two-partial node."""
+"""GPU: the drop-in a maintainer adds to athena (athena_amd/fortran/athena_dropin/), LINKED against libathena_mp.so and RUN from
+Fortran.  Two programs, built in the build container by scripts/integration_check/run.sh (they travel to the GPU box as built):
+
+  run_ops     the autodiff ops through the working tape of the one stand-in for diffstruc (standins.f90; diffstruc itself is not
+              in this image): result nodes, operand links, `pure` get_partial_*_val callbacks asked one at a time.  Every leaf
+              gradient against the op-granular entry points; ONE fused device pass and ONE hand-over per two-partial node.
+  run_layers  the three hip_* LAYER TYPES (they extend athena's concrete kipf / duvenaud / graph_nop types) built with their
+              constructors and driven by athena's OWN compiled code -- forward_msgpass, get_params / set_params / get_gradients,
+              print_to_unit / read, the checkpoint registry -- on the reference's hand graphs and on >= 1024-vertex batches;
+              held in the program against the shipped *_mp_layer_type and HERE, from the dumps it writes, against oracle/layers.py
+              (output, input gradients, flat parameter gradients; 1e-5, float64-anchored)."""
 import os
 import subprocess
+import types
 
+import numpy as np
 import pytest
+
+import oracle_layers as ol
+from helpers import assert_close
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ICHECK = os.path.join(ROOT, "scripts", "integration_check")
+
+
+def _exe(name):
+    exe = os.path.join(ICHECK, name)
+    if not os.path.exists(exe):
+        pytest.fail(f"scripts/integration_check/{name} is not built: __graft_entry__.build() links it where the reference checkout is")
+    return exe
 
 
 def test_drop_in_ops_run_through_a_tape_from_fortran(dev):
-    exe = os.path.join(ROOT, "scripts", "integration_check", "run_ops")
-    if not os.path.exists(exe):
-        pytest.fail("scripts/integration_check/run_ops is not built: __graft_entry__.build() compiles it (amdflang)")
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([_exe("run_ops")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    assert "RUN_OPS_OK 7 7" in r.stdout, r.stdout[-500:]
+    assert "RUN_OPS_OK 6 6" in r.stdout, r.stdout[-500:]
+
+
+@pytest.fixture(scope="module")
+def layer_dumps(tmp_path_factory):
+    d = tmp_path_factory.mktemp("run_layers")
+    r = subprocess.run([_exe("run_layers")], capture_output=True, text=True, timeout=900, cwd=str(d),
+                       env=dict(os.environ, RUN_LAYERS_DUMP=str(d)))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "RUN_LAYERS_OK 3 3" in r.stdout, r.stdout[-500:]
+    return str(d)
+
+
+def test_layer_types_run_inside_athenas_own_layer_machinery(dev, layer_dumps):
+    """constructors, is-a checks, forward_msgpass, grad_reverse, get_gradients, card round trip through the registry and the
+    comparison with the shipped layer types all happen in the Fortran program: it printed RUN_LAYERS_OK 3 3"""
+    assert os.path.exists(os.path.join(layer_dumps, "kipf_hand.meta"))
+
+
+def _meta(d, case):
+    return {k: int(v) for k, v in (line.split() for line in open(os.path.join(d, case + ".meta")))}
+
+
+def _r(d, case, what, cols):
+    """Fortran (features, elements) on disk == [elements, features] row-major"""
+    return np.fromfile(os.path.join(d, f"{case}.{what}.f32"), np.float32).reshape(-1, cols)
+
+
+def _graph(d, case, s):
+    ia = np.fromfile(os.path.join(d, f"{case}.ia{s}.i32"), np.int32)
+    ja = np.fromfile(os.path.join(d, f"{case}.ja{s}.i32"), np.int32).reshape(-1, 2).T      # adj_ja(2, nnz) column-major
+    return types.SimpleNamespace(adj_ia=ia, adj_ja=np.asfortranarray(ja), num_vertices=ia.size - 1)
+
+
+def _split(flat, sizes):
+    out, k = [], 0
+    for n in sizes:
+        out.append(flat[k:k + n]); k += n
+    assert k == flat.size
+    return out
+
+
+@pytest.mark.parametrize("case,act", [("kipf_hand", "relu"), ("kipf_wide", "none"), ("kipf_swish", "swish")])
+def test_hip_kipf_layer_type_against_the_oracle(dev, layer_dumps, case, act):
+    d, m = layer_dumps, _meta(layer_dumps, case)
+    nvf = [int(v) for v in np.fromfile(os.path.join(d, case + ".nvf.i32"), np.int32)]
+    nvf = nvf if len(nvf) == m["steps"] + 1 else [nvf[0]] * (m["steps"] + 1)
+    S = range(1, m["batch"] + 1)
+    graphs = [_graph(d, case, s) for s in S]
+    xs = [_r(d, case, f"x{s}", nvf[0]) for s in S]
+    ups = [_r(d, case, f"up{s}", nvf[-1]) for s in S]
+    flat = np.fromfile(os.path.join(d, case + ".params.f32"), np.float32)
+    params = _split(flat, [nvf[t] * nvf[t - 1] for t in range(1, len(nvf))])
+
+    def run():
+        outs, tapes = ol.kipf_forward(graphs, xs, params, nvf, act)
+        dxs, grads = ol.kipf_backward(graphs, tapes, params, nvf, act, ups)
+        return outs, dxs, np.concatenate(grads)
+
+    outs, dxs, grads = run()
+    hi = ol.f64_lazy(run)
+    for i, s in enumerate(S):
+        assert_close(_r(d, case, f"out{s}", nvf[-1]), outs[i], what=f"{case}: output, sample {s}")
+    assert_close(np.concatenate([_r(d, case, f"dx{s}", nvf[0]) for s in S]), np.concatenate(dxs), what=f"{case}: dx",
+                 f64=hi(1))
+    assert_close(np.fromfile(os.path.join(d, case + ".grads.f32"), np.float32), grads, what=f"{case}: get_gradients",
+                 f64=hi(2))
+
+
+@pytest.mark.parametrize("case,act", [("duvenaud_hand", "sigmoid"), ("duvenaud_wide", "sigmoid"), ("duvenaud_leaky", "leaky_relu")])
+def test_hip_duvenaud_layer_type_against_the_oracle(dev, layer_dumps, case, act):
+    d, m = layer_dumps, _meta(layer_dumps, case)
+    fv, fe, T, nout, mn, mx = m["fv"], m["fe"], m["steps"], m["nout"], m["min_degree"], m["max_degree"]
+    nvf = [fv] * (T + 1)
+    S = range(1, m["batch"] + 1)
+    graphs = [_graph(d, case, s) for s in S]
+    xs = [_r(d, case, f"x{s}", fv) for s in S]
+    es = [_r(d, case, f"e{s}", fe) for s in S]
+    up = _r(d, case, "up", nout)                                            # [batch, nout]
+    flat = np.fromfile(os.path.join(d, case + ".params.f32"), np.float32)
+    params = _split(flat, [fv * (fv + fe) * (mx - mn + 1)] * T + [nout * fv] * T)
+
+    def run():
+        out, tapes = ol.duvenaud_forward(graphs, xs, es, params, nvf, fe, mn, mx, nout, act)
+        dxs, des, grads = ol.duvenaud_backward(graphs, es, tapes, params, nvf, fe, mn, mx, nout, act, up)
+        return out, np.concatenate(dxs), np.concatenate(des), np.concatenate(grads)
+
+    out, dx, de, grads = run()
+    hi = ol.f64_lazy(run)
+    assert_close(_r(d, case, "out", nout), out, what=f"{case}: output", f64=hi(0))
+    assert_close(np.concatenate([_r(d, case, f"dx{s}", fv) for s in S]), dx, what=f"{case}: dx", f64=hi(1))
+    assert_close(np.concatenate([_r(d, case, f"de{s}", fe) for s in S]), de, what=f"{case}: de", f64=hi(2))
+    assert_close(np.fromfile(os.path.join(d, case + ".grads.f32"), np.float32), grads, what=f"{case}: get_gradients",
+                 f64=hi(3))
+
+
+@pytest.mark.parametrize("case,act", [("gno_hand", "tanh"), ("gno_wide", "none")])
+def test_hip_graph_nop_layer_type_against_the_oracle(dev, layer_dumps, case, act):
+    d, m = layer_dumps, _meta(layer_dumps, case)
+    dd, H, fi, fo, bias = m["d"], m["h"], m["fi"], m["fo"], bool(m["use_bias"])
+    graphs = [_graph(d, case, 1)]
+    xs, cs, ups = [_r(d, case, "x1", fi)], [_r(d, case, "c1", dd)], [_r(d, case, "up1", fo)]
+    flat = np.fromfile(os.path.join(d, case + ".params.f32"), np.float32)
+    params = _split(flat, [H * dd + H + fo * fi * H + fo * fi, fo * fi] + ([fo] if bias else []))
+
+    def run():
+        outs, tapes = ol.gno_forward(graphs, xs, cs, params, fi, fo, dd, H, bias, act)
+        dxs, _, grads = ol.gno_backward(graphs, xs, cs, tapes, params, fi, fo, dd, H, bias, act, ups)
+        return outs[0], dxs[0], np.concatenate(grads)
+
+    out, dx, grads = run()
+    hi = ol.f64_lazy(run)
+    assert_close(_r(d, case, "out1", fo), out, what=f"{case}: output", f64=hi(0))
+    assert_close(_r(d, case, "dx1", fi), dx, what=f"{case}: dx", f64=hi(1))
+    assert_close(np.fromfile(os.path.join(d, case + ".grads.f32"), np.float32), grads, what=f"{case}: get_gradients",
+                 f64=hi(2))
