@@ -14,7 +14,7 @@ for s in $SRCS; do
   [ -f "$s" ] || continue
   o=../../build/obj/${s%.hip}.o
   objs="$objs $o"
-  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ transport.h -nt "$o" ] || [ ../../include/athena_mp.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ transport.h -nt "$o" ] || [ radix_sort.h -nt "$o" ] || [ ../../include/athena_mp.h -nt "$o" ]; then
     /opt/rocm/bin/hipcc $FLAGS -c "$s" -o "$o" &
     pids="$pids $!"
   fi

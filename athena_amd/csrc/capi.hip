@@ -116,6 +116,16 @@ int workspace(void **ptr, size_t bytes, int slot)
     return 0;
 }
 
+int workspace_release(int slot)
+{
+    if (slot < 0 || slot >= kWsSlots || !g_ws[slot]) return 0;
+    AMP_HIP(hipStreamSynchronize(g_stream));
+    AMP_HIP(hipFree(g_ws[slot]));
+    g_ws[slot] = nullptr;
+    g_ws_bytes[slot] = 0;
+    return 0;
+}
+
 } // namespace amp
 
 using namespace amp;

@@ -41,6 +41,8 @@ int aux_stream(hipStream_t *s, hipEvent_t **events);
 
 // workspace owned by the library (grown on demand, never shrunk; stream-ordered reuse); per device
 int workspace(void **ptr, size_t bytes, int slot = 0);
+// hand a slot's memory back to the device (after the stream drained); the next workspace() call of that slot allocates again
+int workspace_release(int slot);
 
 // Everything the library keeps on a device belongs to the device athena_mp_init selected: the workspaces above, the
 // named buffers below (ticket ring, identity row pointer, zero bias ...) and the "attribute set" flags of kernels with

@@ -2757,16 +2757,17 @@ int athena_mp_gno_aggregate_bwd(const athena_mp_graph *g, int32_t d, int32_t H, 
     // The fused route keeps nnz * 256 bytes of per-entry partials (7.6 GB at BASELINE configs[3]) and nnz int32 in the handle.
     // When the device cannot give them -- a larger graph, a smaller device, a layer that also keeps S -- the call does what it
     // did before the fused route existed: the separate entry points, which run in the memory there is.
-    if (workspace(&pxp, sizeof(float) * px_half, 13) || workspace(&cvp, sizeof(float) * kGF * (size_t)g->n_rows, 14)) {
+    // Whichever of the three allocations fails, what the earlier ones took goes back first: the separate entry points must find
+    // at least the memory they had before the fused route existed.
+    auto give_up = [&]() -> int {
         (void)hipGetLastError();   // the failed allocation must not surface in the next launch check
+        if (workspace_release(13) || workspace_release(14)) return 1;
         return separate();
-    }
+    };
+    if (workspace(&pxp, sizeof(float) * px_half, 13) || workspace(&cvp, sizeof(float) * kGF * (size_t)g->n_rows, 14)) return give_up();
     if (!g->t_entry && g->nnz > 0) {
         int32_t *te = nullptr;
-        if (hipMalloc((void **)&te, sizeof(int32_t) * (size_t)g->nnz) != hipSuccess) {
-            (void)hipGetLastError();
-            return separate();
-        }
+        if (hipMalloc((void **)&te, sizeof(int32_t) * (size_t)g->nnz) != hipSuccess) return give_up();
         hipLaunchKernelGGL(gno_t_entry_kernel, dim3((g->n_rows + 255) / 256), dim3(256), 0, stream(), g->rowptr, g->col, g->eid,
                            g->t_rowptr, g->t_src, g->n_rows, te);
         if (hipGetLastError() != hipSuccess) {   // the handle only ever holds a map that was built

@@ -5,8 +5,8 @@
 //
 // It produces exactly the arrays of the host builder in capi.hip (tests compare them element for element):
 //   * transposed rows list their sources in ascending row order = a STABLE sort of the entries by column
-//     (hipcub radix sort of (column, entry index) pairs), the reference's scatter order
-//     (athena_diffstruc_extd_sub_kipf.f90:101-109);
+//     (radix_sort.h: counting-sort passes on 8-bit digits written for 64-wide wavefronts; no sort library), the
+//     reference's scatter order (athena_diffstruc_extd_sub_kipf.f90:101-109);
 //   * the edge-column index is the stable sort of the entries that carry an edge id by that id;
 //   * the coefficient (deg_v*deg_u)**(-0.5) stays a HOST libm powf -- a device pow is 1 ulp off glibc for
 //     ~0.06 % of the integer products -- but is evaluated once per pair of DISTINCT degrees into a small
@@ -14,9 +14,9 @@
 #include <math.h>
 
 #include <algorithm>
-#include <hipcub/hipcub.hpp>
 
 #include "common.h"
+#include "radix_sort.h"
 
 namespace {
 
@@ -26,7 +26,7 @@ struct BadEntry {
 
 __global__ void split_kernel(int64_t nnz, const int32_t *__restrict__ ja, int32_t n_cols, int32_t n_edge_cols,
                              int32_t *__restrict__ col, int32_t *__restrict__ eid, int32_t *__restrict__ ekey,
-                             int32_t *__restrict__ iota, BadEntry *__restrict__ bad)
+                             BadEntry *__restrict__ bad)
 {
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= nnz) return;
@@ -35,7 +35,6 @@ __global__ void split_kernel(int64_t nnz, const int32_t *__restrict__ ja, int32_
     col[w] = u;
     eid[w] = e;
     if (ekey) ekey[w] = e + 1;   // 0 = carries no edge id: sorts in front
-    iota[w] = (int32_t)w;
 }
 
 // row of every entry: binary search of the entry index in rowptr (upper bound - 1)
@@ -173,12 +172,12 @@ int graph_build_device(athena_mp_graph *g, const int32_t *adj_ja, const std::vec
         for (size_t b = 0; b < Kc; ++b) table[a * Kc + b] = powf((float)(uniq_r[a] * uniq_c[b]), -0.5f);
 
     Scratch tmp;
-    int32_t *d_ja = nullptr, *d_row_of = nullptr, *d_iota = nullptr, *d_perm = nullptr, *d_keys_sorted = nullptr,
+    int32_t *d_ja = nullptr, *d_row_of = nullptr, *d_perm = nullptr, *d_keys_sorted = nullptr, *d_tmp_k = nullptr, *d_tmp_v = nullptr,
             *d_ekey = nullptr, *d_rank_r = nullptr, *d_rank_c = nullptr;
     float *d_table = nullptr;
     BadEntry *d_bad = nullptr;
-    if ((adj_ja_dev == nullptr && tmp.get(&d_ja, 2 * (size_t)nnz)) || tmp.get(&d_row_of, nnz) || tmp.get(&d_iota, nnz) || tmp.get(&d_perm, nnz) ||
-        tmp.get(&d_keys_sorted, nnz) || tmp.get(&d_rank_r, rank_r.size()) || tmp.get(&d_rank_c, rank_c.size()) ||
+    if ((adj_ja_dev == nullptr && tmp.get(&d_ja, 2 * (size_t)nnz)) || tmp.get(&d_row_of, nnz) || tmp.get(&d_perm, nnz) ||
+        tmp.get(&d_keys_sorted, nnz) || tmp.get(&d_tmp_k, nnz) || tmp.get(&d_tmp_v, nnz) || tmp.get(&d_rank_r, rank_r.size()) || tmp.get(&d_rank_c, rank_c.size()) ||
         tmp.get(&d_table, table.size()) || tmp.get(&d_bad, 1))
         return 1;
     if (n_edge_cols > 0 && tmp.get(&d_ekey, nnz)) return 1;
@@ -204,7 +203,7 @@ int graph_build_device(athena_mp_graph *g, const int32_t *adj_ja, const std::vec
 
     if (nnz > 0) {
         hipLaunchKernelGGL(split_kernel, dim3(blocks(nnz)), dim3(256), 0, st, nnz, (const int32_t *)d_ja, n_cols,
-                           n_edge_cols, g->col, g->eid, d_ekey, d_iota, d_bad);
+                           n_edge_cols, g->col, g->eid, d_ekey, d_bad);
         hipLaunchKernelGGL(row_of_kernel, dim3(blocks(nnz)), dim3(256), 0, st, nnz, n_rows, (const int32_t *)g->rowptr,
                            d_row_of);
         AMP_LAUNCH_CHECK();
@@ -229,22 +228,14 @@ int graph_build_device(athena_mp_graph *g, const int32_t *adj_ja, const std::vec
         AMP_LAUNCH_CHECK();
     }
 
-    // ---- transposed CSR: stable radix sort of (column, entry index) -------------------------------------
-    size_t temp_bytes = 0;
+    // ---- transposed CSR: stable sort of the entries by column; the values are the entry indices ------------------
     void *d_temp = nullptr;
     const int col_bits = bits_for(std::max<int64_t>(n_cols - 1, 1));
     if (nnz > 0) {
-        AMP_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, (const int32_t *)g->col, d_keys_sorted,
-                                                   (const int32_t *)d_iota, d_perm, (int)nnz, 0, col_bits, st));
-        size_t e_bytes = 0;
-        if (n_edge_cols > 0)
-            AMP_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, e_bytes, (const int32_t *)d_ekey, d_keys_sorted,
-                                                       (const int32_t *)d_iota, d_perm, (int)nnz, 0,
-                                                       bits_for(n_edge_cols), st));
-        temp_bytes = std::max(temp_bytes, e_bytes);
-        if (tmp.get((char **)&d_temp, temp_bytes)) return 1;
-        AMP_HIP(hipcub::DeviceRadixSort::SortPairs(d_temp, temp_bytes, (const int32_t *)g->col, d_keys_sorted,
-                                                   (const int32_t *)d_iota, d_perm, (int)nnz, 0, col_bits, st));
+        if (tmp.get((char **)&d_temp, radix::scratch_bytes(nnz))) return 1;
+        if (int rc = radix::sort_pairs<uint32_t>((const uint32_t *)g->col, nullptr, nnz, col_bits, (uint32_t *)d_keys_sorted, d_perm,
+                                                 (uint32_t *)d_tmp_k, d_tmp_v, d_temp, st))
+            return rc;
         hipLaunchKernelGGL(gather_t_kernel, dim3(blocks(nnz)), dim3(256), 0, st, nnz, (const int32_t *)d_perm,
                            (const int32_t *)d_row_of, (const int32_t *)g->eid, (const float *)g->coef, g->t_src, g->t_eid,
                            g->t_coef);
@@ -260,8 +251,9 @@ int graph_build_device(athena_mp_graph *g, const int32_t *adj_ja, const std::vec
     // ---- edge-column index: stable sort of the entries by edge id, entries without one in front --------
     int64_t n_with = 0;
     if (n_edge_cols > 0 && nnz > 0) {
-        AMP_HIP(hipcub::DeviceRadixSort::SortPairs(d_temp, temp_bytes, (const int32_t *)d_ekey, d_keys_sorted,
-                                                   (const int32_t *)d_iota, d_perm, (int)nnz, 0, bits_for(n_edge_cols), st));
+        if (int rc = radix::sort_pairs<uint32_t>((const uint32_t *)d_ekey, nullptr, nnz, bits_for(n_edge_cols), (uint32_t *)d_keys_sorted,
+                                                 d_perm, (uint32_t *)d_tmp_k, d_tmp_v, d_temp, st))
+            return rc;
         // e_rowptr[e] = lower_bound(key >= e + 1) - n_none; computed in two steps: first the raw positions
         hipLaunchKernelGGL(lower_bound_kernel, dim3(blocks((int64_t)n_edge_cols + 1)), dim3(256), 0, st, n_edge_cols,
                            (const int32_t *)d_keys_sorted, nnz, 1, 0, g->e_rowptr);
@@ -297,7 +289,8 @@ int graph_build_device(athena_mp_graph *g, const int32_t *adj_ja, const std::vec
 //   * edge e (1-based column of index_list) contributes (u -> v, id e) and (v -> u, id e); a self edge u == v one entry;
 //   * add_self_loops adds (v, v, id 0) for every vertex without a self entry;
 //   * inside a row the entries are ordered by edge id, self-loop entries without an id first.
-// One radix sort of 64-bit keys  src * (E + 2) + (id + 1 for edges | 0 for an added loop)  does all of it.
+// One stable sort of 64-bit keys  src * (E + 2) + (id + 1 for edges | 0 for an added loop)  does all of it (radix_sort.h, over
+// the bits the largest key uses).
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
 
@@ -377,11 +370,11 @@ int csr_from_edges_core(int32_t n_vertices, int64_t n_pairs, const int32_t *inde
     const int64_t total = 2 * n_pairs + n_vertices;
     const unsigned long long stride = (unsigned long long)n_pairs + 2;
     Scratch tmp;
-    int32_t *d_pairs = nullptr, *d_dst = nullptr, *d_dst_s = nullptr, *d_loop = nullptr, *d_ia = nullptr, *d_ja = nullptr;
-    unsigned long long *d_keys = nullptr, *d_keys_s = nullptr, *d_bad = nullptr;
-    if (tmp.get(&d_pairs, 2 * (size_t)n_pairs) || tmp.get(&d_dst, total) || tmp.get(&d_dst_s, total) ||
+    int32_t *d_pairs = nullptr, *d_dst = nullptr, *d_dst_s = nullptr, *d_dst_t = nullptr, *d_loop = nullptr, *d_ia = nullptr, *d_ja = nullptr;
+    unsigned long long *d_keys = nullptr, *d_keys_s = nullptr, *d_keys_t = nullptr, *d_bad = nullptr;
+    if (tmp.get(&d_pairs, 2 * (size_t)n_pairs) || tmp.get(&d_dst, total) || tmp.get(&d_dst_s, total) || tmp.get(&d_dst_t, total) ||
         tmp.get(&d_loop, n_vertices) || tmp.get(&d_ia, (size_t)n_vertices + 1) || tmp.get(&d_keys, total) ||
-        tmp.get(&d_keys_s, total) || tmp.get(&d_bad, 1))
+        tmp.get(&d_keys_s, total) || tmp.get(&d_keys_t, total) || tmp.get(&d_bad, 1))
         return 1;
     const unsigned long long none = ~0ull;
     AMP_HIP(hipMemcpyAsync(d_bad, &none, sizeof(none), hipMemcpyHostToDevice, st));
@@ -407,13 +400,15 @@ int csr_from_edges_core(int32_t n_vertices, int64_t n_pairs, const int32_t *inde
     }
     int64_t nnz = 0;
     if (total > 0) {
-        size_t temp_bytes = 0;
+        // invalid slots carry the all-ones key: every pass sees digit 255 of them, so they stay behind every row whatever the
+        // number of key bits sorted (the bits of the largest VALID key, n_vertices * stride)
         void *d_temp = nullptr;
-        AMP_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, (const unsigned long long *)d_keys, d_keys_s,
-                                                   (const int32_t *)d_dst, d_dst_s, (int)total, 0, 64, st));
-        if (tmp.get((char **)&d_temp, temp_bytes)) return 1;
-        AMP_HIP(hipcub::DeviceRadixSort::SortPairs(d_temp, temp_bytes, (const unsigned long long *)d_keys, d_keys_s,
-                                                   (const int32_t *)d_dst, d_dst_s, (int)total, 0, 64, st));
+        int key_bits = 1;
+        while (key_bits < 64 && ((unsigned long long)n_vertices * stride) >> key_bits) ++key_bits;
+        if (tmp.get((char **)&d_temp, radix::scratch_bytes(total))) return 1;
+        if (int rc = radix::sort_pairs<unsigned long long>((const unsigned long long *)d_keys, (const int32_t *)d_dst, total, key_bits, d_keys_s,
+                                                           d_dst_s, d_keys_t, d_dst_t, d_temp, st))
+            return rc;
         hipLaunchKernelGGL(csr_rows_kernel, dim3(blocks((int64_t)n_vertices + 1)), dim3(256), 0, st, n_vertices,
                            (const unsigned long long *)d_keys_s, total, stride, d_ia);
         AMP_LAUNCH_CHECK();

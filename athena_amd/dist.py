@@ -380,9 +380,10 @@ _COMM = None
 
 def c_comm(device):
     """the process's athena_mp_comm (created once).  The 128-byte id is drawn by rank 0 through the C ABI and handed
-    round with torch.distributed's object broadcast (any backend); the transport is RCCL when the process group is
-    "nccl", and the host-staged TEST transport (ATHENA_MP_COMM_TRANSPORT=shm) when the group is gloo -- the one-GPU
-    dry run of bench.py and tests/test_gpu_dist.py, where RCCL refuses several ranks on one device."""
+    round with torch.distributed's object broadcast (any backend -- gloo by default in bench.py).  The transport is RCCL;
+    the host-staged TEST transport (ATHENA_MP_COMM_TRANSPORT=shm) is taken when asked for by name or when the ranks of this
+    node outnumber its devices -- the one-GPU dry run of bench.py and tests/test_gpu_dist.py, where RCCL refuses several
+    ranks on one device."""
     global _COMM
     if _COMM is not None:
         return _COMM
@@ -391,7 +392,11 @@ def c_comm(device):
     from . import _capi
     _capi.init(device.index or 0)
     rank, world = dist.get_rank(), dist.get_world_size()
-    if dist.get_backend() != "nccl":
+    # The data plane is RCCL whatever torch's group runs on (gloo is the default control plane of bench.py: one RCCL communicator
+    # per rank).  Only where RCCL cannot work -- more ranks on this node than devices, i.e. ranks SHARING a GPU ("Duplicate GPU
+    # detected"): the one-GPU test boxes -- and nobody chose a transport by name does the test transport step in.
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    if "ATHENA_MP_COMM_TRANSPORT" not in os.environ and local_world > torch.cuda.device_count():
         os.environ["ATHENA_MP_COMM_TRANSPORT"] = "shm"
     buf = C.create_string_buffer(128)
     if rank == 0:
@@ -1375,21 +1380,32 @@ def shard_graphs(graphs, rank, world):
     return [graphs[i] for i in pos], pos
 
 
+def _c_allreduce_(t):
+    """in-place float32 sum of a contiguous DEVICE tensor over the ranks through comm.hip's communicator (athena_mp_allreduce_start /
+    _finish: RCCL on the communication stream, ordered behind and in front of torch's current stream; the host never blocks) --
+    the same communicator the halo exchange uses, whatever backend torch.distributed's control-plane group runs on"""
+    import ctypes as C
+    from . import _capi
+    comm = c_comm(t.device)
+    _capi.use_torch_stream()
+    _capi.call("athena_mp_allreduce_start", comm.handle, C.c_void_p(t.data_ptr()), t.numel())
+    _capi.call("athena_mp_allreduce_finish", comm.handle)
+
+
 def allreduce_layer_gradients(layers):
     """sum the parameter gradients of `layers` over all ranks in ONE bucketed all-reduce (the only collective a
     batch of independent graphs needs: dW / dR of the Duvenaud layer, dtheta / dW / db of the GNO layer), then
-    hand each layer its slice back.  Gradients a rank did not produce count as zero."""
+    hand each layer its slice back.  Gradients a rank did not produce count as zero.  Device tensors travel through the C
+    ABI's communicator (RCCL); host tensors (the gloo CPU mirror) through torch.distributed."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return
     slots = [(l, i) for l in layers for i in range(len(l.params))]
     if not slots:
         return
     flat = torch.cat([(l.grads[i] if l.grads[i] is not None else torch.zeros_like(l.params[i])).reshape(-1)
-                      for l, i in slots])
-    if _host_staged(flat):
-        h = flat.cpu()
-        dist.all_reduce(h)
-        flat.copy_(h)
+                      for l, i in slots]).float().contiguous()
+    if flat.is_cuda:
+        _c_allreduce_(flat)
     else:
         dist.all_reduce(flat)
     off = 0
@@ -1403,12 +1419,10 @@ def gather_graph_outputs(local_out, positions, n_graphs):
     """assemble the per-graph readout [batch, num_outputs] from the ranks' shards (rank r holds the rows
     `positions`); every rank receives the full tensor"""
     pos = torch.as_tensor(positions, dtype=torch.long)
-    if _host_staged(local_out) or not local_out.is_cuda:       # gloo: host memory only
-        full = torch.zeros((n_graphs, local_out.shape[1]), dtype=local_out.dtype)
-        full[pos] = local_out.detach().cpu()
-        dist.all_reduce(full)      # disjoint rows: the sum is the gather
-        return full.to(local_out.device)
     full = torch.zeros((n_graphs, local_out.shape[1]), dtype=local_out.dtype, device=local_out.device)
     full[pos.to(local_out.device)] = local_out.detach()
-    dist.all_reduce(full)          # RCCL: nothing leaves the device
+    if full.is_cuda and full.dtype == torch.float32:
+        _c_allreduce_(full)        # disjoint rows: the sum is the gather (x + 0 is exact); nothing leaves the device
+    else:
+        dist.all_reduce(full)
     return full

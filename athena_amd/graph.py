@@ -78,25 +78,27 @@ class graph_type:
         key = C.c_uint64(0)
         _capi.call("athena_mp_graph_key", int(ia.size - 1), int(ja.shape[1]), ia.ctypes.data, ja.ctypes.data, C.byref(key))
         out = (id(self), self._version, int(self.num_vertices), int(ja.shape[1]), int(key.value))
+        # memoised ONLY for the arrays freeze() made: views of immutable bytes objects, which numpy refuses to make writeable
+        # again -- a read-only array that owns its data could be un-frozen, edited and re-frozen behind the memo
         ia0, ja0 = self._adj_ia, self._adj_ja
-        if (isinstance(ia0, np.ndarray) and isinstance(ja0, np.ndarray) and not ia0.flags.writeable and not ja0.flags.writeable
-                and ia0.base is None and ja0.base is None):
+        if getattr(self, "_frozen", None) == (id(ia0), id(ja0)) and not ia0.flags.writeable and not ja0.flags.writeable:
             self._key_memo = ((self._version, id(ia0), id(ja0), ia0.ctypes.data, ja0.ctypes.data, ia0.size, ja0.size), out)
         else:
             self._key_memo = None
         return out
 
     def freeze(self):
-        """Make adj_ia / adj_ja read-only arrays that own their data (int32, contiguous / Fortran order): an in-place edit
-        now RAISES, so topology_key() may memoise the content key -- nothing can change under it without an assignment
-        (which bumps the version).  Returns self."""
-        ia = np.array(self._adj_ia, dtype=np.int32, order="C", copy=True)
-        ja = np.array(self._adj_ja, dtype=np.int32, order="F", copy=True)
-        ia.flags.writeable = False
-        ja.flags.writeable = False
+        """Make adj_ia / adj_ja IMMUTABLE arrays (int32, contiguous / Fortran order, views of bytes objects: an in-place edit
+        raises, and so does setting flags.writeable back to True), so topology_key() may memoise the content key -- nothing can
+        change under it without an assignment (which bumps the version and drops the memo).  Returns self."""
+        ia_src = np.ascontiguousarray(self._adj_ia, dtype=np.int32)
+        ja_src = np.asfortranarray(self._adj_ja, dtype=np.int32)
+        ia = np.frombuffer(ia_src.tobytes(order="C"), dtype=np.int32)
+        ja = np.frombuffer(ja_src.tobytes(order="F"), dtype=np.int32).reshape(ja_src.shape, order="F")
         self._adj_ia, self._adj_ja = ia, ja
         self._version += 1
         self._key_memo = None
+        self._frozen = (id(ia), id(ja))
         return self
 
     def touch(self):

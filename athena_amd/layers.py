@@ -113,24 +113,43 @@ class msgpass_layer_type:
                                  # athena_network_sub.f90:1882-1915): a forward pass that no reverse pass follows
 
     # -- graph ---------------------------------------------------------------------------------
-    def set_graph(self, graphs):
-        """athena_msgpass_layer_sub.f90:144-174; here the device handle is built once and cached"""
-        if isinstance(graphs, graph_type):
-            graphs = [graphs]
+    def _ensure_graph(self, graphs):
+        """the block-diagonal device graph of `graphs`, built once and cached; True when it was (re)built"""
         # the cache is keyed on CONTENT (object, version, sizes, checksum of adj_ia / adj_ja), and the layer holds the
         # graph objects so that an id cannot be recycled for a new graph while the key is alive
         key = tuple(g.topology_key() for g in graphs)
         old = getattr(self, "_graph_key", None)
-        if old != key:
-            if (self.graph is not None and old is not None and len(old) == len(key)
-                    and all(a[0] == b[0] and a[2:] == b[2:] for a, b in zip(old, key))):
-                # same objects, same sizes, same content key, newer version: graph_type.touch() (or a re-assignment)
-                # says the arrays changed although the key does not -- the cached handle must not be found again
-                self.graph.device.evict()
-            self.graph = _batched_graph(graphs, self.device.index or 0, self._needs_edges)
-            self._graph_key = key
-            self._graph_refs = list(graphs)
-            self._seg = torch.from_numpy(self.graph.vertex_offsets).to(self.device)
+        if old == key:
+            return False
+        if (self.graph is not None and old is not None and len(old) == len(key)
+                and all(a[0] == b[0] and a[2:] == b[2:] for a, b in zip(old, key))):
+            # same objects, same sizes, same content key, newer version: graph_type.touch() (or a re-assignment)
+            # says the arrays changed although the key does not -- the cached handle must not be found again
+            self.graph.device.evict()
+        self.graph = _batched_graph(graphs, self.device.index or 0, self._needs_edges)
+        self._graph_key = key
+        self._graph_refs = list(graphs)
+        self._own_offsets = self.graph.vertex_offsets
+        self._cut = None
+        return True
+
+    def _set_cut(self, vo, batched):
+        """where each sample's vertices start: the list's own offsets (set_graph) or the caller's (set_graph_batched).  Part of
+        the layer's graph state beside the handle's key: the same cached graph can be cut either way by consecutive calls."""
+        cut = getattr(self, "_cut", None)
+        if cut is not None and cut[0] == batched and (cut[1] is vo or np.array_equal(cut[1], vo)):
+            return
+        self.graph.vertex_offsets = vo
+        self.graph.batch = int(vo.size - 1)
+        self._seg = torch.from_numpy(vo).to(self.device)
+        self._cut = (batched, vo)
+
+    def set_graph(self, graphs):
+        """athena_msgpass_layer_sub.f90:144-174; here the device handle is built once and cached"""
+        if isinstance(graphs, graph_type):
+            graphs = [graphs]
+        self._ensure_graph(graphs)
+        self._set_cut(self._own_offsets, False)
         return self
 
     def set_graph_batched(self, graph, vertex_offsets):
@@ -140,10 +159,8 @@ class msgpass_layer_type:
         vo = np.ascontiguousarray(vertex_offsets, dtype=np.int32)
         if not (vo.ndim == 1 and vo.size >= 2 and vo[0] == 0 and vo[-1] == graph.num_vertices and np.all(np.diff(vo) >= 0)):
             raise ValueError("set_graph_batched: vertex_offsets must run from 0 to graph.num_vertices, ascending")
-        self.set_graph([graph])
-        self.graph.vertex_offsets = vo
-        self.graph.batch = int(vo.size - 1)
-        self._seg = torch.from_numpy(vo).to(self.device)
+        self._ensure_graph([graph])
+        self._set_cut(vo.copy(), True)
         return self
 
     # -- text card of the network file (print_base / read) -------------------------------------------

@@ -75,7 +75,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle (no cpu_baseline, N=1 parity null)")
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000,
                     help="rows of the workload the 1-thread CPU oracle runs (default: all of C2, ~7 s per run)")
-    ap.add_argument("--cpu-runs", type=int, default=3, help="timed runs of the CPU oracle after one warm-up (median reported)")
+    ap.add_argument("--cpu-runs", type=int, default=5, help="timed runs of the CPU oracle after one warm-up (median reported)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="N = 1: skip the `secondary` block (configs[2], configs[3], configs[4] on one GPU; ~2-4 min of child processes)")
     ap.add_argument("--secondary", default="c3,c4,c5", help="which secondary configurations to run (comma separated)")
@@ -109,10 +109,37 @@ def _stall_for_test(rank, where):
         time.sleep(3600)
 
 
+def init_control_plane(dev, one_device):
+    """N > 1: the CONTROL plane of the bench (barriers around the timed loop, the max of the step time, scalar agreement, the id
+    broadcast that seeds comm.hip's communicator) is a gloo group by default, so that librccl holds exactly ONE communicator per
+    rank -- comm.hip's, the data plane (halo exchange, dW all-reduce).  ATHENA_MP_BENCH_CONTROL=nccl opts into torch's RCCL
+    group instead (a second communicator on the same devices).  The one-device dry run asks for comm.hip's host-staged TEST
+    transport by name; nothing infers the data plane's transport from the control plane's backend.  Returns the backend."""
+    import torch.distributed as dist
+
+    control = os.environ.get("ATHENA_MP_BENCH_CONTROL") or os.environ.get("ATHENA_MP_BENCH_BACKEND") or "gloo"
+    if control not in ("gloo", "nccl"):
+        sys.exit(f"bench.py: ATHENA_MP_BENCH_CONTROL={control}: gloo or nccl")
+    if one_device:
+        os.environ.setdefault("ATHENA_MP_COMM_TRANSPORT", "shm")
+    if control == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost") and os.path.isdir("/sys/class/net/lo"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")       # one node: the container's hostname need not resolve
+        dist.init_process_group("gloo")
+    return control
+
+
+def control_plane_note(control):
+    return (f"{control} (torch.distributed): barriers, max of the step time, scalar agreement, communicator id broadcast; data plane "
+            f"= comm.hip's own communicator" + ("" if control == "gloo" else " -- beside torch's RCCL group: two communicators per rank"))
+
+
 def transport_error(transport, one_device):
     """N > 1 lines must have moved their halos over RCCL.  comm.hip's host-staged test transport ("shm ...") and the
     python fallback plan exist for boxes with one GPU; a line that used them without the one-device dry-run switch
-    (say, a typo'd ATHENA_MP_BENCH_BACKEND on a real node) is an error, not a slow measurement."""
+    (say, a stray ATHENA_MP_COMM_TRANSPORT on a real node) is an error, not a slow measurement."""
     if transport.startswith("rccl") or one_device:
         return None
     return (f"transport is '{transport}', not RCCL: only the one-device dry run (ATHENA_MP_BENCH_ONE_DEVICE=1) may use "
@@ -375,16 +402,13 @@ def main_gno(args, world, rank, dev, one_device):
     Fi = Fo = H = args.feat
     d = 3
     watch = None
-    backend = os.environ.get("ATHENA_MP_BENCH_BACKEND", "nccl")
+    backend = "none"
     if world > 1:
         os.environ.setdefault("ATHENA_MP_COLLECTIVE_TIMEOUT_S", "120")   # the bench's own deadline, for the python watchdog AND
         watch = adist.Watchdog(rank)                                     # comm.hip's monitor (library default: 1800 s)
         adist.set_watchdog(watch)
         with watch.phase("process group creation"):
-            if backend == "nccl":
-                dist.init_process_group("nccl", device_id=dev)
-            else:
-                dist.init_process_group(backend)
+            backend = init_control_plane(dev, one_device)
 
     def phase(name, factor=1.0):
         return watch.phase(name, factor) if watch is not None else contextlib.nullcontext()
@@ -555,6 +579,7 @@ def main_gno(args, world, rank, dev, one_device):
             out["breakdown"] = adist.measure_breakdown_gno(step)
         out["breakdown"]["note"] = "each part timed alone after the timed loop, rank 0 (events); in the step the exchanges run under the interior work"
         out["rccl"] = adist.c_comm_stats()      # rank 0's communicator: ranks RCCL itself counts, its version, bytes to every peer
+        out["config"]["control_plane"] = control_plane_note(backend)
         err = transport_error(str(shard.transport), one_device)
         if err:
             out["ok"], out["error"], ok = False, err, False
@@ -583,7 +608,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
-    # dev aid: ATHENA_MP_BENCH_ONE_DEVICE=1 ATHENA_MP_BENCH_BACKEND=gloo runs the N > 1 code path with all ranks on
+    # dev aid: ATHENA_MP_BENCH_ONE_DEVICE=1 runs the N > 1 code path with all ranks on
     # device 0 and host-staged transport (a dry run of the partition / halo / overlap logic on a 1-GPU box; the
     # numbers it prints mean nothing).  The driver's runs use one GPU per rank over RCCL.
     one_device = bool(os.environ.get("ATHENA_MP_BENCH_ONE_DEVICE"))
@@ -591,7 +616,7 @@ def main():
         local_rank = 0
     elif torch.cuda.device_count() < world:
         sys.exit(f"bench.py: {world} ranks but {torch.cuda.device_count()} GPU(s) visible "
-                 "(dry run on one device: ATHENA_MP_BENCH_ONE_DEVICE=1 ATHENA_MP_BENCH_BACKEND=gloo)")
+                 "(dry run on one device: ATHENA_MP_BENCH_ONE_DEVICE=1)")
     if not torch.cuda.is_available():
         sys.exit("bench.py measures the HIP path; no GPU visible")
     torch.cuda.set_device(local_rank)
@@ -612,17 +637,13 @@ def main():
 
         from athena_amd import dist as adist
 
-        backend = os.environ.get("ATHENA_MP_BENCH_BACKEND", "nccl")
         # every wait for a peer from here on has a deadline (ATHENA_MP_COLLECTIVE_TIMEOUT_S, default 120 s per phase): a
         # stalled rank prints {"ok": false, "error": "rank r stalled in <phase>"} and leaves with exit code 3
         os.environ.setdefault("ATHENA_MP_COLLECTIVE_TIMEOUT_S", "120")   # the bench's own deadline, for the python watchdog AND
         watch = adist.Watchdog(rank)                                     # comm.hip's monitor (library default: 1800 s)
         adist.set_watchdog(watch)
         with watch.phase("process group creation"):
-            if backend == "nccl":
-                dist.init_process_group("nccl", device_id=dev)
-            else:
-                dist.init_process_group(backend)
+            backend = init_control_plane(dev, one_device)
         _stall_for_test(rank, "setup")
         if weak:
             cut = None if args.cut < 0 else args.cut * (world - 1) / 7.0
@@ -819,6 +840,7 @@ def main():
                                         "avg_launch_ms": out["breakdown"]["dw_ms"]}
         # what rank 0's communicator did: the ranks RCCL itself counts (ncclCommCount), its version, bytes to every peer
         out["rccl"] = adist.c_comm_stats()
+        out["config"]["control_plane"] = control_plane_note(backend)
         # a line that "scaled" through the host-staged TEST transport is not a measurement of RCCL over xGMI: outside the
         # one-device dry run it is an error, stated in the line and in the exit code
         err = transport_error(str(info.get("transport", "")), one_device)

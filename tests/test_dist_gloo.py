@@ -394,10 +394,26 @@ def gno_reference(dims, act):
     n_points, Fi, Fo, d, H = dims
     ia, ja, coords, x, up, theta, w, b = gno_problem(*dims)
     g = graph_type.from_csr(ia, ja, num_edges=coords.shape[0])
-    outs, tapes = ol.gno_forward([g], [x], [coords], [theta, w, b], Fi, Fo, d, H, True, act)
-    dxs, dcs, grads = ol.gno_backward([g], [x], [coords], tapes, [theta, w, b], Fi, Fo, d, H, True, act, [up])
-    gno_reference.dcoords = dcs[0]         # [E, d] of the whole mesh (the callers that check it read it from here)
-    return outs[0], dxs[0], np.concatenate([np.asarray(a, np.float32).reshape(-1) for a in grads])
+    def run():
+        outs, tapes = ol.gno_forward([g], [x], [coords], [theta, w, b], Fi, Fo, d, H, True, act)
+        dxs, dcs, grads = ol.gno_backward([g], [x], [coords], tapes, [theta, w, b], Fi, Fo, d, H, True, act, [up])
+        return outs[0], dxs[0], np.concatenate([np.asarray(a).reshape(-1) for a in grads]), dcs[0]
+
+    out, dx, grads, dcoords = run()
+    gno_reference.dcoords = dcoords        # [E, d] of the whole mesh (the callers that check it read it from here)
+    gno_reference.hi = ol.f64_lazy(run)    # the same composition on the float64 twin: hi(2) grads, hi(3) dcoords (helpers.assert_close)
+    return out, dx, grads.astype(np.float32)
+
+
+def assert_param_grads(res_r, g_ref, dc_ref, r):
+    """a rank's all-reduced parameter gradients and the coordinate gradient of the edge columns it holds: 1e-5 of the whole
+    tensor's scale, anchored on the float64 twin (sums over every vertex / entry of the mesh, in an order that depends on the cut)"""
+    from helpers import assert_close
+
+    assert_close(res_r["grads"], g_ref, 1e-5, f"rank {r}: [dtheta | dW | db]", f64=gno_reference.hi(2))
+    full = dc_ref.copy()
+    full[res_r["edge_ids"]] = res_r["dcoords"]
+    assert_close(full, dc_ref, 1e-5, f"rank {r}: dcoords", f64=gno_reference.hi(3))
 
 
 @pytest.mark.parametrize("world,act,mode,reverse", [(2, "none", "p2p", "pull"), (3, "none", "p2p", "pull"), (8, "none", "p2p", "pull"),
@@ -433,11 +449,10 @@ def test_node_partitioned_gno_layer_matches_the_single_process_oracle(oracle, wo
     assert np.abs(unperm("dX") - dx_ref).max() <= 1e-5 * np.abs(dx_ref).max()
     dc_ref = gno_reference.dcoords
     for r in range(world):
-        assert np.abs(res[r]["grads"] - g_ref).max() <= 2e-5 * np.abs(g_ref).max(), r
         assert res[r]["halo_ok"] and res[r]["coords_ok"] and res[r]["n_halo"] > 0 and res[r]["n_edge_cols"] > 0
         # the coordinate gradient of every edge column the rank holds -- cut columns completed by the peer's share
         assert res[r]["cut_cols"] > 0
-        assert np.abs(res[r]["dcoords"] - dc_ref[res[r]["edge_ids"]]).max() <= 2e-5 * np.abs(dc_ref).max(), r
+        assert_param_grads(res[r], g_ref, dc_ref, r)
         want = mode if mode != "auto" else ("allgather" if res[r]["halo_fraction"] > 0.7 else "p2p")
         assert res[r]["halo_mode"] == want
     assert sum(res[r]["n_int"] for r in range(world)) > 0 or world == 8      # compact blocks keep interior rows

@@ -285,6 +285,55 @@ print(k0, key())
     assert s[0] == s[1] and s[0] != a[0]
 
 
+def _control_plane_worker(rank, world, port, q):
+    import importlib.util
+
+    import torch.distributed as dist
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    for k in ("ATHENA_MP_BENCH_CONTROL", "ATHENA_MP_BENCH_BACKEND", "ATHENA_MP_COMM_TRANSPORT"):
+        os.environ.pop(k, None)
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    control = bench.init_control_plane(None, one_device=(rank >= 0 and world == 2))
+    import torch
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    q.put((rank, control, dist.get_backend(), os.environ.get("ATHENA_MP_COMM_TRANSPORT"), t.item(), bench.control_plane_note(control)))
+    dist.destroy_process_group()
+
+
+def test_bench_control_plane_is_gloo_so_that_rccl_holds_one_communicator_per_rank():
+    """bench.py --gpus N: barriers / the max of the step time / scalar agreement / the communicator id broadcast run on a gloo
+    group unless ATHENA_MP_BENCH_CONTROL=nccl opts into torch's RCCL group; the data plane's transport is never inferred from
+    that backend (dist.c_comm: RCCL unless named otherwise or the ranks of a node outnumber its devices)"""
+    import multiprocessing as mp
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_control_plane_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, control, backend, transport, mx, note in got:
+        assert control == "gloo" and backend == "gloo" and mx == 2.0
+        assert transport == "shm"                      # the one-device dry run names the test transport itself
+        assert note.startswith("gloo") and "two communicators" not in note
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "athena_amd", "dist.py")).read()
+    body = src[src.index("def c_comm("):src.index("def c_comm_stats(")] if "def c_comm_stats(" in src else src[src.index("def c_comm("):]
+    assert "get_backend" not in body.split("_COMM.handle")[0]
+
+
 def test_bench_line_refuses_the_test_transport_outside_the_dry_run():
     """a typo'd backend on a real node must not "scale" through /dev/shm files: bench.py marks such a line ok = false
     and exits non-zero unless the one-device dry-run switch is set"""
@@ -379,6 +428,19 @@ def test_frozen_graph_keeps_its_content_key_and_refuses_in_place_edits():
         g.adj_ja[0, 0] = 3
     with pytest.raises(ValueError):
         g.adj_ia[1] = 7
+    with pytest.raises(ValueError):                                                # ... and it cannot be un-frozen behind the memo
+        g.adj_ja.flags.writeable = True
+    # read-only arrays that merely OWN their data (they could be made writeable again) are never memoised
+    h = graph_type.from_csr(ia, ja)
+    a, b = np.array(h.adj_ia), np.asfortranarray(np.array(h.adj_ja))
+    a.flags.writeable = b.flags.writeable = False
+    h.adj_ia, h.adj_ja = a, b
+    kh = h.topology_key()
+    assert getattr(h, "_key_memo", None) is None
+    b.flags.writeable = True
+    b[0, 7] = b[0, 7] % 2000 + 1
+    b.flags.writeable = False
+    assert h.topology_key()[4] != kh[4] or ja[0, 7] == b[0, 7]
     ja2 = np.asfortranarray(np.array(g.adj_ja))
     ja2[0, 0] = ja2[0, 0] % 2000 + 1
     g.adj_ja = ja2                                                                 # assignment: version bump, memo dropped
