@@ -444,7 +444,10 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 // register file instead of spills inside the tile loop (scripts/isa_lint.py R2); 96 INPUTS with the readout epilogue keep two
 // waves and their 44 B of spills -- measured faster that way, 0.488 against 0.545 ms, while the fused reverse kernel of the same
 // shape gains 26 % from the whole file, 0.961 -> 0.707 ms: profiles/r05_duv_96wide_ab.txt.)
-template <int KJ, int OT, bool RO, bool XS = false>
+// TC: MFMAs of the LAST 16-column fragment of the input.  4 = the plain mapping k = 16 j + 4 q + c.  A tail of 4 TC < 16 columns
+// (K = 72: TC = 2) takes k = 16 (KJ - 1) + TC q + c, c < TC instead -- every k slot of its TC MFMAs is a real column, where the plain
+// mapping spends 4 MFMAs on the tail with the slots of q >= TC zero (K = 72: 18 k-steps per output fragment instead of 20).
+template <int KJ, int OT, bool RO, bool XS = false, int TC = 4>
 __global__ __launch_bounds__(256, (OT > 5 ? 1 : 2)) void duv_rows_wide_kernel(BucketSplit sp, const int32_t *__restrict__ trows,
                                                             const int32_t *__restrict__ trows_t,
                                                             const float *__restrict__ X, int K,
@@ -482,8 +485,8 @@ __global__ __launch_bounds__(256, (OT > 5 ? 1 : 2)) void duv_rows_wide_kernel(Bu
             for (int j = 0; j < KJ; ++j)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const int o = 16 * ot + n, k = 16 * j + 4 * q + c;
-                    const bool ok = o < NO && k < K;
+                    const int o = 16 * ot + n, k = (TC < 4 && j == KJ - 1) ? 16 * j + TC * q + c : 16 * j + 4 * q + c;
+                    const bool ok = o < NO && k < K && (TC == 4 || j < KJ - 1 || c < TC);
                     const float v = wd[(int64_t)(ok ? o : 0) * so + (int64_t)(ok ? k : 0) * sk];
                     Wf[ot][j][c] = ok ? v : 0.0f;
                 }
@@ -544,7 +547,19 @@ __global__ __launch_bounds__(256, (OT > 5 ? 1 : 2)) void duv_rows_wide_kernel(Bu
         for (int u = 0; u < TI; ++u) *reinterpret_cast<v4f *>(tin + ti.row[u] * PI + ti.col[u]) = s.t[u];
         asm volatile("" ::: "memory");
 #pragma unroll
-        for (int j = 0; j < KJ; ++j) xf[j] = *reinterpret_cast<const v4f *>(tin + n * PI + 16 * j + 4 * q);
+        for (int j = 0; j < KJ; ++j) {
+            if (TC < 4 && j == KJ - 1) {          // the tail fragment: TC consecutive columns per lane
+                const float *tp = tin + n * PI + 16 * j + TC * q;
+                if constexpr (TC == 2) {
+                    const v2f t2 = *reinterpret_cast<const v2f *>(tp);
+                    xf[j] = v4f{t2[0], t2[1], 0.0f, 0.0f};
+                } else {
+                    xf[j] = v4f{tp[0], TC > 1 ? tp[1] : 0.0f, TC > 2 ? tp[2] : 0.0f, 0.0f};
+                }
+            } else {
+                xf[j] = *reinterpret_cast<const v4f *>(tin + n * PI + 16 * j + 4 * q);
+            }
+        }
         asm volatile("" ::: "memory");
     };
     auto step = [&](Stage &next, Stage &fill, Ids &id_fill, Ids &id_next, int i) {
@@ -568,7 +583,7 @@ __global__ __launch_bounds__(256, (OT > 5 ? 1 : 2)) void duv_rows_wide_kernel(Bu
 #pragma unroll
         for (int j = 0; j < KJ; ++j)
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
+            for (int c = 0; c < ((TC < 4 && j == KJ - 1) ? TC : 4); ++c)
 #pragma unroll
                 for (int ot = 0; ot < OT; ++ot)
                     accs[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wf[ot][j][c], xf[j][c], accs[ot], 0, 0, 0);
@@ -1031,8 +1046,11 @@ __device__ __forceinline__ float duv_act_back(float y, float g)
 #ifndef DUV_RO_ATTR
 #define DUV_RO_ATTR
 #endif
+#ifndef DUV_RO_NW
+#define DUV_RO_NW 4     // waves per workgroup (A/B builds: 8 = two waves per SIMD under a 256-register cap)
+#endif
 template <int IT, int ACT, bool DIN>
-__global__ __launch_bounds__(256, 1) DUV_RO_ATTR void duv_bwd_ro_kernel(BucketSplit sp, const int32_t *__restrict__ trows,
+__global__ __launch_bounds__(64 * DUV_RO_NW, 1) DUV_RO_ATTR void duv_bwd_ro_kernel(BucketSplit sp, const int32_t *__restrict__ trows,
                                                             const int32_t *__restrict__ trows_t, const int32_t *__restrict__ tgid,
                                                             const float *__restrict__ A, int Fi, const float *__restrict__ Z,
                                                             const float *__restrict__ DZ, const float *__restrict__ P,
@@ -1047,33 +1065,33 @@ __global__ __launch_bounds__(256, 1) DUV_RO_ATTR void duv_bwd_ro_kernel(BucketSp
     const float *at = AT ? AT - 64 : A;
     // acc_e: the edge part of da is ADDED to what DAT holds (the layer sums da_e over its time steps and scatters the sum to the
     // edge features once, instead of one scatter + one axpy per time step); the old values travel with the tile's rows
-    constexpr int OT = 4, Fo = 64;
+    constexpr int OT = 4, Fo = 64, NW = DUV_RO_NW, NT = 64 * NW;
     constexpr int AP = 16 * IT + 4, GP = 16 * OT + 4, ZP = 16 * OT + 4, DP = 20, FOP = 16 * OT, WP = 16 * OT + 4, TA = IT - 4;
-    constexpr int kW = 16 * IT * WP, kWave = 16 * (AP + GP + ZP + DP), kRed = 16 * IT * FOP, kRedR = 4 * Fo * 16;
-    static_assert(4 * kWave >= kRed + kRedR, "the reduction images overlay the waves' tiles");
-    __shared__ __attribute__((aligned(16))) float buf[kW + 4 * kWave];
+    constexpr int kW = 16 * IT * WP, kWave = 16 * (AP + GP + ZP + DP), kRed = 16 * IT * FOP, kRedR = NW * Fo * 16;
+    static_assert(NW * kWave >= kRed + kRedR, "the reduction images overlay the waves' tiles");
+    __shared__ __attribute__((aligned(16))) float buf[kW + NW * kWave];
     float *wl = buf, *red = buf + kW, *redr = red + kRed;
     const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4, wave = threadIdx.x >> 6;
     float *al = red + wave * kWave, *gl = al + 16 * AP, *zt = gl + 16 * GP, *dll = zt + 16 * ZP;
     int b = 0;
     while ((int)blockIdx.x >= sp.unit_off[b + 1]) ++b;
     const int nwg = sp.unit_off[b + 1] - sp.unit_off[b];
-    const int stride = 4 * nwg;
-    const int t0 = sp.tile_off[b] + 4 * ((int)blockIdx.x - sp.unit_off[b]) + wave, t1 = sp.tile_off[b + 1];
+    const int stride = NW * nwg;
+    const int t0 = sp.tile_off[b] + NW * ((int)blockIdx.x - sp.unit_off[b]) + wave, t1 = sp.tile_off[b + 1];
     const int cnt = t0 < t1 ? (t1 - t0 + stride - 1) / stride : 0;
     const float d = (float)(b + 1), inv = 1.0f / d;
     {
         const float *wd = W + (int64_t)b * Fi * Fo;
-        constexpr int kTrips = (16 * IT * WP + 255) / 256;
+        constexpr int kTrips = (16 * IT * WP + NT - 1) / NT;
         float wv[kTrips];
 #pragma unroll
         for (int t = 0; t < kTrips; ++t) {
-            const int e = threadIdx.x + 256 * t, i = e / WP, o = e - i * WP;
+            const int e = threadIdx.x + NT * t, i = e / WP, o = e - i * WP;
             wv[t] = (i < Fi && o < Fo) ? wd[(int64_t)i * Fo + o] : 0.0f;
         }
 #pragma unroll
         for (int t = 0; t < kTrips; ++t) {
-            const int e = threadIdx.x + 256 * t;
+            const int e = threadIdx.x + NT * t;
             if (e < 16 * IT * WP) wl[e] = wv[t];
         }
     }
@@ -1276,7 +1294,7 @@ __global__ __launch_bounds__(256, 1) DUV_RO_ATTR void duv_bwd_ro_kernel(BucketSp
     for (int ft = 0; ft < OT; ++ft)
 #pragma unroll
         for (int r = 0; r < 4; ++r) redr[wave * Fo * 16 + (16 * ft + 4 * q + r) * 16 + n] = accR[ft][r];
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < NW; ++p) {
         if (wave == p) {
 #pragma unroll
             for (int i = 0; i < IT; ++i)
@@ -1291,14 +1309,17 @@ __global__ __launch_bounds__(256, 1) DUV_RO_ATTR void duv_bwd_ro_kernel(BucketSp
         __syncthreads();
     }
     float *slab = slabs + (size_t)blockIdx.x * Fi * Fo;
-    for (int t = threadIdx.x; t < Fi * Fo; t += 256) {
+    for (int t = threadIdx.x; t < Fi * Fo; t += NT) {
         const int i = t / Fo, o = t - i * Fo;
         slab[t] = red[i * FOP + o] / d;
     }
     float *rslab = rslabs + (size_t)blockIdx.x * Fo * O;
-    for (int t = threadIdx.x; t < Fo * O; t += 256) {
+    for (int t = threadIdx.x; t < Fo * O; t += NT) {
         const int f = t / O, o = t - f * O;
-        rslab[t] = ((redr[f * 16 + o] + redr[Fo * 16 + f * 16 + o]) + redr[2 * Fo * 16 + f * 16 + o]) + redr[3 * Fo * 16 + f * 16 + o];
+        float sum = redr[f * 16 + o];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) sum = sum + redr[w * Fo * 16 + f * 16 + o];     // wave order
+        rslab[t] = sum;
     }
 }
 
@@ -1371,9 +1392,26 @@ int launch_rows(const athena_mp_graph *g, const float *X, int K, const float *W,
     if (K >= 64 && NO >= 64) {   // 16+ chunks per row on both sides: the structured numbering (two waves per SIMD at 80 fragments)
         const int32_t *trows_t = g->btile_rows + (size_t)32 * nt;
         const uint32_t p_bytes = ro ? (uint32_t)((size_t)g->n_rows * ro->O * sizeof(float)) : 0u;
+#ifdef DUV_PLAIN_TAIL   // A/B builds (scripts/build_variants.sh ... -DDUV_PLAIN_TAIL=1): the tail fragment in 4 half-empty MFMAs
+        constexpr bool tail2 = false;
+#else
+        constexpr bool tail2 = true;
+#endif
 #define AMP_WIDE(KJ_, OT_)                                                                                            \
     if (kj == KJ_ && ot == OT_) {                                                                                     \
-        if (ro && XT) {                                                                                               \
+        if (KJ_ == 5 && OT_ == 4 && K == 72 && tail2) {   /* 72 -> 64 (configs[2]): the tail fragment in 2 MFMAs, all three forms */ \
+            if constexpr (KJ_ == 5 && OT_ == 4) {                                                                       \
+                if (ro && XT)                                                                                         \
+                    hipLaunchKernelGGL((duv_rows_wide_kernel<5, 4, true, true, 2>), grid, dim3(256), 0, amp::stream(), sp, trows_abs, \
+                                       trows_t, X, K, W, wb, so, sk, Y, NO, act, ro->R, ro->O, ro->P, p_bytes, XT);    \
+                else if (ro)                                                                                          \
+                    hipLaunchKernelGGL((duv_rows_wide_kernel<5, 4, true, false, 2>), grid, dim3(256), 0, amp::stream(), sp, trows_abs, \
+                                       trows_t, X, K, W, wb, so, sk, Y, NO, act, ro->R, ro->O, ro->P, p_bytes, XT);    \
+                else                                                                                                  \
+                    hipLaunchKernelGGL((duv_rows_wide_kernel<5, 4, false, false, 2>), grid, dim3(256), 0, amp::stream(), sp, trows_abs, \
+                                       trows_t, X, K, W, wb, so, sk, Y, NO, act, nullptr, 0, nullptr, 0u, XT);         \
+            }                                                                                                         \
+        } else if (ro && XT) {                                                                                        \
             if constexpr (KJ_ == 5 && OT_ == 4)   /* the split input: 65 .. 80 columns -> 64 only */                          \
                 hipLaunchKernelGGL((duv_rows_wide_kernel<5, 4, true, true>), grid, dim3(256), 0, amp::stream(), sp, trows_abs, \
                                    trows_t, X, K, W, wb, so, sk, Y, NO, act, ro->R, ro->O, ro->P, p_bytes, XT);        \
@@ -1512,7 +1550,7 @@ int duv_mfma_bwd_readout(const athena_mp_graph *g, int Fi, int Fo, int O, int ac
     if (!da_tail || (Fi & 3) || Fo != 64 || Fi <= 64 || it > 6 || O < 1 || O > 16 || act < 0 || act > ATHENA_MP_ACT_TANH) return -1;
     const int nt = g->n_btiles, nb = (int)g->btile_off.size() - 1, n = Fi * Fo;
     if (nt == 0 || nb > kMaxBuckets) return -1;
-    const BucketSplit sp = make_split(g, 256, 4);          // one workgroup per CU
+    const BucketSplit sp = make_split(g, 256, DUV_RO_NW);          // one workgroup per CU
     const int nwg = sp.unit_off[nb];
     *n_slabs = nwg;
     void *slabs = nullptr;
@@ -1521,11 +1559,11 @@ int duv_mfma_bwd_readout(const athena_mp_graph *g, int Fi, int Fo, int O, int ac
 #define AMP_RO(IT_, A_)                                                                                                      \
     if (it == IT_ && act == A_) {                                                                                            \
         if (dz_next)                                                                                                         \
-            hipLaunchKernelGGL((duv_bwd_ro_kernel<IT_, A_, true>), dim3(nwg), dim3(256), 0, stream(), sp, g->btile_rows,      \
+            hipLaunchKernelGGL((duv_bwd_ro_kernel<IT_, A_, true>), dim3(nwg), dim3(64 * DUV_RO_NW), 0, stream(), sp, g->btile_rows,      \
                                g->btile_rows + (size_t)48 * nt, tgid, a, Fi, z, dz_next, p, gout, R, O, w, da, da_tail,       \
                                (float *)slabs, dr_slabs, accumulate_tail ? 1 : 0, a_tail);                                  \
         else                                                                                                                 \
-            hipLaunchKernelGGL((duv_bwd_ro_kernel<IT_, A_, false>), dim3(nwg), dim3(256), 0, stream(), sp, g->btile_rows,     \
+            hipLaunchKernelGGL((duv_bwd_ro_kernel<IT_, A_, false>), dim3(nwg), dim3(64 * DUV_RO_NW), 0, stream(), sp, g->btile_rows,     \
                                g->btile_rows + (size_t)48 * nt, tgid, a, Fi, z, dz_next, p, gout, R, O, w, da, da_tail,       \
                                (float *)slabs, dr_slabs, accumulate_tail ? 1 : 0, a_tail);                                  \
         launched = true;                                                                                                     \
