@@ -1046,11 +1046,8 @@ __device__ __forceinline__ float duv_act_back(float y, float g)
 #ifndef DUV_RO_ATTR
 #define DUV_RO_ATTR
 #endif
-#ifndef DUV_RO_NW
-#define DUV_RO_NW 4     // waves per workgroup (A/B builds: 8 = two waves per SIMD under a 256-register cap)
-#endif
 template <int IT, int ACT, bool DIN>
-__global__ __launch_bounds__(64 * DUV_RO_NW, 1) DUV_RO_ATTR void duv_bwd_ro_kernel(BucketSplit sp, const int32_t *__restrict__ trows,
+__global__ __launch_bounds__(256, 1) DUV_RO_ATTR void duv_bwd_ro_kernel(BucketSplit sp, const int32_t *__restrict__ trows,
                                                             const int32_t *__restrict__ trows_t, const int32_t *__restrict__ tgid,
                                                             const float *__restrict__ A, int Fi, const float *__restrict__ Z,
                                                             const float *__restrict__ DZ, const float *__restrict__ P,
@@ -1065,33 +1062,33 @@ __global__ __launch_bounds__(64 * DUV_RO_NW, 1) DUV_RO_ATTR void duv_bwd_ro_kern
     const float *at = AT ? AT - 64 : A;
     // acc_e: the edge part of da is ADDED to what DAT holds (the layer sums da_e over its time steps and scatters the sum to the
     // edge features once, instead of one scatter + one axpy per time step); the old values travel with the tile's rows
-    constexpr int OT = 4, Fo = 64, NW = DUV_RO_NW, NT = 64 * NW;
+    constexpr int OT = 4, Fo = 64;
     constexpr int AP = 16 * IT + 4, GP = 16 * OT + 4, ZP = 16 * OT + 4, DP = 20, FOP = 16 * OT, WP = 16 * OT + 4, TA = IT - 4;
-    constexpr int kW = 16 * IT * WP, kWave = 16 * (AP + GP + ZP + DP), kRed = 16 * IT * FOP, kRedR = NW * Fo * 16;
-    static_assert(NW * kWave >= kRed + kRedR, "the reduction images overlay the waves' tiles");
-    __shared__ __attribute__((aligned(16))) float buf[kW + NW * kWave];
+    constexpr int kW = 16 * IT * WP, kWave = 16 * (AP + GP + ZP + DP), kRed = 16 * IT * FOP, kRedR = 4 * Fo * 16;
+    static_assert(4 * kWave >= kRed + kRedR, "the reduction images overlay the waves' tiles");
+    __shared__ __attribute__((aligned(16))) float buf[kW + 4 * kWave];
     float *wl = buf, *red = buf + kW, *redr = red + kRed;
     const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4, wave = threadIdx.x >> 6;
     float *al = red + wave * kWave, *gl = al + 16 * AP, *zt = gl + 16 * GP, *dll = zt + 16 * ZP;
     int b = 0;
     while ((int)blockIdx.x >= sp.unit_off[b + 1]) ++b;
     const int nwg = sp.unit_off[b + 1] - sp.unit_off[b];
-    const int stride = NW * nwg;
-    const int t0 = sp.tile_off[b] + NW * ((int)blockIdx.x - sp.unit_off[b]) + wave, t1 = sp.tile_off[b + 1];
+    const int stride = 4 * nwg;
+    const int t0 = sp.tile_off[b] + 4 * ((int)blockIdx.x - sp.unit_off[b]) + wave, t1 = sp.tile_off[b + 1];
     const int cnt = t0 < t1 ? (t1 - t0 + stride - 1) / stride : 0;
     const float d = (float)(b + 1), inv = 1.0f / d;
     {
         const float *wd = W + (int64_t)b * Fi * Fo;
-        constexpr int kTrips = (16 * IT * WP + NT - 1) / NT;
+        constexpr int kTrips = (16 * IT * WP + 255) / 256;
         float wv[kTrips];
 #pragma unroll
         for (int t = 0; t < kTrips; ++t) {
-            const int e = threadIdx.x + NT * t, i = e / WP, o = e - i * WP;
+            const int e = threadIdx.x + 256 * t, i = e / WP, o = e - i * WP;
             wv[t] = (i < Fi && o < Fo) ? wd[(int64_t)i * Fo + o] : 0.0f;
         }
 #pragma unroll
         for (int t = 0; t < kTrips; ++t) {
-            const int e = threadIdx.x + NT * t;
+            const int e = threadIdx.x + 256 * t;
             if (e < 16 * IT * WP) wl[e] = wv[t];
         }
     }
@@ -1294,7 +1291,7 @@ __global__ __launch_bounds__(64 * DUV_RO_NW, 1) DUV_RO_ATTR void duv_bwd_ro_kern
     for (int ft = 0; ft < OT; ++ft)
 #pragma unroll
         for (int r = 0; r < 4; ++r) redr[wave * Fo * 16 + (16 * ft + 4 * q + r) * 16 + n] = accR[ft][r];
-    for (int p = 0; p < NW; ++p) {
+    for (int p = 0; p < 4; ++p) {
         if (wave == p) {
 #pragma unroll
             for (int i = 0; i < IT; ++i)
@@ -1309,17 +1306,14 @@ __global__ __launch_bounds__(64 * DUV_RO_NW, 1) DUV_RO_ATTR void duv_bwd_ro_kern
         __syncthreads();
     }
     float *slab = slabs + (size_t)blockIdx.x * Fi * Fo;
-    for (int t = threadIdx.x; t < Fi * Fo; t += NT) {
+    for (int t = threadIdx.x; t < Fi * Fo; t += 256) {
         const int i = t / Fo, o = t - i * Fo;
         slab[t] = red[i * FOP + o] / d;
     }
     float *rslab = rslabs + (size_t)blockIdx.x * Fo * O;
-    for (int t = threadIdx.x; t < Fo * O; t += NT) {
+    for (int t = threadIdx.x; t < Fo * O; t += 256) {
         const int f = t / O, o = t - f * O;
-        float sum = redr[f * 16 + o];
-#pragma unroll
-        for (int w = 1; w < NW; ++w) sum = sum + redr[w * Fo * 16 + f * 16 + o];     // wave order
-        rslab[t] = sum;
+        rslab[t] = ((redr[f * 16 + o] + redr[Fo * 16 + f * 16 + o]) + redr[2 * Fo * 16 + f * 16 + o]) + redr[3 * Fo * 16 + f * 16 + o];
     }
 }
 
@@ -1550,7 +1544,7 @@ int duv_mfma_bwd_readout(const athena_mp_graph *g, int Fi, int Fo, int O, int ac
     if (!da_tail || (Fi & 3) || Fo != 64 || Fi <= 64 || it > 6 || O < 1 || O > 16 || act < 0 || act > ATHENA_MP_ACT_TANH) return -1;
     const int nt = g->n_btiles, nb = (int)g->btile_off.size() - 1, n = Fi * Fo;
     if (nt == 0 || nb > kMaxBuckets) return -1;
-    const BucketSplit sp = make_split(g, 256, DUV_RO_NW);          // one workgroup per CU
+    const BucketSplit sp = make_split(g, 256, 4);          // one workgroup per CU
     const int nwg = sp.unit_off[nb];
     *n_slabs = nwg;
     void *slabs = nullptr;
@@ -1559,11 +1553,11 @@ int duv_mfma_bwd_readout(const athena_mp_graph *g, int Fi, int Fo, int O, int ac
 #define AMP_RO(IT_, A_)                                                                                                      \
     if (it == IT_ && act == A_) {                                                                                            \
         if (dz_next)                                                                                                         \
-            hipLaunchKernelGGL((duv_bwd_ro_kernel<IT_, A_, true>), dim3(nwg), dim3(64 * DUV_RO_NW), 0, stream(), sp, g->btile_rows,      \
+            hipLaunchKernelGGL((duv_bwd_ro_kernel<IT_, A_, true>), dim3(nwg), dim3(256), 0, stream(), sp, g->btile_rows,      \
                                g->btile_rows + (size_t)48 * nt, tgid, a, Fi, z, dz_next, p, gout, R, O, w, da, da_tail,       \
                                (float *)slabs, dr_slabs, accumulate_tail ? 1 : 0, a_tail);                                  \
         else                                                                                                                 \
-            hipLaunchKernelGGL((duv_bwd_ro_kernel<IT_, A_, false>), dim3(nwg), dim3(64 * DUV_RO_NW), 0, stream(), sp, g->btile_rows,     \
+            hipLaunchKernelGGL((duv_bwd_ro_kernel<IT_, A_, false>), dim3(nwg), dim3(256), 0, stream(), sp, g->btile_rows,     \
                                g->btile_rows + (size_t)48 * nt, tgid, a, Fi, z, dz_next, p, gout, R, O, w, da, da_tail,       \
                                (float *)slabs, dr_slabs, accumulate_tail ? 1 : 0, a_tail);                                  \
         launched = true;                                                                                                     \
