@@ -240,15 +240,20 @@ __global__ __launch_bounds__(256) void csr_gather_short_rows(const int32_t *__re
 // chunk (b % 8) * per + b / 8: the workgroups of one XCD walk neighbouring chunks, so the 2 band rows two chunks share are L2 hits.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kBandRows = 128, kBandMax = 32, kBandEntries = 8;   // rows per workgroup, widest band, entries per row
+// COEF: every entry carries a coefficient (Kipf: y[v] = sum_w coef[w] x[col w], a rounded multiply and a rounded add per entry in CSR
+// order -- the general kernel's arithmetic, athena_diffstruc_extd_sub_kipf.f90:29-46); the coefficients of the block ride into LDS
+// beside the entry ids.  Rows wider than 64 floats are gathered 64 columns at a time (x / y pointers moved, pitches kept).
+template <bool COEF>
 __global__ __launch_bounds__(256) void csr_gather_banded64(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ idx,
-                                                           const float *__restrict__ x, int32_t xp4, float *__restrict__ y,
-                                                           int32_t n_rows, int32_t band, int32_t per)
+                                                           const float *__restrict__ coef, const float *__restrict__ x, int32_t xp4,
+                                                           float *__restrict__ y, int32_t yp4, int32_t n_rows, int32_t band, int32_t per)
 {
-    // xp4: pitch of x in 16-byte slices (16 = dense rows of 64 floats; 18 = the vertex part of packed [N, 72] rows, ...)
+    // xp4 / yp4: pitch of x / y in 16-byte slices (16 = dense rows of 64 floats; 18 = the vertex part of packed [N, 72] rows, ...)
     typedef float v4 __attribute__((ext_vector_type(4)));
     constexpr int RB = kBandRows, XR = RB + 2 * kBandMax, NL = XR * 16 / 256;   // 12 row slices of 16 bytes per thread
     __shared__ __attribute__((aligned(16))) float xs[XR * 64];
     __shared__ int32_t rp[RB + 1], es[RB * kBandEntries];
+    __shared__ float cs[COEF ? RB * kBandEntries : 1];
     const int chunk = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
     const int r0 = chunk * RB;
     if (r0 >= n_rows) return;
@@ -265,10 +270,12 @@ __global__ __launch_bounds__(256) void csr_gather_banded64(const int32_t *__rest
     __syncthreads();
     const int w0 = rp[0], nw = rp[r1 - r0] - w0;
     int32_t ev[RB * kBandEntries / 256];
+    [[maybe_unused]] float cv[RB * kBandEntries / 256];
 #pragma unroll
     for (int i = 0; i < RB * kBandEntries / 256; ++i) {
         const int t = threadIdx.x + 256 * i;
         ev[i] = t < nw ? idx[w0 + t] : 0;
+        if constexpr (COEF) cv[i] = t < nw ? coef[w0 + t] : 0.0f;
     }
     v4 *xs4 = reinterpret_cast<v4 *>(xs);
 #pragma unroll
@@ -279,7 +286,10 @@ __global__ __launch_bounds__(256) void csr_gather_banded64(const int32_t *__rest
 #pragma unroll
     for (int i = 0; i < RB * kBandEntries / 256; ++i) {
         const int t = threadIdx.x + 256 * i;
-        if (t < nw) es[t] = ev[i];
+        if (t < nw) {
+            es[t] = ev[i];
+            if constexpr (COEF) cs[t] = cv[i];
+        }
     }
     __syncthreads();
     const int gl = threadIdx.x & 15, rl = threadIdx.x >> 4;
@@ -290,25 +300,39 @@ __global__ __launch_bounds__(256) void csr_gather_banded64(const int32_t *__rest
         if (r0 + r >= r1) break;
         const int a = rp[r] - w0, b = rp[r + 1] - w0;
         v4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-        for (int w = a; w < b; ++w) acc = acc + xs4[(es[w] - c0) * 16 + gl];
-        y4[(int64_t)(r0 + r) * 16 + gl] = acc;
+        for (int w = a; w < b; ++w) {
+            const v4 v = xs4[(es[w] - c0) * 16 + gl];
+            if constexpr (COEF) acc = acc + cs[w] * v;
+            else acc = acc + v;
+        }
+        y4[(int64_t)(r0 + r) * yp4 + gl] = acc;
     }
 }
 
-// F = 64 dense rows on both sides, every row at most kBandEntries entries, every neighbour within kBandMax rows
+// rows of F = 64 or 128 floats on both sides (pitches in whole 16-byte slices), every row at most kBandEntries entries, every
+// neighbour within kBandMax rows
 bool banded_ok(const athena_mp_graph *g, bool transposed, int F, int64_t ldx, int64_t ldy, const float *x, const float *y)
 {
 #ifdef AGG_NO_BANDED
     return false;
 #endif
-    return g->band <= kBandMax && g->n_rows == g->n_cols && F == 64 && ldx >= 64 && ldx % 4 == 0 && ldx <= 1024 && ldy == 64 &&
-           (transposed ? g->max_col_len : g->max_row_len) <= kBandEntries && (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0;
+    return g->band <= kBandMax && g->n_rows == g->n_cols && (F == 64 || F == 128) && ldx >= F && ldx % 4 == 0 && ldx <= 1024 &&
+           ldy >= F && ldy % 4 == 0 && ldy <= 1024 && (transposed ? g->max_col_len : g->max_row_len) <= kBandEntries &&
+           (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0;
 }
-int gather_banded(const athena_mp_graph *g, const int32_t *rowptr, const int32_t *idx, const float *x, int64_t ldx, float *y)
+int gather_banded(const athena_mp_graph *g, const int32_t *rowptr, const int32_t *idx, const float *coef, const float *x, int64_t ldx,
+                  float *y, int64_t ldy, int F)
 {
     if (g->n_rows == 0) return 0;
     const int chunks = (g->n_rows + kBandRows - 1) / kBandRows, per = (chunks + 7) / 8;
-    hipLaunchKernelGGL(csr_gather_banded64, dim3(8 * per), dim3(256), 0, amp::stream(), rowptr, idx, x, (int32_t)(ldx / 4), y, g->n_rows, g->band, per);
+    for (int f0 = 0; f0 < F; f0 += 64) {
+        if (coef)
+            hipLaunchKernelGGL(csr_gather_banded64<true>, dim3(8 * per), dim3(256), 0, amp::stream(), rowptr, idx, coef, x + f0,
+                               (int32_t)(ldx / 4), y + f0, (int32_t)(ldy / 4), g->n_rows, g->band, per);
+        else
+            hipLaunchKernelGGL(csr_gather_banded64<false>, dim3(8 * per), dim3(256), 0, amp::stream(), rowptr, idx, coef, x + f0,
+                               (int32_t)(ldx / 4), y + f0, (int32_t)(ldy / 4), g->n_rows, g->band, per);
+    }
     AMP_LAUNCH_CHECK();
     return 0;
 }
@@ -421,6 +445,12 @@ __global__ void long_combine_kernel(const int32_t *__restrict__ row_id, const in
 
 namespace amp {
 
+// true where athena_mp_kipf_propagate_fwd / _bwd take the LDS-staged gather for this graph and width (dense rows of F floats)
+bool kipf_gather_is_banded(const athena_mp_graph *g, bool transposed, int F, const float *x, const float *y)
+{
+    return banded_ok(g, transposed, F, F, F, x, y);
+}
+
 // Generic launcher used by every layer family.  x/y may be column slices of wider tensors
 // (ldx/ldy = leading dimension in floats).
 int gather_agg(const int32_t *rowptr, const int32_t *idx, const float *coef, const float *x, int64_t ldx,
@@ -504,6 +534,8 @@ int athena_mp_kipf_propagate_fwd(const athena_mp_graph *g, int32_t F, const floa
     AMP_REQUIRE(g && F > 0, "kipf_propagate_fwd: bad arguments");
     if (g->n_rows == 0) return 0; // empty graph: nothing to do (pointers may be null)
     AMP_REQUIRE(x && y, "kipf_propagate_fwd: null tensor");
+    // a block-diagonal batch of small graphs (onnx_gnn / msgpass_chemical-shaped Kipf batches): the rows a block can touch staged in LDS
+    if (banded_ok(g, false, F, F, F, x, y)) return gather_banded(g, g->rowptr, g->col, g->coef, x, F, y, F, F);
     return gather_agg(g->rowptr, g->col, g->coef, x, F, y, F, g->n_rows, F, &g->lp_fwd);
 }
 
@@ -524,6 +556,7 @@ int athena_mp_kipf_propagate_bwd(const athena_mp_graph *g, int32_t F, const floa
     AMP_REQUIRE(g && F > 0, "kipf_propagate_bwd: bad arguments");
     if (g->n_cols == 0) return 0;
     AMP_REQUIRE(dx && (grad || g->nnz == 0), "kipf_propagate_bwd: null tensor");
+    if (grad && banded_ok(g, true, F, F, F, grad, dx)) return gather_banded(g, g->t_rowptr, g->t_src, exact ? g->t_coef : nullptr, grad, F, dx, F, F);
     return gather_agg(g->t_rowptr, g->t_src, exact ? g->t_coef : nullptr, grad, F, dx, F, g->n_cols, F, &g->lp_bwd);
 }
 
@@ -568,7 +601,7 @@ int athena_mp_duvenaud_propagate_fwd(const athena_mp_graph *g, int32_t Fv, int32
     AMP_REQUIRE(g && c && Fv >= 0 && Fe >= 0 && Fv + Fe > 0 && (Fv == 0 || x), "duvenaud_propagate_fwd: bad arguments");
     AMP_REQUIRE(Fe == 0 || e, "duvenaud_propagate_fwd: null edge features");
     const int64_t Fc = (int64_t)Fv + Fe;
-    if (Fe == 0 && banded_ok(g, false, Fv, Fv, Fv, x, c)) return gather_banded(g, g->rowptr, g->col, x, Fv, c);
+    if (Fe == 0 && banded_ok(g, false, Fv, Fv, Fv, x, c)) return gather_banded(g, g->rowptr, g->col, nullptr, x, Fv, c, Fv, Fv);
     if (Fv == 0)   // the edge part alone, [n_rows, Fe]: the same sums in the same order as columns Fv .. of the packed form
         return gather_agg(g->rowptr, g->eid, nullptr, e, Fe, c, Fe, g->n_rows, Fe, &g->lp_fwd);
     if (short_rows_ok(g->max_row_len, Fv, Fe, x, Fv, e, c, Fc))   // molecule-sized rows: one launch, whole rows written
@@ -583,7 +616,7 @@ int athena_mp_duvenaud_propagate_bwd_x(const athena_mp_graph *g, int32_t Fv, int
 {
     AMP_REQUIRE(g && grad && dx && Fv > 0 && Fe >= 0, "duvenaud_propagate_bwd_x: bad arguments");
     // (the vertex part of packed rows [n, Fv + Fe] as well: the staging loads skip the edge part of every row)
-    if (banded_ok(g, true, Fv, (int64_t)Fv + Fe, Fv, grad, dx)) return gather_banded(g, g->t_rowptr, g->t_src, grad, (int64_t)Fv + Fe, dx);
+    if (banded_ok(g, true, Fv, (int64_t)Fv + Fe, Fv, grad, dx)) return gather_banded(g, g->t_rowptr, g->t_src, nullptr, grad, (int64_t)Fv + Fe, dx, Fv, Fv);
     return gather_agg(g->t_rowptr, g->t_src, nullptr, grad, (int64_t)Fv + Fe, dx, Fv, g->n_cols, Fv, &g->lp_bwd);
 }
 

@@ -147,6 +147,7 @@ void gno_forget_perm(const int32_t *perm_dev);   // gno.hip: counts cached besid
 void graph_cache_clear(); // idle and live handles of athena_mp_graph_acquire (capi.hip)
 void host_pool_release();   // staging buffers of the *_host entry points (host.hip)
 uint64_t content_hash(const void *p, size_t bytes);   // every byte of a host array (capi.hip)
+bool kipf_gather_is_banded(const athena_mp_graph *g, bool transposed, int F, const float *x, const float *y);   // agg.hip
 int agg_blocks_cap();
 void set_agg_blocks_cap(int n);
 // shared launchers (defined in agg.hip / gemm.hip)

@@ -640,7 +640,13 @@ int athena_mp_kipf_layer_fwd(const athena_mp_graph *g, int32_t Fi, int32_t Fo, c
     AMP_REQUIRE(x && W && Z, "kipf_layer_fwd: null tensor");
     // hub rows (> kLongRow entries) would stall a whole workgroup at the chunk barrier: such graphs take
     // the two-kernel route, whose aggregation splits them into parallel segments
-    if (fused_shape(Fi, Fo) && g->lp_fwd.n_long == 0)
+#ifndef KIPF_LAYER_BANDED
+#define KIPF_LAYER_BANDED 1   // A/B builds: 0 = block-diagonal batches through the one-launch kernel like every other graph
+#endif
+    // a block-diagonal batch of small graphs: the aggregation gathers from LDS (agg.hip, csr_gather_banded64) and the dense step
+    // follows as its own launch -- faster than the one launch that chases rows through HBM (profiles/r06_kipf_banded_ab.txt)
+    const bool banded = KIPF_LAYER_BANDED && (Fi == 64 || Fi == 128) && kipf_gather_is_banded(g, false, Fi, x, P ? P : x);
+    if (!banded && fused_shape(Fi, Fo) && g->lp_fwd.n_long == 0)
         return fused_dispatch(g->rowptr, g->col, g->coef, x, Fi, Fo, W, 0, bias, act, P, Z, g->n_rows, g->n_cols);
     if (P == nullptr) {   // the caller keeps no tape of P (its reverse pass is athena_mp_kipf_layer_bwd)
         void *ws = nullptr;
@@ -658,11 +664,12 @@ int athena_mp_kipf_layer_bwd_x(const athena_mp_graph *g, int32_t Fi, int32_t Fo,
     AMP_REQUIRE(g && Fi > 0 && Fo > 0, "kipf_layer_bwd_x: bad arguments");
     if (g->n_cols == 0) return 0;
     AMP_REQUIRE(dZ && W && dX, "kipf_layer_bwd_x: null tensor");
-    if (fused_shape(Fi, Fo) && g->lp_bwd.n_long == 0) // dX = (A^T dZ) . W : aggregate, then contract with B [N=Fi][K=Fo]
+    const bool banded = KIPF_LAYER_BANDED && (Fo == 64 || Fo == 128) && Fo <= Fi && kipf_gather_is_banded(g, true, Fo, dZ, dZ);
+    if (!banded && fused_shape(Fi, Fo) && g->lp_bwd.n_long == 0) // dX = (A^T dZ) . W : aggregate, then contract with B [N=Fi][K=Fo]
         return fused_dispatch(g->t_rowptr, g->t_src, exact ? g->t_coef : nullptr, dZ, Fo, Fi, W, 1, nullptr,
                               ATHENA_MP_ACT_NONE, nullptr, dX, g->n_cols, g->n_rows);
     void *ws = nullptr;
-    if (Fo < Fi) { // (A^T dZ) . W : the scatter moves the narrower rows
+    if (Fo < Fi || banded) { // (A^T dZ) . W : the scatter moves the narrower rows
         if (workspace(&ws, sizeof(float) * (size_t)g->n_cols * Fo, 5)) return 1;
         int rc = athena_mp_kipf_propagate_bwd(g, Fo, dZ, (float *)ws, exact);
         if (rc) return rc;

@@ -1269,3 +1269,52 @@ def test_banded_gather_matches_the_oracle(dev, oracle, n, band, max_len):
     packed = np.concatenate([gup, rng.uniform(-1, 1, (n, 8)).astype(np.float32)], axis=1)
     dx_p = ops.duvenaud_propagate_bwd_x(g, torch.from_numpy(packed).to(dev), 64)
     assert np.array_equal(dx_p.cpu().numpy(), want_dx)
+
+
+@pytest.mark.parametrize("F", [64, 128])
+@pytest.mark.parametrize("n,band,max_len", [(1, 0, 1), (127, 5, 8), (129, 32, 3), (5000, 17, 6), (3001, 33, 4), (3001, 12, 9), (40000, 29, 8)])
+def test_banded_kipf_gather_matches_the_oracle(dev, oracle, n, band, max_len, F):
+    """round 6: the LDS-staged gather with the per-entry Kipf coefficient, F = 64 and 128 (128: two launches of 64 columns) --
+    kipf_propagate forward, its reverse in both forms (the reference's coefficient-free scatter, athena_diffstruc_extd_sub_kipf.f90:85-111,
+    and the exact adjoint), bit for bit the oracle's CSR-order sums; the layer step on the same graphs (aggregation from LDS, dense step
+    as its own launch) and its reverse to x at 1e-5.  A wider band (33) or a longer row (9) takes the general kernels, same bits."""
+    from athena_amd import DeviceGraph, ops
+    from oracle import oracle64 as o64
+
+    rng = np.random.default_rng(n + 7 * band + max_len + F)
+    rows, cols = [], []
+    for v in range(n):
+        k = int(rng.integers(0 if n == 3001 else 1, max_len + 1)) if n > 1 else 1     # n = 3001: empty rows too
+        lo, hi = max(0, v - band), min(n - 1, v + band)
+        c = rng.integers(lo, hi + 1, k)
+        if k and v % 97 == 0:
+            c[0] = lo
+        if k and v % 89 == 0:
+            c[-1] = hi
+        rows += [v] * k; cols += list(c)
+    rows, cols = np.asarray(rows, np.int64), np.asarray(cols, np.int64)
+    ia = np.concatenate([[1], 1 + np.cumsum(np.bincount(rows, minlength=n))]).astype(np.int32)
+    ja = np.zeros((2, rows.size), np.int32, order="F"); ja[0] = cols + 1
+    g = DeviceGraph(ia, ja, n_edge_cols=0)
+    x = rng.uniform(-1, 1, (n, F)).astype(np.float32)
+    up = rng.uniform(-1, 1, (n, F)).astype(np.float32)
+    xd, upd = torch.from_numpy(x).to(dev), torch.from_numpy(up).to(dev)
+    # (a neighbour whose own row is empty has degree 0: the reference's coefficient is (deg_v * 0) ** -0.5 = inf there, and inf - inf
+    # = NaN in a sum -- the same in the oracle and on the device, hence equal_nan)
+    same = lambda a, b: np.array_equal(a, b, equal_nan=True)
+    assert same(ops.kipf_propagate(g, xd).cpu().numpy(), oracle.kipf_propagate(x, ia, ja))
+    assert same(ops.kipf_propagate_bwd(g, upd).cpu().numpy(), oracle.kipf_propagate_bwd(up, ia, ja))
+    assert same(ops.kipf_propagate_bwd(g, upd, exact=True).cpu().numpy(), oracle.kipf_propagate_bwd(up, ia, ja, exact=True))
+    if n == 3001:
+        return            # (infinite coefficients: nothing to hold the dense step to)
+    # the layer step and its reverse to x on the same graph
+    W = (rng.standard_normal(F * F) * np.sqrt(2.0 / F)).astype(np.float32)
+    Wd = torch.from_numpy(W).to(dev)
+    P, Z = ops.kipf_layer_fwd(g, xd, Wd, F, act="relu")
+    p_ref = oracle.kipf_propagate(x, ia, ja)
+    assert np.array_equal(P.cpu().numpy(), p_ref)
+    assert_close(Z.cpu().numpy(), oracle.activation("relu", oracle.matmul(W, p_ref, F)), 1e-5, "Z",
+                 f64=lambda: o64.activation("relu", o64.matmul(W, o64.kipf_propagate(x, ia, ja), F)))
+    dX = ops.kipf_layer_bwd_x(g, upd, Wd, F)
+    assert_close(dX.cpu().numpy(), oracle.kipf_propagate_bwd(oracle.matmul_dx(W, up, F), ia, ja), 1e-5, "dX",
+                 f64=lambda: o64.kipf_propagate_bwd(o64.matmul_dx(W, up, F), ia, ja))
