@@ -34,14 +34,14 @@ def test_shipped_library_is_clean(shipped):
         assert by[name]["scratch_in_loop"] == 0
     # the headline kernels carry no scratch segment at all
     for name in ("agg_gemm_kernel<128, true, 0, true>", "gemm_dw_full_kernel<128, 128, true>", "gemm_dw_full_kernel<128, 128, false>",
-                 "duv_rows_wide_kernel<5, 4, true, false>", "duv_rows_wide_kernel<5, 4, true, true>", "duv_bwd_wide_kernel<5, 4>", "duv_bwd_ro_kernel<5, 2, true>", "gno_stg_kernel<false>", "gno_px_gather_kernel"):
+                 "duv_rows_wide_kernel<5, 4, true, false, 2>", "duv_rows_wide_kernel<5, 4, true, true, 2>", "duv_bwd_wide_kernel<5, 4>", "duv_bwd_ro_kernel<5, 2, true>", "gno_stg_kernel<false>", "gno_px_gather_kernel"):
         assert by[name]["scratch"] == 0, (name, by[name]["scratch"])
 
 
 def test_summary_in_profiles_is_current(shipped):
-    """profiles/r05_isa_summary.txt is the table of THIS library (registers / occupancy per timed kernel)"""
-    path = os.path.join(ROOT, "profiles", "r05_isa_summary.txt")
-    assert os.path.exists(path), "run: python scripts/isa_lint.py --summary profiles/r05_isa_summary.txt"
+    """profiles/r06_isa_summary.txt is the table of THIS library (registers / occupancy per timed kernel)"""
+    path = os.path.join(ROOT, "profiles", "r06_isa_summary.txt")
+    assert os.path.exists(path), "run: python scripts/isa_lint.py --summary profiles/r06_isa_summary.txt"
     have = {}
     for line in open(path):
         if line.startswith("#") or "|" not in line:
