@@ -50,6 +50,7 @@ athena_maxpool2d_layer.f90 athena_maxpool3d_layer.f90 athena_onnx_msgpass_utils.
 athena_onnx_read_sub.f90 athena_orthogonal_attention_layer.f90 athena_orthogonal_nop_block.f90 athena_recurrent_layer.f90
 athena_spectral_filter_layer.f90 athena_duvenaud_msgpass_layer.f90 athena_dynamic_lno_layer.f90 athena_fixed_lno_layer.f90
 athena_kipf_msgpass_layer.f90 athena_neural_operator_layer.f90 athena_onnx_creators.f90 athena_container_layer_sub.f90
+athena_network_sub.f90 athena_onnx_write_sub.f90
 "
 n=0
 for f in $ATHENA_SOURCES; do

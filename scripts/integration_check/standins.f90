@@ -426,7 +426,7 @@ contains
     end if
   end subroutine zero_grad
 
-  subroutine set_requires_grad(this, requires_grad)
+  pure subroutine set_requires_grad(this, requires_grad)
     class(array_type), intent(inout) :: this
     logical, intent(in) :: requires_grad
     this%requires_grad = requires_grad
@@ -1307,23 +1307,43 @@ end module diffstruc
 
 
 module graphstruc
-  !! graph_type as athena's layers and tests touch it: CSR with adj_ja(1,:) = neighbour, adj_ja(2,:) = undirected edge id
-  !! (0 on a self loop), rows in vertex order, a row's neighbours in edge-list order
+  !! graph_type as athena touches it, in its two uses:
+  !!  * the DATA graphs the message-passing layers read -- CSR with adj_ja(1,:) = neighbour, adj_ja(2,:) = undirected edge id (0 on a
+  !!    self loop), rows in vertex order, a row's neighbours in edge-list order;
+  !!  * the small DIRECTED graph network_type keeps of its own layers (auto_graph, athena_network_sub.f90:832-905): vertex(:)%id,
+  !!    edge(:)%index = [source, -target] / %id = the merge operator, a dense adjacency(i, j) = number of the edge i -> j,
+  !!    add_vertex / add_edge / remove_edges / generate_adjacency() -- restated from those call sites.
   use coreutils, only: real32, stop_program
   implicit none
   private
-  public :: graph_type
+  public :: graph_type, vertex_type, edge_type
+  type :: vertex_type
+     integer :: id = 0
+     real(real32), allocatable :: feature(:)
+  end type vertex_type
+  type :: edge_type
+     integer :: index(2) = 0
+     integer :: id = 0
+     real(real32) :: weight = 1._real32
+     real(real32), allocatable :: feature(:)
+  end type edge_type
   type :: graph_type
      integer :: num_vertices = 0, num_edges = 0, num_vertex_features = 0, num_edge_features = 0
      logical :: is_sparse = .true., directed = .false.
      character(len=128) :: name = ""
      integer, allocatable :: adj_ia(:), adj_ja(:,:)
      real(real32), allocatable :: vertex_features(:,:), edge_features(:,:), edge_weights(:)
+     type(vertex_type), allocatable :: vertex(:)
+     type(edge_type), allocatable :: edge(:)
+     integer, allocatable :: adjacency(:,:)
    contains
      procedure, pass(this) :: set_num_vertices
      procedure, pass(this) :: set_num_edges
      procedure, pass(this) :: generate_adjacency
      procedure, pass(this) :: add_self_loops
+     procedure, pass(this) :: add_vertex
+     procedure, pass(this) :: add_edge
+     procedure, pass(this) :: remove_edges
   end type graph_type
 contains
   subroutine set_num_vertices(this, num_vertices, num_vertex_features)
@@ -1332,6 +1352,9 @@ contains
     integer, intent(in), optional :: num_vertex_features
     this%num_vertices = num_vertices
     if(present(num_vertex_features)) this%num_vertex_features = num_vertex_features
+    ! (athena's tests fill vertex_features(f, v) right after this call: test_msgpass_network.f90:258-266)
+    if(allocated(this%vertex_features)) deallocate(this%vertex_features)
+    allocate(this%vertex_features(this%num_vertex_features, num_vertices), source = 0._real32)
   end subroutine set_num_vertices
 
   subroutine set_num_edges(this, num_edges, num_edge_features)
@@ -1340,13 +1363,95 @@ contains
     integer, intent(in), optional :: num_edge_features
     this%num_edges = num_edges
     if(present(num_edge_features)) this%num_edge_features = num_edge_features
+    if(allocated(this%edge_features)) deallocate(this%edge_features)
+    allocate(this%edge_features(this%num_edge_features, num_edges), source = 0._real32)
   end subroutine set_num_edges
 
-  subroutine generate_adjacency(this, index_list)
+  subroutine dense_adjacency(this)
+    !! adjacency(i, j) = number of the edge i -> j (both ways for an undirected edge: index(2) > 0), 0 where there is none
     class(graph_type), intent(inout) :: this
-    integer, dimension(:,:), intent(in) :: index_list
+    integer :: e, i, j
+    if(allocated(this%adjacency)) deallocate(this%adjacency)
+    allocate(this%adjacency(this%num_vertices, this%num_vertices), source = 0)
+    if(.not.allocated(this%edge)) return
+    do e = 1, size(this%edge)
+       i = abs(this%edge(e)%index(1))
+       j = abs(this%edge(e)%index(2))
+       if(i .lt. 1 .or. j .lt. 1 .or. i .gt. this%num_vertices .or. j .gt. this%num_vertices) cycle
+       this%adjacency(i, j) = e
+       if(this%edge(e)%index(2) .gt. 0 .and. .not. this%directed) this%adjacency(j, i) = e
+    end do
+  end subroutine dense_adjacency
+
+  subroutine add_vertex(this, feature, id, update_adjacency)
+    class(graph_type), intent(inout) :: this
+    real(real32), dimension(:), intent(in), optional :: feature
+    integer, intent(in), optional :: id
+    logical, intent(in), optional :: update_adjacency
+    type(vertex_type) :: v
+    if(present(feature)) v%feature = feature
+    if(present(id)) v%id = id
+    if(allocated(this%vertex))then
+       this%vertex = [ this%vertex, v ]
+    else
+       this%vertex = [ v ]
+    end if
+    this%num_vertices = size(this%vertex)
+    call dense_adjacency(this)
+  end subroutine add_vertex
+
+  subroutine add_edge(this, index, feature, id, weight, directed, update_adjacency)
+    class(graph_type), intent(inout) :: this
+    integer, dimension(2), intent(in) :: index
+    real(real32), dimension(:), intent(in), optional :: feature
+    integer, intent(in), optional :: id
+    real(real32), intent(in), optional :: weight
+    logical, intent(in), optional :: directed, update_adjacency
+    type(edge_type) :: e
+    e%index = index
+    if(present(feature)) e%feature = feature
+    if(present(id)) e%id = id
+    if(present(weight)) e%weight = weight
+    if(allocated(this%edge))then
+       this%edge = [ this%edge, e ]
+    else
+       this%edge = [ e ]
+    end if
+    this%num_edges = size(this%edge)
+    call dense_adjacency(this)
+  end subroutine add_edge
+
+  subroutine remove_edges(this, indices, update_adjacency)
+    !! the edges numbered `indices` (zeros ignored) go; the others close ranks, the adjacency follows
+    class(graph_type), intent(inout) :: this
+    integer, dimension(:), intent(in) :: indices
+    logical, intent(in), optional :: update_adjacency
+    type(edge_type), allocatable :: kept(:)
+    integer :: e, k
+    if(.not.allocated(this%edge)) return
+    allocate(kept(count([(all(indices .ne. e), e = 1, size(this%edge))])))
+    k = 0
+    do e = 1, size(this%edge)
+       if(any(indices .eq. e)) cycle
+       k = k + 1
+       kept(k) = this%edge(e)
+    end do
+    call move_alloc(kept, this%edge)
+    this%num_edges = size(this%edge)
+    call dense_adjacency(this)
+  end subroutine remove_edges
+
+  subroutine generate_adjacency(this, index_list)
+    !! with an edge list: the CSR of a data graph; without: the dense adjacency of the directed layer graph from its edge(:)
+    class(graph_type), intent(inout) :: this
+    integer, dimension(:,:), intent(in), optional :: index_list
     integer :: e, v, n
     integer, allocatable :: fill(:)
+    if(.not.present(index_list))then
+       call dense_adjacency(this)
+       this%is_sparse = .false.
+       return
+    end if
     n = this%num_vertices
     if(allocated(this%adj_ia)) deallocate(this%adj_ia)
     if(allocated(this%adj_ja)) deallocate(this%adj_ja)
