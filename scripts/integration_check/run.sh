@@ -1,15 +1,17 @@
 #!/bin/bash
 # The integration check of the drop-in (INTEGRATION.md sections 2-4): compile athena's OWN sources -- read in place from the
 # reference checkout, never copied -- over ONE stand-in for the three libraries this image lacks (standins.f90), then the
-# files a maintainer adds to athena (athena_amd/fortran/athena_dropin/ + athena_mp_c.f90) against THOSE modules, and link two
+# files a maintainer adds to athena (athena_amd/fortran/athena_dropin/ + athena_mp_c.f90) against THOSE modules, and link three
 # programs that run on the GPU box (tests/test_gpu_integration_run.py):
-#   run_ops     the autodiff ops alone, through the stand-in's tape
-#   run_layers  the three hip_* LAYER TYPES built with their constructors and driven by athena's own forward_msgpass /
-#               get_gradients / print_to_unit / read / registry code
-# 97 of athena's 99 src/athena files compile here; athena_network_sub.f90 and athena_onnx_write_sub.f90 do not (they drive
-# graphstruc's directed-graph API -- add_vertex / add_edge / remove_edges / dense adjacency -- which the stand-in does not
-# restate), so network_type itself is not linked.  Objects and modules go to build/integration_check/ (git-ignored); the two
-# programs to scripts/integration_check/ (git-ignored, they travel to the GPU box like the built .so).
+#   run_ops      the autodiff ops alone, through the stand-in's tape
+#   run_layers   the three hip_* LAYER TYPES built with their constructors and driven by athena's own forward_msgpass /
+#                get_gradients / print_to_unit / read / registry code
+#   run_network  athena's own network_type (add / compile / train / test / print / read) with the hip_* types in it, every case
+#                beside the same network built from athena's stock layer types (`run_network stock`: those halves alone, no GPU)
+# ALL 99 files of athena's src/athena compile here: since round 6 the stand-in also restates the small directed-graph API
+# network_type keeps its layers in (add_vertex / add_edge / remove_edges / dense adjacency), so athena_network_sub.f90 and
+# athena_onnx_write_sub.f90 are in.  Objects and modules go to build/integration_check/ (git-ignored); the programs to
+# scripts/integration_check/ (git-ignored, they travel to the GPU box like the built .so).
 #   run.sh            compile + link
 #   run.sh --compile  compile only (no libathena_mp.so needed)
 set -e
@@ -75,4 +77,6 @@ LINK="-L$ROOT/athena_amd -lathena_mp -Wl,-rpath,\$ORIGIN/../../athena_amd"
 "$FC" -O1 -w "$HERE/run_ops.f90" athena_hip_msgpass_ops.o athena_mp_c.o standins.o $LINK -o "$HERE/run_ops"
 "$FC" -cpp -O1 -w "$HERE/run_layers.f90" athena_hip_msgpass_layers.o athena_hip_msgpass_ops.o athena_mp_layers.o athena_mp_c.o \
     libathena_ref.a standins.o $LINK -o "$HERE/run_layers"
-echo "linked: run_ops run_layers"
+"$FC" -cpp -O1 -w "$HERE/run_network.f90" athena_hip_msgpass_layers.o athena_hip_msgpass_ops.o athena_mp_c.o \
+    libathena_ref.a standins.o $LINK -o "$HERE/run_network"
+echo "linked: run_ops run_layers run_network"

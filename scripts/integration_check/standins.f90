@@ -1,13 +1,15 @@
 !! ONE stand-in for the three libraries athena depends on and this image lacks (coreutils v0.1.0, diffstruc v1.2.0,
 !! graphstruc v0.2.1 -- fpm.toml:18-21), doing BOTH jobs of the integration check:
 !!   * it declares the surface athena's own modules touch (inferred from their call sites, SURVEY.md Appendix C), so that
-!!     athena's REAL sources -- misc_types, diffstruc_extd (+ its kipf / duvenaud / nop submodules), the eleven activations,
-!!     the initialisers, tools_infile, onnx utils, base_layer (+ submodules), msgpass_layer (+ submodule), the three concrete
-!!     message-passing layers and the container module -- compile against it, read in place from the reference checkout;
-!!   * it is a WORKING tape: result nodes, operand links, the `pure` get_partial_*_val callback protocol and a grad_reverse
-!!     that accumulates every node's gradient before asking it ONCE for its left and then its right partial, so that the
-!!     hip_* layer types can be built with their constructors and driven by athena's own forward_msgpass / get_gradients
-!!     on the GPU (run_layers.f90), and the ops alone by run_ops.f90.
+!!     athena's REAL sources -- ALL 99 files of src/athena: misc_types, diffstruc_extd (+ submodules), the activations, initialisers,
+!!     losses, optimisers, every layer module, base_layer / msgpass_layer (+ submodules), the container registry, network_type
+!!     (+ athena_network_sub.f90, athena_onnx_write_sub.f90) -- compile against it, read in place from the reference checkout;
+!!   * it is a WORKING tape: result nodes, operand links, the `pure` get_partial_*_val callback protocol, the element-wise /
+!!     matmul / sum / mean nodes athena's losses and host layers build, and a grad_reverse that accumulates every node's gradient
+!!     before asking it ONCE for its left and then its right partial -- and a working directed graph for network_type's graph of
+!!     layers -- so that the hip_* layer types can be built with their constructors and driven by athena's own forward_msgpass /
+!!     get_gradients (run_layers.f90), by athena's own network%train / test / print / read beside networks of athena's stock
+!!     layers (run_network.f90), and the ops alone by run_ops.f90.
 !! It is NOT diffstruc / graphstruc / coreutils: it is test-harness material written from the call sites, it computes
 !! nothing of the reference's message-passing path, and no parity claim of this repository rests on it (the oracle is
 !! pinned without it).  What it cannot tell: anything about the real diffstruc's traversal order, memory ownership

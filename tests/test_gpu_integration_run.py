@@ -8,7 +8,11 @@ Fortran.  Two programs, built in the build container by scripts/integration_chec
               constructors and driven by athena's OWN compiled code -- forward_msgpass, get_params / set_params / get_gradients,
               print_to_unit / read, the checkpoint registry -- on the reference's hand graphs and on >= 1024-vertex batches;
               held in the program against the shipped *_mp_layer_type and HERE, from the dumps it writes, against oracle/layers.py
-              (output, input gradients, flat parameter gradients; 1e-5, float64-anchored)."""
+              (output, input gradients, flat parameter gradients; 1e-5, float64-anchored).
+  run_network athena's OWN network_type (add / compile / train / test / print / read, its optimiser, its loss, its input layers, its
+              graph of layers: all 99 files of src/athena compiled) with the hip_* types in it, every case run twice through the same
+              code -- stock layer types and hip_* types from the same initial parameters -- and held against each other after
+              training: parameters, loss, accuracy (1e-5), and the saved network read back through the registry as hip_* layers."""
 import os
 import subprocess
 import types
@@ -35,6 +39,19 @@ def test_drop_in_ops_run_through_a_tape_from_fortran(dev):
     r = subprocess.run([_exe("run_ops")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert "RUN_OPS_OK 6 6" in r.stdout, r.stdout[-500:]
+
+
+def test_athenas_network_type_trains_the_drop_in_layers_like_its_own(dev, tmp_path):
+    """network%add(hip_kipf_msgpass_layer_type(...)) where the program said kipf_msgpass_layer_type(...): the reference's
+    test/test_msgpass_network.f90 (Kipf, Duvenaud: 5 epochs of SGD on an MSE loss on its 5-vertex graph) and
+    example/gno_regression (two stacked graph_nop layers), plus a batch at 64 features per family, through athena's own
+    network%train / network%test; a network saved by network%print comes back from network%read as hip_* layers"""
+    r = subprocess.run([_exe("run_network")], capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, (r.stdout[-2500:], r.stderr[-3000:])
+    assert "RUN_NETWORK_OK 6 6" in r.stdout, r.stdout[-800:]
+    dev_lines = [l for l in r.stdout.splitlines() if "rel. deviation" in l]
+    assert len(dev_lines) >= 6 * 3 + 4 * 2
+    assert max(float(l.split()[-1]) for l in dev_lines) <= 1e-5
 
 
 @pytest.fixture(scope="module")

@@ -1,6 +1,6 @@
 """CPU, build container only: the drop-in a maintainer adds to athena (athena_amd/fortran/athena_dropin/: the autodiff ops, the three
 hip_* layer TYPES that extend athena's CONCRETE kipf / duvenaud / graph_nop layer types, the patch to athena's own build files)
-goes through the Fortran compiler against athena's REAL module sources -- 97 of the 99 files of src/athena, read in place from the
+goes through the Fortran compiler against athena's REAL module sources -- all 99 files of src/athena, read in place from the
 reference checkout -- over ONE stand-in for coreutils / diffstruc / graphstruc (scripts/integration_check/standins.f90; the image
 lacks the three libraries).  Interface evidence: what is RUN is tests/test_gpu_integration_run.py, and no parity number comes
 from either.  Skipped where the reference checkout or the compiler is absent (e.g. on the GPU box)."""
@@ -75,7 +75,7 @@ def test_drop_in_compiles_against_athenas_own_modules():
     r = subprocess.run(["bash", os.path.join(ROOT, "scripts", "integration_check", "run.sh"), "--compile"], capture_output=True,
                        text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
-    assert "athena's own sources compiled over the stand-in: 97 files" in r.stdout
+    assert "athena's own sources compiled over the stand-in: 99 files" in r.stdout       # every file of src/athena
     assert "OK" in r.stdout
     out = os.path.join(ROOT, "build", "integration_check")
     for mod in ("athena__hip_msgpass_ops.mod", "athena__hip_msgpass_layers.mod", "athena__kipf_msgpass_layer.mod",
@@ -93,3 +93,20 @@ def test_drop_in_compiles_against_athenas_own_modules():
     for needed in ("athena_mp_gno_aggregate_bwd_pair_host", "athena_mp_duvenaud_update_bwd_pair_host", "athena_mp_gemm_fwd_host",
                    "athena_mp_duvenaud_update_readout_fwd_host", "athena_mp_kipf_propagate_fwd_host", "kipf_propagate_hip", "matmul_hip"):
         assert needed in ops, needed
+
+
+@needs_reference
+def test_athenas_network_type_runs_on_the_stand_in_with_its_stock_layers():
+    """the stock halves of scripts/integration_check/run_network (`run_network stock`, no GPU): athena's own network_type -- compile,
+    train, test on the reference's test / example problems -- runs on the stand-in's tape with athena's own layer types; what the GPU
+    test then holds the hip_* networks against is therefore athena's code, not a restatement of it"""
+    exe = os.path.join(ROOT, "scripts", "integration_check", "run_network")
+    if not os.path.exists(exe):
+        r = subprocess.run(["bash", os.path.join(ROOT, "scripts", "integration_check", "run.sh")], capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        r = subprocess.run([exe, "stock"], capture_output=True, text=True, timeout=600, cwd=d)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert "RUN_NETWORK_OK 6 6" in r.stdout
+    assert r.stdout.count("stock network  loss") == 6
