@@ -36,7 +36,9 @@ def _same(a, b):
         assert np.array_equal(x, y), f"{n} differs between the host and the device builder"
 
 
-@pytest.mark.parametrize("n,pairs,loops,iso", [(50, 120, True, 3), (5000, 20000, True, 10), (20000, 30000, False, 500), (1, 0, True, 0)])
+@pytest.mark.parametrize("n,pairs,loops,iso", [(50, 120, True, 3), (5000, 20000, True, 10), (20000, 30000, False, 500), (1, 0, True, 0),
+                                               # entry counts on both sides of the radix passes' 4 096-entry tiles (radix_sort.h), one and two tiles
+                                               (95, 2000, True, 0), (96, 2000, True, 0), (97, 2000, True, 0), (192, 4000, True, 0), (300, 70000, True, 7)])
 def test_device_builder_matches_host_builder(dev, n, pairs, loops, iso):
     ia, ja = random_graph(n, pairs, seed=n, self_loops=loops, isolated=iso)
     E = int(ja[1].max()) if ja.shape[1] else 0
