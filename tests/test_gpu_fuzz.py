@@ -256,3 +256,74 @@ def test_gno_fused_shape_fuzz(dev, oracle, seed):
                  "gno dtheta", f64=lambda: o64.gno_kernel_bwd_theta(coords, theta, dk64(), Hh))
     assert_close(H(ops.gno_aggregate_bwd_coords(g, th, co, xd, gd, d, Hh)), oracle.gno_kernel_bwd_coords(coords, theta, dk, Hh), 1e-5,
                  "gno dcoords", f64=lambda: o64.gno_kernel_bwd_coords(coords, theta, dk64(), Hh))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_kipf_on_random_batches_fuzz(dev, oracle, seed):
+    """round 6: kipf_propagate forward / reverse (both forms) bit for bit and the layer step at 1e-5 on random block-diagonal batches --
+    banded ones (the LDS-staged gather with the coefficient at F = 64 / 128: small graphs, rows of <= 8 entries) and ones that are
+    not (bigger graphs, denser rows, other widths: the general kernels), whichever route the library picks"""
+    from athena_amd import DeviceGraph, ops
+    from oracle import oracle64 as o64
+
+    rng = np.random.default_rng(9000 + seed)
+    banded = seed % 3 != 2
+    ia, ja, seg, E = _batch(rng, int(rng.integers(40, 400)), 8 if banded else 40, self_loops=True, isolated_frac=0.1)
+    N = ia.size - 1
+    if N == 0:
+        pytest.skip("degenerate draw")
+    F = int(rng.choice([64, 128] if seed % 4 else [16, 32, 96, 256]))
+    g = DeviceGraph(ia, ja)
+    x = rng.uniform(-1, 1, (N, F)).astype(np.float32)
+    up = rng.uniform(-1, 1, (N, F)).astype(np.float32)
+    xd, upd = T(x, dev), T(up, dev)
+    assert np.array_equal(H(ops.kipf_propagate(g, xd)), oracle.kipf_propagate(x, ia, ja))
+    assert np.array_equal(H(ops.kipf_propagate_bwd(g, upd)), oracle.kipf_propagate_bwd(up, ia, ja))
+    assert np.array_equal(H(ops.kipf_propagate_bwd(g, upd, exact=True)), oracle.kipf_propagate_bwd(up, ia, ja, exact=True))
+    W = (rng.standard_normal(F * F) * np.sqrt(2.0 / F)).astype(np.float32)
+    act = str(rng.choice(["none", "relu", "sigmoid", "tanh"]))
+    P, Z = ops.kipf_layer_fwd(g, xd, T(W, dev), F, act=act)
+    p_ref = oracle.kipf_propagate(x, ia, ja)
+    assert np.array_equal(H(P), p_ref)
+    assert_close(H(Z), oracle.activation(act, oracle.matmul(W, p_ref, F)), 1e-5, f"Z ({act})",
+                 f64=lambda: o64.activation(act, o64.matmul(W, o64.kipf_propagate(x, ia, ja), F)))
+    dX = ops.kipf_layer_bwd_x(g, upd, T(W, dev), F)
+    assert_close(H(dX), oracle.kipf_propagate_bwd(oracle.matmul_dx(W, up, F), ia, ja), 1e-5, "dX",
+                 f64=lambda: o64.kipf_propagate_bwd(o64.matmul_dx(W, up, F), ia, ja))
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_device_graph_builder_fuzz(dev, seed):
+    """round 6: the device graph builder (hand-written radix passes, graph_build.hip / radix_sort.h) against the host builder, array for
+    array, on random multigraphs of random size -- entry counts from a few to several 4 096-entry tiles, few and many edge columns
+    (1 .. 3 radix passes), duplicate entries, empty rows"""
+    import os
+    from athena_amd import DeviceGraph
+
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.integers(1, 6000))
+    deg = rng.poisson(float(rng.choice([0.5, 3.0, 9.0])), n).astype(np.int64)
+    nnz = int(deg.sum())
+    ia = np.concatenate([[1], 1 + np.cumsum(deg)]).astype(np.int32)
+    ja = np.zeros((2, nnz), np.int32, order="F")
+    n_edge_cols = int(rng.choice([0, 3, 300, 70000]))
+    if nnz:
+        ja[0] = rng.integers(1, n + 1, nnz)
+        ja[1] = rng.integers(0, n_edge_cols + 1, nnz) if n_edge_cols else 0
+    names = ("rowptr", "col", "eid", "coef", "t_rowptr", "t_src", "t_eid", "t_coef", "e_rowptr", "e_row", "e_entry", "deg_row", "deg_col")
+    built = {}
+    old = os.environ.get("ATHENA_MP_GRAPH_BUILD")
+    try:
+        for how in ("host", "device"):
+            os.environ["ATHENA_MP_GRAPH_BUILD"] = how
+            h = DeviceGraph(ia, ja, n_edge_cols=n_edge_cols)
+            built[how] = {k: h.export(k) for k in names}
+            h.close()
+    finally:
+        if old is None:
+            os.environ.pop("ATHENA_MP_GRAPH_BUILD", None)
+        else:
+            os.environ["ATHENA_MP_GRAPH_BUILD"] = old
+    for k in names:
+        a, b = built["host"][k], built["device"][k]
+        assert a.shape == b.shape and np.array_equal(a, b, equal_nan=True), f"{k} differs between the host and the device builder (seed {seed})"
