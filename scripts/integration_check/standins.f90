@@ -750,7 +750,11 @@ contains
     real(real32), dimension(:,:), intent(out) :: output
     select case(this%op)
     case(OP_ADD)
-       output = upstream_grad
+       if(size(output, 2) .eq. 1 .and. size(upstream_grad, 2) .gt. 1)then
+          output(:, 1) = sum(upstream_grad, dim = 2)       ! the broadcast column of add_aa
+       else
+          output = upstream_grad
+       end if
     case(OP_SUB)
        output = -upstream_grad
     case(OP_MUL)
@@ -778,9 +782,19 @@ contains
     class(array_type), intent(in), target :: a
     class(array_type), intent(in), target :: b
     type(array_type), pointer :: c
-    call same_shape(a, b, "+")
-    c => a%create_result()
-    c%val = a%val + b%val
+    integer :: s
+    if(size(b%val, 1) .eq. size(a%val, 1) .and. size(b%val, 2) .eq. 1 .and. size(a%val, 2) .gt. 1)then
+       ! a [F, batch] + b [F, 1]: the same column for every sample (full_layer_type's bias, athena_full_layer.f90:855); the right
+       ! partial sums the upstream gradient over the samples (ew_right_val)
+       c => a%create_result()
+       do s = 1, size(a%val, 2)
+          c%val(:, s) = a%val(:, s) + b%val(:, 1)
+       end do
+    else
+       call same_shape(a, b, "+")
+       c => a%create_result()
+       c%val = a%val + b%val
+    end if
     call link_binary(c, a, b, OP_ADD)
     c%operation = 'add'
   end function add_aa

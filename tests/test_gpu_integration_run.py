@@ -44,14 +44,19 @@ def test_drop_in_ops_run_through_a_tape_from_fortran(dev):
 def test_athenas_network_type_trains_the_drop_in_layers_like_its_own(dev, tmp_path):
     """network%add(hip_kipf_msgpass_layer_type(...)) where the program said kipf_msgpass_layer_type(...): the reference's
     test/test_msgpass_network.f90 (Kipf, Duvenaud: 5 epochs of SGD on an MSE loss on its 5-vertex graph) and
-    example/gno_regression (two stacked graph_nop layers), plus a batch at 64 features per family, through athena's own
-    network%train / network%test; a network saved by network%print comes back from network%read as hip_* layers"""
+    example/gno_regression (two stacked graph_nop layers), example/msgpass_chemical (BASELINE configs[0]: Duvenaud T = 4 into three
+    full layers, Adam with norm clipping, batches of 8 -- the HIP layer between athena's input layer and athena's host layers),
+    plus a batch at 64 features per family, through athena's own network%train / network%test; a network saved by network%print
+    comes back from network%read as hip_* layers"""
     r = subprocess.run([_exe("run_network")], capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
     assert r.returncode == 0, (r.stdout[-2500:], r.stderr[-3000:])
-    assert "RUN_NETWORK_OK 6 6" in r.stdout, r.stdout[-800:]
+    assert "RUN_NETWORK_OK 8 8" in r.stdout, r.stdout[-800:]
     dev_lines = [l for l in r.stdout.splitlines() if "rel. deviation" in l]
-    assert len(dev_lines) >= 6 * 3 + 4 * 2
-    assert max(float(l.split()[-1]) for l in dev_lines) <= 1e-5
+    assert len(dev_lines) >= 8 * 3 + 4 * 2
+    # 1e-5 everywhere; the msgpass_chemical network under its own Adam is held at 1e-3 (Adam's g / sqrt(v) amplifies last-bit
+    # differences of near-zero gradient elements: the SAME network under SGD, `msgpass_chemical_sgd`, is held at 1e-5)
+    assert max(float(l.split()[-1]) for l in dev_lines if "msgpass_chemical_example" not in l) <= 1e-5
+    assert max(float(l.split()[-1]) for l in dev_lines if "msgpass_chemical_example" in l) <= 1e-3
 
 
 @pytest.fixture(scope="module")

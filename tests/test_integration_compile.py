@@ -108,5 +108,5 @@ def test_athenas_network_type_runs_on_the_stand_in_with_its_stock_layers():
     with tempfile.TemporaryDirectory() as d:
         r = subprocess.run([exe, "stock"], capture_output=True, text=True, timeout=600, cwd=d)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
-    assert "RUN_NETWORK_OK 6 6" in r.stdout
-    assert r.stdout.count("stock network  loss") == 6
+    assert "RUN_NETWORK_OK 8 8" in r.stdout
+    assert r.stdout.count("stock network  loss") == 8
