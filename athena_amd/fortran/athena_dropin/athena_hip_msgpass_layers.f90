@@ -263,6 +263,20 @@ contains
     if(athena_mp_resident_flush(c_loc(node%val)) .ne. 0) call stop_program(who//": "//athena_mp_error_message())
   end subroutine flush_output
 
+  subroutine hand_over(dst, src, who)
+    !! dst takes src's value (diffstruc's assign_and_deallocate_source) at the edge of a HIP op chain.  With the residency table on
+    !! the value may live in HBM only: it is materialised FIRST, and the table forgets the source array, whose host storage is
+    !! about to be released or moved -- so the hand-over is right whether diffstruc copies the values or moves the allocation.
+    type(array_type), intent(inout) :: dst
+    type(array_type), pointer, intent(inout) :: src
+    character(*), intent(in) :: who
+    call flush_output(src, who)
+    if(athena_mp_resident_drop(c_loc(src%val)) .ne. 0) call stop_program(who//": "//athena_mp_error_message())
+    call dst%zero_grad()
+    call dst%assign_and_deallocate_source(src)
+    dst%is_temporary = .false.
+  end subroutine hand_over
+
   ! ============================================================================================ Kipf
   subroutine set_graph_hip_kipf(this, graph)
     !! set_graph_msgpass (athena_msgpass_layer_sub.f90:144-174, what the parent inherits) + the device handles
@@ -300,13 +314,11 @@ contains
              ptr1 => matmul_hip(this%params(t), ptr2, act)
           else
              ptr3 => matmul_hip(this%params(t), ptr2)
+             call flush_output(ptr3, "update_message (kipf)")            ! athena's own apply reads it on the host
              ptr1 => this%activation%apply(ptr3)
           end if
        end do
-       call this%output(1, s)%zero_grad()
-       call this%output(1, s)%assign_and_deallocate_source(ptr1)
-       this%output(1, s)%is_temporary = .false.
-       call flush_output(this%output(1, s), "update_message (kipf)")
+       call hand_over(this%output(1, s), ptr1, "update_message (kipf)")
     end do
   end subroutine update_message_hip_kipf
 
@@ -375,11 +387,12 @@ contains
           else
              ptr3 => duvenaud_update_hip(ptr2, ptr_params, this%handle(s), this%min_vertex_degree, this%max_vertex_degree, &
                   this%num_vertex_features(t))
-             if(allocated(this%activation)) ptr3 => this%activation%apply(ptr3)
+             if(allocated(this%activation))then
+                call flush_output(ptr3, "update_message (duvenaud)")     ! athena's own apply reads it on the host
+                ptr3 => this%activation%apply(ptr3)
+             end if
           end if
-          call this%z(t, s)%zero_grad()
-          call this%z(t, s)%assign_and_deallocate_source(ptr3)
-          this%z(t, s)%is_temporary = .false.
+          call hand_over(this%z(t, s), ptr3, "update_message (duvenaud)")
           ptr1 => this%z(t, s)
           if(fused)then
              ! p(t,s) = softmax(matmul(params(T+t), z(t,s))) already holds its value: make it the node the readout sums
@@ -396,6 +409,7 @@ contains
              this%p(t, s)%is_temporary = .false.
              this%p(t, s)%operation = 'duvenaud_readout_softmax'
              call this%p(t, s)%zero_grad()
+             call flush_output(this%p(t, s), "update_message (duvenaud)")      ! update_readout sums it with diffstruc's own sum
           end if
        end do
     end do
@@ -418,6 +432,7 @@ contains
              ptr_params => this%params(t + T_)
              ptr_z => this%z(t, s)
              ptr1 => matmul_hip(ptr_params, ptr_z)
+             call flush_output(ptr1, "update_readout (duvenaud)")
              ptr2 => this%activation_readout%apply(ptr1)
           end if
           if(t .eq. 1 .and. s .eq. 1)then
@@ -427,9 +442,8 @@ contains
           end if
        end do
     end do
-    call this%output(1, 1)%assign_and_deallocate_source(ptr3)
+    call this%output(1, 1)%assign_and_deallocate_source(ptr3)          ! (the sum is diffstruc's own: a host value)
     this%output(1, 1)%is_temporary = .false.
-    call flush_output(this%output(1, 1), "update_readout (duvenaud)")
   end subroutine update_readout_hip_duvenaud
 
   subroutine finalise_hip_duvenaud(this)
@@ -479,6 +493,8 @@ contains
        ptr2 => gno_aggregate_hip(input(1, s), ptr1, this%handle(s), this%coord_dim, this%kernel_hidden, F_in, F_out)
        ! step 3 (:761): the bypass on the MFMA kernel; step 4 (:764): combine
        ptr3 => matmul_hip(this%params(2), input(1, s))
+       call flush_output(ptr2, "update_message (graph_nop)")             ! diffstruc's own + / add_bias / apply read both on the host
+       call flush_output(ptr3, "update_message (graph_nop)")
        ptr4 => ptr2 + ptr3
        ! step 5 (:767-771)
        if(this%use_bias) ptr4 => add_bias(ptr4, this%params(3), dim=1, dim_act_on_shape=.true.)
@@ -486,9 +502,8 @@ contains
        ptr4 => this%activation%apply(ptr4)
 
        call this%output(1, s)%zero_grad()
-       call this%output(1, s)%assign_and_deallocate_source(ptr4)
+       call this%output(1, s)%assign_and_deallocate_source(ptr4)        ! (a host value: the activation is athena's own)
        this%output(1, s)%is_temporary = .false.
-       call flush_output(this%output(1, s), "update_message (graph_nop)")
 
        ! the edge geometry travels on to the next layer, not differentiated (:777-785)
        if(this%output(2, s)%allocated) call this%output(2, s)%deallocate()

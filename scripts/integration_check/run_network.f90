@@ -38,6 +38,11 @@ program run_network
   stock_only = trim(arg) .eq. "stock"
   if(.not.stock_only)then
      if(athena_mp_init(0_c_int) .ne. 0) call fail("athena_mp_init: "//athena_mp_error_message())
+     ! `run_network resident`: the residency table on (INTEGRATION.md section 3, phase 2) -- the HIP ops' forward results stay in HBM
+     ! between the ops of a layer and are materialised where athena's host code reads them (the layers' flush at the island's edge)
+     if(trim(arg) .eq. "resident")then
+        if(athena_mp_resident_mode(1_c_int32_t) .ne. 0) call fail("resident_mode: "//athena_mp_error_message())
+     end if
   end if
   passed = 0
   total = 0
@@ -65,6 +70,16 @@ program run_network
   call gno_case("gno_regression_64", nv=600, f_hidden=64, kernel_hidden=64, epochs=3, lr=0.002_real32)
 
   if(.not.stock_only)then
+     if(trim(arg) .eq. "resident")then
+        block
+          integer(c_int64_t) :: arrays, h2d, d2h, reused, lazy
+          if(athena_mp_resident_stats(arrays, h2d, d2h, reused, lazy) .ne. 0) call fail("resident_stats")
+          write(*, '(A,I0,A,I0,A,I0,A,I0)') "RESIDENT inputs found in HBM ", reused, ", outputs left in HBM ", lazy, &
+               ", bytes up ", h2d, ", bytes down ", d2h
+          if(reused .le. 0 .or. lazy .le. 0) call fail("the residency table was on but never used")
+        end block
+        if(athena_mp_resident_drop(c_null_ptr) .ne. 0) call fail("resident_drop")      ! forget everything, touch no host memory
+     end if
      if(athena_mp_finalize() .ne. 0) call fail("finalize")
   end if
   if(passed .ne. total) call fail("some cases failed")

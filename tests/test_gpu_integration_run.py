@@ -41,16 +41,21 @@ def test_drop_in_ops_run_through_a_tape_from_fortran(dev):
     assert "RUN_OPS_OK 6 6" in r.stdout, r.stdout[-500:]
 
 
-def test_athenas_network_type_trains_the_drop_in_layers_like_its_own(dev, tmp_path):
+@pytest.mark.parametrize("mode", ["staged", "resident"])
+def test_athenas_network_type_trains_the_drop_in_layers_like_its_own(dev, tmp_path, mode):
     """network%add(hip_kipf_msgpass_layer_type(...)) where the program said kipf_msgpass_layer_type(...): the reference's
     test/test_msgpass_network.f90 (Kipf, Duvenaud: 5 epochs of SGD on an MSE loss on its 5-vertex graph) and
     example/gno_regression (two stacked graph_nop layers), example/msgpass_chemical (BASELINE configs[0]: Duvenaud T = 4 into three
     full layers, Adam with norm clipping, batches of 8 -- the HIP layer between athena's input layer and athena's host layers),
     plus a batch at 64 features per family, through athena's own network%train / network%test; a network saved by network%print
-    comes back from network%read as hip_* layers"""
-    r = subprocess.run([_exe("run_network")], capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    comes back from network%read as hip_* layers.  `resident`: the same with athena_mp_resident_mode(1) -- forward results of the HIP
+    ops stay in HBM inside a layer, the drop-in materialises them where athena's host code reads them and before diffstruc's
+    assign_and_deallocate_source takes a value over; the table must have been used (inputs found in HBM, outputs left there)"""
+    r = subprocess.run([_exe("run_network")] + (["resident"] if mode == "resident" else []), capture_output=True, text=True,
+                       timeout=900, cwd=str(tmp_path))
     assert r.returncode == 0, (r.stdout[-2500:], r.stderr[-3000:])
     assert "RUN_NETWORK_OK 8 8" in r.stdout, r.stdout[-800:]
+    assert ("RESIDENT inputs found in HBM" in r.stdout) == (mode == "resident")
     dev_lines = [l for l in r.stdout.splitlines() if "rel. deviation" in l]
     assert len(dev_lines) >= 8 * 3 + 4 * 2
     # 1e-5 everywhere; the msgpass_chemical network under its own Adam is held at 1e-3 (Adam's g / sqrt(v) amplifies last-bit
