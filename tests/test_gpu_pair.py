@@ -1,5 +1,5 @@
 """The *_pair_host entry points a shim inside athena binds in diffstruc's two `pure` partial callbacks
-(scripts/integration_check/hip_duvenaud_gno_layers.f90): both partials of a node from ONE device
+(athena_amd/fortran/athena_dropin/athena_hip_msgpass_ops.f90): both partials of a node from ONE device
 pass, handed over below the C ABI -- and never handed to a request they were not computed for."""
 import ctypes as C
 
