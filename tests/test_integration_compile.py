@@ -96,6 +96,38 @@ def test_drop_in_compiles_against_athenas_own_modules():
 
 
 @needs_reference
+def test_install_script_on_a_scratch_checkout_and_the_patched_top_level_module(tmp_path):
+    """athena_dropin/install.sh on a scratch directory holding the three files of athena the patch edits (copied there for the
+    duration of the test, never into this repository): the sources land in src/athena/, the patch applies, and the patched
+    src/athena.f90 -- the module a user's `use athena` sees -- compiles against the modules of the integration check, so that
+    `use athena, only: network_type, hip_kipf_msgpass_layer_type, register_hip_msgpass_layers` is what a program then writes"""
+    out = os.path.join(ROOT, "build", "integration_check")
+    if not os.path.exists(os.path.join(out, "athena__hip_msgpass_layers.mod")):
+        r = subprocess.run(["bash", os.path.join(ROOT, "scripts", "integration_check", "run.sh"), "--compile"], capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    scratch = tmp_path / "athena"
+    (scratch / "src" / "athena").mkdir(parents=True)
+    for f in ("fpm.toml", "CMakeLists.txt", os.path.join("src", "athena.f90")):
+        shutil.copy(os.path.join(REF, f), scratch / f)
+    r = subprocess.run(["bash", os.path.join(DROPIN, "install.sh"), str(scratch)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert sorted(os.listdir(scratch / "src" / "athena")) == ["athena_hip_msgpass_layers.f90", "athena_hip_msgpass_ops.f90", "athena_mp_c.f90"]
+    assert 'link = ["athena_mp"]' in (scratch / "fpm.toml").read_text()
+    assert "find_library(ATHENA_MP_LIBRARY" in (scratch / "CMakeLists.txt").read_text()
+    prog = tmp_path / "user.f90"
+    prog.write_text("program user\n  use athena, only: network_type, hip_kipf_msgpass_layer_type, hip_duvenaud_msgpass_layer_type, &\n"
+                    "       hip_graph_nop_layer_type, register_hip_msgpass_layers\n  implicit none\n  type(network_type) :: network\n"
+                    "  call register_hip_msgpass_layers()\n"
+                    "  call network%add(hip_kipf_msgpass_layer_type(num_vertex_features=[8, 8], num_time_steps=1))\nend program user\n")
+    for src, obj in ((scratch / "src" / "athena.f90", "athena_top.o"), (prog, "user.o")):
+        r = subprocess.run([FC, "-cpp", "-O1", "-w", "-I", out, "-J", str(tmp_path), "-c", str(src), "-o", str(tmp_path / obj)],
+                           capture_output=True, text=True, cwd=out, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+    assert (tmp_path / "athena.mod").exists()
+
+
+@needs_reference
 def test_athenas_network_type_runs_on_the_stand_in_with_its_stock_layers():
     """the stock halves of scripts/integration_check/run_network (`run_network stock`, no GPU): athena's own network_type -- compile,
     train, test on the reference's test / example problems -- runs on the stand-in's tape with athena's own layer types; what the GPU
