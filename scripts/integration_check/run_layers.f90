@@ -26,12 +26,14 @@ program run_layers
   use athena__kipf_msgpass_layer, only: kipf_msgpass_layer_type
   use athena__duvenaud_msgpass_layer, only: duvenaud_msgpass_layer_type
   use athena__graph_nop_layer, only: graph_nop_layer_type
-  use athena__container_layer, only: list_of_layer_types
+  use athena__container_layer, only: list_of_layer_types, allocate_list_of_layer_types
   use athena__hip_msgpass_layers
   use athena_mp_c
   use athena_mp_layers, only: mp_graph_type, kipf_mp_layer_type, duvenaud_mp_layer_type, graph_nop_mp_layer_type
   implicit none
   integer :: passed
+  logical :: stock_only
+  character(len=32) :: mode_arg
   integer(c_int64_t) :: f0, h0, f1, h1
   character(len=512) :: dump_dir
   integer :: dump_len, dump_stat
@@ -39,8 +41,18 @@ program run_layers
 
   call get_environment_variable("RUN_LAYERS_DUMP", dump_dir, dump_len, dump_stat)
   if(dump_stat .ne. 0) dump_len = 0
-  if(athena_mp_init(0_c_int) .ne. 0) call fail("athena_mp_init: "//athena_mp_error_message())
-  call register_hip_msgpass_layers()
+  ! `run_layers stock`: the SAME program with athena's own layer types in the place of the hip_* ones -- no GPU, nothing of
+  ! libathena_mp.so is called; with RUN_LAYERS_DUMP the results of the reference's own compiled loops are written out, and
+  ! tests/test_integration_compile.py holds oracle/layers.py against them (corroboration of the oracle, not a pin)
+  call get_command_argument(1, mode_arg)
+  stock_only = trim(mode_arg) .eq. "stock"
+  if(.not.stock_only)then
+     if(athena_mp_init(0_c_int) .ne. 0) call fail("athena_mp_init: "//athena_mp_error_message())
+     call register_hip_msgpass_layers()
+  else
+     call allocate_list_of_layer_types()
+  end if
+  f0 = 0; h0 = 0; f1 = 0; h1 = 0
 
   ! the reference's hand topologies (tests/golden/reference_test_topologies.json holds the same lists)
   pairs68 = reshape([1,2, 1,3, 2,3, 2,4, 3,5, 4,5, 4,6, 5,6], [2, 8])
@@ -54,24 +66,36 @@ program run_layers
   passed = passed + 1
   ! ---- Duvenaud: defaults (sigmoid / softmax: the fused route) on the hand graph and on >= 1024 vertices at perf widths
   ! (F_v 64 / F_e 8: MFMA update, one-launch reverse), then an activation the device does not fuse (op-granular route)
-  if(athena_mp_pair_stats(f0, h0) .ne. 0) call fail("pair_stats")
+  if(.not.stock_only)then
+     if(athena_mp_pair_stats(f0, h0) .ne. 0) call fail("pair_stats")
+  end if
   call duvenaud_case("duvenaud_hand", [5, 6], pairs56, fv=6, fe=1, steps=4, nout=10, mx=10, activation="sigmoid")
-  if(athena_mp_pair_stats(f1, h1) .ne. 0) call fail("pair_stats")
-  if(f1 - f0 .ne. 8 .or. h1 - h0 .ne. 8) call fail_counts("duvenaud_hand", f1 - f0, h1 - h0, 8)
+  if(.not.stock_only)then
+     if(athena_mp_pair_stats(f1, h1) .ne. 0) call fail("pair_stats")
+  end if
+  if(.not.stock_only .and. (f1 - f0 .ne. 8 .or. h1 - h0 .ne. 8)) call fail_counts("duvenaud_hand", f1 - f0, h1 - h0, 8)
   call duvenaud_case("duvenaud_wide", [1500, 1200], pairs56, fv=64, fe=8, steps=2, nout=10, mx=4, activation="sigmoid")
-  if(athena_mp_pair_stats(f0, h0) .ne. 0) call fail("pair_stats")
-  if(f0 - f1 .ne. 4 .or. h0 - h1 .ne. 4) call fail_counts("duvenaud_wide", f0 - f1, h0 - h1, 4)
+  if(.not.stock_only)then
+     if(athena_mp_pair_stats(f0, h0) .ne. 0) call fail("pair_stats")
+  end if
+  if(.not.stock_only .and. (f0 - f1 .ne. 4 .or. h0 - h1 .ne. 4)) call fail_counts("duvenaud_wide", f0 - f1, h0 - h1, 4)
   call duvenaud_case("duvenaud_leaky", [5, 6], pairs56, fv=6, fe=2, steps=2, nout=3, mx=4, activation="leaky_relu")
   passed = passed + 1
   ! ---- graph neural operator: the hand graph at generic widths, then 1200 vertices at 64 / 64 / H = 64 (one-contraction reverse)
-  if(athena_mp_pair_stats(f0, h0) .ne. 0) call fail("pair_stats")
+  if(.not.stock_only)then
+     if(athena_mp_pair_stats(f0, h0) .ne. 0) call fail("pair_stats")
+  end if
   call gno_case("gno_hand", [6], pairs68, d=2, h=7, fi=5, fo=9, use_bias=.true., activation="tanh")
   call gno_case("gno_wide", [1200], pairs68, d=3, h=64, fi=64, fo=64, use_bias=.true., activation="none")
-  if(athena_mp_pair_stats(f1, h1) .ne. 0) call fail("pair_stats")
-  if(f1 - f0 .ne. 2 .or. h1 - h0 .ne. 2) call fail_counts("gno", f1 - f0, h1 - h0, 2)
+  if(.not.stock_only)then
+     if(athena_mp_pair_stats(f1, h1) .ne. 0) call fail("pair_stats")
+  end if
+  if(.not.stock_only .and. (f1 - f0 .ne. 2 .or. h1 - h0 .ne. 2)) call fail_counts("gno", f1 - f0, h1 - h0, 2)
   passed = passed + 1
 
-  if(athena_mp_finalize() .ne. 0) call fail("finalize")
+  if(.not.stock_only)then
+     if(athena_mp_finalize() .ne. 0) call fail("finalize")
+  end if
   write(*, '(A,I0,A)') "RUN_LAYERS_OK ", passed, " 3"
 
 contains
@@ -282,7 +306,11 @@ contains
 
     batch = size(sizes)
     fo = nvf(size(nvf))
-    layer = hip_kipf_msgpass_layer_type(num_vertex_features=nvf, num_time_steps=steps, activation=activation)
+    if(stock_only)then
+       layer = kipf_msgpass_layer_type(num_vertex_features=nvf, num_time_steps=steps, activation=activation)
+    else
+       layer = hip_kipf_msgpass_layer_type(num_vertex_features=nvf, num_time_steps=steps, activation=activation)
+    end if
     if(layer%name .ne. 'kipf') call fail(case_name//": layer name")
     select type(layer)
     class is(kipf_msgpass_layer_type)            ! IS-A stock Kipf layer: every consumer of the parent type takes it
@@ -338,16 +366,18 @@ contains
     end select
 
     ! the shipped layer type on the same parameters: the batch as one block-diagonal graph
-    ref = kipf_mp_layer_type(nvf, steps, activation=activation)
-    call ref%set_graph(mg)
-    call ref%set_params(params)
-    ref_out = ref%forward(xs)
-    ref_dx = ref%backward(ups)
-    ref_grads = ref%get_gradients()
+    if(.not.stock_only)then
+       ref = kipf_mp_layer_type(nvf, steps, activation=activation)
+       call ref%set_graph(mg)
+       call ref%set_params(params)
+       ref_out = ref%forward(xs)
+       ref_dx = ref%backward(ups)
+       ref_grads = ref%get_gradients()
+    end if
     v0 = 0
     do s = 1, batch
-       call close_to(layer%output(1, s)%val, ref_out(:, v0 + 1:v0 + sizes(s)), case_name//": output, sample "//sfx(s))
-       call close_to(input(1, s)%grad%val, ref_dx(:, v0 + 1:v0 + sizes(s)), case_name//": input gradient, sample "//sfx(s))
+       if(.not.stock_only) call close_to(layer%output(1, s)%val, ref_out(:, v0 + 1:v0 + sizes(s)), case_name//": output, sample "//sfx(s))
+       if(.not.stock_only) call close_to(input(1, s)%grad%val, ref_dx(:, v0 + 1:v0 + sizes(s)), case_name//": input gradient, sample "//sfx(s))
        call dump_i(case_name, "ia"//sfx(s), graph(s)%adj_ia)
        call dump_i(case_name, "ja"//sfx(s), graph(s)%adj_ja)
        call dump_r(case_name, "x"//sfx(s), input(1, s)%val)
@@ -356,19 +386,21 @@ contains
        call dump_r(case_name, "dx"//sfx(s), input(1, s)%grad%val)
        v0 = v0 + sizes(s)
     end do
-    call close_to_1d(grads, ref_grads, case_name//": flat parameter gradients (get_gradients)")
+    if(.not.stock_only) call close_to_1d(grads, ref_grads, case_name//": flat parameter gradients (get_gradients)")
     call dump_r(case_name, "params", params)
     call dump_r(case_name, "grads", grads)
     call dump_meta(case_name, [character(16) :: "batch", "steps", "f_in", "f_out"], [batch, steps, nvf(1), fo])
     call dump_i(case_name, "nvf", nvf)
 
     call card_round_trip(layer, "KIPF", params, reread, restores_parameters=.true.)
-    select type(reread)
-    type is(hip_kipf_msgpass_layer_type)
-    class default
-       call fail(case_name//": the registry did not hand back a hip_kipf_msgpass_layer_type")
-    end select
-    call ref%destroy()
+    if(.not.stock_only)then
+       select type(reread)
+       type is(hip_kipf_msgpass_layer_type)
+       class default
+          call fail(case_name//": the registry did not hand back a hip_kipf_msgpass_layer_type")
+       end select
+    end if
+    if(.not.stock_only) call ref%destroy()
   end subroutine kipf_case
 
   ! ------------------------------------------------------------------------------------------ Duvenaud
@@ -386,8 +418,13 @@ contains
     integer :: s, batch, n_total, e_total, v0, e0
 
     batch = size(sizes)
-    layer = hip_duvenaud_msgpass_layer_type(num_vertex_features=[fv], num_edge_features=[fe], num_time_steps=steps, &
-         max_vertex_degree=mx, num_outputs=nout, message_activation=activation)
+    if(stock_only)then
+       layer = duvenaud_msgpass_layer_type(num_vertex_features=[fv], num_edge_features=[fe], num_time_steps=steps, &
+            max_vertex_degree=mx, num_outputs=nout, message_activation=activation)
+    else
+       layer = hip_duvenaud_msgpass_layer_type(num_vertex_features=[fv], num_edge_features=[fe], num_time_steps=steps, &
+            max_vertex_degree=mx, num_outputs=nout, message_activation=activation)
+    end if
     if(layer%name .ne. 'duvenaud') call fail(case_name//": layer name")
     select type(layer)
     class is(duvenaud_msgpass_layer_type)
@@ -399,7 +436,10 @@ contains
 
     allocate(graph(batch), mg(batch), input(2, batch))
     do s = 1, batch
-       call build_graph(graph(s), sizes(s), hand_pairs, self_loops=.true., num_edge_features=fe)
+       ! (stock mode: no self loops.  A self-loop entry carries edge id 0, and the reference reads e(:, 0) / writes output(:, 0) for
+       ! it -- athena_diffstruc_extd_sub_duvenaud.f90:34-42, 166-169: one column in front of the array, SURVEY.md F7 -- where the
+       ! oracle and the HIP path contribute a zero edge-feature vector; without self loops the two are the same map)
+       call build_graph(graph(s), sizes(s), hand_pairs, self_loops=.not.stock_only, num_edge_features=fe)
        call to_mp_graph(graph(s), mg(s))
     end do
     n_total = sum(sizes)
@@ -440,18 +480,22 @@ contains
        call fail(case_name//": not learnable")
     end select
 
-    ref = duvenaud_mp_layer_type([fv], [fe], steps, mx, nout, message_activation=activation)
-    call ref%set_graph(mg)
-    call ref%set_params(params)
-    ref_out = ref%forward(xs, es)
-    call ref%backward(up, dx=ref_dx, de=ref_de)
-    ref_grads = ref%get_gradients()
-    call close_to(layer%output(1, 1)%val, ref_out, case_name//": output")
+    if(.not.stock_only)then
+       ref = duvenaud_mp_layer_type([fv], [fe], steps, mx, nout, message_activation=activation)
+       call ref%set_graph(mg)
+       call ref%set_params(params)
+       ref_out = ref%forward(xs, es)
+       call ref%backward(up, dx=ref_dx, de=ref_de)
+       ref_grads = ref%get_gradients()
+    end if
+    if(.not.stock_only) call close_to(layer%output(1, 1)%val, ref_out, case_name//": output")
     v0 = 0; e0 = 0
     do s = 1, batch
-       call close_to(input(1, s)%grad%val, ref_dx(:, v0 + 1:v0 + sizes(s)), case_name//": vertex-feature gradient, sample "//sfx(s))
-       call close_to(input(2, s)%grad%val, ref_de(:, e0 + 1:e0 + graph(s)%num_edges), &
-            case_name//": edge-feature gradient, sample "//sfx(s))
+       if(.not.stock_only) call close_to(input(1, s)%grad%val, ref_dx(:, v0 + 1:v0 + sizes(s)), case_name//": vertex-feature gradient, sample "//sfx(s))
+       if(.not.stock_only)then
+          call close_to(input(2, s)%grad%val, ref_de(:, e0 + 1:e0 + graph(s)%num_edges), &
+               case_name//": edge-feature gradient, sample "//sfx(s))
+       end if
        call dump_i(case_name, "ia"//sfx(s), graph(s)%adj_ia)
        call dump_i(case_name, "ja"//sfx(s), graph(s)%adj_ja)
        call dump_r(case_name, "x"//sfx(s), input(1, s)%val)
@@ -460,7 +504,7 @@ contains
        call dump_r(case_name, "de"//sfx(s), input(2, s)%grad%val)
        v0 = v0 + sizes(s); e0 = e0 + graph(s)%num_edges
     end do
-    call close_to_1d(grads, ref_grads, case_name//": flat parameter gradients (get_gradients)")
+    if(.not.stock_only) call close_to_1d(grads, ref_grads, case_name//": flat parameter gradients (get_gradients)")
     call dump_r(case_name, "up", up)
     call dump_r(case_name, "out", layer%output(1, 1)%val)
     call dump_r(case_name, "params", params)
@@ -469,12 +513,14 @@ contains
          [batch, steps, fv, fe, nout, 1, mx])
 
     call card_round_trip(layer, "DUVENAUD", params, reread, restores_parameters=.false.)
-    select type(reread)
-    type is(hip_duvenaud_msgpass_layer_type)
-    class default
-       call fail(case_name//": the registry did not hand back a hip_duvenaud_msgpass_layer_type")
-    end select
-    call ref%destroy()
+    if(.not.stock_only)then
+       select type(reread)
+       type is(hip_duvenaud_msgpass_layer_type)
+       class default
+          call fail(case_name//": the registry did not hand back a hip_duvenaud_msgpass_layer_type")
+       end select
+    end if
+    if(.not.stock_only) call ref%destroy()
   end subroutine duvenaud_case
 
   ! ------------------------------------------------------------------------------------------ graph neural operator
@@ -493,8 +539,13 @@ contains
 
     batch = size(sizes)
     if(batch .ne. 1) call fail(case_name//": one sample per case")
-    layer = hip_graph_nop_layer_type(num_outputs=fo, coord_dim=d, kernel_hidden=h, num_inputs=fi, use_bias=use_bias, &
-         activation=activation)
+    if(stock_only)then
+       layer = graph_nop_layer_type(num_outputs=fo, coord_dim=d, kernel_hidden=h, num_inputs=fi, use_bias=use_bias, &
+            activation=activation)
+    else
+       layer = hip_graph_nop_layer_type(num_outputs=fo, coord_dim=d, kernel_hidden=h, num_inputs=fi, use_bias=use_bias, &
+            activation=activation)
+    end if
     if(layer%name .ne. 'graph_nop') call fail(case_name//": layer name")
     select type(layer)
     class is(graph_nop_layer_type)
@@ -532,15 +583,17 @@ contains
        call fail(case_name//": not learnable")
     end select
 
-    ref = graph_nop_mp_layer_type(fo, d, fi, kernel_hidden=h, use_bias=use_bias, activation=activation)
-    call ref%set_graph(mg)
-    call ref%set_params(params)
-    ref_out = ref%forward(x, c)
-    call ref%backward(up, dx=ref_dx)
-    ref_grads = ref%get_gradients()
-    call close_to(layer%output(1, 1)%val, ref_out, case_name//": output")
-    call close_to(input(1, 1)%grad%val, ref_dx, case_name//": input gradient")
-    call close_to_1d(grads, ref_grads, case_name//": flat parameter gradients (get_gradients)")
+    if(.not.stock_only)then
+       ref = graph_nop_mp_layer_type(fo, d, fi, kernel_hidden=h, use_bias=use_bias, activation=activation)
+       call ref%set_graph(mg)
+       call ref%set_params(params)
+       ref_out = ref%forward(x, c)
+       call ref%backward(up, dx=ref_dx)
+       ref_grads = ref%get_gradients()
+    end if
+    if(.not.stock_only) call close_to(layer%output(1, 1)%val, ref_out, case_name//": output")
+    if(.not.stock_only) call close_to(input(1, 1)%grad%val, ref_dx, case_name//": input gradient")
+    if(.not.stock_only) call close_to_1d(grads, ref_grads, case_name//": flat parameter gradients (get_gradients)")
     call dump_i(case_name, "ia1", graph(1)%adj_ia)
     call dump_i(case_name, "ja1", graph(1)%adj_ja)
     call dump_r(case_name, "x1", x)
@@ -554,12 +607,14 @@ contains
          [1, d, h, fi, fo, merge(1, 0, use_bias)])
 
     call card_round_trip(layer, "GRAPH_NOP", params, reread, restores_parameters=.true.)
-    select type(reread)
-    type is(hip_graph_nop_layer_type)
-    class default
-       call fail(case_name//": the registry did not hand back a hip_graph_nop_layer_type")
-    end select
-    call ref%destroy()
+    if(.not.stock_only)then
+       select type(reread)
+       type is(hip_graph_nop_layer_type)
+       class default
+          call fail(case_name//": the registry did not hand back a hip_graph_nop_layer_type")
+       end select
+    end if
+    if(.not.stock_only) call ref%destroy()
   end subroutine gno_case
 
 end program run_layers

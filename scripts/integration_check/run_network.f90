@@ -336,7 +336,9 @@ contains
     allocate(x(1, n_graphs))
     do s = 1, n_graphs
        call ring_graph(x(1, s), 9 + modulo(5 * s, 17), 6, 1, s)          ! 9 .. 25 atoms, 6 vertex / 1 edge feature as the example's data
-       call x(1, s)%add_self_loops()                                     ! main.f90:107-110
+       ! (the example also calls add_self_loops, main.f90:107-110; not here: a self-loop entry carries edge id 0 and the reference's
+       ! duvenaud_propagate then reads e(:, 0), one column in front of the array -- SURVEY.md F7 -- so what the STOCK network
+       ! computes would depend on the heap's contents; the hip_* types and the oracle contribute a zero edge-feature vector there)
     end do
     allocate(y(1, 1))
     call y(1, 1)%allocate(array_shape=[1, n_graphs])

@@ -142,3 +142,28 @@ def test_athenas_network_type_runs_on_the_stand_in_with_its_stock_layers():
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     assert "RUN_NETWORK_OK 8 8" in r.stdout
     assert r.stdout.count("stock network  loss") == 8
+
+
+@needs_reference
+def test_the_oracle_against_athenas_own_compiled_layers(tmp_path):
+    """`run_layers stock`: the program of the GPU check with athena's STOCK kipf / duvenaud / graph_nop layer types in the place of the
+    hip_* ones -- the reference's own loops (athena_diffstruc_extd_sub_{kipf,duvenaud,nop}.f90, compiled from the checkout) driven by
+    its own forward_msgpass / grad_reverse over the stand-in tape, no GPU -- dumps output, input gradient and flat parameter gradients
+    of the nine cases, and oracle/layers.py is held against them at 1e-5 (float64-anchored) with the very functions the GPU test
+    uses for the hip_* types.  Corroboration of the oracle's restatement of Duvenaud and GNO against compiled reference code; by
+    the rules NOT a pin (the build stands on a stand-in for diffstruc / graphstruc / coreutils)."""
+    import test_gpu_integration_run as gi
+
+    exe = os.path.join(ROOT, "scripts", "integration_check", "run_layers")
+    if not os.path.exists(exe):
+        r = subprocess.run(["bash", os.path.join(ROOT, "scripts", "integration_check", "run.sh")], capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    r = subprocess.run([exe, "stock"], capture_output=True, text=True, timeout=900, cwd=str(tmp_path), env=dict(os.environ, RUN_LAYERS_DUMP=str(tmp_path)))
+    assert r.returncode == 0 and "RUN_LAYERS_OK 3 3" in r.stdout, (r.stdout[-1000:], r.stderr[-2000:])
+    d = str(tmp_path)
+    for case, act in (("kipf_hand", "relu"), ("kipf_wide", "none"), ("kipf_swish", "swish")):
+        gi.test_hip_kipf_layer_type_against_the_oracle(None, d, case, act)
+    for case, act in (("duvenaud_hand", "sigmoid"), ("duvenaud_wide", "sigmoid"), ("duvenaud_leaky", "leaky_relu")):
+        gi.test_hip_duvenaud_layer_type_against_the_oracle(None, d, case, act)
+    for case, act in (("gno_hand", "tanh"), ("gno_wide", "none")):
+        gi.test_hip_graph_nop_layer_type_against_the_oracle(None, d, case, act)
