@@ -27,6 +27,12 @@
  *       otherwise "parity unpinned" beyond the line-by-line restatement.
  *   matmul / softmax-sum / '+'  -- live in diffstruc v1.2.0 (fpm.toml:20),
  *       not in /root/reference: restated as plain fp32 matmul; unpinned.
+ * Corroboration that is NOT a pin (a reference build over a stand-in for its
+ * un-vendored dependencies pins nothing by the rules): the CPU suite runs
+ * athena's own compiled kipf / duvenaud / graph_nop layers over such a stand-in
+ * (scripts/integration_check/run_layers stock) and oracle/layers.py, which
+ * composes these functions, agrees with their outputs and gradients at 1e-5
+ * (tests/test_integration_compile.py).
  */
 #include <math.h>
 #include <stdint.h>
