@@ -78,7 +78,7 @@ def parse_args():
     ap.add_argument("--cpu-runs", type=int, default=5, help="timed runs of the CPU oracle after one warm-up (median reported)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="N = 1: skip the `secondary` block (configs[2], configs[3], configs[4] on one GPU; ~2-4 min of child processes)")
-    ap.add_argument("--secondary", default="c3,c4,c5", help="which secondary configurations to run (comma separated)")
+    ap.add_argument("--secondary", default="c3,c4,c5,kb", help="which secondary configurations to run (comma separated)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     args.custom = any(v is not None for v in (args.nodes, args.pairs, args.feat))
@@ -358,7 +358,7 @@ def run_secondary(which, budget_s=540.0):
     nor the exit code."""
     out = {"note": "measured after the headline's timed loop, each configuration in a child process of its own; "
                    "never part of `value`"}
-    names = {"c3": "configs[2]", "c4": "configs[3]", "c5": "configs[4]_one_gpu"}
+    names = {"c3": "configs[2]", "c4": "configs[3]", "c5": "configs[4]_one_gpu", "kb": "kipf_block_diagonal_batch"}
     t_start = time.perf_counter()
     for key in which:
         if key not in names:

@@ -5,6 +5,8 @@
     python scripts/bench_secondary.py --config c4     configs[3]: GNO layer step on a 2 M-point radius mesh, 64 features
     python scripts/bench_secondary.py --config c5     configs[4] on ONE GPU: Kipf 10 M / 150 M / 256 (the 8-GPU config's
                                                       whole graph on one device: 50 GB of resident tensors)
+    python scripts/bench_secondary.py --config kb     the Kipf layer on a block-diagonal batch of 130 k molecule-sized graphs (64 and
+                                                      128 features): the LDS-staged gather with the coefficient (round 6)
 
 Each prints {"config", "workload", "step_ms", "ops": {name: {"ms", "bound", "frac", ...}}, "parity": {"ok", ...}}:
 per-op times from HIP events (median of --reps launches after one warm-up), the roofline fraction of every op against
@@ -492,9 +494,66 @@ def run_c5(dev, reps):
             "(the 8-way partition is the driver's multi-GPU run)", "step_ms": round(step, 3), "entries_per_s": nnz / step * 1e3, "ops": opsd, "parity": par}
 
 
+def run_kb(dev, reps):
+    """the Kipf layer on a BATCH of small graphs (msgpass_chemical / onnx_gnn-shaped: BASELINE configs[0]'s layer at configs[2]'s batch):
+    130 000 molecule-sized graphs as one block-diagonal graph, 64 and 128 features, the headline's step -- forward (aggregation from
+    LDS + dense step + relu), dW, reverse to x.  Parity: the first 2 000 graphs are an exact sub-problem for the oracle."""
+    from oracle import oracle as o
+
+    S = 130000
+    ia, ja, voff, E = synth.molecule_batch(S)
+    N, nnz = ia.size - 1, ja.shape[1]
+    g = DeviceGraph(ia, ja, n_edge_cols=0)
+    NG = 2000
+    v1 = int(voff[NG]); w1 = int(ia[v1]) - 1
+    sia, sja = ia[:v1 + 1].copy(), np.asfortranarray(ja[:, :w1])
+    res = {"config": "Kipf on a block-diagonal batch", "workload": f"Kipf GCN layer fwd+bwd on {S} molecule-sized graphs = {N} vertices / {nnz} entries "
+           "as one block-diagonal graph (band 29), relu, fp32", "widths": {}}
+    ok = True
+    for F in (64, 128):
+        gen = torch.Generator(device=dev).manual_seed(F)
+        x = torch.rand((N, F), device=dev, generator=gen).mul_(2.0).sub_(1.0)
+        dy = torch.rand((N, F), device=dev, generator=gen).mul_(2.0).sub_(1.0)
+        w_h = synth.kipf_weight(F)
+        w = torch.from_numpy(w_h).to(dev)
+        P = torch.empty((N, F), device=dev); Y = torch.empty((N, F), device=dev); dX = torch.empty((N, F), device=dev)
+        dZ = torch.empty((N, F), device=dev); dW = torch.empty(F * F, device=dev)
+        t = {"fwd (banded aggregation + dense step + relu)": timeit(lambda: ops.kipf_layer_fwd(g, x, w, F, act="relu", P=P, Z=Y), reps),
+             "relu reverse factor": timeit(lambda: ops.activation_bwd("relu", Y, dy, out=dZ), reps),
+             "dW = dZ . P^T": timeit(lambda: ops.matmul_dw(P, dZ, out=dW), reps),
+             "dX = (A^T dZ) W (banded pull + dense step)": timeit(lambda: ops.kipf_layer_bwd_x(g, dZ, w, F, out=dX), reps)}
+        names = list(t)
+        agg = nnz * 8 + 2 * N * 4 * F          # ids + coefficients, rows in once (banded: every row staged once per block), rows out
+        opsd = {names[0]: hbm_op(t[names[0]], agg + 2 * N * 4 * F, "rows in, P out and in again, Z out, ids + coefficients"),
+                names[1]: hbm_op(t[names[1]], 3 * N * 4 * F, "three tensors"),
+                names[2]: mfma_op(t[names[2]], 2.0 * N * F * F),
+                names[3]: hbm_op(t[names[3]], nnz * 4 + 4 * N * 4 * F, "rows in, pulled rows out and in again, dX out, ids")}
+        step = sum(t.values())
+        par = {}
+        if not TIMING_ONLY:
+            xs = x[:v1].cpu().numpy()
+            p_ref = o.kipf_propagate(xs, sia, sja)
+            z_ref = o.activation("relu", o.matmul(w_h, p_ref, F))
+            dz_h = o.activation_bwd("relu", z_ref, dy[:v1].cpu().numpy())
+            dx_ref = o.kipf_propagate_bwd(o.matmul_dx(w_h, dz_h, F), sia, sja)
+            par = {"against": f"oracle on the first {NG} graphs ({v1} vertices: an exact sub-problem of the block-diagonal batch)",
+                   "P_bit_exact": bool(np.array_equal(P[:v1].cpu().numpy(), p_ref)), "Z_rel": rel(Y[:v1].cpu().numpy(), z_ref),
+                   "dX_rel": rel(dX[:v1].cpu().numpy(), dx_ref), "tol": TOL}
+            d64 = torch.zeros((F, F), device=dev, dtype=torch.float64)
+            for r0 in range(0, N, 1 << 20):
+                d64 += P[r0:r0 + (1 << 20)].double().T @ dZ[r0:r0 + (1 << 20)].double()
+            par["dW_rel_vs_float64"] = float((dW.double() - d64.reshape(-1)).abs().max().item() / d64.abs().max().item())
+            par["ok"] = bool(par["P_bit_exact"] and max(par["Z_rel"], par["dX_rel"], par["dW_rel_vs_float64"]) <= TOL)
+            ok = ok and par["ok"]
+        res["widths"][str(F)] = {"step_ms": round(step, 4), "entries_per_s": nnz / step * 1e3, "ops": opsd, "parity": par}
+    res["step_ms"] = res["widths"]["64"]["step_ms"]
+    res["parity"] = {"ok": bool(ok), "per_width": "see widths"}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", choices=["c3", "c4", "c5"], required=True)
+    ap.add_argument("--config", choices=["c3", "c4", "c5", "kb"], required=True)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--timing-only", action="store_true", help="c4: stop after the timed launches (rocprofv3 runs)")
     ap.add_argument("--mesh-order", choices=["drawn", "cells"], default="drawn",
@@ -507,7 +566,7 @@ def main():
     _capi.init(0)
     dev = torch.device("cuda:0")
     t0 = time.perf_counter()
-    res = {"c3": run_c3, "c4": run_c4, "c5": run_c5}[a.config](dev, a.reps)
+    res = {"c3": run_c3, "c4": run_c4, "c5": run_c5, "kb": run_kb}[a.config](dev, a.reps)
     res["wall_s"] = round(time.perf_counter() - t0, 1)
     print(json.dumps(res), flush=True)
 
