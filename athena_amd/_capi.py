@@ -26,6 +26,7 @@ _i32, _i64, _vp, _f32 = C.c_int32, C.c_int64, C.c_void_p, C.c_float
 # name -> argtypes (restype is int for everything except last_error)
 _PROTOS = {
     "athena_mp_init": [C.c_int],
+    "athena_mp_initialized": [],
     "athena_mp_finalize": [],
     "athena_mp_set_stream": [_vp],
     "athena_mp_synchronize": [],

@@ -36,6 +36,7 @@ struct DevCtx {
 };
 static DevCtx g_ctx[kMaxDevices];
 static int g_device = 0;
+static int g_inited = 0;   // athena_mp_init succeeded at least once
 #define g_ws g_ctx[g_device].ws
 #define g_ws_bytes g_ctx[g_device].ws_bytes
 
@@ -151,8 +152,11 @@ int athena_mp_init(int device)
     if (device != g_device) g_stream = nullptr;   // the stream of the previous device does not carry over
     g_device = device;
     g_ctx[device].cus = prop.multiProcessorCount;
+    g_inited = 1;
     return 0;
 }
+
+int athena_mp_initialized(void) { return g_inited ? g_device : -1; }
 
 int athena_mp_finalize(void)
 {

@@ -210,6 +210,19 @@ contains
     integer(c_int) :: rc
     type(c_ptr) :: fresh
 
+    ! first use inside a host program that never heard of the library (an unmodified athena program whose layer constructors were
+    ! swapped): select a device -- ATHENA_MP_DEVICE, default 0 -- unless the host already did
+    if(athena_mp_initialized() .lt. 0)then
+       block
+         character(len=16) :: env
+         integer :: device, stat
+         device = 0
+         call get_environment_variable("ATHENA_MP_DEVICE", env, status=stat)
+         if(stat .eq. 0) read(env, *, iostat=stat) device
+         if(stat .ne. 0) device = 0
+         if(athena_mp_init(int(device, c_int)) .ne. 0) call stop_program(who//": "//athena_mp_error_message())
+       end block
+    end if
     if(allocated(handle))then
        if(size(handle) .ne. size(graph)) call release_handles(handle)
     end if

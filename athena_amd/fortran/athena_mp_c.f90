@@ -12,7 +12,7 @@ module athena_mp_c
   integer(c_int), parameter, public :: ATHENA_MP_ACT_NONE = 0, ATHENA_MP_ACT_RELU = 1, &
        ATHENA_MP_ACT_SIGMOID = 2, ATHENA_MP_ACT_TANH = 3
 
-  public :: athena_mp_init, athena_mp_finalize, athena_mp_last_error, athena_mp_synchronize
+  public :: athena_mp_init, athena_mp_initialized, athena_mp_finalize, athena_mp_last_error, athena_mp_synchronize
   public :: athena_mp_graph_create, athena_mp_graph_destroy, athena_mp_graph_key
   public :: athena_mp_graph_acquire, athena_mp_graph_release, athena_mp_graph_evict, athena_mp_graph_cache_stats
   public :: athena_mp_kipf_propagate_fwd_host, athena_mp_kipf_propagate_bwd_host
@@ -66,6 +66,9 @@ module athena_mp_c
      integer(c_int) function athena_mp_init(device) bind(C, name="athena_mp_init")
        import :: c_int
        integer(c_int), value :: device
+     end function
+     integer(c_int) function athena_mp_initialized() bind(C, name="athena_mp_initialized")
+       import :: c_int
      end function
      integer(c_int) function athena_mp_finalize() bind(C, name="athena_mp_finalize")
        import :: c_int

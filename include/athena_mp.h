@@ -51,6 +51,10 @@ enum {
 
 /* ---- runtime ------------------------------------------------------------ */
 int athena_mp_init(int device);            /* hipSetDevice + capability check (gfx950) */
+/* the device athena_mp_init selected, -1 before the first successful call (after athena_mp_finalize the selection stands): lets a
+ * layer that lives inside a host program it does not own initialise the library on first use WITHOUT overriding the host's choice --
+ * nothing in the reference corresponds to it (athena has no device); the drop-in types' set_graph calls it (athena_hip_msgpass_layers.f90) */
+int athena_mp_initialized(void);
 int athena_mp_finalize(void);
 const char *athena_mp_last_error(void);
 int athena_mp_set_stream(void *hip_stream); /* hipStream_t; NULL = default stream */

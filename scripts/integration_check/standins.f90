@@ -1348,7 +1348,15 @@ module graphstruc
      logical :: is_sparse = .true., directed = .false.
      character(len=128) :: name = ""
      integer, allocatable :: adj_ia(:), adj_ja(:,:)
-     real(real32), allocatable :: vertex_features(:,:), edge_features(:,:), edge_weights(:)
+     ! What athena's own code and tests do with these three decides their attributes:
+     !   edge_weights     assigned whole while unallocated (set_graph_msgpass, athena_msgpass_layer_sub.f90:169; test_msgpass_network
+     !                    .f90:285) and `allocate`d after set_num_edges (test_kipf_msgpass_layer.f90:97): allocatable, left alone by the setter
+     !   edge_features    sections assigned after set_num_edges(n, nf) (test_msgpass_network.f90:288-289), `allocate`d after
+     !                    set_num_edges(n) (test_kipf_msgpass_layer.f90:100): allocatable, allocated by the setter only when it is given nf
+     !   vertex_features  sections assigned right after set_num_vertices(n, nf) (test_msgpass_network.f90:258-266) AND `allocate`d right
+     !                    after the same call (test_kipf_msgpass_layer.f90:70-76): legal together only for a pointer the setter associates
+     real(real32), pointer :: vertex_features(:,:) => null()
+     real(real32), allocatable :: edge_features(:,:), edge_weights(:)
      type(vertex_type), allocatable :: vertex(:)
      type(edge_type), allocatable :: edge(:)
      integer, allocatable :: adjacency(:,:)
@@ -1369,7 +1377,6 @@ contains
     this%num_vertices = num_vertices
     if(present(num_vertex_features)) this%num_vertex_features = num_vertex_features
     ! (athena's tests fill vertex_features(f, v) right after this call: test_msgpass_network.f90:258-266)
-    if(allocated(this%vertex_features)) deallocate(this%vertex_features)
     allocate(this%vertex_features(this%num_vertex_features, num_vertices), source = 0._real32)
   end subroutine set_num_vertices
 
@@ -1379,8 +1386,10 @@ contains
     integer, intent(in), optional :: num_edge_features
     this%num_edges = num_edges
     if(present(num_edge_features)) this%num_edge_features = num_edge_features
-    if(allocated(this%edge_features)) deallocate(this%edge_features)
-    allocate(this%edge_features(this%num_edge_features, num_edges), source = 0._real32)
+    if(present(num_edge_features))then
+       if(allocated(this%edge_features)) deallocate(this%edge_features)
+       allocate(this%edge_features(num_edge_features, num_edges), source = 0._real32)
+    end if
   end subroutine set_num_edges
 
   subroutine dense_adjacency(this)

@@ -12,7 +12,9 @@ Fortran.  Two programs, built in the build container by scripts/integration_chec
   run_network athena's OWN network_type (add / compile / train / test / print / read, its optimiser, its loss, its input layers, its
               graph of layers: all 99 files of src/athena compiled) with the hip_* types in it, every case run twice through the same
               code -- stock layer types and hip_* types from the same initial parameters -- and held against each other after
-              training: parameters, loss, accuracy (1e-5), and the saved network read back through the registry as hip_* layers."""
+              training: parameters, loss, accuracy (1e-5), and the saved network read back through the registry as hip_* layers.
+  reftest_hip_<name>  the reference's OWN test programs (test/test_kipf_msgpass_layer.f90, test_duvenaud_msgpass_layer.f90,
+              test_gno_layer.f90, test_msgpass_network.f90), unmodified, with the layer type names swapped by the preprocessor."""
 import os
 import subprocess
 import types
@@ -39,6 +41,18 @@ def test_drop_in_ops_run_through_a_tape_from_fortran(dev):
     r = subprocess.run([_exe("run_ops")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert "RUN_OPS_OK 6 6" in r.stdout, r.stdout[-500:]
+
+
+@pytest.mark.parametrize("name", ["test_kipf_msgpass_layer", "test_duvenaud_msgpass_layer", "test_gno_layer", "test_msgpass_network"])
+def test_the_references_own_test_programs_pass_with_the_drop_in_types_swapped_in(dev, tmp_path, name):
+    """/root/reference/test/<name>.f90, read in place and UNMODIFIED, compiled in the build container with the three layer type names
+    (and the three card readers the tests call by name) swapped by the preprocessor -- -Dkipf_msgpass_layer_type=
+    hip_kipf_msgpass_layer_type ... (scripts/integration_check/run.sh) -- so that every constructor, `type is`, `network%add` and file
+    I/O check of the reference's test runs on the hip_* types, on the GPU; nothing in the program knows about the library, which the
+    layers initialise on first use.  The programs print `<name> passed all tests` and stop with code 1 otherwise."""
+    r = subprocess.run([_exe("reftest_hip_" + name)], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    assert f"{name} passed all tests" in r.stdout
 
 
 @pytest.mark.parametrize("mode", ["staged", "resident"])

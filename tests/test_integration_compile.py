@@ -167,3 +167,19 @@ def test_the_oracle_against_athenas_own_compiled_layers(tmp_path):
         gi.test_hip_duvenaud_layer_type_against_the_oracle(None, d, case, act)
     for case, act in (("gno_hand", "tanh"), ("gno_wide", "none")):
         gi.test_hip_graph_nop_layer_type_against_the_oracle(None, d, case, act)
+
+
+@needs_reference
+@pytest.mark.parametrize("name", ["test_diffstruc_extd_kipf", "test_kipf_msgpass_layer", "test_duvenaud_msgpass_layer", "test_gno_layer",
+                                  "test_msgpass_network"])
+def test_the_references_own_test_programs_pass_on_the_stand_in(tmp_path, name):
+    """/root/reference/test/<name>.f90 as written (athena's stock types), linked over the stand-in by scripts/integration_check/run.sh,
+    run here without a GPU: if the reference's own tests pass on the stand-in, what the GPU suite shows with the hip_* types swapped
+    into the SAME sources (tests/test_gpu_integration_run.py) says something about the drop-in and not about the harness"""
+    exe = os.path.join(ROOT, "scripts", "integration_check", "reftest_stock_" + name)
+    if not os.path.exists(exe):
+        r = subprocess.run(["bash", os.path.join(ROOT, "scripts", "integration_check", "run.sh")], capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert "passed all tests" in r.stdout
