@@ -5,7 +5,7 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../libathena_mp.so
-SRCS="capi.hip graph_build.hip agg.hip gemm.hip gemm_tiled.hip fused.hip fused_dw.hip elementwise.hip duvenaud.hip duv_mfma.hip readout.hip gno.hip train.hip host.hip comm.hip"
+SRCS="capi.hip graph_build.hip agg.hip banded_fused.hip gemm.hip gemm_tiled.hip fused.hip fused_dw.hip elementwise.hip duvenaud.hip duv_mfma.hip readout.hip gno.hip train.hip host.hip comm.hip"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function"
 mkdir -p ../../build/obj
 objs=""

@@ -148,6 +148,9 @@ void graph_cache_clear(); // idle and live handles of athena_mp_graph_acquire (c
 void host_pool_release();   // staging buffers of the *_host entry points (host.hip)
 uint64_t content_hash(const void *p, size_t bytes);   // every byte of a host array (capi.hip)
 bool kipf_gather_is_banded(const athena_mp_graph *g, bool transposed, int F, const float *x, const float *y);   // agg.hip
+// banded_fused.hip: the Kipf layer step on a banded graph in one launch at 64 -> 64 (0 done, -1 not its shape, > 0 error)
+int banded_agg_gemm64(const athena_mp_graph *g, bool transposed, const float *coef, const float *x, const float *W, int b_nk,
+                      const float *bias, int act, float *P, float *Z);
 int agg_blocks_cap();
 void set_agg_blocks_cap(int n);
 // shared launchers (defined in agg.hip / gemm.hip)

@@ -646,6 +646,13 @@ int athena_mp_kipf_layer_fwd(const athena_mp_graph *g, int32_t Fi, int32_t Fo, c
     // a block-diagonal batch of small graphs: the aggregation gathers from LDS (agg.hip, csr_gather_banded64) and the dense step
     // follows as its own launch -- faster than the one launch that chases rows through HBM (profiles/r06_kipf_banded_ab.txt)
     const bool banded = KIPF_LAYER_BANDED && (Fi == 64 || Fi == 128) && kipf_gather_is_banded(g, false, Fi, x, P ? P : x);
+#ifndef KIPF_BANDED_FUSED
+#define KIPF_BANDED_FUSED 1   // A/B builds: 0 = banded aggregation and dense step as two launches also at 64 -> 64
+#endif
+    if (KIPF_BANDED_FUSED && banded && Fi == 64 && Fo == 64) {   // ... in ONE launch: P goes from LDS into the dense step (banded_fused.hip)
+        const int rc = banded_agg_gemm64(g, false, g->coef, x, W, 0, bias, act, P, Z);
+        if (rc >= 0) return rc;
+    }
     if (!banded && fused_shape(Fi, Fo) && g->lp_fwd.n_long == 0)
         return fused_dispatch(g->rowptr, g->col, g->coef, x, Fi, Fo, W, 0, bias, act, P, Z, g->n_rows, g->n_cols);
     if (P == nullptr) {   // the caller keeps no tape of P (its reverse pass is athena_mp_kipf_layer_bwd)
@@ -665,6 +672,10 @@ int athena_mp_kipf_layer_bwd_x(const athena_mp_graph *g, int32_t Fi, int32_t Fo,
     if (g->n_cols == 0) return 0;
     AMP_REQUIRE(dZ && W && dX, "kipf_layer_bwd_x: null tensor");
     const bool banded = KIPF_LAYER_BANDED && (Fo == 64 || Fo == 128) && Fo <= Fi && kipf_gather_is_banded(g, true, Fo, dZ, dZ);
+    if (KIPF_BANDED_FUSED && banded && Fi == 64 && Fo == 64) {
+        const int rc = banded_agg_gemm64(g, true, exact ? g->t_coef : nullptr, dZ, W, 1, nullptr, ATHENA_MP_ACT_NONE, nullptr, dX);
+        if (rc >= 0) return rc;
+    }
     if (!banded && fused_shape(Fi, Fo) && g->lp_bwd.n_long == 0) // dX = (A^T dZ) . W : aggregate, then contract with B [N=Fi][K=Fo]
         return fused_dispatch(g->t_rowptr, g->t_src, exact ? g->t_coef : nullptr, dZ, Fo, Fi, W, 1, nullptr,
                               ATHENA_MP_ACT_NONE, nullptr, dX, g->n_cols, g->n_rows);

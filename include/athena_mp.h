@@ -192,9 +192,9 @@ int athena_mp_gemm_dx(int64_t N, int32_t Fi, int32_t Fo, const float *dZ_dev, co
  *   P = kipf_propagate(X) (returned: the reverse pass needs it for dW; P_dev may be NULL when the reverse pass is
  *   athena_mp_kipf_layer_bwd, which works from X),  Z = act(P . Wt + bias)
  * One launch at 64 / 128 / 256 features on graphs without hub rows -- except on BANDED graphs (a block-diagonal batch of small
- * graphs: every neighbour within 32 rows, rows of at most 8 entries) at 64 / 128 features, where the aggregation gathers from
- * LDS and the dense step follows as its own launch (faster there: profiles/r06_kipf_banded_ab.txt); same P bit for bit, Z within
- * the order of the dense step's sums.  _bwd_x likewise. */
+ * graphs: every neighbour within 32 rows, rows of at most 8 entries), where the aggregation gathers from LDS: one launch of its
+ * own at 64 -> 64 (banded_fused.hip: the tile goes from LDS into the dense step), the gather and the dense step as two launches at
+ * 128 features (profiles/r06_kipf_banded_ab.txt); same P bit for bit, Z within the order of the dense step's sums.  _bwd_x likewise. */
 int athena_mp_kipf_layer_fwd(const athena_mp_graph *g, int32_t Fi, int32_t Fo, const float *x_dev,
                              const float *W_dev, const float *bias_dev, int32_t act, float *P_dev,
                              float *Z_dev);

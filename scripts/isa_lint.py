@@ -27,7 +27,7 @@ DEFAULT_LIB = os.path.join(ROOT, "athena_amd", "libathena_mp.so")
 
 # kernel families on the timed paths of bench.py / scripts/bench_configs.py
 TIMED_FAMILIES = ("agg_gemm", "gemm_dw_full", "gno_pc", "gno_dh_pc", "gno_stg", "gno_px_gather", "duv_rows_wide",
-                  "duv_bwd_wide", "duv_bwd_ro", "duv_dw_wide", "csr_gather", "readout_fwd", "readout_bwd")
+                  "duv_bwd_wide", "duv_bwd_ro", "duv_dw_wide", "csr_gather", "readout_fwd", "readout_bwd", "banded_agg_gemm64")
 # ... and the exact instantiations the bench lines launch (BASELINE configs[1] .. [4]; BUF = true is what a tensor below 4 GiB takes)
 TIMED_EXACT = (
     "agg_gemm_kernel<128, true, 0, true>", "agg_gemm_kernel<128, true, 1, true>", "agg_gemm_kernel<128, false, 0, true>",
@@ -39,7 +39,8 @@ TIMED_EXACT = (
     "gno_dh_pc_kernel<true, 2, 2, true>",
     "duv_rows_wide_kernel<5, 4, true, false, 2>", "duv_rows_wide_kernel<5, 4, true, true, 2>", "duv_rows_wide_kernel<5, 4, false, false, 2>", "duv_bwd_wide_kernel<5, 4>",
     "duv_bwd_ro_kernel<5, 2, true>", "duv_bwd_ro_kernel<5, 2, false>",
-    "csr_gather_short_rows<16, 4>", "csr_gather_short_rows<64, 4>", "csr_gather_banded64<false>", "csr_gather_banded64<true>", "readout_bwd_kernel<4, 2, false>", "readout_bwd_kernel<4, 2, true>",
+    "csr_gather_short_rows<16, 4>", "csr_gather_short_rows<64, 4>", "csr_gather_banded64<false>", "csr_gather_banded64<true>",
+    "banded_agg_gemm64_kernel<true, 1, false, true>", "banded_agg_gemm64_kernel<false, 0, false, false>", "readout_bwd_kernel<4, 2, false>", "readout_bwd_kernel<4, 2, true>",
 )
 # Loop-invariant values the register allocator parks across a WHOLE loop nest -- stored once in front of it, reloaded once behind
 # it, no scratch instruction inside any loop -- cost nothing and are accepted up to this many bytes on a bench-line kernel
