@@ -518,16 +518,19 @@ def run_kb(dev, reps):
         w = torch.from_numpy(w_h).to(dev)
         P = torch.empty((N, F), device=dev); Y = torch.empty((N, F), device=dev); dX = torch.empty((N, F), device=dev)
         dZ = torch.empty((N, F), device=dev); dW = torch.empty(F * F, device=dev)
-        t = {"fwd (banded aggregation + dense step + relu)": timeit(lambda: ops.kipf_layer_fwd(g, x, w, F, act="relu", P=P, Z=Y), reps),
+        t = {"fwd (banded aggregation + dense step + relu; one launch at 64)": timeit(lambda: ops.kipf_layer_fwd(g, x, w, F, act="relu", P=P, Z=Y), reps),
              "relu reverse factor": timeit(lambda: ops.activation_bwd("relu", Y, dy, out=dZ), reps),
              "dW = dZ . P^T": timeit(lambda: ops.matmul_dw(P, dZ, out=dW), reps),
-             "dX = (A^T dZ) W (banded pull + dense step)": timeit(lambda: ops.kipf_layer_bwd_x(g, dZ, w, F, out=dX), reps)}
+             "dX = (A^T dZ) W (banded pull + dense step; one launch at 64)": timeit(lambda: ops.kipf_layer_bwd_x(g, dZ, w, F, out=dX), reps)}
         names = list(t)
         agg = nnz * 8 + 2 * N * 4 * F          # ids + coefficients, rows in once (banded: every row staged once per block), rows out
-        opsd = {names[0]: hbm_op(t[names[0]], agg + 2 * N * 4 * F, "rows in, P out and in again, Z out, ids + coefficients"),
+        one = F == 64                          # 64 -> 64: ONE launch (banded_fused.hip), the aggregated tile never re-read from HBM
+        opsd = {names[0]: hbm_op(t[names[0]], agg + (1 if one else 2) * N * 4 * F,
+                                 "rows in, P out, Z out, ids + coefficients" + ("" if one else "; P read again by the dense step's launch")),
                 names[1]: hbm_op(t[names[1]], 3 * N * 4 * F, "three tensors"),
                 names[2]: mfma_op(t[names[2]], 2.0 * N * F * F),
-                names[3]: hbm_op(t[names[3]], nnz * 4 + 4 * N * 4 * F, "rows in, pulled rows out and in again, dX out, ids")}
+                names[3]: hbm_op(t[names[3]], nnz * 4 + (2 if one else 4) * N * 4 * F,
+                                 "rows in, dX out, ids" + ("" if one else "; the pulled rows out and in again between the two launches"))}
         step = sum(t.values())
         par = {}
         if not TIMING_ONLY:
